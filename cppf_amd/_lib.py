@@ -1,0 +1,81 @@
+"""ctypes binding of libcppf_hip.so (C ABI: include/cppf.h).  Fails loudly when the library is
+missing or a call returns an error -- there is no fallback path."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "csrc", "libcppf_hip.so")
+_lib = None
+
+vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+_SIGS = {
+    "cppf_abi_version": (C.c_int, []),
+    "cppf_error_string": (C.c_char_p, [C.c_int]),
+    "cppf_vote_workspace_bytes": (sz, [i64, i32, i32, i32, i32]),
+    "cppf_ppf_voting": (C.c_int, [vp, vp, vp, vp, vp, vp, f32, i64, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "cppf_vote_argmax": (C.c_int, [vp, vp, vp, vp, vp, vp, f32, i64, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
+    "cppf_grid_argmax": (C.c_int, [vp, i64, vp, vp, vp]),
+    "cppf_center_from_argmax": (C.c_int, [vp, vp, C.c_double, i32, i32, vp, vp, vp]),
+    "cppf_backvote": (C.c_int, [vp, vp, vp, vp, vp, f32, i64, i32, i32, i32, i32, vp, f32, vp, vp]),
+    "cppf_compact_workspace_bytes": (sz, [i64]),
+    "cppf_compact_mask": (C.c_int, [vp, i64, vp, vp, vp, sz, vp]),
+    "cppf_rot_voting": (C.c_int, [vp, vp, vp, vp, i64, i32, vp]),
+    "cppf_rot_sphere_count": (C.c_int, [vp, vp, i32, vp, vp, vp, i64, i64, i32, vp, i32, f32, vp, vp]),
+    "cppf_pair_mlp_packed_floats": (sz, [i32, C.POINTER(C.c_int), i32, i32]),
+    "cppf_pair_mlp_pack": (C.c_int, [vp, vp, i32, C.POINTER(C.c_int), i32, i32, vp]),
+    "cppf_pair_mlp_forward": (C.c_int, [vp, vp, vp, vp, i32, vp, i64, i32, C.POINTER(C.c_int), i32, i64, i32, vp, vp]),
+    "cppf_pair_mlp_decode": (C.c_int, [vp, vp, vp, vp, i32, vp, i64, i32, C.POINTER(C.c_int), i32, i64, i32, i32, i32,
+                                       f32, f32, vp, vp, vp, vp, vp]),
+    "cppf_decode_center": (C.c_int, [vp, i64, i32, i32, f32, f32, vp, vp, vp]),
+    "cppf_decode_rot": (C.c_int, [vp, i64, i32, i32, i32, i32, vp, vp, vp]),
+    "cppf_reduce_workspace_bytes": (sz, []),
+    "cppf_axis_sign": (C.c_int, [vp, vp, vp, vp, vp, i64, vp, i32, vp, vp, vp, sz, vp]),
+    "cppf_scale_sum": (C.c_int, [vp, i32, vp, vp, i64, vp, vp, sz, vp]),
+    "cppf_grid_setup": (C.c_int, [vp, i64, f32, vp, vp, vp]),
+}
+
+ABI_VERSION = 1
+
+
+class CppfError(RuntimeError):
+    pass
+
+
+def library_path():
+    return _SO
+
+
+def build(force=False):
+    """Compile libcppf_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    args = ["make", "-C", src_dir] + (["-B"] if force else []) + ["libcppf_hip.so"]
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise CppfError(f"{_SO} is missing: build it with `make -C cppf_amd/csrc` "
+                            "(or __graft_entry__.build()); cppf_amd has no CPU fallback")
+        L = C.CDLL(_SO)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)  # AttributeError = ABI mismatch, also loud
+            fn.restype, fn.argtypes = res, args
+        if L.cppf_abi_version() != ABI_VERSION:
+            raise CppfError("libcppf_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().cppf_error_string(rc)
+        raise CppfError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def exported_symbols():
+    return sorted(_SIGS)

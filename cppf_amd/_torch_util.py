@@ -1,0 +1,54 @@
+"""torch plumbing for the C ABI: pointer extraction, argument checks, stream, scratch cache."""
+import numpy as np
+import torch
+
+from . import _lib
+
+_ws_cache = {}
+
+
+def stream_ptr(device=None):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_cuda():
+    if not torch.cuda.is_available():
+        raise _lib.CppfError("cppf_amd needs a HIP device (torch.cuda.is_available() is False); "
+                             "there is no CPU fallback")
+
+
+def dev_tensor(x, dtype, name, shape_tail=None, device=None):
+    """Validate a device array argument the way the reference's CuPy launch would need it:
+    right dtype, C-contiguous, on a HIP device.  Raises TypeError/ValueError otherwise."""
+    if not isinstance(x, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor on a HIP device, got {type(x).__name__}")
+    if not x.is_cuda:
+        raise ValueError(f"{name}: tensor must live on a HIP device (got {x.device})")
+    if x.dtype != dtype:
+        raise TypeError(f"{name}: expected dtype {dtype}, got {x.dtype}")
+    if not x.is_contiguous():
+        raise ValueError(f"{name}: tensor must be C-contiguous")
+    if shape_tail is not None and tuple(x.shape[-len(shape_tail):]) != tuple(shape_tail):
+        raise ValueError(f"{name}: expected trailing shape {tuple(shape_tail)}, got {tuple(x.shape)}")
+    if device is not None and x.device != device:
+        raise ValueError(f"{name}: on {x.device}, expected {device}")
+    return x
+
+
+def scalar(v):
+    """cp.float32 / np.float32 / python numbers / 0-d tensors passed by value."""
+    if isinstance(v, torch.Tensor):
+        return v.item()
+    if isinstance(v, np.generic):
+        return v.item()
+    return v
+
+
+def workspace(nbytes, device, tag="ws"):
+    """Grow-only scratch per (device, stream, tag); reuse on one stream is stream-ordered."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream, tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf

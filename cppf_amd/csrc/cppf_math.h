@@ -1,0 +1,131 @@
+// Device-side arithmetic shared by the CPPF kernels (gfx950 only).
+//
+// The library is compiled with -ffp-contract=off: every fused multiply-add below is an explicit
+// fmaf()/fma(), every other a*b+c is two roundings.  fp32 divide and sqrt are the correctly
+// rounded forms (hipcc default).  cos/sin/tan/exp are fixed polynomial evaluations rather than
+// OCML calls so that the discrete outcomes of the vote (trip counts, in/out-of-grid tests, sampled
+// bins) do not depend on a vendor math library; their definitions are restated independently in
+// oracle/cppf_oracle.c, which is what the parity tests compare against.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CPPF_PI 3.14159265358979323846264338327950288  // reference models/voting.py:6
+
+namespace cppf {
+
+struct f3 { float x, y, z; };
+
+// float3 helper semantics of the reference (models/include/helper_math.cuh:811,994,1245,1288,1417)
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ float len3(f3 v) { return sqrtf(dot3(v, v)); }
+__device__ __forceinline__ f3 sub3(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 add3(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 scl3(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ f3 div3(f3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+__device__ __forceinline__ f3 neg3(f3 a) { return {-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ f3 cross3(f3 a, f3 b)
+{
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ f3 ld3(const float* __restrict__ p, int i)
+{
+    return {p[3 * i], p[3 * i + 1], p[3 * i + 2]};
+}
+
+// exp(x), x <= ~88; zero below -86.  n = rint(x*log2e); r = x - n*ln2 (two terms); degree-5 core.
+__device__ __forceinline__ float det_expf(float x)
+{
+    if (x < -86.0f) return 0.0f;
+    if (x > 88.0f) x = 88.0f;
+    float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float y = fmaf(p, r * r, r) + 1.0f;
+    return __int_as_float(__float_as_int(y) + ((int)n << 23));
+}
+
+// fp64 sin/cos: Cody-Waite by pi/2 + degree-13/14 kernels on [-pi/4, pi/4].
+__device__ __forceinline__ void det_sincos(double x, double* s, double* c)
+{
+    double k = rint(x * 0.63661977236758134308);
+    double y = fma(-k, 1.57079632673412561417e+00, x);
+    y = fma(-k, 6.07710050650619224932e-11, y);
+    double z = y * y;
+    double ps = 1.58969099521155010221e-10;
+    ps = fma(ps, z, -2.50507602534068634195e-08);
+    ps = fma(ps, z, 2.75573137070700676789e-06);
+    ps = fma(ps, z, -1.98412698298579493134e-04);
+    ps = fma(ps, z, 8.33333333332248946124e-03);
+    ps = fma(ps, z, -1.66666666666666324348e-01);
+    double sn = fma(y * z, ps, y);
+    double pc = -1.13596475577881948265e-11;
+    pc = fma(pc, z, 2.08757232129817482790e-09);
+    pc = fma(pc, z, -2.75573143513906633035e-07);
+    pc = fma(pc, z, 2.48015872894767294178e-05);
+    pc = fma(pc, z, -1.38888888888741095749e-03);
+    pc = fma(pc, z, 4.16666666666666019037e-02);
+    double cs = fma(z * z, pc, fma(-0.5, z, 1.0));
+    int q = ((int)k) & 3;
+    double so = (q & 1) ? cs : sn;
+    double co = (q & 1) ? sn : cs;
+    *s = (q & 2) ? -so : so;
+    *c = (q == 1 || q == 2) ? -co : co;
+}
+
+// cos/sin of rotation i of n: angle = float(i*2*M_PI/n) evaluated in fp64 then rounded to fp32
+// (reference models/voting.py:33), cos/sin of that fp32 angle rounded to fp32.
+__device__ __forceinline__ float2 rot_cs(int i, int n)
+{
+    float angle = (float)((double)(i * 2) * CPPF_PI / (double)n);
+    double s, c;
+    det_sincos((double)angle, &s, &c);
+    return make_float2((float)c, (float)s);
+}
+
+__device__ __forceinline__ float det_tanf(float rot)
+{
+    double s, c;
+    det_sincos((double)rot, &s, &c);
+    return (float)(s / c);
+}
+
+// Front half shared by ppf_voting / backvote / rot_voting (reference models/voting.py:15-29,
+// 81-95, 125-136): unit ab with the fp64 "+1e-7", and the unit in-plane direction x.
+// Returns false for a degenerate pair (the reference returns early).
+__device__ __forceinline__ bool pair_frame(const float* __restrict__ points, int a_idx, int b_idx, f3& a,
+                                           f3& ab, f3& xdir)
+{
+    a = ld3(points, a_idx);
+    f3 b = ld3(points, b_idx);
+    ab = sub3(a, b);
+    float L = len3(ab);
+    if ((double)L < 1e-7) return false;
+    ab = div3(ab, (float)((double)L + 1e-7));
+    f3 co = {0.f, -ab.z, ab.y};
+    if ((double)len3(co) < 1e-7) co = {-ab.y, ab.x, 0.f};
+    xdir = div3(co, (float)((double)len3(co) + 1e-7));
+    return true;
+}
+
+// total order on floats as unsigned (monotone): larger float -> larger key
+__device__ __forceinline__ uint32_t f2ord(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ __forceinline__ float ord2f(uint32_t u)
+{
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    union { uint32_t u; float f; } c;
+    c.u = u;
+    return c.f;
+}
+
+}  // namespace cppf

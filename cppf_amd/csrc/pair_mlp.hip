@@ -1,0 +1,772 @@
+// Pair encoder for gfx950: PPF construction + feature gather + ResLayer chain + (optionally) the
+// bin decode, one kernel, logits never leave the CU.
+//
+// Reference: PPFEncoder.forward_with_idx, models/model.py:117-137; ResLayer.forward :27-31;
+// decode nocs/inference.py:185-188, 238-256.
+//
+// MFMA path (the architecture the reference trains: F = 40, ppffcs = [84,32,32,16], train.py:35).
+// Everything is computed transposed, D[out][pair] = W[out][k] * X^T[k][pair], with
+// v_mfma_f32_16x16x4_f32 (exact fp32, fmaf-chain numerics):
+//   lane l = (j = l & 15, g = l >> 4) of a wave serves pair j of a 16-pair block;
+//   A operand = one weight  W[16*ob + j][k(s,g)]   (pre-packed in lane order, read from LDS)
+//   B operand = one input   X[pair j][k(s,g)]      (a register of lane l)
+//   D         = f32x4: outputs 16*ob + 4*g + r, r = 0..3, of pair j.
+// Because D of one layer leaves output (16*ob + 4*g + r) in the lane that will need it as the
+// B operand of k-step s = 4*ob + r of the next layer, layers chain with no data movement at all:
+// the k order of a hidden layer is k(s,g) = 16*(s/4) + 4*g + s%4, and of the first layer
+// k(s,g) = {feat_a[10g+s] | feat_b[10g+s-10] | ppf[g]} so that each lane gathers two contiguous
+// 40-byte runs.  The oracle accumulates in exactly this order (oracle/cppf_oracle.c:orc_k_order).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/cppf.h"
+#include "cppf_math.h"
+
+using namespace cppf;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define CPPF_CHECK_LAUNCH()                         \
+    do {                                            \
+        hipError_t e__ = hipGetLastError();         \
+        if (e__ != hipSuccess) return (int)e__;     \
+    } while (0)
+
+// ----------------------------------------------------------------------------- packed layout (floats)
+#define STD_F 40
+#define STD_NOB 9                      // final layer padded to 9 x 16 = 144 outputs
+#define STD_NOBP 12                    // floats per lane per k-step of the final layer (3 x b128)
+#define OFF_W0 0                       // [21][64][4]  ob0,1 = fc1 (32), ob2,3 = fc0 (32) of layer 0
+#define OFF_W0B (OFF_W0 + 21 * 64 * 4) // [8][64][2]   layer 0 fc2
+#define OFF_W1A (OFF_W0B + 8 * 64 * 2) // [8][64][2]   layer 1 fc1
+#define OFF_W1B (OFF_W1A + 8 * 64 * 2) // [8][64][2]   layer 1 fc2
+#define OFF_W2 (OFF_W1B + 8 * 64 * 2)  // [8][64][2]   ob0 = layer 2 fc1 (16), ob1 = layer 2 fc0 (16)
+#define OFF_W2B (OFF_W2 + 8 * 64 * 2)  // [4][64][1]   layer 2 fc2
+#define OFF_WF (OFF_W2B + 4 * 64)      // [4][64][12]  final, 9 used
+#define OFF_B0 (OFF_WF + 4 * 64 * STD_NOBP)  // biases in natural output order
+#define OFF_B0B (OFF_B0 + 64)
+#define OFF_B1A (OFF_B0B + 32)
+#define OFF_B1B (OFF_B1A + 32)
+#define OFF_B2 (OFF_B1B + 32)
+#define OFF_B2B (OFF_B2 + 32)
+#define OFF_BF (OFF_B2B + 16)
+#define STD_PACKED (OFF_BF + 144)      // 13152 floats = 52 608 B
+
+static bool is_std(int F, const int* dims, int n_res, int out_dim)
+{
+    return F == STD_F && n_res == 3 && dims[0] == 84 && dims[1] == 32 && dims[2] == 32 && dims[3] == 16 &&
+           out_dim >= 1 && out_dim <= 16 * STD_NOB;
+}
+
+#define GEN_MAX_RES 8
+#define GEN_MAX_DIM 128
+static bool gen_ok(int F, const int* dims, int n_res, int out_dim)
+{
+    if (n_res < 0 || n_res > GEN_MAX_RES || F < 1 || out_dim < 1 || out_dim > 1024) return false;
+    if (dims[0] != 2 * F + 4) return false;
+    for (int i = 0; i <= n_res; ++i)
+        if (dims[i] < 1 || dims[i] > GEN_MAX_DIM) return false;
+    return true;
+}
+static size_t gen_floats(const int* dims, int n_res, int out_dim)
+{
+    size_t n = 0;
+    for (int i = 0; i < n_res; ++i) {
+        size_t K = dims[i], M = dims[i + 1];
+        n += M * K + M + M * M + M;
+        if (K != M) n += M * K + M;
+    }
+    n += (size_t)out_dim * dims[n_res] + out_dim;
+    return n;
+}
+
+extern "C" size_t cppf_pair_mlp_packed_floats(int F, const int* dims, int n_res, int out_dim)
+{
+    if (!dims) return 0;
+    if (is_std(F, dims, n_res, out_dim)) return STD_PACKED;
+    if (gen_ok(F, dims, n_res, out_dim)) return gen_floats(dims, n_res, out_dim);
+    return 0;
+}
+
+static inline int kfirst(int s, int g) { return s < 10 ? 10 * g + s : (s < 20 ? 40 + 10 * g + (s - 10) : 80 + g); }
+static inline int khid(int s, int g) { return 16 * (s / 4) + 4 * g + (s % 4); }
+
+extern "C" int cppf_pair_mlp_pack(const float* params, const int64_t* offs, int F, const int* dims, int n_res,
+                                  int out_dim, float* out)
+{
+    if (!params || !offs || !dims || !out) return CPPF_EINVAL;
+    if (is_std(F, dims, n_res, out_dim)) {
+        memset(out, 0, sizeof(float) * STD_PACKED);
+        const float *w1 = params + offs[0], *b1 = params + offs[1], *w2 = params + offs[2], *b2 = params + offs[3];
+        if (offs[4] < 0 || offs[10] >= 0 || offs[16] < 0) return CPPF_EINVAL;  // fc0 on layers 0 and 2 only
+        const float *w0 = params + offs[4], *b0 = params + offs[5];
+        for (int s = 0; s < 21; ++s)
+            for (int l = 0; l < 64; ++l)
+                for (int ob = 0; ob < 4; ++ob) {
+                    int o = 16 * (ob & 1) + (l & 15), k = kfirst(s, l >> 4);
+                    out[OFF_W0 + (s * 64 + l) * 4 + ob] = (ob < 2 ? w1 : w0)[o * 84 + k];
+                }
+        for (int o = 0; o < 32; ++o) { out[OFF_B0 + o] = b1[o]; out[OFF_B0 + 32 + o] = b0[o]; out[OFF_B0B + o] = b2[o]; }
+        for (int s = 0; s < 8; ++s)
+            for (int l = 0; l < 64; ++l)
+                for (int ob = 0; ob < 2; ++ob)
+                    out[OFF_W0B + (s * 64 + l) * 2 + ob] = w2[(16 * ob + (l & 15)) * 32 + khid(s, l >> 4)];
+        // layer 1 (no fc0)
+        w1 = params + offs[6]; b1 = params + offs[7]; w2 = params + offs[8]; b2 = params + offs[9];
+        for (int s = 0; s < 8; ++s)
+            for (int l = 0; l < 64; ++l)
+                for (int ob = 0; ob < 2; ++ob) {
+                    out[OFF_W1A + (s * 64 + l) * 2 + ob] = w1[(16 * ob + (l & 15)) * 32 + khid(s, l >> 4)];
+                    out[OFF_W1B + (s * 64 + l) * 2 + ob] = w2[(16 * ob + (l & 15)) * 32 + khid(s, l >> 4)];
+                }
+        for (int o = 0; o < 32; ++o) { out[OFF_B1A + o] = b1[o]; out[OFF_B1B + o] = b2[o]; }
+        // layer 2
+        w1 = params + offs[12]; b1 = params + offs[13]; w2 = params + offs[14]; b2 = params + offs[15];
+        w0 = params + offs[16]; b0 = params + offs[17];
+        for (int s = 0; s < 8; ++s)
+            for (int l = 0; l < 64; ++l) {
+                out[OFF_W2 + (s * 64 + l) * 2 + 0] = w1[(l & 15) * 32 + khid(s, l >> 4)];
+                out[OFF_W2 + (s * 64 + l) * 2 + 1] = w0[(l & 15) * 32 + khid(s, l >> 4)];
+            }
+        for (int s = 0; s < 4; ++s)
+            for (int l = 0; l < 64; ++l) out[OFF_W2B + s * 64 + l] = w2[(l & 15) * 16 + khid(s, l >> 4)];
+        for (int o = 0; o < 16; ++o) { out[OFF_B2 + o] = b1[o]; out[OFF_B2 + 16 + o] = b0[o]; out[OFF_B2B + o] = b2[o]; }
+        // final
+        const float *wf = params + offs[18], *bf = params + offs[19];
+        for (int s = 0; s < 4; ++s)
+            for (int l = 0; l < 64; ++l)
+                for (int ob = 0; ob < STD_NOB; ++ob) {
+                    int o = 16 * ob + (l & 15);
+                    out[OFF_WF + (s * 64 + l) * STD_NOBP + ob] = o < out_dim ? wf[o * 16 + khid(s, l >> 4)] : 0.f;
+                }
+        for (int o = 0; o < out_dim; ++o) out[OFF_BF + o] = bf[o];
+        return 0;
+    }
+    if (gen_ok(F, dims, n_res, out_dim)) {
+        // canonical order: per layer fc1.w fc1.b fc2.w fc2.b [fc0.w fc0.b], then final.w final.b
+        size_t n = 0;
+        for (int i = 0; i < n_res; ++i) {
+            size_t K = dims[i], M = dims[i + 1];
+            const int64_t* o = offs + 6 * i;
+            if ((K != M) != (o[4] >= 0)) return CPPF_EINVAL;
+            memcpy(out + n, params + o[0], sizeof(float) * M * K); n += M * K;
+            memcpy(out + n, params + o[1], sizeof(float) * M); n += M;
+            memcpy(out + n, params + o[2], sizeof(float) * M * M); n += M * M;
+            memcpy(out + n, params + o[3], sizeof(float) * M); n += M;
+            if (K != M) {
+                memcpy(out + n, params + o[4], sizeof(float) * M * K); n += M * K;
+                memcpy(out + n, params + o[5], sizeof(float) * M); n += M;
+            }
+        }
+        const int64_t* o = offs + 6 * n_res;
+        memcpy(out + n, params + o[0], sizeof(float) * out_dim * dims[n_res]); n += (size_t)out_dim * dims[n_res];
+        memcpy(out + n, params + o[1], sizeof(float) * out_dim);
+        return 0;
+    }
+    return CPPF_EUNSUPPORTED;
+}
+
+// ----------------------------------------------------------------------------- MFMA kernel
+#define MLP_THREADS 256
+#define PB 2  // 16-pair blocks per wave tile
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 relu4(f32x4 v)
+{
+    f32x4 r;
+    r[0] = v[0] > 0.f ? v[0] : 0.f; r[1] = v[1] > 0.f ? v[1] : 0.f;
+    r[2] = v[2] > 0.f ? v[2] : 0.f; r[3] = v[3] > 0.f ? v[3] : 0.f;
+    return r;
+}
+__device__ __forceinline__ f32x4 ldb4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// PPF of one pair (models/model.py:118-129); returns component `g`.
+__device__ __forceinline__ float ppf_component(const float* __restrict__ pc, const float* __restrict__ nrm, int a, int b,
+                                               int g)
+{
+    const f3 pa = ld3(pc, a), pb = ld3(pc, b), na = ld3(nrm, a), nb = ld3(nrm, b);
+    const f3 xy = sub3(pa, pb);
+    const float d = sqrtf((xy.x * xy.x + xy.y * xy.y) + xy.z * xy.z);
+    const float den = d + 1e-7f;                       // fp32 add (torch), unlike the vote kernels
+    const f3 u = {xy.x / den, xy.y / den, xy.z / den};
+    const float p0 = (na.x * u.x + na.y * u.y) + na.z * u.z;
+    const float p1 = (nb.x * u.x + nb.y * u.y) + nb.z * u.z;
+    const float p2 = (na.x * nb.x + na.y * nb.y) + na.z * nb.z;
+    return g == 0 ? p0 : (g == 1 ? p1 : (g == 2 ? p2 : d));
+}
+
+// ---- decode helpers (semantics: oracle/cppf_oracle.c:orc_sample_bin) --------------------------
+// Logit 16*ob + 4*g + r of the lane's pair lives in L[ob][r] of lane group g; "chunk" c = 4*ob + g.
+__device__ __forceinline__ float xmax4(float v)  // max over the 4 lanes (g = 0..3) of a pair
+{
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ int xmaxi4(int v)
+{
+    v = max(v, __shfl_xor(v, 16, 64));
+    return max(v, __shfl_xor(v, 32, 64));
+}
+
+// Head occupying chunks [C0, C0+NC) (logits [4*C0, 4*(C0+NC))).  Returns the sampled bin (0-based
+// within the head) in every lane of the pair.
+template <int C0, int NC, int NOB>
+__device__ __forceinline__ int sample_head(const f32x4 (&L)[NOB], float u, int g, int lane)
+{
+    constexpr int OB0 = C0 / 4, OB1 = (C0 + NC - 1) / 4;
+    // 1. max and first arg-max over the head
+    float m = -INFINITY;
+    int am = 0x7fffffff;
+#pragma unroll
+    for (int ob = OB0; ob <= OB1; ++ob) {
+        const int c = 4 * ob + g;
+        if (c >= C0 && c < C0 + NC) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (L[ob][r] > m) { m = L[ob][r]; am = (c - C0) * 4 + r; }
+        }
+    }
+    const float mall = xmax4(m);
+    if (u < 0.f) {  // arg-max mode: lowest bin among the maxima
+        int cand = (m == mall) ? am : 0x7fffffff;
+        cand = min(cand, __shfl_xor(cand, 16, 64));
+        cand = min(cand, __shfl_xor(cand, 32, 64));
+        return cand;
+    }
+    // 2. exponentials and chunk sums of the owned chunks
+    f32x4 e[OB1 - OB0 + 1];
+    float cs[OB1 - OB0 + 1];
+#pragma unroll
+    for (int ob = OB0; ob <= OB1; ++ob) {
+        const int c = 4 * ob + g;
+        const bool own = c >= C0 && c < C0 + NC;
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = own ? det_expf(L[ob][r] - mall) : 0.f;
+        e[ob - OB0] = v;
+        cs[ob - OB0] = ((v[0] + v[1]) + v[2]) + v[3];
+    }
+    // 3. chunk CDF in chunk order (all-gather of the chunk sums inside the 4-lane group)
+    const int j = lane & 15;
+    float C[NC];
+    float run = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci) {
+        const int c = C0 + ci;
+        const float v = __shfl(cs[c / 4 - OB0], j + 16 * (c % 4), 64);
+        run = run + v;
+        C[ci] = run;
+    }
+    const float t = u * run;
+    // 4. first chunk whose CDF exceeds t
+    int sel = NC;  // none
+    float base = 0.f;
+#pragma unroll
+    for (int ci = NC - 1; ci >= 0; --ci)
+        if (C[ci] > t) { sel = ci; base = ci ? C[ci - 1] : 0.f; }
+    int bin = -1;
+    if (sel == NC) {
+        bin = 4 * NC - 1;  // rounding left t >= total: last bin
+    } else {
+        const int c = C0 + sel;
+        if ((c & 3) == g) {  // owner lane walks its 4 entries
+            f32x4 ev = e[0];
+#pragma unroll
+            for (int ob = OB0; ob <= OB1; ++ob)
+                if (ob == (c >> 2)) ev = e[ob - OB0];
+            int r = 3;
+            float b = base + ev[0];
+            if (b > t) r = 0;
+            else {
+                b = b + ev[1];
+                if (b > t) r = 1;
+                else {
+                    b = b + ev[2];
+                    if (b > t) r = 2;
+                }
+            }
+            bin = 4 * sel + r;
+        }
+    }
+    return xmaxi4(bin);
+}
+
+struct MlpArgs {
+    const float* pc;
+    const float* nrm;
+    const float* feat;
+    const void* idxs;
+    const float* packed;
+    const float* u_tr;
+    const float* u_rot;
+    float* out;      // logits [P,out_dim]   (LOGITS)
+    float* outputs;  // [P,2]                (DECODE)
+    float* heads;    // [P,8] or null        (DECODE)
+    int64_t P;
+    int out_dim;
+    int idx64;
+    float vr0, vr1;
+};
+
+template <bool LOGITS, bool DECODE>
+__global__ __launch_bounds__(MLP_THREADS, 3) void pair_mlp_kernel(MlpArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float W[];
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(A.packed);
+        f32x4* dst = reinterpret_cast<f32x4*>(W);
+        for (int k = threadIdx.x; k < STD_PACKED / 4; k += MLP_THREADS) dst[k] = src[k];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int64_t n_tiles = (A.P + 16 * PB - 1) / (16 * PB);
+    const int64_t wave_gid = (int64_t)blockIdx.x * (MLP_THREADS / 64) + wave;
+    const int64_t wave_cnt = (int64_t)gridDim.x * (MLP_THREADS / 64);
+
+    for (int64_t tile = wave_gid; tile < n_tiles; tile += wave_cnt) {
+        // The packed weights are loop-invariant LDS data: without this compiler barrier LICM hoists
+        // all ~200 weight registers out of the tile loop and the kernel spills.
+        asm volatile("" ::: "memory");
+        // ---- gather: x0[pb][s], s = 0..20 -------------------------------------------------------
+        float x0[PB][21];
+        int64_t pair[PB];
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            pair[pb] = tile * (16 * PB) + pb * 16 + j;
+            const int64_t pc_ = pair[pb] < A.P ? pair[pb] : A.P - 1;
+            int ia, ib;
+            if (A.idx64) {
+                const longlong2 v = reinterpret_cast<const longlong2*>(A.idxs)[pc_];
+                ia = (int)v.x; ib = (int)v.y;
+            } else {
+                const int2 v = reinterpret_cast<const int2*>(A.idxs)[pc_];
+                ia = v.x; ib = v.y;
+            }
+            const f32x2* fa = reinterpret_cast<const f32x2*>(A.feat + (int64_t)ia * STD_F + 10 * g);
+            const f32x2* fb = reinterpret_cast<const f32x2*>(A.feat + (int64_t)ib * STD_F + 10 * g);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const f32x2 va = fa[q], vb = fb[q];
+                x0[pb][2 * q] = va[0]; x0[pb][2 * q + 1] = va[1];
+                x0[pb][10 + 2 * q] = vb[0]; x0[pb][11 + 2 * q] = vb[1];
+            }
+            x0[pb][20] = ppf_component(A.pc, A.nrm, ia, ib, g);
+        }
+
+        // ---- layer 0: fc1 | fc0 (84 -> 32 | 32) -------------------------------------------------
+        f32x4 acc[PB][4];
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            const f32x4 b = ldb4(W + OFF_B0 + 16 * ob + 4 * g);
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) acc[pb][ob] = b;
+        }
+#pragma unroll
+        for (int s = 0; s < 21; ++s) {
+            const f32x4 w = ldb4(W + OFF_W0 + (s * 64 + lane) * 4);
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) acc[pb][ob] = mfma4(w[ob], x0[pb][s], acc[pb][ob]);
+        }
+        // ---- layer 0: fc2 (32 -> 32) on relu(fc1), + fc0 ---------------------------------------
+        f32x4 y[PB][2];
+        {
+            f32x4 h[PB][2], a2[PB][2];
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) { h[pb][0] = relu4(acc[pb][0]); h[pb][1] = relu4(acc[pb][1]); }
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) {
+                const f32x4 b = ldb4(W + OFF_B0B + 16 * ob + 4 * g);
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) a2[pb][ob] = b;
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const f32x2 w = *reinterpret_cast<const f32x2*>(W + OFF_W0B + (s * 64 + lane) * 2);
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb) a2[pb][ob] = mfma4(w[ob], h[pb][s >> 2][s & 3], a2[pb][ob]);
+            }
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) { y[pb][0] = a2[pb][0] + acc[pb][2]; y[pb][1] = a2[pb][1] + acc[pb][3]; }
+        }
+        // ---- layer 1: 32 -> 32 -> 32, identity skip --------------------------------------------
+        {
+            f32x4 a1[PB][2], h[PB][2], a2[PB][2];
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) {
+                const f32x4 b1 = ldb4(W + OFF_B1A + 16 * ob + 4 * g), b2 = ldb4(W + OFF_B1B + 16 * ob + 4 * g);
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) { a1[pb][ob] = b1; a2[pb][ob] = b2; }
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const f32x2 w = *reinterpret_cast<const f32x2*>(W + OFF_W1A + (s * 64 + lane) * 2);
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb) a1[pb][ob] = mfma4(w[ob], y[pb][s >> 2][s & 3], a1[pb][ob]);
+            }
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) { h[pb][0] = relu4(a1[pb][0]); h[pb][1] = relu4(a1[pb][1]); }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const f32x2 w = *reinterpret_cast<const f32x2*>(W + OFF_W1B + (s * 64 + lane) * 2);
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb) a2[pb][ob] = mfma4(w[ob], h[pb][s >> 2][s & 3], a2[pb][ob]);
+            }
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) { y[pb][0] = a2[pb][0] + y[pb][0]; y[pb][1] = a2[pb][1] + y[pb][1]; }
+        }
+        // ---- layer 2: fc1 | fc0 (32 -> 16 | 16), fc2 (16 -> 16) ---------------------------------
+        f32x4 z[PB];
+        {
+            f32x4 a1[PB][2], a2[PB];
+            {
+                const f32x4 b1 = ldb4(W + OFF_B2 + 4 * g), b0 = ldb4(W + OFF_B2 + 16 + 4 * g), b2 = ldb4(W + OFF_B2B + 4 * g);
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) { a1[pb][0] = b1; a1[pb][1] = b0; a2[pb] = b2; }
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const f32x2 w = *reinterpret_cast<const f32x2*>(W + OFF_W2 + (s * 64 + lane) * 2);
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb) a1[pb][ob] = mfma4(w[ob], y[pb][s >> 2][s & 3], a1[pb][ob]);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float w = W[OFF_W2B + s * 64 + lane];
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) {
+                    const f32x4 h = relu4(a1[pb][0]);
+                    a2[pb] = mfma4(w, h[s], a2[pb]);
+                }
+            }
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) z[pb] = a2[pb] + a1[pb][1];
+        }
+        // ---- final: 16 -> 144 (9 x 16) ------------------------------------------------------------
+        f32x4 L[PB][STD_NOB];
+#pragma unroll
+        for (int ob = 0; ob < STD_NOB; ++ob) {
+            const f32x4 b = ldb4(W + OFF_BF + 16 * ob + 4 * g);
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) L[pb][ob] = b;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float* wp = W + OFF_WF + (s * 64 + lane) * STD_NOBP;
+            const f32x4 w0 = ldb4(wp), w1 = ldb4(wp + 4), w2 = ldb4(wp + 8);
+#pragma unroll
+            for (int ob = 0; ob < STD_NOB; ++ob) {
+                const float w = ob < 4 ? w0[ob & 3] : (ob < 8 ? w1[ob & 3] : w2[ob & 3]);
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) L[pb][ob] = mfma4(w, z[pb][s], L[pb][ob]);
+            }
+        }
+
+        // ---- epilogue -----------------------------------------------------------------------------
+        if (LOGITS) {
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) {
+                if (pair[pb] < A.P) {
+                    float* o = A.out + pair[pb] * A.out_dim + 4 * g;
+#pragma unroll
+                    for (int ob = 0; ob < STD_NOB; ++ob)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (16 * ob + 4 * g + r < A.out_dim) o[16 * ob + r] = L[pb][ob][r];
+                }
+            }
+        }
+        if (DECODE) {
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) {
+                const bool live = pair[pb] < A.P;
+                const int64_t pc_ = live ? pair[pb] : A.P - 1;
+                const f32x2 ut = reinterpret_cast<const f32x2*>(A.u_tr)[pc_];
+                const int k0 = sample_head<0, 8, STD_NOB>(L[pb], ut[0], g, lane);
+                const int k1 = sample_head<8, 8, STD_NOB>(L[pb], ut[1], g, lane);
+                if (live && g == 0) {
+                    // nocs/inference.py:187-188, fp32 left to right
+                    f32x2 o;
+                    o[0] = ((float)k0 / 31.0f * 2.0f) * A.vr0 - A.vr0;
+                    o[1] = (float)k1 / 31.0f * A.vr1;
+                    reinterpret_cast<f32x2*>(A.outputs)[pair[pb]] = o;
+                }
+                if (A.heads) {
+                    const f32x2 ur = reinterpret_cast<const f32x2*>(A.u_rot)[pc_];
+                    const int ku = sample_head<16, 9, STD_NOB>(L[pb], ur[0], g, lane);
+                    const int kr = sample_head<25, 9, STD_NOB>(L[pb], ur[1], g, lane);
+                    if (live) {
+                        f32x2* h = reinterpret_cast<f32x2*>(A.heads + pair[pb] * 8);
+                        const float pif = (float)CPPF_PI;
+                        if (g == 0) { f32x2 v; v[0] = (float)ku / 35.0f * pif; v[1] = (float)kr / 35.0f * pif; h[0] = v; }
+                        if (g == 2) {  // logits 136..139 = aux_up, aux_right, sx, sy
+                            f32x2 v; v[0] = L[pb][8][0]; v[1] = L[pb][8][1]; h[1] = v;
+                            f32x2 w; w[0] = L[pb][8][2]; w[1] = L[pb][8][3]; h[2] = w;
+                        }
+                        if (g == 3) { f32x2 v; v[0] = L[pb][8][0]; v[1] = 0.f; h[3] = v; }  // logit 140 = sz
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- generic kernel
+// Any ResLayer stack up to 128 units wide: one pair per lane, activations in LDS ([k][lane], no
+// bank conflicts), weights read through the scalar path (wave-uniform addresses), natural k order
+// (oracle order 0), fmaf chain seeded by the bias.
+struct GenArgs {
+    const float* pc;
+    const float* nrm;
+    const float* feat;
+    const void* idxs;
+    const float* packed;
+    float* out;
+    int64_t P;
+    int F, n_res, out_dim, idx64;
+    int dims[GEN_MAX_RES + 1];
+};
+#define GEN_THREADS 64
+__global__ __launch_bounds__(GEN_THREADS) void pair_mlp_generic_kernel(GenArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float S[];
+    int maxd = 0;
+    for (int i = 0; i <= A.n_res; ++i) maxd = max(maxd, A.dims[i]);
+    float* X = S;                          // [maxd][64]
+    float* H = S + maxd * GEN_THREADS;     // [maxd][64]
+    const int t = threadIdx.x;
+    for (int64_t p = (int64_t)blockIdx.x * GEN_THREADS + t; p < (A.P + GEN_THREADS - 1) / GEN_THREADS * GEN_THREADS;
+         p += (int64_t)gridDim.x * GEN_THREADS) {
+        const bool live = p < A.P;
+        const int64_t pc_ = live ? p : A.P - 1;
+        int ia, ib;
+        if (A.idx64) {
+            const longlong2 v = reinterpret_cast<const longlong2*>(A.idxs)[pc_];
+            ia = (int)v.x; ib = (int)v.y;
+        } else {
+            const int2 v = reinterpret_cast<const int2*>(A.idxs)[pc_];
+            ia = v.x; ib = v.y;
+        }
+        const int F = A.F;
+        for (int k = 0; k < F; ++k) {
+            X[k * GEN_THREADS + t] = A.feat[(int64_t)ia * F + k];
+            X[(F + k) * GEN_THREADS + t] = A.feat[(int64_t)ib * F + k];
+        }
+        for (int c = 0; c < 4; ++c) X[(2 * F + c) * GEN_THREADS + t] = ppf_component(A.pc, A.nrm, ia, ib, c);
+        const float* w = A.packed;
+        for (int l = 0; l < A.n_res; ++l) {
+            const int K = A.dims[l], M = A.dims[l + 1];
+            const float *w1 = w, *b1 = w1 + M * K, *w2 = b1 + M, *b2 = w2 + M * M;
+            const float *w0 = b2 + M, *b0 = w0 + M * K;
+            const bool has0 = K != M;
+            // H = relu(fc1 X)
+            for (int o = 0; o < M; ++o) {
+                float acc = b1[o];
+                for (int k = 0; k < K; ++k) acc = fmaf(w1[o * K + k], X[k * GEN_THREADS + t], acc);
+                H[o * GEN_THREADS + t] = acc > 0.f ? acc : 0.f;
+            }
+            // Y = fc2 H + (fc0 X | X): every output needs all of X, so Y is a third buffer
+            for (int o = 0; o < M; ++o) {
+                float acc = b2[o];
+                for (int k = 0; k < M; ++k) acc = fmaf(w2[o * M + k], H[k * GEN_THREADS + t], acc);
+                float skip;
+                if (has0) {
+                    float a0 = b0[o];
+                    for (int k = 0; k < K; ++k) a0 = fmaf(w0[o * K + k], X[k * GEN_THREADS + t], a0);
+                    skip = a0;
+                } else {
+                    skip = X[o * GEN_THREADS + t];
+                }
+                S[(2 * maxd + o) * GEN_THREADS + t] = acc + skip;
+            }
+            for (int o = 0; o < M; ++o) X[o * GEN_THREADS + t] = S[(2 * maxd + o) * GEN_THREADS + t];
+            w = has0 ? b0 + M : b2 + M;
+        }
+        const int K = A.dims[A.n_res];
+        const float *wf = w, *bf = wf + A.out_dim * K;
+        for (int o = 0; o < A.out_dim; ++o) {
+            float acc = bf[o];
+            for (int k = 0; k < K; ++k) acc = fmaf(wf[o * K + k], X[k * GEN_THREADS + t], acc);
+            if (live) A.out[p * A.out_dim + o] = acc;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- decode from memory
+// One lane per (pair, head): same arithmetic as sample_head / oracle orc_sample_bin.
+__device__ int sample_bin_mem(const float* __restrict__ l, int nb, float u)
+{
+    float m = l[0];
+    int am = 0;
+    for (int k = 1; k < nb; ++k)
+        if (l[k] > m) { m = l[k]; am = k; }
+    if (u < 0.f) return am;
+    const int nc = (nb + 3) / 4;
+    float run = 0.f;
+    for (int c = 0; c < nc; ++c) {
+        float e[4];
+        for (int r = 0; r < 4; ++r) e[r] = 4 * c + r < nb ? det_expf(l[4 * c + r] - m) : 0.f;
+        run = run + (((e[0] + e[1]) + e[2]) + e[3]);
+    }
+    const float t = u * run;
+    float C = 0.f;
+    for (int c = 0; c < nc; ++c) {
+        float e[4];
+        for (int r = 0; r < 4; ++r) e[r] = 4 * c + r < nb ? det_expf(l[4 * c + r] - m) : 0.f;
+        const float Cn = C + (((e[0] + e[1]) + e[2]) + e[3]);
+        if (Cn > t) {
+            float b = C;
+            for (int r = 0; r < 4; ++r) {
+                b = b + e[r];
+                if (b > t) return min(4 * c + r, nb - 1);
+            }
+            return min(4 * c + 3, nb - 1);
+        }
+        C = Cn;
+    }
+    return nb - 1;
+}
+
+__global__ __launch_bounds__(256) void decode_center_kernel(const float* __restrict__ logits, int64_t P, int ld, int nb,
+                                                            float vr0, float vr1, const float* __restrict__ u,
+                                                            float* __restrict__ outputs)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (pair, head)
+    if (i >= 2 * P) return;
+    const int64_t p = i >> 1;
+    const int h = (int)(i & 1);
+    const int k = sample_bin_mem(logits + p * ld + h * nb, nb, u[i]);
+    const float d = (float)(nb - 1);
+    outputs[i] = h == 0 ? ((float)k / d * 2.0f) * vr0 - vr0 : (float)k / d * vr1;
+}
+
+__global__ __launch_bounds__(256) void decode_rot_kernel(const float* __restrict__ logits, int64_t P, int ld, int out_dim,
+                                                         int tb, int rb, const float* __restrict__ u,
+                                                         float* __restrict__ heads)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * P) return;
+    const int64_t p = i >> 1;
+    const int h = (int)(i & 1);
+    const float* l = logits + p * ld;
+    const int k = sample_bin_mem(l + 2 * tb + h * rb, rb, u[i]);
+    float* o = heads + 8 * p;
+    o[h] = (float)k / (float)(rb - 1) * (float)CPPF_PI;
+    if (h == 0) { o[2] = l[out_dim - 5]; o[3] = l[out_dim - 4]; o[4] = l[out_dim - 3]; }
+    else { o[5] = l[out_dim - 2]; o[6] = l[out_dim - 1]; o[7] = 0.f; }
+}
+
+// ----------------------------------------------------------------------------- entry points
+static int mlp_grid(int64_t P)
+{
+    const int64_t tiles = (P + 16 * PB - 1) / (16 * PB);
+    int64_t nb = (tiles + MLP_THREADS / 64 - 1) / (MLP_THREADS / 64);
+    if (nb > 768) nb = 768;  // 3 workgroups of 4 waves per CU resident (52.6 KB LDS each, <=168 VGPR)
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+template <bool LOGITS, bool DECODE>
+static int launch_std(const MlpArgs& A, hipStream_t st)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mlp_kernel<LOGITS, DECODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, STD_PACKED * sizeof(float));
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((pair_mlp_kernel<LOGITS, DECODE>), dim3(mlp_grid(A.P)), dim3(MLP_THREADS),
+                       STD_PACKED * sizeof(float), st, A);
+    CPPF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cppf_pair_mlp_forward(const float* pc, const float* nrm, const float* feat, const void* idxs,
+                                     int idx_is_i64, const float* packed, int64_t N, int F, const int* dims, int n_res,
+                                     int64_t P, int out_dim, float* out, void* stream)
+{
+    (void)N;
+    if (!pc || !nrm || !feat || !idxs || !packed || !dims || !out || P < 0) return CPPF_EINVAL;
+    if (P == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (is_std(F, dims, n_res, out_dim)) {
+        MlpArgs A = {};
+        A.pc = pc; A.nrm = nrm; A.feat = feat; A.idxs = idxs; A.packed = packed; A.out = out; A.P = P;
+        A.out_dim = out_dim; A.idx64 = idx_is_i64;
+        return launch_std<true, false>(A, st);
+    }
+    if (!gen_ok(F, dims, n_res, out_dim)) return CPPF_EUNSUPPORTED;
+    GenArgs G = {};
+    G.pc = pc; G.nrm = nrm; G.feat = feat; G.idxs = idxs; G.packed = packed; G.out = out; G.P = P;
+    G.F = F; G.n_res = n_res; G.out_dim = out_dim; G.idx64 = idx_is_i64;
+    int maxd = 0;
+    for (int i = 0; i <= n_res; ++i) { G.dims[i] = dims[i]; if (dims[i] > maxd) maxd = dims[i]; }
+    const size_t lds = (size_t)3 * maxd * GEN_THREADS * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mlp_generic_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 3 * GEN_MAX_DIM * GEN_THREADS * sizeof(float));
+        attr_done = true;
+    }
+    int64_t nb = (P + GEN_THREADS - 1) / GEN_THREADS;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(pair_mlp_generic_kernel, dim3((unsigned)nb), dim3(GEN_THREADS), lds, st, G);
+    CPPF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cppf_pair_mlp_decode(const float* pc, const float* nrm, const float* feat, const void* idxs,
+                                    int idx_is_i64, const float* packed, int64_t N, int F, const int* dims, int n_res,
+                                    int64_t P, int out_dim, int tr_bins, int rot_bins, float vr0, float vr1,
+                                    const float* u_tr, const float* u_rot, float* outputs, float* heads, void* stream)
+{
+    (void)N;
+    if (!pc || !nrm || !feat || !idxs || !packed || !dims || !u_tr || !outputs || P < 0) return CPPF_EINVAL;
+    if ((heads != nullptr) != (u_rot != nullptr)) return CPPF_EINVAL;
+    if (!is_std(F, dims, n_res, out_dim) || tr_bins != 32 || rot_bins != 36 || out_dim != 141) return CPPF_EUNSUPPORTED;
+    if (P == 0) return 0;
+    MlpArgs A = {};
+    A.pc = pc; A.nrm = nrm; A.feat = feat; A.idxs = idxs; A.packed = packed; A.P = P; A.out_dim = out_dim;
+    A.idx64 = idx_is_i64; A.u_tr = u_tr; A.u_rot = u_rot; A.outputs = outputs; A.heads = heads; A.vr0 = vr0; A.vr1 = vr1;
+    return launch_std<false, true>(A, (hipStream_t)stream);
+}
+
+extern "C" int cppf_decode_center(const float* logits, int64_t P, int ld, int tr_bins, float vr0, float vr1,
+                                  const float* u_tr, float* outputs, void* stream)
+{
+    if (!logits || !u_tr || !outputs || P < 0 || tr_bins < 2 || ld < 2 * tr_bins) return CPPF_EINVAL;
+    if (P == 0) return 0;
+    hipLaunchKernelGGL(decode_center_kernel, dim3((unsigned)((2 * P + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       logits, P, ld, tr_bins, vr0, vr1, u_tr, outputs);
+    CPPF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cppf_decode_rot(const float* logits, int64_t P, int ld, int out_dim, int tr_bins, int rot_bins,
+                               const float* u_rot, float* heads, void* stream)
+{
+    if (!logits || !u_rot || !heads || P < 0 || rot_bins < 2 || out_dim < 2 * tr_bins + 2 * rot_bins + 5 || ld < out_dim)
+        return CPPF_EINVAL;
+    if (P == 0) return 0;
+    hipLaunchKernelGGL(decode_rot_kernel, dim3((unsigned)((2 * P + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       logits, P, ld, out_dim, tr_bins, rot_bins, u_rot, heads);
+    CPPF_CHECK_LAUNCH();
+    return 0;
+}

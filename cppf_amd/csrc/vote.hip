@@ -1,0 +1,878 @@
+// Centre vote, arg-max, back-vote, compaction, orientation vote and the pose-tail reductions
+// for gfx950 (MI355X).  C ABI in include/cppf.h; reference semantics cited per kernel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/cppf.h"
+#include "cppf_math.h"
+
+using namespace cppf;
+
+#define CPPF_CHECK_LAUNCH()                         \
+    do {                                            \
+        hipError_t e__ = hipGetLastError();         \
+        if (e__ != hipSuccess) return (int)e__;     \
+    } while (0)
+
+// ----------------------------------------------------------------------------- rotation table
+// tab[n*(n-1)/2 + i] = (cos, sin) of rotation i of n, n = 1..n_rots.  Built per call into the
+// caller's workspace (a 2.6k-entry kernel for n_rots = 72); vote workgroups copy it to LDS.
+__global__ void rot_table_kernel(float2* __restrict__ tab, int n_rots)
+{
+    int n = blockIdx.x + 1;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) tab[n * (n - 1) / 2 + i] = rot_cs(i, n);
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int tri(int n) { return n * (n + 1) / 2; }
+
+// ----------------------------------------------------------------------------- vote plan
+#define VOTE_TILE_FLOATS 32768  // 128 KiB of the CU's 160 KiB LDS for the grid tile
+#define VOTE_TAB_LDS_MAX 3600   // (cos,sin) pairs kept in LDS (n_rots <= 84); else read via L1/L2
+#define VOTE_MAX_TILES 16       // beyond this the geometry redundancy costs more than L2 atomics
+#define VOTE_THREADS 1024
+
+struct VotePlan {
+    int tiled;            // 1: LDS tiles + partial grids, 0: global atomics
+    int tx, ty;           // tile extent in x and y (z is never cut)
+    int ntx, nty, T;      // tiles per axis, total
+    int chunks;           // pair chunks (= partial grids)
+    int64_t chunk_pairs;  // pairs per chunk
+    size_t tab_off, packed_off, part_off, total;
+    int tab_entries;
+};
+
+static VotePlan make_vote_plan(int64_t n_ppfs, int n_rots, int gx, int gy, int gz)
+{
+    VotePlan p = {};
+    int64_t G = (int64_t)gx * gy * gz;
+    p.tab_entries = tri(n_rots);
+    int best_T = 1 << 30;
+    if ((int64_t)gz <= VOTE_TILE_FLOATS) {
+        for (int nty = 1; nty <= gy; ++nty) {
+            int ty = (gy + nty - 1) / nty;
+            if ((int64_t)ty * gz > VOTE_TILE_FLOATS) continue;
+            int txmax = (int)(VOTE_TILE_FLOATS / ((int64_t)ty * gz));
+            if (txmax > gx) txmax = gx;
+            int ntx = (gx + txmax - 1) / txmax;
+            int tx = (gx + ntx - 1) / ntx;
+            int T = ntx * ((gy + ty - 1) / ty);
+            if (T < best_T) { best_T = T; p.tx = tx; p.ty = ty; p.ntx = ntx; p.nty = (gy + ty - 1) / ty; }
+            if (ntx == 1) break;  // more y cuts can only add tiles
+        }
+    }
+    p.tiled = best_T <= VOTE_MAX_TILES && n_ppfs > 0;
+    p.T = p.tiled ? best_T : 1;
+    if (p.tiled) {
+        // one workgroup per CU (tile ~128 KiB): T*chunks ~ 256 workgroups, chunks of >= 1024 pairs
+        int64_t c = 256 / p.T;
+        int64_t cmax = (n_ppfs + 1023) / 1024;
+        if (c > cmax) c = cmax;
+        if (c < 1) c = 1;
+        p.chunks = (int)c;
+        p.chunk_pairs = (n_ppfs + c - 1) / c;
+    } else {
+        p.chunks = 0;
+        p.chunk_pairs = 0;
+    }
+    p.tab_off = 0;
+    p.packed_off = align_up((size_t)p.tab_entries * sizeof(float2), 256);
+    p.part_off = p.packed_off + 256;
+    p.total = p.part_off + (size_t)p.chunks * (size_t)G * sizeof(float);
+    return p;
+}
+
+extern "C" size_t cppf_vote_workspace_bytes(int64_t n_ppfs, int n_rots, int gx, int gy, int gz)
+{
+    if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || gx < 1 || gy < 1 || gz < 1 || n_ppfs < 0) return 0;
+    return make_vote_plan(n_ppfs, n_rots, gx, gy, gz).total;
+}
+
+// ----------------------------------------------------------------------------- centre vote
+// Reference: CUDA ppf_voting, models/voting.py:8-66.  One pair per lane, rotations in a loop.
+// TILED: the workgroup owns grid tile (x0..x0+tx, y0..y0+ty, all z) in LDS and pair chunk c; every
+// corner of every vote that falls into the tile is added with ds_add_f32; the tile is then stored
+// to partial grid c.  Cells belong to exactly one tile, so a partial grid is written exactly once.
+// !TILED: global_atomic_add_f32 straight into grid_obj (large grids).
+struct VoteArgs {
+    const float* points;
+    const float* outputs;
+    const float* probs;
+    const int32_t* point_idxs;
+    float* grid;       // !TILED target
+    float* partials;   // TILED target [chunks][G]
+    const float* corner;
+    const float2* tab;
+    unsigned long long* packed;  // arg-max scratch, zeroed here for the reduce kernel
+    float res;
+    int64_t n_ppfs;
+    int n_rots, gx, gy, gz, adaptive;
+    int tx, ty, ntx, nty, T;
+    int64_t chunk_pairs;
+    int tab_entries;
+};
+
+template <bool TILED, bool TAB_LDS>
+__global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* tile = lds;
+    float2* ltab = reinterpret_cast<float2*>(lds + (TILED ? VOTE_TILE_FLOATS : 0));
+    const int tid = threadIdx.x;
+    const int gz = A.gz, gy = A.gy, gx = A.gx;
+
+    int t = 0, c = 0, x0 = 0, y0 = 0, tx = gx, ty = gy;
+    int64_t p_begin, p_end, p_step;
+    if (TILED) {
+        t = blockIdx.x % A.T;
+        c = blockIdx.x / A.T;
+        int tix = t / A.nty, tiy = t % A.nty;
+        x0 = tix * A.tx;
+        y0 = tiy * A.ty;
+        tx = min(A.tx, gx - x0);
+        ty = min(A.ty, gy - y0);
+        p_begin = (int64_t)c * A.chunk_pairs + tid;
+        p_end = min((int64_t)(c + 1) * A.chunk_pairs, A.n_ppfs);
+        p_step = VOTE_THREADS;
+        const int nt = tx * ty * gz;
+        for (int k = tid; k < nt; k += VOTE_THREADS) tile[k] = 0.f;
+    } else {
+        p_begin = (int64_t)blockIdx.x * VOTE_THREADS + tid;
+        p_end = A.n_ppfs;
+        p_step = (int64_t)gridDim.x * VOTE_THREADS;
+    }
+    if (TAB_LDS)
+        for (int k = tid; k < A.tab_entries; k += VOTE_THREADS) ltab[k] = A.tab[k];
+    if (blockIdx.x == 0 && tid == 0) *A.packed = 0ull;
+    __syncthreads();
+
+    const f3 cr = {A.corner[0], A.corner[1], A.corner[2]};
+    const float res = A.res;
+    const double hx = (double)gx - 1.01, hy = (double)gy - 1.01, hz = (double)gz - 1.01;
+    const int syz = gy * gz;       // global x stride
+    const int ltyz = ty * gz;      // tile x stride
+
+    for (int64_t p = p_begin; p < p_end; p += p_step) {
+        const float2 o = reinterpret_cast<const float2*>(A.outputs)[p];
+        const int2 ij = reinterpret_cast<const int2*>(A.point_idxs)[p];
+        f3 a, ab, xd;
+        if (!pair_frame(A.points, ij.x, ij.y, a, ab, xd)) continue;
+        const float proj_len = o.x, odist = o.y;
+        const f3 cc = sub3(a, scl3(ab, proj_len));                     // :23
+        const float prob = fmaxf(A.probs[ij.x], A.probs[ij.y]);       // :25
+        const f3 x = scl3(xd, odist);                                  // :28
+        const f3 y = cross3(x, ab);                                    // :29
+        int n = A.n_rots;
+        if (A.adaptive) n = min((int)((double)(odist / res) * (2 * CPPF_PI)), A.n_rots);  // :31
+        const int tbase = n * (n - 1) / 2;
+        for (int i = 0; i < n; ++i) {
+            const float2 cs = TAB_LDS ? ltab[tbase + i] : A.tab[tbase + i];
+            const f3 offset = add3(scl3(x, cs.x), scl3(y, cs.y));      // :34
+            const f3 g = div3(sub3(add3(cc, offset), cr), res);        // :35
+            if ((double)g.x < 0.01 || (double)g.y < 0.01 || (double)g.z < 0.01 || (double)g.x >= hx ||
+                (double)g.y >= hy || (double)g.z >= hz)
+                continue;                                              // :36-39
+            const int fx = (int)g.x, fy = (int)g.y, fz = (int)g.z;     // :40
+            const float rx = g.x - floorf(g.x), ry = g.y - floorf(g.y), rz = g.z - floorf(g.z);
+            const float w0x = 1.f - rx, w0y = 1.f - ry, w0z = 1.f - rz;
+            const float ll = w0x * w0y, lh = w0x * ry, hl = rx * w0y, hh = rx * ry;
+            const float lll = ll * w0z * prob, llh = ll * rz * prob, lhl = lh * w0z * prob, lhh = lh * rz * prob;
+            const float hll = hl * w0z * prob, hlh = hl * rz * prob, hhl = hh * w0z * prob, hhh = hh * rz * prob;
+            if (TILED) {
+                const int lx = fx - x0, ly = fy - y0;
+                const bool x0in = (unsigned)lx < (unsigned)tx, x1in = (unsigned)(lx + 1) < (unsigned)tx;
+                const bool y0in = (unsigned)ly < (unsigned)ty, y1in = (unsigned)(ly + 1) < (unsigned)ty;
+                if (!((x0in | x1in) & (y0in | y1in))) continue;
+                float* b = tile + (lx * ty + ly) * gz + fz;
+                if (x0in & y0in) { atomicAdd(b, lll); atomicAdd(b + 1, llh); }
+                if (x0in & y1in) { atomicAdd(b + gz, lhl); atomicAdd(b + gz + 1, lhh); }
+                if (x1in & y0in) { atomicAdd(b + ltyz, hll); atomicAdd(b + ltyz + 1, hlh); }
+                if (x1in & y1in) { atomicAdd(b + ltyz + gz, hhl); atomicAdd(b + ltyz + gz + 1, hhh); }
+            } else {
+                float* b = A.grid + ((int64_t)fx * syz + fy * gz + fz);
+                atomicAdd(b, lll);
+                atomicAdd(b + 1, llh);
+                atomicAdd(b + gz, lhl);
+                atomicAdd(b + gz + 1, lhh);
+                atomicAdd(b + syz, hll);
+                atomicAdd(b + syz + 1, hlh);
+                atomicAdd(b + syz + gz, hhl);
+                atomicAdd(b + syz + gz + 1, hhh);
+            }
+        }
+    }
+
+    if (TILED) {
+        __syncthreads();
+        float* part = A.partials + (int64_t)c * ((int64_t)gx * syz);
+        if (ty == gy) {  // x slabs: the tile is one contiguous run of the grid
+            float* dst = part + (int64_t)x0 * syz;
+            const int nt = tx * syz;
+            for (int k = tid; k < nt; k += VOTE_THREADS) dst[k] = tile[k];
+        } else {
+            const int row = ty * gz, nt = tx * row;
+            for (int k = tid; k < nt; k += VOTE_THREADS) {
+                int lx = k / row, r = k - lx * row;
+                part[(int64_t)(x0 + lx) * syz + y0 * gz + r] = tile[k];
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- reduce + arg-max
+// grid[cell] += sum_c partials[c][cell] (fixed order), and the arg-max of the result with numpy's
+// tie rule (first maximum in C order, nocs/inference.py:208): key = ord(value) << 32 | ~index,
+// reduced with max inside the wave, the block and one atomicMax per block.
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long o = __shfl_xor(k, off, 64);
+        k = o > k ? o : k;
+    }
+    return k;
+}
+
+__global__ __launch_bounds__(256) void reduce_argmax_kernel(float* __restrict__ grid,
+                                                            const float* __restrict__ partials, int chunks,
+                                                            int64_t G, unsigned long long* packed, int write_back)
+{
+    __shared__ unsigned long long wk[4];
+    unsigned long long best = 0ull;
+    for (int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x; cell < G; cell += (int64_t)gridDim.x * 256) {
+        float v = grid[cell];
+        for (int c = 0; c < chunks; ++c) v = v + partials[(int64_t)c * G + cell];
+        if (write_back) grid[cell] = v;
+        unsigned long long k = ((unsigned long long)f2ord(v) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)cell);
+        best = k > best ? k : best;
+    }
+    best = wave_max_u64(best);
+    if ((threadIdx.x & 63) == 0) wk[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long b = wk[0];
+        for (int w = 1; w < 4; ++w) b = wk[w] > b ? wk[w] : b;
+        if (b) atomicMax(packed, b);
+    }
+}
+
+__global__ void unpack_argmax_kernel(const unsigned long long* packed, long long* out_idx, float* out_val)
+{
+    unsigned long long k = *packed;
+    if (out_idx) *out_idx = (long long)(0xffffffffu - (uint32_t)(k & 0xffffffffull));
+    if (out_val) *out_val = ord2f((uint32_t)(k >> 32));
+}
+
+__global__ void zero_u64_kernel(unsigned long long* p) { *p = 0ull; }
+
+static int vote_impl(const float* points, const float* outputs, const float* probs, const int32_t* point_idxs,
+                     float* grid_obj, const float* corner, float res, int64_t n_ppfs, int n_rots, int gx, int gy,
+                     int gz, int adaptive, bool want_argmax, long long* out_idx, float* out_val, void* workspace,
+                     size_t workspace_bytes, hipStream_t st)
+{
+    if (!points || !outputs || !probs || !point_idxs || !grid_obj || !corner) return CPPF_EINVAL;
+    if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || gx < 1 || gy < 1 || gz < 1 || n_ppfs < 0) return CPPF_EINVAL;
+    if ((int64_t)gx * gy * gz > 0x7fffffffll) return CPPF_EINVAL;
+    VotePlan pl = make_vote_plan(n_ppfs, n_rots, gx, gy, gz);
+    if (!workspace || workspace_bytes < pl.total) return CPPF_EWORKSPACE;
+    char* ws = static_cast<char*>(workspace);
+    float2* tab = reinterpret_cast<float2*>(ws + pl.tab_off);
+    unsigned long long* packed = reinterpret_cast<unsigned long long*>(ws + pl.packed_off);
+    float* partials = reinterpret_cast<float*>(ws + pl.part_off);
+    const int64_t G = (int64_t)gx * gy * gz;
+
+    hipLaunchKernelGGL(rot_table_kernel, dim3(n_rots), dim3(64), 0, st, tab, n_rots);
+    CPPF_CHECK_LAUNCH();
+
+    VoteArgs A;
+    A.points = points; A.outputs = outputs; A.probs = probs; A.point_idxs = point_idxs;
+    A.grid = grid_obj; A.partials = partials; A.corner = corner; A.tab = tab; A.packed = packed;
+    A.res = res; A.n_ppfs = n_ppfs; A.n_rots = n_rots; A.gx = gx; A.gy = gy; A.gz = gz; A.adaptive = adaptive;
+    A.tx = pl.tx; A.ty = pl.ty; A.ntx = pl.ntx; A.nty = pl.nty; A.T = pl.T; A.chunk_pairs = pl.chunk_pairs;
+    A.tab_entries = pl.tab_entries;
+    const bool tab_lds = pl.tab_entries <= VOTE_TAB_LDS_MAX;
+    const size_t tab_bytes = tab_lds ? (size_t)pl.tab_entries * sizeof(float2) : 0;
+    if (pl.tiled) {
+        const size_t lds = VOTE_TILE_FLOATS * sizeof(float) + tab_bytes;
+        dim3 grid(pl.T * pl.chunks);
+        if (tab_lds) {
+            static bool attr_done = false;
+            if (!attr_done) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&vote_kernel<true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr_done = true;
+            }
+            hipLaunchKernelGGL((vote_kernel<true, true>), grid, dim3(VOTE_THREADS), lds, st, A);
+        } else {
+            static bool attr_done = false;
+            if (!attr_done) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&vote_kernel<true, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr_done = true;
+            }
+            hipLaunchKernelGGL((vote_kernel<true, false>), grid, dim3(VOTE_THREADS), lds, st, A);
+        }
+    } else {
+        int64_t nb = (n_ppfs + VOTE_THREADS - 1) / VOTE_THREADS;
+        if (nb > 2048) nb = 2048;
+        if (nb < 1) nb = 1;
+        if (tab_lds)
+            hipLaunchKernelGGL((vote_kernel<false, true>), dim3((unsigned)nb), dim3(VOTE_THREADS), tab_bytes, st, A);
+        else
+            hipLaunchKernelGGL((vote_kernel<false, false>), dim3((unsigned)nb), dim3(VOTE_THREADS), 0, st, A);
+    }
+    CPPF_CHECK_LAUNCH();
+
+    if (pl.tiled || want_argmax) {
+        int64_t nb = (G + 255) / 256;
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(reduce_argmax_kernel, dim3((unsigned)nb), dim3(256), 0, st, grid_obj, partials,
+                           pl.chunks, G, packed, pl.tiled ? 1 : 0);
+        CPPF_CHECK_LAUNCH();
+    }
+    if (want_argmax && (out_idx || out_val)) {
+        hipLaunchKernelGGL(unpack_argmax_kernel, dim3(1), dim3(1), 0, st, packed, out_idx, out_val);
+        CPPF_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+extern "C" int cppf_ppf_voting(const float* points, const float* outputs, const float* probs,
+                               const int32_t* point_idxs, float* grid_obj, const float* corner, float res,
+                               int64_t n_ppfs, int n_rots, int gx, int gy, int gz, int adaptive, void* workspace,
+                               size_t workspace_bytes, void* stream)
+{
+    return vote_impl(points, outputs, probs, point_idxs, grid_obj, corner, res, n_ppfs, n_rots, gx, gy, gz,
+                     adaptive, false, nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int cppf_vote_argmax(const float* points, const float* outputs, const float* probs,
+                                const int32_t* point_idxs, float* grid_obj, const float* corner, float res,
+                                int64_t n_ppfs, int n_rots, int gx, int gy, int gz, int adaptive,
+                                long long* out_idx, float* out_val, void* workspace, size_t workspace_bytes,
+                                void* stream)
+{
+    return vote_impl(points, outputs, probs, point_idxs, grid_obj, corner, res, n_ppfs, n_rots, gx, gy, gz,
+                     adaptive, true, out_idx, out_val, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int cppf_grid_argmax(const float* grid, int64_t n, long long* out_idx, float* out_val, void* stream)
+{
+    if (!grid || n < 1 || n > 0x7fffffffll || !out_idx) return CPPF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    // out_idx doubles as the 8-byte packed scratch
+    unsigned long long* packed = reinterpret_cast<unsigned long long*>(out_idx);
+    hipLaunchKernelGGL(zero_u64_kernel, dim3(1), dim3(1), 0, st, packed);
+    int64_t nb = (n + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(reduce_argmax_kernel, dim3((unsigned)nb), dim3(256), 0, st, const_cast<float*>(grid),
+                       (const float*)nullptr, 0, n, packed, 0);
+    hipLaunchKernelGGL(unpack_argmax_kernel, dim3(1), dim3(1), 0, st, packed, out_idx, out_val);
+    CPPF_CHECK_LAUNCH();
+    return 0;
+}
+
+// nocs/inference.py:209-210: cand = unravel_index(argmax); T = corners[0] + cand * res in fp64;
+// T32 is the float32 copy handed to backvote (:225).
+__global__ void center_from_argmax_kernel(const long long* __restrict__ idx, const float* __restrict__ corner, double res,
+                                          int gy, int gz, double* __restrict__ T64, float* __restrict__ T32)
+{
+    const long long flat = *idx;
+    const long long syz = (long long)gy * gz;
+    const long long c[3] = {flat / syz, (flat % syz) / gz, (flat % syz) % gz};
+    const int j = threadIdx.x;
+    if (j < 3) {
+        const double t = (double)corner[j] + (double)c[j] * res;
+        if (T64) T64[j] = t;
+        if (T32) T32[j] = (float)t;
+    }
+}
+
+extern "C" int cppf_center_from_argmax(const long long* idx, const float* corner, double res, int gy, int gz,
+                                       double* T64, float* T32, void* stream)
+{
+    if (!idx || !corner || gy < 1 || gz < 1) return CPPF_EINVAL;
+    hipLaunchKernelGGL(center_from_argmax_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, idx, corner, res, gy, gz,
+                       T64, T32);
+    CPPF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ----------------------------------------------------------------------------- back-vote
+// Reference: CUDA backvote, models/voting.py:74-112 (always adaptive, bounds [0, dim-1)).
+// The reference's 13-argument shape has no workspace, so each (persistent, grid-stride) block
+// builds the (cos,sin) table for every n <= n_rots in LDS when it fits.
+__global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__ points,
+                                                              const float* __restrict__ outputs,
+                                                              float* __restrict__ out_offsets,
+                                                              const int32_t* __restrict__ point_idxs,
+                                                              const float* __restrict__ corner, float res, int64_t n_ppfs,
+                                                              int n_rots, int gx, int gy, int gz,
+                                                              const float* __restrict__ gt_center, float tol,
+                                                              uint8_t* __restrict__ mask)
+{
+    // (cos,sin) table for every n <= n_rots, built per block in LDS when it fits.
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float2* ltab = reinterpret_cast<float2*>(lds);
+    const int entries = n_rots * (n_rots + 1) / 2;
+    const bool in_lds = entries <= VOTE_TAB_LDS_MAX;
+    if (in_lds) {
+        // rows are found by walking n; each thread fills a strided subset of the triangular table
+        for (int e = threadIdx.x; e < entries; e += blockDim.x) {
+            int n = (int)((sqrtf(8.f * (float)e + 1.f) + 1.f) * 0.5f);
+            while (n * (n - 1) / 2 > e) --n;
+            while ((n + 1) * n / 2 <= e) ++n;
+            ltab[e] = rot_cs(e - n * (n - 1) / 2, n);
+        }
+        __syncthreads();
+    }
+    const f3 cr = {corner[0], corner[1], corner[2]};
+    const f3 gt = {gt_center[0], gt_center[1], gt_center[2]};
+    const float bx = (float)(gx - 1), by = (float)(gy - 1), bz = (float)(gz - 1);
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_ppfs;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const float2 o = reinterpret_cast<const float2*>(outputs)[idx];
+        const int2 ij = reinterpret_cast<const int2*>(point_idxs)[idx];
+        float* oo = out_offsets + 3 * idx;
+        f3 a, ab, xd;
+        f3 found = {oo[0], oo[1], oo[2]};  // degenerate pairs keep the caller's value (:87 returns early)
+        if (pair_frame(points, ij.x, ij.y, a, ab, xd)) {
+            const float proj_len = o.x, odist = o.y;
+            const f3 cc = sub3(a, scl3(ab, proj_len));
+            const f3 x = scl3(xd, odist);
+            const f3 y = cross3(x, ab);
+            found = {0.f, 0.f, 0.f};                                                   // :96
+            const int n = min((int)((double)(odist / res) * (2 * CPPF_PI)), n_rots);  // :97
+            const int tbase = n * (n - 1) / 2;
+            for (int i = 0; i < n; ++i) {
+                const float2 cs = in_lds ? ltab[tbase + i] : rot_cs(i, n);
+                const f3 offset = add3(scl3(x, cs.x), scl3(y, cs.y));
+                const f3 pc = add3(cc, offset);
+                if (len3(sub3(pc, gt)) > tol) continue;                               // :101
+                const f3 g = div3(sub3(pc, cr), res);
+                if (g.x < 0.f || g.y < 0.f || g.z < 0.f || g.x >= bx || g.y >= by || g.z >= bz) continue;  // :103-107
+                found = neg3(offset);                                                  // :108
+                break;
+            }
+            oo[0] = found.x; oo[1] = found.y; oo[2] = found.z;
+        }
+        if (mask) mask[idx] = (found.x != 0.f) || (found.y != 0.f) || (found.z != 0.f);
+    }
+}
+
+extern "C" int cppf_backvote(const float* points, const float* outputs, float* out_offsets,
+                             const int32_t* point_idxs, const float* corner, float res, int64_t n_ppfs, int n_rots,
+                             int gx, int gy, int gz, const float* gt_center, float tol, uint8_t* mask, void* stream)
+{
+    if (!points || !outputs || !out_offsets || !point_idxs || !corner || !gt_center) return CPPF_EINVAL;
+    if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || n_ppfs < 0) return CPPF_EINVAL;
+    if (n_ppfs == 0) return 0;
+    const int entries = tri(n_rots);
+    const size_t lds = entries <= VOTE_TAB_LDS_MAX ? (size_t)entries * sizeof(float2) : 0;
+    int64_t nb = (n_ppfs + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(backvote_kernel, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, points,
+                       outputs, out_offsets, point_idxs, corner, res, n_ppfs, n_rots, gx, gy, gz, gt_center, tol,
+                       mask);
+    CPPF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ----------------------------------------------------------------------------- compaction
+// surv = nonzero(mask) in increasing order (point_idxs[mask], nocs/inference.py:231).
+// Three small kernels: per-block counts, one-block scan of the counts, scatter.
+#define CMP_BLOCK 1024
+__global__ __launch_bounds__(CMP_BLOCK) void compact_count_kernel(const uint8_t* __restrict__ mask, int64_t n,
+                                                                   int32_t* __restrict__ block_counts)
+{
+    __shared__ int wsum[CMP_BLOCK / 64];
+    const int64_t i = (int64_t)blockIdx.x * CMP_BLOCK + threadIdx.x;
+    const bool f = i < n && mask[i] != 0;
+    const unsigned long long b = __ballot(f);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int w = 0; w < CMP_BLOCK / 64; ++w) s += wsum[w];
+        block_counts[blockIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(1024) void compact_scan_kernel(int32_t* __restrict__ block_counts, int64_t nblocks,
+                                                            int32_t* __restrict__ total)
+{
+    // exclusive scan in place, 1024 entries per sweep with a running carry
+    __shared__ int buf[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nblocks; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const int v = i < nblocks ? block_counts[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            int t = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const int incl = buf[threadIdx.x];
+        const int c = carry;
+        if (i < nblocks) block_counts[i] = c + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(CMP_BLOCK) void compact_scatter_kernel(const uint8_t* __restrict__ mask, int64_t n,
+                                                                     const int32_t* __restrict__ block_offs,
+                                                                     int32_t* __restrict__ surv)
+{
+    __shared__ int wsum[CMP_BLOCK / 64];
+    const int64_t i = (int64_t)blockIdx.x * CMP_BLOCK + threadIdx.x;
+    const bool f = i < n && mask[i] != 0;
+    const unsigned long long b = __ballot(f);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) wsum[w] = __popcll(b);
+    __syncthreads();
+    int woff = 0;
+    for (int k = 0; k < w; ++k) woff += wsum[k];
+    if (f) {
+        const int rank = __popcll(b & ((1ull << lane) - 1ull));
+        surv[block_offs[blockIdx.x] + woff + rank] = (int32_t)i;
+    }
+}
+
+extern "C" size_t cppf_compact_workspace_bytes(int64_t n)
+{
+    if (n < 0) return 0;
+    return align_up((size_t)((n + CMP_BLOCK - 1) / CMP_BLOCK + 1) * sizeof(int32_t), 256);
+}
+
+extern "C" int cppf_compact_mask(const uint8_t* mask, int64_t n, int32_t* surv, int32_t* count, void* workspace,
+                                 size_t workspace_bytes, void* stream)
+{
+    if (!mask || !surv || !count || n < 0 || n > 0x7fffffffll) return CPPF_EINVAL;
+    if (!workspace || workspace_bytes < cppf_compact_workspace_bytes(n)) return CPPF_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int32_t* bc = static_cast<int32_t*>(workspace);
+    const int64_t nb = (n + CMP_BLOCK - 1) / CMP_BLOCK;
+    if (nb > 0) {
+        hipLaunchKernelGGL(compact_count_kernel, dim3((unsigned)nb), dim3(CMP_BLOCK), 0, st, mask, n, bc);
+        CPPF_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, st, bc, nb, count);
+    CPPF_CHECK_LAUNCH();
+    if (nb > 0) {
+        hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)nb), dim3(CMP_BLOCK), 0, st, mask, n, bc, surv);
+        CPPF_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+// ----------------------------------------------------------------------------- orientation vote
+// Reference: CUDA rot_voting, models/voting.py:119-147.  A block takes ROT_PPB pairs: their frames
+// are computed once into LDS, then the (pair, rotation) items are spread over the lanes so that the
+// 12-byte candidates of consecutive lanes are consecutive in memory.
+#define ROT_PPB 32
+struct RotFrame { f3 x, y, base; float t; int ok; int pad; };  // 48 B: keeps the dynamic LDS base 16-B aligned
+
+__device__ __forceinline__ RotFrame rot_frame(const float* __restrict__ points, int ia, int ib, float rot)
+{
+    RotFrame fr;
+    f3 a, ab, xd;
+    fr.ok = pair_frame(points, ia, ib, a, ab, xd);
+    if (fr.ok) {
+        fr.x = xd;
+        fr.y = cross3(xd, ab);                 // :135
+        fr.t = det_tanf(rot);
+        fr.base = fr.t > 0.f ? ab : neg3(ab);  // :142
+    }
+    return fr;
+}
+__device__ __forceinline__ f3 rot_candidate(const RotFrame& fr, float2 cs)
+{
+    const f3 offset = add3(scl3(fr.x, cs.x), scl3(fr.y, cs.y));                  // :141
+    f3 up = add3(scl3(offset, fr.t), fr.base);                                     // :142
+    return div3(up, (float)((double)len3(up) + 1e-7));                            // :143
+}
+
+__global__ __launch_bounds__(256) void rot_voting_kernel(const float* __restrict__ points,
+                                                         const float* __restrict__ preds_rot,
+                                                         float* __restrict__ outputs_up,
+                                                         const int32_t* __restrict__ point_idxs, int64_t n_ppfs,
+                                                         int n_rots)
+{
+    __shared__ RotFrame frames[ROT_PPB];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float2* row = reinterpret_cast<float2*>(lds);  // (cos,sin) of the n_rots rotations
+    const int64_t p0 = (int64_t)blockIdx.x * ROT_PPB;
+    const int np = (int)min((int64_t)ROT_PPB, n_ppfs - p0);
+    for (int i = threadIdx.x; i < n_rots; i += blockDim.x) row[i] = rot_cs(i, n_rots);
+    if ((int)threadIdx.x < np) {
+        const int2 ij = reinterpret_cast<const int2*>(point_idxs)[p0 + threadIdx.x];
+        frames[threadIdx.x] = rot_frame(points, ij.x, ij.y, preds_rot[p0 + threadIdx.x]);
+    }
+    __syncthreads();
+    const int items = np * n_rots;
+    float* out = outputs_up + p0 * n_rots * 3;
+    for (int k = threadIdx.x; k < items; k += blockDim.x) {
+        const int pl = k / n_rots, i = k - pl * n_rots;
+        if (!frames[pl].ok) continue;  // caller's zeros stay (:131)
+        const f3 up = rot_candidate(frames[pl], row[i]);
+        out[3 * k] = up.x; out[3 * k + 1] = up.y; out[3 * k + 2] = up.z;
+    }
+}
+
+extern "C" int cppf_rot_voting(const float* points, const float* preds_rot, float* outputs_up,
+                               const int32_t* point_idxs, int64_t n_ppfs, int n_rots, void* stream)
+{
+    if (!points || !preds_rot || !outputs_up || !point_idxs) return CPPF_EINVAL;
+    if (n_rots < 1 || n_rots > 4096 || n_ppfs < 0) return CPPF_EINVAL;
+    if (n_ppfs == 0) return 0;
+    const int64_t nb = (n_ppfs + ROT_PPB - 1) / ROT_PPB;
+    hipLaunchKernelGGL(rot_voting_kernel, dim3((unsigned)nb), dim3(256), (size_t)n_rots * sizeof(float2),
+                       (hipStream_t)stream, points, preds_rot, outputs_up, point_idxs, n_ppfs, n_rots);
+    CPPF_CHECK_LAUNCH();
+    return 0;
+}
+
+// Fused rot_voting + sphere count (nocs/inference.py:265-284): candidates of SPH_PPB pairs go to
+// LDS, then every lane owns sphere bins and sweeps the block's candidates (broadcast LDS reads),
+// cos = fma(c.z,s.z, fma(c.y,s.y, c.x*s.x)) > thr.  Integer atomics: deterministic counts.
+#define SPH_PPB 16
+#define SPH_THREADS 512
+__global__ __launch_bounds__(SPH_THREADS) void rot_sphere_kernel(const float* __restrict__ points,
+                                                                 const float* __restrict__ preds_rot, int rot_stride,
+                                                                 const int32_t* __restrict__ point_idxs,
+                                                                 const int32_t* __restrict__ sel,
+                                                                 const int32_t* __restrict__ n_sel_dev,
+                                                                 int64_t n_sel_host, int64_t max_pairs, int n_rots,
+                                                                 const float* __restrict__ sphere, int n_sphere,
+                                                                 float thr, int32_t* __restrict__ counts)
+{
+    __shared__ RotFrame frames[SPH_PPB];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float4* cand = reinterpret_cast<float4*>(lds);                       // [SPH_PPB*n_rots]
+    float2* row = reinterpret_cast<float2*>(lds + 4 * SPH_PPB * n_rots);  // [n_rots]
+    int64_t n_sel = n_sel_dev ? (int64_t)*n_sel_dev : n_sel_host;
+    if (n_sel > max_pairs) n_sel = max_pairs;
+    const int64_t k0 = (int64_t)blockIdx.x * SPH_PPB;
+    if (k0 >= n_sel) return;
+    const int np = (int)min((int64_t)SPH_PPB, n_sel - k0);
+    for (int i = threadIdx.x; i < n_rots; i += SPH_THREADS) row[i] = rot_cs(i, n_rots);
+    if ((int)threadIdx.x < np) {
+        const int p = sel ? sel[k0 + threadIdx.x] : (int)(k0 + threadIdx.x);
+        const int2 ij = reinterpret_cast<const int2*>(point_idxs)[p];
+        frames[threadIdx.x] = rot_frame(points, ij.x, ij.y, preds_rot[(int64_t)p * rot_stride]);
+    }
+    __syncthreads();
+    const int items = np * n_rots;
+    for (int k = threadIdx.x; k < items; k += SPH_THREADS) {
+        const int pl = k / n_rots, i = k - pl * n_rots;
+        f3 up = {0.f, 0.f, 0.f};  // degenerate pair: the reference leaves zeros, which still count if thr < 0
+        if (frames[pl].ok) up = rot_candidate(frames[pl], row[i]);
+        cand[k] = make_float4(up.x, up.y, up.z, 0.f);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < n_sphere; j += SPH_THREADS) {
+        const float sx = sphere[3 * j], sy = sphere[3 * j + 1], sz = sphere[3 * j + 2];
+        int cnt = 0;
+        for (int k = 0; k < items; ++k) {
+            const float4 c = cand[k];
+            const float d = fmaf(c.z, sz, fmaf(c.y, sy, c.x * sx));
+            cnt += d > thr;
+        }
+        if (cnt) atomicAdd(&counts[j], cnt);
+    }
+}
+
+extern "C" int cppf_rot_sphere_count(const float* points, const float* preds_rot, int rot_stride,
+                                     const int32_t* point_idxs, const int32_t* sel, const int32_t* n_sel_dev,
+                                     int64_t n_sel_host, int64_t max_pairs, int n_rots, const float* sphere,
+                                     int n_sphere, float thr, int32_t* counts, void* stream)
+{
+    if (!points || !preds_rot || !point_idxs || !sphere || !counts) return CPPF_EINVAL;
+    if (n_rots < 1 || n_rots > 512 || n_sphere < 1 || max_pairs < 0 || n_sel_host < 0 || rot_stride < 1)
+        return CPPF_EINVAL;
+    int64_t bound = n_sel_host < max_pairs ? n_sel_host : max_pairs;
+    if (bound == 0) return 0;
+    const int64_t nb = (bound + SPH_PPB - 1) / SPH_PPB;
+    const size_t lds = (size_t)(4 * SPH_PPB * n_rots + 2 * n_rots) * sizeof(float);
+    hipLaunchKernelGGL(rot_sphere_kernel, dim3((unsigned)nb), dim3(SPH_THREADS), lds, (hipStream_t)stream, points,
+                       preds_rot, rot_stride, point_idxs, sel, n_sel_dev, n_sel_host, max_pairs, n_rots, sphere,
+                       n_sphere, thr, counts);
+    CPPF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ----------------------------------------------------------------------------- pose-tail reductions
+#define RED_BLOCKS 256
+#define RED_THREADS 256
+extern "C" size_t cppf_reduce_workspace_bytes(void) { return (size_t)RED_BLOCKS * 4 * sizeof(double); }
+
+__device__ __forceinline__ double block_sum(double v, double* sh)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int w = 0; w < RED_THREADS / 64; ++w) s += sh[w];
+    return s;
+}
+
+// nocs/inference.py:287-301
+__global__ __launch_bounds__(RED_THREADS) void axis_sign_kernel(const float* __restrict__ pc,
+                                                                const float* __restrict__ nrm,
+                                                                const int32_t* __restrict__ point_idxs,
+                                                                const int32_t* __restrict__ sel,
+                                                                const int32_t* __restrict__ n_sel_dev, int64_t n_sel_host,
+                                                                const float* __restrict__ aux, int aux_stride,
+                                                                const double* __restrict__ best_dir,
+                                                                double* __restrict__ partial)
+{
+    __shared__ double sh[RED_THREADS / 64];
+    const int64_t n_sel = n_sel_dev ? (int64_t)*n_sel_dev : n_sel_host;
+    const double bx = best_dir[0], by = best_dir[1], bz = best_dir[2];
+    double up = 0.0, down = 0.0;
+    for (int64_t k = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x; k < n_sel; k += (int64_t)RED_BLOCKS * RED_THREADS) {
+        const int p = sel ? sel[k] : (int)k;
+        const int2 ij = reinterpret_cast<const int2*>(point_idxs)[p];
+        const f3 ab = sub3(ld3(pc, ij.x), ld3(pc, ij.y));
+        const float distsq = (ab.x * ab.x + ab.y * ab.y) + ab.z * ab.z;
+        const float den = sqrtf(distsq) + 1e-7f;
+        const f3 abn = {ab.x / den, ab.y / den, ab.z / den};
+        f3 n = ld3(nrm, ij.x);
+        const float d = (n.x * abn.x + n.y * abn.y) + n.z * abn.z;
+        if (d < 0.f) n = neg3(n);
+        const double proj = ((double)n.x * bx + (double)n.y * by) + (double)n.z * bz;
+        const double t = proj > 0.0 ? 1.0 : 0.0;
+        const double x = (double)aux[(int64_t)p * aux_stride];
+        const double sp = (x > 0.0 ? x : 0.0) + log1p(exp(-fabs(x)));
+        up += sp - x * t;
+        down += sp - x * (1.0 - t);
+    }
+    const double su = block_sum(up, sh);
+    const double sd = block_sum(down, sh);
+    if (threadIdx.x == 0) {
+        partial[4 * blockIdx.x] = su;
+        partial[4 * blockIdx.x + 1] = sd;
+    }
+}
+
+// nocs/inference.py:335 (sums; the caller finishes exp(mean)*scale_mean*2)
+__global__ __launch_bounds__(RED_THREADS) void scale_sum_kernel(const float* __restrict__ scale_logits, int stride,
+                                                                const int32_t* __restrict__ sel,
+                                                                const int32_t* __restrict__ n_sel_dev, int64_t n_sel_host,
+                                                                double* __restrict__ partial)
+{
+    __shared__ double sh[RED_THREADS / 64];
+    const int64_t n_sel = n_sel_dev ? (int64_t)*n_sel_dev : n_sel_host;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int64_t k = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x; k < n_sel; k += (int64_t)RED_BLOCKS * RED_THREADS) {
+        const int64_t p = sel ? sel[k] : k;
+        const float* s = scale_logits + p * stride;
+        s0 += (double)s[0]; s1 += (double)s[1]; s2 += (double)s[2];
+    }
+    const double a = block_sum(s0, sh), b = block_sum(s1, sh), c = block_sum(s2, sh);
+    if (threadIdx.x == 0) {
+        partial[4 * blockIdx.x] = a;
+        partial[4 * blockIdx.x + 1] = b;
+        partial[4 * blockIdx.x + 2] = c;
+    }
+}
+
+__global__ void reduce_final_kernel(const double* __restrict__ partial, int ncomp, const int32_t* n_sel_dev,
+                                    int64_t n_sel_host, double* __restrict__ out)
+{
+    if (threadIdx.x < ncomp) {
+        double s = 0.0;
+        for (int b = 0; b < RED_BLOCKS; ++b) s += partial[4 * b + threadIdx.x];
+        out[threadIdx.x] = s;
+    }
+    if (threadIdx.x == 0) out[ncomp] = (double)(n_sel_dev ? (int64_t)*n_sel_dev : n_sel_host);
+}
+
+extern "C" int cppf_axis_sign(const float* pc, const float* nrm, const int32_t* point_idxs, const int32_t* sel,
+                              const int32_t* n_sel_dev, int64_t n_sel_host, const float* aux, int aux_stride,
+                              const double* best_dir, double* out, void* workspace, size_t workspace_bytes,
+                              void* stream)
+{
+    if (!pc || !nrm || !point_idxs || !aux || !best_dir || !out || aux_stride < 1 || n_sel_host < 0) return CPPF_EINVAL;
+    if (!workspace || workspace_bytes < cppf_reduce_workspace_bytes()) return CPPF_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    double* partial = static_cast<double*>(workspace);
+    hipLaunchKernelGGL(axis_sign_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, pc, nrm, point_idxs, sel,
+                       n_sel_dev, n_sel_host, aux, aux_stride, best_dir, partial);
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(64), 0, st, partial, 2, n_sel_dev, n_sel_host, out);
+    CPPF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cppf_scale_sum(const float* scale_logits, int stride, const int32_t* sel, const int32_t* n_sel_dev,
+                              int64_t n_sel_host, double* out, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!scale_logits || !out || stride < 3 || n_sel_host < 0) return CPPF_EINVAL;
+    if (!workspace || workspace_bytes < cppf_reduce_workspace_bytes()) return CPPF_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    double* partial = static_cast<double*>(workspace);
+    hipLaunchKernelGGL(scale_sum_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, scale_logits, stride, sel,
+                       n_sel_dev, n_sel_host, partial);
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(64), 0, st, partial, 3, n_sel_dev, n_sel_host, out);
+    CPPF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ----------------------------------------------------------------------------- grid setup
+// nocs/inference.py:194-195: corners = [min(pc), max(pc)]; grid_res = int32((max-min)/res) + 1
+__global__ __launch_bounds__(1024) void grid_setup_kernel(const float* __restrict__ pc, int64_t N, float res,
+                                                          float* __restrict__ corner, int32_t* __restrict__ dims)
+{
+    __shared__ float slo[16][3], shi[16][3];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = threadIdx.x; i < N; i += 1024)
+        for (int j = 0; j < 3; ++j) {
+            const float v = pc[3 * i + j];
+            lo[j] = fminf(lo[j], v);
+            hi[j] = fmaxf(hi[j], v);
+        }
+    for (int j = 0; j < 3; ++j)
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[j] = fminf(lo[j], __shfl_xor(lo[j], off, 64));
+            hi[j] = fmaxf(hi[j], __shfl_xor(hi[j], off, 64));
+        }
+    if ((threadIdx.x & 63) == 0)
+        for (int j = 0; j < 3; ++j) { slo[threadIdx.x >> 6][j] = lo[j]; shi[threadIdx.x >> 6][j] = hi[j]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int j = threadIdx.x;
+        float l = slo[0][j], h = shi[0][j];
+        for (int w = 1; w < 16; ++w) { l = fminf(l, slo[w][j]); h = fmaxf(h, shi[w][j]); }
+        corner[j] = l;
+        dims[j] = (int32_t)((h - l) / res) + 1;
+    }
+}
+
+extern "C" int cppf_grid_setup(const float* pc, int64_t N, float res, float* corner, int32_t* dims, void* stream)
+{
+    if (!pc || !corner || !dims || N < 1) return CPPF_EINVAL;
+    hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pc, N, res, corner, dims);
+    CPPF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cppf_abi_version(void) { return CPPF_ABI_VERSION; }
+extern "C" const char* cppf_error_string(int code)
+{
+    switch (code) {
+    case 0: return "success";
+    case CPPF_EINVAL: return "cppf: invalid argument";
+    case CPPF_EWORKSPACE: return "cppf: workspace missing or too small";
+    case CPPF_EUNSUPPORTED: return "cppf: unsupported layer shape";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "cppf: unknown error";
+    }
+}

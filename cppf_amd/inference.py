@@ -1,0 +1,187 @@
+"""Device-resident counterpart of the per-instance hot section of the reference's inference script
+(nocs/inference.py:177-335; the same lines are duplicated at sunrgbd/inference.py:136-241).
+
+The reference bounces every stage through the host (torch -> numpy -> CuPy and back, :191-231,
+:265-284).  Here the whole chain is enqueued on one HIP stream and the host reads back ONE small
+record at the end:
+
+  PPF + pair MLP + decode      PPFEncoder.forward_decode            (:182-188, :236-256)
+  centre vote + arg-max        cppf_vote_argmax                     (:191-208)
+  T = corner + cand * res      cppf_center_from_argmax              (:209-213)
+  back-vote + compaction       cppf_backvote / cppf_compact_mask    (:216-231)
+  orientation vote + count     cppf_rot_sphere_count, arg-max       (:259-284)
+  axis sign                    cppf_axis_sign                       (:286-303)
+  scale                        cppf_scale_sum                       (:335)
+
+Stochastic pieces of the reference are made explicit inputs: `u_tr`/`u_rot` (uniforms replacing
+torch.multinomial at :186/:250/:254, indexed by ORIGINAL pair -- the second MLP pass of :236 only
+recomputes rows the first pass already produced, so it is replaced by a gather), and the random
+10 000-pair subset of :277-280 is the first `max_rot_pairs` survivors in pair order (pairs are
+i.i.d. uniform, so a prefix is distributed exactly like a shuffled subset).
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._torch_util import require_cuda, stream_ptr, workspace
+from .models import voting
+
+F32, I32 = torch.float32, torch.int32
+
+
+def grid_shape(pc_host, res):
+    """nocs/inference.py:194-195 on the host copy of the cloud: corners, int32((max-min)/res)+1."""
+    pc_host = np.asarray(pc_host, dtype=np.float32)
+    corners = np.stack([np.min(pc_host, 0), np.max(pc_host, 0)])
+    grid_res = ((corners[1] - corners[0]) / np.float32(res)).astype(np.int32) + 1
+    return corners, tuple(int(v) for v in grid_res)
+
+
+class PoseWorkspace:
+    """Per-object device buffers, allocated once and reused across calls of the same size."""
+
+    def __init__(self, device, n_pairs, dims, n_sphere):
+        self.device, self.n_pairs, self.dims, self.n_sphere = device, n_pairs, tuple(dims), n_sphere
+        self.grid = torch.empty(self.dims, dtype=F32, device=device)
+        self.out_idx = torch.empty(1, dtype=torch.int64, device=device)
+        self.out_val = torch.empty(1, dtype=F32, device=device)
+        self.T64 = torch.empty(3, dtype=torch.float64, device=device)
+        self.T32 = torch.empty(3, dtype=F32, device=device)
+        self.offsets = torch.empty((n_pairs, 3), dtype=F32, device=device)
+        self.mask = torch.empty(n_pairs, dtype=torch.uint8, device=device)
+        self.surv = torch.empty(n_pairs, dtype=I32, device=device)
+        self.count = torch.empty(1, dtype=I32, device=device)
+        self.counts = torch.empty((2, n_sphere), dtype=I32, device=device)
+        self.countsf = torch.empty((2, n_sphere), dtype=F32, device=device)
+        self.best_idx = torch.empty(2, dtype=torch.int64, device=device)
+        self.best_dir = torch.empty((2, 3), dtype=torch.float64, device=device)
+        self.sign = torch.empty((2, 3), dtype=torch.float64, device=device)
+        self.scale = torch.empty(4, dtype=torch.float64, device=device)
+        self.probs = None
+
+
+def estimate_center(encoder, pc, pc_normal, feat, point_idxs, u_tr, cfg, corner, dims, num_rots=72, adaptive=True,
+                    u_rot=None, ws=None, idx32=None, probs=None):
+    """PPF -> MLP -> decode -> centre vote -> arg-max, all on device (the benchmarked chain).
+    Returns (out_idx i64[1], out_val f32[1], outputs f32[P,2], heads f32[P,8] | None, grid)."""
+    require_cuda()
+    dev = pc.device
+    P = point_idxs.shape[0]
+    if ws is None:
+        ws = PoseWorkspace(dev, P, dims, 1)
+    if idx32 is None:
+        idx32 = point_idxs.to(I32)
+    if probs is None:
+        if ws.probs is None or ws.probs.numel() != pc.shape[0]:
+            ws.probs = torch.ones(pc.shape[0], dtype=F32, device=dev)   # nocs/inference.py:201
+        probs = ws.probs
+    outputs, heads = encoder.forward_decode(pc, pc_normal, feat, point_idxs, u_tr, cfg.vote_range, u_rot,
+                                            cfg.tr_num_bins, cfg.rot_num_bins)
+    ws.grid.zero_()                                                        # :196
+    voting.vote_argmax(pc, outputs, probs, idx32, ws.grid, corner, cfg.res, num_rots, adaptive, ws.out_idx,
+                       ws.out_val)
+    return ws.out_idx, ws.out_val, outputs, heads, ws.grid
+
+
+def estimate_pose(encoder, pc, pc_normal, feat, point_idxs, u_tr, u_rot, cfg, sphere_pts, pc_host=None, num_rots=72,
+                  adaptive=True, angle_tol=1.5, max_rot_pairs=10000, ws=None, rng=None):
+    """Full per-instance pose (nocs/inference.py:177-339 minus dataset I/O and the laptop segmenter).
+
+    encoder: cppf_amd.models.model.PPFEncoder on `pc.device`, eval mode.
+    pc, pc_normal f32[N,3], feat f32[N,F], point_idxs i64/i32[P,2], u_tr/u_rot f32[P,2]: device tensors.
+    sphere_pts: fp64 array [S,3] (np.array(fibonacci_sphere(S)), :100-102).
+    Returns a dict of host values: T f64[3], up/right f64[3], R f64[3,3], scale f64[3], scale_norm,
+    argmax (flat grid index), peak, n_surv, counts_up/right (i32[S])."""
+    require_cuda()
+    dev = pc.device
+    L = _lib.lib()
+    st = stream_ptr(dev)
+    P = point_idxs.shape[0]
+    if pc_host is None:
+        pc_host = pc.detach().cpu().numpy()
+    corners, dims = grid_shape(pc_host, cfg.res)                              # :194-195
+    corner = torch.from_numpy(corners[0].copy()).to(dev)
+    sph64 = np.asarray(sphere_pts, dtype=np.float64)
+    S = sph64.shape[0]
+    if ws is None or ws.n_pairs != P or ws.dims != dims or ws.n_sphere != S or ws.device != dev:
+        ws = PoseWorkspace(dev, P, dims, S)
+    sph32_d = torch.from_numpy(sph64.astype(np.float32)).to(dev)              # :276
+    sph64_d = torch.from_numpy(sph64).to(dev)
+    idx32 = point_idxs.to(I32)
+
+    # centre ------------------------------------------------------------------------------------------
+    _, _, outputs, heads, _ = estimate_center(encoder, pc, pc_normal, feat, point_idxs, u_tr, cfg, corner, dims,
+                                              num_rots, adaptive, u_rot, ws, idx32)
+    with torch.cuda.device(dev):
+        _lib.check(L.cppf_center_from_argmax(ws.out_idx.data_ptr(), corner.data_ptr(), float(cfg.res), dims[1],
+                                             dims[2], ws.T64.data_ptr(), ws.T32.data_ptr(), st),
+                   "cppf_center_from_argmax")
+        # back-vote filter (:216-231) --------------------------------------------------------------
+        ws.offsets.zero_()                                                    # :220
+        _lib.check(L.cppf_backvote(pc.data_ptr(), outputs.data_ptr(), ws.offsets.data_ptr(), idx32.data_ptr(),
+                                   corner.data_ptr(), float(cfg.res), P, num_rots, dims[0], dims[1], dims[2],
+                                   ws.T32.data_ptr(), float(np.float32(3 * cfg.res)), ws.mask.data_ptr(), st),
+                   "cppf_backvote")
+        cws = workspace(L.cppf_compact_workspace_bytes(P), dev, "compact")
+        _lib.check(L.cppf_compact_mask(ws.mask.data_ptr(), P, ws.surv.data_ptr(), ws.count.data_ptr(),
+                                       cws.data_ptr(), cws.numel(), st), "cppf_compact_mask")
+        # orientation (:259-303) -------------------------------------------------------------------
+        thr = float(np.float32(np.cos(angle_tol / 180 * np.pi)))
+        n_dirs = 2 if cfg.regress_right else 1
+        ws.counts.zero_()
+        rws = workspace(L.cppf_reduce_workspace_bytes(), dev, "reduce")
+        for j in range(n_dirs):
+            _lib.check(L.cppf_rot_sphere_count(pc.data_ptr(), heads.data_ptr() + 4 * j, 8, idx32.data_ptr(),
+                                               ws.surv.data_ptr(), ws.count.data_ptr(), P, max_rot_pairs, num_rots,
+                                               sph32_d.data_ptr(), S, thr, ws.counts[j].data_ptr(), st),
+                       "cppf_rot_sphere_count")
+            ws.countsf[j].copy_(ws.counts[j])                                 # exact: counts < 2**24
+            _lib.check(L.cppf_grid_argmax(ws.countsf[j].data_ptr(), S, ws.best_idx[j:].data_ptr(), None, st),
+                       "cppf_grid_argmax")                                    # np.argmax(counts), :283
+            torch.index_select(sph64_d, 0, ws.best_idx[j:j + 1], out=ws.best_dir[j:j + 1])
+            _lib.check(L.cppf_axis_sign(pc.data_ptr(), pc_normal.data_ptr(), idx32.data_ptr(), ws.surv.data_ptr(),
+                                        ws.count.data_ptr(), P, heads.data_ptr() + 4 * (2 + j), 8,
+                                        ws.best_dir[j].data_ptr(), ws.sign[j].data_ptr(), rws.data_ptr(),
+                                        rws.numel(), st), "cppf_axis_sign")
+        # scale (:335) -----------------------------------------------------------------------------
+        _lib.check(L.cppf_scale_sum(heads.data_ptr() + 4 * 4, 8, ws.surv.data_ptr(), ws.count.data_ptr(), P,
+                                    ws.scale.data_ptr(), rws.data_ptr(), rws.numel(), st), "cppf_scale_sum")
+
+    # one read-back ---------------------------------------------------------------------------------
+    rec = torch.cat([ws.T64, ws.best_dir.reshape(-1), ws.sign.reshape(-1), ws.scale, ws.out_idx.double(),
+                     ws.out_val.double()]).cpu().numpy()
+    T = rec[0:3]
+    best = rec[3:9].reshape(2, 3)
+    sign = rec[9:15].reshape(2, 3)
+    ssum = rec[15:19]
+    flat, peak = int(rec[19]), float(rec[20])
+    n_surv = int(ssum[3])
+
+    dirs = []
+    for j in range(n_dirs):
+        n = max(sign[j, 2], 1.0)
+        up_loss, down_loss = sign[j, 0] / n, sign[j, 1] / n
+        dirs.append(-best[j] if down_loss < up_loss else best[j].copy())      # :299-302
+    up = dirs[0]
+    if cfg.regress_right:                                                     # :305-312
+        right = dirs[1]
+        right = right - np.dot(up, right) * up
+        right = right / (np.linalg.norm(right) + 1e-9)
+    else:
+        right = np.array([0, -up[2], up[1]])
+        right = right / (np.linalg.norm(right) + 1e-9)
+    if np.linalg.norm(right) < 1e-7:                                          # :325-328
+        rng = rng or np.random.default_rng(0)
+        right = rng.standard_normal(3)
+        right -= right.dot(up) * up
+        right /= np.linalg.norm(right)
+    if cfg.z_right:                                                           # :330-333
+        R = np.stack([np.cross(up, right), up, right], -1)
+    else:
+        R = np.stack([right, up, np.cross(right, up)], -1)
+    mean = (ssum[:3] / max(n_surv, 1)).astype(np.float32)                     # torch mean is fp32
+    pred_scale = np.exp(mean).astype(np.float64) * np.asarray(cfg.scale_mean, np.float64) * 2   # :335
+    scale_norm = float(np.linalg.norm(pred_scale))
+    return dict(T=T, up=up, right=right, R=R, scale=pred_scale, scale_norm=scale_norm, argmax=flat, peak=peak,
+                n_surv=n_surv, dims=dims, corner=corners[0], best_up=best[0], best_right=best[1] if n_dirs > 1 else None,
+                losses=sign, ws=ws, outputs=outputs, heads=heads)

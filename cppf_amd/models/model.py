@@ -1,0 +1,209 @@
+"""Drop-in for the pair-encoder half of the reference's models/model.py.
+
+`ResLayer` and `PPFEncoder` keep the reference's constructor signatures, parameter names and shapes
+(models/model.py:8-31, 80-87), so reference checkpoints load with `load_state_dict`
+(nocs/inference.py:88), and the same call signatures (models/model.py:89-91, 117):
+
+    PPFEncoder(ppffcs, out_dim)
+    .forward(pc[1,N,3], pc_normal[1,N,3], feat[1,N,F], dist=None, idxs=None) -> f32[1,P,out_dim]
+    .forward_with_idx(pc[N,3], pc_normal[N,3], feat[N,F], idxs[P,2])        -> f32[P,out_dim]
+
+Under `torch.no_grad()` (inference, nocs/inference.py:179-182) the whole of forward_with_idx -- PPF
+construction, gather/concat, three ResLayers and the final linear -- is one HIP kernel
+(csrc/pair_mlp.hip).  When autograd needs the graph (train.py:66,91) the same module evaluates the
+composite of torch ops instead; the HIP path has no backward yet.
+`PointEncoder` (SPRIN) is upstream of the hot path and not part of this package.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib
+from .._torch_util import require_cuda, stream_ptr
+
+__all__ = ["ResLayer", "PPFEncoder"]
+
+
+class ResLayer(nn.Module):
+    """models/model.py:8-31: fc1 -> relu -> fc2, plus fc0(x) (or x when dim_in == dim_out)."""
+
+    def __init__(self, dim_in, dim_out, bn=False):
+        super().__init__()
+        assert bn is False
+        self.fc1 = nn.Linear(dim_in, dim_out)
+        self.fc2 = nn.Linear(dim_out, dim_out)
+        self.fc0 = nn.Linear(dim_in, dim_out) if dim_in != dim_out else None
+
+    def forward(self, x):
+        x_res = x if self.fc0 is None else self.fc0(x)
+        return self.fc2(F.relu(self.fc1(x))) + x_res
+
+
+class PPFEncoder(nn.Module):
+    def __init__(self, ppffcs, out_dim):
+        super().__init__()
+        self.ppffcs = [int(d) for d in ppffcs]
+        self.out_dim = int(out_dim)
+        self.res_layers = nn.ModuleList(
+            ResLayer(self.ppffcs[i], self.ppffcs[i + 1]) for i in range(len(self.ppffcs) - 1))
+        self.final = nn.Linear(self.ppffcs[-1], self.out_dim)
+        self._packed = None
+        self._packed_key = None
+
+    # ------------------------------------------------------------------ reference signatures
+    def forward(self, pc, pc_normal, feat, dist=None, idxs=None):
+        if idxs is not None:                                   # models/model.py:90-91
+            return self.forward_with_idx(pc[0], pc_normal[0], feat[0], idxs)[None]
+        # Dense all-pairs branch (models/model.py:92-115; no caller in the reference): pair (i, j)
+        # for every i, j, evaluated through the same sampled-pair path.  `dist` is not needed: the
+        # pair kernel recomputes ||pc_i - pc_j|| itself.
+        if pc.dim() != 3 or pc.shape[0] != 1:
+            raise ValueError("dense forward supports batch size 1 (the reference asserts it, train.py:32)")
+        n = pc.shape[1]
+        ii, jj = torch.meshgrid(torch.arange(n, device=pc.device), torch.arange(n, device=pc.device), indexing="ij")
+        allp = torch.stack([ii.reshape(-1), jj.reshape(-1)], -1)
+        return self.forward_with_idx(pc[0], pc_normal[0], feat[0], allp).reshape(1, n, n, self.out_dim)
+
+    def forward_with_idx(self, pc, pc_normal, feat, idxs):
+        idxs = self._as_index_tensor(idxs, pc.device)
+        if self._needs_graph(feat):
+            return self._composite(pc, pc_normal, feat, idxs)
+        pc, pc_normal, feat = self._check_inputs(pc, pc_normal, feat)
+        P = idxs.shape[0]
+        out = torch.empty((P, self.out_dim), dtype=torch.float32, device=pc.device)
+        dims = (C.c_int * len(self.ppffcs))(*self.ppffcs)
+        with torch.cuda.device(pc.device):
+            rc = _lib.lib().cppf_pair_mlp_forward(
+                pc.data_ptr(), pc_normal.data_ptr(), feat.data_ptr(), idxs.data_ptr(),
+                1 if idxs.dtype == torch.int64 else 0, self._packed_weights(pc.device).data_ptr(), pc.shape[0],
+                feat.shape[1], dims, len(self.ppffcs) - 1, P, self.out_dim, out.data_ptr(), stream_ptr(pc.device))
+        _lib.check(rc, "cppf_pair_mlp_forward")
+        return out
+
+    # ------------------------------------------------------------------ fused decode (this package)
+    def forward_decode(self, pc, pc_normal, feat, idxs, u_tr, vote_range, u_rot=None, tr_num_bins=32,
+                       rot_num_bins=36):
+        """forward_with_idx fused with the decode of nocs/inference.py:185-188 (and :245-256 when
+        u_rot is given): returns (outputs f32[P,2] = (mu, nu), heads f32[P,8] or None) without ever
+        writing the [P,out_dim] logits.  u_* are uniforms in [0,1) standing in for torch.multinomial
+        (negative = arg-max bin)."""
+        idxs = self._as_index_tensor(idxs, pc.device)
+        pc, pc_normal, feat = self._check_inputs(pc, pc_normal, feat)
+        P = idxs.shape[0]
+        for nm, u in (("u_tr", u_tr), ("u_rot", u_rot)):
+            if u is not None and (u.dtype != torch.float32 or not u.is_contiguous() or tuple(u.shape) != (P, 2)
+                                  or u.device != pc.device):
+                raise ValueError(f"{nm} must be a contiguous f32[P,2] tensor on {pc.device}")
+        outputs = torch.empty((P, 2), dtype=torch.float32, device=pc.device)
+        heads = torch.empty((P, 8), dtype=torch.float32, device=pc.device) if u_rot is not None else None
+        dims = (C.c_int * len(self.ppffcs))(*self.ppffcs)
+        L = _lib.lib()
+        with torch.cuda.device(pc.device):
+            rc = L.cppf_pair_mlp_decode(
+                pc.data_ptr(), pc_normal.data_ptr(), feat.data_ptr(), idxs.data_ptr(),
+                1 if idxs.dtype == torch.int64 else 0, self._packed_weights(pc.device).data_ptr(), pc.shape[0],
+                feat.shape[1], dims, len(self.ppffcs) - 1, P, self.out_dim, tr_num_bins, rot_num_bins,
+                float(vote_range[0]), float(vote_range[1]), u_tr.data_ptr(),
+                u_rot.data_ptr() if u_rot is not None else None, outputs.data_ptr(),
+                heads.data_ptr() if heads is not None else None, stream_ptr(pc.device))
+            if rc == -3:  # architecture / bin counts outside the fused kernel: logits + decode kernels
+                logits = self.forward_with_idx(pc, pc_normal, feat, idxs)
+                rc = L.cppf_decode_center(logits.data_ptr(), P, self.out_dim, tr_num_bins, float(vote_range[0]),
+                                          float(vote_range[1]), u_tr.data_ptr(), outputs.data_ptr(),
+                                          stream_ptr(pc.device))
+                _lib.check(rc, "cppf_decode_center")
+                if heads is not None:
+                    rc = L.cppf_decode_rot(logits.data_ptr(), P, self.out_dim, self.out_dim, tr_num_bins, rot_num_bins,
+                                           u_rot.data_ptr(), heads.data_ptr(), stream_ptr(pc.device))
+        _lib.check(rc, "cppf_pair_mlp_decode")
+        return outputs, heads
+
+    # ------------------------------------------------------------------ internals
+    def _needs_graph(self, feat):
+        if not torch.is_grad_enabled():
+            return False
+        return feat.requires_grad or any(p.requires_grad for p in self.parameters())
+
+    def _composite(self, pc, pc_normal, feat, idxs):
+        """models/model.py:118-137 as torch ops (autograd path)."""
+        a, b = idxs[:, 0].long(), idxs[:, 1].long()
+        xy = pc[a] - pc[b]
+        d = torch.norm(xy, dim=-1)
+        u = xy / (d[..., None] + 1e-7)
+        na, nb = pc_normal[a], pc_normal[b]
+        ppf = torch.stack([(na * u).sum(-1), (nb * u).sum(-1), (na * nb).sum(-1), d], -1)
+        x = torch.cat([feat[a], feat[b], ppf], -1)
+        for layer in self.res_layers:
+            x = layer(x)
+        return self.final(x)
+
+    @staticmethod
+    def _as_index_tensor(idxs, device):
+        if isinstance(idxs, np.ndarray):                       # nocs/inference.py:177,182
+            if idxs.dtype not in (np.int64, np.int32):
+                idxs = idxs.astype(np.int64)
+            idxs = torch.from_numpy(np.ascontiguousarray(idxs)).to(device, non_blocking=True)
+        if not isinstance(idxs, torch.Tensor):
+            raise TypeError(f"idxs: expected numpy array or torch tensor, got {type(idxs).__name__}")
+        if idxs.dtype not in (torch.int64, torch.int32):
+            raise TypeError(f"idxs: expected int64/int32, got {idxs.dtype}")
+        if idxs.dim() != 2 or idxs.shape[1] != 2:
+            raise ValueError(f"idxs: expected shape [P,2], got {tuple(idxs.shape)}")
+        return idxs.to(device).contiguous()
+
+    def _check_inputs(self, pc, pc_normal, feat):
+        require_cuda()
+        if not pc.is_cuda:
+            raise _lib.CppfError("PPFEncoder inference runs on a HIP device only (no CPU fallback); "
+                                 "move the module and its inputs to cuda")
+        if pc.dim() != 2 or pc.shape[1] != 3 or pc_normal.shape != pc.shape:
+            raise ValueError("pc / pc_normal must be [N,3]")
+        if feat.dim() != 2 or feat.shape[0] != pc.shape[0] or 2 * feat.shape[1] + 4 != self.ppffcs[0]:
+            raise ValueError(f"feat must be [N,F] with 2F+4 == ppffcs[0] == {self.ppffcs[0]}")
+        return (pc.detach().float().contiguous(), pc_normal.detach().float().contiguous(),
+                feat.detach().float().contiguous())
+
+    def _packed_weights(self, device):
+        """Lane-ordered weight image for the HIP kernel, rebuilt when a parameter changes."""
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._packed is not None and self._packed_key == key:
+            return self._packed
+        sd = {k: v.detach().float().cpu().numpy() for k, v in self.state_dict().items()}
+        params, offs = flatten_state_dict(sd, self.ppffcs)
+        dims = (C.c_int * len(self.ppffcs))(*self.ppffcs)
+        L = _lib.lib()
+        F_ = (self.ppffcs[0] - 4) // 2
+        n = L.cppf_pair_mlp_packed_floats(F_, dims, len(self.ppffcs) - 1, self.out_dim)
+        if n == 0:
+            raise _lib.CppfError(f"no device kernel for ppffcs={self.ppffcs}, out_dim={self.out_dim} "
+                                 "(layers wider than 128 units are unsupported)")
+        packed = np.zeros(n, np.float32)
+        rc = L.cppf_pair_mlp_pack(params.ctypes.data, offs.ctypes.data, F_, dims, len(self.ppffcs) - 1, self.out_dim,
+                                  packed.ctypes.data)
+        _lib.check(rc, "cppf_pair_mlp_pack")
+        self._packed = torch.from_numpy(packed).to(device)
+        self._packed_key = key
+        return self._packed
+
+
+def flatten_state_dict(sd, ppffcs):
+    """state_dict (numpy values, reference key names) -> (flat f32 params, i64 offset table) in the
+    layout cppf_pair_mlp_pack() documents: 6 offsets per res layer, then final.weight/bias."""
+    chunks, offs, pos = [], [], 0
+    names = []
+    for i in range(len(ppffcs) - 1):
+        names += [f"res_layers.{i}.{k}" for k in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc0.weight",
+                                                   "fc0.bias")]
+    names += ["final.weight", "final.bias"]
+    for nme in names:
+        if nme not in sd:
+            offs.append(-1)
+            continue
+        a = np.ascontiguousarray(sd[nme], dtype=np.float32).reshape(-1)
+        chunks.append(a)
+        offs.append(pos)
+        pos += a.size
+    return np.concatenate(chunks).astype(np.float32), np.asarray(offs, dtype=np.int64)

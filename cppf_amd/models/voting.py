@@ -1,0 +1,149 @@
+"""Drop-in for the reference's models/voting.py: the three module-level kernel objects
+`ppf_kernel`, `backvote_kernel`, `rot_voting_kernel`, called exactly like the CuPy RawKernels
+they replace (models/voting.py:4,70,115):
+
+    kernel((grid, 1, 1), (block, 1, 1), (arg0, arg1, ...))   ->   None
+
+with the same positional argument order.  Differences a caller sees:
+  * array arguments are torch tensors on a HIP device (replace `cp.asarray(x)` by a torch tensor);
+    dtype/shape/contiguity mistakes raise TypeError/ValueError instead of corrupting memory;
+  * the (grid, block) tuples are accepted and ignored -- launch geometry is the library's business
+    (the reference's own grid for ppf_voting is sized by N**2, nocs/inference.py:192);
+  * work is enqueued on the current torch stream; outputs are updated in place, as before.
+`findpeak_kernel` is not provided: it is dead code in the reference (never launched, and its source
+includes a file that does not exist).
+"""
+import torch
+
+from .. import _lib
+from .._torch_util import dev_tensor, require_cuda, scalar, stream_ptr, workspace
+
+__all__ = ["ppf_kernel", "backvote_kernel", "rot_voting_kernel", "vote_argmax"]
+
+F32, I32 = torch.float32, torch.int32
+
+
+class _Kernel:
+    def __init__(self, name, nargs, fn):
+        self.name, self._nargs, self._fn = name, nargs, fn
+
+    def __call__(self, grid, block, args, **kw):
+        if kw:
+            raise TypeError(f"{self.name}: unexpected keyword arguments {sorted(kw)}")
+        if len(args) != self._nargs:
+            raise TypeError(f"{self.name}: expected {self._nargs} kernel arguments, got {len(args)}")
+        require_cuda()
+        self._fn(*args)
+        return None
+
+    def __repr__(self):
+        return f"<cppf_amd kernel {self.name}>"
+
+
+def _dims(gx, gy, gz, grid=None):
+    gx, gy, gz = int(scalar(gx)), int(scalar(gy)), int(scalar(gz))
+    if min(gx, gy, gz) < 1:
+        raise ValueError(f"grid dims must be positive, got {(gx, gy, gz)}")
+    if grid is not None and grid.numel() != gx * gy * gz:
+        raise ValueError(f"grid_obj has {grid.numel()} cells, dims say {gx}x{gy}x{gz}")
+    return gx, gy, gz
+
+
+def _ppf_voting(points, outputs, probs, point_idxs, grid_obj, corner, res, n_ppfs, n_rots, gx, gy, gz, adaptive):
+    """models/voting.py:8-66 (launch: nocs/inference.py:197-205)"""
+    dev = dev_tensor(points, F32, "points", (3,)).device
+    n_ppfs, n_rots = int(scalar(n_ppfs)), int(scalar(n_rots))
+    dev_tensor(outputs, F32, "outputs", (2,), dev)
+    dev_tensor(probs, F32, "probs", None, dev)
+    dev_tensor(point_idxs, I32, "point_idxs", (2,), dev)
+    dev_tensor(grid_obj, F32, "grid_obj", None, dev)
+    dev_tensor(corner, F32, "corner", None, dev)
+    gx, gy, gz = _dims(gx, gy, gz, grid_obj)
+    if probs.numel() != points.shape[0]:
+        raise ValueError("probs must have one entry per point")
+    if outputs.shape[0] < n_ppfs or point_idxs.shape[0] < n_ppfs or n_ppfs < 0:
+        raise ValueError("n_ppfs exceeds the outputs/point_idxs arrays")
+    L = _lib.lib()
+    need = L.cppf_vote_workspace_bytes(n_ppfs, n_rots, gx, gy, gz)
+    if need == 0:
+        raise ValueError(f"n_rots must be in 1..360, got {n_rots}")
+    ws = workspace(need, dev, "vote")
+    with torch.cuda.device(dev):
+        rc = L.cppf_ppf_voting(points.data_ptr(), outputs.data_ptr(), probs.data_ptr(), point_idxs.data_ptr(),
+                               grid_obj.data_ptr(), corner.data_ptr(), float(scalar(res)), n_ppfs, n_rots, gx, gy, gz,
+                               1 if bool(scalar(adaptive)) else 0, ws.data_ptr(), ws.numel(), stream_ptr(dev))
+    _lib.check(rc, "cppf_ppf_voting")
+
+
+def vote_argmax(points, outputs, probs, point_idxs, grid_obj, corner, res, n_rots, adaptive, out_idx=None,
+                out_val=None):
+    """ppf_voting + np.argmax (nocs/inference.py:197-208) without the host round trip.
+    Returns (out_idx i64[1], out_val f32[1]) device tensors."""
+    dev = dev_tensor(points, F32, "points", (3,)).device
+    dev_tensor(outputs, F32, "outputs", (2,), dev)
+    dev_tensor(probs, F32, "probs", None, dev)
+    dev_tensor(point_idxs, I32, "point_idxs", (2,), dev)
+    dev_tensor(grid_obj, F32, "grid_obj", None, dev)
+    dev_tensor(corner, F32, "corner", None, dev)
+    if grid_obj.dim() != 3:
+        raise ValueError("grid_obj must be [gx,gy,gz]")
+    gx, gy, gz = grid_obj.shape
+    n_ppfs = point_idxs.shape[0]
+    if out_idx is None:
+        out_idx = torch.empty(1, dtype=torch.int64, device=dev)
+    if out_val is None:
+        out_val = torch.empty(1, dtype=F32, device=dev)
+    L = _lib.lib()
+    need = L.cppf_vote_workspace_bytes(n_ppfs, int(n_rots), gx, gy, gz)
+    if need == 0:
+        raise ValueError(f"n_rots must be in 1..360, got {n_rots}")
+    ws = workspace(need, dev, "vote")
+    with torch.cuda.device(dev):
+        rc = L.cppf_vote_argmax(points.data_ptr(), outputs.data_ptr(), probs.data_ptr(), point_idxs.data_ptr(),
+                                grid_obj.data_ptr(), corner.data_ptr(), float(scalar(res)), n_ppfs, int(n_rots), gx, gy,
+                                gz, 1 if adaptive else 0, out_idx.data_ptr(), out_val.data_ptr(), ws.data_ptr(),
+                                ws.numel(), stream_ptr(dev))
+    _lib.check(rc, "cppf_vote_argmax")
+    return out_idx, out_val
+
+
+def _backvote(points, outputs, out_offsets, point_idxs, corner, res, n_ppfs, n_rots, gx, gy, gz, gt_center, tol):
+    """models/voting.py:74-112 (launch: nocs/inference.py:219-228)"""
+    dev = dev_tensor(points, F32, "points", (3,)).device
+    n_ppfs, n_rots = int(scalar(n_ppfs)), int(scalar(n_rots))
+    dev_tensor(outputs, F32, "outputs", (2,), dev)
+    dev_tensor(out_offsets, F32, "out_offsets", (3,), dev)
+    dev_tensor(point_idxs, I32, "point_idxs", (2,), dev)
+    dev_tensor(corner, F32, "corner", None, dev)
+    dev_tensor(gt_center, F32, "gt_center", None, dev)
+    gx, gy, gz = _dims(gx, gy, gz)
+    if min(outputs.shape[0], point_idxs.shape[0], out_offsets.shape[0]) < n_ppfs or n_ppfs < 0:
+        raise ValueError("n_ppfs exceeds the outputs/point_idxs/out_offsets arrays")
+    with torch.cuda.device(dev):
+        rc = _lib.lib().cppf_backvote(points.data_ptr(), outputs.data_ptr(), out_offsets.data_ptr(),
+                                      point_idxs.data_ptr(), corner.data_ptr(), float(scalar(res)), n_ppfs, n_rots, gx,
+                                      gy, gz, gt_center.data_ptr(), float(scalar(tol)), None, stream_ptr(dev))
+    _lib.check(rc, "cppf_backvote")
+
+
+def _rot_voting(points, not_used, preds_rot, outputs_up, point_idxs, corner, res, n_ppfs, n_rots, gx, gy, gz):
+    """models/voting.py:119-147 (launch: nocs/inference.py:268-275); `not_used`, corner, res and the
+    grid dims are ignored by the reference kernel too."""
+    dev = dev_tensor(points, F32, "points", (3,)).device
+    n_ppfs, n_rots = int(scalar(n_ppfs)), int(scalar(n_rots))
+    dev_tensor(preds_rot, F32, "preds_rot", None, dev)
+    dev_tensor(outputs_up, F32, "outputs_up", None, dev)
+    dev_tensor(point_idxs, I32, "point_idxs", (2,), dev)
+    if preds_rot.numel() < n_ppfs or point_idxs.shape[0] < n_ppfs or n_ppfs < 0:
+        raise ValueError("n_ppfs exceeds the preds_rot/point_idxs arrays")
+    if outputs_up.numel() < n_ppfs * n_rots * 3:
+        raise ValueError("outputs_up must hold n_ppfs*n_rots*3 floats")
+    with torch.cuda.device(dev):
+        rc = _lib.lib().cppf_rot_voting(points.data_ptr(), preds_rot.data_ptr(), outputs_up.data_ptr(),
+                                        point_idxs.data_ptr(), n_ppfs, n_rots, stream_ptr(dev))
+    _lib.check(rc, "cppf_rot_voting")
+
+
+ppf_kernel = _Kernel("ppf_voting", 13, _ppf_voting)
+backvote_kernel = _Kernel("backvote", 13, _backvote)
+rot_voting_kernel = _Kernel("rot_voting", 12, _rot_voting)

@@ -1,0 +1,177 @@
+/*
+ * cppf.h -- C ABI of libcppf_hip.so: the MI355X (gfx950) implementation of CPPF's
+ * point-pair-feature -> pair-MLP -> vote -> argmax hot path.
+ *
+ * This is the drop-in boundary.  The reference (qq456cvb/CPPF) has no FFI of its own: its
+ * scripts call three CuPy RawKernels and one torch module directly.  Each entry point below
+ * names the reference interface it replaces (paths relative to the reference root); the Python
+ * binding that mirrors the reference's call convention lives in cppf_amd/models/{voting,model}.py
+ * and the stub a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a BORROWED pointer; `const float* / int* ...` arguments named below as
+ *     "device" are HIP device pointers valid on the current device, nothing is copied or kept.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued
+ *     asynchronously on it, nothing synchronises.
+ *   - return value: 0 on success, a hipError_t value (>0) when a HIP call failed, or a negative
+ *     CPPF_E* code for argument errors.  No exceptions cross the ABI.
+ *   - outputs follow the reference: caller-allocated, (zero-)initialised by the caller, updated
+ *     in place.
+ *   - workspaces are caller-provided device scratch; size them with the *_workspace_bytes()
+ *     queries.  The library allocates nothing and keeps no global state.
+ */
+#ifndef CPPF_H
+#define CPPF_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPPF_ABI_VERSION 1
+
+#define CPPF_EINVAL (-1)     /* bad argument (null pointer, negative size, n_rots out of range) */
+#define CPPF_EWORKSPACE (-2) /* workspace too small / missing */
+#define CPPF_EUNSUPPORTED (-3) /* layer shape not supported by any device kernel */
+
+int cppf_abi_version(void);
+const char* cppf_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------------
+ * Centre vote.  Replaces the CuPy RawKernel `ppf_kernel` = CUDA `ppf_voting`
+ * (models/voting.py:4-67), launched at nocs/inference.py:192-205.
+ *   points      device f32[N,3]        outputs  device f32[n_ppfs,2] = (mu, nu)
+ *   probs       device f32[N]          point_idxs device i32[n_ppfs,2]
+ *   grid_obj    device f32[gx,gy,gz]   in/out, accumulated (+=) like the reference's atomicAdd
+ *   corner      device f32[3]          res, n_rots (1..CPPF_MAX_ROTS), adaptive: as the reference
+ * The reference's launch geometry (grid, block) is not part of the ABI.
+ * Strategy: the grid is cut into tiles that fit LDS; every workgroup accumulates one tile for one
+ * chunk of pairs with LDS atomics, tiles are written to `workspace` and summed into grid_obj by
+ * a second kernel that also yields the arg-max (cppf_vote_argmax).  Grids that would need too many
+ * tiles fall back to global fp32 atomics.
+ * ------------------------------------------------------------------------------------------- */
+#define CPPF_MAX_ROTS 360
+size_t cppf_vote_workspace_bytes(int64_t n_ppfs, int n_rots, int gx, int gy, int gz);
+int cppf_ppf_voting(const float* points, const float* outputs, const float* probs, const int32_t* point_idxs,
+                    float* grid_obj, const float* corner, float res, int64_t n_ppfs, int n_rots, int gx, int gy,
+                    int gz, int adaptive, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Same vote, plus the arg-max that the reference takes on the host (nocs/inference.py:207-208:
+ * grid_obj.get(); np.argmax -> first maximum in C order).  out_idx: device i64[1] flat index,
+ * out_val: device f32[1] peak value (either may be NULL). */
+int cppf_vote_argmax(const float* points, const float* outputs, const float* probs, const int32_t* point_idxs,
+                     float* grid_obj, const float* corner, float res, int64_t n_ppfs, int n_rots, int gx, int gy,
+                     int gz, int adaptive, long long* out_idx, float* out_val, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+/* np.argmax(grid, axis=None) on device (nocs/inference.py:208).  n cells; ties -> lowest index. */
+int cppf_grid_argmax(const float* grid, int64_t n, long long* out_idx, float* out_val, void* stream);
+
+/* nocs/inference.py:209-210: T = corners[0] + unravel_index(argmax) * res (fp64); idx device i64[1];
+ * T64 device f64[3] and/or T32 device f32[3] (the copy the reference hands to backvote, :225). */
+int cppf_center_from_argmax(const long long* idx, const float* corner, double res, int gy, int gz, double* T64,
+                            float* T32, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Back-vote filter.  Replaces `backvote_kernel` = CUDA `backvote` (models/voting.py:70-113),
+ * launched at nocs/inference.py:216-228; always adaptive.
+ *   out_offsets device f32[n_ppfs,3] zero-initialised by the caller (degenerate pairs are not
+ *               written, as in the reference)
+ *   gt_center   device f32[3], tol = 3*res in the reference
+ *   mask        device u8[n_ppfs] or NULL: any(out_offsets != 0) (nocs/inference.py:230)
+ * ------------------------------------------------------------------------------------------- */
+int cppf_backvote(const float* points, const float* outputs, float* out_offsets, const int32_t* point_idxs,
+                  const float* corner, float res, int64_t n_ppfs, int n_rots, int gx, int gy, int gz,
+                  const float* gt_center, float tol, uint8_t* mask, void* stream);
+
+/* Order-preserving compaction of the surviving pairs (point_idxs[mask], nocs/inference.py:231),
+ * done on device.  surv: device i32[n] receives the indices i with mask[i] != 0 in increasing
+ * order; count: device i32[1].  workspace >= cppf_compact_workspace_bytes(n). */
+size_t cppf_compact_workspace_bytes(int64_t n);
+int cppf_compact_mask(const uint8_t* mask, int64_t n, int32_t* surv, int32_t* count, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Orientation candidates.  Replaces `rot_voting_kernel` = CUDA `rot_voting`
+ * (models/voting.py:115-148), launched at nocs/inference.py:265-275.
+ *   preds_rot  device f32[n_ppfs]          outputs_up device f32[n_ppfs,n_rots,3], zero-initialised
+ * ------------------------------------------------------------------------------------------- */
+int cppf_rot_voting(const float* points, const float* preds_rot, float* outputs_up, const int32_t* point_idxs,
+                    int64_t n_ppfs, int n_rots, void* stream);
+
+/* Fused rot_voting + sphere-bin count (nocs/inference.py:265-284) without materialising the
+ * [n,n_rots,3] candidates: for the pairs sel[0..min(*n_sel_dev, max_pairs)) (indices into the
+ * pair arrays; sel == NULL -> pairs 0..), counts[j] += #(cand . sphere[j] > thr).
+ *   preds_rot device f32, element i at preds_rot[i*rot_stride]
+ *   sphere device f32[S,3]; counts device i32[S] zero-initialised by the caller
+ *   n_sel_dev device i32[1] (number of valid entries of sel) or NULL -> n_sel_host */
+int cppf_rot_sphere_count(const float* points, const float* preds_rot, int rot_stride, const int32_t* point_idxs,
+                          const int32_t* sel, const int32_t* n_sel_dev, int64_t n_sel_host, int64_t max_pairs,
+                          int n_rots, const float* sphere, int n_sphere, float thr, int32_t* counts,
+                          void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pair encoder.  Replaces PPFEncoder.forward_with_idx (models/model.py:117-137) incl. the PPF
+ * construction (:118-129), the feature gather/concat (:132) and the ResLayer chain (:27-31).
+ *   pc, nrm    device f32[N,3]    feat device f32[N,F]
+ *   idxs       device i64[P,2] (idx_is_i64 != 0) or i32[P,2]
+ *   packed     device f32[cppf_pair_mlp_packed_floats(...)], built by cppf_pair_mlp_pack()
+ *   out        device f32[P,out_dim] logits
+ * Supported on the MFMA path: dims = {2F+4, 32, 32, 16} with F = 40 and out_dim <= 144 (the only
+ * architecture the reference trains, train.py:35); any other ResLayer stack runs on the generic
+ * kernel (one pair per lane, weights in LDS, at most 128 units per layer).
+ * ------------------------------------------------------------------------------------------- */
+size_t cppf_pair_mlp_packed_floats(int F, const int* dims, int n_res, int out_dim);
+/* host-side packing: params/offs use the layout documented in oracle/cppf_oracle.c:orc_pair_mlp
+ * (flat torch tensors + offset table: 6 per res layer {fc1.w, fc1.b, fc2.w, fc2.b, fc0.w|-1,
+ * fc0.b|-1} then {final.w, final.b}); packed_host receives cppf_pair_mlp_packed_floats() floats. */
+int cppf_pair_mlp_pack(const float* params, const int64_t* offs, int F, const int* dims, int n_res, int out_dim,
+                       float* packed_host);
+int cppf_pair_mlp_forward(const float* pc, const float* nrm, const float* feat, const void* idxs, int idx_is_i64,
+                          const float* packed, int64_t N, int F, const int* dims, int n_res, int64_t P,
+                          int out_dim, float* out, void* stream);
+
+/* Pair encoder fused with the decode of nocs/inference.py:185-188 (+ :245-256 when heads != NULL):
+ * softmax over the bins + inverse-CDF draw with caller-supplied uniforms (stand-in for
+ * torch.multinomial; u < 0 selects the arg-max bin) + bin -> value.  Logits never leave the CU.
+ *   u_tr  device f32[P,2]   -> outputs device f32[P,2] = (mu, nu)
+ *   u_rot device f32[P,2]   -> heads   device f32[P,8] = {theta_up, theta_right, aux_up, aux_right,
+ *                                                         sx, sy, sz, 0}    (both NULL to skip)
+ * Requires the MFMA architecture above with tr_bins = 32, rot_bins = 36, out_dim = 141. */
+int cppf_pair_mlp_decode(const float* pc, const float* nrm, const float* feat, const void* idxs, int idx_is_i64,
+                         const float* packed, int64_t N, int F, const int* dims, int n_res, int64_t P,
+                         int out_dim, int tr_bins, int rot_bins, float vr0, float vr1, const float* u_tr,
+                         const float* u_rot, float* outputs, float* heads, void* stream);
+
+/* Decode from logits already in memory (generic architectures / bin counts). */
+int cppf_decode_center(const float* logits, int64_t P, int ld, int tr_bins, float vr0, float vr1,
+                       const float* u_tr, float* outputs, void* stream);
+int cppf_decode_rot(const float* logits, int64_t P, int ld, int out_dim, int tr_bins, int rot_bins,
+                    const float* u_rot, float* heads, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Reductions of the pose tail.
+ *  cppf_axis_sign: nocs/inference.py:287-301.  For pairs sel[0..*n_sel_dev): flip n_a to agree with
+ *    ab, target = (n . best_dir > 0), sums of BCEWithLogits(aux, target) and (aux, 1-target).
+ *    aux element i at aux[i*aux_stride]; best_dir device f64[3]; out device f64[3] =
+ *    {up_loss_sum, down_loss_sum, n}.  The caller compares the two means.
+ *  cppf_scale_sum: nocs/inference.py:335.  out device f64[4] = {sum sx, sum sy, sum sz, n} over the
+ *    selected pairs; the caller finishes exp(mean)*scale_mean*2.
+ *  Both are two-kernel deterministic reductions (fixed order), workspace >= cppf_reduce_workspace_bytes().
+ * ------------------------------------------------------------------------------------------- */
+size_t cppf_reduce_workspace_bytes(void);
+int cppf_axis_sign(const float* pc, const float* nrm, const int32_t* point_idxs, const int32_t* sel,
+                   const int32_t* n_sel_dev, int64_t n_sel_host, const float* aux, int aux_stride,
+                   const double* best_dir, double* out, void* workspace, size_t workspace_bytes, void* stream);
+int cppf_scale_sum(const float* scale_logits, int stride, const int32_t* sel, const int32_t* n_sel_dev,
+                   int64_t n_sel_host, double* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* nocs/inference.py:194-195 on device: corner = min(pc), dims = int32((max-min)/res)+1.
+ * corner device f32[3], dims device i32[3]. */
+int cppf_grid_setup(const float* pc, int64_t N, float res, float* corner, int32_t* dims, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPPF_H */

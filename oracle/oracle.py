@@ -1,0 +1,320 @@
+"""ctypes/numpy front end of the CPU oracle (oracle/cppf_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- see the header of cppf_oracle.c.  Imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg; never by cppf_amd/.
+
+Every function cites the reference lines it restates (paths relative to qq456cvb/CPPF).
+"""
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_f = np.float32
+_pf = C.POINTER(C.c_float)
+_pd = C.POINTER(C.c_double)
+_pi32 = C.POINTER(C.c_int32)
+_pi64 = C.POINTER(C.c_int64)
+_pu8 = C.POINTER(C.c_uint8)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "cppf_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+        _LIB.orc_expf.restype = C.c_float
+        _LIB.orc_expf.argtypes = [C.c_float]
+        _LIB.orc_tan.restype = C.c_float
+        _LIB.orc_tan.argtypes = [C.c_float]
+        _LIB.orc_grid_argmax.restype = C.c_int64
+        _LIB.orc_sample_bin.restype = C.c_int
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+# --------------------------------------------------------------------------- math
+def expf(x):
+    return float(lib().orc_expf(C.c_float(float(x))))
+
+
+def sincos(x):
+    s, c = C.c_double(), C.c_double()
+    lib().orc_sincos(C.c_double(float(x)), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def rot_cs(i, n):
+    cs, sn = C.c_float(), C.c_float()
+    lib().orc_rot_cs(C.c_int(i), C.c_int(n), C.byref(cs), C.byref(sn))
+    return cs.value, sn.value
+
+
+def tanf(x):
+    return float(lib().orc_tan(C.c_float(float(x))))
+
+
+def set_threads(n):
+    lib().orc_set_threads(C.c_int(int(n)))
+
+
+def num_threads():
+    return int(lib().orc_num_threads())
+
+
+# --------------------------------------------------------------------------- MLP
+def pack_params(sd, ppffcs):
+    """Flatten a PPFEncoder state_dict (models/model.py:80-87 key names) into one fp32 buffer +
+    the offset table orc_pair_mlp() expects."""
+    chunks, offs, pos = [], [], 0
+
+    def put(name):
+        nonlocal pos
+        if name not in sd:
+            offs.append(-1)
+            return
+        a = np.asarray(sd[name], dtype=_f).reshape(-1)
+        chunks.append(a)
+        offs.append(pos)
+        pos += a.size
+
+    for i in range(len(ppffcs) - 1):
+        for k in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc0.weight", "fc0.bias"):
+            put(f"res_layers.{i}.{k}")
+    put("final.weight")
+    put("final.bias")
+    return np.concatenate(chunks).astype(_f), np.asarray(offs, dtype=np.int64)
+
+
+def ppf_features(pc, nrm, idxs):
+    """models/model.py:118-129 -> [P,4]"""
+    pc, nrm, idxs = _c(pc, _f), _c(nrm, _f), _c(idxs, np.int64)
+    out = np.empty((idxs.shape[0], 4), _f)
+    lib().orc_ppf_features(_p(pc, _pf), _p(nrm, _pf), _p(idxs, _pi64), C.c_int64(idxs.shape[0]), _p(out, _pf))
+    return out
+
+
+def pair_mlp(pc, nrm, feat, idxs, sd, ppffcs, out_dim, order=0):
+    """PPFEncoder.forward_with_idx (models/model.py:117-137) -> logits [P,out_dim]."""
+    pc, nrm, feat, idxs = _c(pc, _f), _c(nrm, _f), _c(feat, _f), _c(idxs, np.int64)
+    params, offs = pack_params(sd, ppffcs)
+    dims = np.asarray(ppffcs, dtype=np.int32)
+    P = idxs.shape[0]
+    out = np.empty((P, out_dim), _f)
+    rc = lib().orc_pair_mlp(_p(pc, _pf), _p(nrm, _pf), _p(feat, _pf), _p(idxs, _pi64), C.c_int64(pc.shape[0]),
+                            C.c_int(feat.shape[1]), C.c_int64(P), _p(params, _pf), _p(offs, _pi64),
+                            _p(dims, _pi32), C.c_int(len(ppffcs) - 1), C.c_int(out_dim), C.c_int(order),
+                            _p(out, _pf))
+    if rc != 0:
+        raise ValueError(f"orc_pair_mlp failed: {rc}")
+    return out
+
+
+# --------------------------------------------------------------------------- decode
+def sample_bin(logits, u):
+    logits = _c(logits, _f)
+    return int(lib().orc_sample_bin(_p(logits, _pf), C.c_int(logits.size), C.c_float(float(u))))
+
+
+def decode_center(logits, u, tr_num_bins, vote_range):
+    """nocs/inference.py:185-188 with explicit uniforms u[P,2] (u<0: argmax bin)."""
+    logits, u = _c(logits, _f), _c(u, _f)
+    P = logits.shape[0]
+    outputs = np.empty((P, 2), _f)
+    bins = np.empty((P, 2), np.int32)
+    lib().orc_decode_center(_p(logits, _pf), C.c_int64(P), C.c_int(logits.shape[1]), C.c_int(tr_num_bins),
+                            _p(u, _pf), C.c_float(vote_range[0]), C.c_float(vote_range[1]), _p(outputs, _pf),
+                            _p(bins, _pi32))
+    return outputs, bins
+
+
+def decode_rot(logits, u, tr_num_bins, rot_num_bins):
+    """nocs/inference.py:238-256 -> heads[P,8] = {theta_up, theta_right, aux_up, aux_right, sx,sy,sz,0}"""
+    logits, u = _c(logits, _f), _c(u, _f)
+    P = logits.shape[0]
+    heads = np.empty((P, 8), _f)
+    bins = np.empty((P, 2), np.int32)
+    lib().orc_decode_rot(_p(logits, _pf), C.c_int64(P), C.c_int(logits.shape[1]), C.c_int(logits.shape[1]),
+                         C.c_int(tr_num_bins), C.c_int(rot_num_bins), _p(u, _pf), _p(heads, _pf),
+                         _p(bins, _pi32))
+    return heads, bins
+
+
+# --------------------------------------------------------------------------- vote
+def grid_setup(pc, res):
+    """nocs/inference.py:194-195 -> (corner f32[3], dims i32[3])"""
+    pc = _c(pc, _f)
+    corner = np.empty(3, _f)
+    dims = np.empty(3, np.int32)
+    lib().orc_grid_setup(_p(pc, _pf), C.c_int64(pc.shape[0]), C.c_float(res), _p(corner, _pf), _p(dims, _pi32))
+    return corner, dims
+
+
+def ppf_voting(points, outputs, probs, point_idxs, grid, corner, res, n_rots, adaptive, threads=1):
+    """models/voting.py:8-66, in place on `grid` (f32[gx,gy,gz]); returns the number of atomicAdds."""
+    points, outputs, probs = _c(points, _f), _c(outputs, _f), _c(probs, _f)
+    point_idxs, corner = _c(point_idxs, np.int32), _c(corner, _f)
+    assert grid.dtype == _f and grid.flags.c_contiguous
+    gx, gy, gz = grid.shape
+    na = C.c_int64(0)
+    args = [_p(points, _pf), _p(outputs, _pf), _p(probs, _pf), _p(point_idxs, _pi32), _p(grid, _pf),
+            _p(corner, _pf), C.c_float(res), C.c_int64(point_idxs.shape[0]), C.c_int(n_rots), C.c_int(gx),
+            C.c_int(gy), C.c_int(gz), C.c_int(1 if adaptive else 0)]
+    if threads == 1:
+        lib().orc_ppf_voting(*args, C.byref(na))
+        return na.value
+    lib().orc_ppf_voting_mt(*args)
+    return None
+
+
+def grid_argmax(grid):
+    """np.argmax(grid) (first maximum, C order), nocs/inference.py:208"""
+    g = _c(grid, _f).reshape(-1)
+    v = C.c_float()
+    i = lib().orc_grid_argmax(_p(g, _pf), C.c_int64(g.size), C.byref(v))
+    return int(i), float(v.value)
+
+
+def center_from_argmax(flat, dims, corner, res):
+    """nocs/inference.py:209-210 -> T f64[3]"""
+    corner = _c(corner, _f)
+    T = np.empty(3, np.float64)
+    lib().orc_center_from_argmax(C.c_int64(flat), C.c_int(int(dims[1])), C.c_int(int(dims[2])), _p(corner, _pf),
+                                 C.c_double(float(res)), _p(T, _pd))
+    return T
+
+
+def backvote(points, outputs, point_idxs, corner, res, n_rots, dims, gt_center, tol):
+    """models/voting.py:74-112 -> (out_offsets f32[P,3], mask bool[P])"""
+    points, outputs = _c(points, _f), _c(outputs, _f)
+    point_idxs, corner, gt = _c(point_idxs, np.int32), _c(corner, _f), _c(gt_center, _f)
+    P = point_idxs.shape[0]
+    oo = np.zeros((P, 3), _f)
+    mask = np.zeros(P, np.uint8)
+    lib().orc_backvote(_p(points, _pf), _p(outputs, _pf), _p(oo, _pf), _p(point_idxs, _pi32), _p(corner, _pf),
+                       C.c_float(res), C.c_int64(P), C.c_int(n_rots), C.c_int(int(dims[0])), C.c_int(int(dims[1])),
+                       C.c_int(int(dims[2])), _p(gt, _pf), C.c_float(tol), _p(mask, _pu8))
+    return oo, mask.astype(bool)
+
+
+def rot_voting(points, preds_rot, point_idxs, n_rots):
+    """models/voting.py:119-147 -> candidates f32[P,n_rots,3]"""
+    points, preds_rot, point_idxs = _c(points, _f), _c(preds_rot, _f), _c(point_idxs, np.int32)
+    P = point_idxs.shape[0]
+    out = np.zeros((P, n_rots, 3), _f)
+    lib().orc_rot_voting(_p(points, _pf), _p(preds_rot, _pf), _p(out, _pf), _p(point_idxs, _pi32), C.c_int64(P),
+                         C.c_int(n_rots))
+    return out
+
+
+def sphere_count(cands, sphere_pts, angle_tol_deg):
+    """nocs/inference.py:281-282 -> counts i64[S]; thr = cos(angle_tol) rounded to fp32."""
+    cands, sph = _c(cands, _f).reshape(-1, 3), _c(sphere_pts, _f)
+    thr = np.float32(np.cos(angle_tol_deg / 180 * np.pi))
+    counts = np.empty(sph.shape[0], np.int64)
+    lib().orc_sphere_count(_p(cands, _pf), C.c_int64(cands.shape[0]), _p(sph, _pf), C.c_int(sph.shape[0]),
+                           C.c_float(thr), _p(counts, _pi64))
+    return counts
+
+
+def axis_sign(pc, nrm, point_idxs, aux, best_dir):
+    """nocs/inference.py:287-301 -> (flip: bool, (up_loss, down_loss))"""
+    pc, nrm, point_idxs, aux = _c(pc, _f), _c(nrm, _f), _c(point_idxs, np.int32), _c(aux, _f)
+    bd = _c(best_dir, np.float64)
+    losses = np.empty(2, np.float64)
+    flip = lib().orc_axis_sign(_p(pc, _pf), _p(nrm, _pf), _p(point_idxs, _pi32), C.c_int64(point_idxs.shape[0]),
+                               _p(aux, _pf), C.c_int(1), _p(bd, _pd), _p(losses, _pd))
+    return bool(flip), (float(losses[0]), float(losses[1]))
+
+
+def scale(scale_logits, scale_mean):
+    """nocs/inference.py:335 -> f64[3]"""
+    sl = _c(scale_logits, _f)
+    sm = _c(scale_mean, np.float64)
+    out = np.empty(3, np.float64)
+    lib().orc_scale(_p(sl, _pf), C.c_int64(sl.shape[0]), C.c_int(sl.shape[1]), _p(sm, _pd), _p(out, _pd))
+    return out
+
+
+# --------------------------------------------------------------------------- host-side pieces
+def fibonacci_sphere(samples):
+    """utils/util.py:102-118: golden-angle spiral, y from 1 to -1; fp64 -> [samples,3]"""
+    phi = math.pi * (3.0 - math.sqrt(5.0))
+    pts = np.empty((samples, 3), np.float64)
+    for i in range(samples):
+        y = 1 - (i / float(samples - 1)) * 2
+        r = math.sqrt(1 - y * y)
+        t = phi * i
+        pts[i] = (math.cos(t) * r, y, math.sin(t) * r)
+    return pts
+
+
+def closed_form_targets(pc, point_idxs):
+    """utils/dataset.py:27-36: (mu, nu) of each pair for an object centred at the origin."""
+    a = pc[point_idxs[:, 0]]
+    b = pc[point_idxs[:, 1]]
+    pd = a - b
+    pu = pd / (np.linalg.norm(pd, axis=-1, keepdims=True) + 1e-7)
+    proj = np.sum(a * pu, -1)
+    oc = a - proj[..., None] * pu
+    return np.stack([proj, np.linalg.norm(oc, axis=-1)], -1).astype(_f)
+
+
+def estimate_pose(pc, nrm, feat, point_idxs, sd, cfg, u_tr, u_rot, sphere_pts, num_rots=72, adaptive=True,
+                  angle_tol=1.5, max_rot_pairs=10000, order=1):
+    """The glue of nocs/inference.py:177-335 chained from the pieces above, with the stochastic
+    draws supplied: u_tr[P,2] (centre bins), u_rot[P,2] (up/right bins, indexed by ORIGINAL pair so
+    the second MLP pass of :236 is a gather of first-pass rows -- the MLP is deterministic in eval
+    mode), and the 10 000-pair subsample of :278-280 taken as the first survivors in pair order
+    (pairs are i.i.d. uniform, so this is the same distribution as the reference's shuffle).
+    cfg: dict(res, tr_num_bins, rot_num_bins, vote_range, scale_mean, regress_right, ppffcs, out_dim)."""
+    res = float(cfg["res"])
+    tb, rb = cfg["tr_num_bins"], cfg["rot_num_bins"]
+    logits = pair_mlp(pc, nrm, feat, point_idxs, sd, cfg["ppffcs"], cfg["out_dim"], order=order)
+    outputs, _ = decode_center(logits, u_tr, tb, cfg["vote_range"])
+    corner, dims = grid_setup(pc, res)
+    grid = np.zeros(tuple(int(d) for d in dims), _f)
+    idx32 = point_idxs.astype(np.int32)
+    ppf_voting(pc, outputs, np.ones(pc.shape[0], _f), idx32, grid, corner, res, num_rots, adaptive)
+    flat, peak = grid_argmax(grid)
+    T = center_from_argmax(flat, dims, corner, res)
+    _, mask = backvote(pc, outputs, idx32, corner, res, num_rots, dims, T.astype(_f), np.float32(3 * res))
+    surv = np.nonzero(mask)[0]
+    heads, _ = decode_rot(logits, u_rot, tb, rb)
+    sidx = idx32[surv]
+    sel = surv[:max_rot_pairs]
+    dirs = []
+    for j in range(2):
+        if j == 1 and not cfg["regress_right"]:
+            continue
+        cands = rot_voting(pc, heads[sel, j], idx32[sel], num_rots)
+        counts = sphere_count(cands, sphere_pts, angle_tol)
+        best = np.asarray(sphere_pts[int(np.argmax(counts))], np.float64)
+        flip, _ = axis_sign(pc, nrm, sidx, heads[surv, 2 + j], best)
+        dirs.append(-best if flip else best)
+    sc = scale(heads[surv, 4:7], cfg["scale_mean"]) if surv.size else np.zeros(3)
+    return dict(T=T, argmax=flat, peak=peak, grid=grid, outputs=outputs, logits=logits, mask=mask,
+                up=dirs[0] if dirs else None, right=dirs[1] if len(dirs) > 1 else None, scale=sc,
+                corner=corner, dims=dims, heads=heads)
