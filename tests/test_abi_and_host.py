@@ -1,0 +1,161 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/cppf.h declares, host
+logic (packing, planning, argument validation, drop-in module surface) -- no device compute."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, sd_from_npz
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from cppf_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "cppf.h")).read()
+    declared = sorted(set(re.findall(r"\b(cppf_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 20
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/cppf.h but not exported"
+    assert set(declared) == set(_lib.exported_symbols())
+    assert L.cppf_abi_version() == 1
+    assert b"workspace" in L.cppf_error_string(-2)
+
+
+def test_workspace_queries_and_argument_errors_without_a_device():
+    from cppf_amd import _lib
+    L = _lib.lib()
+    # bottle grid of BASELINE config 2: two x slabs x 128 pair chunks of partial grids
+    need = L.cppf_vote_workspace_bytes(524288, 72, 26, 76, 26)
+    G = 26 * 76 * 26
+    assert need >= 128 * G * 4 and need < 140 * G * 4
+    assert L.cppf_vote_workspace_bytes(100, 0, 26, 76, 26) == 0          # n_rots out of range
+    assert L.cppf_vote_workspace_bytes(100, 361, 26, 76, 26) == 0
+    # huge grid -> global-atomic path: only table + scratch
+    assert L.cppf_vote_workspace_bytes(524288, 72, 400, 400, 400) < 1 << 20
+    assert L.cppf_compact_workspace_bytes(0) > 0 and L.cppf_reduce_workspace_bytes() > 0
+    # null pointers / bad sizes are rejected before any HIP call
+    assert L.cppf_ppf_voting(None, None, None, None, None, None, 0.004, 10, 72, 4, 4, 4, 1, None, 0, None) == -1
+    assert L.cppf_backvote(None, None, None, None, None, 0.004, 10, 72, 4, 4, 4, None, 0.01, None, None) == -1
+    assert L.cppf_grid_argmax(None, 10, None, None, None) == -1
+    assert L.cppf_rot_voting(None, None, None, None, 10, 72, None) == -1
+
+
+def test_weight_packing_follows_the_documented_lane_order(golden):
+    from cppf_amd import _lib
+    from cppf_amd.models.model import flatten_state_dict
+    g = golden("mlp_141.npz")
+    sd = sd_from_npz(g)
+    params, offs = flatten_state_dict(sd, [84, 32, 32, 16])
+    L = _lib.lib()
+    dims = (C.c_int * 4)(84, 32, 32, 16)
+    n = L.cppf_pair_mlp_packed_floats(40, dims, 3, 141)
+    assert n == 13152
+    packed = np.zeros(n, np.float32)
+    assert L.cppf_pair_mlp_pack(params.ctypes.data, offs.ctypes.data, 40, dims, 3, 141, packed.ctypes.data) == 0
+    w1, w0 = sd["res_layers.0.fc1.weight"], sd["res_layers.0.fc0.weight"]
+
+    def kfirst(s, g_):
+        return 10 * g_ + s if s < 10 else (40 + 10 * g_ + (s - 10) if s < 20 else 80 + g_)
+
+    for s, lane, ob in ((0, 0, 0), (5, 17, 1), (12, 40, 2), (20, 63, 3), (19, 33, 0)):
+        o, k = 16 * (ob & 1) + (lane & 15), kfirst(s, lane >> 4)
+        assert packed[(s * 64 + lane) * 4 + ob] == (w1 if ob < 2 else w0)[o, k]
+    # final layer: [4][64][12], zero padded past out_dim; biases in natural order at the tail
+    off_wf = 21 * 64 * 4 + 4 * (8 * 64 * 2) + 4 * 64
+    wf = sd["final.weight"]
+    for s, lane, ob in ((0, 0, 0), (3, 63, 8), (2, 20, 5)):
+        o, k = 16 * ob + (lane & 15), 16 * (s // 4) + 4 * (lane >> 4) + s % 4
+        exp = wf[o, k] if o < 141 else 0.0
+        assert packed[off_wf + (s * 64 + lane) * 12 + ob] == exp
+    np.testing.assert_array_equal(packed[-144:-3], sd["final.bias"])
+    assert np.all(packed[-3:] == 0)
+    # unsupported: layer wider than 128
+    dims_bad = (C.c_int * 3)(84, 256, 16)
+    assert L.cppf_pair_mlp_packed_floats(40, dims_bad, 2, 10) == 0
+    # generic architecture: canonical concatenation
+    gg = golden("mlp_generic.npz")
+    sdg = sd_from_npz(gg)
+    pg, og = flatten_state_dict(sdg, [44, 24, 24])
+    dg = (C.c_int * 3)(44, 24, 24)
+    ng = L.cppf_pair_mlp_packed_floats(20, dg, 2, 10)
+    assert ng == pg.size
+    out = np.zeros(ng, np.float32)
+    assert L.cppf_pair_mlp_pack(pg.ctypes.data, og.ctypes.data, 20, dg, 2, 10, out.ctypes.data) == 0
+    np.testing.assert_array_equal(out, pg)
+
+
+def test_flatten_state_dict_matches_oracle_packing(oracle, golden):
+    from cppf_amd.models.model import flatten_state_dict
+    sd = sd_from_npz(golden("mlp_141.npz"))
+    p1, o1 = flatten_state_dict(sd, [84, 32, 32, 16])
+    p2, o2 = oracle.pack_params(sd, [84, 32, 32, 16])
+    np.testing.assert_array_equal(p1, p2)
+    np.testing.assert_array_equal(o1, o2)
+    assert o1[10] == -1 and o1[4] >= 0 and o1[16] >= 0        # fc0 only where dim_in != dim_out
+
+
+def test_ppfencoder_module_surface_matches_reference(golden):
+    from cppf_amd.models.model import PPFEncoder, ResLayer
+    g = golden("mlp_141.npz")
+    sd = sd_from_npz(g)
+    enc = PPFEncoder([84, 32, 32, 16], 141)
+    assert sorted(enc.state_dict().keys()) == sorted(sd.keys())            # reference checkpoints load as-is
+    assert sum(p.numel() for p in enc.parameters()) == 12333
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    assert isinstance(enc.res_layers[0], ResLayer) and enc.res_layers[1].fc0 is None
+    # autograd path (train.py:66,91): composite torch ops, equals the reference logits, gives grads
+    feat = torch.from_numpy(g["feat"]).requires_grad_(True)
+    y = enc(torch.from_numpy(g["pc"])[None], torch.from_numpy(g["nrm"])[None], feat[None],
+            idxs=torch.from_numpy(g["idxs"]))
+    assert y.shape == (1, 512, 141)
+    np.testing.assert_allclose(y[0].detach().numpy(), g["logits"], atol=2e-6)
+    y.sum().backward()
+    assert feat.grad is not None and enc.final.weight.grad is not None
+    # inference path never falls back to the CPU
+    from cppf_amd import _lib
+    with torch.no_grad(), pytest.raises(_lib.CppfError):
+        enc(torch.from_numpy(g["pc"])[None], torch.from_numpy(g["nrm"])[None], torch.from_numpy(g["feat"])[None],
+            idxs=g["idxs"])
+
+
+def test_voting_module_surface_and_loud_failure_without_device():
+    from cppf_amd import _lib
+    from cppf_amd.models import voting
+    assert {"ppf_kernel", "backvote_kernel", "rot_voting_kernel"} <= set(dir(voting))
+    assert not hasattr(voting, "findpeak_kernel")
+    with pytest.raises(TypeError):
+        voting.ppf_kernel((1, 1, 1), (512, 1, 1), (1, 2, 3))
+    if not torch.cuda.is_available():
+        args = (torch.zeros(4, 3), torch.zeros(8, 2), torch.ones(4), torch.zeros((8, 2), dtype=torch.int32),
+                torch.zeros(4, 4, 4), torch.zeros(3), 0.004, 8, 72, 4, 4, 4, True)
+        with pytest.raises(_lib.CppfError):
+            voting.ppf_kernel((1, 1, 1), (512, 1, 1), args)
+
+
+def test_host_utilities(golden):
+    from cppf_amd.utils.util import fibonacci_sphere, num_sphere_bins
+    s = golden("sphere.npz")
+    assert num_sphere_bins(1.5) == 480
+    pts = fibonacci_sphere(480)
+    assert isinstance(pts, list) and len(pts[0]) == 3
+    np.testing.assert_array_equal(np.array(pts), s["pts"])
+    import cppf_amd.synthetic as syn
+    a, b = syn.make_object("bottle", 256, 3), syn.make_object("bottle", 256, 3)
+    np.testing.assert_array_equal(a["pc"], b["pc"])
+    assert a["pc"].dtype == np.float32 and a["feat"].shape == (256, 40)
+    np.testing.assert_allclose(np.linalg.norm(a["normals"], axis=-1), 1.0, atol=1e-6)
+    idx = syn.make_pairs(256, 4, 3)
+    assert idx.shape == (1024, 2) and idx.dtype == np.int64 and idx.max() < 256
+    from cppf_amd.config import CATEGORIES
+    assert CATEGORIES["bottle"].out_dim == 141 and CATEGORIES["laptop"].res == 1e-2
+
+
+def test_missing_library_is_a_loud_error(monkeypatch, tmp_path):
+    from cppf_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_SO", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.CppfError):
+        _lib.lib()

@@ -1,0 +1,465 @@
+"""Parity of the HIP path (through the C ABI) with the oracle on identical seeded inputs.
+
+Bar: bit-exact for every integer / index / discrete outcome (sampled bins, masks, survivor lists,
+sphere counts, arg-max) and -- because the kernels and the oracle follow the same arithmetic
+conventions -- also bit-exact for the per-pair float outputs (logits, (mu,nu), offsets,
+candidates).  Only the vote grid is compared with a tolerance: fp32 atomic accumulation order is
+unspecified, in the reference as well (atol = 1e-5 * number of contributions).
+"""
+import numpy as np
+import pytest
+import torch
+
+import cppf_amd.synthetic as syn
+from cppf_amd import _lib
+from cppf_amd.config import CATEGORIES
+from cppf_amd.models import voting
+from cppf_amd.models.model import PPFEncoder
+from cppf_amd._torch_util import stream_ptr, workspace
+from conftest import sd_from_npz
+
+pytestmark = pytest.mark.gpu
+
+
+def t(x, dev, dtype=None):
+    a = torch.from_numpy(np.ascontiguousarray(x))
+    if dtype is not None:
+        a = a.to(dtype)
+    return a.to(dev)
+
+
+def make_encoder(sd, ppffcs, out_dim, dev):
+    enc = PPFEncoder(ppffcs, out_dim)
+    enc.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    return enc.to(dev).eval()
+
+
+def seeded_sd(seed=0, ppffcs=(84, 32, 32, 16), out_dim=141):
+    torch.manual_seed(seed)
+    enc = PPFEncoder(list(ppffcs), out_dim)
+    return {k: v.detach().numpy().copy() for k, v in enc.state_dict().items()}
+
+
+# ------------------------------------------------------------------------------------ pair MLP
+@pytest.mark.parametrize("tag,out_dim", [("141", 141), ("9", 9)])
+def test_mlp_mfma_bit_exact_vs_oracle_and_close_to_reference(oracle, golden, dev, tag, out_dim):
+    g = golden(f"mlp_{tag}.npz")
+    sd = sd_from_npz(g)
+    enc = make_encoder(sd, [84, 32, 32, 16], out_dim, dev)
+    with torch.no_grad():
+        y = enc(t(g["pc"], dev)[None], t(g["nrm"], dev)[None], t(g["feat"], dev)[None], idxs=g["idxs"])
+        y2 = enc.forward_with_idx(t(g["pc"], dev), t(g["nrm"], dev), t(g["feat"], dev), t(g["idxs"], dev))
+        y3 = enc.forward_with_idx(t(g["pc"], dev), t(g["nrm"], dev), t(g["feat"], dev), t(g["idxs"], dev, torch.int32))
+    assert y.shape == (1, g["idxs"].shape[0], out_dim) and y.dtype == torch.float32 and y.device == dev
+    yo = oracle.pair_mlp(g["pc"], g["nrm"], g["feat"], g["idxs"], sd, [84, 32, 32, 16], out_dim, order=1)
+    np.testing.assert_array_equal(y[0].cpu().numpy(), yo)               # MFMA chain == fmaf chain, bit for bit
+    assert torch.equal(y[0], y2) and torch.equal(y2, y3)
+    np.testing.assert_allclose(y[0].cpu().numpy(), g["logits"], rtol=0, atol=2e-6)   # reference forward
+
+
+def test_mlp_generic_architecture(oracle, golden, dev):
+    g = golden("mlp_generic.npz")
+    sd = sd_from_npz(g)
+    enc = make_encoder(sd, [44, 24, 24], 10, dev)
+    with torch.no_grad():
+        y = enc.forward_with_idx(t(g["pc"], dev), t(g["nrm"], dev), t(g["feat"], dev), t(g["idxs"], dev))
+    yo = oracle.pair_mlp(g["pc"], g["nrm"], g["feat"], g["idxs"], sd, [44, 24, 24], 10, order=0)
+    np.testing.assert_array_equal(y.cpu().numpy(), yo)
+    np.testing.assert_allclose(y.cpu().numpy(), g["logits"], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("P", [1, 15, 33, 1000, 4097])
+def test_mlp_ragged_sizes(oracle, dev, P):
+    ob = syn.make_object("bottle", 300, 5)
+    idx = np.random.default_rng(P).integers(0, 300, (P, 2)).astype(np.int64)
+    sd = seeded_sd(1)
+    enc = make_encoder(sd, [84, 32, 32, 16], 141, dev)
+    with torch.no_grad():
+        y = enc.forward_with_idx(t(ob["pc"], dev), t(ob["normals"], dev), t(ob["feat"], dev), t(idx, dev))
+    yo = oracle.pair_mlp(ob["pc"], ob["normals"], ob["feat"], idx, sd, [84, 32, 32, 16], 141, order=1)
+    np.testing.assert_array_equal(y.cpu().numpy(), yo)
+
+
+def test_mlp_empty_and_dense(oracle, dev):
+    ob = syn.make_object("can", 40, 2)
+    sd = seeded_sd(2)
+    enc = make_encoder(sd, [84, 32, 32, 16], 141, dev)
+    pc, n, f = t(ob["pc"], dev), t(ob["normals"], dev), t(ob["feat"], dev)
+    with torch.no_grad():
+        y0 = enc.forward_with_idx(pc, n, f, torch.zeros((0, 2), dtype=torch.int64, device=dev))
+        yd = enc(pc[None], n[None], f[None])                       # dense all-pairs branch
+    assert y0.shape == (0, 141)
+    assert yd.shape == (1, 40, 40, 141)
+    ii, jj = np.meshgrid(np.arange(40), np.arange(40), indexing="ij")
+    allp = np.stack([ii.reshape(-1), jj.reshape(-1)], -1).astype(np.int64)
+    yo = oracle.pair_mlp(ob["pc"], ob["normals"], ob["feat"], allp, sd, [84, 32, 32, 16], 141, order=1)
+    np.testing.assert_array_equal(yd.reshape(-1, 141).cpu().numpy(), yo)
+
+
+# ------------------------------------------------------------------------------------ decode
+def test_fused_decode_bit_exact(oracle, dev):
+    ob = syn.make_object("bottle", 1024, 7)
+    idx = syn.make_pairs(1024, 16, 7)
+    P = idx.shape[0]
+    u_tr, u_rot = syn.make_uniforms(P, 7)
+    u_tr[:50] = -1.0                                               # arg-max mode rows
+    u_rot[25:75] = -1.0
+    u_tr[100, 0] = 0.0
+    u_tr[101, 1] = np.float32(1.0) - np.float32(2 ** -24)
+    sd = seeded_sd(0)
+    for k in ("final.weight", "final.bias"):                       # sharper, non-uniform distributions
+        sd[k] = sd[k] * 8
+    enc = make_encoder(sd, [84, 32, 32, 16], 141, dev)
+    cfg = ob["cfg"]
+    with torch.no_grad():
+        outputs, heads = enc.forward_decode(t(ob["pc"], dev), t(ob["normals"], dev), t(ob["feat"], dev), t(idx, dev),
+                                            t(u_tr, dev), cfg.vote_range, t(u_rot, dev))
+        logits = enc.forward_with_idx(t(ob["pc"], dev), t(ob["normals"], dev), t(ob["feat"], dev), t(idx, dev))
+    lo = oracle.pair_mlp(ob["pc"], ob["normals"], ob["feat"], idx, sd, [84, 32, 32, 16], 141, order=1)
+    oo, bins = oracle.decode_center(lo, u_tr, 32, cfg.vote_range)
+    ho, rbins = oracle.decode_rot(lo, u_rot, 32, 36)
+    np.testing.assert_array_equal(outputs.cpu().numpy(), oo)
+    np.testing.assert_array_equal(heads.cpu().numpy(), ho)
+    assert len(np.unique(bins)) > 20 and len(np.unique(rbins)) > 20
+    # decode-from-memory kernels agree too
+    L = _lib.lib()
+    out2 = torch.empty_like(outputs)
+    heads2 = torch.empty_like(heads)
+    _lib.check(L.cppf_decode_center(logits.data_ptr(), P, 141, 32, cfg.vote_range[0], cfg.vote_range[1],
+                                    t(u_tr, dev).data_ptr(), out2.data_ptr(), stream_ptr(dev)), "decode_center")
+    _lib.check(L.cppf_decode_rot(logits.data_ptr(), P, 141, 141, 32, 36, t(u_rot, dev).data_ptr(), heads2.data_ptr(),
+                                 stream_ptr(dev)), "decode_rot")
+    torch.cuda.synchronize()
+    assert torch.equal(out2, outputs) and torch.equal(heads2, heads)
+
+
+# ------------------------------------------------------------------------------------ centre vote
+def run_vote(dev, pc, outputs, idx32, corner, dims, res, n_rots, adaptive, probs=None, grid0=None):
+    N = pc.shape[0]
+    probs = np.ones(N, np.float32) if probs is None else probs
+    grid = torch.zeros(tuple(int(d) for d in dims), dtype=torch.float32, device=dev)
+    if grid0 is not None:
+        grid.copy_(t(grid0, dev))
+    oi, ov = voting.vote_argmax(t(pc, dev), t(outputs, dev), t(probs, dev), t(idx32, dev), grid, t(corner, dev), res,
+                                n_rots, adaptive)
+    torch.cuda.synchronize()
+    return grid.cpu().numpy(), int(oi.item()), float(ov.item())
+
+
+def oracle_vote(oracle, pc, outputs, idx32, corner, dims, res, n_rots, adaptive, probs=None, grid0=None):
+    probs = np.ones(pc.shape[0], np.float32) if probs is None else probs
+    grid = np.zeros(tuple(int(d) for d in dims), np.float32) if grid0 is None else grid0.copy()
+    na = oracle.ppf_voting(pc, outputs, probs, idx32, grid, corner, res, n_rots, adaptive)
+    return grid, na
+
+
+def vote_case(oracle, dev, cat, n, k, seed, adaptive, quantise=True, n_rots=72, res_scale=1.0, corner_shift=0.0):
+    ob = syn.make_object(cat, n, seed)
+    cfg = ob["cfg"]
+    res = cfg.res * res_scale
+    idx = syn.make_pairs(n, k, seed)
+    outputs = syn.closed_form_outputs(ob["pc"], ob["center"], idx, cfg, quantise=quantise)
+    corner, dims = oracle.grid_setup(ob["pc"], res)
+    corner = (corner + np.float32(corner_shift)).astype(np.float32)
+    idx32 = idx.astype(np.int32)
+    go, na = oracle_vote(oracle, ob["pc"], outputs, idx32, corner, dims, res, n_rots, adaptive)
+    gg, flat, peak = run_vote(dev, ob["pc"], outputs, idx32, corner, dims, res, n_rots, adaptive)
+    return ob, go, na, gg, flat, peak, dims
+
+
+@pytest.mark.parametrize("cat,adaptive,quantise", [("bottle", True, True), ("bottle", False, True), ("bottle", True, False),
+                                                    ("laptop", True, True), ("mug", False, False), ("bed", True, True)])
+def test_vote_grid_and_argmax_match_oracle(oracle, dev, cat, adaptive, quantise):
+    ob, go, na, gg, flat, peak, dims = vote_case(oracle, dev, cat, 1024, 32, 11, adaptive, quantise)
+    assert na > 0
+    # identical set of touched cells and near-identical values (same votes, different fp32 sum order)
+    assert np.array_equal(go != 0, gg != 0)
+    np.testing.assert_allclose(gg, go, rtol=2e-5, atol=1e-5 * max(1.0, go.max()))
+    np.testing.assert_allclose(gg.sum(dtype=np.float64), na / 8, rtol=1e-5)     # checksum: total weight = #votes
+    oflat, opeak = oracle.grid_argmax(go)
+    srt = np.sort(go.reshape(-1))
+    assert srt[-1] - srt[-2] > 1e-4 * srt[-1], "fixture must have a dominant peak"
+    assert flat == oflat                                                        # bit-exact arg-max index
+    assert abs(peak - opeak) <= 2e-5 * opeak
+
+
+def test_vote_tiling_paths(oracle, dev):
+    # fine grid -> x and y tiles; very fine grid -> global-atomic fallback; coarse -> single tile
+    for res_scale, expect in ((1.0, "tiles"), (0.5, "tiles"), (0.2, "global"), (4.0, "one")):
+        ob, go, na, gg, flat, peak, dims = vote_case(oracle, dev, "bottle", 512, 16, 3, True, True,
+                                                     res_scale=res_scale)
+        G = int(np.prod(dims))
+        if expect == "global":
+            assert G > 16 * 32768
+        if expect == "one":
+            assert G <= 32768
+        np.testing.assert_allclose(gg, go, rtol=2e-5, atol=1e-5 * max(1.0, go.max()))
+        assert flat == oracle.grid_argmax(go)[0]
+    # wide-and-flat grid: forces y cuts (gy*gz > tile budget)
+    pc = np.array([[0, 0, 0], [0.02, 2.0, 0.5], [0.01, 1.0, 0.2], [0.0, 0.5, 0.4]], np.float32)
+    rng = np.random.default_rng(0)
+    idx32 = rng.integers(0, 4, (4096, 2)).astype(np.int32)
+    outputs = np.stack([rng.uniform(-0.2, 0.2, 4096), rng.uniform(0, 0.3, 4096)], -1).astype(np.float32)
+    corner = np.array([-0.02, -0.1, -0.1], np.float32)
+    dims = (6, 300, 140)                     # plane of 42 000 cells > tile budget: 2 y cuts x 6 x slabs
+    go, na = oracle_vote(oracle, pc, outputs, idx32, corner, dims, 0.01, 72, True)
+    gg, flat, peak = run_vote(dev, pc, outputs, idx32, corner, dims, 0.01, 72, True)
+    assert na > 0
+    np.testing.assert_allclose(gg, go, rtol=2e-5, atol=1e-5 * max(1.0, go.max()))
+
+
+def test_vote_edge_cases(oracle, dev):
+    pc = np.array([[0, 0, 0], [0.1, 0, 0], [0, 0.1, 0], [0, 0, 0.1]], np.float32)
+    corner = np.array([-0.2, -0.2, -0.2], np.float32)
+    idx = np.array([[0, 0], [1, 0], [2, 0], [3, 0], [1, 2], [2, 2]], np.int32)
+    out = np.array([[0.1, 0.05], [0.1, 0.003], [0.0, 0.01], [0.05, 0.25], [-0.1, 0.1], [0.1, 0.1]], np.float32)
+    probs = np.array([1.0, 0.5, 2.0, 0.25], np.float32)                        # prob = max(probs[a], probs[b])
+    for adaptive in (True, False):
+        for n_rots in (72, 7, 1, 100):
+            go, na = oracle_vote(oracle, pc, out, idx, corner, (20, 20, 20), 0.02, n_rots, adaptive, probs)
+            gg, flat, peak = run_vote(dev, pc, out, idx, corner, (20, 20, 20), 0.02, n_rots, adaptive, probs)
+            np.testing.assert_allclose(gg, go, rtol=1e-5, atol=1e-6)
+            assert flat == oracle.grid_argmax(go)[0]
+    # everything out of the grid: grid untouched, arg-max = first cell (np.argmax of zeros)
+    gg, flat, peak = run_vote(dev, pc, out, idx, corner + 5, (20, 20, 20), 0.02, 72, True)
+    assert gg.sum() == 0 and flat == 0 and peak == 0
+    # accumulation into a pre-filled grid (+=, like the reference's atomicAdd) and n_ppfs = 0
+    g0 = np.random.default_rng(1).random((20, 20, 20)).astype(np.float32)
+    go, _ = oracle_vote(oracle, pc, out, idx, corner, (20, 20, 20), 0.02, 72, True, grid0=g0)
+    gg, flat, _ = run_vote(dev, pc, out, idx, corner, (20, 20, 20), 0.02, 72, True, grid0=g0)
+    np.testing.assert_allclose(gg, go, rtol=1e-5, atol=1e-6)
+    assert flat == oracle.grid_argmax(go)[0]
+    gg, flat, _ = run_vote(dev, pc, out[:0], idx[:0], corner, (20, 20, 20), 0.02, 72, True, grid0=g0)
+    np.testing.assert_array_equal(gg, g0)
+    assert flat == int(np.argmax(g0))
+
+
+def test_ppf_kernel_drop_in_call_convention(oracle, dev):
+    """Called exactly like the reference's launch at nocs/inference.py:197-205."""
+    ob = syn.make_object("bottle", 256, 4)
+    cfg = ob["cfg"]
+    idx = syn.make_pairs(256, 8, 4)
+    outputs = syn.closed_form_outputs(ob["pc"], ob["center"], idx, cfg)
+    corner, dims = oracle.grid_setup(ob["pc"], cfg.res)
+    pc = ob["pc"]
+    block_size = (pc.shape[0] ** 2 + 512 - 1) // 512
+    grid_obj = torch.zeros(tuple(int(d) for d in dims), dtype=torch.float32, device=dev)
+    ret = voting.ppf_kernel(
+        (block_size, 1, 1), (512, 1, 1),
+        (t(pc, dev), t(outputs, dev), torch.ones(256, device=dev), t(idx, dev, torch.int32), grid_obj, t(corner, dev),
+         np.float32(cfg.res), idx.shape[0], 72, grid_obj.shape[0], grid_obj.shape[1], grid_obj.shape[2], True))
+    assert ret is None
+    go, _ = oracle_vote(oracle, pc, outputs, idx.astype(np.int32), corner, dims, cfg.res, 72, True)
+    np.testing.assert_allclose(grid_obj.cpu().numpy(), go, rtol=2e-5, atol=1e-5 * go.max())
+    with pytest.raises(TypeError):
+        voting.ppf_kernel((1, 1, 1), (512, 1, 1), (t(pc, dev),))
+    with pytest.raises(TypeError):
+        voting.ppf_kernel((1, 1, 1), (512, 1, 1),
+                          (t(pc, dev), t(outputs, dev), torch.ones(256, device=dev), t(idx, dev), grid_obj,
+                           t(corner, dev), cfg.res, idx.shape[0], 72, *grid_obj.shape, True))   # int64 idxs
+    with pytest.raises(ValueError):
+        voting.ppf_kernel((1, 1, 1), (512, 1, 1),
+                          (t(pc, dev), t(outputs, dev), torch.ones(256, device=dev), t(idx, dev, torch.int32),
+                           grid_obj, torch.from_numpy(corner), cfg.res, idx.shape[0], 72, *grid_obj.shape, True))
+
+
+def test_grid_argmax_tie_rule_and_negatives(dev):
+    L = _lib.lib()
+    rng = np.random.default_rng(0)
+    for n in (1, 63, 64, 65, 1000, 300001):
+        g = rng.integers(-5, 5, n).astype(np.float32)            # many ties
+        gt = t(g, dev)
+        oi = torch.empty(1, dtype=torch.int64, device=dev)
+        ov = torch.empty(1, dtype=torch.float32, device=dev)
+        _lib.check(L.cppf_grid_argmax(gt.data_ptr(), n, oi.data_ptr(), ov.data_ptr(), stream_ptr(dev)), "argmax")
+        assert int(oi.item()) == int(np.argmax(g)) and float(ov.item()) == g.max()
+    g = -np.abs(rng.normal(size=5000)).astype(np.float32) - 1      # all negative
+    gt = t(g, dev)
+    _lib.check(L.cppf_grid_argmax(gt.data_ptr(), g.size, oi.data_ptr(), ov.data_ptr(), stream_ptr(dev)), "argmax")
+    assert int(oi.item()) == int(np.argmax(g)) and float(ov.item()) == g.max()
+
+
+# ------------------------------------------------------------------------------------ back-vote / rot
+def test_backvote_compaction_bit_exact(oracle, dev):
+    ob = syn.make_object("bottle", 1024, 9)
+    cfg = ob["cfg"]
+    idx = syn.make_pairs(1024, 20, 9)
+    P = idx.shape[0]
+    outputs = syn.closed_form_outputs(ob["pc"], ob["center"], idx, cfg)
+    corner, dims = oracle.grid_setup(ob["pc"], cfg.res)
+    idx32 = idx.astype(np.int32)
+    center = (ob["center"] + 0.5 * cfg.res).astype(np.float32)
+    oo, mask = oracle.backvote(ob["pc"], outputs, idx32, corner, cfg.res, 72, dims, center, np.float32(3 * cfg.res))
+    # drop-in call (nocs/inference.py:219-228)
+    output_ocs = torch.zeros((P, 3), dtype=torch.float32, device=dev)
+    voting.backvote_kernel(((P + 511) // 512, 1, 1), (512, 1, 1),
+                           (t(ob["pc"], dev), t(outputs, dev), output_ocs, t(idx32, dev), t(corner, dev),
+                            np.float32(cfg.res), P, 72, int(dims[0]), int(dims[1]), int(dims[2]), t(center, dev),
+                            np.float32(3 * cfg.res)))
+    np.testing.assert_array_equal(output_ocs.cpu().numpy(), oo)
+    assert 0.05 < mask.mean() < 1
+    # C ABI with mask + compaction
+    L = _lib.lib()
+    m = torch.empty(P, dtype=torch.uint8, device=dev)
+    surv = torch.full((P,), -1, dtype=torch.int32, device=dev)
+    cnt = torch.empty(1, dtype=torch.int32, device=dev)
+    output_ocs.zero_()
+    _lib.check(L.cppf_backvote(t(ob["pc"], dev).data_ptr(), t(outputs, dev).data_ptr(), output_ocs.data_ptr(),
+                               t(idx32, dev).data_ptr(), t(corner, dev).data_ptr(), cfg.res, P, 72, int(dims[0]),
+                               int(dims[1]), int(dims[2]), t(center, dev).data_ptr(), float(np.float32(3 * cfg.res)),
+                               m.data_ptr(), stream_ptr(dev)), "backvote")
+    ws = workspace(L.cppf_compact_workspace_bytes(P), dev, "compact")
+    _lib.check(L.cppf_compact_mask(m.data_ptr(), P, surv.data_ptr(), cnt.data_ptr(), ws.data_ptr(), ws.numel(),
+                                   stream_ptr(dev)), "compact")
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(m.cpu().numpy().astype(bool), mask)
+    ref = np.nonzero(mask)[0]
+    assert int(cnt.item()) == ref.size
+    np.testing.assert_array_equal(surv.cpu().numpy()[:ref.size], ref)
+
+
+@pytest.mark.parametrize("n", [0, 1, 1023, 1024, 1025, 70000, 1200000])
+def test_compaction_sizes(dev, n):
+    L = _lib.lib()
+    rng = np.random.default_rng(n)
+    mask = (rng.random(n) < 0.37).astype(np.uint8)
+    m = t(mask, dev) if n else torch.empty(0, dtype=torch.uint8, device=dev)
+    surv = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    cnt = torch.full((1,), -7, dtype=torch.int32, device=dev)
+    ws = workspace(L.cppf_compact_workspace_bytes(n), dev, "compact")
+    _lib.check(L.cppf_compact_mask(m.data_ptr() if n else ws.data_ptr(), n, surv.data_ptr(), cnt.data_ptr(),
+                                   ws.data_ptr(), ws.numel(), stream_ptr(dev)), "compact")
+    ref = np.nonzero(mask)[0]
+    assert int(cnt.item()) == ref.size
+    np.testing.assert_array_equal(surv.cpu().numpy()[:ref.size], ref)
+
+
+def test_rot_voting_and_sphere_count_bit_exact(oracle, golden, dev):
+    ob = syn.make_object("camera", 512, 13)
+    idx = syn.make_pairs(512, 6, 13)
+    P = idx.shape[0]
+    idx32 = idx.astype(np.int32)
+    rng = np.random.default_rng(13)
+    theta = (rng.integers(0, 36, P) / 35 * np.pi).astype(np.float32)     # both sides of pi/2, incl. 0 and pi
+    co = oracle.rot_voting(ob["pc"], theta, idx32, 72)
+    candidates = torch.zeros((P, 72, 3), dtype=torch.float32, device=dev)
+    voting.rot_voting_kernel(((P + 511) // 512, 1, 1), (512, 1, 1),
+                             (t(ob["pc"], dev), torch.zeros((P, 2), device=dev), t(theta, dev), candidates,
+                              t(idx32, dev), torch.zeros(3, device=dev), np.float32(4e-3), P, 72, 10, 10, 10))
+    np.testing.assert_array_equal(candidates.cpu().numpy(), co)
+    # fused count on a selection, against the oracle's mm + threshold
+    sph = golden("sphere.npz")["pts"]
+    sel = np.sort(rng.choice(P, 700, replace=False)).astype(np.int32)
+    counts_o = oracle.sphere_count(co[sel[:500]], sph, 1.5)
+    L = _lib.lib()
+    counts = torch.zeros(480, dtype=torch.int32, device=dev)
+    nsel = torch.tensor([700], dtype=torch.int32, device=dev)
+    thr = float(np.float32(np.cos(1.5 / 180 * np.pi)))
+    _lib.check(L.cppf_rot_sphere_count(t(ob["pc"], dev).data_ptr(), t(theta, dev).data_ptr(), 1,
+                                       t(idx32, dev).data_ptr(), t(sel, dev).data_ptr(), nsel.data_ptr(), P, 500, 72,
+                                       t(sph.astype(np.float32), dev).data_ptr(), 480, thr, counts.data_ptr(),
+                                       stream_ptr(dev)), "rot_sphere_count")
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(counts.cpu().numpy().astype(np.int64), counts_o)
+    assert counts_o.sum() > 0
+
+
+def test_axis_sign_and_scale_sums(oracle, dev):
+    ob = syn.make_object("mug", 600, 21)
+    idx = syn.make_pairs(600, 10, 21)
+    P = idx.shape[0]
+    idx32 = idx.astype(np.int32)
+    rng = np.random.default_rng(21)
+    heads = rng.normal(0, 1.5, (P, 8)).astype(np.float32)
+    sel = np.sort(rng.choice(P, 2500, replace=False)).astype(np.int32)
+    bd = np.array([0.2, 0.95, -0.1])
+    bd /= np.linalg.norm(bd)
+    flip, (up, down) = oracle.axis_sign(ob["pc"], ob["normals"], idx32[sel], heads[sel, 3], bd)
+    L = _lib.lib()
+    out = torch.empty(3, dtype=torch.float64, device=dev)
+    out4 = torch.empty(4, dtype=torch.float64, device=dev)
+    ws = workspace(L.cppf_reduce_workspace_bytes(), dev, "reduce")
+    nsel = torch.tensor([2500], dtype=torch.int32, device=dev)
+    hd = t(heads, dev)
+    _lib.check(L.cppf_axis_sign(t(ob["pc"], dev).data_ptr(), t(ob["normals"], dev).data_ptr(), t(idx32, dev).data_ptr(),
+                                t(sel, dev).data_ptr(), nsel.data_ptr(), P, hd.data_ptr() + 12, 8, t(bd, dev).data_ptr(),
+                                out.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr(dev)), "axis_sign")
+    _lib.check(L.cppf_scale_sum(hd.data_ptr() + 16, 8, t(sel, dev).data_ptr(), nsel.data_ptr(), P, out4.data_ptr(),
+                                ws.data_ptr(), ws.numel(), stream_ptr(dev)), "scale_sum")
+    o, o4 = out.cpu().numpy(), out4.cpu().numpy()
+    assert o[2] == 2500 and o4[3] == 2500
+    np.testing.assert_allclose([o[0] / 2500, o[1] / 2500], [up, down], rtol=1e-12)
+    np.testing.assert_allclose(o4[:3], heads[sel, 4:7].astype(np.float64).sum(0), rtol=1e-12)
+    sc = oracle.scale(heads[sel, 4:7], [0.06, 0.05, 0.045])
+    mean = (o4[:3] / 2500).astype(np.float32)
+    np.testing.assert_allclose(np.exp(mean).astype(np.float64) * np.array([0.06, 0.05, 0.045]) * 2, sc, rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------------ end to end
+@pytest.mark.parametrize("cat", ["bottle", "camera"])
+def test_estimate_pose_matches_oracle_chain(oracle, golden, dev, cat):
+    from cppf_amd.inference import estimate_pose
+    ob = syn.make_object(cat, 1024, 31)
+    cfg = ob["cfg"]
+    idx = syn.make_pairs(1024, 32, 31)
+    P = idx.shape[0]
+    u_tr, u_rot = syn.make_uniforms(P, 31)
+    sd = seeded_sd(0)
+    for k in ("final.weight", "final.bias"):
+        sd[k] = sd[k] * 4
+    enc = make_encoder(sd, [84, 32, 32, 16], 141, dev)
+    sph = golden("sphere.npz")["pts"]
+    with torch.no_grad():
+        r = estimate_pose(enc, t(ob["pc"], dev), t(ob["normals"], dev), t(ob["feat"], dev), t(idx, dev), t(u_tr, dev),
+                          t(u_rot, dev), cfg, sph, pc_host=ob["pc"])
+    ocfg = dict(res=cfg.res, tr_num_bins=32, rot_num_bins=36, vote_range=cfg.vote_range, scale_mean=cfg.scale_mean,
+                regress_right=cfg.regress_right, ppffcs=[84, 32, 32, 16], out_dim=141)
+    o = oracle.estimate_pose(ob["pc"], ob["normals"], ob["feat"], idx, sd, ocfg, u_tr, u_rot, sph)
+    np.testing.assert_array_equal(r["outputs"].cpu().numpy(), o["outputs"])
+    np.testing.assert_array_equal(r["heads"].cpu().numpy(), o["heads"])
+    assert r["argmax"] == o["argmax"]                                   # bit-exact vote-grid arg-max
+    np.testing.assert_allclose(r["T"], o["T"], rtol=0, atol=1e-12)
+    assert r["n_surv"] == int(o["mask"].sum())
+    np.testing.assert_array_equal(r["ws"].mask.cpu().numpy().astype(bool), o["mask"])
+    np.testing.assert_allclose(r["up"], o["up"], atol=1e-12)
+    if cfg.regress_right:
+        assert r["best_right"] is not None
+    np.testing.assert_allclose(r["scale"], o["scale"], rtol=1e-6)       # <= 1e-4 bar of the north star
+    np.testing.assert_allclose(r["peak"], o["peak"], rtol=2e-5)
+
+
+# ------------------------------------------------------------------------------------ full-size properties
+def test_full_size_properties_c2(dev):
+    """N=4096, K=128 (BASELINE.json config 2): size-independent properties, no oracle."""
+    ob = syn.make_object("bottle", 4096, 0)
+    cfg = ob["cfg"]
+    idx = syn.make_pairs(4096, 128, 0)
+    P = idx.shape[0]
+    outputs = syn.closed_form_outputs(ob["pc"], ob["center"], idx, cfg, quantise=True)
+    from cppf_amd.inference import grid_shape
+    corners, dims = grid_shape(ob["pc"], cfg.res)
+    corner = corners[0]
+    idx32 = idx.astype(np.int32)
+    g1, flat1, peak1 = run_vote(dev, ob["pc"], outputs, idx32, corner, dims, cfg.res, 72, True)
+    # known answer: the arg-max is the cell holding the true centre (utils/dataset.py:27-36)
+    cell = np.array(np.unravel_index(flat1, dims))
+    assert np.all(np.abs(cell - (ob["center"] - corner) / cfg.res) <= 1.0)
+    # permutation invariance of the pairs (same multiset of votes)
+    perm = np.random.default_rng(0).permutation(P)
+    g2, flat2, _ = run_vote(dev, ob["pc"], outputs[perm], idx32[perm], corner, dims, cfg.res, 72, True)
+    assert flat2 == flat1
+    np.testing.assert_allclose(g2, g1, rtol=1e-4, atol=1e-4 * g1.max())
+    # linearity: voting twice into the same grid doubles it
+    g3, flat3, _ = run_vote(dev, ob["pc"], outputs, idx32, corner, dims, cfg.res, 72, True, grid0=g1)
+    np.testing.assert_allclose(g3, 2 * g1, rtol=1e-4, atol=1e-4 * g1.max())
+    assert flat3 == flat1
+    # probs scale the grid: probs = 0.5 halves every vote exactly
+    gh, flath, _ = run_vote(dev, ob["pc"], outputs, idx32, corner, dims, cfg.res, 72, True,
+                            probs=np.full(4096, 0.5, np.float32))
+    np.testing.assert_allclose(gh, 0.5 * g1, rtol=1e-4, atol=1e-4 * g1.max())
+    # checksum: total mass is an integer count of in-grid votes, <= 72 per pair
+    mass = g1.sum(dtype=np.float64)
+    assert abs(mass - round(mass)) < 1e-3 * mass ** 0.5 + 0.5 and mass <= 72.0 * P
+    # non-adaptive deposits at least as much mass
+    g4, _, _ = run_vote(dev, ob["pc"], outputs, idx32, corner, dims, cfg.res, 72, False)
+    assert g4.sum(dtype=np.float64) >= mass * 0.999
