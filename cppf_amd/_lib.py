@@ -61,6 +61,10 @@ def lib():
         if not os.path.exists(_SO):
             raise CppfError(f"{_SO} is missing: build it with `make -C cppf_amd/csrc` "
                             "(or __graft_entry__.build()); cppf_amd has no CPU fallback")
+        # torch bundles its own HIP runtime (same soname as /opt/rocm's): import it first so that this
+        # library binds to the runtime torch's tensors and streams live in.  Loading in the other
+        # order puts two runtimes' worth of state in one process ("no ROCm-capable device").
+        import torch  # noqa: F401
         L = C.CDLL(_SO)
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)  # AttributeError = ABI mismatch, also loud

@@ -703,8 +703,9 @@ extern "C" int cppf_pair_mlp_forward(const float* pc, const float* nrm, const fl
                                      int64_t P, int out_dim, float* out, void* stream)
 {
     (void)N;
-    if (!pc || !nrm || !feat || !idxs || !packed || !dims || !out || P < 0) return CPPF_EINVAL;
-    if (P == 0) return 0;
+    if (P < 0 || !dims) return CPPF_EINVAL;
+    if (P == 0) return 0;  // empty pair list: nothing to do, pointers may be null
+    if (!pc || !nrm || !feat || !idxs || !packed || !out) return CPPF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (is_std(F, dims, n_res, out_dim)) {
         MlpArgs A = {};
@@ -738,10 +739,11 @@ extern "C" int cppf_pair_mlp_decode(const float* pc, const float* nrm, const flo
                                     const float* u_tr, const float* u_rot, float* outputs, float* heads, void* stream)
 {
     (void)N;
-    if (!pc || !nrm || !feat || !idxs || !packed || !dims || !u_tr || !outputs || P < 0) return CPPF_EINVAL;
-    if ((heads != nullptr) != (u_rot != nullptr)) return CPPF_EINVAL;
+    if (P < 0 || !dims) return CPPF_EINVAL;
     if (!is_std(F, dims, n_res, out_dim) || tr_bins != 32 || rot_bins != 36 || out_dim != 141) return CPPF_EUNSUPPORTED;
     if (P == 0) return 0;
+    if (!pc || !nrm || !feat || !idxs || !packed || !u_tr || !outputs) return CPPF_EINVAL;
+    if ((heads != nullptr) != (u_rot != nullptr)) return CPPF_EINVAL;
     MlpArgs A = {};
     A.pc = pc; A.nrm = nrm; A.feat = feat; A.idxs = idxs; A.packed = packed; A.P = P; A.out_dim = out_dim;
     A.idx64 = idx_is_i64; A.u_tr = u_tr; A.u_rot = u_rot; A.outputs = outputs; A.heads = heads; A.vr0 = vr0; A.vr1 = vr1;
@@ -751,8 +753,9 @@ extern "C" int cppf_pair_mlp_decode(const float* pc, const float* nrm, const flo
 extern "C" int cppf_decode_center(const float* logits, int64_t P, int ld, int tr_bins, float vr0, float vr1,
                                   const float* u_tr, float* outputs, void* stream)
 {
-    if (!logits || !u_tr || !outputs || P < 0 || tr_bins < 2 || ld < 2 * tr_bins) return CPPF_EINVAL;
+    if (P < 0 || tr_bins < 2 || ld < 2 * tr_bins) return CPPF_EINVAL;
     if (P == 0) return 0;
+    if (!logits || !u_tr || !outputs) return CPPF_EINVAL;
     hipLaunchKernelGGL(decode_center_kernel, dim3((unsigned)((2 * P + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        logits, P, ld, tr_bins, vr0, vr1, u_tr, outputs);
     CPPF_CHECK_LAUNCH();
@@ -762,9 +765,9 @@ extern "C" int cppf_decode_center(const float* logits, int64_t P, int ld, int tr
 extern "C" int cppf_decode_rot(const float* logits, int64_t P, int ld, int out_dim, int tr_bins, int rot_bins,
                                const float* u_rot, float* heads, void* stream)
 {
-    if (!logits || !u_rot || !heads || P < 0 || rot_bins < 2 || out_dim < 2 * tr_bins + 2 * rot_bins + 5 || ld < out_dim)
-        return CPPF_EINVAL;
+    if (P < 0 || rot_bins < 2 || out_dim < 2 * tr_bins + 2 * rot_bins + 5 || ld < out_dim) return CPPF_EINVAL;
     if (P == 0) return 0;
+    if (!logits || !u_rot || !heads) return CPPF_EINVAL;
     hipLaunchKernelGGL(decode_rot_kernel, dim3((unsigned)((2 * P + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        logits, P, ld, out_dim, tr_bins, rot_bins, u_rot, heads);
     CPPF_CHECK_LAUNCH();

@@ -270,7 +270,8 @@ static int vote_impl(const float* points, const float* outputs, const float* pro
                      int gz, int adaptive, bool want_argmax, long long* out_idx, float* out_val, void* workspace,
                      size_t workspace_bytes, hipStream_t st)
 {
-    if (!points || !outputs || !probs || !point_idxs || !grid_obj || !corner) return CPPF_EINVAL;
+    if (!points || !probs || !grid_obj || !corner) return CPPF_EINVAL;
+    if (n_ppfs > 0 && (!outputs || !point_idxs)) return CPPF_EINVAL;
     if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || gx < 1 || gy < 1 || gz < 1 || n_ppfs < 0) return CPPF_EINVAL;
     if ((int64_t)gx * gy * gz > 0x7fffffffll) return CPPF_EINVAL;
     VotePlan pl = make_vote_plan(n_ppfs, n_rots, gx, gy, gz);
@@ -464,9 +465,9 @@ extern "C" int cppf_backvote(const float* points, const float* outputs, float* o
                              const int32_t* point_idxs, const float* corner, float res, int64_t n_ppfs, int n_rots,
                              int gx, int gy, int gz, const float* gt_center, float tol, uint8_t* mask, void* stream)
 {
-    if (!points || !outputs || !out_offsets || !point_idxs || !corner || !gt_center) return CPPF_EINVAL;
     if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || n_ppfs < 0) return CPPF_EINVAL;
     if (n_ppfs == 0) return 0;
+    if (!points || !outputs || !out_offsets || !point_idxs || !corner || !gt_center) return CPPF_EINVAL;
     const int entries = tri(n_rots);
     const size_t lds = entries <= VOTE_TAB_LDS_MAX ? (size_t)entries * sizeof(float2) : 0;
     int64_t nb = (n_ppfs + 255) / 256;
@@ -555,7 +556,7 @@ extern "C" size_t cppf_compact_workspace_bytes(int64_t n)
 extern "C" int cppf_compact_mask(const uint8_t* mask, int64_t n, int32_t* surv, int32_t* count, void* workspace,
                                  size_t workspace_bytes, void* stream)
 {
-    if (!mask || !surv || !count || n < 0 || n > 0x7fffffffll) return CPPF_EINVAL;
+    if ((n > 0 && (!mask || !surv)) || !count || n < 0 || n > 0x7fffffffll) return CPPF_EINVAL;
     if (!workspace || workspace_bytes < cppf_compact_workspace_bytes(n)) return CPPF_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     int32_t* bc = static_cast<int32_t*>(workspace);
@@ -630,9 +631,9 @@ __global__ __launch_bounds__(256) void rot_voting_kernel(const float* __restrict
 extern "C" int cppf_rot_voting(const float* points, const float* preds_rot, float* outputs_up,
                                const int32_t* point_idxs, int64_t n_ppfs, int n_rots, void* stream)
 {
-    if (!points || !preds_rot || !outputs_up || !point_idxs) return CPPF_EINVAL;
     if (n_rots < 1 || n_rots > 4096 || n_ppfs < 0) return CPPF_EINVAL;
     if (n_ppfs == 0) return 0;
+    if (!points || !preds_rot || !outputs_up || !point_idxs) return CPPF_EINVAL;
     const int64_t nb = (n_ppfs + ROT_PPB - 1) / ROT_PPB;
     hipLaunchKernelGGL(rot_voting_kernel, dim3((unsigned)nb), dim3(256), (size_t)n_rots * sizeof(float2),
                        (hipStream_t)stream, points, preds_rot, outputs_up, point_idxs, n_ppfs, n_rots);

@@ -41,6 +41,9 @@ def test_workspace_queries_and_argument_errors_without_a_device():
     assert L.cppf_backvote(None, None, None, None, None, 0.004, 10, 72, 4, 4, 4, None, 0.01, None, None) == -1
     assert L.cppf_grid_argmax(None, 10, None, None, None) == -1
     assert L.cppf_rot_voting(None, None, None, None, 10, 72, None) == -1
+    # empty pair lists are legal no-ops (ragged inputs), with null pointers
+    assert L.cppf_backvote(None, None, None, None, None, 0.004, 0, 72, 4, 4, 4, None, 0.01, None, None) == 0
+    assert L.cppf_rot_voting(None, None, None, None, 0, 72, None) == 0
 
 
 def test_weight_packing_follows_the_documented_lane_order(golden):

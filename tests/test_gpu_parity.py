@@ -125,9 +125,10 @@ def test_fused_decode_bit_exact(oracle, dev):
     L = _lib.lib()
     out2 = torch.empty_like(outputs)
     heads2 = torch.empty_like(heads)
+    utr_d, urot_d = t(u_tr, dev), t(u_rot, dev)
     _lib.check(L.cppf_decode_center(logits.data_ptr(), P, 141, 32, cfg.vote_range[0], cfg.vote_range[1],
-                                    t(u_tr, dev).data_ptr(), out2.data_ptr(), stream_ptr(dev)), "decode_center")
-    _lib.check(L.cppf_decode_rot(logits.data_ptr(), P, 141, 141, 32, 36, t(u_rot, dev).data_ptr(), heads2.data_ptr(),
+                                    utr_d.data_ptr(), out2.data_ptr(), stream_ptr(dev)), "decode_center")
+    _lib.check(L.cppf_decode_rot(logits.data_ptr(), P, 141, 141, 32, 36, urot_d.data_ptr(), heads2.data_ptr(),
                                  stream_ptr(dev)), "decode_rot")
     torch.cuda.synchronize()
     assert torch.equal(out2, outputs) and torch.equal(heads2, heads)
@@ -304,9 +305,11 @@ def test_backvote_compaction_bit_exact(oracle, dev):
     surv = torch.full((P,), -1, dtype=torch.int32, device=dev)
     cnt = torch.empty(1, dtype=torch.int32, device=dev)
     output_ocs.zero_()
-    _lib.check(L.cppf_backvote(t(ob["pc"], dev).data_ptr(), t(outputs, dev).data_ptr(), output_ocs.data_ptr(),
-                               t(idx32, dev).data_ptr(), t(corner, dev).data_ptr(), cfg.res, P, 72, int(dims[0]),
-                               int(dims[1]), int(dims[2]), t(center, dev).data_ptr(), float(np.float32(3 * cfg.res)),
+    # (device tensors are kept in named variables: a temporary's data_ptr() dangles once it is freed)
+    pc_d, out_d, idx_d, cor_d, cen_d = t(ob["pc"], dev), t(outputs, dev), t(idx32, dev), t(corner, dev), t(center, dev)
+    _lib.check(L.cppf_backvote(pc_d.data_ptr(), out_d.data_ptr(), output_ocs.data_ptr(),
+                               idx_d.data_ptr(), cor_d.data_ptr(), cfg.res, P, 72, int(dims[0]),
+                               int(dims[1]), int(dims[2]), cen_d.data_ptr(), float(np.float32(3 * cfg.res)),
                                m.data_ptr(), stream_ptr(dev)), "backvote")
     ws = workspace(L.cppf_compact_workspace_bytes(P), dev, "compact")
     _lib.check(L.cppf_compact_mask(m.data_ptr(), P, surv.data_ptr(), cnt.data_ptr(), ws.data_ptr(), ws.numel(),
@@ -355,9 +358,10 @@ def test_rot_voting_and_sphere_count_bit_exact(oracle, golden, dev):
     counts = torch.zeros(480, dtype=torch.int32, device=dev)
     nsel = torch.tensor([700], dtype=torch.int32, device=dev)
     thr = float(np.float32(np.cos(1.5 / 180 * np.pi)))
-    _lib.check(L.cppf_rot_sphere_count(t(ob["pc"], dev).data_ptr(), t(theta, dev).data_ptr(), 1,
-                                       t(idx32, dev).data_ptr(), t(sel, dev).data_ptr(), nsel.data_ptr(), P, 500, 72,
-                                       t(sph.astype(np.float32), dev).data_ptr(), 480, thr, counts.data_ptr(),
+    pc_d, th_d, idx_d, sel_d, sph_d = t(ob["pc"], dev), t(theta, dev), t(idx32, dev), t(sel, dev), t(sph.astype(np.float32), dev)
+    _lib.check(L.cppf_rot_sphere_count(pc_d.data_ptr(), th_d.data_ptr(), 1,
+                                       idx_d.data_ptr(), sel_d.data_ptr(), nsel.data_ptr(), P, 500, 72,
+                                       sph_d.data_ptr(), 480, thr, counts.data_ptr(),
                                        stream_ptr(dev)), "rot_sphere_count")
     torch.cuda.synchronize()
     np.testing.assert_array_equal(counts.cpu().numpy().astype(np.int64), counts_o)
@@ -381,10 +385,11 @@ def test_axis_sign_and_scale_sums(oracle, dev):
     ws = workspace(L.cppf_reduce_workspace_bytes(), dev, "reduce")
     nsel = torch.tensor([2500], dtype=torch.int32, device=dev)
     hd = t(heads, dev)
-    _lib.check(L.cppf_axis_sign(t(ob["pc"], dev).data_ptr(), t(ob["normals"], dev).data_ptr(), t(idx32, dev).data_ptr(),
-                                t(sel, dev).data_ptr(), nsel.data_ptr(), P, hd.data_ptr() + 12, 8, t(bd, dev).data_ptr(),
+    pc_d, n_d, idx_d, sel_d, bd_d = t(ob["pc"], dev), t(ob["normals"], dev), t(idx32, dev), t(sel, dev), t(bd, dev)
+    _lib.check(L.cppf_axis_sign(pc_d.data_ptr(), n_d.data_ptr(), idx_d.data_ptr(),
+                                sel_d.data_ptr(), nsel.data_ptr(), P, hd.data_ptr() + 12, 8, bd_d.data_ptr(),
                                 out.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr(dev)), "axis_sign")
-    _lib.check(L.cppf_scale_sum(hd.data_ptr() + 16, 8, t(sel, dev).data_ptr(), nsel.data_ptr(), P, out4.data_ptr(),
+    _lib.check(L.cppf_scale_sum(hd.data_ptr() + 16, 8, sel_d.data_ptr(), nsel.data_ptr(), P, out4.data_ptr(),
                                 ws.data_ptr(), ws.numel(), stream_ptr(dev)), "scale_sum")
     o, o4 = out.cpu().numpy(), out4.cpu().numpy()
     assert o[2] == 2500 and o4[3] == 2500
