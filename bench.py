@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 import cppf_amd.synthetic as syn                      # noqa: E402
 from cppf_amd import sharding                         # noqa: E402
 from cppf_amd.inference import PoseWorkspace, estimate_center, grid_shape   # noqa: E402
+from cppf_amd.models import voting                    # noqa: E402
 from cppf_amd.models.model import PPFEncoder         # noqa: E402
 
 N_POINTS, PAIRS_PER_POINT, NUM_ROTS = 4096, 128, 72
@@ -100,11 +101,9 @@ def main():
                                                 cfg.tr_num_bins, cfg.rot_num_bins)
             if k is not None:
                 ev[k][1].record()
-            ws.grid.zero_()
-            from cppf_amd.models import voting
             kk = 0 if k is None else k
             voting.vote_argmax(pc, outputs, ws.probs, idx32, ws.grid, corner_d, cfg.res, NUM_ROTS, True,
-                               idx_all[kk:kk + 1], val_all[kk:kk + 1])
+                               idx_all[kk:kk + 1], val_all[kk:kk + 1], accumulate=False)
             if k is not None:
                 ev[k][2].record()
 

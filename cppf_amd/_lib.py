@@ -14,9 +14,11 @@ _SIGS = {
     "cppf_abi_version": (C.c_int, []),
     "cppf_error_string": (C.c_char_p, [C.c_int]),
     "cppf_vote_workspace_bytes": (sz, [i64, i32, i32, i32, i32]),
-    "cppf_ppf_voting": (C.c_int, [vp, vp, vp, vp, vp, vp, f32, i64, i32, i32, i32, i32, i32, vp, sz, vp]),
-    "cppf_vote_argmax": (C.c_int, [vp, vp, vp, vp, vp, vp, f32, i64, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
-    "cppf_grid_argmax": (C.c_int, [vp, i64, vp, vp, vp]),
+    "cppf_vote_fixed_point_bits": (C.c_int, [i64, i32, i32, i32, i32]),
+    "cppf_ppf_voting": (C.c_int, [vp, vp, vp, vp, vp, vp, f32, i64, i64, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "cppf_vote_argmax": (C.c_int, [vp, vp, vp, vp, vp, vp, f32, i64, i64, i32, i32, i32, i32, i32, i32, vp, vp, vp, sz,
+                                   vp]),
+    "cppf_grid_argmax": (C.c_int, [vp, i64, vp, vp, vp, sz, vp]),
     "cppf_center_from_argmax": (C.c_int, [vp, vp, C.c_double, i32, i32, vp, vp, vp]),
     "cppf_backvote": (C.c_int, [vp, vp, vp, vp, vp, f32, i64, i32, i32, i32, i32, vp, f32, vp, vp]),
     "cppf_compact_workspace_bytes": (sz, [i64]),

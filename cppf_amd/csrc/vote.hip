@@ -16,21 +16,25 @@ using namespace cppf;
     } while (0)
 
 // ----------------------------------------------------------------------------- rotation table
-// tab[n*(n-1)/2 + i] = (cos, sin) of rotation i of n, n = 1..n_rots.  Built per call into the
-// caller's workspace (a 2.6k-entry kernel for n_rots = 72); vote workgroups copy it to LDS.
-__global__ void rot_table_kernel(float2* __restrict__ tab, int n_rots)
+// tab[n*(n-1)/2 + i] = (cos, sin) of rotation i of n, n = 1..n_rots: every workgroup that needs it
+// builds it in LDS in its prologue (2 628 entries for n_rots = 72, ~3 fp64 sincos per thread).
+__device__ __forceinline__ void fill_rot_table(float2* ltab, int entries, int tid, int nthreads)
 {
-    int n = blockIdx.x + 1;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) tab[n * (n - 1) / 2 + i] = rot_cs(i, n);
+    for (int e = tid; e < entries; e += nthreads) {
+        int n = (int)((sqrtf(8.f * (float)e + 1.f) + 1.f) * 0.5f);
+        while (n * (n - 1) / 2 > e) --n;
+        while ((n + 1) * n / 2 <= e) ++n;
+        ltab[e] = rot_cs(e - n * (n - 1) / 2, n);
+    }
 }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int tri(int n) { return n * (n + 1) / 2; }
 
 // ----------------------------------------------------------------------------- vote plan
-#define VOTE_TILE_FLOATS 32768  // 128 KiB of the CU's 160 KiB LDS for the grid tile
-#define VOTE_TAB_LDS_MAX 3600   // (cos,sin) pairs kept in LDS (n_rots <= 84); else read via L1/L2
-#define VOTE_MAX_TILES 16       // beyond this the geometry redundancy costs more than L2 atomics
+#define VOTE_TILE_FLOATS 32512  // 127 KiB of the CU's 160 KiB LDS for the grid tile (4 KiB rings, 8 KiB carry log, 21 KiB table)
+#define VOTE_TAB_LDS_MAX 2628   // (cos,sin) pairs kept in LDS (n_rots <= 72); else computed per sample
+#define VOTE_MAX_TILES 16       // beyond this, L2 atomics beat re-walking the pairs once per tile
 #define VOTE_THREADS 1024
 
 struct VotePlan {
@@ -39,7 +43,7 @@ struct VotePlan {
     int ntx, nty, T;      // tiles per axis, total
     int chunks;           // pair chunks (= partial grids)
     int64_t chunk_pairs;  // pairs per chunk
-    size_t tab_off, packed_off, part_off, total;
+    size_t packed_off, part_off, total;
     int tab_entries;
 };
 
@@ -76,11 +80,27 @@ static VotePlan make_vote_plan(int64_t n_ppfs, int n_rots, int gx, int gy, int g
         p.chunks = 0;
         p.chunk_pairs = 0;
     }
-    p.tab_off = 0;
-    p.packed_off = align_up((size_t)p.tab_entries * sizeof(float2), 256);
-    p.part_off = p.packed_off + 256;
+    p.packed_off = 0;   // u64 packed arg-max key + u32 ticket counter
+    p.part_off = 256;
     p.total = p.part_off + (size_t)p.chunks * (size_t)G * sizeof(float);
     return p;
+}
+
+// fixed-point bits of the largest weight: a workgroup deposits at most chunk_pairs*n_rots*(2^kk + 4) in
+// total, and every 2^32 of that is one carry-log entry (VOTE_CARRY_CAP of them)
+static int vote_fixed_bits(const VotePlan& pl, int n_rots)
+{
+    if (!pl.tiled) return 0;
+    const double cap = 2048.0 * 4294967296.0 / ((double)(pl.chunk_pairs > 0 ? pl.chunk_pairs : 1) * n_rots) - 4.0;
+    int kk = 24;
+    while (kk > 8 && (double)(1u << kk) > cap) --kk;
+    return kk;
+}
+
+extern "C" int cppf_vote_fixed_point_bits(int64_t n_ppfs, int n_rots, int gx, int gy, int gz)
+{
+    if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || gx < 1 || gy < 1 || gz < 1 || n_ppfs < 0) return -1;
+    return vote_fixed_bits(make_vote_plan(n_ppfs, n_rots, gx, gy, gz), n_rots);
 }
 
 extern "C" size_t cppf_vote_workspace_bytes(int64_t n_ppfs, int n_rots, int gx, int gy, int gz)
@@ -90,11 +110,34 @@ extern "C" size_t cppf_vote_workspace_bytes(int64_t n_ppfs, int n_rots, int gx, 
 }
 
 // ----------------------------------------------------------------------------- centre vote
-// Reference: CUDA ppf_voting, models/voting.py:8-66.  One pair per lane, rotations in a loop.
+// Reference: CUDA ppf_voting, models/voting.py:8-66.
 // TILED: the workgroup owns grid tile (x0..x0+tx, y0..y0+ty, all z) in LDS and pair chunk c; every
-// corner of every vote that falls into the tile is added with ds_add_f32; the tile is then stored
-// to partial grid c.  Cells belong to exactly one tile, so a partial grid is written exactly once.
+// corner of every vote that falls into the tile is accumulated there; the tile is then stored to
+// partial grid c.  Cells belong to exactly one tile, so a partial grid is written exactly once.
 // !TILED: global_atomic_add_f32 straight into grid_obj (large grids).
+//
+// LDS accumulation is 32-bit FIXED POINT: on gfx950 ds_add_f32 costs ~195 cycles per wave
+// instruction (3 cycles/lane, any address pattern) while ds_add_rtn_u32 costs ~22
+// (profiles/microbench/atomics_bench.hip).  A weight w is deposited as rn(w * S), S = 2^kk / p2 with
+// p2 = max(probs) rounded up to a power of two and kk <= 24 chosen by the host so that the number of
+// 32-bit wrap-arounds a workgroup can produce fits the carry log; a wrap-around (detected on the
+// returned old value) appends the cell to that log and is added back as 2^32/S when the tile is
+// converted to fp32.  With kk = 24 the quantum is 2^-24 of the largest weight: each deposit is
+// exact to fp32 precision and the sum is order-independent, i.e. at least as accurate as any order
+// of the reference's fp32 atomicAdd.  Negative / non-finite probs fall back to ds_add_f32.
+//
+// Two stages per wave, decoupled by a 128-entry ring of 16-bit codes in LDS so that the expensive
+// stage always runs with full lanes (a plain one-pair-per-lane loop executes the union of all lanes'
+// branches):
+//   screen  one pair per lane, rotations in a loop, everything pre-scaled by ~1/res:
+//           q = cq + cos*xq + sin*yq against the tile's acceptance box widened by more than the
+//           approximation error (no sample the exact test accepts is ever dropped); survivors push
+//           (lane, rotation) to the ring in ballot order;
+//   deposit whenever the ring holds >= 64 codes every lane pops one, pulls the owning lane's pair
+//           frame with ds_bpermute, and does the exact work of the reference: offset, the three
+//           correctly rounded divisions, the bound tests, trilinear weights, 8 atomics.
+#define VOTE_RING 128
+#define VOTE_CARRY_CAP 2048
 struct VoteArgs {
     const float* points;
     const float* outputs;
@@ -103,27 +146,126 @@ struct VoteArgs {
     float* grid;       // !TILED target
     float* partials;   // TILED target [chunks][G]
     const float* corner;
-    const float2* tab;
-    unsigned long long* packed;  // arg-max scratch, zeroed here for the reduce kernel
+    unsigned long long* packed;  // arg-max key + ticket, zeroed here for the reduce kernel
     float res;
-    int64_t n_ppfs;
+    int64_t n_ppfs, n_points;
     int n_rots, gx, gy, gz, adaptive;
     int tx, ty, ntx, nty, T;
     int64_t chunk_pairs;
     int tab_entries;
+    int kk;            // fixed-point bits of the largest weight
 };
+
+struct VoteTile {
+    float* tile;   // LDS tile (TILED) or grid_obj (!TILED)
+    uint32_t* carry_log;
+    int* carry_n;
+    int x0, y0, tx, ty, gz, ltyz, syz;
+    float res, S;  // S > 0: fixed-point scale; S == 0: fp32 atomics
+    float lo, hx, hy, hz;  // fp32 thresholds equivalent to the reference's fp64 tests
+};
+
+// (double)g < 0.01  <=>  g < smallest float >= 0.01 ;  (double)g >= d  <=>  g >= smallest float >= d
+__device__ __forceinline__ float ceil_to_float(double d)
+{
+    float f = (float)d;
+    if ((double)f < d) f = __uint_as_float(__float_as_uint(f) + (f > 0.f ? 1u : -1u));
+    return f;
+}
+
+__device__ __forceinline__ void fixed_add(const VoteTile& T, int idx, float w)
+{
+    uint32_t* p = reinterpret_cast<uint32_t*>(T.tile) + idx;
+    const uint32_t inc = __float2uint_rn(w * T.S);
+    const uint32_t old = atomicAdd(p, inc);
+    if (old + inc < old) {  // wrapped: remember the cell, 2^32/S is added back at the flush
+        const int slot = atomicAdd(T.carry_n, 1);
+        if (slot < VOTE_CARRY_CAP) T.carry_log[slot] = (uint32_t)idx;
+    }
+}
+
+template <bool TILED>
+__device__ __forceinline__ void vote_deposit(const VoteTile& T, f3 v, float prob)
+{
+    const f3 g = div3(v, T.res);                                   // :35
+    if (g.x < T.lo || g.y < T.lo || g.z < T.lo || g.x >= T.hx || g.y >= T.hy || g.z >= T.hz)
+        return;                                                    // :36-39, fp64 tests folded to fp32 thresholds
+    const int fx = (int)g.x, fy = (int)g.y, fz = (int)g.z;         // :40
+    const float rx = g.x - floorf(g.x), ry = g.y - floorf(g.y), rz = g.z - floorf(g.z);
+    const float w0x = 1.f - rx, w0y = 1.f - ry, w0z = 1.f - rz;
+    const float ll = w0x * w0y, lh = w0x * ry, hl = rx * w0y, hh = rx * ry;
+    const float lll = ll * w0z * prob, llh = ll * rz * prob, lhl = lh * w0z * prob, lhh = lh * rz * prob;
+    const float hll = hl * w0z * prob, hlh = hl * rz * prob, hhl = hh * w0z * prob, hhh = hh * rz * prob;
+    if (TILED) {
+        const int lx = fx - T.x0, ly = fy - T.y0;
+        const bool x0in = (unsigned)lx < (unsigned)T.tx, x1in = (unsigned)(lx + 1) < (unsigned)T.tx;
+        const bool y0in = (unsigned)ly < (unsigned)T.ty, y1in = (unsigned)(ly + 1) < (unsigned)T.ty;
+        const int b = (lx * T.ty + ly) * T.gz + fz;
+        if (T.S > 0.f) {
+            if (x0in & y0in) { fixed_add(T, b, lll); fixed_add(T, b + 1, llh); }
+            if (x0in & y1in) { fixed_add(T, b + T.gz, lhl); fixed_add(T, b + T.gz + 1, lhh); }
+            if (x1in & y0in) { fixed_add(T, b + T.ltyz, hll); fixed_add(T, b + T.ltyz + 1, hlh); }
+            if (x1in & y1in) { fixed_add(T, b + T.ltyz + T.gz, hhl); fixed_add(T, b + T.ltyz + T.gz + 1, hhh); }
+        } else {
+            float* t = T.tile + b;
+            if (x0in & y0in) { atomicAdd(t, lll); atomicAdd(t + 1, llh); }
+            if (x0in & y1in) { atomicAdd(t + T.gz, lhl); atomicAdd(t + T.gz + 1, lhh); }
+            if (x1in & y0in) { atomicAdd(t + T.ltyz, hll); atomicAdd(t + T.ltyz + 1, hlh); }
+            if (x1in & y1in) { atomicAdd(t + T.ltyz + T.gz, hhl); atomicAdd(t + T.ltyz + T.gz + 1, hhh); }
+        }
+    } else {
+        float* b = T.tile + ((int64_t)fx * T.syz + fy * T.gz + fz);
+        atomicAdd(b, lll);
+        atomicAdd(b + 1, llh);
+        atomicAdd(b + T.gz, lhl);
+        atomicAdd(b + T.gz + 1, lhh);
+        atomicAdd(b + T.syz, hll);
+        atomicAdd(b + T.syz + 1, hlh);
+        atomicAdd(b + T.syz + T.gz, hhl);
+        atomicAdd(b + T.syz + T.gz + 1, hhh);
+    }
+}
+
+// one pair frame per lane, pulled across lanes by the deposit stage
+struct PairFrame { f3 cc, x, y; float prob; int n; };
+
+template <bool TILED, bool TAB_LDS>
+__device__ __forceinline__ void vote_pop(const VoteTile& VT, const PairFrame& F, const f3 cr, const float2* ltab,
+                                         const uint16_t* ring, int qhead, int lane, int count)
+{
+    // all 64 lanes execute the pulls (an inactive source lane would read as 0); only `count` deposit
+    const unsigned code = ring[(qhead + lane) & (VOTE_RING - 1)];
+    const int src = (int)(code & 63u), i = (int)(code >> 6);
+    f3 cc, x, y;
+    cc.x = __shfl(F.cc.x, src, 64); cc.y = __shfl(F.cc.y, src, 64); cc.z = __shfl(F.cc.z, src, 64);
+    x.x = __shfl(F.x.x, src, 64); x.y = __shfl(F.x.y, src, 64); x.z = __shfl(F.x.z, src, 64);
+    y.x = __shfl(F.y.x, src, 64); y.y = __shfl(F.y.y, src, 64); y.z = __shfl(F.y.z, src, 64);
+    const float prob = __shfl(F.prob, src, 64);
+    const int n = __shfl(F.n, src, 64);
+    if (lane < count) {
+        const float2 cs = TAB_LDS ? ltab[n * (n - 1) / 2 + i] : rot_cs(i, n);
+        const f3 offset = add3(scl3(x, cs.x), scl3(y, cs.y));      // :34
+        const f3 v = sub3(add3(cc, offset), cr);                   // numerator of :35
+        vote_deposit<TILED>(VT, v, prob);
+    }
+}
 
 template <bool TILED, bool TAB_LDS>
 __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* tile = lds;
-    float2* ltab = reinterpret_cast<float2*>(lds + (TILED ? VOTE_TILE_FLOATS : 0));
-    const int tid = threadIdx.x;
+    // LDS: [rings: 16 waves x 128 x u16 = 4 KiB][carry log 8 KiB][ctrl 64 B][rotation table][tile]
+    uint16_t* ring = reinterpret_cast<uint16_t*>(lds) + (threadIdx.x >> 6) * VOTE_RING;
+    uint32_t* carry_log = reinterpret_cast<uint32_t*>(lds) + (VOTE_THREADS / 64) * VOTE_RING / 2;
+    int* ctrl = reinterpret_cast<int*>(carry_log + VOTE_CARRY_CAP);  // [0] carry count, [1] max(prob) bits, [2] bad probs
+    float2* ltab = reinterpret_cast<float2*>(ctrl + 16);
+    float* tile = reinterpret_cast<float*>(ltab + (TAB_LDS ? A.tab_entries : 0));
+    const int tid = threadIdx.x, lane = tid & 63;
     const int gz = A.gz, gy = A.gy, gx = A.gx;
 
     int t = 0, c = 0, x0 = 0, y0 = 0, tx = gx, ty = gy;
     int64_t p_begin, p_end, p_step;
+    if (tid < 16) ctrl[tid] = 0;
     if (TILED) {
         t = blockIdx.x % A.T;
         c = blockIdx.x / A.T;
@@ -132,86 +274,142 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
         y0 = tiy * A.ty;
         tx = min(A.tx, gx - x0);
         ty = min(A.ty, gy - y0);
-        p_begin = (int64_t)c * A.chunk_pairs + tid;
+        p_begin = (int64_t)c * A.chunk_pairs;
         p_end = min((int64_t)(c + 1) * A.chunk_pairs, A.n_ppfs);
         p_step = VOTE_THREADS;
         const int nt = tx * ty * gz;
-        for (int k = tid; k < nt; k += VOTE_THREADS) tile[k] = 0.f;
+        for (int k = tid; k < nt; k += VOTE_THREADS) tile[k] = 0.f;  // +0.0f == 0u
     } else {
-        p_begin = (int64_t)blockIdx.x * VOTE_THREADS + tid;
+        p_begin = (int64_t)blockIdx.x * VOTE_THREADS;
         p_end = A.n_ppfs;
         p_step = (int64_t)gridDim.x * VOTE_THREADS;
     }
-    if (TAB_LDS)
-        for (int k = tid; k < A.tab_entries; k += VOTE_THREADS) ltab[k] = A.tab[k];
-    if (blockIdx.x == 0 && tid == 0) *A.packed = 0ull;
+    if (TAB_LDS) fill_rot_table(ltab, A.tab_entries, tid, VOTE_THREADS);
+    if (blockIdx.x == 0 && tid == 0) { A.packed[0] = 0ull; A.packed[1] = 0ull; }
     __syncthreads();
+    float S = 0.f;
+    if (TILED) {
+        // largest prob (weights are w * max(probs[a], probs[b]) <= max(probs)); any negative or
+        // non-finite value disables the fixed-point path for this workgroup
+        float pm = 0.f;
+        int bad = 0;
+        for (int64_t k = tid; k < A.n_points; k += VOTE_THREADS) {
+            const float pv = A.probs[k];
+            bad |= !(pv >= 0.f) || !(pv < INFINITY);
+            pm = fmaxf(pm, pv);
+        }
+        for (int off = 32; off > 0; off >>= 1) pm = fmaxf(pm, __shfl_xor(pm, off, 64));
+        if (__any(bad) && lane == 0) ctrl[2] = 1;
+        if (lane == 0) atomicMax(&ctrl[1], __float_as_int(pm));  // non-negative floats order like ints
+        __syncthreads();
+        const float pmax = __int_as_float(ctrl[1]);
+        if (!ctrl[2]) {
+            // p2 = pmax rounded up to a power of two (1 when pmax == 0); S = 2^kk / p2, exact
+            int e = 127;
+            if (pmax > 0.f) {
+                const unsigned bits = __float_as_uint(pmax);
+                e = (int)(bits >> 23) + ((bits & 0x7fffffu) ? 1 : 0);
+                if (e < 1) e = 1;  // subnormal pmax: treat as the smallest normal
+            }
+            const int se = 127 + A.kk - (e - 127);
+            S = (se >= 1 && se <= 254) ? __uint_as_float((unsigned)se << 23) : 0.f;
+        }
+    }
 
     const f3 cr = {A.corner[0], A.corner[1], A.corner[2]};
     const float res = A.res;
-    const double hx = (double)gx - 1.01, hy = (double)gy - 1.01, hz = (double)gz - 1.01;
-    const int syz = gy * gz;       // global x stride
-    const int ltyz = ty * gz;      // tile x stride
+    const float rinv = 1.0f / res;
+    VoteTile VT;
+    VT.tile = TILED ? tile : A.grid;
+    VT.carry_log = carry_log; VT.carry_n = ctrl;
+    VT.x0 = x0; VT.y0 = y0; VT.tx = tx; VT.ty = ty; VT.gz = gz; VT.ltyz = ty * gz; VT.syz = gy * gz; VT.res = res;
+    VT.S = S;
+    VT.lo = ceil_to_float(0.01);
+    VT.hx = ceil_to_float((double)gx - 1.01); VT.hy = ceil_to_float((double)gy - 1.01);
+    VT.hz = ceil_to_float((double)gz - 1.01);
+    // acceptance box of exact grid coordinates that can touch this tile: valid in the grid
+    // ([0.01, dim-1.01)) and floor in [x0-1, x0+tx-1]
+    const float blx = fmaxf(0.01f, (float)(x0 - 1)), bhx = fminf((float)gx - 1.01f, (float)(x0 + tx));
+    const float bly = fmaxf(0.01f, (float)(y0 - 1)), bhy = fminf((float)gy - 1.01f, (float)(y0 + ty));
+    const float blz = 0.01f, bhz = (float)gz - 1.01f;
 
-    for (int64_t p = p_begin; p < p_end; p += p_step) {
-        const float2 o = reinterpret_cast<const float2*>(A.outputs)[p];
-        const int2 ij = reinterpret_cast<const int2*>(A.point_idxs)[p];
-        f3 a, ab, xd;
-        if (!pair_frame(A.points, ij.x, ij.y, a, ab, xd)) continue;
-        const float proj_len = o.x, odist = o.y;
-        const f3 cc = sub3(a, scl3(ab, proj_len));                     // :23
-        const float prob = fmaxf(A.probs[ij.x], A.probs[ij.y]);       // :25
-        const f3 x = scl3(xd, odist);                                  // :28
-        const f3 y = cross3(x, ab);                                    // :29
-        int n = A.n_rots;
-        if (A.adaptive) n = min((int)((double)(odist / res) * (2 * CPPF_PI)), A.n_rots);  // :31
-        const int tbase = n * (n - 1) / 2;
-        for (int i = 0; i < n; ++i) {
-            const float2 cs = TAB_LDS ? ltab[tbase + i] : A.tab[tbase + i];
-            const f3 offset = add3(scl3(x, cs.x), scl3(y, cs.y));      // :34
-            const f3 g = div3(sub3(add3(cc, offset), cr), res);        // :35
-            if ((double)g.x < 0.01 || (double)g.y < 0.01 || (double)g.z < 0.01 || (double)g.x >= hx ||
-                (double)g.y >= hy || (double)g.z >= hz)
-                continue;                                              // :36-39
-            const int fx = (int)g.x, fy = (int)g.y, fz = (int)g.z;     // :40
-            const float rx = g.x - floorf(g.x), ry = g.y - floorf(g.y), rz = g.z - floorf(g.z);
-            const float w0x = 1.f - rx, w0y = 1.f - ry, w0z = 1.f - rz;
-            const float ll = w0x * w0y, lh = w0x * ry, hl = rx * w0y, hh = rx * ry;
-            const float lll = ll * w0z * prob, llh = ll * rz * prob, lhl = lh * w0z * prob, lhh = lh * rz * prob;
-            const float hll = hl * w0z * prob, hlh = hl * rz * prob, hhl = hh * w0z * prob, hhh = hh * rz * prob;
-            if (TILED) {
-                const int lx = fx - x0, ly = fy - y0;
-                const bool x0in = (unsigned)lx < (unsigned)tx, x1in = (unsigned)(lx + 1) < (unsigned)tx;
-                const bool y0in = (unsigned)ly < (unsigned)ty, y1in = (unsigned)(ly + 1) < (unsigned)ty;
-                if (!((x0in | x1in) & (y0in | y1in))) continue;
-                float* b = tile + (lx * ty + ly) * gz + fz;
-                if (x0in & y0in) { atomicAdd(b, lll); atomicAdd(b + 1, llh); }
-                if (x0in & y1in) { atomicAdd(b + gz, lhl); atomicAdd(b + gz + 1, lhh); }
-                if (x1in & y0in) { atomicAdd(b + ltyz, hll); atomicAdd(b + ltyz + 1, hlh); }
-                if (x1in & y1in) { atomicAdd(b + ltyz + gz, hhl); atomicAdd(b + ltyz + gz + 1, hhh); }
-            } else {
-                float* b = A.grid + ((int64_t)fx * syz + fy * gz + fz);
-                atomicAdd(b, lll);
-                atomicAdd(b + 1, llh);
-                atomicAdd(b + gz, lhl);
-                atomicAdd(b + gz + 1, lhh);
-                atomicAdd(b + syz, hll);
-                atomicAdd(b + syz + 1, hlh);
-                atomicAdd(b + syz + gz, hhl);
-                atomicAdd(b + syz + gz + 1, hhh);
+    for (int64_t pb = p_begin; pb < p_end; pb += p_step) {  // uniform trip count for the whole wave
+        const int64_t p = pb + tid;
+        PairFrame F;
+        F.cc = {0.f, 0.f, 0.f}; F.x = F.cc; F.y = F.cc; F.prob = 0.f; F.n = 0;
+        if (p < p_end) {
+            const float2 o = reinterpret_cast<const float2*>(A.outputs)[p];
+            const int2 ij = reinterpret_cast<const int2*>(A.point_idxs)[p];
+            f3 a, ab, xd;
+            if (pair_frame(A.points, ij.x, ij.y, a, ab, xd)) {
+                const float proj_len = o.x, odist = o.y;
+                F.cc = sub3(a, scl3(ab, proj_len));                    // :23
+                F.prob = fmaxf(A.probs[ij.x], A.probs[ij.y]);         // :25
+                F.x = scl3(xd, odist);                                 // :28
+                F.y = cross3(F.x, ab);                                 // :29
+                F.n = A.n_rots;
+                if (A.adaptive) F.n = min((int)((double)(odist / res) * (2 * CPPF_PI)), A.n_rots);  // :31
             }
         }
+        const int n = F.n, tbase = n * (n - 1) / 2;
+        // screen in grid units: q = cq + cos*xq + sin*yq.  It differs from the exact coordinate of :35
+        // by a few roundings of terms no larger than `mag`, so the acceptance box is widened per pair
+        // by 1e-6*mag + 1e-3 cells (>= 16 ulp of the largest term).
+        const f3 cq = scl3(sub3(F.cc, cr), rinv), xq = scl3(F.x, rinv), yq = scl3(F.y, rinv);
+        const float ex = fmaf((fabsf(F.cc.x) + fabsf(cr.x) + fabsf(F.x.x) + fabsf(F.y.x)) * rinv, 1e-6f, 1e-3f);
+        const float ey = fmaf((fabsf(F.cc.y) + fabsf(cr.y) + fabsf(F.x.y) + fabsf(F.y.y)) * rinv, 1e-6f, 1e-3f);
+        const float ez = fmaf((fabsf(F.cc.z) + fabsf(cr.z) + fabsf(F.x.z) + fabsf(F.y.z)) * rinv, 1e-6f, 1e-3f);
+        const float lox = blx - ex, hix = bhx + ex, loy = bly - ey, hiy = bhy + ey, loz = blz - ez, hiz = bhz + ez;
+        int qhead = 0, qtail = 0;  // wave-uniform ring cursors, the ring is drained at the end of every batch
+        for (int i = 0; __any(i < n); ++i) {
+            bool acc = false;
+            if (i < n) {
+                const float2 cs = TAB_LDS ? ltab[tbase + i] : rot_cs(i, n);
+                const float qx = fmaf(cs.y, yq.x, fmaf(cs.x, xq.x, cq.x));
+                const float qy = fmaf(cs.y, yq.y, fmaf(cs.x, xq.y, cq.y));
+                const float qz = fmaf(cs.y, yq.z, fmaf(cs.x, xq.z, cq.z));
+                acc = (qx >= lox) & (qx < hix) & (qy >= loy) & (qy < hiy) & (qz >= loz) & (qz < hiz);
+            }
+            const unsigned long long m = __ballot(acc);
+            if (m == 0ull) continue;
+            if (acc) {
+                const int pos = qtail + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                                  __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                ring[pos & (VOTE_RING - 1)] = (uint16_t)(lane | (i << 6));
+            }
+            qtail += __popcll(m);
+            if (qtail - qhead >= 64) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                vote_pop<TILED, TAB_LDS>(VT, F, cr, ltab, ring, qhead, lane, 64);
+                qhead += 64;
+            }
+        }
+        if (qtail != qhead) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            vote_pop<TILED, TAB_LDS>(VT, F, cr, ltab, ring, qhead, lane, qtail - qhead);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 
     if (TILED) {
         __syncthreads();
+        const int syz = gy * gz;
+        const int nt = tx * ty * gz;
+        if (S > 0.f) {  // fixed point -> fp32 in place, then the logged wrap-arounds
+            const float invS = 1.0f / S;  // exact: S is a power of two
+            uint32_t* tu = reinterpret_cast<uint32_t*>(tile);
+            for (int k = tid; k < nt; k += VOTE_THREADS) tile[k] = (float)tu[k] * invS;
+            __syncthreads();
+            const int nc = min(ctrl[0], VOTE_CARRY_CAP);
+            for (int k = tid; k < nc; k += VOTE_THREADS) atomicAdd(&tile[carry_log[k]], 4294967296.0f * invS);
+            __syncthreads();
+        }
         float* part = A.partials + (int64_t)c * ((int64_t)gx * syz);
         if (ty == gy) {  // x slabs: the tile is one contiguous run of the grid
             float* dst = part + (int64_t)x0 * syz;
-            const int nt = tx * syz;
             for (int k = tid; k < nt; k += VOTE_THREADS) dst[k] = tile[k];
         } else {
-            const int row = ty * gz, nt = tx * row;
+            const int row = ty * gz;
             for (int k = tid; k < nt; k += VOTE_THREADS) {
                 int lx = k / row, r = k - lx * row;
                 part[(int64_t)(x0 + lx) * syz + y0 * gz + r] = tile[k];
@@ -221,9 +419,13 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
 }
 
 // ----------------------------------------------------------------------------- reduce + arg-max
-// grid[cell] += sum_c partials[c][cell] (fixed order), and the arg-max of the result with numpy's
-// tie rule (first maximum in C order, nocs/inference.py:208): key = ord(value) << 32 | ~index,
-// reduced with max inside the wave, the block and one atomicMax per block.
+// grid[cell] (+)= sum_c partials[c][cell] in a fixed order, and the arg-max of the result with
+// numpy's tie rule (first maximum in C order, nocs/inference.py:208): key = ord(value) << 32 |
+// ~index, max-reduced in the wave, then one returning atomicMax per block.  A block = 64 cells x 4
+// chunk groups (chunk c goes to group c & 3) so that ~100 partial grids stream with 4x the loads in
+// flight.  The last block to take a ticket unpacks the key into out_idx / out_val: every access to
+// the key and the ticket is a device-scope atomic whose result is consumed before the next one is
+// issued, so no cache maintenance is needed.
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
 {
     for (int off = 32; off > 0; off >>= 1) {
@@ -235,66 +437,79 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
 
 __global__ __launch_bounds__(256) void reduce_argmax_kernel(float* __restrict__ grid,
                                                             const float* __restrict__ partials, int chunks,
-                                                            int64_t G, unsigned long long* packed, int write_back)
+                                                            int64_t G, unsigned long long* packed, int accumulate,
+                                                            int write_back, long long* out_idx, float* out_val)
 {
-    __shared__ unsigned long long wk[4];
-    unsigned long long best = 0ull;
-    for (int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x; cell < G; cell += (int64_t)gridDim.x * 256) {
-        float v = grid[cell];
-        for (int c = 0; c < chunks; ++c) v = v + partials[(int64_t)c * G + cell];
-        if (write_back) grid[cell] = v;
-        unsigned long long k = ((unsigned long long)f2ord(v) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)cell);
-        best = k > best ? k : best;
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const int64_t cell = (int64_t)blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (cell < G) {
+        int c = cg;
+        for (; c + 12 < chunks; c += 16) {  // 4 independent loads in flight per lane
+            const float v0 = partials[(int64_t)c * G + cell], v1 = partials[(int64_t)(c + 4) * G + cell];
+            const float v2 = partials[(int64_t)(c + 8) * G + cell], v3 = partials[(int64_t)(c + 12) * G + cell];
+            s = (((s + v0) + v1) + v2) + v3;
+        }
+        for (; c < chunks; c += 4) s = s + partials[(int64_t)c * G + cell];
     }
-    best = wave_max_u64(best);
-    if ((threadIdx.x & 63) == 0) wk[threadIdx.x >> 6] = best;
+    part[cg][lane] = s;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long b = wk[0];
-        for (int w = 1; w < 4; ++w) b = wk[w] > b ? wk[w] : b;
-        if (b) atomicMax(packed, b);
+    if (cg != 0) return;
+    unsigned long long key = 0ull;
+    if (cell < G) {
+        float v = accumulate ? grid[cell] : 0.f;
+        v = (((v + part[0][lane]) + part[1][lane]) + part[2][lane]) + part[3][lane];
+        if (write_back) grid[cell] = v;
+        key = ((unsigned long long)f2ord(v) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)cell);
+    }
+    key = wave_max_u64(key);
+    if (lane == 0) {
+        const unsigned long long old = atomicMax(packed, key);          // returning: completes before the ticket
+        unsigned d1 = (unsigned)old, d2;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(d2) : "v"(d1));
+        unsigned* ticket = reinterpret_cast<unsigned*>(packed + 1);
+        const unsigned tk = atomicAdd(ticket, 1u + (d1 ^ d2));           // d1 ^ d2 == 0, data-dependent on `old`
+        if (tk == gridDim.x - 1) {
+            const unsigned long long best = atomicMax(packed, 0ull);
+            if (out_idx) *out_idx = (long long)(0xffffffffu - (uint32_t)(best & 0xffffffffull));
+            if (out_val) *out_val = ord2f((uint32_t)(best >> 32));
+        }
     }
 }
 
-__global__ void unpack_argmax_kernel(const unsigned long long* packed, long long* out_idx, float* out_val)
-{
-    unsigned long long k = *packed;
-    if (out_idx) *out_idx = (long long)(0xffffffffu - (uint32_t)(k & 0xffffffffull));
-    if (out_val) *out_val = ord2f((uint32_t)(k >> 32));
-}
+__global__ void zero_u64x2_kernel(unsigned long long* p) { p[0] = 0ull; p[1] = 0ull; }
 
-__global__ void zero_u64_kernel(unsigned long long* p) { *p = 0ull; }
+#define VOTE_LDS_HEAD ((VOTE_THREADS / 64) * VOTE_RING * 2 + VOTE_CARRY_CAP * 4 + 64)
 
 static int vote_impl(const float* points, const float* outputs, const float* probs, const int32_t* point_idxs,
-                     float* grid_obj, const float* corner, float res, int64_t n_ppfs, int n_rots, int gx, int gy,
-                     int gz, int adaptive, bool want_argmax, long long* out_idx, float* out_val, void* workspace,
-                     size_t workspace_bytes, hipStream_t st)
+                     float* grid_obj, const float* corner, float res, int64_t n_points, int64_t n_ppfs, int n_rots,
+                     int gx, int gy, int gz, int adaptive, int accumulate, bool want_argmax, long long* out_idx, float* out_val,
+                     void* workspace, size_t workspace_bytes, hipStream_t st)
 {
     if (!points || !probs || !grid_obj || !corner) return CPPF_EINVAL;
     if (n_ppfs > 0 && (!outputs || !point_idxs)) return CPPF_EINVAL;
-    if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || gx < 1 || gy < 1 || gz < 1 || n_ppfs < 0) return CPPF_EINVAL;
+    if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || gx < 1 || gy < 1 || gz < 1 || n_ppfs < 0 || n_points < 1) return CPPF_EINVAL;
     if ((int64_t)gx * gy * gz > 0x7fffffffll) return CPPF_EINVAL;
     VotePlan pl = make_vote_plan(n_ppfs, n_rots, gx, gy, gz);
     if (!workspace || workspace_bytes < pl.total) return CPPF_EWORKSPACE;
     char* ws = static_cast<char*>(workspace);
-    float2* tab = reinterpret_cast<float2*>(ws + pl.tab_off);
     unsigned long long* packed = reinterpret_cast<unsigned long long*>(ws + pl.packed_off);
     float* partials = reinterpret_cast<float*>(ws + pl.part_off);
     const int64_t G = (int64_t)gx * gy * gz;
 
-    hipLaunchKernelGGL(rot_table_kernel, dim3(n_rots), dim3(64), 0, st, tab, n_rots);
-    CPPF_CHECK_LAUNCH();
-
     VoteArgs A;
     A.points = points; A.outputs = outputs; A.probs = probs; A.point_idxs = point_idxs;
-    A.grid = grid_obj; A.partials = partials; A.corner = corner; A.tab = tab; A.packed = packed;
+    A.grid = grid_obj; A.partials = partials; A.corner = corner; A.packed = packed;
     A.res = res; A.n_ppfs = n_ppfs; A.n_rots = n_rots; A.gx = gx; A.gy = gy; A.gz = gz; A.adaptive = adaptive;
     A.tx = pl.tx; A.ty = pl.ty; A.ntx = pl.ntx; A.nty = pl.nty; A.T = pl.T; A.chunk_pairs = pl.chunk_pairs;
     A.tab_entries = pl.tab_entries;
+    A.n_points = n_points;
+    A.kk = vote_fixed_bits(pl, n_rots);
     const bool tab_lds = pl.tab_entries <= VOTE_TAB_LDS_MAX;
     const size_t tab_bytes = tab_lds ? (size_t)pl.tab_entries * sizeof(float2) : 0;
     if (pl.tiled) {
-        const size_t lds = VOTE_TILE_FLOATS * sizeof(float) + tab_bytes;
+        const size_t lds = VOTE_LDS_HEAD + VOTE_TILE_FLOATS * sizeof(float) + tab_bytes;
         dim3 grid(pl.T * pl.chunks);
         if (tab_lds) {
             static bool attr_done = false;
@@ -314,25 +529,26 @@ static int vote_impl(const float* points, const float* outputs, const float* pro
             hipLaunchKernelGGL((vote_kernel<true, false>), grid, dim3(VOTE_THREADS), lds, st, A);
         }
     } else {
+        if (!accumulate) {  // global atomics add into the grid: an overwrite request zeroes it first
+            hipError_t e = hipMemsetAsync(grid_obj, 0, (size_t)G * sizeof(float), st);
+            if (e != hipSuccess) return (int)e;
+        }
         int64_t nb = (n_ppfs + VOTE_THREADS - 1) / VOTE_THREADS;
         if (nb > 2048) nb = 2048;
         if (nb < 1) nb = 1;
         if (tab_lds)
-            hipLaunchKernelGGL((vote_kernel<false, true>), dim3((unsigned)nb), dim3(VOTE_THREADS), tab_bytes, st, A);
+            hipLaunchKernelGGL((vote_kernel<false, true>), dim3((unsigned)nb), dim3(VOTE_THREADS),
+                               VOTE_LDS_HEAD + tab_bytes, st, A);
         else
-            hipLaunchKernelGGL((vote_kernel<false, false>), dim3((unsigned)nb), dim3(VOTE_THREADS), 0, st, A);
+            hipLaunchKernelGGL((vote_kernel<false, false>), dim3((unsigned)nb), dim3(VOTE_THREADS), VOTE_LDS_HEAD, st, A);
     }
     CPPF_CHECK_LAUNCH();
 
     if (pl.tiled || want_argmax) {
-        int64_t nb = (G + 255) / 256;
-        if (nb > 2048) nb = 2048;
+        const int64_t nb = (G + 63) / 64;
         hipLaunchKernelGGL(reduce_argmax_kernel, dim3((unsigned)nb), dim3(256), 0, st, grid_obj, partials,
-                           pl.chunks, G, packed, pl.tiled ? 1 : 0);
-        CPPF_CHECK_LAUNCH();
-    }
-    if (want_argmax && (out_idx || out_val)) {
-        hipLaunchKernelGGL(unpack_argmax_kernel, dim3(1), dim3(1), 0, st, packed, out_idx, out_val);
+                           pl.chunks, G, packed, pl.tiled ? accumulate : 1, pl.tiled ? 1 : 0,
+                           want_argmax ? out_idx : nullptr, want_argmax ? out_val : nullptr);
         CPPF_CHECK_LAUNCH();
     }
     return 0;
@@ -340,35 +556,34 @@ static int vote_impl(const float* points, const float* outputs, const float* pro
 
 extern "C" int cppf_ppf_voting(const float* points, const float* outputs, const float* probs,
                                const int32_t* point_idxs, float* grid_obj, const float* corner, float res,
-                               int64_t n_ppfs, int n_rots, int gx, int gy, int gz, int adaptive, void* workspace,
-                               size_t workspace_bytes, void* stream)
+                               int64_t n_points, int64_t n_ppfs, int n_rots, int gx, int gy, int gz, int adaptive,
+                               void* workspace, size_t workspace_bytes, void* stream)
 {
-    return vote_impl(points, outputs, probs, point_idxs, grid_obj, corner, res, n_ppfs, n_rots, gx, gy, gz,
-                     adaptive, false, nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
+    return vote_impl(points, outputs, probs, point_idxs, grid_obj, corner, res, n_points, n_ppfs, n_rots, gx, gy, gz,
+                     adaptive, 1, false, nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int cppf_vote_argmax(const float* points, const float* outputs, const float* probs,
                                 const int32_t* point_idxs, float* grid_obj, const float* corner, float res,
-                                int64_t n_ppfs, int n_rots, int gx, int gy, int gz, int adaptive,
-                                long long* out_idx, float* out_val, void* workspace, size_t workspace_bytes,
-                                void* stream)
+                                int64_t n_points, int64_t n_ppfs, int n_rots, int gx, int gy, int gz, int adaptive,
+                                int accumulate, long long* out_idx, float* out_val, void* workspace,
+                                size_t workspace_bytes, void* stream)
 {
-    return vote_impl(points, outputs, probs, point_idxs, grid_obj, corner, res, n_ppfs, n_rots, gx, gy, gz,
-                     adaptive, true, out_idx, out_val, workspace, workspace_bytes, (hipStream_t)stream);
+    return vote_impl(points, outputs, probs, point_idxs, grid_obj, corner, res, n_points, n_ppfs, n_rots, gx, gy, gz,
+                     adaptive, accumulate, true, out_idx, out_val, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-extern "C" int cppf_grid_argmax(const float* grid, int64_t n, long long* out_idx, float* out_val, void* stream)
+extern "C" int cppf_grid_argmax(const float* grid, int64_t n, long long* out_idx, float* out_val, void* workspace,
+                                size_t workspace_bytes, void* stream)
 {
     if (!grid || n < 1 || n > 0x7fffffffll || !out_idx) return CPPF_EINVAL;
+    if (!workspace || workspace_bytes < 16) return CPPF_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    // out_idx doubles as the 8-byte packed scratch
-    unsigned long long* packed = reinterpret_cast<unsigned long long*>(out_idx);
-    hipLaunchKernelGGL(zero_u64_kernel, dim3(1), dim3(1), 0, st, packed);
-    int64_t nb = (n + 255) / 256;
-    if (nb > 2048) nb = 2048;
+    unsigned long long* packed = static_cast<unsigned long long*>(workspace);
+    hipLaunchKernelGGL(zero_u64x2_kernel, dim3(1), dim3(1), 0, st, packed);
+    const int64_t nb = (n + 63) / 64;
     hipLaunchKernelGGL(reduce_argmax_kernel, dim3((unsigned)nb), dim3(256), 0, st, const_cast<float*>(grid),
-                       (const float*)nullptr, 0, n, packed, 0);
-    hipLaunchKernelGGL(unpack_argmax_kernel, dim3(1), dim3(1), 0, st, packed, out_idx, out_val);
+                       (const float*)nullptr, 0, n, packed, 1, 0, out_idx, out_val);
     CPPF_CHECK_LAUNCH();
     return 0;
 }
@@ -418,13 +633,7 @@ __global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__
     const int entries = n_rots * (n_rots + 1) / 2;
     const bool in_lds = entries <= VOTE_TAB_LDS_MAX;
     if (in_lds) {
-        // rows are found by walking n; each thread fills a strided subset of the triangular table
-        for (int e = threadIdx.x; e < entries; e += blockDim.x) {
-            int n = (int)((sqrtf(8.f * (float)e + 1.f) + 1.f) * 0.5f);
-            while (n * (n - 1) / 2 > e) --n;
-            while ((n + 1) * n / 2 <= e) ++n;
-            ltab[e] = rot_cs(e - n * (n - 1) / 2, n);
-        }
+        fill_rot_table(ltab, entries, threadIdx.x, blockDim.x);
         __syncthreads();
     }
     const f3 cr = {corner[0], corner[1], corner[2]};

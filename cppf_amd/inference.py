@@ -77,9 +77,9 @@ def estimate_center(encoder, pc, pc_normal, feat, point_idxs, u_tr, cfg, corner,
         probs = ws.probs
     outputs, heads = encoder.forward_decode(pc, pc_normal, feat, point_idxs, u_tr, cfg.vote_range, u_rot,
                                             cfg.tr_num_bins, cfg.rot_num_bins)
-    ws.grid.zero_()                                                        # :196
+    # grid = votes (overwrite mode replaces the zero-initialisation of :196)
     voting.vote_argmax(pc, outputs, probs, idx32, ws.grid, corner, cfg.res, num_rots, adaptive, ws.out_idx,
-                       ws.out_val)
+                       ws.out_val, accumulate=False)
     return ws.out_idx, ws.out_val, outputs, heads, ws.grid
 
 
@@ -136,7 +136,8 @@ def estimate_pose(encoder, pc, pc_normal, feat, point_idxs, u_tr, u_rot, cfg, sp
                                                sph32_d.data_ptr(), S, thr, ws.counts[j].data_ptr(), st),
                        "cppf_rot_sphere_count")
             ws.countsf[j].copy_(ws.counts[j])                                 # exact: counts < 2**24
-            _lib.check(L.cppf_grid_argmax(ws.countsf[j].data_ptr(), S, ws.best_idx[j:].data_ptr(), None, st),
+            _lib.check(L.cppf_grid_argmax(ws.countsf[j].data_ptr(), S, ws.best_idx[j:].data_ptr(), None,
+                                          rws.data_ptr(), rws.numel(), st),
                        "cppf_grid_argmax")                                    # np.argmax(counts), :283
             torch.index_select(sph64_d, 0, ws.best_idx[j:j + 1], out=ws.best_dir[j:j + 1])
             _lib.check(L.cppf_axis_sign(pc.data_ptr(), pc_normal.data_ptr(), idx32.data_ptr(), ws.surv.data_ptr(),

@@ -18,7 +18,7 @@ import torch
 from .. import _lib
 from .._torch_util import dev_tensor, require_cuda, scalar, stream_ptr, workspace
 
-__all__ = ["ppf_kernel", "backvote_kernel", "rot_voting_kernel", "vote_argmax"]
+__all__ = ["ppf_kernel", "backvote_kernel", "rot_voting_kernel", "vote_argmax", "grid_argmax"]
 
 F32, I32 = torch.float32, torch.int32
 
@@ -70,14 +70,17 @@ def _ppf_voting(points, outputs, probs, point_idxs, grid_obj, corner, res, n_ppf
     ws = workspace(need, dev, "vote")
     with torch.cuda.device(dev):
         rc = L.cppf_ppf_voting(points.data_ptr(), outputs.data_ptr(), probs.data_ptr(), point_idxs.data_ptr(),
-                               grid_obj.data_ptr(), corner.data_ptr(), float(scalar(res)), n_ppfs, n_rots, gx, gy, gz,
-                               1 if bool(scalar(adaptive)) else 0, ws.data_ptr(), ws.numel(), stream_ptr(dev))
+                               grid_obj.data_ptr(), corner.data_ptr(), float(scalar(res)), points.shape[0], n_ppfs,
+                               n_rots, gx, gy, gz, 1 if bool(scalar(adaptive)) else 0, ws.data_ptr(), ws.numel(),
+                               stream_ptr(dev))
     _lib.check(rc, "cppf_ppf_voting")
 
 
 def vote_argmax(points, outputs, probs, point_idxs, grid_obj, corner, res, n_rots, adaptive, out_idx=None,
-                out_val=None):
+                out_val=None, accumulate=True):
     """ppf_voting + np.argmax (nocs/inference.py:197-208) without the host round trip.
+    accumulate=True: grid_obj += votes (reference semantics, grid zero-initialised by the caller);
+    accumulate=False: grid_obj = votes (no memset needed).
     Returns (out_idx i64[1], out_val f32[1]) device tensors."""
     dev = dev_tensor(points, F32, "points", (3,)).device
     dev_tensor(outputs, F32, "outputs", (2,), dev)
@@ -87,6 +90,8 @@ def vote_argmax(points, outputs, probs, point_idxs, grid_obj, corner, res, n_rot
     dev_tensor(corner, F32, "corner", None, dev)
     if grid_obj.dim() != 3:
         raise ValueError("grid_obj must be [gx,gy,gz]")
+    if probs.numel() != points.shape[0]:
+        raise ValueError("probs must have one entry per point")
     gx, gy, gz = grid_obj.shape
     n_ppfs = point_idxs.shape[0]
     if out_idx is None:
@@ -100,10 +105,25 @@ def vote_argmax(points, outputs, probs, point_idxs, grid_obj, corner, res, n_rot
     ws = workspace(need, dev, "vote")
     with torch.cuda.device(dev):
         rc = L.cppf_vote_argmax(points.data_ptr(), outputs.data_ptr(), probs.data_ptr(), point_idxs.data_ptr(),
-                                grid_obj.data_ptr(), corner.data_ptr(), float(scalar(res)), n_ppfs, int(n_rots), gx, gy,
-                                gz, 1 if adaptive else 0, out_idx.data_ptr(), out_val.data_ptr(), ws.data_ptr(),
-                                ws.numel(), stream_ptr(dev))
+                                grid_obj.data_ptr(), corner.data_ptr(), float(scalar(res)), points.shape[0], n_ppfs,
+                                int(n_rots), gx, gy, gz, 1 if adaptive else 0, 1 if accumulate else 0,
+                                out_idx.data_ptr(), out_val.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr(dev))
     _lib.check(rc, "cppf_vote_argmax")
+    return out_idx, out_val
+
+
+def grid_argmax(grid, out_idx=None, out_val=None):
+    """np.argmax(grid) on device (nocs/inference.py:208): (idx i64[1], val f32[1]) device tensors."""
+    dev = dev_tensor(grid, F32, "grid").device
+    if out_idx is None:
+        out_idx = torch.empty(1, dtype=torch.int64, device=dev)
+    if out_val is None:
+        out_val = torch.empty(1, dtype=F32, device=dev)
+    ws = workspace(256, dev, "argmax")
+    with torch.cuda.device(dev):
+        rc = _lib.lib().cppf_grid_argmax(grid.data_ptr(), grid.numel(), out_idx.data_ptr(), out_val.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), stream_ptr(dev))
+    _lib.check(rc, "cppf_grid_argmax")
     return out_idx, out_val
 
 

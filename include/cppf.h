@@ -45,28 +45,37 @@ const char* cppf_error_string(int code);
  *   probs       device f32[N]          point_idxs device i32[n_ppfs,2]
  *   grid_obj    device f32[gx,gy,gz]   in/out, accumulated (+=) like the reference's atomicAdd
  *   corner      device f32[3]          res, n_rots (1..CPPF_MAX_ROTS), adaptive: as the reference
+ *   n_points    N (the reference kernel never needs it; here it bounds the scan for max(probs))
  * The reference's launch geometry (grid, block) is not part of the ABI.
  * Strategy: the grid is cut into tiles that fit LDS; every workgroup accumulates one tile for one
- * chunk of pairs with LDS atomics, tiles are written to `workspace` and summed into grid_obj by
- * a second kernel that also yields the arg-max (cppf_vote_argmax).  Grids that would need too many
- * tiles fall back to global fp32 atomics.
+ * chunk of pairs with 32-bit fixed-point LDS atomics (fp32-exact quantum, see csrc/vote.hip), tiles
+ * are written to `workspace` and summed into grid_obj by a second kernel that also yields the
+ * arg-max (cppf_vote_argmax).  Grids that would need too many tiles fall back to global fp32 atomics.
  * ------------------------------------------------------------------------------------------- */
 #define CPPF_MAX_ROTS 360
 size_t cppf_vote_workspace_bytes(int64_t n_ppfs, int n_rots, int gx, int gy, int gz);
+/* Fixed-point resolution of the LDS accumulation for this problem size: each deposited weight is
+ * rounded to a multiple of p2 * 2^-bits, p2 = max(probs) rounded up to a power of two (24 = fp32
+ * precision for every problem of practical size; 0 = global fp32 atomics path, no quantisation). */
+int cppf_vote_fixed_point_bits(int64_t n_ppfs, int n_rots, int gx, int gy, int gz);
 int cppf_ppf_voting(const float* points, const float* outputs, const float* probs, const int32_t* point_idxs,
-                    float* grid_obj, const float* corner, float res, int64_t n_ppfs, int n_rots, int gx, int gy,
-                    int gz, int adaptive, void* workspace, size_t workspace_bytes, void* stream);
+                    float* grid_obj, const float* corner, float res, int64_t n_points, int64_t n_ppfs, int n_rots,
+                    int gx, int gy, int gz, int adaptive, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Same vote, plus the arg-max that the reference takes on the host (nocs/inference.py:207-208:
  * grid_obj.get(); np.argmax -> first maximum in C order).  out_idx: device i64[1] flat index,
- * out_val: device f32[1] peak value (either may be NULL). */
+ * out_val: device f32[1] peak value (either may be NULL).
+ * accumulate != 0: grid_obj += votes (the reference's semantics, caller zero-initialises, :196);
+ * accumulate == 0: grid_obj  = votes (spares the caller's memset). */
 int cppf_vote_argmax(const float* points, const float* outputs, const float* probs, const int32_t* point_idxs,
-                     float* grid_obj, const float* corner, float res, int64_t n_ppfs, int n_rots, int gx, int gy,
-                     int gz, int adaptive, long long* out_idx, float* out_val, void* workspace,
-                     size_t workspace_bytes, void* stream);
+                     float* grid_obj, const float* corner, float res, int64_t n_points, int64_t n_ppfs, int n_rots,
+                     int gx, int gy, int gz, int adaptive, int accumulate, long long* out_idx, float* out_val,
+                     void* workspace, size_t workspace_bytes, void* stream);
 
-/* np.argmax(grid, axis=None) on device (nocs/inference.py:208).  n cells; ties -> lowest index. */
-int cppf_grid_argmax(const float* grid, int64_t n, long long* out_idx, float* out_val, void* stream);
+/* np.argmax(grid, axis=None) on device (nocs/inference.py:208).  n cells; ties -> lowest index.
+ * workspace: >= 16 bytes of device scratch. */
+int cppf_grid_argmax(const float* grid, int64_t n, long long* out_idx, float* out_val, void* workspace,
+                     size_t workspace_bytes, void* stream);
 
 /* nocs/inference.py:209-210: T = corners[0] + unravel_index(argmax) * res (fp64); idx device i64[1];
  * T64 device f64[3] and/or T32 device f32[3] (the copy the reference hands to backvote, :225). */

@@ -189,6 +189,19 @@ def ppf_voting(points, outputs, probs, point_idxs, grid, corner, res, n_rots, ad
     return None
 
 
+def ppf_voting_f64(points, outputs, probs, point_idxs, dims, corner, res, n_rots, adaptive):
+    """models/voting.py:8-66 with the grid accumulated in fp64 -> (grid f64, deposits-per-cell i32)."""
+    points, outputs, probs = _c(points, _f), _c(outputs, _f), _c(probs, _f)
+    point_idxs, corner = _c(point_idxs, np.int32), _c(corner, _f)
+    gx, gy, gz = (int(d) for d in dims)
+    grid = np.zeros((gx, gy, gz), np.float64)
+    counts = np.zeros((gx, gy, gz), np.int32)
+    lib().orc_ppf_voting_f64(_p(points, _pf), _p(outputs, _pf), _p(probs, _pf), _p(point_idxs, _pi32), _p(grid, _pd),
+                             _p(counts, _pi32), _p(corner, _pf), C.c_float(res), C.c_int64(point_idxs.shape[0]),
+                             C.c_int(n_rots), C.c_int(gx), C.c_int(gy), C.c_int(gz), C.c_int(1 if adaptive else 0))
+    return grid, counts
+
+
 def grid_argmax(grid):
     """np.argmax(grid) (first maximum, C order), nocs/inference.py:208"""
     g = _c(grid, _f).reshape(-1)
