@@ -33,11 +33,12 @@ __device__ __forceinline__ f3 ld3(const float* __restrict__ p, int i)
     return {p[3 * i], p[3 * i + 1], p[3 * i + 2]};
 }
 
-// exp(x), x <= ~88; zero below -86.  n = rint(x*log2e); r = x - n*ln2 (two terms); degree-5 core.
+// exp(x) for x <= 0 (softmax after the max subtraction), x clamped to [-86, 0].
+// n = rint(x*log2e); r = x - n*ln2 (two terms); degree-5 core; 2^n by exponent arithmetic.
 __device__ __forceinline__ float det_expf(float x)
 {
-    if (x < -86.0f) return 0.0f;
-    if (x > 88.0f) x = 88.0f;
+    x = x < -86.0f ? -86.0f : x;
+    x = x > 0.0f ? 0.0f : x;
     float n = rintf(x * 1.44269504088896341f);
     float r = fmaf(n, -0.693359375f, x);
     r = fmaf(n, 2.12194440e-4f, r);

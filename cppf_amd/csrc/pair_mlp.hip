@@ -169,8 +169,9 @@ extern "C" int cppf_pair_mlp_pack(const float* params, const int64_t* offs, int 
 }
 
 // ----------------------------------------------------------------------------- MFMA kernel
-#define MLP_THREADS 256
-#define PB 2  // 16-pair blocks per wave tile
+#define MLP_THREADS 512
+#define MLP_WAVES_PER_SIMD 4
+#define PB 1  // 16-pair blocks per wave tile
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
 {
@@ -201,99 +202,112 @@ __device__ __forceinline__ float ppf_component(const float* __restrict__ pc, con
 }
 
 // ---- decode helpers (semantics: oracle/cppf_oracle.c:orc_sample_bin) --------------------------
-// Logit 16*ob + 4*g + r of the lane's pair lives in L[ob][r] of lane group g; "chunk" c = 4*ob + g.
-__device__ __forceinline__ float xmax4(float v)  // max over the 4 lanes (g = 0..3) of a pair
+// Logit 16*R + 4*g + r of the lane's pair lives in L[R][r] of lane group g = lane >> 4: one "chunk"
+// of 4 consecutive logits per lane per MFMA output block ("row") R.  Cross-lane traffic inside the
+// 4 lanes of a pair uses v_permlane16_swap / v_permlane32_swap (VALU, no LDS round trip).
+__device__ __forceinline__ unsigned xor16u(unsigned v, int lane)
 {
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    return fmaxf(v, __shfl_xor(v, 32, 64));
+    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return (lane & 16) ? r[0] : r[1];
 }
-__device__ __forceinline__ int xmaxi4(int v)
+__device__ __forceinline__ unsigned xor32u(unsigned v, int lane)
 {
-    v = max(v, __shfl_xor(v, 16, 64));
-    return max(v, __shfl_xor(v, 32, 64));
+    auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (lane & 32) ? r[0] : r[1];
 }
+__device__ __forceinline__ float xor16f(float v, int lane) { return __uint_as_float(xor16u(__float_as_uint(v), lane)); }
+__device__ __forceinline__ float xor32f(float v, int lane) { return __uint_as_float(xor32u(__float_as_uint(v), lane)); }
 
-// Head occupying chunks [C0, C0+NC) (logits [4*C0, 4*(C0+NC))).  Returns the sampled bin (0-based
-// within the head) in every lane of the pair.
+// Head occupying chunks [C0, C0+NC) (columns [4*C0, 4*(C0+NC))).  Returns true in exactly one of the
+// pair's 4 lanes -- the one that owns the sampled bin -- with the bin (0-based within the head).
 template <int C0, int NC, int NOB>
-__device__ __forceinline__ int sample_head(const f32x4 (&L)[NOB], float u, int g, int lane)
+__device__ __forceinline__ bool sample_head(const f32x4 (&L)[NOB], float u, int g, int lane, int& bin)
 {
-    constexpr int OB0 = C0 / 4, OB1 = (C0 + NC - 1) / 4;
+    constexpr int R0 = C0 / 4, R1 = (C0 + NC - 1) / 4, NR = R1 - R0 + 1;
     // 1. max and first arg-max over the head
     float m = -INFINITY;
     int am = 0x7fffffff;
 #pragma unroll
-    for (int ob = OB0; ob <= OB1; ++ob) {
-        const int c = 4 * ob + g;
+    for (int R = R0; R <= R1; ++R) {
+        const int c = 4 * R + g;
         if (c >= C0 && c < C0 + NC) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (L[ob][r] > m) { m = L[ob][r]; am = (c - C0) * 4 + r; }
+                if (L[R][r] > m) { m = L[R][r]; am = (c - C0) * 4 + r; }
         }
     }
-    const float mall = xmax4(m);
-    if (u < 0.f) {  // arg-max mode: lowest bin among the maxima
+    float mall = fmaxf(m, xor16f(m, lane));
+    mall = fmaxf(mall, xor32f(mall, lane));
+    if (u < 0.f) {  // arg-max mode: the lane holding the lowest bin among the maxima owns it
         int cand = (m == mall) ? am : 0x7fffffff;
-        cand = min(cand, __shfl_xor(cand, 16, 64));
-        cand = min(cand, __shfl_xor(cand, 32, 64));
-        return cand;
+        int best = min(cand, (int)xor16u((unsigned)cand, lane));
+        best = min(best, (int)xor32u((unsigned)best, lane));
+        bin = best;
+        return cand == best;
     }
-    // 2. exponentials and chunk sums of the owned chunks
-    f32x4 e[OB1 - OB0 + 1];
-    float cs[OB1 - OB0 + 1];
+    // 2. exponentials, chunk sums, row sums (two exchanges per row)
+    f32x4 e[NR];
+    float cs[NR], x16[NR], s01[NR], rowcdf[NR];
+    float run = 0.f;
 #pragma unroll
-    for (int ob = OB0; ob <= OB1; ++ob) {
-        const int c = 4 * ob + g;
+    for (int R = R0; R <= R1; ++R) {
+        const int c = 4 * R + g;
         const bool own = c >= C0 && c < C0 + NC;
         f32x4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = own ? det_expf(L[ob][r] - mall) : 0.f;
-        e[ob - OB0] = v;
-        cs[ob - OB0] = ((v[0] + v[1]) + v[2]) + v[3];
-    }
-    // 3. chunk CDF in chunk order (all-gather of the chunk sums inside the 4-lane group)
-    const int j = lane & 15;
-    float C[NC];
-    float run = 0.f;
-#pragma unroll
-    for (int ci = 0; ci < NC; ++ci) {
-        const int c = C0 + ci;
-        const float v = __shfl(cs[c / 4 - OB0], j + 16 * (c % 4), 64);
-        run = run + v;
-        C[ci] = run;
+        for (int r = 0; r < 4; ++r) v[r] = own ? det_expf(L[R][r] - mall) : 0.f;
+        e[R - R0] = v;
+        const float c_ = ((v[0] + v[1]) + v[2]) + v[3];
+        const float p16 = xor16f(c_, lane);      // the other chunk of my half-row
+        const float half = c_ + p16;             // s01 in lanes g = 0,1; s23 in lanes g = 2,3 (a+b == b+a)
+        const float oth = xor32f(half, lane);    // the other half-row
+        cs[R - R0] = c_;
+        x16[R - R0] = p16;
+        s01[R - R0] = (g & 2) ? oth : half;
+        run = run + (half + oth);                // s01 + s23
+        rowcdf[R - R0] = run;
     }
     const float t = u * run;
-    // 4. first chunk whose CDF exceeds t
-    int sel = NC;  // none
-    float base = 0.f;
+    // 3. row: first with rowcdf > t, else the last
+    int rs = NR - 1;
 #pragma unroll
-    for (int ci = NC - 1; ci >= 0; --ci)
-        if (C[ci] > t) { sel = ci; base = ci ? C[ci - 1] : 0.f; }
-    int bin = -1;
-    if (sel == NC) {
-        bin = 4 * NC - 1;  // rounding left t >= total: last bin
-    } else {
-        const int c = C0 + sel;
-        if ((c & 3) == g) {  // owner lane walks its 4 entries
-            f32x4 ev = e[0];
+    for (int q = NR - 2; q >= 0; --q)
+        if (rowcdf[q] > t) rs = q;
+    float base = 0.f, c_s = cs[0], p_s = x16[0], h_s = s01[0];
+    f32x4 e_s = e[0];
 #pragma unroll
-            for (int ob = OB0; ob <= OB1; ++ob)
-                if (ob == (c >> 2)) ev = e[ob - OB0];
-            int r = 3;
-            float b = base + ev[0];
-            if (b > t) r = 0;
+    for (int q = 1; q < NR; ++q)
+        if (rs == q) { base = rowcdf[q - 1]; c_s = cs[q]; p_s = x16[q]; h_s = s01[q]; e_s = e[q]; }
+    // 4. chunk inside the row: B0 = base, B1 = base+cs0, B2 = base+s01, B3 = (base+s01)+cs2
+    float B = base;
+    if (g == 1) B = base + p_s;
+    if (g == 2) B = base + h_s;
+    if (g == 3) B = (base + h_s) + p_s;
+    const int cabs = 4 * (R0 + rs) + g;
+    const bool member = cabs >= C0 && cabs < C0 + NC;
+    const bool hit = member && (B + c_s > t);
+    const unsigned long long hm = (__ballot(hit) >> (lane & 15)) & 0x0001000100010001ull;
+    int gsel = -1;
+    if (hm) gsel = (__ffsll((long long)hm) - 1) >> 4;
+    int glast = C0 + NC - 1 - 4 * (R0 + rs);  // last chunk of the head inside this row
+    glast = glast > 3 ? 3 : glast;
+    const bool owner = gsel >= 0 ? (g == gsel) : (g == glast);
+    // 5. entry inside the chunk
+    int r = 3;
+    if (gsel >= 0) {
+        float b = B + e_s[0];
+        if (b > t) r = 0;
+        else {
+            b = b + e_s[1];
+            if (b > t) r = 1;
             else {
-                b = b + ev[1];
-                if (b > t) r = 1;
-                else {
-                    b = b + ev[2];
-                    if (b > t) r = 2;
-                }
+                b = b + e_s[2];
+                if (b > t) r = 2;
             }
-            bin = 4 * sel + r;
         }
     }
-    return xmaxi4(bin);
+    bin = 4 * (cabs - C0) + r;
+    return owner;
 }
 
 struct MlpArgs {
@@ -313,8 +327,36 @@ struct MlpArgs {
     float vr0, vr1;
 };
 
-template <bool LOGITS, bool DECODE>
-__global__ __launch_bounds__(MLP_THREADS, 3) void pair_mlp_kernel(MlpArgs A)
+__device__ __forceinline__ void load_pair_idx(const MlpArgs& A, int64_t pair, int& ia, int& ib)
+{
+    const int64_t p = pair < A.P ? pair : A.P - 1;
+    if (A.idx64) {
+        const longlong2 v = reinterpret_cast<const longlong2*>(A.idxs)[p];
+        ia = (int)v.x; ib = (int)v.y;
+    } else {
+        const int2 v = reinterpret_cast<const int2*>(A.idxs)[p];
+        ia = v.x; ib = v.y;
+    }
+}
+
+// PPF of one pair from already loaded points/normals (models/model.py:118-129); component `g`.
+__device__ __forceinline__ float ppf_from(f3 pa, f3 pb, f3 na, f3 nb, int g)
+{
+    const f3 xy = sub3(pa, pb);
+    const float d = sqrtf((xy.x * xy.x + xy.y * xy.y) + xy.z * xy.z);
+    const float den = d + 1e-7f;                       // fp32 add (torch), unlike the vote kernels
+    const f3 u = {xy.x / den, xy.y / den, xy.z / den};
+    const float p0 = (na.x * u.x + na.y * u.y) + na.z * u.z;
+    const float p1 = (nb.x * u.x + nb.y * u.y) + nb.z * u.z;
+    const float p2 = (na.x * nb.x + na.y * nb.y) + na.z * nb.z;
+    // branch-free 4-way select (a ?: chain becomes divergent branches that split the MFMA schedule)
+    const unsigned m0 = g == 0 ? ~0u : 0u, m1 = g == 1 ? ~0u : 0u, m2 = g == 2 ? ~0u : 0u, m3 = g == 3 ? ~0u : 0u;
+    return __uint_as_float((__float_as_uint(p0) & m0) | (__float_as_uint(p1) & m1) | (__float_as_uint(p2) & m2) |
+                           (__float_as_uint(d) & m3));
+}
+
+template <bool LOGITS, bool DECODE, bool HEADS>
+__global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kernel(MlpArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float W[];
     {
@@ -329,35 +371,57 @@ __global__ __launch_bounds__(MLP_THREADS, 3) void pair_mlp_kernel(MlpArgs A)
     const int64_t n_tiles = (A.P + 16 * PB - 1) / (16 * PB);
     const int64_t wave_gid = (int64_t)blockIdx.x * (MLP_THREADS / 64) + wave;
     const int64_t wave_cnt = (int64_t)gridDim.x * (MLP_THREADS / 64);
+    if (wave_gid >= n_tiles) return;
 
-    for (int64_t tile = wave_gid; tile < n_tiles; tile += wave_cnt) {
-        // The packed weights are loop-invariant LDS data: without this compiler barrier LICM hoists
-        // all ~200 weight registers out of the tile loop and the kernel spills.
-        asm volatile("" ::: "memory");
-        // ---- gather: x0[pb][s], s = 0..20 -------------------------------------------------------
-        float x0[PB][21];
-        int64_t pair[PB];
+    // Software pipeline over this wave's tiles (t, t + wave_cnt, ...): while tile t runs through the
+    // MFMA chain, the gathers of tile t+1 are in flight (indices were fetched one tile earlier still),
+    // so a tile never starts with a dependent idx -> feature round trip to L2/HBM.
+    float x0[PB][21];
+    int ia1[PB], ib1[PB];
+    {
+        int ia[PB], ib[PB];
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) load_pair_idx(A, wave_gid * (16 * PB) + pb * 16 + j, ia[pb], ib[pb]);
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
-            pair[pb] = tile * (16 * PB) + pb * 16 + j;
-            const int64_t pc_ = pair[pb] < A.P ? pair[pb] : A.P - 1;
-            int ia, ib;
-            if (A.idx64) {
-                const longlong2 v = reinterpret_cast<const longlong2*>(A.idxs)[pc_];
-                ia = (int)v.x; ib = (int)v.y;
-            } else {
-                const int2 v = reinterpret_cast<const int2*>(A.idxs)[pc_];
-                ia = v.x; ib = v.y;
-            }
-            const f32x2* fa = reinterpret_cast<const f32x2*>(A.feat + (int64_t)ia * STD_F + 10 * g);
-            const f32x2* fb = reinterpret_cast<const f32x2*>(A.feat + (int64_t)ib * STD_F + 10 * g);
+            const f32x2* fa = reinterpret_cast<const f32x2*>(A.feat + (int64_t)ia[pb] * STD_F + 10 * g);
+            const f32x2* fb = reinterpret_cast<const f32x2*>(A.feat + (int64_t)ib[pb] * STD_F + 10 * g);
 #pragma unroll
             for (int q = 0; q < 5; ++q) {
                 const f32x2 va = fa[q], vb = fb[q];
                 x0[pb][2 * q] = va[0]; x0[pb][2 * q + 1] = va[1];
                 x0[pb][10 + 2 * q] = vb[0]; x0[pb][11 + 2 * q] = vb[1];
             }
-            x0[pb][20] = ppf_component(A.pc, A.nrm, ia, ib, g);
+            x0[pb][20] = ppf_from(ld3(A.pc, ia[pb]), ld3(A.pc, ib[pb]), ld3(A.nrm, ia[pb]), ld3(A.nrm, ib[pb]), g);
+        }
+        const int64_t nt = wave_gid + wave_cnt < n_tiles ? wave_gid + wave_cnt : wave_gid;
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) load_pair_idx(A, nt * (16 * PB) + pb * 16 + j, ia1[pb], ib1[pb]);
+    }
+
+    for (int64_t tile = wave_gid; tile < n_tiles; tile += wave_cnt) {
+        // The packed weights are loop-invariant LDS data: without this compiler barrier LICM hoists
+        // all ~200 weight registers out of the tile loop and the kernel spills.
+        asm volatile("" ::: "memory");
+        int64_t pair[PB];
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) pair[pb] = tile * (16 * PB) + pb * 16 + j;
+
+        // ---- next tile: points / normals in flight during layer 0 ---------------------------------
+        f3 npa[PB], npb[PB], nna[PB], nnb[PB];
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            npa[pb] = ld3(A.pc, ia1[pb]); npb[pb] = ld3(A.pc, ib1[pb]);
+            nna[pb] = ld3(A.nrm, ia1[pb]); nnb[pb] = ld3(A.nrm, ib1[pb]);
+        }
+        f32x2 ut[PB], ur[PB];
+        if (DECODE) {
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) {
+                const int64_t pc_ = pair[pb] < A.P ? pair[pb] : A.P - 1;
+                ut[pb] = reinterpret_cast<const f32x2*>(A.u_tr)[pc_];
+                if (HEADS) ur[pb] = reinterpret_cast<const f32x2*>(A.u_rot)[pc_];
+            }
         }
 
         // ---- layer 0: fc1 | fc0 (84 -> 32 | 32) -------------------------------------------------
@@ -376,6 +440,28 @@ __global__ __launch_bounds__(MLP_THREADS, 3) void pair_mlp_kernel(MlpArgs A)
 #pragma unroll
                 for (int pb = 0; pb < PB; ++pb) acc[pb][ob] = mfma4(w[ob], x0[pb][s], acc[pb][ob]);
         }
+
+        // ---- next tile: PPF from the landed points, feature gathers into the (dead) x0 registers,
+        //      and the indices of the tile after it ---------------------------------------------------
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            x0[pb][20] = ppf_from(npa[pb], npb[pb], nna[pb], nnb[pb], g);
+            const f32x2* fa = reinterpret_cast<const f32x2*>(A.feat + (int64_t)ia1[pb] * STD_F + 10 * g);
+            const f32x2* fb = reinterpret_cast<const f32x2*>(A.feat + (int64_t)ib1[pb] * STD_F + 10 * g);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const f32x2 va = fa[q], vb = fb[q];
+                x0[pb][2 * q] = va[0]; x0[pb][2 * q + 1] = va[1];
+                x0[pb][10 + 2 * q] = vb[0]; x0[pb][11 + 2 * q] = vb[1];
+            }
+        }
+        {
+            int64_t nt = tile + 2 * wave_cnt;
+            nt = nt < n_tiles ? nt : tile;
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) load_pair_idx(A, nt * (16 * PB) + pb * 16 + j, ia1[pb], ib1[pb]);
+        }
+
         // ---- layer 0: fc2 (32 -> 32) on relu(fc1), + fc0 ---------------------------------------
         f32x4 y[PB][2];
         {
@@ -458,69 +544,59 @@ __global__ __launch_bounds__(MLP_THREADS, 3) void pair_mlp_kernel(MlpArgs A)
 #pragma unroll
             for (int pb = 0; pb < PB; ++pb) z[pb] = a2[pb] + a1[pb][1];
         }
-        // ---- final: 16 -> 144 (9 x 16) ------------------------------------------------------------
-        f32x4 L[PB][STD_NOB];
+        // ---- final 16 -> 144 (9 x 16) and epilogue, one 16-pair block at a time (halves the live
+        //      logit registers; the 12 weight reads per block are cheap) ----------------------------
 #pragma unroll
-        for (int ob = 0; ob < STD_NOB; ++ob) {
-            const f32x4 b = ldb4(W + OFF_BF + 16 * ob + 4 * g);
+        for (int pb = 0; pb < PB; ++pb) {
+            f32x4 L[STD_NOB];
 #pragma unroll
-            for (int pb = 0; pb < PB; ++pb) L[pb][ob] = b;
-        }
+            for (int ob = 0; ob < STD_NOB; ++ob) L[ob] = ldb4(W + OFF_BF + 16 * ob + 4 * g);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const float* wp = W + OFF_WF + (s * 64 + lane) * STD_NOBP;
-            const f32x4 w0 = ldb4(wp), w1 = ldb4(wp + 4), w2 = ldb4(wp + 8);
+            for (int s = 0; s < 4; ++s) {
+                const float* wp = W + OFF_WF + (s * 64 + lane) * STD_NOBP;
+                const f32x4 w0 = ldb4(wp), w1 = ldb4(wp + 4), w2 = ldb4(wp + 8);
 #pragma unroll
-            for (int ob = 0; ob < STD_NOB; ++ob) {
-                const float w = ob < 4 ? w0[ob & 3] : (ob < 8 ? w1[ob & 3] : w2[ob & 3]);
-#pragma unroll
-                for (int pb = 0; pb < PB; ++pb) L[pb][ob] = mfma4(w, z[pb][s], L[pb][ob]);
+                for (int ob = 0; ob < STD_NOB; ++ob) {
+                    const float w = ob < 4 ? w0[ob & 3] : (ob < 8 ? w1[ob & 3] : w2[ob & 3]);
+                    L[ob] = mfma4(w, z[pb][s], L[ob]);
+                }
             }
-        }
-
-        // ---- epilogue -----------------------------------------------------------------------------
-        if (LOGITS) {
+            const bool live = pair[pb] < A.P;
+            if (!LOGITS && !DECODE) {  // profiling variant: the MFMA chain alone, results kept alive by a never-true store
+                float sacc = 0.f;
 #pragma unroll
-            for (int pb = 0; pb < PB; ++pb) {
-                if (pair[pb] < A.P) {
+                for (int ob = 0; ob < STD_NOB; ++ob) sacc += (L[ob][0] + L[ob][1]) + (L[ob][2] + L[ob][3]);
+                if (sacc == 1.2345e30f) A.outputs[0] = sacc;
+            }
+            if (LOGITS) {
+                if (live) {
                     float* o = A.out + pair[pb] * A.out_dim + 4 * g;
 #pragma unroll
                     for (int ob = 0; ob < STD_NOB; ++ob)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if (16 * ob + 4 * g + r < A.out_dim) o[16 * ob + r] = L[pb][ob][r];
+                            if (16 * ob + 4 * g + r < A.out_dim) o[16 * ob + r] = L[ob][r];
                 }
             }
-        }
-        if (DECODE) {
-#pragma unroll
-            for (int pb = 0; pb < PB; ++pb) {
-                const bool live = pair[pb] < A.P;
-                const int64_t pc_ = live ? pair[pb] : A.P - 1;
-                const f32x2 ut = reinterpret_cast<const f32x2*>(A.u_tr)[pc_];
-                const int k0 = sample_head<0, 8, STD_NOB>(L[pb], ut[0], g, lane);
-                const int k1 = sample_head<8, 8, STD_NOB>(L[pb], ut[1], g, lane);
-                if (live && g == 0) {
-                    // nocs/inference.py:187-188, fp32 left to right
-                    f32x2 o;
-                    o[0] = ((float)k0 / 31.0f * 2.0f) * A.vr0 - A.vr0;
-                    o[1] = (float)k1 / 31.0f * A.vr1;
-                    reinterpret_cast<f32x2*>(A.outputs)[pair[pb]] = o;
-                }
-                if (A.heads) {
-                    const f32x2 ur = reinterpret_cast<const f32x2*>(A.u_rot)[pc_];
-                    const int ku = sample_head<16, 9, STD_NOB>(L[pb], ur[0], g, lane);
-                    const int kr = sample_head<25, 9, STD_NOB>(L[pb], ur[1], g, lane);
-                    if (live) {
-                        f32x2* h = reinterpret_cast<f32x2*>(A.heads + pair[pb] * 8);
-                        const float pif = (float)CPPF_PI;
-                        if (g == 0) { f32x2 v; v[0] = (float)ku / 35.0f * pif; v[1] = (float)kr / 35.0f * pif; h[0] = v; }
-                        if (g == 2) {  // logits 136..139 = aux_up, aux_right, sx, sy
-                            f32x2 v; v[0] = L[pb][8][0]; v[1] = L[pb][8][1]; h[1] = v;
-                            f32x2 w; w[0] = L[pb][8][2]; w[1] = L[pb][8][3]; h[2] = w;
-                        }
-                        if (g == 3) { f32x2 v; v[0] = L[pb][8][0]; v[1] = 0.f; h[3] = v; }  // logit 140 = sz
+            if (DECODE) {
+                int k;
+                // nocs/inference.py:187-188 (fp32, left to right); the owning lane stores its value
+                if (sample_head<0, 8, STD_NOB>(L, ut[pb][0], g, lane, k) && live)
+                    A.outputs[2 * pair[pb]] = ((float)k / 31.0f * 2.0f) * A.vr0 - A.vr0;
+                if (sample_head<8, 8, STD_NOB>(L, ut[pb][1], g, lane, k) && live)
+                    A.outputs[2 * pair[pb] + 1] = (float)k / 31.0f * A.vr1;
+                if (HEADS) {
+                    float* h = A.heads + pair[pb] * 8;
+                    const float pif = (float)CPPF_PI;
+                    if (sample_head<16, 9, STD_NOB>(L, ur[pb][0], g, lane, k) && live) h[0] = (float)k / 35.0f * pif;
+                    if (sample_head<25, 9, STD_NOB>(L, ur[pb][1], g, lane, k) && live) h[1] = (float)k / 35.0f * pif;
+                    if (live && g == 2) {  // logits 136..139 = aux_up, aux_right, sx, sy
+                        f32x2 v; v[0] = L[8][0]; v[1] = L[8][1];
+                        f32x2 w; w[0] = L[8][2]; w[1] = L[8][3];
+                        reinterpret_cast<f32x2*>(h)[1] = v;
+                        reinterpret_cast<f32x2*>(h)[2] = w;
                     }
+                    if (live && g == 3) { f32x2 v; v[0] = L[8][0]; v[1] = 0.f; reinterpret_cast<f32x2*>(h)[3] = v; }  // 140 = sz
                 }
             }
         }
@@ -610,37 +686,58 @@ __global__ __launch_bounds__(GEN_THREADS) void pair_mlp_generic_kernel(GenArgs A
 
 // ----------------------------------------------------------------------------- decode from memory
 // One lane per (pair, head): same arithmetic as sample_head / oracle orc_sample_bin.
-__device__ int sample_bin_mem(const float* __restrict__ l, int nb, float u)
+__device__ int sample_bin_mem(const float* __restrict__ l, int nb, float u, int col0)
 {
     float m = l[0];
     int am = 0;
     for (int k = 1; k < nb; ++k)
         if (l[k] > m) { m = l[k]; am = k; }
     if (u < 0.f) return am;
-    const int nc = (nb + 3) / 4;
-    float run = 0.f;
-    for (int c = 0; c < nc; ++c) {
+    const int c0 = col0 / 4, c1 = (col0 + nb - 1) / 4, r0 = c0 / 4, r1 = c1 / 4;
+    auto chunk_sum = [&](int c) {
+        if (c < c0 || c > c1) return 0.f;
         float e[4];
-        for (int r = 0; r < 4; ++r) e[r] = 4 * c + r < nb ? det_expf(l[4 * c + r] - m) : 0.f;
-        run = run + (((e[0] + e[1]) + e[2]) + e[3]);
+        for (int r = 0; r < 4; ++r) { const int k = 4 * c + r - col0; e[r] = k < nb ? det_expf(l[k] - m) : 0.f; }
+        return ((e[0] + e[1]) + e[2]) + e[3];
+    };
+    float run = 0.f;
+    for (int R = r0; R <= r1; ++R) {
+        const float s01 = chunk_sum(4 * R) + chunk_sum(4 * R + 1), s23 = chunk_sum(4 * R + 2) + chunk_sum(4 * R + 3);
+        run = run + (s01 + s23);
     }
     const float t = u * run;
-    float C = 0.f;
-    for (int c = 0; c < nc; ++c) {
-        float e[4];
-        for (int r = 0; r < 4; ++r) e[r] = 4 * c + r < nb ? det_expf(l[4 * c + r] - m) : 0.f;
-        const float Cn = C + (((e[0] + e[1]) + e[2]) + e[3]);
-        if (Cn > t) {
-            float b = C;
-            for (int r = 0; r < 4; ++r) {
-                b = b + e[r];
-                if (b > t) return min(4 * c + r, nb - 1);
-            }
-            return min(4 * c + 3, nb - 1);
-        }
-        C = Cn;
+    int Rs = r1;
+    float base = 0.f, cdf = 0.f;
+    for (int R = r0; R <= r1; ++R) {
+        const float s01 = chunk_sum(4 * R) + chunk_sum(4 * R + 1), s23 = chunk_sum(4 * R + 2) + chunk_sum(4 * R + 3);
+        const float nxt = cdf + (s01 + s23);
+        if (nxt > t || R == r1) { Rs = R; base = cdf; break; }
+        cdf = nxt;
     }
-    return nb - 1;
+    const float c[4] = {chunk_sum(4 * Rs), chunk_sum(4 * Rs + 1), chunk_sum(4 * Rs + 2), chunk_sum(4 * Rs + 3)};
+    const float s01 = c[0] + c[1];
+    const float B[4] = {base, base + c[0], base + s01, (base + s01) + c[2]};
+    int gsel = -1, glast = 0;
+    for (int g = 0; g < 4; ++g) {
+        const int ca = 4 * Rs + g;
+        if (ca < c0 || ca > c1) continue;
+        glast = g;
+        if (gsel < 0 && B[g] + c[g] > t) gsel = g;
+    }
+    int k;
+    if (gsel < 0) {
+        k = 4 * (4 * Rs + glast) + 3 - col0;
+    } else {
+        float b = B[gsel];
+        int rsel = 3;
+        for (int r = 0; r < 4; ++r) {
+            const int kk = 4 * (4 * Rs + gsel) + r - col0;
+            b = b + (kk < nb ? det_expf(l[kk] - m) : 0.f);
+            if (b > t) { rsel = r; break; }
+        }
+        k = 4 * (4 * Rs + gsel) + rsel - col0;
+    }
+    return k < nb ? k : nb - 1;
 }
 
 __global__ __launch_bounds__(256) void decode_center_kernel(const float* __restrict__ logits, int64_t P, int ld, int nb,
@@ -651,7 +748,7 @@ __global__ __launch_bounds__(256) void decode_center_kernel(const float* __restr
     if (i >= 2 * P) return;
     const int64_t p = i >> 1;
     const int h = (int)(i & 1);
-    const int k = sample_bin_mem(logits + p * ld + h * nb, nb, u[i]);
+    const int k = sample_bin_mem(logits + p * ld + h * nb, nb, u[i], h * nb);
     const float d = (float)(nb - 1);
     outputs[i] = h == 0 ? ((float)k / d * 2.0f) * vr0 - vr0 : (float)k / d * vr1;
 }
@@ -665,7 +762,7 @@ __global__ __launch_bounds__(256) void decode_rot_kernel(const float* __restrict
     const int64_t p = i >> 1;
     const int h = (int)(i & 1);
     const float* l = logits + p * ld;
-    const int k = sample_bin_mem(l + 2 * tb + h * rb, rb, u[i]);
+    const int k = sample_bin_mem(l + 2 * tb + h * rb, rb, u[i], 2 * tb + h * rb);
     float* o = heads + 8 * p;
     o[h] = (float)k / (float)(rb - 1) * (float)CPPF_PI;
     if (h == 0) { o[2] = l[out_dim - 5]; o[3] = l[out_dim - 4]; o[4] = l[out_dim - 3]; }
@@ -677,22 +774,23 @@ static int mlp_grid(int64_t P)
 {
     const int64_t tiles = (P + 16 * PB - 1) / (16 * PB);
     int64_t nb = (tiles + MLP_THREADS / 64 - 1) / (MLP_THREADS / 64);
-    if (nb > 768) nb = 768;  // 3 workgroups of 4 waves per CU resident (52.6 KB LDS each, <=168 VGPR)
+    const int64_t resident = 256 * (MLP_WAVES_PER_SIMD * 4 / (MLP_THREADS / 64));  // workgroups the chip holds at once
+    if (nb > resident) nb = resident;
     if (nb < 1) nb = 1;
     return (int)nb;
 }
 
-template <bool LOGITS, bool DECODE>
+template <bool LOGITS, bool DECODE, bool HEADS>
 static int launch_std(const MlpArgs& A, hipStream_t st)
 {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mlp_kernel<LOGITS, DECODE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mlp_kernel<LOGITS, DECODE, HEADS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, STD_PACKED * sizeof(float));
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((pair_mlp_kernel<LOGITS, DECODE>), dim3(mlp_grid(A.P)), dim3(MLP_THREADS),
+    hipLaunchKernelGGL((pair_mlp_kernel<LOGITS, DECODE, HEADS>), dim3(mlp_grid(A.P)), dim3(MLP_THREADS),
                        STD_PACKED * sizeof(float), st, A);
     CPPF_CHECK_LAUNCH();
     return 0;
@@ -711,7 +809,7 @@ extern "C" int cppf_pair_mlp_forward(const float* pc, const float* nrm, const fl
         MlpArgs A = {};
         A.pc = pc; A.nrm = nrm; A.feat = feat; A.idxs = idxs; A.packed = packed; A.out = out; A.P = P;
         A.out_dim = out_dim; A.idx64 = idx_is_i64;
-        return launch_std<true, false>(A, st);
+        return launch_std<true, false, false>(A, st);
     }
     if (!gen_ok(F, dims, n_res, out_dim)) return CPPF_EUNSUPPORTED;
     GenArgs G = {};
@@ -747,7 +845,19 @@ extern "C" int cppf_pair_mlp_decode(const float* pc, const float* nrm, const flo
     MlpArgs A = {};
     A.pc = pc; A.nrm = nrm; A.feat = feat; A.idxs = idxs; A.packed = packed; A.P = P; A.out_dim = out_dim;
     A.idx64 = idx_is_i64; A.u_tr = u_tr; A.u_rot = u_rot; A.outputs = outputs; A.heads = heads; A.vr0 = vr0; A.vr1 = vr1;
-    return launch_std<false, true>(A, (hipStream_t)stream);
+    return heads ? launch_std<false, true, true>(A, (hipStream_t)stream)
+                 : launch_std<false, true, false>(A, (hipStream_t)stream);
+}
+
+// Profiling aid (not part of the drop-in surface): the PPF + gather + MFMA chain with no epilogue.
+extern "C" int cppf_debug_mlp_chain_only(const float* pc, const float* nrm, const float* feat, const void* idxs,
+                                         int idx_is_i64, const float* packed, int64_t P, float* scratch, void* stream)
+{
+    if (!pc || !nrm || !feat || !idxs || !packed || !scratch || P < 1) return CPPF_EINVAL;
+    MlpArgs A = {};
+    A.pc = pc; A.nrm = nrm; A.feat = feat; A.idxs = idxs; A.packed = packed; A.P = P; A.out_dim = 141;
+    A.idx64 = idx_is_i64; A.outputs = scratch;
+    return launch_std<false, false, false>(A, (hipStream_t)stream);
 }
 
 extern "C" int cppf_decode_center(const float* logits, int64_t P, int ld, int tr_bins, float vr0, float vr1,

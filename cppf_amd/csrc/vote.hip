@@ -421,9 +421,9 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
 // ----------------------------------------------------------------------------- reduce + arg-max
 // grid[cell] (+)= sum_c partials[c][cell] in a fixed order, and the arg-max of the result with
 // numpy's tie rule (first maximum in C order, nocs/inference.py:208): key = ord(value) << 32 |
-// ~index, max-reduced in the wave, then one returning atomicMax per block.  A block = 64 cells x 4
-// chunk groups (chunk c goes to group c & 3) so that ~100 partial grids stream with 4x the loads in
-// flight.  The last block to take a ticket unpacks the key into out_idx / out_val: every access to
+// ~index, max-reduced in the wave, then one returning atomicMax per block.  A block = 64 cells x 16
+// chunk groups (chunk c goes to group c % 16) with 8 loads in flight per lane, so the ~100 partial
+// grids stream at L2/HBM rate instead of one dependent load at a time.  The last block to take a ticket unpacks the key into out_idx / out_val: every access to
 // the key and the ticket is a device-scope atomic whose result is consumed before the next one is
 // issued, so no cache maintenance is needed.
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
@@ -435,34 +435,48 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
     return k;
 }
 
-__global__ __launch_bounds__(256) void reduce_argmax_kernel(float* __restrict__ grid,
-                                                            const float* __restrict__ partials, int chunks,
-                                                            int64_t G, unsigned long long* packed, int accumulate,
-                                                            int write_back, long long* out_idx, float* out_val)
+#define RED_GROUPS 16
+#define RED_MAX_BLOCKS 256
+__global__ __launch_bounds__(64 * RED_GROUPS) void reduce_argmax_kernel(float* __restrict__ grid,
+                                                                        const float* __restrict__ partials, int chunks,
+                                                                        int64_t G, unsigned long long* packed,
+                                                                        int accumulate, int write_back,
+                                                                        long long* out_idx, float* out_val)
 {
-    __shared__ float part[4][64];
+    __shared__ float part[RED_GROUPS][64];
     const int lane = threadIdx.x & 63, cg = threadIdx.x >> 6;
-    const int64_t cell = (int64_t)blockIdx.x * 64 + lane;
-    float s = 0.f;
-    if (cell < G) {
-        int c = cg;
-        for (; c + 12 < chunks; c += 16) {  // 4 independent loads in flight per lane
-            const float v0 = partials[(int64_t)c * G + cell], v1 = partials[(int64_t)(c + 4) * G + cell];
-            const float v2 = partials[(int64_t)(c + 8) * G + cell], v3 = partials[(int64_t)(c + 12) * G + cell];
-            s = (((s + v0) + v1) + v2) + v3;
-        }
-        for (; c < chunks; c += 4) s = s + partials[(int64_t)c * G + cell];
-    }
-    part[cg][lane] = s;
-    __syncthreads();
-    if (cg != 0) return;
+    const int64_t ngroups = (G + 63) / 64;
     unsigned long long key = 0ull;
-    if (cell < G) {
-        float v = accumulate ? grid[cell] : 0.f;
-        v = (((v + part[0][lane]) + part[1][lane]) + part[2][lane]) + part[3][lane];
-        if (write_back) grid[cell] = v;
-        key = ((unsigned long long)f2ord(v) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)cell);
+    // grid-stride over 64-cell groups: few blocks, so the two same-address atomics per block at the end
+    // (~12 ns each, serialised chip-wide) stay negligible
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int64_t cell = grp * 64 + lane;
+        float s = 0.f;
+        if (cell < G) {
+            int c = cg;
+            for (; c + 7 * RED_GROUPS < chunks; c += 8 * RED_GROUPS) {  // 8 independent loads in flight per lane
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = partials[(int64_t)(c + k * RED_GROUPS) * G + cell];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s = s + v[k];
+            }
+            for (; c < chunks; c += RED_GROUPS) s = s + partials[(int64_t)c * G + cell];
+        }
+        part[cg][lane] = s;
+        __syncthreads();
+        if (cg == 0 && cell < G) {
+            float v = accumulate ? grid[cell] : 0.f;
+#pragma unroll
+            for (int k = 0; k < RED_GROUPS; ++k) v = v + part[k][lane];
+            if (write_back) grid[cell] = v;
+            const unsigned long long kk =
+                ((unsigned long long)f2ord(v) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)cell);
+            key = kk > key ? kk : key;
+        }
+        __syncthreads();
     }
+    if (cg != 0) return;
     key = wave_max_u64(key);
     if (lane == 0) {
         const unsigned long long old = atomicMax(packed, key);          // returning: completes before the ticket
@@ -545,8 +559,9 @@ static int vote_impl(const float* points, const float* outputs, const float* pro
     CPPF_CHECK_LAUNCH();
 
     if (pl.tiled || want_argmax) {
-        const int64_t nb = (G + 63) / 64;
-        hipLaunchKernelGGL(reduce_argmax_kernel, dim3((unsigned)nb), dim3(256), 0, st, grid_obj, partials,
+        int64_t nb = (G + 63) / 64;
+        if (nb > RED_MAX_BLOCKS) nb = RED_MAX_BLOCKS;
+        hipLaunchKernelGGL(reduce_argmax_kernel, dim3((unsigned)nb), dim3(64 * RED_GROUPS), 0, st, grid_obj, partials,
                            pl.chunks, G, packed, pl.tiled ? accumulate : 1, pl.tiled ? 1 : 0,
                            want_argmax ? out_idx : nullptr, want_argmax ? out_val : nullptr);
         CPPF_CHECK_LAUNCH();
@@ -581,8 +596,9 @@ extern "C" int cppf_grid_argmax(const float* grid, int64_t n, long long* out_idx
     hipStream_t st = (hipStream_t)stream;
     unsigned long long* packed = static_cast<unsigned long long*>(workspace);
     hipLaunchKernelGGL(zero_u64x2_kernel, dim3(1), dim3(1), 0, st, packed);
-    const int64_t nb = (n + 63) / 64;
-    hipLaunchKernelGGL(reduce_argmax_kernel, dim3((unsigned)nb), dim3(256), 0, st, const_cast<float*>(grid),
+    int64_t nb = (n + 63) / 64;
+    if (nb > RED_MAX_BLOCKS) nb = RED_MAX_BLOCKS;
+    hipLaunchKernelGGL(reduce_argmax_kernel, dim3((unsigned)nb), dim3(64 * RED_GROUPS), 0, st, const_cast<float*>(grid),
                        (const float*)nullptr, 0, n, packed, 1, 0, out_idx, out_val);
     CPPF_CHECK_LAUNCH();
     return 0;

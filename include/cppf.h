@@ -153,6 +153,12 @@ int cppf_pair_mlp_decode(const float* pc, const float* nrm, const float* feat, c
                          int out_dim, int tr_bins, int rot_bins, float vr0, float vr1, const float* u_tr,
                          const float* u_rot, float* outputs, float* heads, void* stream);
 
+/* Profiling aid, not part of the drop-in surface: the PPF + gather + MFMA chain of the standard
+ * architecture with no epilogue (isolates the matrix pipeline when reading rocprof counters).
+ * scratch: >= 4 bytes of device memory (never written in practice). */
+int cppf_debug_mlp_chain_only(const float* pc, const float* nrm, const float* feat, const void* idxs, int idx_is_i64,
+                              const float* packed, int64_t P, float* scratch, void* stream);
+
 /* Decode from logits already in memory (generic architectures / bin counts). */
 int cppf_decode_center(const float* logits, int64_t P, int ld, int tr_bins, float vr0, float vr1,
                        const float* u_tr, float* outputs, void* stream);

@@ -84,12 +84,12 @@ static inline int sat_int(double v)
 static inline float bits_f(int32_t b) { float f; memcpy(&f, &b, 4); return f; }
 static inline int32_t f_bits(float f) { int32_t b; memcpy(&b, &f, 4); return b; }
 
-/* exp(x) for x <= ~88: n = rint(x*log2e), r = x - n*ln2 (two-term), degree-5 core, 2^n by
- * exponent arithmetic.  Max error ~1.5 ulp on [-86, 0].  Flushes to 0 below -86. */
+/* exp(x) for x <= 0 (softmax after the max subtraction): x clamped to [-86, 0], n = rint(x*log2e),
+ * r = x - n*ln2 (two-term), degree-5 core, 2^n by exponent arithmetic.  Max error ~1.5 ulp. */
 float orc_expf(float x)
 {
-    if (x < -86.0f) return 0.0f;
-    if (x > 88.0f) x = 88.0f;
+    x = x < -86.0f ? -86.0f : x;
+    x = x > 0.0f ? 0.0f : x;
     float n = rintf(x * 1.44269504088896341f);
     float r = fmaf(n, -0.693359375f, x);
     r = fmaf(n, 2.12194440e-4f, r);
@@ -310,47 +310,77 @@ int orc_pair_mlp(const float* pc, const float* nrm, const float* feat, const int
 /* ------------------------------------------------------------------ decode */
 
 /*
- * Sample one bin from softmax(logits[0..nb)) with uniform u in [0,1) by inverse CDF
- * (deterministic stand-in for torch.multinomial, nocs/inference.py:186; the draw itself is
- * supplied by the caller).  The CDF is built hierarchically so that 4 lanes of a wave can
- * build it without a serial 32-long dependency:
- *   e_k = orc_expf(l_k - max_k l)
- *   chunk sums  cs[c] = ((e[4c]+e[4c+1])+e[4c+2])+e[4c+3]         (missing entries = 0)
- *   chunk CDF   C[c]  = C[c-1] + cs[c]  (C[-1] = 0), total = C[last]
- *   t = u * total; first chunk c with C[c] > t; inside it first r with
- *   (...((C[c-1] + e[4c]) + e[4c+1]) ...) > t; no such chunk/entry -> last bin.
- * u < 0 selects the argmax bin (first maximum) instead.
+ * Sample one bin from softmax(l[0..nb)) with uniform u in [0,1) by inverse CDF (deterministic
+ * stand-in for torch.multinomial, nocs/inference.py:186; the draw itself is supplied by the
+ * caller).  u < 0 selects the arg-max bin (first maximum) instead.
+ *
+ * The CDF is built on the layout the HIP kernel holds the logits in, so that four lanes can build
+ * it with two cross-lane exchanges per 16 logits and no serial 32-long dependency.  col0 is the
+ * absolute column of l[0] in the logit row (a multiple of 4); columns are grouped as
+ *     row  R = col / 16      (one MFMA output block)
+ *     chunk g = (col / 4) % 4 (the 4 consecutive logits one lane owns), entries r = col % 4.
+ *   e_k    = orc_expf(l_k - max l)
+ *   cs[R][g] = ((e0+e1)+e2)+e3 of the chunk (0 for chunks outside the head)
+ *   s01 = cs0 + cs1, s23 = cs2 + cs3, rowsum[R] = s01 + s23
+ *   rowcdf[R] = rowcdf[R-1] + rowsum[R]; total = last; t = u * total
+ *   row:   first R with rowcdf[R] > t, else the last row;  base = rowcdf[R-1] (0 for the first)
+ *   chunk: B0 = base, B1 = base + cs0, B2 = base + s01, B3 = (base + s01) + cs2, E_g = B_g + cs_g;
+ *          first g inside the head with E_g > t; none -> last bin of the row's part of the head
+ *   entry: b = B_g; first r with (b += e_r) > t, else r = 3.
  */
-int orc_sample_bin(const float* l, int nb, float u)
+int orc_sample_bin(const float* l, int nb, float u, int col0)
 {
     float m = l[0];
     int am = 0;
     for (int k = 1; k < nb; ++k)
         if (l[k] > m) { m = l[k]; am = k; }
     if (u < 0.0f) return am;
-    float e[ORC_MAXD];
-    int nc = (nb + 3) / 4;
-    for (int k = 0; k < nb; ++k) e[k] = orc_expf(l[k] - m);
-    for (int k = nb; k < 4 * nc; ++k) e[k] = 0.0f;
-    float C[ORC_MAXD / 4];
+    const int c0 = col0 / 4, c1 = (col0 + nb - 1) / 4;      /* absolute chunk range (inclusive) */
+    const int r0 = c0 / 4, r1 = c1 / 4;
+    float cs[ORC_MAXD / 16 + 2][4], e[ORC_MAXD / 16 + 2][4][4], rowcdf[ORC_MAXD / 16 + 2];
     float run = 0.0f;
-    for (int c = 0; c < nc; ++c) {
-        float cs = ((e[4 * c] + e[4 * c + 1]) + e[4 * c + 2]) + e[4 * c + 3];
-        run = run + cs;
-        C[c] = run;
-    }
-    float t = u * run;
-    for (int c = 0; c < nc; ++c) {
-        if (C[c] > t) {
-            float base = c ? C[c - 1] : 0.0f;
+    for (int R = r0; R <= r1; ++R) {
+        for (int g = 0; g < 4; ++g) {
+            const int c = 4 * R + g;
             for (int r = 0; r < 4; ++r) {
-                base = base + e[4 * c + r];
-                if (base > t) { int k = 4 * c + r; return k < nb ? k : nb - 1; }
+                const int k = 4 * c + r - col0;
+                e[R - r0][g][r] = (c >= c0 && c <= c1 && k < nb) ? orc_expf(l[k] - m) : 0.0f;
             }
-            { int k = 4 * c + 3; return k < nb ? k : nb - 1; }
+            const float* q = e[R - r0][g];
+            cs[R - r0][g] = ((q[0] + q[1]) + q[2]) + q[3];
         }
+        const float s01 = cs[R - r0][0] + cs[R - r0][1], s23 = cs[R - r0][2] + cs[R - r0][3];
+        run = run + (s01 + s23);
+        rowcdf[R - r0] = run;
     }
-    return nb - 1;
+    const float t = u * run;
+    int R = r1;
+    for (int q = r0; q <= r1; ++q)
+        if (rowcdf[q - r0] > t) { R = q; break; }
+    const float base = R > r0 ? rowcdf[R - r0 - 1] : 0.0f;
+    const float* c = cs[R - r0];
+    const float s01 = c[0] + c[1];
+    const float B[4] = {base, base + c[0], base + s01, (base + s01) + c[2]};
+    int gsel = -1, glast = 0;
+    for (int g = 0; g < 4; ++g) {
+        const int ca = 4 * R + g;
+        if (ca < c0 || ca > c1) continue;
+        glast = g;
+        if (gsel < 0 && B[g] + c[g] > t) gsel = g;
+    }
+    int k;
+    if (gsel < 0) {
+        k = 4 * (4 * R + glast) + 3 - col0;
+    } else {
+        float b = B[gsel];
+        int rsel = 3;
+        for (int r = 0; r < 4; ++r) {
+            b = b + e[R - r0][gsel][r];
+            if (b > t) { rsel = r; break; }
+        }
+        k = 4 * (4 * R + gsel) + rsel - col0;
+    }
+    return k < nb ? k : nb - 1;
 }
 
 /* nocs/inference.py:185-188: mu = k/(nb-1)*2*vr0 - vr0, nu = k/(nb-1)*vr1, fp32 left to right
@@ -361,8 +391,8 @@ void orc_decode_center(const float* logits, int64_t P, int ld, int nb, const flo
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < P; ++i) {
         const float* l = logits + i * ld;
-        int k0 = orc_sample_bin(l, nb, u[2 * i]);
-        int k1 = orc_sample_bin(l + nb, nb, u[2 * i + 1]);
+        int k0 = orc_sample_bin(l, nb, u[2 * i], 0);
+        int k1 = orc_sample_bin(l + nb, nb, u[2 * i + 1], nb);
         float d = (float)(nb - 1);
         outputs[2 * i] = ((float)k0 / d * 2.0f) * vr0 - vr0;
         outputs[2 * i + 1] = (float)k1 / d * vr1;
@@ -380,8 +410,8 @@ void orc_decode_rot(const float* logits, int64_t P, int ld, int out_dim, int tb,
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < P; ++i) {
         const float* l = logits + i * ld;
-        int ku = orc_sample_bin(l + 2 * tb, rb, u[2 * i]);
-        int kr = orc_sample_bin(l + 2 * tb + rb, rb, u[2 * i + 1]);
+        int ku = orc_sample_bin(l + 2 * tb, rb, u[2 * i], 2 * tb);
+        int kr = orc_sample_bin(l + 2 * tb + rb, rb, u[2 * i + 1], 2 * tb + rb);
         float d = (float)(rb - 1);
         float* h = heads + 8 * i;
         h[0] = (float)ku / d * pif;

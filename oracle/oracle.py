@@ -133,9 +133,10 @@ def pair_mlp(pc, nrm, feat, idxs, sd, ppffcs, out_dim, order=0):
 
 
 # --------------------------------------------------------------------------- decode
-def sample_bin(logits, u):
+def sample_bin(logits, u, col0=0):
+    """inverse-CDF draw; col0 = absolute column of logits[0] in the logit row (layout of the CDF)"""
     logits = _c(logits, _f)
-    return int(lib().orc_sample_bin(_p(logits, _pf), C.c_int(logits.size), C.c_float(float(u))))
+    return int(lib().orc_sample_bin(_p(logits, _pf), C.c_int(logits.size), C.c_float(float(u)), C.c_int(col0)))
 
 
 def decode_center(logits, u, tr_num_bins, vote_range):

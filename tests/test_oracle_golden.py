@@ -68,7 +68,7 @@ def test_det_math_accuracy(oracle):
     e = np.array([oracle.expf(x) for x in xs])
     r = np.exp(xs.astype(np.float64))
     assert np.max(np.abs(e - r) / r) < 2e-7
-    assert oracle.expf(-100.0) == 0.0 and oracle.expf(0.0) == 1.0
+    assert oracle.expf(-100.0) == oracle.expf(-86.0) < 1e-37 and oracle.expf(0.0) == 1.0
     for x in np.linspace(-7, 7, 1001):
         s, c = oracle.sincos(x)
         assert abs(s - math.sin(x)) < 5e-16 and abs(c - math.cos(x)) < 5e-16
@@ -93,6 +93,14 @@ def test_sample_bin_is_an_inverse_cdf(oracle):
     ref = np.searchsorted(cdf, us, side="right")
     assert np.mean(ks == np.clip(ref, 0, 31)) > 0.995       # fp32 CDF rounding near bin edges only
     assert np.all(np.abs(ks - np.clip(ref, 0, 31)) <= 1)
+    # a 36-bin head that starts mid-row (column 100, like the "right" head) samples the same law
+    l36 = rng.normal(0, 2, 36).astype(np.float32)
+    p36 = np.exp(l36 - l36.max()); p36 /= p36.sum()
+    for col0 in (64, 100, 0, 4):
+        k36 = np.array([oracle.sample_bin(l36, u, col0) for u in us])
+        r36 = np.clip(np.searchsorted(np.cumsum(p36), us, side="right"), 0, 35)
+        assert np.mean(k36 == r36) > 0.995 and np.all(np.abs(k36 - r36) <= 1)
+        assert oracle.sample_bin(l36, -1.0, col0) == int(np.argmax(l36))
     assert oracle.sample_bin(l, -1.0) == int(np.argmax(l))
     assert oracle.sample_bin(l, 0.0) == int(np.nonzero(p > 0)[0][0]) or True
     assert oracle.sample_bin(l, np.float32(1.0) - np.float32(2 ** -24)) <= 31
