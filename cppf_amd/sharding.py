@@ -60,9 +60,9 @@ def gather_records(local_records, n_objects, rank, world, device=None):
         dev = device if device is not None else local_records.device
         buf = torch.full((n_max, RECORD), -1.0, dtype=torch.float64, device=dev)
         buf[:local_records.shape[0]] = local_records.to(dev)
-        allb = torch.empty((world, n_max, RECORD), dtype=torch.float64, device=dev)
+        allb = torch.empty((world * n_max, RECORD), dtype=torch.float64, device=dev)   # rank-major concatenation
         dist.all_gather_into_tensor(allb, buf)
-        out = allb.reshape(-1, RECORD)
+        out = allb
         out = out[out[:, 15] >= 0]
     order = torch.argsort(out[:, 15])
     out = out[order]
