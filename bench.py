@@ -48,7 +48,7 @@ def pmc_traffic(kernel):
 def cpu_baseline(ob, idx, u_tr, u_rot, sd, cfg, corner, dims, budget_s=12.0):
     """The oracle (CPU restatement, all host cores via OpenMP) timed on the same workload."""
     from oracle import oracle as O
-    threads = os.cpu_count() or 1
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     O.set_threads(threads)
     P = idx.shape[0]
     idx32 = idx.astype(np.int32)

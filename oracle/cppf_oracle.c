@@ -213,14 +213,15 @@ static void orc_k_order(int K, int F, int first, int order, int* perm)
 
 /* y[o] = b[o] (+) sum_k W[o][k] x[k] as an fmaf chain in perm order; Wt is [K][Nout] (k-major
  * copy of torch's [Nout][K] weight so the o-loop vectorises). */
-static inline void linear_chain(const float* Wt, const float* b, const float* x, const int* perm,
-                                int K, int Nout, float* y)
+static inline void linear_chain(const float* restrict Wt, const float* restrict b, const float* restrict x,
+                                const int* restrict perm, int K, int Nout, float* restrict y)
 {
     for (int o = 0; o < Nout; ++o) y[o] = b[o];
     for (int kk = 0; kk < K; ++kk) {
         int k = perm[kk];
         float xv = x[k];
-        const float* w = Wt + (size_t)k * Nout;
+        const float* restrict w = Wt + (size_t)k * Nout;
+#pragma omp simd
         for (int o = 0; o < Nout; ++o) y[o] = fmaf(w[o], xv, y[o]);
     }
 }
