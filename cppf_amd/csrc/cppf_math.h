@@ -33,23 +33,22 @@ __device__ __forceinline__ f3 ld3(const float* __restrict__ p, int i)
     return {p[3 * i], p[3 * i + 1], p[3 * i + 2]};
 }
 
-// exp(x) for x <= 0 (softmax after the max subtraction), x clamped to [-86, 0].
-// n = rint(x*log2e); r = x - n*ln2 (two terms); degree-5 core; 2^n by exponent arithmetic.
+// exp(x) for x <= 0 (softmax after the max subtraction; callers guarantee x <= 0), clamped below at -86:
+// 2^(x*log2e) = 2^n * p(f), n = rint(y), f = y - n in [-0.5, 0.5] (exact), p = degree-4 minimax of 2^f.
+// Max relative error 7e-6 (2.7e-6 from the core, the rest from rounding x*log2e) -- far below what an inverse-CDF draw can resolve -- at 10 VALU instead of
+// 18: on gfx950 fp32 MFMA and VALU share one datapath, so every decode instruction is paid in full.
 __device__ __forceinline__ float det_expf(float x)
 {
-    x = x < -86.0f ? -86.0f : x;
-    x = x > 0.0f ? 0.0f : x;
-    float n = rintf(x * 1.44269504088896341f);
-    float r = fmaf(n, -0.693359375f, x);
-    r = fmaf(n, 2.12194440e-4f, r);
-    float p = 1.9875691500e-4f;
-    p = fmaf(p, r, 1.3981999507e-3f);
-    p = fmaf(p, r, 8.3334519073e-3f);
-    p = fmaf(p, r, 4.1665795894e-2f);
-    p = fmaf(p, r, 1.6666665459e-1f);
-    p = fmaf(p, r, 5.0000001201e-1f);
-    float y = fmaf(p, r * r, r) + 1.0f;
-    return __int_as_float(__float_as_int(y) + ((int)n << 23));
+    x = fmaxf(x, -86.0f);
+    const float y = x * 1.44269504088896341f;
+    const float n = rintf(y);
+    const float f = y - n;
+    float p = 9.570102207e-03f;
+    p = fmaf(p, f, 5.591785908e-02f);
+    p = fmaf(p, f, 2.402474433e-01f);
+    p = fmaf(p, f, 6.931217909e-01f);
+    p = fmaf(p, f, 9.999992847e-01f);
+    return __int_as_float(__float_as_int(p) + ((int)n << 23));
 }
 
 // fp64 sin/cos: Cody-Waite by pi/2 + degree-13/14 kernels on [-pi/4, pi/4].

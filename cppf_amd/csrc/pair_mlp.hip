@@ -224,27 +224,17 @@ template <int C0, int NC, int NOB>
 __device__ __forceinline__ bool sample_head(const f32x4 (&L)[NOB], float u, int g, int lane, int& bin)
 {
     constexpr int R0 = C0 / 4, R1 = (C0 + NC - 1) / 4, NR = R1 - R0 + 1;
-    // 1. max and first arg-max over the head
+    // 1. max over the head
     float m = -INFINITY;
-    int am = 0x7fffffff;
 #pragma unroll
     for (int R = R0; R <= R1; ++R) {
         const int c = 4 * R + g;
-        if (c >= C0 && c < C0 + NC) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (L[R][r] > m) { m = L[R][r]; am = (c - C0) * 4 + r; }
-        }
+        const bool own = c >= C0 && c < C0 + NC;
+        const float mr = fmaxf(fmaxf(L[R][0], L[R][1]), fmaxf(L[R][2], L[R][3]));
+        m = own ? fmaxf(m, mr) : m;
     }
     float mall = fmaxf(m, xor16f(m, lane));
     mall = fmaxf(mall, xor32f(mall, lane));
-    if (u < 0.f) {  // arg-max mode: the lane holding the lowest bin among the maxima owns it
-        int cand = (m == mall) ? am : 0x7fffffff;
-        int best = min(cand, (int)xor16u((unsigned)cand, lane));
-        best = min(best, (int)xor32u((unsigned)best, lane));
-        bin = best;
-        return cand == best;
-    }
     // 2. exponentials, chunk sums, row sums (two exchanges per row)
     f32x4 e[NR];
     float cs[NR], x16[NR], s01[NR], rowcdf[NR];
@@ -255,7 +245,10 @@ __device__ __forceinline__ bool sample_head(const f32x4 (&L)[NOB], float u, int 
         const bool own = c >= C0 && c < C0 + NC;
         f32x4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = own ? det_expf(L[R][r] - mall) : 0.f;
+        for (int r = 0; r < 4; ++r) {
+            const float ex = det_expf(L[R][r] - mall);
+            v[r] = own ? ex : 0.f;
+        }
         e[R - R0] = v;
         const float c_ = ((v[0] + v[1]) + v[2]) + v[3];
         const float p16 = xor16f(c_, lane);      // the other chunk of my half-row
@@ -268,45 +261,55 @@ __device__ __forceinline__ bool sample_head(const f32x4 (&L)[NOB], float u, int 
         rowcdf[R - R0] = run;
     }
     const float t = u * run;
-    // 3. row: first with rowcdf > t, else the last
+    // 3. row: first with rowcdf > t, else the last (branch-free selects)
     int rs = NR - 1;
+    float base = NR > 1 ? rowcdf[NR - 2] : 0.f, c_s = cs[NR - 1], p_s = x16[NR - 1], h_s = s01[NR - 1];
+    f32x4 e_s = e[NR - 1];
 #pragma unroll
-    for (int q = NR - 2; q >= 0; --q)
-        if (rowcdf[q] > t) rs = q;
-    float base = 0.f, c_s = cs[0], p_s = x16[0], h_s = s01[0];
-    f32x4 e_s = e[0];
+    for (int q = NR - 2; q >= 0; --q) {
+        const bool pick = rowcdf[q] > t;
+        rs = pick ? q : rs;
+        base = pick ? (q ? rowcdf[q > 0 ? q - 1 : 0] : 0.f) : base;
+        c_s = pick ? cs[q] : c_s;
+        p_s = pick ? x16[q] : p_s;
+        h_s = pick ? s01[q] : h_s;
 #pragma unroll
-    for (int q = 1; q < NR; ++q)
-        if (rs == q) { base = rowcdf[q - 1]; c_s = cs[q]; p_s = x16[q]; h_s = s01[q]; e_s = e[q]; }
+        for (int r = 0; r < 4; ++r) e_s[r] = pick ? e[q][r] : e_s[r];
+    }
     // 4. chunk inside the row: B0 = base, B1 = base+cs0, B2 = base+s01, B3 = (base+s01)+cs2
-    float B = base;
-    if (g == 1) B = base + p_s;
-    if (g == 2) B = base + h_s;
-    if (g == 3) B = (base + h_s) + p_s;
+    const float bh = base + h_s;
+    const float B = g == 0 ? base : (g == 1 ? base + p_s : (g == 2 ? bh : bh + p_s));
     const int cabs = 4 * (R0 + rs) + g;
     const bool member = cabs >= C0 && cabs < C0 + NC;
-    const bool hit = member && (B + c_s > t);
+    const bool hit = member & (B + c_s > t);
     const unsigned long long hm = (__ballot(hit) >> (lane & 15)) & 0x0001000100010001ull;
-    int gsel = -1;
-    if (hm) gsel = (__ffsll((long long)hm) - 1) >> 4;
+    const int gsel = hm ? ((__ffsll((long long)hm) - 1) >> 4) : -1;
     int glast = C0 + NC - 1 - 4 * (R0 + rs);  // last chunk of the head inside this row
     glast = glast > 3 ? 3 : glast;
-    const bool owner = gsel >= 0 ? (g == gsel) : (g == glast);
-    // 5. entry inside the chunk
-    int r = 3;
-    if (gsel >= 0) {
-        float b = B + e_s[0];
-        if (b > t) r = 0;
-        else {
-            b = b + e_s[1];
-            if (b > t) r = 1;
-            else {
-                b = b + e_s[2];
-                if (b > t) r = 2;
+    bool owner = gsel >= 0 ? (g == gsel) : (g == glast);
+    // 5. entry inside the chunk (r = 3 when nothing in the row was hit)
+    const float b0 = B + e_s[0], b1 = b0 + e_s[1], b2 = b1 + e_s[2];
+    int r = b2 > t ? 2 : 3;
+    r = b1 > t ? 1 : r;
+    r = b0 > t ? 0 : r;
+    r = gsel >= 0 ? r : 3;
+    bin = 4 * (cabs - C0) + r;
+    if (u < 0.f) {  // arg-max mode (rare): the lane holding the lowest bin among the maxima owns it
+        int am = 0x7fffffff;
+#pragma unroll
+        for (int R = R1; R >= R0; --R) {
+            const int c = 4 * R + g;
+            if (c >= C0 && c < C0 + NC) {
+#pragma unroll
+                for (int q = 3; q >= 0; --q)
+                    if (L[R][q] == mall) am = (c - C0) * 4 + q;
             }
         }
+        int best = min(am, (int)xor16u((unsigned)am, lane));
+        best = min(best, (int)xor32u((unsigned)best, lane));
+        bin = best;
+        owner = am == best;
     }
-    bin = 4 * (cabs - C0) + r;
     return owner;
 }
 
@@ -368,6 +371,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, g = lane >> 4;
+    __builtin_assume(g >= 0 && g < 4);
     const int64_t n_tiles = (A.P + 16 * PB - 1) / (16 * PB);
     const int64_t wave_gid = (int64_t)blockIdx.x * (MLP_THREADS / 64) + wave;
     const int64_t wave_cnt = (int64_t)gridDim.x * (MLP_THREADS / 64);
