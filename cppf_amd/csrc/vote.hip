@@ -361,10 +361,15 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
         const float ez = fmaf((fabsf(F.cc.z) + fabsf(cr.z) + fabsf(F.x.z) + fabsf(F.y.z)) * rinv, 1e-6f, 1e-3f);
         const float lox = blx - ex, hix = bhx + ex, loy = bly - ey, hiy = bhy + ey, loz = blz - ez, hiz = bhz + ez;
         int qhead = 0, qtail = 0;  // wave-uniform ring cursors, the ring is drained at the end of every batch
+        // the (cos,sin) of rotation i+1 is fetched while rotation i is screened (hides the LDS latency
+        // that would otherwise sit at the head of every iteration; the table has one spare entry)
+        float2 cs_next = (TAB_LDS && n > 0) ? ltab[tbase] : make_float2(0.f, 0.f);
         for (int i = 0; __any(i < n); ++i) {
             bool acc = false;
+            float2 cs = cs_next;
+            if (TAB_LDS && i + 1 < n) cs_next = ltab[tbase + i + 1];
             if (i < n) {
-                const float2 cs = TAB_LDS ? ltab[tbase + i] : rot_cs(i, n);
+                if (!TAB_LDS) cs = rot_cs(i, n);
                 const float qx = fmaf(cs.y, yq.x, fmaf(cs.x, xq.x, cq.x));
                 const float qy = fmaf(cs.y, yq.y, fmaf(cs.x, xq.y, cq.y));
                 const float qz = fmaf(cs.y, yq.z, fmaf(cs.x, xq.z, cq.z));
