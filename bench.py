@@ -26,11 +26,11 @@ sys.path.insert(0, ROOT)
 
 import cppf_amd.synthetic as syn                      # noqa: E402
 from cppf_amd import sharding                         # noqa: E402
-from cppf_amd.inference import PoseWorkspace, estimate_center, grid_shape   # noqa: E402
+from cppf_amd.inference import CenterPipeline, PoseWorkspace, grid_shape   # noqa: E402
 from cppf_amd.models import voting                    # noqa: E402
 from cppf_amd.models.model import PPFEncoder         # noqa: E402
 
-N_POINTS, PAIRS_PER_POINT, NUM_ROTS = 4096, 128, 72
+NUM_ROTS = 72
 FLOP_PER_PAIR = 23968            # 2 x 11 984 MAC of the pair MLP
 PEAK_F32_MFMA = 157.3            # TFLOP/s, MI355X_MICROARCH.md
 PEAK_HBM = 8000.0                # GB/s
@@ -45,7 +45,7 @@ def pmc_traffic(kernel):
         return None
 
 
-def cpu_baseline(ob, idx, u_tr, u_rot, sd, cfg, corner, dims, budget_s=12.0):
+def cpu_baseline(ob, idx, u_tr, u_rot, sd, cfg, corner, dims, N_POINTS, PAIRS_PER_POINT, budget_s=12.0):
     """The oracle (CPU restatement, all host cores via OpenMP) timed on the same workload."""
     from oracle import oracle as O
     threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -74,8 +74,12 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch the chain eagerly instead of replaying a hipGraph")
+    ap.add_argument("--n-points", type=int, default=4096, help="exploration only; the headline is 4096")
+    ap.add_argument("--pairs-per-point", type=int, default=128, help="exploration only; the headline is 128")
     args = ap.parse_args()
 
+    N_POINTS, PAIRS_PER_POINT = args.n_points, args.pairs_per_point
     rank, world, local = sharding.init_distributed()
     assert world == args.gpus, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
     dev = torch.device("cuda", local)
@@ -93,46 +97,39 @@ def main():
     enc = enc.to(dev)
     corners, dims = grid_shape(ob["pc"], cfg.res)
     d = lambda a: torch.from_numpy(a).to(dev)
-    pc, nrm, feat, idx_d, utr_d, urot_d, corner_d = d(ob["pc"]), d(ob["normals"]), d(ob["feat"]), d(idx), d(u_tr), d(u_rot), d(corners[0].copy())
-    idx32 = idx_d.to(torch.int32)
-    ws = PoseWorkspace(dev, P, dims, 1)
-    idx_all = torch.zeros(args.steps, dtype=torch.int64, device=dev)      # arg-max per step, written in place
+    # static device buffers + the three launches of the chain captured once in a hipGraph
+    pipe = CenterPipeline(enc, cfg, N_POINTS, P, dims, dev, NUM_ROTS, adaptive=True, with_heads=True,
+                          use_graph=not args.no_graph)
+    pipe.load(ob["pc"], ob["normals"], ob["feat"], idx, u_tr, u_rot, corners[0].copy())
+    idx_all = torch.zeros(args.steps, dtype=torch.int64, device=dev)      # arg-max of every step
     val_all = torch.zeros(args.steps, dtype=torch.float32, device=dev)
 
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    def close_batch():
+        """Pack the K per-step results into records and run the single end-of-batch collective."""
+        records = torch.zeros((args.steps, sharding.RECORD), dtype=torch.float64, device=dev)
+        records[:, 12] = idx_all.double()
+        records[:, 13] = val_all.double()
+        records[:, 15] = torch.arange(rank * args.steps, (rank + 1) * args.steps, device=dev).double()
+        if world > 1:
+            return sharding.gather_records(records, world * args.steps, rank, world, dev)   # the one collective
+        return records
 
-    def step(k=None):
-        with torch.no_grad():
-            if k is not None:
-                ev[k][0].record()
-            outputs, heads = enc.forward_decode(pc, nrm, feat, idx_d, utr_d, cfg.vote_range, urot_d,
-                                                cfg.tr_num_bins, cfg.rot_num_bins)
-            if k is not None:
-                ev[k][1].record()
-            kk = 0 if k is None else k
-            voting.vote_argmax(pc, outputs, ws.probs, idx32, ws.grid, corner_d, cfg.res, NUM_ROTS, True,
-                               idx_all[kk:kk + 1], val_all[kk:kk + 1], accumulate=False)
-            if k is not None:
-                ev[k][2].record()
-
-    ws.probs = torch.ones(N_POINTS, dtype=torch.float32, device=dev)
-    for _ in range(args.warmup):
-        step()
+    for _ in range(max(args.warmup, 1)):
+        oi, ov = pipe.run()
+        idx_all[0:1].copy_(oi, non_blocking=True)
+        val_all[0:1].copy_(ov, non_blocking=True)
+    close_batch()            # warm-up of the gather too (RCCL communicators are created on first use)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(k)
-    records = torch.zeros((args.steps, sharding.RECORD), dtype=torch.float64, device=dev)
-    records[:, 12] = idx_all.double()
-    records[:, 13] = val_all.double()
-    records[:, 15] = torch.arange(rank * args.steps, (rank + 1) * args.steps, device=dev).double()
+        oi, ov = pipe.run()
+        idx_all[k:k + 1].copy_(oi, non_blocking=True)
+        val_all[k:k + 1].copy_(ov, non_blocking=True)
+    allrec = close_batch()
     if world > 1:
-        allrec = sharding.gather_records(records, world * args.steps, rank, world, dev)   # the one collective
         torch.distributed.barrier()
-    else:
-        allrec = records
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -140,8 +137,27 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    t_mlp = float(np.mean([ev[k][0].elapsed_time(ev[k][1]) for k in range(args.steps)]))     # ms
-    t_vote = float(np.mean([ev[k][1].elapsed_time(ev[k][2]) for k in range(args.steps)]))
+    # per-kernel durations (HIP events on the stream the C ABI launches on), measured eagerly right after
+    # the timed region with the same buffers: the dominant kernel alone between two events
+    pc, nrm, feat, idx_d, utr_d, urot_d, corner_d, idx32 = (pipe.pc, pipe.nrm, pipe.feat, pipe.idx, pipe.u_tr,
+                                                              pipe.u_rot, pipe.corner, pipe.idx32)
+    ws = PoseWorkspace(dev, P, dims, 1)
+    ws.probs = pipe.probs
+    n_ev = max(args.steps, 5)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n_ev)]
+    with torch.no_grad():
+        for k in range(n_ev):
+            ev[k][0].record()
+            outputs, heads = enc.forward_decode(pc, nrm, feat, idx_d, utr_d, cfg.vote_range, urot_d,
+                                                cfg.tr_num_bins, cfg.rot_num_bins)
+            ev[k][1].record()
+            voting.vote_argmax(pc, outputs, ws.probs, idx32, ws.grid, corner_d, cfg.res, NUM_ROTS, True,
+                               ws.out_idx, ws.out_val, accumulate=False)
+            ev[k][2].record()
+    torch.cuda.synchronize()
+    args_steps_ev = n_ev
+    t_mlp = float(np.mean([ev[k][0].elapsed_time(ev[k][1]) for k in range(args_steps_ev)]))     # ms
+    t_vote = float(np.mean([ev[k][1].elapsed_time(ev[k][2]) for k in range(args_steps_ev)]))
 
     # secondary (untimed for `value`): the vote stage alone on known-answer inputs -- every vote circle
     # passes through the object centre, so most samples land in the grid (the atomic-heavy regime a
@@ -154,7 +170,7 @@ def main():
             if it == 1:
                 e0.record()
             voting.vote_argmax(pc, out_ka, ws.probs, idx32, ws.grid, corner_d, cfg.res, NUM_ROTS, True,
-                               idx_all[0:1], val_all[0:1], accumulate=False)
+                               ws.out_idx, ws.out_val, accumulate=False)
         e1.record()
         torch.cuda.synchronize()
         t_vote_ka = e0.elapsed_time(e1) / 5
@@ -174,9 +190,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "single object N=4096 K=128 (P=524288 pairs), bottle config, res 4e-3, "
+            "config": {"workload": f"single object N={N_POINTS} K={PAIRS_PER_POINT} (P={P} pairs), bottle config, res 4e-3, "
                                    f"grid {dims[0]}x{dims[1]}x{dims[2]}, num_rots 72 adaptive, fused PPF+MLP(MFMA f32)+decode -> "
-                                   "LDS-tiled vote -> argmax; one object per GPU per step",
+                                   "LDS-tiled vote -> argmax; one object per GPU per step; " +
+                                   ("three launches replayed from a hipGraph" if not args.no_graph else "eager launches"),
                        "pairs_per_step_per_gpu": P, "parallelism": f"objects x{world}"},
             "pairs_per_ms_per_gpu": args.steps * P / elapsed / 1e3,
             "stage_ms": {"ppf_mlp_decode": t_mlp, "vote_reduce_argmax": t_vote,
@@ -189,7 +206,7 @@ def main():
                          "traffic": pmc_traffic("pair_mlp_kernel<false, true, true>")},
         }
         if world == 1 and not args.no_cpu_baseline:
-            cb, flat_cpu = cpu_baseline(ob, idx, u_tr, u_rot, sd, cfg, corners[0], dims)
+            cb, flat_cpu = cpu_baseline(ob, idx, u_tr, u_rot, sd, cfg, corners[0], dims, N_POINTS, PAIRS_PER_POINT)
             out["cpu_baseline"] = cb
             out["argmax_matches_oracle"] = bool(flat_cpu == argmax_gpu)
         print(json.dumps(out))

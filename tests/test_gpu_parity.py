@@ -526,3 +526,30 @@ def test_full_size_properties_c2(dev):
     # non-adaptive deposits at least as much mass
     g4, _, _ = run_vote(dev, ob["pc"], outputs, idx32, corner, dims, cfg.res, 72, False)
     assert g4.sum(dtype=np.float64) >= mass * 0.999
+
+
+def test_large_config_c5_properties(oracle, dev):
+    """BASELINE.json config 5 sizes: N=8192, K=256 (P = 2 097 152 pairs), fine grid res 2e-3
+    (~400 k cells -> 13 LDS tiles, 110 k pairs per chunk, 20-bit fixed point)."""
+    ob = syn.make_object("bottle", 8192, 3)
+    cfg = ob["cfg"]
+    res = 2e-3
+    idx = syn.make_pairs(8192, 256, 3)
+    P = idx.shape[0]
+    outputs = syn.closed_form_outputs(ob["pc"], ob["center"], idx, cfg, quantise=True)
+    from cppf_amd.inference import grid_shape
+    corners, dims = grid_shape(ob["pc"], res)
+    assert int(np.prod(dims)) > 300000
+    bits = _lib.lib().cppf_vote_fixed_point_bits(P, 72, *dims)
+    assert 16 <= bits <= 24
+    idx32 = idx.astype(np.int32)
+    gg, flat, peak = run_vote(dev, ob["pc"], outputs, idx32, corners[0], dims, res, 72, True)
+    cell = np.array(np.unravel_index(flat, dims))
+    assert np.all(np.abs(cell - (ob["center"] - corners[0]) / res) <= 1.5)
+    assert flat == int(np.argmax(gg)) and peak == gg.max()
+    # exact-sum check on a 131 072-pair prefix (keeps the CPU side to a couple of seconds)
+    n = 131072
+    g2, f2, _ = run_vote(dev, ob["pc"], outputs[:n], idx32[:n], corners[0], dims, res, 72, True)
+    check_grid(oracle, g2, ob["pc"], outputs[:n], idx32[:n], corners[0], dims, res, 72, True)
+    mass = gg.sum(dtype=np.float64)
+    assert abs(mass - round(mass)) < 1.0 and mass <= 72.0 * P
