@@ -175,6 +175,22 @@ def main():
         torch.cuda.synchronize()
         t_vote_ka = e0.elapsed_time(e1) / 5
 
+    # secondary metric: the same object through the FULL pose (centre chain + back-vote +
+    # orientation vote + axis sign + scale + one read-back), one hipGraph replay per object
+    t_pose = None
+    if rank == 0:
+        from cppf_amd.inference import PosePipeline
+        from cppf_amd.utils.util import fibonacci_sphere
+        pp = PosePipeline(enc, cfg, N_POINTS, P, dims, dev, np.array(fibonacci_sphere(480)), NUM_ROTS)
+        pp.load(ob["pc"], ob["normals"], ob["feat"], idx, u_tr, u_rot, corners[0].copy())
+        for _ in range(3):
+            pose = pp.run()
+        torch.cuda.synchronize()
+        tp0 = time.perf_counter()
+        for _ in range(10):
+            pose = pp.run()
+        t_pose = (time.perf_counter() - tp0) / 10 * 1e3
+
     if rank == 0:
         argmax_gpu = int(allrec[0, 12].item())
         out = {
@@ -197,7 +213,8 @@ def main():
                        "pairs_per_step_per_gpu": P, "parallelism": f"objects x{world}"},
             "pairs_per_ms_per_gpu": args.steps * P / elapsed / 1e3,
             "stage_ms": {"ppf_mlp_decode": t_mlp, "vote_reduce_argmax": t_vote,
-                         "vote_reduce_argmax_known_answer_inputs": t_vote_ka},
+                         "vote_reduce_argmax_known_answer_inputs": t_vote_ka,
+                         "full_pose_incl_readback": t_pose, "full_pose_n_surv": pose["n_surv"]},
             # dominant kernel = the fused pair encoder (one launch between the two events): exact-fp32
             # MFMA, 23 968 algorithmic FLOP per pair
             "roofline": {"bound": "mfma", "kernel": "pair_mlp_kernel<false,true,true>",

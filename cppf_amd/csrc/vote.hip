@@ -673,7 +673,12 @@ __global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__
             const f3 x = scl3(xd, odist);
             const f3 y = cross3(x, ab);
             found = {0.f, 0.f, 0.f};                                                   // :96
-            const int n = min((int)((double)(odist / res) * (2 * CPPF_PI)), n_rots);  // :97
+            int n = min((int)((double)(odist / res) * (2 * CPPF_PI)), n_rots);        // :97
+            // every sample lies at distance |offset| = rho (1 +- 1e-6) from cc, so it is at least
+            // | |cc - gt| - rho | away from gt: when that exceeds tol (with a margin far above the rounding)
+            // no rotation can pass the test of :101 and the loop is skipped -- same result, no work.
+            const float dc = len3(sub3(cc, gt)), rho = len3(x);
+            if (fabsf(dc - rho) > tol + 1e-5f * (dc + rho + tol) + 1e-7f) n = 0;
             const int tbase = n * (n - 1) / 2;
             for (int i = 0; i < n; ++i) {
                 const float2 cs = in_lds ? ltab[tbase + i] : rot_cs(i, n);
@@ -921,16 +926,86 @@ __global__ __launch_bounds__(SPH_THREADS) void rot_sphere_kernel(const float* __
     }
 }
 
+// Same count when the sphere bins are unit vectors sorted by y (the Fibonacci sphere of
+// utils/util.py:102-118 is): a candidate c can only match bins with |s.y - c.y| < sqrt(2 - 2 thr), so
+// each lane takes candidates and tests only that band of bins (~14 of 480 at 1.5 deg) instead of every
+// lane sweeping every candidate.  Same dot product, same threshold test -> identical counts.
+#define SPHB_PPB 32
+__global__ __launch_bounds__(256) void rot_sphere_band_kernel(const float* __restrict__ points,
+                                                              const float* __restrict__ preds_rot, int rot_stride,
+                                                              const int32_t* __restrict__ point_idxs,
+                                                              const int32_t* __restrict__ sel,
+                                                              const int32_t* __restrict__ n_sel_dev, int64_t n_sel_host,
+                                                              int64_t max_pairs, int n_rots,
+                                                              const float* __restrict__ sphere, int n_sphere, float thr,
+                                                              int32_t* __restrict__ counts, int descending)
+{
+    __shared__ RotFrame frames[SPHB_PPB];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* sph = lds;                                             // [n_sphere][3]
+    int* cnt = reinterpret_cast<int*>(lds + 3 * n_sphere);        // [n_sphere]
+    float2* row = reinterpret_cast<float2*>(cnt + n_sphere);      // [n_rots]
+    int64_t n_sel = n_sel_dev ? (int64_t)*n_sel_dev : n_sel_host;
+    if (n_sel > max_pairs) n_sel = max_pairs;
+    const int64_t k0 = (int64_t)blockIdx.x * SPHB_PPB;
+    if (k0 >= n_sel) return;
+    const int np = (int)min((int64_t)SPHB_PPB, n_sel - k0);
+    for (int i = threadIdx.x; i < 3 * n_sphere; i += 256) sph[i] = sphere[i];
+    for (int i = threadIdx.x; i < n_sphere; i += 256) cnt[i] = 0;
+    for (int i = threadIdx.x; i < n_rots; i += 256) row[i] = rot_cs(i, n_rots);
+    if ((int)threadIdx.x < np) {
+        const int p = sel ? sel[k0 + threadIdx.x] : (int)(k0 + threadIdx.x);
+        const int2 ij = reinterpret_cast<const int2*>(point_idxs)[p];
+        frames[threadIdx.x] = rot_frame(points, ij.x, ij.y, preds_rot[(int64_t)p * rot_stride]);
+    }
+    __syncthreads();
+    float band = 2.f - 2.f * thr;
+    band = sqrtf(fminf(fmaxf(band, 0.f), 4.f) + 1e-5f) + 1e-4f;
+    const int items = np * n_rots;
+    for (int k = threadIdx.x; k < items; k += 256) {
+        const int pl = k / n_rots, i = k - pl * n_rots;
+        f3 up = {0.f, 0.f, 0.f};
+        if (frames[pl].ok) up = rot_candidate(frames[pl], row[i]);
+        // bins with y in [up.y - band, up.y + band]: binary searches on the sorted y column
+        const float ylo = up.y - band, yhi = up.y + band;
+        int lo = 0, hi = n_sphere;  // first bin inside the band
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const float y = sph[3 * mid + 1];
+            const bool before = descending ? (y > yhi) : (y < ylo);
+            if (before) lo = mid + 1; else hi = mid;
+        }
+        for (int j = lo; j < n_sphere; ++j) {
+            const float sy = sph[3 * j + 1];
+            if (descending ? (sy < ylo) : (sy > yhi)) break;
+            const float d = fmaf(up.z, sph[3 * j + 2], fmaf(up.y, sy, up.x * sph[3 * j]));
+            if (d > thr) atomicAdd(&cnt[j], 1);
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < n_sphere; j += 256)
+        if (cnt[j]) atomicAdd(&counts[j], cnt[j]);
+}
+
 extern "C" int cppf_rot_sphere_count(const float* points, const float* preds_rot, int rot_stride,
                                      const int32_t* point_idxs, const int32_t* sel, const int32_t* n_sel_dev,
                                      int64_t n_sel_host, int64_t max_pairs, int n_rots, const float* sphere,
-                                     int n_sphere, float thr, int32_t* counts, void* stream)
+                                     int n_sphere, float thr, int sphere_sorted_by_y, int32_t* counts, void* stream)
 {
     if (!points || !preds_rot || !point_idxs || !sphere || !counts) return CPPF_EINVAL;
     if (n_rots < 1 || n_rots > 512 || n_sphere < 1 || max_pairs < 0 || n_sel_host < 0 || rot_stride < 1)
         return CPPF_EINVAL;
     int64_t bound = n_sel_host < max_pairs ? n_sel_host : max_pairs;
     if (bound == 0) return 0;
+    if (sphere_sorted_by_y != 0 && n_sphere <= 4096) {
+        const int64_t nb = (bound + SPHB_PPB - 1) / SPHB_PPB;
+        const size_t lds = (size_t)(4 * n_sphere + 2 * n_rots) * sizeof(float);
+        hipLaunchKernelGGL(rot_sphere_band_kernel, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, points,
+                           preds_rot, rot_stride, point_idxs, sel, n_sel_dev, n_sel_host, max_pairs, n_rots, sphere,
+                           n_sphere, thr, counts, sphere_sorted_by_y > 0 ? 1 : 0);
+        CPPF_CHECK_LAUNCH();
+        return 0;
+    }
     const int64_t nb = (bound + SPH_PPB - 1) / SPH_PPB;
     const size_t lds = (size_t)(4 * SPH_PPB * n_rots + 2 * n_rots) * sizeof(float);
     hipLaunchKernelGGL(rot_sphere_kernel, dim3((unsigned)nb), dim3(SPH_THREADS), lds, (hipStream_t)stream, points,

@@ -57,7 +57,24 @@ class PoseWorkspace:
         self.best_dir = torch.empty((2, 3), dtype=torch.float64, device=device)
         self.sign = torch.empty((2, 3), dtype=torch.float64, device=device)
         self.scale = torch.empty(4, dtype=torch.float64, device=device)
+        self.rec = torch.zeros(21, dtype=torch.float64, device=device)
         self.probs = None
+        self._sph_key = None
+
+    def sphere(self, sph64):
+        """Device copies of the sphere bins (fp32 for the count, fp64 for best_dir) and whether the bins
+        are unit vectors with a monotone y column (true for fibonacci_sphere), which lets
+        cppf_rot_sphere_count search a band of bins instead of all of them."""
+        key = (sph64.shape, sph64.tobytes())
+        if self._sph_key != key:
+            s32 = sph64.astype(np.float32)
+            unit = bool(np.all(np.abs(np.linalg.norm(s32.astype(np.float64), axis=-1) - 1.0) < 1e-4))
+            dy = np.diff(s32[:, 1])
+            self._sorted_y = (1 if np.all(dy <= 0) else (-1 if np.all(dy >= 0) else 0)) if unit else 0
+            self._sph32 = torch.from_numpy(s32).to(self.device)
+            self._sph64 = torch.from_numpy(sph64).to(self.device)
+            self._sph_key = key
+        return self._sph32, self._sph64, self._sorted_y
 
 
 def estimate_center(encoder, pc, pc_normal, feat, point_idxs, u_tr, cfg, corner, dims, num_rots=72, adaptive=True,
@@ -173,13 +190,27 @@ def estimate_pose(encoder, pc, pc_normal, feat, point_idxs, u_tr, u_rot, cfg, sp
     S = sph64.shape[0]
     if ws is None or ws.n_pairs != P or ws.dims != dims or ws.n_sphere != S or ws.device != dev:
         ws = PoseWorkspace(dev, P, dims, S)
-    sph32_d = torch.from_numpy(sph64.astype(np.float32)).to(dev)              # :276
-    sph64_d = torch.from_numpy(sph64).to(dev)
+    sph32_d, sph64_d, sorted_y = ws.sphere(sph64)                             # :276 (uploaded once per workspace)
     idx32 = point_idxs.to(I32)
 
     # centre ------------------------------------------------------------------------------------------
     _, _, outputs, heads, _ = estimate_center(encoder, pc, pc_normal, feat, point_idxs, u_tr, cfg, corner, dims,
                                               num_rots, adaptive, u_rot, ws, idx32)
+    _enqueue_tail(ws, pc, pc_normal, idx32, outputs, heads, corner, cfg, dims, num_rots, angle_tol, max_rot_pairs,
+                  sph32_d, sph64_d, sorted_y)
+    out = _assemble(ws.rec.cpu().numpy(), cfg, rng)                           # the one read-back
+    out.update(dims=dims, corner=corners[0], ws=ws, outputs=outputs, heads=heads)
+    return out
+
+
+def _enqueue_tail(ws, pc, pc_normal, idx32, outputs, heads, corner, cfg, dims, num_rots, angle_tol, max_rot_pairs,
+                  sph32_d, sph64_d, sorted_y):
+    """nocs/inference.py:209-303,335 after the centre vote, all on the current stream; leaves the 21-double
+    result record in ws.rec (T[3], best_dir[2,3], sign sums[2,3], scale sums[4], argmax, peak)."""
+    dev = pc.device
+    L = _lib.lib()
+    st = stream_ptr(dev)
+    P, S = idx32.shape[0], sph32_d.shape[0]
     with torch.cuda.device(dev):
         _lib.check(L.cppf_center_from_argmax(ws.out_idx.data_ptr(), corner.data_ptr(), float(cfg.res), dims[1],
                                              dims[2], ws.T64.data_ptr(), ws.T32.data_ptr(), st),
@@ -197,11 +228,13 @@ def estimate_pose(encoder, pc, pc_normal, feat, point_idxs, u_tr, u_rot, cfg, sp
         thr = float(np.float32(np.cos(angle_tol / 180 * np.pi)))
         n_dirs = 2 if cfg.regress_right else 1
         ws.counts.zero_()
+        ws.best_dir.zero_()
+        ws.sign.zero_()
         rws = workspace(L.cppf_reduce_workspace_bytes(), dev, "reduce")
         for j in range(n_dirs):
             _lib.check(L.cppf_rot_sphere_count(pc.data_ptr(), heads.data_ptr() + 4 * j, 8, idx32.data_ptr(),
                                                ws.surv.data_ptr(), ws.count.data_ptr(), P, max_rot_pairs, num_rots,
-                                               sph32_d.data_ptr(), S, thr, ws.counts[j].data_ptr(), st),
+                                               sph32_d.data_ptr(), S, thr, sorted_y, ws.counts[j].data_ptr(), st),
                        "cppf_rot_sphere_count")
             ws.countsf[j].copy_(ws.counts[j])                                 # exact: counts < 2**24
             _lib.check(L.cppf_grid_argmax(ws.countsf[j].data_ptr(), S, ws.best_idx[j:].data_ptr(), None,
@@ -215,16 +248,23 @@ def estimate_pose(encoder, pc, pc_normal, feat, point_idxs, u_tr, u_rot, cfg, sp
         # scale (:335) -----------------------------------------------------------------------------
         _lib.check(L.cppf_scale_sum(heads.data_ptr() + 4 * 4, 8, ws.surv.data_ptr(), ws.count.data_ptr(), P,
                                     ws.scale.data_ptr(), rws.data_ptr(), rws.numel(), st), "cppf_scale_sum")
+    ws.rec[0:3].copy_(ws.T64)
+    ws.rec[3:9].copy_(ws.best_dir.reshape(-1))
+    ws.rec[9:15].copy_(ws.sign.reshape(-1))
+    ws.rec[15:19].copy_(ws.scale)
+    ws.rec[19:20].copy_(ws.out_idx)
+    ws.rec[20:21].copy_(ws.out_val)
 
-    # one read-back ---------------------------------------------------------------------------------
-    rec = torch.cat([ws.T64, ws.best_dir.reshape(-1), ws.sign.reshape(-1), ws.scale, ws.out_idx.double(),
-                     ws.out_val.double()]).cpu().numpy()
-    T = rec[0:3]
+
+def _assemble(rec, cfg, rng=None):
+    """Host end of nocs/inference.py:299-339 from the 21-double record."""
+    T = rec[0:3].copy()
     best = rec[3:9].reshape(2, 3)
     sign = rec[9:15].reshape(2, 3)
     ssum = rec[15:19]
     flat, peak = int(rec[19]), float(rec[20])
     n_surv = int(ssum[3])
+    n_dirs = 2 if cfg.regress_right else 1
 
     dirs = []
     for j in range(n_dirs):
@@ -252,5 +292,30 @@ def estimate_pose(encoder, pc, pc_normal, feat, point_idxs, u_tr, u_rot, cfg, sp
     pred_scale = np.exp(mean).astype(np.float64) * np.asarray(cfg.scale_mean, np.float64) * 2   # :335
     scale_norm = float(np.linalg.norm(pred_scale))
     return dict(T=T, up=up, right=right, R=R, scale=pred_scale, scale_norm=scale_norm, argmax=flat, peak=peak,
-                n_surv=n_surv, dims=dims, corner=corners[0], best_up=best[0], best_right=best[1] if n_dirs > 1 else None,
-                losses=sign, ws=ws, outputs=outputs, heads=heads)
+                n_surv=n_surv, best_up=best[0].copy(), best_right=best[1].copy() if n_dirs > 1 else None,
+                losses=sign.copy())
+
+
+class PosePipeline(CenterPipeline):
+    """Full per-instance pose for a fixed problem shape: CenterPipeline's chain plus the pose tail, captured
+    together in one hipGraph; `run()` replays it and reads back the 21-double record (one sync)."""
+
+    def __init__(self, encoder, cfg, n_points, n_pairs, dims, device, sphere_pts, num_rots=72, adaptive=True,
+                 angle_tol=1.5, max_rot_pairs=10000, use_graph=True):
+        super().__init__(encoder, cfg, n_points, n_pairs, dims, device, num_rots, adaptive, True, use_graph)
+        sph64 = np.asarray(sphere_pts, dtype=np.float64)
+        self.ws = PoseWorkspace(device, n_pairs, dims, sph64.shape[0])
+        self.ws.out_idx, self.ws.out_val, self.ws.grid = self.out_idx, self.out_val, self.grid
+        self._sph = self.ws.sphere(sph64)
+        self.dims, self.angle_tol, self.max_rot_pairs = tuple(dims), angle_tol, max_rot_pairs
+
+    def _chain(self):
+        super()._chain()
+        _enqueue_tail(self.ws, self.pc, self.nrm, self.idx32, self.outputs, self.heads, self.corner, self.cfg,
+                      self.dims, self.num_rots, self.angle_tol, self.max_rot_pairs, *self._sph)
+
+    def run(self, rng=None):
+        super().run()
+        out = _assemble(self.ws.rec.cpu().numpy(), self.cfg, rng)
+        out.update(dims=self.dims, ws=self.ws, outputs=self.outputs, heads=self.heads)
+        return out

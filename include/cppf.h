@@ -114,11 +114,14 @@ int cppf_rot_voting(const float* points, const float* preds_rot, float* outputs_
  * pair arrays; sel == NULL -> pairs 0..), counts[j] += #(cand . sphere[j] > thr).
  *   preds_rot device f32, element i at preds_rot[i*rot_stride]
  *   sphere device f32[S,3]; counts device i32[S] zero-initialised by the caller
- *   n_sel_dev device i32[1] (number of valid entries of sel) or NULL -> n_sel_host */
+ *   n_sel_dev device i32[1] (number of valid entries of sel) or NULL -> n_sel_host
+ *   sphere_sorted_by_y: +1 / -1 when the bins are unit vectors whose y column is sorted descending /
+ *     ascending (the Fibonacci sphere of utils/util.py:102-118 is descending): enables the banded
+ *     search (identical counts, ~30x less work); 0 = no assumption. */
 int cppf_rot_sphere_count(const float* points, const float* preds_rot, int rot_stride, const int32_t* point_idxs,
                           const int32_t* sel, const int32_t* n_sel_dev, int64_t n_sel_host, int64_t max_pairs,
-                          int n_rots, const float* sphere, int n_sphere, float thr, int32_t* counts,
-                          void* stream);
+                          int n_rots, const float* sphere, int n_sphere, float thr, int sphere_sorted_by_y,
+                          int32_t* counts, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Pair encoder.  Replaces PPFEncoder.forward_with_idx (models/model.py:117-137) incl. the PPF

@@ -417,12 +417,25 @@ def test_rot_voting_and_sphere_count_bit_exact(oracle, golden, dev):
     nsel = torch.tensor([700], dtype=torch.int32, device=dev)
     thr = float(np.float32(np.cos(1.5 / 180 * np.pi)))
     pc_d, th_d, idx_d, sel_d, sph_d = t(ob["pc"], dev), t(theta, dev), t(idx32, dev), t(sel, dev), t(sph.astype(np.float32), dev)
-    _lib.check(L.cppf_rot_sphere_count(pc_d.data_ptr(), th_d.data_ptr(), 1,
-                                       idx_d.data_ptr(), sel_d.data_ptr(), nsel.data_ptr(), P, 500, 72,
-                                       sph_d.data_ptr(), 480, thr, counts.data_ptr(),
+    for sorted_y in (0, 1):          # full sweep and the banded search (Fibonacci bins: y descending)
+        counts.zero_()
+        _lib.check(L.cppf_rot_sphere_count(pc_d.data_ptr(), th_d.data_ptr(), 1,
+                                           idx_d.data_ptr(), sel_d.data_ptr(), nsel.data_ptr(), P, 500, 72,
+                                           sph_d.data_ptr(), 480, thr, sorted_y, counts.data_ptr(),
+                                           stream_ptr(dev)), "rot_sphere_count")
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(counts.cpu().numpy().astype(np.int64), counts_o)
+    # ascending order and a loose threshold (wide band) give the same counts as the oracle as well
+    rev = sph[::-1].copy()
+    counts_r = oracle.sphere_count(co[sel[:500]], rev, 25.0)
+    rev_d = t(rev.astype(np.float32), dev)
+    thr2 = float(np.float32(np.cos(25.0 / 180 * np.pi)))
+    counts.zero_()
+    _lib.check(L.cppf_rot_sphere_count(pc_d.data_ptr(), th_d.data_ptr(), 1, idx_d.data_ptr(), sel_d.data_ptr(),
+                                       nsel.data_ptr(), P, 500, 72, rev_d.data_ptr(), 480, thr2, -1, counts.data_ptr(),
                                        stream_ptr(dev)), "rot_sphere_count")
     torch.cuda.synchronize()
-    np.testing.assert_array_equal(counts.cpu().numpy().astype(np.int64), counts_o)
+    np.testing.assert_array_equal(counts.cpu().numpy().astype(np.int64), counts_r)
     assert counts_o.sum() > 0
 
 
@@ -553,3 +566,39 @@ def test_large_config_c5_properties(oracle, dev):
     check_grid(oracle, g2, ob["pc"], outputs[:n], idx32[:n], corners[0], dims, res, 72, True)
     mass = gg.sum(dtype=np.float64)
     assert abs(mass - round(mass)) < 1.0 and mass <= 72.0 * P
+
+
+def test_pipelines_graph_replay_equals_eager(golden, dev):
+    """CenterPipeline / PosePipeline (static buffers + hipGraph replay) give the eager results, also after
+    new data is loaded into the same graph."""
+    from cppf_amd.inference import CenterPipeline, PosePipeline, estimate_pose, grid_shape
+    sph = golden("sphere.npz")["pts"]
+    sd = seeded_sd(0)
+    for k in ("final.weight", "final.bias"):
+        sd[k] = sd[k] * 4
+    enc = make_encoder(sd, [84, 32, 32, 16], 141, dev)
+    cfg = CATEGORIES["camera"]
+    pipe = None
+    for seed in (41, 42):
+        ob = syn.make_object("camera", 1024, seed)
+        idx = syn.make_pairs(1024, 32, seed)
+        P = idx.shape[0]
+        u_tr, u_rot = syn.make_uniforms(P, seed)
+        corners, dims = grid_shape(ob["pc"], cfg.res)
+        with torch.no_grad():
+            ref = estimate_pose(enc, t(ob["pc"], dev), t(ob["normals"], dev), t(ob["feat"], dev), t(idx, dev),
+                                t(u_tr, dev), t(u_rot, dev), cfg, sph, pc_host=ob["pc"])
+        if pipe is None or pipe.dims != tuple(dims):
+            pipe = PosePipeline(enc, cfg, 1024, P, dims, dev, sph)
+        pipe.load(ob["pc"], ob["normals"], ob["feat"], idx, u_tr, u_rot, corners[0].copy())
+        for rep in range(2):                      # first call captures, second replays
+            r = pipe.run()
+            assert r["argmax"] == ref["argmax"] and r["n_surv"] == ref["n_surv"]
+            np.testing.assert_array_equal(r["T"], ref["T"])
+            np.testing.assert_array_equal(r["up"], ref["up"])
+            np.testing.assert_allclose(r["scale"], ref["scale"], rtol=1e-12)
+            assert torch.equal(r["outputs"], ref["outputs"]) and torch.equal(r["heads"], ref["heads"])
+        cp = CenterPipeline(enc, cfg, 1024, P, dims, dev, use_graph=False)
+        cp.load(ob["pc"], ob["normals"], ob["feat"], idx, u_tr, u_rot, corners[0].copy())
+        oi, ov = cp.run()
+        assert int(oi.item()) == ref["argmax"]
