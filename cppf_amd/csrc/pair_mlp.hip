@@ -27,6 +27,7 @@ using namespace cppf;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte access at 4-byte alignment
 
 #define CPPF_CHECK_LAUNCH()                         \
     do {                                            \
@@ -574,12 +575,20 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
             }
             if (LOGITS) {
                 if (live) {
+                    // the lane holds 4 consecutive logits per output block: one 16-byte store each (rows are
+                    // only 4-byte aligned when out_dim % 4 != 0; global dwordx4 stores allow that)
                     float* o = A.out + pair[pb] * A.out_dim + 4 * g;
 #pragma unroll
-                    for (int ob = 0; ob < STD_NOB; ++ob)
+                    for (int ob = 0; ob < STD_NOB; ++ob) {
+                        const int c0 = 16 * ob + 4 * g;
+                        if (c0 + 3 < A.out_dim) {
+                            *reinterpret_cast<f32x4u*>(o + 16 * ob) = L[ob];
+                        } else {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (16 * ob + 4 * g + r < A.out_dim) o[16 * ob + r] = L[ob][r];
+                            for (int r = 0; r < 3; ++r)
+                                if (c0 + r < A.out_dim) o[16 * ob + r] = L[ob][r];
+                        }
+                    }
                 }
             }
             if (DECODE) {
