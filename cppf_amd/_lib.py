@@ -27,10 +27,12 @@ _SIGS = {
     "cppf_rot_sphere_count": (C.c_int, [vp, vp, i32, vp, vp, vp, i64, i64, i32, vp, i32, f32, i32, vp, vp]),
     "cppf_pair_mlp_packed_floats": (sz, [i32, C.POINTER(C.c_int), i32, i32]),
     "cppf_pair_mlp_pack": (C.c_int, [vp, vp, i32, C.POINTER(C.c_int), i32, i32, vp]),
-    "cppf_pair_mlp_forward": (C.c_int, [vp, vp, vp, vp, i32, vp, i64, i32, C.POINTER(C.c_int), i32, i64, i32, vp, vp]),
+    "cppf_pair_mlp_workspace_bytes": (sz, [i64, i32, C.POINTER(C.c_int), i32, i32]),
+    "cppf_pair_mlp_forward": (C.c_int, [vp, vp, vp, vp, i32, vp, i64, i32, C.POINTER(C.c_int), i32, i64, i32, vp, vp,
+                                        sz, vp]),
     "cppf_pair_mlp_decode": (C.c_int, [vp, vp, vp, vp, i32, vp, i64, i32, C.POINTER(C.c_int), i32, i64, i32, i32, i32,
-                                       f32, f32, vp, vp, vp, vp, vp]),
-    "cppf_debug_mlp_chain_only": (C.c_int, [vp, vp, vp, vp, i32, vp, i64, vp, vp]),
+                                       f32, f32, vp, vp, vp, vp, vp, sz, vp]),
+    "cppf_debug_mlp_chain_only": (C.c_int, [vp, vp, vp, vp, i32, vp, i64, i64, vp, vp, sz, vp]),
     "cppf_decode_center": (C.c_int, [vp, i64, i32, i32, f32, f32, vp, vp, vp]),
     "cppf_decode_rot": (C.c_int, [vp, i64, i32, i32, i32, i32, vp, vp, vp]),
     "cppf_reduce_workspace_bytes": (sz, []),

@@ -13,9 +13,15 @@
 //   D         = f32x4: outputs 16*ob + 4*g + r, r = 0..3, of pair j.
 // Because D of one layer leaves output (16*ob + 4*g + r) in the lane that will need it as the
 // B operand of k-step s = 4*ob + r of the next layer, layers chain with no data movement at all:
-// the k order of a hidden layer is k(s,g) = 16*(s/4) + 4*g + s%4, and of the first layer
-// k(s,g) = {feat_a[10g+s] | feat_b[10g+s-10] | ppf[g]} so that each lane gathers two contiguous
-// 40-byte runs.  The oracle accumulates in exactly this order (oracle/cppf_oracle.c:orc_k_order).
+// the k order of a hidden layer is k(s,g) = 16*(s/4) + 4*g + s%4.
+//
+// The first layer (84 -> 32|32) is linear in cat(feat[a], feat[b], ppf), so its two 40-wide blocks are
+// hoisted out of the pair loop: a small kernel projects every POINT once,
+//     TA[n][o] = b[o] + sum_k W[o][k]    feat[n][k]        TB[n][o] = sum_k W[o][40+k] feat[n][k]
+// (fmaf chains, k = 0..39), and a pair's pre-activation is (TA[a][o] + TB[b][o]) plus one MFMA k-step for
+// the 4 PPF inputs.  That removes 80 of the 188 MFMAs per 16 pairs (the per-point work is N*128*40 MAC,
+// 0.2 % of the pair work at K = 128) and turns the 2x160-byte feature gather into 2x256 bytes of an
+// L2-resident 2 MB table.  The oracle follows the same association (oracle/cppf_oracle.c, order 1).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -39,21 +45,24 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byt
 #define STD_F 40
 #define STD_NOB 9                      // final layer padded to 9 x 16 = 144 outputs
 #define STD_NOBP 12                    // floats per lane per k-step of the final layer (3 x b128)
-#define OFF_W0 0                       // [21][64][4]  ob0,1 = fc1 (32), ob2,3 = fc0 (32) of layer 0
-#define OFF_W0B (OFF_W0 + 21 * 64 * 4) // [8][64][2]   layer 0 fc2
-#define OFF_W1A (OFF_W0B + 8 * 64 * 2) // [8][64][2]   layer 1 fc1
-#define OFF_W1B (OFF_W1A + 8 * 64 * 2) // [8][64][2]   layer 1 fc2
-#define OFF_W2 (OFF_W1B + 8 * 64 * 2)  // [8][64][2]   ob0 = layer 2 fc1 (16), ob1 = layer 2 fc0 (16)
-#define OFF_W2B (OFF_W2 + 8 * 64 * 2)  // [4][64][1]   layer 2 fc2
-#define OFF_WF (OFF_W2B + 4 * 64)      // [4][64][12]  final, 9 used
-#define OFF_B0 (OFF_WF + 4 * 64 * STD_NOBP)  // biases in natural output order
-#define OFF_B0B (OFF_B0 + 64)
+#define OFF_W0P 0                       // [64][4]     PPF k-step of layer 0 (k = 80 + g): ob0,1 = fc1, ob2,3 = fc0
+#define OFF_W0B (OFF_W0P + 64 * 4)      // [8][64][2]  layer 0 fc2
+#define OFF_W1A (OFF_W0B + 8 * 64 * 2)  // [8][64][2]  layer 1 fc1
+#define OFF_W1B (OFF_W1A + 8 * 64 * 2)  // [8][64][2]  layer 1 fc2
+#define OFF_W2 (OFF_W1B + 8 * 64 * 2)   // [8][64][2]  ob0 = layer 2 fc1 (16), ob1 = layer 2 fc0 (16)
+#define OFF_W2B (OFF_W2 + 8 * 64 * 2)   // [4][64][1]  layer 2 fc2
+#define OFF_WF (OFF_W2B + 4 * 64)       // [4][64][12] final, 9 used
+#define OFF_B0B (OFF_WF + 4 * 64 * STD_NOBP)  // biases in natural output order
 #define OFF_B1A (OFF_B0B + 32)
 #define OFF_B1B (OFF_B1A + 32)
 #define OFF_B2 (OFF_B1B + 32)
 #define OFF_B2B (OFF_B2 + 32)
 #define OFF_BF (OFF_B2B + 16)
-#define STD_PACKED (OFF_BF + 144)      // 13152 floats = 52 608 B
+#define STD_LDS (OFF_BF + 144)          // 7 968 floats = 31 872 B live in LDS
+#define OFF_WPT STD_LDS                 // [40][128]   per-point projection: column r < 64: W[r][k], r >= 64: W[r-64][40+k]
+#define OFF_BPT (OFF_WPT + 40 * 128)    // [64]        fc1 | fc0 bias of layer 0 (folded into the feat_a table)
+#define STD_PACKED (OFF_BPT + 64)       // 13 152 floats
+#define PROJ_COLS 128
 
 static bool is_std(int F, const int* dims, int n_res, int out_dim)
 {
@@ -91,7 +100,6 @@ extern "C" size_t cppf_pair_mlp_packed_floats(int F, const int* dims, int n_res,
     return 0;
 }
 
-static inline int kfirst(int s, int g) { return s < 10 ? 10 * g + s : (s < 20 ? 40 + 10 * g + (s - 10) : 80 + g); }
 static inline int khid(int s, int g) { return 16 * (s / 4) + 4 * g + (s % 4); }
 
 extern "C" int cppf_pair_mlp_pack(const float* params, const int64_t* offs, int F, const int* dims, int n_res,
@@ -103,13 +111,18 @@ extern "C" int cppf_pair_mlp_pack(const float* params, const int64_t* offs, int 
         const float *w1 = params + offs[0], *b1 = params + offs[1], *w2 = params + offs[2], *b2 = params + offs[3];
         if (offs[4] < 0 || offs[10] >= 0 || offs[16] < 0) return CPPF_EINVAL;  // fc0 on layers 0 and 2 only
         const float *w0 = params + offs[4], *b0 = params + offs[5];
-        for (int s = 0; s < 21; ++s)
-            for (int l = 0; l < 64; ++l)
-                for (int ob = 0; ob < 4; ++ob) {
-                    int o = 16 * (ob & 1) + (l & 15), k = kfirst(s, l >> 4);
-                    out[OFF_W0 + (s * 64 + l) * 4 + ob] = (ob < 2 ? w1 : w0)[o * 84 + k];
-                }
-        for (int o = 0; o < 32; ++o) { out[OFF_B0 + o] = b1[o]; out[OFF_B0 + 32 + o] = b0[o]; out[OFF_B0B + o] = b2[o]; }
+        for (int l = 0; l < 64; ++l)
+            for (int ob = 0; ob < 4; ++ob) {
+                int o = 16 * (ob & 1) + (l & 15), k = 80 + (l >> 4);
+                out[OFF_W0P + l * 4 + ob] = (ob < 2 ? w1 : w0)[o * 84 + k];
+            }
+        for (int k = 0; k < 40; ++k)
+            for (int r = 0; r < 128; ++r) {
+                int oc = r & 63;  // 0..31 fc1, 32..63 fc0
+                const float* w = oc < 32 ? w1 + oc * 84 : w0 + (oc - 32) * 84;
+                out[OFF_WPT + k * 128 + r] = w[(r < 64 ? 0 : 40) + k];
+            }
+        for (int o = 0; o < 32; ++o) { out[OFF_BPT + o] = b1[o]; out[OFF_BPT + 32 + o] = b0[o]; out[OFF_B0B + o] = b2[o]; }
         for (int s = 0; s < 8; ++s)
             for (int l = 0; l < 64; ++l)
                 for (int ob = 0; ob < 2; ++ob)
@@ -322,6 +335,7 @@ struct MlpArgs {
     const float* packed;
     const float* u_tr;
     const float* u_rot;
+    const float* table;  // [N][128] per-point layer-0 projections (point_proj_kernel)
     float* out;      // logits [P,out_dim]   (LOGITS)
     float* outputs;  // [P,2]                (DECODE)
     float* heads;    // [P,8] or null        (DECODE)
@@ -359,6 +373,24 @@ __device__ __forceinline__ float ppf_from(f3 pa, f3 pb, f3 na, f3 nb, int g)
                            (__float_as_uint(d) & m3));
 }
 
+// Layer-0 projections of every point: T[n][r] = (r < 64 ? bias[r] : 0) + sum_{k<40} WPT[k][r] * feat[n][k],
+// one fmaf chain per output in k order.  One block per 2 points, a thread per column.
+__global__ __launch_bounds__(256) void point_proj_kernel(const float* __restrict__ feat,
+                                                         const float* __restrict__ packed, float* __restrict__ T,
+                                                         int64_t N)
+{
+    __shared__ float f[2][STD_F];
+    const int half = threadIdx.x >> 7, r = threadIdx.x & 127;
+    const int64_t n = (int64_t)blockIdx.x * 2 + half;
+    if (r < STD_F && n < N) f[half][r] = feat[n * STD_F + r];
+    __syncthreads();
+    if (n >= N) return;
+    float acc = r < 64 ? packed[OFF_BPT + r] : 0.f;
+#pragma unroll 8
+    for (int k = 0; k < STD_F; ++k) acc = fmaf(packed[OFF_WPT + k * PROJ_COLS + r], f[half][k], acc);
+    T[n * PROJ_COLS + r] = acc;
+}
+
 template <bool LOGITS, bool DECODE, bool HEADS>
 __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kernel(MlpArgs A)
 {
@@ -366,7 +398,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(A.packed);
         f32x4* dst = reinterpret_cast<f32x4*>(W);
-        for (int k = threadIdx.x; k < STD_PACKED / 4; k += MLP_THREADS) dst[k] = src[k];
+        for (int k = threadIdx.x; k < STD_LDS / 4; k += MLP_THREADS) dst[k] = src[k];
     }
     __syncthreads();
 
@@ -381,7 +413,9 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
     // Software pipeline over this wave's tiles (t, t + wave_cnt, ...): while tile t runs through the
     // MFMA chain, the gathers of tile t+1 are in flight (indices were fetched one tile earlier still),
     // so a tile never starts with a dependent idx -> feature round trip to L2/HBM.
-    float x0[PB][21];
+    // ta/tb[pb][ob] = the lane's 4 outputs (16*ob + 4*g ..) of TA[a] and TB[b]; xp = its PPF input (ppf[g])
+    f32x4 ta[PB][4], tb[PB][4];
+    float xp[PB];
     int ia1[PB], ib1[PB];
     {
         int ia[PB], ib[PB];
@@ -389,15 +423,11 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
         for (int pb = 0; pb < PB; ++pb) load_pair_idx(A, wave_gid * (16 * PB) + pb * 16 + j, ia[pb], ib[pb]);
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
-            const f32x2* fa = reinterpret_cast<const f32x2*>(A.feat + (int64_t)ia[pb] * STD_F + 10 * g);
-            const f32x2* fb = reinterpret_cast<const f32x2*>(A.feat + (int64_t)ib[pb] * STD_F + 10 * g);
+            const f32x4* pa = reinterpret_cast<const f32x4*>(A.table + (int64_t)ia[pb] * PROJ_COLS + 4 * g);
+            const f32x4* pbp = reinterpret_cast<const f32x4*>(A.table + (int64_t)ib[pb] * PROJ_COLS + 64 + 4 * g);
 #pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                const f32x2 va = fa[q], vb = fb[q];
-                x0[pb][2 * q] = va[0]; x0[pb][2 * q + 1] = va[1];
-                x0[pb][10 + 2 * q] = vb[0]; x0[pb][11 + 2 * q] = vb[1];
-            }
-            x0[pb][20] = ppf_from(ld3(A.pc, ia[pb]), ld3(A.pc, ib[pb]), ld3(A.nrm, ia[pb]), ld3(A.nrm, ib[pb]), g);
+            for (int ob = 0; ob < 4; ++ob) { ta[pb][ob] = pa[4 * ob]; tb[pb][ob] = pbp[4 * ob]; }
+            xp[pb] = ppf_from(ld3(A.pc, ia[pb]), ld3(A.pc, ib[pb]), ld3(A.nrm, ia[pb]), ld3(A.nrm, ib[pb]), g);
         }
         const int64_t nt = wave_gid + wave_cnt < n_tiles ? wave_gid + wave_cnt : wave_gid;
 #pragma unroll
@@ -429,42 +459,14 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
             }
         }
 
-        // ---- layer 0: fc1 | fc0 (84 -> 32 | 32) -------------------------------------------------
+        // ---- layer 0: fc1 | fc0 (84 -> 32 | 32) = (TA[a] + TB[b]) + one MFMA step over the 4 PPF inputs ----
         f32x4 acc[PB][4];
-#pragma unroll
-        for (int ob = 0; ob < 4; ++ob) {
-            const f32x4 b = ldb4(W + OFF_B0 + 16 * ob + 4 * g);
-#pragma unroll
-            for (int pb = 0; pb < PB; ++pb) acc[pb][ob] = b;
-        }
-#pragma unroll
-        for (int s = 0; s < 21; ++s) {
-            const f32x4 w = ldb4(W + OFF_W0 + (s * 64 + lane) * 4);
+        {
+            const f32x4 w = ldb4(W + OFF_W0P + lane * 4);
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
-                for (int pb = 0; pb < PB; ++pb) acc[pb][ob] = mfma4(w[ob], x0[pb][s], acc[pb][ob]);
-        }
-
-        // ---- next tile: PPF from the landed points, feature gathers into the (dead) x0 registers,
-        //      and the indices of the tile after it ---------------------------------------------------
-#pragma unroll
-        for (int pb = 0; pb < PB; ++pb) {
-            x0[pb][20] = ppf_from(npa[pb], npb[pb], nna[pb], nnb[pb], g);
-            const f32x2* fa = reinterpret_cast<const f32x2*>(A.feat + (int64_t)ia1[pb] * STD_F + 10 * g);
-            const f32x2* fb = reinterpret_cast<const f32x2*>(A.feat + (int64_t)ib1[pb] * STD_F + 10 * g);
-#pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                const f32x2 va = fa[q], vb = fb[q];
-                x0[pb][2 * q] = va[0]; x0[pb][2 * q + 1] = va[1];
-                x0[pb][10 + 2 * q] = vb[0]; x0[pb][11 + 2 * q] = vb[1];
-            }
-        }
-        {
-            int64_t nt = tile + 2 * wave_cnt;
-            nt = nt < n_tiles ? nt : tile;
-#pragma unroll
-            for (int pb = 0; pb < PB; ++pb) load_pair_idx(A, nt * (16 * PB) + pb * 16 + j, ia1[pb], ib1[pb]);
+                for (int pb = 0; pb < PB; ++pb) acc[pb][ob] = mfma4(w[ob], xp[pb], ta[pb][ob] + tb[pb][ob]);
         }
 
         // ---- layer 0: fc2 (32 -> 32) on relu(fc1), + fc0 ---------------------------------------
@@ -520,6 +522,23 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
 #pragma unroll
             for (int pb = 0; pb < PB; ++pb) { y[pb][0] = a2[pb][0] + y[pb][0]; y[pb][1] = a2[pb][1] + y[pb][1]; }
         }
+        // ---- next tile: PPF from the landed points, table gathers into the (now dead) ta/tb registers,
+        //      and the indices of the tile after it ---------------------------------------------------
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            xp[pb] = ppf_from(npa[pb], npb[pb], nna[pb], nnb[pb], g);
+            const f32x4* pa = reinterpret_cast<const f32x4*>(A.table + (int64_t)ia1[pb] * PROJ_COLS + 4 * g);
+            const f32x4* pbp = reinterpret_cast<const f32x4*>(A.table + (int64_t)ib1[pb] * PROJ_COLS + 64 + 4 * g);
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) { ta[pb][ob] = pa[4 * ob]; tb[pb][ob] = pbp[4 * ob]; }
+        }
+        {
+            int64_t nt = tile + 2 * wave_cnt;
+            nt = nt < n_tiles ? nt : tile;
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) load_pair_idx(A, nt * (16 * PB) + pb * 16 + j, ia1[pb], ib1[pb]);
+        }
+
         // ---- layer 2: fc1 | fc0 (32 -> 16 | 16), fc2 (16 -> 16) ---------------------------------
         f32x4 z[PB];
         {
@@ -793,27 +812,39 @@ static int mlp_grid(int64_t P)
     return (int)nb;
 }
 
-template <bool LOGITS, bool DECODE, bool HEADS>
-static int launch_std(const MlpArgs& A, hipStream_t st)
+extern "C" size_t cppf_pair_mlp_workspace_bytes(int64_t N, int F, const int* dims, int n_res, int out_dim)
 {
+    if (!dims || N < 0) return 0;
+    return is_std(F, dims, n_res, out_dim) ? (size_t)N * PROJ_COLS * sizeof(float) : 0;
+}
+
+template <bool LOGITS, bool DECODE, bool HEADS>
+static int launch_std(MlpArgs& A, int64_t N, void* workspace, size_t workspace_bytes, hipStream_t st)
+{
+    if (N < 1) return CPPF_EINVAL;
+    if (!workspace || workspace_bytes < (size_t)N * PROJ_COLS * sizeof(float)) return CPPF_EWORKSPACE;
+    float* table = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(point_proj_kernel, dim3((unsigned)((N + 1) / 2)), dim3(256), 0, st, A.feat, A.packed, table, N);
+    CPPF_CHECK_LAUNCH();
+    A.table = table;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mlp_kernel<LOGITS, DECODE, HEADS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, STD_PACKED * sizeof(float));
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, STD_LDS * sizeof(float));
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
     hipLaunchKernelGGL((pair_mlp_kernel<LOGITS, DECODE, HEADS>), dim3(mlp_grid(A.P)), dim3(MLP_THREADS),
-                       STD_PACKED * sizeof(float), st, A);
+                       STD_LDS * sizeof(float), st, A);
     CPPF_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int cppf_pair_mlp_forward(const float* pc, const float* nrm, const float* feat, const void* idxs,
                                      int idx_is_i64, const float* packed, int64_t N, int F, const int* dims, int n_res,
-                                     int64_t P, int out_dim, float* out, void* stream)
+                                     int64_t P, int out_dim, float* out, void* workspace, size_t workspace_bytes,
+                                     void* stream)
 {
-    (void)N;
     if (P < 0 || !dims) return CPPF_EINVAL;
     if (P == 0) return 0;  // empty pair list: nothing to do, pointers may be null
     if (!pc || !nrm || !feat || !idxs || !packed || !out) return CPPF_EINVAL;
@@ -822,7 +853,7 @@ extern "C" int cppf_pair_mlp_forward(const float* pc, const float* nrm, const fl
         MlpArgs A = {};
         A.pc = pc; A.nrm = nrm; A.feat = feat; A.idxs = idxs; A.packed = packed; A.out = out; A.P = P;
         A.out_dim = out_dim; A.idx64 = idx_is_i64;
-        return launch_std<true, false, false>(A, st);
+        return launch_std<true, false, false>(A, N, workspace, workspace_bytes, st);
     }
     if (!gen_ok(F, dims, n_res, out_dim)) return CPPF_EUNSUPPORTED;
     GenArgs G = {};
@@ -847,9 +878,9 @@ extern "C" int cppf_pair_mlp_forward(const float* pc, const float* nrm, const fl
 extern "C" int cppf_pair_mlp_decode(const float* pc, const float* nrm, const float* feat, const void* idxs,
                                     int idx_is_i64, const float* packed, int64_t N, int F, const int* dims, int n_res,
                                     int64_t P, int out_dim, int tr_bins, int rot_bins, float vr0, float vr1,
-                                    const float* u_tr, const float* u_rot, float* outputs, float* heads, void* stream)
+                                    const float* u_tr, const float* u_rot, float* outputs, float* heads,
+                                    void* workspace, size_t workspace_bytes, void* stream)
 {
-    (void)N;
     if (P < 0 || !dims) return CPPF_EINVAL;
     if (!is_std(F, dims, n_res, out_dim) || tr_bins != 32 || rot_bins != 36 || out_dim != 141) return CPPF_EUNSUPPORTED;
     if (P == 0) return 0;
@@ -858,19 +889,20 @@ extern "C" int cppf_pair_mlp_decode(const float* pc, const float* nrm, const flo
     MlpArgs A = {};
     A.pc = pc; A.nrm = nrm; A.feat = feat; A.idxs = idxs; A.packed = packed; A.P = P; A.out_dim = out_dim;
     A.idx64 = idx_is_i64; A.u_tr = u_tr; A.u_rot = u_rot; A.outputs = outputs; A.heads = heads; A.vr0 = vr0; A.vr1 = vr1;
-    return heads ? launch_std<false, true, true>(A, (hipStream_t)stream)
-                 : launch_std<false, true, false>(A, (hipStream_t)stream);
+    return heads ? launch_std<false, true, true>(A, N, workspace, workspace_bytes, (hipStream_t)stream)
+                 : launch_std<false, true, false>(A, N, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 // Profiling aid (not part of the drop-in surface): the PPF + gather + MFMA chain with no epilogue.
 extern "C" int cppf_debug_mlp_chain_only(const float* pc, const float* nrm, const float* feat, const void* idxs,
-                                         int idx_is_i64, const float* packed, int64_t P, float* scratch, void* stream)
+                                         int idx_is_i64, const float* packed, int64_t N, int64_t P, float* scratch,
+                                         void* workspace, size_t workspace_bytes, void* stream)
 {
     if (!pc || !nrm || !feat || !idxs || !packed || !scratch || P < 1) return CPPF_EINVAL;
     MlpArgs A = {};
     A.pc = pc; A.nrm = nrm; A.feat = feat; A.idxs = idxs; A.packed = packed; A.P = P; A.out_dim = 141;
     A.idx64 = idx_is_i64; A.outputs = scratch;
-    return launch_std<false, false, false>(A, (hipStream_t)stream);
+    return launch_std<false, false, false>(A, N, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int cppf_decode_center(const float* logits, int64_t P, int ld, int tr_bins, float vr0, float vr1,

@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib
-from .._torch_util import require_cuda, stream_ptr
+from .._torch_util import require_cuda, stream_ptr, workspace
 
 __all__ = ["ResLayer", "PPFEncoder"]
 
@@ -75,11 +75,13 @@ class PPFEncoder(nn.Module):
         P = idxs.shape[0]
         out = torch.empty((P, self.out_dim), dtype=torch.float32, device=pc.device)
         dims = (C.c_int * len(self.ppffcs))(*self.ppffcs)
+        ws = self._scratch(pc, feat, dims)
         with torch.cuda.device(pc.device):
             rc = _lib.lib().cppf_pair_mlp_forward(
                 pc.data_ptr(), pc_normal.data_ptr(), feat.data_ptr(), idxs.data_ptr(),
                 1 if idxs.dtype == torch.int64 else 0, self._packed_weights(pc.device).data_ptr(), pc.shape[0],
-                feat.shape[1], dims, len(self.ppffcs) - 1, P, self.out_dim, out.data_ptr(), stream_ptr(pc.device))
+                feat.shape[1], dims, len(self.ppffcs) - 1, P, self.out_dim, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                stream_ptr(pc.device))
         _lib.check(rc, "cppf_pair_mlp_forward")
         return out
 
@@ -101,6 +103,7 @@ class PPFEncoder(nn.Module):
         heads = torch.empty((P, 8), dtype=torch.float32, device=pc.device) if u_rot is not None else None
         dims = (C.c_int * len(self.ppffcs))(*self.ppffcs)
         L = _lib.lib()
+        ws = self._scratch(pc, feat, dims)
         with torch.cuda.device(pc.device):
             rc = L.cppf_pair_mlp_decode(
                 pc.data_ptr(), pc_normal.data_ptr(), feat.data_ptr(), idxs.data_ptr(),
@@ -108,7 +111,7 @@ class PPFEncoder(nn.Module):
                 feat.shape[1], dims, len(self.ppffcs) - 1, P, self.out_dim, tr_num_bins, rot_num_bins,
                 float(vote_range[0]), float(vote_range[1]), u_tr.data_ptr(),
                 u_rot.data_ptr() if u_rot is not None else None, outputs.data_ptr(),
-                heads.data_ptr() if heads is not None else None, stream_ptr(pc.device))
+                heads.data_ptr() if heads is not None else None, ws.data_ptr(), ws.numel(), stream_ptr(pc.device))
             if rc == -3:  # architecture / bin counts outside the fused kernel: logits + decode kernels
                 logits = self.forward_with_idx(pc, pc_normal, feat, idxs)
                 rc = L.cppf_decode_center(logits.data_ptr(), P, self.out_dim, tr_num_bins, float(vote_range[0]),
@@ -122,6 +125,11 @@ class PPFEncoder(nn.Module):
         return outputs, heads
 
     # ------------------------------------------------------------------ internals
+    def _scratch(self, pc, feat, dims):
+        need = _lib.lib().cppf_pair_mlp_workspace_bytes(pc.shape[0], feat.shape[1], dims, len(self.ppffcs) - 1,
+                                                        self.out_dim)
+        return workspace(max(int(need), 256), pc.device, "pair_mlp")
+
     def _needs_graph(self, feat):
         if not torch.is_grad_enabled():
             return False

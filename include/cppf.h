@@ -132,9 +132,13 @@ int cppf_rot_sphere_count(const float* points, const float* preds_rot, int rot_s
  *   out        device f32[P,out_dim] logits
  * Supported on the MFMA path: dims = {2F+4, 32, 32, 16} with F = 40 and out_dim <= 144 (the only
  * architecture the reference trains, train.py:35); any other ResLayer stack runs on the generic
- * kernel (one pair per lane, weights in LDS, at most 128 units per layer).
+ * kernel (one pair per lane, at most 128 units per layer).  The MFMA path first projects every point
+ * through the feat columns of layer 0 (N*128 floats in `workspace`), see csrc/pair_mlp.hip.
  * ------------------------------------------------------------------------------------------- */
 size_t cppf_pair_mlp_packed_floats(int F, const int* dims, int n_res, int out_dim);
+/* device scratch for one call: the per-point layer-0 projection table of the MFMA path (N*128 floats),
+ * 0 for the generic kernel */
+size_t cppf_pair_mlp_workspace_bytes(int64_t N, int F, const int* dims, int n_res, int out_dim);
 /* host-side packing: params/offs use the layout documented in oracle/cppf_oracle.c:orc_pair_mlp
  * (flat torch tensors + offset table: 6 per res layer {fc1.w, fc1.b, fc2.w, fc2.b, fc0.w|-1,
  * fc0.b|-1} then {final.w, final.b}); packed_host receives cppf_pair_mlp_packed_floats() floats. */
@@ -142,7 +146,7 @@ int cppf_pair_mlp_pack(const float* params, const int64_t* offs, int F, const in
                        float* packed_host);
 int cppf_pair_mlp_forward(const float* pc, const float* nrm, const float* feat, const void* idxs, int idx_is_i64,
                           const float* packed, int64_t N, int F, const int* dims, int n_res, int64_t P,
-                          int out_dim, float* out, void* stream);
+                          int out_dim, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Pair encoder fused with the decode of nocs/inference.py:185-188 (+ :245-256 when heads != NULL):
  * softmax over the bins + inverse-CDF draw with caller-supplied uniforms (stand-in for
@@ -154,13 +158,15 @@ int cppf_pair_mlp_forward(const float* pc, const float* nrm, const float* feat, 
 int cppf_pair_mlp_decode(const float* pc, const float* nrm, const float* feat, const void* idxs, int idx_is_i64,
                          const float* packed, int64_t N, int F, const int* dims, int n_res, int64_t P,
                          int out_dim, int tr_bins, int rot_bins, float vr0, float vr1, const float* u_tr,
-                         const float* u_rot, float* outputs, float* heads, void* stream);
+                         const float* u_rot, float* outputs, float* heads, void* workspace, size_t workspace_bytes,
+                         void* stream);
 
 /* Profiling aid, not part of the drop-in surface: the PPF + gather + MFMA chain of the standard
  * architecture with no epilogue (isolates the matrix pipeline when reading rocprof counters).
  * scratch: >= 4 bytes of device memory (never written in practice). */
 int cppf_debug_mlp_chain_only(const float* pc, const float* nrm, const float* feat, const void* idxs, int idx_is_i64,
-                              const float* packed, int64_t P, float* scratch, void* stream);
+                              const float* packed, int64_t N, int64_t P, float* scratch, void* workspace,
+                              size_t workspace_bytes, void* stream);
 
 /* Decode from logits already in memory (generic architectures / bin counts). */
 int cppf_decode_center(const float* logits, int64_t P, int ld, int tr_bins, float vr0, float vr1,

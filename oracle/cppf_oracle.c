@@ -39,7 +39,8 @@
  *     discrete outcomes (trip counts, in/out-of-grid tests, sampled bins).
  *   - the MLP accumulates each output with an fmaf chain seeded by the bias.  order=0 walks
  *     k = 0..K-1; order=1 walks k in the order the fp32 MFMA tiles of the HIP kernel consume
- *     it (documented at orc_k_order).  Both are within ~1e-6 of torch's GEMM.
+ *     it, incl. the per-point hoisting of the first layer (documented at orc_k_order).  Both are
+ *     within ~1e-6 of torch's GEMM.
  */
 #include <math.h>
 #include <stdint.h>
@@ -179,25 +180,22 @@ void orc_ppf_features(const float* pc, const float* nrm, const int64_t* idxs, in
  *  order 0: k = 0..K-1.
  *  order 1 ("mfma"): the HIP kernel feeds v_mfma_f32_16x16x4_f32, which consumes 4 k-values
  *    per instruction (one per 16-lane group g = 0..3, accumulated g = 0,1,2,3) in steps s:
- *      first layer (K = 2F+4, F % 4 == 0, q = F/4): step s, group g reads
- *         s <  q      feat_a[q*g + s]
- *         s < 2q      feat_b[q*g + (s-q)]        (input index F + ...)
- *         s == 2q     ppf[g]                     (input index 2F + g)
+ *      first layer (K = 2F+4): it is linear in cat(feat[a], feat[b], ppf), and the HIP path hoists the
+ *        two F-wide blocks out of the pair loop (csrc/pair_mlp.hip): per POINT n and output o
+ *           TA[n][o] = fmaf chain over k = 0..F-1 of W[o][k]   * feat[n][k], seeded with the bias
+ *           TB[n][o] = fmaf chain over k = 0..F-1 of W[o][F+k] * feat[n][k], seeded with 0
+ *        and per pair  y[o] = fmaf chain over k = 0..3 of W[o][2F+k] * ppf[k], seeded with TA[a][o] + TB[b][o]
+ *        (handled in orc_pair_mlp, not through a permutation)
  *      hidden layers (K % 16 == 0): step s, group g reads input 16*(s/4) + 4*g + (s%4)
  *        (= the register the previous layer's MFMA left in that lane: no data movement).
  *    Falls back to order 0 when the shape does not fit.
  */
 static void orc_k_order(int K, int F, int first, int order, int* perm)
 {
+    (void)F;
     int ok = 0;
     if (order == 1) {
-        if (first && F > 0 && F % 4 == 0 && K == 2 * F + 4) {
-            int q = F / 4, n = 0;
-            for (int s = 0; s <= 2 * q; ++s)
-                for (int g = 0; g < 4; ++g)
-                    perm[n++] = s < q ? q * g + s : (s < 2 * q ? F + q * g + (s - q) : 2 * F + g);
-            ok = 1;
-        } else if (!first && K % 16 == 0) {
+        if (!first && K % 16 == 0) {
             int n = 0;
             for (int s = 0; s < K / 4; ++s)
                 for (int g = 0; g < 4; ++g) perm[n++] = 16 * (s / 4) + 4 * g + (s % 4);
@@ -272,7 +270,6 @@ int orc_pair_mlp(const float* pc, const float* nrm, const float* feat, const int
                  int F, int64_t P, const float* params, const int64_t* offs, const int* dims, int n_res,
                  int out_dim, int order, float* out)
 {
-    (void)N;
     if (dims[0] != 2 * F + 4) return -1;
     for (int i = 0; i <= n_res; ++i)
         if (dims[i] > ORC_MAXD) return -2;
@@ -311,6 +308,29 @@ int orc_pair_mlp(const float* pc, const float* nrm, const float* feat, const int
         orc_k_order(K, F, n_res == 0, order, perm[3 * n_res]);
     }
 
+    /* order 1: per-point tables of the first layer (see orc_k_order): tab[w] = {TA | TB} for w = fc1, fc0 */
+    float* tab[2] = {NULL, NULL};
+    const int hoist = order == 1 && n_res > 0;
+    if (hoist) {
+        const int K = dims[0], Nn = dims[1];
+        int* nat = (int*)malloc(sizeof(int) * F);
+        for (int k = 0; k < F; ++k) nat[k] = k;
+        float* zero = (float*)calloc(Nn, sizeof(float));
+        for (int w = 0; w < 2; ++w) {
+            const int64_t ow = offs[w == 0 ? 0 : 4], ob = offs[w == 0 ? 1 : 5];
+            if (ow < 0) continue;
+            const float* Wk = Wt[w == 0 ? 0 : 2];           /* [K][Nn] k-major */
+            tab[w] = (float*)malloc(sizeof(float) * (size_t)N * 2 * Nn);
+#pragma omp parallel for schedule(static)
+            for (int64_t n = 0; n < N; ++n) {
+                linear_chain(Wk, params + ob, feat + n * F, nat, F, Nn, tab[w] + (size_t)n * 2 * Nn);
+                linear_chain(Wk + (size_t)F * Nn, zero, feat + n * F, nat, F, Nn, tab[w] + (size_t)n * 2 * Nn + Nn);
+            }
+        }
+        (void)K;
+        free(nat); free(zero);
+    }
+
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < P; ++i) {
         float x[ORC_MAXD], h[ORC_MAXD], y2[ORC_MAXD], y0[ORC_MAXD];
@@ -323,10 +343,28 @@ int orc_pair_mlp(const float* pc, const float* nrm, const float* feat, const int
             int K = dims[l], Nn = dims[l + 1];
             const int64_t* o = offs + 6 * l;
             /* models/model.py:27-31: x_res = fc0(x) or x; x = relu(fc1(x)); x = fc2(x); x + x_res */
-            linear_chain(Wt[3 * l], params + o[1], x, perm[3 * l], K, Nn, h);
+            const int hl = hoist && l == 0;
+            if (hl) {   /* TA[a] + TB[b], then the 4 PPF inputs */
+                const float *ta = tab[0] + (size_t)a * 2 * Nn, *tb = tab[0] + (size_t)b * 2 * Nn + Nn;
+                for (int j = 0; j < Nn; ++j) {
+                    float acc = ta[j] + tb[j];
+                    for (int k = 0; k < 4; ++k) acc = fmaf(Wt[0][(size_t)(2 * F + k) * Nn + j], x[2 * F + k], acc);
+                    h[j] = acc;
+                }
+            } else {
+                linear_chain(Wt[3 * l], params + o[1], x, perm[3 * l], K, Nn, h);
+            }
             for (int j = 0; j < Nn; ++j) h[j] = h[j] > 0.0f ? h[j] : 0.0f;
             linear_chain(Wt[3 * l + 1], params + o[3], h, perm[3 * l + 1], Nn, Nn, y2);
-            if (o[4] >= 0) {
+            if (o[4] >= 0 && hl) {
+                const float *ta = tab[1] + (size_t)a * 2 * Nn, *tb = tab[1] + (size_t)b * 2 * Nn + Nn;
+                for (int j = 0; j < Nn; ++j) {
+                    float acc = ta[j] + tb[j];
+                    for (int k = 0; k < 4; ++k) acc = fmaf(Wt[2][(size_t)(2 * F + k) * Nn + j], x[2 * F + k], acc);
+                    y0[j] = acc;
+                }
+                for (int j = 0; j < Nn; ++j) x[j] = y2[j] + y0[j];
+            } else if (o[4] >= 0) {
                 linear_chain(Wt[3 * l + 2], params + o[5], x, perm[3 * l], K, Nn, y0);
                 for (int j = 0; j < Nn; ++j) x[j] = y2[j] + y0[j];
             } else {
@@ -339,6 +377,7 @@ int orc_pair_mlp(const float* pc, const float* nrm, const float* feat, const int
     }
     for (int i = 0; i < nl; ++i) { free(Wt[i]); free(perm[i]); }
     free(Wt); free(perm);
+    free(tab[0]); free(tab[1]);
     return 0;
 }
 

@@ -59,22 +59,28 @@ def test_weight_packing_follows_the_documented_lane_order(golden):
     packed = np.zeros(n, np.float32)
     assert L.cppf_pair_mlp_pack(params.ctypes.data, offs.ctypes.data, 40, dims, 3, 141, packed.ctypes.data) == 0
     w1, w0 = sd["res_layers.0.fc1.weight"], sd["res_layers.0.fc0.weight"]
-
-    def kfirst(s, g_):
-        return 10 * g_ + s if s < 10 else (40 + 10 * g_ + (s - 10) if s < 20 else 80 + g_)
-
-    for s, lane, ob in ((0, 0, 0), (5, 17, 1), (12, 40, 2), (20, 63, 3), (19, 33, 0)):
-        o, k = 16 * (ob & 1) + (lane & 15), kfirst(s, lane >> 4)
-        assert packed[(s * 64 + lane) * 4 + ob] == (w1 if ob < 2 else w0)[o, k]
+    # layer 0: one PPF k-step [64 lanes][4 blocks] at the head, the per-point projection [40][128] + bias at the tail
+    for lane, ob in ((0, 0), (17, 1), (40, 2), (63, 3)):
+        o, k = 16 * (ob & 1) + (lane & 15), 80 + (lane >> 4)
+        assert packed[lane * 4 + ob] == (w1 if ob < 2 else w0)[o, k]
+    lds_floats = 64 * 4 + 4 * (8 * 64 * 2) + 4 * 64 + 4 * 64 * 12 + 32 * 4 + 16 + 144
+    wpt = packed[lds_floats:lds_floats + 40 * 128].reshape(40, 128)
+    np.testing.assert_array_equal(wpt[:, :32], w1[:, :40].T)
+    np.testing.assert_array_equal(wpt[:, 32:64], w0[:, :40].T)
+    np.testing.assert_array_equal(wpt[:, 64:96], w1[:, 40:80].T)
+    np.testing.assert_array_equal(wpt[:, 96:], w0[:, 40:80].T)
+    np.testing.assert_array_equal(packed[lds_floats + 5120:lds_floats + 5120 + 64],
+                                  np.concatenate([sd["res_layers.0.fc1.bias"], sd["res_layers.0.fc0.bias"]]))
+    assert L.cppf_pair_mlp_workspace_bytes(4096, 40, dims, 3, 141) == 4096 * 128 * 4
     # final layer: [4][64][12], zero padded past out_dim; biases in natural order at the tail
-    off_wf = 21 * 64 * 4 + 4 * (8 * 64 * 2) + 4 * 64
+    off_wf = 64 * 4 + 4 * (8 * 64 * 2) + 4 * 64
     wf = sd["final.weight"]
     for s, lane, ob in ((0, 0, 0), (3, 63, 8), (2, 20, 5)):
         o, k = 16 * ob + (lane & 15), 16 * (s // 4) + 4 * (lane >> 4) + s % 4
         exp = wf[o, k] if o < 141 else 0.0
         assert packed[off_wf + (s * 64 + lane) * 12 + ob] == exp
-    np.testing.assert_array_equal(packed[-144:-3], sd["final.bias"])
-    assert np.all(packed[-3:] == 0)
+    np.testing.assert_array_equal(packed[lds_floats - 144:lds_floats - 3], sd["final.bias"])
+    assert np.all(packed[lds_floats - 3:lds_floats] == 0)
     # unsupported: layer wider than 128
     dims_bad = (C.c_int * 3)(84, 256, 16)
     assert L.cppf_pair_mlp_packed_floats(40, dims_bad, 2, 10) == 0
