@@ -32,7 +32,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 static inline int tri(int n) { return n * (n + 1) / 2; }
 
 // ----------------------------------------------------------------------------- vote plan
-#define VOTE_TILE_FLOATS 32512  // 127 KiB of the CU's 160 KiB LDS for the grid tile (4 KiB rings, 8 KiB carry log, 21 KiB table)
+#define VOTE_TILE_FLOATS 31488  // 123 KiB of the CU's 160 KiB LDS for the grid tile (8 KiB rings, 8 KiB carry log, 21 KiB table)
 #define VOTE_TAB_LDS_MAX 2628   // (cos,sin) pairs kept in LDS (n_rots <= 72); else computed per sample
 #define VOTE_MAX_TILES 16       // beyond this, L2 atomics beat re-walking the pairs once per tile
 #define VOTE_THREADS 1024
@@ -126,7 +126,7 @@ extern "C" size_t cppf_vote_workspace_bytes(int64_t n_ppfs, int n_rots, int gx, 
 // exact to fp32 precision and the sum is order-independent, i.e. at least as accurate as any order
 // of the reference's fp32 atomicAdd.  Negative / non-finite probs fall back to ds_add_f32.
 //
-// Two stages per wave, decoupled by a 128-entry ring of 16-bit codes in LDS so that the expensive
+// Two stages per wave, decoupled by a 256-entry ring of 16-bit codes in LDS so that the expensive
 // stage always runs with full lanes (a plain one-pair-per-lane loop executes the union of all lanes'
 // branches):
 //   screen  one pair per lane, rotations in a loop, everything pre-scaled by ~1/res:
@@ -136,7 +136,7 @@ extern "C" size_t cppf_vote_workspace_bytes(int64_t n_ppfs, int n_rots, int gx, 
 //   deposit whenever the ring holds >= 64 codes every lane pops one, pulls the owning lane's pair
 //           frame with ds_bpermute, and does the exact work of the reference: offset, the three
 //           correctly rounded divisions, the bound tests, trilinear weights, 8 atomics.
-#define VOTE_RING 128
+#define VOTE_RING 256  // >= 63 queued + 128 pushed per trip
 #define VOTE_CARRY_CAP 2048
 struct VoteArgs {
     const float* points;
@@ -254,12 +254,12 @@ template <bool TILED, bool TAB_LDS>
 __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    // LDS: [rings: 16 waves x 128 x u16 = 4 KiB][carry log 8 KiB][ctrl 64 B][rotation table][tile]
+    // LDS: [rings: 16 waves x 256 x u16 = 8 KiB][carry log 8 KiB][ctrl 64 B][rotation table (+1 spare)][tile]
     uint16_t* ring = reinterpret_cast<uint16_t*>(lds) + (threadIdx.x >> 6) * VOTE_RING;
     uint32_t* carry_log = reinterpret_cast<uint32_t*>(lds) + (VOTE_THREADS / 64) * VOTE_RING / 2;
     int* ctrl = reinterpret_cast<int*>(carry_log + VOTE_CARRY_CAP);  // [0] carry count, [1] max(prob) bits, [2] bad probs
     float2* ltab = reinterpret_cast<float2*>(ctrl + 16);
-    float* tile = reinterpret_cast<float*>(ltab + (TAB_LDS ? A.tab_entries : 0));
+    float* tile = reinterpret_cast<float*>(ltab + (TAB_LDS ? A.tab_entries + 2 : 0));  // +2: spare entry, 16-B alignment
     const int tid = threadIdx.x, lane = tid & 63;
     const int gz = A.gz, gy = A.gy, gx = A.gx;
 
@@ -284,7 +284,10 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
         p_end = A.n_ppfs;
         p_step = (int64_t)gridDim.x * VOTE_THREADS;
     }
-    if (TAB_LDS) fill_rot_table(ltab, A.tab_entries, tid, VOTE_THREADS);
+    if (TAB_LDS) {
+        fill_rot_table(ltab, A.tab_entries, tid, VOTE_THREADS);
+        if (tid < 2) ltab[A.tab_entries + tid] = make_float2(0.f, 0.f);  // spare entries read by the 2-wide loop
+    }
     if (blockIdx.x == 0 && tid == 0) { A.packed[0] = 0ull; A.packed[1] = 0ull; }
     __syncthreads();
     float S = 0.f;
@@ -361,29 +364,35 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
         const float ez = fmaf((fabsf(F.cc.z) + fabsf(cr.z) + fabsf(F.x.z) + fabsf(F.y.z)) * rinv, 1e-6f, 1e-3f);
         const float lox = blx - ex, hix = bhx + ex, loy = bly - ey, hiy = bhy + ey, loz = blz - ez, hiz = bhz + ez;
         int qhead = 0, qtail = 0;  // wave-uniform ring cursors, the ring is drained at the end of every batch
-        // the (cos,sin) of rotation i+1 is fetched while rotation i is screened (hides the LDS latency
-        // that would otherwise sit at the head of every iteration; the table has one spare entry)
-        float2 cs_next = (TAB_LDS && n > 0) ? ltab[tbase] : make_float2(0.f, 0.f);
-        for (int i = 0; __any(i < n); ++i) {
-            bool acc = false;
-            float2 cs = cs_next;
-            if (TAB_LDS && i + 1 < n) cs_next = ltab[tbase + i + 1];
+        // two rotations per trip: half the loop/scalar overhead and two independent table reads + fma chains
+        // in flight (the loop is issue- and latency-bound, not bandwidth-bound); the table has a spare entry
+        for (int i = 0; __any(i < n); i += 2) {
+            bool acc0 = false, acc1 = false;
             if (i < n) {
-                if (!TAB_LDS) cs = rot_cs(i, n);
-                const float qx = fmaf(cs.y, yq.x, fmaf(cs.x, xq.x, cq.x));
-                const float qy = fmaf(cs.y, yq.y, fmaf(cs.x, xq.y, cq.y));
-                const float qz = fmaf(cs.y, yq.z, fmaf(cs.x, xq.z, cq.z));
-                acc = (qx >= lox) & (qx < hix) & (qy >= loy) & (qy < hiy) & (qz >= loz) & (qz < hiz);
+                float2 c0, c1;
+                if (TAB_LDS) { c0 = ltab[tbase + i]; c1 = ltab[tbase + i + 1]; }
+                else { c0 = rot_cs(i, n); c1 = rot_cs(i + 1, n); }
+                const float qx0 = fmaf(c0.y, yq.x, fmaf(c0.x, xq.x, cq.x)), qx1 = fmaf(c1.y, yq.x, fmaf(c1.x, xq.x, cq.x));
+                const float qy0 = fmaf(c0.y, yq.y, fmaf(c0.x, xq.y, cq.y)), qy1 = fmaf(c1.y, yq.y, fmaf(c1.x, xq.y, cq.y));
+                const float qz0 = fmaf(c0.y, yq.z, fmaf(c0.x, xq.z, cq.z)), qz1 = fmaf(c1.y, yq.z, fmaf(c1.x, xq.z, cq.z));
+                acc0 = (qx0 >= lox) & (qx0 < hix) & (qy0 >= loy) & (qy0 < hiy) & (qz0 >= loz) & (qz0 < hiz);
+                acc1 = (i + 1 < n) & (qx1 >= lox) & (qx1 < hix) & (qy1 >= loy) & (qy1 < hiy) & (qz1 >= loz) & (qz1 < hiz);
             }
-            const unsigned long long m = __ballot(acc);
-            if (m == 0ull) continue;
-            if (acc) {
-                const int pos = qtail + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
-                                                                  __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+            const unsigned long long m0 = __ballot(acc0), m1 = __ballot(acc1);
+            if ((m0 | m1) == 0ull) continue;
+            const int n0 = __popcll(m0);
+            if (acc0) {
+                const int pos = qtail + __builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32),
+                                                                  __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0));
                 ring[pos & (VOTE_RING - 1)] = (uint16_t)(lane | (i << 6));
             }
-            qtail += __popcll(m);
-            if (qtail - qhead >= 64) {
+            if (acc1) {
+                const int pos = qtail + n0 + __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32),
+                                                                       __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0));
+                ring[pos & (VOTE_RING - 1)] = (uint16_t)(lane | ((i + 1) << 6));
+            }
+            qtail += n0 + __popcll(m1);
+            while (qtail - qhead >= 64) {  // at most two pops: <= 63 queued + <= 128 pushed
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 vote_pop<TILED, TAB_LDS>(VT, F, cr, ltab, ring, qhead, lane, 64);
                 qhead += 64;
@@ -526,7 +535,7 @@ static int vote_impl(const float* points, const float* outputs, const float* pro
     A.n_points = n_points;
     A.kk = vote_fixed_bits(pl, n_rots);
     const bool tab_lds = pl.tab_entries <= VOTE_TAB_LDS_MAX;
-    const size_t tab_bytes = tab_lds ? (size_t)pl.tab_entries * sizeof(float2) : 0;
+    const size_t tab_bytes = tab_lds ? (size_t)(pl.tab_entries + 2) * sizeof(float2) : 0;
     if (pl.tiled) {
         const size_t lds = VOTE_LDS_HEAD + VOTE_TILE_FLOATS * sizeof(float) + tab_bytes;
         dim3 grid(pl.T * pl.chunks);
