@@ -31,7 +31,8 @@ from cppf_amd.models import voting                    # noqa: E402
 from cppf_amd.models.model import PPFEncoder         # noqa: E402
 
 NUM_ROTS = 72
-FLOP_PER_PAIR = 23968            # 2 x 11 984 MAC of the pair MLP
+FLOP_PER_PAIR = 23968            # 2 x 11 984 MAC of the pair MLP: the algorithmic work of the path
+FLOP_PER_PAIR_EXECUTED = 13728   # what the pair kernel issues after hoisting 2x40 layer-0 columns to a per-point table
 PEAK_F32_MFMA = 157.3            # TFLOP/s, MI355X_MICROARCH.md
 PEAK_HBM = 8000.0                # GB/s
 
@@ -220,7 +221,13 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "pair_mlp_kernel<false,true,true>",
                          "achieved": FLOP_PER_PAIR * P / (t_mlp * 1e-3) / 1e12, "peak": PEAK_F32_MFMA,
                          "unit": "TFLOP/s", "frac": FLOP_PER_PAIR * P / (t_mlp * 1e-3) / 1e12 / PEAK_F32_MFMA,
-                         "traffic": pmc_traffic("pair_mlp_kernel<false, true, true>")},
+                         "traffic": pmc_traffic("pair_mlp_kernel<false, true, true>"),
+                         "note": "achieved = algorithmic FLOP of the reference path (23 968 per pair) / duration of the "
+                                 "pair-encoder stage (point_proj_kernel + pair_mlp_kernel); the pair kernel itself issues "
+                                 f"{FLOP_PER_PAIR_EXECUTED} MFMA FLOP per pair because the two 40-wide feature blocks of layer 0 "
+                                 "are projected once per point; fp32 MFMA shares the VALU datapath on gfx950, so the in-register "
+                                 "decode (about 1 000 VALU per 16 pairs) is paid on the same pipe",
+                         "executed_mfma_tflops": FLOP_PER_PAIR_EXECUTED * P / (t_mlp * 1e-3) / 1e12},
         }
         if world == 1 and not args.no_cpu_baseline:
             cb, flat_cpu = cpu_baseline(ob, idx, u_tr, u_rot, sd, cfg, corners[0], dims, N_POINTS, PAIRS_PER_POINT)

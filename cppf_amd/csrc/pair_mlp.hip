@@ -308,7 +308,8 @@ __device__ __forceinline__ bool sample_head(const f32x4 (&L)[NOB], float u, int 
     r = b0 > t ? 0 : r;
     r = gsel >= 0 ? r : 3;
     bin = 4 * (cabs - C0) + r;
-    if (u < 0.f) {  // arg-max mode (rare): the lane holding the lowest bin among the maxima owns it
+    if (__any(u < 0.f)) {  // arg-max mode (rare, wave-uniform test so the common path really skips it)
+        asm volatile("" ::: "memory");
         int am = 0x7fffffff;
 #pragma unroll
         for (int R = R1; R >= R0; --R) {
@@ -321,8 +322,7 @@ __device__ __forceinline__ bool sample_head(const f32x4 (&L)[NOB], float u, int 
         }
         int best = min(am, (int)xor16u((unsigned)am, lane));
         best = min(best, (int)xor32u((unsigned)best, lane));
-        bin = best;
-        owner = am == best;
+        if (u < 0.f) { bin = best; owner = am == best; }
     }
     return owner;
 }
@@ -400,6 +400,17 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
         f32x4* dst = reinterpret_cast<f32x4*>(W);
         for (int k = threadIdx.x; k < STD_LDS / 4; k += MLP_THREADS) dst[k] = src[k];
     }
+    // bin -> value tables (nocs/inference.py:187-188,252,256; fp32, left to right, true division): a
+    // correctly rounded divide is ~12 VALU, a table read is one LDS access
+    float* lut = W + STD_LDS;  // [0,32) mu, [32,64) nu, [64,100) theta
+    if (DECODE && threadIdx.x < 100) {
+        const int k = threadIdx.x;
+        float v;
+        if (k < 32) v = ((float)k / 31.0f * 2.0f) * A.vr0 - A.vr0;
+        else if (k < 64) v = (float)(k - 32) / 31.0f * A.vr1;
+        else v = (float)(k - 64) / 35.0f * (float)CPPF_PI;
+        lut[k] = v;
+    }
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -414,10 +425,14 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
     // MFMA chain, the gathers of tile t+1 are in flight (indices were fetched one tile earlier still),
     // so a tile never starts with a dependent idx -> feature round trip to L2/HBM.
     // ta/tb[pb][ob] = the lane's 4 outputs (16*ob + 4*g ..) of TA[a] and TB[b]; xp = its PPF input (ppf[g])
-    f32x4 ta[PB][4], tb[PB][4];
-    float xp[PB];
+    // The layer-0 accumulators of the NEXT tile (16 registers) are what is carried across the loop, not the
+    // 32 gathered table registers: they are formed right after the current tile's last MFMA, before the
+    // decode, which is where register pressure peaks.
+    f32x4 acc[PB][4];
     int ia1[PB], ib1[PB];
     {
+        f32x4 ta[PB][4], tb[PB][4];
+        float xp[PB];
         int ia[PB], ib[PB];
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) load_pair_idx(A, wave_gid * (16 * PB) + pb * 16 + j, ia[pb], ib[pb]);
@@ -432,6 +447,11 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
         const int64_t nt = wave_gid + wave_cnt < n_tiles ? wave_gid + wave_cnt : wave_gid;
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) load_pair_idx(A, nt * (16 * PB) + pb * 16 + j, ia1[pb], ib1[pb]);
+        const f32x4 w = ldb4(W + OFF_W0P + lane * 4);
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) acc[pb][ob] = mfma4(w[ob], xp[pb], ta[pb][ob] + tb[pb][ob]);
     }
 
     for (int64_t tile = wave_gid; tile < n_tiles; tile += wave_cnt) {
@@ -459,16 +479,8 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
             }
         }
 
-        // ---- layer 0: fc1 | fc0 (84 -> 32 | 32) = (TA[a] + TB[b]) + one MFMA step over the 4 PPF inputs ----
-        f32x4 acc[PB][4];
-        {
-            const f32x4 w = ldb4(W + OFF_W0P + lane * 4);
-#pragma unroll
-            for (int ob = 0; ob < 4; ++ob)
-#pragma unroll
-                for (int pb = 0; pb < PB; ++pb) acc[pb][ob] = mfma4(w[ob], xp[pb], ta[pb][ob] + tb[pb][ob]);
-        }
-
+        // ---- layer 0 (84 -> 32 | 32) is already in `acc`: (TA[a] + TB[b]) + one MFMA step over the 4 PPF inputs,
+        //      formed at the end of the previous trip (or in the prologue) ------------------------------
         // ---- layer 0: fc2 (32 -> 32) on relu(fc1), + fc0 ---------------------------------------
         f32x4 y[PB][2];
         {
@@ -522,8 +534,10 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
 #pragma unroll
             for (int pb = 0; pb < PB; ++pb) { y[pb][0] = a2[pb][0] + y[pb][0]; y[pb][1] = a2[pb][1] + y[pb][1]; }
         }
-        // ---- next tile: PPF from the landed points, table gathers into the (now dead) ta/tb registers,
+        // ---- next tile: PPF from the landed points, table gathers (consumed after the final layer),
         //      and the indices of the tile after it ---------------------------------------------------
+        f32x4 ta[PB][4], tb[PB][4];
+        float xp[PB];
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
             xp[pb] = ppf_from(npa[pb], npb[pb], nna[pb], nnb[pb], g);
@@ -567,6 +581,14 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
             }
 #pragma unroll
             for (int pb = 0; pb < PB; ++pb) z[pb] = a2[pb] + a1[pb][1];
+        }
+        // ---- layer 0 of the next tile from the gathers that have been in flight since layer 1 --------
+        {
+            const f32x4 w = ldb4(W + OFF_W0P + lane * 4);
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) acc[pb][ob] = mfma4(w[ob], xp[pb], ta[pb][ob] + tb[pb][ob]);
         }
         // ---- final 16 -> 144 (9 x 16) and epilogue, one 16-pair block at a time (halves the live
         //      logit registers; the 12 weight reads per block are cheap) ----------------------------
@@ -614,14 +636,13 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
                 int k;
                 // nocs/inference.py:187-188 (fp32, left to right); the owning lane stores its value
                 if (sample_head<0, 8, STD_NOB>(L, ut[pb][0], g, lane, k) && live)
-                    A.outputs[2 * pair[pb]] = ((float)k / 31.0f * 2.0f) * A.vr0 - A.vr0;
+                    A.outputs[2 * pair[pb]] = lut[k];
                 if (sample_head<8, 8, STD_NOB>(L, ut[pb][1], g, lane, k) && live)
-                    A.outputs[2 * pair[pb] + 1] = (float)k / 31.0f * A.vr1;
+                    A.outputs[2 * pair[pb] + 1] = lut[32 + k];
                 if (HEADS) {
                     float* h = A.heads + pair[pb] * 8;
-                    const float pif = (float)CPPF_PI;
-                    if (sample_head<16, 9, STD_NOB>(L, ur[pb][0], g, lane, k) && live) h[0] = (float)k / 35.0f * pif;
-                    if (sample_head<25, 9, STD_NOB>(L, ur[pb][1], g, lane, k) && live) h[1] = (float)k / 35.0f * pif;
+                    if (sample_head<16, 9, STD_NOB>(L, ur[pb][0], g, lane, k) && live) h[0] = lut[64 + k];
+                    if (sample_head<25, 9, STD_NOB>(L, ur[pb][1], g, lane, k) && live) h[1] = lut[64 + k];
                     if (live && g == 2) {  // logits 136..139 = aux_up, aux_right, sx, sy
                         f32x2 v; v[0] = L[8][0]; v[1] = L[8][1];
                         f32x2 w; w[0] = L[8][2]; w[1] = L[8][3];
@@ -830,12 +851,12 @@ static int launch_std(MlpArgs& A, int64_t N, void* workspace, size_t workspace_b
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mlp_kernel<LOGITS, DECODE, HEADS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, STD_LDS * sizeof(float));
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (STD_LDS + 128) * sizeof(float));
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
     hipLaunchKernelGGL((pair_mlp_kernel<LOGITS, DECODE, HEADS>), dim3(mlp_grid(A.P)), dim3(MLP_THREADS),
-                       STD_LDS * sizeof(float), st, A);
+                       (STD_LDS + 128) * sizeof(float), st, A);
     CPPF_CHECK_LAUNCH();
     return 0;
 }

@@ -84,12 +84,12 @@ static inline int sat_int(double v)
 static inline float bits_f(int32_t b) { float f; memcpy(&f, &b, 4); return f; }
 static inline int32_t f_bits(float f) { int32_t b; memcpy(&b, &f, 4); return b; }
 
-/* exp(x) for x <= 0 (softmax after the max subtraction; callers guarantee x <= 0), clamped below at
- * -86: 2^(x*log2e) = 2^n * p(f), n = rint(y), f = y - n in [-0.5, 0.5] (exact), p = degree-4 minimax of
+/* exp(x) for x <= 0 (softmax after the max subtraction; callers guarantee x <= 0):
+ * 2^(x*log2e) = 2^n * p(f), n = rint(y), f = y - n in [-0.5, 0.5] (exact), p = degree-4 minimax of
  * 2^f.  Max relative error 7e-6 (far below what an inverse-CDF draw can resolve). */
 float orc_expf(float x)
 {
-    x = x < -86.0f ? -86.0f : x;
+    x = x < -86.0f ? -86.0f : x;   /* keeps 2^n a normal number for the exponent arithmetic below */
     float y = x * 1.44269504088896341f;
     float n = rintf(y);
     float f = y - n;
