@@ -602,3 +602,38 @@ def test_pipelines_graph_replay_equals_eager(golden, dev):
         cp.load(ob["pc"], ob["normals"], ob["feat"], idx, u_tr, u_rot, corners[0].copy())
         oi, ov = cp.run()
         assert int(oi.item()) == ref["argmax"]
+
+
+def test_batch_of_mixed_categories_matches_per_object_oracle(oracle, golden, dev):
+    """BASELINE.json config 4 in miniature: mixed NOCS categories through BatchPoseRunner (one cached
+    hipGraph pipeline per shape, records in object order); every object is checked against the oracle chain."""
+    from cppf_amd.batch import BatchPoseRunner
+    from cppf_amd.config import NOCS_CATEGORIES
+    sd = seeded_sd(0)
+    for k in ("final.weight", "final.bias"):
+        sd[k] = sd[k] * 4
+    encoders = {c: make_encoder(sd, [84, 32, 32, 16], 141, dev) for c in NOCS_CATEGORIES}
+    objects = []
+    for j in range(8):
+        cat = NOCS_CATEGORIES[j % 6]
+        ob = syn.make_object(cat, 768, 100 + j)
+        idx = syn.make_pairs(768, 24, 100 + j)
+        u_tr, u_rot = syn.make_uniforms(idx.shape[0], 100 + j)
+        objects.append(dict(pc=ob["pc"], normals=ob["normals"], feat=ob["feat"], point_idxs=idx, u_tr=u_tr, u_rot=u_rot,
+                            cfg=ob["cfg"]))
+    runner = BatchPoseRunner(encoders, dev)
+    recs = runner.run(objects).cpu().numpy()
+    recs2 = runner.run(objects).cpu().numpy()               # second pass replays the cached graphs
+    np.testing.assert_array_equal(recs, recs2)
+    assert recs.shape == (8, 20) and recs[:, 15].tolist() == list(range(8))
+    sph = golden("sphere.npz")["pts"]
+    for j, obj in enumerate(objects):
+        cfg = obj["cfg"]
+        ocfg = dict(res=cfg.res, tr_num_bins=32, rot_num_bins=36, vote_range=cfg.vote_range, scale_mean=cfg.scale_mean,
+                    regress_right=cfg.regress_right, ppffcs=[84, 32, 32, 16], out_dim=141)
+        o = oracle.estimate_pose(obj["pc"], obj["normals"], obj["feat"], obj["point_idxs"], sd, ocfg, obj["u_tr"],
+                                 obj["u_rot"], sph)
+        assert int(recs[j, 12]) == o["argmax"] and int(recs[j, 14]) == int(o["mask"].sum())
+        np.testing.assert_allclose(recs[j, 0:3], o["T"], atol=1e-12)
+        np.testing.assert_allclose(recs[j, 3:6], o["up"], atol=1e-12)
+        np.testing.assert_allclose(recs[j, 9:12], o["scale"], rtol=1e-6)
