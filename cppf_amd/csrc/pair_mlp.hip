@@ -218,16 +218,17 @@ __device__ __forceinline__ float ppf_component(const float* __restrict__ pc, con
 // ---- decode helpers (semantics: oracle/cppf_oracle.c:orc_sample_bin) --------------------------
 // Logit 16*R + 4*g + r of the lane's pair lives in L[R][r] of lane group g = lane >> 4: one "chunk"
 // of 4 consecutive logits per lane per MFMA output block ("row") R.  Cross-lane traffic inside the
-// 4 lanes of a pair uses v_permlane16_swap / v_permlane32_swap (VALU, no LDS round trip).
+// 4 lanes of a pair goes through the LDS crossbar (ds_swizzle / ds_bpermute: no LDS memory, and no VALU
+// issue slots -- a v_permlane*_swap exchange costs 2 moves + swap (2 slots) + select = 5 slots on the pipe
+// the fp32 MFMAs also need; measured 3 % faster, profiles/microbench/valu_bench.hip).
 __device__ __forceinline__ unsigned xor16u(unsigned v, int lane)
 {
-    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-    return (lane & 16) ? r[0] : r[1];
+    (void)lane;
+    return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x401f);  // bit mode: and 0x1f, or 0, xor 0x10
 }
 __device__ __forceinline__ unsigned xor32u(unsigned v, int lane)
 {
-    auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    return (lane & 32) ? r[0] : r[1];
+    return (unsigned)__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, (int)v);
 }
 __device__ __forceinline__ float xor16f(float v, int lane) { return __uint_as_float(xor16u(__float_as_uint(v), lane)); }
 __device__ __forceinline__ float xor32f(float v, int lane) { return __uint_as_float(xor32u(__float_as_uint(v), lane)); }
