@@ -25,8 +25,8 @@ _pu8 = C.POINTER(C.c_uint8)
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    src = os.path.join(_HERE, "cppf_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("cppf_oracle.c", "sprin_oracle.c")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
 
@@ -44,6 +44,7 @@ def lib():
         _LIB.orc_tan.argtypes = [C.c_float]
         _LIB.orc_grid_argmax.restype = C.c_int64
         _LIB.orc_sample_bin.restype = C.c_int
+        _LIB.orc_sprin_conv_params.restype = C.c_int64
     return _LIB
 
 
@@ -332,3 +333,66 @@ def estimate_pose(pc, nrm, feat, point_idxs, sd, cfg, u_tr, u_rot, sphere_pts, n
     return dict(T=T, argmax=flat, peak=peak, grid=grid, outputs=outputs, logits=logits, mask=mask,
                 up=dirs[0] if dirs else None, right=dirs[1] if len(dirs) > 1 else None, scale=sc,
                 corner=corner, dims=dims, heads=heads)
+
+
+# --------------------------------------------------------------------------- SPRIN point encoder (row f1)
+def pack_point_encoder(sd, num_layers):
+    """Flatten a reference PointEncoder state_dict (models/model.py:36-44, models/sprin.py:64-95) into the
+    packed layout documented in sprin_oracle.c.  Returns (packed f32, desc dict)."""
+    g = lambda k: np.asarray(sd[k], dtype=np.float32)
+    parts = []
+    hidden = None
+    for l in range(num_layers):
+        pre = f"spconvs.{l}.kernel."
+        lin = sorted({int(k[len(pre):].split(".")[0]) for k in sd if k.startswith(pre)})
+        # Sequential indices: Linear at 0,3,6,..., LayerNorm at 1,4,...; the last Linear has no LayerNorm after it
+        lins = [i for i in lin if g(f"{pre}{i}.weight").ndim == 2]
+        hid = []
+        for i in lins[:-1]:
+            W = g(f"{pre}{i}.weight")
+            parts += [W.ravel(), g(f"{pre}{i}.bias"), g(f"{pre}{i + 1}.weight"), g(f"{pre}{i + 1}.bias")]
+            hid.append(W.shape[0])
+        Wk = g(f"{pre}{lins[-1]}.weight")
+        parts += [Wk.ravel(), g(f"{pre}{lins[-1]}.bias")]
+        rank = Wk.shape[0]
+        Wo = g(f"spconvs.{l}.outnet.weight")
+        n_out = Wo.shape[0]
+        n_in = Wo.shape[1] // rank
+        parts += [np.ascontiguousarray(Wo.T).ravel(), g(f"spconvs.{l}.outnet.bias"),
+                  g(f"spconvs.{l}.layer_norm.weight"), g(f"spconvs.{l}.layer_norm.bias")]
+        Wa = g(f"aggrs.{l}.linear.weight")
+        parts += [Wa.ravel(), g(f"aggrs.{l}.linear.bias")]
+        if l == 0:
+            hidden, desc = hid, dict(hidden=hid, rank=rank, n_nbr_feats=n_in, n_out=n_out, n_glob=Wa.shape[0],
+                                     num_layers=num_layers)
+        else:
+            assert hid == hidden
+    return np.concatenate(parts).astype(np.float32), desc
+
+
+def knn(pc=None, k=60, dist=None):
+    """torch.topk(dist, k, largest=False) neighbour sets (models/model.py:47), ascending index order."""
+    N = (pc if dist is None else dist).shape[0]
+    out = np.empty((N, k), np.int32)
+    pcc = _c(pc, _f) if pc is not None else None
+    dc = _c(dist, _f) if dist is not None else None
+    rc = lib().orc_knn(_p(pcc, _pf) if pcc is not None else None, _p(dc, _pf) if dc is not None else None,
+                       C.c_int(N), C.c_int(k), _p(out, _pi32))
+    assert rc == 0
+    return out
+
+
+def point_encoder(pc, nrm, nbrs, packed, desc):
+    """PointEncoder.forward_nbrs (models/model.py:63-78) -> f32[N, n_out + n_glob]."""
+    pc, nrm = _c(pc, _f), _c(nrm, _f)
+    nbrs = _c(nbrs, np.int32)
+    N, k = nbrs.shape
+    hid = np.asarray(desc["hidden"], np.int32)
+    out = np.empty((N, desc["n_out"] + desc["n_glob"]), np.float32)
+    packed = _c(packed, _f)
+    rc = lib().orc_point_encoder(_p(pc, _pf), _p(nrm, _pf), _p(nbrs, _pi32), C.c_int(N), C.c_int(k), _p(packed, _pf),
+                                 _p(hid, _pi32), C.c_int(len(hid)), C.c_int(desc["rank"]), C.c_int(desc["n_nbr_feats"]),
+                                 C.c_int(desc["n_out"]), C.c_int(desc["n_glob"]), C.c_int(desc["num_layers"]),
+                                 _p(out, _pf))
+    assert rc == 0
+    return out

@@ -242,3 +242,31 @@ def test_grid_setup_matches_reference_expression(oracle):
         np.testing.assert_array_equal(corner, corners[0])
         c2, d2 = grid_shape(pc, ob["cfg"].res)
         assert tuple(ref) == d2 and np.array_equal(c2[0], corner)
+
+
+# --------------------------------------------------------------------------- SPRIN point encoder (row f1)
+@pytest.mark.parametrize("tag", ["l1", "l2"])
+def test_point_encoder_matches_reference(oracle, golden, tag):
+    """oracle/sprin_oracle.c vs the reference PointEncoder's own output (tests/golden/make_golden_sprin.py).
+    Tolerance 2e-5 absolute on O(1) LayerNorm outputs: ATen sums in a different order."""
+    z = golden(f"sprin_{tag}.npz")
+    sd = {k[4:]: z[k] for k in z.files if k.startswith("sd::")}
+    packed, desc = oracle.pack_point_encoder(sd, int(z["num_layers"]))
+    assert desc["hidden"] == list(z["spfcs"])
+    out = oracle.point_encoder(z["pc"], z["nrm"], z["nbrs_topk"].astype(np.int32), packed, desc)
+    assert out.shape == z["out"].shape
+    np.testing.assert_allclose(out, z["out"], atol=2e-5, rtol=0)
+
+
+@pytest.mark.parametrize("tag", ["l1", "l2"])
+def test_knn_matches_torch_topk(oracle, golden, tag):
+    """Neighbour sets: exact squared distances vs torch.topk on torch.cdist (models/model.py:47,
+    nocs/inference.py:180) for every row whose k-th/(k+1)-th gap exceeds cdist's matmul noise."""
+    z = golden(f"sprin_{tag}.npz")
+    k = int(z["k"])
+    nb = oracle.knn(z["pc"], k)
+    safe = z["kth_gap"] > 5e-7
+    assert safe.sum() >= 0.9 * len(safe)
+    assert (nb[safe] == z["nbrs_topk"][safe]).all()
+    if z["dist"].size:  # the selection itself, on the reference's own distance matrix: exact
+        assert (oracle.knn(None, k, dist=z["dist"]) == z["nbrs_topk"]).all()
