@@ -12,7 +12,13 @@ Under `torch.no_grad()` (inference, nocs/inference.py:179-182) the whole of forw
 construction, gather/concat, three ResLayers and the final linear -- is one HIP kernel
 (csrc/pair_mlp.hip).  When autograd needs the graph (train.py:66,91) the same module evaluates the
 composite of torch ops instead; the HIP path has no backward yet.
-`PointEncoder` (SPRIN) is upstream of the hot path and not part of this package.
+
+`PointEncoder` (SPRIN, models/model.py:36-78) produces the per-point `feat` the pair encoder gathers:
+    PointEncoder(k, spfcs, out_dim, num_layers=2, num_nbr_feats=2)
+    .forward(pc[1,N,3], pc_normal[1,N,3], dist[1,N,N])      -> f32[1,N,out_dim + out_dim//4]
+    .forward_nbrs(pc, pc_normal, nbrs_idx[1,N,k])           -> same
+Under `no_grad` it is kNN selection + one fused HIP kernel per layer (csrc/sprin.hip); `dist=None` is
+accepted as an extension and selects neighbours from exact squared distances without an N x N matrix.
 """
 import ctypes as C
 
@@ -23,8 +29,9 @@ import torch.nn.functional as F
 
 from .. import _lib
 from .._torch_util import require_cuda, stream_ptr, workspace
+from .sprin import GlobalInfoProp, SparseSO3Conv, pack_point_encoder
 
-__all__ = ["ResLayer", "PPFEncoder"]
+__all__ = ["ResLayer", "PPFEncoder", "PointEncoder"]
 
 
 class ResLayer(nn.Module):
@@ -40,6 +47,116 @@ class ResLayer(nn.Module):
     def forward(self, x):
         x_res = x if self.fc0 is None else self.fc0(x)
         return self.fc2(F.relu(self.fc1(x))) + x_res
+
+
+class PointEncoder(nn.Module):
+    """models/model.py:36-78.  Same constructor, parameter names and call signatures as the reference."""
+
+    def __init__(self, k, spfcs, out_dim, num_layers=2, num_nbr_feats=2):
+        super().__init__()
+        self.k = int(k)
+        self.spfcs = [int(h) for h in spfcs]
+        self.out_dim = int(out_dim)
+        self.num_layers = int(num_layers)
+        self.num_nbr_feats = int(num_nbr_feats)
+        self.spconvs = nn.ModuleList([SparseSO3Conv(32, num_nbr_feats, out_dim, *spfcs)])
+        self.aggrs = nn.ModuleList([GlobalInfoProp(out_dim, out_dim // 4)])
+        for _ in range(num_layers - 1):
+            self.spconvs.append(SparseSO3Conv(32, out_dim + out_dim // 4, out_dim, *spfcs))
+            self.aggrs.append(GlobalInfoProp(out_dim, out_dim // 4))
+        self._packed = None
+        self._packed_key = None
+
+    # ------------------------------------------------------------------ reference signatures
+    def forward(self, pc, pc_normal, dist=None):
+        if self._needs_graph(pc):
+            if dist is None:
+                dist = torch.cdist(pc, pc)
+            nbrs = torch.topk(dist, self.k, largest=False, sorted=False)[1]          # models/model.py:47
+            return self._composite(pc, pc_normal, nbrs)
+        pc2, nrm2 = self._check_inputs(pc, pc_normal)
+        if dist is not None:
+            if dist.shape[-2:] != (pc2.shape[0], pc2.shape[0]):
+                raise ValueError(f"dist must be [..., N, N], got {tuple(dist.shape)}")
+            dist = dist.detach().reshape(pc2.shape[0], pc2.shape[0]).float().contiguous()
+        return self._forward_device(pc2, nrm2, self.neighbours(pc2, dist)).reshape(*pc.shape[:-1], -1)
+
+    def forward_nbrs(self, pc, pc_normal, nbrs_idx):
+        if self._needs_graph(pc):
+            return self._composite(pc, pc_normal, nbrs_idx)
+        pc2, nrm2 = self._check_inputs(pc, pc_normal)
+        nbrs = nbrs_idx.reshape(pc2.shape[0], -1).to(device=pc2.device, dtype=torch.int32).contiguous()
+        return self._forward_device(pc2, nrm2, nbrs).reshape(*pc.shape[:-1], -1)
+
+    # ------------------------------------------------------------------ device path
+    def neighbours(self, pc, dist=None):
+        """i32[N,k]: rows of torch.topk(dist, k, largest=False) in ascending index order; without `dist`
+        the keys are exact squared distances computed from pc."""
+        N = pc.shape[0]
+        if self.k > N:
+            raise ValueError(f"k={self.k} neighbours requested from {N} points")
+        nbrs = torch.empty((N, self.k), dtype=torch.int32, device=pc.device)
+        with torch.cuda.device(pc.device):
+            rc = _lib.lib().cppf_knn(pc.data_ptr(), 0 if dist is None else dist.data_ptr(), N, self.k, nbrs.data_ptr(),
+                                     stream_ptr(pc.device))
+        _lib.check(rc, "cppf_knn")
+        return nbrs
+
+    def _forward_device(self, pc, nrm, nbrs):
+        N, k = nbrs.shape
+        packed, desc = self._packed_weights(pc.device)
+        hid = (C.c_int * len(desc["hidden"]))(*desc["hidden"])
+        L = _lib.lib()
+        W = desc["n_out"] + desc["n_glob"]
+        out = torch.empty((N, W), dtype=torch.float32, device=pc.device)
+        ws = workspace(L.cppf_point_encoder_workspace_bytes(N, desc["n_out"], desc["n_glob"], self.num_layers), pc.device,
+                       "point_encoder")
+        with torch.cuda.device(pc.device):
+            rc = L.cppf_point_encoder_forward(pc.data_ptr(), nrm.data_ptr(), nbrs.data_ptr(), N, k, packed.data_ptr(), hid,
+                                              len(desc["hidden"]), desc["rank"], desc["n_nbr_feats"], desc["n_out"],
+                                              desc["n_glob"], self.num_layers, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                              stream_ptr(pc.device))
+        if rc == -3:
+            raise _lib.CppfError(f"no device kernel for PointEncoder(k={self.k}, spfcs={self.spfcs}, out_dim={self.out_dim}): "
+                                 "csrc/sprin.hip covers spfcs=[32,64,32,32], out_dim=32, k<=64 (train.py:34)")
+        _lib.check(rc, "cppf_point_encoder_forward")
+        return out
+
+    # ------------------------------------------------------------------ internals
+    def _needs_graph(self, pc):
+        if not torch.is_grad_enabled():
+            return False
+        return pc.requires_grad or any(p.requires_grad for p in self.parameters())
+
+    def _composite(self, pc, pc_normal, nbrs_idx):
+        """models/model.py:63-78 as torch ops (autograd path)."""
+        gather = lambda t: torch.gather(t.unsqueeze(-3).expand(*t.shape[:-1], *t.shape[-2:]), -2,
+                                        nbrs_idx[..., None].expand(*nbrs_idx.shape, t.shape[-1]))
+        pc_nbrs = gather(pc)
+        norm = torch.norm(pc_nbrs - pc.unsqueeze(-2), dim=-1, keepdim=True)
+        cos = torch.sum(gather(pc_normal) * pc_normal.unsqueeze(-2), -1, keepdim=True)
+        feat = self.aggrs[0](self.spconvs[0](pc_nbrs, torch.cat([norm, cos], -1), pc))
+        for spconv, aggr in zip(self.spconvs[1:], self.aggrs[1:]):
+            feat = aggr(spconv(pc_nbrs, gather(feat), pc))
+        return feat
+
+    def _check_inputs(self, pc, pc_normal):
+        require_cuda()
+        if not pc.is_cuda:
+            raise _lib.CppfError("PointEncoder inference runs on a HIP device only (no CPU fallback); "
+                                 "move the module and its inputs to cuda")
+        if pc.shape[-1] != 3 or pc_normal.shape != pc.shape or pc.dim() not in (2, 3) or (pc.dim() == 3 and pc.shape[0] != 1):
+            raise ValueError("pc / pc_normal must be [1,N,3] (or [N,3])")
+        return (pc.detach().reshape(-1, 3).float().contiguous(), pc_normal.detach().reshape(-1, 3).float().contiguous())
+
+    def _packed_weights(self, device):
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._packed is None or self._packed_key != key:
+            sd = {k: v.detach().float().cpu().numpy() for k, v in self.state_dict().items()}
+            packed, desc = pack_point_encoder(sd, self.num_layers)
+            self._packed = (torch.from_numpy(packed).to(device), desc)
+            self._packed_key = key
+        return self._packed
 
 
 class PPFEncoder(nn.Module):

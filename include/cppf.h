@@ -195,6 +195,38 @@ int cppf_scale_sum(const float* scale_logits, int stride, const int32_t* sel, co
  * corner device f32[3], dims device i32[3]. */
 int cppf_grid_setup(const float* pc, int64_t N, float res, float* corner, int32_t* dims, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * SPRIN point encoder: produces the per-point `feat` the pair MLP gathers.
+ * Replaces models/model.py:36-78 `PointEncoder.forward(pc, pc_normal, dist)` / `forward_nbrs(...)` with
+ * models/sprin.py:40-107 (rifeat, conv_kernel, SparseSO3Conv, GlobalInfoProp), called at
+ * nocs/inference.py:180-181 and train.py:62-64.
+ *
+ * cppf_knn: the neighbour sets of `torch.topk(dist, k, largest=False)` (models/model.py:47).
+ *   dist != NULL: device f32[N,N], keys are dist[i][j] (the matrix the reference passes in);
+ *   dist == NULL: keys are exact squared distances from pc (device f32[N,3]) -- no N x N matrix.
+ *   nbrs: device i32[N,k], each row the k smallest keys (ties -> lower index) in ascending index order.
+ *   One wavefront per query; 4-pass 8-bit radix select on order-preserving key bits, keys staged in LDS
+ *   for N <= 8192 and recomputed per pass above that.
+ *
+ * cppf_point_encoder_forward: forward_nbrs.  pc, nrm device f32[N,3]; nbrs device i32[N,k], k <= 64;
+ *   out device f32[N, n_out+n_glob].  `packed` device f32: per layer, in this order,
+ *     for each hidden width h_i (in_i = 6, then h_{i-1}):  W[h_i][in_i], b[h_i], ln_weight[h_i], ln_bias[h_i]
+ *     Wk[rank][h_last], bk[rank]                      (spconvs.l.kernel.*)
+ *     Wo_t[rank*n_in][n_out] = outnet.weight TRANSPOSED, bo[n_out], ln_weight[n_out], ln_bias[n_out]
+ *     Wa[n_glob][n_out], ba[n_glob]                   (aggrs.l.linear)
+ *   with n_in = n_nbr_feats (must be 2) for layer 0 and n_out+n_glob after it.
+ *   Device kernel exists for hidden = {32,64,32,32}, rank = 32, n_out = 32, n_glob <= 32 (the
+ *   configuration of train.py:34 / nocs/inference.py:82); anything else returns CPPF_EUNSUPPORTED.
+ * ------------------------------------------------------------------------------------------- */
+int cppf_knn(const float* pc, const float* dist, int n_points, int k, int32_t* nbrs, void* stream);
+size_t cppf_point_encoder_packed_floats(const int32_t* hidden, int n_hidden, int rank, int n_nbr_feats, int n_out,
+                                        int n_glob, int num_layers);
+size_t cppf_point_encoder_workspace_bytes(int n_points, int n_out, int n_glob, int num_layers);
+int cppf_point_encoder_forward(const float* pc, const float* nrm, const int32_t* nbrs, int n_points, int k,
+                               const float* packed, const int32_t* hidden, int n_hidden, int rank, int n_nbr_feats,
+                               int n_out, int n_glob, int num_layers, float* out, void* workspace,
+                               size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,103 @@
+"""SPRIN point encoder on the MI355X through the C ABI: HIP vs the oracle
+(bit-exact: same operation order) and vs the reference's own outputs (tests/golden/sprin_*.npz, 2e-5)."""
+import numpy as np
+import pytest
+import torch
+
+from cppf_amd import _lib
+from cppf_amd.models.model import PointEncoder
+
+pytestmark = pytest.mark.gpu
+
+
+def _cloud(n, seed, dup=0):
+    rng = np.random.default_rng(seed)
+    th, h = rng.uniform(0, 2 * np.pi, n), rng.uniform(-0.15, 0.15, n)
+    pc = (np.stack([0.05 * np.cos(th), h, 0.05 * np.sin(th)], -1) + rng.normal(0, 1e-3, (n, 3))).astype(np.float32)
+    nrm = np.stack([np.cos(th), np.zeros(n), np.sin(th)], -1) + rng.normal(0, 0.05, (n, 3))
+    nrm = (nrm / np.linalg.norm(nrm, axis=-1, keepdims=True)).astype(np.float32)
+    if dup:                                   # exact duplicates: equal keys at the selection boundary
+        pc[-dup:] = pc[:dup]
+    return pc, nrm
+
+
+def _encoder(dev, num_layers=1, seed=3, k=60):
+    torch.manual_seed(seed)
+    enc = PointEncoder(k=k, spfcs=[32, 64, 32, 32], num_layers=num_layers, out_dim=32).eval()
+    with torch.no_grad():
+        for name, p in enc.named_parameters():
+            if "layer_norm" in name or (".kernel." in name and p.ndim == 1 and name.endswith("weight")):
+                p.copy_(1.0 + 0.2 * torch.randn_like(p))
+    return enc.to(dev)
+
+
+def _oracle_out(oracle, enc, pc, nrm, nbrs):
+    sd = {k: v.detach().cpu().numpy() for k, v in enc.state_dict().items()}
+    packed, desc = oracle.pack_point_encoder(sd, enc.num_layers)
+    return oracle.point_encoder(pc, nrm, nbrs, packed, desc)
+
+
+@pytest.mark.parametrize("n,k,dup", [(1000, 60, 0), (257, 64, 0), (64, 64, 0), (515, 7, 40), (9001, 16, 0)])
+def test_knn_points_matches_oracle(dev, oracle, n, k, dup):
+    pc, _ = _cloud(n, n + k, dup)
+    enc = PointEncoder(k=k, spfcs=[32, 64, 32, 32], num_layers=1, out_dim=32)
+    got = enc.neighbours(torch.from_numpy(pc).to(dev)).cpu().numpy()
+    assert np.array_equal(got, oracle.knn(pc, k))
+
+
+def test_knn_from_dist_matches_torch_topk(dev, oracle, golden):
+    z = golden("sprin_l2.npz")                       # holds the reference's own torch.cdist matrix
+    k = int(z["k"])
+    enc = PointEncoder(k=k, spfcs=[32, 64, 32, 32], num_layers=1, out_dim=32)
+    pc = torch.from_numpy(z["pc"]).to(dev)
+    got = enc.neighbours(pc, torch.from_numpy(z["dist"]).to(dev)).cpu().numpy()
+    assert np.array_equal(got, z["nbrs_topk"].astype(np.int32))
+    # a matrix with negative and repeated entries: ordering and tie rule
+    rng = np.random.default_rng(0)
+    d = rng.integers(-3, 4, (96, 96)).astype(np.float32)
+    got = enc.neighbours(pc, torch.from_numpy(d).to(dev)).cpu().numpy()
+    assert np.array_equal(got, oracle.knn(None, k, dist=d))
+
+
+def test_point_encoder_matches_reference_and_oracle(dev, oracle, golden):
+    z = golden("sprin_l1.npz")
+    enc = PointEncoder(k=int(z["k"]), spfcs=list(z["spfcs"]), num_layers=1, out_dim=32).eval()
+    enc.load_state_dict({k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")})
+    enc = enc.to(dev)
+    pc, nrm = torch.from_numpy(z["pc"][None]).to(dev), torch.from_numpy(z["nrm"][None]).to(dev)
+    nbrs = torch.from_numpy(z["nbrs_topk"].astype(np.int64)[None]).to(dev)
+    with torch.no_grad():
+        out_nbrs = enc.forward_nbrs(pc, nrm, nbrs)
+        out_dist = enc(pc, nrm, torch.cdist(pc, pc))             # the call of nocs/inference.py:180-181
+        out_none = enc(pc, nrm)                                   # extension: no N x N matrix
+    assert out_nbrs.shape == (1, 256, 40)
+    want = _oracle_out(oracle, enc, z["pc"], z["nrm"], z["nbrs_topk"].astype(np.int32))
+    assert np.array_equal(out_nbrs[0].cpu().numpy(), want)        # same operation order: bit-exact
+    for o in (out_nbrs, out_dist, out_none):
+        np.testing.assert_allclose(o[0].cpu().numpy(), z["out"], atol=2e-5, rtol=0)   # the reference's own output
+
+
+@pytest.mark.parametrize("n,k,layers", [(1024, 60, 1), (333, 17, 1), (300, 60, 2), (130, 64, 3)])
+def test_point_encoder_bit_exact_vs_oracle(dev, oracle, n, k, layers):
+    pc, nrm = _cloud(n, 5 * n + k)
+    enc = _encoder(dev, layers, seed=n, k=k)
+    nbrs = oracle.knn(pc, k)
+    with torch.no_grad():
+        out = enc.forward_nbrs(torch.from_numpy(pc[None]).to(dev), torch.from_numpy(nrm[None]).to(dev),
+                               torch.from_numpy(nbrs.astype(np.int64)[None]).to(dev))
+    assert np.array_equal(out[0].cpu().numpy(), _oracle_out(oracle, enc, pc, nrm, nbrs))
+
+
+def test_unsupported_shapes_raise_and_autograd_uses_composite(dev, golden):
+    z = golden("sprin_l2.npz")
+    enc = PointEncoder(k=int(z["k"]), spfcs=list(z["spfcs"]), num_layers=2, out_dim=32).eval()
+    enc.load_state_dict({k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")})
+    enc = enc.to(dev)
+    pc, nrm = torch.from_numpy(z["pc"][None]).to(dev), torch.from_numpy(z["nrm"][None]).to(dev)
+    with torch.no_grad(), pytest.raises(_lib.CppfError, match="no device kernel"):
+        enc(pc, nrm, torch.cdist(pc, pc))
+    out = enc(pc, nrm, torch.cdist(pc, pc))                        # grad enabled -> torch composite (train.py:64)
+    assert out.requires_grad
+    np.testing.assert_allclose(out[0].detach().cpu().numpy(), z["out"], atol=5e-5, rtol=0)
+    with torch.no_grad(), pytest.raises(_lib.CppfError, match="HIP device only"):
+        enc.cpu()(pc.cpu(), nrm.cpu(), None)
