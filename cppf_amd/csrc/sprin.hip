@@ -22,92 +22,164 @@ using namespace cppf;
 
 namespace {
 
-constexpr int KNN_WAVES = 4;        // queries per workgroup
-constexpr int KNN_LDS_MAX_N = 8192; // keys staged in LDS up to this N (4 x 32 KB + histograms)
+constexpr int KNN_WAVES = 4;    // queries per workgroup
+constexpr int KNN_CAP = 512;    // candidate slots per query in LDS
 
 __device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-__device__ __forceinline__ uint32_t knn_key(const float* __restrict__ pc, const float* __restrict__ dist, int N, int q,
-                                            float qx, float qy, float qz, int j)
+// Selection key of point j for the query: order-preserving bits of dist[q][j], or of the exact squared
+// distance ((dx*dx + dy*dy) + dz*dz), which is never negative so its raw bits already order correctly.
+template <bool FROM_DIST>
+__device__ __forceinline__ uint32_t knn_key(const float* __restrict__ pc, const float* __restrict__ row, float qx, float qy,
+                                            float qz, int j)
 {
-    float d;
-    if (dist) d = dist[(size_t)q * N + j];
-    else {
-        const float dx = pc[3 * j] - qx, dy = pc[3 * j + 1] - qy, dz = pc[3 * j + 2] - qz;
-        d = (dx * dx + dy * dy) + dz * dz;
-    }
-    return f2ord(d);
+    if (FROM_DIST) return f2ord(row[j]);
+    const float dx = pc[3 * j] - qx, dy = pc[3 * j + 1] - qy, dz = pc[3 * j + 2] - qz;
+    return __float_as_uint((dx * dx + dy * dy) + dz * dz) | 0x80000000u;  // == f2ord() for non-negative floats
 }
 
-// One wavefront per query point.  Four 8-bit radix passes find the exact key of the k-th smallest
-// entry (per-wave 256-bin LDS histogram, wave scan), then one ordered pass emits the indices.
-template <bool KEYS_IN_LDS>
+// Sum of one int per lane over the wavefront (DPP butterflies inside each row of 16, then four readlanes).
+__device__ __forceinline__ int wave_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4e, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);  // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);  // row_mirror
+    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) +
+           (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
+}
+
+// One wavefront per query, keys streamed twice, nothing kept per point:
+//   1. every lane keeps the minimum of its keys (j = lane mod 64).  The k-th smallest of those 64 minima, T0,
+//      bounds the k-th smallest key from above (the k minima below it are k distinct keys), and for points in
+//      arbitrary order only ~3k keys are <= T0;
+//   2. keys <= T0 are compacted, in ascending index order, into LDS (ballot prefix);
+//   3. a 32-step bitwise bisection over the candidates finds the exact k-th smallest key (per-lane VALU counts
+//      + one DPP wave sum per step: a ballot + scalar popcount per key costs a VALU->SGPR->SALU round trip);
+//   4. candidates below it, and the first ties, are written out in slot (= index) order.
+// More than KNN_CAP candidates (duplicate-heavy inputs) run the bisection over re-streamed keys instead.
+template <bool FROM_DIST>
 __global__ __launch_bounds__(KNN_WAVES * 64) void knn_kernel(const float* __restrict__ pc, const float* __restrict__ dist,
                                                              int N, int k, int32_t* __restrict__ out)
 {
-    extern __shared__ uint32_t knn_lds[];
+    __shared__ uint32_t cand_key[KNN_WAVES][KNN_CAP];
+    __shared__ int cand_idx[KNN_WAVES][KNN_CAP];
     const int w = threadIdx.x >> 6, lane = lane_id();
-    uint32_t* hist = knn_lds + w * 256;
-    uint32_t* keys = knn_lds + KNN_WAVES * 256 + (size_t)w * (KEYS_IN_LDS ? N : 0);
     const int q = blockIdx.x * KNN_WAVES + w;
-    const bool live = q < N;
-    const int qc = live ? q : N - 1;
+    if (q >= N) return;
     float qx = 0.f, qy = 0.f, qz = 0.f;
-    if (!dist) { qx = pc[3 * qc]; qy = pc[3 * qc + 1]; qz = pc[3 * qc + 2]; }
-    if (KEYS_IN_LDS)
-        for (int j = lane; j < N; j += 64) keys[j] = knn_key(pc, dist, N, qc, qx, qy, qz, j);
-    uint32_t prefix = 0, mask = 0;
-    int remaining = k;
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        for (int b = lane; b < 256; b += 64) hist[b] = 0;
-        __syncthreads();
-        for (int j = lane; j < N; j += 64) {
-            const uint32_t key = KEYS_IN_LDS ? keys[j] : knn_key(pc, dist, N, qc, qx, qy, qz, j);
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        // lane owns bins 4*lane .. 4*lane+3
-        const uint32_t c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
-        const int lsum = (int)(c0 + c1 + c2 + c3);
-        int incl = lsum;
+    if (!FROM_DIST) { qx = pc[3 * q]; qy = pc[3 * q + 1]; qz = pc[3 * q + 2]; }
+    const float* row = FROM_DIST ? dist + (size_t)q * N : nullptr;
+    // 1. lane minima and their k-th smallest
+    // (both streaming loops are unrolled 8x: a query is one wavefront and there are only N of them, so the
+    //  loads of several chunks have to be in flight at once to cover L2 latency)
+    uint32_t lmin = 0xffffffffu;
+    {
+        int j = lane;
+        for (; j + 7 * 64 < N; j += 8 * 64) {
+            uint32_t kk[8];
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(incl, d);
-            if (lane >= d) incl += t;
+            for (int u = 0; u < 8; ++u) kk[u] = knn_key<FROM_DIST>(pc, row, qx, qy, qz, j + u * 64);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) lmin = kk[u] < lmin ? kk[u] : lmin;
         }
-        const int excl = incl - lsum;
-        const bool hit = excl < remaining && remaining <= incl;
-        int digit = 0, below = 0;
-        if (hit) {
-            int need = remaining - excl;  // 1-based rank inside this lane's 4 bins
-            int b = 0;
-            int acc = 0;
-            if (need > (int)c0) { acc += c0; b = 1; if (need > (int)(c0 + c1)) { acc += c1; b = 2; if (need > (int)(c0 + c1 + c2)) { acc += c2; b = 3; } } }
-            digit = 4 * lane + b;
-            below = excl + acc;
+        for (; j < N; j += 64) {
+            const uint32_t key = knn_key<FROM_DIST>(pc, row, qx, qy, qz, j);
+            lmin = key < lmin ? key : lmin;
         }
-        const unsigned long long hm = __ballot(hit);
-        const int src = __ffsll((long long)hm) - 1;  // exactly one lane hits (k <= N)
-        digit = __shfl(digit, src);
-        below = __shfl(below, src);
-        remaining -= below;
-        prefix |= (uint32_t)digit << shift;
-        mask |= 255u << shift;
-        __syncthreads();
     }
-    // prefix = key of the k-th smallest; take every key below it and the first `remaining` equal to it
-    int base = 0, eq_seen = 0;
+    uint32_t T0 = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t c = T0 | (1u << bit);
+        if (__popcll(__ballot(lmin < c)) < k) T0 = c;
+    }
+    // 2. candidates
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    int n_cand = 0;
+    for (int j0 = 0; j0 < N; j0 += 8 * 64) {
+        uint32_t kk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * 64 + lane;
+            kk[u] = j < N ? knn_key<FROM_DIST>(pc, row, qx, qy, qz, j) : 0xffffffffu;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * 64 + lane;
+            const bool c = j < N && kk[u] <= T0;
+            const unsigned long long m = __ballot(c);
+            const int pos = n_cand + __popcll(m & lt_mask);
+            if (c && pos < KNN_CAP) { cand_key[w][pos] = kk[u]; cand_idx[w][pos] = j; }
+            n_cand += __popcll(m);
+        }
+    }
+    int32_t* o = out + (size_t)q * k;
+    if (n_cand <= KNN_CAP) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS writes, before other lanes read them
+        const int R = (n_cand + 63) >> 6;
+        // 3. exact k-th smallest among the candidates (held in registers): two key bits per step, the three
+        //    counts packed into one int (10 bits each, n_cand <= 512) so that a step costs one wave sum
+        constexpr int RMAX = KNN_CAP / 64;
+        uint32_t ck[RMAX];
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            const int s_ = r * 64 + lane;
+            ck[r] = s_ < n_cand ? cand_key[w][s_] : 0xffffffffu;
+        }
+        uint32_t T = 0;
+        for (int bit = 30; bit >= 0; bit -= 2) {
+            const uint32_t c1 = T | (1u << bit), c2 = T | (2u << bit), c3 = T | (3u << bit);
+            int cnt = 0;
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r)
+                if (r < R) cnt += (ck[r] < c1 ? 1 : 0) + (ck[r] < c2 ? 1 << 10 : 0) + (ck[r] < c3 ? 1 << 20 : 0);
+            cnt = wave_sum(cnt);
+            const int n1 = cnt & 1023, n2 = (cnt >> 10) & 1023, n3 = cnt >> 20;
+            T = n3 < k ? c3 : (n2 < k ? c2 : (n1 < k ? c1 : T));   // largest threshold with fewer than k keys below it
+        }
+        int below = 0;
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) below += ck[r] < T ? 1 : 0;
+        below = wave_sum(below);
+        // 4. emit
+        const int remaining = k - below;
+        int base = 0, eq_seen = 0;
+        for (int r = 0; r < R; ++r) {
+            const int s_ = r * 64 + lane;
+            const bool in = s_ < n_cand;
+            const uint32_t key = in ? cand_key[w][s_] : 0xffffffffu;
+            const bool eq = in && key == T;
+            const unsigned long long eqm = __ballot(eq);
+            const bool take = in && (key < T || (eq && eq_seen + __popcll(eqm & lt_mask) < remaining));
+            const unsigned long long tm = __ballot(take);
+            if (take) o[base + __popcll(tm & lt_mask)] = cand_idx[w][s_];
+            base += __popcll(tm);
+            eq_seen += __popcll(eqm);
+        }
+        return;
+    }
+    // rare: bisection over re-streamed keys
+    uint32_t T = 0;
+    int below = 0;
+    for (int bit = 31; bit >= -1; --bit) {
+        const uint32_t c = bit >= 0 ? (T | (1u << bit)) : T;
+        int cnt = 0;
+        for (int j = lane; j < N; j += 64) cnt += knn_key<FROM_DIST>(pc, row, qx, qy, qz, j) < c ? 1 : 0;
+        cnt = wave_sum(cnt);
+        if (bit < 0) below = cnt;
+        else if (cnt < k) T = c;
+    }
+    const int remaining = k - below;
+    int base = 0, eq_seen = 0;
     for (int j0 = 0; j0 < N; j0 += 64) {
         const int j = j0 + lane;
         const bool in = j < N;
-        const uint32_t key = in ? (KEYS_IN_LDS ? keys[j] : knn_key(pc, dist, N, qc, qx, qy, qz, j)) : 0xffffffffu;
-        const bool eq = in && key == prefix;
+        const uint32_t key = in ? knn_key<FROM_DIST>(pc, row, qx, qy, qz, j) : 0xffffffffu;
+        const bool eq = in && key == T;
         const unsigned long long eqm = __ballot(eq);
-        const bool take = in && (key < prefix || (eq && eq_seen + __popcll(eqm & lt_mask) < remaining));
+        const bool take = in && (key < T || (eq && eq_seen + __popcll(eqm & lt_mask) < remaining));
         const unsigned long long tm = __ballot(take);
-        if (take && live) out[(size_t)q * k + base + __popcll(tm & lt_mask)] = j;
+        if (take) o[base + __popcll(tm & lt_mask)] = j;
         base += __popcll(tm);
         eq_seen += __popcll(eqm);
     }
@@ -311,15 +383,8 @@ int cppf_knn(const float* pc, const float* dist, int n_points, int k, int32_t* n
     if ((!pc && !dist) || !nbrs || k > n_points) return CPPF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int blocks = (n_points + KNN_WAVES - 1) / KNN_WAVES;
-    const bool in_lds = n_points <= KNN_LDS_MAX_N;
-    const size_t lds = (size_t)KNN_WAVES * (256 + (in_lds ? n_points : 0)) * sizeof(uint32_t);
-    if (in_lds) {
-        hipError_t e = hipFuncSetAttribute((const void*)knn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        knn_kernel<true><<<blocks, KNN_WAVES * 64, lds, st>>>(pc, dist, n_points, k, nbrs);
-    } else {
-        knn_kernel<false><<<blocks, KNN_WAVES * 64, lds, st>>>(pc, dist, n_points, k, nbrs);
-    }
+    if (dist) knn_kernel<true><<<blocks, KNN_WAVES * 64, 0, st>>>(pc, dist, n_points, k, nbrs);
+    else knn_kernel<false><<<blocks, KNN_WAVES * 64, 0, st>>>(pc, dist, n_points, k, nbrs);
     return (int)hipGetLastError();
 }
 

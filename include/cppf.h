@@ -205,8 +205,8 @@ int cppf_grid_setup(const float* pc, int64_t N, float res, float* corner, int32_
  *   dist != NULL: device f32[N,N], keys are dist[i][j] (the matrix the reference passes in);
  *   dist == NULL: keys are exact squared distances from pc (device f32[N,3]) -- no N x N matrix.
  *   nbrs: device i32[N,k], each row the k smallest keys (ties -> lower index) in ascending index order.
- *   One wavefront per query; 4-pass 8-bit radix select on order-preserving key bits, keys staged in LDS
- *   for N <= 8192 and recomputed per pass above that.
+ *   One wavefront per query, keys streamed twice: the k-th smallest of the 64 per-lane minima bounds the
+ *   answer, the ~3k keys below that bound are compacted into LDS and an exact 32-step bisection runs on them.
  *
  * cppf_point_encoder_forward: forward_nbrs.  pc, nrm device f32[N,3]; nbrs device i32[N,k], k <= 64;
  *   out device f32[N, n_out+n_glob].  `packed` device f32: per layer, in this order,

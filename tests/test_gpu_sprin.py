@@ -37,12 +37,23 @@ def _oracle_out(oracle, enc, pc, nrm, nbrs):
     return oracle.point_encoder(pc, nrm, nbrs, packed, desc)
 
 
-@pytest.mark.parametrize("n,k,dup", [(1000, 60, 0), (257, 64, 0), (64, 64, 0), (515, 7, 40), (9001, 16, 0)])
+@pytest.mark.parametrize("n,k,dup", [(1000, 60, 0), (257, 64, 0), (64, 64, 0), (515, 7, 40), (2000, 33, 0), (4096, 60, 3), (8000, 60, 0), (9001, 16, 0), (10050, 9, 0)])
 def test_knn_points_matches_oracle(dev, oracle, n, k, dup):
     pc, _ = _cloud(n, n + k, dup)
     enc = PointEncoder(k=k, spfcs=[32, 64, 32, 32], num_layers=1, out_dim=32)
     got = enc.neighbours(torch.from_numpy(pc).to(dev)).cpu().numpy()
     assert np.array_equal(got, oracle.knn(pc, k))
+
+
+def test_knn_duplicate_heavy_cloud_takes_the_full_bisection(dev, oracle):
+    """3 distinct locations x 400 copies: > 256 keys tie below the pruning bound, so the kernel's fallback
+    (bisection over all keys) runs; ties resolve to the lowest indices like the oracle's."""
+    rng = np.random.default_rng(7)
+    pc = np.repeat(rng.normal(0, 0.1, (3, 3)).astype(np.float32), 400, 0)[rng.permutation(1200)]
+    for k in (60, 5):
+        enc = PointEncoder(k=k, spfcs=[32, 64, 32, 32], num_layers=1, out_dim=32)
+        got = enc.neighbours(torch.from_numpy(pc).to(dev)).cpu().numpy()
+        assert np.array_equal(got, oracle.knn(pc, k))
 
 
 def test_knn_from_dist_matches_torch_topk(dev, oracle, golden):
