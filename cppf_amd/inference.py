@@ -109,12 +109,15 @@ class CenterPipeline:
         pipe.load(pc, normals, feat, point_idxs, u_tr, u_rot, corner)     # host or device arrays
         idx, val = pipe.run()                                             # device i64[1], f32[1]
 
-    `outputs` (mu, nu), `heads` and `grid` of the last run stay available as attributes."""
+    `outputs` (mu, nu), `heads` and `grid` of the last run stay available as attributes.  With
+    `point_encoder=` (a cppf_amd PointEncoder) the per-point features are computed on device at the head of the
+    chain (kNN + SPRIN, nocs/inference.py:180-181) and `load(feat=None)` is enough."""
 
     def __init__(self, encoder, cfg, n_points, n_pairs, dims, device, num_rots=72, adaptive=True, with_heads=True,
-                 use_graph=True):
+                 use_graph=True, point_encoder=None):
         require_cuda()
         self.encoder, self.cfg, self.device = encoder, cfg, device
+        self.point_encoder = point_encoder
         self.num_rots, self.adaptive, self.with_heads = num_rots, adaptive, with_heads
         F = (encoder.ppffcs[0] - 4) // 2
         z = lambda *shape, dtype=F32: torch.zeros(shape, dtype=dtype, device=device)
@@ -139,6 +142,8 @@ class CenterPipeline:
             dst.copy_(torch.as_tensor(src), non_blocking=True)
 
     def _chain(self):
+        if self.point_encoder is not None:                                    # nocs/inference.py:180-181, no N x N matrix
+            self.feat = self.point_encoder(self.pc[None], self.nrm[None])[0]
         self.idx32.copy_(self.idx)                                            # .astype(cp.int32), nocs/inference.py:202
         self.outputs, self.heads = self.encoder.forward_decode(
             self.pc, self.nrm, self.feat, self.idx, self.u_tr, self.cfg.vote_range,
@@ -301,8 +306,8 @@ class PosePipeline(CenterPipeline):
     together in one hipGraph; `run()` replays it and reads back the 21-double record (one sync)."""
 
     def __init__(self, encoder, cfg, n_points, n_pairs, dims, device, sphere_pts, num_rots=72, adaptive=True,
-                 angle_tol=1.5, max_rot_pairs=10000, use_graph=True):
-        super().__init__(encoder, cfg, n_points, n_pairs, dims, device, num_rots, adaptive, True, use_graph)
+                 angle_tol=1.5, max_rot_pairs=10000, use_graph=True, point_encoder=None):
+        super().__init__(encoder, cfg, n_points, n_pairs, dims, device, num_rots, adaptive, True, use_graph, point_encoder)
         sph64 = np.asarray(sphere_pts, dtype=np.float64)
         self.ws = PoseWorkspace(device, n_pairs, dims, sph64.shape[0])
         self.ws.out_idx, self.ws.out_val, self.ws.grid = self.out_idx, self.out_val, self.grid

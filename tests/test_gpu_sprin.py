@@ -112,3 +112,35 @@ def test_unsupported_shapes_raise_and_autograd_uses_composite(dev, golden):
     np.testing.assert_allclose(out[0].detach().cpu().numpy(), z["out"], atol=5e-5, rtol=0)
     with torch.no_grad(), pytest.raises(_lib.CppfError, match="HIP device only"):
         enc.cpu()(pc.cpu(), nrm.cpu(), None)
+
+
+def test_pipeline_with_point_encoder_equals_precomputed_features(dev, oracle):
+    """PosePipeline(point_encoder=...) -- kNN + SPRIN + pair path + pose tail in one captured graph -- gives the
+    record of the same pipeline fed with the oracle's features; replaying the graph is stable."""
+    import cppf_amd.synthetic as syn
+    from cppf_amd.inference import PosePipeline, grid_shape
+    from cppf_amd.models.model import PPFEncoder
+    from cppf_amd.utils.util import fibonacci_sphere
+    ob = syn.make_object("mug", 1024, 11)
+    cfg, pc, nrm = ob["cfg"], ob["pc"], ob["normals"]
+    torch.manual_seed(4)
+    ppf = PPFEncoder([84, 32, 32, 16], 2 * cfg.tr_num_bins + 2 * cfg.rot_num_bins + 5).eval().to(dev)
+    penc = _encoder(dev, 1, seed=9, k=60)
+    idx = syn.make_pairs(1024, 32, 11)
+    u_tr, u_rot = syn.make_uniforms(idx.shape[0], 11)
+    corners, dims = grid_shape(pc, cfg.res)
+    corner = corners[0]
+    sphere = np.array(fibonacci_sphere(480))
+    feat = _oracle_out(oracle, penc, pc, nrm, oracle.knn(pc, 60))
+    a = PosePipeline(ppf, cfg, 1024, idx.shape[0], dims, dev, sphere, point_encoder=penc)
+    a.load(pc, nrm, None, idx, u_tr, u_rot, corner)
+    ra = a.run()
+    ra2 = a.run()
+    b = PosePipeline(ppf, cfg, 1024, idx.shape[0], dims, dev, sphere)
+    b.load(pc, nrm, feat, idx, u_tr, u_rot, corner)
+    rb = b.run()
+    assert np.array_equal(a.feat.cpu().numpy(), feat)
+    for key in ("argmax", "n_surv"):
+        assert ra[key] == rb[key] == ra2[key]
+    for key in ("T", "up", "scale"):
+        assert np.array_equal(ra[key], rb[key]) and np.array_equal(ra[key], ra2[key])
