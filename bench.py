@@ -192,6 +192,23 @@ def main():
             pose = pp.run()
         t_pose = (time.perf_counter() - tp0) / 10 * 1e3
 
+    # secondary: the step before the path -- kNN(60) + SPRIN point encoder producing `feat`
+    # (nocs/inference.py:180-181), random-init weights of the reference's configuration (train.py:34)
+    t_penc = None
+    if rank == 0:
+        from cppf_amd.models.model import PointEncoder
+        torch.manual_seed(1)
+        penc = PointEncoder(k=60, spfcs=[32, 64, 32, 32], num_layers=1, out_dim=32).eval().to(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.no_grad():
+            for it in range(6):
+                if it == 1:
+                    e0.record()
+                penc(pc[None], nrm[None])
+            e1.record()
+        torch.cuda.synchronize()
+        t_penc = e0.elapsed_time(e1) / 5
+
     if rank == 0:
         argmax_gpu = int(allrec[0, 12].item())
         out = {
@@ -215,7 +232,8 @@ def main():
             "pairs_per_ms_per_gpu": args.steps * P / elapsed / 1e3,
             "stage_ms": {"ppf_mlp_decode": t_mlp, "vote_reduce_argmax": t_vote,
                          "vote_reduce_argmax_known_answer_inputs": t_vote_ka,
-                         "full_pose_incl_readback": t_pose, "full_pose_n_surv": pose["n_surv"]},
+                         "full_pose_incl_readback": t_pose, "full_pose_n_surv": pose["n_surv"],
+                         "point_encoder_knn60_sprin": t_penc},
             # dominant kernel = the fused pair encoder (one launch between the two events): exact-fp32
             # MFMA, 23 968 algorithmic FLOP per pair
             "roofline": {"bound": "mfma", "kernel": "pair_mlp_kernel<false,true,true>",
