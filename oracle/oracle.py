@@ -25,7 +25,7 @@ _pu8 = C.POINTER(C.c_uint8)
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("cppf_oracle.c", "sprin_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("cppf_oracle.c", "sprin_oracle.c", "backward_oracle.c")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -396,3 +396,40 @@ def point_encoder(pc, nrm, nbrs, packed, desc):
                                  _p(out, _pf))
     assert rc == 0
     return out
+
+
+# --------------------------------------------------------------------------- backward of the pair MLP (row f2)
+BWD_MAX_PARTS = 1024
+
+
+def bwd_parts(P):
+    """number of partial accumulators the device kernel uses for P pairs (cppf.h: CPPF_BWD_MAX_PARTS)"""
+    return max(1, min((P + 63) // 64, BWD_MAX_PARTS))
+
+
+def pair_mlp_backward(pc, nrm, feat, idxs, sd, ppffcs, out_dim, grad_out, n_parts=None):
+    """autograd of models/model.py:117-137 (train.py:91): returns ({param name: grad}, grad_feat[N,F])."""
+    pc, nrm, feat, idxs = _c(pc, _f), _c(nrm, _f), _c(feat, _f), _c(idxs, np.int64)
+    grad_out = _c(grad_out, _f)
+    params, offs = pack_params(sd, ppffcs)
+    dims = np.asarray(ppffcs, dtype=np.int32)
+    P = idxs.shape[0]
+    n_parts = bwd_parts(P) if n_parts is None else n_parts
+    gp = np.zeros_like(params)
+    gf = np.zeros_like(feat)
+    rc = lib().orc_pair_mlp_backward(_p(pc, _pf), _p(nrm, _pf), _p(feat, _pf), _p(idxs, _pi64), C.c_int64(pc.shape[0]),
+                                     C.c_int(feat.shape[1]), C.c_int64(P), _p(params, _pf), _p(offs, _pi64),
+                                     _p(dims, _pi32), C.c_int(len(ppffcs) - 1), C.c_int(out_dim), _p(grad_out, _pf),
+                                     C.c_int(n_parts), C.c_int64(params.size), _p(gp, _pf), _p(gf, _pf))
+    if rc != 0:
+        raise ValueError(f"orc_pair_mlp_backward failed: {rc}")
+    names = []
+    for i in range(len(ppffcs) - 1):
+        names += [f"res_layers.{i}.{k}" for k in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc0.weight",
+                                                   "fc0.bias")]
+    names += ["final.weight", "final.bias"]
+    grads = {}
+    for nme, o in zip(names, offs):
+        if o >= 0:
+            grads[nme] = gp[o:o + sd[nme].size].reshape(np.shape(sd[nme]))
+    return grads, gf, gp

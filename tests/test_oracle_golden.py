@@ -270,3 +270,20 @@ def test_knn_matches_torch_topk(oracle, golden, tag):
     assert (nb[safe] == z["nbrs_topk"][safe]).all()
     if z["dist"].size:  # the selection itself, on the reference's own distance matrix: exact
         assert (oracle.knn(None, k, dist=z["dist"]) == z["nbrs_topk"]).all()
+
+
+# --------------------------------------------------------------------------- backward of the pair MLP (row f2)
+@pytest.mark.parametrize("tag,ppffcs,out_dim", [("141", [84, 32, 32, 16], 141), ("generic", [44, 24, 24], 10)])
+@pytest.mark.parametrize("n_parts", [None, 1, 3])
+def test_pair_mlp_backward_matches_reference_autograd(oracle, golden, tag, ppffcs, out_dim, n_parts):
+    """oracle/backward_oracle.c vs torch autograd through the reference's forward_with_idx
+    (tests/golden/make_golden_bwd.py).  2e-5 of each gradient's scale: autograd sums in ATen's order."""
+    z = golden(f"bwd_{tag}.npz")
+    grads, gf, _ = oracle.pair_mlp_backward(z["pc"], z["nrm"], z["feat"], z["idxs"], sd_from_npz(z), ppffcs, out_dim,
+                                            z["R"], n_parts)
+    assert set(grads) == {k[5:] for k in z.files if k.startswith("grad.")}
+    for k, g in grads.items():
+        ref = z["grad." + k]
+        assert g.shape == ref.shape
+        np.testing.assert_allclose(g, ref, rtol=0, atol=2e-5 * np.abs(ref).max())
+    np.testing.assert_allclose(gf, z["grad_feat"], rtol=0, atol=2e-5 * np.abs(z["grad_feat"]).max())
