@@ -10,8 +10,10 @@
 
 Under `torch.no_grad()` (inference, nocs/inference.py:179-182) the whole of forward_with_idx -- PPF
 construction, gather/concat, three ResLayers and the final linear -- is one HIP kernel
-(csrc/pair_mlp.hip).  When autograd needs the graph (train.py:66,91) the same module evaluates the
-composite of torch ops instead; the HIP path has no backward yet.
+(csrc/pair_mlp.hip).  When autograd needs the graph (train.py:66,91) and the shape is the standard one
+(ppffcs [84,32,32,16]) the forward is the same HIP kernel wrapped in an autograd.Function whose backward is
+csrc/pair_mlp_bwd.hip (gradients of every parameter and of `feat`); other
+shapes evaluate the composite of torch ops.
 
 `PointEncoder` (SPRIN, models/model.py:36-78) produces the per-point `feat` the pair encoder gathers:
     PointEncoder(k, spfcs, out_dim, num_layers=2, num_nbr_feats=2)
@@ -47,6 +49,56 @@ class ResLayer(nn.Module):
     def forward(self, x):
         x_res = x if self.fc0 is None else self.fc0(x)
         return self.fc2(F.relu(self.fc1(x))) + x_res
+
+
+class _PairMlpFunction(torch.autograd.Function):
+    """forward_with_idx with a HIP backward (train.py:66,91).  Saves only the inputs; the backward kernel
+    recomputes the forward.  Gradients: feat, then the parameters in `flatten_state_dict` order."""
+
+    @staticmethod
+    def forward(ctx, enc, pc, pc_normal, feat, idxs, *params):
+        with torch.no_grad():
+            out = enc._forward_device(pc, pc_normal, feat, idxs)
+        ctx.enc = enc
+        ctx.save_for_backward(pc, pc_normal, feat, idxs, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        enc = ctx.enc
+        pc, nrm, feat, idxs, *params = ctx.saved_tensors
+        dev = pc.device
+        flat = torch.cat([p.detach().reshape(-1).float() for p in params]).contiguous()
+        offs, pos = [], 0
+        it = iter(params)
+        for present in enc._param_presence():
+            if present:
+                offs.append(pos)
+                pos += next(it).numel()
+            else:
+                offs.append(-1)
+        offs_c = (C.c_int64 * len(offs))(*offs)
+        dims = (C.c_int * len(enc.ppffcs))(*enc.ppffcs)
+        L = _lib.lib()
+        P, F_ = idxs.shape[0], feat.shape[1]
+        grad_out = grad_out.detach().float().contiguous()
+        gp = torch.empty_like(flat)
+        gf = torch.zeros((feat.shape[0], F_), dtype=torch.float32, device=dev)
+        need = L.cppf_pair_mlp_backward_workspace_bytes(P, F_, dims, len(enc.ppffcs) - 1, enc.out_dim)
+        ws = workspace(max(int(need), 256), dev, "pair_mlp_bwd")
+        pcc, nrmc, featc = (pc.detach().float().contiguous(), nrm.detach().float().contiguous(),
+                            feat.detach().float().contiguous())
+        with torch.cuda.device(dev):
+            rc = L.cppf_pair_mlp_backward(pcc.data_ptr(), nrmc.data_ptr(), featc.data_ptr(), idxs.data_ptr(),
+                                          1 if idxs.dtype == torch.int64 else 0, flat.data_ptr(), offs_c, pc.shape[0], F_,
+                                          dims, len(enc.ppffcs) - 1, P, enc.out_dim, grad_out.data_ptr(), gp.data_ptr(),
+                                          gf.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr(dev))
+        _lib.check(rc, "cppf_pair_mlp_backward")
+        grads, pos = [], 0
+        for p in params:
+            grads.append(gp[pos:pos + p.numel()].reshape(p.shape))
+            pos += p.numel()
+        return (None, None, None, gf if ctx.needs_input_grad[3] else None, None, *grads)
 
 
 class PointEncoder(nn.Module):
@@ -187,7 +239,12 @@ class PPFEncoder(nn.Module):
     def forward_with_idx(self, pc, pc_normal, feat, idxs):
         idxs = self._as_index_tensor(idxs, pc.device)
         if self._needs_graph(feat):
+            if self._has_device_backward(pc, feat):
+                return _PairMlpFunction.apply(self, pc, pc_normal, feat, idxs, *self._ordered_params())
             return self._composite(pc, pc_normal, feat, idxs)
+        return self._forward_device(pc, pc_normal, feat, idxs)
+
+    def _forward_device(self, pc, pc_normal, feat, idxs):
         pc, pc_normal, feat = self._check_inputs(pc, pc_normal, feat)
         P = idxs.shape[0]
         out = torch.empty((P, self.out_dim), dtype=torch.float32, device=pc.device)
@@ -252,8 +309,27 @@ class PPFEncoder(nn.Module):
             return False
         return feat.requires_grad or any(p.requires_grad for p in self.parameters())
 
+    def _has_device_backward(self, pc, feat):
+        """csrc/pair_mlp_bwd.hip covers ppffcs = [84,32,32,16] (train.py:35) on a HIP device."""
+        return pc.is_cuda and self.ppffcs == [84, 32, 32, 16] and feat.dim() == 2 and feat.shape[1] == 40
+
+    def _param_presence(self):
+        pres = []
+        for layer in self.res_layers:
+            pres += [True, True, True, True, layer.fc0 is not None, layer.fc0 is not None]
+        return pres + [True, True]
+
+    def _ordered_params(self):
+        """parameters in `flatten_state_dict` order: per layer fc1.w, fc1.b, fc2.w, fc2.b, [fc0.w, fc0.b]; final"""
+        ps = []
+        for layer in self.res_layers:
+            ps += [layer.fc1.weight, layer.fc1.bias, layer.fc2.weight, layer.fc2.bias]
+            if layer.fc0 is not None:
+                ps += [layer.fc0.weight, layer.fc0.bias]
+        return ps + [self.final.weight, self.final.bias]
+
     def _composite(self, pc, pc_normal, feat, idxs):
-        """models/model.py:118-137 as torch ops (autograd path)."""
+        """models/model.py:118-137 as torch ops (autograd path for shapes without a device backward)."""
         a, b = idxs[:, 0].long(), idxs[:, 1].long()
         xy = pc[a] - pc[b]
         d = torch.norm(xy, dim=-1)

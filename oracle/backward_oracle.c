@@ -18,7 +18,7 @@
  *       ReLU mask (h > 0), residual: d(x) = d(fc1 path) + d(fc0 path) (or + d(out) for an identity skip);
  *   - per tile and weight W[o][i]:  tile_sum = chain over the tile's pairs j ascending of
  *       fmaf(delta_o(j), x_i(j), .) from 0;  part[w] = part[w] + tile_sum  (biases: plain adds of delta_o(j));
- *   - grad = ((0 + part[0]) + part[1]) + ... ascending.
+ *   - grad = sum over groups of 32 consecutive parts (ascending) of the group's own ascending sum.
  *   grad_feat is a scatter-add (atomics on the device, any order): accumulated here in double over the
  *   per-pair fp32 contributions and compared with a tolerance.
  */
@@ -171,7 +171,11 @@ int orc_pair_mlp_backward(const float* pc, const float* nrm, const float* feat, 
     }
     for (int64_t q = 0; q < n_params; ++q) {
         float acc = 0.f;
-        for (int w = 0; w < n_parts; ++w) acc = acc + parts[(size_t)w * n_params + q];
+        for (int w0 = 0; w0 < n_parts; w0 += 32) {
+            float ga = 0.f;
+            for (int w = w0; w < n_parts && w < w0 + 32; ++w) ga = ga + parts[(size_t)w * n_params + q];
+            acc = acc + ga;
+        }
         grad_params[q] = acc;
     }
     for (size_t q = 0; q < (size_t)N * F; ++q) grad_feat[q] = (float)gf[q];

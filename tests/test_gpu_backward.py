@@ -1,0 +1,115 @@
+"""Backward of the pair encoder on the MI355X through the C ABI: parameter gradients
+bit-exact against oracle/backward_oracle.c (same summation spec), everything within 2e-5 of the gradients torch
+autograd computes through the reference module (tests/golden/bwd_*.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import sd_from_npz
+from cppf_amd.models.model import PPFEncoder
+
+pytestmark = pytest.mark.gpu
+PPFFCS = [84, 32, 32, 16]
+
+
+def _flat_grads(enc):
+    return torch.cat([p.grad.reshape(-1) for p in enc._ordered_params()]).cpu().numpy()
+
+
+def _run(enc, dev, pc, nrm, feat, idxs, R):
+    enc.zero_grad()
+    f = torch.from_numpy(feat).to(dev).requires_grad_(True)
+    logits = enc.forward_with_idx(torch.from_numpy(pc).to(dev), torch.from_numpy(nrm).to(dev), f, idxs)
+    (logits * torch.from_numpy(R).to(dev)).sum().backward()
+    return logits.detach().cpu().numpy(), f.grad.cpu().numpy()
+
+
+def test_backward_matches_reference_autograd_and_oracle(dev, oracle, golden):
+    z = golden("bwd_141.npz")
+    sd = sd_from_npz(z)
+    enc = PPFEncoder(PPFFCS, 141)
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    enc = enc.to(dev).train()
+    logits, gf = _run(enc, dev, z["pc"], z["nrm"], z["feat"], torch.from_numpy(z["idxs"]).to(dev), z["R"])
+    np.testing.assert_allclose(logits, z["logits"], atol=2e-6, rtol=0)                      # forward = the HIP kernel
+    grads_o, gf_o, flat_o = oracle.pair_mlp_backward(z["pc"], z["nrm"], z["feat"], z["idxs"], sd, PPFFCS, 141, z["R"])
+    assert np.array_equal(_flat_grads(enc), flat_o)                                          # deterministic spec: bit-exact
+    for name, p in enc.named_parameters():
+        ref = z["grad." + name]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=0, atol=2e-5 * np.abs(ref).max())
+    np.testing.assert_allclose(gf, z["grad_feat"], rtol=0, atol=2e-5 * np.abs(z["grad_feat"]).max())
+    np.testing.assert_allclose(gf, gf_o, rtol=0, atol=2e-6 * np.abs(gf_o).max())             # fp32 atomics vs fp64 sums
+
+
+@pytest.mark.parametrize("n,p,out_dim,i32", [(2048, 20000, 141, False), (1500, 70001, 141, True), (512, 4097, 9, False)])
+def test_backward_bit_exact_vs_oracle_at_size(dev, oracle, n, p, out_dim, i32):
+    """more tiles than partial accumulators (70 001 pairs -> 1 094 tiles on 1 024 parts), ragged last tile,
+    int32 indices, the notebook's out_dim = 9"""
+    rng = np.random.default_rng(p)
+    pc = rng.normal(0, 0.1, (n, 3)).astype(np.float32)
+    nrm = rng.normal(0, 1, (n, 3)); nrm = (nrm / np.linalg.norm(nrm, axis=-1, keepdims=True)).astype(np.float32)
+    feat = rng.normal(0, 1, (n, 40)).astype(np.float32)
+    idxs = rng.integers(0, n, (p, 2)).astype(np.int64)
+    R = rng.normal(0, 1, (p, out_dim)).astype(np.float32)
+    torch.manual_seed(p)
+    enc = PPFEncoder(PPFFCS, out_dim)
+    sd = {k: v.detach().numpy().copy() for k, v in enc.state_dict().items()}
+    enc = enc.to(dev).train()
+    it = torch.from_numpy(idxs.astype(np.int32) if i32 else idxs).to(dev)
+    _, gf = _run(enc, dev, pc, nrm, feat, it, R)
+    _, gf_o, flat_o = oracle.pair_mlp_backward(pc, nrm, feat, idxs, sd, PPFFCS, out_dim, R)
+    assert np.array_equal(_flat_grads(enc), flat_o)
+    np.testing.assert_allclose(gf, gf_o, rtol=0, atol=1e-5 * np.abs(gf_o).max())
+    # and against torch's own autograd through the composite of the same module, on the device
+    enc2 = PPFEncoder(PPFFCS, out_dim)
+    enc2.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    enc2 = enc2.to(dev)
+    f2 = torch.from_numpy(feat).to(dev).requires_grad_(True)
+    out2 = enc2._composite(torch.from_numpy(pc).to(dev), torch.from_numpy(nrm).to(dev), f2, it)
+    (out2 * torch.from_numpy(R).to(dev)).sum().backward()
+    for a, b in zip(enc._ordered_params(), enc2._ordered_params()):
+        np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.cpu().numpy(), rtol=0,
+                                   atol=1e-4 * float(b.grad.abs().max()))
+    np.testing.assert_allclose(gf, f2.grad.cpu().numpy(), rtol=0, atol=1e-4 * float(f2.grad.abs().max()))
+
+
+def test_training_step_like_train_py(dev):
+    """train.py:53-93 in miniature: CUDA LongTensor pairs, Adam over both encoders, loss.backward() through the HIP
+    backward of the pair encoder and the torch composite of the point encoder; the loss goes down."""
+    from cppf_amd.models.model import PointEncoder
+    import cppf_amd.synthetic as syn
+    ob = syn.make_object("bottle", 512, 3)
+    pcs = torch.from_numpy(ob["pc"][None]).to(dev)
+    nrms = torch.from_numpy(ob["normals"][None]).to(dev)
+    torch.manual_seed(0)
+    point_encoder = PointEncoder(k=30, spfcs=[32, 64, 32, 32], num_layers=1, out_dim=32).to(dev)
+    ppf_encoder = PPFEncoder(PPFFCS, 141).to(dev)
+    opt = torch.optim.Adam([*point_encoder.parameters(), *ppf_encoder.parameters()], lr=1e-3)
+    idxs = torch.from_numpy(syn.make_pairs(512, 16, 3)).to(dev)
+    target = torch.randint(0, 32, (idxs.shape[0],), device=dev)
+    losses = []
+    for _ in range(8):
+        opt.zero_grad()
+        with torch.no_grad():
+            dist = torch.cdist(pcs, pcs)
+        sprin_feat = point_encoder(pcs, nrms, dist)
+        preds = ppf_encoder(pcs, nrms, sprin_feat, idxs=idxs)
+        loss = torch.nn.functional.cross_entropy(preds[0, :, :32], target)
+        loss.backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in ppf_encoder.parameters())
+        assert all(p.grad is not None for p in point_encoder.parameters())
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0]
+
+
+def test_other_shapes_use_the_composite(dev, golden):
+    z = golden("bwd_generic.npz")
+    enc = PPFEncoder([44, 24, 24], 10)
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in sd_from_npz(z).items()})
+    enc = enc.to(dev)
+    _, gf = _run(enc, dev, z["pc"], z["nrm"], z["feat"], torch.from_numpy(z["idxs"]).to(dev), z["R"])
+    for name, p in enc.named_parameters():
+        ref = z["grad." + name]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=0, atol=5e-5 * np.abs(ref).max())
+    np.testing.assert_allclose(gf, z["grad_feat"], rtol=0, atol=5e-5 * np.abs(z["grad_feat"]).max())
