@@ -1,0 +1,25 @@
+#!/bin/bash
+# Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
+#   1. --kernel-trace --stats of the default benchmark command  -> gpurun_out/prof/kernel_trace_stats.txt
+#   2. PMC passes, one counter group per pass, no trace domains -> gpurun_out/prof/pmc_counters.txt
+#   3. the HBM-traffic summary bench.py reads                   -> gpurun_out/prof/pmc_traffic.json
+# Copy the three files into profiles/ (renamed r<round>_*) to have them judged.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt -- $BENCH > $OUT/bench_under_trace.log 2>&1
+python $R/profiles/kstats.py $(find /tmp/kt -name '*.db' | head -1) > $OUT/kernel_trace_stats.txt 2>&1
+: > $OUT/pmc_counters.txt
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" \
+           "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" \
+           "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAVE_CYCLES"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc$i -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /tmp/pmc$i.log 2>&1
+  f=$(find /tmp/pmc$i -name '*counter_collection.csv' | head -1)
+  python $R/profiles/pmcstats.py $f >> $OUT/pmc_counters.txt
+done
+python $R/profiles/make_traffic_json.py $OUT/pmc_counters.txt > $OUT/pmc_traffic.json
+tail -3 $OUT/bench_under_trace.log | cut -c1-300
