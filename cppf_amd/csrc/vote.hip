@@ -32,7 +32,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 static inline int tri(int n) { return n * (n + 1) / 2; }
 
 // ----------------------------------------------------------------------------- vote plan
-#define VOTE_TILE_FLOATS 31488  // 123 KiB of the CU's 160 KiB LDS for the grid tile (8 KiB rings, 8 KiB carry log, 21 KiB table)
+#define VOTE_TILE_FLOATS 29440  // 115 KiB of the CU's 160 KiB LDS for the grid tile (8 KiB rings, 8 KiB carry log, 8 KiB pair queues, 21 KiB table)
 #define VOTE_TAB_LDS_MAX 2628   // (cos,sin) pairs kept in LDS (n_rots <= 72); else computed per sample
 #define VOTE_MAX_TILES 16       // beyond this, L2 atomics beat re-walking the pairs once per tile
 #define VOTE_THREADS 1024
@@ -137,6 +137,7 @@ extern "C" size_t cppf_vote_workspace_bytes(int64_t n_ppfs, int n_rots, int gx, 
 //           frame with ds_bpermute, and does the exact work of the reference: offset, the three
 //           correctly rounded divisions, the bound tests, trilinear weights, 8 atomics.
 #define VOTE_RING 256  // >= 63 queued + 128 pushed per trip
+#define VOTE_PAIRQ 128  // per-wave queue of culled pair offsets: <= 63 waiting + 64 pushed
 #define VOTE_CARRY_CAP 2048
 struct VoteArgs {
     const float* points;
@@ -254,10 +255,12 @@ template <bool TILED, bool TAB_LDS>
 __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    // LDS: [rings: 16 waves x 256 x u16 = 8 KiB][carry log 8 KiB][ctrl 64 B][rotation table (+1 spare)][tile]
+    // LDS: [rings: 16 waves x 256 x u16 = 8 KiB][carry log 8 KiB][pair queues: 16 x 128 x u32 = 8 KiB][ctrl 64 B]
+    //      [rotation table (+1 spare)][tile]
     uint16_t* ring = reinterpret_cast<uint16_t*>(lds) + (threadIdx.x >> 6) * VOTE_RING;
     uint32_t* carry_log = reinterpret_cast<uint32_t*>(lds) + (VOTE_THREADS / 64) * VOTE_RING / 2;
-    int* ctrl = reinterpret_cast<int*>(carry_log + VOTE_CARRY_CAP);  // [0] carry count, [1] max(prob) bits, [2] bad probs
+    uint32_t* pairq = carry_log + VOTE_CARRY_CAP + (threadIdx.x >> 6) * VOTE_PAIRQ;
+    int* ctrl = reinterpret_cast<int*>(carry_log + VOTE_CARRY_CAP + (VOTE_THREADS / 64) * VOTE_PAIRQ);  // [0] carry count, [1] max(prob) bits, [2] bad probs
     float2* ltab = reinterpret_cast<float2*>(ctrl + 16);
     float* tile = reinterpret_cast<float*>(ltab + (TAB_LDS ? A.tab_entries + 2 : 0));  // +2: spare entry, 16-B alignment
     const int tid = threadIdx.x, lane = tid & 63;
@@ -336,11 +339,11 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
     const float bly = fmaxf(0.01f, (float)(y0 - 1)), bhy = fminf((float)gy - 1.01f, (float)(y0 + ty));
     const float blz = 0.01f, bhz = (float)gz - 1.01f;
 
-    for (int64_t pb = p_begin; pb < p_end; pb += p_step) {  // uniform trip count for the whole wave
-        const int64_t p = pb + tid;
+    // one pair per lane (`valid` lanes), all of its rotations: screen, queue, deposit
+    auto process = [&](const int64_t p, const bool valid) {
         PairFrame F;
         F.cc = {0.f, 0.f, 0.f}; F.x = F.cc; F.y = F.cc; F.prob = 0.f; F.n = 0;
-        if (p < p_end) {
+        if (valid) {
             const float2 o = reinterpret_cast<const float2*>(A.outputs)[p];
             const int2 ij = reinterpret_cast<const int2*>(A.point_idxs)[p];
             f3 a, ab, xd;
@@ -403,6 +406,60 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
             vote_pop<TILED, TAB_LDS>(VT, F, cr, ltab, ring, qhead, lane, qtail - qhead);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
+
+    if (!TILED) {
+        for (int64_t pb = p_begin; pb < p_end; pb += p_step) process(pb + tid, pb + tid < p_end);  // uniform trip count per wave
+    } else {
+        // Pair culling: a pair whose whole vote circle misses this tile's acceptance box is dropped before the
+        // rotation loop (with many tiles, or outputs that point away from the object, that is most pairs), and the
+        // survivors are compacted through a per-wave LDS queue so that the rotation loop runs with full lanes.
+        // The circle of pair (a, b) has centre cc = a - u*mu, radius |nu| and lies in the plane normal to u, so its
+        // extent along axis k is |nu|*sqrt(1 - u_k^2); the test uses approximate arithmetic and a slack far above
+        // both its own error and the widening of the rotation screen, so no depositing pair is ever dropped.
+        const int wv = tid >> 6;
+        int qn = 0;
+        for (int64_t pb = p_begin + wv * 64;; pb += VOTE_THREADS) {
+            const bool more = pb < p_end;
+            if (more) {
+                const int64_t p = pb + lane;
+                bool pass = false;
+                if (p < p_end) {
+                    const float2 o = reinterpret_cast<const float2*>(A.outputs)[p];
+                    const int2 ij = reinterpret_cast<const int2*>(A.point_idxs)[p];
+                    const f3 a = ld3(A.points, ij.x), b = ld3(A.points, ij.y);
+                    const f3 d = sub3(a, b);
+                    const float L = sqrtf(dot3(d, d));
+                    const float inv = __builtin_amdgcn_rcpf(L + 1e-7f);
+                    const f3 u = scl3(d, inv);
+                    const f3 cc = sub3(a, scl3(u, o.x));
+                    const float R = fabsf(o.y) * rinv;
+                    const float ex_ = R * __builtin_amdgcn_sqrtf(fmaxf(0.f, 1.f - u.x * u.x));
+                    const float ey_ = R * __builtin_amdgcn_sqrtf(fmaxf(0.f, 1.f - u.y * u.y));
+                    const float ez_ = R * __builtin_amdgcn_sqrtf(fmaxf(0.f, 1.f - u.z * u.z));
+                    const float sl = fmaf(R, 1.1e-3f, 4e-3f);
+                    const float sx = sl + 8e-6f * (fabsf(cc.x) + fabsf(cr.x)) * rinv, sy = sl + 8e-6f * (fabsf(cc.y) + fabsf(cr.y)) * rinv,
+                                sz = sl + 8e-6f * (fabsf(cc.z) + fabsf(cr.z)) * rinv;
+                    const float qx = (cc.x - cr.x) * rinv, qy = (cc.y - cr.y) * rinv, qz = (cc.z - cr.z) * rinv;
+                    pass = (L >= 9e-8f) & (!A.adaptive | (R >= 0.15f)) &
+                           (qx + ex_ + sx >= blx) & (qx - ex_ - sx < bhx) & (qy + ey_ + sy >= bly) & (qy - ey_ - sy < bhy) &
+                           (qz + ez_ + sz >= blz) & (qz - ez_ - sz < bhz);
+                }
+                const unsigned long long m = __ballot(pass);
+                if (pass)
+                    pairq[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] =
+                        (uint32_t)(p - p_begin);
+                qn += __popcll(m);
+            }
+            while (qn >= 64 || (!more && qn > 0)) {
+                const int take = qn < 64 ? qn : 64;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const uint32_t off = lane < take ? pairq[qn - take + lane] : 0u;
+                qn -= take;
+                process(p_begin + off, lane < take);
+            }
+            if (!more) break;
+        }
     }
 
     if (TILED) {
@@ -508,7 +565,7 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void reduce_argmax_kernel(float* _
 
 __global__ void zero_u64x2_kernel(unsigned long long* p) { p[0] = 0ull; p[1] = 0ull; }
 
-#define VOTE_LDS_HEAD ((VOTE_THREADS / 64) * VOTE_RING * 2 + VOTE_CARRY_CAP * 4 + 64)
+#define VOTE_LDS_HEAD ((VOTE_THREADS / 64) * VOTE_RING * 2 + VOTE_CARRY_CAP * 4 + (VOTE_THREADS / 64) * VOTE_PAIRQ * 4 + 64)
 
 static int vote_impl(const float* points, const float* outputs, const float* probs, const int32_t* point_idxs,
                      float* grid_obj, const float* corner, float res, int64_t n_points, int64_t n_ppfs, int n_rots,
