@@ -168,3 +168,47 @@ def test_missing_library_is_a_loud_error(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_SO", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.CppfError):
         _lib.lib()
+
+
+def test_point_encoder_and_backward_abi_without_a_device(golden):
+    """Rows f1/f2: workspace queries, argument validation (no HIP call is reached), packing, module surface."""
+    from cppf_amd import _lib
+    from cppf_amd.models.model import PointEncoder
+    from cppf_amd.models.sprin import pack_point_encoder
+    L = _lib.lib()
+    hid = (C.c_int * 4)(32, 64, 32, 32)
+    assert L.cppf_point_encoder_packed_floats(hid, 4, 32, 2, 32, 8, 1) == 9256          # parameter count of train.py:34
+    assert L.cppf_point_encoder_workspace_bytes(4096, 32, 8, 1) == 256
+    assert L.cppf_point_encoder_workspace_bytes(4096, 32, 8, 2) == 256 + 4096 * 40 * 4
+    assert L.cppf_knn(None, None, 10, 3, None, None) == -1                               # no points, no matrix
+    assert L.cppf_knn(None, None, 0, 3, None, None) == 0                                 # empty cloud: legal no-op
+    assert L.cppf_knn(None, None, 10, 0, None, None) == -1
+    bad = (C.c_int * 2)(16, 24)
+    one = C.c_void_p(8)                                                                  # non-null dummy, never dereferenced
+    assert L.cppf_point_encoder_forward(one, one, one, 10, 3, one, bad, 2, 32, 2, 32, 8, 1, one, one, 1 << 20, None) == -3
+    assert L.cppf_point_encoder_forward(one, one, one, 10, 3, one, hid, 4, 32, 2, 32, 8, 1, one, None, 0, None) == -2
+    assert L.cppf_point_encoder_forward(one, one, one, 100, 65, one, hid, 4, 32, 2, 32, 8, 1, one, one, 1 << 20, None) == -3
+    dims = (C.c_int * 4)(84, 32, 32, 16)
+    assert L.cppf_pair_mlp_backward_workspace_bytes(200000, 40, dims, 3, 141) == 1024 * 12333 * 4
+    assert L.cppf_pair_mlp_backward_workspace_bytes(130, 40, dims, 3, 141) == 3 * 12333 * 4
+    other = (C.c_int * 3)(44, 24, 24)
+    assert L.cppf_pair_mlp_backward_workspace_bytes(130, 20, other, 2, 10) == 0
+    offs = (C.c_int64 * 20)(*range(20))
+    assert L.cppf_pair_mlp_backward(one, one, one, one, 1, one, offs, 10, 20, other, 2, 5, 10, one, one, one, one, 1 << 20,
+                                    None) == -3
+    assert L.cppf_pair_mlp_backward(one, one, one, one, 1, one, offs, 10, 40, dims, 3, 5, 141, one, one, one, None, 0,
+                                    None) == -2
+    # module surface: the reference checkpoint layout loads, and the CPU autograd composite equals the reference
+    z = golden("sprin_l1.npz")
+    sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}
+    enc = PointEncoder(k=60, spfcs=[32, 64, 32, 32], num_layers=1, out_dim=32)
+    assert sorted(enc.state_dict().keys()) == sorted(sd.keys())
+    enc.load_state_dict(sd)
+    pc, nrm = torch.from_numpy(z["pc"][None]), torch.from_numpy(z["nrm"][None])
+    out = enc(pc, nrm, torch.cdist(pc, pc))                                              # grad enabled -> composite
+    np.testing.assert_allclose(out[0].detach().numpy(), z["out"], atol=1e-6)
+    with torch.no_grad(), pytest.raises(_lib.CppfError):
+        enc(pc, nrm, torch.cdist(pc, pc))                                                # no CPU fallback for inference
+    packed, desc = pack_point_encoder({k: v.numpy() for k, v in sd.items()}, 1)
+    assert packed.size == 9256 and desc == dict(hidden=[32, 64, 32, 32], rank=32, n_nbr_feats=2, n_out=32, n_glob=8,
+                                                num_layers=1)
