@@ -15,6 +15,7 @@
 // through the scalar cache as SGPR operands of v_fma_f32.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include "../../include/cppf.h"
 #include "cppf_math.h"
 
@@ -190,72 +191,106 @@ constexpr int SP_WAVES = 4;   // points per workgroup
 constexpr int SP_RANK = 32, SP_NOUT = 32;
 constexpr int SP_KSTRIDE = SP_RANK + 1;  // kern[j][r] row stride in LDS (odd: conflict-free column walks)
 
-template <int IN, int OUT>
-__device__ __forceinline__ void sp_linear(const float* __restrict__ W, const float* __restrict__ b, const float (&x)[IN],
-                                          float (&y)[OUT])
+// ---- kernel-MLP on v_mfma_f32_16x16x4_f32, transposed: D[out][row] = W[out][k] * X^T[k][row].
+// One instruction covers 16 outputs x 16 neighbour rows x 4 inputs; lane l = (j = l & 15 -> row, g = l >> 4).
+// A operand = one weight from the lane-ordered LDS image, B operand = one activation register, D = f32x4 =
+// outputs 16*ob + 4*g + r of row j.  The D layout of a layer is the B layout of the next one if that layer walks
+// its inputs as k(s, g) = 16*(s/4) + 4*g + s%4, so the five layers chain with no data movement (same scheme as
+// csrc/pair_mlp.hip); the exact-fp32 MFMA reproduces the oracle's fmaf chain in that order (order = 1).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int SPW_L1 = 0;                         // [2 ob][2 s][64]   (inputs 6, 7 are zero columns)
+constexpr int SPW_L2 = SPW_L1 + 2 * 2 * 64;       // [4 ob][8 s][64]
+constexpr int SPW_L3 = SPW_L2 + 4 * 8 * 64;       // [2 ob][16 s][64]
+constexpr int SPW_L4 = SPW_L3 + 2 * 16 * 64;      // [2 ob][8 s][64]
+constexpr int SPW_L5 = SPW_L4 + 2 * 8 * 64;       // [2 ob][8 s][64]
+constexpr int SPW_VEC = SPW_L5 + 2 * 8 * 64;      // bias/gamma/beta in natural order: b1 g1 be1 b2 g2 be2 b3 g3 be3 b4 g4 be4 b5
+constexpr int SPW_B1 = SPW_VEC, SPW_B2 = SPW_B1 + 96, SPW_B3 = SPW_B2 + 192, SPW_B4 = SPW_B3 + 96, SPW_B5 = SPW_B4 + 96;
+constexpr int SPW_FLOATS = SPW_B5 + 32;           // 6 912 floats = 27 KB, one copy per workgroup
+constexpr int SP_NAT_KERNEL = 6 * 32 + 3 * 32 + 32 * 64 + 3 * 64 + 64 * 32 + 3 * 32 + 32 * 32 + 3 * 32 + 32 * 32 + 32;  // natural floats
+
+__device__ __forceinline__ float sp_xor16(float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401f)); }
+__device__ __forceinline__ float sp_xor32(float v, int lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_int(v))); }
+
+template <int NIB, int NOB>   // inputs 16*NIB (held as NIB f32x4), outputs 16*NOB
+__device__ __forceinline__ void sp_mfma_layer(const float* __restrict__ Wl, const float* __restrict__ bias, const f32x4 (&x)[NIB],
+                                              f32x4 (&y)[NOB], int lane, int g)
 {
 #pragma unroll
-    for (int o = 0; o < OUT; ++o) {
-        float acc = b[o];
+    for (int ob = 0; ob < NOB; ++ob) y[ob] = *reinterpret_cast<const f32x4*>(bias + 16 * ob + 4 * g);
 #pragma unroll
-        for (int k = 0; k < IN; ++k) acc = fmaf(W[o * IN + k], x[k], acc);
-        y[o] = acc;
+    for (int s = 0; s < 4 * NIB; ++s) {
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+            y[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wl[(ob * 4 * NIB + s) * 64 + lane], x[s / 4][s % 4], y[ob], 0, 0, 0);
     }
 }
-// nn.LayerNorm (eps 1e-5, affine) + ReLU, lane-local (oracle/sprin_oracle.c:layer_norm)
-template <int H>
-__device__ __forceinline__ void sp_ln_relu(const float (&y)[H], const float* __restrict__ g, const float* __restrict__ b,
-                                           float (&x)[H])
+// LayerNorm (eps 1e-5, affine) + ReLU on a row spread over the 4 lanes g: per-lane partial sums in (ob, r) order,
+// combined as (p0 + p1) + (p2 + p3) through the LDS crossbar (oracle/sprin_oracle.c:layer_norm_ord)
+template <int NOB>
+__device__ __forceinline__ void sp_ln_relu4(f32x4 (&y)[NOB], const float* __restrict__ gamma, const float* __restrict__ beta, int lane,
+                                            int g)
 {
-    float s = 0.f;
+    constexpr float H = 16.f * NOB;
+    float p = 0.f;
 #pragma unroll
-    for (int o = 0; o < H; ++o) s = s + y[o];
-    const float mean = s / (float)H;
-    float v = 0.f;
+    for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
-    for (int o = 0; o < H; ++o) { const float d = y[o] - mean; v = v + d * d; }
-    const float inv = 1.0f / sqrtf(v / (float)H + 1e-5f);
+        for (int r = 0; r < 4; ++r) p = p + y[ob][r];
+    p = p + sp_xor16(p);
+    p = p + sp_xor32(p, lane);
+    const float mean = p / H;
+    float q = 0.f;
 #pragma unroll
-    for (int o = 0; o < H; ++o) {
-        const float z = ((y[o] - mean) * inv) * g[o] + b[o];
-        x[o] = z > 0.f ? z : 0.f;
+    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float d = y[ob][r] - mean; q = q + d * d; }
+    q = q + sp_xor16(q);
+    q = q + sp_xor32(q, lane);
+    const float inv = 1.0f / sqrtf(q / H + 1e-5f);
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 16 * ob + 4 * g);
+        const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + 16 * ob + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float z = ((y[ob][r] - mean) * inv) * gm[r] + bt[r];
+            y[ob][r] = z > 0.f ? z : 0.f;
+        }
     }
-}
-template <int IN, int H>
-__device__ __forceinline__ const float* sp_hidden(const float* __restrict__ p, const float (&x)[IN], float (&xo)[H])
-{
-    float y[H];
-    sp_linear<IN, H>(p, p + H * IN, x, y);
-    p += H * IN + H;
-    sp_ln_relu<H>(y, p, p + H, xo);
-    return p + 2 * H;
 }
 
 __device__ __forceinline__ float norm3(float x, float y, float z) { return sqrtf((x * x + y * y) + z * z); }
+
+__host__ __device__ constexpr int sp_per_wave(int n_in) { return 64 * SP_KSTRIDE + 64 * n_in + SP_RANK * n_in + 64 * 3 + SP_NOUT + 64 * 8; }
 
 struct ConvArgs {
     const float* pc;
     const float* nrm;
     const float* feat_in;   // null for the first layer, else [N][n_in]
     const int32_t* nbrs;    // [N][k]
-    const float* params;    // this layer's packed parameters
+    const float* params;    // this layer's parameters, natural layout (outnet part is used from here)
+    const float* wimg;      // this layer's MFMA image (SPW_FLOATS), cppf_point_encoder_pack
     float* out;             // [N][out_stride], columns 0..31 written
     int N, k, n_in, out_stride;
 };
 
-// hidden = {32, 64, 32, 32}, rank 32, n_out 32 (train.py:34).  Dynamic LDS per wave:
-//   kern[64][33] | nf[64][n_in] | contracted[32*n_in] | r[64][3] | y[32]
+// hidden = {32, 64, 32, 32}, rank 32, n_out 32 (train.py:34).  Dynamic LDS: the workgroup's weight image
+// (SPW_FLOATS), then per wave  kern[64][33] | nf[64][n_in] | contracted[32*n_in] | r[64][3] | y[32] | x6[64][8]
 __global__ __launch_bounds__(SP_WAVES * 64) void sprin_conv_kernel(ConvArgs A)
 {
-    extern __shared__ float sp_lds[];
+    extern __shared__ __attribute__((aligned(16))) float sp_lds[];
     const int w = threadIdx.x >> 6, lane = lane_id();
     const int n_in = A.n_in, k = A.k;
-    const int per_wave = 64 * SP_KSTRIDE + 64 * n_in + SP_RANK * n_in + 64 * 3 + SP_NOUT;
-    float* kern = sp_lds + (size_t)w * per_wave;
+    const int per_wave = sp_per_wave(n_in);
+    float* Wl = sp_lds;                                   // 16-byte aligned image
+    float* kern = sp_lds + SPW_FLOATS + (size_t)w * per_wave;
     float* nf = kern + 64 * SP_KSTRIDE;
     float* contracted = nf + 64 * n_in;
     float* rr = contracted + SP_RANK * n_in;
     float* yv = rr + 64 * 3;
+    float* x6l = yv + SP_NOUT;
+    for (int i = threadIdx.x; i < SPW_FLOATS / 4; i += SP_WAVES * 64)
+        reinterpret_cast<f32x4*>(Wl)[i] = reinterpret_cast<const f32x4*>(A.wimg)[i];
     const int n = blockIdx.x * SP_WAVES + w;
     const bool live = n < A.N;
     const int nc = live ? n : A.N - 1;
@@ -288,19 +323,40 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sprin_conv_kernel(ConvArgs A)
         nf[lane * 2] = l2n;                                         // |p_j - p_i|     (models/model.py:50-51)
         nf[lane * 2 + 1] = (nax * nsx + nay * nsy) + naz * nsz;     // n_j . n_i       (models/model.py:53-54)
     }
-    // conv_kernel(6, 32, 32, 64, 32, 32) (models/sprin.py:64-72): lane-local, weights via scalar loads
-    const float* p = A.params;
-    {
-        float a[32], b[64], c[32], d[32], kr[SP_RANK];
-        p = sp_hidden<6, 32>(p, x6, a);
-        p = sp_hidden<32, 64>(p, a, b);
-        p = sp_hidden<64, 32>(p, b, c);
-        p = sp_hidden<32, 32>(p, c, d);
-        sp_linear<32, SP_RANK>(p, p + SP_RANK * 32, d, kr);
-        p += SP_RANK * 32 + SP_RANK;
 #pragma unroll
-        for (int r = 0; r < SP_RANK; ++r) kern[lane * SP_KSTRIDE + r] = kr[r];
+    for (int c = 0; c < 6; ++c) x6l[lane * 8 + c] = x6[c];
+    x6l[lane * 8 + 6] = 0.f; x6l[lane * 8 + 7] = 0.f;
+    __syncthreads();
+    // conv_kernel(6, 32, 32, 64, 32, 32) (models/sprin.py:64-72) on MFMA, 16 neighbour rows at a time
+    {
+        const int j = lane & 15, g = lane >> 4;
+#pragma unroll 1
+        for (int rb = 0; rb < 4; ++rb) {
+            f32x4 a1[2], a2[4], a3[2], a4[2], kr[2];
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) a1[ob] = *reinterpret_cast<const f32x4*>(Wl + SPW_B1 + 16 * ob + 4 * g);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const float bx = x6l[(16 * rb + j) * 8 + 4 * s + g];
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob)
+                    a1[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wl[SPW_L1 + (ob * 2 + s) * 64 + lane], bx, a1[ob], 0, 0, 0);
+            }
+            sp_ln_relu4<2>(a1, Wl + SPW_B1 + 32, Wl + SPW_B1 + 64, lane, g);
+            sp_mfma_layer<2, 4>(Wl + SPW_L2, Wl + SPW_B2, a1, a2, lane, g);
+            sp_ln_relu4<4>(a2, Wl + SPW_B2 + 64, Wl + SPW_B2 + 128, lane, g);
+            sp_mfma_layer<4, 2>(Wl + SPW_L3, Wl + SPW_B3, a2, a3, lane, g);
+            sp_ln_relu4<2>(a3, Wl + SPW_B3 + 32, Wl + SPW_B3 + 64, lane, g);
+            sp_mfma_layer<2, 2>(Wl + SPW_L4, Wl + SPW_B4, a3, a4, lane, g);
+            sp_ln_relu4<2>(a4, Wl + SPW_B4 + 32, Wl + SPW_B4 + 64, lane, g);
+            sp_mfma_layer<2, 2>(Wl + SPW_L5, Wl + SPW_B5, a4, kr, lane, g);
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) kern[(16 * rb + j) * SP_KSTRIDE + 16 * ob + 4 * g + r] = kr[ob][r];
+        }
     }
+    const float* p = A.params + SP_NAT_KERNEL;   // outnet parameters follow the kernel-MLP in the natural layout
     __syncthreads();
     // einsum("bnkr,bnki->bnri") (models/sprin.py:99): contracted[r*n_in + i], sequential over neighbours
     const int C = SP_RANK * n_in;
@@ -388,15 +444,71 @@ int cppf_knn(const float* pc, const float* dist, int n_points, int k, int32_t* n
     return (int)hipGetLastError();
 }
 
-size_t cppf_point_encoder_packed_floats(const int32_t* hidden, int n_hidden, int rank, int n_nbr_feats, int n_out,
-                                        int n_glob, int num_layers)
+static bool sp_std_shape(const int32_t* hidden, int n_hidden, int rank, int n_nbr_feats, int n_out, int n_glob)
 {
-    if (!hidden || n_hidden <= 0 || num_layers <= 0) return 0;
+    return n_hidden == 4 && hidden[0] == 32 && hidden[1] == 64 && hidden[2] == 32 && hidden[3] == 32 && rank == SP_RANK &&
+           n_out == SP_NOUT && n_glob >= 1 && n_glob <= 32 && n_nbr_feats == 2;
+}
+static size_t sp_natural_floats(const int32_t* hidden, int n_hidden, int rank, int n_nbr_feats, int n_out, int n_glob,
+                                int num_layers)
+{
     size_t n = 0;
     for (int l = 0; l < num_layers; ++l)
         n += (size_t)conv_params(hidden, n_hidden, rank, l == 0 ? n_nbr_feats : n_out + n_glob, n_out) +
              (size_t)n_glob * n_out + n_glob;
     return n;
+}
+
+size_t cppf_point_encoder_packed_floats(const int32_t* hidden, int n_hidden, int rank, int n_nbr_feats, int n_out,
+                                        int n_glob, int num_layers)
+{
+    if (!hidden || n_hidden <= 0 || num_layers <= 0) return 0;
+    size_t n = sp_natural_floats(hidden, n_hidden, rank, n_nbr_feats, n_out, n_glob, num_layers);
+    if (sp_std_shape(hidden, n_hidden, rank, n_nbr_feats, n_out, n_glob)) n += (size_t)num_layers * SPW_FLOATS;
+    return n;
+}
+
+// natural parameters (host) -> device image (host buffer): the natural block verbatim, then one lane-ordered MFMA
+// image of the kernel-MLP per layer
+int cppf_point_encoder_pack(const float* natural, const int32_t* hidden, int n_hidden, int rank, int n_nbr_feats,
+                            int n_out, int n_glob, int num_layers, float* out)
+{
+    if (!natural || !hidden || !out || n_hidden <= 0 || num_layers <= 0) return CPPF_EINVAL;
+    const size_t nat = sp_natural_floats(hidden, n_hidden, rank, n_nbr_feats, n_out, n_glob, num_layers);
+    memcpy(out, natural, nat * sizeof(float));
+    if (!sp_std_shape(hidden, n_hidden, rank, n_nbr_feats, n_out, n_glob)) return 0;
+    const float* p = natural;
+    for (int l = 0; l < num_layers; ++l) {
+        const int n_in = l == 0 ? n_nbr_feats : n_out + n_glob;
+        float* img = out + nat + (size_t)l * SPW_FLOATS;
+        const float* q = p;
+        // layer 1: k = 4*s + g, inputs 6 and 7 are zero columns
+        for (int ob = 0; ob < 2; ++ob)
+            for (int s_ = 0; s_ < 2; ++s_)
+                for (int ln = 0; ln < 64; ++ln) {
+                    const int o = 16 * ob + (ln & 15), k = 4 * s_ + (ln >> 4);
+                    img[SPW_L1 + (ob * 2 + s_) * 64 + ln] = k < 6 ? q[o * 6 + k] : 0.f;
+                }
+        q += 32 * 6;
+        memcpy(img + SPW_B1, q, 96 * sizeof(float)); q += 96;
+        // layers 2..5: k(s, g) = 16*(s/4) + 4*g + s%4
+        const int off[4] = {SPW_L2, SPW_L3, SPW_L4, SPW_L5}, in_[4] = {32, 64, 32, 32}, out_[4] = {64, 32, 32, 32};
+        const int vec[4] = {SPW_B2, SPW_B3, SPW_B4, SPW_B5};
+        for (int L = 0; L < 4; ++L) {
+            const int S = in_[L] / 4;
+            for (int ob = 0; ob < out_[L] / 16; ++ob)
+                for (int s_ = 0; s_ < S; ++s_)
+                    for (int ln = 0; ln < 64; ++ln) {
+                        const int o = 16 * ob + (ln & 15), k = 16 * (s_ / 4) + 4 * (ln >> 4) + (s_ % 4);
+                        img[off[L] + (ob * S + s_) * 64 + ln] = q[o * in_[L] + k];
+                    }
+            q += out_[L] * in_[L];
+            const int nv = L < 3 ? 3 * out_[L] : out_[L];   // bias, ln weight, ln bias (the last linear has only a bias)
+            memcpy(img + vec[L], q, nv * sizeof(float)); q += nv;
+        }
+        p += conv_params(hidden, n_hidden, rank, n_in, n_out) + (size_t)n_glob * n_out + n_glob;
+    }
+    return 0;
 }
 
 size_t cppf_point_encoder_workspace_bytes(int n_points, int n_out, int n_glob, int num_layers)
@@ -415,9 +527,7 @@ int cppf_point_encoder_forward(const float* pc, const float* nrm, const int32_t*
     if (n_points < 0 || k <= 0 || num_layers <= 0 || !hidden) return CPPF_EINVAL;
     if (n_points == 0) return 0;
     if (!pc || !nrm || !nbrs || !packed || !out) return CPPF_EINVAL;
-    if (n_hidden != 4 || hidden[0] != 32 || hidden[1] != 64 || hidden[2] != 32 || hidden[3] != 32 || rank != SP_RANK ||
-        n_out != SP_NOUT || n_glob < 1 || n_glob > 32 || n_nbr_feats != 2 || k > 64 || k > n_points)
-        return CPPF_EUNSUPPORTED;
+    if (!sp_std_shape(hidden, n_hidden, rank, n_nbr_feats, n_out, n_glob) || k > 64 || k > n_points) return CPPF_EUNSUPPORTED;
     if (!workspace || workspace_bytes < cppf_point_encoder_workspace_bytes(n_points, n_out, n_glob, num_layers))
         return CPPF_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -425,13 +535,14 @@ int cppf_point_encoder_forward(const float* pc, const float* nrm, const int32_t*
     uint32_t* glob = (uint32_t*)workspace;
     float* ping = (float*)((char*)workspace + 256);
     const float* p = packed;
+    const float* images = packed + sp_natural_floats(hidden, n_hidden, rank, n_nbr_feats, n_out, n_glob, num_layers);
     // layer l writes `dst`; the last layer must land in `out`
     for (int l = 0; l < num_layers; ++l) {
         const int n_in = l == 0 ? n_nbr_feats : W;
         float* dst = ((num_layers - 1 - l) & 1) ? ping : out;
         const float* src = l == 0 ? nullptr : (dst == out ? ping : out);
-        ConvArgs A{pc, nrm, src, nbrs, p, dst, n_points, k, n_in, W};
-        const size_t lds = (size_t)SP_WAVES * (64 * SP_KSTRIDE + 64 * n_in + SP_RANK * n_in + 64 * 3 + SP_NOUT) * sizeof(float);
+        ConvArgs A{pc, nrm, src, nbrs, p, images + (size_t)l * SPW_FLOATS, dst, n_points, k, n_in, W};
+        const size_t lds = ((size_t)SPW_FLOATS + (size_t)SP_WAVES * sp_per_wave(n_in)) * sizeof(float);
         hipError_t e = hipFuncSetAttribute((const void*)sprin_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         e = hipMemsetAsync(glob, 0, 256, st);

@@ -205,8 +205,16 @@ class PointEncoder(nn.Module):
         key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
         if self._packed is None or self._packed_key != key:
             sd = {k: v.detach().float().cpu().numpy() for k, v in self.state_dict().items()}
-            packed, desc = pack_point_encoder(sd, self.num_layers)
-            self._packed = (torch.from_numpy(packed).to(device), desc)
+            natural, desc = pack_point_encoder(sd, self.num_layers)
+            hid = (C.c_int * len(desc["hidden"]))(*desc["hidden"])
+            L = _lib.lib()
+            n = L.cppf_point_encoder_packed_floats(hid, len(desc["hidden"]), desc["rank"], desc["n_nbr_feats"], desc["n_out"],
+                                                   desc["n_glob"], self.num_layers)
+            image = np.zeros(max(int(n), natural.size), np.float32)
+            _lib.check(L.cppf_point_encoder_pack(natural.ctypes.data, hid, len(desc["hidden"]), desc["rank"],
+                                                 desc["n_nbr_feats"], desc["n_out"], desc["n_glob"], self.num_layers,
+                                                 image.ctypes.data), "cppf_point_encoder_pack")
+            self._packed = (torch.from_numpy(image).to(device), desc)
             self._packed_key = key
         return self._packed
 

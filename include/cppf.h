@@ -209,18 +209,22 @@ int cppf_grid_setup(const float* pc, int64_t N, float res, float* corner, int32_
  *   answer, the ~3k keys below that bound are compacted into LDS and an exact 32-step bisection runs on them.
  *
  * cppf_point_encoder_forward: forward_nbrs.  pc, nrm device f32[N,3]; nbrs device i32[N,k], k <= 64;
- *   out device f32[N, n_out+n_glob].  `packed` device f32: per layer, in this order,
+ *   out device f32[N, n_out+n_glob].  `packed` device f32 = the image cppf_point_encoder_pack() builds on the host
+ *   from the parameters in NATURAL order, which is per layer
  *     for each hidden width h_i (in_i = 6, then h_{i-1}):  W[h_i][in_i], b[h_i], ln_weight[h_i], ln_bias[h_i]
  *     Wk[rank][h_last], bk[rank]                      (spconvs.l.kernel.*)
  *     Wo_t[rank*n_in][n_out] = outnet.weight TRANSPOSED, bo[n_out], ln_weight[n_out], ln_bias[n_out]
  *     Wa[n_glob][n_out], ba[n_glob]                   (aggrs.l.linear)
- *   with n_in = n_nbr_feats (must be 2) for layer 0 and n_out+n_glob after it.
+ *   with n_in = n_nbr_feats (must be 2) for layer 0 and n_out+n_glob after it.  The image is that block followed,
+ *   for the supported shape, by a lane-ordered copy of each layer's kernel-MLP weights for the MFMA kernel.
  *   Device kernel exists for hidden = {32,64,32,32}, rank = 32, n_out = 32, n_glob <= 32 (the
  *   configuration of train.py:34 / nocs/inference.py:82); anything else returns CPPF_EUNSUPPORTED.
  * ------------------------------------------------------------------------------------------- */
 int cppf_knn(const float* pc, const float* dist, int n_points, int k, int32_t* nbrs, void* stream);
 size_t cppf_point_encoder_packed_floats(const int32_t* hidden, int n_hidden, int rank, int n_nbr_feats, int n_out,
                                         int n_glob, int num_layers);
+int cppf_point_encoder_pack(const float* natural /*host*/, const int32_t* hidden, int n_hidden, int rank, int n_nbr_feats,
+                            int n_out, int n_glob, int num_layers, float* packed_out /*host, packed_floats() long*/);
 size_t cppf_point_encoder_workspace_bytes(int n_points, int n_out, int n_glob, int num_layers);
 int cppf_point_encoder_forward(const float* pc, const float* nrm, const int32_t* nbrs, int n_points, int k,
                                const float* packed, const int32_t* hidden, int n_hidden, int rank, int n_nbr_feats,

@@ -382,8 +382,9 @@ def knn(pc=None, k=60, dist=None):
     return out
 
 
-def point_encoder(pc, nrm, nbrs, packed, desc):
-    """PointEncoder.forward_nbrs (models/model.py:63-78) -> f32[N, n_out + n_glob]."""
+def point_encoder(pc, nrm, nbrs, packed, desc, order=0):
+    """PointEncoder.forward_nbrs (models/model.py:63-78) -> f32[N, n_out + n_glob].
+    order 0: natural summation order; 1: the order of the device MFMA kernel (bit-exact with it)."""
     pc, nrm = _c(pc, _f), _c(nrm, _f)
     nbrs = _c(nbrs, np.int32)
     N, k = nbrs.shape
@@ -393,7 +394,7 @@ def point_encoder(pc, nrm, nbrs, packed, desc):
     rc = lib().orc_point_encoder(_p(pc, _pf), _p(nrm, _pf), _p(nbrs, _pi32), C.c_int(N), C.c_int(k), _p(packed, _pf),
                                  _p(hid, _pi32), C.c_int(len(hid)), C.c_int(desc["rank"]), C.c_int(desc["n_nbr_feats"]),
                                  C.c_int(desc["n_out"]), C.c_int(desc["n_glob"]), C.c_int(desc["num_layers"]),
-                                 _p(out, _pf))
+                                 C.c_int(order), _p(out, _pf))
     assert rc == 0
     return out
 

@@ -17,8 +17,8 @@
  *   SparseSO3Conv (rank contraction, outnet)   models/sprin.py:87-107
  *   GlobalInfoProp                             models/sprin.py:75-84
  *
- * Arithmetic conventions (the HIP kernels in cppf_amd/csrc/sprin.hip follow the same ones, so HIP vs
- * oracle is bit-exact): compiled with -ffp-contract=off; every Linear is a bias-seeded fmaf chain over
+ * Arithmetic conventions (the HIP kernels in cppf_amd/csrc/sprin.hip follow the same ones -- with `order` = 1,
+ * the summation order of the MFMA kernel-MLP, see linear_ord / layer_norm_ord -- so HIP vs oracle is bit-exact): compiled with -ffp-contract=off; every Linear is a bias-seeded fmaf chain over
  * ascending input index; every other sum is sequential over ascending index with separate multiply and
  * add; LayerNorm is mean = sum/n, var = sum((y-mean)^2)/n, z = ((y-mean) * (1/sqrt(var+1e-5))) * g + b
  * with correctly rounded sqrt and divide; neighbour order is ascending point index.
@@ -90,6 +90,47 @@ static void linear(const float* W, const float* b, const float* x, int n_in, int
         y[o] = acc;
     }
 }
+/* order 1 (the MFMA kernel's order, cppf_amd/csrc/sprin.hip): a layer whose input width is a multiple of 16
+ * walks its inputs as k(s, g) = 16*(s/4) + 4*g + s%4 for s = 0.., g = 0..3 -- the D layout of one
+ * v_mfma_f32_16x16x4_f32 layer is the B layout of the next (same rule as orc_k_order in cppf_oracle.c). */
+static void linear_ord(const float* W, const float* b, const float* x, int n_in, int n_out, float* y, int order)
+{
+    if (order != 1 || n_in % 16 != 0) { linear(W, b, x, n_in, n_out, y); return; }
+    for (int o = 0; o < n_out; ++o) {
+        float acc = b[o];
+        for (int s_ = 0; s_ < n_in / 4; ++s_)
+            for (int g = 0; g < 4; ++g) {
+                const int k = 16 * (s_ / 4) + 4 * g + (s_ % 4);
+                acc = fmaf(W[(size_t)o * n_in + k], x[k], acc);
+            }
+        y[o] = acc;
+    }
+}
+/* order 1: the n features of a row live in 4 lanes, lane g holding features 16*ob + 4*g + r; each lane sums its
+ * own values (ob, then r ascending) and the four partial sums combine as (p0 + p1) + (p2 + p3). */
+static float sum_ord1(const float* v, int n, int squared, float mean)
+{
+    float p[4];
+    for (int g = 0; g < 4; ++g) {
+        float acc = 0.f;
+        for (int ob = 0; ob < n / 16; ++ob)
+            for (int r = 0; r < 4; ++r) {
+                const float x = v[16 * ob + 4 * g + r];
+                if (squared) { const float d = x - mean; acc = acc + d * d; }
+                else acc = acc + x;
+            }
+        p[g] = acc;
+    }
+    return (p[0] + p[1]) + (p[2] + p[3]);
+}
+static void layer_norm(float* y, int n, const float* g, const float* b);
+static void layer_norm_ord(float* y, int n, const float* g, const float* b, int order)
+{
+    if (order != 1 || n % 16 != 0) { layer_norm(y, n, g, b); return; }
+    const float mean = sum_ord1(y, n, 0, 0.f) / (float)n;
+    const float inv = 1.0f / sqrtf(sum_ord1(y, n, 1, mean) / (float)n + 1e-5f);
+    for (int o = 0; o < n; ++o) y[o] = ((y[o] - mean) * inv) * g[o] + b[o];
+}
 /* nn.LayerNorm(n), eps 1e-5, affine (models/sprin.py:68,93) */
 static void layer_norm(float* y, int n, const float* g, const float* b)
 {
@@ -107,7 +148,7 @@ static void layer_norm(float* y, int n, const float* g, const float* b)
  * or [N][n_in] features gathered by neighbour index (models/model.py:59).  Returns a pointer past the
  * parameters consumed (the aggr parameters follow). */
 int orc_sprin_conv(const float* pc, const float* nrm, const float* feat_in, int n_in, const int32_t* nbrs, int N, int k,
-                   const float* params, const int32_t* hidden, int n_hidden, int rank, int n_out, float* out)
+                   const float* params, const int32_t* hidden, int n_hidden, int rank, int n_out, int order, float* out)
 {
     for (int i = 0; i < n_hidden; ++i)
         if (hidden[i] > SPRIN_MAX_W) return -1;
@@ -150,14 +191,14 @@ int orc_sprin_conv(const float* pc, const float* nrm, const float* feat_in, int 
                 int in = 6;
                 for (int i = 0; i < n_hidden; ++i) {
                     const int h = hidden[i];
-                    linear(p, p + (size_t)h * in, x, in, h, y);
+                    linear_ord(p, p + (size_t)h * in, x, in, h, y, order);
                     p += (size_t)h * in + h;
-                    layer_norm(y, h, p, p + h);
+                    layer_norm_ord(y, h, p, p + h, order);
                     p += 2 * h;
                     for (int o = 0; o < h; ++o) x[o] = y[o] > 0.f ? y[o] : 0.f;
                     in = h;
                 }
-                linear(p, p + (size_t)rank * in, x, in, rank, kern + (size_t)j * rank);
+                linear_ord(p, p + (size_t)rank * in, x, in, rank, kern + (size_t)j * rank, order);
             }
             const float* p = params;
             {
@@ -220,7 +261,7 @@ void orc_sprin_global(const float* conv, int N, int n_out, int n_glob, const flo
 /* PointEncoder.forward_nbrs (models/model.py:63-78): num_layers conv+aggr stages.  out: [N][n_out+n_glob]. */
 int orc_point_encoder(const float* pc, const float* nrm, const int32_t* nbrs, int N, int k, const float* params,
                       const int32_t* hidden, int n_hidden, int rank, int n_nbr_feats, int n_out, int n_glob,
-                      int num_layers, float* out)
+                      int num_layers, int order, float* out)
 {
     const int W = n_out + n_glob;
     float* conv = malloc(sizeof(float) * (size_t)N * n_out);
@@ -230,7 +271,7 @@ int orc_point_encoder(const float* pc, const float* nrm, const int32_t* nbrs, in
     for (int l = 0; l < num_layers && rc == 0; ++l) {
         const int n_in = l == 0 ? n_nbr_feats : W;
         if (l > 0) memcpy(prev, out, sizeof(float) * (size_t)N * W);
-        rc = orc_sprin_conv(pc, nrm, l == 0 ? NULL : prev, n_in, nbrs, N, k, p, hidden, n_hidden, rank, n_out, conv);
+        rc = orc_sprin_conv(pc, nrm, l == 0 ? NULL : prev, n_in, nbrs, N, k, p, hidden, n_hidden, rank, n_out, order, conv);
         p += orc_sprin_conv_params(hidden, n_hidden, rank, n_in, n_out);
         orc_sprin_global(conv, N, n_out, n_glob, p, p + (size_t)n_glob * n_out, out);
         p += (size_t)n_glob * n_out + n_glob;

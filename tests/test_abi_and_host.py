@@ -177,7 +177,8 @@ def test_point_encoder_and_backward_abi_without_a_device(golden):
     from cppf_amd.models.sprin import pack_point_encoder
     L = _lib.lib()
     hid = (C.c_int * 4)(32, 64, 32, 32)
-    assert L.cppf_point_encoder_packed_floats(hid, 4, 32, 2, 32, 8, 1) == 9256          # parameter count of train.py:34
+    assert L.cppf_point_encoder_packed_floats(hid, 4, 32, 2, 32, 8, 1) == 9256 + 6912   # parameters of train.py:34 + MFMA image
+    assert L.cppf_point_encoder_packed_floats((C.c_int * 2)(16, 24), 2, 32, 2, 32, 8, 1) == 3808        # other shapes: natural block only
     assert L.cppf_point_encoder_workspace_bytes(4096, 32, 8, 1) == 256
     assert L.cppf_point_encoder_workspace_bytes(4096, 32, 8, 2) == 256 + 4096 * 40 * 4
     assert L.cppf_knn(None, None, 10, 3, None, None) == -1                               # no points, no matrix
@@ -210,5 +211,11 @@ def test_point_encoder_and_backward_abi_without_a_device(golden):
     with torch.no_grad(), pytest.raises(_lib.CppfError):
         enc(pc, nrm, torch.cdist(pc, pc))                                                # no CPU fallback for inference
     packed, desc = pack_point_encoder({k: v.numpy() for k, v in sd.items()}, 1)
+    image = np.zeros(9256 + 6912, np.float32)
+    assert L.cppf_point_encoder_pack(packed.ctypes.data, hid, 4, 32, 2, 32, 8, 1, image.ctypes.data) == 0
+    assert np.array_equal(image[:9256], packed)
+    W2 = sd["spconvs.0.kernel.3.weight"].numpy()                                         # Linear(32, 64)
+    ob, s_, ln = 3, 5, 37                                                                # lane (row 5, g = 2) of block 3, step 5
+    assert image[9256 + 256 + (ob * 8 + s_) * 64 + ln] == W2[16 * ob + (ln & 15), 16 * (s_ // 4) + 4 * (ln >> 4) + s_ % 4]
     assert packed.size == 9256 and desc == dict(hidden=[32, 64, 32, 32], rank=32, n_nbr_feats=2, n_out=32, n_glob=8,
                                                 num_layers=1)

@@ -34,7 +34,7 @@ def _encoder(dev, num_layers=1, seed=3, k=60):
 def _oracle_out(oracle, enc, pc, nrm, nbrs):
     sd = {k: v.detach().cpu().numpy() for k, v in enc.state_dict().items()}
     packed, desc = oracle.pack_point_encoder(sd, enc.num_layers)
-    return oracle.point_encoder(pc, nrm, nbrs, packed, desc)
+    return oracle.point_encoder(pc, nrm, nbrs, packed, desc, order=1)     # the MFMA kernel's summation order
 
 
 @pytest.mark.parametrize("n,k,dup", [(1000, 60, 0), (257, 64, 0), (64, 64, 0), (515, 7, 40), (2000, 33, 0), (4096, 60, 3), (8000, 60, 0), (9001, 16, 0), (10050, 9, 0)])

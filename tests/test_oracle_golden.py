@@ -245,15 +245,16 @@ def test_grid_setup_matches_reference_expression(oracle):
 
 
 # --------------------------------------------------------------------------- SPRIN point encoder (row f1)
+@pytest.mark.parametrize("order", [0, 1])
 @pytest.mark.parametrize("tag", ["l1", "l2"])
-def test_point_encoder_matches_reference(oracle, golden, tag):
+def test_point_encoder_matches_reference(oracle, golden, tag, order):
     """oracle/sprin_oracle.c vs the reference PointEncoder's own output (tests/golden/make_golden_sprin.py).
     Tolerance 2e-5 absolute on O(1) LayerNorm outputs: ATen sums in a different order."""
     z = golden(f"sprin_{tag}.npz")
     sd = {k[4:]: z[k] for k in z.files if k.startswith("sd::")}
     packed, desc = oracle.pack_point_encoder(sd, int(z["num_layers"]))
     assert desc["hidden"] == list(z["spfcs"])
-    out = oracle.point_encoder(z["pc"], z["nrm"], z["nbrs_topk"].astype(np.int32), packed, desc)
+    out = oracle.point_encoder(z["pc"], z["nrm"], z["nbrs_topk"].astype(np.int32), packed, desc, order)
     assert out.shape == z["out"].shape
     np.testing.assert_allclose(out, z["out"], atol=2e-5, rtol=0)
 
