@@ -637,3 +637,33 @@ def test_batch_of_mixed_categories_matches_per_object_oracle(oracle, golden, dev
         np.testing.assert_allclose(recs[j, 0:3], o["T"], atol=1e-12)
         np.testing.assert_allclose(recs[j, 3:6], o["up"], atol=1e-12)
         np.testing.assert_allclose(recs[j, 9:12], o["scale"], rtol=1e-6)
+
+
+def test_pair_sharded_center_world1_equals_unsharded(oracle, dev):
+    """sharding.estimate_center_sharded (pairs split across ranks + grid all-reduce) with a single rank is the
+    plain chain; two emulated ranks (slices summed on one device) give the same grid to fp32 rounding."""
+    from cppf_amd import sharding
+    from cppf_amd.inference import estimate_center, grid_shape
+    from cppf_amd.models import voting
+    ob = syn.make_object("mug", 1024, 2)
+    cfg = ob["cfg"]
+    torch.manual_seed(2)
+    enc = PPFEncoder(cfg.ppffcs, cfg.out_dim).eval().to(dev)
+    idx = torch.from_numpy(syn.make_pairs(1024, 32, 2)).to(dev)
+    u_tr = torch.from_numpy(syn.make_uniforms(idx.shape[0], 2)[0]).to(dev)
+    corners, dims = grid_shape(ob["pc"], cfg.res)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    pc, nrm, feat, corner = d(ob["pc"]), d(ob["normals"]), d(ob["feat"]), d(corners[0])
+    with torch.no_grad():
+        i0, v0, _, _, g0 = estimate_center(enc, pc, nrm, feat, idx, u_tr, cfg, corner, dims)
+        g0 = g0.clone()
+        i1, v1, g1 = sharding.estimate_center_sharded(enc, pc, nrm, feat, idx, u_tr, cfg, corner, dims, 0, 1)
+        assert torch.equal(g0, g1) and int(i0) == int(i1)
+        parts = []
+        for r in range(2):
+            lo, hi = sharding.shard_pairs(idx.shape[0], r, 2)
+            parts.append(estimate_center(enc, pc, nrm, feat, idx[lo:hi].contiguous(), u_tr[lo:hi].contiguous(), cfg, corner,
+                                         dims)[4].clone())
+        gs = parts[0] + parts[1]
+        assert float((gs - g0).abs().max()) <= 1e-5 * float(g0.max())
+        assert int(voting.grid_argmax(gs)[0]) == int(i0)

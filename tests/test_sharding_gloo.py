@@ -60,3 +60,53 @@ def test_shard_objects_round_robin():
     assert allj == list(range(13))
     one = sharding.gather_records(torch.stack([sharding.pack_record(j, _fake_pose(j)) for j in (2, 0, 1)]), 3, 0, 1)
     assert one[:, 15].tolist() == [0.0, 1.0, 2.0]
+
+
+# --------------------------------------------------------------------------- intra-object pair sharding
+def _vote_worker(rank, world, port, out_dir):
+    """each rank votes its slice of the pairs with the oracle into a private grid; one all-reduce sums them"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import cppf_amd.synthetic as syn
+    from oracle import oracle as O
+    sharding.init_distributed("gloo")
+    ob = syn.make_object("bottle", 256, 5)
+    cfg = ob["cfg"]
+    idx = syn.make_pairs(256, 16, 5).astype(np.int32)
+    outputs = syn.closed_form_outputs(ob["pc"], ob["center"], idx, cfg, quantise=True)
+    corner, dims = O.grid_setup(ob["pc"], cfg.res)
+    lo, hi = sharding.shard_pairs(idx.shape[0], rank, world)
+    grid = np.zeros(tuple(dims), np.float32)
+    O.ppf_voting(ob["pc"], outputs[lo:hi], np.ones(256, np.float32), idx[lo:hi], grid, corner, cfg.res, 72, True)
+    g = torch.from_numpy(grid)
+    sharding.allreduce_grid(g, world)
+    torch.save(g, os.path.join(out_dir, f"grid{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pair_sharded_vote_allreduce_matches_single_rank(tmp_path):
+    import cppf_amd.synthetic as syn
+    from oracle import oracle as O
+    world = 2
+    mp.spawn(_vote_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ob = syn.make_object("bottle", 256, 5)
+    cfg = ob["cfg"]
+    idx = syn.make_pairs(256, 16, 5).astype(np.int32)
+    outputs = syn.closed_form_outputs(ob["pc"], ob["center"], idx, cfg, quantise=True)
+    corner, dims = O.grid_setup(ob["pc"], cfg.res)
+    full = np.zeros(tuple(dims), np.float32)
+    O.ppf_voting(ob["pc"], outputs, np.ones(256, np.float32), idx, full, corner, cfg.res, 72, True)
+    g0, g1 = (torch.load(os.path.join(tmp_path, f"grid{r}.pt")).numpy() for r in range(world))
+    assert np.array_equal(g0, g1)                                     # every rank holds the same summed grid
+    np.testing.assert_allclose(g0, full, rtol=0, atol=1e-5 * full.max())   # fp32 sums in a different order
+    assert int(np.argmax(g0)) == int(np.argmax(full))
+
+
+def test_shard_pairs_is_a_balanced_partition():
+    for n, w in ((10, 3), (524288, 8), (5, 8), (0, 4)):
+        cuts = [sharding.shard_pairs(n, r, w) for r in range(w)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n
+        assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
+        sizes = [hi - lo for lo, hi in cuts]
+        assert max(sizes) - min(sizes) <= 1
