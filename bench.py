@@ -8,9 +8,11 @@
 
 A step = one pass of the hot path over one object (N=4096 points, K=128 pairs/point ->
 P=524 288 pairs; BASELINE.json configs[1] sizes, fused HIP path): inputs (points, normals, 40-d
-point features, pair indices, uniforms, packed weights) already resident in HBM; per step the grid
-three kernels run (fused PPF+MLP+decode of all 141 logits, LDS-tiled vote, reduce+arg-max).  With N GPUs every rank processes its own object per step (weak scaling) and
-ONE all_gather of the K result records closes the batch inside the timed region.
+point features, int64 pair indices, uniforms, packed weights) already resident in HBM; per step four
+kernels run (per-point layer-0 projection, fused PPF+MLP+decode of all 141 logits, LDS-tiled vote reading
+the int64 pair list directly, reduce+arg-max), replayed from a hipGraph.  With N GPUs every rank processes
+its own object per step (weak scaling) and ONE all_gather of the K result records closes the batch inside
+the timed region.
 """
 import argparse
 import json
@@ -98,7 +100,7 @@ def main():
     enc = enc.to(dev)
     corners, dims = grid_shape(ob["pc"], cfg.res)
     d = lambda a: torch.from_numpy(a).to(dev)
-    # static device buffers + the three launches of the chain captured once in a hipGraph
+    # static device buffers + the four launches of the chain captured once in a hipGraph
     pipe = CenterPipeline(enc, cfg, N_POINTS, P, dims, dev, NUM_ROTS, adaptive=True, with_heads=True,
                           use_graph=not args.no_graph)
     pipe.load(ob["pc"], ob["normals"], ob["feat"], idx, u_tr, u_rot, corners[0].copy())
@@ -140,8 +142,8 @@ def main():
 
     # per-kernel durations (HIP events on the stream the C ABI launches on), measured eagerly right after
     # the timed region with the same buffers: the dominant kernel alone between two events
-    pc, nrm, feat, idx_d, utr_d, urot_d, corner_d, idx32 = (pipe.pc, pipe.nrm, pipe.feat, pipe.idx, pipe.u_tr,
-                                                              pipe.u_rot, pipe.corner, pipe.idx32)
+    pc, nrm, feat, idx_d, utr_d, urot_d, corner_d = (pipe.pc, pipe.nrm, pipe.feat, pipe.idx, pipe.u_tr, pipe.u_rot,
+                                                       pipe.corner)
     ws = PoseWorkspace(dev, P, dims, 1)
     ws.probs = pipe.probs
     n_ev = max(args.steps, 5)
@@ -156,11 +158,11 @@ def main():
             outputs, heads = enc.forward_decode(pc, nrm, feat, idx_d, utr_d, cfg.vote_range, urot_d,
                                                 cfg.tr_num_bins, cfg.rot_num_bins)
         ev[1].record()
-        voting.vote_argmax(pc, outputs, ws.probs, idx32, ws.grid, corner_d, cfg.res, NUM_ROTS, True,
+        voting.vote_argmax(pc, outputs, ws.probs, idx_d, ws.grid, corner_d, cfg.res, NUM_ROTS, True,
                            ws.out_idx, ws.out_val, accumulate=False)
         ev[2].record()
         for _ in range(n_ev):
-            voting.vote_argmax(pc, outputs, ws.probs, idx32, ws.grid, corner_d, cfg.res, NUM_ROTS, True,
+            voting.vote_argmax(pc, outputs, ws.probs, idx_d, ws.grid, corner_d, cfg.res, NUM_ROTS, True,
                                ws.out_idx, ws.out_val, accumulate=False)
         ev[3].record()
     torch.cuda.synchronize()
@@ -177,7 +179,7 @@ def main():
         for it in range(6):
             if it == 1:
                 e0.record()
-            voting.vote_argmax(pc, out_ka, ws.probs, idx32, ws.grid, corner_d, cfg.res, NUM_ROTS, True,
+            voting.vote_argmax(pc, out_ka, ws.probs, idx_d, ws.grid, corner_d, cfg.res, NUM_ROTS, True,
                                ws.out_idx, ws.out_val, accumulate=False)
         e1.record()
         torch.cuda.synchronize()
@@ -234,7 +236,7 @@ def main():
             "config": {"workload": f"single object N={N_POINTS} K={PAIRS_PER_POINT} (P={P} pairs), bottle config, res 4e-3, "
                                    f"grid {dims[0]}x{dims[1]}x{dims[2]}, num_rots 72 adaptive, fused PPF+MLP(MFMA f32)+decode -> "
                                    "LDS-tiled vote -> argmax; one object per GPU per step; " +
-                                   ("three launches replayed from a hipGraph" if not args.no_graph else "eager launches"),
+                                   ("four launches replayed from a hipGraph" if not args.no_graph else "eager launches"),
                        "pairs_per_step_per_gpu": P, "parallelism": f"objects x{world}"},
             "pairs_per_ms_per_gpu": args.steps * P / elapsed / 1e3,
             "stage_ms": {"ppf_mlp_decode": t_mlp, "vote_reduce_argmax": t_vote,

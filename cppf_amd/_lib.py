@@ -16,7 +16,7 @@ _SIGS = {
     "cppf_vote_workspace_bytes": (sz, [i64, i32, i32, i32, i32]),
     "cppf_vote_fixed_point_bits": (C.c_int, [i64, i32, i32, i32, i32]),
     "cppf_ppf_voting": (C.c_int, [vp, vp, vp, vp, vp, vp, f32, i64, i64, i32, i32, i32, i32, i32, vp, sz, vp]),
-    "cppf_vote_argmax": (C.c_int, [vp, vp, vp, vp, vp, vp, f32, i64, i64, i32, i32, i32, i32, i32, i32, vp, vp, vp, sz,
+    "cppf_vote_argmax": (C.c_int, [vp, vp, vp, vp, i32, vp, vp, f32, i64, i64, i32, i32, i32, i32, i32, i32, vp, vp, vp, sz,
                                    vp]),
     "cppf_grid_argmax": (C.c_int, [vp, i64, vp, vp, vp, sz, vp]),
     "cppf_center_from_argmax": (C.c_int, [vp, vp, C.c_double, i32, i32, vp, vp, vp]),

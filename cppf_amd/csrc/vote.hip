@@ -143,7 +143,8 @@ struct VoteArgs {
     const float* points;
     const float* outputs;
     const float* probs;
-    const int32_t* point_idxs;
+    const void* point_idxs;  // i32[P,2] or i64[P,2] (idx64)
+    int idx64;
     float* grid;       // !TILED target
     float* partials;   // TILED target [chunks][G]
     const float* corner;
@@ -225,6 +226,15 @@ __device__ __forceinline__ void vote_deposit(const VoteTile& T, f3 v, float prob
         atomicAdd(b + T.syz + T.gz, hhl);
         atomicAdd(b + T.syz + T.gz + 1, hhh);
     }
+}
+
+__device__ __forceinline__ int2 vote_pair_idx(const VoteArgs& A, int64_t p)
+{
+    if (A.idx64) {
+        const longlong2 v = reinterpret_cast<const longlong2*>(A.point_idxs)[p];
+        return make_int2((int)v.x, (int)v.y);
+    }
+    return reinterpret_cast<const int2*>(A.point_idxs)[p];
 }
 
 // one pair frame per lane, pulled across lanes by the deposit stage
@@ -345,7 +355,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
         F.cc = {0.f, 0.f, 0.f}; F.x = F.cc; F.y = F.cc; F.prob = 0.f; F.n = 0;
         if (valid) {
             const float2 o = reinterpret_cast<const float2*>(A.outputs)[p];
-            const int2 ij = reinterpret_cast<const int2*>(A.point_idxs)[p];
+            const int2 ij = vote_pair_idx(A, p);
             f3 a, ab, xd;
             if (pair_frame(A.points, ij.x, ij.y, a, ab, xd)) {
                 const float proj_len = o.x, odist = o.y;
@@ -426,7 +436,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
                 bool pass = false;
                 if (p < p_end) {
                     const float2 o = reinterpret_cast<const float2*>(A.outputs)[p];
-                    const int2 ij = reinterpret_cast<const int2*>(A.point_idxs)[p];
+                    const int2 ij = vote_pair_idx(A, p);
                     const f3 a = ld3(A.points, ij.x), b = ld3(A.points, ij.y);
                     const f3 d = sub3(a, b);
                     const float L = sqrtf(dot3(d, d));
@@ -567,7 +577,7 @@ __global__ void zero_u64x2_kernel(unsigned long long* p) { p[0] = 0ull; p[1] = 0
 
 #define VOTE_LDS_HEAD ((VOTE_THREADS / 64) * VOTE_RING * 2 + VOTE_CARRY_CAP * 4 + (VOTE_THREADS / 64) * VOTE_PAIRQ * 4 + 64)
 
-static int vote_impl(const float* points, const float* outputs, const float* probs, const int32_t* point_idxs,
+static int vote_impl(const float* points, const float* outputs, const float* probs, const void* point_idxs, int idx_is_i64,
                      float* grid_obj, const float* corner, float res, int64_t n_points, int64_t n_ppfs, int n_rots,
                      int gx, int gy, int gz, int adaptive, int accumulate, bool want_argmax, long long* out_idx, float* out_val,
                      void* workspace, size_t workspace_bytes, hipStream_t st)
@@ -584,7 +594,7 @@ static int vote_impl(const float* points, const float* outputs, const float* pro
     const int64_t G = (int64_t)gx * gy * gz;
 
     VoteArgs A;
-    A.points = points; A.outputs = outputs; A.probs = probs; A.point_idxs = point_idxs;
+    A.points = points; A.outputs = outputs; A.probs = probs; A.point_idxs = point_idxs; A.idx64 = idx_is_i64;
     A.grid = grid_obj; A.partials = partials; A.corner = corner; A.packed = packed;
     A.res = res; A.n_ppfs = n_ppfs; A.n_rots = n_rots; A.gx = gx; A.gy = gy; A.gz = gz; A.adaptive = adaptive;
     A.tx = pl.tx; A.ty = pl.ty; A.ntx = pl.ntx; A.nty = pl.nty; A.T = pl.T; A.chunk_pairs = pl.chunk_pairs;
@@ -645,17 +655,17 @@ extern "C" int cppf_ppf_voting(const float* points, const float* outputs, const 
                                int64_t n_points, int64_t n_ppfs, int n_rots, int gx, int gy, int gz, int adaptive,
                                void* workspace, size_t workspace_bytes, void* stream)
 {
-    return vote_impl(points, outputs, probs, point_idxs, grid_obj, corner, res, n_points, n_ppfs, n_rots, gx, gy, gz,
+    return vote_impl(points, outputs, probs, point_idxs, 0, grid_obj, corner, res, n_points, n_ppfs, n_rots, gx, gy, gz,
                      adaptive, 1, false, nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int cppf_vote_argmax(const float* points, const float* outputs, const float* probs,
-                                const int32_t* point_idxs, float* grid_obj, const float* corner, float res,
+                                const void* point_idxs, int idx_is_i64, float* grid_obj, const float* corner, float res,
                                 int64_t n_points, int64_t n_ppfs, int n_rots, int gx, int gy, int gz, int adaptive,
                                 int accumulate, long long* out_idx, float* out_val, void* workspace,
                                 size_t workspace_bytes, void* stream)
 {
-    return vote_impl(points, outputs, probs, point_idxs, grid_obj, corner, res, n_points, n_ppfs, n_rots, gx, gy, gz,
+    return vote_impl(points, outputs, probs, point_idxs, idx_is_i64, grid_obj, corner, res, n_points, n_ppfs, n_rots, gx, gy, gz,
                      adaptive, accumulate, true, out_idx, out_val, workspace, workspace_bytes, (hipStream_t)stream);
 }
 

@@ -144,11 +144,11 @@ class CenterPipeline:
     def _chain(self):
         if self.point_encoder is not None:                                    # nocs/inference.py:180-181, no N x N matrix
             self.feat = self.point_encoder(self.pc[None], self.nrm[None])[0]
-        self.idx32.copy_(self.idx)                                            # .astype(cp.int32), nocs/inference.py:202
         self.outputs, self.heads = self.encoder.forward_decode(
             self.pc, self.nrm, self.feat, self.idx, self.u_tr, self.cfg.vote_range,
             self.u_rot if self.with_heads else None, self.cfg.tr_num_bins, self.cfg.rot_num_bins)
-        voting.vote_argmax(self.pc, self.outputs, self.probs, self.idx32, self.grid, self.corner, self.cfg.res,
+        # the vote reads the int64 pair list directly (the reference copies it to int32 first, nocs/inference.py:202)
+        voting.vote_argmax(self.pc, self.outputs, self.probs, self.idx, self.grid, self.corner, self.cfg.res,
                            self.num_rots, self.adaptive, self.out_idx, self.out_val, accumulate=False)
 
     def run(self):
@@ -316,6 +316,7 @@ class PosePipeline(CenterPipeline):
 
     def _chain(self):
         super()._chain()
+        self.idx32.copy_(self.idx)                                            # the pose-tail kernels take int32 indices
         _enqueue_tail(self.ws, self.pc, self.nrm, self.idx32, self.outputs, self.heads, self.corner, self.cfg,
                       self.dims, self.num_rots, self.angle_tol, self.max_rot_pairs, *self._sph)
 

@@ -81,11 +81,13 @@ def vote_argmax(points, outputs, probs, point_idxs, grid_obj, corner, res, n_rot
     """ppf_voting + np.argmax (nocs/inference.py:197-208) without the host round trip.
     accumulate=True: grid_obj += votes (reference semantics, grid zero-initialised by the caller);
     accumulate=False: grid_obj = votes (no memset needed).
+    point_idxs may be int32 (as the reference passes it) or the original int64 pair list.
     Returns (out_idx i64[1], out_val f32[1]) device tensors."""
     dev = dev_tensor(points, F32, "points", (3,)).device
     dev_tensor(outputs, F32, "outputs", (2,), dev)
     dev_tensor(probs, F32, "probs", None, dev)
-    dev_tensor(point_idxs, I32, "point_idxs", (2,), dev)
+    i64 = isinstance(point_idxs, torch.Tensor) and point_idxs.dtype == torch.int64
+    dev_tensor(point_idxs, torch.int64 if i64 else I32, "point_idxs", (2,), dev)
     dev_tensor(grid_obj, F32, "grid_obj", None, dev)
     dev_tensor(corner, F32, "corner", None, dev)
     if grid_obj.dim() != 3:
@@ -105,7 +107,7 @@ def vote_argmax(points, outputs, probs, point_idxs, grid_obj, corner, res, n_rot
     ws = workspace(need, dev, "vote")
     with torch.cuda.device(dev):
         rc = L.cppf_vote_argmax(points.data_ptr(), outputs.data_ptr(), probs.data_ptr(), point_idxs.data_ptr(),
-                                grid_obj.data_ptr(), corner.data_ptr(), float(scalar(res)), points.shape[0], n_ppfs,
+                                1 if i64 else 0, grid_obj.data_ptr(), corner.data_ptr(), float(scalar(res)), points.shape[0], n_ppfs,
                                 int(n_rots), gx, gy, gz, 1 if adaptive else 0, 1 if accumulate else 0,
                                 out_idx.data_ptr(), out_val.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr(dev))
     _lib.check(rc, "cppf_vote_argmax")

@@ -66,9 +66,11 @@ int cppf_ppf_voting(const float* points, const float* outputs, const float* prob
  * grid_obj.get(); np.argmax -> first maximum in C order).  out_idx: device i64[1] flat index,
  * out_val: device f32[1] peak value (either may be NULL).
  * accumulate != 0: grid_obj += votes (the reference's semantics, caller zero-initialises, :196);
- * accumulate == 0: grid_obj  = votes (spares the caller's memset). */
-int cppf_vote_argmax(const float* points, const float* outputs, const float* probs, const int32_t* point_idxs,
-                     float* grid_obj, const float* corner, float res, int64_t n_points, int64_t n_ppfs, int n_rots,
+ * accumulate == 0: grid_obj  = votes (spares the caller's memset).
+ * point_idxs: device i32[n_ppfs,2] (idx_is_i64 == 0, what the reference passes after `.astype(cp.int32)`,
+ * nocs/inference.py:202) or the original i64[n_ppfs,2] of np.random.randint (idx_is_i64 != 0; spares the copy). */
+int cppf_vote_argmax(const float* points, const float* outputs, const float* probs, const void* point_idxs,
+                     int idx_is_i64, float* grid_obj, const float* corner, float res, int64_t n_points, int64_t n_ppfs, int n_rots,
                      int gx, int gy, int gz, int adaptive, int accumulate, long long* out_idx, float* out_val,
                      void* workspace, size_t workspace_bytes, void* stream);
 
