@@ -736,39 +736,79 @@ __global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__
     const f3 cr = {corner[0], corner[1], corner[2]};
     const f3 gt = {gt_center[0], gt_center[1], gt_center[2]};
     const float bx = (float)(gx - 1), by = (float)(gy - 1), bz = (float)(gz - 1);
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_ppfs;
-         idx += (int64_t)gridDim.x * blockDim.x) {
+    // Two stages per wave.  Stage 1, one pair per lane: frame, rotation count, and the skip test -- every sample
+    // lies at distance |offset| = rho (1 +- 1e-6) from cc, hence at least | |cc - gt| - rho | from gt; when that
+    // exceeds tol (with a margin far above the rounding) no rotation can pass :101 and the pair is finished
+    // (offset 0).  The other pairs go to a per-wave LDS queue and stage 2 runs their rotation loops 64 at a time,
+    // so a wave never walks 72 rotations for the sake of one lane.
+    uint32_t* q = reinterpret_cast<uint32_t*>(lds + (in_lds ? 2 * entries : 0)) + (threadIdx.x >> 6) * 128;
+    const int lane = threadIdx.x & 63;
+    int qn = 0;
+    auto finish = [&](const int64_t idx, const f3 found) {
+        float* oo = out_offsets + 3 * idx;
+        oo[0] = found.x; oo[1] = found.y; oo[2] = found.z;
+        if (mask) mask[idx] = (found.x != 0.f) || (found.y != 0.f) || (found.z != 0.f);
+    };
+    auto rotations = [&](const int64_t idx) {   // the reference's loop (:97-110) for one pair that passed stage 1
         const float2 o = reinterpret_cast<const float2*>(outputs)[idx];
         const int2 ij = reinterpret_cast<const int2*>(point_idxs)[idx];
-        float* oo = out_offsets + 3 * idx;
         f3 a, ab, xd;
-        f3 found = {oo[0], oo[1], oo[2]};  // degenerate pairs keep the caller's value (:87 returns early)
-        if (pair_frame(points, ij.x, ij.y, a, ab, xd)) {
-            const float proj_len = o.x, odist = o.y;
-            const f3 cc = sub3(a, scl3(ab, proj_len));
-            const f3 x = scl3(xd, odist);
-            const f3 y = cross3(x, ab);
-            found = {0.f, 0.f, 0.f};                                                   // :96
-            int n = min((int)((double)(odist / res) * (2 * CPPF_PI)), n_rots);        // :97
-            // every sample lies at distance |offset| = rho (1 +- 1e-6) from cc, so it is at least
-            // | |cc - gt| - rho | away from gt: when that exceeds tol (with a margin far above the rounding)
-            // no rotation can pass the test of :101 and the loop is skipped -- same result, no work.
-            const float dc = len3(sub3(cc, gt)), rho = len3(x);
-            if (fabsf(dc - rho) > tol + 1e-5f * (dc + rho + tol) + 1e-7f) n = 0;
-            const int tbase = n * (n - 1) / 2;
-            for (int i = 0; i < n; ++i) {
-                const float2 cs = in_lds ? ltab[tbase + i] : rot_cs(i, n);
-                const f3 offset = add3(scl3(x, cs.x), scl3(y, cs.y));
-                const f3 pc = add3(cc, offset);
-                if (len3(sub3(pc, gt)) > tol) continue;                               // :101
-                const f3 g = div3(sub3(pc, cr), res);
-                if (g.x < 0.f || g.y < 0.f || g.z < 0.f || g.x >= bx || g.y >= by || g.z >= bz) continue;  // :103-107
-                found = neg3(offset);                                                  // :108
-                break;
-            }
-            oo[0] = found.x; oo[1] = found.y; oo[2] = found.z;
+        pair_frame(points, ij.x, ij.y, a, ab, xd);
+        const float proj_len = o.x, odist = o.y;
+        const f3 cc = sub3(a, scl3(ab, proj_len));
+        const f3 x = scl3(xd, odist);
+        const f3 y = cross3(x, ab);
+        f3 found = {0.f, 0.f, 0.f};                                                   // :96
+        const int n = min((int)((double)(odist / res) * (2 * CPPF_PI)), n_rots);      // :97
+        const int tbase = n * (n - 1) / 2;
+        for (int i = 0; i < n; ++i) {
+            const float2 cs = in_lds ? ltab[tbase + i] : rot_cs(i, n);
+            const f3 offset = add3(scl3(x, cs.x), scl3(y, cs.y));
+            const f3 pc = add3(cc, offset);
+            if (len3(sub3(pc, gt)) > tol) continue;                                   // :101
+            const f3 g = div3(sub3(pc, cr), res);
+            if (g.x < 0.f || g.y < 0.f || g.z < 0.f || g.x >= bx || g.y >= by || g.z >= bz) continue;  // :103-107
+            found = neg3(offset);                                                      // :108
+            break;
         }
-        if (mask) mask[idx] = (found.x != 0.f) || (found.y != 0.f) || (found.z != 0.f);
+        finish(idx, found);
+    };
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63);; base += stride) {
+        const bool more = base < n_ppfs;   // wave-uniform
+        if (more) {
+            const int64_t idx = base + lane;
+            bool pass = false;
+            if (idx < n_ppfs) {
+                const float2 o = reinterpret_cast<const float2*>(outputs)[idx];
+                const int2 ij = reinterpret_cast<const int2*>(point_idxs)[idx];
+                f3 a, ab, xd;
+                if (pair_frame(points, ij.x, ij.y, a, ab, xd)) {
+                    const float proj_len = o.x, odist = o.y;
+                    const f3 cc = sub3(a, scl3(ab, proj_len));
+                    const f3 x = scl3(xd, odist);
+                    const int n = min((int)((double)(odist / res) * (2 * CPPF_PI)), n_rots);
+                    const float dc = len3(sub3(cc, gt)), rho = len3(x);
+                    pass = n > 0 && !(fabsf(dc - rho) > tol + 1e-5f * (dc + rho + tol) + 1e-7f);
+                    if (!pass) finish(idx, f3{0.f, 0.f, 0.f});
+                } else if (mask) {   // degenerate pair: out_offsets keeps the caller's value (:87 returns early)
+                    const float* oo = out_offsets + 3 * idx;
+                    mask[idx] = (oo[0] != 0.f) || (oo[1] != 0.f) || (oo[2] != 0.f);
+                }
+            }
+            const unsigned long long m = __ballot(pass);
+            if (pass)
+                q[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] = (uint32_t)idx;
+            qn += __popcll(m);
+        }
+        while (qn >= 64 || (!more && qn > 0)) {
+            const int take = qn < 64 ? qn : 64;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const uint32_t pidx = lane < take ? q[qn - take + lane] : 0u;
+            qn -= take;
+            if (lane < take) rotations((int64_t)pidx);
+        }
+        if (!more) break;
     }
 }
 
@@ -776,11 +816,11 @@ extern "C" int cppf_backvote(const float* points, const float* outputs, float* o
                              const int32_t* point_idxs, const float* corner, float res, int64_t n_ppfs, int n_rots,
                              int gx, int gy, int gz, const float* gt_center, float tol, uint8_t* mask, void* stream)
 {
-    if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || n_ppfs < 0) return CPPF_EINVAL;
+    if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || n_ppfs < 0 || n_ppfs > 0xffffffffll) return CPPF_EINVAL;
     if (n_ppfs == 0) return 0;
     if (!points || !outputs || !out_offsets || !point_idxs || !corner || !gt_center) return CPPF_EINVAL;
     const int entries = tri(n_rots);
-    const size_t lds = entries <= VOTE_TAB_LDS_MAX ? (size_t)entries * sizeof(float2) : 0;
+    const size_t lds = (entries <= VOTE_TAB_LDS_MAX ? (size_t)entries * sizeof(float2) : 0) + 4 * 128 * sizeof(uint32_t);
     int64_t nb = (n_ppfs + 255) / 256;
     if (nb > 1024) nb = 1024;
     hipLaunchKernelGGL(backvote_kernel, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, points,
@@ -1006,7 +1046,7 @@ __global__ __launch_bounds__(SPH_THREADS) void rot_sphere_kernel(const float* __
 // utils/util.py:102-118 is): a candidate c can only match bins with |s.y - c.y| < sqrt(2 - 2 thr), so
 // each lane takes candidates and tests only that band of bins (~14 of 480 at 1.5 deg) instead of every
 // lane sweeping every candidate.  Same dot product, same threshold test -> identical counts.
-#define SPHB_PPB 32
+#define SPHB_PPB 8
 __global__ __launch_bounds__(256) void rot_sphere_band_kernel(const float* __restrict__ points,
                                                               const float* __restrict__ preds_rot, int rot_stride,
                                                               const int32_t* __restrict__ point_idxs,
