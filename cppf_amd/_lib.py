@@ -19,7 +19,8 @@ _SIGS = {
     "cppf_vote_argmax": (C.c_int, [vp, vp, vp, vp, i32, vp, vp, f32, i64, i64, i32, i32, i32, i32, i32, i32, vp, vp, vp, sz,
                                    vp]),
     "cppf_grid_argmax": (C.c_int, [vp, i64, vp, vp, vp, sz, vp]),
-    "cppf_center_from_argmax": (C.c_int, [vp, vp, C.c_double, i32, i32, vp, vp, vp]),
+    "cppf_center_from_argmax": (C.c_int, [vp, vp, C.c_double, i32, i32, vp, vp, vp, vp, vp]),
+    "cppf_counts_argmax_select": (C.c_int, [vp, i32, vp, vp, vp, vp]),
     "cppf_backvote": (C.c_int, [vp, vp, vp, vp, vp, f32, i64, i32, i32, i32, i32, vp, f32, vp, vp]),
     "cppf_compact_workspace_bytes": (sz, [i64]),
     "cppf_compact_mask": (C.c_int, [vp, i64, vp, vp, vp, sz, vp]),

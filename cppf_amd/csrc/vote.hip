@@ -688,7 +688,8 @@ extern "C" int cppf_grid_argmax(const float* grid, int64_t n, long long* out_idx
 // nocs/inference.py:209-210: cand = unravel_index(argmax); T = corners[0] + cand * res in fp64;
 // T32 is the float32 copy handed to backvote (:225).
 __global__ void center_from_argmax_kernel(const long long* __restrict__ idx, const float* __restrict__ corner, double res,
-                                          int gy, int gz, double* __restrict__ T64, float* __restrict__ T32)
+                                          int gy, int gz, double* __restrict__ T64, float* __restrict__ T32,
+                                          const float* __restrict__ peak, double* __restrict__ idx_peak)
 {
     const long long flat = *idx;
     const long long syz = (long long)gy * gz;
@@ -699,14 +700,55 @@ __global__ void center_from_argmax_kernel(const long long* __restrict__ idx, con
         if (T64) T64[j] = t;
         if (T32) T32[j] = (float)t;
     }
+    if (j == 3 && idx_peak) {   // the arg-max index and its value as doubles, for the pose record
+        idx_peak[0] = (double)flat;
+        idx_peak[1] = peak ? (double)*peak : 0.0;
+    }
+}
+
+// np.argmax(counts) (first maximum, nocs/inference.py:283) and best_dir = sphere_pts[argmax] (fp64) in one launch
+__global__ __launch_bounds__(256) void counts_argmax_select_kernel(const int32_t* __restrict__ counts, int n,
+                                                                   const double* __restrict__ sphere64,
+                                                                   long long* __restrict__ best_idx, double* __restrict__ best_dir)
+{
+    __shared__ unsigned long long best[4];
+    // key = count << 32 | ~index: the largest key is the largest count at the lowest index
+    unsigned long long k = 0ull;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const unsigned long long ki = ((unsigned long long)(uint32_t)counts[i] << 32) | (uint32_t)(~(uint32_t)i);
+        k = ki > k ? ki : k;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(k, off, 64);
+        k = o > k ? o : k;
+    }
+    if ((threadIdx.x & 63) == 0) best[threadIdx.x >> 6] = k;
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        unsigned long long b = best[0];
+        for (int w = 1; w < 4; ++w) b = best[w] > b ? best[w] : b;
+        const int bi = (int)(~(uint32_t)(b & 0xffffffffull));
+        best_dir[threadIdx.x] = sphere64[3 * (size_t)bi + threadIdx.x];
+        if (threadIdx.x == 0 && best_idx) *best_idx = bi;
+    }
 }
 
 extern "C" int cppf_center_from_argmax(const long long* idx, const float* corner, double res, int gy, int gz,
-                                       double* T64, float* T32, void* stream)
+                                       double* T64, float* T32, const float* peak, double* idx_peak_f64, void* stream)
 {
     if (!idx || !corner || gy < 1 || gz < 1) return CPPF_EINVAL;
     hipLaunchKernelGGL(center_from_argmax_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, idx, corner, res, gy, gz,
-                       T64, T32);
+                       T64, T32, peak, idx_peak_f64);
+    CPPF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cppf_counts_argmax_select(const int32_t* counts, int n, const double* sphere64, long long* best_idx,
+                                         double* best_dir, void* stream)
+{
+    if (!counts || !sphere64 || !best_dir || n < 1) return CPPF_EINVAL;
+    hipLaunchKernelGGL(counts_argmax_select_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, counts, n, sphere64,
+                       best_idx, best_dir);
     CPPF_CHECK_LAUNCH();
     return 0;
 }

@@ -45,19 +45,20 @@ class PoseWorkspace:
         self.grid = torch.empty(self.dims, dtype=F32, device=device)
         self.out_idx = torch.empty(1, dtype=torch.int64, device=device)
         self.out_val = torch.empty(1, dtype=F32, device=device)
-        self.T64 = torch.empty(3, dtype=torch.float64, device=device)
+        # the 21-double result record; T64 / best_dir / sign / scale are views into it, so the kernels write the
+        # record directly and the read-back is one copy
+        self.rec = torch.zeros(21, dtype=torch.float64, device=device)
+        self.T64 = self.rec[0:3]
         self.T32 = torch.empty(3, dtype=F32, device=device)
         self.offsets = torch.empty((n_pairs, 3), dtype=F32, device=device)
         self.mask = torch.empty(n_pairs, dtype=torch.uint8, device=device)
         self.surv = torch.empty(n_pairs, dtype=I32, device=device)
         self.count = torch.empty(1, dtype=I32, device=device)
         self.counts = torch.empty((2, n_sphere), dtype=I32, device=device)
-        self.countsf = torch.empty((2, n_sphere), dtype=F32, device=device)
         self.best_idx = torch.empty(2, dtype=torch.int64, device=device)
-        self.best_dir = torch.empty((2, 3), dtype=torch.float64, device=device)
-        self.sign = torch.empty((2, 3), dtype=torch.float64, device=device)
-        self.scale = torch.empty(4, dtype=torch.float64, device=device)
-        self.rec = torch.zeros(21, dtype=torch.float64, device=device)
+        self.best_dir = self.rec[3:9].view(2, 3)
+        self.sign = self.rec[9:15].view(2, 3)
+        self.scale = self.rec[15:19]
         self.probs = None
         self._sph_key = None
 
@@ -218,7 +219,8 @@ def _enqueue_tail(ws, pc, pc_normal, idx32, outputs, heads, corner, cfg, dims, n
     P, S = idx32.shape[0], sph32_d.shape[0]
     with torch.cuda.device(dev):
         _lib.check(L.cppf_center_from_argmax(ws.out_idx.data_ptr(), corner.data_ptr(), float(cfg.res), dims[1],
-                                             dims[2], ws.T64.data_ptr(), ws.T32.data_ptr(), st),
+                                             dims[2], ws.T64.data_ptr(), ws.T32.data_ptr(), ws.out_val.data_ptr(),
+                                             ws.rec[19:21].data_ptr(), st),
                    "cppf_center_from_argmax")
         # back-vote filter (:216-231) --------------------------------------------------------------
         ws.offsets.zero_()                                                    # :220
@@ -233,19 +235,16 @@ def _enqueue_tail(ws, pc, pc_normal, idx32, outputs, heads, corner, cfg, dims, n
         thr = float(np.float32(np.cos(angle_tol / 180 * np.pi)))
         n_dirs = 2 if cfg.regress_right else 1
         ws.counts.zero_()
-        ws.best_dir.zero_()
-        ws.sign.zero_()
+        ws.rec[3:15].zero_()                                                  # best_dir, sign
         rws = workspace(L.cppf_reduce_workspace_bytes(), dev, "reduce")
         for j in range(n_dirs):
             _lib.check(L.cppf_rot_sphere_count(pc.data_ptr(), heads.data_ptr() + 4 * j, 8, idx32.data_ptr(),
                                                ws.surv.data_ptr(), ws.count.data_ptr(), P, max_rot_pairs, num_rots,
                                                sph32_d.data_ptr(), S, thr, sorted_y, ws.counts[j].data_ptr(), st),
                        "cppf_rot_sphere_count")
-            ws.countsf[j].copy_(ws.counts[j])                                 # exact: counts < 2**24
-            _lib.check(L.cppf_grid_argmax(ws.countsf[j].data_ptr(), S, ws.best_idx[j:].data_ptr(), None,
-                                          rws.data_ptr(), rws.numel(), st),
-                       "cppf_grid_argmax")                                    # np.argmax(counts), :283
-            torch.index_select(sph64_d, 0, ws.best_idx[j:j + 1], out=ws.best_dir[j:j + 1])
+            _lib.check(L.cppf_counts_argmax_select(ws.counts[j].data_ptr(), S, sph64_d.data_ptr(), ws.best_idx[j:].data_ptr(),
+                                                   ws.best_dir[j].data_ptr(), st),
+                       "cppf_counts_argmax_select")                           # np.argmax(counts), sphere_pts[...], :283-284
             _lib.check(L.cppf_axis_sign(pc.data_ptr(), pc_normal.data_ptr(), idx32.data_ptr(), ws.surv.data_ptr(),
                                         ws.count.data_ptr(), P, heads.data_ptr() + 4 * (2 + j), 8,
                                         ws.best_dir[j].data_ptr(), ws.sign[j].data_ptr(), rws.data_ptr(),
@@ -253,12 +252,7 @@ def _enqueue_tail(ws, pc, pc_normal, idx32, outputs, heads, corner, cfg, dims, n
         # scale (:335) -----------------------------------------------------------------------------
         _lib.check(L.cppf_scale_sum(heads.data_ptr() + 4 * 4, 8, ws.surv.data_ptr(), ws.count.data_ptr(), P,
                                     ws.scale.data_ptr(), rws.data_ptr(), rws.numel(), st), "cppf_scale_sum")
-    ws.rec[0:3].copy_(ws.T64)
-    ws.rec[3:9].copy_(ws.best_dir.reshape(-1))
-    ws.rec[9:15].copy_(ws.sign.reshape(-1))
-    ws.rec[15:19].copy_(ws.scale)
-    ws.rec[19:20].copy_(ws.out_idx)
-    ws.rec[20:21].copy_(ws.out_val)
+    # (T64, best_dir, sign, scale, arg-max index and value were written into ws.rec by the kernels above)
 
 
 def _assemble(rec, cfg, rng=None):

@@ -80,9 +80,16 @@ int cppf_grid_argmax(const float* grid, int64_t n, long long* out_idx, float* ou
                      size_t workspace_bytes, void* stream);
 
 /* nocs/inference.py:209-210: T = corners[0] + unravel_index(argmax) * res (fp64); idx device i64[1];
- * T64 device f64[3] and/or T32 device f32[3] (the copy the reference hands to backvote, :225). */
+ * T64 device f64[3] and/or T32 device f32[3] (the copy the reference hands to backvote, :225).
+ * Optional: peak (device f32[1], the arg-max value) and idx_peak_f64 (device f64[2]) -> {(double)idx, (double)peak},
+ * so a host can read index, value and T back as one block of doubles. */
 int cppf_center_from_argmax(const long long* idx, const float* corner, double res, int gy, int gz, double* T64,
-                            float* T32, void* stream);
+                            float* T32, const float* peak, double* idx_peak_f64, void* stream);
+
+/* np.argmax(counts) (first maximum) and best_dir = sphere_pts[argmax] (nocs/inference.py:283-284) in one launch:
+ * counts device i32[n], sphere64 device f64[n,3], best_idx device i64[1] (optional), best_dir device f64[3]. */
+int cppf_counts_argmax_select(const int32_t* counts, int n, const double* sphere64, long long* best_idx,
+                              double* best_dir, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Back-vote filter.  Replaces `backvote_kernel` = CUDA `backvote` (models/voting.py:70-113),
