@@ -218,6 +218,27 @@ def main():
         torch.cuda.synchronize()
         t_penc = e0.elapsed_time(e1) / 5
 
+    # secondary: one training-size forward + backward of the pair encoder (train.py:66,91:
+    # 200 000 pairs, dL/dlogits given), HIP forward + HIP backward through the autograd.Function
+    t_train = None
+    if rank == 0:
+        Pt = 200000
+        idx_t = d(syn.make_pairs(N_POINTS, (Pt + N_POINTS - 1) // N_POINTS, 7)[:Pt])
+        Rt = torch.randn((Pt, cfg.out_dim), device=dev)
+        feat_t = feat.clone().requires_grad_(True)
+        enc.train()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for it in range(4):
+            if it == 1:
+                e0.record()
+            enc.zero_grad()
+            feat_t.grad = None
+            (enc.forward_with_idx(pc, nrm, feat_t, idx_t) * Rt).sum().backward()
+        e1.record()
+        torch.cuda.synchronize()
+        enc.eval()
+        t_train = e0.elapsed_time(e1) / 3
+
     if rank == 0:
         argmax_gpu = int(allrec[0, 12].item())
         out = {
@@ -242,7 +263,8 @@ def main():
             "stage_ms": {"ppf_mlp_decode": t_mlp, "vote_reduce_argmax": t_vote,
                          "vote_reduce_argmax_known_answer_inputs": t_vote_ka,
                          "full_pose_incl_readback": t_pose, "full_pose_n_surv": pose["n_surv"],
-                         "point_encoder_knn60_sprin": t_penc},
+                         "point_encoder_knn60_sprin": t_penc,
+                         "pair_encoder_fwd_bwd_200k_pairs": t_train},
             # dominant kernel = the fused pair encoder (one launch between the two events): exact-fp32
             # MFMA, 23 968 algorithmic FLOP per pair
             "roofline": {"bound": "mfma", "kernel": "pair_mlp_kernel<false,true,true>",

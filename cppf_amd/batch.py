@@ -15,10 +15,12 @@ from .utils.util import fibonacci_sphere, num_sphere_bins
 
 class BatchPoseRunner:
     def __init__(self, encoders, device, num_rots=72, adaptive=True, angle_tol=1.5, max_rot_pairs=10000,
-                 use_graph=True):
+                 use_graph=True, point_encoders=None):
         """encoders: {category name: PPFEncoder on `device`} (the reference keeps one per category,
-        nocs/inference.py:79-90)."""
+        nocs/inference.py:79-90).  point_encoders: optional {category name: PointEncoder}; objects of those
+        categories need no `feat` -- kNN + SPRIN run at the head of the captured graph (:180-181)."""
         self.encoders, self.device = encoders, device
+        self.point_encoders = point_encoders or {}
         self.kw = dict(num_rots=num_rots, adaptive=adaptive, angle_tol=angle_tol, max_rot_pairs=max_rot_pairs,
                        use_graph=use_graph)
         self.sphere = np.array(fibonacci_sphere(num_sphere_bins(angle_tol)))      # :100-102
@@ -28,14 +30,14 @@ class BatchPoseRunner:
         key = (cfg.category, n_points, n_pairs, tuple(dims))
         if key not in self._pipes:
             self._pipes[key] = PosePipeline(self.encoders[cfg.category], cfg, n_points, n_pairs, dims, self.device,
-                                            self.sphere, **self.kw)
+                                            self.sphere, point_encoder=self.point_encoders.get(cfg.category), **self.kw)
         return self._pipes[key]
 
     def run_object(self, obj):
         """obj: dict(pc, normals, feat, point_idxs, u_tr, u_rot, cfg) of host arrays -> pose dict."""
         corners, dims = grid_shape(obj["pc"], obj["cfg"].res)
         pipe = self._pipe(obj["cfg"], obj["pc"].shape[0], obj["point_idxs"].shape[0], dims)
-        pipe.load(obj["pc"], obj["normals"], obj["feat"], obj["point_idxs"], obj["u_tr"], obj["u_rot"],
+        pipe.load(obj["pc"], obj["normals"], obj.get("feat"), obj["point_idxs"], obj["u_tr"], obj["u_rot"],
                   corners[0].copy())
         return pipe.run()
 

@@ -144,3 +144,29 @@ def test_pipeline_with_point_encoder_equals_precomputed_features(dev, oracle):
         assert ra[key] == rb[key] == ra2[key]
     for key in ("T", "up", "scale"):
         assert np.array_equal(ra[key], rb[key]) and np.array_equal(ra[key], ra2[key])
+
+
+def test_batch_runner_with_point_encoders(dev, oracle):
+    """BatchPoseRunner(point_encoders=...): objects arrive without `feat`; every record equals the pipeline fed with
+    the oracle's features."""
+    import cppf_amd.synthetic as syn
+    from cppf_amd.batch import BatchPoseRunner
+    from cppf_amd.models.model import PPFEncoder
+    cats = ["bottle", "mug", "bowl"]
+    encs, pencs, objs, objs_feat = {}, {}, [], []
+    for i, c in enumerate(cats):
+        cfg = syn.make_object(c, 64, 0)["cfg"]
+        torch.manual_seed(20 + i)
+        encs[c] = PPFEncoder([84, 32, 32, 16], 2 * cfg.tr_num_bins + 2 * cfg.rot_num_bins + 5).eval().to(dev)
+        pencs[c] = _encoder(dev, 1, seed=30 + i, k=60)
+    for j in range(5):
+        c = cats[j % 3]
+        ob = syn.make_object(c, 768, 40 + j)
+        idx = syn.make_pairs(768, 24, 40 + j)
+        u_tr, u_rot = syn.make_uniforms(idx.shape[0], 40 + j)
+        base = dict(pc=ob["pc"], normals=ob["normals"], point_idxs=idx, u_tr=u_tr, u_rot=u_rot, cfg=ob["cfg"])
+        objs.append(base)
+        objs_feat.append(dict(base, feat=_oracle_out(oracle, pencs[c], ob["pc"], ob["normals"], oracle.knn(ob["pc"], 60))))
+    a = BatchPoseRunner(encs, dev, point_encoders=pencs).run(objs).cpu().numpy()
+    b = BatchPoseRunner(encs, dev).run(objs_feat).cpu().numpy()
+    assert a.shape == (5, 20) and np.array_equal(a, b)
