@@ -667,3 +667,11 @@ def test_pair_sharded_center_world1_equals_unsharded(oracle, dev):
         gs = parts[0] + parts[1]
         assert float((gs - g0).abs().max()) <= 1e-5 * float(g0.max())
         assert int(voting.grid_argmax(gs)[0]) == int(i0)
+
+
+def test_randomised_soak(dev):
+    """a few seconds of tests/soak_gpu.py: random categories, sizes, grid resolutions, output regimes, rotation
+    counts, weights -- vote grids, arg-max, back-vote offsets and kNN sets against the oracle"""
+    import soak_gpu
+    n_v, n_b, n_k = soak_gpu.run(8.0, 12345, dev)
+    assert n_v >= 20 and n_b >= 20 and n_k >= 20
