@@ -787,8 +787,10 @@ __global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__
     const int lane = threadIdx.x & 63;
     int qn = 0;
     auto finish = [&](const int64_t idx, const f3 found) {
-        float* oo = out_offsets + 3 * idx;
-        oo[0] = found.x; oo[1] = found.y; oo[2] = found.z;
+        if (out_offsets) {
+            float* oo = out_offsets + 3 * idx;
+            oo[0] = found.x; oo[1] = found.y; oo[2] = found.z;
+        }
         if (mask) mask[idx] = (found.x != 0.f) || (found.y != 0.f) || (found.z != 0.f);
     };
     auto rotations = [&](const int64_t idx) {   // the reference's loop (:97-110) for one pair that passed stage 1
@@ -834,8 +836,8 @@ __global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__
                     pass = n > 0 && !(fabsf(dc - rho) > tol + 1e-5f * (dc + rho + tol) + 1e-7f);
                     if (!pass) finish(idx, f3{0.f, 0.f, 0.f});
                 } else if (mask) {   // degenerate pair: out_offsets keeps the caller's value (:87 returns early)
-                    const float* oo = out_offsets + 3 * idx;
-                    mask[idx] = (oo[0] != 0.f) || (oo[1] != 0.f) || (oo[2] != 0.f);
+                    const float* oo = out_offsets ? out_offsets + 3 * idx : nullptr;
+                    mask[idx] = oo ? ((oo[0] != 0.f) || (oo[1] != 0.f) || (oo[2] != 0.f)) : 0;   // mask-only: as if zero-initialised (:220)
                 }
             }
             const unsigned long long m = __ballot(pass);
@@ -860,7 +862,7 @@ extern "C" int cppf_backvote(const float* points, const float* outputs, float* o
 {
     if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || n_ppfs < 0 || n_ppfs > 0xffffffffll) return CPPF_EINVAL;
     if (n_ppfs == 0) return 0;
-    if (!points || !outputs || !out_offsets || !point_idxs || !corner || !gt_center) return CPPF_EINVAL;
+    if (!points || !outputs || (!out_offsets && !mask) || !point_idxs || !corner || !gt_center) return CPPF_EINVAL;
     const int entries = tri(n_rots);
     const size_t lds = (entries <= VOTE_TAB_LDS_MAX ? (size_t)entries * sizeof(float2) : 0) + 4 * 128 * sizeof(uint32_t);
     int64_t nb = (n_ppfs + 255) / 256;

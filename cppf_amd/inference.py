@@ -50,7 +50,6 @@ class PoseWorkspace:
         self.rec = torch.zeros(21, dtype=torch.float64, device=device)
         self.T64 = self.rec[0:3]
         self.T32 = torch.empty(3, dtype=F32, device=device)
-        self.offsets = torch.empty((n_pairs, 3), dtype=F32, device=device)
         self.mask = torch.empty(n_pairs, dtype=torch.uint8, device=device)
         self.surv = torch.empty(n_pairs, dtype=I32, device=device)
         self.count = torch.empty(1, dtype=I32, device=device)
@@ -223,8 +222,8 @@ def _enqueue_tail(ws, pc, pc_normal, idx32, outputs, heads, corner, cfg, dims, n
                                              ws.rec[19:21].data_ptr(), st),
                    "cppf_center_from_argmax")
         # back-vote filter (:216-231) --------------------------------------------------------------
-        ws.offsets.zero_()                                                    # :220
-        _lib.check(L.cppf_backvote(pc.data_ptr(), outputs.data_ptr(), ws.offsets.data_ptr(), idx32.data_ptr(),
+        # mask only: the offsets themselves (:220-228) are consumed nowhere else, so no buffer is zeroed or written
+        _lib.check(L.cppf_backvote(pc.data_ptr(), outputs.data_ptr(), None, idx32.data_ptr(),
                                    corner.data_ptr(), float(cfg.res), P, num_rots, dims[0], dims[1], dims[2],
                                    ws.T32.data_ptr(), float(np.float32(3 * cfg.res)), ws.mask.data_ptr(), st),
                    "cppf_backvote")

@@ -95,7 +95,8 @@ int cppf_counts_argmax_select(const int32_t* counts, int n, const double* sphere
  * Back-vote filter.  Replaces `backvote_kernel` = CUDA `backvote` (models/voting.py:70-113),
  * launched at nocs/inference.py:216-228; always adaptive.
  *   out_offsets device f32[n_ppfs,3] zero-initialised by the caller (degenerate pairs are not
- *               written, as in the reference)
+ *               written, as in the reference); may be NULL when only `mask` is wanted (degenerate
+ *               pairs then get mask 0, as with a zero-initialised buffer)
  *   gt_center   device f32[3], tol = 3*res in the reference
  *   mask        device u8[n_ppfs] or NULL: any(out_offsets != 0) (nocs/inference.py:230)
  * ------------------------------------------------------------------------------------------- */
