@@ -275,7 +275,7 @@ def main():
                                  "pair-encoder stage (point_proj_kernel + pair_mlp_kernel); the pair kernel itself issues "
                                  f"{FLOP_PER_PAIR_EXECUTED} MFMA FLOP per pair because the two 40-wide feature blocks of layer 0 "
                                  "are projected once per point; fp32 MFMA shares the VALU datapath on gfx950, so the in-register "
-                                 "decode (about 1 000 VALU per 16 pairs) is paid on the same pipe",
+                                 "decode (about 480 VALU per 16 pairs) is paid on the same pipe",
                          "executed_mfma_tflops": FLOP_PER_PAIR_EXECUTED * P / (t_mlp * 1e-3) / 1e12},
         }
         if world == 1 and not args.no_cpu_baseline:

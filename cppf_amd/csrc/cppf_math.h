@@ -51,6 +51,27 @@ __device__ __forceinline__ float det_expf(float x)
     return __int_as_float(__float_as_int(p) + ((int)n << 23));  // (v_ldexp_f32 measured slower here)
 }
 
+// Two det_expf at once on the packed-fp32 pipe (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 are IEEE per
+// component, so each half is bit-identical to det_expf).
+typedef float cppf_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cppf_f32x2 det_expf2(cppf_f32x2 x)
+{
+    x[0] = fmaxf(x[0], -86.0f); x[1] = fmaxf(x[1], -86.0f);
+    const cppf_f32x2 y = x * 1.44269504088896341f;
+    cppf_f32x2 n;
+    n[0] = rintf(y[0]); n[1] = rintf(y[1]);
+    const cppf_f32x2 f = y - n;
+    cppf_f32x2 p = {9.570102207e-03f, 9.570102207e-03f};
+    p = __builtin_elementwise_fma(p, f, cppf_f32x2{5.591785908e-02f, 5.591785908e-02f});
+    p = __builtin_elementwise_fma(p, f, cppf_f32x2{2.402474433e-01f, 2.402474433e-01f});
+    p = __builtin_elementwise_fma(p, f, cppf_f32x2{6.931217909e-01f, 6.931217909e-01f});
+    p = __builtin_elementwise_fma(p, f, cppf_f32x2{9.999992847e-01f, 9.999992847e-01f});
+    cppf_f32x2 r;
+    r[0] = __int_as_float(__float_as_int(p[0]) + ((int)n[0] << 23));
+    r[1] = __int_as_float(__float_as_int(p[1]) + ((int)n[1] << 23));
+    return r;
+}
+
 // fp64 sin/cos: Cody-Waite by pi/2 + degree-13/14 kernels on [-pi/4, pi/4].
 __device__ __forceinline__ void det_sincos(double x, double* s, double* c)
 {

@@ -61,7 +61,9 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byt
 #define STD_LDS (OFF_BF + 144)          // 7 968 floats = 31 872 B live in LDS
 #define OFF_WPT STD_LDS                 // [40][128]   per-point projection: column r < 64: W[r][k], r >= 64: W[r-64][40+k]
 #define OFF_BPT (OFF_WPT + 40 * 128)    // [64]        fc1 | fc0 bias of layer 0 (folded into the feat_a table)
-#define STD_PACKED (OFF_BPT + 64)       // 13 152 floats
+#define OFF_WFD (OFF_BPT + 64)          // [4][64][12] final layer with the output columns in DECODE order (dec_col)
+#define OFF_BFD (OFF_WFD + 4 * 64 * STD_NOBP)  // [144] its bias, slot order
+#define STD_PACKED (OFF_BFD + 144)      // 16 368 floats
 #define PROJ_COLS 128
 
 static bool is_std(int F, const int* dims, int n_res, int out_dim)
@@ -101,6 +103,20 @@ extern "C" size_t cppf_pair_mlp_packed_floats(int F, const int* dims, int n_res,
 }
 
 static inline int khid(int s, int g) { return 16 * (s / 4) + 4 * g + (s % 4); }
+
+// DECODE order of the 141 output columns (train.py:68-75: 2 x 32 centre bins, 2 x 36 angle bins, 2 sign logits, 3
+// log-scales): accumulator slot (block ob, lane group g, register r) holds
+//   ob 0..7 : bin 8g (or 9g) + 4*(ob & 1) + r of head ob / 2 -- a lane owns a run of consecutive bins of every head
+//   ob 8    : r = 0, 1: the 9th bin (9g + 8) of the up / right head;  r = 2, 3: aux_up aux_right | sx sy | sz - | - -  for g = 0..3
+// so that the in-register sampler needs two lane exchanges per statistic and no per-row bookkeeping.
+static inline int dec_col(int ob, int g, int r)
+{
+    if (ob < 4) return 32 * (ob >> 1) + 8 * g + 4 * (ob & 1) + r;
+    if (ob < 8) return 64 + 36 * ((ob - 4) >> 1) + 9 * g + 4 * (ob & 1) + r;
+    if (r < 2) return 64 + 36 * r + 9 * g + 8;
+    const int q = 2 * g + (r - 2);   // 0..7 -> columns 136..140, then unused
+    return q < 5 ? 136 + q : -1;
+}
 
 extern "C" int cppf_pair_mlp_pack(const float* params, const int64_t* offs, int F, const int* dims, int n_res,
                                   int out_dim, float* out)
@@ -156,6 +172,19 @@ extern "C" int cppf_pair_mlp_pack(const float* params, const int64_t* offs, int 
                     out[OFF_WF + (s * 64 + l) * STD_NOBP + ob] = o < out_dim ? wf[o * 16 + khid(s, l >> 4)] : 0.f;
                 }
         for (int o = 0; o < out_dim; ++o) out[OFF_BF + o] = bf[o];
+        if (out_dim == 141) {   // the decode kernels' copy of the final layer, columns in dec_col order
+            for (int s = 0; s < 4; ++s)
+                for (int l = 0; l < 64; ++l)
+                    for (int ob = 0; ob < STD_NOB; ++ob) {
+                        const int m = l & 15, c = dec_col(ob, m >> 2, m & 3);
+                        out[OFF_WFD + (s * 64 + l) * STD_NOBP + ob] = c >= 0 ? wf[c * 16 + khid(s, l >> 4)] : 0.f;
+                    }
+            for (int ob = 0; ob < STD_NOB; ++ob)
+                for (int m = 0; m < 16; ++m) {
+                    const int c = dec_col(ob, m >> 2, m & 3);
+                    out[OFF_BFD + 16 * ob + m] = c >= 0 ? bf[c] : 0.f;
+                }
+        }
         return 0;
     }
     if (gen_ok(F, dims, n_res, out_dim)) {
@@ -233,94 +262,49 @@ __device__ __forceinline__ unsigned xor32u(unsigned v, int lane)
 __device__ __forceinline__ float xor16f(float v, int lane) { return __uint_as_float(xor16u(__float_as_uint(v), lane)); }
 __device__ __forceinline__ float xor32f(float v, int lane) { return __uint_as_float(xor32u(__float_as_uint(v), lane)); }
 
-// Head occupying chunks [C0, C0+NC) (columns [4*C0, 4*(C0+NC))).  Returns true in exactly one of the
-// pair's 4 lanes -- the one that owns the sampled bin -- with the bin (0-based within the head).
-template <int C0, int NC, int NOB>
-__device__ __forceinline__ bool sample_head(const f32x4 (&L)[NOB], float u, int g, int lane, int& bin)
+// One head whose NL consecutive bins NL*g .. NL*g + NL-1 sit in v[] of lane group g (dec_col layout).  Semantics:
+// oracle/cppf_oracle.c:orc_sample_bin.  Returns true in exactly one of the pair's 4 lanes -- the one that owns
+// the sampled bin -- with the bin index.
+template <int NL>
+__device__ __forceinline__ bool sample_seg(const float (&v)[NL], float u, int g, int lane, int& bin)
 {
-    constexpr int R0 = C0 / 4, R1 = (C0 + NC - 1) / 4, NR = R1 - R0 + 1;
-    // 1. max over the head
-    float m = -INFINITY;
+    float m = v[0];
 #pragma unroll
-    for (int R = R0; R <= R1; ++R) {
-        const int c = 4 * R + g;
-        const bool own = c >= C0 && c < C0 + NC;
-        const float mr = fmaxf(fmaxf(L[R][0], L[R][1]), fmaxf(L[R][2], L[R][3]));
-        m = own ? fmaxf(m, mr) : m;
-    }
+    for (int k = 1; k < NL; ++k) m = fmaxf(m, v[k]);
     float mall = fmaxf(m, xor16f(m, lane));
     mall = fmaxf(mall, xor32f(mall, lane));
-    // 2. exponentials, chunk sums, row sums (two exchanges per row)
-    f32x4 e[NR];
-    float cs[NR], x16[NR], s01[NR], rowcdf[NR];
-    float run = 0.f;
+    float e[NL], T = 0.f;
 #pragma unroll
-    for (int R = R0; R <= R1; ++R) {
-        const int c = 4 * R + g;
-        const bool own = c >= C0 && c < C0 + NC;
-        f32x4 v;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float ex = det_expf(L[R][r] - mall);
-            v[r] = own ? ex : 0.f;
-        }
-        e[R - R0] = v;
-        const float c_ = ((v[0] + v[1]) + v[2]) + v[3];
-        const float p16 = xor16f(c_, lane);      // the other chunk of my half-row
-        const float half = c_ + p16;             // s01 in lanes g = 0,1; s23 in lanes g = 2,3 (a+b == b+a)
-        const float oth = xor32f(half, lane);    // the other half-row
-        cs[R - R0] = c_;
-        x16[R - R0] = p16;
-        s01[R - R0] = (g & 2) ? oth : half;
-        run = run + (half + oth);                // s01 + s23
-        rowcdf[R - R0] = run;
+    for (int k = 0; k + 1 < NL; k += 2) {   // two exponentials per packed-fp32 instruction
+        const cppf_f32x2 ex = det_expf2(cppf_f32x2{v[k] - mall, v[k + 1] - mall});
+        e[k] = ex[0]; e[k + 1] = ex[1];
     }
-    const float t = u * run;
-    // 3. row: first with rowcdf > t, else the last (branch-free selects)
-    int rs = NR - 1;
-    float base = NR > 1 ? rowcdf[NR - 2] : 0.f, c_s = cs[NR - 1], p_s = x16[NR - 1], h_s = s01[NR - 1];
-    f32x4 e_s = e[NR - 1];
+    if (NL & 1) e[NL - 1] = det_expf(v[NL - 1] - mall);
 #pragma unroll
-    for (int q = NR - 2; q >= 0; --q) {
-        const bool pick = rowcdf[q] > t;
-        rs = pick ? q : rs;
-        base = pick ? (q ? rowcdf[q > 0 ? q - 1 : 0] : 0.f) : base;
-        c_s = pick ? cs[q] : c_s;
-        p_s = pick ? x16[q] : p_s;
-        h_s = pick ? s01[q] : h_s;
+    for (int k = 0; k < NL; ++k) T = T + e[k];
+    const float Tp = xor16f(T, lane);           // the other lane of my half
+    const float half = T + Tp;                  // T0 + T1 in lanes g = 0,1; T2 + T3 in lanes g = 2,3 (a+b == b+a)
+    const float oth = xor32f(half, lane);
+    const float t = u * ((g & 2) ? oth + half : half + oth);   // (T0 + T1) + (T2 + T3) in every lane
+    const float off = ((g & 2) ? oth : 0.f) + ((g & 1) ? Tp : 0.f);
+    float b[NL];
+    b[0] = off + e[0];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) e_s[r] = pick ? e[q][r] : e_s[r];
-    }
-    // 4. chunk inside the row: B0 = base, B1 = base+cs0, B2 = base+s01, B3 = (base+s01)+cs2
-    const float bh = base + h_s;
-    const float B = g == 0 ? base : (g == 1 ? base + p_s : (g == 2 ? bh : bh + p_s));
-    const int cabs = 4 * (R0 + rs) + g;
-    const bool member = cabs >= C0 && cabs < C0 + NC;
-    const bool hit = member & (B + c_s > t);
+    for (int k = 1; k < NL; ++k) b[k] = b[k - 1] + e[k];
+    const bool hit = b[NL - 1] > t;
+    int kk = NL - 1;
+#pragma unroll
+    for (int k = NL - 2; k >= 0; --k) kk = b[k] > t ? k : kk;
     const unsigned long long hm = (__ballot(hit) >> (lane & 15)) & 0x0001000100010001ull;
-    const int gsel = hm ? ((__ffsll((long long)hm) - 1) >> 4) : -1;
-    int glast = C0 + NC - 1 - 4 * (R0 + rs);  // last chunk of the head inside this row
-    glast = glast > 3 ? 3 : glast;
-    bool owner = gsel >= 0 ? (g == gsel) : (g == glast);
-    // 5. entry inside the chunk (r = 3 when nothing in the row was hit)
-    const float b0 = B + e_s[0], b1 = b0 + e_s[1], b2 = b1 + e_s[2];
-    int r = b2 > t ? 2 : 3;
-    r = b1 > t ? 1 : r;
-    r = b0 > t ? 0 : r;
-    r = gsel >= 0 ? r : 3;
-    bin = 4 * (cabs - C0) + r;
+    const int gsel = hm ? ((__ffsll((long long)hm) - 1) >> 4) : 3;   // first lane with a hit, else the last bin
+    bool owner = g == gsel;
+    bin = NL * g + (hm ? kk : NL - 1);
     if (__any(u < 0.f)) {  // arg-max mode (rare, wave-uniform test so the common path really skips it)
         asm volatile("" ::: "memory");
         int am = 0x7fffffff;
 #pragma unroll
-        for (int R = R1; R >= R0; --R) {
-            const int c = 4 * R + g;
-            if (c >= C0 && c < C0 + NC) {
-#pragma unroll
-                for (int q = 3; q >= 0; --q)
-                    if (L[R][q] == mall) am = (c - C0) * 4 + q;
-            }
-        }
+        for (int k = NL - 1; k >= 0; --k)
+            if (v[k] == mall) am = NL * g + k;
         int best = min(am, (int)xor16u((unsigned)am, lane));
         best = min(best, (int)xor32u((unsigned)best, lane));
         if (u < 0.f) { bin = best; owner = am == best; }
@@ -400,6 +384,10 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
         const f32x4* src = reinterpret_cast<const f32x4*>(A.packed);
         f32x4* dst = reinterpret_cast<f32x4*>(W);
         for (int k = threadIdx.x; k < STD_LDS / 4; k += MLP_THREADS) dst[k] = src[k];
+        if (DECODE) {   // the final layer with its output columns in dec_col order replaces the natural one
+            for (int k = threadIdx.x; k < 4 * 64 * STD_NOBP / 4; k += MLP_THREADS) dst[OFF_WF / 4 + k] = src[OFF_WFD / 4 + k];
+            for (int k = threadIdx.x; k < 144 / 4; k += MLP_THREADS) dst[OFF_BF / 4 + k] = src[OFF_BFD / 4 + k];
+        }
     }
     // bin -> value tables (nocs/inference.py:187-188,252,256; fp32, left to right, true division): a
     // correctly rounded divide is ~12 VALU, a table read is one LDS access
@@ -636,21 +624,27 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
             if (DECODE) {
                 int k;
                 // nocs/inference.py:187-188 (fp32, left to right); the owning lane stores its value
-                if (sample_head<0, 8, STD_NOB>(L, ut[pb][0], g, lane, k) && live)
-                    A.outputs[2 * pair[pb]] = lut[k];
-                if (sample_head<8, 8, STD_NOB>(L, ut[pb][1], g, lane, k) && live)
-                    A.outputs[2 * pair[pb] + 1] = lut[32 + k];
+                {
+                    const float v[8] = {L[0][0], L[0][1], L[0][2], L[0][3], L[1][0], L[1][1], L[1][2], L[1][3]};
+                    if (sample_seg<8>(v, ut[pb][0], g, lane, k) && live) A.outputs[2 * pair[pb]] = lut[k];
+                }
+                {
+                    const float v[8] = {L[2][0], L[2][1], L[2][2], L[2][3], L[3][0], L[3][1], L[3][2], L[3][3]};
+                    if (sample_seg<8>(v, ut[pb][1], g, lane, k) && live) A.outputs[2 * pair[pb] + 1] = lut[32 + k];
+                }
                 if (HEADS) {
                     float* h = A.heads + pair[pb] * 8;
-                    if (sample_head<16, 9, STD_NOB>(L, ur[pb][0], g, lane, k) && live) h[0] = lut[64 + k];
-                    if (sample_head<25, 9, STD_NOB>(L, ur[pb][1], g, lane, k) && live) h[1] = lut[64 + k];
-                    if (live && g == 2) {  // logits 136..139 = aux_up, aux_right, sx, sy
-                        f32x2 v; v[0] = L[8][0]; v[1] = L[8][1];
-                        f32x2 w; w[0] = L[8][2]; w[1] = L[8][3];
-                        reinterpret_cast<f32x2*>(h)[1] = v;
-                        reinterpret_cast<f32x2*>(h)[2] = w;
+                    {
+                        const float v[9] = {L[4][0], L[4][1], L[4][2], L[4][3], L[5][0], L[5][1], L[5][2], L[5][3], L[8][0]};
+                        if (sample_seg<9>(v, ur[pb][0], g, lane, k) && live) h[0] = lut[64 + k];
                     }
-                    if (live && g == 3) { f32x2 v; v[0] = L[8][0]; v[1] = 0.f; reinterpret_cast<f32x2*>(h)[3] = v; }  // 140 = sz
+                    {
+                        const float v[9] = {L[6][0], L[6][1], L[6][2], L[6][3], L[7][0], L[7][1], L[7][2], L[7][3], L[8][1]};
+                        if (sample_seg<9>(v, ur[pb][1], g, lane, k) && live) h[1] = lut[64 + k];
+                    }
+                    // block 8, registers 2..3: aux_up aux_right | sx sy | sz - (dec_col)
+                    if (live && g < 2) { f32x2 w; w[0] = L[8][2]; w[1] = L[8][3]; reinterpret_cast<f32x2*>(h)[1 + g] = w; }
+                    if (live && g == 2) { f32x2 w; w[0] = L[8][2]; w[1] = 0.f; reinterpret_cast<f32x2*>(h)[3] = w; }
                 }
             }
         }
@@ -742,57 +736,32 @@ __global__ __launch_bounds__(GEN_THREADS) void pair_mlp_generic_kernel(GenArgs A
 // One lane per (pair, head): same arithmetic as sample_head / oracle orc_sample_bin.
 __device__ int sample_bin_mem(const float* __restrict__ l, int nb, float u, int col0)
 {
+    (void)col0;
     float m = l[0];
     int am = 0;
     for (int k = 1; k < nb; ++k)
         if (l[k] > m) { m = l[k]; am = k; }
     if (u < 0.f) return am;
-    const int c0 = col0 / 4, c1 = (col0 + nb - 1) / 4, r0 = c0 / 4, r1 = c1 / 4;
-    auto chunk_sum = [&](int c) {
-        if (c < c0 || c > c1) return 0.f;
-        float e[4];
-        for (int r = 0; r < 4; ++r) { const int k = 4 * c + r - col0; e[r] = k < nb ? det_expf(l[k] - m) : 0.f; }
-        return ((e[0] + e[1]) + e[2]) + e[3];
-    };
-    float run = 0.f;
-    for (int R = r0; R <= r1; ++R) {
-        const float s01 = chunk_sum(4 * R) + chunk_sum(4 * R + 1), s23 = chunk_sum(4 * R + 2) + chunk_sum(4 * R + 3);
-        run = run + (s01 + s23);
-    }
-    const float t = u * run;
-    int Rs = r1;
-    float base = 0.f, cdf = 0.f;
-    for (int R = r0; R <= r1; ++R) {
-        const float s01 = chunk_sum(4 * R) + chunk_sum(4 * R + 1), s23 = chunk_sum(4 * R + 2) + chunk_sum(4 * R + 3);
-        const float nxt = cdf + (s01 + s23);
-        if (nxt > t || R == r1) { Rs = R; base = cdf; break; }
-        cdf = nxt;
-    }
-    const float c[4] = {chunk_sum(4 * Rs), chunk_sum(4 * Rs + 1), chunk_sum(4 * Rs + 2), chunk_sum(4 * Rs + 3)};
-    const float s01 = c[0] + c[1];
-    const float B[4] = {base, base + c[0], base + s01, (base + s01) + c[2]};
-    int gsel = -1, glast = 0;
+    const int NL = (nb + 3) / 4;
+    float T[4];
     for (int g = 0; g < 4; ++g) {
-        const int ca = 4 * Rs + g;
-        if (ca < c0 || ca > c1) continue;
-        glast = g;
-        if (gsel < 0 && B[g] + c[g] > t) gsel = g;
+        float acc = 0.f;
+        for (int k = g * NL; k < (g + 1) * NL && k < nb; ++k) acc = acc + det_expf(l[k] - m);
+        T[g] = acc;
     }
-    int k;
-    if (gsel < 0) {
-        k = 4 * (4 * Rs + glast) + 3 - col0;
-    } else {
-        float b = B[gsel];
-        int rsel = 3;
-        for (int r = 0; r < 4; ++r) {
-            const int kk = 4 * (4 * Rs + gsel) + r - col0;
-            b = b + (kk < nb ? det_expf(l[kk] - m) : 0.f);
-            if (b > t) { rsel = r; break; }
+    const float s01 = T[0] + T[1], s23 = T[2] + T[3];
+    const float t = u * (s01 + s23);
+    const float off[4] = {0.f, T[0], s01, s01 + T[2]};
+    for (int g = 0; g < 4; ++g) {
+        float b = off[g];
+        for (int k = g * NL; k < (g + 1) * NL && k < nb; ++k) {
+            b = b + det_expf(l[k] - m);
+            if (b > t) return k;
         }
-        k = 4 * (4 * Rs + gsel) + rsel - col0;
     }
-    return k < nb ? k : nb - 1;
+    return nb - 1;
 }
+
 
 __global__ __launch_bounds__(256) void decode_center_kernel(const float* __restrict__ logits, int64_t P, int ld, int nb,
                                                             float vr0, float vr1, const float* __restrict__ u,

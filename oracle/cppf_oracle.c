@@ -388,73 +388,42 @@ int orc_pair_mlp(const float* pc, const float* nrm, const float* feat, const int
  * stand-in for torch.multinomial, nocs/inference.py:186; the draw itself is supplied by the
  * caller).  u < 0 selects the arg-max bin (first maximum) instead.
  *
- * The CDF is built on the layout the HIP kernel holds the logits in, so that four lanes can build
- * it with two cross-lane exchanges per 16 logits and no serial 32-long dependency.  col0 is the
- * absolute column of l[0] in the logit row (a multiple of 4); columns are grouped as
- *     row  R = col / 16      (one MFMA output block)
- *     chunk g = (col / 4) % 4 (the 4 consecutive logits one lane owns), entries r = col % 4.
- *   e_k    = orc_expf(l_k - max l)
- *   cs[R][g] = ((e0+e1)+e2)+e3 of the chunk (0 for chunks outside the head)
- *   s01 = cs0 + cs1, s23 = cs2 + cs3, rowsum[R] = s01 + s23
- *   rowcdf[R] = rowcdf[R-1] + rowsum[R]; total = last; t = u * total
- *   row:   first R with rowcdf[R] > t, else the last row;  base = rowcdf[R-1] (0 for the first)
- *   chunk: B0 = base, B1 = base + cs0, B2 = base + s01, B3 = (base + s01) + cs2, E_g = B_g + cs_g;
- *          first g inside the head with E_g > t; none -> last bin of the row's part of the head
- *   entry: b = B_g; first r with (b += e_r) > t, else r = 3.
+ * The CDF is built on the layout the HIP kernel holds the logits in, so that the four lanes that share a pair
+ * can build it with two cross-lane exchanges and no serial 32-long dependency: the nb bins are cut into four
+ * consecutive segments of NL = ceil(nb/4) bins (one per lane; the final layer's output columns are permuted at
+ * pack time so that a lane's registers hold exactly its segment).
+ *   e_k   = orc_expf(l_k - max l)
+ *   T_g   = e summed sequentially over segment g (from 0);  total = (T0 + T1) + (T2 + T3);  t = u * total
+ *   off_g = 0, T0, T0 + T1, (T0 + T1) + T2
+ *   the bin is the first k of the first segment g with off_g + (e summed up to and including k) > t;
+ *   none -> the last bin.
  */
 int orc_sample_bin(const float* l, int nb, float u, int col0)
 {
+    (void)col0;   /* (kept in the signature: position of the head in the logit row, unused by this layout) */
     float m = l[0];
     int am = 0;
     for (int k = 1; k < nb; ++k)
         if (l[k] > m) { m = l[k]; am = k; }
     if (u < 0.0f) return am;
-    const int c0 = col0 / 4, c1 = (col0 + nb - 1) / 4;      /* absolute chunk range (inclusive) */
-    const int r0 = c0 / 4, r1 = c1 / 4;
-    float cs[ORC_MAXD / 16 + 2][4], e[ORC_MAXD / 16 + 2][4][4], rowcdf[ORC_MAXD / 16 + 2];
-    float run = 0.0f;
-    for (int R = r0; R <= r1; ++R) {
-        for (int g = 0; g < 4; ++g) {
-            const int c = 4 * R + g;
-            for (int r = 0; r < 4; ++r) {
-                const int k = 4 * c + r - col0;
-                e[R - r0][g][r] = (c >= c0 && c <= c1 && k < nb) ? orc_expf(l[k] - m) : 0.0f;
-            }
-            const float* q = e[R - r0][g];
-            cs[R - r0][g] = ((q[0] + q[1]) + q[2]) + q[3];
-        }
-        const float s01 = cs[R - r0][0] + cs[R - r0][1], s23 = cs[R - r0][2] + cs[R - r0][3];
-        run = run + (s01 + s23);
-        rowcdf[R - r0] = run;
-    }
-    const float t = u * run;
-    int R = r1;
-    for (int q = r0; q <= r1; ++q)
-        if (rowcdf[q - r0] > t) { R = q; break; }
-    const float base = R > r0 ? rowcdf[R - r0 - 1] : 0.0f;
-    const float* c = cs[R - r0];
-    const float s01 = c[0] + c[1];
-    const float B[4] = {base, base + c[0], base + s01, (base + s01) + c[2]};
-    int gsel = -1, glast = 0;
+    const int NL = (nb + 3) / 4;
+    float e[ORC_MAXD], T[4];
     for (int g = 0; g < 4; ++g) {
-        const int ca = 4 * R + g;
-        if (ca < c0 || ca > c1) continue;
-        glast = g;
-        if (gsel < 0 && B[g] + c[g] > t) gsel = g;
+        float acc = 0.0f;
+        for (int k = g * NL; k < (g + 1) * NL && k < nb; ++k) { e[k] = orc_expf(l[k] - m); acc = acc + e[k]; }
+        T[g] = acc;
     }
-    int k;
-    if (gsel < 0) {
-        k = 4 * (4 * R + glast) + 3 - col0;
-    } else {
-        float b = B[gsel];
-        int rsel = 3;
-        for (int r = 0; r < 4; ++r) {
-            b = b + e[R - r0][gsel][r];
-            if (b > t) { rsel = r; break; }
+    const float s01 = T[0] + T[1], s23 = T[2] + T[3];
+    const float t = u * (s01 + s23);
+    const float off[4] = {0.0f, T[0], s01, s01 + T[2]};
+    for (int g = 0; g < 4; ++g) {
+        float b = off[g];
+        for (int k = g * NL; k < (g + 1) * NL && k < nb; ++k) {
+            b = b + e[k];
+            if (b > t) return k;
         }
-        k = 4 * (4 * R + gsel) + rsel - col0;
     }
-    return k < nb ? k : nb - 1;
+    return nb - 1;
 }
 
 /* nocs/inference.py:185-188: mu = k/(nb-1)*2*vr0 - vr0, nu = k/(nb-1)*vr1, fp32 left to right

@@ -135,7 +135,7 @@ def pair_mlp(pc, nrm, feat, idxs, sd, ppffcs, out_dim, order=0):
 
 # --------------------------------------------------------------------------- decode
 def sample_bin(logits, u, col0=0):
-    """inverse-CDF draw; col0 = absolute column of logits[0] in the logit row (layout of the CDF)"""
+    """inverse-CDF draw over four consecutive segments of the bins (orc_sample_bin); col0 is unused, kept for callers"""
     logits = _c(logits, _f)
     return int(lib().orc_sample_bin(_p(logits, _pf), C.c_int(logits.size), C.c_float(float(u)), C.c_int(col0)))
 

@@ -55,7 +55,7 @@ def test_weight_packing_follows_the_documented_lane_order(golden):
     L = _lib.lib()
     dims = (C.c_int * 4)(84, 32, 32, 16)
     n = L.cppf_pair_mlp_packed_floats(40, dims, 3, 141)
-    assert n == 13152
+    assert n == 16368                                                    # 13 152 + the decode-order copy of the final layer
     packed = np.zeros(n, np.float32)
     assert L.cppf_pair_mlp_pack(params.ctypes.data, offs.ctypes.data, 40, dims, 3, 141, packed.ctypes.data) == 0
     w1, w0 = sd["res_layers.0.fc1.weight"], sd["res_layers.0.fc0.weight"]
@@ -81,6 +81,26 @@ def test_weight_packing_follows_the_documented_lane_order(golden):
         assert packed[off_wf + (s * 64 + lane) * 12 + ob] == exp
     np.testing.assert_array_equal(packed[lds_floats - 144:lds_floats - 3], sd["final.bias"])
     assert np.all(packed[lds_floats - 3:lds_floats] == 0)
+    # decode-order copy of the final layer (dec_col in csrc/pair_mlp.hip): a lane group owns consecutive bins
+    off_wfd = 13152
+    off_bfd = off_wfd + 4 * 64 * 12
+
+    def dec_col(ob, g, r):
+        if ob < 4:
+            return 32 * (ob >> 1) + 8 * g + 4 * (ob & 1) + r
+        if ob < 8:
+            return 64 + 36 * ((ob - 4) >> 1) + 9 * g + 4 * (ob & 1) + r
+        if r < 2:
+            return 64 + 36 * r + 9 * g + 8
+        q = 2 * g + (r - 2)
+        return 136 + q if q < 5 else -1
+    cols = sorted(c for ob in range(9) for g_ in range(4) for r in range(4) if (c := dec_col(ob, g_, r)) >= 0)
+    assert cols == list(range(141))                                       # a permutation of the 141 columns
+    for s, lane, ob in ((0, 0, 0), (3, 63, 8), (1, 22, 5), (2, 40, 8), (0, 15, 7)):
+        m, k = lane & 15, 16 * (s // 4) + 4 * (lane >> 4) + s % 4
+        c = dec_col(ob, m >> 2, m & 3)
+        assert packed[off_wfd + (s * 64 + lane) * 12 + ob] == (wf[c, k] if c >= 0 else 0.0)
+        assert packed[off_bfd + 16 * ob + m] == (sd["final.bias"][c] if c >= 0 else 0.0)
     # unsupported: layer wider than 128
     dims_bad = (C.c_int * 3)(84, 256, 16)
     assert L.cppf_pair_mlp_packed_floats(40, dims_bad, 2, 10) == 0
