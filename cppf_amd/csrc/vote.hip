@@ -376,6 +376,9 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
         const float ey = fmaf((fabsf(F.cc.y) + fabsf(cr.y) + fabsf(F.x.y) + fabsf(F.y.y)) * rinv, 1e-6f, 1e-3f);
         const float ez = fmaf((fabsf(F.cc.z) + fabsf(cr.z) + fabsf(F.x.z) + fabsf(F.y.z)) * rinv, 1e-6f, 1e-3f);
         const float lox = blx - ex, hix = bhx + ex, loy = bly - ey, hiy = bhy + ey, loz = blz - ez, hiz = bhz + ez;
+        // largest floats below the (positive) upper bounds
+        const float hix1 = __uint_as_float(__float_as_uint(hix) - 1u), hiy1 = __uint_as_float(__float_as_uint(hiy) - 1u),
+                    hiz1 = __uint_as_float(__float_as_uint(hiz) - 1u);
         int qhead = 0, qtail = 0;  // wave-uniform ring cursors, the ring is drained at the end of every batch
         // two rotations per trip: half the loop/scalar overhead and two independent table reads + fma chains
         // in flight (the loop is issue- and latency-bound, not bandwidth-bound); the table has a spare entry
@@ -388,8 +391,11 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
                 const float qx0 = fmaf(c0.y, yq.x, fmaf(c0.x, xq.x, cq.x)), qx1 = fmaf(c1.y, yq.x, fmaf(c1.x, xq.x, cq.x));
                 const float qy0 = fmaf(c0.y, yq.y, fmaf(c0.x, xq.y, cq.y)), qy1 = fmaf(c1.y, yq.y, fmaf(c1.x, xq.y, cq.y));
                 const float qz0 = fmaf(c0.y, yq.z, fmaf(c0.x, xq.z, cq.z)), qz1 = fmaf(c1.y, yq.z, fmaf(c1.x, xq.z, cq.z));
-                acc0 = (qx0 >= lox) & (qx0 < hix) & (qy0 >= loy) & (qy0 < hiy) & (qz0 >= loz) & (qz0 < hiz);
-                acc1 = (i + 1 < n) & (qx1 >= lox) & (qx1 < hix) & (qy1 >= loy) & (qy1 < hiy) & (qz1 >= loz) & (qz1 < hiz);
+                // lo <= q < hi as med3(q, lo, pred(hi)) == q: one SGPR-writing compare per coordinate instead of two
+                acc0 = (__builtin_amdgcn_fmed3f(qx0, lox, hix1) == qx0) & (__builtin_amdgcn_fmed3f(qy0, loy, hiy1) == qy0) &
+                       (__builtin_amdgcn_fmed3f(qz0, loz, hiz1) == qz0);
+                acc1 = (i + 1 < n) & (__builtin_amdgcn_fmed3f(qx1, lox, hix1) == qx1) &
+                       (__builtin_amdgcn_fmed3f(qy1, loy, hiy1) == qy1) & (__builtin_amdgcn_fmed3f(qz1, loz, hiz1) == qz1);
             }
             const unsigned long long m0 = __ballot(acc0), m1 = __ballot(acc1);
             if ((m0 | m1) == 0ull) continue;
