@@ -383,16 +383,18 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
         // two rotations per trip: half the loop/scalar overhead and two independent table reads + fma chains
         // in flight (the loop is issue- and latency-bound, not bandwidth-bound); the table has a spare entry
         for (int i = 0; __any(i < n); i += 2) {
-            bool acc0 = false, acc1 = false;
-            if (i < n) {
+            // every lane evaluates (no exec-masked region to leave: lanes past their n read a valid table slot -- tbase + i + 1
+            // stays inside the table and its spare entries -- and are masked by the i < n terms)
+            bool acc0, acc1;
+            {
                 float2 c0, c1;
                 if (TAB_LDS) { c0 = ltab[tbase + i]; c1 = ltab[tbase + i + 1]; }
-                else { c0 = rot_cs(i, n); c1 = rot_cs(i + 1, n); }
+                else { const int nn = n > 0 ? n : 1; c0 = rot_cs(i, nn); c1 = rot_cs(i + 1, nn); }
                 const float qx0 = fmaf(c0.y, yq.x, fmaf(c0.x, xq.x, cq.x)), qx1 = fmaf(c1.y, yq.x, fmaf(c1.x, xq.x, cq.x));
                 const float qy0 = fmaf(c0.y, yq.y, fmaf(c0.x, xq.y, cq.y)), qy1 = fmaf(c1.y, yq.y, fmaf(c1.x, xq.y, cq.y));
                 const float qz0 = fmaf(c0.y, yq.z, fmaf(c0.x, xq.z, cq.z)), qz1 = fmaf(c1.y, yq.z, fmaf(c1.x, xq.z, cq.z));
                 // lo <= q < hi as med3(q, lo, pred(hi)) == q: one SGPR-writing compare per coordinate instead of two
-                acc0 = (__builtin_amdgcn_fmed3f(qx0, lox, hix1) == qx0) & (__builtin_amdgcn_fmed3f(qy0, loy, hiy1) == qy0) &
+                acc0 = (i < n) & (__builtin_amdgcn_fmed3f(qx0, lox, hix1) == qx0) & (__builtin_amdgcn_fmed3f(qy0, loy, hiy1) == qy0) &
                        (__builtin_amdgcn_fmed3f(qz0, loz, hiz1) == qz0);
                 acc1 = (i + 1 < n) & (__builtin_amdgcn_fmed3f(qx1, lox, hix1) == qx1) &
                        (__builtin_amdgcn_fmed3f(qy1, loy, hiy1) == qy1) & (__builtin_amdgcn_fmed3f(qz1, loz, hiz1) == qz1);
