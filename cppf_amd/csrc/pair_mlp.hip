@@ -383,10 +383,13 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(A.packed);
         f32x4* dst = reinterpret_cast<f32x4*>(W);
-        for (int k = threadIdx.x; k < STD_LDS / 4; k += MLP_THREADS) dst[k] = src[k];
-        if (DECODE) {   // the final layer with its output columns in dec_col order replaces the natural one
-            for (int k = threadIdx.x; k < 4 * 64 * STD_NOBP / 4; k += MLP_THREADS) dst[OFF_WF / 4 + k] = src[OFF_WFD / 4 + k];
-            for (int k = threadIdx.x; k < 144 / 4; k += MLP_THREADS) dst[OFF_BF / 4 + k] = src[OFF_BFD / 4 + k];
+        // the decode variants take the final layer (weights and bias) from the copy whose output columns are in
+        // dec_col order; everything else is common
+        for (int k = threadIdx.x; k < STD_LDS / 4; k += MLP_THREADS) {
+            int from = k;
+            if (DECODE && k >= OFF_WF / 4 && k < OFF_B0B / 4) from = OFF_WFD / 4 + (k - OFF_WF / 4);
+            if (DECODE && k >= OFF_BF / 4) from = OFF_BFD / 4 + (k - OFF_BF / 4);
+            dst[k] = src[from];
         }
     }
     // bin -> value tables (nocs/inference.py:187-188,252,256; fp32, left to right, true division): a
