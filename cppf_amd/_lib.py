@@ -40,7 +40,7 @@ _SIGS = {
     "cppf_axis_sign": (C.c_int, [vp, vp, vp, vp, vp, i64, vp, i32, vp, vp, vp, sz, vp]),
     "cppf_scale_sum": (C.c_int, [vp, i32, vp, vp, i64, vp, vp, sz, vp]),
     "cppf_grid_setup": (C.c_int, [vp, i64, f32, vp, vp, vp]),
-    "cppf_pair_mlp_backward_workspace_bytes": (sz, [i64, i32, C.POINTER(C.c_int), i32, i32]),
+    "cppf_pair_mlp_backward_workspace_bytes": (sz, [i64, i64, i32, C.POINTER(C.c_int), i32, i32]),
     "cppf_pair_mlp_backward": (C.c_int, [vp, vp, vp, vp, i32, vp, C.POINTER(C.c_int64), i64, i32, C.POINTER(C.c_int), i32,
                                          i64, i32, vp, vp, vp, vp, sz, vp]),
     "cppf_knn": (C.c_int, [vp, vp, i32, i32, vp, vp]),

@@ -13,8 +13,11 @@
 //   3. the tile's sums are added to the wavefront's own partial-gradient slice in the workspace (no atomics);
 //      a second kernel adds the slices in a fixed two-level order (groups of 32, ascending).
 // The summation order is therefore fixed and is restated in oracle/backward_oracle.c: parameter gradients
-// are bit-identical to the oracle.  d/d(feat) uses global fp32 atomics (order-dependent rounding).
+// are bit-identical to the oracle.  d/d(feat) is a scatter-add over the pair indices: the per-pair rows d(x0)[0:80]
+// go to the workspace, the 2P (point, entry) keys are radix-sorted (stable: a-entries in pair order, then
+// b-entries), and one wavefront per point adds its rows in that order -- no atomics, deterministic, also bit-exact.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include <stdint.h>
 #include "../../include/cppf.h"
 #include "cppf_math.h"
@@ -36,7 +39,7 @@ struct BwdArgs {
     const float* params;
     const float* grad_out;
     float* parts;      // [n_parts][n_params]
-    float* grad_feat;  // [N][F], +=
+    float* dx;         // [P][2F] per-pair d(x0) feature columns (workspace)
     int64_t P;
     int64_t n_params;
     int64_t offs[20];  // 6 per res layer {fc1.w, fc1.b, fc2.w, fc2.b, fc0.w | -1, fc0.b | -1}, final.w, final.b
@@ -315,9 +318,9 @@ __global__ __launch_bounds__(64) void pair_mlp_bwd_kernel(BwdArgs A)
             bwd_lin<BW_D0, 20, BW_D1>(Pm + A.offs[0] + 20 * cc, DL + lane * BW_DSTR, t1);
             bwd_lin<BW_D0, 20, BW_D1>(Pm + A.offs[4] + 20 * cc, T, t2);
             if (live) {
-                float* dst = A.grad_feat + (size_t)(cc < 2 ? ia : ib) * BW_F + (cc & 1) * 20;
+                float* dst = A.dx + (size_t)p * (2 * BW_F) + 20 * cc;
 #pragma unroll
-                for (int c = 0; c < 20; ++c) atomicAdd(dst + c, t1[c] + t2[c]);
+                for (int c = 0; c < 20; ++c) dst[c] = t1[c] + t2[c];
             }
         }
         lds_fence();
@@ -351,6 +354,46 @@ __global__ __launch_bounds__(256) void bwd_reduce_kernel(const float* __restrict
     }
 }
 
+// ---- deterministic scatter-add of the per-pair rows into grad_feat ------------------------------------------------
+// entry e in [0, 2P): e < P is pair e's a-half (key idx[e][0]), e >= P is pair (e - P)'s b-half (key idx[e-P][1])
+__global__ __launch_bounds__(256) void bwd_keys_kernel(const void* __restrict__ idxs, int idx64, int64_t P, int32_t* __restrict__ keys,
+                                                       int32_t* __restrict__ vals)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= 2 * P) return;
+    const int64_t p = e < P ? e : e - P;
+    const int half = e < P ? 0 : 1;
+    keys[e] = idx64 ? (int32_t)reinterpret_cast<const int64_t*>(idxs)[2 * p + half]
+                    : reinterpret_cast<const int32_t*>(idxs)[2 * p + half];
+    vals[e] = (int32_t)e;
+}
+// seg[n] = first sorted position with key >= n (seg[N] = 2P)
+__global__ __launch_bounds__(256) void bwd_seg_kernel(const int32_t* __restrict__ skeys, int64_t M, int64_t N, int32_t* __restrict__ seg)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i > M) return;
+    const int64_t lo = i == 0 ? 0 : (int64_t)skeys[i - 1] + 1;
+    const int64_t hi = i == M ? N : (int64_t)skeys[i];
+    for (int64_t n = lo; n <= hi && n <= N; ++n) seg[n] = (int32_t)i;   // (every n in (key[i-1], key[i]] starts at i)
+}
+// one wavefront per point: grad_feat[n][c] += rows of its entries in sorted (= entry) order, lanes = columns
+__global__ __launch_bounds__(256) void bwd_gather_kernel(const float* __restrict__ dx, const int32_t* __restrict__ svals,
+                                                         const int32_t* __restrict__ seg, int64_t P, int64_t N,
+                                                         float* __restrict__ grad_feat)
+{
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int c = threadIdx.x & 63;
+    if (n >= N || c >= BW_F) return;
+    const int b = seg[n], e_ = seg[n + 1];
+    float acc = 0.f;
+    for (int i = b; i < e_; ++i) {
+        const int64_t e = svals[i];
+        const float* row = e < P ? dx + (size_t)e * (2 * BW_F) : dx + (size_t)(e - P) * (2 * BW_F) + BW_F;
+        acc = acc + row[c];
+    }
+    grad_feat[(size_t)n * BW_F + c] = grad_feat[(size_t)n * BW_F + c] + acc;
+}
+
 bool std_shape(int F, const int* dims, int n_res)
 {
     return F == BW_F && n_res == 3 && dims[0] == BW_D0 && dims[1] == BW_D1 && dims[2] == BW_D2 && dims[3] == BW_D3;
@@ -370,10 +413,26 @@ int n_parts_for(int64_t P) { const int64_t t = (P + 63) / 64; return (int)(t < 1
 
 extern "C" {
 
-size_t cppf_pair_mlp_backward_workspace_bytes(int64_t n_pairs, int F, const int* dims, int n_res, int out_dim)
+// workspace: [partial gradients][dx P*2F f32][keys, vals, sorted keys, sorted vals: 4 x 2P i32][seg N+1 i32][sort temp]
+struct BwdLayout { size_t parts, dx, keys, seg, temp, temp_bytes, total; };
+static BwdLayout bwd_layout(int64_t n_pairs, int64_t n_points, const int* dims, int n_res, int out_dim)
 {
-    if (!dims || n_pairs < 0 || !std_shape(F, dims, n_res) || out_dim < 1) return 0;
-    return (size_t)n_parts_for(n_pairs) * (size_t)count_params(dims, n_res, out_dim) * sizeof(float);
+    BwdLayout L;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    L.parts = 0;
+    L.dx = up((size_t)n_parts_for(n_pairs) * (size_t)count_params(dims, n_res, out_dim) * sizeof(float));
+    L.keys = L.dx + up((size_t)n_pairs * 2 * BW_F * sizeof(float));
+    L.seg = L.keys + up((size_t)8 * n_pairs * sizeof(int32_t));
+    L.temp = L.seg + up((size_t)(n_points + 1) * sizeof(int32_t));
+    L.temp_bytes = up((size_t)64 * n_pairs + (1u << 20));   // generous bound for the radix sort's scratch (checked at run time)
+    L.total = L.temp + L.temp_bytes;
+    return L;
+}
+
+size_t cppf_pair_mlp_backward_workspace_bytes(int64_t n_pairs, int64_t n_points, int F, const int* dims, int n_res, int out_dim)
+{
+    if (!dims || n_pairs < 0 || n_points < 0 || !std_shape(F, dims, n_res) || out_dim < 1) return 0;
+    return bwd_layout(n_pairs, n_points, dims, n_res, out_dim).total;
 }
 
 int cppf_pair_mlp_backward(const float* pc, const float* nrm, const float* feat, const void* idxs, int idx_is_i64,
@@ -381,7 +440,7 @@ int cppf_pair_mlp_backward(const float* pc, const float* nrm, const float* feat,
                            int64_t n_pairs, int out_dim, const float* grad_out, float* grad_params, float* grad_feat,
                            void* workspace, size_t workspace_bytes, void* stream)
 {
-    if (n_pairs < 0 || n_points < 0 || !dims || !offs || out_dim < 1) return CPPF_EINVAL;
+    if (n_pairs < 0 || n_points < 0 || !dims || !offs || out_dim < 1 || n_pairs > 0x3fffffffll) return CPPF_EINVAL;
     if (!std_shape(F, dims, n_res)) return CPPF_EUNSUPPORTED;
     if (!grad_params) return CPPF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -389,17 +448,34 @@ int cppf_pair_mlp_backward(const float* pc, const float* nrm, const float* feat,
     if (n_pairs == 0) return (int)hipMemsetAsync(grad_params, 0, n_params * sizeof(float), st);
     if (!pc || !nrm || !feat || !idxs || !params || !grad_out || !grad_feat) return CPPF_EINVAL;
     const int n_parts = n_parts_for(n_pairs);
-    const size_t need = (size_t)n_parts * n_params * sizeof(float);
-    if (!workspace || workspace_bytes < need) return CPPF_EWORKSPACE;
-    hipError_t e = hipMemsetAsync(workspace, 0, need, st);
+    const BwdLayout Lw = bwd_layout(n_pairs, n_points, dims, n_res, out_dim);
+    if (!workspace || workspace_bytes < Lw.total) return CPPF_EWORKSPACE;
+    char* ws = static_cast<char*>(workspace);
+    hipError_t e = hipMemsetAsync(ws + Lw.parts, 0, (size_t)n_parts * n_params * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
     BwdArgs A;
     A.pc = pc; A.nrm = nrm; A.feat = feat; A.idxs = idxs; A.params = params; A.grad_out = grad_out;
-    A.parts = (float*)workspace; A.grad_feat = grad_feat; A.P = n_pairs; A.n_params = n_params;
+    A.parts = (float*)(ws + Lw.parts); A.dx = (float*)(ws + Lw.dx); A.P = n_pairs; A.n_params = n_params;
     for (int i = 0; i < 20; ++i) A.offs[i] = offs[i];
     A.out_dim = out_dim; A.idx64 = idx_is_i64; A.n_parts = n_parts;
     pair_mlp_bwd_kernel<<<n_parts, 64, 0, st>>>(A);
-    bwd_reduce_kernel<<<(int)((n_params + 63) / 64), 256, 0, st>>>((const float*)workspace, n_parts, n_params, grad_params);
+    bwd_reduce_kernel<<<(int)((n_params + 63) / 64), 256, 0, st>>>(A.parts, n_parts, n_params, grad_params);
+    // d/d(feat): stable sort of the 2P (point, entry) keys, segment starts, ordered row sums
+    const int64_t M = 2 * n_pairs;
+    int32_t* keys = (int32_t*)(ws + Lw.keys);
+    int32_t *vals = keys + M, *skeys = keys + 2 * M, *svals = keys + 3 * M, *seg = (int32_t*)(ws + Lw.seg);
+    bwd_keys_kernel<<<(int)((M + 255) / 256), 256, 0, st>>>(idxs, idx_is_i64, n_pairs, keys, vals);
+    int end_bit = 1;
+    while (end_bit < 31 && (1ll << end_bit) < n_points) ++end_bit;
+    size_t need = 0;
+    e = hipcub::DeviceRadixSort::SortPairs(nullptr, need, keys, skeys, vals, svals, (int)M, 0, end_bit, st);
+    if (e != hipSuccess) return (int)e;
+    if (need > Lw.temp_bytes) return CPPF_EWORKSPACE;
+    need = Lw.temp_bytes;
+    e = hipcub::DeviceRadixSort::SortPairs(ws + Lw.temp, need, keys, skeys, vals, svals, (int)M, 0, end_bit, st);
+    if (e != hipSuccess) return (int)e;
+    bwd_seg_kernel<<<(int)((M + 256) / 256), 256, 0, st>>>(skeys, M, n_points, seg);
+    bwd_gather_kernel<<<(int)((n_points + 3) / 4), 256, 0, st>>>(A.dx, svals, seg, n_pairs, n_points, grad_feat);
     return (int)hipGetLastError();
 }
 

@@ -84,7 +84,7 @@ class _PairMlpFunction(torch.autograd.Function):
         grad_out = grad_out.detach().float().contiguous()
         gp = torch.empty_like(flat)
         gf = torch.zeros((feat.shape[0], F_), dtype=torch.float32, device=dev)
-        need = L.cppf_pair_mlp_backward_workspace_bytes(P, F_, dims, len(enc.ppffcs) - 1, enc.out_dim)
+        need = L.cppf_pair_mlp_backward_workspace_bytes(P, feat.shape[0], F_, dims, len(enc.ppffcs) - 1, enc.out_dim)
         ws = workspace(max(int(need), 256), dev, "pair_mlp_bwd")
         pcc, nrmc, featc = (pc.detach().float().contiguous(), nrm.detach().float().contiguous(),
                             feat.detach().float().contiguous())

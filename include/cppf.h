@@ -250,13 +250,16 @@ int cppf_point_encoder_forward(const float* pc, const float* nrm, const int32_t*
  *   offs         HOST i64[6*n_res+2]: offset of each of those tensors in `params` (-1 for an absent fc0)
  *   grad_out     device f32[n_pairs, out_dim]  (dL/dlogits)
  *   grad_params  device f32, same layout as `params`, OVERWRITTEN
- *   grad_feat    device f32[n_points, F], ACCUMULATED (+=, fp32 atomics; zero it first for a plain gradient)
+ *   grad_feat    device f32[n_points, F], ACCUMULATED (+=; zero it first for a plain gradient)
  * One wavefront per tile of 64 pairs recomputes the forward, back-propagates lane-locally and adds the tile's
  * outer products to one of min(ceil(n_pairs/64), CPPF_BWD_MAX_PARTS) partial gradients in the workspace; the
  * partials are then added in a fixed two-level order, so grad_params is deterministic (oracle/backward_oracle.c).
+ * grad_feat is deterministic too: the per-pair rows go to the workspace, the 2*n_pairs (point, entry) keys are radix
+ * sorted (stable) and every point adds its rows in pair order, a-halves first -- no atomics anywhere.
  * ------------------------------------------------------------------------------------------- */
 #define CPPF_BWD_MAX_PARTS 1024
-size_t cppf_pair_mlp_backward_workspace_bytes(int64_t n_pairs, int F, const int* dims, int n_res, int out_dim);
+size_t cppf_pair_mlp_backward_workspace_bytes(int64_t n_pairs, int64_t n_points, int F, const int* dims, int n_res,
+                                              int out_dim);
 int cppf_pair_mlp_backward(const float* pc, const float* nrm, const float* feat, const void* idxs, int idx_is_i64,
                            const float* params, const int64_t* offs, int64_t n_points, int F, const int* dims, int n_res,
                            int64_t n_pairs, int out_dim, const float* grad_out, float* grad_params, float* grad_feat,

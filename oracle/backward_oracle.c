@@ -19,8 +19,9 @@
  *   - per tile and weight W[o][i]:  tile_sum = chain over the tile's pairs j ascending of
  *       fmaf(delta_o(j), x_i(j), .) from 0;  part[w] = part[w] + tile_sum  (biases: plain adds of delta_o(j));
  *   - grad = sum over groups of 32 consecutive parts (ascending) of the group's own ascending sum.
- *   grad_feat is a scatter-add (atomics on the device, any order): accumulated here in double over the
- *   per-pair fp32 contributions and compared with a tolerance.
+ *   - grad_feat[n] = sequential fp32 sum (from 0) of the per-pair rows d(x0)[0:F] of every pair with a == n in
+ *     ascending pair order, then of the rows d(x0)[F:2F] of every pair with b == n in ascending pair order (the
+ *     device sorts the 2P (point, entry) keys stably and adds in that order).
  */
 #include <math.h>
 #include <stdint.h>
@@ -69,13 +70,12 @@ int orc_pair_mlp_backward(const float* pc, const float* nrm, const float* feat, 
     const int64_t n_tiles = (P + BW_TILE - 1) / BW_TILE;
     if (n_parts < 1) return -1;
     float* parts = calloc((size_t)n_parts * n_params, sizeof(float));
-    double* gf = calloc((size_t)N * F, sizeof(double));
+    float* dxall = malloc(sizeof(float) * (size_t)(P > 0 ? P : 1) * 2 * F);
     const int KL = dims[n_res];
 
 #pragma omp parallel
     {
         pair_state* S = malloc(sizeof(pair_state) * BW_TILE);
-        double* gf_local = calloc((size_t)N * F, sizeof(double));
 #pragma omp for schedule(dynamic, 1)
         for (int w = 0; w < n_parts; ++w) {
             float* part = parts + (size_t)w * n_params;
@@ -121,10 +121,8 @@ int orc_pair_mlp_backward(const float* pc, const float* nrm, const float* feat, 
                             for (int i = 0; i < K; ++i) s->dy[l][i] = t1[i] + s->dy[l + 1][i];
                         }
                     }
-                    for (int c = 0; c < F; ++c) {
-                        gf_local[a * F + c] += (double)s->dy[0][c];
-                        gf_local[b * F + c] += (double)s->dy[0][F + c];
-                    }
+                    (void)a; (void)b;
+                    memcpy(dxall + (size_t)p * 2 * F, s->dy[0], sizeof(float) * 2 * F);
                 }
                 /* weight gradients of this tile, then part += tile_sum */
 #define OUTER(OFFW, OFFB, DELTA, XIN, O_, I_)                                                          \
@@ -165,9 +163,7 @@ int orc_pair_mlp_backward(const float* pc, const float* nrm, const float* feat, 
                 }
             }
         }
-#pragma omp critical
-        for (size_t q = 0; q < (size_t)N * F; ++q) gf[q] += gf_local[q];
-        free(S); free(gf_local);
+        free(S);
     }
     for (int64_t q = 0; q < n_params; ++q) {
         float acc = 0.f;
@@ -178,7 +174,13 @@ int orc_pair_mlp_backward(const float* pc, const float* nrm, const float* feat, 
         }
         grad_params[q] = acc;
     }
-    for (size_t q = 0; q < (size_t)N * F; ++q) grad_feat[q] = (float)gf[q];
-    free(parts); free(gf);
+    for (size_t q = 0; q < (size_t)N * F; ++q) grad_feat[q] = 0.f;
+    for (int half = 0; half < 2; ++half)
+        for (int64_t p = 0; p < P; ++p) {
+            float* g = grad_feat + idxs[2 * p + half] * F;
+            const float* row = dxall + (size_t)p * 2 * F + (size_t)half * F;
+            for (int c = 0; c < F; ++c) g[c] = g[c] + row[c];
+        }
+    free(parts); free(dxall);
     return 0;
 }

@@ -210,10 +210,12 @@ def test_point_encoder_and_backward_abi_without_a_device(golden):
     assert L.cppf_point_encoder_forward(one, one, one, 10, 3, one, hid, 4, 32, 2, 32, 8, 1, one, None, 0, None) == -2
     assert L.cppf_point_encoder_forward(one, one, one, 100, 65, one, hid, 4, 32, 2, 32, 8, 1, one, one, 1 << 20, None) == -3
     dims = (C.c_int * 4)(84, 32, 32, 16)
-    assert L.cppf_pair_mlp_backward_workspace_bytes(200000, 40, dims, 3, 141) == 1024 * 12333 * 4
-    assert L.cppf_pair_mlp_backward_workspace_bytes(130, 40, dims, 3, 141) == 3 * 12333 * 4
+    # partial gradients + per-pair d(x0) rows + sort keys/values + segment starts + sort scratch
+    need = L.cppf_pair_mlp_backward_workspace_bytes(200000, 4096, 40, dims, 3, 141)
+    assert 1024 * 12333 * 4 + 200000 * 80 * 4 + 8 * 200000 * 4 <= need < 1024 * 12333 * 4 + 200000 * 80 * 4 + 100 * 200000
+    assert L.cppf_pair_mlp_backward_workspace_bytes(130, 64, 40, dims, 3, 141) >= 3 * 12333 * 4 + 130 * 80 * 4
     other = (C.c_int * 3)(44, 24, 24)
-    assert L.cppf_pair_mlp_backward_workspace_bytes(130, 20, other, 2, 10) == 0
+    assert L.cppf_pair_mlp_backward_workspace_bytes(130, 64, 20, other, 2, 10) == 0
     offs = (C.c_int64 * 20)(*range(20))
     assert L.cppf_pair_mlp_backward(one, one, one, one, 1, one, offs, 10, 20, other, 2, 5, 10, one, one, one, one, 1 << 20,
                                     None) == -3

@@ -38,7 +38,7 @@ def test_backward_matches_reference_autograd_and_oracle(dev, oracle, golden):
         ref = z["grad." + name]
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=0, atol=2e-5 * np.abs(ref).max())
     np.testing.assert_allclose(gf, z["grad_feat"], rtol=0, atol=2e-5 * np.abs(z["grad_feat"]).max())
-    np.testing.assert_allclose(gf, gf_o, rtol=0, atol=2e-6 * np.abs(gf_o).max())             # fp32 atomics vs fp64 sums
+    assert np.array_equal(gf, gf_o)                                                          # sorted scatter: bit-exact too
 
 
 @pytest.mark.parametrize("n,p,out_dim,i32", [(2048, 20000, 141, False), (1500, 70001, 141, True), (512, 4097, 9, False)])
@@ -59,7 +59,7 @@ def test_backward_bit_exact_vs_oracle_at_size(dev, oracle, n, p, out_dim, i32):
     _, gf = _run(enc, dev, pc, nrm, feat, it, R)
     _, gf_o, flat_o = oracle.pair_mlp_backward(pc, nrm, feat, idxs, sd, PPFFCS, out_dim, R)
     assert np.array_equal(_flat_grads(enc), flat_o)
-    np.testing.assert_allclose(gf, gf_o, rtol=0, atol=1e-5 * np.abs(gf_o).max())
+    assert np.array_equal(gf, gf_o)
     # and against torch's own autograd through the composite of the same module, on the device
     enc2 = PPFEncoder(PPFFCS, out_dim)
     enc2.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
