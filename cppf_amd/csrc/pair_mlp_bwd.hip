@@ -28,8 +28,7 @@ namespace {
 
 constexpr int BW_F = 40, BW_D0 = 84, BW_D1 = 32, BW_D2 = 32, BW_D3 = 16;
 constexpr int BW_DSTR = 36;  // delta rows in LDS (16-byte aligned rows: broadcast ds_read_b128)
-constexpr int BW_XSTR = 85;  // input rows in LDS (odd stride: conflict-free row writes)
-constexpr int BW_RSTR = 33;  // the lane's own delta / transient row
+constexpr int BW_XSTR = 43;  // input rows in LDS (odd stride: conflict-free row writes); x0 is staged in two halves of 42
 
 struct BwdArgs {
     const float* pc;
@@ -107,9 +106,11 @@ __device__ __forceinline__ void stage(float* __restrict__ L, int stride, int lan
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // part[offW + o*I + i] += sum_j delta[j][o] * x[j][i];  part[offB + o] += sum_j delta[j][o]   (j ascending)
-template <int O, int I>
+// I columns of a weight whose rows are ISTR long, starting at column col0 (XL holds just those columns); BIAS: also
+// the bias gradient
+template <int O, int I, int ISTR = I, bool BIAS = true>
 __device__ __forceinline__ void outer(const float* __restrict__ DL, const float* __restrict__ XL, float* __restrict__ part,
-                                      int64_t offW, int64_t offB, int lane)
+                                      int64_t offW, int64_t offB, int lane, int col0 = 0)
 {
     lds_fence();
     constexpr int PASSES = (I + 63) / 64;
@@ -135,10 +136,10 @@ __device__ __forceinline__ void outer(const float* __restrict__ DL, const float*
         }
         if (act) {
 #pragma unroll
-            for (int o = 0; o < O; ++o) part[offW + (int64_t)o * I + i] = part[offW + (int64_t)o * I + i] + acc[o];
+            for (int o = 0; o < O; ++o) part[offW + (int64_t)o * ISTR + col0 + i] = part[offW + (int64_t)o * ISTR + col0 + i] + acc[o];
         }
     }
-    if (lane < O) {
+    if (BIAS && lane < O) {
         float accb = 0.f;
 #pragma unroll 4
         for (int j = 0; j < 64; ++j) accb = accb + DL[j * BW_DSTR + lane];
@@ -160,11 +161,10 @@ __device__ __forceinline__ void ppf4(const float* __restrict__ pc, const float* 
     out[3] = d;
 }
 
-__global__ __launch_bounds__(64) void pair_mlp_bwd_kernel(BwdArgs A)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void pair_mlp_bwd_kernel(BwdArgs A)
 {
     __shared__ __attribute__((aligned(16))) float DL[64 * BW_DSTR];
     __shared__ float XL[64 * BW_XSTR];
-    __shared__ float DR[64 * BW_RSTR];
     const int lane = threadIdx.x;
     const int w = blockIdx.x;
     float* part = A.parts + (size_t)w * A.n_params;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64) void pair_mlp_bwd_kernel(BwdArgs A)
         // ---- forward (natural order); x0 is gathered again when it is staged for the layer-0 outer products
         float h0[BW_D1], x1[BW_D1], h1[BW_D2], x2[BW_D2], h2[BW_D3], x3[BW_D3], ppf[4];
         ppf4(A.pc, A.nrm, ia, ib, ppf);
-        float* const T = DR + lane * BW_RSTR;     // the lane's own LDS row: matvec outputs, then its deltas
+        float* const T = DL + lane * BW_DSTR;     // the lane's own LDS row: matvec outputs, then its deltas
         {
             float x0[BW_D0];
 #pragma unroll
@@ -269,14 +269,14 @@ __global__ __launch_bounds__(64) void pair_mlp_bwd_kernel(BwdArgs A)
         lds_fence();
         // ---- res layer 2 (32 -> 16, fc0): deltas dy3 (wrt x3), dh2
         float dh2[BW_D3], dy2[BW_D2];
-        stage(DL, BW_DSTR, lane, dy3); stage(DR, BW_RSTR, lane, dy3); stage(XL, BW_XSTR, lane, h2);
+        stage(DL, BW_DSTR, lane, dy3); stage(XL, BW_XSTR, lane, h2);
         lds_fence();
         bwd_lin<BW_D3, BW_D3, BW_D3>(Pm + A.offs[14], T, dh2); mask(dh2, h2);
         bwd_lin<BW_D2, BW_D2, BW_D3>(Pm + A.offs[16], T, dy2);                      // fc0 path of d(x2)
         outer<BW_D3, BW_D3>(DL, XL, part, A.offs[14], A.offs[15], lane);            // fc2: dy3 x h2
         stage(XL, BW_XSTR, lane, x2);
         outer<BW_D3, BW_D2>(DL, XL, part, A.offs[16], A.offs[17], lane);            // fc0: dy3 x x2
-        stage(DL, BW_DSTR, lane, dh2); stage(DR, BW_RSTR, lane, dh2);
+        stage(DL, BW_DSTR, lane, dh2);
         lds_fence();
         {
             float t1[BW_D2];
@@ -287,11 +287,11 @@ __global__ __launch_bounds__(64) void pair_mlp_bwd_kernel(BwdArgs A)
         outer<BW_D3, BW_D2>(DL, XL, part, A.offs[12], A.offs[13], lane);            // fc1: dh2 x x2
         // ---- res layer 1 (32 -> 32, identity skip): deltas dy2 (wrt x2), dh1
         float dh1[BW_D2], dy1[BW_D1];
-        stage(DL, BW_DSTR, lane, dy2); stage(DR, BW_RSTR, lane, dy2); stage(XL, BW_XSTR, lane, h1);
+        stage(DL, BW_DSTR, lane, dy2); stage(XL, BW_XSTR, lane, h1);
         lds_fence();
         bwd_lin<BW_D2, BW_D2, BW_D2>(Pm + A.offs[8], T, dh1); mask(dh1, h1);
         outer<BW_D2, BW_D2>(DL, XL, part, A.offs[8], A.offs[9], lane);              // fc2: dy2 x h1
-        stage(DL, BW_DSTR, lane, dh1); stage(DR, BW_RSTR, lane, dh1); stage(XL, BW_XSTR, lane, x1);
+        stage(DL, BW_DSTR, lane, dh1); stage(XL, BW_XSTR, lane, x1);
         lds_fence();
         bwd_lin<BW_D1, BW_D1, BW_D2>(Pm + A.offs[6], T, dy1);
 #pragma unroll
@@ -299,28 +299,45 @@ __global__ __launch_bounds__(64) void pair_mlp_bwd_kernel(BwdArgs A)
         outer<BW_D2, BW_D1>(DL, XL, part, A.offs[6], A.offs[7], lane);              // fc1: dh1 x x1
         // ---- res layer 0 (84 -> 32, fc0): deltas dy1 (wrt x1), dh0
         float dh0[BW_D1];
-        stage(DL, BW_DSTR, lane, dy1); stage(DR, BW_RSTR, lane, dy1); stage(XL, BW_XSTR, lane, h0);
+        stage(DL, BW_DSTR, lane, dy1); stage(XL, BW_XSTR, lane, h0);
         lds_fence();
         bwd_lin<BW_D1, BW_D1, BW_D1>(Pm + A.offs[2], T, dh0); mask(dh0, h0);
         outer<BW_D1, BW_D1>(DL, XL, part, A.offs[2], A.offs[3], lane);              // fc2: dy1 x h0
-        for (int c = 0; c < BW_F; ++c) {
-            XL[lane * BW_XSTR + c] = A.feat[(size_t)ia * BW_F + c];
-            XL[lane * BW_XSTR + BW_F + c] = A.feat[(size_t)ib * BW_F + c];
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) XL[lane * BW_XSTR + 2 * BW_F + c] = ppf[c];
-        outer<BW_D1, BW_D0>(DL, XL, part, A.offs[4], A.offs[5], lane);              // fc0: dy1 x x0
-        stage(DL, BW_DSTR, lane, dh0);                                              // (the lane's row T keeps dy1)
-        outer<BW_D1, BW_D0>(DL, XL, part, A.offs[0], A.offs[1], lane);              // fc1: dh0 x x0
-        // ---- d/d(feat): the 80 feature columns of d(x0) = W1^T dh0 + W0^T dy1, 20 columns at a time
+        // d/d(feat) = the 80 feature columns of d(x0) = W1^T dh0 + W0^T dy1: the W0 term now (T holds dy1), 20 columns at
+        // a time, parked in the pair's workspace row; the W1 term is added to it once T holds dh0
+        float* const dxrow = A.dx + (size_t)pcl * (2 * BW_F);
         for (int cc = 0; cc < 4; ++cc) {
-            float t1[20], t2[20];
-            bwd_lin<BW_D0, 20, BW_D1>(Pm + A.offs[0] + 20 * cc, DL + lane * BW_DSTR, t1);
+            float t2[20];
             bwd_lin<BW_D0, 20, BW_D1>(Pm + A.offs[4] + 20 * cc, T, t2);
             if (live) {
-                float* dst = A.dx + (size_t)p * (2 * BW_F) + 20 * cc;
 #pragma unroll
-                for (int c = 0; c < 20; ++c) dst[c] = t1[c] + t2[c];
+                for (int c = 0; c < 20; ++c) dxrow[20 * cc + c] = t2[c];
+            }
+        }
+        // x0 = [feat[a] (40), feat[b] (40), ppf (4)] is staged 42 columns at a time
+        auto stage_x0 = [&](int half) {
+            lds_fence();
+            for (int c = 0; c < 42; ++c) {
+                const int col = 42 * half + c;
+                XL[lane * BW_XSTR + c] = col < BW_F ? A.feat[(size_t)ia * BW_F + col]
+                                         : (col < 2 * BW_F ? A.feat[(size_t)ib * BW_F + col - BW_F]
+                                                           : (col == 80 ? ppf[0] : (col == 81 ? ppf[1] : (col == 82 ? ppf[2] : ppf[3]))));
+            }
+        };
+        stage_x0(0);
+        outer<BW_D1, 42, BW_D0, true>(DL, XL, part, A.offs[4], A.offs[5], lane, 0);   // fc0: dy1 x x0[0:42], bias
+        stage_x0(1);
+        outer<BW_D1, 42, BW_D0, false>(DL, XL, part, A.offs[4], A.offs[5], lane, 42); // fc0: dy1 x x0[42:84]
+        stage(DL, BW_DSTR, lane, dh0);                                               // T now holds dh0
+        outer<BW_D1, 42, BW_D0, true>(DL, XL, part, A.offs[0], A.offs[1], lane, 42);  // fc1: dh0 x x0[42:84], bias
+        stage_x0(0);
+        outer<BW_D1, 42, BW_D0, false>(DL, XL, part, A.offs[0], A.offs[1], lane, 0);  // fc1: dh0 x x0[0:42]
+        for (int cc = 0; cc < 4; ++cc) {
+            float t1[20];
+            bwd_lin<BW_D0, 20, BW_D1>(Pm + A.offs[0] + 20 * cc, T, t1);
+            if (live) {
+#pragma unroll
+                for (int c = 0; c < 20; ++c) dxrow[20 * cc + c] = t1[c] + dxrow[20 * cc + c];
             }
         }
         lds_fence();
@@ -328,12 +345,12 @@ __global__ __launch_bounds__(64) void pair_mlp_bwd_kernel(BwdArgs A)
 }
 
 // grad[q] = sum over groups of 32 consecutive partials (ascending) of the group's sum (ascending): a fixed
-// two-level order (oracle/backward_oracle.c), 32 + 32 dependent adds instead of 1 024.
+// two-level order (oracle/backward_oracle.c), 32 + 64 dependent adds instead of 2 048.
 constexpr int BW_GROUP = 32;
 __global__ __launch_bounds__(256) void bwd_reduce_kernel(const float* __restrict__ parts, int n_parts, int64_t n_params,
                                                          float* __restrict__ grad)
 {
-    __shared__ float gs[BW_GROUP][64];
+    __shared__ float gs[(CPPF_BWD_MAX_PARTS + BW_GROUP - 1) / BW_GROUP][64];
     const int qi = threadIdx.x & 63, slot = threadIdx.x >> 6;
     const int64_t q = (int64_t)blockIdx.x * 64 + qi;
     const int n_groups = (n_parts + BW_GROUP - 1) / BW_GROUP;
@@ -407,7 +424,15 @@ int64_t count_params(const int* dims, int n_res, int out_dim)
     }
     return n + (int64_t)out_dim * dims[n_res] + out_dim;
 }
-int n_parts_for(int64_t P) { const int64_t t = (P + 63) / 64; return (int)(t < 1 ? 1 : (t > CPPF_BWD_MAX_PARTS ? CPPF_BWD_MAX_PARTS : t)); }
+// number of partial accumulators = wavefronts: every wavefront gets the same number of tiles (+-1), at most
+// CPPF_BWD_MAX_PARTS of them
+int n_parts_for(int64_t P)
+{
+    const int64_t t = (P + 63) / 64;
+    if (t <= 1) return 1;
+    const int64_t per = (t + CPPF_BWD_MAX_PARTS - 1) / CPPF_BWD_MAX_PARTS;
+    return (int)((t + per - 1) / per);
+}
 
 }  // namespace
 

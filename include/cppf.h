@@ -252,12 +252,12 @@ int cppf_point_encoder_forward(const float* pc, const float* nrm, const int32_t*
  *   grad_params  device f32, same layout as `params`, OVERWRITTEN
  *   grad_feat    device f32[n_points, F], ACCUMULATED (+=; zero it first for a plain gradient)
  * One wavefront per tile of 64 pairs recomputes the forward, back-propagates lane-locally and adds the tile's
- * outer products to one of min(ceil(n_pairs/64), CPPF_BWD_MAX_PARTS) partial gradients in the workspace; the
+ * outer products to one of at most CPPF_BWD_MAX_PARTS partial gradients in the workspace (tiles dealt evenly); the
  * partials are then added in a fixed two-level order, so grad_params is deterministic (oracle/backward_oracle.c).
  * grad_feat is deterministic too: the per-pair rows go to the workspace, the 2*n_pairs (point, entry) keys are radix
  * sorted (stable) and every point adds its rows in pair order, a-halves first -- no atomics anywhere.
  * ------------------------------------------------------------------------------------------- */
-#define CPPF_BWD_MAX_PARTS 1024
+#define CPPF_BWD_MAX_PARTS 2048
 size_t cppf_pair_mlp_backward_workspace_bytes(int64_t n_pairs, int64_t n_points, int F, const int* dims, int n_res,
                                               int out_dim);
 int cppf_pair_mlp_backward(const float* pc, const float* nrm, const float* feat, const void* idxs, int idx_is_i64,

@@ -400,12 +400,17 @@ def point_encoder(pc, nrm, nbrs, packed, desc, order=0):
 
 
 # --------------------------------------------------------------------------- backward of the pair MLP (row f2)
-BWD_MAX_PARTS = 1024
+BWD_MAX_PARTS = 2048
 
 
 def bwd_parts(P):
-    """number of partial accumulators the device kernel uses for P pairs (cppf.h: CPPF_BWD_MAX_PARTS)"""
-    return max(1, min((P + 63) // 64, BWD_MAX_PARTS))
+    """number of partial accumulators the device kernel uses for P pairs (cppf.h: CPPF_BWD_MAX_PARTS): every
+    wavefront gets the same number of 64-pair tiles (+-1)"""
+    t = (P + 63) // 64
+    if t <= 1:
+        return 1
+    per = (t + BWD_MAX_PARTS - 1) // BWD_MAX_PARTS
+    return (t + per - 1) // per
 
 
 def pair_mlp_backward(pc, nrm, feat, idxs, sd, ppffcs, out_dim, grad_out, n_parts=None):

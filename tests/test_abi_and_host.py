@@ -212,7 +212,8 @@ def test_point_encoder_and_backward_abi_without_a_device(golden):
     dims = (C.c_int * 4)(84, 32, 32, 16)
     # partial gradients + per-pair d(x0) rows + sort keys/values + segment starts + sort scratch
     need = L.cppf_pair_mlp_backward_workspace_bytes(200000, 4096, 40, dims, 3, 141)
-    assert 1024 * 12333 * 4 + 200000 * 80 * 4 + 8 * 200000 * 4 <= need < 1024 * 12333 * 4 + 200000 * 80 * 4 + 110 * 200000
+    parts = 1563                                                          # 3 125 tiles, two per wavefront
+    assert parts * 12333 * 4 + 200000 * 80 * 4 + 8 * 200000 * 4 <= need < parts * 12333 * 4 + 200000 * 80 * 4 + 110 * 200000
     assert L.cppf_pair_mlp_backward_workspace_bytes(130, 64, 40, dims, 3, 141) >= 3 * 12333 * 4 + 130 * 80 * 4
     other = (C.c_int * 3)(44, 24, 24)
     assert L.cppf_pair_mlp_backward_workspace_bytes(130, 64, 20, other, 2, 10) == 0
