@@ -187,7 +187,7 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_kernel(const float* __rest
 }
 
 // --------------------------------------------------------------------------------------------- conv
-constexpr int SP_WAVES = 4;   // points per workgroup
+constexpr int SP_WAVES_MAX = 8;   // points per workgroup: 8 when the per-wave LDS is small (first layer), else 4
 constexpr int SP_RANK = 32, SP_NOUT = 32;
 constexpr int SP_KSTRIDE = SP_RANK + 1;  // kern[j][r] row stride in LDS (odd: conflict-free column walks)
 
@@ -261,7 +261,8 @@ __device__ __forceinline__ void sp_ln_relu4(f32x4 (&y)[NOB], const float* __rest
 
 __device__ __forceinline__ float norm3(float x, float y, float z) { return sqrtf((x * x + y * y) + z * z); }
 
-__host__ __device__ constexpr int sp_per_wave(int n_in) { return 64 * SP_KSTRIDE + 64 * n_in + SP_RANK * n_in + 64 * 3 + SP_NOUT + 64 * 8; }
+__host__ __device__ constexpr int sp_per_wave(int n_in) { return 16 * SP_KSTRIDE + 64 * n_in + SP_RANK * n_in + 64 * 3 + SP_NOUT + 64 * 8; }
+__host__ __device__ constexpr int sp_waves(int n_in) { return n_in <= 4 ? SP_WAVES_MAX : 4; }
 
 struct ConvArgs {
     const float* pc;
@@ -275,8 +276,8 @@ struct ConvArgs {
 };
 
 // hidden = {32, 64, 32, 32}, rank 32, n_out 32 (train.py:34).  Dynamic LDS: the workgroup's weight image
-// (SPW_FLOATS), then per wave  kern[64][33] | nf[64][n_in] | contracted[32*n_in] | r[64][3] | y[32] | x6[64][8]
-__global__ __launch_bounds__(SP_WAVES * 64) void sprin_conv_kernel(ConvArgs A)
+// (SPW_FLOATS), then per wave  kern[16][33] | nf[64][n_in] | contracted[32*n_in] | r[64][3] | y[32] | x6[64][8]
+__global__ __launch_bounds__(SP_WAVES_MAX * 64) void sprin_conv_kernel(ConvArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float sp_lds[];
     const int w = threadIdx.x >> 6, lane = lane_id();
@@ -284,14 +285,14 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sprin_conv_kernel(ConvArgs A)
     const int per_wave = sp_per_wave(n_in);
     float* Wl = sp_lds;                                   // 16-byte aligned image
     float* kern = sp_lds + SPW_FLOATS + (size_t)w * per_wave;
-    float* nf = kern + 64 * SP_KSTRIDE;
+    float* nf = kern + 16 * SP_KSTRIDE;
     float* contracted = nf + 64 * n_in;
     float* rr = contracted + SP_RANK * n_in;
     float* yv = rr + 64 * 3;
     float* x6l = yv + SP_NOUT;
-    for (int i = threadIdx.x; i < SPW_FLOATS / 4; i += SP_WAVES * 64)
+    for (int i = threadIdx.x; i < SPW_FLOATS / 4; i += blockDim.x)
         reinterpret_cast<f32x4*>(Wl)[i] = reinterpret_cast<const f32x4*>(A.wimg)[i];
-    const int n = blockIdx.x * SP_WAVES + w;
+    const int n = blockIdx.x * (blockDim.x >> 6) + w;
     const bool live = n < A.N;
     const int nc = live ? n : A.N - 1;
     const int jc = lane < k ? lane : k - 1;
@@ -353,19 +354,22 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sprin_conv_kernel(ConvArgs A)
 #pragma unroll
             for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) kern[(16 * rb + j) * SP_KSTRIDE + 16 * ob + 4 * g + r] = kr[ob][r];
+                for (int r = 0; r < 4; ++r) kern[j * SP_KSTRIDE + 16 * ob + 4 * g + r] = kr[ob][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes, before other lanes read them
+            // einsum("bnkr,bnki->bnri") (models/sprin.py:99): contracted[r*n_in + i] accumulates these 16 neighbours,
+            // sequentially and in neighbour order across the row blocks
+            const int jn = min(16, k - 16 * rb);
+            for (int t = lane; t < SP_RANK * n_in; t += 64) {
+                const int r = t / n_in, i = t - r * n_in;
+                float acc = rb == 0 ? 0.f : contracted[t];
+                for (int jj = 0; jj < jn; ++jj) acc = fmaf(kern[jj * SP_KSTRIDE + r], nf[(16 * rb + jj) * n_in + i], acc);
+                contracted[t] = acc;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
     const float* p = A.params + SP_NAT_KERNEL;   // outnet parameters follow the kernel-MLP in the natural layout
-    __syncthreads();
-    // einsum("bnkr,bnki->bnri") (models/sprin.py:99): contracted[r*n_in + i], sequential over neighbours
     const int C = SP_RANK * n_in;
-    for (int t = lane; t < C; t += 64) {
-        const int r = t / n_in, i = t - r * n_in;
-        float acc = 0.f;
-        for (int j = 0; j < k; ++j) acc = fmaf(kern[j * SP_KSTRIDE + r], nf[j * n_in + i], acc);
-        contracted[t] = acc;
-    }
     __syncthreads();
     // outnet (transposed weights: lane o reads Wo_t[c][o], coalesced) + LayerNorm (models/sprin.py:100,105)
     const float* Wo = p;
@@ -542,12 +546,13 @@ int cppf_point_encoder_forward(const float* pc, const float* nrm, const int32_t*
         float* dst = ((num_layers - 1 - l) & 1) ? ping : out;
         const float* src = l == 0 ? nullptr : (dst == out ? ping : out);
         ConvArgs A{pc, nrm, src, nbrs, p, images + (size_t)l * SPW_FLOATS, dst, n_points, k, n_in, W};
-        const size_t lds = ((size_t)SPW_FLOATS + (size_t)SP_WAVES * sp_per_wave(n_in)) * sizeof(float);
+        const int waves = sp_waves(n_in);
+        const size_t lds = ((size_t)SPW_FLOATS + (size_t)waves * sp_per_wave(n_in)) * sizeof(float);
         hipError_t e = hipFuncSetAttribute((const void*)sprin_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         e = hipMemsetAsync(glob, 0, 256, st);
         if (e != hipSuccess) return (int)e;
-        sprin_conv_kernel<<<(n_points + SP_WAVES - 1) / SP_WAVES, SP_WAVES * 64, lds, st>>>(A);
+        sprin_conv_kernel<<<(n_points + waves - 1) / waves, waves * 64, lds, st>>>(A);
         p += conv_params(hidden, n_hidden, rank, n_in, n_out);
         sprin_glob_kernel<<<(n_points + 255) / 256, 256, 0, st>>>(dst, n_points, W, n_glob, p, glob);
         sprin_fill_kernel<<<(n_points * n_glob + 255) / 256, 256, 0, st>>>(dst, n_points, W, n_glob, glob);
