@@ -303,6 +303,7 @@ __global__ __launch_bounds__(SP_WAVES_MAX * 64) void sprin_conv_kernel(ConvArgs 
     __syncthreads();
     // r_mean: sequential over neighbours (every lane redundantly; LDS broadcast reads)
     float mx = 0.f, my = 0.f, mz = 0.f;
+#pragma unroll 8
     for (int j = 0; j < k; ++j) { mx = mx + rr[3 * j]; my = my + rr[3 * j + 1]; mz = mz + rr[3 * j + 2]; }
     mx = mx / (float)k; my = my / (float)k; mz = mz / (float)k;
     // rifeat (models/sprin.py:40-61)
@@ -362,6 +363,7 @@ __global__ __launch_bounds__(SP_WAVES_MAX * 64) void sprin_conv_kernel(ConvArgs 
             for (int t = lane; t < SP_RANK * n_in; t += 64) {
                 const int r = t / n_in, i = t - r * n_in;
                 float acc = rb == 0 ? 0.f : contracted[t];
+#pragma unroll 8
                 for (int jj = 0; jj < jn; ++jj) acc = fmaf(kern[jj * SP_KSTRIDE + r], nf[(16 * rb + jj) * n_in + i], acc);
                 contracted[t] = acc;
             }
@@ -376,13 +378,16 @@ __global__ __launch_bounds__(SP_WAVES_MAX * 64) void sprin_conv_kernel(ConvArgs 
     const float* bo = Wo + (size_t)C * SP_NOUT;
     const int o = lane & (SP_NOUT - 1);
     float acc = bo[o];
+#pragma unroll 8
     for (int c = 0; c < C; ++c) acc = fmaf(Wo[(size_t)c * SP_NOUT + o], contracted[c], acc);
     if (lane < SP_NOUT) yv[lane] = acc;
     __syncthreads();
     float s = 0.f;
+#pragma unroll
     for (int q = 0; q < SP_NOUT; ++q) s = s + yv[q];
     const float mean = s / (float)SP_NOUT;
     float v = 0.f;
+#pragma unroll
     for (int q = 0; q < SP_NOUT; ++q) { const float dd = yv[q] - mean; v = v + dd * dd; }
     const float inv = 1.0f / sqrtf(v / (float)SP_NOUT + 1e-5f);
     const float z = ((acc - mean) * inv) * bo[SP_NOUT + o] + bo[2 * SP_NOUT + o];
