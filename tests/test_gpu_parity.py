@@ -543,7 +543,7 @@ def test_full_size_properties_c2(dev):
 
 def test_large_config_c5_properties(oracle, dev):
     """BASELINE.json config 5 sizes: N=8192, K=256 (P = 2 097 152 pairs), fine grid res 2e-3
-    (~400 k cells -> 13 LDS tiles, 110 k pairs per chunk, 20-bit fixed point)."""
+    (~400 k cells -> 14 LDS tiles x 146 pair chunks scheduled over the CUs, 24-bit fixed point)."""
     ob = syn.make_object("bottle", 8192, 3)
     cfg = ob["cfg"]
     res = 2e-3
