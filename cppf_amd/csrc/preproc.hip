@@ -1,0 +1,169 @@
+// Per-instance pre-processing in front of the CPPF path, on device (C ABI in include/cppf.h).
+//
+// Replaces two third-party host calls of the reference's instance loop:
+//   voxel de-duplication  ME.utils.sparse_quantize(pc, return_index=True, quantization_size=res)   nocs/inference.py:140
+//   normals               open3d estimate_normals(KDTreeSearchParamKNN(knn))                        utils/util.py:61-65
+// Neither library is in this image and neither result is fully specified (which point represents a voxel; the sign of
+// a normal), so parity with the reference is UNPINNED; the definitions used here (lowest index per voxel, largest
+// component positive) are restated in oracle/preproc_oracle.c and the kernels match that file bit for bit.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+#include "../../include/cppf.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void vox_keys_kernel(const float* __restrict__ pc, int64_t N, double res, int64_t* __restrict__ keys,
+                                                       int32_t* __restrict__ vals)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    int64_t k = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int64_t v = (int64_t)floor((double)pc[3 * i + c] / res) + (1 << 20);
+        k = (k << 21) | (v & ((1 << 21) - 1));
+    }
+    keys[i] = k;
+    vals[i] = (int32_t)i;
+}
+// the first entry of every run of equal keys (stable sort: the lowest index of the voxel) marks its point
+__global__ __launch_bounds__(256) void vox_mark_kernel(const int64_t* __restrict__ skeys, const int32_t* __restrict__ svals, int64_t N,
+                                                       uint8_t* __restrict__ mask)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    if (i == 0 || skeys[i] != skeys[i - 1]) mask[svals[i]] = 1;
+}
+
+// smallest-eigenvalue eigenvector of a symmetric 3x3 matrix by 8 cyclic Jacobi sweeps in fp64 (oracle/preproc_oracle.c)
+__device__ void smallest_eigvec(double a00, double a01, double a02, double a11, double a12, double a22, double* out)
+{
+    double A[3][3] = {{a00, a01, a02}, {a01, a11, a12}, {a02, a12, a22}};
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+#pragma unroll
+    for (int sweep = 0; sweep < 8; ++sweep) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int p = r == 2 ? 1 : 0, q = r == 0 ? 1 : 2;
+            const double apq = A[p][q];
+            if (apq == 0.0) continue;
+            const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+            const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double akp = A[k][p], akq = A[k][q];
+                A[k][p] = c * akp - s * akq;
+                A[k][q] = s * akp + c * akq;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double apk = A[p][k], aqk = A[q][k];
+                A[p][k] = c * apk - s * aqk;
+                A[q][k] = s * apk + c * aqk;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double vkp = V[k][p], vkq = V[k][q];
+                V[k][p] = c * vkp - s * vkq;
+                V[k][q] = s * vkp + c * vkq;
+            }
+        }
+    }
+    int m = 0;
+    if (A[1][1] < A[m][m]) m = 1;
+    if (A[2][2] < A[m][m]) m = 2;
+    const double v[3] = {m == 0 ? V[0][0] : (m == 1 ? V[0][1] : V[0][2]), m == 0 ? V[1][0] : (m == 1 ? V[1][1] : V[1][2]),
+                         m == 0 ? V[2][0] : (m == 1 ? V[2][1] : V[2][2])};
+    const double n = sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    if (!(n > 0.0)) { out[0] = 0; out[1] = 0; out[2] = 1; return; }
+    int big = 0;
+    if (fabs(v[1]) > fabs(v[big])) big = 1;
+    if (fabs(v[2]) > fabs(v[big])) big = 2;
+    const double vb = big == 0 ? v[0] : (big == 1 ? v[1] : v[2]);
+    const double sg = vb < 0.0 ? -1.0 : 1.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[c] = sg * (v[c] / n);
+}
+
+__global__ __launch_bounds__(256) void normals_kernel(const float* __restrict__ pc, const int32_t* __restrict__ nbrs, int64_t N, int k,
+                                                      float* __restrict__ normals)
+{
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < k; ++j) {
+        const float* p = pc + 3 * (int64_t)nbrs[n * k + j];
+        const double x = p[0], y = p[1], z = p[2];
+        c[0] += x; c[1] += y; c[2] += z;
+        c[3] += x * x; c[4] += x * y; c[5] += x * z; c[6] += y * y; c[7] += y * z; c[8] += z * z;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c[i] /= (double)k;
+    double v[3];
+    smallest_eigvec(c[3] - c[0] * c[0], c[4] - c[0] * c[1], c[5] - c[0] * c[2], c[6] - c[1] * c[1], c[7] - c[1] * c[2],
+                    c[8] - c[2] * c[2], v);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) normals[3 * n + i] = (float)v[i];
+}
+
+struct VoxLayout { size_t keys, vals, mask, compact, temp, temp_bytes, total; };
+VoxLayout vox_layout(int64_t N)
+{
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    VoxLayout L;
+    L.keys = 0;
+    L.vals = L.keys + up(2 * (size_t)N * sizeof(int64_t));   // keys + sorted keys
+    L.mask = L.vals + up(2 * (size_t)N * sizeof(int32_t));   // vals + sorted vals
+    L.compact = L.mask + up((size_t)N);
+    L.temp = L.compact + up(cppf_compact_workspace_bytes(N));
+    L.temp_bytes = up((size_t)48 * N + (1u << 20));
+    L.total = L.temp + L.temp_bytes;
+    return L;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t cppf_voxel_dedupe_workspace_bytes(int64_t n_points) { return n_points < 0 ? 0 : vox_layout(n_points).total; }
+
+int cppf_voxel_dedupe(const float* pc, int64_t n_points, double res, int32_t* keep_idx, int32_t* count, void* workspace,
+                      size_t workspace_bytes, void* stream)
+{
+    if (n_points < 0 || n_points > 0x7fffffffll || !(res > 0.0) || !count) return CPPF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_points == 0) return (int)hipMemsetAsync(count, 0, sizeof(int32_t), st);
+    if (!pc || !keep_idx) return CPPF_EINVAL;
+    const VoxLayout L = vox_layout(n_points);
+    if (!workspace || workspace_bytes < L.total) return CPPF_EWORKSPACE;
+    char* ws = static_cast<char*>(workspace);
+    int64_t *keys = (int64_t*)(ws + L.keys), *skeys = keys + n_points;
+    int32_t *vals = (int32_t*)(ws + L.vals), *svals = vals + n_points;
+    uint8_t* mask = (uint8_t*)(ws + L.mask);
+    const int nb = (int)((n_points + 255) / 256);
+    vox_keys_kernel<<<nb, 256, 0, st>>>(pc, n_points, res, keys, vals);
+    size_t need = 0;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, need, keys, skeys, vals, svals, (int)n_points, 0, 63, st);
+    if (e != hipSuccess) return (int)e;
+    if (need > L.temp_bytes) return CPPF_EWORKSPACE;
+    need = L.temp_bytes;
+    e = hipcub::DeviceRadixSort::SortPairs(ws + L.temp, need, keys, skeys, vals, svals, (int)n_points, 0, 63, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(mask, 0, (size_t)n_points, st);
+    if (e != hipSuccess) return (int)e;
+    vox_mark_kernel<<<nb, 256, 0, st>>>(skeys, svals, n_points, mask);
+    return cppf_compact_mask(mask, n_points, keep_idx, count, ws + L.compact, cppf_compact_workspace_bytes(n_points), stream);
+}
+
+int cppf_estimate_normals(const float* pc, const int32_t* nbrs, int64_t n_points, int k, float* normals, void* stream)
+{
+    if (n_points < 0 || k < 1) return CPPF_EINVAL;
+    if (n_points == 0) return 0;
+    if (!pc || !nbrs || !normals) return CPPF_EINVAL;
+    normals_kernel<<<(int)((n_points + 255) / 256), 256, 0, (hipStream_t)stream>>>(pc, nbrs, n_points, k, normals);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

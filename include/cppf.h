@@ -265,6 +265,23 @@ int cppf_pair_mlp_backward(const float* pc, const float* nrm, const float* feat,
                            int64_t n_pairs, int out_dim, const float* grad_out, float* grad_params, float* grad_feat,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Pre-processing in front of the path.  Both replace third-party host calls whose
+ * results are not fully specified, so parity with the reference is unpinned; the definitions are in
+ * oracle/preproc_oracle.c.
+ *  cppf_voxel_dedupe     the role of ME.utils.sparse_quantize(pc, return_index=True, quantization_size=res)[1]
+ *                        (nocs/inference.py:140): keep_idx device i32[n_points] receives, in ascending order, the lowest
+ *                        index of every occupied voxel floor(p / res) (fp64 divide); count device i32[1] = how many.
+ *  cppf_estimate_normals open3d estimate_normals(KDTreeSearchParamKNN(knn)) (utils/util.py:61-65): nbrs device
+ *                        i32[n_points, k] (cppf_knn output: the point itself is a neighbour); normals device
+ *                        f32[n_points, 3] = unit eigenvector of the smallest eigenvalue of the neighbours' covariance
+ *                        (fp64 cumulants, 8 Jacobi sweeps), sign: component of largest magnitude positive.
+ * ------------------------------------------------------------------------------------------- */
+size_t cppf_voxel_dedupe_workspace_bytes(int64_t n_points);
+int cppf_voxel_dedupe(const float* pc, int64_t n_points, double res, int32_t* keep_idx, int32_t* count, void* workspace,
+                      size_t workspace_bytes, void* stream);
+int cppf_estimate_normals(const float* pc, const int32_t* nbrs, int64_t n_points, int k, float* normals, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,7 +25,7 @@ _pu8 = C.POINTER(C.c_uint8)
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("cppf_oracle.c", "sprin_oracle.c", "backward_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("cppf_oracle.c", "sprin_oracle.c", "backward_oracle.c", "preproc_oracle.c")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -45,6 +45,7 @@ def lib():
         _LIB.orc_grid_argmax.restype = C.c_int64
         _LIB.orc_sample_bin.restype = C.c_int
         _LIB.orc_sprin_conv_params.restype = C.c_int64
+        _LIB.orc_voxel_dedupe.restype = C.c_int64
     return _LIB
 
 
@@ -439,3 +440,21 @@ def pair_mlp_backward(pc, nrm, feat, idxs, sd, ppffcs, out_dim, grad_out, n_part
         if o >= 0:
             grads[nme] = gp[o:o + sd[nme].size].reshape(np.shape(sd[nme]))
     return grads, gf, gp
+
+
+# --------------------------------------------------------------------------- pre-processing (row f3)
+def voxel_dedupe(pc, res):
+    """one representative (lowest index) per occupied voxel floor(p / res), ascending -- the role of
+    ME.utils.sparse_quantize(..., return_index=True)[1] at nocs/inference.py:140"""
+    pc = _c(pc, _f)
+    keep = np.empty(pc.shape[0], np.int32)
+    n = lib().orc_voxel_dedupe(_p(pc, _pf), C.c_int64(pc.shape[0]), C.c_double(float(res)), _p(keep, _pi32))
+    return keep[:n].copy()
+
+
+def estimate_normals(pc, nbrs):
+    """PCA normals of the neighbour sets (utils/util.py:61-65 semantics, sign: largest component positive)"""
+    pc, nbrs = _c(pc, _f), _c(nbrs, np.int32)
+    out = np.empty((pc.shape[0], 3), _f)
+    lib().orc_estimate_normals(_p(pc, _pf), _p(nbrs, _pi32), C.c_int64(pc.shape[0]), C.c_int(nbrs.shape[1]), _p(out, _pf))
+    return out

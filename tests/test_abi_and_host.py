@@ -222,6 +222,12 @@ def test_point_encoder_and_backward_abi_without_a_device(golden):
                                     None) == -3
     assert L.cppf_pair_mlp_backward(one, one, one, one, 1, one, offs, 10, 40, dims, 3, 5, 141, one, one, one, None, 0,
                                     None) == -2
+    # row f3 entry points
+    assert L.cppf_voxel_dedupe_workspace_bytes(70000) > 70000 * (16 + 8 + 1)
+    assert L.cppf_voxel_dedupe(one, 10, 0.0, one, one, one, 1 << 30, None) == -1           # res must be positive
+    assert L.cppf_voxel_dedupe(one, 10, 0.01, one, one, None, 0, None) == -2
+    assert L.cppf_estimate_normals(None, None, 0, 30, None, None) == 0
+    assert L.cppf_estimate_normals(None, None, 10, 30, None, None) == -1
     # module surface: the reference checkpoint layout loads, and the CPU autograd composite equals the reference
     z = golden("sprin_l1.npz")
     sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}

@@ -1,0 +1,53 @@
+"""Pre-processing on the device: voxel de-duplication and PCA normals, against the oracle
+(bit-exact) and against numpy definitions.  Parity with MinkowskiEngine / open3d themselves is unpinned (absent here,
+and their results are not fully specified: representative point per voxel, sign of a normal)."""
+import numpy as np
+import pytest
+import torch
+
+from cppf_amd.utils.util import estimate_normals, sparse_quantize
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,res", [(5000, 0.02), (70000, 0.004), (1, 0.01), (300, 5.0)])
+def test_voxel_dedupe_matches_oracle_and_numpy_unique(dev, oracle, n, res):
+    rng = np.random.default_rng(n)
+    pc = rng.uniform(-0.2, 0.3, (n, 3)).astype(np.float32)
+    pc[n // 2:] = pc[:n - n // 2]                                  # exact duplicates: one survivor each, the lower index
+    coords, idx = sparse_quantize(pc, return_index=True, quantization_size=res)
+    assert np.array_equal(idx, oracle.voxel_dedupe(pc, res).astype(np.int64))
+    keys = np.floor(pc.astype(np.float64) / res).astype(np.int64)
+    _, first = np.unique(keys, axis=0, return_index=True)
+    assert np.array_equal(idx, np.sort(first))
+    assert np.array_equal(coords, keys[idx].astype(np.int32))
+    t_coords, t_idx = sparse_quantize(torch.from_numpy(pc).to(dev), quantization_size=res)   # torch in -> torch out
+    assert t_idx.is_cuda and np.array_equal(t_idx.cpu().numpy(), idx)
+
+
+def test_normals_match_oracle_numpy_and_known_answers(dev, oracle):
+    rng = np.random.default_rng(3)
+    # a noisy plane: the normal is known
+    n0 = np.array([0.3, -0.5, 0.8]); n0 /= np.linalg.norm(n0)
+    a = np.cross(n0, [1, 0, 0]); a /= np.linalg.norm(a)
+    b = np.cross(n0, a)
+    P = (rng.uniform(-1, 1, (3000, 1)) * a + rng.uniform(-1, 1, (3000, 1)) * b + rng.normal(0, 1e-3, (3000, 1)) * n0).astype(np.float32)
+    nr = estimate_normals(P, 30)
+    assert nr.shape == (3000, 3) and nr.dtype == np.float32
+    assert np.array_equal(nr, oracle.estimate_normals(P, oracle.knn(P, 30)))            # bit-exact vs the oracle
+    assert np.degrees(np.arccos(np.clip(np.abs(nr @ n0), 0, 1))).max() < 2.0
+    np.testing.assert_allclose(np.linalg.norm(nr.astype(np.float64), axis=1), 1.0, atol=1e-6)
+    assert (nr[np.arange(3000), np.abs(nr).argmax(1)] > 0).all()                       # the sign convention
+    # a sphere: normals are radial; against numpy's eigh on the same neighbour sets, up to sign
+    S = rng.normal(size=(4096, 3)); S = (S / np.linalg.norm(S, axis=1, keepdims=True) * 0.5).astype(np.float32)
+    ns = estimate_normals(torch.from_numpy(S).to(dev), 60)
+    assert ns.is_cuda
+    ns = ns.cpu().numpy()
+    radial = S / np.linalg.norm(S, axis=1, keepdims=True)
+    assert np.degrees(np.arccos(np.clip(np.abs((ns * radial).sum(1)), 0, 1))).max() < 3.0
+    nb = oracle.knn(S, 60)
+    for i in range(0, 4096, 257):
+        q = S[nb[i]].astype(np.float64)
+        w, v = np.linalg.eigh(np.cov(q.T, bias=True))
+        e = v[:, 0] * np.sign(v[np.abs(v[:, 0]).argmax(), 0])
+        np.testing.assert_allclose(ns[i], e, atol=2e-6)

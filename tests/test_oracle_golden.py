@@ -288,3 +288,25 @@ def test_pair_mlp_backward_matches_reference_autograd(oracle, golden, tag, ppffc
         assert g.shape == ref.shape
         np.testing.assert_allclose(g, ref, rtol=0, atol=2e-5 * np.abs(ref).max())
     np.testing.assert_allclose(gf, z["grad_feat"], rtol=0, atol=2e-5 * np.abs(z["grad_feat"]).max())
+
+
+# --------------------------------------------------------------------------- pre-processing (row f3)
+def test_preprocessing_oracle_against_numpy(oracle):
+    """oracle/preproc_oracle.c (parity with MinkowskiEngine / open3d is unpinned: absent here and under-specified) against
+    numpy's definitions: np.unique on the voxel keys, np.linalg.eigh of the neighbour covariance up to sign."""
+    rng = np.random.default_rng(0)
+    pc = rng.uniform(-0.2, 0.3, (5000, 3)).astype(np.float32)
+    pc[4000:] = pc[:1000]
+    keep = oracle.voxel_dedupe(pc, 0.02)
+    keys = np.floor(pc.astype(np.float64) / 0.02).astype(np.int64)
+    _, first = np.unique(keys, axis=0, return_index=True)
+    assert np.array_equal(keep, np.sort(first))
+    S = rng.normal(size=(1500, 3))
+    S = (S / np.linalg.norm(S, axis=1, keepdims=True) * 0.5).astype(np.float32)
+    nb = oracle.knn(S, 40)
+    nr = oracle.estimate_normals(S, nb)
+    for i in range(0, 1500, 61):
+        q = S[nb[i]].astype(np.float64)
+        w, v = np.linalg.eigh(np.cov(q.T, bias=True))
+        e = v[:, 0] * np.sign(v[np.abs(v[:, 0]).argmax(), 0])
+        np.testing.assert_allclose(nr[i], e, atol=2e-6)
