@@ -51,3 +51,44 @@ def test_normals_match_oracle_numpy_and_known_answers(dev, oracle):
         w, v = np.linalg.eigh(np.cov(q.T, bias=True))
         e = v[:, 0] * np.sign(v[np.abs(v[:, 0]).argmax(), 0])
         np.testing.assert_allclose(ns[i], e, atol=2e-6)
+
+
+def test_raw_points_to_pose_entirely_on_device(dev, oracle):
+    """The instance loop of nocs/inference.py:131-339 from raw points: voxel de-duplication -> normals -> kNN + SPRIN
+    features -> pair path -> pose, every stage a device kernel of this package; each intermediate equals the oracle's."""
+    import cppf_amd.synthetic as syn
+    from cppf_amd.inference import estimate_pose
+    from cppf_amd.models.model import PPFEncoder, PointEncoder
+    from cppf_amd.utils.util import fibonacci_sphere
+    ob = syn.make_object("mug", 3000, 21)
+    cfg = ob["cfg"]
+    raw = np.concatenate([ob["pc"], ob["pc"][:500] + np.float32(1e-5)])          # near-duplicates inside the same voxels
+    _, keep = sparse_quantize(raw, return_index=True, quantization_size=cfg.res)
+    assert np.array_equal(keep, oracle.voxel_dedupe(raw, cfg.res))
+    pc = raw[keep].astype(np.float32)
+    nrm = estimate_normals(pc, 60)
+    assert np.array_equal(nrm, oracle.estimate_normals(pc, oracle.knn(pc, 60)))
+    torch.manual_seed(5)
+    penc = PointEncoder(k=60, spfcs=[32, 64, 32, 32], num_layers=1, out_dim=32).eval()
+    psd = {k: v.detach().numpy().copy() for k, v in penc.state_dict().items()}
+    enc = PPFEncoder(cfg.ppffcs, cfg.out_dim).eval()
+    sd = {k: v.detach().numpy().copy() for k, v in enc.state_dict().items()}
+    penc, enc = penc.to(dev), enc.to(dev)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    with torch.no_grad():
+        feat = penc(d(pc)[None], d(nrm)[None])[0]
+    packed, desc = oracle.pack_point_encoder(psd, 1)
+    feat_o = oracle.point_encoder(pc, nrm, oracle.knn(pc, 60), packed, desc, order=1)
+    assert np.array_equal(feat.cpu().numpy(), feat_o)
+    n = pc.shape[0]
+    idx = syn.make_pairs(n, 24, 21)
+    u_tr, u_rot = syn.make_uniforms(idx.shape[0], 21)
+    sph = np.array(fibonacci_sphere(480))
+    with torch.no_grad():
+        r = estimate_pose(enc, d(pc), d(nrm), feat, d(idx), d(u_tr), d(u_rot), cfg, sph, pc_host=pc)
+    ocfg = dict(res=cfg.res, tr_num_bins=32, rot_num_bins=36, vote_range=cfg.vote_range, scale_mean=cfg.scale_mean,
+                regress_right=cfg.regress_right, ppffcs=cfg.ppffcs, out_dim=cfg.out_dim)
+    o = oracle.estimate_pose(pc, nrm, feat_o, idx, sd, ocfg, u_tr, u_rot, sph)
+    assert r["argmax"] == o["argmax"] and r["n_surv"] == int(o["mask"].sum())
+    assert np.allclose(r["T"], o["T"], atol=1e-9) and np.allclose(r["up"], o["up"], atol=1e-9)
+    assert np.allclose(r["scale"], o["scale"], rtol=1e-5)
