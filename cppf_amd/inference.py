@@ -294,6 +294,29 @@ def _assemble(rec, cfg, rng=None):
                 losses=sign.copy())
 
 
+def nocs_result(poses, res=None):
+    """The per-image result record of nocs/inference.py:114-117,213,338-342 from a list of pose dicts (estimate_pose /
+    PosePipeline.run / _assemble): `pred_RTs` f32[n,4,4] (identity-initialised, translation in the last column, rotation
+    scaled by |scale|) and `pred_scales` f32[n,3] (scale / |scale|), written into `res` (the detection dict the script
+    pickles, :344-345) or a new dict -- the format nocs/eval.py reads."""
+    n = len(poses)
+    RTs = np.zeros((n, 4, 4), dtype=np.float32)
+    for i in range(n):
+        RTs[i] = np.eye(4)
+    scales = np.ones((n, 3), dtype=np.float32)
+    for i, p in enumerate(poses):
+        if p is None:                                   # skipped instance (:121-123): identity pose, unit scale
+            continue
+        RTs[i][:3, -1] = p["T"]
+        assert p["scale_norm"] > 0
+        RTs[i][:3, :3] = p["R"] * p["scale_norm"]
+        scales[i, :] = p["scale"] / p["scale_norm"]
+    res = {} if res is None else res
+    res["pred_RTs"] = RTs
+    res["pred_scales"] = scales
+    return res
+
+
 class PosePipeline(CenterPipeline):
     """Full per-instance pose for a fixed problem shape: CenterPipeline's chain plus the pose tail, captured
     together in one hipGraph; `run()` replays it and reads back the 21-double record (one sync)."""

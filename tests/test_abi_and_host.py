@@ -248,3 +248,18 @@ def test_point_encoder_and_backward_abi_without_a_device(golden):
     assert image[9256 + 256 + (ob * 8 + s_) * 64 + ln] == W2[16 * ob + (ln & 15), 16 * (s_ // 4) + 4 * (ln >> 4) + s_ % 4]
     assert packed.size == 9256 and desc == dict(hidden=[32, 64, 32, 32], rank=32, n_nbr_feats=2, n_out=32, n_glob=8,
                                                 num_layers=1)
+
+
+def test_nocs_result_record_format():
+    """pred_RTs / pred_scales as nocs/inference.py:114-117,213,338-342 builds them (the input of nocs/eval.py)"""
+    from cppf_amd.inference import nocs_result
+    R = np.array([[0, 1, 0], [0, 0, 1], [1, 0, 0]], np.float64)
+    scale = np.array([0.1, 0.3, 0.1])
+    pose = dict(T=np.array([0.05, -0.02, 0.7]), R=R, scale=scale, scale_norm=float(np.linalg.norm(scale)))
+    res = nocs_result([pose, None], {"image_path": "x"})
+    assert res["image_path"] == "x" and res["pred_RTs"].shape == (2, 4, 4) and res["pred_RTs"].dtype == np.float32
+    np.testing.assert_allclose(res["pred_RTs"][0][:3, :3], (R * np.linalg.norm(scale)).astype(np.float32))
+    np.testing.assert_allclose(res["pred_RTs"][0][:3, 3], pose["T"].astype(np.float32))
+    assert res["pred_RTs"][0][3].tolist() == [0, 0, 0, 1]
+    np.testing.assert_allclose(np.linalg.norm(res["pred_scales"][0]), 1.0, atol=1e-6)
+    assert np.array_equal(res["pred_RTs"][1], np.eye(4, dtype=np.float32)) and res["pred_scales"][1].tolist() == [1, 1, 1]
