@@ -14,53 +14,65 @@ import torch.nn as nn
 __all__ = ["rifeat", "conv_kernel", "GlobalInfoProp", "SparseSO3Conv", "pack_point_encoder"]
 
 
+def _unit_cos(u, v, nu, nv):
+    """cosine between two edge vectors with the reference's 1e-7 guard (models/sprin.py:56-58)"""
+    return (u * v).sum(-1, keepdim=True) / (nu * nv + 1e-7)
+
+
 def rifeat(points_r, points_s):
-    """models/sprin.py:40-61: six rotation-invariant features of (neighbour, centre, neighbour mean)."""
+    """Six rotation-invariant numbers per neighbour (models/sprin.py:40-61): the triangle (neighbour r, centre s,
+    neighbour mean m) described by its three edge lengths |m-r|, |r-s|, |s-m| and the cosines at its corners.
+    points_r [B,N,K,3], points_s [B,N,1,3] -> [B,N,K,6]."""
     if points_r.shape[1] != points_s.shape[1]:
         points_r = points_r.expand(-1, points_s.shape[1], -1, -1)
-    r_mean = points_r.mean(-2, keepdim=True)
-    l1, l2, l3 = r_mean - points_r, points_r - points_s, points_s - r_mean
-    l1n, l2n = l1.norm(dim=-1, keepdim=True), l2.norm(dim=-1, keepdim=True)
-    l3n = l3.norm(dim=-1, keepdim=True).expand_as(l2n)
-    th1 = (l1 * l2).sum(-1, keepdim=True) / (l1n * l2n + 1e-7)
-    th2 = (l2 * l3).sum(-1, keepdim=True) / (l2n * l3n + 1e-7)
-    th3 = (l3 * l1).sum(-1, keepdim=True) / (l3n * l1n + 1e-7)
-    return torch.cat([l1n, l2n, l3n, th1, th2, th3], -1)
+    centroid = points_r.mean(dim=-2, keepdim=True)
+    e_mr, e_rs, e_sm = centroid - points_r, points_r - points_s, points_s - centroid
+    n_mr = torch.linalg.vector_norm(e_mr, dim=-1, keepdim=True)
+    n_rs = torch.linalg.vector_norm(e_rs, dim=-1, keepdim=True)
+    n_sm = torch.linalg.vector_norm(e_sm, dim=-1, keepdim=True).expand_as(n_rs)
+    return torch.cat([n_mr, n_rs, n_sm, _unit_cos(e_mr, e_rs, n_mr, n_rs), _unit_cos(e_rs, e_sm, n_rs, n_sm),
+                      _unit_cos(e_sm, e_mr, n_sm, n_mr)], dim=-1)
 
 
 def conv_kernel(iunit, ounit, *hunits):
-    layers = []
-    for unit in hunits:
-        layers += [nn.Linear(iunit, unit), nn.LayerNorm(unit), nn.ReLU()]
-        iunit = unit
-    layers.append(nn.Linear(iunit, ounit))
-    return nn.Sequential(*layers)
+    """nn.Sequential of (Linear, LayerNorm, ReLU) per hidden width, then Linear -- the layout whose indices
+    (0, 1, 3, 4, ...) the reference checkpoints use (models/sprin.py:64-72)."""
+    widths = [iunit, *hunits]
+    stack = []
+    for w_in, w_out in zip(widths[:-1], widths[1:]):
+        stack.extend((nn.Linear(w_in, w_out), nn.LayerNorm(w_out), nn.ReLU()))
+    stack.append(nn.Linear(widths[-1], ounit))
+    return nn.Sequential(*stack)
 
 
 class GlobalInfoProp(nn.Module):
+    """models/sprin.py:75-84: append the per-channel maximum over all points of a linear map of the features."""
+
     def __init__(self, n_in, n_global):
         super().__init__()
         self.linear = nn.Linear(n_in, n_global)
 
     def forward(self, feat):
-        tran = self.linear(feat)
-        glob = tran.max(-2, keepdim=True)[0].expand(*feat.shape[:-1], tran.shape[-1])
-        return torch.cat([feat, glob], -1)
+        pooled = self.linear(feat).amax(dim=-2, keepdim=True)
+        return torch.cat([feat, pooled.expand(*feat.shape[:-1], pooled.shape[-1])], dim=-1)
 
 
 class SparseSO3Conv(nn.Module):
+    """models/sprin.py:87-107: per-neighbour kernel MLP on the rotation-invariant features, rank-`rank` contraction with
+    the neighbour features, output linear, LayerNorm."""
+
     def __init__(self, rank, n_in, n_out, *kernel_interns, layer_norm=True):
         super().__init__()
+        self.rank = rank
         self.kernel = conv_kernel(6, rank, *kernel_interns)
         self.outnet = nn.Linear(rank * n_in, n_out)
-        self.rank = rank
         self.layer_norm = nn.LayerNorm(n_out) if layer_norm else None
 
     def forward(self, feat_points, feat, eval_points):
-        r_inv_s = rifeat(feat_points, eval_points.unsqueeze(-2))
-        kern = self.kernel(r_inv_s).reshape(*feat.shape[:-1], self.rank)
-        conv = self.outnet(torch.einsum("bnkr,bnki->bnri", kern, feat).flatten(-2))
-        return conv if self.layer_norm is None else self.layer_norm(conv)
+        weights = self.kernel(rifeat(feat_points, eval_points.unsqueeze(-2)))          # [B,N,K,rank]
+        mixed = torch.einsum("bnkr,bnki->bnri", weights.reshape(*feat.shape[:-1], self.rank), feat)
+        out = self.outnet(mixed.flatten(-2))
+        return out if self.layer_norm is None else self.layer_norm(out)
 
 
 def pack_point_encoder(sd, num_layers):
