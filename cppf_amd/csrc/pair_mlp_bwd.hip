@@ -402,12 +402,20 @@ __global__ __launch_bounds__(256) void bwd_gather_kernel(const float* __restrict
     const int c = threadIdx.x & 63;
     if (n >= N || c >= BW_F) return;
     const int b = seg[n], e_ = seg[n + 1];
-    float acc = 0.f;
-    for (int i = b; i < e_; ++i) {
+    auto row_of = [&](int i) {
         const int64_t e = svals[i];
-        const float* row = e < P ? dx + (size_t)e * (2 * BW_F) : dx + (size_t)(e - P) * (2 * BW_F) + BW_F;
-        acc = acc + row[c];
+        return e < P ? dx + (size_t)e * (2 * BW_F) : dx + (size_t)(e - P) * (2 * BW_F) + BW_F;
+    };
+    float acc = 0.f;
+    int i = b;
+    for (; i + 8 <= e_; i += 8) {   // eight independent row loads in flight, added in order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = row_of(i + u)[c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = acc + v[u];
     }
+    for (; i < e_; ++i) acc = acc + row_of(i)[c];
     grad_feat[(size_t)n * BW_F + c] = grad_feat[(size_t)n * BW_F + c] + acc;
 }
 
