@@ -28,6 +28,7 @@ _SIGS = {
     "cppf_rot_sphere_count": (C.c_int, [vp, vp, i32, vp, vp, vp, i64, i64, i32, vp, i32, f32, i32, vp, vp]),
     "cppf_pair_mlp_packed_floats": (sz, [i32, C.POINTER(C.c_int), i32, i32]),
     "cppf_pair_mlp_pack": (C.c_int, [vp, vp, i32, C.POINTER(C.c_int), i32, i32, vp]),
+    "cppf_pair_mlp_pack_device": (C.c_int, [vp, C.POINTER(C.c_int64), i32, C.POINTER(C.c_int), i32, i32, vp, vp]),
     "cppf_pair_mlp_workspace_bytes": (sz, [i64, i32, C.POINTER(C.c_int), i32, i32]),
     "cppf_pair_mlp_forward": (C.c_int, [vp, vp, vp, vp, i32, vp, i64, i32, C.POINTER(C.c_int), i32, i64, i32, vp, vp,
                                         sz, vp]),

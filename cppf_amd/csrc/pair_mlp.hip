@@ -41,30 +41,7 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byt
         if (e__ != hipSuccess) return (int)e__;     \
     } while (0)
 
-// ----------------------------------------------------------------------------- packed layout (floats)
-#define STD_F 40
-#define STD_NOB 9                      // final layer padded to 9 x 16 = 144 outputs
-#define STD_NOBP 12                    // floats per lane per k-step of the final layer (3 x b128)
-#define OFF_W0P 0                       // [64][4]     PPF k-step of layer 0 (k = 80 + g): ob0,1 = fc1, ob2,3 = fc0
-#define OFF_W0B (OFF_W0P + 64 * 4)      // [8][64][2]  layer 0 fc2
-#define OFF_W1A (OFF_W0B + 8 * 64 * 2)  // [8][64][2]  layer 1 fc1
-#define OFF_W1B (OFF_W1A + 8 * 64 * 2)  // [8][64][2]  layer 1 fc2
-#define OFF_W2 (OFF_W1B + 8 * 64 * 2)   // [8][64][2]  ob0 = layer 2 fc1 (16), ob1 = layer 2 fc0 (16)
-#define OFF_W2B (OFF_W2 + 8 * 64 * 2)   // [4][64][1]  layer 2 fc2
-#define OFF_WF (OFF_W2B + 4 * 64)       // [4][64][12] final, 9 used
-#define OFF_B0B (OFF_WF + 4 * 64 * STD_NOBP)  // biases in natural output order
-#define OFF_B1A (OFF_B0B + 32)
-#define OFF_B1B (OFF_B1A + 32)
-#define OFF_B2 (OFF_B1B + 32)
-#define OFF_B2B (OFF_B2 + 32)
-#define OFF_BF (OFF_B2B + 16)
-#define STD_LDS (OFF_BF + 144)          // 7 968 floats = 31 872 B live in LDS
-#define OFF_WPT STD_LDS                 // [40][128]   per-point projection: column r < 64: W[r][k], r >= 64: W[r-64][40+k]
-#define OFF_BPT (OFF_WPT + 40 * 128)    // [64]        fc1 | fc0 bias of layer 0 (folded into the feat_a table)
-#define OFF_WFD (OFF_BPT + 64)          // [4][64][12] final layer with the output columns in DECODE order (dec_col)
-#define OFF_BFD (OFF_WFD + 4 * 64 * STD_NOBP)  // [144] its bias, slot order
-#define STD_PACKED (OFF_BFD + 144)      // 16 368 floats
-#define PROJ_COLS 128
+#include "pair_layout.h"   // packed image: offsets, khid, dec_col, std_pack_elem
 
 static bool is_std(int F, const int* dims, int n_res, int out_dim)
 {
@@ -102,89 +79,13 @@ extern "C" size_t cppf_pair_mlp_packed_floats(int F, const int* dims, int n_res,
     return 0;
 }
 
-static inline int khid(int s, int g) { return 16 * (s / 4) + 4 * g + (s % 4); }
-
-// DECODE order of the 141 output columns (train.py:68-75: 2 x 32 centre bins, 2 x 36 angle bins, 2 sign logits, 3
-// log-scales): accumulator slot (block ob, lane group g, register r) holds
-//   ob 0..7 : bin 8g (or 9g) + 4*(ob & 1) + r of head ob / 2 -- a lane owns a run of consecutive bins of every head
-//   ob 8    : r = 0, 1: the 9th bin (9g + 8) of the up / right head;  r = 2, 3: aux_up aux_right | sx sy | sz - | - -  for g = 0..3
-// so that the in-register sampler needs two lane exchanges per statistic and no per-row bookkeeping.
-static inline int dec_col(int ob, int g, int r)
-{
-    if (ob < 4) return 32 * (ob >> 1) + 8 * g + 4 * (ob & 1) + r;
-    if (ob < 8) return 64 + 36 * ((ob - 4) >> 1) + 9 * g + 4 * (ob & 1) + r;
-    if (r < 2) return 64 + 36 * r + 9 * g + 8;
-    const int q = 2 * g + (r - 2);   // 0..7 -> columns 136..140, then unused
-    return q < 5 ? 136 + q : -1;
-}
-
 extern "C" int cppf_pair_mlp_pack(const float* params, const int64_t* offs, int F, const int* dims, int n_res,
                                   int out_dim, float* out)
 {
     if (!params || !offs || !dims || !out) return CPPF_EINVAL;
     if (is_std(F, dims, n_res, out_dim)) {
-        memset(out, 0, sizeof(float) * STD_PACKED);
-        const float *w1 = params + offs[0], *b1 = params + offs[1], *w2 = params + offs[2], *b2 = params + offs[3];
         if (offs[4] < 0 || offs[10] >= 0 || offs[16] < 0) return CPPF_EINVAL;  // fc0 on layers 0 and 2 only
-        const float *w0 = params + offs[4], *b0 = params + offs[5];
-        for (int l = 0; l < 64; ++l)
-            for (int ob = 0; ob < 4; ++ob) {
-                int o = 16 * (ob & 1) + (l & 15), k = 80 + (l >> 4);
-                out[OFF_W0P + l * 4 + ob] = (ob < 2 ? w1 : w0)[o * 84 + k];
-            }
-        for (int k = 0; k < 40; ++k)
-            for (int r = 0; r < 128; ++r) {
-                int oc = r & 63;  // 0..31 fc1, 32..63 fc0
-                const float* w = oc < 32 ? w1 + oc * 84 : w0 + (oc - 32) * 84;
-                out[OFF_WPT + k * 128 + r] = w[(r < 64 ? 0 : 40) + k];
-            }
-        for (int o = 0; o < 32; ++o) { out[OFF_BPT + o] = b1[o]; out[OFF_BPT + 32 + o] = b0[o]; out[OFF_B0B + o] = b2[o]; }
-        for (int s = 0; s < 8; ++s)
-            for (int l = 0; l < 64; ++l)
-                for (int ob = 0; ob < 2; ++ob)
-                    out[OFF_W0B + (s * 64 + l) * 2 + ob] = w2[(16 * ob + (l & 15)) * 32 + khid(s, l >> 4)];
-        // layer 1 (no fc0)
-        w1 = params + offs[6]; b1 = params + offs[7]; w2 = params + offs[8]; b2 = params + offs[9];
-        for (int s = 0; s < 8; ++s)
-            for (int l = 0; l < 64; ++l)
-                for (int ob = 0; ob < 2; ++ob) {
-                    out[OFF_W1A + (s * 64 + l) * 2 + ob] = w1[(16 * ob + (l & 15)) * 32 + khid(s, l >> 4)];
-                    out[OFF_W1B + (s * 64 + l) * 2 + ob] = w2[(16 * ob + (l & 15)) * 32 + khid(s, l >> 4)];
-                }
-        for (int o = 0; o < 32; ++o) { out[OFF_B1A + o] = b1[o]; out[OFF_B1B + o] = b2[o]; }
-        // layer 2
-        w1 = params + offs[12]; b1 = params + offs[13]; w2 = params + offs[14]; b2 = params + offs[15];
-        w0 = params + offs[16]; b0 = params + offs[17];
-        for (int s = 0; s < 8; ++s)
-            for (int l = 0; l < 64; ++l) {
-                out[OFF_W2 + (s * 64 + l) * 2 + 0] = w1[(l & 15) * 32 + khid(s, l >> 4)];
-                out[OFF_W2 + (s * 64 + l) * 2 + 1] = w0[(l & 15) * 32 + khid(s, l >> 4)];
-            }
-        for (int s = 0; s < 4; ++s)
-            for (int l = 0; l < 64; ++l) out[OFF_W2B + s * 64 + l] = w2[(l & 15) * 16 + khid(s, l >> 4)];
-        for (int o = 0; o < 16; ++o) { out[OFF_B2 + o] = b1[o]; out[OFF_B2 + 16 + o] = b0[o]; out[OFF_B2B + o] = b2[o]; }
-        // final
-        const float *wf = params + offs[18], *bf = params + offs[19];
-        for (int s = 0; s < 4; ++s)
-            for (int l = 0; l < 64; ++l)
-                for (int ob = 0; ob < STD_NOB; ++ob) {
-                    int o = 16 * ob + (l & 15);
-                    out[OFF_WF + (s * 64 + l) * STD_NOBP + ob] = o < out_dim ? wf[o * 16 + khid(s, l >> 4)] : 0.f;
-                }
-        for (int o = 0; o < out_dim; ++o) out[OFF_BF + o] = bf[o];
-        if (out_dim == 141) {   // the decode kernels' copy of the final layer, columns in dec_col order
-            for (int s = 0; s < 4; ++s)
-                for (int l = 0; l < 64; ++l)
-                    for (int ob = 0; ob < STD_NOB; ++ob) {
-                        const int m = l & 15, c = dec_col(ob, m >> 2, m & 3);
-                        out[OFF_WFD + (s * 64 + l) * STD_NOBP + ob] = c >= 0 ? wf[c * 16 + khid(s, l >> 4)] : 0.f;
-                    }
-            for (int ob = 0; ob < STD_NOB; ++ob)
-                for (int m = 0; m < 16; ++m) {
-                    const int c = dec_col(ob, m >> 2, m & 3);
-                    out[OFF_BFD + 16 * ob + m] = c >= 0 ? bf[c] : 0.f;
-                }
-        }
+        for (int i = 0; i < STD_PACKED; ++i) out[i] = std_pack_elem(i, params, offs, out_dim);
         return 0;
     }
     if (gen_ok(F, dims, n_res, out_dim)) {
@@ -209,6 +110,29 @@ extern "C" int cppf_pair_mlp_pack(const float* params, const int64_t* offs, int 
         return 0;
     }
     return CPPF_EUNSUPPORTED;
+}
+
+// The same image built on the device from parameters that live there (training: the weights change every step and a
+// host pack would cost a device -> host -> device round trip with a synchronisation).
+struct PackOffs { int64_t o[20]; };
+__global__ __launch_bounds__(256) void pair_pack_kernel(const float* __restrict__ params, PackOffs offs, int out_dim,
+                                                        float* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < STD_PACKED) out[i] = std_pack_elem(i, params, offs.o, out_dim);
+}
+extern "C" int cppf_pair_mlp_pack_device(const float* params, const int64_t* offs, int F, const int* dims, int n_res,
+                                         int out_dim, float* out, void* stream)
+{
+    if (!params || !offs || !dims || !out) return CPPF_EINVAL;
+    if (!is_std(F, dims, n_res, out_dim)) return CPPF_EUNSUPPORTED;
+    if (offs[4] < 0 || offs[10] >= 0 || offs[16] < 0) return CPPF_EINVAL;
+    PackOffs po;
+    for (int i = 0; i < 20; ++i) po.o[i] = offs[i];
+    hipLaunchKernelGGL(pair_pack_kernel, dim3((STD_PACKED + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, po,
+                       out_dim, out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
 }
 
 // ----------------------------------------------------------------------------- MFMA kernel

@@ -68,16 +68,7 @@ class _PairMlpFunction(torch.autograd.Function):
         enc = ctx.enc
         pc, nrm, feat, idxs, *params = ctx.saved_tensors
         dev = pc.device
-        flat = torch.cat([p.detach().reshape(-1).float() for p in params]).contiguous()
-        offs, pos = [], 0
-        it = iter(params)
-        for present in enc._param_presence():
-            if present:
-                offs.append(pos)
-                pos += next(it).numel()
-            else:
-                offs.append(-1)
-        offs_c = (C.c_int64 * len(offs))(*offs)
+        flat, offs_c = enc._flat_params(dev)                   # the forward's flat copy unless a parameter changed since
         dims = (C.c_int * len(enc.ppffcs))(*enc.ppffcs)
         L = _lib.lib()
         P, F_ = idxs.shape[0], feat.shape[1]
@@ -229,6 +220,8 @@ class PPFEncoder(nn.Module):
         self.final = nn.Linear(self.ppffcs[-1], self.out_dim)
         self._packed = None
         self._packed_key = None
+        self._flat = None
+        self._flat_key = None
 
     # ------------------------------------------------------------------ reference signatures
     def forward(self, pc, pc_normal, feat, dist=None, idxs=None):
@@ -319,7 +312,8 @@ class PPFEncoder(nn.Module):
 
     def _has_device_backward(self, pc, feat):
         """csrc/pair_mlp_bwd.hip covers ppffcs = [84,32,32,16] (train.py:35) on a HIP device."""
-        return pc.is_cuda and self.ppffcs == [84, 32, 32, 16] and feat.dim() == 2 and feat.shape[1] == 40
+        return (pc.is_cuda and self.ppffcs == [84, 32, 32, 16] and feat.dim() == 2 and feat.shape[1] == 40
+                and self.out_dim <= 144)
 
     def _param_presence(self):
         pres = []
@@ -375,25 +369,60 @@ class PPFEncoder(nn.Module):
         return (pc.detach().float().contiguous(), pc_normal.detach().float().contiguous(),
                 feat.detach().float().contiguous())
 
+    def _param_key(self, device):
+        return (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _flat_params(self, device):
+        """(flat device f32 copy of the parameters in `flatten_state_dict` order, host i64 offset table), rebuilt when a
+        parameter changes (one torch.cat on the device, no host round trip)."""
+        key = self._param_key(device)
+        if self._flat is None or self._flat_key != key:
+            ps = self._ordered_params()
+            flat = torch.cat([p.detach().reshape(-1).float() for p in ps]).to(device).contiguous()
+            offs, pos = [], 0
+            it = iter(ps)
+            for present in self._param_presence():
+                if present:
+                    offs.append(pos)
+                    pos += next(it).numel()
+                else:
+                    offs.append(-1)
+            self._flat = (flat, (C.c_int64 * len(offs))(*offs))
+            self._flat_key = key
+        return self._flat
+
     def _packed_weights(self, device):
-        """Lane-ordered weight image for the HIP kernel, rebuilt when a parameter changes."""
-        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        """Lane-ordered weight image for the HIP kernels, rebuilt when a parameter changes.  The standard architecture
+        packs on the device (cppf_pair_mlp_pack_device: a training loop changes the weights every step and never
+        leaves the stream); other stacks pack on the host."""
+        key = self._param_key(device)
         if self._packed is not None and self._packed_key == key:
             return self._packed
-        sd = {k: v.detach().float().cpu().numpy() for k, v in self.state_dict().items()}
-        params, offs = flatten_state_dict(sd, self.ppffcs)
         dims = (C.c_int * len(self.ppffcs))(*self.ppffcs)
         L = _lib.lib()
         F_ = (self.ppffcs[0] - 4) // 2
-        n = L.cppf_pair_mlp_packed_floats(F_, dims, len(self.ppffcs) - 1, self.out_dim)
+        n_res = len(self.ppffcs) - 1
+        n = L.cppf_pair_mlp_packed_floats(F_, dims, n_res, self.out_dim)
         if n == 0:
             raise _lib.CppfError(f"no device kernel for ppffcs={self.ppffcs}, out_dim={self.out_dim} "
                                  "(layers wider than 128 units are unsupported)")
-        packed = np.zeros(n, np.float32)
-        rc = L.cppf_pair_mlp_pack(params.ctypes.data, offs.ctypes.data, F_, dims, len(self.ppffcs) - 1, self.out_dim,
-                                  packed.ctypes.data)
-        _lib.check(rc, "cppf_pair_mlp_pack")
-        self._packed = torch.from_numpy(packed).to(device)
+        dev = torch.device(device)
+        if dev.type == "cuda" and self.ppffcs == [84, 32, 32, 16] and self.out_dim <= 144:
+            flat, offs_c = self._flat_params(dev)
+            packed = torch.empty(n, dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                rc = L.cppf_pair_mlp_pack_device(flat.data_ptr(), offs_c, F_, dims, n_res, self.out_dim, packed.data_ptr(),
+                                                 stream_ptr(dev))
+            _lib.check(rc, "cppf_pair_mlp_pack_device")
+            self._packed = packed
+        else:
+            sd = {k: v.detach().float().cpu().numpy() for k, v in self.state_dict().items()}
+            params, offs = flatten_state_dict(sd, self.ppffcs)
+            packed = np.zeros(n, np.float32)
+            rc = L.cppf_pair_mlp_pack(params.ctypes.data, offs.ctypes.data, F_, dims, n_res, self.out_dim,
+                                      packed.ctypes.data)
+            _lib.check(rc, "cppf_pair_mlp_pack")
+            self._packed = torch.from_numpy(packed).to(device)
         self._packed_key = key
         return self._packed
 

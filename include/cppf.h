@@ -154,6 +154,11 @@ size_t cppf_pair_mlp_workspace_bytes(int64_t N, int F, const int* dims, int n_re
  * fc0.b|-1} then {final.w, final.b}); packed_host receives cppf_pair_mlp_packed_floats() floats. */
 int cppf_pair_mlp_pack(const float* params, const int64_t* offs, int F, const int* dims, int n_res, int out_dim,
                        float* packed_host);
+/* the same image built on the device from DEVICE parameters (`params` device f32, `offs` HOST): what a training
+ * loop uses, where the weights change every step (train.py:92 optimizer.step) and a host pack would cost a device ->
+ * host -> device round trip with a synchronisation.  MFMA path only (else CPPF_EUNSUPPORTED). */
+int cppf_pair_mlp_pack_device(const float* params, const int64_t* offs, int F, const int* dims, int n_res, int out_dim,
+                              float* packed_device, void* stream);
 int cppf_pair_mlp_forward(const float* pc, const float* nrm, const float* feat, const void* idxs, int idx_is_i64,
                           const float* packed, int64_t N, int F, const int* dims, int n_res, int64_t P,
                           int out_dim, float* out, void* workspace, size_t workspace_bytes, void* stream);
@@ -251,13 +256,16 @@ int cppf_point_encoder_forward(const float* pc, const float* nrm, const int32_t*
  *   grad_out     device f32[n_pairs, out_dim]  (dL/dlogits)
  *   grad_params  device f32, same layout as `params`, OVERWRITTEN
  *   grad_feat    device f32[n_points, F], ACCUMULATED (+=; zero it first for a plain gradient)
- * One wavefront per tile of 64 pairs recomputes the forward, back-propagates lane-locally and adds the tile's
- * outer products to one of at most CPPF_BWD_MAX_PARTS partial gradients in the workspace (tiles dealt evenly); the
- * partials are then added in a fixed two-level order, so grad_params is deterministic (oracle/backward_oracle.c).
- * grad_feat is deterministic too: the per-pair rows go to the workspace, the 2*n_pairs (point, entry) keys are radix
- * sorted (stable) and every point adds its rows in pair order, a-halves first -- no atomics anywhere.
+ * Formulation (cppf_amd/csrc/pair_mlp_bwd.hip): one workgroup of four wavefronts per tile of 64 pairs recomputes the
+ * forward and back-propagates on the fp32 matrix cores; weight-gradient tiles accumulate in registers over all the
+ * workgroup's pairs and are written once to one of at most CPPF_BWD_MAX_PARTS partial gradients in the workspace
+ * (tiles dealt evenly), which are then added in a fixed two-level order.  Everything that touches the 2 x 40 feature
+ * columns of layer 0 is done per POINT: each pair emits one 64-float row, the 2*n_pairs (point, entry) keys are radix
+ * sorted (stable), every point adds its rows in pair order per role, and d(feat) and the feature columns of the two
+ * layer-0 weight gradients are products of those sums.  No atomics anywhere: every result is deterministic
+ * (oracle/backward_oracle.c restates the order).
  * ------------------------------------------------------------------------------------------- */
-#define CPPF_BWD_MAX_PARTS 2048
+#define CPPF_BWD_MAX_PARTS 512
 size_t cppf_pair_mlp_backward_workspace_bytes(int64_t n_pairs, int64_t n_points, int F, const int* dims, int n_res,
                                               int out_dim);
 int cppf_pair_mlp_backward(const float* pc, const float* nrm, const float* feat, const void* idxs, int idx_is_i64,

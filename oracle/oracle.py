@@ -401,12 +401,12 @@ def point_encoder(pc, nrm, nbrs, packed, desc, order=0):
 
 
 # --------------------------------------------------------------------------- backward of the pair MLP (row f2)
-BWD_MAX_PARTS = 2048
+BWD_MAX_PARTS = 512
 
 
 def bwd_parts(P):
     """number of partial accumulators the device kernel uses for P pairs (cppf.h: CPPF_BWD_MAX_PARTS): every
-    wavefront gets the same number of 64-pair tiles (+-1)"""
+    workgroup gets the same number of 64-pair tiles (+-1)"""
     t = (P + 63) // 64
     if t <= 1:
         return 1

@@ -55,7 +55,7 @@ def test_weight_packing_follows_the_documented_lane_order(golden):
     L = _lib.lib()
     dims = (C.c_int * 4)(84, 32, 32, 16)
     n = L.cppf_pair_mlp_packed_floats(40, dims, 3, 141)
-    assert n == 16368                                                    # 13 152 + the decode-order copy of the final layer
+    assert n == 23024                                                    # forward 13 152 + decode-order final 3 216 + transposed (backward) 6 656
     packed = np.zeros(n, np.float32)
     assert L.cppf_pair_mlp_pack(params.ctypes.data, offs.ctypes.data, 40, dims, 3, 141, packed.ctypes.data) == 0
     w1, w0 = sd["res_layers.0.fc1.weight"], sd["res_layers.0.fc0.weight"]
@@ -101,6 +101,25 @@ def test_weight_packing_follows_the_documented_lane_order(golden):
         c = dec_col(ob, m >> 2, m & 3)
         assert packed[off_wfd + (s * 64 + lane) * 12 + ob] == (wf[c, k] if c >= 0 else 0.0)
         assert packed[off_bfd + 16 * ob + m] == (sd["final.bias"][c] if c >= 0 else 0.0)
+    # backward section (csrc/pair_layout.h): TRANSPOSED weights as MFMA A operands, A[input row][k = output khid(s, g)]
+    off_t0b = off_bfd + 144
+    khid = lambda s, g_: 16 * (s // 4) + 4 * g_ + s % 4
+    t32 = packed[off_t0b:off_t0b + 3 * 1024].reshape(3, 8, 64, 2)           # layer 0 fc2^T, layer 1 fc1^T, layer 1 fc2^T
+    for which, name in enumerate(("res_layers.0.fc2.weight", "res_layers.1.fc1.weight", "res_layers.1.fc2.weight")):
+        for s, lane, ib in ((0, 0, 0), (7, 63, 1), (3, 37, 0)):
+            assert t32[which, s, lane, ib] == sd[name][khid(s, lane >> 4), 16 * ib + (lane & 15)]
+    t2 = packed[off_t0b + 3072:off_t0b + 4096].reshape(4, 64, 4)            # layer 2: fc0^T ib 0,1 | fc1^T ib 0,1
+    t2b = packed[off_t0b + 4096:off_t0b + 4352].reshape(4, 64)
+    tf = packed[off_t0b + 4352:off_t0b + 4352 + 36 * 64].reshape(36, 64)
+    for s, lane in ((0, 0), (3, 63), (2, 21)):
+        k, m = khid(s, lane >> 4), lane & 15
+        assert t2[s, lane, 0] == sd["res_layers.2.fc0.weight"][k, m] and t2[s, lane, 1] == sd["res_layers.2.fc0.weight"][k, 16 + m]
+        assert t2[s, lane, 2] == sd["res_layers.2.fc1.weight"][k, m] and t2[s, lane, 3] == sd["res_layers.2.fc1.weight"][k, 16 + m]
+        assert t2b[s, lane] == sd["res_layers.2.fc2.weight"][k, m]
+    for s, lane in ((0, 0), (35, 63), (35, 5), (17, 40)):
+        k = khid(s, lane >> 4)
+        assert tf[s, lane] == (wf[k, lane & 15] if k < 141 else 0.0)
+    assert off_t0b + 4352 + 36 * 64 == n
     # unsupported: layer wider than 128
     dims_bad = (C.c_int * 3)(84, 256, 16)
     assert L.cppf_pair_mlp_packed_floats(40, dims_bad, 2, 10) == 0
@@ -210,18 +229,23 @@ def test_point_encoder_and_backward_abi_without_a_device(golden):
     assert L.cppf_point_encoder_forward(one, one, one, 10, 3, one, hid, 4, 32, 2, 32, 8, 1, one, None, 0, None) == -2
     assert L.cppf_point_encoder_forward(one, one, one, 100, 65, one, hid, 4, 32, 2, 32, 8, 1, one, one, 1 << 20, None) == -3
     dims = (C.c_int * 4)(84, 32, 32, 16)
-    # partial gradients + per-pair d(x0) rows + sort keys/values + segment starts + sort scratch
+    # weight image + point table + partial gradients + per-pair rows [d(h0) | d(x1)] + sort keys/values + per-point sums + scratch
     need = L.cppf_pair_mlp_backward_workspace_bytes(200000, 4096, 40, dims, 3, 141)
-    parts = 1563                                                          # 3 125 tiles, two per wavefront
-    assert parts * 12333 * 4 + 200000 * 80 * 4 + 8 * 200000 * 4 <= need < parts * 12333 * 4 + 200000 * 80 * 4 + 110 * 200000
-    assert L.cppf_pair_mlp_backward_workspace_bytes(130, 64, 40, dims, 3, 141) >= 3 * 12333 * 4 + 130 * 80 * 4
+    parts = 447                                                           # 3 125 tiles, seven per workgroup
+    fixed = 23024 * 4 + 4096 * 128 * 4 * 2 + parts * 12333 * 4 + 200000 * 64 * 4 + 8 * 200000 * 4
+    assert fixed <= need < fixed + 110 * 200000
+    assert L.cppf_pair_mlp_backward_workspace_bytes(130, 64, 40, dims, 3, 141) >= 3 * 12333 * 4 + 130 * 64 * 4
     other = (C.c_int * 3)(44, 24, 24)
     assert L.cppf_pair_mlp_backward_workspace_bytes(130, 64, 20, other, 2, 10) == 0
     offs = (C.c_int64 * 20)(*range(20))
     assert L.cppf_pair_mlp_backward(one, one, one, one, 1, one, offs, 10, 20, other, 2, 5, 10, one, one, one, one, 1 << 20,
                                     None) == -3
     assert L.cppf_pair_mlp_backward(one, one, one, one, 1, one, offs, 10, 40, dims, 3, 5, 141, one, one, one, None, 0,
+                                    None) == -1                                          # layer 1 has no fc0: offs[10] must be -1
+    offs[10] = offs[11] = -1
+    assert L.cppf_pair_mlp_backward(one, one, one, one, 1, one, offs, 10, 40, dims, 3, 5, 141, one, one, one, None, 0,
                                     None) == -2
+    assert L.cppf_pair_mlp_pack_device(one, offs, 20, other, 2, 10, one, None) == -3       # device pack: MFMA path only
     # row f3 entry points
     assert L.cppf_voxel_dedupe_workspace_bytes(70000) > 70000 * (16 + 8 + 1)
     assert L.cppf_voxel_dedupe(one, 10, 0.0, one, one, one, 1 << 30, None) == -1           # res must be positive
