@@ -220,7 +220,7 @@ def main():
 
     # secondary: one training-size forward + backward of the pair encoder (train.py:66,91:
     # 200 000 pairs, dL/dlogits given), HIP forward + HIP backward through the autograd.Function
-    t_train = None
+    t_train = t_step = None
     if rank == 0 and world == 1:
         Pt = 200000
         idx_t = d(syn.make_pairs(N_POINTS, (Pt + N_POINTS - 1) // N_POINTS, 7)[:Pt])
@@ -228,16 +228,31 @@ def main():
         feat_t = feat.clone().requires_grad_(True)
         enc.train()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for it in range(4):
+        for it in range(11):
             if it == 1:
                 e0.record()
             enc.zero_grad()
             feat_t.grad = None
-            (enc.forward_with_idx(pc, nrm, feat_t, idx_t) * Rt).sum().backward()
+            enc.forward_with_idx(pc, nrm, feat_t, idx_t).backward(Rt)
         e1.record()
         torch.cuda.synchronize()
+        t_train = e0.elapsed_time(e1) / 10
+        # the same with the weights changing every step (train.py:89-92: zero_grad, backward, Adam step): the weight
+        # image is re-packed on the device each step, nothing synchronises with the host
+        import copy
+        enc_t = copy.deepcopy(enc)
+        opt = torch.optim.Adam(enc_t.parameters(), lr=1e-4)
+        for it in range(11):
+            if it == 1:
+                e0.record()
+            opt.zero_grad()
+            feat_t.grad = None
+            enc_t.forward_with_idx(pc, nrm, feat_t, idx_t).backward(Rt)
+            opt.step()
+        e1.record()
+        torch.cuda.synchronize()
+        t_step = e0.elapsed_time(e1) / 10
         enc.eval()
-        t_train = e0.elapsed_time(e1) / 3
 
     if rank == 0:
         argmax_gpu = int(allrec[0, 12].item())
@@ -264,7 +279,8 @@ def main():
                          "vote_reduce_argmax_known_answer_inputs": t_vote_ka,
                          "full_pose_incl_readback": t_pose, "full_pose_n_surv": pose["n_surv"],
                          "point_encoder_knn60_sprin": t_penc,
-                         "pair_encoder_fwd_bwd_200k_pairs": t_train},
+                         "pair_encoder_fwd_bwd_200k_pairs": t_train,
+                         "pair_encoder_fwd_bwd_adam_step_200k_pairs": t_step},
             # dominant kernel = the fused pair encoder (one launch between the two events): exact-fp32
             # MFMA, 23 968 algorithmic FLOP per pair
             "roofline": {"bound": "mfma", "kernel": "pair_mlp_kernel<false,true,true>",
