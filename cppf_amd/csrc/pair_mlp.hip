@@ -256,14 +256,13 @@ struct MlpArgs {
 
 __device__ __forceinline__ void load_pair_idx(const MlpArgs& A, int64_t pair, int& ia, int& ib)
 {
+    // two 4-byte loads of the low words whatever the index width: an i32 / i64 branch around the loads ends in a
+    // wait for ALL outstanding loads (the gathers of the next tile that are in flight at this point)
     const int64_t p = pair < A.P ? pair : A.P - 1;
-    if (A.idx64) {
-        const longlong2 v = reinterpret_cast<const longlong2*>(A.idxs)[p];
-        ia = (int)v.x; ib = (int)v.y;
-    } else {
-        const int2 v = reinterpret_cast<const int2*>(A.idxs)[p];
-        ia = v.x; ib = v.y;
-    }
+    const int str = A.idx64 ? 4 : 2;
+    const int* q = reinterpret_cast<const int*>(A.idxs) + p * str;
+    ia = q[0];
+    ib = q[str >> 1];
 }
 
 // PPF of one pair from already loaded points/normals (models/model.py:118-129); component `g`.
