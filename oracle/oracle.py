@@ -400,6 +400,59 @@ def point_encoder(pc, nrm, nbrs, packed, desc, order=0):
     return out
 
 
+# --------------------------------------------------------------------------- backward of the point encoder
+SPRIN_BWD_MAX_PARTS = 1024
+
+
+def sprin_bwd_parts(N):
+    """number of partial accumulators (= wavefronts) the device kernel uses for N points"""
+    return min(SPRIN_BWD_MAX_PARTS, N)
+
+
+def point_encoder_grad_names():
+    """(parameter name, packed offset, shape, transposed) in the packed layout of cppf_point_encoder_pack for the
+    standard one-layer encoder (train.py:34)"""
+    out, pos = [], 0
+    dims = [(32, 6), (64, 32), (32, 64), (32, 32)]
+    for i, (h, w) in enumerate(dims):
+        out.append((f"spconvs.0.kernel.{3 * i}.weight", pos, (h, w), False)); pos += h * w
+        out.append((f"spconvs.0.kernel.{3 * i}.bias", pos, (h,), False)); pos += h
+        out.append((f"spconvs.0.kernel.{3 * i + 1}.weight", pos, (h,), False)); pos += h
+        out.append((f"spconvs.0.kernel.{3 * i + 1}.bias", pos, (h,), False)); pos += h
+    out.append(("spconvs.0.kernel.12.weight", pos, (32, 32), False)); pos += 1024
+    out.append(("spconvs.0.kernel.12.bias", pos, (32,), False)); pos += 32
+    out.append(("spconvs.0.outnet.weight", pos, (64, 32), True)); pos += 2048      # packed transposed [C][n_out]
+    out.append(("spconvs.0.outnet.bias", pos, (32,), False)); pos += 32
+    out.append(("spconvs.0.layer_norm.weight", pos, (32,), False)); pos += 32
+    out.append(("spconvs.0.layer_norm.bias", pos, (32,), False)); pos += 32
+    out.append(("aggrs.0.linear.weight", pos, (8, 32), False)); pos += 256
+    out.append(("aggrs.0.linear.bias", pos, (8,), False)); pos += 8
+    return out, pos
+
+
+def point_encoder_backward(pc, nrm, nbrs, packed, grad_out, n_parts=None):
+    """autograd of models/model.py:46-61 + models/sprin.py:40-107 w.r.t. the parameters (train.py:91):
+    returns ({parameter name: grad}, flat packed gradient)."""
+    pc, nrm, nbrs = _c(pc, _f), _c(nrm, _f), _c(nbrs, np.int32)
+    packed, grad_out = _c(packed, _f), _c(grad_out, _f)
+    N, k = nbrs.shape
+    names, total = point_encoder_grad_names()
+    L = lib()
+    L.orc_point_encoder_backward_params.restype = C.c_int64
+    assert L.orc_point_encoder_backward_params() == total
+    n_parts = sprin_bwd_parts(N) if n_parts is None else n_parts
+    g = np.zeros(total, np.float32)
+    rc = L.orc_point_encoder_backward(_p(pc, _pf), _p(nrm, _pf), _p(nbrs, _pi32), C.c_int(N), C.c_int(k), _p(packed, _pf),
+                                      _p(grad_out, _pf), C.c_int(n_parts), _p(g, _pf))
+    if rc != 0:
+        raise ValueError(f"orc_point_encoder_backward failed: {rc}")
+    grads = {}
+    for name, off, shape, tr in names:
+        a = g[off:off + int(np.prod(shape))].reshape(shape)
+        grads[name] = a.T.copy() if tr else a.copy()
+    return grads, g
+
+
 # --------------------------------------------------------------------------- backward of the pair MLP (row f2)
 BWD_MAX_PARTS = 512
 
