@@ -51,6 +51,10 @@ _SIGS = {
     "cppf_point_encoder_packed_floats": (sz, [C.POINTER(C.c_int), i32, i32, i32, i32, i32, i32]),
     "cppf_point_encoder_pack": (C.c_int, [vp, C.POINTER(C.c_int), i32, i32, i32, i32, i32, i32, vp]),
     "cppf_point_encoder_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "cppf_point_encoder_backward_workspace_bytes": (sz, [i32]),
+    "cppf_point_encoder_pack_device": (C.c_int, [vp, C.POINTER(C.c_int), i32, i32, i32, i32, i32, i32, vp, vp]),
+    "cppf_point_encoder_backward": (C.c_int, [vp, vp, vp, i32, i32, vp, C.POINTER(C.c_int), i32, i32, i32, i32, i32, i32, vp, vp,
+                                              vp, vp, sz, vp]),
     "cppf_point_encoder_forward": (C.c_int, [vp, vp, vp, i32, i32, vp, C.POINTER(C.c_int), i32, i32, i32, i32, i32, i32,
                                              vp, vp, sz, vp]),
 }

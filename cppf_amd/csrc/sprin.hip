@@ -18,8 +18,10 @@
 #include <string.h>
 #include "../../include/cppf.h"
 #include "cppf_math.h"
+#include "sprin_layout.h"
 
 using namespace cppf;
+using namespace sprin;
 
 namespace {
 
@@ -187,80 +189,6 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_kernel(const float* __rest
 }
 
 // --------------------------------------------------------------------------------------------- conv
-constexpr int SP_WAVES_MAX = 8;   // points per workgroup: 8 when the per-wave LDS is small (first layer), else 4
-constexpr int SP_RANK = 32, SP_NOUT = 32;
-constexpr int SP_KSTRIDE = SP_RANK + 1;  // kern[j][r] row stride in LDS (odd: conflict-free column walks)
-
-// ---- kernel-MLP on v_mfma_f32_16x16x4_f32, transposed: D[out][row] = W[out][k] * X^T[k][row].
-// One instruction covers 16 outputs x 16 neighbour rows x 4 inputs; lane l = (j = l & 15 -> row, g = l >> 4).
-// A operand = one weight from the lane-ordered LDS image, B operand = one activation register, D = f32x4 =
-// outputs 16*ob + 4*g + r of row j.  The D layout of a layer is the B layout of the next one if that layer walks
-// its inputs as k(s, g) = 16*(s/4) + 4*g + s%4, so the five layers chain with no data movement (same scheme as
-// csrc/pair_mlp.hip); the exact-fp32 MFMA reproduces the oracle's fmaf chain in that order (order = 1).
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int SPW_L1 = 0;                         // [2 ob][2 s][64]   (inputs 6, 7 are zero columns)
-constexpr int SPW_L2 = SPW_L1 + 2 * 2 * 64;       // [4 ob][8 s][64]
-constexpr int SPW_L3 = SPW_L2 + 4 * 8 * 64;       // [2 ob][16 s][64]
-constexpr int SPW_L4 = SPW_L3 + 2 * 16 * 64;      // [2 ob][8 s][64]
-constexpr int SPW_L5 = SPW_L4 + 2 * 8 * 64;       // [2 ob][8 s][64]
-constexpr int SPW_VEC = SPW_L5 + 2 * 8 * 64;      // bias/gamma/beta in natural order: b1 g1 be1 b2 g2 be2 b3 g3 be3 b4 g4 be4 b5
-constexpr int SPW_B1 = SPW_VEC, SPW_B2 = SPW_B1 + 96, SPW_B3 = SPW_B2 + 192, SPW_B4 = SPW_B3 + 96, SPW_B5 = SPW_B4 + 96;
-constexpr int SPW_FLOATS = SPW_B5 + 32;           // 6 912 floats = 27 KB, one copy per workgroup
-constexpr int SP_NAT_KERNEL = 6 * 32 + 3 * 32 + 32 * 64 + 3 * 64 + 64 * 32 + 3 * 32 + 32 * 32 + 3 * 32 + 32 * 32 + 32;  // natural floats
-
-__device__ __forceinline__ float sp_xor16(float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401f)); }
-__device__ __forceinline__ float sp_xor32(float v, int lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_int(v))); }
-
-template <int NIB, int NOB>   // inputs 16*NIB (held as NIB f32x4), outputs 16*NOB
-__device__ __forceinline__ void sp_mfma_layer(const float* __restrict__ Wl, const float* __restrict__ bias, const f32x4 (&x)[NIB],
-                                              f32x4 (&y)[NOB], int lane, int g)
-{
-#pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) y[ob] = *reinterpret_cast<const f32x4*>(bias + 16 * ob + 4 * g);
-#pragma unroll
-    for (int s = 0; s < 4 * NIB; ++s) {
-#pragma unroll
-        for (int ob = 0; ob < NOB; ++ob)
-            y[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wl[(ob * 4 * NIB + s) * 64 + lane], x[s / 4][s % 4], y[ob], 0, 0, 0);
-    }
-}
-// LayerNorm (eps 1e-5, affine) + ReLU on a row spread over the 4 lanes g: per-lane partial sums in (ob, r) order,
-// combined as (p0 + p1) + (p2 + p3) through the LDS crossbar (oracle/sprin_oracle.c:layer_norm_ord)
-template <int NOB>
-__device__ __forceinline__ void sp_ln_relu4(f32x4 (&y)[NOB], const float* __restrict__ gamma, const float* __restrict__ beta, int lane,
-                                            int g)
-{
-    constexpr float H = 16.f * NOB;
-    float p = 0.f;
-#pragma unroll
-    for (int ob = 0; ob < NOB; ++ob)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) p = p + y[ob][r];
-    p = p + sp_xor16(p);
-    p = p + sp_xor32(p, lane);
-    const float mean = p / H;
-    float q = 0.f;
-#pragma unroll
-    for (int ob = 0; ob < NOB; ++ob)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const float d = y[ob][r] - mean; q = q + d * d; }
-    q = q + sp_xor16(q);
-    q = q + sp_xor32(q, lane);
-    const float inv = 1.0f / sqrtf(q / H + 1e-5f);
-#pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) {
-        const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 16 * ob + 4 * g);
-        const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + 16 * ob + 4 * g);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float z = ((y[ob][r] - mean) * inv) * gm[r] + bt[r];
-            y[ob][r] = z > 0.f ? z : 0.f;
-        }
-    }
-}
-
-__device__ __forceinline__ float norm3(float x, float y, float z) { return sqrtf((x * x + y * y) + z * z); }
-
 __host__ __device__ constexpr int sp_per_wave(int n_in) { return 16 * SP_KSTRIDE + 64 * n_in + SP_RANK * n_in + 64 * 3 + SP_NOUT + 64 * 8; }
 __host__ __device__ constexpr int sp_waves(int n_in) { return n_in <= 4 ? SP_WAVES_MAX : 4; }
 
@@ -490,31 +418,7 @@ int cppf_point_encoder_pack(const float* natural, const int32_t* hidden, int n_h
     for (int l = 0; l < num_layers; ++l) {
         const int n_in = l == 0 ? n_nbr_feats : n_out + n_glob;
         float* img = out + nat + (size_t)l * SPW_FLOATS;
-        const float* q = p;
-        // layer 1: k = 4*s + g, inputs 6 and 7 are zero columns
-        for (int ob = 0; ob < 2; ++ob)
-            for (int s_ = 0; s_ < 2; ++s_)
-                for (int ln = 0; ln < 64; ++ln) {
-                    const int o = 16 * ob + (ln & 15), k = 4 * s_ + (ln >> 4);
-                    img[SPW_L1 + (ob * 2 + s_) * 64 + ln] = k < 6 ? q[o * 6 + k] : 0.f;
-                }
-        q += 32 * 6;
-        memcpy(img + SPW_B1, q, 96 * sizeof(float)); q += 96;
-        // layers 2..5: k(s, g) = 16*(s/4) + 4*g + s%4
-        const int off[4] = {SPW_L2, SPW_L3, SPW_L4, SPW_L5}, in_[4] = {32, 64, 32, 32}, out_[4] = {64, 32, 32, 32};
-        const int vec[4] = {SPW_B2, SPW_B3, SPW_B4, SPW_B5};
-        for (int L = 0; L < 4; ++L) {
-            const int S = in_[L] / 4;
-            for (int ob = 0; ob < out_[L] / 16; ++ob)
-                for (int s_ = 0; s_ < S; ++s_)
-                    for (int ln = 0; ln < 64; ++ln) {
-                        const int o = 16 * ob + (ln & 15), k = 16 * (s_ / 4) + 4 * (ln >> 4) + (s_ % 4);
-                        img[off[L] + (ob * S + s_) * 64 + ln] = q[o * in_[L] + k];
-                    }
-            q += out_[L] * in_[L];
-            const int nv = L < 3 ? 3 * out_[L] : out_[L];   // bias, ln weight, ln bias (the last linear has only a bias)
-            memcpy(img + vec[L], q, nv * sizeof(float)); q += nv;
-        }
+        for (int i = 0; i < SPW_FLOATS; ++i) img[i] = sp_image_elem(i, p);
         p += conv_params(hidden, n_hidden, rank, n_in, n_out) + (size_t)n_glob * n_out + n_glob;
     }
     return 0;

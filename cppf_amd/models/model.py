@@ -92,6 +92,46 @@ class _PairMlpFunction(torch.autograd.Function):
         return (None, None, None, gf if ctx.needs_input_grad[3] else None, None, *grads)
 
 
+class _PointEncoderFunction(torch.autograd.Function):
+    """PointEncoder.forward under autograd with a HIP backward (train.py:62-64,91): forward = the inference kernels
+    (kNN from `dist` + SPRIN), backward = cppf_point_encoder_backward, which recomputes the forward per point.  Points
+    and normals carry no gradient (train.py:58-60); gradients flow to the parameters, in `_ordered_params` order."""
+
+    @staticmethod
+    def forward(ctx, enc, pc, nrm, nbrs, *params):
+        with torch.no_grad():
+            out = enc._forward_device(pc, nrm, nbrs)
+        ctx.enc = enc
+        ctx.save_for_backward(pc, nrm, nbrs, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        enc = ctx.enc
+        pc, nrm, nbrs, out = ctx.saved_tensors
+        dev = pc.device
+        packed, desc = enc._packed_weights(dev)
+        hid = (C.c_int * len(desc["hidden"]))(*desc["hidden"])
+        L = _lib.lib()
+        N, k = nbrs.shape
+        g = grad_out.detach().float().contiguous()
+        n_nat = sum(p.numel() for p in enc._ordered_params())
+        gp = torch.empty(n_nat, dtype=torch.float32, device=dev)
+        ws = workspace(max(int(L.cppf_point_encoder_backward_workspace_bytes(N)), 256), dev, "point_encoder_bwd")
+        with torch.cuda.device(dev):
+            rc = L.cppf_point_encoder_backward(pc.data_ptr(), nrm.data_ptr(), nbrs.data_ptr(), N, k, packed.data_ptr(), hid,
+                                               len(desc["hidden"]), desc["rank"], desc["n_nbr_feats"], desc["n_out"],
+                                               desc["n_glob"], enc.num_layers, out.data_ptr(), g.data_ptr(), gp.data_ptr(),
+                                               ws.data_ptr(), ws.numel(), stream_ptr(dev))
+        _lib.check(rc, "cppf_point_encoder_backward")
+        grads, pos = [], 0
+        for p, transposed in zip(enc._ordered_params(), enc._ordered_transposed()):
+            v = gp[pos:pos + p.numel()]
+            grads.append(v.reshape(p.shape[1], p.shape[0]).t() if transposed else v.reshape(p.shape))
+            pos += p.numel()
+        return (None, None, None, None, *grads)
+
+
 class PointEncoder(nn.Module):
     """models/model.py:36-78.  Same constructor, parameter names and call signatures as the reference."""
 
@@ -113,6 +153,11 @@ class PointEncoder(nn.Module):
     # ------------------------------------------------------------------ reference signatures
     def forward(self, pc, pc_normal, dist=None):
         if self._needs_graph(pc):
+            if self._has_device_backward(pc, pc_normal):
+                pc2, nrm2 = self._check_inputs(pc, pc_normal)
+                d2 = None if dist is None else dist.detach().reshape(pc2.shape[0], pc2.shape[0]).float().contiguous()
+                out = _PointEncoderFunction.apply(self, pc2, nrm2, self.neighbours(pc2, d2), *self._ordered_params())
+                return out.reshape(*pc.shape[:-1], -1)
             if dist is None:
                 dist = torch.cdist(pc, pc)
             nbrs = torch.topk(dist, self.k, largest=False, sorted=False)[1]          # models/model.py:47
@@ -126,6 +171,11 @@ class PointEncoder(nn.Module):
 
     def forward_nbrs(self, pc, pc_normal, nbrs_idx):
         if self._needs_graph(pc):
+            if self._has_device_backward(pc, pc_normal):
+                pc2, nrm2 = self._check_inputs(pc, pc_normal)
+                nbrs = nbrs_idx.reshape(pc2.shape[0], -1).to(device=pc2.device, dtype=torch.int32).contiguous()
+                out = _PointEncoderFunction.apply(self, pc2, nrm2, nbrs, *self._ordered_params())
+                return out.reshape(*pc.shape[:-1], -1)
             return self._composite(pc, pc_normal, nbrs_idx)
         pc2, nrm2 = self._check_inputs(pc, pc_normal)
         nbrs = nbrs_idx.reshape(pc2.shape[0], -1).to(device=pc2.device, dtype=torch.int32).contiguous()
@@ -171,6 +221,28 @@ class PointEncoder(nn.Module):
             return False
         return pc.requires_grad or any(p.requires_grad for p in self.parameters())
 
+    def _has_device_backward(self, pc, pc_normal):
+        """csrc/sprin_bwd.hip covers the one-layer standard encoder (train.py:34) when only the parameters need gradients"""
+        return (pc.is_cuda and self.num_layers == 1 and self.spfcs == [32, 64, 32, 32] and self.out_dim == 32
+                and self.num_nbr_feats == 2 and self.k <= 64 and not pc.requires_grad and not pc_normal.requires_grad
+                and self.spconvs[0].layer_norm is not None)
+
+    def _ordered_params(self):
+        """parameters in the packed natural order of `pack_point_encoder` (one layer)"""
+        ker = self.spconvs[0].kernel
+        ps = []
+        for i in range(0, len(ker) - 1, 3):
+            ps += [ker[i].weight, ker[i].bias, ker[i + 1].weight, ker[i + 1].bias]
+        ps += [ker[len(ker) - 1].weight, ker[len(ker) - 1].bias]
+        sc = self.spconvs[0]
+        return ps + [sc.outnet.weight, sc.outnet.bias, sc.layer_norm.weight, sc.layer_norm.bias,
+                     self.aggrs[0].linear.weight, self.aggrs[0].linear.bias]
+
+    def _ordered_transposed(self):
+        """which of `_ordered_params` are stored transposed in the packed layout (outnet.weight: [C][n_out])"""
+        ps = self._ordered_params()
+        return [p is self.spconvs[0].outnet.weight for p in ps]
+
     def _composite(self, pc, pc_normal, nbrs_idx):
         """models/model.py:63-78 as torch ops (autograd path)."""
         gather = lambda t: torch.gather(t.unsqueeze(-3).expand(*t.shape[:-1], *t.shape[-2:]), -2,
@@ -194,6 +266,25 @@ class PointEncoder(nn.Module):
 
     def _packed_weights(self, device):
         key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        dev = torch.device(device)
+        if (self._packed is None or self._packed_key != key) and dev.type == "cuda" and self.num_layers == 1 \
+                and self.spfcs == [32, 64, 32, 32] and self.out_dim == 32 and self.num_nbr_feats == 2 \
+                and self.spconvs[0].layer_norm is not None:
+            # standard encoder: natural block by one torch.cat, MFMA image by a device kernel -- no host round trip, so
+            # a training loop (weights change every step) stays on the stream
+            nat = torch.cat([(p.detach().t() if tr else p.detach()).reshape(-1).float()
+                             for p, tr in zip(self._ordered_params(), self._ordered_transposed())]).to(dev).contiguous()
+            desc = dict(hidden=list(self.spfcs), rank=32, n_nbr_feats=2, n_out=32, n_glob=self.out_dim // 4, num_layers=1)
+            hid = (C.c_int * 4)(*self.spfcs)
+            L = _lib.lib()
+            n = L.cppf_point_encoder_packed_floats(hid, 4, 32, 2, 32, desc["n_glob"], 1)
+            packed = torch.empty(int(n), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                rc = L.cppf_point_encoder_pack_device(nat.data_ptr(), hid, 4, 32, 2, 32, desc["n_glob"], 1, packed.data_ptr(),
+                                                      stream_ptr(dev))
+            _lib.check(rc, "cppf_point_encoder_pack_device")
+            self._packed = (packed, desc)
+            self._packed_key = key
         if self._packed is None or self._packed_key != key:
             sd = {k: v.detach().float().cpu().numpy() for k, v in self.state_dict().items()}
             natural, desc = pack_point_encoder(sd, self.num_layers)

@@ -274,6 +274,28 @@ int cppf_pair_mlp_backward(const float* pc, const float* nrm, const float* feat,
                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Backward of the point encoder: gradients of the parameters of the one-layer standard encoder (train.py:34: hidden
+ * {32,64,32,32}, rank 32, 2 neighbour features, n_out 32, n_glob 8, k <= 64; anything else CPPF_EUNSUPPORTED).  The
+ * reference has no backward code -- train.py:91 differentiates models/model.py:46-61 + models/sprin.py:40-107 with
+ * autograd; points and normals carry no gradient there (train.py:58-60).
+ *   packed       device f32: natural parameters + forward image, as cppf_point_encoder_forward takes them
+ *   out_fwd      device f32[n_points, 40]: the forward output for the same inputs (the pooled maxima are read from it)
+ *   grad_out     device f32[n_points, 40]
+ *   grad_packed  device f32[9 256]: d/d(natural parameters) in the natural layout (outnet weight transposed), OVERWRITTEN
+ * cppf_point_encoder_pack_device builds `packed` from natural parameters that already live on the device (training).
+ * One wavefront per point, at most CPPF_SPRIN_BWD_MAX_PARTS partial gradients added in a fixed two-level order: the
+ * result is deterministic (oracle/sprin_bwd_oracle.c restates the order).
+ * ------------------------------------------------------------------------------------------- */
+#define CPPF_SPRIN_BWD_MAX_PARTS 1024
+size_t cppf_point_encoder_backward_workspace_bytes(int n_points);
+int cppf_point_encoder_pack_device(const float* natural, const int32_t* hidden, int n_hidden, int rank, int n_nbr_feats, int n_out,
+                                   int n_glob, int num_layers, float* packed, void* stream);
+int cppf_point_encoder_backward(const float* pc, const float* nrm, const int32_t* nbrs, int n_points, int k, const float* packed,
+                                const int32_t* hidden, int n_hidden, int rank, int n_nbr_feats, int n_out, int n_glob,
+                                int num_layers, const float* out_fwd, const float* grad_out, float* grad_packed, void* workspace,
+                                size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Pre-processing in front of the path.  Both replace third-party host calls whose
  * results are not fully specified, so parity with the reference is unpinned; the definitions are in
  * oracle/preproc_oracle.c.
