@@ -220,7 +220,7 @@ def main():
 
     # secondary: one training-size forward + backward of the pair encoder (train.py:66,91:
     # 200 000 pairs, dL/dlogits given), HIP forward + HIP backward through the autograd.Function
-    t_train = t_step = None
+    t_train = t_step = t_full = None
     if rank == 0 and world == 1:
         Pt = 200000
         idx_t = d(syn.make_pairs(N_POINTS, (Pt + N_POINTS - 1) // N_POINTS, 7)[:Pt])
@@ -252,6 +252,24 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         t_step = e0.elapsed_time(e1) / 10
+        # the whole of train.py:58-92 for one sample: cdist, point encoder, pair encoder, backward through both, Adam
+        from cppf_amd.models.model import PointEncoder
+        torch.manual_seed(2)
+        penc_t = PointEncoder(k=60, spfcs=[32, 64, 32, 32], num_layers=1, out_dim=32).to(dev).train()
+        opt2 = torch.optim.Adam([*penc_t.parameters(), *enc_t.parameters()], lr=1e-4)
+        pcs_b, nrm_b = pc[None], nrm[None]
+        for it in range(11):
+            if it == 1:
+                e0.record()
+            opt2.zero_grad()
+            with torch.no_grad():
+                dist_b = torch.cdist(pcs_b, pcs_b)
+            f_b = penc_t(pcs_b, nrm_b, dist_b)
+            enc_t(pcs_b, nrm_b, f_b, idxs=idx_t)[0].backward(Rt)
+            opt2.step()
+        e1.record()
+        torch.cuda.synchronize()
+        t_full = e0.elapsed_time(e1) / 10
         enc.eval()
 
     if rank == 0:
@@ -280,7 +298,8 @@ def main():
                          "full_pose_incl_readback": t_pose, "full_pose_n_surv": pose["n_surv"],
                          "point_encoder_knn60_sprin": t_penc,
                          "pair_encoder_fwd_bwd_200k_pairs": t_train,
-                         "pair_encoder_fwd_bwd_adam_step_200k_pairs": t_step},
+                         "pair_encoder_fwd_bwd_adam_step_200k_pairs": t_step,
+                         "train_step_both_encoders_adam_200k_pairs": t_full},
             # dominant kernel = the fused pair encoder (one launch between the two events): exact-fp32
             # MFMA, 23 968 algorithmic FLOP per pair
             "roofline": {"bound": "mfma", "kernel": "pair_mlp_kernel<false,true,true>",

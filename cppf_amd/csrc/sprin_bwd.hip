@@ -127,16 +127,38 @@ __device__ __forceinline__ void ln_bwd(const f32x4 (&da)[NOB], const f32x4 (&xh)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dy[ob][r] = ((gd[ob][r] - m1) - xh[ob][r] * m2) * inv;
 }
-// transposed chain: d(in)[16*ib + 4g + r] of the lane's row = chain over the outputs in khid order of W[o][i] * d[o], from 0
-template <int NIB, int NOB>   // NIB input blocks produced, NOB output blocks consumed
-__device__ __forceinline__ void t_layer(const float* __restrict__ T, const f32x4 (&d)[NOB], f32x4 (&dx)[NIB], int lane)
+// One wavefront per SIMD hides nothing by itself: every block of MFMAs gets its A operands (a layer's lane-ordered
+// weights, or the staged deltas / activations of a gradient tile) loaded into registers one block AHEAD, and
+// sched_barrier pins "next block's ds_reads | this block's MFMAs" (see pair_mlp_bwd.hip).
+#define SPB_SB() __builtin_amdgcn_sched_barrier(0)
+template <int NW>
+__device__ __forceinline__ void ldw(const float* __restrict__ base, int lane, float (&w)[NW])
+{
+#pragma unroll
+    for (int i = 0; i < NW; ++i) w[i] = base[i * 64 + lane];
+}
+template <int NIB, int NOB>   // y = bias + W x with the layer's weights already in registers (image order [ob][s])
+__device__ __forceinline__ void layer_pre(const float (&w)[NOB * 4 * NIB], const float* __restrict__ bias, const f32x4 (&x)[NIB],
+                                          f32x4 (&y)[NOB], int g)
+{
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) y[ob] = *reinterpret_cast<const f32x4*>(bias + 16 * ob + 4 * g);
+#pragma unroll
+    for (int s = 0; s < 4 * NIB; ++s)
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) y[ob] = mfma4(w[ob * 4 * NIB + s], x[s / 4][s % 4], y[ob]);
+}
+// transposed chain: d(in)[16*ib + 4g + r] of the lane's row = chain over the outputs in khid order of W[o][i] * d[o], from 0;
+// the transposed weights are already in registers (image order [ib][s])
+template <int NIB, int NOB>
+__device__ __forceinline__ void t_pre(const float (&w)[NIB * 4 * NOB], const f32x4 (&d)[NOB], f32x4 (&dx)[NIB])
 {
 #pragma unroll
     for (int ib = 0; ib < NIB; ++ib) dx[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 4 * NOB; ++s)
 #pragma unroll
-        for (int ib = 0; ib < NIB; ++ib) dx[ib] = mfma4(T[(ib * 4 * NOB + s) * 64 + lane], d[s / 4][s % 4], dx[ib]);
+        for (int ib = 0; ib < NIB; ++ib) dx[ib] = mfma4(w[ib * 4 * NOB + s], d[s / 4][s % 4], dx[ib]);
 }
 
 __global__ __launch_bounds__(SPB_WAVES * 64, 1) void sprin_bwd_kernel(SpbArgs A)
@@ -195,20 +217,21 @@ __global__ __launch_bounds__(SPB_WAVES * 64, 1) void sprin_bwd_kernel(SpbArgs A)
     const int rd0 = 16 * g + 4 * ((j >> 2) ^ (g >> 1)) + (j & 3);
     auto put = [&](int blk, f32x4 v) { *reinterpret_cast<f32x4*>(my + blk * STG_BLK) = v; };
     auto rdw = [&](int blk, int s) -> float { return stg[blk * STG_BLK + 64 * s + (rd0 ^ ((s & 1) << 3))]; };
-    // NA delta blocks (staged 0..NA-1) x NB input blocks (staged NA..NA+NB-1): tiles += delta^T input over the 16 rows;
-    // bias sub-sums += the delta operand
-#define WGRAD(NA, NB, TILE, SB)                                                                   \
+    // gradient tiles of one layer: NA delta blocks (staged 0..NA-1) x NB input blocks (staged NA..NA+NB-1).  WG_FETCH
+    // reads the 4 x (NA + NB) operands (rows on the k axis), WG_RUN issues the NA x NB x 4 MFMAs; bias sub-sums += deltas
+#define WG_FETCH(NA, NB, OPS)                                                                     \
     do {                                                                                          \
         wave_lds_fence();                                                                         \
-        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                           \
-            float av[NA], bv[NB];                                                                 \
-            _Pragma("unroll") for (int a = 0; a < NA; ++a) av[a] = rdw(a, s);                     \
-            _Pragma("unroll") for (int b = 0; b < NB; ++b) bv[b] = rdw(NA + b, s);                \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s)                                             \
+            _Pragma("unroll") for (int q = 0; q < NA + NB; ++q) OPS[s][q] = rdw(q, s);            \
+    } while (0)
+#define WG_RUN(NA, NB, OPS, TILE, SB)                                                             \
+    do {                                                                                          \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s)                                             \
             _Pragma("unroll") for (int a = 0; a < NA; ++a) {                                      \
-                SB[a] = SB[a] + av[a];                                                            \
-                _Pragma("unroll") for (int b = 0; b < NB; ++b) TILE[a][b] = mfma4(av[a], bv[b], TILE[a][b]); \
+                SB[a] = SB[a] + OPS[s][a];                                                        \
+                _Pragma("unroll") for (int b = 0; b < NB; ++b) TILE[a][b] = mfma4(OPS[s][a], OPS[s][NA + b], TILE[a][b]); \
             }                                                                                     \
-        }                                                                                         \
     } while (0)
 
     for (int n = w; n < A.N; n += A.n_parts) {
@@ -245,22 +268,32 @@ __global__ __launch_bounds__(SPB_WAVES * 64, 1) void sprin_bwd_kernel(SpbArgs A)
 #pragma unroll 1
         for (int rb = 0; rb < 4; ++rb) {
             f32x4 a1[2], a2[4], a3[2], a4[2], kr[2];
+            float w1[4], wa[32], wb[32], wc[16];
+            ldw<4>(Wl + SPW_L1, lane, w1);
+            ldw<32>(Wl + SPW_L2, lane, wa);
+            const float bx0 = x6l[(16 * rb + j) * 8 + g], bx1 = x6l[(16 * rb + j) * 8 + 4 + g];
 #pragma unroll
             for (int ob = 0; ob < 2; ++ob) a1[ob] = *reinterpret_cast<const f32x4*>(Wl + SPW_B1 + 16 * ob + 4 * g);
+            SPB_SB();
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const float bx = x6l[(16 * rb + j) * 8 + 4 * s + g];
-#pragma unroll
-                for (int ob = 0; ob < 2; ++ob) a1[ob] = mfma4(Wl[SPW_L1 + (ob * 2 + s) * 64 + lane], bx, a1[ob]);
-            }
+            for (int ob = 0; ob < 2; ++ob) { a1[ob] = mfma4(w1[ob * 2], bx0, a1[ob]); a1[ob] = mfma4(w1[ob * 2 + 1], bx1, a1[ob]); }
+            ldw<32>(Wl + SPW_L3, lane, wb);
+            SPB_SB();
             sp_ln_relu4<2>(a1, Wl + SPW_B1 + 32, Wl + SPW_B1 + 64, lane, g);
-            sp_mfma_layer<2, 4>(Wl + SPW_L2, Wl + SPW_B2, a1, a2, lane, g);
+            layer_pre<2, 4>(wa, Wl + SPW_B2, a1, a2, g);
+            ldw<16>(Wl + SPW_L4, lane, wc);
+            SPB_SB();
             sp_ln_relu4<4>(a2, Wl + SPW_B2 + 64, Wl + SPW_B2 + 128, lane, g);
-            sp_mfma_layer<4, 2>(Wl + SPW_L3, Wl + SPW_B3, a2, a3, lane, g);
-            sp_ln_relu4<2>(a3, Wl + SPW_B3 + 32, Wl + SPW_B3 + 64, lane, g);
-            sp_mfma_layer<2, 2>(Wl + SPW_L4, Wl + SPW_B4, a3, a4, lane, g);
-            sp_ln_relu4<2>(a4, Wl + SPW_B4 + 32, Wl + SPW_B4 + 64, lane, g);
-            sp_mfma_layer<2, 2>(Wl + SPW_L5, Wl + SPW_B5, a4, kr, lane, g);
+            layer_pre<4, 2>(wb, Wl + SPW_B3, a2, a3, g);
+            {
+                float wd[16];
+                ldw<16>(Wl + SPW_L5, lane, wd);
+                SPB_SB();
+                sp_ln_relu4<2>(a3, Wl + SPW_B3 + 32, Wl + SPW_B3 + 64, lane, g);
+                layer_pre<2, 2>(wc, Wl + SPW_B4, a3, a4, g);
+                sp_ln_relu4<2>(a4, Wl + SPW_B4 + 32, Wl + SPW_B4 + 64, lane, g);
+                layer_pre<2, 2>(wd, Wl + SPW_B5, a4, kr, g);
+            }
 #pragma unroll
             for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
@@ -339,22 +372,26 @@ __global__ __launch_bounds__(SPB_WAVES * 64, 1) void sprin_bwd_kernel(SpbArgs A)
             const int row = 16 * rb + j;
             f32x4 y1[2], y2[4], y3[2], y4[2], xh1[2], xh2[4], xh3[2], xh4[2], a1[2], a2[4], a3[2], a4[2];
             float inv1, inv2, inv3, inv4;
-            f32x4 x6b;   // inputs of layer 1 as a staged block: features 4g + r of the row (6, 7 and 8..15 are zero)
+            float wa[32], wb[32], wc[16], ops[4][6];
+            {
+                float w1[4];
+                ldw<4>(Wl + SPW_L1, lane, w1);
+                ldw<32>(Wl + SPW_L2, lane, wa);
+                const float bx0 = x6l[row * 8 + g], bx1 = x6l[row * 8 + 4 + g];
 #pragma unroll
-            for (int ob = 0; ob < 2; ++ob) y1[ob] = *reinterpret_cast<const f32x4*>(Wl + SPW_B1 + 16 * ob + 4 * g);
+                for (int ob = 0; ob < 2; ++ob) y1[ob] = *reinterpret_cast<const f32x4*>(Wl + SPW_B1 + 16 * ob + 4 * g);
+                SPB_SB();
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const float bx = x6l[row * 8 + 4 * s + g];
-#pragma unroll
-                for (int ob = 0; ob < 2; ++ob) y1[ob] = mfma4(Wl[SPW_L1 + (ob * 2 + s) * 64 + lane], bx, y1[ob]);
+                for (int ob = 0; ob < 2; ++ob) { y1[ob] = mfma4(w1[ob * 2], bx0, y1[ob]); y1[ob] = mfma4(w1[ob * 2 + 1], bx1, y1[ob]); }
             }
+            ldw<32>(Wl + SPW_L3, lane, wb);
+            SPB_SB();
             ln_fwd<2>(y1, Wl + SPW_B1 + 32, Wl + SPW_B1 + 64, lane, g, xh1, a1, inv1);
-            sp_mfma_layer<2, 4>(Wl + SPW_L2, Wl + SPW_B2, a1, y2, lane, g);
+            layer_pre<2, 4>(wa, Wl + SPW_B2, a1, y2, g);
+            ldw<16>(Wl + SPW_L4, lane, wc);
+            SPB_SB();
             ln_fwd<4>(y2, Wl + SPW_B2 + 64, Wl + SPW_B2 + 128, lane, g, xh2, a2, inv2);
-            sp_mfma_layer<4, 2>(Wl + SPW_L3, Wl + SPW_B3, a2, y3, lane, g);
-            ln_fwd<2>(y3, Wl + SPW_B3 + 32, Wl + SPW_B3 + 64, lane, g, xh3, a3, inv3);
-            sp_mfma_layer<2, 2>(Wl + SPW_L4, Wl + SPW_B4, a3, y4, lane, g);
-            ln_fwd<2>(y4, Wl + SPW_B4 + 32, Wl + SPW_B4 + 64, lane, g, xh4, a4, inv4);
+            layer_pre<4, 2>(wb, Wl + SPW_B3, a2, y3, g);
             // d(kernel value)[f] of the row = chain_i d(mixed)[2f + i] * nf[row][i]; rows past k contribute nothing
             f32x4 dk[2];
             {
@@ -369,46 +406,61 @@ __global__ __launch_bounds__(SPB_WAVES * 64, 1) void sprin_bwd_kernel(SpbArgs A)
                         dk[ob][r] = live ? v : 0.f;
                     }
             }
-            // layer 5: d(W5) += dk x a4;  d(a4) = W5^T dk
+            float w5[16];
+            ldw<16>(Tl + SPT_5, lane, w5);
+            SPB_SB();
+            ln_fwd<2>(y3, Wl + SPW_B3 + 32, Wl + SPW_B3 + 64, lane, g, xh3, a3, inv3);
+            layer_pre<2, 2>(wc, Wl + SPW_B4, a3, y4, g);
+            ln_fwd<2>(y4, Wl + SPW_B4 + 32, Wl + SPW_B4 + 64, lane, g, xh4, a4, inv4);
+            // ---- layer 5: d(W5) += dk x a4;  d(a4) = W5^T dk
             put(0, dk[0]); put(1, dk[1]); put(2, a4[0]); put(3, a4[1]);
-            f32x4 da4[2];
-            t_layer<2, 2>(Tl + SPT_5, dk, da4, lane);
-            WGRAD(2, 2, tW5, sb5);
-            f32x4 dy4[2];
+            WG_FETCH(2, 2, ops);
+            ldw<16>(Tl + SPT_4, lane, wc);
+            SPB_SB();
+            f32x4 da4[2], dy4[2];
+            t_pre<2, 2>(w5, dk, da4);
+            WG_RUN(2, 2, ops, tW5, sb5);
             ln_bwd<2>(da4, xh4, a4, inv4, Wl + SPW_B4 + 32, lane, g, dy4, dG4, dE4);
-            // layer 4
+            // ---- layer 4
             put(0, dy4[0]); put(1, dy4[1]); put(2, a3[0]); put(3, a3[1]);
-            f32x4 da3[2];
-            t_layer<2, 2>(Tl + SPT_4, dy4, da3, lane);
-            WGRAD(2, 2, tW4, sb4);
-            f32x4 dy3[2];
+            WG_FETCH(2, 2, ops);
+            ldw<32>(Tl + SPT_3, lane, wa);
+            SPB_SB();
+            f32x4 da3[2], dy3[2];
+            t_pre<2, 2>(wc, dy4, da3);
+            WG_RUN(2, 2, ops, tW4, sb4);
             ln_bwd<2>(da3, xh3, a3, inv3, Wl + SPW_B3 + 32, lane, g, dy3, dG3, dE3);
-            // layer 3 (64 -> 32)
+            // ---- layer 3 (64 -> 32)
             put(0, dy3[0]); put(1, dy3[1]); put(2, a2[0]); put(3, a2[1]); put(4, a2[2]); put(5, a2[3]);
-            f32x4 da2[4];
-            t_layer<4, 2>(Tl + SPT_3, dy3, da2, lane);
-            WGRAD(2, 4, tW3, sb3);
-            f32x4 dy2[4];
+            WG_FETCH(2, 4, ops);
+            ldw<32>(Tl + SPT_2, lane, wb);
+            SPB_SB();
+            f32x4 da2[4], dy2[4];
+            t_pre<4, 2>(wa, dy3, da2);
+            WG_RUN(2, 4, ops, tW3, sb3);
             ln_bwd<4>(da2, xh2, a2, inv2, Wl + SPW_B2 + 64, lane, g, dy2, dG2, dE2);
-            // layer 2 (32 -> 64)
+            // ---- layer 2 (32 -> 64)
             put(0, dy2[0]); put(1, dy2[1]); put(2, dy2[2]); put(3, dy2[3]); put(4, a1[0]); put(5, a1[1]);
-            f32x4 da1[2];
-            t_layer<2, 4>(Tl + SPT_2, dy2, da1, lane);
-            WGRAD(4, 2, tW2, sb2);
-            f32x4 dy1[2];
+            WG_FETCH(4, 2, ops);
+            SPB_SB();
+            f32x4 da1[2], dy1[2];
+            t_pre<2, 4>(wb, dy2, da1);
+            WG_RUN(4, 2, ops, tW2, sb2);
             ln_bwd<2>(da1, xh1, a1, inv1, Wl + SPW_B1 + 32, lane, g, dy1, dG1, dE1);
-            // layer 1 (6 -> 32): inputs as one block [row][x6 (6) | zeros]
-            x6b = f32x4{0.f, 0.f, 0.f, 0.f};
+            // ---- layer 1 (6 -> 32): inputs as one block [row][x6 (6) | zeros]
+            f32x4 x6b = {0.f, 0.f, 0.f, 0.f};
             if (g < 2) x6b = *reinterpret_cast<const f32x4*>(x6l + row * 8 + 4 * g);
             put(0, dy1[0]); put(1, dy1[1]); put(2, x6b);
+            WG_FETCH(2, 1, ops);
             {
                 f32x4 (&t1)[2][1] = *reinterpret_cast<f32x4 (*)[2][1]>(&tW1);
-                WGRAD(2, 1, t1, sb1);
+                WG_RUN(2, 1, ops, t1, sb1);
             }
             wave_lds_fence();
         }
     }
-#undef WGRAD
+#undef WG_FETCH
+#undef WG_RUN
 
     // ---- epilogue: this wavefront's partial gradient ------------------------------------------------------------
     float* part = A.parts + (size_t)w * NAT_TOTAL;
@@ -499,19 +551,27 @@ __global__ __launch_bounds__(256) void spb_pack_kernel(const float* __restrict__
 __global__ __launch_bounds__(64) void spb_pool_chunk_kernel(const float* __restrict__ out_fwd, const float* __restrict__ grad_out, int N,
                                                             const float* __restrict__ P, float* __restrict__ chunk_sums, int* __restrict__ cnt)
 {
+    __shared__ float gsh[64][NG + 1];
     const int n = blockIdx.x * 64 + threadIdx.x;
-    if (n < N) {
+    const bool in = n < N;
+#pragma unroll
+    for (int c = 0; c < NG; ++c) gsh[threadIdx.x][c] = in ? grad_out[(size_t)n * OUTW + SP_NOUT + c] : 0.f;
+    if (in) {
+        float x[SP_NOUT];
+#pragma unroll
+        for (int q = 0; q < SP_NOUT; ++q) x[q] = out_fwd[(size_t)n * OUTW + q];
         for (int c = 0; c < NG; ++c) {
             float lin = P[NAT_BA + c];
-#pragma unroll 8
-            for (int q = 0; q < SP_NOUT; ++q) lin = fmaf(P[NAT_WA + c * SP_NOUT + q], out_fwd[(size_t)n * OUTW + q], lin);
+#pragma unroll
+            for (int q = 0; q < SP_NOUT; ++q) lin = fmaf(P[NAT_WA + c * SP_NOUT + q], x[q], lin);
             if (lin == out_fwd[(size_t)n * OUTW + SP_NOUT + c]) atomicAdd(&cnt[c], 1);
         }
     }
+    __syncthreads();
     if (threadIdx.x < NG) {
         const int c = threadIdx.x;
         float acc = 0.f;
-        for (int q = 0; q < 64 && blockIdx.x * 64 + q < N; ++q) acc = acc + grad_out[(size_t)(blockIdx.x * 64 + q) * OUTW + SP_NOUT + c];
+        for (int q = 0; q < 64 && blockIdx.x * 64 + q < N; ++q) acc = acc + gsh[q][c];
         chunk_sums[blockIdx.x * NG + c] = acc;
     }
 }
