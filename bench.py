@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary stage timings (counter-collection passes)")
     ap.add_argument("--no-graph", action="store_true", help="launch the chain eagerly instead of replaying a hipGraph")
     ap.add_argument("--n-points", type=int, default=4096, help="exploration only; the headline is 4096")
     ap.add_argument("--pairs-per-point", type=int, default=128, help="exploration only; the headline is 128")
@@ -173,7 +174,7 @@ def main():
     # passes through the object centre, so most samples land in the grid (the atomic-heavy regime a
     # trained network produces), unlike the near-uniform bins of a random-weight MLP above.
     t_vote_ka = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_secondary:
         out_ka = d(syn.closed_form_outputs(ob["pc"], ob["center"], idx, cfg, quantise=True))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for it in range(6):
@@ -188,7 +189,7 @@ def main():
     # secondary metric: the same object through the FULL pose (centre chain + back-vote +
     # orientation vote + axis sign + scale + one read-back), one hipGraph replay per object
     t_pose, pose = None, {"n_surv": None}
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_secondary:
         from cppf_amd.inference import PosePipeline
         from cppf_amd.utils.util import fibonacci_sphere
         pp = PosePipeline(enc, cfg, N_POINTS, P, dims, dev, np.array(fibonacci_sphere(480)), NUM_ROTS)
@@ -204,7 +205,7 @@ def main():
     # secondary: the step before the path -- kNN(60) + SPRIN point encoder producing `feat`
     # (nocs/inference.py:180-181), random-init weights of the reference's configuration (train.py:34)
     t_penc = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_secondary:
         from cppf_amd.models.model import PointEncoder
         torch.manual_seed(1)
         penc = PointEncoder(k=60, spfcs=[32, 64, 32, 32], num_layers=1, out_dim=32).eval().to(dev)
@@ -221,7 +222,7 @@ def main():
     # secondary: one training-size forward + backward of the pair encoder (train.py:66,91:
     # 200 000 pairs, dL/dlogits given), HIP forward + HIP backward through the autograd.Function
     t_train = t_step = t_full = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_secondary:
         Pt = 200000
         idx_t = d(syn.make_pairs(N_POINTS, (Pt + N_POINTS - 1) // N_POINTS, 7)[:Pt])
         Rt = torch.randn((Pt, cfg.out_dim), device=dev)

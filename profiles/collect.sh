@@ -17,7 +17,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_s
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" \
            "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAVE_CYCLES"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc$i -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /tmp/pmc$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc$i -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > /tmp/pmc$i.log 2>&1
   f=$(find /tmp/pmc$i -name '*counter_collection.csv' | head -1)
   python $R/profiles/pmcstats.py $f >> $OUT/pmc_counters.txt
 done
