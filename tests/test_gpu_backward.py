@@ -132,3 +132,22 @@ def test_other_shapes_use_the_composite(dev, golden):
         ref = z["grad." + name]
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=0, atol=5e-5 * np.abs(ref).max())
     np.testing.assert_allclose(gf, z["grad_feat"], rtol=0, atol=5e-5 * np.abs(z["grad_feat"]).max())
+
+
+@pytest.mark.parametrize("n,p", [(5, 1), (7, 63), (64, 64), (33, 65), (40, 129), (2, 700)])
+def test_backward_edge_sizes_bit_exact(dev, oracle, n, p):
+    """a single pair, one pair short of / exactly / one pair past a tile, two tiles and a bit, two points sharing 700 pairs"""
+    rng = np.random.default_rng(100 * n + p)
+    pc = rng.normal(0, 0.1, (n, 3)).astype(np.float32)
+    nrm = rng.normal(0, 1, (n, 3)); nrm = (nrm / np.linalg.norm(nrm, axis=-1, keepdims=True)).astype(np.float32)
+    feat = rng.normal(0, 1, (n, 40)).astype(np.float32)
+    idxs = rng.integers(0, n, (p, 2)).astype(np.int64)
+    R = rng.normal(0, 1, (p, 141)).astype(np.float32)
+    torch.manual_seed(p)
+    enc = PPFEncoder(PPFFCS, 141)
+    sd = {k: v.detach().numpy().copy() for k, v in enc.state_dict().items()}
+    enc = enc.to(dev).train()
+    _, gf = _run(enc, dev, pc, nrm, feat, torch.from_numpy(idxs).to(dev), R)
+    _, gf_o, flat_o = oracle.pair_mlp_backward(pc, nrm, feat, idxs, sd, PPFFCS, 141, R)
+    assert np.array_equal(_flat_grads(enc), flat_o)
+    assert np.array_equal(gf, gf_o)

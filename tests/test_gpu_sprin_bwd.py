@@ -156,3 +156,23 @@ def test_training_step_runs_on_the_device_kernels(dev):
         opt.step()
         losses.append(loss.item())
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("n,k", [(1, 1), (3, 2), (17, 16), (65, 33)])
+def test_backward_edge_sizes_bit_exact(dev, oracle, n, k):
+    """one point that is its own neighbour, fewer points than a workgroup's wavefronts, exactly one full row block, three row blocks"""
+    rng = np.random.default_rng(10 * n + k)
+    pc, nrm = _cloud(rng, n)
+    R = rng.normal(0, 1, (n, 40)).astype(np.float32)
+    torch.manual_seed(n)
+    enc = PointEncoder(k=k, **CFG)
+    _perturb(enc, n)
+    sd = {kk: v.detach().numpy().copy() for kk, v in enc.state_dict().items()}
+    enc = enc.to(dev).train()
+    nbrs = enc.neighbours(torch.from_numpy(pc).to(dev)).cpu().numpy()
+    _, grads = _grads_hip(enc, dev, pc, nrm, nbrs, R)
+    packed, _ = pack_point_encoder(sd, 1)
+    g_o, _ = oracle.point_encoder_backward(pc, nrm, nbrs, packed, R)
+    for name, g in grads.items():
+        assert np.all(np.isfinite(g)), name
+        assert np.array_equal(g, g_o[name]), name
