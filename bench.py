@@ -173,6 +173,21 @@ def main():
     # secondary (untimed for `value`): the vote stage alone on known-answer inputs -- every vote circle
     # passes through the object centre, so most samples land in the grid (the atomic-heavy regime a
     # trained network produces), unlike the near-uniform bins of a random-weight MLP above.
+    # secondary: the pair encoder decoding only the two centre heads (all the centre vote consumes; the reference
+    # computes the other 77 logits in this pass too and throws them away, nocs/inference.py:182-188).  Not the headline:
+    # `value` is measured with all heads decoded.
+    t_mlp_tr = None
+    if rank == 0 and world == 1 and not args.no_secondary:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.no_grad():
+            enc.forward_decode(pc, nrm, feat, idx_d, utr_d, cfg.vote_range, None, cfg.tr_num_bins, cfg.rot_num_bins)
+            e0.record()
+            for _ in range(n_ev):
+                enc.forward_decode(pc, nrm, feat, idx_d, utr_d, cfg.vote_range, None, cfg.tr_num_bins, cfg.rot_num_bins)
+            e1.record()
+        torch.cuda.synchronize()
+        t_mlp_tr = e0.elapsed_time(e1) / n_ev
+
     t_vote_ka = None
     if rank == 0 and world == 1 and not args.no_secondary:
         out_ka = d(syn.closed_form_outputs(ob["pc"], ob["center"], idx, cfg, quantise=True))
@@ -294,7 +309,7 @@ def main():
                                    ("four launches replayed from a hipGraph" if not args.no_graph else "eager launches"),
                        "pairs_per_step_per_gpu": P, "parallelism": f"objects x{world}"},
             "pairs_per_ms_per_gpu": args.steps * P / elapsed / 1e3,
-            "stage_ms": {"ppf_mlp_decode": t_mlp, "vote_reduce_argmax": t_vote,
+            "stage_ms": {"ppf_mlp_decode": t_mlp, "ppf_mlp_decode_centre_heads_only": t_mlp_tr, "vote_reduce_argmax": t_vote,
                          "vote_reduce_argmax_known_answer_inputs": t_vote_ka,
                          "full_pose_incl_readback": t_pose, "full_pose_n_surv": pose["n_surv"],
                          "point_encoder_knn60_sprin": t_penc,
