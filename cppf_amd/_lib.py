@@ -54,7 +54,9 @@ _SIGS = {
     "cppf_point_encoder_backward_workspace_bytes": (sz, [i32]),
     "cppf_point_encoder_pack_device": (C.c_int, [vp, C.POINTER(C.c_int), i32, i32, i32, i32, i32, i32, vp, vp]),
     "cppf_point_encoder_backward": (C.c_int, [vp, vp, vp, i32, i32, vp, C.POINTER(C.c_int), i32, i32, i32, i32, i32, i32, vp, vp,
-                                              vp, vp, sz, vp]),
+                                              vp, vp, vp, sz, vp]),
+    "cppf_point_encoder_forward_train": (C.c_int, [vp, vp, vp, i32, i32, vp, C.POINTER(C.c_int), i32, i32, i32, i32, i32, i32,
+                                                   vp, vp, vp, sz, vp]),
     "cppf_point_encoder_forward": (C.c_int, [vp, vp, vp, i32, i32, vp, C.POINTER(C.c_int), i32, i32, i32, i32, i32, i32,
                                              vp, vp, sz, vp]),
 }

@@ -201,6 +201,7 @@ struct ConvArgs {
     const float* wimg;      // this layer's MFMA image (SPW_FLOATS), cppf_point_encoder_pack
     float* out;             // [N][out_stride], columns 0..31 written
     int N, k, n_in, out_stride;
+    float* mixed_out;       // optional [N][32 * n_in]: the contraction, kept for the backward (training)
 };
 
 // hidden = {32, 64, 32, 32}, rank 32, n_out 32 (train.py:34).  Dynamic LDS: the workgroup's weight image
@@ -300,6 +301,8 @@ __global__ __launch_bounds__(SP_WAVES_MAX * 64) void sprin_conv_kernel(ConvArgs 
     }
     const float* p = A.params + SP_NAT_KERNEL;   // outnet parameters follow the kernel-MLP in the natural layout
     const int C = SP_RANK * n_in;
+    if (A.mixed_out && live)
+        for (int t = lane; t < C; t += 64) A.mixed_out[(size_t)n * C + t] = contracted[t];
     __syncthreads();
     // outnet (transposed weights: lane o reads Wo_t[c][o], coalesced) + LayerNorm (models/sprin.py:100,105)
     const float* Wo = p;
@@ -432,10 +435,32 @@ size_t cppf_point_encoder_workspace_bytes(int n_points, int n_out, int n_glob, i
     return b;
 }
 
+static int sp_forward(const float* pc, const float* nrm, const int32_t* nbrs, int n_points, int k, const float* packed,
+                      const int32_t* hidden, int n_hidden, int rank, int n_nbr_feats, int n_out, int n_glob, int num_layers,
+                      float* out, float* mixed_out, void* workspace, size_t workspace_bytes, void* stream);
+
 int cppf_point_encoder_forward(const float* pc, const float* nrm, const int32_t* nbrs, int n_points, int k,
                                const float* packed, const int32_t* hidden, int n_hidden, int rank, int n_nbr_feats,
                                int n_out, int n_glob, int num_layers, float* out, void* workspace,
                                size_t workspace_bytes, void* stream)
+{
+    return sp_forward(pc, nrm, nbrs, n_points, k, packed, hidden, n_hidden, rank, n_nbr_feats, n_out, n_glob, num_layers, out,
+                      nullptr, workspace, workspace_bytes, stream);
+}
+
+int cppf_point_encoder_forward_train(const float* pc, const float* nrm, const int32_t* nbrs, int n_points, int k,
+                                     const float* packed, const int32_t* hidden, int n_hidden, int rank, int n_nbr_feats,
+                                     int n_out, int n_glob, int num_layers, float* out, float* contraction_out, void* workspace,
+                                     size_t workspace_bytes, void* stream)
+{
+    if (num_layers != 1 || !contraction_out) return num_layers != 1 ? CPPF_EUNSUPPORTED : CPPF_EINVAL;
+    return sp_forward(pc, nrm, nbrs, n_points, k, packed, hidden, n_hidden, rank, n_nbr_feats, n_out, n_glob, num_layers, out,
+                      contraction_out, workspace, workspace_bytes, stream);
+}
+
+static int sp_forward(const float* pc, const float* nrm, const int32_t* nbrs, int n_points, int k, const float* packed,
+                      const int32_t* hidden, int n_hidden, int rank, int n_nbr_feats, int n_out, int n_glob, int num_layers,
+                      float* out, float* mixed_out, void* workspace, size_t workspace_bytes, void* stream)
 {
     if (n_points < 0 || k <= 0 || num_layers <= 0 || !hidden) return CPPF_EINVAL;
     if (n_points == 0) return 0;
@@ -454,7 +479,7 @@ int cppf_point_encoder_forward(const float* pc, const float* nrm, const int32_t*
         const int n_in = l == 0 ? n_nbr_feats : W;
         float* dst = ((num_layers - 1 - l) & 1) ? ping : out;
         const float* src = l == 0 ? nullptr : (dst == out ? ping : out);
-        ConvArgs A{pc, nrm, src, nbrs, p, images + (size_t)l * SPW_FLOATS, dst, n_points, k, n_in, W};
+        ConvArgs A{pc, nrm, src, nbrs, p, images + (size_t)l * SPW_FLOATS, dst, n_points, k, n_in, W, l == 0 ? mixed_out : nullptr};
         const int waves = sp_waves(n_in);
         const size_t lds = ((size_t)SPW_FLOATS + (size_t)waves * sp_per_wave(n_in)) * sizeof(float);
         hipError_t e = hipFuncSetAttribute((const void*)sprin_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

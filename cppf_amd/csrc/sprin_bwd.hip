@@ -52,6 +52,7 @@ struct SpbArgs {
     const float* grad_out;  // [N][40]
     const float* share;     // [8] d(pooled)[c] / number of points attaining the maximum
     const float* pooled;    // [8] the maxima (columns 32..39 of any row of the forward output)
+    const float* mixed;     // optional [N][64]: the contraction the forward kept (cppf_point_encoder_forward_train); null = recompute
     float* parts;           // [n_parts][NAT_TOTAL]
     int N, k, n_parts;
 };
@@ -265,8 +266,9 @@ __global__ __launch_bounds__(SPB_WAVES * 64, 1) void sprin_bwd_kernel(SpbArgs A)
         wave_lds_fence();
         // ---- pass 1: kernel values of the four row blocks, contraction (lane t = r * 2 + i) ------------------------
         float contr = 0.f;
+        if (A.mixed) contr = A.mixed[(size_t)n * CMIX + lane];
 #pragma unroll 1
-        for (int rb = 0; rb < 4; ++rb) {
+        for (int rb = 0; rb < (A.mixed ? 0 : 4); ++rb) {
             f32x4 a1[2], a2[4], a3[2], a4[2], kr[2];
             float w1[4], wa[32], wb[32], wc[16];
             ldw<4>(Wl + SPW_L1, lane, w1);
@@ -631,8 +633,8 @@ int cppf_point_encoder_pack_device(const float* natural, const int32_t* hidden, 
 
 int cppf_point_encoder_backward(const float* pc, const float* nrm, const int32_t* nbrs, int n_points, int k, const float* packed,
                                 const int32_t* hidden, int n_hidden, int rank, int n_nbr_feats, int n_out, int n_glob,
-                                int num_layers, const float* out_fwd, const float* grad_out, float* grad_packed, void* workspace,
-                                size_t workspace_bytes, void* stream)
+                                int num_layers, const float* out_fwd, const float* contraction, const float* grad_out,
+                                float* grad_packed, void* workspace, size_t workspace_bytes, void* stream)
 {
     if (n_points < 0 || k <= 0) return CPPF_EINVAL;
     if (!spb_std(hidden, n_hidden, rank, n_nbr_feats, n_out, n_glob, num_layers) || k > 64 || (n_points > 0 && k > n_points))
@@ -656,7 +658,7 @@ int cppf_point_encoder_backward(const float* pc, const float* nrm, const int32_t
     spb_pack_kernel<<<(SPW_FLOATS + 255) / 256, 256, 0, st>>>(packed, nullptr, timg);
     spb_pool_chunk_kernel<<<L.n_chunks, 64, 0, st>>>(out_fwd, grad_out, n_points, packed, chunk_sums, cnt);
     spb_pool_final_kernel<<<1, 64, 0, st>>>(chunk_sums, L.n_chunks, cnt, out_fwd, share, pooled);
-    SpbArgs A{pc, nrm, nbrs, packed, packed + NAT_TOTAL, timg, grad_out, share, pooled, parts, n_points, k, n_parts};
+    SpbArgs A{pc, nrm, nbrs, packed, packed + NAT_TOTAL, timg, grad_out, share, pooled, contraction, parts, n_points, k, n_parts};
     static bool attr_done = false;
     if (!attr_done) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sprin_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

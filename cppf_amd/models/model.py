@@ -100,15 +100,16 @@ class _PointEncoderFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, enc, pc, nrm, nbrs, *params):
         with torch.no_grad():
-            out = enc._forward_device(pc, nrm, nbrs)
+            mixed = torch.empty((pc.shape[0], 64), dtype=torch.float32, device=pc.device)
+            out = enc._forward_device(pc, nrm, nbrs, keep_contraction=mixed)
         ctx.enc = enc
-        ctx.save_for_backward(pc, nrm, nbrs, out)
+        ctx.save_for_backward(pc, nrm, nbrs, out, mixed)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         enc = ctx.enc
-        pc, nrm, nbrs, out = ctx.saved_tensors
+        pc, nrm, nbrs, out, mixed = ctx.saved_tensors
         dev = pc.device
         packed, desc = enc._packed_weights(dev)
         hid = (C.c_int * len(desc["hidden"]))(*desc["hidden"])
@@ -121,8 +122,8 @@ class _PointEncoderFunction(torch.autograd.Function):
         with torch.cuda.device(dev):
             rc = L.cppf_point_encoder_backward(pc.data_ptr(), nrm.data_ptr(), nbrs.data_ptr(), N, k, packed.data_ptr(), hid,
                                                len(desc["hidden"]), desc["rank"], desc["n_nbr_feats"], desc["n_out"],
-                                               desc["n_glob"], enc.num_layers, out.data_ptr(), g.data_ptr(), gp.data_ptr(),
-                                               ws.data_ptr(), ws.numel(), stream_ptr(dev))
+                                               desc["n_glob"], enc.num_layers, out.data_ptr(), mixed.data_ptr(), g.data_ptr(),
+                                               gp.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr(dev))
         _lib.check(rc, "cppf_point_encoder_backward")
         grads, pos = [], 0
         for p, transposed in zip(enc._ordered_params(), enc._ordered_transposed()):
@@ -195,7 +196,7 @@ class PointEncoder(nn.Module):
         _lib.check(rc, "cppf_knn")
         return nbrs
 
-    def _forward_device(self, pc, nrm, nbrs):
+    def _forward_device(self, pc, nrm, nbrs, keep_contraction=None):
         N, k = nbrs.shape
         packed, desc = self._packed_weights(pc.device)
         hid = (C.c_int * len(desc["hidden"]))(*desc["hidden"])
@@ -205,10 +206,17 @@ class PointEncoder(nn.Module):
         ws = workspace(L.cppf_point_encoder_workspace_bytes(N, desc["n_out"], desc["n_glob"], self.num_layers), pc.device,
                        "point_encoder")
         with torch.cuda.device(pc.device):
-            rc = L.cppf_point_encoder_forward(pc.data_ptr(), nrm.data_ptr(), nbrs.data_ptr(), N, k, packed.data_ptr(), hid,
-                                              len(desc["hidden"]), desc["rank"], desc["n_nbr_feats"], desc["n_out"],
-                                              desc["n_glob"], self.num_layers, out.data_ptr(), ws.data_ptr(), ws.numel(),
-                                              stream_ptr(pc.device))
+            if keep_contraction is not None:   # training: the backward reuses the per-point contraction
+                rc = L.cppf_point_encoder_forward_train(pc.data_ptr(), nrm.data_ptr(), nbrs.data_ptr(), N, k, packed.data_ptr(),
+                                                        hid, len(desc["hidden"]), desc["rank"], desc["n_nbr_feats"],
+                                                        desc["n_out"], desc["n_glob"], self.num_layers, out.data_ptr(),
+                                                        keep_contraction.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                        stream_ptr(pc.device))
+            else:
+                rc = L.cppf_point_encoder_forward(pc.data_ptr(), nrm.data_ptr(), nbrs.data_ptr(), N, k, packed.data_ptr(), hid,
+                                                  len(desc["hidden"]), desc["rank"], desc["n_nbr_feats"], desc["n_out"],
+                                                  desc["n_glob"], self.num_layers, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                  stream_ptr(pc.device))
         if rc == -3:
             raise _lib.CppfError(f"no device kernel for PointEncoder(k={self.k}, spfcs={self.spfcs}, out_dim={self.out_dim}): "
                                  "csrc/sprin.hip covers spfcs=[32,64,32,32], out_dim=32, k<=64 (train.py:34)")

@@ -280,6 +280,8 @@ int cppf_pair_mlp_backward(const float* pc, const float* nrm, const float* feat,
  * autograd; points and normals carry no gradient there (train.py:58-60).
  *   packed       device f32: natural parameters + forward image, as cppf_point_encoder_forward takes them
  *   out_fwd      device f32[n_points, 40]: the forward output for the same inputs (the pooled maxima are read from it)
+ *   contraction  device f32[n_points, 64] kept by cppf_point_encoder_forward_train, or NULL: the backward then recomputes
+ *                it (one more forward pass of the kernel-MLP per point); the result is the same bit for bit
  *   grad_out     device f32[n_points, 40]
  *   grad_packed  device f32[9 256]: d/d(natural parameters) in the natural layout (outnet weight transposed), OVERWRITTEN
  * cppf_point_encoder_pack_device builds `packed` from natural parameters that already live on the device (training).
@@ -292,8 +294,13 @@ int cppf_point_encoder_pack_device(const float* natural, const int32_t* hidden, 
                                    int n_glob, int num_layers, float* packed, void* stream);
 int cppf_point_encoder_backward(const float* pc, const float* nrm, const int32_t* nbrs, int n_points, int k, const float* packed,
                                 const int32_t* hidden, int n_hidden, int rank, int n_nbr_feats, int n_out, int n_glob,
-                                int num_layers, const float* out_fwd, const float* grad_out, float* grad_packed, void* workspace,
-                                size_t workspace_bytes, void* stream);
+                                int num_layers, const float* out_fwd, const float* contraction, const float* grad_out,
+                                float* grad_packed, void* workspace, size_t workspace_bytes, void* stream);
+/* cppf_point_encoder_forward that also keeps the per-point contraction (einsum of models/sprin.py:99) for the backward */
+int cppf_point_encoder_forward_train(const float* pc, const float* nrm, const int32_t* nbrs, int n_points, int k,
+                                     const float* packed, const int32_t* hidden, int n_hidden, int rank, int n_nbr_feats,
+                                     int n_out, int n_glob, int num_layers, float* out, float* contraction_out, void* workspace,
+                                     size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Pre-processing in front of the path.  Both replace third-party host calls whose

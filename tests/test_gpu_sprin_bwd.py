@@ -176,3 +176,37 @@ def test_backward_edge_sizes_bit_exact(dev, oracle, n, k):
     for name, g in grads.items():
         assert np.all(np.isfinite(g)), name
         assert np.array_equal(g, g_o[name]), name
+
+
+def test_backward_with_and_without_the_kept_contraction(dev):
+    """cppf_point_encoder_backward recomputes the contraction when the forward did not keep it: same gradients, bit for bit"""
+    import ctypes as C
+    from cppf_amd import _lib
+    from cppf_amd._torch_util import stream_ptr, workspace
+    rng = np.random.default_rng(21)
+    n, k = 333, 47
+    pc, nrm = _cloud(rng, n)
+    torch.manual_seed(21)
+    enc = PointEncoder(k=k, **CFG)
+    _perturb(enc, 21)
+    enc = enc.to(dev)
+    pcd, nrmd = torch.from_numpy(pc).to(dev), torch.from_numpy(nrm).to(dev)
+    nbrs = enc.neighbours(pcd)
+    mixed = torch.empty((n, 64), dtype=torch.float32, device=dev)
+    with torch.no_grad():
+        out = enc._forward_device(pcd, nrmd, nbrs, keep_contraction=mixed)
+        assert torch.equal(out, enc._forward_device(pcd, nrmd, nbrs))
+    packed, desc = enc._packed_weights(dev)
+    L = _lib.lib()
+    hid = (C.c_int * 4)(32, 64, 32, 32)
+    g = torch.from_numpy(rng.normal(0, 1, (n, 40)).astype(np.float32)).to(dev)
+    ws = workspace(int(L.cppf_point_encoder_backward_workspace_bytes(n)), dev, "t")
+    res = []
+    for mx in (mixed.data_ptr(), None):
+        gp = torch.zeros(9256, dtype=torch.float32, device=dev)
+        rc = L.cppf_point_encoder_backward(pcd.data_ptr(), nrmd.data_ptr(), nbrs.data_ptr(), n, k, packed.data_ptr(), hid, 4, 32, 2,
+                                           32, 8, 1, out.data_ptr(), mx, g.data_ptr(), gp.data_ptr(), ws.data_ptr(), ws.numel(),
+                                           stream_ptr(dev))
+        assert rc == 0
+        res.append(gp.cpu().numpy())
+    assert np.array_equal(res[0], res[1]) and np.abs(res[0]).max() > 0
