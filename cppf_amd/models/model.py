@@ -51,6 +51,17 @@ class ResLayer(nn.Module):
         return self.fc2(F.relu(self.fc1(x))) + x_res
 
 
+def _params_of(module):
+    """The module's parameters as a cached list.  nn.Module.parameters() walks the module tree on every call (~100 us for
+    these encoders, several times per training step); the Parameter objects themselves are stable: .to() / .cuda() /
+    load_state_dict() swap or fill their data in place, and the encoders' structure is fixed by their constructors."""
+    plist = module.__dict__.get("_cppf_plist")
+    if plist is None:
+        plist = list(module.parameters())
+        module.__dict__["_cppf_plist"] = plist
+    return plist
+
+
 class _PairMlpFunction(torch.autograd.Function):
     """forward_with_idx with a HIP backward (train.py:66,91).  Saves only the inputs; the backward kernel
     recomputes the forward.  Gradients: feat, then the parameters in `flatten_state_dict` order."""
@@ -227,7 +238,7 @@ class PointEncoder(nn.Module):
     def _needs_graph(self, pc):
         if not torch.is_grad_enabled():
             return False
-        return pc.requires_grad or any(p.requires_grad for p in self.parameters())
+        return pc.requires_grad or any(p.requires_grad for p in _params_of(self))
 
     def _has_device_backward(self, pc, pc_normal):
         """csrc/sprin_bwd.hip covers the one-layer standard encoder (train.py:34) when only the parameters need gradients"""
@@ -236,20 +247,28 @@ class PointEncoder(nn.Module):
                 and self.spconvs[0].layer_norm is not None)
 
     def _ordered_params(self):
-        """parameters in the packed natural order of `pack_point_encoder` (one layer)"""
+        """parameters in the packed natural order of `pack_point_encoder` (one layer); cached like `_params_of`"""
+        cached = self.__dict__.get("_cppf_ordered")
+        if cached is not None:
+            return cached
         ker = self.spconvs[0].kernel
         ps = []
         for i in range(0, len(ker) - 1, 3):
             ps += [ker[i].weight, ker[i].bias, ker[i + 1].weight, ker[i + 1].bias]
         ps += [ker[len(ker) - 1].weight, ker[len(ker) - 1].bias]
         sc = self.spconvs[0]
-        return ps + [sc.outnet.weight, sc.outnet.bias, sc.layer_norm.weight, sc.layer_norm.bias,
-                     self.aggrs[0].linear.weight, self.aggrs[0].linear.bias]
+        ps += [sc.outnet.weight, sc.outnet.bias, sc.layer_norm.weight, sc.layer_norm.bias,
+               self.aggrs[0].linear.weight, self.aggrs[0].linear.bias]
+        self.__dict__["_cppf_ordered"] = ps
+        return ps
 
     def _ordered_transposed(self):
         """which of `_ordered_params` are stored transposed in the packed layout (outnet.weight: [C][n_out])"""
-        ps = self._ordered_params()
-        return [p is self.spconvs[0].outnet.weight for p in ps]
+        cached = self.__dict__.get("_cppf_transposed")
+        if cached is None:
+            cached = [p is self.spconvs[0].outnet.weight for p in self._ordered_params()]
+            self.__dict__["_cppf_transposed"] = cached
+        return cached
 
     def _composite(self, pc, pc_normal, nbrs_idx):
         """models/model.py:63-78 as torch ops (autograd path)."""
@@ -273,7 +292,7 @@ class PointEncoder(nn.Module):
         return (pc.detach().reshape(-1, 3).float().contiguous(), pc_normal.detach().reshape(-1, 3).float().contiguous())
 
     def _packed_weights(self, device):
-        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in _params_of(self))
         dev = torch.device(device)
         if (self._packed is None or self._packed_key != key) and dev.type == "cuda" and self.num_layers == 1 \
                 and self.spfcs == [32, 64, 32, 32] and self.out_dim == 32 and self.num_nbr_feats == 2 \
@@ -407,7 +426,7 @@ class PPFEncoder(nn.Module):
     def _needs_graph(self, feat):
         if not torch.is_grad_enabled():
             return False
-        return feat.requires_grad or any(p.requires_grad for p in self.parameters())
+        return feat.requires_grad or any(p.requires_grad for p in _params_of(self))
 
     def _has_device_backward(self, pc, feat):
         """csrc/pair_mlp_bwd.hip covers ppffcs = [84,32,32,16] (train.py:35) on a HIP device."""
@@ -421,13 +440,19 @@ class PPFEncoder(nn.Module):
         return pres + [True, True]
 
     def _ordered_params(self):
-        """parameters in `flatten_state_dict` order: per layer fc1.w, fc1.b, fc2.w, fc2.b, [fc0.w, fc0.b]; final"""
+        """parameters in `flatten_state_dict` order: per layer fc1.w, fc1.b, fc2.w, fc2.b, [fc0.w, fc0.b]; final
+        (cached like `_params_of`)"""
+        cached = self.__dict__.get("_cppf_ordered")
+        if cached is not None:
+            return cached
         ps = []
         for layer in self.res_layers:
             ps += [layer.fc1.weight, layer.fc1.bias, layer.fc2.weight, layer.fc2.bias]
             if layer.fc0 is not None:
                 ps += [layer.fc0.weight, layer.fc0.bias]
-        return ps + [self.final.weight, self.final.bias]
+        ps += [self.final.weight, self.final.bias]
+        self.__dict__["_cppf_ordered"] = ps
+        return ps
 
     def _composite(self, pc, pc_normal, feat, idxs):
         """models/model.py:118-137 as torch ops (autograd path for shapes without a device backward)."""
@@ -469,7 +494,7 @@ class PPFEncoder(nn.Module):
                 feat.detach().float().contiguous())
 
     def _param_key(self, device):
-        return (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (str(device),) + tuple((p.data_ptr(), p._version) for p in _params_of(self))
 
     def _flat_params(self, device):
         """(flat device f32 copy of the parameters in `flatten_state_dict` order, host i64 offset table), rebuilt when a
