@@ -509,15 +509,17 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
         //      logit registers; the 12 weight reads per block are cheap) ----------------------------
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
+            // a decode without the rotation heads consumes only the two centre heads = output blocks 0..3 in dec_col order
+            constexpr int NOB_USED = (DECODE && !HEADS) ? 4 : STD_NOB;
             f32x4 L[STD_NOB];
 #pragma unroll
-            for (int ob = 0; ob < STD_NOB; ++ob) L[ob] = ldb4(W + OFF_BF + 16 * ob + 4 * g);
+            for (int ob = 0; ob < NOB_USED; ++ob) L[ob] = ldb4(W + OFF_BF + 16 * ob + 4 * g);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const float* wp = W + OFF_WF + (s * 64 + lane) * STD_NOBP;
                 const f32x4 w0 = ldb4(wp), w1 = ldb4(wp + 4), w2 = ldb4(wp + 8);
 #pragma unroll
-                for (int ob = 0; ob < STD_NOB; ++ob) {
+                for (int ob = 0; ob < NOB_USED; ++ob) {
                     const float w = ob < 4 ? w0[ob & 3] : (ob < 8 ? w1[ob & 3] : w2[ob & 3]);
                     L[ob] = mfma4(w, z[pb][s], L[ob]);
                 }
