@@ -151,3 +151,10 @@ def test_backward_edge_sizes_bit_exact(dev, oracle, n, p):
     _, gf_o, flat_o = oracle.pair_mlp_backward(pc, nrm, feat, idxs, sd, PPFFCS, 141, R)
     assert np.array_equal(_flat_grads(enc), flat_o)
     assert np.array_equal(gf, gf_o)
+
+
+def test_randomised_backward_soak(dev):
+    """a few seconds of tests/soak_gpu_bwd.py: random sizes, head widths (both kernel instantiations), index widths"""
+    import soak_gpu_bwd
+    n_pair, n_point = soak_gpu_bwd.run(6.0, 123, dev)
+    assert n_pair >= 2 and n_point >= 2
