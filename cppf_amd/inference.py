@@ -128,8 +128,11 @@ class CenterPipeline:
         self.corner = z(3)
         self.probs = torch.ones(n_points, dtype=F32, device=device)           # nocs/inference.py:201
         self.grid = torch.empty(tuple(dims), dtype=F32, device=device)
-        self.out_idx = torch.zeros(1, dtype=torch.int64, device=device)
-        self.out_val = torch.zeros(1, dtype=F32, device=device)
+        # arg-max index and value side by side in one 16-byte record, so a caller that logs every step moves them with
+        # one small copy: `result` u8[16] = {i64 flat index, f32 peak, 4 bytes unused}
+        self.result = torch.zeros(16, dtype=torch.uint8, device=device)
+        self.out_idx = self.result[:8].view(torch.int64)
+        self.out_val = self.result[8:12].view(F32)
         self.outputs = self.heads = None
         self._graph = None
         self._use_graph = use_graph
