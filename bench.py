@@ -214,6 +214,28 @@ def main():
             pose = pp.run()
         t_pose = (time.perf_counter() - tp0) / 10 * 1e3
 
+    # secondary (BASELINE config 4, one GPU's share): 8 instances through BatchPoseRunner -- cloud in from the host, pairs and
+    # bin uniforms drawn on the device, kNN + SPRIN + full pose per instance, one read-back for the batch
+    t_batch = None
+    if rank == 0 and world == 1 and not args.no_secondary:
+        from cppf_amd.batch import BatchPoseRunner
+        from cppf_amd.models.model import PointEncoder
+        torch.manual_seed(3)
+        penc_b = PointEncoder(k=60, spfcs=[32, 64, 32, 32], num_layers=1, out_dim=32).eval().to(dev)
+        runner = BatchPoseRunner({cfg.category: enc}, dev, point_encoders={cfg.category: penc_b})
+        batch = []
+        for j in range(8):
+            obj_j = syn.make_object("bottle", N_POINTS, seed=100 + j)
+            batch.append(dict(pc=obj_j["pc"], normals=obj_j["normals"], cfg=obj_j["cfg"], n_pairs=P))
+        for _ in range(2):
+            runner.run(batch)
+        torch.cuda.synchronize()
+        tb0 = time.perf_counter()
+        for _ in range(3):
+            runner.run(batch)
+        torch.cuda.synchronize()
+        t_batch = (time.perf_counter() - tb0) / 3 / 8 * 1e3
+
     # secondary: the step before the path -- kNN(60) + SPRIN point encoder producing `feat`
     # (nocs/inference.py:180-181), random-init weights of the reference's configuration (train.py:34)
     t_penc = None
@@ -309,6 +331,7 @@ def main():
             "stage_ms": {"ppf_mlp_decode": t_mlp, "ppf_mlp_decode_centre_heads_only": t_mlp_tr, "vote_reduce_argmax": t_vote,
                          "vote_reduce_argmax_known_answer_inputs": t_vote_ka,
                          "full_pose_incl_readback": t_pose, "full_pose_n_surv": pose["n_surv"],
+                         "batch_of_8_instances_knn_sprin_full_pose_per_instance": t_batch,
                          "point_encoder_knn60_sprin": t_penc,
                          "pair_encoder_fwd_bwd_200k_pairs": t_train,
                          "pair_encoder_fwd_bwd_adam_step_200k_pairs": t_step,

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import sharding
-from .inference import PosePipeline, grid_shape
+from .inference import PosePipeline, assemble_record, grid_shape
 from .utils.util import fibonacci_sphere, num_sphere_bins
 
 
@@ -25,6 +25,8 @@ class BatchPoseRunner:
                        use_graph=use_graph)
         self.sphere = np.array(fibonacci_sphere(num_sphere_bins(angle_tol)))      # :100-102
         self._pipes = {}
+        self._staging = {}         # pinned host staging sets for the small per-instance arrays, see _stage()
+        self._stage_pos = 0
 
     def _pipe(self, cfg, n_points, n_pairs, dims):
         key = (cfg.category, n_points, n_pairs, tuple(dims))
@@ -32,6 +34,34 @@ class BatchPoseRunner:
             self._pipes[key] = PosePipeline(self.encoders[cfg.category], cfg, n_points, n_pairs, dims, self.device,
                                             self.sphere, point_encoder=self.point_encoders.get(cfg.category), **self.kw)
         return self._pipes[key]
+
+    _RING = 4
+
+    def _stage(self, pipe, pc, normals, feat, corner):
+        """cloud, normals, (features,) grid corner -> the pipeline's device buffers through PINNED host memory, so the copies
+        are truly asynchronous (a copy from pageable memory blocks the host until everything queued before it has run, i.e.
+        until the previous instance has finished).  A ring of staging sets, each guarded by an event."""
+        n = pc.shape[0]
+        key = (n, None if feat is None else feat.shape[1])
+        ring = self._staging.get(key)
+        if ring is None:
+            mk = lambda *shape: torch.empty(shape, dtype=torch.float32).pin_memory()
+            ring = [dict(pc=mk(n, 3), nrm=mk(n, 3), corner=mk(3), feat=None if feat is None else mk(n, feat.shape[1]),
+                         ev=torch.cuda.Event()) for _ in range(self._RING)]
+            self._staging[key] = ring
+        st = ring[self._stage_pos % self._RING]
+        self._stage_pos += 1
+        st["ev"].synchronize()                          # the copies that last read this set have executed
+        st["pc"].numpy()[...] = pc
+        st["nrm"].numpy()[...] = normals
+        st["corner"].numpy()[...] = corner
+        pipe.pc.copy_(st["pc"], non_blocking=True)
+        pipe.nrm.copy_(st["nrm"], non_blocking=True)
+        pipe.corner.copy_(st["corner"], non_blocking=True)
+        if feat is not None:
+            st["feat"].numpy()[...] = feat
+            pipe.feat.copy_(st["feat"], non_blocking=True)
+        st["ev"].record(torch.cuda.current_stream(self.device))
 
     def run_object(self, obj):
         """obj: dict(pc, normals, feat, point_idxs, u_tr, u_rot, cfg) of host arrays -> pose dict."""
@@ -41,11 +71,34 @@ class BatchPoseRunner:
                   corners[0].copy())
         return pipe.run()
 
-    def run(self, objects, rank=0, world=1):
+    def run(self, objects, rank=0, world=1, seed=0):
         """objects: the WHOLE batch (list, same on every rank).  Returns f64[n_objects, RECORD] in object
-        order on every rank (sharding.pack_record layout)."""
+        order on every rank (sharding.pack_record layout).
+
+        The rank's instances are enqueued back to back -- inputs, graph replay, a 21-double device copy of the result --
+        and all results are read back once at the end (one synchronisation per batch instead of one per instance).  An
+        object without `point_idxs` gets its pairs (n_pairs = obj["n_pairs"]) and bin uniforms drawn on the device from
+        `seed` and its index: then only the cloud itself crosses PCIe."""
         mine = sharding.shard_objects(len(objects), rank, world)
-        recs = [sharding.pack_record(j, self.run_object(objects[j])) for j in mine]
+        raw = torch.zeros((max(len(mine), 1), 21), dtype=torch.float64, device=self.device)
+        cfgs = []
+        for slot, j in enumerate(mine):
+            obj = objects[j]
+            corners, dims = grid_shape(obj["pc"], obj["cfg"].res)
+            on_device = obj.get("point_idxs") is None
+            n_pairs = int(obj["n_pairs"]) if on_device else obj["point_idxs"].shape[0]
+            pipe = self._pipe(obj["cfg"], obj["pc"].shape[0], n_pairs, dims)
+            self._stage(pipe, obj["pc"], obj["normals"], obj.get("feat") if pipe.point_encoder is None else None, corners[0])
+            if not on_device:
+                pipe.load(None, None, None, obj["point_idxs"], obj["u_tr"], obj["u_rot"], None)
+            if on_device:
+                gen = torch.Generator(device=self.device)
+                gen.manual_seed(int(seed) * 1000003 + j)
+                pipe.sample_inputs(gen)
+            pipe.run_async(raw[slot])
+            cfgs.append(obj["cfg"])
+        host = raw.cpu().numpy()                       # the batch's only synchronisation
+        recs = [sharding.pack_record(j, assemble_record(host[slot], cfgs[slot])) for slot, j in enumerate(mine)]
         local = torch.stack(recs).to(self.device) if recs else \
             torch.zeros((0, sharding.RECORD), dtype=torch.float64, device=self.device)
         return sharding.gather_records(local, len(objects), rank, world, self.device)
