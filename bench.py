@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary stage timings (counter-collection passes)")
+    ap.add_argument("--streams", type=int, default=2, help="instances in flight per GPU: step k runs on HIP stream k mod S with its "
+                    "own buffers and captured graph (1 = strictly one instance at a time)")
     ap.add_argument("--no-graph", action="store_true", help="launch the chain eagerly instead of replaying a hipGraph")
     ap.add_argument("--n-points", type=int, default=4096, help="exploration only; the headline is 4096")
     ap.add_argument("--pairs-per-point", type=int, default=128, help="exploration only; the headline is 128")
@@ -102,9 +104,18 @@ def main():
     corners, dims = grid_shape(ob["pc"], cfg.res)
     d = lambda a: torch.from_numpy(a).to(dev)
     # static device buffers + the four launches of the chain captured once in a hipGraph
-    pipe = CenterPipeline(enc, cfg, N_POINTS, P, dims, dev, NUM_ROTS, adaptive=True, with_heads=True,
-                          use_graph=not args.no_graph)
-    pipe.load(ob["pc"], ob["normals"], ob["feat"], idx, u_tr, u_rot, corners[0].copy())
+    # S instances in flight: independent objects, so step k + 1 (other buffers, other stream) may start while step k's
+    # vote / arg-max tail drains -- the pair kernel is MFMA/VALU-bound, the vote LDS-atomic-bound, and every launch has
+    # a head and a tail that do not fill the chip
+    n_streams = max(1, args.streams)
+    pipes = []
+    for _ in range(n_streams):
+        p_ = CenterPipeline(enc, cfg, N_POINTS, P, dims, dev, NUM_ROTS, adaptive=True, with_heads=True,
+                            use_graph=not args.no_graph)
+        p_.load(ob["pc"], ob["normals"], ob["feat"], idx, u_tr, u_rot, corners[0].copy())
+        pipes.append(p_)
+    pipe = pipes[0]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
     res_all = torch.zeros((args.steps, 16), dtype=torch.uint8, device=dev)   # {i64 arg-max, f32 peak} of every step
 
     def close_batch():
@@ -117,17 +128,26 @@ def main():
             return sharding.gather_records(records, world * args.steps, rank, world, dev)   # the one collective
         return records
 
-    for _ in range(max(args.warmup, 1)):
-        pipe.run()
-        res_all[0].copy_(pipe.result, non_blocking=True)
+    def run_steps(n, first_slot=0):
+        """n steps, step k on stream k mod S; every step's result is kept (one 16-byte device copy on its stream); the
+        caller's stream waits for all of them at the end"""
+        main = torch.cuda.current_stream(dev)
+        for st in streams:
+            st.wait_stream(main)
+        for k in range(n):
+            with torch.cuda.stream(streams[k % n_streams]):
+                pipes[k % n_streams].run()
+                res_all[(first_slot + k) % args.steps].copy_(pipes[k % n_streams].result, non_blocking=True)
+        for st in streams:
+            main.wait_stream(st)
+
+    run_steps(max(args.warmup, n_streams))
     close_batch()            # warm-up of the gather too (RCCL communicators are created on first use)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        pipe.run()
-        res_all[k].copy_(pipe.result, non_blocking=True)     # every step's result is kept (one 16-byte device copy)
+    run_steps(args.steps)
     allrec = close_batch()
     if world > 1:
         torch.distributed.barrier()
@@ -137,6 +157,15 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
+
+    # the same K steps strictly one at a time on one stream (per-instance latency), reported next to the headline
+    torch.cuda.synchronize()
+    ts0 = time.perf_counter()
+    for k in range(args.steps):
+        pipe.run()
+        res_all[k].copy_(pipe.result, non_blocking=True)
+    torch.cuda.synchronize()
+    ms_single = (time.perf_counter() - ts0) / args.steps * 1e3
 
     # per-kernel durations (HIP events on the stream the C ABI launches on), measured eagerly right after
     # the timed region with the same buffers: the dominant kernel alone between two events
@@ -324,10 +353,13 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"single object N={N_POINTS} K={PAIRS_PER_POINT} (P={P} pairs), bottle config, res 4e-3, "
                                    f"grid {dims[0]}x{dims[1]}x{dims[2]}, num_rots 72 adaptive, fused PPF+MLP(MFMA f32)+decode -> "
-                                   "LDS-tiled vote -> argmax; one object per GPU per step; " +
-                                   ("four launches replayed from a hipGraph" if not args.no_graph else "eager launches"),
+                                   "LDS-tiled vote -> argmax; one object per GPU per step, " +
+                                   (f"{n_streams} independent objects in flight on {n_streams} HIP streams (double-buffered); "
+                                    if n_streams > 1 else "one object at a time; ") +
+                                   ("four launches per step replayed from a hipGraph" if not args.no_graph else "eager launches"),
                        "pairs_per_step_per_gpu": P, "parallelism": f"objects x{world}"},
             "pairs_per_ms_per_gpu": args.steps * P / elapsed / 1e3,
+            "ms_per_step_one_instance_at_a_time": ms_single,
             "stage_ms": {"ppf_mlp_decode": t_mlp, "ppf_mlp_decode_centre_heads_only": t_mlp_tr, "vote_reduce_argmax": t_vote,
                          "vote_reduce_argmax_known_answer_inputs": t_vote_ka,
                          "full_pose_incl_readback": t_pose, "full_pose_n_surv": pose["n_surv"],
