@@ -27,9 +27,10 @@ class BatchPoseRunner:
         self._pipes = {}
         self._staging = {}         # pinned host staging sets for the small per-instance arrays, see _stage()
         self._stage_pos = 0
+        self._streams = None
 
-    def _pipe(self, cfg, n_points, n_pairs, dims):
-        key = (cfg.category, n_points, n_pairs, tuple(dims))
+    def _pipe(self, cfg, n_points, n_pairs, dims, lane=0):
+        key = (cfg.category, n_points, n_pairs, tuple(dims), lane)
         if key not in self._pipes:
             self._pipes[key] = PosePipeline(self.encoders[cfg.category], cfg, n_points, n_pairs, dims, self.device,
                                             self.sphere, point_encoder=self.point_encoders.get(cfg.category), **self.kw)
@@ -61,7 +62,7 @@ class BatchPoseRunner:
         if feat is not None:
             st["feat"].numpy()[...] = feat
             pipe.feat.copy_(st["feat"], non_blocking=True)
-        st["ev"].record(torch.cuda.current_stream(self.device))
+        st["ev"].record(torch.cuda.current_stream(self.device))   # (the lane's stream: _stage is called inside its context)
 
     def run_object(self, obj):
         """obj: dict(pc, normals, feat, point_idxs, u_tr, u_rot, cfg) of host arrays -> pose dict."""
@@ -82,21 +83,32 @@ class BatchPoseRunner:
         mine = sharding.shard_objects(len(objects), rank, world)
         raw = torch.zeros((max(len(mine), 1), 21), dtype=torch.float64, device=self.device)
         cfgs = []
+        # two instances in flight: consecutive instances alternate between two HIP streams, each with its own pipelines
+        # (buffers + captured graph), so one instance's head overlaps the previous one's tail
+        if self._streams is None:
+            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(2)]
+        main = torch.cuda.current_stream(self.device)
+        for st in self._streams:
+            st.wait_stream(main)
         for slot, j in enumerate(mine):
             obj = objects[j]
             corners, dims = grid_shape(obj["pc"], obj["cfg"].res)
             on_device = obj.get("point_idxs") is None
             n_pairs = int(obj["n_pairs"]) if on_device else obj["point_idxs"].shape[0]
-            pipe = self._pipe(obj["cfg"], obj["pc"].shape[0], n_pairs, dims)
-            self._stage(pipe, obj["pc"], obj["normals"], obj.get("feat") if pipe.point_encoder is None else None, corners[0])
-            if not on_device:
-                pipe.load(None, None, None, obj["point_idxs"], obj["u_tr"], obj["u_rot"], None)
-            if on_device:
-                gen = torch.Generator(device=self.device)
-                gen.manual_seed(int(seed) * 1000003 + j)
-                pipe.sample_inputs(gen)
-            pipe.run_async(raw[slot])
+            lane = slot & 1
+            pipe = self._pipe(obj["cfg"], obj["pc"].shape[0], n_pairs, dims, lane)
+            with torch.cuda.stream(self._streams[lane]):
+                self._stage(pipe, obj["pc"], obj["normals"], obj.get("feat") if pipe.point_encoder is None else None, corners[0])
+                if not on_device:
+                    pipe.load(None, None, None, obj["point_idxs"], obj["u_tr"], obj["u_rot"], None)
+                if on_device:
+                    gen = torch.Generator(device=self.device)
+                    gen.manual_seed(int(seed) * 1000003 + j)
+                    pipe.sample_inputs(gen)
+                pipe.run_async(raw[slot])
             cfgs.append(obj["cfg"])
+        for st in self._streams:
+            main.wait_stream(st)
         host = raw.cpu().numpy()                       # the batch's only synchronisation
         recs = [sharding.pack_record(j, assemble_record(host[slot], cfgs[slot])) for slot, j in enumerate(mine)]
         local = torch.stack(recs).to(self.device) if recs else \
