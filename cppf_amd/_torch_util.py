@@ -44,9 +44,34 @@ def scalar(v):
     return v
 
 
+_ws_scope = None
+
+
+class workspace_scope:
+    """Scratch buffers requested inside the block belong to `owner` instead of to the current stream.  A captured
+    pipeline needs this: all graph captures run on torch's one capture stream, so per-stream scratch would be SHARED by
+    every captured pipeline -- fine while they replay one after the other, a data race once two of them are in flight on
+    two streams (the per-point table, the vote's partial tiles, the reduction scratch)."""
+
+    def __init__(self, owner):
+        self.owner = owner
+
+    def __enter__(self):
+        global _ws_scope
+        self.prev, _ws_scope = _ws_scope, self.owner
+        return self
+
+    def __exit__(self, *exc):
+        global _ws_scope
+        _ws_scope = self.prev
+        return False
+
+
 def workspace(nbytes, device, tag="ws"):
-    """Grow-only scratch per (device, stream, tag); reuse on one stream is stream-ordered."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream, tag)
+    """Grow-only scratch per (device, owner, tag); owner = the enclosing workspace_scope, else the current stream (reuse on
+    one stream is stream-ordered)."""
+    owner = ("scope", _ws_scope) if _ws_scope is not None else torch.cuda.current_stream(device).cuda_stream
+    key = (device, owner, tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._torch_util import require_cuda, stream_ptr, workspace
+from ._torch_util import require_cuda, stream_ptr, workspace, workspace_scope
 from .models import voting
 
 F32, I32 = torch.float32, torch.int32
@@ -155,7 +155,8 @@ class CenterPipeline:
                            self.num_rots, self.adaptive, self.out_idx, self.out_val, accumulate=False)
 
     def run(self):
-        with torch.no_grad():
+        # scratch requested by the chain belongs to this pipeline (see workspace_scope): pipelines replay concurrently
+        with torch.no_grad(), workspace_scope(id(self)):
             if not self._use_graph:
                 self._chain()
             elif self._graph is None:

@@ -698,3 +698,31 @@ def test_batch_runner_device_sampled_inputs(golden, dev):
     c = runner.run(objs, seed=6).cpu().numpy()
     assert a.shape[0] == 5 and np.array_equal(a, b) and not np.array_equal(a, c)
     assert np.all(np.isfinite(a)) and np.array_equal(a[:, 15], np.arange(5))
+
+
+def test_batch_runner_lanes_do_not_share_scratch(golden, dev):
+    """instances of ONE shape but different data, two in flight on two streams: every record equals the one the same
+    instance produces alone (captured pipelines own their scratch: the per-point table, the vote's partial tiles and the
+    reduction buffers must not be shared between the two lanes)"""
+    from cppf_amd.batch import BatchPoseRunner
+    from cppf_amd.models.model import PPFEncoder
+    cfg = syn.make_object("bottle", 64, 0)["cfg"]
+    torch.manual_seed(0)
+    encs = {"bottle": PPFEncoder(cfg.ppffcs, cfg.out_dim).eval().to(dev)}
+    objs = []
+    for j in range(8):
+        ob = syn.make_object("bottle", 2048, 50 + j)
+        ob["pc"] = (ob["pc"] - ob["pc"].min(0) + np.float32(0.01 * j)).astype(np.float32)      # same extents -> same grid dims
+        idx = syn.make_pairs(2048, 64, 50 + j)
+        u1, u2 = syn.make_uniforms(idx.shape[0], 50 + j)
+        objs.append(dict(pc=ob["pc"], normals=ob["normals"], feat=ob["feat"], point_idxs=idx, u_tr=u1, u_rot=u2, cfg=ob["cfg"]))
+    runner = BatchPoseRunner(encs, dev)
+    alone = []
+    for o in objs:
+        r = runner.run_object(o)
+        alone.append(np.concatenate([r["T"], r["up"], r["scale"], [r["argmax"], r["n_surv"]]]))
+    for rep in range(3):
+        recs = runner.run(objs).cpu().numpy()
+        for j, a in enumerate(alone):
+            got = np.concatenate([recs[j, 0:3], recs[j, 3:6], recs[j, 9:12], recs[j, 12:13], recs[j, 14:15]])
+            assert np.array_equal(got, a), (rep, j, got, a)
