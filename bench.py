@@ -378,7 +378,9 @@ def main():
                                  "pair-encoder stage (point_proj_kernel + pair_mlp_kernel); the pair kernel itself issues "
                                  f"{FLOP_PER_PAIR_EXECUTED} MFMA FLOP per pair because the two 40-wide feature blocks of layer 0 "
                                  "are projected once per point; fp32 MFMA shares the VALU datapath on gfx950, so the in-register "
-                                 "decode (about 480 VALU per 16 pairs) is paid on the same pipe",
+                                 "decode (about 480 VALU per 16 pairs) is paid on the same pipe; the duration is that of launches "
+                                 "without a neighbour (back to back on one stream) -- in the timed region two objects are in flight, "
+                                 "so a kernel trace of this command also holds launches that overlap another object's vote and take longer",
                          "executed_mfma_tflops": FLOP_PER_PAIR_EXECUTED * P / (t_mlp * 1e-3) / 1e12},
         }
         if world == 1 and not args.no_cpu_baseline:
