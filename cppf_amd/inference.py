@@ -169,7 +169,8 @@ class CenterPipeline:
                     self._chain()
                 torch.cuda.current_stream(self.device).wait_stream(s)
                 self._graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._graph):
+                # thread_local: other threads (the RCCL watchdog of a multi-rank run) may touch the runtime meanwhile
+                with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
                     self._chain()
                 self._graph.replay()
             else:
