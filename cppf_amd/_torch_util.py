@@ -67,6 +67,12 @@ class workspace_scope:
         return False
 
 
+def release_scope(owner):
+    """Drop every scratch buffer that belongs to workspace_scope(owner)."""
+    for key in [k for k in _ws_cache if k[1] == ("scope", owner)]:
+        del _ws_cache[key]
+
+
 def workspace(nbytes, device, tag="ws"):
     """Grow-only scratch per (device, owner, tag); owner = the enclosing workspace_scope, else the current stream (reuse on
     one stream is stream-ordered)."""

@@ -1,75 +1,123 @@
 """A batch of object instances (BASELINE.json config 4: mixed NOCS categories) on one or many GPUs.
 
 Objects are independent, so the batch is sharded round-robin over the ranks (object j -> rank j mod W,
-cppf_amd.sharding), each rank runs its objects back to back on its GPU -- one hipGraph replay per object,
-pipelines cached per (category, N, P, grid dims) -- and ONE all_gather of the fixed-size records closes
-the batch.  Mirrors the per-instance loop of nocs/inference.py:120-339 (different categories use different
-encoders and configs, :124-128)."""
+cppf_amd.sharding), each rank runs its objects back to back on its GPU -- one hipGraph replay per object -- and ONE
+all_gather of the fixed-size records closes the batch.  Mirrors the per-instance loop of nocs/inference.py:120-339
+(different categories use different encoders and configs, :124-128).
+
+Real instances almost never repeat a shape: N is whatever voxel de-duplication leaves (nocs/inference.py:140-142) and
+the grid is the cloud's bounding box over `res` (:194-195).  The runner therefore keeps SHAPE-POLYMORPHIC pipelines
+(inference.PosePipeline(dynamic=True)): one captured graph per (category, N rounded up to `n_bucket`, number of pairs,
+grid class, lane); an instance's real {N, gx, gy, gz} travels in a 16-byte device record next to its cloud.  The cache
+is bounded (least recently used pipelines are released with their buffers and scratch).  Grids beyond the tiled vote
+(> 64 LDS tiles) run on exact-shape pipelines, which share the same bounded cache."""
+from collections import OrderedDict
+
 import numpy as np
 import torch
 
 from . import sharding
-from .inference import PosePipeline, assemble_record, grid_shape
+from .inference import PosePipeline, assemble_record, grid_class, grid_shape
 from .utils.util import fibonacci_sphere, num_sphere_bins
 
 
 class BatchPoseRunner:
     def __init__(self, encoders, device, num_rots=72, adaptive=True, angle_tol=1.5, max_rot_pairs=10000,
-                 use_graph=True, point_encoders=None):
+                 use_graph=True, point_encoders=None, n_bucket=1024, max_pipelines=16, dynamic=True):
         """encoders: {category name: PPFEncoder on `device`} (the reference keeps one per category,
         nocs/inference.py:79-90).  point_encoders: optional {category name: PointEncoder}; objects of those
-        categories need no `feat` -- kNN + SPRIN run at the head of the captured graph (:180-181)."""
+        categories need no `feat` -- kNN + SPRIN run at the head of the captured graph (:180-181).
+        n_bucket: point capacities are multiples of it; max_pipelines: bound of the pipeline cache;
+        dynamic=False: one exact-shape pipeline per distinct instance shape (fixed-shape workloads only)."""
         self.encoders, self.device = encoders, device
         self.point_encoders = point_encoders or {}
         self.kw = dict(num_rots=num_rots, adaptive=adaptive, angle_tol=angle_tol, max_rot_pairs=max_rot_pairs,
                        use_graph=use_graph)
         self.sphere = np.array(fibonacci_sphere(num_sphere_bins(angle_tol)))      # :100-102
-        self._pipes = {}
+        self.n_bucket, self.max_pipelines, self.dynamic = int(n_bucket), int(max_pipelines), bool(dynamic)
+        self._pipes = OrderedDict()    # LRU: key -> PosePipeline
         self._staging = {}         # pinned host staging sets for the small per-instance arrays, see _stage()
         self._stage_pos = 0
         self._streams = None
 
+    # ------------------------------------------------------------------ pipeline cache
     def _pipe(self, cfg, n_points, n_pairs, dims, lane=0):
-        key = (cfg.category, n_points, n_pairs, tuple(dims), lane)
-        if key not in self._pipes:
-            self._pipes[key] = PosePipeline(self.encoders[cfg.category], cfg, n_points, n_pairs, dims, self.device,
-                                            self.sphere, point_encoder=self.point_encoders.get(cfg.category), **self.kw)
-        return self._pipes[key]
+        """The pipeline that serves this instance shape on this lane (created on first use, LRU-bounded)."""
+        T, many, _ = grid_class(dims)
+        dyn = self.dynamic and T > 0
+        if dyn:
+            n_cap = -(-int(n_points) // self.n_bucket) * self.n_bucket
+            key = (cfg.category, n_cap, n_pairs, many, lane)
+        else:
+            key = (cfg.category, n_points, n_pairs, tuple(dims), lane)
+        pipe = self._pipes.get(key)
+        if pipe is None:
+            while len(self._pipes) >= self.max_pipelines:
+                # the victim may still have a replay in flight on its lane's stream: drain before its buffers go back
+                # to the allocator (evictions are rare: a new shape bucket beyond the cache bound)
+                torch.cuda.synchronize(self.device)
+                _, old = self._pipes.popitem(last=False)
+                old.release()
+            if dyn:
+                pipe = PosePipeline(self.encoders[cfg.category], cfg, n_cap, n_pairs, many, self.device, self.sphere,
+                                    point_encoder=self.point_encoders.get(cfg.category), dynamic=True, **self.kw)
+            else:
+                pipe = PosePipeline(self.encoders[cfg.category], cfg, n_points, n_pairs, dims, self.device,
+                                    self.sphere, point_encoder=self.point_encoders.get(cfg.category), **self.kw)
+            self._pipes[key] = pipe
+        else:
+            self._pipes.move_to_end(key)
+        return pipe
 
     _RING = 4
 
-    def _stage(self, pipe, pc, normals, feat, corner):
-        """cloud, normals, (features,) grid corner -> the pipeline's device buffers through PINNED host memory, so the copies
-        are truly asynchronous (a copy from pageable memory blocks the host until everything queued before it has run, i.e.
-        until the previous instance has finished).  A ring of staging sets, each guarded by an event."""
-        n = pc.shape[0]
-        key = (n, None if feat is None else feat.shape[1])
+    def _stage(self, pipe, pc, normals, feat, corner, dims):
+        """cloud, normals, (features,) grid corner (and, for a dynamic pipeline, the shape record) -> the pipeline's device
+        buffers through PINNED host memory, so the copies are truly asynchronous (a copy from pageable memory blocks the host
+        until everything queued before it has run, i.e. until the previous instance has finished).  A ring of staging sets
+        per point capacity, each guarded by an event."""
+        n, cap = pc.shape[0], pipe.n_points
+        key = (cap, None if feat is None else feat.shape[1])
         ring = self._staging.get(key)
         if ring is None:
-            mk = lambda *shape: torch.empty(shape, dtype=torch.float32).pin_memory()
-            ring = [dict(pc=mk(n, 3), nrm=mk(n, 3), corner=mk(3), feat=None if feat is None else mk(n, feat.shape[1]),
-                         ev=torch.cuda.Event()) for _ in range(self._RING)]
+            mk = lambda *shape, dtype=torch.float32: torch.empty(shape, dtype=dtype).pin_memory()
+            ring = [dict(pc=mk(cap, 3), nrm=mk(cap, 3), corner=mk(3), shape=mk(4, dtype=torch.int32),
+                         feat=None if feat is None else mk(cap, feat.shape[1]), ev=torch.cuda.Event())
+                    for _ in range(self._RING)]
             self._staging[key] = ring
         st = ring[self._stage_pos % self._RING]
         self._stage_pos += 1
         st["ev"].synchronize()                          # the copies that last read this set have executed
-        st["pc"].numpy()[...] = pc
-        st["nrm"].numpy()[...] = normals
+        st["pc"].numpy()[:n] = pc
+        st["nrm"].numpy()[:n] = normals
         st["corner"].numpy()[...] = corner
-        pipe.pc.copy_(st["pc"], non_blocking=True)
-        pipe.nrm.copy_(st["nrm"], non_blocking=True)
+        pipe.pc[:n].copy_(st["pc"][:n], non_blocking=True)
+        pipe.nrm[:n].copy_(st["nrm"][:n], non_blocking=True)
         pipe.corner.copy_(st["corner"], non_blocking=True)
+        if pipe.dynamic:
+            st["shape"].numpy()[...] = (n,) + tuple(dims)
+            pipe.set_shape(n, dims, shape_src=st["shape"])
         if feat is not None:
-            st["feat"].numpy()[...] = feat
-            pipe.feat.copy_(st["feat"], non_blocking=True)
+            st["feat"].numpy()[:n] = feat
+            pipe.feat[:n].copy_(st["feat"][:n], non_blocking=True)
         st["ev"].record(torch.cuda.current_stream(self.device))   # (the lane's stream: _stage is called inside its context)
+
+    def _check(self, j, obj):
+        cat = obj["cfg"].category
+        if cat not in self.encoders:
+            raise ValueError(f"object {j}: no pair encoder for category {cat!r}")
+        if obj.get("feat") is None and cat not in self.point_encoders:
+            raise ValueError(f"object {j} ({cat}) has no `feat` and the runner has no point encoder for that category")
+        if obj["normals"].shape != obj["pc"].shape:
+            raise ValueError(f"object {j}: normals {obj['normals'].shape} vs points {obj['pc'].shape}")
 
     def run_object(self, obj):
         """obj: dict(pc, normals, feat, point_idxs, u_tr, u_rot, cfg) of host arrays -> pose dict."""
+        self._check(0, obj)
         corners, dims = grid_shape(obj["pc"], obj["cfg"].res)
         pipe = self._pipe(obj["cfg"], obj["pc"].shape[0], obj["point_idxs"].shape[0], dims)
-        pipe.load(obj["pc"], obj["normals"], obj.get("feat"), obj["point_idxs"], obj["u_tr"], obj["u_rot"],
-                  corners[0].copy())
+        feat = obj.get("feat") if pipe.point_encoder is None else None
+        pipe.load(obj["pc"], obj["normals"], feat, obj["point_idxs"], obj["u_tr"], obj["u_rot"], corners[0].copy(), dims=dims)
         return pipe.run()
 
     def run(self, objects, rank=0, world=1, seed=0):
@@ -92,19 +140,21 @@ class BatchPoseRunner:
             st.wait_stream(main)
         for slot, j in enumerate(mine):
             obj = objects[j]
+            self._check(j, obj)
             corners, dims = grid_shape(obj["pc"], obj["cfg"].res)
             on_device = obj.get("point_idxs") is None
             n_pairs = int(obj["n_pairs"]) if on_device else obj["point_idxs"].shape[0]
             lane = slot & 1
             pipe = self._pipe(obj["cfg"], obj["pc"].shape[0], n_pairs, dims, lane)
             with torch.cuda.stream(self._streams[lane]):
-                self._stage(pipe, obj["pc"], obj["normals"], obj.get("feat") if pipe.point_encoder is None else None, corners[0])
+                self._stage(pipe, obj["pc"], obj["normals"], obj.get("feat") if pipe.point_encoder is None else None,
+                            corners[0], dims)
                 if not on_device:
                     pipe.load(None, None, None, obj["point_idxs"], obj["u_tr"], obj["u_rot"], None)
                 if on_device:
                     gen = torch.Generator(device=self.device)
                     gen.manual_seed(int(seed) * 1000003 + j)
-                    pipe.sample_inputs(gen)
+                    pipe.sample_inputs(gen, n_points=obj["pc"].shape[0])
                 pipe.run_async(raw[slot])
             cfgs.append(obj["cfg"])
         for st in self._streams:

@@ -63,8 +63,10 @@ __device__ __forceinline__ int wave_sum(int v)
 // More than KNN_CAP candidates (duplicate-heavy inputs) run the bisection over re-streamed keys instead.
 template <bool FROM_DIST>
 __global__ __launch_bounds__(KNN_WAVES * 64) void knn_kernel(const float* __restrict__ pc, const float* __restrict__ dist,
-                                                             int N, int k, int32_t* __restrict__ out)
+                                                             int N, int k, int32_t* __restrict__ out,
+                                                             const int32_t* __restrict__ n_dev)
 {
+    if (n_dev) N = min(*n_dev, N);   // *_dyn: the launch is sized for a capacity, the point count is in memory
     __shared__ uint32_t cand_key[KNN_WAVES][KNN_CAP];
     __shared__ int cand_idx[KNN_WAVES][KNN_CAP];
     const int w = threadIdx.x >> 6, lane = lane_id();
@@ -202,6 +204,7 @@ struct ConvArgs {
     float* out;             // [N][out_stride], columns 0..31 written
     int N, k, n_in, out_stride;
     float* mixed_out;       // optional [N][32 * n_in]: the contraction, kept for the backward (training)
+    const int32_t* n_dev;   // *_dyn: point count in memory (N is then the capacity the launch is sized for)
 };
 
 // hidden = {32, 64, 32, 32}, rank 32, n_out 32 (train.py:34).  Dynamic LDS: the workgroup's weight image
@@ -222,8 +225,10 @@ __global__ __launch_bounds__(SP_WAVES_MAX * 64) void sprin_conv_kernel(ConvArgs 
     for (int i = threadIdx.x; i < SPW_FLOATS / 4; i += blockDim.x)
         reinterpret_cast<f32x4*>(Wl)[i] = reinterpret_cast<const f32x4*>(A.wimg)[i];
     const int n = blockIdx.x * (blockDim.x >> 6) + w;
-    const bool live = n < A.N;
-    const int nc = live ? n : A.N - 1;
+    const int N = A.n_dev ? min(*A.n_dev, A.N) : A.N;
+    if (blockIdx.x * (blockDim.x >> 6) >= N) return;   // whole workgroup past the cloud (capacity launch)
+    const bool live = n < N;
+    const int nc = live ? n : N - 1;
     const int jc = lane < k ? lane : k - 1;
     const int nb = A.nbrs[(size_t)nc * k + jc];
     const float rx = A.pc[3 * nb], ry = A.pc[3 * nb + 1], rz = A.pc[3 * nb + 2];
@@ -328,8 +333,11 @@ __global__ __launch_bounds__(SP_WAVES_MAX * 64) void sprin_conv_kernel(ConvArgs 
 // GlobalInfoProp (models/sprin.py:75-84): one thread per point computes linear(n_out -> n_glob), the
 // per-channel maximum goes to glob[] as an order-preserving uint (max is exact in any order).
 __global__ __launch_bounds__(256) void sprin_glob_kernel(const float* __restrict__ feat, int N, int stride, int n_glob,
-                                                         const float* __restrict__ Wa, uint32_t* __restrict__ glob)
+                                                         const float* __restrict__ Wa, uint32_t* __restrict__ glob,
+                                                         const int32_t* __restrict__ n_dev)
 {
+    if (n_dev) N = min(*n_dev, N);
+    if ((int)blockIdx.x * 256 >= N) return;
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int nc = n < N ? n : N - 1;
     float x[SP_NOUT];
@@ -350,8 +358,9 @@ __global__ __launch_bounds__(256) void sprin_glob_kernel(const float* __restrict
     }
 }
 __global__ __launch_bounds__(256) void sprin_fill_kernel(float* __restrict__ out, int N, int stride, int n_glob,
-                                                         const uint32_t* __restrict__ glob)
+                                                         const uint32_t* __restrict__ glob, const int32_t* __restrict__ n_dev)
 {
+    if (n_dev) N = min(*n_dev, N);
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= N * n_glob) return;
     const int n = t / n_glob, g = t - n * n_glob;
@@ -379,8 +388,16 @@ int cppf_knn(const float* pc, const float* dist, int n_points, int k, int32_t* n
     if ((!pc && !dist) || !nbrs || k > n_points) return CPPF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int blocks = (n_points + KNN_WAVES - 1) / KNN_WAVES;
-    if (dist) knn_kernel<true><<<blocks, KNN_WAVES * 64, 0, st>>>(pc, dist, n_points, k, nbrs);
-    else knn_kernel<false><<<blocks, KNN_WAVES * 64, 0, st>>>(pc, dist, n_points, k, nbrs);
+    if (dist) knn_kernel<true><<<blocks, KNN_WAVES * 64, 0, st>>>(pc, dist, n_points, k, nbrs, nullptr);
+    else knn_kernel<false><<<blocks, KNN_WAVES * 64, 0, st>>>(pc, dist, n_points, k, nbrs, nullptr);
+    return (int)hipGetLastError();
+}
+
+int cppf_knn_dyn(const float* pc, int n_cap, const int32_t* n_dev, int k, int32_t* nbrs, void* stream)
+{
+    if (n_cap < 1 || k <= 0 || !pc || !nbrs || !n_dev || k > n_cap) return CPPF_EINVAL;
+    const int blocks = (n_cap + KNN_WAVES - 1) / KNN_WAVES;
+    knn_kernel<false><<<blocks, KNN_WAVES * 64, 0, (hipStream_t)stream>>>(pc, nullptr, n_cap, k, nbrs, n_dev);
     return (int)hipGetLastError();
 }
 
@@ -437,7 +454,18 @@ size_t cppf_point_encoder_workspace_bytes(int n_points, int n_out, int n_glob, i
 
 static int sp_forward(const float* pc, const float* nrm, const int32_t* nbrs, int n_points, int k, const float* packed,
                       const int32_t* hidden, int n_hidden, int rank, int n_nbr_feats, int n_out, int n_glob, int num_layers,
-                      float* out, float* mixed_out, void* workspace, size_t workspace_bytes, void* stream);
+                      float* out, float* mixed_out, void* workspace, size_t workspace_bytes, void* stream,
+                      const int32_t* n_dev = nullptr);
+
+int cppf_point_encoder_forward_dyn(const float* pc, const float* nrm, const int32_t* nbrs, int n_cap, const int32_t* n_dev, int k,
+                                   const float* packed, const int32_t* hidden, int n_hidden, int rank, int n_nbr_feats,
+                                   int n_out, int n_glob, int num_layers, float* out, void* workspace,
+                                   size_t workspace_bytes, void* stream)
+{
+    if (!n_dev) return CPPF_EINVAL;
+    return sp_forward(pc, nrm, nbrs, n_cap, k, packed, hidden, n_hidden, rank, n_nbr_feats, n_out, n_glob, num_layers, out,
+                      nullptr, workspace, workspace_bytes, stream, n_dev);
+}
 
 int cppf_point_encoder_forward(const float* pc, const float* nrm, const int32_t* nbrs, int n_points, int k,
                                const float* packed, const int32_t* hidden, int n_hidden, int rank, int n_nbr_feats,
@@ -460,7 +488,8 @@ int cppf_point_encoder_forward_train(const float* pc, const float* nrm, const in
 
 static int sp_forward(const float* pc, const float* nrm, const int32_t* nbrs, int n_points, int k, const float* packed,
                       const int32_t* hidden, int n_hidden, int rank, int n_nbr_feats, int n_out, int n_glob, int num_layers,
-                      float* out, float* mixed_out, void* workspace, size_t workspace_bytes, void* stream)
+                      float* out, float* mixed_out, void* workspace, size_t workspace_bytes, void* stream,
+                      const int32_t* n_dev)
 {
     if (n_points < 0 || k <= 0 || num_layers <= 0 || !hidden) return CPPF_EINVAL;
     if (n_points == 0) return 0;
@@ -479,7 +508,7 @@ static int sp_forward(const float* pc, const float* nrm, const int32_t* nbrs, in
         const int n_in = l == 0 ? n_nbr_feats : W;
         float* dst = ((num_layers - 1 - l) & 1) ? ping : out;
         const float* src = l == 0 ? nullptr : (dst == out ? ping : out);
-        ConvArgs A{pc, nrm, src, nbrs, p, images + (size_t)l * SPW_FLOATS, dst, n_points, k, n_in, W, l == 0 ? mixed_out : nullptr};
+        ConvArgs A{pc, nrm, src, nbrs, p, images + (size_t)l * SPW_FLOATS, dst, n_points, k, n_in, W, l == 0 ? mixed_out : nullptr, n_dev};
         const int waves = sp_waves(n_in);
         const size_t lds = ((size_t)SPW_FLOATS + (size_t)waves * sp_per_wave(n_in)) * sizeof(float);
         hipError_t e = hipFuncSetAttribute((const void*)sprin_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -488,8 +517,8 @@ static int sp_forward(const float* pc, const float* nrm, const int32_t* nbrs, in
         if (e != hipSuccess) return (int)e;
         sprin_conv_kernel<<<(n_points + waves - 1) / waves, waves * 64, lds, st>>>(A);
         p += conv_params(hidden, n_hidden, rank, n_in, n_out);
-        sprin_glob_kernel<<<(n_points + 255) / 256, 256, 0, st>>>(dst, n_points, W, n_glob, p, glob);
-        sprin_fill_kernel<<<(n_points * n_glob + 255) / 256, 256, 0, st>>>(dst, n_points, W, n_glob, glob);
+        sprin_glob_kernel<<<(n_points + 255) / 256, 256, 0, st>>>(dst, n_points, W, n_glob, p, glob, n_dev);
+        sprin_fill_kernel<<<(n_points * n_glob + 255) / 256, 256, 0, st>>>(dst, n_points, W, n_glob, glob, n_dev);
         p += (size_t)n_glob * n_out + n_glob;
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;

@@ -36,6 +36,58 @@ static inline int tri(int n) { return n * (n + 1) / 2; }
 #define VOTE_TAB_LDS_MAX 2628   // (cos,sin) pairs kept in LDS (n_rots <= 72); else computed per sample
 #define VOTE_MAX_TILES 64       // beyond this the grid goes to global atomics (measured: 32 tiles still beat them 4-9x)
 #define VOTE_THREADS 1024
+#define VOTE_WGS_FEW 256        // workgroups of a launch with < 4 tiles (one per CU)
+#define VOTE_WGS_MANY 2048      // ... with >= 4 tiles: the hardware scheduler balances the peak tiles
+
+// The plan is a pure function of (n_ppfs, n_rots, grid dims): host code evaluates it for a launch with by-value
+// dims, the *_dyn kernels evaluate the SAME function on the device from a dims record in memory (one captured
+// graph then serves every instance shape up to its capacities, with results identical to the by-value launch).
+struct VoteTiling {
+    int tx, ty;       // tile extent in x and y (z is never cut)
+    int ntx, nty, T;  // tiles per axis, total (T = 1 << 30: no decomposition fits)
+};
+
+__host__ __device__ inline VoteTiling vote_tiling(int gx, int gy, int gz)
+{
+    VoteTiling p = {0, 0, 0, 0, 1 << 30};
+    if ((int64_t)gz <= VOTE_TILE_FLOATS) {
+        for (int nty = 1; nty <= gy; ++nty) {
+            int ty = (gy + nty - 1) / nty;
+            if ((int64_t)ty * gz > VOTE_TILE_FLOATS) continue;
+            int txmax = (int)(VOTE_TILE_FLOATS / ((int64_t)ty * gz));
+            if (txmax > gx) txmax = gx;
+            int ntx = (gx + txmax - 1) / txmax;
+            int tx = (gx + ntx - 1) / ntx;
+            int T = ntx * ((gy + ty - 1) / ty);
+            if (T < p.T) { p.T = T; p.tx = tx; p.ty = ty; p.ntx = ntx; p.nty = (gy + ty - 1) / ty; }
+            if (ntx == 1) break;  // more y cuts can only add tiles
+        }
+    }
+    return p;
+}
+
+// one workgroup per CU (tile ~115 KiB): T*chunks ~ 256 workgroups, chunks of >= 1024 pairs.  With many tiles the
+// votes pile up in the few tiles around the peak, so the chunks are made 8x smaller and the hardware scheduler
+// balances ~2 000 workgroups over the CUs (measured 2.4x on a 14-tile grid with a sharp peak).
+__host__ __device__ inline int vote_chunks(int64_t n_ppfs, int T, int64_t* chunk_pairs)
+{
+    int64_t c = (T >= 4 ? VOTE_WGS_MANY : VOTE_WGS_FEW) / T;
+    int64_t cmax = (n_ppfs + 1023) / 1024;
+    if (c > cmax) c = cmax;
+    if (c < 1) c = 1;
+    *chunk_pairs = (n_ppfs + c - 1) / c;
+    return (int)c;
+}
+
+// fixed-point bits of the largest weight: a workgroup deposits at most chunk_pairs*n_rots*(2^kk + 4) in
+// total, and every 2^32 of that is one carry-log entry (VOTE_CARRY_CAP of them)
+__host__ __device__ inline int vote_fixed_bits_of(int64_t chunk_pairs, int n_rots)
+{
+    const double cap = 2048.0 * 4294967296.0 / ((double)(chunk_pairs > 0 ? chunk_pairs : 1) * n_rots) - 4.0;
+    int kk = 24;
+    while (kk > 8 && (double)(1u << kk) > cap) --kk;
+    return kk;
+}
 
 struct VotePlan {
     int tiled;            // 1: LDS tiles + partial grids, 0: global atomics
@@ -52,32 +104,12 @@ static VotePlan make_vote_plan(int64_t n_ppfs, int n_rots, int gx, int gy, int g
     VotePlan p = {};
     int64_t G = (int64_t)gx * gy * gz;
     p.tab_entries = tri(n_rots);
-    int best_T = 1 << 30;
-    if ((int64_t)gz <= VOTE_TILE_FLOATS) {
-        for (int nty = 1; nty <= gy; ++nty) {
-            int ty = (gy + nty - 1) / nty;
-            if ((int64_t)ty * gz > VOTE_TILE_FLOATS) continue;
-            int txmax = (int)(VOTE_TILE_FLOATS / ((int64_t)ty * gz));
-            if (txmax > gx) txmax = gx;
-            int ntx = (gx + txmax - 1) / txmax;
-            int tx = (gx + ntx - 1) / ntx;
-            int T = ntx * ((gy + ty - 1) / ty);
-            if (T < best_T) { best_T = T; p.tx = tx; p.ty = ty; p.ntx = ntx; p.nty = (gy + ty - 1) / ty; }
-            if (ntx == 1) break;  // more y cuts can only add tiles
-        }
-    }
-    p.tiled = best_T <= VOTE_MAX_TILES && n_ppfs > 0;
-    p.T = p.tiled ? best_T : 1;
+    const VoteTiling t = vote_tiling(gx, gy, gz);
+    p.tx = t.tx; p.ty = t.ty; p.ntx = t.ntx; p.nty = t.nty;
+    p.tiled = t.T <= VOTE_MAX_TILES && n_ppfs > 0;
+    p.T = p.tiled ? t.T : 1;
     if (p.tiled) {
-        // one workgroup per CU (tile ~115 KiB): T*chunks ~ 256 workgroups, chunks of >= 1024 pairs.  With many tiles the
-        // votes pile up in the few tiles around the peak, so the chunks are made 8x smaller and the hardware scheduler
-        // balances ~2 000 workgroups over the CUs (measured 2.4x on a 14-tile grid with a sharp peak).
-        int64_t c = (p.T >= 4 ? 2048 : 256) / p.T;
-        int64_t cmax = (n_ppfs + 1023) / 1024;
-        if (c > cmax) c = cmax;
-        if (c < 1) c = 1;
-        p.chunks = (int)c;
-        p.chunk_pairs = (n_ppfs + c - 1) / c;
+        p.chunks = vote_chunks(n_ppfs, p.T, &p.chunk_pairs);
     } else {
         p.chunks = 0;
         p.chunk_pairs = 0;
@@ -88,21 +120,22 @@ static VotePlan make_vote_plan(int64_t n_ppfs, int n_rots, int gx, int gy, int g
     return p;
 }
 
-// fixed-point bits of the largest weight: a workgroup deposits at most chunk_pairs*n_rots*(2^kk + 4) in
-// total, and every 2^32 of that is one carry-log entry (VOTE_CARRY_CAP of them)
 static int vote_fixed_bits(const VotePlan& pl, int n_rots)
 {
     if (!pl.tiled) return 0;
-    const double cap = 2048.0 * 4294967296.0 / ((double)(pl.chunk_pairs > 0 ? pl.chunk_pairs : 1) * n_rots) - 4.0;
-    int kk = 24;
-    while (kk > 8 && (double)(1u << kk) > cap) --kk;
-    return kk;
+    return vote_fixed_bits_of(pl.chunk_pairs, n_rots);
 }
 
 extern "C" int cppf_vote_fixed_point_bits(int64_t n_ppfs, int n_rots, int gx, int gy, int gz)
 {
     if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || gx < 1 || gy < 1 || gz < 1 || n_ppfs < 0) return -1;
     return vote_fixed_bits(make_vote_plan(n_ppfs, n_rots, gx, gy, gz), n_rots);
+}
+
+// any plan a *_dyn launch can meet writes chunks * G <= workgroups * VOTE_TILE_FLOATS partial cells (G <= T * tile)
+extern "C" size_t cppf_vote_workspace_bytes_dyn(int many_tiles)
+{
+    return 256 + (size_t)(many_tiles ? VOTE_WGS_MANY : VOTE_WGS_FEW) * VOTE_TILE_FLOATS * sizeof(float);
 }
 
 extern "C" size_t cppf_vote_workspace_bytes(int64_t n_ppfs, int n_rots, int gx, int gy, int gz)
@@ -158,6 +191,10 @@ struct VoteArgs {
     int64_t chunk_pairs;
     int tab_entries;
     int kk;            // fixed-point bits of the largest weight
+    // *_dyn launches: {n_points, gx, gy, gz} in device memory; the by-value n_points / T / grid_cap are then CAPACITIES
+    // (n_points bounds the probs scan, T the tile count this launch geometry serves, grid_cap the cells of grid_obj)
+    const int32_t* shape;
+    int64_t grid_cap;
 };
 
 struct VoteTile {
@@ -276,21 +313,36 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
     float2* ltab = reinterpret_cast<float2*>(ctrl + 16);
     float* tile = reinterpret_cast<float*>(ltab + (TAB_LDS ? A.tab_entries + 2 : 0));  // +2: spare entry, 16-B alignment
     const int tid = threadIdx.x, lane = tid & 63;
-    const int gz = A.gz, gy = A.gy, gx = A.gx;
+    int gz = A.gz, gy = A.gy, gx = A.gx;
+    int pT = A.T, pnty = A.nty, ptx = A.tx, pty = A.ty, kk = A.kk;
+    int64_t chunk_pairs = A.chunk_pairs, n_points = A.n_points;
+    if (blockIdx.x == 0 && tid == 0) { A.packed[0] = 0ull; A.packed[1] = 0ull; }
+    if (TILED && A.shape) {
+        // dims record in memory: the plan of make_vote_plan(), evaluated here (uniform, scalar unit).  A record that does
+        // not fit the launch's capacities stops every workgroup; reduce_argmax_kernel reports it (index -1).
+        n_points = A.shape[0]; gx = A.shape[1]; gy = A.shape[2]; gz = A.shape[3];
+        if (n_points < 1 || n_points > A.n_points || gx < 1 || gy < 1 || gz < 1 || (int64_t)gx * gy * gz > A.grid_cap) return;
+        const VoteTiling vt = vote_tiling(gx, gy, gz);
+        if (vt.T > A.T) return;
+        pT = vt.T; pnty = vt.nty; ptx = vt.tx; pty = vt.ty;
+        const int chunks = vote_chunks(A.n_ppfs, pT, &chunk_pairs);
+        kk = vote_fixed_bits_of(chunk_pairs, A.n_rots);
+        if ((int)blockIdx.x >= pT * chunks) return;
+    }
 
     int t = 0, c = 0, x0 = 0, y0 = 0, tx = gx, ty = gy;
     int64_t p_begin, p_end, p_step;
     if (tid < 16) ctrl[tid] = 0;
     if (TILED) {
-        t = blockIdx.x % A.T;
-        c = blockIdx.x / A.T;
-        int tix = t / A.nty, tiy = t % A.nty;
-        x0 = tix * A.tx;
-        y0 = tiy * A.ty;
-        tx = min(A.tx, gx - x0);
-        ty = min(A.ty, gy - y0);
-        p_begin = (int64_t)c * A.chunk_pairs;
-        p_end = min((int64_t)(c + 1) * A.chunk_pairs, A.n_ppfs);
+        t = blockIdx.x % pT;
+        c = blockIdx.x / pT;
+        int tix = t / pnty, tiy = t % pnty;
+        x0 = tix * ptx;
+        y0 = tiy * pty;
+        tx = min(ptx, gx - x0);
+        ty = min(pty, gy - y0);
+        p_begin = (int64_t)c * chunk_pairs;
+        p_end = min((int64_t)(c + 1) * chunk_pairs, A.n_ppfs);
         p_step = VOTE_THREADS;
         const int nt = tx * ty * gz;
         for (int k = tid; k < nt; k += VOTE_THREADS) tile[k] = 0.f;  // +0.0f == 0u
@@ -303,7 +355,6 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
         fill_rot_table(ltab, A.tab_entries, tid, VOTE_THREADS);
         if (tid < 2) ltab[A.tab_entries + tid] = make_float2(0.f, 0.f);  // spare entries read by the 2-wide loop
     }
-    if (blockIdx.x == 0 && tid == 0) { A.packed[0] = 0ull; A.packed[1] = 0ull; }
     __syncthreads();
     float S = 0.f;
     if (TILED) {
@@ -311,7 +362,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
         // non-finite value disables the fixed-point path for this workgroup
         float pm = 0.f;
         int bad = 0;
-        for (int64_t k = tid; k < A.n_points; k += VOTE_THREADS) {
+        for (int64_t k = tid; k < n_points; k += VOTE_THREADS) {
             const float pv = A.probs[k];
             bad |= !(pv >= 0.f) || !(pv < INFINITY);
             pm = fmaxf(pm, pv);
@@ -329,7 +380,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
                 e = (int)(bits >> 23) + ((bits & 0x7fffffu) ? 1 : 0);
                 if (e < 1) e = 1;  // subnormal pmax: treat as the smallest normal
             }
-            const int se = 127 + A.kk - (e - 127);
+            const int se = 127 + kk - (e - 127);
             S = (se >= 1 && se <= 254) ? __uint_as_float((unsigned)se << 23) : 0.f;
         }
     }
@@ -528,14 +579,37 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
 
 #define RED_GROUPS 16
 #define RED_MAX_BLOCKS 256
+// *_dyn launches: the dims record the vote kernel read, plus what it takes to re-derive its plan
+struct RedDyn {
+    const int32_t* shape;  // {n_points, gx, gy, gz} or null
+    int64_t n_ppfs, grid_cap, n_points_cap;
+    int t_max;
+};
+
 __global__ __launch_bounds__(64 * RED_GROUPS) void reduce_argmax_kernel(float* __restrict__ grid,
                                                                         const float* __restrict__ partials, int chunks,
                                                                         int64_t G, unsigned long long* packed,
                                                                         int accumulate, int write_back,
-                                                                        long long* out_idx, float* out_val)
+                                                                        long long* out_idx, float* out_val, RedDyn D)
 {
     __shared__ float part[RED_GROUPS][64];
     const int lane = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    if (D.shape) {
+        const int64_t np = D.shape[0];
+        const int gx = D.shape[1], gy = D.shape[2], gz = D.shape[3];
+        const bool dims_ok = np >= 1 && np <= D.n_points_cap && gx >= 1 && gy >= 1 && gz >= 1 && (int64_t)gx * gy * gz <= D.grid_cap;
+        const VoteTiling vt = dims_ok ? vote_tiling(gx, gy, gz) : VoteTiling{0, 0, 0, 0, 1 << 30};
+        if (!dims_ok || vt.T > D.t_max) {   // the vote kernel did nothing: say so instead of reducing stale partials
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                if (out_idx) *out_idx = -1;
+                if (out_val) *out_val = __uint_as_float(0x7fc00000u);
+            }
+            return;
+        }
+        G = (int64_t)gx * gy * gz;
+        int64_t cp;
+        chunks = vote_chunks(D.n_ppfs, vt.T, &cp);
+    }
     const int64_t ngroups = (G + 63) / 64;
     unsigned long long key = 0ull;
     // grid-stride over 64-cell groups: few blocks, so the two same-address atomics per block at the end
@@ -587,21 +661,36 @@ __global__ void zero_u64x2_kernel(unsigned long long* p) { p[0] = 0ull; p[1] = 0
 
 #define VOTE_LDS_HEAD ((VOTE_THREADS / 64) * VOTE_RING * 2 + VOTE_CARRY_CAP * 4 + (VOTE_THREADS / 64) * VOTE_PAIRQ * 4 + 64)
 
+// shape_dev != null: gx, gy, gz, n_points are CAPACITIES (gx*gy*gz = cells of grid_obj) and the real values come from the
+// device record; only the tiled path exists in that mode.
 static int vote_impl(const float* points, const float* outputs, const float* probs, const void* point_idxs, int idx_is_i64,
                      float* grid_obj, const float* corner, float res, int64_t n_points, int64_t n_ppfs, int n_rots,
                      int gx, int gy, int gz, int adaptive, int accumulate, bool want_argmax, long long* out_idx, float* out_val,
-                     void* workspace, size_t workspace_bytes, hipStream_t st)
+                     void* workspace, size_t workspace_bytes, hipStream_t st, const int32_t* shape_dev = nullptr,
+                     int64_t grid_cap = 0, int many_tiles = 0)
 {
     if (!points || !probs || !grid_obj || !corner) return CPPF_EINVAL;
     if (n_ppfs > 0 && (!outputs || !point_idxs)) return CPPF_EINVAL;
     if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || gx < 1 || gy < 1 || gz < 1 || n_ppfs < 0 || n_points < 1) return CPPF_EINVAL;
     if ((int64_t)gx * gy * gz > 0x7fffffffll) return CPPF_EINVAL;
-    VotePlan pl = make_vote_plan(n_ppfs, n_rots, gx, gy, gz);
+    VotePlan pl;
+    if (shape_dev) {
+        if (n_ppfs < 1 || grid_cap < 1 || grid_cap > 0x7fffffffll) return CPPF_EINVAL;
+        pl = VotePlan{};
+        pl.tiled = 1;
+        pl.tab_entries = tri(n_rots);
+        pl.T = many_tiles ? VOTE_MAX_TILES : 3;                       // most tiles this launch geometry serves
+        pl.chunks = (many_tiles ? VOTE_WGS_MANY : VOTE_WGS_FEW);      // workgroups launched (>= T * chunks of any plan)
+        pl.part_off = 256;
+        pl.total = cppf_vote_workspace_bytes_dyn(many_tiles);
+    } else {
+        pl = make_vote_plan(n_ppfs, n_rots, gx, gy, gz);
+    }
     if (!workspace || workspace_bytes < pl.total) return CPPF_EWORKSPACE;
     char* ws = static_cast<char*>(workspace);
     unsigned long long* packed = reinterpret_cast<unsigned long long*>(ws + pl.packed_off);
     float* partials = reinterpret_cast<float*>(ws + pl.part_off);
-    const int64_t G = (int64_t)gx * gy * gz;
+    const int64_t G = shape_dev ? grid_cap : (int64_t)gx * gy * gz;
 
     VoteArgs A;
     A.points = points; A.outputs = outputs; A.probs = probs; A.point_idxs = point_idxs; A.idx64 = idx_is_i64;
@@ -610,12 +699,13 @@ static int vote_impl(const float* points, const float* outputs, const float* pro
     A.tx = pl.tx; A.ty = pl.ty; A.ntx = pl.ntx; A.nty = pl.nty; A.T = pl.T; A.chunk_pairs = pl.chunk_pairs;
     A.tab_entries = pl.tab_entries;
     A.n_points = n_points;
-    A.kk = vote_fixed_bits(pl, n_rots);
+    A.kk = shape_dev ? 0 : vote_fixed_bits(pl, n_rots);
+    A.shape = shape_dev; A.grid_cap = grid_cap;
     const bool tab_lds = pl.tab_entries <= VOTE_TAB_LDS_MAX;
     const size_t tab_bytes = tab_lds ? (size_t)(pl.tab_entries + 2) * sizeof(float2) : 0;
     if (pl.tiled) {
         const size_t lds = VOTE_LDS_HEAD + VOTE_TILE_FLOATS * sizeof(float) + tab_bytes;
-        dim3 grid(pl.T * pl.chunks);
+        dim3 grid(shape_dev ? pl.chunks : pl.T * pl.chunks);
         if (tab_lds) {
             static bool attr_done = false;
             if (!attr_done) {
@@ -652,9 +742,10 @@ static int vote_impl(const float* points, const float* outputs, const float* pro
     if (pl.tiled || want_argmax) {
         int64_t nb = (G + 63) / 64;
         if (nb > RED_MAX_BLOCKS) nb = RED_MAX_BLOCKS;
+        RedDyn D{shape_dev, n_ppfs, grid_cap, n_points, pl.T};
         hipLaunchKernelGGL(reduce_argmax_kernel, dim3((unsigned)nb), dim3(64 * RED_GROUPS), 0, st, grid_obj, partials,
                            pl.chunks, G, packed, pl.tiled ? accumulate : 1, pl.tiled ? 1 : 0,
-                           want_argmax ? out_idx : nullptr, want_argmax ? out_val : nullptr);
+                           want_argmax ? out_idx : nullptr, want_argmax ? out_val : nullptr, D);
         CPPF_CHECK_LAUNCH();
     }
     return 0;
@@ -679,6 +770,25 @@ extern "C" int cppf_vote_argmax(const float* points, const float* outputs, const
                      adaptive, accumulate, true, out_idx, out_val, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+extern "C" int cppf_vote_argmax_dyn(const float* points, const float* outputs, const float* probs, const void* point_idxs,
+                                    int idx_is_i64, float* grid_obj, int64_t grid_capacity, const float* corner, float res,
+                                    int64_t n_points_cap, int64_t n_ppfs, int n_rots, const int32_t* shape_dev, int many_tiles,
+                                    int adaptive, int accumulate, long long* out_idx, float* out_val, void* workspace,
+                                    size_t workspace_bytes, void* stream)
+{
+    if (!shape_dev) return CPPF_EINVAL;
+    return vote_impl(points, outputs, probs, point_idxs, idx_is_i64, grid_obj, corner, res, n_points_cap, n_ppfs, n_rots, 1, 1, 1,
+                     adaptive, accumulate, true, out_idx, out_val, workspace, workspace_bytes, (hipStream_t)stream, shape_dev,
+                     grid_capacity, many_tiles);
+}
+
+extern "C" int cppf_vote_tiles(int gx, int gy, int gz)
+{
+    if (gx < 1 || gy < 1 || gz < 1) return CPPF_EINVAL;
+    const VoteTiling t = vote_tiling(gx, gy, gz);
+    return t.T <= VOTE_MAX_TILES ? t.T : 0;
+}
+
 extern "C" int cppf_grid_argmax(const float* grid, int64_t n, long long* out_idx, float* out_val, void* workspace,
                                 size_t workspace_bytes, void* stream)
 {
@@ -690,7 +800,7 @@ extern "C" int cppf_grid_argmax(const float* grid, int64_t n, long long* out_idx
     int64_t nb = (n + 63) / 64;
     if (nb > RED_MAX_BLOCKS) nb = RED_MAX_BLOCKS;
     hipLaunchKernelGGL(reduce_argmax_kernel, dim3((unsigned)nb), dim3(64 * RED_GROUPS), 0, st, const_cast<float*>(grid),
-                       (const float*)nullptr, 0, n, packed, 1, 0, out_idx, out_val);
+                       (const float*)nullptr, 0, n, packed, 1, 0, out_idx, out_val, RedDyn{nullptr, 0, 0, 0, 0});
     CPPF_CHECK_LAUNCH();
     return 0;
 }
@@ -699,8 +809,10 @@ extern "C" int cppf_grid_argmax(const float* grid, int64_t n, long long* out_idx
 // T32 is the float32 copy handed to backvote (:225).
 __global__ void center_from_argmax_kernel(const long long* __restrict__ idx, const float* __restrict__ corner, double res,
                                           int gy, int gz, double* __restrict__ T64, float* __restrict__ T32,
-                                          const float* __restrict__ peak, double* __restrict__ idx_peak)
+                                          const float* __restrict__ peak, double* __restrict__ idx_peak,
+                                          const int32_t* __restrict__ shape)
 {
+    if (shape) { gy = max(shape[2], 1); gz = max(shape[3], 1); }   // dims record in memory (*_dyn)
     const long long flat = *idx;
     const long long syz = (long long)gy * gz;
     const long long c[3] = {flat / syz, (flat % syz) / gz, (flat % syz) % gz};
@@ -748,7 +860,17 @@ extern "C" int cppf_center_from_argmax(const long long* idx, const float* corner
 {
     if (!idx || !corner || gy < 1 || gz < 1) return CPPF_EINVAL;
     hipLaunchKernelGGL(center_from_argmax_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, idx, corner, res, gy, gz,
-                       T64, T32, peak, idx_peak_f64);
+                       T64, T32, peak, idx_peak_f64, (const int32_t*)nullptr);
+    CPPF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cppf_center_from_argmax_dyn(const long long* idx, const float* corner, double res, const int32_t* shape_dev,
+                                           double* T64, float* T32, const float* peak, double* idx_peak_f64, void* stream)
+{
+    if (!idx || !corner || !shape_dev) return CPPF_EINVAL;
+    hipLaunchKernelGGL(center_from_argmax_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, idx, corner, res, 1, 1,
+                       T64, T32, peak, idx_peak_f64, shape_dev);
     CPPF_CHECK_LAUNCH();
     return 0;
 }
@@ -774,8 +896,9 @@ __global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__
                                                               const float* __restrict__ corner, float res, int64_t n_ppfs,
                                                               int n_rots, int gx, int gy, int gz,
                                                               const float* __restrict__ gt_center, float tol,
-                                                              uint8_t* __restrict__ mask)
+                                                              uint8_t* __restrict__ mask, const int32_t* __restrict__ shape)
 {
+    if (shape) { gx = shape[1]; gy = shape[2]; gz = shape[3]; }   // dims record in memory (*_dyn)
     // (cos,sin) table for every n <= n_rots, built per block in LDS when it fits.
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float2* ltab = reinterpret_cast<float2*>(lds);
@@ -866,9 +989,10 @@ __global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__
     }
 }
 
-extern "C" int cppf_backvote(const float* points, const float* outputs, float* out_offsets,
-                             const int32_t* point_idxs, const float* corner, float res, int64_t n_ppfs, int n_rots,
-                             int gx, int gy, int gz, const float* gt_center, float tol, uint8_t* mask, void* stream)
+static int backvote_impl(const float* points, const float* outputs, float* out_offsets,
+                         const int32_t* point_idxs, const float* corner, float res, int64_t n_ppfs, int n_rots,
+                         int gx, int gy, int gz, const float* gt_center, float tol, uint8_t* mask, void* stream,
+                         const int32_t* shape_dev)
 {
     if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || n_ppfs < 0 || n_ppfs > 0xffffffffll) return CPPF_EINVAL;
     if (n_ppfs == 0) return 0;
@@ -879,9 +1003,26 @@ extern "C" int cppf_backvote(const float* points, const float* outputs, float* o
     if (nb > 1024) nb = 1024;
     hipLaunchKernelGGL(backvote_kernel, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, points,
                        outputs, out_offsets, point_idxs, corner, res, n_ppfs, n_rots, gx, gy, gz, gt_center, tol,
-                       mask);
+                       mask, shape_dev);
     CPPF_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int cppf_backvote(const float* points, const float* outputs, float* out_offsets,
+                             const int32_t* point_idxs, const float* corner, float res, int64_t n_ppfs, int n_rots,
+                             int gx, int gy, int gz, const float* gt_center, float tol, uint8_t* mask, void* stream)
+{
+    return backvote_impl(points, outputs, out_offsets, point_idxs, corner, res, n_ppfs, n_rots, gx, gy, gz, gt_center, tol,
+                         mask, stream, nullptr);
+}
+
+extern "C" int cppf_backvote_dyn(const float* points, const float* outputs, float* out_offsets,
+                                 const int32_t* point_idxs, const float* corner, float res, int64_t n_ppfs, int n_rots,
+                                 const int32_t* shape_dev, const float* gt_center, float tol, uint8_t* mask, void* stream)
+{
+    if (!shape_dev) return CPPF_EINVAL;
+    return backvote_impl(points, outputs, out_offsets, point_idxs, corner, res, n_ppfs, n_rots, 1, 1, 1, gt_center, tol,
+                         mask, stream, shape_dev);
 }
 
 // ----------------------------------------------------------------------------- compaction

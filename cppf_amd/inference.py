@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._torch_util import require_cuda, stream_ptr, workspace, workspace_scope
+from ._torch_util import release_scope, require_cuda, stream_ptr, workspace, workspace_scope
 from .models import voting
 
 F32, I32 = torch.float32, torch.int32
@@ -40,9 +40,9 @@ def grid_shape(pc_host, res):
 class PoseWorkspace:
     """Per-object device buffers, allocated once and reused across calls of the same size."""
 
-    def __init__(self, device, n_pairs, dims, n_sphere):
-        self.device, self.n_pairs, self.dims, self.n_sphere = device, n_pairs, tuple(dims), n_sphere
-        self.grid = torch.empty(self.dims, dtype=F32, device=device)
+    def __init__(self, device, n_pairs, dims, n_sphere, grid=None):
+        self.device, self.n_pairs, self.dims, self.n_sphere = device, n_pairs, None if dims is None else tuple(dims), n_sphere
+        self.grid = grid if grid is not None else torch.empty(self.dims, dtype=F32, device=device)
         self.out_idx = torch.empty(1, dtype=torch.int64, device=device)
         self.out_val = torch.empty(1, dtype=F32, device=device)
         # the 21-double result record; T64 / best_dir / sign / scale are views into it, so the kernels write the
@@ -100,6 +100,15 @@ def estimate_center(encoder, pc, pc_normal, feat, point_idxs, u_tr, cfg, corner,
     return ws.out_idx, ws.out_val, outputs, heads, ws.grid
 
 
+def grid_class(dims):
+    """(tiles, many_tiles, cell capacity) of the shape-polymorphic vote for a grid of `dims`: launches come in two
+    geometries, < 4 LDS tiles (256 workgroups, <= 88 320 cells) and <= 64 tiles (2 048 workgroups, <= 1 884 160 cells);
+    tiles == 0: the grid needs more than the tiled vote serves -- only the exact-shape pipeline runs it."""
+    T = int(_lib.lib().cppf_vote_tiles(int(dims[0]), int(dims[1]), int(dims[2])))
+    many = T >= 4
+    return T, many, (64 if many else 3) * 29440
+
+
 class CenterPipeline:
     """The centre chain (PPF -> MLP -> decode -> vote -> arg-max) for a fixed problem shape, with static
     device buffers and -- by default -- the three kernel launches captured once in a hipGraph, so that a
@@ -111,14 +120,25 @@ class CenterPipeline:
 
     `outputs` (mu, nu), `heads` and `grid` of the last run stay available as attributes.  With
     `point_encoder=` (a cppf_amd PointEncoder) the per-point features are computed on device at the head of the
-    chain (kNN + SPRIN, nocs/inference.py:180-181) and `load(feat=None)` is enough."""
+    chain (kNN + SPRIN, nocs/inference.py:180-181) and `load(feat=None)` is enough.
+
+    dynamic=True makes the pipeline SHAPE-POLYMORPHIC: `n_points` is then a capacity and `dims` either a capacity
+    class (`many_tiles` bool) or any grid of that class; every instance with N <= n_points points (N >= k of the point
+    encoder) and a grid of that class runs on the same captured graph -- its real shape {N, gx, gy, gz} travels in the
+    device record `shape` (written by load()) and the *_dyn kernels read it.  Real scenes give every instance its own N
+    (voxel de-duplication, nocs/inference.py:140-142) and its own grid (:194-195); the number of pairs is the caller's
+    constant (:177).  Results equal the exact-shape pipeline's bit for bit.
+
+    The encoders' weight images are re-checked before every run: a parameter update (optimizer step, load_state_dict)
+    is re-packed into the same device buffer, which the captured launches read; a moved / resized image re-captures."""
 
     def __init__(self, encoder, cfg, n_points, n_pairs, dims, device, num_rots=72, adaptive=True, with_heads=True,
-                 use_graph=True, point_encoder=None):
+                 use_graph=True, point_encoder=None, dynamic=False):
         require_cuda()
         self.encoder, self.cfg, self.device = encoder, cfg, device
         self.point_encoder = point_encoder
         self.num_rots, self.adaptive, self.with_heads = num_rots, adaptive, with_heads
+        self.n_points, self.n_pairs, self.dynamic = int(n_points), int(n_pairs), bool(dynamic)
         F = (encoder.ppffcs[0] - 4) // 2
         z = lambda *shape, dtype=F32: torch.zeros(shape, dtype=dtype, device=device)
         self.pc, self.nrm, self.feat = z(n_points, 3), z(n_points, 3), z(n_points, F)
@@ -127,7 +147,23 @@ class CenterPipeline:
         self.u_tr, self.u_rot = z(n_pairs, 2), z(n_pairs, 2)
         self.corner = z(3)
         self.probs = torch.ones(n_points, dtype=F32, device=device)           # nocs/inference.py:201
-        self.grid = torch.empty(tuple(dims), dtype=F32, device=device)
+        if self.dynamic:
+            if isinstance(dims, (bool, np.bool_)):
+                self.many_tiles = bool(dims)
+            else:
+                T, self.many_tiles, _ = grid_class(dims)
+                if T == 0:
+                    raise _lib.CppfError(f"grid {tuple(dims)} needs more LDS tiles than the shape-polymorphic vote serves")
+            self.grid_flat = z((64 if self.many_tiles else 3) * 29440)
+            self.shape = z(4, dtype=I32)                                       # {n_points, gx, gy, gz}, read by the *_dyn kernels
+            self.shape_host = (0, 0, 0, 0)
+            self.dims = None
+            if point_encoder is not None:
+                self._nbrs = z(n_points, point_encoder.k, dtype=I32)
+                self._feat_out = z(n_points, point_encoder.out_dim + point_encoder.out_dim // 4)
+        else:
+            self.dims = tuple(int(v) for v in dims)
+            self.grid = torch.empty(self.dims, dtype=F32, device=device)
         # arg-max index and value side by side in one 16-byte record, so a caller that logs every step moves them with
         # one small copy: `result` u8[16] = {i64 flat index, f32 peak, 4 bytes unused}
         self.result = torch.zeros(16, dtype=torch.uint8, device=device)
@@ -136,30 +172,89 @@ class CenterPipeline:
         self.outputs = self.heads = None
         self._graph = None
         self._use_graph = use_graph
+        self._images = None
 
-    def load(self, pc, pc_normal, feat, point_idxs, u_tr, u_rot, corner):
-        for dst, src in ((self.pc, pc), (self.nrm, pc_normal), (self.feat, feat), (self.idx, point_idxs),
-                         (self.u_tr, u_tr), (self.u_rot, u_rot), (self.corner, corner)):
+    def set_shape(self, n_points, dims, shape_src=None):
+        """dynamic pipelines: the next run's real shape.  `shape_src`: a (pinned) host i32[4] tensor the caller has filled
+        with {n_points, gx, gy, gz} -- copied asynchronously; without it a small synchronous upload is made."""
+        if not self.dynamic:
+            raise _lib.CppfError("set_shape() is for dynamic pipelines")
+        T, many, cap = grid_class(dims)
+        k_min = self.point_encoder.k if self.point_encoder is not None else 1
+        if not (k_min <= n_points <= self.n_points) or T == 0 or (many and not self.many_tiles) or \
+                int(dims[0]) * int(dims[1]) * int(dims[2]) > self.grid_flat.numel():
+            raise _lib.CppfError(f"instance shape N={n_points}, grid {tuple(dims)} does not fit this pipeline "
+                                 f"(N in {k_min}..{self.n_points}, many_tiles={self.many_tiles})")
+        self.shape_host = (int(n_points), int(dims[0]), int(dims[1]), int(dims[2]))
+        self.dims = self.shape_host[1:]
+        if shape_src is None:
+            shape_src = torch.tensor(self.shape_host, dtype=I32)
+        self.shape.copy_(shape_src, non_blocking=True)
+
+    @property
+    def grid_view(self):
+        """the vote grid of the last run as f32[gx,gy,gz]"""
+        if not self.dynamic:
+            return self.grid
+        gx, gy, gz = self.dims
+        return self.grid_flat[:gx * gy * gz].view(gx, gy, gz)
+
+    def load(self, pc, pc_normal, feat, point_idxs, u_tr, u_rot, corner, dims=None):
+        """host or device arrays -> the static buffers (None = keep).  Dynamic pipelines take clouds of any N <= capacity
+        and need `dims` (grid_shape(pc, res)[1]) together with `pc`."""
+        n = None if pc is None else int(pc.shape[0])
+        if self.dynamic and pc is not None:
+            if dims is None:
+                raise ValueError("a dynamic pipeline needs dims with every cloud")
+            self.set_shape(n, dims)
+        for dst, src, per_point in ((self.pc, pc, True), (self.nrm, pc_normal, True), (self.feat, feat, True),
+                                    (self.idx, point_idxs, False), (self.u_tr, u_tr, False), (self.u_rot, u_rot, False),
+                                    (self.corner, corner, False)):
             if src is None:
                 continue
-            dst.copy_(torch.as_tensor(src), non_blocking=True)
+            src = torch.as_tensor(src)
+            if self.dynamic and per_point:
+                dst = dst[:src.shape[0]]
+            dst.copy_(src, non_blocking=True)
 
     def _chain(self):
+        shape = self.shape if self.dynamic else None
         if self.point_encoder is not None:                                    # nocs/inference.py:180-181, no N x N matrix
-            self.feat = self.point_encoder(self.pc[None], self.nrm[None])[0]
+            if self.dynamic:
+                self.feat = self.point_encoder.forward_dyn(self.pc, self.nrm, shape, out=self._feat_out, nbrs=self._nbrs)
+            else:
+                self.feat = self.point_encoder(self.pc[None], self.nrm[None])[0]
         self.outputs, self.heads = self.encoder.forward_decode(
             self.pc, self.nrm, self.feat, self.idx, self.u_tr, self.cfg.vote_range,
             self.u_rot if self.with_heads else None, self.cfg.tr_num_bins, self.cfg.rot_num_bins)
         # the vote reads the int64 pair list directly (the reference copies it to int32 first, nocs/inference.py:202)
-        voting.vote_argmax(self.pc, self.outputs, self.probs, self.idx, self.grid, self.corner, self.cfg.res,
-                           self.num_rots, self.adaptive, self.out_idx, self.out_val, accumulate=False)
+        if self.dynamic:
+            voting.vote_argmax_dyn(self.pc, self.outputs, self.probs, self.idx, self.grid_flat, shape, self.corner,
+                                   self.cfg.res, self.num_rots, self.adaptive, self.out_idx, self.out_val,
+                                   many_tiles=self.many_tiles, accumulate=False)
+        else:
+            voting.vote_argmax(self.pc, self.outputs, self.probs, self.idx, self.grid, self.corner, self.cfg.res,
+                               self.num_rots, self.adaptive, self.out_idx, self.out_val, accumulate=False)
+
+    def _weight_images(self):
+        """(re)build the encoders' weight images if a parameter changed; returns their identity (addresses)"""
+        ids = [self.encoder._packed_weights(self.device).data_ptr()]
+        if self.point_encoder is not None:
+            ids.append(self.point_encoder._packed_weights(self.device)[0].data_ptr())
+        return tuple(ids)
 
     def run(self):
         # scratch requested by the chain belongs to this pipeline (see workspace_scope): pipelines replay concurrently
         with torch.no_grad(), workspace_scope(id(self)):
             if not self._use_graph:
                 self._chain()
-            elif self._graph is None:
+                return self.out_idx, self.out_val
+            # a changed parameter is re-packed here, on this stream, into the buffer the captured launches read; if the
+            # image itself moved (device change, other size) the captured addresses are stale: capture again
+            images = self._weight_images()
+            if self._graph is not None and images != self._images:
+                self._graph = None
+            if self._graph is None:
                 # warm up on a side stream (lazy attribute setting, weight packing, scratch allocation), then
                 # capture; the captured launches read the static buffers, so later loads just change the data
                 s = torch.cuda.Stream(device=self.device)
@@ -172,10 +267,20 @@ class CenterPipeline:
                 # thread_local: other threads (the RCCL watchdog of a multi-rank run) may touch the runtime meanwhile
                 with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
                     self._chain()
-                self._graph.replay()
-            else:
-                self._graph.replay()
+                self._images = images
+            self._graph.replay()
         return self.out_idx, self.out_val
+
+    def release(self):
+        """drop the captured graph and this pipeline's scratch buffers (BatchPoseRunner's cache eviction)"""
+        self._graph = None
+        release_scope(id(self))
+
+    def __del__(self):
+        try:
+            release_scope(id(self))      # scratch is keyed by id(self): it must not outlive the object
+        except Exception:
+            pass
 
 
 def estimate_pose(encoder, pc, pc_normal, feat, point_idxs, u_tr, u_rot, cfg, sphere_pts, pc_host=None, num_rots=72,
@@ -214,24 +319,33 @@ def estimate_pose(encoder, pc, pc_normal, feat, point_idxs, u_tr, u_rot, cfg, sp
 
 
 def _enqueue_tail(ws, pc, pc_normal, idx32, outputs, heads, corner, cfg, dims, num_rots, angle_tol, max_rot_pairs,
-                  sph32_d, sph64_d, sorted_y):
+                  sph32_d, sph64_d, sorted_y, shape=None):
     """nocs/inference.py:209-303,335 after the centre vote, all on the current stream; leaves the 21-double
-    result record in ws.rec (T[3], best_dir[2,3], sign sums[2,3], scale sums[4], argmax, peak)."""
+    result record in ws.rec (T[3], best_dir[2,3], sign sums[2,3], scale sums[4], argmax, peak).  `shape`: the device
+    dims record of a shape-polymorphic pipeline (then `dims` is unused)."""
     dev = pc.device
     L = _lib.lib()
     st = stream_ptr(dev)
     P, S = idx32.shape[0], sph32_d.shape[0]
     with torch.cuda.device(dev):
-        _lib.check(L.cppf_center_from_argmax(ws.out_idx.data_ptr(), corner.data_ptr(), float(cfg.res), dims[1],
-                                             dims[2], ws.T64.data_ptr(), ws.T32.data_ptr(), ws.out_val.data_ptr(),
-                                             ws.rec[19:21].data_ptr(), st),
-                   "cppf_center_from_argmax")
-        # back-vote filter (:216-231) --------------------------------------------------------------
-        # mask only: the offsets themselves (:220-228) are consumed nowhere else, so no buffer is zeroed or written
-        _lib.check(L.cppf_backvote(pc.data_ptr(), outputs.data_ptr(), None, idx32.data_ptr(),
-                                   corner.data_ptr(), float(cfg.res), P, num_rots, dims[0], dims[1], dims[2],
-                                   ws.T32.data_ptr(), float(np.float32(3 * cfg.res)), ws.mask.data_ptr(), st),
-                   "cppf_backvote")
+        if shape is not None:
+            _lib.check(L.cppf_center_from_argmax_dyn(ws.out_idx.data_ptr(), corner.data_ptr(), float(cfg.res), shape.data_ptr(),
+                                                     ws.T64.data_ptr(), ws.T32.data_ptr(), ws.out_val.data_ptr(),
+                                                     ws.rec[19:21].data_ptr(), st), "cppf_center_from_argmax_dyn")
+            _lib.check(L.cppf_backvote_dyn(pc.data_ptr(), outputs.data_ptr(), None, idx32.data_ptr(), corner.data_ptr(),
+                                           float(cfg.res), P, num_rots, shape.data_ptr(), ws.T32.data_ptr(),
+                                           float(np.float32(3 * cfg.res)), ws.mask.data_ptr(), st), "cppf_backvote_dyn")
+        else:
+            _lib.check(L.cppf_center_from_argmax(ws.out_idx.data_ptr(), corner.data_ptr(), float(cfg.res), dims[1],
+                                                 dims[2], ws.T64.data_ptr(), ws.T32.data_ptr(), ws.out_val.data_ptr(),
+                                                 ws.rec[19:21].data_ptr(), st),
+                       "cppf_center_from_argmax")
+            # back-vote filter (:216-231) --------------------------------------------------------------
+            # mask only: the offsets themselves (:220-228) are consumed nowhere else, so no buffer is zeroed or written
+            _lib.check(L.cppf_backvote(pc.data_ptr(), outputs.data_ptr(), None, idx32.data_ptr(),
+                                       corner.data_ptr(), float(cfg.res), P, num_rots, dims[0], dims[1], dims[2],
+                                       ws.T32.data_ptr(), float(np.float32(3 * cfg.res)), ws.mask.data_ptr(), st),
+                       "cppf_backvote")
         cws = workspace(L.cppf_compact_workspace_bytes(P), dev, "compact")
         _lib.check(L.cppf_compact_mask(ws.mask.data_ptr(), P, ws.surv.data_ptr(), ws.count.data_ptr(),
                                        cws.data_ptr(), cws.numel(), st), "cppf_compact_mask")
@@ -266,6 +380,8 @@ def _assemble(rec, cfg, rng=None):
     sign = rec[9:15].reshape(2, 3)
     ssum = rec[15:19]
     flat, peak = int(rec[19]), float(rec[20])
+    if flat < 0:    # cppf_vote_argmax_dyn: the instance's shape record exceeded the captured launch's capacities
+        raise _lib.CppfError("the instance shape did not fit the shape-polymorphic pipeline it ran on (arg-max index -1)")
     n_surv = int(ssum[3])
     n_dirs = 2 if cfg.regress_right else 1
 
@@ -323,23 +439,26 @@ def nocs_result(poses, res=None):
 
 
 class PosePipeline(CenterPipeline):
-    """Full per-instance pose for a fixed problem shape: CenterPipeline's chain plus the pose tail, captured
-    together in one hipGraph; `run()` replays it and reads back the 21-double record (one sync)."""
+    """Full per-instance pose for a fixed problem shape (or, with dynamic=True, for every shape up to its capacities, see
+    CenterPipeline): the centre chain plus the pose tail, captured together in one hipGraph; `run()` replays it and
+    reads back the 21-double record (one sync)."""
 
     def __init__(self, encoder, cfg, n_points, n_pairs, dims, device, sphere_pts, num_rots=72, adaptive=True,
-                 angle_tol=1.5, max_rot_pairs=10000, use_graph=True, point_encoder=None):
-        super().__init__(encoder, cfg, n_points, n_pairs, dims, device, num_rots, adaptive, True, use_graph, point_encoder)
+                 angle_tol=1.5, max_rot_pairs=10000, use_graph=True, point_encoder=None, dynamic=False):
+        super().__init__(encoder, cfg, n_points, n_pairs, dims, device, num_rots, adaptive, True, use_graph, point_encoder,
+                         dynamic)
         sph64 = np.asarray(sphere_pts, dtype=np.float64)
-        self.ws = PoseWorkspace(device, n_pairs, dims, sph64.shape[0])
-        self.ws.out_idx, self.ws.out_val, self.ws.grid = self.out_idx, self.out_val, self.grid
+        self.ws = PoseWorkspace(device, n_pairs, self.dims, sph64.shape[0], grid=self.grid_flat if self.dynamic else self.grid)
+        self.ws.out_idx, self.ws.out_val = self.out_idx, self.out_val
         self._sph = self.ws.sphere(sph64)
-        self.dims, self.angle_tol, self.max_rot_pairs = tuple(dims), angle_tol, max_rot_pairs
+        self.angle_tol, self.max_rot_pairs = angle_tol, max_rot_pairs
 
     def _chain(self):
         super()._chain()
         self.idx32.copy_(self.idx)                                            # the pose-tail kernels take int32 indices
         _enqueue_tail(self.ws, self.pc, self.nrm, self.idx32, self.outputs, self.heads, self.corner, self.cfg,
-                      self.dims, self.num_rots, self.angle_tol, self.max_rot_pairs, *self._sph)
+                      self.dims, self.num_rots, self.angle_tol, self.max_rot_pairs, *self._sph,
+                      shape=self.shape if self.dynamic else None)
 
     def run(self, rng=None):
         super().run()
@@ -354,11 +473,12 @@ class PosePipeline(CenterPipeline):
         super().run()
         record_out.copy_(self.ws.rec, non_blocking=True)
 
-    def sample_inputs(self, generator):
+    def sample_inputs(self, generator, n_points=None):
         """Draw the pair list and the bin-sampling uniforms on the device (the reference draws the pairs with
         np.random.randint on the host and the bins with torch.multinomial, nocs/inference.py:177,186): 17 MB per instance
         at C2 that never cross PCIe.  Same distribution, not the same stream of numbers -- parity tests pass explicit arrays."""
-        self.idx.random_(0, self.pc.shape[0], generator=generator)
+        n = self.shape_host[0] if self.dynamic else self.pc.shape[0]
+        self.idx.random_(0, int(n_points) if n_points is not None else n, generator=generator)
         self.u_tr.uniform_(0.0, 1.0, generator=generator)
         self.u_rot.uniform_(0.0, 1.0, generator=generator)
 

@@ -54,12 +54,38 @@ class ResLayer(nn.Module):
 def _params_of(module):
     """The module's parameters as a cached list.  nn.Module.parameters() walks the module tree on every call (~100 us for
     these encoders, several times per training step); the Parameter objects themselves are stable: .to() / .cuda() /
-    load_state_dict() swap or fill their data in place, and the encoders' structure is fixed by their constructors."""
+    load_state_dict() swap or fill their data in place, and the encoders' structure is fixed by their constructors.
+    Code that REPLACES a Parameter object or a submodule afterwards must call the encoder's invalidate()."""
     plist = module.__dict__.get("_cppf_plist")
     if plist is None:
         plist = list(module.parameters())
         module.__dict__["_cppf_plist"] = plist
     return plist
+
+
+class _DeviceWeights:
+    """What both encoders share about their device-side weight images.
+
+    The HIP kernels read a lane-ordered IMAGE of the parameters, rebuilt when a parameter changes.  A change is detected
+    through (data_ptr, _version) of every Parameter -- what optimizers, load_state_dict(), .to() and any in-place torch
+    op on the Parameter update.  Writes that bypass the version counter (`p.data.copy_()`, `p.data.mul_()`, EMA / weight
+    surgery through `.data`) are invisible to it: call `invalidate()` after them.  The image is rebuilt IN PLACE (same
+    device buffer) whenever size and device allow, so captured hipGraphs that baked its address in stay valid and pick
+    the new weights up at their next replay (inference.CenterPipeline re-checks before every replay)."""
+
+    def invalidate(self):
+        """Forget every cached view of the parameters (weight images, flat copies, parameter lists)."""
+        self.__dict__["_cppf_epoch"] = self.__dict__.get("_cppf_epoch", 0) + 1
+        for k in ("_cppf_plist", "_cppf_ordered", "_cppf_transposed"):
+            self.__dict__.pop(k, None)
+
+    def _apply(self, fn, *args, **kwargs):          # .to() / .cuda() / .float(): parameters may move or be re-created
+        out = super()._apply(fn, *args, **kwargs)
+        self.invalidate()
+        return out
+
+    def _param_key(self, device):
+        return (str(device), self.__dict__.get("_cppf_epoch", 0)) + tuple((p.data_ptr(), p._version) for p in _params_of(self))
 
 
 class _PairMlpFunction(torch.autograd.Function):
@@ -111,16 +137,20 @@ class _PointEncoderFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, enc, pc, nrm, nbrs, *params):
         with torch.no_grad():
-            mixed = torch.empty((pc.shape[0], 64), dtype=torch.float32, device=pc.device)
+            # the per-point contraction [rank 32 x n_nbr_feats], kept for the backward
+            mixed = torch.empty((pc.shape[0], 32 * enc.num_nbr_feats), dtype=torch.float32, device=pc.device)
             out = enc._forward_device(pc, nrm, nbrs, keep_contraction=mixed)
         ctx.enc = enc
-        ctx.save_for_backward(pc, nrm, nbrs, out, mixed)
+        # the parameters are saved too: the backward recomputes the forward from the weight image of the CURRENT parameters,
+        # so an in-place update between forward and backward must fail autograd's version check instead of giving
+        # silently wrong gradients
+        ctx.save_for_backward(pc, nrm, nbrs, out, mixed, *params)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         enc = ctx.enc
-        pc, nrm, nbrs, out, mixed = ctx.saved_tensors
+        pc, nrm, nbrs, out, mixed = ctx.saved_tensors[:5]
         dev = pc.device
         packed, desc = enc._packed_weights(dev)
         hid = (C.c_int * len(desc["hidden"]))(*desc["hidden"])
@@ -144,7 +174,7 @@ class _PointEncoderFunction(torch.autograd.Function):
         return (None, None, None, None, *grads)
 
 
-class PointEncoder(nn.Module):
+class PointEncoder(_DeviceWeights, nn.Module):
     """models/model.py:36-78.  Same constructor, parameter names and call signatures as the reference."""
 
     def __init__(self, k, spfcs, out_dim, num_layers=2, num_nbr_feats=2):
@@ -292,43 +322,75 @@ class PointEncoder(nn.Module):
         return (pc.detach().reshape(-1, 3).float().contiguous(), pc_normal.detach().reshape(-1, 3).float().contiguous())
 
     def _packed_weights(self, device):
-        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in _params_of(self))
+        key = self._param_key(device)
+        if self._packed is not None and self._packed_key == key:
+            return self._packed
         dev = torch.device(device)
-        if (self._packed is None or self._packed_key != key) and dev.type == "cuda" and self.num_layers == 1 \
-                and self.spfcs == [32, 64, 32, 32] and self.out_dim == 32 and self.num_nbr_feats == 2 \
-                and self.spconvs[0].layer_norm is not None:
+        L = _lib.lib()
+        old = self._packed[0] if self._packed is not None and self._packed[0].device == dev else None
+        if dev.type == "cuda" and self.num_layers == 1 and self.spfcs == [32, 64, 32, 32] and self.out_dim == 32 \
+                and self.num_nbr_feats == 2 and self.spconvs[0].layer_norm is not None:
             # standard encoder: natural block by one torch.cat, MFMA image by a device kernel -- no host round trip, so
             # a training loop (weights change every step) stays on the stream
             nat = torch.cat([(p.detach().t() if tr else p.detach()).reshape(-1).float()
                              for p, tr in zip(self._ordered_params(), self._ordered_transposed())]).to(dev).contiguous()
             desc = dict(hidden=list(self.spfcs), rank=32, n_nbr_feats=2, n_out=32, n_glob=self.out_dim // 4, num_layers=1)
             hid = (C.c_int * 4)(*self.spfcs)
-            L = _lib.lib()
-            n = L.cppf_point_encoder_packed_floats(hid, 4, 32, 2, 32, desc["n_glob"], 1)
-            packed = torch.empty(int(n), dtype=torch.float32, device=dev)
+            n = int(L.cppf_point_encoder_packed_floats(hid, 4, 32, 2, 32, desc["n_glob"], 1))
+            packed = old if old is not None and old.numel() == n else torch.empty(n, dtype=torch.float32, device=dev)
             with torch.cuda.device(dev):
                 rc = L.cppf_point_encoder_pack_device(nat.data_ptr(), hid, 4, 32, 2, 32, desc["n_glob"], 1, packed.data_ptr(),
                                                       stream_ptr(dev))
             _lib.check(rc, "cppf_point_encoder_pack_device")
-            self._packed = (packed, desc)
-            self._packed_key = key
-        if self._packed is None or self._packed_key != key:
+        else:
             sd = {k: v.detach().float().cpu().numpy() for k, v in self.state_dict().items()}
             natural, desc = pack_point_encoder(sd, self.num_layers)
             hid = (C.c_int * len(desc["hidden"]))(*desc["hidden"])
-            L = _lib.lib()
             n = L.cppf_point_encoder_packed_floats(hid, len(desc["hidden"]), desc["rank"], desc["n_nbr_feats"], desc["n_out"],
                                                    desc["n_glob"], self.num_layers)
             image = np.zeros(max(int(n), natural.size), np.float32)
             _lib.check(L.cppf_point_encoder_pack(natural.ctypes.data, hid, len(desc["hidden"]), desc["rank"],
                                                  desc["n_nbr_feats"], desc["n_out"], desc["n_glob"], self.num_layers,
                                                  image.ctypes.data), "cppf_point_encoder_pack")
-            self._packed = (torch.from_numpy(image).to(device), desc)
-            self._packed_key = key
+            if old is not None and old.numel() == image.size:
+                packed = old
+                packed.copy_(torch.from_numpy(image))
+            else:
+                packed = torch.from_numpy(image).to(device)
+        self._packed = (packed, desc)
+        self._packed_key = key
         return self._packed
 
+    def forward_dyn(self, pc, pc_normal, n_dev, out=None, nbrs=None):
+        """Shape-polymorphic forward for captured chains (cppf_knn_dyn + cppf_point_encoder_forward_dyn): pc / pc_normal are
+        capacity-sized f32[n_cap,3] device tensors, `n_dev` a device i32 tensor whose first element is the number of valid
+        points (>= k: the caller's duty).  Rows >= n of the result are left untouched.  Returns f32[n_cap, out_dim + out_dim//4]."""
+        require_cuda()
+        n_cap = pc.shape[0]
+        packed, desc = self._packed_weights(pc.device)
+        hid = (C.c_int * len(desc["hidden"]))(*desc["hidden"])
+        L = _lib.lib()
+        W = desc["n_out"] + desc["n_glob"]
+        if out is None:
+            out = torch.zeros((n_cap, W), dtype=torch.float32, device=pc.device)
+        if nbrs is None:
+            nbrs = torch.zeros((n_cap, self.k), dtype=torch.int32, device=pc.device)
+        ws = workspace(L.cppf_point_encoder_workspace_bytes(n_cap, desc["n_out"], desc["n_glob"], self.num_layers), pc.device,
+                       "point_encoder")
+        with torch.cuda.device(pc.device):
+            _lib.check(L.cppf_knn_dyn(pc.data_ptr(), n_cap, n_dev.data_ptr(), self.k, nbrs.data_ptr(), stream_ptr(pc.device)),
+                       "cppf_knn_dyn")
+            rc = L.cppf_point_encoder_forward_dyn(pc.data_ptr(), pc_normal.data_ptr(), nbrs.data_ptr(), n_cap, n_dev.data_ptr(),
+                                                  self.k, packed.data_ptr(), hid, len(desc["hidden"]), desc["rank"],
+                                                  desc["n_nbr_feats"], desc["n_out"], desc["n_glob"], self.num_layers,
+                                                  out.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr(pc.device))
+        if rc == -3:
+            raise _lib.CppfError(f"no device kernel for PointEncoder(k={self.k}, spfcs={self.spfcs}, out_dim={self.out_dim})")
+        _lib.check(rc, "cppf_point_encoder_forward_dyn")
+        return out
 
-class PPFEncoder(nn.Module):
+
+class PPFEncoder(_DeviceWeights, nn.Module):
     def __init__(self, ppffcs, out_dim):
         super().__init__()
         self.ppffcs = [int(d) for d in ppffcs]
@@ -493,16 +555,19 @@ class PPFEncoder(nn.Module):
         return (pc.detach().float().contiguous(), pc_normal.detach().float().contiguous(),
                 feat.detach().float().contiguous())
 
-    def _param_key(self, device):
-        return (str(device),) + tuple((p.data_ptr(), p._version) for p in _params_of(self))
-
     def _flat_params(self, device):
         """(flat device f32 copy of the parameters in `flatten_state_dict` order, host i64 offset table), rebuilt when a
         parameter changes (one torch.cat on the device, no host round trip)."""
         key = self._param_key(device)
         if self._flat is None or self._flat_key != key:
             ps = self._ordered_params()
-            flat = torch.cat([p.detach().reshape(-1).float() for p in ps]).to(device).contiguous()
+            dev = torch.device(device)
+            parts = [p.detach().reshape(-1).float() for p in ps]
+            old = self._flat[0] if self._flat is not None else None
+            if old is not None and old.device == dev and parts[0].device == dev and old.numel() == sum(t.numel() for t in parts):
+                flat = torch.cat(parts, out=old)             # same buffer: see _DeviceWeights
+            else:
+                flat = torch.cat(parts).to(device).contiguous()
             offs, pos = [], 0
             it = iter(ps)
             for present in self._param_presence():
@@ -531,9 +596,10 @@ class PPFEncoder(nn.Module):
             raise _lib.CppfError(f"no device kernel for ppffcs={self.ppffcs}, out_dim={self.out_dim} "
                                  "(layers wider than 128 units are unsupported)")
         dev = torch.device(device)
+        old = self._packed if self._packed is not None and self._packed.device == dev and self._packed.numel() == n else None
         if dev.type == "cuda" and self.ppffcs == [84, 32, 32, 16] and self.out_dim <= 144:
             flat, offs_c = self._flat_params(dev)
-            packed = torch.empty(n, dtype=torch.float32, device=dev)
+            packed = old if old is not None else torch.empty(n, dtype=torch.float32, device=dev)
             with torch.cuda.device(dev):
                 rc = L.cppf_pair_mlp_pack_device(flat.data_ptr(), offs_c, F_, dims, n_res, self.out_dim, packed.data_ptr(),
                                                  stream_ptr(dev))
@@ -546,7 +612,11 @@ class PPFEncoder(nn.Module):
             rc = L.cppf_pair_mlp_pack(params.ctypes.data, offs.ctypes.data, F_, dims, n_res, self.out_dim,
                                       packed.ctypes.data)
             _lib.check(rc, "cppf_pair_mlp_pack")
-            self._packed = torch.from_numpy(packed).to(device)
+            if old is not None:
+                old.copy_(torch.from_numpy(packed))
+                self._packed = old
+            else:
+                self._packed = torch.from_numpy(packed).to(device)
         self._packed_key = key
         return self._packed
 

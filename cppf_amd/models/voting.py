@@ -18,7 +18,7 @@ import torch
 from .. import _lib
 from .._torch_util import dev_tensor, require_cuda, scalar, stream_ptr, workspace
 
-__all__ = ["ppf_kernel", "backvote_kernel", "rot_voting_kernel", "vote_argmax", "grid_argmax"]
+__all__ = ["ppf_kernel", "backvote_kernel", "rot_voting_kernel", "vote_argmax", "vote_argmax_dyn", "grid_argmax"]
 
 F32, I32 = torch.float32, torch.int32
 
@@ -111,6 +111,34 @@ def vote_argmax(points, outputs, probs, point_idxs, grid_obj, corner, res, n_rot
                                 int(n_rots), gx, gy, gz, 1 if adaptive else 0, 1 if accumulate else 0,
                                 out_idx.data_ptr(), out_val.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr(dev))
     _lib.check(rc, "cppf_vote_argmax")
+    return out_idx, out_val
+
+
+def vote_argmax_dyn(points, outputs, probs, point_idxs, grid_flat, shape, corner, res, n_rots, adaptive, out_idx, out_val,
+                    many_tiles=False, accumulate=False):
+    """vote_argmax for a captured, shape-polymorphic chain (cppf_vote_argmax_dyn): `shape` is a device i32[4]
+    {n_points, gx, gy, gz}; `points`/`probs` are capacity-sized (rows beyond n_points are never read), `grid_flat` is a
+    flat f32 buffer whose first gx*gy*gz cells receive the grid in the usual C order.  Same results as vote_argmax on
+    the real shape.  A record exceeding a capacity yields out_idx = -1."""
+    dev = dev_tensor(points, F32, "points", (3,)).device
+    dev_tensor(outputs, F32, "outputs", (2,), dev)
+    dev_tensor(probs, F32, "probs", None, dev)
+    i64 = point_idxs.dtype == torch.int64
+    dev_tensor(point_idxs, torch.int64 if i64 else I32, "point_idxs", (2,), dev)
+    dev_tensor(grid_flat, F32, "grid_flat", None, dev)
+    dev_tensor(shape, I32, "shape", None, dev)
+    dev_tensor(corner, F32, "corner", None, dev)
+    if shape.numel() < 4 or probs.numel() != points.shape[0]:
+        raise ValueError("shape must be i32[4]; probs must have one entry per (capacity) point")
+    L = _lib.lib()
+    ws = workspace(L.cppf_vote_workspace_bytes_dyn(1 if many_tiles else 0), dev, "vote_dyn")
+    with torch.cuda.device(dev):
+        rc = L.cppf_vote_argmax_dyn(points.data_ptr(), outputs.data_ptr(), probs.data_ptr(), point_idxs.data_ptr(),
+                                    1 if i64 else 0, grid_flat.data_ptr(), grid_flat.numel(), corner.data_ptr(),
+                                    float(scalar(res)), points.shape[0], point_idxs.shape[0], int(n_rots), shape.data_ptr(),
+                                    1 if many_tiles else 0, 1 if adaptive else 0, 1 if accumulate else 0,
+                                    out_idx.data_ptr(), out_val.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr(dev))
+    _lib.check(rc, "cppf_vote_argmax_dyn")
     return out_idx, out_val
 
 

@@ -112,6 +112,42 @@ int cppf_compact_mask(const uint8_t* mask, int64_t n, int32_t* surv, int32_t* co
                       size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Shape-polymorphic (`_dyn`) variants: the instance shape lives in DEVICE memory.
+ *
+ * The reference runs one instance at a time and re-derives every size on the host (N after voxel de-duplication,
+ * nocs/inference.py:140-142; grid dims, :194-195), so every instance has its own launch geometry.  A captured hipGraph
+ * bakes by-value arguments in; these variants read `shape_dev` = device i32[4] {n_points, gx, gy, gz} instead, so ONE
+ * captured chain serves every instance whose shape fits the launch's capacities.  Layout and results are those of the
+ * by-value entry points for the same real shape, bit for bit: the kernels evaluate the same plan function on the device;
+ * capacities only size allocations and launch geometry.
+ *   cppf_vote_tiles           LDS tiles the vote needs for a grid (0: more than the tiled path serves) -- lets the caller
+ *                             pick `many_tiles` (needed when any instance can need >= 4 tiles; costs a 2 048-workgroup launch)
+ *   cppf_vote_argmax_dyn      cppf_vote_argmax; grid_obj holds grid_capacity cells, the real grid f32[gx,gy,gz] occupies its
+ *                             first gx*gy*gz cells; probs/points rows beyond n_points are never read.  A record that exceeds
+ *                             a capacity (cells, n_points_cap, tiles) writes out_idx = -1, out_val = NaN and votes nothing.
+ *   cppf_center_from_argmax_dyn, cppf_backvote_dyn   as their by-value forms, dims from the record
+ *   cppf_knn_dyn, cppf_point_encoder_forward_dyn     n_points from n_dev (device i32[1], e.g. shape_dev); launches sized
+ *                             for n_cap; rows >= n_points of nbrs / out are left untouched.  k <= n_points is the caller's duty.
+ * ------------------------------------------------------------------------------------------- */
+int cppf_vote_tiles(int gx, int gy, int gz);
+size_t cppf_vote_workspace_bytes_dyn(int many_tiles);
+int cppf_vote_argmax_dyn(const float* points, const float* outputs, const float* probs, const void* point_idxs,
+                         int idx_is_i64, float* grid_obj, int64_t grid_capacity, const float* corner, float res,
+                         int64_t n_points_cap, int64_t n_ppfs, int n_rots, const int32_t* shape_dev, int many_tiles,
+                         int adaptive, int accumulate, long long* out_idx, float* out_val, void* workspace,
+                         size_t workspace_bytes, void* stream);
+int cppf_center_from_argmax_dyn(const long long* idx, const float* corner, double res, const int32_t* shape_dev, double* T64,
+                                float* T32, const float* peak, double* idx_peak_f64, void* stream);
+int cppf_backvote_dyn(const float* points, const float* outputs, float* out_offsets, const int32_t* point_idxs,
+                      const float* corner, float res, int64_t n_ppfs, int n_rots, const int32_t* shape_dev,
+                      const float* gt_center, float tol, uint8_t* mask, void* stream);
+int cppf_knn_dyn(const float* pc, int n_cap, const int32_t* n_dev, int k, int32_t* nbrs, void* stream);
+int cppf_point_encoder_forward_dyn(const float* pc, const float* nrm, const int32_t* nbrs, int n_cap, const int32_t* n_dev,
+                                   int k, const float* packed, const int32_t* hidden, int n_hidden, int rank, int n_nbr_feats,
+                                   int n_out, int n_glob, int num_layers, float* out, void* workspace,
+                                   size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Orientation candidates.  Replaces `rot_voting_kernel` = CUDA `rot_voting`
  * (models/voting.py:115-148), launched at nocs/inference.py:265-275.
  *   preds_rot  device f32[n_ppfs]          outputs_up device f32[n_ppfs,n_rots,3], zero-initialised
