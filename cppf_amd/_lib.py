@@ -19,6 +19,7 @@ _SIGS = {
     "cppf_vote_argmax": (C.c_int, [vp, vp, vp, vp, i32, vp, vp, f32, i64, i64, i32, i32, i32, i32, i32, i32, vp, vp, vp, sz,
                                    vp]),
     "cppf_vote_tiles": (C.c_int, [i32, i32, i32]),
+    "cppf_vote_tile_cells": (C.c_int, []),
     "cppf_vote_workspace_bytes_dyn": (sz, [i32]),
     "cppf_vote_argmax_dyn": (C.c_int, [vp, vp, vp, vp, i32, vp, i64, vp, f32, i64, i64, i32, vp, i32, i32, i32, vp, vp, vp, sz,
                                        vp]),

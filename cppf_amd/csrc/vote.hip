@@ -32,7 +32,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 static inline int tri(int n) { return n * (n + 1) / 2; }
 
 // ----------------------------------------------------------------------------- vote plan
-#define VOTE_TILE_FLOATS 29440  // 115 KiB of the CU's 160 KiB LDS for the grid tile (8 KiB rings, 8 KiB carry log, 8 KiB pair queues, 21 KiB table)
+#define VOTE_TILE_FLOATS 28960  // 113 KiB of the CU's 160 KiB LDS for the grid tile (8 KiB rings, 8 KiB carry log, 8 KiB pair queues, 1.5 KiB arc-mask table, 21 KiB rotation table)
 #define VOTE_TAB_LDS_MAX 2628   // (cos,sin) pairs kept in LDS (n_rots <= 72); else computed per sample
 #define VOTE_MAX_TILES 64       // beyond this the grid goes to global atomics (measured: 32 tiles still beat them 4-9x)
 #define VOTE_THREADS 1024
@@ -203,8 +203,41 @@ struct VoteTile {
     int* carry_n;
     int x0, y0, tx, ty, gz, ltyz, syz;
     float res, S;  // S > 0: fixed-point scale; S == 0: fp32 atomics
+    float rres;    // 1/res refined the way the IEEE division sequence refines it, see div_by()
+    int dummy;     // index (relative to `tile`, in words) of this lane's two dummy words: the target of out-of-tile corners
+    int unit_probs;  // every prob is exactly 1.0f (all the reference's callers, nocs/inference.py:201): w * 1.0f == w
     float lo, hx, hy, hz;  // fp32 thresholds equivalent to the reference's fp64 tests
 };
+
+// a / b for a loop-invariant b: the compiler's IEEE-exact fp32 division (v_div_scale, v_rcp, two Newton steps on the
+// reciprocal, q0, residual, q1, residual, v_div_fmas, v_div_fixup) minus the parts that only act outside the normal
+// range -- the reciprocal refinement is hoisted (refined_rcp), operands are never rescaled (|a| <= a few metres over
+// res ~ 1e-3..1e-1: no scaling would be applied) and inf/NaN/0 fix-ups are not needed because such coordinates fail
+// the bound tests either way.  Same result bit for bit on that range (checked exhaustively on the device against `/`:
+// profiles/r2_div_check.txt); 5 instructions per division instead of 9.
+__device__ __forceinline__ float refined_rcp(float b)
+{
+    const float y0 = __builtin_amdgcn_rcpf(b);
+    const float e = fmaf(-b, y0, 1.0f);
+    return fmaf(e, y0, y0);
+}
+__device__ __forceinline__ float div_by(float a, float b, float y)
+{
+    const float q0 = a * y;
+    const float r0 = fmaf(-b, q0, a);
+    const float q1 = fmaf(r0, y, q0);
+    const float r1 = fmaf(-b, q1, a);
+    return fmaf(r1, y, q1);
+}
+
+// floor(x + 0.5) evaluated exactly, one instruction (x in [0, 2^24]: checked exhaustively, profiles/r2_div_check.txt); the
+// fixed-point deposit's rounding (ties go up; any nearest rounding keeps the half-quantum error bound)
+__device__ __forceinline__ uint32_t rpi_u32(float x)
+{
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return (uint32_t)r;
+}
 
 // (double)g < 0.01  <=>  g < smallest float >= 0.01 ;  (double)g >= d  <=>  g >= smallest float >= d
 __device__ __forceinline__ float ceil_to_float(double d)
@@ -214,26 +247,61 @@ __device__ __forceinline__ float ceil_to_float(double d)
     return f;
 }
 
-__device__ __forceinline__ void fixed_add(const VoteTile& T, int idx, float w)
-{
-    uint32_t* p = reinterpret_cast<uint32_t*>(T.tile) + idx;
-    const uint32_t inc = __float2uint_rn(w * T.S);
-    const uint32_t old = atomicAdd(p, inc);
-    if (old + inc < old) {  // wrapped: remember the cell, 2^32/S is added back at the flush
-        const int slot = atomicAdd(T.carry_n, 1);
-        if (slot < VOTE_CARRY_CAP) T.carry_log[slot] = (uint32_t)idx;
-    }
-}
-
 template <bool TILED>
 __device__ __forceinline__ void vote_deposit(const VoteTile& T, f3 v, float prob)
 {
-    const f3 g = div3(v, T.res);                                   // :35
+    const f3 g = {div_by(v.x, T.res, T.rres), div_by(v.y, T.res, T.rres), div_by(v.z, T.res, T.rres)};   // :35
     if (g.x < T.lo || g.y < T.lo || g.z < T.lo || g.x >= T.hx || g.y >= T.hy || g.z >= T.hz)
         return;                                                    // :36-39, fp64 tests folded to fp32 thresholds
     const int fx = (int)g.x, fy = (int)g.y, fz = (int)g.z;         // :40
-    const float rx = g.x - floorf(g.x), ry = g.y - floorf(g.y), rz = g.z - floorf(g.z);
+    // g - floorf(g) for g >= 0.01: the difference is exact, which is what v_fract_f32 returns
+    const float rx = __builtin_amdgcn_fractf(g.x), ry = __builtin_amdgcn_fractf(g.y), rz = __builtin_amdgcn_fractf(g.z);
     const float w0x = 1.f - rx, w0y = 1.f - ry, w0z = 1.f - rz;
+    if (TILED && T.S > 0.f) {
+        // Fixed point: inc = rn(weight * S), S a power of two, so S can ride on the last factor:
+        // rn((ll * w0z) * (prob * S)) == rn((ll * w0z) * prob) * S, and with unit probs rn(ll * (w0z * S)) == rn(ll * w0z) * S.
+        // All eight accumulations are issued back to back and waited for once (a returning LDS atomic is ~100 cycles away).
+        // A corner outside the tile is not branched around: its x or y factor is zeroed (the increment becomes 0) and its
+        // address is the lane's own pair of dummy words.
+        const int lx = fx - T.x0, ly = fy - T.y0;
+        const bool x0in = (unsigned)lx < (unsigned)T.tx, x1in = (unsigned)(lx + 1) < (unsigned)T.tx;
+        const bool y0in = (unsigned)ly < (unsigned)T.ty, y1in = (unsigned)(ly + 1) < (unsigned)T.ty;
+        const float ax0 = x0in ? w0x : 0.f, ax1 = x1in ? rx : 0.f, ay0 = y0in ? w0y : 0.f, ay1 = y1in ? ry : 0.f;
+        const float ll = ax0 * ay0, lh = ax0 * ay1, hl = ax1 * ay0, hh = ax1 * ay1;
+        float lll, llh, lhl, lhh, hll, hlh, hhl, hhh;
+        if (T.unit_probs) {
+            const float z0 = w0z * T.S, z1 = rz * T.S;
+            lll = ll * z0; llh = ll * z1; lhl = lh * z0; lhh = lh * z1;
+            hll = hl * z0; hlh = hl * z1; hhl = hh * z0; hhh = hh * z1;
+        } else {
+            const float ps = prob * T.S;
+            lll = ll * w0z * ps; llh = ll * rz * ps; lhl = lh * w0z * ps; lhh = lh * rz * ps;
+            hll = hl * w0z * ps; hlh = hl * rz * ps; hhl = hh * w0z * ps; hhh = hh * rz * ps;
+        }
+        const int b = __mul24(__mul24(lx, T.ty) + ly, T.gz) + fz;   // all < 2^24
+        const int dm = T.dummy;
+        const int a0 = (x0in && y0in) ? b : dm, a2 = (x0in && y1in) ? b + T.gz : dm;
+        const int a4 = (x1in && y0in) ? b + T.ltyz : dm, a6 = (x1in && y1in) ? b + T.ltyz + T.gz : dm;
+        uint32_t* tu = reinterpret_cast<uint32_t*>(T.tile);
+        const uint32_t i0 = rpi_u32(lll), i1 = rpi_u32(llh), i2 = rpi_u32(lhl), i3 = rpi_u32(lhh);
+        const uint32_t i4 = rpi_u32(hll), i5 = rpi_u32(hlh), i6 = rpi_u32(hhl), i7 = rpi_u32(hhh);
+        const uint32_t o0 = atomicAdd(tu + a0, i0), o1 = atomicAdd(tu + a0 + 1, i1), o2 = atomicAdd(tu + a2, i2),
+                       o3 = atomicAdd(tu + a2 + 1, i3), o4 = atomicAdd(tu + a4, i4), o5 = atomicAdd(tu + a4 + 1, i5),
+                       o6 = atomicAdd(tu + a6, i6), o7 = atomicAdd(tu + a6 + 1, i7);
+        // a wrap needs old >= 2^32 - inc with inc <= 2^24: one compare of the largest old value screens all eight
+        const uint32_t om = max(max(max(o0, o1), max(o2, o3)), max(max(o4, o5), max(o6, o7)));
+        if (om >= 0xfe000000u) {
+            auto wrapped = [&](uint32_t o, uint32_t inc, int a) {   // remember the cell, 2^32/S is added back at the flush
+                if (o + inc < o) {
+                    const int slot = atomicAdd(T.carry_n, 1);
+                    if (slot < VOTE_CARRY_CAP) T.carry_log[slot] = (uint32_t)a;
+                }
+            };
+            wrapped(o0, i0, a0); wrapped(o1, i1, a0 + 1); wrapped(o2, i2, a2); wrapped(o3, i3, a2 + 1);
+            wrapped(o4, i4, a4); wrapped(o5, i5, a4 + 1); wrapped(o6, i6, a6); wrapped(o7, i7, a6 + 1);
+        }
+        return;
+    }
     const float ll = w0x * w0y, lh = w0x * ry, hl = rx * w0y, hh = rx * ry;
     const float lll = ll * w0z * prob, llh = ll * rz * prob, lhl = lh * w0z * prob, lhh = lh * rz * prob;
     const float hll = hl * w0z * prob, hlh = hl * rz * prob, hhl = hh * w0z * prob, hhh = hh * rz * prob;
@@ -242,18 +310,11 @@ __device__ __forceinline__ void vote_deposit(const VoteTile& T, f3 v, float prob
         const bool x0in = (unsigned)lx < (unsigned)T.tx, x1in = (unsigned)(lx + 1) < (unsigned)T.tx;
         const bool y0in = (unsigned)ly < (unsigned)T.ty, y1in = (unsigned)(ly + 1) < (unsigned)T.ty;
         const int b = (lx * T.ty + ly) * T.gz + fz;
-        if (T.S > 0.f) {
-            if (x0in & y0in) { fixed_add(T, b, lll); fixed_add(T, b + 1, llh); }
-            if (x0in & y1in) { fixed_add(T, b + T.gz, lhl); fixed_add(T, b + T.gz + 1, lhh); }
-            if (x1in & y0in) { fixed_add(T, b + T.ltyz, hll); fixed_add(T, b + T.ltyz + 1, hlh); }
-            if (x1in & y1in) { fixed_add(T, b + T.ltyz + T.gz, hhl); fixed_add(T, b + T.ltyz + T.gz + 1, hhh); }
-        } else {
-            float* t = T.tile + b;
-            if (x0in & y0in) { atomicAdd(t, lll); atomicAdd(t + 1, llh); }
-            if (x0in & y1in) { atomicAdd(t + T.gz, lhl); atomicAdd(t + T.gz + 1, lhh); }
-            if (x1in & y0in) { atomicAdd(t + T.ltyz, hll); atomicAdd(t + T.ltyz + 1, hlh); }
-            if (x1in & y1in) { atomicAdd(t + T.ltyz + T.gz, hhl); atomicAdd(t + T.ltyz + T.gz + 1, hhh); }
-        }
+        float* t = T.tile + b;
+        if (x0in & y0in) { atomicAdd(t, lll); atomicAdd(t + 1, llh); }
+        if (x0in & y1in) { atomicAdd(t + T.gz, lhl); atomicAdd(t + T.gz + 1, lhh); }
+        if (x1in & y0in) { atomicAdd(t + T.ltyz, hll); atomicAdd(t + T.ltyz + 1, hlh); }
+        if (x1in & y1in) { atomicAdd(t + T.ltyz + T.gz, hhl); atomicAdd(t + T.ltyz + T.gz + 1, hhh); }
     } else {
         float* b = T.tile + ((int64_t)fx * T.syz + fy * T.gz + fz);
         atomicAdd(b, lll);
@@ -277,7 +338,7 @@ __device__ __forceinline__ int2 vote_pair_idx(const VoteArgs& A, int64_t p)
 }
 
 // one pair frame per lane, pulled across lanes by the deposit stage
-struct PairFrame { f3 cc, x, y; float prob; int n; };
+struct PairFrame { f3 cc, x, y; float prob; int n; };   // (n: rotation count; the pop pulls n*(n-1)/2, the table row)
 
 template <bool TILED, bool TAB_LDS>
 __device__ __forceinline__ void vote_pop(const VoteTile& VT, const PairFrame& F, const f3 cr, const float2* ltab,
@@ -290,14 +351,90 @@ __device__ __forceinline__ void vote_pop(const VoteTile& VT, const PairFrame& F,
     cc.x = __shfl(F.cc.x, src, 64); cc.y = __shfl(F.cc.y, src, 64); cc.z = __shfl(F.cc.z, src, 64);
     x.x = __shfl(F.x.x, src, 64); x.y = __shfl(F.x.y, src, 64); x.z = __shfl(F.x.z, src, 64);
     y.x = __shfl(F.y.x, src, 64); y.y = __shfl(F.y.y, src, 64); y.z = __shfl(F.y.z, src, 64);
-    const float prob = __shfl(F.prob, src, 64);
-    const int n = __shfl(F.n, src, 64);
+    const float prob = VT.unit_probs ? 1.0f : __shfl(F.prob, src, 64);
+    // TAB_LDS: the source lane's table row n*(n-1)/2 (computed once per pair), else n itself
+    const int n = __shfl(TAB_LDS ? __mul24(F.n, F.n - 1) >> 1 : F.n, src, 64);
     if (lane < count) {
-        const float2 cs = TAB_LDS ? ltab[n * (n - 1) / 2 + i] : rot_cs(i, n);
+        const float2 cs = TAB_LDS ? ltab[n + i] : rot_cs(i, n);
         const f3 offset = add3(scl3(x, cs.x), scl3(y, cs.y));      // :34
         const f3 v = sub3(add3(cc, offset), cr);                   // numerator of :35
         vote_deposit<TILED>(VT, v, prob);
     }
+}
+
+// ----------------------------------------------------------------------------- arc screen
+// Which rotations of a pair can land in the tile?  Along axis k the sample coordinate is
+//   q_k(theta) = c_k + x_k cos(theta) + y_k sin(theta) = c_k + A_k cos(theta - phi_k),
+// so lo <= q_k <= hi holds on the set  { alpha2 <= |theta - phi_k| <= alpha1 }  with alpha1 = acos((lo - c_k)/A_k),
+// alpha2 = acos((hi - c_k)/A_k): an arc around phi_k minus a smaller arc around phi_k.  Rotation i of n sits at
+// theta_i = 2 pi i / n, so each arc is a cyclic run of indices: a 96-bit mask per axis (n <= 72), and the AND of the three
+// axes is a superset of the rotations the exact test of the deposit stage accepts -- cheap approximations with explicit
+// slack (1e-4 in the cosine, 2e-3 rad in the angle, far above their error), never a dropped vote.  A pair costs ~300
+// instructions for its masks instead of ~45 per pair of rotations in a loop over all of them.
+#define VOTE_BELOW_N 97   // BELOW[j] = bits [0, j) set, j = 0..96, as uint4 (x, y, z = three words)
+
+__device__ __forceinline__ float atan01_approx(float t)   // atan on [0, 1], |error| < 2e-5
+{
+    const float t2 = t * t;
+    float p = fmaf(t2, 0.0208351f, -0.0851330f);
+    p = fmaf(t2, p, 0.1801410f);
+    p = fmaf(t2, p, -0.3302995f);
+    p = fmaf(t2, p, 0.9998660f);
+    return p * t;
+}
+__device__ __forceinline__ float atan2_approx(float y, float x)   // (-pi, pi], |error| < 1e-4; atan2(0, 0) = 0
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float r = atan01_approx(mn * __builtin_amdgcn_rcpf(fmaxf(mx, 1e-30f)));
+    r = ay > ax ? 1.57079633f - r : r;
+    r = x < 0.f ? 3.14159265f - r : r;
+    return __builtin_copysignf(r, y);
+}
+__device__ __forceinline__ float acos_approx(float u)   // u in [-1, 1]; |error| < 2e-4
+{
+    const float sn = __builtin_amdgcn_sqrtf(fmaxf(0.f, (1.f - u) * (1.f + u)));
+    const float ax = fabsf(u);
+    const float mx = fmaxf(ax, sn), mn = fminf(ax, sn);
+    float r = atan01_approx(mn * __builtin_amdgcn_rcpf(fmaxf(mx, 1e-30f)));
+    r = sn > ax ? 1.57079633f - r : r;
+    return u < 0.f ? 3.14159265f - r : r;
+}
+
+struct Mask96 { uint32_t a, b, c; };
+
+// bits of the cyclic index run [ia, ib] (mod n) -- all of [0, n) when it has n or more members, none when ib < ia
+__device__ __forceinline__ Mask96 arc_run(const uint4* __restrict__ below, int ia, int ib, int n)
+{
+    int len = ib - ia + 1;
+    len = len < 0 ? 0 : len;
+    const bool full = len >= n;
+    int s0 = ia < 0 ? ia + n : ia;
+    s0 = s0 >= n ? s0 - n : s0;
+    s0 = full ? 0 : (s0 < 0 ? 0 : s0);
+    const int e = full ? n : s0 + len;
+    const uint4 B1 = below[e < n ? e : n], B0 = below[s0], B2 = below[e > n ? e - n : 0];
+    return {(B1.x & ~B0.x) | B2.x, (B1.y & ~B0.y) | B2.y, (B1.z & ~B0.z) | B2.z};
+}
+
+// rotations i of n whose coordinate c + x cos(theta_i) + y sin(theta_i) can lie in [lo, hi]; nf = n / (2 pi)
+__device__ __forceinline__ Mask96 axis_arc_mask(const uint4* __restrict__ below, float c, float x, float y, float lo, float hi,
+                                                float nf, int n)
+{
+    const float A = __builtin_amdgcn_sqrtf(fmaf(x, x, y * y));
+    const float rA = __builtin_amdgcn_rcpf(fmaxf(A, 1e-20f));
+    const float u1 = fmaf(lo - c, rA, -1e-4f);   // cos(theta - phi) >= u1
+    const float u2 = fmaf(hi - c, rA, 1e-4f);    // cos(theta - phi) <= u2
+    const bool none = !(u1 <= 1.f) || !(u2 >= -1.f);   // (NaN-safe: a NaN coordinate drops the pair like the exact test does)
+    const float a1 = u1 <= -1.f ? 3.14159265f : acos_approx(fminf(u1, 1.f));
+    const float a2 = u2 >= 1.f ? 0.f : acos_approx(fmaxf(u2, -1.f));
+    const float f = atan2_approx(y, x) * nf;
+    const float W1 = (a1 + 2e-3f) * nf, W2 = (a2 - 2e-3f) * nf;
+    const Mask96 O = arc_run(below, (int)ceilf(f - W1), (int)floorf(f + W1), n);
+    // excluded: the integers strictly inside (f - W2, f + W2)
+    const Mask96 I = arc_run(below, (int)floorf(f - W2) + 1, W2 > 0.f ? (int)ceilf(f + W2) - 1 : -(1 << 20), n);
+    const uint32_t keep = none ? 0u : 0xffffffffu;
+    return {O.a & ~I.a & keep, O.b & ~I.b & keep, O.c & ~I.c & keep};
 }
 
 template <bool TILED, bool TAB_LDS>
@@ -305,12 +442,14 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // LDS: [rings: 16 waves x 256 x u16 = 8 KiB][carry log 8 KiB][pair queues: 16 x 128 x u32 = 8 KiB][ctrl 64 B]
-    //      [rotation table (+1 spare)][tile]
+    //      [128 dummy words][arc-mask table 97 x 16 B][rotation table (+1 spare)][tile]
     uint16_t* ring = reinterpret_cast<uint16_t*>(lds) + (threadIdx.x >> 6) * VOTE_RING;
     uint32_t* carry_log = reinterpret_cast<uint32_t*>(lds) + (VOTE_THREADS / 64) * VOTE_RING / 2;
     uint32_t* pairq = carry_log + VOTE_CARRY_CAP + (threadIdx.x >> 6) * VOTE_PAIRQ;
-    int* ctrl = reinterpret_cast<int*>(carry_log + VOTE_CARRY_CAP + (VOTE_THREADS / 64) * VOTE_PAIRQ);  // [0] carry count, [1] max(prob) bits, [2] bad probs
-    float2* ltab = reinterpret_cast<float2*>(ctrl + 16);
+    int* ctrl = reinterpret_cast<int*>(carry_log + VOTE_CARRY_CAP + (VOTE_THREADS / 64) * VOTE_PAIRQ);  // [0] carry count, [1] max(prob) bits, [2] bad probs, [3] some prob != 1
+    uint32_t* dummy = reinterpret_cast<uint32_t*>(ctrl + 16);   // 2 words per lane, see vote_deposit
+    uint4* below = reinterpret_cast<uint4*>(dummy + 128);   // arc-mask table, see axis_arc_mask
+    float2* ltab = reinterpret_cast<float2*>(below + VOTE_BELOW_N);
     float* tile = reinterpret_cast<float*>(ltab + (TAB_LDS ? A.tab_entries + 2 : 0));  // +2: spare entry, 16-B alignment
     const int tid = threadIdx.x, lane = tid & 63;
     int gz = A.gz, gy = A.gy, gx = A.gx;
@@ -333,6 +472,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
     int t = 0, c = 0, x0 = 0, y0 = 0, tx = gx, ty = gy;
     int64_t p_begin, p_end, p_step;
     if (tid < 16) ctrl[tid] = 0;
+    if (tid < 128) dummy[tid] = 0u;
     if (TILED) {
         t = blockIdx.x % pT;
         c = blockIdx.x / pT;
@@ -351,6 +491,11 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
         p_end = A.n_ppfs;
         p_step = (int64_t)gridDim.x * VOTE_THREADS;
     }
+    if (tid < VOTE_BELOW_N) {
+        const int j = tid;
+        auto w = [](int c) { return c <= 0 ? 0u : (c >= 32 ? 0xffffffffu : ((1u << c) - 1u)); };
+        below[j] = make_uint4(w(j), w(j - 32), w(j - 64), 0u);
+    }
     if (TAB_LDS) {
         fill_rot_table(ltab, A.tab_entries, tid, VOTE_THREADS);
         if (tid < 2) ltab[A.tab_entries + tid] = make_float2(0.f, 0.f);  // spare entries read by the 2-wide loop
@@ -361,14 +506,16 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
         // largest prob (weights are w * max(probs[a], probs[b]) <= max(probs)); any negative or
         // non-finite value disables the fixed-point path for this workgroup
         float pm = 0.f;
-        int bad = 0;
+        int bad = 0, nonunit = 0;
         for (int64_t k = tid; k < n_points; k += VOTE_THREADS) {
             const float pv = A.probs[k];
             bad |= !(pv >= 0.f) || !(pv < INFINITY);
+            nonunit |= pv != 1.0f;
             pm = fmaxf(pm, pv);
         }
         for (int off = 32; off > 0; off >>= 1) pm = fmaxf(pm, __shfl_xor(pm, off, 64));
         if (__any(bad) && lane == 0) ctrl[2] = 1;
+        if (__any(nonunit) && lane == 0) ctrl[3] = 1;
         if (lane == 0) atomicMax(&ctrl[1], __float_as_int(pm));  // non-negative floats order like ints
         __syncthreads();
         const float pmax = __int_as_float(ctrl[1]);
@@ -393,6 +540,9 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
     VT.carry_log = carry_log; VT.carry_n = ctrl;
     VT.x0 = x0; VT.y0 = y0; VT.tx = tx; VT.ty = ty; VT.gz = gz; VT.ltyz = ty * gz; VT.syz = gy * gz; VT.res = res;
     VT.S = S;
+    VT.rres = refined_rcp(res);
+    VT.dummy = (int)(dummy + 2 * lane - reinterpret_cast<uint32_t*>(tile));
+    VT.unit_probs = TILED ? !ctrl[3] : 0;
     VT.lo = ceil_to_float(0.01);
     VT.hx = ceil_to_float((double)gx - 1.01); VT.hy = ceil_to_float((double)gy - 1.01);
     VT.hz = ceil_to_float((double)gz - 1.01);
@@ -420,7 +570,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
                 if (A.adaptive) F.n = min((int)((double)(odist / res) * (2 * CPPF_PI)), A.n_rots);  // :31
             }
         }
-        const int n = F.n, tbase = n * (n - 1) / 2;
+        const int n = F.n;
         // screen in grid units: q = cq + cos*xq + sin*yq.  It differs from the exact coordinate of :35
         // by a few roundings of terms no larger than `mag`, so the acceptance box is widened per pair
         // by 1e-6*mag + 1e-3 cells (>= 16 ulp of the largest term).
@@ -433,16 +583,54 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
         const float hix1 = __uint_as_float(__float_as_uint(hix) - 1u), hiy1 = __uint_as_float(__float_as_uint(hiy) - 1u),
                     hiz1 = __uint_as_float(__float_as_uint(hiz) - 1u);
         int qhead = 0, qtail = 0;  // wave-uniform ring cursors, the ring is drained at the end of every batch
-        // two rotations per trip: half the loop/scalar overhead and two independent table reads + fma chains
-        // in flight (the loop is issue- and latency-bound, not bandwidth-bound); the table has a spare entry
+        if (TAB_LDS) {
+            // arc screen (n <= 72 rotations): three per-axis masks, their AND, then the set bits go to the ring two per
+            // trip in ballot order
+            const float nf = (float)n * 0.159154943f;
+            const Mask96 mx = axis_arc_mask(below, cq.x, xq.x, yq.x, lox, hix, nf, n);
+            const Mask96 my = axis_arc_mask(below, cq.y, xq.y, yq.y, loy, hiy, nf, n);
+            const Mask96 mz = axis_arc_mask(below, cq.z, xq.z, yq.z, loz, hiz, nf, n);
+            const uint32_t live = n > 0 ? 0xffffffffu : 0u;
+            uint32_t mw[3] = {mx.a & my.a & mz.a & live, mx.b & my.b & mz.b & live, mx.c & my.c & mz.c & live};
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+                uint32_t m = mw[w];
+                while (__any(m != 0u)) {
+                    const bool acc0 = m != 0u;
+                    const int b0 = __builtin_ctz(m | 0x80000000u);
+                    m &= m - 1u;
+                    const bool acc1 = m != 0u;
+                    const int b1 = __builtin_ctz(m | 0x80000000u);
+                    m &= m - 1u;
+                    const unsigned long long m0 = __ballot(acc0), m1 = __ballot(acc1);
+                    const int n0 = __popcll(m0);
+                    if (acc0) {
+                        const int pos = qtail + __builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32),
+                                                                          __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0));
+                        ring[pos & (VOTE_RING - 1)] = (uint16_t)(lane | ((32 * w + b0) << 6));
+                    }
+                    if (acc1) {
+                        const int pos = qtail + n0 + __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32),
+                                                                               __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0));
+                        ring[pos & (VOTE_RING - 1)] = (uint16_t)(lane | ((32 * w + b1) << 6));
+                    }
+                    qtail += n0 + __popcll(m1);
+                    while (qtail - qhead >= 64) {  // at most two pops: <= 63 queued + <= 128 pushed
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        vote_pop<TILED, TAB_LDS>(VT, F, cr, ltab, ring, qhead, lane, 64);
+                        qhead += 64;
+                    }
+                }
+            }
+        } else {
+        // more than 72 rotations: the rotation loop.  Two rotations per trip: half the loop/scalar overhead and two
+        // independent fma chains in flight (the loop is issue- and latency-bound, not bandwidth-bound)
         for (int i = 0; __any(i < n); i += 2) {
-            // every lane evaluates (no exec-masked region to leave: lanes past their n read a valid table slot -- tbase + i + 1
-            // stays inside the table and its spare entries -- and are masked by the i < n terms)
+            // every lane evaluates (no exec-masked region to leave); lanes past their n are masked by the i < n terms
             bool acc0, acc1;
             {
-                float2 c0, c1;
-                if (TAB_LDS) { c0 = ltab[tbase + i]; c1 = ltab[tbase + i + 1]; }
-                else { const int nn = n > 0 ? n : 1; c0 = rot_cs(i, nn); c1 = rot_cs(i + 1, nn); }
+                const int nn = n > 0 ? n : 1;
+                const float2 c0 = rot_cs(i, nn), c1 = rot_cs(i + 1, nn);
                 const float qx0 = fmaf(c0.y, yq.x, fmaf(c0.x, xq.x, cq.x)), qx1 = fmaf(c1.y, yq.x, fmaf(c1.x, xq.x, cq.x));
                 const float qy0 = fmaf(c0.y, yq.y, fmaf(c0.x, xq.y, cq.y)), qy1 = fmaf(c1.y, yq.y, fmaf(c1.x, xq.y, cq.y));
                 const float qz0 = fmaf(c0.y, yq.z, fmaf(c0.x, xq.z, cq.z)), qz1 = fmaf(c1.y, yq.z, fmaf(c1.x, xq.z, cq.z));
@@ -471,6 +659,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
                 vote_pop<TILED, TAB_LDS>(VT, F, cr, ltab, ring, qhead, lane, 64);
                 qhead += 64;
             }
+        }
         }
         if (qtail != qhead) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -659,7 +848,7 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void reduce_argmax_kernel(float* _
 
 __global__ void zero_u64x2_kernel(unsigned long long* p) { p[0] = 0ull; p[1] = 0ull; }
 
-#define VOTE_LDS_HEAD ((VOTE_THREADS / 64) * VOTE_RING * 2 + VOTE_CARRY_CAP * 4 + (VOTE_THREADS / 64) * VOTE_PAIRQ * 4 + 64)
+#define VOTE_LDS_HEAD ((VOTE_THREADS / 64) * VOTE_RING * 2 + VOTE_CARRY_CAP * 4 + (VOTE_THREADS / 64) * VOTE_PAIRQ * 4 + 64 + 512 + VOTE_BELOW_N * 16)
 
 // shape_dev != null: gx, gy, gz, n_points are CAPACITIES (gx*gy*gz = cells of grid_obj) and the real values come from the
 // device record; only the tiled path exists in that mode.
@@ -781,6 +970,8 @@ extern "C" int cppf_vote_argmax_dyn(const float* points, const float* outputs, c
                      adaptive, accumulate, true, out_idx, out_val, workspace, workspace_bytes, (hipStream_t)stream, shape_dev,
                      grid_capacity, many_tiles);
 }
+
+extern "C" int cppf_vote_tile_cells(void) { return VOTE_TILE_FLOATS; }
 
 extern "C" int cppf_vote_tiles(int gx, int gy, int gz)
 {

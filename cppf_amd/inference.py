@@ -102,11 +102,12 @@ def estimate_center(encoder, pc, pc_normal, feat, point_idxs, u_tr, cfg, corner,
 
 def grid_class(dims):
     """(tiles, many_tiles, cell capacity) of the shape-polymorphic vote for a grid of `dims`: launches come in two
-    geometries, < 4 LDS tiles (256 workgroups, <= 88 320 cells) and <= 64 tiles (2 048 workgroups, <= 1 884 160 cells);
+    geometries, < 4 LDS tiles (256 workgroups, <= 3 tiles of cells) and <= 64 tiles (2 048 workgroups, <= 64 tiles of cells);
     tiles == 0: the grid needs more than the tiled vote serves -- only the exact-shape pipeline runs it."""
-    T = int(_lib.lib().cppf_vote_tiles(int(dims[0]), int(dims[1]), int(dims[2])))
+    L = _lib.lib()
+    T = int(L.cppf_vote_tiles(int(dims[0]), int(dims[1]), int(dims[2])))
     many = T >= 4
-    return T, many, (64 if many else 3) * 29440
+    return T, many, (64 if many else 3) * int(L.cppf_vote_tile_cells())
 
 
 class CenterPipeline:
@@ -154,7 +155,7 @@ class CenterPipeline:
                 T, self.many_tiles, _ = grid_class(dims)
                 if T == 0:
                     raise _lib.CppfError(f"grid {tuple(dims)} needs more LDS tiles than the shape-polymorphic vote serves")
-            self.grid_flat = z((64 if self.many_tiles else 3) * 29440)
+            self.grid_flat = z((64 if self.many_tiles else 3) * int(_lib.lib().cppf_vote_tile_cells()))
             self.shape = z(4, dtype=I32)                                       # {n_points, gx, gy, gz}, read by the *_dyn kernels
             self.shape_host = (0, 0, 0, 0)
             self.dims = None

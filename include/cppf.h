@@ -130,6 +130,7 @@ int cppf_compact_mask(const uint8_t* mask, int64_t n, int32_t* surv, int32_t* co
  *                             for n_cap; rows >= n_points of nbrs / out are left untouched.  k <= n_points is the caller's duty.
  * ------------------------------------------------------------------------------------------- */
 int cppf_vote_tiles(int gx, int gy, int gz);
+int cppf_vote_tile_cells(void);   /* cells of one LDS tile: a launch serves grids of up to 3 (64 with many_tiles) times that */
 size_t cppf_vote_workspace_bytes_dyn(int many_tiles);
 int cppf_vote_argmax_dyn(const float* points, const float* outputs, const float* probs, const void* point_idxs,
                          int idx_is_i64, float* grid_obj, int64_t grid_capacity, const float* corner, float res,

@@ -65,7 +65,7 @@ def test_dyn_vote_equals_by_value_vote(dev, cat, n, res_scale, n_cap):
     assert torch.equal(flat[:G].view(dims), grid)
     assert bool((flat[G:] == -7.0).all())                   # nothing written past the real grid
     if not many:                                            # the 2 048-workgroup geometry serves small grids too
-        flat2 = torch.empty(64 * 29440, dtype=F32, device=dev)
+        flat2 = torch.empty(64 * _lib.lib().cppf_vote_tile_cells(), dtype=F32, device=dev)
         voting.vote_argmax_dyn(pc_cap, outputs, probs_cap, idx_d, flat2, shape, corner, res, 72, True, oi, ov, many_tiles=True)
         assert int(oi) == int(i0) and torch.equal(flat2[:G].view(dims), grid)
 
@@ -79,7 +79,7 @@ def test_dyn_vote_reports_a_record_beyond_its_capacities(dev):
     pc, outputs, idx_d, corner = t(ob["pc"], dev), t(out, dev), t(idx, dev), t(corners[0].copy(), dev)
     probs = torch.ones(512, dtype=F32, device=dev)
     oi, ov = torch.zeros(1, dtype=torch.int64, device=dev), torch.zeros(1, dtype=F32, device=dev)
-    flat = torch.zeros(3 * 29440, dtype=F32, device=dev)
+    flat = torch.zeros(3 * _lib.lib().cppf_vote_tile_cells(), dtype=F32, device=dev)
     for bad in ([513, *dims], [512, 200, 200, 200], [512, 0, 5, 5], [0, *dims]):
         shape = torch.tensor(bad, dtype=I32, device=dev)
         flat.fill_(3.0)
