@@ -5,7 +5,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "csrc", "libcppf_hip.so")
+# CPPF_SO: developer override (ablation / instrumented builds of the same ABI)
+_SO = os.environ.get("CPPF_SO") or os.path.join(_HERE, "csrc", "libcppf_hip.so")
 _lib = None
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t

@@ -79,6 +79,11 @@ __host__ __device__ inline int vote_chunks(int64_t n_ppfs, int T, int64_t* chunk
     return (int)c;
 }
 
+// Partial grids are TILE-MAJOR: partial c = T slots of `slot` floats (the largest tile's cells rounded up to 4), slot t =
+// the tile in its LDS order (x, y, z within the tile).  A workgroup dumps its tile with aligned 16-byte stores and the
+// reduce kernel reads every chunk's copy of a tile with aligned 16-byte loads.
+__host__ __device__ inline int vote_slot_floats(const VoteTiling& t, int gz) { return (t.tx * t.ty * gz + 3) & ~3; }
+
 // fixed-point bits of the largest weight: a workgroup deposits at most chunk_pairs*n_rots*(2^kk + 4) in
 // total, and every 2^32 of that is one carry-log entry (VOTE_CARRY_CAP of them)
 __host__ __device__ inline int vote_fixed_bits_of(int64_t chunk_pairs, int n_rots)
@@ -88,6 +93,15 @@ __host__ __device__ inline int vote_fixed_bits_of(int64_t chunk_pairs, int n_rot
     while (kk > 8 && (double)(1u << kk) > cap) --kk;
     return kk;
 }
+
+// Workspace layout: [0, 256) arg-max keys and tickets; [256, VOTE_WS_PART) the (cos, sin) rotation table of the LAST launch
+// that used this workspace, stamped with its n_rots at byte 248 -- building the table (2 628 fp64 sincos for 72 rotations)
+// cost every workgroup ~5 us of its prologue, so the first launch on a workspace builds it in LDS as before and workgroup 0
+// also leaves a copy here; later launches with the same n_rots find the stamp and load the 21 KB instead.  Nothing is kept
+// outside the caller's workspace.  [VOTE_WS_PART, ...) the partial grids.
+#define VOTE_WS_TAB 256
+#define VOTE_WS_PART (256 + ((VOTE_TAB_LDS_MAX + 2) * 8 + 255) / 256 * 256)
+#define VOTE_TAB_STAMP 0x43505046726f7400ull   // "CPPFrot\0" ^ n_rots
 
 struct VotePlan {
     int tiled;            // 1: LDS tiles + partial grids, 0: global atomics
@@ -115,8 +129,9 @@ static VotePlan make_vote_plan(int64_t n_ppfs, int n_rots, int gx, int gy, int g
         p.chunk_pairs = 0;
     }
     p.packed_off = 0;   // u64 packed arg-max key + u32 ticket counter
-    p.part_off = 256;
-    p.total = p.part_off + (size_t)p.chunks * (size_t)G * sizeof(float);
+    p.part_off = VOTE_WS_PART;
+    p.total = p.part_off + (size_t)p.chunks * (size_t)p.T * (p.tiled ? vote_slot_floats(t, gz) : 0) * sizeof(float);
+    (void)G;
     return p;
 }
 
@@ -135,7 +150,7 @@ extern "C" int cppf_vote_fixed_point_bits(int64_t n_ppfs, int n_rots, int gx, in
 // any plan a *_dyn launch can meet writes chunks * G <= workgroups * VOTE_TILE_FLOATS partial cells (G <= T * tile)
 extern "C" size_t cppf_vote_workspace_bytes_dyn(int many_tiles)
 {
-    return 256 + (size_t)(many_tiles ? VOTE_WGS_MANY : VOTE_WGS_FEW) * VOTE_TILE_FLOATS * sizeof(float);
+    return VOTE_WS_PART + (size_t)(many_tiles ? VOTE_WGS_MANY : VOTE_WGS_FEW) * VOTE_TILE_FLOATS * sizeof(float);
 }
 
 extern "C" size_t cppf_vote_workspace_bytes(int64_t n_ppfs, int n_rots, int gx, int gy, int gz)
@@ -181,7 +196,7 @@ struct VoteArgs {
     const void* point_idxs;  // i32[P,2] or i64[P,2] (idx64)
     int idx64;
     float* grid;       // !TILED target
-    float* partials;   // TILED target [chunks][G]
+    float* partials;   // TILED target [chunks][T][slot], see vote_slot_floats
     const float* corner;
     unsigned long long* packed;  // arg-max key + ticket, zeroed here for the reduce kernel
     float res;
@@ -446,7 +461,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
     uint16_t* ring = reinterpret_cast<uint16_t*>(lds) + (threadIdx.x >> 6) * VOTE_RING;
     uint32_t* carry_log = reinterpret_cast<uint32_t*>(lds) + (VOTE_THREADS / 64) * VOTE_RING / 2;
     uint32_t* pairq = carry_log + VOTE_CARRY_CAP + (threadIdx.x >> 6) * VOTE_PAIRQ;
-    int* ctrl = reinterpret_cast<int*>(carry_log + VOTE_CARRY_CAP + (VOTE_THREADS / 64) * VOTE_PAIRQ);  // [0] carry count, [1] max(prob) bits, [2] bad probs, [3] some prob != 1
+    int* ctrl = reinterpret_cast<int*>(carry_log + VOTE_CARRY_CAP + (VOTE_THREADS / 64) * VOTE_PAIRQ);  // [0] carry count, [4] next block of 64 pairs
     uint32_t* dummy = reinterpret_cast<uint32_t*>(ctrl + 16);   // 2 words per lane, see vote_deposit
     uint4* below = reinterpret_cast<uint4*>(dummy + 128);   // arc-mask table, see axis_arc_mask
     float2* ltab = reinterpret_cast<float2*>(below + VOTE_BELOW_N);
@@ -455,7 +470,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
     int gz = A.gz, gy = A.gy, gx = A.gx;
     int pT = A.T, pnty = A.nty, ptx = A.tx, pty = A.ty, kk = A.kk;
     int64_t chunk_pairs = A.chunk_pairs, n_points = A.n_points;
-    if (blockIdx.x == 0 && tid == 0) { A.packed[0] = 0ull; A.packed[1] = 0ull; }
+    if (blockIdx.x == 0 && tid < 2 + 2 * 8) A.packed[tid] = 0ull;   // arg-max keys + tickets of the reduce kernel (root + 8 groups)
     if (TILED && A.shape) {
         // dims record in memory: the plan of make_vote_plan(), evaluated here (uniform, scalar unit).  A record that does
         // not fit the launch's capacities stops every workgroup; reduce_argmax_kernel reports it (index -1).
@@ -471,6 +486,35 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
 
     int t = 0, c = 0, x0 = 0, y0 = 0, tx = gx, ty = gy;
     int64_t p_begin, p_end, p_step;
+    // Prologue, one barrier: the global loads (probs scan, rotation table) are issued first and land while the tile is
+    // being zeroed; every wave leaves its summary of the probs in its own words of LDS instead of meeting at an atomic.
+    // largest prob (weights are w * max(probs[a], probs[b]) <= max(probs)); any negative or non-finite value disables the
+    // fixed-point path for this workgroup
+    float pm = 0.f;
+    int bad = 0, nonunit = 0;
+    if (TILED) {
+        for (int64_t k0 = tid; k0 < n_points; k0 += 4 * VOTE_THREADS) {   // four independent loads in flight per trip
+            float pv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pv[u] = k0 + u * VOTE_THREADS < n_points ? A.probs[k0 + u * VOTE_THREADS] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool there = k0 + u * VOTE_THREADS < n_points;
+                bad |= !(pv[u] >= 0.f) || !(pv[u] < INFINITY);
+                nonunit |= there && pv[u] != 1.0f;
+                pm = fmaxf(pm, pv[u]);
+            }
+        }
+    }
+    // rotation table: from the workspace when the previous launch on it left one for this n_rots, else built below
+    float2* wtab = reinterpret_cast<float2*>(reinterpret_cast<char*>(A.packed) + VOTE_WS_TAB);
+    const bool tab_cached = TAB_LDS && A.packed[31] == (VOTE_TAB_STAMP ^ (unsigned long long)A.n_rots);
+    float2 tab_in[(VOTE_TAB_LDS_MAX + VOTE_THREADS - 1) / VOTE_THREADS];
+    if (tab_cached) {
+#pragma unroll
+        for (int u = 0; u < (VOTE_TAB_LDS_MAX + VOTE_THREADS - 1) / VOTE_THREADS; ++u)
+            if (tid + u * VOTE_THREADS < A.tab_entries) tab_in[u] = wtab[tid + u * VOTE_THREADS];
+    }
     if (tid < 16) ctrl[tid] = 0;
     if (tid < 128) dummy[tid] = 0u;
     if (TILED) {
@@ -484,8 +528,8 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
         p_begin = (int64_t)c * chunk_pairs;
         p_end = min((int64_t)(c + 1) * chunk_pairs, A.n_ppfs);
         p_step = VOTE_THREADS;
-        const int nt = tx * ty * gz;
-        for (int k = tid; k < nt; k += VOTE_THREADS) tile[k] = 0.f;  // +0.0f == 0u
+        const int nt4 = (tx * ty * gz + 3) >> 2;   // (the tile buffer is a multiple of 4 floats; the pad cells stay zero)
+        for (int k = tid; k < nt4; k += VOTE_THREADS) reinterpret_cast<uint4*>(tile)[k] = make_uint4(0u, 0u, 0u, 0u);  // +0.0f == 0u
     } else {
         p_begin = (int64_t)blockIdx.x * VOTE_THREADS;
         p_end = A.n_ppfs;
@@ -497,29 +541,39 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
         below[j] = make_uint4(w(j), w(j - 32), w(j - 64), 0u);
     }
     if (TAB_LDS) {
-        fill_rot_table(ltab, A.tab_entries, tid, VOTE_THREADS);
-        if (tid < 2) ltab[A.tab_entries + tid] = make_float2(0.f, 0.f);  // spare entries read by the 2-wide loop
+        if (tab_cached) {
+#pragma unroll
+            for (int u = 0; u < (VOTE_TAB_LDS_MAX + VOTE_THREADS - 1) / VOTE_THREADS; ++u)
+                if (tid + u * VOTE_THREADS < A.tab_entries) ltab[tid + u * VOTE_THREADS] = tab_in[u];
+        } else {
+            fill_rot_table(ltab, A.tab_entries, tid, VOTE_THREADS);
+            if (blockIdx.x == 0) {   // leave a copy for the next launch (visible to it: kernel boundary)
+                __syncthreads();
+                for (int e = tid; e < A.tab_entries; e += VOTE_THREADS) wtab[e] = ltab[e];
+                if (tid == 0) A.packed[31] = VOTE_TAB_STAMP ^ (unsigned long long)A.n_rots;
+            }
+        }
+        if (tid < 2) ltab[A.tab_entries + tid] = make_float2(0.f, 0.f);  // spare entries
+    }
+    float S = 0.f;
+    int unit_probs = 0;
+    if (TILED) {
+        // the wave's summary goes to the first two words of its (still unused) candidate ring
+        for (int off = 32; off > 0; off >>= 1) pm = fmaxf(pm, __shfl_xor(pm, off, 64));
+        const int flags = (__any(bad) ? 1 : 0) | (__any(nonunit) ? 2 : 0);
+        if (lane == 0) { reinterpret_cast<float*>(ring)[0] = pm; reinterpret_cast<int*>(ring)[1] = flags; }
     }
     __syncthreads();
-    float S = 0.f;
     if (TILED) {
-        // largest prob (weights are w * max(probs[a], probs[b]) <= max(probs)); any negative or
-        // non-finite value disables the fixed-point path for this workgroup
-        float pm = 0.f;
-        int bad = 0, nonunit = 0;
-        for (int64_t k = tid; k < n_points; k += VOTE_THREADS) {
-            const float pv = A.probs[k];
-            bad |= !(pv >= 0.f) || !(pv < INFINITY);
-            nonunit |= pv != 1.0f;
-            pm = fmaxf(pm, pv);
+        float pmax = 0.f;
+        int flags = 0;
+        for (int w = 0; w < VOTE_THREADS / 64; ++w) {
+            const uint16_t* rw = reinterpret_cast<const uint16_t*>(lds) + w * VOTE_RING;
+            pmax = fmaxf(pmax, reinterpret_cast<const float*>(rw)[0]);
+            flags |= reinterpret_cast<const int*>(rw)[1];
         }
-        for (int off = 32; off > 0; off >>= 1) pm = fmaxf(pm, __shfl_xor(pm, off, 64));
-        if (__any(bad) && lane == 0) ctrl[2] = 1;
-        if (__any(nonunit) && lane == 0) ctrl[3] = 1;
-        if (lane == 0) atomicMax(&ctrl[1], __float_as_int(pm));  // non-negative floats order like ints
-        __syncthreads();
-        const float pmax = __int_as_float(ctrl[1]);
-        if (!ctrl[2]) {
+        unit_probs = !(flags & 2);
+        if (!(flags & 1)) {
             // p2 = pmax rounded up to a power of two (1 when pmax == 0); S = 2^kk / p2, exact
             int e = 127;
             if (pmax > 0.f) {
@@ -530,6 +584,8 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
             const int se = 127 + kk - (e - 127);
             S = (se >= 1 && se <= 254) ? __uint_as_float((unsigned)se << 23) : 0.f;
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __syncthreads();   // (the summaries live in the rings: nobody pushes a candidate before everybody has read them)
     }
 
     const f3 cr = {A.corner[0], A.corner[1], A.corner[2]};
@@ -542,7 +598,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
     VT.S = S;
     VT.rres = refined_rcp(res);
     VT.dummy = (int)(dummy + 2 * lane - reinterpret_cast<uint32_t*>(tile));
-    VT.unit_probs = TILED ? !ctrl[3] : 0;
+    VT.unit_probs = unit_probs;
     VT.lo = ceil_to_float(0.01);
     VT.hx = ceil_to_float((double)gx - 1.01); VT.hy = ceil_to_float((double)gy - 1.01);
     VT.hz = ceil_to_float((double)gz - 1.01);
@@ -677,9 +733,15 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
         // The circle of pair (a, b) has centre cc = a - u*mu, radius |nu| and lies in the plane normal to u, so its
         // extent along axis k is |nu|*sqrt(1 - u_k^2); the test uses approximate arithmetic and a slack far above
         // both its own error and the widening of the rotation screen, so no depositing pair is ever dropped.
-        const int wv = tid >> 6;
+        // Blocks of 64 pairs are handed out through an LDS counter: the work per block varies (culling, trip counts), and
+        // with a fixed interleave the slowest of the 16 waves kept the others waiting at the final barrier for a quarter of
+        // the kernel (s_memtime trace, profiles/r2_vote_phases.txt).  Fixed-point deposits commute, so who takes which
+        // block does not change the result.
         int qn = 0;
-        for (int64_t pb = p_begin + wv * 64;; pb += VOTE_THREADS) {
+        for (;;) {
+            int blk = 0;
+            if (lane == 0) blk = atomicAdd(&ctrl[4], 1);
+            const int64_t pb = p_begin + 64 * (int64_t)__builtin_amdgcn_readfirstlane(blk);
             const bool more = pb < p_end;
             if (more) {
                 const int64_t p = pb + lane;
@@ -724,27 +786,28 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
 
     if (TILED) {
         __syncthreads();
-        const int syz = gy * gz;
-        const int nt = tx * ty * gz;
-        if (S > 0.f) {  // fixed point -> fp32 in place, then the logged wrap-arounds
+        const int nt = tx * ty * gz, nt4 = (nt + 3) >> 2;
+        const int slot = (ptx * pty * gz + 3) & ~3;
+        float4* part4 = reinterpret_cast<float4*>(A.partials + ((int64_t)c * pT + t) * slot);
+        const int nc = min(ctrl[0], VOTE_CARRY_CAP);   // logged 32-bit wrap-arounds (none, normally)
+        if (S > 0.f && nc == 0) {   // fixed point -> fp32 on the way out: one pass, 16 bytes per lane
             const float invS = 1.0f / S;  // exact: S is a power of two
-            uint32_t* tu = reinterpret_cast<uint32_t*>(tile);
-            for (int k = tid; k < nt; k += VOTE_THREADS) tile[k] = (float)tu[k] * invS;
-            __syncthreads();
-            const int nc = min(ctrl[0], VOTE_CARRY_CAP);
-            for (int k = tid; k < nc; k += VOTE_THREADS) atomicAdd(&tile[carry_log[k]], 4294967296.0f * invS);
-            __syncthreads();
-        }
-        float* part = A.partials + (int64_t)c * ((int64_t)gx * syz);
-        if (ty == gy) {  // x slabs: the tile is one contiguous run of the grid
-            float* dst = part + (int64_t)x0 * syz;
-            for (int k = tid; k < nt; k += VOTE_THREADS) dst[k] = tile[k];
-        } else {
-            const int row = ty * gz;
-            for (int k = tid; k < nt; k += VOTE_THREADS) {
-                int lx = k / row, r = k - lx * row;
-                part[(int64_t)(x0 + lx) * syz + y0 * gz + r] = tile[k];
+            const uint4* tu4 = reinterpret_cast<const uint4*>(tile);
+            for (int k = tid; k < nt4; k += VOTE_THREADS) {
+                const uint4 u = tu4[k];
+                part4[k] = make_float4((float)u.x * invS, (float)u.y * invS, (float)u.z * invS, (float)u.w * invS);
             }
+        } else {
+            if (S > 0.f) {  // fixed point -> fp32 in place, then the logged wrap-arounds
+                const float invS = 1.0f / S;
+                uint32_t* tu = reinterpret_cast<uint32_t*>(tile);
+                for (int k = tid; k < nt; k += VOTE_THREADS) tile[k] = (float)tu[k] * invS;
+                __syncthreads();
+                for (int k = tid; k < nc; k += VOTE_THREADS) atomicAdd(&tile[carry_log[k]], 4294967296.0f * invS);
+                __syncthreads();
+            }
+            const float4* t4 = reinterpret_cast<const float4*>(tile);
+            for (int k = tid; k < nt4; k += VOTE_THREADS) part4[k] = t4[k];
         }
     }
 }
@@ -768,37 +831,14 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
 
 #define RED_GROUPS 16
 #define RED_MAX_BLOCKS 256
-// *_dyn launches: the dims record the vote kernel read, plus what it takes to re-derive its plan
-struct RedDyn {
-    const int32_t* shape;  // {n_points, gx, gy, gz} or null
-    int64_t n_ppfs, grid_cap, n_points_cap;
-    int t_max;
-};
-
 __global__ __launch_bounds__(64 * RED_GROUPS) void reduce_argmax_kernel(float* __restrict__ grid,
                                                                         const float* __restrict__ partials, int chunks,
                                                                         int64_t G, unsigned long long* packed,
                                                                         int accumulate, int write_back,
-                                                                        long long* out_idx, float* out_val, RedDyn D)
+                                                                        long long* out_idx, float* out_val)
 {
     __shared__ float part[RED_GROUPS][64];
     const int lane = threadIdx.x & 63, cg = threadIdx.x >> 6;
-    if (D.shape) {
-        const int64_t np = D.shape[0];
-        const int gx = D.shape[1], gy = D.shape[2], gz = D.shape[3];
-        const bool dims_ok = np >= 1 && np <= D.n_points_cap && gx >= 1 && gy >= 1 && gz >= 1 && (int64_t)gx * gy * gz <= D.grid_cap;
-        const VoteTiling vt = dims_ok ? vote_tiling(gx, gy, gz) : VoteTiling{0, 0, 0, 0, 1 << 30};
-        if (!dims_ok || vt.T > D.t_max) {   // the vote kernel did nothing: say so instead of reducing stale partials
-            if (blockIdx.x == 0 && threadIdx.x == 0) {
-                if (out_idx) *out_idx = -1;
-                if (out_val) *out_val = __uint_as_float(0x7fc00000u);
-            }
-            return;
-        }
-        G = (int64_t)gx * gy * gz;
-        int64_t cp;
-        chunks = vote_chunks(D.n_ppfs, vt.T, &cp);
-    }
     const int64_t ngroups = (G + 63) / 64;
     unsigned long long key = 0ull;
     // grid-stride over 64-cell groups: few blocks, so the two same-address atomics per block at the end
@@ -846,6 +886,137 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void reduce_argmax_kernel(float* _
     }
 }
 
+// Tiled vote: grid[cell] (+)= sum over chunks of the tile-major partials (vote_slot_floats), same fixed order as above
+// (chunk c goes to group c % 16; groups added in order), plus the arg-max.  A block = 16 waves = one run of 256 cells of
+// one tile: wave g adds the copies of chunks g, g + 16, ... with 16-byte loads, 8 in flight per lane; 256 threads then
+// add the 16 group sums of their cell, find its place in the grid and write it.  *_dyn launches re-derive the plan the
+// vote kernel used from the dims record.
+struct RedArgs {
+    float* grid;
+    const float* partials;
+    unsigned long long* packed;
+    long long* out_idx;
+    float* out_val;
+    int gx, gy, gz, tx, ty, nty, T, chunks, accumulate, bps;   // bps: blocks per tile of this launch
+    const int32_t* shape;  // {n_points, gx, gy, gz} or null
+    int64_t n_ppfs, grid_cap, n_points_cap;
+    int t_max;
+};
+
+#define RED_CELLS 256
+#define RED_FANIN 8   // groups of the two-level arg-max (power of two)
+__global__ __launch_bounds__(64 * RED_GROUPS) void reduce_tiles_kernel(RedArgs R)
+{
+    __shared__ __attribute__((aligned(16))) float part[RED_GROUPS][RED_CELLS];
+    __shared__ unsigned long long wkey[RED_CELLS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, cg = tid >> 6;
+    int gx = R.gx, gy = R.gy, gz = R.gz, ptx = R.tx, pty = R.ty, pnty = R.nty, T = R.T, chunks = R.chunks;
+    if (R.shape) {
+        const int64_t np = R.shape[0];
+        gx = R.shape[1]; gy = R.shape[2]; gz = R.shape[3];
+        const bool dims_ok = np >= 1 && np <= R.n_points_cap && gx >= 1 && gy >= 1 && gz >= 1 && (int64_t)gx * gy * gz <= R.grid_cap;
+        const VoteTiling vt = dims_ok ? vote_tiling(gx, gy, gz) : VoteTiling{0, 0, 0, 0, 1 << 30};
+        if (!dims_ok || vt.T > R.t_max) {   // the vote kernel did nothing: say so instead of reducing stale partials
+            if (blockIdx.x == 0 && tid == 0) {
+                if (R.out_idx) *R.out_idx = -1;
+                if (R.out_val) *R.out_val = __uint_as_float(0x7fc00000u);
+            }
+            return;
+        }
+        ptx = vt.tx; pty = vt.ty; pnty = vt.nty; T = vt.T;
+        int64_t cp;
+        chunks = vote_chunks(R.n_ppfs, T, &cp);
+    }
+    const int slot = (ptx * pty * gz + 3) & ~3;
+    const int t = blockIdx.x / R.bps, j = blockIdx.x - t * R.bps;
+    if (t >= T) return;
+    const int tix = t / pnty, tiy = t - tix * pnty;
+    const int x0 = tix * ptx, y0 = tiy * pty;
+    const int tx = min(ptx, gx - x0), ty = min(pty, gy - y0);
+    const int nt = tx * ty * gz;
+    if (j * RED_CELLS >= nt) return;
+    const int k0 = j * RED_CELLS + lane * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k0 < nt) {   // (k0 + 3 < slot: both are multiples of 4)
+        const int64_t cstride = (int64_t)T * slot;
+        const float* base = R.partials + (int64_t)t * slot + k0;
+        int c = cg;
+        for (; c + 7 * RED_GROUPS < chunks; c += 8 * RED_GROUPS) {  // 8 independent 16-byte loads in flight per lane
+            float4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4*>(base + (int64_t)(c + k * RED_GROUPS) * cstride);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s.x = s.x + v[k].x; s.y = s.y + v[k].y; s.z = s.z + v[k].z; s.w = s.w + v[k].w; }
+        }
+        for (; c < chunks; c += RED_GROUPS) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)c * cstride);
+            s.x = s.x + v.x; s.y = s.y + v.y; s.z = s.z + v.z; s.w = s.w + v.w;
+        }
+    }
+    *reinterpret_cast<float4*>(&part[cg][lane * 4]) = s;
+    __syncthreads();
+    unsigned long long key = 0ull;
+    const int k = j * RED_CELLS + tid;
+    if (tid < RED_CELLS && k < nt) {
+        const int row = ty * gz;
+        const int lx = k / row, r = k - lx * row;
+        const int64_t cell = (int64_t)(x0 + lx) * ((int64_t)gy * gz) + (int64_t)y0 * gz + r;
+        float v = R.accumulate ? R.grid[cell] : 0.f;
+#pragma unroll
+        for (int g = 0; g < RED_GROUPS; ++g) v = v + part[g][tid];
+        R.grid[cell] = v;
+        key = ((unsigned long long)f2ord(v) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)cell);
+    }
+    if (tid < RED_CELLS) {
+        key = wave_max_u64(key);
+        if (lane == 0) wkey[cg] = key;
+    }
+    // how many blocks report to this block's group, and how many groups are in use: block ids are t * bps + j with bps a
+    // multiple of RED_FANIN, so tile t sends its blocks j = g, g + 8, ... < nb_t to group g (lane t of wave 0 counts tile t)
+    unsigned n_group = 0, n_groups_used = 0;
+    if (cg == 0) {
+        unsigned nb = 0;
+        if (lane < T) {
+            const int ax = lane / pnty, ay = lane - ax * pnty;
+            nb = (unsigned)((min(ptx, gx - ax * ptx) * min(pty, gy - ay * pty) * gz + RED_CELLS - 1) / RED_CELLS);
+        }
+        const unsigned gsel = blockIdx.x & (RED_FANIN - 1);
+        unsigned mine = nb > gsel ? (nb - gsel + RED_FANIN - 1) / RED_FANIN : 0u, most = nb;
+        for (int off = 32; off > 0; off >>= 1) {
+            mine += __shfl_xor(mine, off, 64);
+            const unsigned o = __shfl_xor(most, off, 64);
+            most = o > most ? o : most;
+        }
+        n_group = mine;
+        n_groups_used = most < RED_FANIN ? most : RED_FANIN;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < RED_CELLS / 64; ++w) key = wkey[w] > key ? wkey[w] : key;
+        // Arg-max across blocks, two levels: same-address atomics serialise chip-wide (~12 ns each, and every block
+        // arrives at about the same time), so block b reports to group b % 8 -- {key, ticket} pairs packed[2 + 2g] --
+        // and the last block of a group carries the group's maximum to the root pair packed[0..1].  Every access is a
+        // device-scope atomic whose result is consumed before the next one is issued (data dependence), so no cache
+        // maintenance is needed.
+        auto report = [](unsigned long long* slot, unsigned long long k) -> unsigned {   // returns the ticket drawn
+            const unsigned long long old = atomicMax(slot, k);          // returning: completes before the ticket
+            unsigned d1 = (unsigned)old, d2;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(d2) : "v"(d1));
+            return atomicAdd(reinterpret_cast<unsigned*>(slot + 1), 1u + (d1 ^ d2));   // d1 ^ d2 == 0, depends on `old`
+        };
+        const unsigned g = blockIdx.x & (RED_FANIN - 1);
+        unsigned long long* slot = R.packed + 2 + 2 * g;
+        if (report(slot, key) == n_group - 1) {
+            const unsigned long long gbest = atomicMax(slot, 0ull);
+            if (report(R.packed, gbest) == n_groups_used - 1) {
+                const unsigned long long best = atomicMax(R.packed, 0ull);
+                if (R.out_idx) *R.out_idx = (long long)(0xffffffffu - (uint32_t)(best & 0xffffffffull));
+                if (R.out_val) *R.out_val = ord2f((uint32_t)(best >> 32));
+            }
+        }
+    }
+}
+
 __global__ void zero_u64x2_kernel(unsigned long long* p) { p[0] = 0ull; p[1] = 0ull; }
 
 #define VOTE_LDS_HEAD ((VOTE_THREADS / 64) * VOTE_RING * 2 + VOTE_CARRY_CAP * 4 + (VOTE_THREADS / 64) * VOTE_PAIRQ * 4 + 64 + 512 + VOTE_BELOW_N * 16)
@@ -870,7 +1041,7 @@ static int vote_impl(const float* points, const float* outputs, const float* pro
         pl.tab_entries = tri(n_rots);
         pl.T = many_tiles ? VOTE_MAX_TILES : 3;                       // most tiles this launch geometry serves
         pl.chunks = (many_tiles ? VOTE_WGS_MANY : VOTE_WGS_FEW);      // workgroups launched (>= T * chunks of any plan)
-        pl.part_off = 256;
+        pl.part_off = VOTE_WS_PART;
         pl.total = cppf_vote_workspace_bytes_dyn(many_tiles);
     } else {
         pl = make_vote_plan(n_ppfs, n_rots, gx, gy, gz);
@@ -928,13 +1099,23 @@ static int vote_impl(const float* points, const float* outputs, const float* pro
     }
     CPPF_CHECK_LAUNCH();
 
-    if (pl.tiled || want_argmax) {
+    if (pl.tiled) {
+        RedArgs R;
+        R.grid = grid_obj; R.partials = partials; R.packed = packed;
+        R.out_idx = want_argmax ? out_idx : nullptr; R.out_val = want_argmax ? out_val : nullptr;
+        R.gx = gx; R.gy = gy; R.gz = gz; R.tx = pl.tx; R.ty = pl.ty; R.nty = pl.nty; R.T = pl.T; R.chunks = pl.chunks;
+        R.accumulate = accumulate;
+        R.shape = shape_dev; R.n_ppfs = n_ppfs; R.grid_cap = grid_cap; R.n_points_cap = n_points; R.t_max = pl.T;
+        // blocks per tile: the largest tile's cells (a *_dyn launch cannot know them: a full LDS tile)
+        const int slot = shape_dev ? VOTE_TILE_FLOATS : ((pl.tx * pl.ty * gz + 3) & ~3);
+        R.bps = ((slot + RED_CELLS - 1) / RED_CELLS + RED_FANIN - 1) / RED_FANIN * RED_FANIN;   // a multiple of the arg-max fan-in
+        hipLaunchKernelGGL(reduce_tiles_kernel, dim3((unsigned)(pl.T * R.bps)), dim3(64 * RED_GROUPS), 0, st, R);
+        CPPF_CHECK_LAUNCH();
+    } else if (want_argmax) {
         int64_t nb = (G + 63) / 64;
         if (nb > RED_MAX_BLOCKS) nb = RED_MAX_BLOCKS;
-        RedDyn D{shape_dev, n_ppfs, grid_cap, n_points, pl.T};
-        hipLaunchKernelGGL(reduce_argmax_kernel, dim3((unsigned)nb), dim3(64 * RED_GROUPS), 0, st, grid_obj, partials,
-                           pl.chunks, G, packed, pl.tiled ? accumulate : 1, pl.tiled ? 1 : 0,
-                           want_argmax ? out_idx : nullptr, want_argmax ? out_val : nullptr, D);
+        hipLaunchKernelGGL(reduce_argmax_kernel, dim3((unsigned)nb), dim3(64 * RED_GROUPS), 0, st, grid_obj,
+                           (const float*)nullptr, 0, G, packed, 1, 0, out_idx, out_val);
         CPPF_CHECK_LAUNCH();
     }
     return 0;
@@ -991,7 +1172,7 @@ extern "C" int cppf_grid_argmax(const float* grid, int64_t n, long long* out_idx
     int64_t nb = (n + 63) / 64;
     if (nb > RED_MAX_BLOCKS) nb = RED_MAX_BLOCKS;
     hipLaunchKernelGGL(reduce_argmax_kernel, dim3((unsigned)nb), dim3(64 * RED_GROUPS), 0, st, const_cast<float*>(grid),
-                       (const float*)nullptr, 0, n, packed, 1, 0, out_idx, out_val, RedDyn{nullptr, 0, 0, 0, 0});
+                       (const float*)nullptr, 0, n, packed, 1, 0, out_idx, out_val);
     CPPF_CHECK_LAUNCH();
     return 0;
 }
