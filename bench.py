@@ -40,12 +40,15 @@ PEAK_HBM = 8000.0                # GB/s
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r1_pmc_traffic.json)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
-            return json.load(f)[kernel]["hbm_bytes"]
-    except (OSError, KeyError, ValueError):
-        return None
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r<round>_pmc_traffic.json, newest round)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                return json.load(f)[kernel]["hbm_bytes"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def cpu_baseline(ob, idx, u_tr, u_rot, sd, cfg, corner, dims, N_POINTS, PAIRS_PER_POINT, budget_s=12.0):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""pmcstats.py output -> the per-kernel HBM traffic summary bench.py reads (profiles/r1_pmc_traffic.json)."""
+"""pmcstats.py output -> the per-kernel HBM traffic summary bench.py reads (profiles/r<round>_pmc_traffic.json)."""
 import collections
 import json
 import re
@@ -15,6 +15,7 @@ for line in open(sys.argv[1]):
         kernel = line.strip()
 names = {"point_proj_kernel": "point_proj_kernel", "pair_mlp_kernel<false, true, true>": "pair_mlp_kernel<false, true, true>",
          "vote_kernel<true, true>": "vote_kernel<true, true>", "reduce_argmax_kernel": "reduce_argmax_kernel",
+         "reduce_tiles_kernel": "reduce_tiles_kernel",
          "sprin_conv_kernel": "sprin_conv_kernel", "knn_kernel<false>": "knn_kernel<false>"}
 out = {"_source": "rocprofv3 --pmc <one counter group per pass> -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline "
                   "(MI355X; profiles/collect.sh); per-launch averages; FETCH_SIZE/WRITE_SIZE in KiB as reported; gfx950: "
