@@ -386,6 +386,9 @@ __device__ __forceinline__ void vote_pop(const VoteTile& VT, const PairFrame& F,
 // axes is a superset of the rotations the exact test of the deposit stage accepts -- cheap approximations with explicit
 // slack (1e-4 in the cosine, 2e-3 rad in the angle, far above their error), never a dropped vote.  A pair costs ~300
 // instructions for its masks instead of ~45 per pair of rotations in a loop over all of them.
+#ifndef VOTE_SERIAL_MAX
+#define VOTE_SERIAL_MAX 28   // pairs with a non-empty mask up to which a batch is expanded pair by pair
+#endif
 #define VOTE_BELOW_N 97   // BELOW[j] = bits [0, j) set, j = 0..96, as uint4 (x, y, z = three words)
 
 __device__ __forceinline__ float atan01_approx(float t)   // atan on [0, 1], |error| < 2e-5
@@ -647,36 +650,81 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
             const Mask96 my = axis_arc_mask(below, cq.y, xq.y, yq.y, loy, hiy, nf, n);
             const Mask96 mz = axis_arc_mask(below, cq.z, xq.z, yq.z, loz, hiz, nf, n);
             const uint32_t live = n > 0 ? 0xffffffffu : 0u;
-            uint32_t mw[3] = {mx.a & my.a & mz.a & live, mx.b & my.b & mz.b & live, mx.c & my.c & mz.c & live};
-#pragma unroll
-            for (int w = 0; w < 3; ++w) {
-                uint32_t m = mw[w];
-                while (__any(m != 0u)) {
-                    const bool acc0 = m != 0u;
-                    const int b0 = __builtin_ctz(m | 0x80000000u);
-                    m &= m - 1u;
-                    const bool acc1 = m != 0u;
-                    const int b1 = __builtin_ctz(m | 0x80000000u);
-                    m &= m - 1u;
-                    const unsigned long long m0 = __ballot(acc0), m1 = __ballot(acc1);
-                    const int n0 = __popcll(m0);
-                    if (acc0) {
-                        const int pos = qtail + __builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32),
-                                                                          __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0));
-                        ring[pos & (VOTE_RING - 1)] = (uint16_t)(lane | ((32 * w + b0) << 6));
+            const uint32_t mw0 = mx.a & my.a & mz.a & live, mw1 = mx.b & my.b & mz.b & live, mw2 = mx.c & my.c & mz.c & live;
+            // Expansion of the masks into the candidate ring, two ways (wave-uniform choice per batch of 64 pairs):
+            //  * few pairs with any bit set (three quarters of the lanes are empty on the benchmark's inputs): one PAIR per
+            //    step with the lanes standing for its rotations -- the pair's mask, read into scalar registers, IS the ballot
+            //    of "lane i queues rotation i": no bit extraction, no compare, empty pairs cost nothing;
+            //  * most lanes busy (a trained network: every circle passes near the centre): every lane queues two of its own
+            //    bits per step, word by word, in ballot order.
+            // A loop over the lanes' own bits alone ran max-over-lanes trips of ~30 instructions with an eighth of the lane
+            // slots doing anything on the benchmark's inputs; the pair-serial form alone lost 10 % on dense masks
+            // (profiles/r2_vote_phases.txt).
+            unsigned long long todo = __ballot((mw0 | mw1 | mw2) != 0u);
+            if (__popcll(todo) <= VOTE_SERIAL_MAX) {
+                while (todo) {
+                    const int src = __builtin_ctzll(todo);
+                    todo &= todo - 1ull;
+                    const unsigned long long lo = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mw0, src) |
+                                                  ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mw1, src) << 32);
+                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)mw2, src);
+                    if (lo) {
+                        if (__builtin_amdgcn_inverse_ballot_w64(lo)) {
+                            const int pos = qtail + __builtin_amdgcn_mbcnt_hi((unsigned)(lo >> 32),
+                                                                              __builtin_amdgcn_mbcnt_lo((unsigned)lo, 0));
+                            ring[pos & (VOTE_RING - 1)] = (uint16_t)(src | (lane << 6));
+                        }
+                        qtail += __popcll(lo);
                     }
-                    if (acc1) {
-                        const int pos = qtail + n0 + __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32),
-                                                                               __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0));
-                        ring[pos & (VOTE_RING - 1)] = (uint16_t)(lane | ((32 * w + b1) << 6));
+                    if (hi) {
+                        if (__builtin_amdgcn_inverse_ballot_w64((unsigned long long)hi)) {
+                            const int pos = qtail + __builtin_amdgcn_mbcnt_lo(hi, 0);
+                            ring[pos & (VOTE_RING - 1)] = (uint16_t)(src | ((64 + lane) << 6));
+                        }
+                        qtail += __popc(hi);
                     }
-                    qtail += n0 + __popcll(m1);
-                    while (qtail - qhead >= 64) {  // at most two pops: <= 63 queued + <= 128 pushed
+                    while (qtail - qhead >= 64) {  // at most two pops: <= 63 queued + <= 72 pushed
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         vote_pop<TILED, TAB_LDS>(VT, F, cr, ltab, ring, qhead, lane, 64);
                         qhead += 64;
                     }
                 }
+            } else {
+                uint32_t mw[3] = {mw0, mw1, mw2};
+#pragma unroll
+                for (int w = 0; w < 3; ++w) {
+                    uint32_t m = mw[w];
+                    while (__any(m != 0u)) {
+                        const bool acc0 = m != 0u;
+                        const int b0 = __builtin_ctz(m | 0x80000000u);
+                        m &= m - 1u;
+                        const bool acc1 = m != 0u;
+                        const int b1 = __builtin_ctz(m | 0x80000000u);
+                        m &= m - 1u;
+                        const unsigned long long q0 = __ballot(acc0), q1 = __ballot(acc1);
+                        const int n0 = __popcll(q0);
+                        if (acc0) {
+                            const int pos = qtail + __builtin_amdgcn_mbcnt_hi((unsigned)(q0 >> 32),
+                                                                              __builtin_amdgcn_mbcnt_lo((unsigned)q0, 0));
+                            ring[pos & (VOTE_RING - 1)] = (uint16_t)(lane | ((32 * w + b0) << 6));
+                        }
+                        if (acc1) {
+                            const int pos = qtail + n0 + __builtin_amdgcn_mbcnt_hi((unsigned)(q1 >> 32),
+                                                                                   __builtin_amdgcn_mbcnt_lo((unsigned)q1, 0));
+                            ring[pos & (VOTE_RING - 1)] = (uint16_t)(lane | ((32 * w + b1) << 6));
+                        }
+                        qtail += n0 + __popcll(q1);
+                        while (qtail - qhead >= 64) {  // at most two pops: <= 63 queued + <= 128 pushed
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            vote_pop<TILED, TAB_LDS>(VT, F, cr, ltab, ring, qhead, lane, 64);
+                            qhead += 64;
+                        }
+                    }
+                }
+            }
+            if (qtail != qhead) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                vote_pop<TILED, TAB_LDS>(VT, F, cr, ltab, ring, qhead, lane, qtail - qhead);
             }
         } else {
         // more than 72 rotations: the rotation loop.  Two rotations per trip: half the loop/scalar overhead and two
@@ -716,10 +764,10 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
                 qhead += 64;
             }
         }
-        }
         if (qtail != qhead) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             vote_pop<TILED, TAB_LDS>(VT, F, cr, ltab, ring, qhead, lane, qtail - qhead);
+        }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     };
