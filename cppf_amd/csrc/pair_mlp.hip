@@ -254,15 +254,33 @@ struct MlpArgs {
     float vr0, vr1;
 };
 
+// Addresses inside the tile loop are a uniform base (SGPR pair) + an unsigned 32-bit byte offset (one VGPR): the
+// `global_load v, v_off, s[base]` form.  64-bit pointer arithmetic per lane (v_lshl_add_u64, v_lshlrev_b64 ...) was ~50 VALU
+// per tile on the pipe the fp32 MFMAs share.  Hence the limits of the MFMA path: N < 2^23 points, P < 2^27 pairs (launch_std).
+template <typename T>
+__device__ __forceinline__ const T& at_off(const void* base, unsigned byte_off)
+{
+    return *reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_off);
+}
+template <typename T>
+__device__ __forceinline__ T& at_off(void* base, unsigned byte_off)
+{
+    return *reinterpret_cast<T*>(static_cast<char*>(base) + byte_off);
+}
+__device__ __forceinline__ f3 ld3o(const float* __restrict__ base, int i)
+{
+    const unsigned o = (unsigned)i * 12u;
+    return {at_off<float>(base, o), at_off<float>(base, o + 4u), at_off<float>(base, o + 8u)};
+}
+
 __device__ __forceinline__ void load_pair_idx(const MlpArgs& A, int64_t pair, int& ia, int& ib)
 {
     // two 4-byte loads of the low words whatever the index width: an i32 / i64 branch around the loads ends in a
     // wait for ALL outstanding loads (the gathers of the next tile that are in flight at this point)
-    const int64_t p = pair < A.P ? pair : A.P - 1;
-    const int str = A.idx64 ? 4 : 2;
-    const int* q = reinterpret_cast<const int*>(A.idxs) + p * str;
-    ia = q[0];
-    ib = q[str >> 1];
+    const unsigned p = (unsigned)(pair < A.P ? pair : A.P - 1);
+    const unsigned o = p * (A.idx64 ? 16u : 8u);
+    ia = at_off<int>(A.idxs, o);
+    ib = at_off<int>(A.idxs, o + (A.idx64 ? 8u : 4u));
 }
 
 // PPF of one pair from already loaded points/normals (models/model.py:118-129); component `g`.
@@ -271,7 +289,9 @@ __device__ __forceinline__ float ppf_from(f3 pa, f3 pb, f3 na, f3 nb, int g)
     const f3 xy = sub3(pa, pb);
     const float d = sqrtf((xy.x * xy.x + xy.y * xy.y) + xy.z * xy.z);
     const float den = d + 1e-7f;                       // fp32 add (torch), unlike the vote kernels
-    const f3 u = {xy.x / den, xy.y / den, xy.z / den};
+    // three IEEE divisions by one denominator (den in [1e-7, ~2], |xy| <= d: no rescaling or fix-up would apply): div_by()
+    const float rden = refined_rcp(den);
+    const f3 u = {div_by(xy.x, den, rden), div_by(xy.y, den, rden), div_by(xy.z, den, rden)};
     const float p0 = (na.x * u.x + na.y * u.y) + na.z * u.z;
     const float p1 = (nb.x * u.x + nb.y * u.y) + nb.z * u.z;
     const float p2 = (na.x * nb.x + na.y * nb.y) + na.z * nb.z;
@@ -353,11 +373,10 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
         for (int pb = 0; pb < PB; ++pb) load_pair_idx(A, wave_gid * (16 * PB) + pb * 16 + j, ia[pb], ib[pb]);
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
-            const f32x4* pa = reinterpret_cast<const f32x4*>(A.table + (int64_t)ia[pb] * PROJ_COLS + 4 * g);
-            const f32x4* pbp = reinterpret_cast<const f32x4*>(A.table + (int64_t)ib[pb] * PROJ_COLS + 64 + 4 * g);
+            const unsigned oa = (unsigned)ia[pb] * (PROJ_COLS * 4u) + 16u * g, ob_ = (unsigned)ib[pb] * (PROJ_COLS * 4u) + 256u + 16u * g;
 #pragma unroll
-            for (int ob = 0; ob < 4; ++ob) { ta[pb][ob] = pa[4 * ob]; tb[pb][ob] = pbp[4 * ob]; }
-            xp[pb] = ppf_from(ld3(A.pc, ia[pb]), ld3(A.pc, ib[pb]), ld3(A.nrm, ia[pb]), ld3(A.nrm, ib[pb]), g);
+            for (int ob = 0; ob < 4; ++ob) { ta[pb][ob] = at_off<f32x4>(A.table, oa + 64u * ob); tb[pb][ob] = at_off<f32x4>(A.table, ob_ + 64u * ob); }
+            xp[pb] = ppf_from(ld3o(A.pc, ia[pb]), ld3o(A.pc, ib[pb]), ld3o(A.nrm, ia[pb]), ld3o(A.nrm, ib[pb]), g);
         }
         const int64_t nt = wave_gid + wave_cnt < n_tiles ? wave_gid + wave_cnt : wave_gid;
 #pragma unroll
@@ -381,16 +400,16 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
         f3 npa[PB], npb[PB], nna[PB], nnb[PB];
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
-            npa[pb] = ld3(A.pc, ia1[pb]); npb[pb] = ld3(A.pc, ib1[pb]);
-            nna[pb] = ld3(A.nrm, ia1[pb]); nnb[pb] = ld3(A.nrm, ib1[pb]);
+            npa[pb] = ld3o(A.pc, ia1[pb]); npb[pb] = ld3o(A.pc, ib1[pb]);
+            nna[pb] = ld3o(A.nrm, ia1[pb]); nnb[pb] = ld3o(A.nrm, ib1[pb]);
         }
         f32x2 ut[PB], ur[PB];
         if (DECODE) {
 #pragma unroll
             for (int pb = 0; pb < PB; ++pb) {
-                const int64_t pc_ = pair[pb] < A.P ? pair[pb] : A.P - 1;
-                ut[pb] = reinterpret_cast<const f32x2*>(A.u_tr)[pc_];
-                if (HEADS) ur[pb] = reinterpret_cast<const f32x2*>(A.u_rot)[pc_];
+                const unsigned po = (unsigned)(pair[pb] < A.P ? pair[pb] : A.P - 1) * 8u;
+                ut[pb] = at_off<f32x2>(A.u_tr, po);
+                if (HEADS) ur[pb] = at_off<f32x2>(A.u_rot, po);
             }
         }
 
@@ -456,10 +475,9 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
             xp[pb] = ppf_from(npa[pb], npb[pb], nna[pb], nnb[pb], g);
-            const f32x4* pa = reinterpret_cast<const f32x4*>(A.table + (int64_t)ia1[pb] * PROJ_COLS + 4 * g);
-            const f32x4* pbp = reinterpret_cast<const f32x4*>(A.table + (int64_t)ib1[pb] * PROJ_COLS + 64 + 4 * g);
+            const unsigned oa = (unsigned)ia1[pb] * (PROJ_COLS * 4u) + 16u * g, ob_ = (unsigned)ib1[pb] * (PROJ_COLS * 4u) + 256u + 16u * g;
 #pragma unroll
-            for (int ob = 0; ob < 4; ++ob) { ta[pb][ob] = pa[4 * ob]; tb[pb][ob] = pbp[4 * ob]; }
+            for (int ob = 0; ob < 4; ++ob) { ta[pb][ob] = at_off<f32x4>(A.table, oa + 64u * ob); tb[pb][ob] = at_off<f32x4>(A.table, ob_ + 64u * ob); }
         }
         {
             int64_t nt = tile + 2 * wave_cnt;
@@ -554,25 +572,25 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
                 // nocs/inference.py:187-188 (fp32, left to right); the owning lane stores its value
                 {
                     const float v[8] = {L[0][0], L[0][1], L[0][2], L[0][3], L[1][0], L[1][1], L[1][2], L[1][3]};
-                    if (sample_seg<8>(v, ut[pb][0], g, lane, k) && live) A.outputs[2 * pair[pb]] = lut[k];
+                    if (sample_seg<8>(v, ut[pb][0], g, lane, k) && live) at_off<float>(A.outputs, (unsigned)pair[pb] * 8u) = lut[k];
                 }
                 {
                     const float v[8] = {L[2][0], L[2][1], L[2][2], L[2][3], L[3][0], L[3][1], L[3][2], L[3][3]};
-                    if (sample_seg<8>(v, ut[pb][1], g, lane, k) && live) A.outputs[2 * pair[pb] + 1] = lut[32 + k];
+                    if (sample_seg<8>(v, ut[pb][1], g, lane, k) && live) at_off<float>(A.outputs, (unsigned)pair[pb] * 8u + 4u) = lut[32 + k];
                 }
                 if (HEADS) {
-                    float* h = A.heads + pair[pb] * 8;
+                    const unsigned ho = (unsigned)pair[pb] * 32u;
                     {
                         const float v[9] = {L[4][0], L[4][1], L[4][2], L[4][3], L[5][0], L[5][1], L[5][2], L[5][3], L[8][0]};
-                        if (sample_seg<9>(v, ur[pb][0], g, lane, k) && live) h[0] = lut[64 + k];
+                        if (sample_seg<9>(v, ur[pb][0], g, lane, k) && live) at_off<float>(A.heads, ho) = lut[64 + k];
                     }
                     {
                         const float v[9] = {L[6][0], L[6][1], L[6][2], L[6][3], L[7][0], L[7][1], L[7][2], L[7][3], L[8][1]};
-                        if (sample_seg<9>(v, ur[pb][1], g, lane, k) && live) h[1] = lut[64 + k];
+                        if (sample_seg<9>(v, ur[pb][1], g, lane, k) && live) at_off<float>(A.heads, ho + 4u) = lut[64 + k];
                     }
                     // block 8, registers 2..3: aux_up aux_right | sx sy | sz - (dec_col)
-                    if (live && g < 2) { f32x2 w; w[0] = L[8][2]; w[1] = L[8][3]; reinterpret_cast<f32x2*>(h)[1 + g] = w; }
-                    if (live && g == 2) { f32x2 w; w[0] = L[8][2]; w[1] = 0.f; reinterpret_cast<f32x2*>(h)[3] = w; }
+                    if (live && g < 2) { f32x2 w; w[0] = L[8][2]; w[1] = L[8][3]; at_off<f32x2>(A.heads, ho + 8u + 8u * g) = w; }
+                    if (live && g == 2) { f32x2 w; w[0] = L[8][2]; w[1] = 0.f; at_off<f32x2>(A.heads, ho + 24u) = w; }
                 }
             }
         }
@@ -741,6 +759,7 @@ template <bool LOGITS, bool DECODE, bool HEADS>
 static int launch_std(MlpArgs& A, int64_t N, void* workspace, size_t workspace_bytes, hipStream_t st)
 {
     if (N < 1) return CPPF_EINVAL;
+    if (N >= (1ll << 23) || A.P >= (1ll << 27)) return CPPF_EUNSUPPORTED;   // 32-bit byte offsets inside the kernel
     if (!workspace || workspace_bytes < (size_t)N * PROJ_COLS * sizeof(float)) return CPPF_EWORKSPACE;
     float* table = static_cast<float*>(workspace);
     hipLaunchKernelGGL(point_proj_kernel, dim3((unsigned)((N + 1) / 2)), dim3(256), 0, st, A.feat, A.packed, table, N);

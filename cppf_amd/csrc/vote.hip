@@ -101,7 +101,12 @@ __host__ __device__ inline int vote_fixed_bits_of(int64_t chunk_pairs, int n_rot
 // outside the caller's workspace.  [VOTE_WS_PART, ...) the partial grids.
 #define VOTE_WS_TAB 256
 #define VOTE_WS_PART (256 + ((VOTE_TAB_LDS_MAX + 2) * 8 + 255) / 256 * 256)
-#define VOTE_TAB_STAMP 0x43505046726f7400ull   // "CPPFrot\0" ^ n_rots
+#define VOTE_TAB_STAMP 0x43505046726f7400ull   // "CPPFrot\0" ^ n_rots: table valid
+// The launch that builds the table must not be able to read it back: workgroups of that same launch that start late
+// (more workgroups than the chip holds at once) would see workgroup 0's stamp without any guarantee of seeing its table
+// (no release/acquire between workgroups of one kernel).  So the vote kernel leaves a PENDING stamp and the reduce kernel
+// that follows it -- a kernel boundary later -- turns it into the valid one.
+#define VOTE_TAB_PENDING 0x43505046726f5000ull
 
 struct VotePlan {
     int tiled;            // 1: LDS tiles + partial grids, 0: global atomics
@@ -223,27 +228,6 @@ struct VoteTile {
     int unit_probs;  // every prob is exactly 1.0f (all the reference's callers, nocs/inference.py:201): w * 1.0f == w
     float lo, hx, hy, hz;  // fp32 thresholds equivalent to the reference's fp64 tests
 };
-
-// a / b for a loop-invariant b: the compiler's IEEE-exact fp32 division (v_div_scale, v_rcp, two Newton steps on the
-// reciprocal, q0, residual, q1, residual, v_div_fmas, v_div_fixup) minus the parts that only act outside the normal
-// range -- the reciprocal refinement is hoisted (refined_rcp), operands are never rescaled (|a| <= a few metres over
-// res ~ 1e-3..1e-1: no scaling would be applied) and inf/NaN/0 fix-ups are not needed because such coordinates fail
-// the bound tests either way.  Same result bit for bit on that range (checked exhaustively on the device against `/`:
-// profiles/r2_div_check.txt); 5 instructions per division instead of 9.
-__device__ __forceinline__ float refined_rcp(float b)
-{
-    const float y0 = __builtin_amdgcn_rcpf(b);
-    const float e = fmaf(-b, y0, 1.0f);
-    return fmaf(e, y0, y0);
-}
-__device__ __forceinline__ float div_by(float a, float b, float y)
-{
-    const float q0 = a * y;
-    const float r0 = fmaf(-b, q0, a);
-    const float q1 = fmaf(r0, y, q0);
-    const float r1 = fmaf(-b, q1, a);
-    return fmaf(r1, y, q1);
-}
 
 // floor(x + 0.5) evaluated exactly, one instruction (x in [0, 2^24]: checked exhaustively, profiles/r2_div_check.txt); the
 // fixed-point deposit's rounding (ties go up; any nearest rounding keeps the half-quantum error bound)
@@ -553,7 +537,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
             if (blockIdx.x == 0) {   // leave a copy for the next launch (visible to it: kernel boundary)
                 __syncthreads();
                 for (int e = tid; e < A.tab_entries; e += VOTE_THREADS) wtab[e] = ltab[e];
-                if (tid == 0) A.packed[31] = VOTE_TAB_STAMP ^ (unsigned long long)A.n_rots;
+                if (tid == 0) A.packed[31] = VOTE_TAB_PENDING ^ (unsigned long long)A.n_rots;
             }
         }
         if (tid < 2) ltab[A.tab_entries + tid] = make_float2(0.f, 0.f);  // spare entries
@@ -958,6 +942,10 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void reduce_tiles_kernel(RedArgs R
     __shared__ __attribute__((aligned(16))) float part[RED_GROUPS][RED_CELLS];
     __shared__ unsigned long long wkey[RED_CELLS / 64];
     const int tid = threadIdx.x, lane = tid & 63, cg = tid >> 6;
+    if (blockIdx.x == 0 && tid == 0) {   // rotation table left by the vote kernel of this call: valid from the next launch on
+        const unsigned long long st = R.packed[31];
+        if ((st & ~0xfffull) == VOTE_TAB_PENDING) R.packed[31] = st ^ (VOTE_TAB_PENDING ^ VOTE_TAB_STAMP);
+    }
     int gx = R.gx, gy = R.gy, gz = R.gz, ptx = R.tx, pty = R.ty, pnty = R.nty, T = R.T, chunks = R.chunks;
     if (R.shape) {
         const int64_t np = R.shape[0];

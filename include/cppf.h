@@ -180,7 +180,9 @@ int cppf_rot_sphere_count(const float* points, const float* preds_rot, int rot_s
  * Supported on the MFMA path: dims = {2F+4, 32, 32, 16} with F = 40 and out_dim <= 144 (the only
  * architecture the reference trains, train.py:35); any other ResLayer stack runs on the generic
  * kernel (one pair per lane, at most 128 units per layer).  The MFMA path first projects every point
- * through the feat columns of layer 0 (N*128 floats in `workspace`), see csrc/pair_mlp.hip.
+ * through the feat columns of layer 0 (N*128 floats in `workspace`), see csrc/pair_mlp.hip; it addresses with
+ * 32-bit byte offsets and serves N < 2^23 points and P < 2^27 pairs per call (CPPF_EUNSUPPORTED beyond:
+ * split the pair list).
  * ------------------------------------------------------------------------------------------- */
 size_t cppf_pair_mlp_packed_floats(int F, const int* dims, int n_res, int out_dim);
 /* device scratch for one call: the per-point layer-0 projection table of the MFMA path (N*128 floats),

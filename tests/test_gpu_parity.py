@@ -233,6 +233,34 @@ def test_vote_tiling_paths(oracle, dev):
     assert flat == oracle.grid_argmax(go)[0]
 
 
+def test_vote_rotation_table_cached_in_workspace(oracle, dev):
+    """The (cos, sin) table is built by the first launch on a workspace and read back by later ones (csrc/vote.hip,
+    VOTE_TAB_STAMP): a fresh workspace, repeated launches and a change of n_rots all give the same, correct grid.  (The
+    launch that builds the table leaves a PENDING stamp that only the following reduce kernel validates: late workgroups
+    of a 2 000-workgroup launch once read the table their own launch was still writing -- an intermittent failure of
+    test_randomised_soak in round 2; this case has that geometry.)"""
+    from cppf_amd import _torch_util
+    ob = syn.make_object("bottle", 2048, 31)
+    cfg = ob["cfg"]
+    res = cfg.res * 0.45                                     # ~20 tiles -> 2 000+ workgroups
+    idx = syn.make_pairs(2048, 48, 31).astype(np.int32)
+    out = syn.closed_form_outputs(ob["pc"], ob["center"], idx, cfg, quantise=True)
+    from cppf_amd.inference import grid_shape
+    corners, dims = grid_shape(ob["pc"], res)
+    assert _lib.lib().cppf_vote_tiles(*dims) >= 8
+    rng = np.random.default_rng(3)
+    probs = rng.uniform(0.4, 2.0, 2048).astype(np.float32)
+    grids = {}
+    for rep, n_rots in enumerate((72, 72, 72, 40, 72, 72)):
+        if rep in (0, 3):
+            _torch_util._ws_cache.clear()                    # a fresh (uninitialised) workspace: no stamp
+        gg, flat, peak = run_vote(dev, ob["pc"], out, idx, corners[0], dims, res, n_rots, True, probs)
+        check_grid(oracle, gg, ob["pc"], out, idx, corners[0], dims, res, n_rots, True, probs)
+        if n_rots in grids:
+            assert np.array_equal(gg, grids[n_rots]), rep
+        grids[n_rots] = gg
+
+
 def test_vote_edge_cases(oracle, dev):
     pc = np.array([[0, 0, 0], [0.1, 0, 0], [0, 0.1, 0], [0, 0, 0.1]], np.float32)
     corner = np.array([-0.2, -0.2, -0.2], np.float32)
