@@ -287,3 +287,54 @@ def test_nocs_result_record_format():
     assert res["pred_RTs"][0][3].tolist() == [0, 0, 0, 1]
     np.testing.assert_allclose(np.linalg.norm(res["pred_scales"][0]), 1.0, atol=1e-6)
     assert np.array_equal(res["pred_RTs"][1], np.eye(4, dtype=np.float32)) and res["pred_scales"][1].tolist() == [1, 1, 1]
+
+
+def test_shape_polymorphic_plan_queries_without_a_device():
+    """The *_dyn launch geometry is derived on the host from these queries (cppf_amd/inference.py:grid_class)."""
+    from cppf_amd import _lib
+    from cppf_amd.inference import grid_class
+    L = _lib.lib()
+    cells = L.cppf_vote_tile_cells()
+    assert cells % 4 == 0 and 20000 < cells < 40960                      # one LDS tile of a 160 KB CU
+    assert L.cppf_vote_tiles(26, 76, 26) == 2                            # the bottle grid of BASELINE config 2
+    assert L.cppf_vote_tiles(10, 10, 10) == 1
+    assert L.cppf_vote_tiles(0, 10, 10) < 0
+    assert L.cppf_vote_tiles(600, 600, 600) == 0                         # beyond the tiled vote: global atomics only
+    for dims in ((26, 76, 26), (52, 152, 52), (100, 49, 76), (5, 5, cells)):
+        T, many, cap = grid_class(dims)
+        assert T * cells >= dims[0] * dims[1] * dims[2] and many == (T >= 4) and cap == (64 if many else 3) * cells
+    # the dyn workspace holds the partial tiles of ANY plan its launch geometry can meet
+    few, many = L.cppf_vote_workspace_bytes_dyn(0), L.cppf_vote_workspace_bytes_dyn(1)
+    assert few >= L.cppf_vote_workspace_bytes(524288, 72, 26, 76, 26) and many >= L.cppf_vote_workspace_bytes(2 ** 21, 72, 52, 152, 52)
+    # entry points reject a missing shape record before any HIP call
+    assert L.cppf_vote_argmax_dyn(None, None, None, None, 0, None, 100, None, 0.004, 4, 10, 72, None, 0, 1, 0, None, None,
+                                  None, 0, None) == -1
+    assert L.cppf_backvote_dyn(None, None, None, None, None, 0.004, 10, 72, None, None, 0.01, None, None) == -1
+    assert L.cppf_knn_dyn(None, 64, None, 60, None, None) == -1
+
+
+def test_weight_image_invalidation_keys():
+    """the device weight images are keyed on (data_ptr, _version) of every parameter; `.data` edits bypass
+    the version counter and need invalidate(); .to()/.float() re-key through _apply; replaced Parameters are picked up
+    after invalidate()."""
+    import torch
+    from cppf_amd.models.model import PPFEncoder, PointEncoder
+    for enc in (PPFEncoder([84, 32, 32, 16], 141), PointEncoder(60, [32, 64, 32, 32], 32, 1)):
+        p0 = next(enc.parameters())
+        k0 = enc._param_key("cpu")
+        with torch.no_grad():
+            p0.add_(1.0)                                  # what an optimizer step / load_state_dict does
+        k1 = enc._param_key("cpu")
+        assert k1 != k0
+        p0.data.mul_(2.0)                                 # invisible to the version counter ...
+        assert enc._param_key("cpu") == k1
+        enc.invalidate()                                  # ... until told
+        k2 = enc._param_key("cpu")
+        assert k2 != k1
+        enc.double().float()                              # _apply: parameters re-created / re-typed
+        assert enc._param_key("cpu") != k2
+        n_before = len(enc._param_key("cpu"))
+        first = [m for m in enc.modules() if isinstance(m, torch.nn.Linear)][0]
+        first.bias = torch.nn.Parameter(torch.zeros_like(first.bias))     # a replaced Parameter object
+        enc.invalidate()
+        assert len(enc._param_key("cpu")) == n_before and any(p is first.bias for p in enc.parameters())
