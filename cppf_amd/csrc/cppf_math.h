@@ -55,41 +55,45 @@ __device__ __forceinline__ f3 ld3(const float* __restrict__ p, int i)
 }
 
 // exp(x) for x <= 0 (softmax after the max subtraction; callers guarantee -3e38 < x <= 0):
-// 2^(x*log2e) = 2^n * p(f), n = rint(y), f = y - n in [-0.5, 0.5] (exact), p = degree-4 minimax of 2^f.
-// Max relative error 7e-6 (2.7e-6 from the core, the rest from rounding x*log2e) -- far below what an inverse-CDF draw can resolve -- at 10 VALU instead of
-// 18: on gfx950 fp32 MFMA and VALU share one datapath, so every decode instruction is paid in full.
+// 2^(x*log2e) = 2^n * p(f), n = rint(x*log2e), f = x*log2e - n in [-0.5, 0.5], p = degree-4 minimax of 2^f.
+// n comes from the float's own rounding: t = fma(x, log2e, 1.5*2^23) has unit spacing, so t - 1.5*2^23 = n exactly and
+// the low bits of t's pattern hold n in two's complement -- (bits(t) << 23) IS n << 23, no rint, no float->int conversion;
+// f = fma(x, log2e, -n) is rounded once.  Max relative error 3e-6 -- far below what an inverse-CDF draw can resolve -- at
+// 8 VALU (5.5 per value on the packed pipe): on gfx950 fp32 MFMA and VALU share one datapath, so every decode
+// instruction is paid in full.  oracle/cppf_oracle.c:orc_expf is the same sequence.
+#define CPPF_EXP_MAGIC 12582912.0f   // 1.5 * 2^23
 __device__ __forceinline__ float det_expf(float x)
 {
     x = fmaxf(x, -86.0f);  // keeps 2^n a normal number for the exponent arithmetic below
-    const float y = x * 1.44269504088896341f;
-    const float n = rintf(y);
-    const float f = y - n;
+    const float t = fmaf(x, 1.44269504088896341f, CPPF_EXP_MAGIC);
+    const float n = t - CPPF_EXP_MAGIC;
+    const float f = fmaf(x, 1.44269504088896341f, -n);
     float p = 9.570102207e-03f;
     p = fmaf(p, f, 5.591785908e-02f);
     p = fmaf(p, f, 2.402474433e-01f);
     p = fmaf(p, f, 6.931217909e-01f);
     p = fmaf(p, f, 9.999992847e-01f);
-    return __int_as_float(__float_as_int(p) + ((int)n << 23));  // (v_ldexp_f32 measured slower here)
+    return __uint_as_float(__float_as_uint(p) + (__float_as_uint(t) << 23));
 }
 
-// Two det_expf at once on the packed-fp32 pipe (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 are IEEE per
-// component, so each half is bit-identical to det_expf).
+// Two det_expf at once on the packed-fp32 pipe (v_pk_add_f32 / v_pk_fma_f32 are IEEE per component, so each half is
+// bit-identical to det_expf).
 typedef float cppf_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ cppf_f32x2 det_expf2(cppf_f32x2 x)
 {
     x[0] = fmaxf(x[0], -86.0f); x[1] = fmaxf(x[1], -86.0f);
-    const cppf_f32x2 y = x * 1.44269504088896341f;
-    cppf_f32x2 n;
-    n[0] = rintf(y[0]); n[1] = rintf(y[1]);
-    const cppf_f32x2 f = y - n;
+    const cppf_f32x2 L = {1.44269504088896341f, 1.44269504088896341f}, M = {CPPF_EXP_MAGIC, CPPF_EXP_MAGIC};
+    const cppf_f32x2 t = __builtin_elementwise_fma(x, L, M);
+    const cppf_f32x2 n = t - M;
+    const cppf_f32x2 f = __builtin_elementwise_fma(x, L, -n);
     cppf_f32x2 p = {9.570102207e-03f, 9.570102207e-03f};
     p = __builtin_elementwise_fma(p, f, cppf_f32x2{5.591785908e-02f, 5.591785908e-02f});
     p = __builtin_elementwise_fma(p, f, cppf_f32x2{2.402474433e-01f, 2.402474433e-01f});
     p = __builtin_elementwise_fma(p, f, cppf_f32x2{6.931217909e-01f, 6.931217909e-01f});
     p = __builtin_elementwise_fma(p, f, cppf_f32x2{9.999992847e-01f, 9.999992847e-01f});
     cppf_f32x2 r;
-    r[0] = __int_as_float(__float_as_int(p[0]) + ((int)n[0] << 23));
-    r[1] = __int_as_float(__float_as_int(p[1]) + ((int)n[1] << 23));
+    r[0] = __uint_as_float(__float_as_uint(p[0]) + (__float_as_uint(t[0]) << 23));
+    r[1] = __uint_as_float(__float_as_uint(p[1]) + (__float_as_uint(t[1]) << 23));
     return r;
 }
 

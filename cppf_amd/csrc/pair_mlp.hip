@@ -136,7 +136,7 @@ extern "C" int cppf_pair_mlp_pack_device(const float* params, const int64_t* off
 }
 
 // ----------------------------------------------------------------------------- MFMA kernel
-#define MLP_THREADS 512
+#define MLP_THREADS 1024
 #define MLP_WAVES_PER_SIMD 4
 #define PB 1  // 16-pair blocks per wave tile
 
@@ -197,24 +197,25 @@ __device__ __forceinline__ bool sample_seg(const float (&v)[NL], float u, int g,
     for (int k = 1; k < NL; ++k) m = fmaxf(m, v[k]);
     float mall = fmaxf(m, xor16f(m, lane));
     mall = fmaxf(mall, xor32f(mall, lane));
-    float e[NL], T = 0.f;
+    float e[NL];
 #pragma unroll
     for (int k = 0; k + 1 < NL; k += 2) {   // two exponentials per packed-fp32 instruction
         const cppf_f32x2 ex = det_expf2(cppf_f32x2{v[k] - mall, v[k + 1] - mall});
         e[k] = ex[0]; e[k + 1] = ex[1];
     }
     if (NL & 1) e[NL - 1] = det_expf(v[NL - 1] - mall);
+    // running sums of the lane's segment: the last one is the segment total, and the draw compares them with the
+    // threshold moved into the segment (t - off) -- one chain of NL - 1 additions serves both
+    float b[NL];
+    b[0] = e[0];
 #pragma unroll
-    for (int k = 0; k < NL; ++k) T = T + e[k];
+    for (int k = 1; k < NL; ++k) b[k] = b[k - 1] + e[k];
+    const float T = b[NL - 1];
     const float Tp = xor16f(T, lane);           // the other lane of my half
     const float half = T + Tp;                  // T0 + T1 in lanes g = 0,1; T2 + T3 in lanes g = 2,3 (a+b == b+a)
     const float oth = xor32f(half, lane);
-    const float t = u * ((g & 2) ? oth + half : half + oth);   // (T0 + T1) + (T2 + T3) in every lane
     const float off = ((g & 2) ? oth : 0.f) + ((g & 1) ? Tp : 0.f);
-    float b[NL];
-    b[0] = off + e[0];
-#pragma unroll
-    for (int k = 1; k < NL; ++k) b[k] = b[k - 1] + e[k];
+    const float t = u * ((g & 2) ? oth + half : half + oth) - off;   // u * ((T0 + T1) + (T2 + T3)) - off_g
     const bool hit = b[NL - 1] > t;
     int kk = NL - 1;
 #pragma unroll
@@ -338,6 +339,8 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
     // bin -> value tables (nocs/inference.py:187-188,252,256; fp32, left to right, true division): a
     // correctly rounded divide is ~12 VALU, a table read is one LDS access
     float* lut = W + STD_LDS;  // [0,32) mu, [32,64) nu, [64,100) theta
+    int* tile_ctr = reinterpret_cast<int*>(W + STD_LDS + 112);   // next tile of this workgroup's range, see below
+    if (threadIdx.x == 0) *tile_ctr = 0;
     if (DECODE && threadIdx.x < 100) {
         const int k = threadIdx.x;
         float v;
@@ -352,11 +355,24 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
     const int j = lane & 15, g = lane >> 4;
     __builtin_assume(g >= 0 && g < 4);
     const int64_t n_tiles = (A.P + 16 * PB - 1) / (16 * PB);
-    const int64_t wave_gid = (int64_t)blockIdx.x * (MLP_THREADS / 64) + wave;
-    const int64_t wave_cnt = (int64_t)gridDim.x * (MLP_THREADS / 64);
-    if (wave_gid >= n_tiles) return;
+    // Tiles are handed out per workgroup through an LDS counter.  With a fixed share (8 tiles per wave at the benchmark's
+    // size) the waves of a SIMD -- arbitrated oldest first -- ran the same work in 119k ... 211k cycles and the kernel
+    // waited for the slowest with a fifth of its issue slots idle (s_memtime trace, profiles/r2_pair_mlp_phases.txt).
+    // A workgroup owns a contiguous range of tiles; a wave claims tile t+2 (whose pair indices it prefetches) while
+    // tile t runs, so the claim's latency is never waited for.
+    const int64_t per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
+    const int64_t wg_begin = (int64_t)blockIdx.x * per_wg;
+    const int64_t wg_end = wg_begin + per_wg < n_tiles ? wg_begin + per_wg : n_tiles;
+    auto claim = [&]() -> int64_t {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(tile_ctr, 1);
+        return wg_begin + __builtin_amdgcn_readfirstlane(v);
+    };
+    int64_t cur = claim();
+    if (cur >= wg_end) return;
+    int64_t nxt = claim();
 
-    // Software pipeline over this wave's tiles (t, t + wave_cnt, ...): while tile t runs through the
+    // Software pipeline over the tiles this wave claims: while tile t runs through the
     // MFMA chain, the gathers of tile t+1 are in flight (indices were fetched one tile earlier still),
     // so a tile never starts with a dependent idx -> feature round trip to L2/HBM.
     // ta/tb[pb][ob] = the lane's 4 outputs (16*ob + 4*g ..) of TA[a] and TB[b]; xp = its PPF input (ppf[g])
@@ -370,7 +386,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
         float xp[PB];
         int ia[PB], ib[PB];
 #pragma unroll
-        for (int pb = 0; pb < PB; ++pb) load_pair_idx(A, wave_gid * (16 * PB) + pb * 16 + j, ia[pb], ib[pb]);
+        for (int pb = 0; pb < PB; ++pb) load_pair_idx(A, cur * (16 * PB) + pb * 16 + j, ia[pb], ib[pb]);
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
             const unsigned oa = (unsigned)ia[pb] * (PROJ_COLS * 4u) + 16u * g, ob_ = (unsigned)ib[pb] * (PROJ_COLS * 4u) + 256u + 16u * g;
@@ -378,7 +394,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
             for (int ob = 0; ob < 4; ++ob) { ta[pb][ob] = at_off<f32x4>(A.table, oa + 64u * ob); tb[pb][ob] = at_off<f32x4>(A.table, ob_ + 64u * ob); }
             xp[pb] = ppf_from(ld3o(A.pc, ia[pb]), ld3o(A.pc, ib[pb]), ld3o(A.nrm, ia[pb]), ld3o(A.nrm, ib[pb]), g);
         }
-        const int64_t nt = wave_gid + wave_cnt < n_tiles ? wave_gid + wave_cnt : wave_gid;
+        const int64_t nt = nxt < wg_end ? nxt : cur;   // (no next tile: reload this one, the values are never used)
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) load_pair_idx(A, nt * (16 * PB) + pb * 16 + j, ia1[pb], ib1[pb]);
         const f32x4 w = ldb4(W + OFF_W0P + lane * 4);
@@ -388,7 +404,8 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
             for (int pb = 0; pb < PB; ++pb) acc[pb][ob] = mfma4(w[ob], xp[pb], ta[pb][ob] + tb[pb][ob]);
     }
 
-    for (int64_t tile = wave_gid; tile < n_tiles; tile += wave_cnt) {
+    for (;;) {
+        const int64_t tile = cur;
         // The packed weights are loop-invariant LDS data: without this compiler barrier LICM hoists
         // all ~200 weight registers out of the tile loop and the kernel spills.
         asm volatile("" ::: "memory");
@@ -479,9 +496,9 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob) { ta[pb][ob] = at_off<f32x4>(A.table, oa + 64u * ob); tb[pb][ob] = at_off<f32x4>(A.table, ob_ + 64u * ob); }
         }
+        const int64_t nxt2 = claim();
         {
-            int64_t nt = tile + 2 * wave_cnt;
-            nt = nt < n_tiles ? nt : tile;
+            const int64_t nt = nxt2 < wg_end ? nxt2 : tile;
 #pragma unroll
             for (int pb = 0; pb < PB; ++pb) load_pair_idx(A, nt * (16 * PB) + pb * 16 + j, ia1[pb], ib1[pb]);
         }
@@ -594,6 +611,9 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
                 }
             }
         }
+        cur = nxt;
+        nxt = nxt2;
+        if (cur >= wg_end) break;
     }
 }
 
@@ -692,16 +712,21 @@ __device__ int sample_bin_mem(const float* __restrict__ l, int nb, float u, int 
     float T[4];
     for (int g = 0; g < 4; ++g) {
         float acc = 0.f;
-        for (int k = g * NL; k < (g + 1) * NL && k < nb; ++k) acc = acc + det_expf(l[k] - m);
+        for (int k = g * NL; k < (g + 1) * NL && k < nb; ++k) {
+            const float ek = det_expf(l[k] - m);
+            acc = k == g * NL ? ek : acc + ek;
+        }
         T[g] = acc;
     }
     const float s01 = T[0] + T[1], s23 = T[2] + T[3];
-    const float t = u * (s01 + s23);
+    const float tt = u * (s01 + s23);
     const float off[4] = {0.f, T[0], s01, s01 + T[2]};
     for (int g = 0; g < 4; ++g) {
-        float b = off[g];
+        const float t = tt - off[g];
+        float b = 0.f;
         for (int k = g * NL; k < (g + 1) * NL && k < nb; ++k) {
-            b = b + det_expf(l[k] - m);
+            const float ek = det_expf(l[k] - m);
+            b = k == g * NL ? ek : b + ek;
             if (b > t) return k;
         }
     }

@@ -85,20 +85,23 @@ static inline float bits_f(int32_t b) { float f; memcpy(&f, &b, 4); return f; }
 static inline int32_t f_bits(float f) { int32_t b; memcpy(&b, &f, 4); return b; }
 
 /* exp(x) for x <= 0 (softmax after the max subtraction; callers guarantee x <= 0):
- * 2^(x*log2e) = 2^n * p(f), n = rint(y), f = y - n in [-0.5, 0.5] (exact), p = degree-4 minimax of
- * 2^f.  Max relative error 7e-6 (far below what an inverse-CDF draw can resolve). */
+ * 2^(x*log2e) = 2^n * p(f), n = rint(x*log2e) taken from the rounding of fma(x, log2e, 1.5*2^23),
+ * f = fma(x, log2e, -n) in [-0.5, 0.5], p = degree-4 minimax of 2^f.  Max relative error 3e-6 (far below what an
+ * inverse-CDF draw can resolve).  Same instruction sequence as csrc/cppf_math.h:det_expf. */
 float orc_expf(float x)
 {
     x = x < -86.0f ? -86.0f : x;   /* keeps 2^n a normal number for the exponent arithmetic below */
-    float y = x * 1.44269504088896341f;
-    float n = rintf(y);
-    float f = y - n;
+    /* t has unit spacing: t - 1.5*2^23 = n = rint(x*log2e) exactly, and the low bits of t's pattern hold n */
+    const float magic = 12582912.0f;
+    float t = fmaf(x, 1.44269504088896341f, magic);
+    float n = t - magic;
+    float f = fmaf(x, 1.44269504088896341f, -n);
     float p = 9.570102207e-03f;
     p = fmaf(p, f, 5.591785908e-02f);
     p = fmaf(p, f, 2.402474433e-01f);
     p = fmaf(p, f, 6.931217909e-01f);
     p = fmaf(p, f, 9.999992847e-01f);
-    return bits_f(f_bits(p) + ((int32_t)n << 23));
+    return bits_f((int32_t)((uint32_t)f_bits(p) + ((uint32_t)f_bits(t) << 23)));
 }
 
 /* sin and cos of x in fp64: Cody-Waite reduction by pi/2 (two terms; exact for |x| < ~1e5)
@@ -393,10 +396,10 @@ int orc_pair_mlp(const float* pc, const float* nrm, const float* feat, const int
  * consecutive segments of NL = ceil(nb/4) bins (one per lane; the final layer's output columns are permuted at
  * pack time so that a lane's registers hold exactly its segment).
  *   e_k   = orc_expf(l_k - max l)
- *   T_g   = e summed sequentially over segment g (from 0);  total = (T0 + T1) + (T2 + T3);  t = u * total
+ *   T_g   = e summed sequentially over segment g;  total = (T0 + T1) + (T2 + T3);  t = u * total
  *   off_g = 0, T0, T0 + T1, (T0 + T1) + T2
- *   the bin is the first k of the first segment g with off_g + (e summed up to and including k) > t;
- *   none -> the last bin.
+ *   the bin is the first k of the first segment g with (e summed over the segment up to and including k) > t - off_g
+ *   (the running sums that end in T_g; the threshold is moved into the segment); none -> the last bin.
  */
 int orc_sample_bin(const float* l, int nb, float u, int col0)
 {
@@ -410,16 +413,20 @@ int orc_sample_bin(const float* l, int nb, float u, int col0)
     float e[ORC_MAXD], T[4];
     for (int g = 0; g < 4; ++g) {
         float acc = 0.0f;
-        for (int k = g * NL; k < (g + 1) * NL && k < nb; ++k) { e[k] = orc_expf(l[k] - m); acc = acc + e[k]; }
+        for (int k = g * NL; k < (g + 1) * NL && k < nb; ++k) {
+            e[k] = orc_expf(l[k] - m);
+            acc = k == g * NL ? e[k] : acc + e[k];
+        }
         T[g] = acc;
     }
     const float s01 = T[0] + T[1], s23 = T[2] + T[3];
-    const float t = u * (s01 + s23);
+    const float tt = u * (s01 + s23);
     const float off[4] = {0.0f, T[0], s01, s01 + T[2]};
     for (int g = 0; g < 4; ++g) {
-        float b = off[g];
+        const float t = tt - off[g];
+        float b = 0.0f;
         for (int k = g * NL; k < (g + 1) * NL && k < nb; ++k) {
-            b = b + e[k];
+            b = k == g * NL ? e[k] : b + e[k];
             if (b > t) return k;
         }
     }
