@@ -25,6 +25,7 @@ _SIGS = {
     "cppf_vote_argmax_dyn": (C.c_int, [vp, vp, vp, vp, i32, vp, i64, vp, f32, i64, i64, i32, vp, i32, i32, i32, vp, vp, vp, sz,
                                        vp]),
     "cppf_center_from_argmax_dyn": (C.c_int, [vp, vp, C.c_double, vp, vp, vp, vp, vp, vp]),
+    "cppf_backvote_ws": (C.c_int, [vp, vp, vp, vp, vp, f32, i64, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp]),
     "cppf_backvote_dyn": (C.c_int, [vp, vp, vp, vp, vp, f32, i64, i32, vp, vp, f32, vp, vp]),
     "cppf_knn_dyn": (C.c_int, [vp, i32, vp, i32, vp, vp]),
     "cppf_point_encoder_forward_dyn": (C.c_int, [vp, vp, vp, i32, vp, i32, vp, C.POINTER(C.c_int), i32, i32, i32, i32, i32, i32,

@@ -1304,7 +1304,8 @@ __global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__
                                                               const float* __restrict__ corner, float res, int64_t n_ppfs,
                                                               int n_rots, int gx, int gy, int gz,
                                                               const float* __restrict__ gt_center, float tol,
-                                                              uint8_t* __restrict__ mask, const int32_t* __restrict__ shape)
+                                                              uint8_t* __restrict__ mask, const int32_t* __restrict__ shape,
+                                                              const unsigned long long* __restrict__ vote_ws)
 {
     if (shape) { gx = shape[1]; gy = shape[2]; gz = shape[3]; }   // dims record in memory (*_dyn)
     // (cos,sin) table for every n <= n_rots, built per block in LDS when it fits.
@@ -1313,12 +1314,20 @@ __global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__
     const int entries = n_rots * (n_rots + 1) / 2;
     const bool in_lds = entries <= VOTE_TAB_LDS_MAX;
     if (in_lds) {
-        fill_rot_table(ltab, entries, threadIdx.x, blockDim.x);
+        // the vote that produced gt_center left the same table in its workspace (VOTE_TAB_STAMP): 21 KB to load instead of
+        // 2 628 fp64 sincos per block
+        if (vote_ws && vote_ws[31] == (VOTE_TAB_STAMP ^ (unsigned long long)n_rots)) {
+            const float2* wtab = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(vote_ws) + VOTE_WS_TAB);
+            for (int e = threadIdx.x; e < entries; e += blockDim.x) ltab[e] = wtab[e];
+        } else {
+            fill_rot_table(ltab, entries, threadIdx.x, blockDim.x);
+        }
         __syncthreads();
     }
     const f3 cr = {corner[0], corner[1], corner[2]};
     const f3 gt = {gt_center[0], gt_center[1], gt_center[2]};
     const float bx = (float)(gx - 1), by = (float)(gy - 1), bz = (float)(gz - 1);
+    const float rinv_res = 1.0f / res;
     // Two stages per wave.  Stage 1, one pair per lane: frame, rotation count, and the skip test -- every sample
     // lies at distance |offset| = rho (1 +- 1e-6) from cc, hence at least | |cc - gt| - rho | from gt; when that
     // exceeds tol (with a margin far above the rounding) no rotation can pass :101 and the pair is finished
@@ -1358,60 +1367,148 @@ __global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__
         }
         finish(idx, found);
     };
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63);; base += stride) {
+    // A wave takes BV_U x 64 consecutive pairs per trip and has all their loads in flight before it looks at any of them
+    // (one pair per lane per trip was two dependent round trips to memory per pair with nothing else to do: 27 us for 9 MB).
+    constexpr int BV_U = 4;
+    constexpr int BV_COOP_MAX = 6;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * BV_U;
+    for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63)) * BV_U;; base += stride) {
         const bool more = base < n_ppfs;   // wave-uniform
         if (more) {
-            const int64_t idx = base + lane;
-            bool pass = false;
-            if (idx < n_ppfs) {
+            float2 o_[BV_U];
+            int2 ij_[BV_U];
+            f3 pa_[BV_U], pb_[BV_U];
+#pragma unroll
+            for (int u = 0; u < BV_U; ++u) {
+                const int64_t i = base + u * 64 + lane;
+                const int64_t c = i < n_ppfs ? i : n_ppfs - 1;
+                o_[u] = reinterpret_cast<const float2*>(outputs)[c];
+                ij_[u] = reinterpret_cast<const int2*>(point_idxs)[c];
+            }
+#pragma unroll
+            for (int u = 0; u < BV_U; ++u) { pa_[u] = ld3(points, ij_[u].x); pb_[u] = ld3(points, ij_[u].y); }
+#pragma unroll
+            for (int u = 0; u < BV_U; ++u) {
+                const int64_t idx = base + u * 64 + lane;
+                bool pass = false;
+                if (idx < n_ppfs) {
+                    const float2 o = o_[u];
+                    const int2 ij = ij_[u];
+                    const f3 pa = pa_[u], pb = pb_[u];
+                    const f3 dd = sub3(pa, pb);
+                    const float L2 = dot3(dd, dd);
+                    if (L2 >= 1e-13f) {
+                        // approximate arithmetic (v_sqrt / v_rcp, no exact divisions) and a slack far above its error: a pair
+                        // that fails here cannot pass :101 for any rotation; the others get the reference's exact
+                        // arithmetic in stage 2
+                        const float L = __builtin_amdgcn_sqrtf(L2);
+                        const float inv = __builtin_amdgcn_rcpf(L + 1e-7f);
+                        const float proj_len = o.x, odist = o.y;
+                        const f3 u = scl3(dd, inv);
+                        const f3 cc = sub3(pa, scl3(u, proj_len));
+                        // distance from gt to the vote CIRCLE (centre cc, axis u, radius |nu|): h along the axis, r in the
+                        // circle's plane; every sample lies on that circle (to 1e-6), so none can be nearer than this
+                        const f3 w = sub3(gt, cc);
+                        const float h = dot3(w, u), w2 = dot3(w, w), rho = fabsf(odist);
+                        const float r = __builtin_amdgcn_sqrtf(fmaxf(w2 - h * h, 0.f));
+                        const float dist = __builtin_amdgcn_sqrtf((r - rho) * (r - rho) + h * h);
+                        const float mag = __builtin_amdgcn_sqrtf(w2) + rho + tol;
+                        // ab = (a-b)/(L + 1e-7) is shorter than a unit vector by 1e-7/L: the samples sit on an ellipse inside
+                        // that circle and cc is off the ideal axis point, both by at most (|nu| + |mu|) * 1e-7 / L
+                        const float squash = (rho + fabsf(proj_len)) * 2e-7f * inv;
+                        pass = (odist * rinv_res * 6.2831855f >= 0.9999f) && !(dist > tol + 2e-4f * mag + 1e-6f + squash);
+                        if (!pass) finish(idx, f3{0.f, 0.f, 0.f});
+                    } else {   // (nearly) coincident points: the exact test decides what is degenerate
+                        f3 a, ab, xd;
+                        if (pair_frame(points, ij.x, ij.y, a, ab, xd)) {
+                            const float proj_len = o.x, odist = o.y;
+                            const f3 cc = sub3(a, scl3(ab, proj_len));
+                            const f3 x = scl3(xd, odist);
+                            const int n = min((int)((double)(odist / res) * (2 * CPPF_PI)), n_rots);
+                            const float dc = len3(sub3(cc, gt)), rho = len3(x);
+                            pass = n > 0 && !(fabsf(dc - rho) > tol + 1e-5f * (dc + rho + tol) + 1e-7f);
+                            if (!pass) finish(idx, f3{0.f, 0.f, 0.f});
+                        } else if (mask) {   // degenerate pair: out_offsets keeps the caller's value (:87 returns early)
+                            const float* oo = out_offsets ? out_offsets + 3 * idx : nullptr;
+                            mask[idx] = oo ? ((oo[0] != 0.f) || (oo[1] != 0.f) || (oo[2] != 0.f)) : 0;   // mask-only: as if zero-initialised (:220)
+                        }
+                    }
+                }
+                const unsigned long long m = __ballot(pass);
+                if (pass)
+                    q[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] = (uint32_t)idx;
+                qn += __popcll(m);
+                while (qn >= 64) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    const uint32_t pidx = q[qn - 64 + lane];
+                    qn -= 64;
+                    rotations((int64_t)pidx);
+                }
+            }
+        }
+        if (!more) {
+            // A handful of pairs left in the queue are taken
+            // one at a time by the WHOLE wave, lane i testing rotation i: the first rotation that passes is the lowest set
+            // bit of a ballot -- a lane walking up to 72 rotations of ~60 instructions alone was a third of the launch.
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (qn > BV_COOP_MAX) {   // enough of them to fill lanes: one pair per lane as above
+                const uint32_t pidx = lane < qn ? q[lane] : 0u;
+                if (lane < qn) rotations((int64_t)pidx);
+                qn = 0;
+            }
+            for (int e = 0; e < qn; ++e) {
+                const int64_t idx = (int64_t)q[e];
                 const float2 o = reinterpret_cast<const float2*>(outputs)[idx];
                 const int2 ij = reinterpret_cast<const int2*>(point_idxs)[idx];
                 f3 a, ab, xd;
-                if (pair_frame(points, ij.x, ij.y, a, ab, xd)) {
-                    const float proj_len = o.x, odist = o.y;
-                    const f3 cc = sub3(a, scl3(ab, proj_len));
-                    const f3 x = scl3(xd, odist);
-                    const int n = min((int)((double)(odist / res) * (2 * CPPF_PI)), n_rots);
-                    const float dc = len3(sub3(cc, gt)), rho = len3(x);
-                    pass = n > 0 && !(fabsf(dc - rho) > tol + 1e-5f * (dc + rho + tol) + 1e-7f);
-                    if (!pass) finish(idx, f3{0.f, 0.f, 0.f});
-                } else if (mask) {   // degenerate pair: out_offsets keeps the caller's value (:87 returns early)
-                    const float* oo = out_offsets ? out_offsets + 3 * idx : nullptr;
-                    mask[idx] = oo ? ((oo[0] != 0.f) || (oo[1] != 0.f) || (oo[2] != 0.f)) : 0;   // mask-only: as if zero-initialised (:220)
+                pair_frame(points, ij.x, ij.y, a, ab, xd);
+                const float proj_len = o.x, odist = o.y;
+                const f3 cc = sub3(a, scl3(ab, proj_len));
+                const f3 x = scl3(xd, odist);
+                const f3 y = cross3(x, ab);
+                const int n = min((int)((double)(odist / res) * (2 * CPPF_PI)), n_rots);      // :97
+                const int tbase = n * (n - 1) / 2;
+                bool done = false;
+                for (int i0 = 0; i0 < n && !done; i0 += 64) {
+                    const int i = i0 + lane;
+                    bool ok = false;
+                    f3 offset = {0.f, 0.f, 0.f};
+                    if (i < n) {
+                        const float2 cs = in_lds ? ltab[tbase + i] : rot_cs(i, n);
+                        offset = add3(scl3(x, cs.x), scl3(y, cs.y));
+                        const f3 pc = add3(cc, offset);
+                        const f3 g = div3(sub3(pc, cr), res);
+                        ok = !(len3(sub3(pc, gt)) > tol) &&                                     // :101
+                             !(g.x < 0.f || g.y < 0.f || g.z < 0.f || g.x >= bx || g.y >= by || g.z >= bz);  // :103-107
+                    }
+                    const unsigned long long hit = __ballot(ok);
+                    if (hit) {
+                        if (lane == __builtin_ctzll(hit)) finish(idx, neg3(offset));            // :108, the first such rotation
+                        done = true;
+                    }
                 }
+                if (!done && lane == 0) finish(idx, f3{0.f, 0.f, 0.f});
             }
-            const unsigned long long m = __ballot(pass);
-            if (pass)
-                q[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] = (uint32_t)idx;
-            qn += __popcll(m);
+            break;
         }
-        while (qn >= 64 || (!more && qn > 0)) {
-            const int take = qn < 64 ? qn : 64;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            const uint32_t pidx = lane < take ? q[qn - take + lane] : 0u;
-            qn -= take;
-            if (lane < take) rotations((int64_t)pidx);
-        }
-        if (!more) break;
     }
 }
 
 static int backvote_impl(const float* points, const float* outputs, float* out_offsets,
                          const int32_t* point_idxs, const float* corner, float res, int64_t n_ppfs, int n_rots,
                          int gx, int gy, int gz, const float* gt_center, float tol, uint8_t* mask, void* stream,
-                         const int32_t* shape_dev)
+                         const int32_t* shape_dev, const void* vote_workspace = nullptr)
 {
     if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || n_ppfs < 0 || n_ppfs > 0xffffffffll) return CPPF_EINVAL;
     if (n_ppfs == 0) return 0;
     if (!points || !outputs || (!out_offsets && !mask) || !point_idxs || !corner || !gt_center) return CPPF_EINVAL;
     const int entries = tri(n_rots);
     const size_t lds = (entries <= VOTE_TAB_LDS_MAX ? (size_t)entries * sizeof(float2) : 0) + 4 * 128 * sizeof(uint32_t);
-    int64_t nb = (n_ppfs + 255) / 256;
+    int64_t nb = (n_ppfs + 4 * 256 - 1) / (4 * 256);   // BV_U = 4 pairs per thread and trip
     if (nb > 1024) nb = 1024;
     hipLaunchKernelGGL(backvote_kernel, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, points,
                        outputs, out_offsets, point_idxs, corner, res, n_ppfs, n_rots, gx, gy, gz, gt_center, tol,
-                       mask, shape_dev);
+                       mask, shape_dev, static_cast<const unsigned long long*>(vote_workspace));
     CPPF_CHECK_LAUNCH();
     return 0;
 }
@@ -1422,6 +1519,16 @@ extern "C" int cppf_backvote(const float* points, const float* outputs, float* o
 {
     return backvote_impl(points, outputs, out_offsets, point_idxs, corner, res, n_ppfs, n_rots, gx, gy, gz, gt_center, tol,
                          mask, stream, nullptr);
+}
+
+extern "C" int cppf_backvote_ws(const float* points, const float* outputs, float* out_offsets,
+                                const int32_t* point_idxs, const float* corner, float res, int64_t n_ppfs, int n_rots,
+                                int gx, int gy, int gz, const int32_t* shape_dev, const float* gt_center, float tol,
+                                uint8_t* mask, const void* vote_workspace, void* stream)
+{
+    if (!shape_dev && (gx < 1 || gy < 1 || gz < 1)) return CPPF_EINVAL;
+    return backvote_impl(points, outputs, out_offsets, point_idxs, corner, res, n_ppfs, n_rots, shape_dev ? 1 : gx,
+                         shape_dev ? 1 : gy, shape_dev ? 1 : gz, gt_center, tol, mask, stream, shape_dev, vote_workspace);
 }
 
 extern "C" int cppf_backvote_dyn(const float* points, const float* outputs, float* out_offsets,

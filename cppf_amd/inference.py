@@ -329,24 +329,24 @@ def _enqueue_tail(ws, pc, pc_normal, idx32, outputs, heads, corner, cfg, dims, n
     st = stream_ptr(dev)
     P, S = idx32.shape[0], sph32_d.shape[0]
     with torch.cuda.device(dev):
+        # the vote's workspace (same scope, same tag as models/voting.py): its rotation table is reused by the back-vote
+        vws = workspace(256, dev, "vote_dyn" if shape is not None else "vote")
         if shape is not None:
             _lib.check(L.cppf_center_from_argmax_dyn(ws.out_idx.data_ptr(), corner.data_ptr(), float(cfg.res), shape.data_ptr(),
                                                      ws.T64.data_ptr(), ws.T32.data_ptr(), ws.out_val.data_ptr(),
                                                      ws.rec[19:21].data_ptr(), st), "cppf_center_from_argmax_dyn")
-            _lib.check(L.cppf_backvote_dyn(pc.data_ptr(), outputs.data_ptr(), None, idx32.data_ptr(), corner.data_ptr(),
-                                           float(cfg.res), P, num_rots, shape.data_ptr(), ws.T32.data_ptr(),
-                                           float(np.float32(3 * cfg.res)), ws.mask.data_ptr(), st), "cppf_backvote_dyn")
         else:
             _lib.check(L.cppf_center_from_argmax(ws.out_idx.data_ptr(), corner.data_ptr(), float(cfg.res), dims[1],
                                                  dims[2], ws.T64.data_ptr(), ws.T32.data_ptr(), ws.out_val.data_ptr(),
                                                  ws.rec[19:21].data_ptr(), st),
                        "cppf_center_from_argmax")
-            # back-vote filter (:216-231) --------------------------------------------------------------
-            # mask only: the offsets themselves (:220-228) are consumed nowhere else, so no buffer is zeroed or written
-            _lib.check(L.cppf_backvote(pc.data_ptr(), outputs.data_ptr(), None, idx32.data_ptr(),
-                                       corner.data_ptr(), float(cfg.res), P, num_rots, dims[0], dims[1], dims[2],
-                                       ws.T32.data_ptr(), float(np.float32(3 * cfg.res)), ws.mask.data_ptr(), st),
-                       "cppf_backvote")
+        # back-vote filter (:216-231) --------------------------------------------------------------
+        # mask only: the offsets themselves (:220-228) are consumed nowhere else, so no buffer is zeroed or written
+        gx, gy, gz = (1, 1, 1) if shape is not None else dims
+        _lib.check(L.cppf_backvote_ws(pc.data_ptr(), outputs.data_ptr(), None, idx32.data_ptr(), corner.data_ptr(),
+                                      float(cfg.res), P, num_rots, gx, gy, gz, None if shape is None else shape.data_ptr(),
+                                      ws.T32.data_ptr(), float(np.float32(3 * cfg.res)), ws.mask.data_ptr(),
+                                      vws.data_ptr() if vws.numel() >= 32768 else None, st), "cppf_backvote_ws")
         cws = workspace(L.cppf_compact_workspace_bytes(P), dev, "compact")
         _lib.check(L.cppf_compact_mask(ws.mask.data_ptr(), P, ws.surv.data_ptr(), ws.count.data_ptr(),
                                        cws.data_ptr(), cws.numel(), st), "cppf_compact_mask")

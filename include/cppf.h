@@ -103,6 +103,13 @@ int cppf_counts_argmax_select(const int32_t* counts, int n, const double* sphere
 int cppf_backvote(const float* points, const float* outputs, float* out_offsets, const int32_t* point_idxs,
                   const float* corner, float res, int64_t n_ppfs, int n_rots, int gx, int gy, int gz,
                   const float* gt_center, float tol, uint8_t* mask, void* stream);
+/* The same with (a) the dims optionally in a device record (shape_dev != NULL: gx, gy, gz ignored, see the `_dyn` section)
+ * and (b) the workspace of the cppf_vote_argmax* call that produced gt_center (may be NULL): the vote leaves its (cos, sin)
+ * rotation table there and the back-vote loads it instead of rebuilding it per workgroup.  Same results. */
+int cppf_backvote_ws(const float* points, const float* outputs, float* out_offsets, const int32_t* point_idxs,
+                     const float* corner, float res, int64_t n_ppfs, int n_rots, int gx, int gy, int gz,
+                     const int32_t* shape_dev, const float* gt_center, float tol, uint8_t* mask,
+                     const void* vote_workspace, void* stream);
 
 /* Order-preserving compaction of the surviving pairs (point_idxs[mask], nocs/inference.py:231),
  * done on device.  surv: device i32[n] receives the indices i with mask[i] != 0 in increasing
