@@ -46,6 +46,8 @@ _SIGS = {
                                         sz, vp]),
     "cppf_pair_mlp_decode": (C.c_int, [vp, vp, vp, vp, i32, vp, i64, i32, C.POINTER(C.c_int), i32, i64, i32, i32, i32,
                                        f32, f32, vp, vp, vp, vp, vp, sz, vp]),
+    "cppf_pair_mlp_decode_sel": (C.c_int, [vp, vp, vp, vp, i32, vp, i64, i32, C.POINTER(C.c_int), i32, i64, i32, i32, i32, vp, vp, vp,
+                                           i64, vp, vp, sz, vp]),
     "cppf_debug_mlp_chain_only": (C.c_int, [vp, vp, vp, vp, i32, vp, i64, i64, vp, vp, sz, vp]),
     "cppf_decode_center": (C.c_int, [vp, i64, i32, i32, f32, f32, vp, vp, vp]),
     "cppf_decode_rot": (C.c_int, [vp, i64, i32, i32, i32, i32, vp, vp, vp]),

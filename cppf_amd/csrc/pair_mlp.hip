@@ -253,6 +253,10 @@ struct MlpArgs {
     int out_dim;
     int idx64;
     float vr0, vr1;
+    // SEL variant (second MLP pass of nocs/inference.py:236 on the pairs that survived the back-vote): slot i of the launch
+    // works on pair sel[i], i < min(*n_sel, P); everything per pair (indices, uniforms, results) stays at the pair's own row
+    const int32_t* sel;
+    const int32_t* n_sel;
 };
 
 // Addresses inside the tile loop are a uniform base (SGPR pair) + an unsigned 32-bit byte offset (one VGPR): the
@@ -274,11 +278,20 @@ __device__ __forceinline__ f3 ld3o(const float* __restrict__ base, int i)
     return {at_off<float>(base, o), at_off<float>(base, o + 4u), at_off<float>(base, o + 8u)};
 }
 
-__device__ __forceinline__ void load_pair_idx(const MlpArgs& A, int64_t pair, int& ia, int& ib)
+// slot of the launch -> row of the pair arrays (identity unless SEL)
+template <bool SEL>
+__device__ __forceinline__ unsigned pair_row(const MlpArgs& A, int64_t slot, int64_t Pn)
+{
+    const unsigned s = (unsigned)(slot < Pn ? slot : Pn - 1);
+    return SEL ? (unsigned)at_off<int>(A.sel, s * 4u) : s;
+}
+
+template <bool SEL>
+__device__ __forceinline__ void load_pair_idx(const MlpArgs& A, int64_t slot, int64_t Pn, int& ia, int& ib)
 {
     // two 4-byte loads of the low words whatever the index width: an i32 / i64 branch around the loads ends in a
     // wait for ALL outstanding loads (the gathers of the next tile that are in flight at this point)
-    const unsigned p = (unsigned)(pair < A.P ? pair : A.P - 1);
+    const unsigned p = pair_row<SEL>(A, slot, Pn);
     const unsigned o = p * (A.idx64 ? 16u : 8u);
     ia = at_off<int>(A.idxs, o);
     ib = at_off<int>(A.idxs, o + (A.idx64 ? 8u : 4u));
@@ -320,7 +333,7 @@ __global__ __launch_bounds__(256) void point_proj_kernel(const float* __restrict
     T[n * PROJ_COLS + r] = acc;
 }
 
-template <bool LOGITS, bool DECODE, bool HEADS>
+template <bool LOGITS, bool DECODE, bool HEADS, bool SEL = false>
 __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kernel(MlpArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float W[];
@@ -354,7 +367,9 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, g = lane >> 4;
     __builtin_assume(g >= 0 && g < 4);
-    const int64_t n_tiles = (A.P + 16 * PB - 1) / (16 * PB);
+    int64_t Pn = A.P;
+    if (SEL) { const int64_t ns = *A.n_sel; Pn = ns < A.P ? ns : A.P; }
+    const int64_t n_tiles = (Pn + 16 * PB - 1) / (16 * PB);
     // Tiles are handed out per workgroup through an LDS counter.  With a fixed share (8 tiles per wave at the benchmark's
     // size) the waves of a SIMD -- arbitrated oldest first -- ran the same work in 119k ... 211k cycles and the kernel
     // waited for the slowest with a fifth of its issue slots idle (s_memtime trace, profiles/r2_pair_mlp_phases.txt).
@@ -386,7 +401,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
         float xp[PB];
         int ia[PB], ib[PB];
 #pragma unroll
-        for (int pb = 0; pb < PB; ++pb) load_pair_idx(A, cur * (16 * PB) + pb * 16 + j, ia[pb], ib[pb]);
+        for (int pb = 0; pb < PB; ++pb) load_pair_idx<SEL>(A, cur * (16 * PB) + pb * 16 + j, Pn, ia[pb], ib[pb]);
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
             const unsigned oa = (unsigned)ia[pb] * (PROJ_COLS * 4u) + 16u * g, ob_ = (unsigned)ib[pb] * (PROJ_COLS * 4u) + 256u + 16u * g;
@@ -396,7 +411,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
         }
         const int64_t nt = nxt < wg_end ? nxt : cur;   // (no next tile: reload this one, the values are never used)
 #pragma unroll
-        for (int pb = 0; pb < PB; ++pb) load_pair_idx(A, nt * (16 * PB) + pb * 16 + j, ia1[pb], ib1[pb]);
+        for (int pb = 0; pb < PB; ++pb) load_pair_idx<SEL>(A, nt * (16 * PB) + pb * 16 + j, Pn, ia1[pb], ib1[pb]);
         const f32x4 w = ldb4(W + OFF_W0P + lane * 4);
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob)
@@ -411,7 +426,10 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
         asm volatile("" ::: "memory");
         int64_t pair[PB];
 #pragma unroll
-        for (int pb = 0; pb < PB; ++pb) pair[pb] = tile * (16 * PB) + pb * 16 + j;
+        for (int pb = 0; pb < PB; ++pb) pair[pb] = tile * (16 * PB) + pb * 16 + j;   // slot of the launch
+        unsigned row[PB];                                                              // row of the pair arrays
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) row[pb] = pair_row<SEL>(A, pair[pb], Pn);
 
         // ---- next tile: points / normals in flight during layer 0 ---------------------------------
         f3 npa[PB], npb[PB], nna[PB], nnb[PB];
@@ -424,8 +442,8 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
         if (DECODE) {
 #pragma unroll
             for (int pb = 0; pb < PB; ++pb) {
-                const unsigned po = (unsigned)(pair[pb] < A.P ? pair[pb] : A.P - 1) * 8u;
-                ut[pb] = at_off<f32x2>(A.u_tr, po);
+                const unsigned po = row[pb] * 8u;
+                if (!SEL) ut[pb] = at_off<f32x2>(A.u_tr, po);
                 if (HEADS) ur[pb] = at_off<f32x2>(A.u_rot, po);
             }
         }
@@ -500,7 +518,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
         {
             const int64_t nt = nxt2 < wg_end ? nxt2 : tile;
 #pragma unroll
-            for (int pb = 0; pb < PB; ++pb) load_pair_idx(A, nt * (16 * PB) + pb * 16 + j, ia1[pb], ib1[pb]);
+            for (int pb = 0; pb < PB; ++pb) load_pair_idx<SEL>(A, nt * (16 * PB) + pb * 16 + j, Pn, ia1[pb], ib1[pb]);
         }
 
         // ---- layer 2: fc1 | fc0 (32 -> 16 | 16), fc2 (16 -> 16) ---------------------------------
@@ -559,7 +577,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
                     L[ob] = mfma4(w, z[pb][s], L[ob]);
                 }
             }
-            const bool live = pair[pb] < A.P;
+            const bool live = pair[pb] < Pn;
             if (!LOGITS && !DECODE) {  // profiling variant: the MFMA chain alone, results kept alive by a never-true store
                 float sacc = 0.f;
 #pragma unroll
@@ -587,16 +605,18 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
             if (DECODE) {
                 int k;
                 // nocs/inference.py:187-188 (fp32, left to right); the owning lane stores its value
-                {
-                    const float v[8] = {L[0][0], L[0][1], L[0][2], L[0][3], L[1][0], L[1][1], L[1][2], L[1][3]};
-                    if (sample_seg<8>(v, ut[pb][0], g, lane, k) && live) at_off<float>(A.outputs, (unsigned)pair[pb] * 8u) = lut[k];
-                }
-                {
-                    const float v[8] = {L[2][0], L[2][1], L[2][2], L[2][3], L[3][0], L[3][1], L[3][2], L[3][3]};
-                    if (sample_seg<8>(v, ut[pb][1], g, lane, k) && live) at_off<float>(A.outputs, (unsigned)pair[pb] * 8u + 4u) = lut[32 + k];
+                if (!SEL) {   // (the second pass only needs the rotation / sign / scale heads: the centre was decoded in the first)
+                    {
+                        const float v[8] = {L[0][0], L[0][1], L[0][2], L[0][3], L[1][0], L[1][1], L[1][2], L[1][3]};
+                        if (sample_seg<8>(v, ut[pb][0], g, lane, k) && live) at_off<float>(A.outputs, row[pb] * 8u) = lut[k];
+                    }
+                    {
+                        const float v[8] = {L[2][0], L[2][1], L[2][2], L[2][3], L[3][0], L[3][1], L[3][2], L[3][3]};
+                        if (sample_seg<8>(v, ut[pb][1], g, lane, k) && live) at_off<float>(A.outputs, row[pb] * 8u + 4u) = lut[32 + k];
+                    }
                 }
                 if (HEADS) {
-                    const unsigned ho = (unsigned)pair[pb] * 32u;
+                    const unsigned ho = row[pb] * 32u;
                     {
                         const float v[9] = {L[4][0], L[4][1], L[4][2], L[4][3], L[5][0], L[5][1], L[5][2], L[5][3], L[8][0]};
                         if (sample_seg<9>(v, ur[pb][0], g, lane, k) && live) at_off<float>(A.heads, ho) = lut[64 + k];
@@ -780,24 +800,26 @@ extern "C" size_t cppf_pair_mlp_workspace_bytes(int64_t N, int F, const int* dim
     return is_std(F, dims, n_res, out_dim) ? (size_t)N * PROJ_COLS * sizeof(float) : 0;
 }
 
-template <bool LOGITS, bool DECODE, bool HEADS>
+template <bool LOGITS, bool DECODE, bool HEADS, bool SEL = false>
 static int launch_std(MlpArgs& A, int64_t N, void* workspace, size_t workspace_bytes, hipStream_t st)
 {
     if (N < 1) return CPPF_EINVAL;
     if (N >= (1ll << 23) || A.P >= (1ll << 27)) return CPPF_EUNSUPPORTED;   // 32-bit byte offsets inside the kernel
     if (!workspace || workspace_bytes < (size_t)N * PROJ_COLS * sizeof(float)) return CPPF_EWORKSPACE;
     float* table = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(point_proj_kernel, dim3((unsigned)((N + 1) / 2)), dim3(256), 0, st, A.feat, A.packed, table, N);
-    CPPF_CHECK_LAUNCH();
+    if (!SEL) {   // (the SEL pass reuses the table the first pass left in the same workspace)
+        hipLaunchKernelGGL(point_proj_kernel, dim3((unsigned)((N + 1) / 2)), dim3(256), 0, st, A.feat, A.packed, table, N);
+        CPPF_CHECK_LAUNCH();
+    }
     A.table = table;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mlp_kernel<LOGITS, DECODE, HEADS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mlp_kernel<LOGITS, DECODE, HEADS, SEL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (STD_LDS + 128) * sizeof(float));
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((pair_mlp_kernel<LOGITS, DECODE, HEADS>), dim3(mlp_grid(A.P)), dim3(MLP_THREADS),
+    hipLaunchKernelGGL((pair_mlp_kernel<LOGITS, DECODE, HEADS, SEL>), dim3(mlp_grid(A.P)), dim3(MLP_THREADS),
                        (STD_LDS + 128) * sizeof(float), st, A);
     CPPF_CHECK_LAUNCH();
     return 0;
@@ -854,6 +876,23 @@ extern "C" int cppf_pair_mlp_decode(const float* pc, const float* nrm, const flo
     A.idx64 = idx_is_i64; A.u_tr = u_tr; A.u_rot = u_rot; A.outputs = outputs; A.heads = heads; A.vr0 = vr0; A.vr1 = vr1;
     return heads ? launch_std<false, true, true>(A, N, workspace, workspace_bytes, (hipStream_t)stream)
                  : launch_std<false, true, false>(A, N, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int cppf_pair_mlp_decode_sel(const float* pc, const float* nrm, const float* feat, const void* idxs,
+                                        int idx_is_i64, const float* packed, int64_t N, int F, const int* dims, int n_res,
+                                        int64_t P, int out_dim, int tr_bins, int rot_bins, const float* u_rot,
+                                        const int32_t* sel, const int32_t* n_sel_dev, int64_t max_sel, float* heads,
+                                        void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (P < 0 || max_sel < 0 || !dims) return CPPF_EINVAL;
+    if (!is_std(F, dims, n_res, out_dim) || tr_bins != 32 || rot_bins != 36 || out_dim != 141) return CPPF_EUNSUPPORTED;
+    if (P == 0 || max_sel == 0) return 0;
+    if (!pc || !nrm || !feat || !idxs || !packed || !u_rot || !sel || !n_sel_dev || !heads) return CPPF_EINVAL;
+    MlpArgs A = {};
+    A.pc = pc; A.nrm = nrm; A.feat = feat; A.idxs = idxs; A.packed = packed; A.out_dim = out_dim;
+    A.P = max_sel < P ? max_sel : P;   // slots of the launch (capacity); the device count bounds what runs
+    A.idx64 = idx_is_i64; A.u_rot = u_rot; A.heads = heads; A.sel = sel; A.n_sel = n_sel_dev;
+    return launch_std<false, true, true, true>(A, N, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 // Profiling aid (not part of the drop-in surface): the PPF + gather + MFMA chain with no epilogue.

@@ -5,7 +5,8 @@ The reference bounces every stage through the host (torch -> numpy -> CuPy and b
 :265-284).  Here the whole chain is enqueued on one HIP stream and the host reads back ONE small
 record at the end:
 
-  PPF + pair MLP + decode      PPFEncoder.forward_decode            (:182-188, :236-256)
+  PPF + pair MLP + decode      PPFEncoder.forward_decode            (:182-188)
+  second pass on survivors     PPFEncoder.forward_decode_sel        (:236-256)
   centre vote + arg-max        cppf_vote_argmax                     (:191-208)
   T = corner + cand * res      cppf_center_from_argmax              (:209-213)
   back-vote + compaction       cppf_backvote / cppf_compact_mask    (:216-231)
@@ -14,8 +15,8 @@ record at the end:
   scale                        cppf_scale_sum                       (:335)
 
 Stochastic pieces of the reference are made explicit inputs: `u_tr`/`u_rot` (uniforms replacing
-torch.multinomial at :186/:250/:254, indexed by ORIGINAL pair -- the second MLP pass of :236 only
-recomputes rows the first pass already produced, so it is replaced by a gather), and the random
+torch.multinomial at :186/:250/:254, indexed by ORIGINAL pair; the second MLP pass of :236 runs on the
+surviving pairs only, like the reference's, through cppf_pair_mlp_decode_sel), and the random
 10 000-pair subset of :277-280 is the first `max_rot_pairs` survivors in pair order (pairs are
 i.i.d. uniform, so a prefix is distributed exactly like a shuffled subset).
 """
@@ -58,6 +59,9 @@ class PoseWorkspace:
         self.best_dir = self.rec[3:9].view(2, 3)
         self.sign = self.rec[9:15].view(2, 3)
         self.scale = self.rec[15:19]
+        # {theta_up, theta_right, aux_up, aux_right, sx, sy, sz, 0} per pair, written by the second MLP pass for the pairs
+        # that survive the back-vote (nocs/inference.py:236-256); other rows keep whatever an earlier instance left
+        self.heads = torch.zeros((n_pairs, 8), dtype=F32, device=device)
         self.probs = None
         self._sph_key = None
 
@@ -310,20 +314,23 @@ def estimate_pose(encoder, pc, pc_normal, feat, point_idxs, u_tr, u_rot, cfg, sp
     idx32 = point_idxs.to(I32)
 
     # centre ------------------------------------------------------------------------------------------
-    _, _, outputs, heads, _ = estimate_center(encoder, pc, pc_normal, feat, point_idxs, u_tr, cfg, corner, dims,
-                                              num_rots, adaptive, u_rot, ws, idx32)
+    _, _, outputs, _, _ = estimate_center(encoder, pc, pc_normal, feat, point_idxs, u_tr, cfg, corner, dims,
+                                          num_rots, adaptive, None, ws, idx32)
+    heads = ws.heads
     _enqueue_tail(ws, pc, pc_normal, idx32, outputs, heads, corner, cfg, dims, num_rots, angle_tol, max_rot_pairs,
-                  sph32_d, sph64_d, sorted_y)
+                  sph32_d, sph64_d, sorted_y, second_pass=(encoder, feat, point_idxs, u_rot))
     out = _assemble(ws.rec.cpu().numpy(), cfg, rng)                           # the one read-back
     out.update(dims=dims, corner=corners[0], ws=ws, outputs=outputs, heads=heads)
     return out
 
 
 def _enqueue_tail(ws, pc, pc_normal, idx32, outputs, heads, corner, cfg, dims, num_rots, angle_tol, max_rot_pairs,
-                  sph32_d, sph64_d, sorted_y, shape=None):
+                  sph32_d, sph64_d, sorted_y, shape=None, second_pass=None):
     """nocs/inference.py:209-303,335 after the centre vote, all on the current stream; leaves the 21-double
     result record in ws.rec (T[3], best_dir[2,3], sign sums[2,3], scale sums[4], argmax, peak).  `shape`: the device
-    dims record of a shape-polymorphic pipeline (then `dims` is unused)."""
+    dims record of a shape-polymorphic pipeline (then `dims` is unused).  `second_pass` = (encoder, feat, point_idxs, u_rot):
+    the heads of the surviving pairs are computed here, after the compaction, like the reference's second
+    ppf_encoder call (:236-256); without it `heads` must already hold them."""
     dev = pc.device
     L = _lib.lib()
     st = stream_ptr(dev)
@@ -350,6 +357,10 @@ def _enqueue_tail(ws, pc, pc_normal, idx32, outputs, heads, corner, cfg, dims, n
         cws = workspace(L.cppf_compact_workspace_bytes(P), dev, "compact")
         _lib.check(L.cppf_compact_mask(ws.mask.data_ptr(), P, ws.surv.data_ptr(), ws.count.data_ptr(),
                                        cws.data_ptr(), cws.numel(), st), "cppf_compact_mask")
+        if second_pass is not None:                                          # :236-256, survivors only
+            enc2, feat2, idxs2, u_rot2 = second_pass
+            enc2.forward_decode_sel(pc, pc_normal, feat2, idxs2, u_rot2, ws.surv, ws.count, heads, max_sel=P,
+                                    tr_num_bins=cfg.tr_num_bins, rot_num_bins=cfg.rot_num_bins)
         # orientation (:259-303) -------------------------------------------------------------------
         thr = float(np.float32(np.cos(angle_tol / 180 * np.pi)))
         n_dirs = 2 if cfg.regress_right else 1
@@ -446,7 +457,7 @@ class PosePipeline(CenterPipeline):
 
     def __init__(self, encoder, cfg, n_points, n_pairs, dims, device, sphere_pts, num_rots=72, adaptive=True,
                  angle_tol=1.5, max_rot_pairs=10000, use_graph=True, point_encoder=None, dynamic=False):
-        super().__init__(encoder, cfg, n_points, n_pairs, dims, device, num_rots, adaptive, True, use_graph, point_encoder,
+        super().__init__(encoder, cfg, n_points, n_pairs, dims, device, num_rots, adaptive, False, use_graph, point_encoder,
                          dynamic)
         sph64 = np.asarray(sphere_pts, dtype=np.float64)
         self.ws = PoseWorkspace(device, n_pairs, self.dims, sph64.shape[0], grid=self.grid_flat if self.dynamic else self.grid)
@@ -457,9 +468,11 @@ class PosePipeline(CenterPipeline):
     def _chain(self):
         super()._chain()
         self.idx32.copy_(self.idx)                                            # the pose-tail kernels take int32 indices
+        self.heads = self.ws.heads
         _enqueue_tail(self.ws, self.pc, self.nrm, self.idx32, self.outputs, self.heads, self.corner, self.cfg,
                       self.dims, self.num_rots, self.angle_tol, self.max_rot_pairs, *self._sph,
-                      shape=self.shape if self.dynamic else None)
+                      shape=self.shape if self.dynamic else None,
+                      second_pass=(self.encoder, self.feat, self.idx, self.u_rot))
 
     def run(self, rng=None):
         super().run()

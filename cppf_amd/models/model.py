@@ -479,6 +479,28 @@ class PPFEncoder(_DeviceWeights, nn.Module):
         _lib.check(rc, "cppf_pair_mlp_decode")
         return outputs, heads
 
+    def forward_decode_sel(self, pc, pc_normal, feat, idxs, u_rot, sel, n_sel, heads, max_sel=None, tr_num_bins=32,
+                           rot_num_bins=36):
+        """The second MLP pass of nocs/inference.py:236-256 on the pairs that survived the back-vote: for i < min(n_sel[0],
+        max_sel) the pair sel[i] gets its heads row {theta_up, theta_right, aux_up, aux_right, sx, sy, sz, 0} written into
+        `heads` f32[P,8] (other rows untouched); u_rot f32[P,2] is indexed by original pair.  Must follow a forward_decode /
+        forward_with_idx call on the same (feat, parameters) in the same scratch scope: the per-point table it left is reused.
+        sel i32[>=max_sel] and n_sel i32[1] are device tensors (cppf_compact_mask's outputs), so no host sync."""
+        idxs = self._as_index_tensor(idxs, pc.device)
+        pc, pc_normal, feat = self._check_inputs(pc, pc_normal, feat)
+        P = idxs.shape[0]
+        max_sel = P if max_sel is None else min(int(max_sel), P)
+        dims = (C.c_int * len(self.ppffcs))(*self.ppffcs)
+        ws = self._scratch(pc, feat, dims)
+        with torch.cuda.device(pc.device):
+            rc = _lib.lib().cppf_pair_mlp_decode_sel(
+                pc.data_ptr(), pc_normal.data_ptr(), feat.data_ptr(), idxs.data_ptr(), 1 if idxs.dtype == torch.int64 else 0,
+                self._packed_weights(pc.device).data_ptr(), pc.shape[0], feat.shape[1], dims, len(self.ppffcs) - 1, P,
+                self.out_dim, tr_num_bins, rot_num_bins, u_rot.data_ptr(), sel.data_ptr(), n_sel.data_ptr(), max_sel,
+                heads.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr(pc.device))
+        _lib.check(rc, "cppf_pair_mlp_decode_sel")
+        return heads
+
     # ------------------------------------------------------------------ internals
     def _scratch(self, pc, feat, dims):
         need = _lib.lib().cppf_pair_mlp_workspace_bytes(pc.shape[0], feat.shape[1], dims, len(self.ppffcs) - 1,

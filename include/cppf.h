@@ -222,6 +222,17 @@ int cppf_pair_mlp_decode(const float* pc, const float* nrm, const float* feat, c
                          const float* u_rot, float* outputs, float* heads, void* workspace, size_t workspace_bytes,
                          void* stream);
 
+/* The second MLP pass of nocs/inference.py:236-256 -- ppf_encoder(..., idxs=point_idxs[mask]) followed by the decode of the
+ * rotation bins, the sign logits and the log-scales -- on the surviving pairs only, without materialising point_idxs[mask]:
+ * slot i < min(*n_sel_dev, max_sel) works on pair sel[i] (cppf_compact_mask's output) and writes heads[sel[i]]; u_rot is
+ * indexed by ORIGINAL pair like heads.  Rows of pairs that are not selected are left untouched.  `workspace` must be the one
+ * the preceding cppf_pair_mlp_decode call on the same (feat, packed) used: its per-point table is reused, not rebuilt.
+ * The launch is sized for max_sel slots (a captured graph cannot know the count); surplus workgroups exit at once. */
+int cppf_pair_mlp_decode_sel(const float* pc, const float* nrm, const float* feat, const void* idxs, int idx_is_i64,
+                             const float* packed, int64_t N, int F, const int* dims, int n_res, int64_t P, int out_dim,
+                             int tr_bins, int rot_bins, const float* u_rot, const int32_t* sel, const int32_t* n_sel_dev,
+                             int64_t max_sel, float* heads, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Profiling aid, not part of the drop-in surface: the PPF + gather + MFMA chain of the standard
  * architecture with no epilogue (isolates the matrix pipeline when reading rocprof counters).
  * scratch: >= 4 bytes of device memory (never written in practice). */

@@ -142,7 +142,8 @@ def test_dynamic_pipeline_serves_ragged_shapes_with_one_graph(golden, dev):
         assert r["argmax"] == ref["argmax"] and r["n_surv"] == ref["n_surv"] and r["peak"] == ref["peak"]
         for k in ("T", "up", "scale", "R"):
             np.testing.assert_array_equal(r[k], ref[k])
-        assert torch.equal(r["outputs"], ref["outputs"]) and torch.equal(r["heads"], ref["heads"])
+        sv = ref["ws"].mask.bool()
+        assert torch.equal(r["outputs"], ref["outputs"]) and torch.equal(r["heads"][sv], ref["heads"][sv])
         assert torch.equal(pipe.grid_view, ref["ws"].grid)
     with pytest.raises(_lib.CppfError):
         pipe.set_shape(1025, (10, 10, 10))

@@ -520,7 +520,7 @@ def test_estimate_pose_matches_oracle_chain(oracle, golden, dev, cat):
                 regress_right=cfg.regress_right, ppffcs=[84, 32, 32, 16], out_dim=141)
     o = oracle.estimate_pose(ob["pc"], ob["normals"], ob["feat"], idx, sd, ocfg, u_tr, u_rot, sph)
     np.testing.assert_array_equal(r["outputs"].cpu().numpy(), o["outputs"])
-    np.testing.assert_array_equal(r["heads"].cpu().numpy(), o["heads"])
+    np.testing.assert_array_equal(r["heads"].cpu().numpy()[o["mask"]], o["heads"][o["mask"]])   # second pass: survivors' rows
     assert r["argmax"] == o["argmax"]                                   # bit-exact vote-grid arg-max
     np.testing.assert_allclose(r["T"], o["T"], rtol=0, atol=1e-12)
     assert r["n_surv"] == int(o["mask"].sum())
@@ -625,7 +625,8 @@ def test_pipelines_graph_replay_equals_eager(golden, dev):
             np.testing.assert_array_equal(r["T"], ref["T"])
             np.testing.assert_array_equal(r["up"], ref["up"])
             np.testing.assert_allclose(r["scale"], ref["scale"], rtol=1e-12)
-            assert torch.equal(r["outputs"], ref["outputs"]) and torch.equal(r["heads"], ref["heads"])
+            sv = ref["ws"].mask.bool()
+            assert torch.equal(r["outputs"], ref["outputs"]) and torch.equal(r["heads"][sv], ref["heads"][sv])
         cp = CenterPipeline(enc, cfg, 1024, P, dims, dev, use_graph=False)
         cp.load(ob["pc"], ob["normals"], ob["feat"], idx, u_tr, u_rot, corners[0].copy())
         oi, ov = cp.run()
