@@ -13,7 +13,7 @@ for line in open(sys.argv[1]):
         acc[kernel][m.group(1)] = float(m.group(2))
     elif line.strip() and not line.startswith(" "):
         kernel = line.strip()
-names = {"point_proj_kernel": "point_proj_kernel", "pair_mlp_kernel<false, true, true>": "pair_mlp_kernel<false, true, true>",
+names = {"point_proj_kernel": "point_proj_kernel", "pair_mlp_kernel<false, true, true, false>": "pair_mlp_kernel<false, true, true>",
          "vote_kernel<true, true>": "vote_kernel<true, true>", "reduce_argmax_kernel": "reduce_argmax_kernel",
          "reduce_tiles_kernel": "reduce_tiles_kernel",
          "sprin_conv_kernel": "sprin_conv_kernel", "knn_kernel<false>": "knn_kernel<false>"}
