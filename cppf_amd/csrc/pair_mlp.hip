@@ -198,12 +198,11 @@ __device__ __forceinline__ bool sample_seg(const float (&v)[NL], float u, int g,
     float mall = fmaxf(m, xor16f(m, lane));
     mall = fmaxf(mall, xor32f(mall, lane));
     float e[NL];
+    // (scalar instructions on purpose: beside the fp32 MFMAs, which run on the same datapath, a v_pk_fma_f32 costs as much as
+    //  the two v_fma_f32 it replaces or more -- packed exponentials and the compiler's SLP packing measured 2.5-3 % slower,
+    //  profiles/r2_pair_mlp_phases.txt; the Makefile passes -fno-slp-vectorize)
 #pragma unroll
-    for (int k = 0; k + 1 < NL; k += 2) {   // two exponentials per packed-fp32 instruction
-        const cppf_f32x2 ex = det_expf2(cppf_f32x2{v[k] - mall, v[k + 1] - mall});
-        e[k] = ex[0]; e[k + 1] = ex[1];
-    }
-    if (NL & 1) e[NL - 1] = det_expf(v[NL - 1] - mall);
+    for (int k = 0; k < NL; ++k) e[k] = det_expf(v[k] - mall);
     // running sums of the lane's segment: the last one is the segment total, and the draw compares them with the
     // threshold moved into the segment (t - off) -- one chain of NL - 1 additions serves both
     float b[NL];
