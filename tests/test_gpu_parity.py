@@ -134,6 +134,45 @@ def test_fused_decode_bit_exact(oracle, dev):
     assert torch.equal(out2, outputs) and torch.equal(heads2, heads)
 
 
+def test_second_pass_on_selected_pairs(oracle, dev):
+    """cppf_pair_mlp_decode_sel (nocs/inference.py:236-256 on point_idxs[mask]): the heads rows of the selected pairs equal
+    the full decode's (hence the oracle's), rows that are not selected are untouched, the count comes from the device, a
+    smaller max_sel caps it, an empty selection writes nothing; int32 and int64 pair lists."""
+    ob = syn.make_object("mug", 777, 9)
+    idx = syn.make_pairs(777, 20, 9)
+    P = idx.shape[0]
+    u_tr, u_rot = syn.make_uniforms(P, 9)
+    u_rot[::97] = -1.0
+    sd = seeded_sd(3)
+    for k in ("final.weight", "final.bias"):
+        sd[k] = sd[k] * 6
+    enc = make_encoder(sd, [84, 32, 32, 16], 141, dev)
+    cfg = ob["cfg"]
+    pc, nrm, feat, urot_d = t(ob["pc"], dev), t(ob["normals"], dev), t(ob["feat"], dev), t(u_rot, dev)
+    rng = np.random.default_rng(1)
+    for idx_d in (t(idx, dev), t(idx.astype(np.int32), dev)):
+        with torch.no_grad():
+            _, full = enc.forward_decode(pc, nrm, feat, idx_d, t(u_tr, dev), cfg.vote_range, urot_d)
+            enc.forward_decode(pc, nrm, feat, idx_d, t(u_tr, dev), cfg.vote_range, None)      # the first pass of a pose chain
+        for n_sel, max_sel in ((0, P), (1, P), (15, P), (16, P), (17, P), (1000, P), (1000, 333), (P, P)):
+            sel = np.sort(rng.choice(P, n_sel, replace=False)).astype(np.int32)
+            sel_d = torch.full((P,), -1, dtype=torch.int32, device=dev)                        # garbage behind the count
+            sel_d[:n_sel] = t(sel, dev)
+            cnt = torch.tensor([n_sel], dtype=torch.int32, device=dev)
+            heads = torch.full((P, 8), -3.0, dtype=torch.float32, device=dev)
+            with torch.no_grad():
+                enc.forward_decode_sel(pc, nrm, feat, idx_d, urot_d, sel_d, cnt, heads, max_sel=max_sel)
+            used = sel[:min(n_sel, max_sel)]
+            got = heads.cpu().numpy()
+            np.testing.assert_array_equal(got[used], full.cpu().numpy()[used])
+            rest = np.ones(P, bool)
+            rest[used] = False
+            assert np.all(got[rest] == -3.0)
+    lo = oracle.pair_mlp(ob["pc"], ob["normals"], ob["feat"], idx, sd, [84, 32, 32, 16], 141, order=1)
+    ho, _ = oracle.decode_rot(lo, u_rot, 32, 36)
+    np.testing.assert_array_equal(full.cpu().numpy(), ho)
+
+
 # ------------------------------------------------------------------------------------ centre vote
 def run_vote(dev, pc, outputs, idx32, corner, dims, res, n_rots, adaptive, probs=None, grid0=None):
     N = pc.shape[0]
