@@ -330,3 +330,49 @@ def test_point_encoder_backward_oracle_matches_reference_autograd(oracle, golden
     # the number of accumulators changes the summation tree, not the result (beyond rounding)
     _, flat1 = oracle.point_encoder_backward(z["pc"], z["nrm"], nbrs, packed, z["R"], n_parts=7)
     np.testing.assert_allclose(flat1, flat, rtol=0, atol=1e-5 * np.abs(flat).max())
+
+
+def test_two_independent_restatements_of_the_vote_kernels_agree(oracle):
+    """ppf_voting / backvote / rot_voting exist only as CUDA text in the reference (models/voting.py:4-148) and cannot be run
+    here, so they are restated twice, independently -- oracle/cppf_oracle.c (scalar C) and oracle/voting_numpy.py (vectorised
+    numpy written from the CUDA text) -- and the two must agree BIT FOR BIT on grids (same atomicAdd order), offsets and
+    candidates, including degenerate pairs, zero-rotation pairs, out-of-grid samples and both adaptive settings."""
+    import functools
+    from oracle import voting_numpy as VN
+    import cppf_amd.synthetic as syn
+    from cppf_amd.inference import grid_shape
+    cs = functools.lru_cache(maxsize=None)(oracle.rot_cs)
+    tan = functools.lru_cache(maxsize=None)(oracle.tanf)
+    rng = np.random.default_rng(11)
+    for case, (cat, n, k, n_rots, adaptive, res_scale, shift) in enumerate((
+            ("bottle", 300, 6, 72, True, 1.0, 0.0), ("mug", 200, 8, 72, False, 1.0, 0.0), ("laptop", 150, 10, 36, True, 1.7, 0.0),
+            ("camera", 256, 6, 7, True, 0.6, 0.03), ("bowl", 128, 8, 72, True, 1.0, -0.05))):
+        ob = syn.make_object(cat, n, 50 + case)
+        cfg = ob["cfg"]
+        res = float(np.float32(cfg.res * res_scale))
+        idx = syn.make_pairs(n, k, 50 + case).astype(np.int32)
+        idx[::17, 1] = idx[::17, 0]                                       # degenerate pairs (a == b)
+        out = syn.closed_form_outputs(ob["pc"], ob["center"], idx, cfg, quantise=(case % 2 == 0))
+        out[::13, 1] = 1e-5                                               # nu < res / 2 pi: zero rotations when adaptive
+        out[5::29, 1] *= -1                                               # negative nu
+        out[7::31, 0] += 0.4                                              # circles far outside the grid
+        probs = rng.uniform(0.25, 2.0, n).astype(np.float32) if case % 2 else np.ones(n, np.float32)
+        corners, dims = grid_shape(ob["pc"], res)
+        corner = (corners[0] + np.float32(shift)).astype(np.float32)      # shifted corner: many samples leave the grid
+        g_c = np.zeros(dims, np.float32)
+        na_c = oracle.ppf_voting(ob["pc"], out, probs, idx, g_c, corner, res, n_rots, adaptive)
+        g_n = np.zeros(dims, np.float32)
+        na_n = VN.ppf_voting(ob["pc"], out, probs, idx, g_n, corner, res, n_rots, adaptive, cs)
+        assert na_c == na_n and na_c > 1000, (case, na_c, na_n)
+        np.testing.assert_array_equal(g_n, g_c)
+        flat, _ = oracle.grid_argmax(g_c)
+        T = oracle.center_from_argmax(flat, dims, corner, res)
+        oo_c, mask_c = oracle.backvote(ob["pc"], out, idx, corner, res, n_rots, dims, T.astype(np.float32), np.float32(3 * res))
+        oo_n = VN.backvote(ob["pc"], out, idx, corner, res, n_rots, dims, T.astype(np.float32), np.float32(3 * res), cs)
+        np.testing.assert_array_equal(oo_n, oo_c)
+        assert mask_c.sum() > 10 and np.array_equal(mask_c, np.any(oo_n != 0, -1))
+        rot = rng.uniform(0, np.pi, idx.shape[0]).astype(np.float32)
+        rot[:4] = [0.0, np.float32(np.pi / 2), np.float32(np.pi), 1e-8]    # tan = 0, huge, ~-0, tiny
+        ca_c = oracle.rot_voting(ob["pc"], rot, idx, n_rots)
+        ca_n = VN.rot_voting(ob["pc"], rot, idx, n_rots, cs, tan)
+        np.testing.assert_array_equal(ca_n, ca_c)
