@@ -23,18 +23,20 @@ from .utils.util import fibonacci_sphere, num_sphere_bins
 
 class BatchPoseRunner:
     def __init__(self, encoders, device, num_rots=72, adaptive=True, angle_tol=1.5, max_rot_pairs=10000,
-                 use_graph=True, point_encoders=None, n_bucket=1024, max_pipelines=16, dynamic=True):
+                 use_graph=True, point_encoders=None, n_bucket=1024, max_pipelines=16, dynamic=True, n_lanes=2):
         """encoders: {category name: PPFEncoder on `device`} (the reference keeps one per category,
         nocs/inference.py:79-90).  point_encoders: optional {category name: PointEncoder}; objects of those
         categories need no `feat` -- kNN + SPRIN run at the head of the captured graph (:180-181).
         n_bucket: point capacities are multiples of it; max_pipelines: bound of the pipeline cache;
-        dynamic=False: one exact-shape pipeline per distinct instance shape (fixed-shape workloads only)."""
+        dynamic=False: one exact-shape pipeline per distinct instance shape (fixed-shape workloads only);
+        n_lanes: instances in flight (HIP streams, each with its own pipelines)."""
         self.encoders, self.device = encoders, device
         self.point_encoders = point_encoders or {}
         self.kw = dict(num_rots=num_rots, adaptive=adaptive, angle_tol=angle_tol, max_rot_pairs=max_rot_pairs,
                        use_graph=use_graph)
         self.sphere = np.array(fibonacci_sphere(num_sphere_bins(angle_tol)))      # :100-102
         self.n_bucket, self.max_pipelines, self.dynamic = int(n_bucket), int(max_pipelines), bool(dynamic)
+        self.n_lanes = max(1, int(n_lanes))
         self._pipes = OrderedDict()    # LRU: key -> PosePipeline
         self._staging = {}         # pinned host staging sets for the small per-instance arrays, see _stage()
         self._stage_pos = 0
@@ -131,10 +133,10 @@ class BatchPoseRunner:
         mine = sharding.shard_objects(len(objects), rank, world)
         raw = torch.zeros((max(len(mine), 1), 21), dtype=torch.float64, device=self.device)
         cfgs = []
-        # two instances in flight: consecutive instances alternate between two HIP streams, each with its own pipelines
+        # n_lanes instances in flight: consecutive instances rotate over the HIP streams, each with its own pipelines
         # (buffers + captured graph), so one instance's head overlaps the previous one's tail
         if self._streams is None:
-            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(2)]
+            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n_lanes)]
         main = torch.cuda.current_stream(self.device)
         for st in self._streams:
             st.wait_stream(main)
@@ -144,7 +146,7 @@ class BatchPoseRunner:
             corners, dims = grid_shape(obj["pc"], obj["cfg"].res)
             on_device = obj.get("point_idxs") is None
             n_pairs = int(obj["n_pairs"]) if on_device else obj["point_idxs"].shape[0]
-            lane = slot & 1
+            lane = slot % self.n_lanes
             pipe = self._pipe(obj["cfg"], obj["pc"].shape[0], n_pairs, dims, lane)
             with torch.cuda.stream(self._streams[lane]):
                 self._stage(pipe, obj["pc"], obj["normals"], obj.get("feat") if pipe.point_encoder is None else None,
