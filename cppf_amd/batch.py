@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import sharding
-from .inference import PosePipeline, assemble_record, grid_class, grid_shape
+from .inference import PosePipeline, assemble_batch, grid_class, grid_shape
 from .utils.util import fibonacci_sphere, num_sphere_bins
 
 
@@ -140,7 +140,8 @@ class BatchPoseRunner:
         main = torch.cuda.current_stream(self.device)
         for st in self._streams:
             st.wait_stream(main)
-        for slot, j in enumerate(mine):
+        checked = set()          # pipelines whose weight images were looked at in this batch (once is enough: nothing
+        for slot, j in enumerate(mine):   # updates parameters while run() is on the stack)
             obj = objects[j]
             self._check(j, obj)
             corners, dims = grid_shape(obj["pc"], obj["cfg"].res)
@@ -157,12 +158,11 @@ class BatchPoseRunner:
                     gen = torch.Generator(device=self.device)
                     gen.manual_seed(int(seed) * 1000003 + j)
                     pipe.sample_inputs(gen, n_points=obj["pc"].shape[0])
-                pipe.run_async(raw[slot])
+                pipe.run_async(raw[slot], check_weights=id(pipe) not in checked)
+                checked.add(id(pipe))
             cfgs.append(obj["cfg"])
         for st in self._streams:
             main.wait_stream(st)
         host = raw.cpu().numpy()                       # the batch's only synchronisation
-        recs = [sharding.pack_record(j, assemble_record(host[slot], cfgs[slot])) for slot, j in enumerate(mine)]
-        local = torch.stack(recs).to(self.device) if recs else \
-            torch.zeros((0, sharding.RECORD), dtype=torch.float64, device=self.device)
+        local = torch.from_numpy(assemble_batch(host[:len(mine)], cfgs, mine, sharding.RECORD)).to(self.device)
         return sharding.gather_records(local, len(objects), rank, world, self.device)

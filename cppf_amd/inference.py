@@ -104,14 +104,23 @@ def estimate_center(encoder, pc, pc_normal, feat, point_idxs, u_tr, cfg, corner,
     return ws.out_idx, ws.out_val, outputs, heads, ws.grid
 
 
+_grid_class_cache = {}
+
+
 def grid_class(dims):
     """(tiles, many_tiles, cell capacity) of the shape-polymorphic vote for a grid of `dims`: launches come in two
     geometries, < 4 LDS tiles (256 workgroups, <= 3 tiles of cells) and <= 64 tiles (2 048 workgroups, <= 64 tiles of cells);
     tiles == 0: the grid needs more than the tiled vote serves -- only the exact-shape pipeline runs it."""
-    L = _lib.lib()
-    T = int(L.cppf_vote_tiles(int(dims[0]), int(dims[1]), int(dims[2])))
-    many = T >= 4
-    return T, many, (64 if many else 3) * int(L.cppf_vote_tile_cells())
+    key = (int(dims[0]), int(dims[1]), int(dims[2]))
+    hit = _grid_class_cache.get(key)
+    if hit is None:
+        L = _lib.lib()
+        T = int(L.cppf_vote_tiles(*key))
+        many = T >= 4
+        hit = (T, many, (64 if many else 3) * int(L.cppf_vote_tile_cells()))
+        if len(_grid_class_cache) < 4096:
+            _grid_class_cache[key] = hit
+    return hit
 
 
 class CenterPipeline:
@@ -149,7 +158,8 @@ class CenterPipeline:
         self.pc, self.nrm, self.feat = z(n_points, 3), z(n_points, 3), z(n_points, F)
         self.idx = z(n_pairs, 2, dtype=torch.int64)
         self.idx32 = z(n_pairs, 2, dtype=I32)
-        self.u_tr, self.u_rot = z(n_pairs, 2), z(n_pairs, 2)
+        self._u = z(2, n_pairs, 2)                     # one buffer: device-side sampling fills both with one launch
+        self.u_tr, self.u_rot = self._u[0], self._u[1]
         self.corner = z(3)
         self.probs = torch.ones(n_points, dtype=F32, device=device)           # nocs/inference.py:201
         if self.dynamic:
@@ -248,7 +258,9 @@ class CenterPipeline:
             ids.append(self.point_encoder._packed_weights(self.device)[0].data_ptr())
         return tuple(ids)
 
-    def run(self):
+    def run(self, check_weights=True):
+        """check_weights=False skips the per-run look at the encoders' parameters (a caller that runs many instances
+        between parameter updates checks once per batch: BatchPoseRunner)."""
         # scratch requested by the chain belongs to this pipeline (see workspace_scope): pipelines replay concurrently
         with torch.no_grad(), workspace_scope(id(self)):
             if not self._use_graph:
@@ -256,7 +268,7 @@ class CenterPipeline:
                 return self.out_idx, self.out_val
             # a changed parameter is re-packed here, on this stream, into the buffer the captured launches read; if the
             # image itself moved (device change, other size) the captured addresses are stale: capture again
-            images = self._weight_images()
+            images = self._weight_images() if check_weights or self._graph is None else self._images
             if self._graph is not None and images != self._images:
                 self._graph = None
             if self._graph is None:
@@ -474,17 +486,17 @@ class PosePipeline(CenterPipeline):
                       shape=self.shape if self.dynamic else None,
                       second_pass=(self.encoder, self.feat, self.idx, self.u_rot))
 
-    def run(self, rng=None):
-        super().run()
+    def run(self, rng=None, check_weights=True):
+        super().run(check_weights)
         out = _assemble(self.ws.rec.cpu().numpy(), self.cfg, rng)
         out.update(dims=self.dims, ws=self.ws, outputs=self.outputs, heads=self.heads)
         return out
 
-    def run_async(self, record_out):
+    def run_async(self, record_out, check_weights=True):
         """Replay the graph and copy the 21-double record into `record_out` (device f64[21]) on the current stream:
         no host synchronisation, so a batch of instances runs back to back (BatchPoseRunner reads all records back at
         once and assembles the poses with `assemble_record`)."""
-        super().run()
+        super().run(check_weights)
         record_out.copy_(self.ws.rec, non_blocking=True)
 
     def sample_inputs(self, generator, n_points=None):
@@ -493,8 +505,42 @@ class PosePipeline(CenterPipeline):
         at C2 that never cross PCIe.  Same distribution, not the same stream of numbers -- parity tests pass explicit arrays."""
         n = self.shape_host[0] if self.dynamic else self.pc.shape[0]
         self.idx.random_(0, int(n_points) if n_points is not None else n, generator=generator)
-        self.u_tr.uniform_(0.0, 1.0, generator=generator)
-        self.u_rot.uniform_(0.0, 1.0, generator=generator)
+        self._u.uniform_(0.0, 1.0, generator=generator)
+
+
+def assemble_batch(recs, cfgs, object_ids, n_cols):
+    """_assemble + sharding.pack_record for a whole batch in one numpy pass: recs f64[n,21] (read back from the device),
+    cfgs a list of n category configs -> f64[n, n_cols] = {T, up, right, scale, argmax, peak, n_surv, object id}.
+    Same arithmetic per row as _assemble (nocs/inference.py:299-339); a row whose `right` degenerates (|right| < 1e-7, :325)
+    goes through _assemble itself for its random fallback."""
+    recs = np.asarray(recs, dtype=np.float64).reshape(-1, 21)
+    n = recs.shape[0]
+    out = np.zeros((n, n_cols), np.float64)
+    if n == 0:
+        return out
+    if np.any(recs[:, 19] < 0):
+        raise _lib.CppfError("an instance shape did not fit the shape-polymorphic pipeline it ran on (arg-max index -1)")
+    rr = np.array([bool(c.regress_right) for c in cfgs])
+    sm = np.array([c.scale_mean for c in cfgs], np.float64)
+    best = recs[:, 3:9].reshape(n, 2, 3)
+    sign = recs[:, 9:15].reshape(n, 2, 3)
+    cnt = np.maximum(sign[:, :, 2], 1.0)
+    flip = (sign[:, :, 1] / cnt) < (sign[:, :, 0] / cnt)                  # down_loss < up_loss  (:299-302)
+    dirs = np.where(flip[:, :, None], -best, best)
+    up = dirs[:, 0]
+    right_r = dirs[:, 1] - np.sum(up * dirs[:, 1], -1, keepdims=True) * up  # :305-312
+    right_n = np.stack([np.zeros(n), -up[:, 2], up[:, 1]], -1)
+    right = np.where(rr[:, None], right_r, right_n)
+    right = right / (np.linalg.norm(right, axis=-1, keepdims=True) + 1e-9)
+    n_surv = recs[:, 18].astype(np.int64)
+    mean = (recs[:, 15:18] / np.maximum(n_surv, 1)[:, None]).astype(np.float32)     # torch mean is fp32
+    scale = np.exp(mean).astype(np.float64) * sm * 2                                  # :335
+    out[:, 0:3], out[:, 3:6], out[:, 6:9], out[:, 9:12] = recs[:, 0:3], up, right, scale
+    out[:, 12], out[:, 13], out[:, 14], out[:, 15] = recs[:, 19], recs[:, 20], n_surv, np.asarray(object_ids, np.float64)
+    for i in np.nonzero(np.linalg.norm(right, axis=-1) < 1e-7)[0]:                    # :325-328, random fallback
+        p = _assemble(recs[i], cfgs[i])
+        out[i, 3:6], out[i, 6:9] = p["up"], p["right"]
+    return out
 
 
 def assemble_record(rec, cfg, rng=None):
