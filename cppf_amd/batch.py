@@ -74,31 +74,34 @@ class BatchPoseRunner:
     _RING = 4
 
     def _stage(self, pipe, pc, normals, feat, corner, dims):
-        """cloud, normals, (features,) grid corner (and, for a dynamic pipeline, the shape record) -> the pipeline's device
-        buffers through PINNED host memory, so the copies are truly asynchronous (a copy from pageable memory blocks the host
-        until everything queued before it has run, i.e. until the previous instance has finished).  A ring of staging sets
-        per point capacity, each guarded by an event."""
+        """cloud, normals, grid corner and (dynamic pipelines) the shape record -> the pipeline's input buffer with ONE copy
+        through PINNED host memory, so the copy is truly asynchronous (a copy from pageable memory blocks the host until
+        everything queued before it has run, i.e. until the previous instance has finished); features, when the caller
+        supplies them, with a second one.  A ring of staging sets per point capacity, each guarded by an event."""
         n, cap = pc.shape[0], pipe.n_points
         key = (cap, None if feat is None else feat.shape[1])
         ring = self._staging.get(key)
         if ring is None:
-            mk = lambda *shape, dtype=torch.float32: torch.empty(shape, dtype=dtype).pin_memory()
-            ring = [dict(pc=mk(cap, 3), nrm=mk(cap, 3), corner=mk(3), shape=mk(4, dtype=torch.int32),
-                         feat=None if feat is None else mk(cap, feat.shape[1]), ev=torch.cuda.Event())
-                    for _ in range(self._RING)]
+            mk = lambda *shape: torch.empty(shape, dtype=torch.float32).pin_memory()
+            ring = []
+            for _ in range(self._RING):
+                buf = mk(6 * cap + 8)
+                buf.zero_()
+                arr = buf.numpy()
+                ring.append(dict(buf=buf, pc=arr[:3 * cap].reshape(cap, 3), nrm=arr[3 * cap:6 * cap].reshape(cap, 3),
+                                 corner=arr[6 * cap:6 * cap + 3], shape=arr[6 * cap + 4:6 * cap + 8].view(np.int32),
+                                 feat=None if feat is None else mk(cap, feat.shape[1]), ev=torch.cuda.Event()))
             self._staging[key] = ring
         st = ring[self._stage_pos % self._RING]
         self._stage_pos += 1
         st["ev"].synchronize()                          # the copies that last read this set have executed
-        st["pc"].numpy()[:n] = pc
-        st["nrm"].numpy()[:n] = normals
-        st["corner"].numpy()[...] = corner
-        pipe.pc[:n].copy_(st["pc"][:n], non_blocking=True)
-        pipe.nrm[:n].copy_(st["nrm"][:n], non_blocking=True)
-        pipe.corner.copy_(st["corner"], non_blocking=True)
+        st["pc"][:n] = pc
+        st["nrm"][:n] = normals
+        st["corner"][...] = corner
         if pipe.dynamic:
-            st["shape"].numpy()[...] = (n,) + tuple(dims)
-            pipe.set_shape(n, dims, shape_src=st["shape"])
+            st["shape"][...] = (n,) + tuple(dims)
+            pipe.set_shape(n, dims, upload=False)
+        pipe._in.copy_(st["buf"], non_blocking=True)    # (rows behind the cloud carry stale values nobody reads)
         if feat is not None:
             st["feat"].numpy()[:n] = feat
             pipe.feat[:n].copy_(st["feat"][:n], non_blocking=True)

@@ -155,12 +155,17 @@ class CenterPipeline:
         self.n_points, self.n_pairs, self.dynamic = int(n_points), int(n_pairs), bool(dynamic)
         F = (encoder.ppffcs[0] - 4) // 2
         z = lambda *shape, dtype=F32: torch.zeros(shape, dtype=dtype, device=device)
-        self.pc, self.nrm, self.feat = z(n_points, 3), z(n_points, 3), z(n_points, F)
+        # the small per-instance inputs live in ONE buffer -- points | normals | corner | shape record -- so that a caller can
+        # stage and upload them with a single copy (BatchPoseRunner); pc / nrm / corner / shape are views into it
+        n = self.n_points
+        self._in = z(6 * n + 8)
+        self.pc, self.nrm = self._in[:3 * n].view(n, 3), self._in[3 * n:6 * n].view(n, 3)
+        self.feat = z(n_points, F)
         self.idx = z(n_pairs, 2, dtype=torch.int64)
         self.idx32 = z(n_pairs, 2, dtype=I32)
         self._u = z(2, n_pairs, 2)                     # one buffer: device-side sampling fills both with one launch
         self.u_tr, self.u_rot = self._u[0], self._u[1]
-        self.corner = z(3)
+        self.corner = self._in[6 * n:6 * n + 3]
         self.probs = torch.ones(n_points, dtype=F32, device=device)           # nocs/inference.py:201
         if self.dynamic:
             if isinstance(dims, (bool, np.bool_)):
@@ -170,7 +175,7 @@ class CenterPipeline:
                 if T == 0:
                     raise _lib.CppfError(f"grid {tuple(dims)} needs more LDS tiles than the shape-polymorphic vote serves")
             self.grid_flat = z((64 if self.many_tiles else 3) * int(_lib.lib().cppf_vote_tile_cells()))
-            self.shape = z(4, dtype=I32)                                       # {n_points, gx, gy, gz}, read by the *_dyn kernels
+            self.shape = self._in[6 * n + 4:6 * n + 8].view(I32)               # {n_points, gx, gy, gz}, read by the *_dyn kernels
             self.shape_host = (0, 0, 0, 0)
             self.dims = None
             if point_encoder is not None:
@@ -189,9 +194,10 @@ class CenterPipeline:
         self._use_graph = use_graph
         self._images = None
 
-    def set_shape(self, n_points, dims, shape_src=None):
+    def set_shape(self, n_points, dims, shape_src=None, upload=True):
         """dynamic pipelines: the next run's real shape.  `shape_src`: a (pinned) host i32[4] tensor the caller has filled
-        with {n_points, gx, gy, gz} -- copied asynchronously; without it a small synchronous upload is made."""
+        with {n_points, gx, gy, gz} -- copied asynchronously; without it a small synchronous upload is made;
+        upload=False: the caller writes the record itself (it is part of the `_in` buffer)."""
         if not self.dynamic:
             raise _lib.CppfError("set_shape() is for dynamic pipelines")
         T, many, cap = grid_class(dims)
@@ -202,6 +208,8 @@ class CenterPipeline:
                                  f"(N in {k_min}..{self.n_points}, many_tiles={self.many_tiles})")
         self.shape_host = (int(n_points), int(dims[0]), int(dims[1]), int(dims[2]))
         self.dims = self.shape_host[1:]
+        if not upload:
+            return
         if shape_src is None:
             shape_src = torch.tensor(self.shape_host, dtype=I32)
         self.shape.copy_(shape_src, non_blocking=True)
