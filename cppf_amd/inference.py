@@ -48,13 +48,15 @@ class PoseWorkspace:
         self.out_val = torch.empty(1, dtype=F32, device=device)
         # the 21-double result record; T64 / best_dir / sign / scale are views into it, so the kernels write the
         # record directly and the read-back is one copy
-        self.rec = torch.zeros(21, dtype=torch.float64, device=device)
+        # (the record and the sphere-bin counts share one buffer: both start every tail zeroed, with one fill)
+        self._tail0 = torch.zeros(176 + 2 * n_sphere * 4, dtype=torch.uint8, device=device)
+        self.rec = self._tail0[:168].view(torch.float64)
         self.T64 = self.rec[0:3]
         self.T32 = torch.empty(3, dtype=F32, device=device)
         self.mask = torch.empty(n_pairs, dtype=torch.uint8, device=device)
         self.surv = torch.empty(n_pairs, dtype=I32, device=device)
         self.count = torch.empty(1, dtype=I32, device=device)
-        self.counts = torch.empty((2, n_sphere), dtype=I32, device=device)
+        self.counts = self._tail0[176:].view(I32).view(2, n_sphere)
         self.best_idx = torch.empty(2, dtype=torch.int64, device=device)
         self.best_dir = self.rec[3:9].view(2, 3)
         self.sign = self.rec[9:15].view(2, 3)
@@ -356,6 +358,7 @@ def _enqueue_tail(ws, pc, pc_normal, idx32, outputs, heads, corner, cfg, dims, n
     st = stream_ptr(dev)
     P, S = idx32.shape[0], sph32_d.shape[0]
     with torch.cuda.device(dev):
+        ws._tail0.zero_()                                                     # record (best_dir, sign sums, ...) and bin counts
         # the vote's workspace (same scope, same tag as models/voting.py): its rotation table is reused by the back-vote
         vws = workspace(256, dev, "vote_dyn" if shape is not None else "vote")
         if shape is not None:
@@ -384,8 +387,6 @@ def _enqueue_tail(ws, pc, pc_normal, idx32, outputs, heads, corner, cfg, dims, n
         # orientation (:259-303) -------------------------------------------------------------------
         thr = float(np.float32(np.cos(angle_tol / 180 * np.pi)))
         n_dirs = 2 if cfg.regress_right else 1
-        ws.counts.zero_()
-        ws.rec[3:15].zero_()                                                  # best_dir, sign
         rws = workspace(L.cppf_reduce_workspace_bytes(), dev, "reduce")
         for j in range(n_dirs):
             _lib.check(L.cppf_rot_sphere_count(pc.data_ptr(), heads.data_ptr() + 4 * j, 8, idx32.data_ptr(),
