@@ -59,6 +59,8 @@ _SIGS = {
     "cppf_pair_mlp_backward": (C.c_int, [vp, vp, vp, vp, i32, vp, C.POINTER(C.c_int64), i64, i32, C.POINTER(C.c_int), i32,
                                          i64, i32, vp, vp, vp, vp, sz, vp]),
     "cppf_knn": (C.c_int, [vp, vp, i32, i32, vp, vp]),
+    "cppf_backproject_workspace_bytes": (sz, [i32, i32]),
+    "cppf_backproject": (C.c_int, [vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
     "cppf_voxel_dedupe_workspace_bytes": (sz, [i64]),
     "cppf_voxel_dedupe": (C.c_int, [vp, i64, C.c_double, vp, vp, vp, sz, vp]),
     "cppf_estimate_normals": (C.c_int, [vp, vp, i64, i32, vp, vp]),

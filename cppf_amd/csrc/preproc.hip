@@ -36,6 +36,34 @@ __global__ __launch_bounds__(256) void vox_mark_kernel(const int64_t* __restrict
     if (i == 0 || skeys[i] != skeys[i - 1]) mask[svals[i]] = 1;
 }
 
+// utils/util.py:598-631 backproject: valid = mask & (depth > 0) (:609-610); pixels in row-major order (np.where, :612);
+// xyz = inv(K) @ (u, v, 1) (:622); pts = xyz * z / xyz.z (:628); x and y negated (:629-630).  fp64 like numpy; the 3-term
+// products as k0*u, then fma(k1, v, .), then + k2 (oracle/preproc_oracle.c:orc_backproject is the same sequence).
+template <typename T>
+__global__ __launch_bounds__(256) void bp_valid_kernel(const T* __restrict__ depth, const uint8_t* __restrict__ mask, int64_t n,
+                                                       uint8_t* __restrict__ valid)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) valid[i] = (mask[i] != 0) && (depth[i] > (T)0);
+}
+struct Kinv { double k[9]; };
+template <typename T>
+__global__ __launch_bounds__(256) void bp_points_kernel(const T* __restrict__ depth, const int32_t* __restrict__ pix,
+                                                        const int32_t* __restrict__ count, int W, Kinv K,
+                                                        double* __restrict__ pts)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= *count) return;
+    const int p = pix[i];
+    const double u = (double)(p % W), v = (double)(p / W), z = (double)depth[p];
+    double xyz[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xyz[c] = fma(K.k[3 * c + 1], v, K.k[3 * c] * u) + K.k[3 * c + 2];
+    pts[3 * i] = -(xyz[0] * z / xyz[2]);
+    pts[3 * i + 1] = -(xyz[1] * z / xyz[2]);
+    pts[3 * i + 2] = xyz[2] * z / xyz[2];
+}
+
 // smallest-eigenvalue eigenvector of a symmetric 3x3 matrix by 8 cyclic Jacobi sweeps in fp64 (oracle/preproc_oracle.c)
 __device__ void smallest_eigvec(double a00, double a01, double a02, double a11, double a12, double a22, double* out)
 {
@@ -155,6 +183,35 @@ int cppf_voxel_dedupe(const float* pc, int64_t n_points, double res, int32_t* ke
     if (e != hipSuccess) return (int)e;
     vox_mark_kernel<<<nb, 256, 0, st>>>(skeys, svals, n_points, mask);
     return cppf_compact_mask(mask, n_points, keep_idx, count, ws + L.compact, cppf_compact_workspace_bytes(n_points), stream);
+}
+
+size_t cppf_backproject_workspace_bytes(int H, int W)
+{
+    if (H < 1 || W < 1) return 0;
+    const int64_t n = (int64_t)H * W;
+    return (size_t)((n + 255) / 256 * 256) + cppf_compact_workspace_bytes(n);
+}
+
+int cppf_backproject(const void* depth, int depth_is_u16, const uint8_t* mask, int H, int W, const double* kinv_host,
+                     double* pts, int32_t* pix, int32_t* count, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (H < 1 || W < 1 || (int64_t)H * W > 0x7fffffffll || !depth || !mask || !kinv_host || !pts || !pix || !count)
+        return CPPF_EINVAL;
+    if (!workspace || workspace_bytes < cppf_backproject_workspace_bytes(H, W)) return CPPF_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = (int64_t)H * W;
+    uint8_t* valid = static_cast<uint8_t*>(workspace);
+    char* cws = static_cast<char*>(workspace) + (n + 255) / 256 * 256;
+    const int nb = (int)((n + 255) / 256);
+    if (depth_is_u16) bp_valid_kernel<uint16_t><<<nb, 256, 0, st>>>((const uint16_t*)depth, mask, n, valid);
+    else bp_valid_kernel<float><<<nb, 256, 0, st>>>((const float*)depth, mask, n, valid);
+    int rc = cppf_compact_mask(valid, n, pix, count, cws, cppf_compact_workspace_bytes(n), stream);
+    if (rc) return rc;
+    Kinv K;
+    for (int i = 0; i < 9; ++i) K.k[i] = kinv_host[i];
+    if (depth_is_u16) bp_points_kernel<uint16_t><<<nb, 256, 0, st>>>((const uint16_t*)depth, pix, count, W, K, pts);
+    else bp_points_kernel<float><<<nb, 256, 0, st>>>((const float*)depth, pix, count, W, K, pts);
+    return (int)hipGetLastError();
 }
 
 int cppf_estimate_normals(const float* pc, const int32_t* nbrs, int64_t n_points, int k, float* normals, void* stream)

@@ -34,6 +34,52 @@ def _device_cloud(pc):
     return t.detach().float().contiguous(), was_np
 
 
+def backproject(depth, intrinsics, instance_mask, return_device=False):
+    """utils/util.py:598-631 `backproject(depth, intrinsics, instance_mask)` (nocs/inference.py:131) on the device: the
+    pixels of the instance mask with depth > 0, in row-major order, through inv(intrinsics) in fp64, x and y negated like
+    the reference.  depth: [H,W] uint16 (NOCS depth PNGs) / float32 / anything castable, numpy or device tensor;
+    instance_mask: [H,W] bool / uint8.  Returns (pts f64[n,3], (rows, cols)) as numpy like the reference, or device tensors
+    (pts, flat pixel index i32[n]) with return_device=True (no host round trip: the cloud can go straight into
+    sparse_quantize / estimate_normals / the encoders).  The depth image of a frame can be uploaded once and reused for
+    all of its instances (pass the device tensor)."""
+    import torch
+    from .. import _lib
+    from .._torch_util import require_cuda, stream_ptr, workspace
+    require_cuda()
+
+    def dev(x, kinds):
+        t = torch.from_numpy(np.ascontiguousarray(x)) if isinstance(x, np.ndarray) else x
+        if t.dtype not in kinds:
+            t = t.to(kinds[-1])
+        return (t if t.is_cuda else t.cuda()).contiguous()
+
+    d = depth
+    if isinstance(d, np.ndarray) and d.dtype == np.uint16:
+        d = torch.from_numpy(np.ascontiguousarray(d).view(np.int16))       # torch has no uint16 arithmetic; bits are what matter
+    d = dev(d, (torch.int16, torch.float32))
+    m = dev(instance_mask, (torch.uint8, torch.bool, torch.uint8))
+    if m.dtype == torch.bool:
+        m = m.view(torch.uint8)
+    if d.dim() != 2 or tuple(m.shape) != tuple(d.shape):
+        raise ValueError(f"depth {tuple(d.shape)} and instance_mask {tuple(m.shape)} must be the same [H,W]")
+    H, W = d.shape
+    kinv = np.ascontiguousarray(np.linalg.inv(np.asarray(intrinsics, np.float64)))
+    pts = torch.empty((H * W, 3), dtype=torch.float64, device=d.device)
+    pix = torch.empty(H * W, dtype=torch.int32, device=d.device)
+    count = torch.zeros(1, dtype=torch.int32, device=d.device)
+    L = _lib.lib()
+    ws = workspace(L.cppf_backproject_workspace_bytes(H, W), d.device, "backproject")
+    with torch.cuda.device(d.device):
+        _lib.check(L.cppf_backproject(d.data_ptr(), 1 if d.dtype == torch.int16 else 0, m.data_ptr(), H, W, kinv.ctypes.data,
+                                      pts.data_ptr(), pix.data_ptr(), count.data_ptr(), ws.data_ptr(), ws.numel(),
+                                      stream_ptr(d.device)), "cppf_backproject")
+    n = int(count.item())
+    if return_device:
+        return pts[:n], pix[:n]
+    p = pix[:n].cpu().numpy().astype(np.int64)
+    return pts[:n].cpu().numpy(), (p // W, p % W)
+
+
 def estimate_normals(pc, knn):
     """utils/util.py:61-65 `estimate_normals(pc, knn)` (open3d PCA normals over the knn nearest neighbours, the point
     itself included) on the device: neighbour selection (csrc/sprin.hip) + a 3x3 Jacobi per point (csrc/preproc.hip).

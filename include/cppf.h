@@ -370,7 +370,16 @@ int cppf_point_encoder_forward_train(const float* pc, const float* nrm, const in
  *                        i32[n_points, k] (cppf_knn output: the point itself is a neighbour); normals device
  *                        f32[n_points, 3] = unit eigenvector of the smallest eigenvalue of the neighbours' covariance
  *                        (fp64 cumulants, 8 Jacobi sweeps), sign: component of largest magnitude positive.
+ *  cppf_backproject      utils/util.py:598-631 `backproject(depth, intrinsics, instance_mask)` (nocs/inference.py:131): the
+ *                        pixels with mask != 0 and depth > 0, in row-major order, back-projected through inv(intrinsics) in
+ *                        fp64: pts device f64[H*W,3] (x and y negated like the reference's return value), pix device
+ *                        i32[H*W] = v*W + u of each point (the reference's `idxs`), count device i32[1].  depth: device
+ *                        u16[H,W] (depth_is_u16 != 0; NOCS depth PNGs) or f32[H,W]; mask device u8[H,W]; kinv_host: HOST
+ *                        f64[9], row-major inverse of the 3x3 intrinsics.
  * ------------------------------------------------------------------------------------------- */
+size_t cppf_backproject_workspace_bytes(int H, int W);
+int cppf_backproject(const void* depth, int depth_is_u16, const uint8_t* mask, int H, int W, const double* kinv_host,
+                     double* pts, int32_t* pix, int32_t* count, void* workspace, size_t workspace_bytes, void* stream);
 size_t cppf_voxel_dedupe_workspace_bytes(int64_t n_points);
 int cppf_voxel_dedupe(const float* pc, int64_t n_points, double res, int32_t* keep_idx, int32_t* count, void* workspace,
                       size_t workspace_bytes, void* stream);

@@ -505,6 +505,21 @@ def voxel_dedupe(pc, res):
     return keep[:n].copy()
 
 
+def backproject(depth, intrinsics, instance_mask):
+    """utils/util.py:598-631 -> (pts f64[n,3], (rows, cols)) like the reference"""
+    d = np.ascontiguousarray(depth, dtype=np.float64)
+    m = np.ascontiguousarray(instance_mask).astype(np.uint8)
+    H, W = d.shape
+    kinv = np.ascontiguousarray(np.linalg.inv(np.asarray(intrinsics, np.float64)))
+    pts = np.empty((H * W, 3), np.float64)
+    pix = np.empty(H * W, np.int32)
+    f = lib().orc_backproject
+    f.restype = C.c_int64
+    n = f(_p(d, _pd), _p(m, _pu8), C.c_int(H), C.c_int(W), _p(kinv, _pd), _p(pts, _pd), _p(pix, _pi32))
+    pix = pix[:n]
+    return pts[:n].copy(), (pix // W, pix % W)
+
+
 def estimate_normals(pc, nbrs):
     """PCA normals of the neighbour sets (utils/util.py:61-65 semantics, sign: largest component positive)"""
     pc, nbrs = _c(pc, _f), _c(nbrs, np.int32)

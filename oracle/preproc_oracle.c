@@ -119,3 +119,25 @@ void orc_estimate_normals(const float* pc, const int32_t* nbrs, int64_t N, int k
         for (int i = 0; i < 3; ++i) normals[3 * n + i] = (float)v[i];
     }
 }
+
+/* utils/util.py:598-631 backproject: pixels with mask != 0 and depth > 0 in row-major order (np.where); xyz = inv(K) @ (u, v, 1)
+ * with each 3-term product as k0*u, fma(k1, v, .), + k2; pts = xyz * z / xyz.z; x and y negated.  depth as double (exact for
+ * u16 and f32 inputs).  Returns the number of points; pix[i] = v*W + u. */
+int64_t orc_backproject(const double* depth, const uint8_t* mask, int H, int W, const double* kinv, double* pts, int32_t* pix)
+{
+    int64_t n = 0;
+    for (int v = 0; v < H; ++v)
+        for (int u = 0; u < W; ++u) {
+            const int64_t p = (int64_t)v * W + u;
+            if (!mask[p] || !(depth[p] > 0.0)) continue;
+            double xyz[3];
+            for (int c = 0; c < 3; ++c) xyz[c] = fma(kinv[3 * c + 1], (double)v, kinv[3 * c] * (double)u) + kinv[3 * c + 2];
+            const double z = depth[p];
+            pts[3 * n] = -(xyz[0] * z / xyz[2]);
+            pts[3 * n + 1] = -(xyz[1] * z / xyz[2]);
+            pts[3 * n + 2] = xyz[2] * z / xyz[2];
+            pix[n] = (int32_t)p;
+            ++n;
+        }
+    return n;
+}

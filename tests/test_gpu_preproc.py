@@ -92,3 +92,30 @@ def test_raw_points_to_pose_entirely_on_device(dev, oracle):
     assert r["argmax"] == o["argmax"] and r["n_surv"] == int(o["mask"].sum())
     assert np.allclose(r["T"], o["T"], atol=1e-9) and np.allclose(r["up"], o["up"], atol=1e-9)
     assert np.allclose(r["scale"], o["scale"], rtol=1e-5)
+
+
+def test_backproject_on_device_equals_oracle(oracle, golden, dev):
+    """cppf_backproject (utils/util.py:598-631 on the device): pixel list and fp64 points bit for bit the oracle's, which
+    tests/test_oracle_golden.py pins on the reference's own function; uint16 and float32 depth, numpy and device inputs,
+    an empty mask; and the cloud goes on to voxel de-duplication without leaving the device."""
+    from cppf_amd.utils.util import backproject, sparse_quantize
+    g = golden("backproject.npz")
+    K = g["intrinsics"]
+    for k in range(2):
+        for d in (g["depth"], g["depth"].astype(np.float32) * np.float32(0.37)):
+            po, (ro, co) = oracle.backproject(d, K, g["masks"][k])
+            pts, (rows, cols) = backproject(d, K, g["masks"][k])
+            assert np.array_equal(rows, ro) and np.array_equal(cols, co)
+            assert np.array_equal(pts, po)
+    pts, (rows, cols) = backproject(g["depth"], K, np.zeros_like(g["masks"][0]))
+    assert pts.shape == (0, 3) and rows.size == 0
+    # device in, device out: one depth upload per frame, the points never visit the host
+    d_dev = torch.from_numpy(g["depth"].view(np.int16)).to(dev)
+    pd, pix = backproject(d_dev, K, torch.from_numpy(g["masks"][0]).to(dev), return_device=True)
+    po, (ro, co) = oracle.backproject(g["depth"], K, g["masks"][0])
+    assert pd.is_cuda and np.array_equal(pd.cpu().numpy(), po) and np.array_equal(pix.cpu().numpy(), ro * g["depth"].shape[1] + co)
+    pc = (pd / 1000.0)                                                      # nocs/inference.py:132
+    pc = torch.stack([-pc[:, 0], -pc[:, 1], pc[:, 2]], -1).float()          # :136-137
+    _, keep = sparse_quantize(pc, return_index=True, quantization_size=0.004)
+    ko = oracle.voxel_dedupe(pc.cpu().numpy(), 0.004)
+    assert np.array_equal(keep.cpu().numpy() if hasattr(keep, "cpu") else keep, ko)

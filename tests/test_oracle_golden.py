@@ -376,3 +376,17 @@ def test_two_independent_restatements_of_the_vote_kernels_agree(oracle):
         ca_c = oracle.rot_voting(ob["pc"], rot, idx, n_rots)
         ca_n = VN.rot_voting(ob["pc"], rot, idx, n_rots, cs, tan)
         np.testing.assert_array_equal(ca_n, ca_c)
+
+
+def test_backproject_oracle_matches_the_reference_function(oracle, golden):
+    """utils/util.py:598-631 executed from its own source (tests/golden/make_golden_backproject.py): same pixels in the same
+    order, points to the last bits (numpy's 3x3 product may associate differently: 1e-13 relative)."""
+    g = golden("backproject.npz")
+    for k in range(2):
+        for tag, d in (("u16", g["depth"]), ("f32", g["depth"].astype(np.float32) * np.float32(0.37))):
+            pts, (rows, cols) = oracle.backproject(d, g["intrinsics"], g["masks"][k])
+            np.testing.assert_array_equal(rows, g[f"rows_{tag}_{k}"])
+            np.testing.assert_array_equal(cols, g[f"cols_{tag}_{k}"])
+            np.testing.assert_allclose(pts, g[f"pts_{tag}_{k}"], rtol=1e-13, atol=0)
+    pts, (rows, cols) = oracle.backproject(g["depth"], g["intrinsics"], np.zeros_like(g["masks"][0]))
+    assert pts.shape == (0, 3) and rows.size == 0
