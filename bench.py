@@ -15,6 +15,7 @@ its own object per step (weak scaling) and ONE all_gather of the K result record
 the timed region.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -37,6 +38,15 @@ FLOP_PER_PAIR = 23968            # 2 x 11 984 MAC of the pair MLP
 FLOP_PER_PAIR_EXECUTED = 13728   # what the pair kernel issues after hoisting 2x40 layer-0 columns to a per-point table
 PEAK_F32_MFMA = 157.3            # TFLOP/s, MI355X_MICROARCH.md
 PEAK_HBM = 8000.0                # GB/s
+
+
+def settle():
+    """A generation-2 pass of Python's garbage collector over a process that has torch loaded takes 35-70 ms (measured:
+    profiles/r2_pose_tail.txt) -- ten to twenty times a whole timed region here -- and when it runs depends on how many
+    objects the set-up happened to allocate.  Collect now and move the survivors out of the collector's sight, so that the
+    timed loops that follow measure the device path."""
+    gc.collect()
+    gc.freeze()
 
 
 def pmc_traffic(kernel):
@@ -150,6 +160,7 @@ def main():
 
     run_steps(max(args.warmup, n_streams))
     close_batch()            # warm-up of the gather too (RCCL communicators are created on first use)
+    settle()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -244,6 +255,7 @@ def main():
         pp.load(ob["pc"], ob["normals"], ob["feat"], idx, u_tr, u_rot, corners[0].copy())
         for _ in range(3):
             pose = pp.run()
+        settle()
         torch.cuda.synchronize()
         tp0 = time.perf_counter()
         for _ in range(10):
@@ -265,6 +277,7 @@ def main():
             batch.append(dict(pc=obj_j["pc"], normals=obj_j["normals"], cfg=obj_j["cfg"], n_pairs=P))
         for _ in range(2):
             runner.run(batch)
+        settle()
         torch.cuda.synchronize()
         tb0 = time.perf_counter()
         for _ in range(3):

@@ -363,7 +363,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
     }
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     const int j = lane & 15, g = lane >> 4;
     __builtin_assume(g >= 0 && g < 4);
     int64_t Pn = A.P;
@@ -848,7 +848,7 @@ extern "C" int cppf_pair_mlp_forward(const float* pc, const float* nrm, const fl
     const size_t lds = (size_t)3 * maxd * GEN_THREADS * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mlp_generic_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mlp_generic_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 3 * GEN_MAX_DIM * GEN_THREADS * sizeof(float));
         attr_done = true;
     }

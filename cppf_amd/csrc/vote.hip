@@ -1105,7 +1105,7 @@ static int vote_impl(const float* points, const float* outputs, const float* pro
         if (tab_lds) {
             static bool attr_done = false;
             if (!attr_done) {
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&vote_kernel<true, true>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vote_kernel<true, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr_done = true;
             }
@@ -1113,7 +1113,7 @@ static int vote_impl(const float* points, const float* outputs, const float* pro
         } else {
             static bool attr_done = false;
             if (!attr_done) {
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&vote_kernel<true, false>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vote_kernel<true, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr_done = true;
             }
@@ -1218,8 +1218,13 @@ extern "C" int cppf_grid_argmax(const float* grid, int64_t n, long long* out_idx
 __global__ void center_from_argmax_kernel(const long long* __restrict__ idx, const float* __restrict__ corner, double res,
                                           int gy, int gz, double* __restrict__ T64, float* __restrict__ T32,
                                           const float* __restrict__ peak, double* __restrict__ idx_peak,
-                                          const int32_t* __restrict__ shape)
+                                          const int32_t* __restrict__ shape, uint4* __restrict__ zero16 = nullptr,
+                                          int n_zero16 = 0)
 {
+    // cppf_pose_tail_begin: the accumulators of the launches that follow (sphere-bin counts, chunk counts, ticket, record)
+    // start at zero; T64 / idx_peak may lie inside the region, so the zeroing comes first
+    for (int k = threadIdx.x; k < n_zero16; k += blockDim.x) zero16[k] = make_uint4(0u, 0u, 0u, 0u);
+    if (n_zero16) __syncthreads();
     if (shape) { gy = max(shape[2], 1); gz = max(shape[3], 1); }   // dims record in memory (*_dyn)
     const long long flat = *idx;
     const long long syz = (long long)gy * gz;
@@ -1283,6 +1288,20 @@ extern "C" int cppf_center_from_argmax_dyn(const long long* idx, const float* co
     return 0;
 }
 
+extern "C" int cppf_pose_tail_begin(const long long* idx, const float* corner, double res, int gy, int gz,
+                                    const int32_t* shape_dev, double* T64, float* T32, const float* peak,
+                                    double* idx_peak_f64, void* zero_ptr, size_t zero_bytes, void* stream)
+{
+    if (!idx || !corner || (!shape_dev && (gy < 1 || gz < 1))) return CPPF_EINVAL;
+    if (zero_bytes && (!zero_ptr || (zero_bytes & 15) || (reinterpret_cast<uintptr_t>(zero_ptr) & 15) || zero_bytes > (1u << 26)))
+        return CPPF_EINVAL;
+    hipLaunchKernelGGL(center_from_argmax_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, idx, corner, res,
+                       shape_dev ? 1 : gy, shape_dev ? 1 : gz, T64, T32, peak, idx_peak_f64, shape_dev,
+                       static_cast<uint4*>(zero_ptr), (int)(zero_bytes / 16));
+    CPPF_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int cppf_counts_argmax_select(const int32_t* counts, int n, const double* sphere64, long long* best_idx,
                                          double* best_dir, void* stream)
 {
@@ -1305,7 +1324,8 @@ __global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__
                                                               int n_rots, int gx, int gy, int gz,
                                                               const float* __restrict__ gt_center, float tol,
                                                               uint8_t* __restrict__ mask, const int32_t* __restrict__ shape,
-                                                              const unsigned long long* __restrict__ vote_ws)
+                                                              const unsigned long long* __restrict__ vote_ws,
+                                                              int32_t* __restrict__ chunk_counts)
 {
     if (shape) { gx = shape[1]; gy = shape[2]; gz = shape[3]; }   // dims record in memory (*_dyn)
     // (cos,sin) table for every n <= n_rots, built per block in LDS when it fits.
@@ -1336,12 +1356,26 @@ __global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__
     uint32_t* q = reinterpret_cast<uint32_t*>(lds + (in_lds ? 2 * entries : 0)) + (threadIdx.x >> 6) * 128;
     const int lane = threadIdx.x & 63;
     int qn = 0;
+    // cppf_backvote_count: survivors per chunk of CMP_BLOCK pairs (integer atomics: the counts do not depend on the
+    // order), so the compaction that follows needs no counting pass.  The lanes that call this together mostly hold pairs
+    // of one chunk: those send one atomic, the others their own.
+    auto count_survivor = [&](const int64_t idx, const bool nz) {
+        const int ch = (int)(idx >> 10);
+        const int ch0 = __builtin_amdgcn_readfirstlane(ch);
+        const unsigned long long m = __ballot(nz && ch == ch0);
+        if (nz) {
+            if (ch != ch0) atomicAdd(&chunk_counts[ch], 1);
+            else if ((threadIdx.x & 63) == __builtin_ctzll(m)) atomicAdd(&chunk_counts[ch0], __popcll(m));
+        }
+    };
     auto finish = [&](const int64_t idx, const f3 found) {
         if (out_offsets) {
             float* oo = out_offsets + 3 * idx;
             oo[0] = found.x; oo[1] = found.y; oo[2] = found.z;
         }
-        if (mask) mask[idx] = (found.x != 0.f) || (found.y != 0.f) || (found.z != 0.f);
+        const bool nz = (found.x != 0.f) || (found.y != 0.f) || (found.z != 0.f);
+        if (mask) mask[idx] = nz;
+        if (chunk_counts) count_survivor(idx, nz);
     };
     auto rotations = [&](const int64_t idx) {   // the reference's loop (:97-110) for one pair that passed stage 1
         const float2 o = reinterpret_cast<const float2*>(outputs)[idx];
@@ -1430,7 +1464,9 @@ __global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__
                             if (!pass) finish(idx, f3{0.f, 0.f, 0.f});
                         } else if (mask) {   // degenerate pair: out_offsets keeps the caller's value (:87 returns early)
                             const float* oo = out_offsets ? out_offsets + 3 * idx : nullptr;
-                            mask[idx] = oo ? ((oo[0] != 0.f) || (oo[1] != 0.f) || (oo[2] != 0.f)) : 0;   // mask-only: as if zero-initialised (:220)
+                            const bool nz = oo ? ((oo[0] != 0.f) || (oo[1] != 0.f) || (oo[2] != 0.f)) : false;   // mask-only: as if zero-initialised (:220)
+                            mask[idx] = nz;
+                            if (chunk_counts) count_survivor(idx, nz);
                         }
                     }
                 }
@@ -1497,7 +1533,7 @@ __global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__
 static int backvote_impl(const float* points, const float* outputs, float* out_offsets,
                          const int32_t* point_idxs, const float* corner, float res, int64_t n_ppfs, int n_rots,
                          int gx, int gy, int gz, const float* gt_center, float tol, uint8_t* mask, void* stream,
-                         const int32_t* shape_dev, const void* vote_workspace = nullptr)
+                         const int32_t* shape_dev, const void* vote_workspace = nullptr, int32_t* chunk_counts = nullptr)
 {
     if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || n_ppfs < 0 || n_ppfs > 0xffffffffll) return CPPF_EINVAL;
     if (n_ppfs == 0) return 0;
@@ -1508,7 +1544,7 @@ static int backvote_impl(const float* points, const float* outputs, float* out_o
     if (nb > 1024) nb = 1024;
     hipLaunchKernelGGL(backvote_kernel, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, points,
                        outputs, out_offsets, point_idxs, corner, res, n_ppfs, n_rots, gx, gy, gz, gt_center, tol,
-                       mask, shape_dev, static_cast<const unsigned long long*>(vote_workspace));
+                       mask, shape_dev, static_cast<const unsigned long long*>(vote_workspace), chunk_counts);
     CPPF_CHECK_LAUNCH();
     return 0;
 }
@@ -1529,6 +1565,18 @@ extern "C" int cppf_backvote_ws(const float* points, const float* outputs, float
     if (!shape_dev && (gx < 1 || gy < 1 || gz < 1)) return CPPF_EINVAL;
     return backvote_impl(points, outputs, out_offsets, point_idxs, corner, res, n_ppfs, n_rots, shape_dev ? 1 : gx,
                          shape_dev ? 1 : gy, shape_dev ? 1 : gz, gt_center, tol, mask, stream, shape_dev, vote_workspace);
+}
+
+extern "C" int cppf_backvote_count(const float* points, const float* outputs, const int32_t* point_idxs, const float* corner,
+                                   float res, int64_t n_ppfs, int n_rots, int gx, int gy, int gz, const int32_t* shape_dev,
+                                   const float* gt_center, float tol, uint8_t* mask, int32_t* chunk_counts,
+                                   const void* vote_workspace, void* stream)
+{
+    if (!mask || !chunk_counts) return CPPF_EINVAL;
+    if (!shape_dev && (gx < 1 || gy < 1 || gz < 1)) return CPPF_EINVAL;
+    return backvote_impl(points, outputs, nullptr, point_idxs, corner, res, n_ppfs, n_rots, shape_dev ? 1 : gx,
+                         shape_dev ? 1 : gy, shape_dev ? 1 : gz, gt_center, tol, mask, stream, shape_dev, vote_workspace,
+                         chunk_counts);
 }
 
 extern "C" int cppf_backvote_dyn(const float* points, const float* outputs, float* out_offsets,
@@ -1606,6 +1654,47 @@ __global__ __launch_bounds__(CMP_BLOCK) void compact_scatter_kernel(const uint8_
         const int rank = __popcll(b & ((1ull << lane) - 1ull));
         surv[block_offs[blockIdx.x] + woff + rank] = (int32_t)i;
     }
+}
+
+// cppf_compact_scatter: the scatter step alone, for chunk counts that already exist (cppf_backvote_count): every block sums
+// the counts of the chunks before its own (<= CMP_SELF_MAX of them, from L2) instead of waiting for a scan kernel.
+#define CMP_SELF_MAX 8192
+static_assert(CMP_BLOCK == 1024, "backvote_kernel counts survivors per chunk of 1 << 10 pairs");
+__global__ __launch_bounds__(CMP_BLOCK) void compact_scatter_self_kernel(const uint8_t* __restrict__ mask, int64_t n,
+                                                                          const int32_t* __restrict__ chunk_counts,
+                                                                          int32_t* __restrict__ surv, int32_t* __restrict__ total)
+{
+    __shared__ int wsum[CMP_BLOCK / 64];
+    __shared__ int wpre[CMP_BLOCK / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int before = 0;
+    for (int k = threadIdx.x; k < (int)blockIdx.x; k += CMP_BLOCK) before += chunk_counts[k];
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
+    const int64_t i = (int64_t)blockIdx.x * CMP_BLOCK + threadIdx.x;
+    const bool f = i < n && mask[i] != 0;
+    const unsigned long long b = __ballot(f);
+    if (lane == 0) { wsum[w] = __popcll(b); wpre[w] = before; }
+    __syncthreads();
+    int woff = 0, base = 0;
+    for (int k = 0; k < CMP_BLOCK / 64; ++k) { base += wpre[k]; woff += k < w ? wsum[k] : 0; }
+    if (f) surv[base + woff + __popcll(b & ((1ull << lane) - 1ull))] = (int32_t)i;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        int own = 0;
+        for (int k = 0; k < CMP_BLOCK / 64; ++k) own += wsum[k];
+        *total = base + own;
+    }
+}
+
+extern "C" int cppf_compact_scatter(const uint8_t* mask, int64_t n, const int32_t* chunk_counts, int32_t* surv,
+                                    int32_t* count, void* stream)
+{
+    if (n < 1 || !mask || !surv || !count || !chunk_counts) return CPPF_EINVAL;
+    const int64_t nb = (n + CMP_BLOCK - 1) / CMP_BLOCK;
+    if (nb > CMP_SELF_MAX) return CPPF_EUNSUPPORTED;   // use cppf_compact_mask
+    hipLaunchKernelGGL(compact_scatter_self_kernel, dim3((unsigned)nb), dim3(CMP_BLOCK), 0, (hipStream_t)stream, mask, n,
+                       chunk_counts, surv, count);
+    CPPF_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" size_t cppf_compact_workspace_bytes(int64_t n)
@@ -1714,8 +1803,11 @@ __global__ __launch_bounds__(SPH_THREADS) void rot_sphere_kernel(const float* __
                                                                  const int32_t* __restrict__ n_sel_dev,
                                                                  int64_t n_sel_host, int64_t max_pairs, int n_rots,
                                                                  const float* __restrict__ sphere, int n_sphere,
-                                                                 float thr, int32_t* __restrict__ counts)
+                                                                 float thr, int32_t* __restrict__ counts,
+                                                                 int rot_dir_step, int counts_dir_step)
 {
+    preds_rot += (int64_t)blockIdx.y * rot_dir_step;
+    counts += (int64_t)blockIdx.y * counts_dir_step;
     __shared__ RotFrame frames[SPH_PPB];
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float4* cand = reinterpret_cast<float4*>(lds);                       // [SPH_PPB*n_rots]
@@ -1764,8 +1856,11 @@ __global__ __launch_bounds__(256) void rot_sphere_band_kernel(const float* __res
                                                               const int32_t* __restrict__ n_sel_dev, int64_t n_sel_host,
                                                               int64_t max_pairs, int n_rots,
                                                               const float* __restrict__ sphere, int n_sphere, float thr,
-                                                              int32_t* __restrict__ counts, int descending)
+                                                              int32_t* __restrict__ counts, int descending,
+                                                              int rot_dir_step, int counts_dir_step)
 {
+    preds_rot += (int64_t)blockIdx.y * rot_dir_step;   // cppf_rot_sphere_count_dirs: direction blockIdx.y of the launch
+    counts += (int64_t)blockIdx.y * counts_dir_step;
     __shared__ RotFrame frames[SPHB_PPB];
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sph = lds;                                             // [n_sphere][3]
@@ -1813,32 +1908,53 @@ __global__ __launch_bounds__(256) void rot_sphere_band_kernel(const float* __res
         if (cnt[j]) atomicAdd(&counts[j], cnt[j]);
 }
 
-extern "C" int cppf_rot_sphere_count(const float* points, const float* preds_rot, int rot_stride,
-                                     const int32_t* point_idxs, const int32_t* sel, const int32_t* n_sel_dev,
-                                     int64_t n_sel_host, int64_t max_pairs, int n_rots, const float* sphere,
-                                     int n_sphere, float thr, int sphere_sorted_by_y, int32_t* counts, void* stream)
+static int rot_sphere_impl(const float* points, const float* preds_rot, int rot_stride, int rot_dir_step, int n_dirs,
+                           const int32_t* point_idxs, const int32_t* sel, const int32_t* n_sel_dev,
+                           int64_t n_sel_host, int64_t max_pairs, int n_rots, const float* sphere,
+                           int n_sphere, float thr, int sphere_sorted_by_y, int32_t* counts, int counts_dir_step, void* stream)
 {
     if (!points || !preds_rot || !point_idxs || !sphere || !counts) return CPPF_EINVAL;
-    if (n_rots < 1 || n_rots > 512 || n_sphere < 1 || max_pairs < 0 || n_sel_host < 0 || rot_stride < 1)
+    if (n_rots < 1 || n_rots > 512 || n_sphere < 1 || max_pairs < 0 || n_sel_host < 0 || rot_stride < 1 || n_dirs < 1 ||
+        n_dirs > 16)
         return CPPF_EINVAL;
     int64_t bound = n_sel_host < max_pairs ? n_sel_host : max_pairs;
     if (bound == 0) return 0;
     if (sphere_sorted_by_y != 0 && n_sphere <= 4096) {
         const int64_t nb = (bound + SPHB_PPB - 1) / SPHB_PPB;
         const size_t lds = (size_t)(4 * n_sphere + 2 * n_rots) * sizeof(float);
-        hipLaunchKernelGGL(rot_sphere_band_kernel, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, points,
+        hipLaunchKernelGGL(rot_sphere_band_kernel, dim3((unsigned)nb, (unsigned)n_dirs), dim3(256), lds, (hipStream_t)stream, points,
                            preds_rot, rot_stride, point_idxs, sel, n_sel_dev, n_sel_host, max_pairs, n_rots, sphere,
-                           n_sphere, thr, counts, sphere_sorted_by_y > 0 ? 1 : 0);
+                           n_sphere, thr, counts, sphere_sorted_by_y > 0 ? 1 : 0, rot_dir_step, counts_dir_step);
         CPPF_CHECK_LAUNCH();
         return 0;
     }
     const int64_t nb = (bound + SPH_PPB - 1) / SPH_PPB;
     const size_t lds = (size_t)(4 * SPH_PPB * n_rots + 2 * n_rots) * sizeof(float);
-    hipLaunchKernelGGL(rot_sphere_kernel, dim3((unsigned)nb), dim3(SPH_THREADS), lds, (hipStream_t)stream, points,
+    hipLaunchKernelGGL(rot_sphere_kernel, dim3((unsigned)nb, (unsigned)n_dirs), dim3(SPH_THREADS), lds, (hipStream_t)stream, points,
                        preds_rot, rot_stride, point_idxs, sel, n_sel_dev, n_sel_host, max_pairs, n_rots, sphere,
-                       n_sphere, thr, counts);
+                       n_sphere, thr, counts, rot_dir_step, counts_dir_step);
     CPPF_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int cppf_rot_sphere_count(const float* points, const float* preds_rot, int rot_stride,
+                                     const int32_t* point_idxs, const int32_t* sel, const int32_t* n_sel_dev,
+                                     int64_t n_sel_host, int64_t max_pairs, int n_rots, const float* sphere,
+                                     int n_sphere, float thr, int sphere_sorted_by_y, int32_t* counts, void* stream)
+{
+    return rot_sphere_impl(points, preds_rot, rot_stride, 0, 1, point_idxs, sel, n_sel_dev, n_sel_host, max_pairs, n_rots,
+                           sphere, n_sphere, thr, sphere_sorted_by_y, counts, 0, stream);
+}
+
+extern "C" int cppf_rot_sphere_count_dirs(const float* points, const float* preds_rot, int rot_stride, int rot_dir_step,
+                                          int n_dirs, const int32_t* point_idxs, const int32_t* sel,
+                                          const int32_t* n_sel_dev, int64_t n_sel_host, int64_t max_pairs, int n_rots,
+                                          const float* sphere, int n_sphere, float thr, int sphere_sorted_by_y,
+                                          int32_t* counts, int counts_dir_step, void* stream)
+{
+    if (n_dirs > 1 && (rot_dir_step < 1 || counts_dir_step < n_sphere)) return CPPF_EINVAL;
+    return rot_sphere_impl(points, preds_rot, rot_stride, rot_dir_step, n_dirs, point_idxs, sel, n_sel_dev, n_sel_host,
+                           max_pairs, n_rots, sphere, n_sphere, thr, sphere_sorted_by_y, counts, counts_dir_step, stream);
 }
 
 // ----------------------------------------------------------------------------- pose-tail reductions
@@ -1955,6 +2071,135 @@ extern "C" int cppf_scale_sum(const float* scale_logits, int stride, const int32
     hipLaunchKernelGGL(scale_sum_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, scale_logits, stride, sel,
                        n_sel_dev, n_sel_host, partial);
     hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(64), 0, st, partial, 3, n_sel_dev, n_sel_host, out);
+    CPPF_CHECK_LAUNCH();
+    return 0;
+}
+
+// One launch for what follows the orientation vote (nocs/inference.py:283-301,335): np.argmax of every direction's bin
+// counts and best_dir = sphere_pts[argmax] (every block, from L2: 480 integers per direction), the two BCE sums per
+// direction and the three scale sums over the surviving pairs, and -- in the block that draws the last ticket -- the sum
+// of the per-block partials.  Replaces counts_argmax_select + (axis_sign + reduce_final) per direction + scale_sum +
+// reduce_final: 4 n_dirs + 2 launches.  Per block and per pair the arithmetic is that of axis_sign_kernel and
+// scale_sum_kernel; the partials are summed 8 per lane and then across 32 lanes (fixed order).
+#define PS_MAX_DIRS 2
+#define PS_COMP 8   // doubles per block partial: {up, down} x 2 directions, 3 scale sums, unused
+struct PoseSumsArgs {
+    const float *pc, *nrm, *aux, *scale_logits;
+    const int32_t *point_idxs, *sel, *n_sel_dev, *counts;
+    const double* sphere64;
+    int64_t n_sel_host;
+    int aux_stride, scale_stride, n_dirs, n_sphere, counts_dir_step;
+    long long* best_idx;
+    double *best_dir, *sign, *scale_out, *partial;
+    unsigned* ticket;
+};
+__global__ __launch_bounds__(RED_THREADS) void pose_sums_kernel(PoseSumsArgs A)
+{
+    __shared__ double sh[RED_THREADS / 64];
+    __shared__ unsigned long long best[PS_MAX_DIRS][RED_THREADS / 64];
+    __shared__ double bdir[PS_MAX_DIRS][3];
+    __shared__ unsigned drawn;
+    const int tid = threadIdx.x;
+    for (int j = 0; j < A.n_dirs; ++j) {   // key = count << 32 | ~index: the largest count at the lowest index (:283)
+        const int32_t* cj = A.counts + (int64_t)j * A.counts_dir_step;
+        unsigned long long k = 0ull;
+        for (int i = tid; i < A.n_sphere; i += RED_THREADS) {
+            const unsigned long long ki = ((unsigned long long)(uint32_t)cj[i] << 32) | (uint32_t)(~(uint32_t)i);
+            k = ki > k ? ki : k;
+        }
+        k = wave_max_u64(k);
+        if ((tid & 63) == 0) best[j][tid >> 6] = k;
+    }
+    __syncthreads();
+    if (tid < 3 * A.n_dirs) {
+        const int j = tid / 3, c = tid - 3 * j;
+        unsigned long long b = best[j][0];
+        for (int w = 1; w < RED_THREADS / 64; ++w) b = best[j][w] > b ? best[j][w] : b;
+        const int bi = (int)(~(uint32_t)(b & 0xffffffffull));
+        const double v = A.sphere64[3 * (size_t)bi + c];
+        bdir[j][c] = v;
+        if (blockIdx.x == 0) {
+            A.best_dir[3 * j + c] = v;
+            if (c == 0 && A.best_idx) A.best_idx[j] = bi;
+        }
+    }
+    __syncthreads();
+    const int64_t n_sel = A.n_sel_dev ? (int64_t)*A.n_sel_dev : A.n_sel_host;
+    double acc[PS_COMP] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int64_t k = (int64_t)blockIdx.x * RED_THREADS + tid; k < n_sel; k += (int64_t)RED_BLOCKS * RED_THREADS) {
+        const int p = A.sel ? A.sel[k] : (int)k;
+        const int2 ij = reinterpret_cast<const int2*>(A.point_idxs)[p];
+        const f3 ab = sub3(ld3(A.pc, ij.x), ld3(A.pc, ij.y));
+        const float distsq = (ab.x * ab.x + ab.y * ab.y) + ab.z * ab.z;
+        const float den = sqrtf(distsq) + 1e-7f;
+        const f3 abn = {ab.x / den, ab.y / den, ab.z / den};
+        f3 n = ld3(A.nrm, ij.x);
+        const float d = (n.x * abn.x + n.y * abn.y) + n.z * abn.z;
+        if (d < 0.f) n = neg3(n);
+#pragma unroll
+        for (int j = 0; j < PS_MAX_DIRS; ++j) {
+            if (j >= A.n_dirs) break;
+            const double proj = ((double)n.x * bdir[j][0] + (double)n.y * bdir[j][1]) + (double)n.z * bdir[j][2];
+            const double t = proj > 0.0 ? 1.0 : 0.0;
+            const double x = (double)A.aux[(int64_t)p * A.aux_stride + j];
+            const double sp = (x > 0.0 ? x : 0.0) + log1p(exp(-fabs(x)));
+            acc[2 * j] += sp - x * t;
+            acc[2 * j + 1] += sp - x * (1.0 - t);
+        }
+        if (A.scale_logits) {
+            const float* sl = A.scale_logits + (int64_t)p * A.scale_stride;
+            acc[4] += (double)sl[0]; acc[5] += (double)sl[1]; acc[6] += (double)sl[2];
+        }
+    }
+    double* mine = A.partial + (size_t)PS_COMP * blockIdx.x;
+#pragma unroll
+    for (int c = 0; c < PS_COMP - 1; ++c) {
+        const double v = block_sum(acc[c], sh);
+        // device-scope atomic stores and loads: the block that sums them runs on another CU, maybe another XCD
+        if (tid == 0) __hip_atomic_store(mine + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) drawn = __hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (drawn != RED_BLOCKS - 1) return;
+    static_assert(RED_THREADS == 32 * PS_COMP && RED_BLOCKS == 32 * 8, "final sum: 8 components x 32 lanes x 8 partials");
+    const int c = tid >> 5, l = tid & 31;
+    double s = 0.0;
+    if (c < PS_COMP - 1)
+        for (int b = 8 * l; b < 8 * l + 8; ++b)
+            s += __hip_atomic_load(A.partial + (size_t)PS_COMP * b + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (l == 0) {
+        if (c < 4) { if (c < 2 * A.n_dirs) A.sign[3 * (c >> 1) + (c & 1)] = s; }
+        else if (c < 7 && A.scale_logits) A.scale_out[c - 4] = s;
+    }
+    if (tid < A.n_dirs) A.sign[3 * tid + 2] = (double)n_sel;
+    if (tid == 0 && A.scale_logits) A.scale_out[3] = (double)n_sel;
+    if (tid == 0) __hip_atomic_store(A.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
+}
+
+extern "C" size_t cppf_pose_sums_workspace_bytes(void) { return (size_t)RED_BLOCKS * PS_COMP * sizeof(double) + 16; }
+
+extern "C" int cppf_pose_sums(const float* pc, const float* nrm, const int32_t* point_idxs, const int32_t* sel,
+                              const int32_t* n_sel_dev, int64_t n_sel_host, const float* aux, int aux_stride, int n_dirs,
+                              const int32_t* counts, int n_sphere, int counts_dir_step, const double* sphere64,
+                              const float* scale_logits, int scale_stride, long long* best_idx, double* best_dir,
+                              double* sign, double* scale_out, void* workspace, size_t workspace_bytes, unsigned* ticket,
+                              void* stream)
+{
+    if (!pc || !nrm || !point_idxs || !aux || !counts || !sphere64 || !best_dir || !sign || !ticket) return CPPF_EINVAL;
+    if (n_dirs < 1 || n_dirs > PS_MAX_DIRS || aux_stride < n_dirs || n_sphere < 1 || n_sel_host < 0 ||
+        (n_dirs > 1 && counts_dir_step < n_sphere) || (scale_logits && (scale_stride < 3 || !scale_out)))
+        return CPPF_EINVAL;
+    if (!workspace || workspace_bytes < cppf_pose_sums_workspace_bytes()) return CPPF_EWORKSPACE;
+    PoseSumsArgs A;
+    A.pc = pc; A.nrm = nrm; A.aux = aux; A.scale_logits = scale_logits;
+    A.point_idxs = point_idxs; A.sel = sel; A.n_sel_dev = n_sel_dev; A.counts = counts;
+    A.sphere64 = sphere64; A.n_sel_host = n_sel_host;
+    A.aux_stride = aux_stride; A.scale_stride = scale_stride; A.n_dirs = n_dirs; A.n_sphere = n_sphere;
+    A.counts_dir_step = counts_dir_step;
+    A.best_idx = best_idx; A.best_dir = best_dir; A.sign = sign; A.scale_out = scale_out;
+    A.partial = static_cast<double*>(workspace); A.ticket = ticket;
+    hipLaunchKernelGGL(pose_sums_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, (hipStream_t)stream, A);
     CPPF_CHECK_LAUNCH();
     return 0;
 }

@@ -49,14 +49,19 @@ class PoseWorkspace:
         # the 21-double result record; T64 / best_dir / sign / scale are views into it, so the kernels write the
         # record directly and the read-back is one copy
         # (the record and the sphere-bin counts share one buffer: both start every tail zeroed, with one fill)
-        self._tail0 = torch.zeros(176 + 2 * n_sphere * 4, dtype=torch.uint8, device=device)
+        # layout: record 176 B | counts 2 x n_sphere i32 | ticket 16 B | survivors per chunk of 1024 pairs i32[...]; 16 B multiple
+        c0 = 176 + ((2 * n_sphere * 4 + 15) & ~15)
+        n_chunks = (n_pairs + 1023) // 1024
+        self._tail0 = torch.zeros(c0 + 16 + ((4 * n_chunks + 15) & ~15), dtype=torch.uint8, device=device)
+        self.ticket = self._tail0[c0:c0 + 16].view(I32)
+        self.chunk_counts = self._tail0[c0 + 16:c0 + 16 + 4 * n_chunks].view(I32)
         self.rec = self._tail0[:168].view(torch.float64)
         self.T64 = self.rec[0:3]
         self.T32 = torch.empty(3, dtype=F32, device=device)
         self.mask = torch.empty(n_pairs, dtype=torch.uint8, device=device)
         self.surv = torch.empty(n_pairs, dtype=I32, device=device)
         self.count = torch.empty(1, dtype=I32, device=device)
-        self.counts = self._tail0[176:].view(I32).view(2, n_sphere)
+        self.counts = self._tail0[176:176 + 2 * n_sphere * 4].view(I32).view(2, n_sphere)
         self.best_idx = torch.empty(2, dtype=torch.int64, device=device)
         self.best_dir = self.rec[3:9].view(2, 3)
         self.sign = self.rec[9:15].view(2, 3)
@@ -358,51 +363,53 @@ def _enqueue_tail(ws, pc, pc_normal, idx32, outputs, heads, corner, cfg, dims, n
     st = stream_ptr(dev)
     P, S = idx32.shape[0], sph32_d.shape[0]
     with torch.cuda.device(dev):
-        ws._tail0.zero_()                                                     # record (best_dir, sign sums, ...) and bin counts
         # the vote's workspace (same scope, same tag as models/voting.py): its rotation table is reused by the back-vote
         vws = workspace(256, dev, "vote_dyn" if shape is not None else "vote")
-        if shape is not None:
-            _lib.check(L.cppf_center_from_argmax_dyn(ws.out_idx.data_ptr(), corner.data_ptr(), float(cfg.res), shape.data_ptr(),
-                                                     ws.T64.data_ptr(), ws.T32.data_ptr(), ws.out_val.data_ptr(),
-                                                     ws.rec[19:21].data_ptr(), st), "cppf_center_from_argmax_dyn")
-        else:
-            _lib.check(L.cppf_center_from_argmax(ws.out_idx.data_ptr(), corner.data_ptr(), float(cfg.res), dims[1],
-                                                 dims[2], ws.T64.data_ptr(), ws.T32.data_ptr(), ws.out_val.data_ptr(),
-                                                 ws.rec[19:21].data_ptr(), st),
-                       "cppf_center_from_argmax")
+        vws_ptr = vws.data_ptr() if vws.numel() >= 32768 else None
+        shape_ptr = None if shape is None else shape.data_ptr()
+        gx, gy, gz = (1, 1, 1) if shape is not None else dims
+        # T = corner + unravel(argmax) * res (:209-210); the same launch zeroes the record, the bin counts, the chunk counts
+        # and the ticket of the launches below
+        _lib.check(L.cppf_pose_tail_begin(ws.out_idx.data_ptr(), corner.data_ptr(), float(cfg.res), gy, gz, shape_ptr,
+                                          ws.T64.data_ptr(), ws.T32.data_ptr(), ws.out_val.data_ptr(),
+                                          ws.rec[19:21].data_ptr(), ws._tail0.data_ptr(), ws._tail0.numel(), st),
+                   "cppf_pose_tail_begin")
         # back-vote filter (:216-231) --------------------------------------------------------------
         # mask only: the offsets themselves (:220-228) are consumed nowhere else, so no buffer is zeroed or written
-        gx, gy, gz = (1, 1, 1) if shape is not None else dims
-        _lib.check(L.cppf_backvote_ws(pc.data_ptr(), outputs.data_ptr(), None, idx32.data_ptr(), corner.data_ptr(),
-                                      float(cfg.res), P, num_rots, gx, gy, gz, None if shape is None else shape.data_ptr(),
-                                      ws.T32.data_ptr(), float(np.float32(3 * cfg.res)), ws.mask.data_ptr(),
-                                      vws.data_ptr() if vws.numel() >= 32768 else None, st), "cppf_backvote_ws")
-        cws = workspace(L.cppf_compact_workspace_bytes(P), dev, "compact")
-        _lib.check(L.cppf_compact_mask(ws.mask.data_ptr(), P, ws.surv.data_ptr(), ws.count.data_ptr(),
-                                       cws.data_ptr(), cws.numel(), st), "cppf_compact_mask")
+        tol = float(np.float32(3 * cfg.res))
+        if 0 < P <= 8192 * 1024:     # survivors counted per chunk by the back-vote itself: the compaction is one launch
+            _lib.check(L.cppf_backvote_count(pc.data_ptr(), outputs.data_ptr(), idx32.data_ptr(), corner.data_ptr(),
+                                             float(cfg.res), P, num_rots, gx, gy, gz, shape_ptr, ws.T32.data_ptr(), tol,
+                                             ws.mask.data_ptr(), ws.chunk_counts.data_ptr(), vws_ptr, st),
+                       "cppf_backvote_count")
+            _lib.check(L.cppf_compact_scatter(ws.mask.data_ptr(), P, ws.chunk_counts.data_ptr(), ws.surv.data_ptr(),
+                                              ws.count.data_ptr(), st), "cppf_compact_scatter")
+        else:
+            _lib.check(L.cppf_backvote_ws(pc.data_ptr(), outputs.data_ptr(), None, idx32.data_ptr(), corner.data_ptr(),
+                                          float(cfg.res), P, num_rots, gx, gy, gz, shape_ptr, ws.T32.data_ptr(), tol,
+                                          ws.mask.data_ptr(), vws_ptr, st), "cppf_backvote_ws")
+            cws = workspace(L.cppf_compact_workspace_bytes(P), dev, "compact")
+            _lib.check(L.cppf_compact_mask(ws.mask.data_ptr(), P, ws.surv.data_ptr(), ws.count.data_ptr(),
+                                           cws.data_ptr(), cws.numel(), st), "cppf_compact_mask")
         if second_pass is not None:                                          # :236-256, survivors only
             enc2, feat2, idxs2, u_rot2 = second_pass
             enc2.forward_decode_sel(pc, pc_normal, feat2, idxs2, u_rot2, ws.surv, ws.count, heads, max_sel=P,
                                     tr_num_bins=cfg.tr_num_bins, rot_num_bins=cfg.rot_num_bins)
-        # orientation (:259-303) -------------------------------------------------------------------
+        # orientation (:259-303) and scale (:335) ---------------------------------------------------
+        # heads row = {theta_up, theta_right, aux_up, aux_right, sx, sy, sz, 0}: both directions' candidates are counted in
+        # one launch; np.argmax(counts), sphere_pts[...] (:283-284), the sign sums (:287-301) and the scale sums in another
         thr = float(np.float32(np.cos(angle_tol / 180 * np.pi)))
         n_dirs = 2 if cfg.regress_right else 1
-        rws = workspace(L.cppf_reduce_workspace_bytes(), dev, "reduce")
-        for j in range(n_dirs):
-            _lib.check(L.cppf_rot_sphere_count(pc.data_ptr(), heads.data_ptr() + 4 * j, 8, idx32.data_ptr(),
-                                               ws.surv.data_ptr(), ws.count.data_ptr(), P, max_rot_pairs, num_rots,
-                                               sph32_d.data_ptr(), S, thr, sorted_y, ws.counts[j].data_ptr(), st),
-                       "cppf_rot_sphere_count")
-            _lib.check(L.cppf_counts_argmax_select(ws.counts[j].data_ptr(), S, sph64_d.data_ptr(), ws.best_idx[j:].data_ptr(),
-                                                   ws.best_dir[j].data_ptr(), st),
-                       "cppf_counts_argmax_select")                           # np.argmax(counts), sphere_pts[...], :283-284
-            _lib.check(L.cppf_axis_sign(pc.data_ptr(), pc_normal.data_ptr(), idx32.data_ptr(), ws.surv.data_ptr(),
-                                        ws.count.data_ptr(), P, heads.data_ptr() + 4 * (2 + j), 8,
-                                        ws.best_dir[j].data_ptr(), ws.sign[j].data_ptr(), rws.data_ptr(),
-                                        rws.numel(), st), "cppf_axis_sign")
-        # scale (:335) -----------------------------------------------------------------------------
-        _lib.check(L.cppf_scale_sum(heads.data_ptr() + 4 * 4, 8, ws.surv.data_ptr(), ws.count.data_ptr(), P,
-                                    ws.scale.data_ptr(), rws.data_ptr(), rws.numel(), st), "cppf_scale_sum")
+        _lib.check(L.cppf_rot_sphere_count_dirs(pc.data_ptr(), heads.data_ptr(), 8, 1, n_dirs, idx32.data_ptr(),
+                                                ws.surv.data_ptr(), ws.count.data_ptr(), P, max_rot_pairs, num_rots,
+                                                sph32_d.data_ptr(), S, thr, sorted_y, ws.counts.data_ptr(), S, st),
+                   "cppf_rot_sphere_count_dirs")
+        pws = workspace(L.cppf_pose_sums_workspace_bytes(), dev, "pose_sums")
+        _lib.check(L.cppf_pose_sums(pc.data_ptr(), pc_normal.data_ptr(), idx32.data_ptr(), ws.surv.data_ptr(),
+                                    ws.count.data_ptr(), P, heads.data_ptr() + 4 * 2, 8, n_dirs, ws.counts.data_ptr(), S, S,
+                                    sph64_d.data_ptr(), heads.data_ptr() + 4 * 4, 8, ws.best_idx.data_ptr(),
+                                    ws.best_dir.data_ptr(), ws.sign.data_ptr(), ws.scale.data_ptr(), pws.data_ptr(),
+                                    pws.numel(), ws.ticket.data_ptr(), st), "cppf_pose_sums")
     # (T64, best_dir, sign, scale, arg-max index and value were written into ws.rec by the kernels above)
 
 

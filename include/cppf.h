@@ -263,6 +263,46 @@ int cppf_axis_sign(const float* pc, const float* nrm, const int32_t* point_idxs,
 int cppf_scale_sum(const float* scale_logits, int stride, const int32_t* sel, const int32_t* n_sel_dev,
                    int64_t n_sel_host, double* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * The pose tail in six launches (nocs/inference.py:209-303,335 after the centre vote).  The entry points above map one
+ * to one onto the reference's steps; these fuse neighbours whose only separation was a launch boundary, with identical
+ * results (the integer outputs bit for bit; the fp64 sums of cppf_pose_sums within 1e-12 relative of the two-kernel forms:
+ * other order of the final partial sum).
+ *  cppf_pose_tail_begin: cppf_center_from_argmax(_dyn) (shape_dev non-null: dims from the record) that first zeroes
+ *    zero_bytes (multiple of 16, 16-byte aligned) at zero_ptr: the bin counts, chunk counts, ticket and result record of
+ *    the launches below.  T64 / idx_peak_f64 may lie inside the region.
+ *  cppf_backvote_count: cppf_backvote_ws writing the mask only, plus chunk_counts[i] += survivors among pairs
+ *    [1024 i, 1024 i + 1024) (int32[(n_ppfs + 1023) / 1024], zero on entry).
+ *  cppf_compact_scatter: cppf_compact_mask given those counts (no counting pass, no scan launch).  n <= 8192 * 1024
+ *    pairs (CPPF_EUNSUPPORTED beyond: use cppf_compact_mask).
+ *  cppf_rot_sphere_count_dirs: cppf_rot_sphere_count for n_dirs angle columns in one launch: direction j reads
+ *    preds_rot[p * rot_stride + j * rot_dir_step] and adds to counts[j * counts_dir_step + bin].
+ *  cppf_pose_sums: np.argmax of each direction's counts and best_dir = sphere64[argmax] (cppf_counts_argmax_select),
+ *    the sign sums of each direction (cppf_axis_sign; aux of direction j at aux[p * aux_stride + j]) and the scale sums
+ *    (cppf_scale_sum; scale_logits may be null) in one launch.  best_idx i64[n_dirs] (may be null), best_dir f64[n_dirs][3],
+ *    sign f64[n_dirs][3], scale_out f64[4]; n_dirs <= 2; workspace >= cppf_pose_sums_workspace_bytes(); ticket: one
+ *    device uint32, zero before the first call and left at zero.
+ * ------------------------------------------------------------------------------------------- */
+int cppf_pose_tail_begin(const long long* idx, const float* corner, double res, int gy, int gz, const int32_t* shape_dev,
+                         double* T64, float* T32, const float* peak, double* idx_peak_f64, void* zero_ptr,
+                         size_t zero_bytes, void* stream);
+int cppf_backvote_count(const float* points, const float* outputs, const int32_t* point_idxs, const float* corner,
+                        float res, int64_t n_ppfs, int n_rots, int gx, int gy, int gz, const int32_t* shape_dev,
+                        const float* gt_center, float tol, uint8_t* mask, int32_t* chunk_counts,
+                        const void* vote_workspace, void* stream);
+int cppf_compact_scatter(const uint8_t* mask, int64_t n, const int32_t* chunk_counts, int32_t* surv, int32_t* count,
+                         void* stream);
+int cppf_rot_sphere_count_dirs(const float* points, const float* preds_rot, int rot_stride, int rot_dir_step, int n_dirs,
+                               const int32_t* point_idxs, const int32_t* sel, const int32_t* n_sel_dev,
+                               int64_t n_sel_host, int64_t max_pairs, int n_rots, const float* sphere, int n_sphere,
+                               float thr, int sphere_sorted_by_y, int32_t* counts, int counts_dir_step, void* stream);
+size_t cppf_pose_sums_workspace_bytes(void);
+int cppf_pose_sums(const float* pc, const float* nrm, const int32_t* point_idxs, const int32_t* sel,
+                   const int32_t* n_sel_dev, int64_t n_sel_host, const float* aux, int aux_stride, int n_dirs,
+                   const int32_t* counts, int n_sphere, int counts_dir_step, const double* sphere64,
+                   const float* scale_logits, int scale_stride, long long* best_idx, double* best_dir, double* sign,
+                   double* scale_out, void* workspace, size_t workspace_bytes, unsigned* ticket, void* stream);
+
 /* nocs/inference.py:194-195 on device: corner = min(pc), dims = int32((max-min)/res)+1.
  * corner device f32[3], dims device i32[3]. */
 int cppf_grid_setup(const float* pc, int64_t N, float res, float* corner, int32_t* dims, void* stream);

@@ -538,6 +538,133 @@ def test_axis_sign_and_scale_sums(oracle, dev):
     np.testing.assert_allclose(np.exp(mean).astype(np.float64) * np.array([0.06, 0.05, 0.045]) * 2, sc, rtol=1e-6)
 
 
+# ------------------------------------------------------------------------------------ the pose tail's fused launches
+@pytest.mark.parametrize("n_pairs_per_point,known_answer", [(20, True), (3, True), (40, False)])
+def test_backvote_count_and_scatter_match_oracle(oracle, dev, n_pairs_per_point, known_answer):
+    """cppf_pose_tail_begin + cppf_backvote_count + cppf_compact_scatter = center_from_argmax + backvote + count/scan/scatter"""
+    ob = syn.make_object("bottle", 1024, 9)
+    cfg = ob["cfg"]
+    idx = syn.make_pairs(1024, n_pairs_per_point, 9)
+    P = idx.shape[0]
+    outputs = syn.closed_form_outputs(ob["pc"], ob["center"], idx, cfg)
+    if not known_answer:                          # few survivors, many chunks without any
+        rng = np.random.default_rng(5)
+        keep = rng.random(P) < 0.02
+        outputs = np.where(keep[:, None], outputs, rng.uniform(0.0, 0.25, (P, 2)).astype(np.float32)).astype(np.float32)
+    corner, dims = oracle.grid_setup(ob["pc"], cfg.res)
+    idx32 = idx.astype(np.int32)
+    # the arg-max cell nearest the true centre: the begin launch turns it into T (fp64) and its float copy
+    cand = np.round((ob["center"] - corner.astype(np.float64)) / cfg.res).astype(np.int64)
+    flat = int((cand[0] * dims[1] + cand[1]) * dims[2] + cand[2])
+    T = corner.astype(np.float64) + cand * float(cfg.res)
+    center = T.astype(np.float32)
+    oo, mask = oracle.backvote(ob["pc"], outputs, idx32, corner, cfg.res, 72, dims, center, np.float32(3 * cfg.res))
+    L = _lib.lib()
+    n_chunks = (P + 1023) // 1024
+    zero = torch.full((16 + 4 * ((n_chunks + 3) // 4 * 4) + 32,), 0xAB, dtype=torch.uint8, device=dev)   # garbage on entry
+    T64 = zero[:32].view(torch.float64)                     # inside the zeroed region, like the pipeline's record
+    chunk_counts = zero[32:32 + 4 * n_chunks].view(torch.int32)
+    T32 = torch.empty(3, dtype=torch.float32, device=dev)
+    oi = torch.tensor([flat], dtype=torch.int64, device=dev)
+    pk = torch.tensor([7.5], dtype=torch.float32, device=dev)
+    ip = torch.empty(2, dtype=torch.float64, device=dev)
+    pc_d, out_d, idx_d, cor_d = t(ob["pc"], dev), t(outputs, dev), t(idx32, dev), t(corner, dev)
+    _lib.check(L.cppf_pose_tail_begin(oi.data_ptr(), cor_d.data_ptr(), float(cfg.res), int(dims[1]), int(dims[2]), None,
+                                      T64.data_ptr(), T32.data_ptr(), pk.data_ptr(), ip.data_ptr(), zero.data_ptr(),
+                                      zero.numel(), stream_ptr(dev)), "begin")
+    m = torch.empty(P, dtype=torch.uint8, device=dev)
+    surv = torch.full((P,), -1, dtype=torch.int32, device=dev)
+    cnt = torch.full((1,), -5, dtype=torch.int32, device=dev)
+    _lib.check(L.cppf_backvote_count(pc_d.data_ptr(), out_d.data_ptr(), idx_d.data_ptr(), cor_d.data_ptr(), cfg.res, P, 72,
+                                     int(dims[0]), int(dims[1]), int(dims[2]), None, T32.data_ptr(),
+                                     float(np.float32(3 * cfg.res)), m.data_ptr(), chunk_counts.data_ptr(), None,
+                                     stream_ptr(dev)), "backvote_count")
+    _lib.check(L.cppf_compact_scatter(m.data_ptr(), P, chunk_counts.data_ptr(), surv.data_ptr(), cnt.data_ptr(),
+                                      stream_ptr(dev)), "compact_scatter")
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(T64.cpu().numpy()[:3], T)
+    np.testing.assert_array_equal(T32.cpu().numpy(), center)
+    np.testing.assert_array_equal(ip.cpu().numpy(), [flat, 7.5])
+    assert not zero[24:32].any().item() and not zero[32 + 4 * n_chunks:].any().item()
+    np.testing.assert_array_equal(m.cpu().numpy().astype(bool), mask)
+    pad = np.zeros(n_chunks * 1024, bool)
+    pad[:P] = mask
+    np.testing.assert_array_equal(chunk_counts.cpu().numpy(), pad.reshape(n_chunks, 1024).sum(1))
+    ref = np.nonzero(mask)[0]
+    assert int(cnt.item()) == ref.size and (ref.size > 0)
+    np.testing.assert_array_equal(surv.cpu().numpy()[:ref.size], ref)
+
+
+@pytest.mark.parametrize("n", [1, 1023, 1024, 1025, 70000, 1200000])
+def test_compact_scatter_sizes(dev, n):
+    L = _lib.lib()
+    rng = np.random.default_rng(n)
+    mask = (rng.random(n) < (0.37 if n != 70000 else 0.001)).astype(np.uint8)
+    n_chunks = (n + 1023) // 1024
+    pad = np.zeros(n_chunks * 1024, np.int32)
+    pad[:n] = mask
+    m, cc = t(mask, dev), t(pad.reshape(n_chunks, 1024).sum(1).astype(np.int32), dev)
+    surv = torch.empty(n, dtype=torch.int32, device=dev)
+    cnt = torch.full((1,), -7, dtype=torch.int32, device=dev)
+    _lib.check(L.cppf_compact_scatter(m.data_ptr(), n, cc.data_ptr(), surv.data_ptr(), cnt.data_ptr(), stream_ptr(dev)), "scatter")
+    ref = np.nonzero(mask)[0]
+    assert int(cnt.item()) == ref.size
+    np.testing.assert_array_equal(surv.cpu().numpy()[:ref.size], ref)
+    assert L.cppf_compact_scatter(m.data_ptr(), 8192 * 1024 + 1, cc.data_ptr(), surv.data_ptr(), cnt.data_ptr(),
+                                  stream_ptr(dev)) == -3      # CPPF_EUNSUPPORTED: the three-launch form serves it
+
+
+@pytest.mark.parametrize("n_dirs", [1, 2])
+def test_sphere_count_dirs_and_pose_sums_match_oracle(oracle, golden, dev, n_dirs):
+    ob = syn.make_object("mug", 600, 21)
+    idx = syn.make_pairs(600, 10, 21)
+    P = idx.shape[0]
+    idx32 = idx.astype(np.int32)
+    rng = np.random.default_rng(21)
+    heads = rng.normal(0, 1.5, (P, 8)).astype(np.float32)
+    heads[:, :2] = (rng.integers(0, 36, (P, 2)) / 35 * np.pi).astype(np.float32)
+    sel = np.sort(rng.choice(P, 2500, replace=False)).astype(np.int32)
+    sph = golden("sphere.npz")["pts"]
+    L = _lib.lib()
+    thr = float(np.float32(np.cos(1.5 / 180 * np.pi)))
+    counts = torch.zeros((2, 480), dtype=torch.int32, device=dev)
+    nsel = torch.tensor([2500], dtype=torch.int32, device=dev)
+    hd = t(heads, dev)
+    pc_d, n_d, idx_d, sel_d = t(ob["pc"], dev), t(ob["normals"], dev), t(idx32, dev), t(sel, dev)
+    s32_d, s64_d = t(sph.astype(np.float32), dev), t(sph, dev)
+    _lib.check(L.cppf_rot_sphere_count_dirs(pc_d.data_ptr(), hd.data_ptr(), 8, 1, n_dirs, idx_d.data_ptr(), sel_d.data_ptr(),
+                                            nsel.data_ptr(), P, 2000, 72, s32_d.data_ptr(), 480, thr, 1, counts.data_ptr(),
+                                            480, stream_ptr(dev)), "rot_sphere_count_dirs")
+    best_idx = torch.full((2,), -1, dtype=torch.int64, device=dev)
+    best_dir = torch.full((2, 3), 9.0, dtype=torch.float64, device=dev)
+    sign = torch.full((2, 3), 9.0, dtype=torch.float64, device=dev)
+    scale = torch.full((4,), 9.0, dtype=torch.float64, device=dev)
+    ws = workspace(L.cppf_pose_sums_workspace_bytes(), dev, "pose_sums")
+    ticket = torch.zeros(4, dtype=torch.int32, device=dev)
+    for _ in range(2):                                                     # the ticket is left ready for the next call
+        _lib.check(L.cppf_pose_sums(pc_d.data_ptr(), n_d.data_ptr(), idx_d.data_ptr(), sel_d.data_ptr(), nsel.data_ptr(), P,
+                                    hd.data_ptr() + 8, 8, n_dirs, counts.data_ptr(), 480, 480, s64_d.data_ptr(),
+                                    hd.data_ptr() + 16, 8, best_idx.data_ptr(), best_dir.data_ptr(), sign.data_ptr(),
+                                    scale.data_ptr(), ws.data_ptr(), ws.numel(), ticket.data_ptr(), stream_ptr(dev)),
+                   "pose_sums")
+    torch.cuda.synchronize()
+    assert int(ticket[0].item()) == 0
+    cn, bi, bd, sg, sc = (x.cpu().numpy() for x in (counts, best_idx, best_dir, sign, scale))
+    for j in range(n_dirs):
+        co = oracle.rot_voting(ob["pc"], heads[sel[:2000], j], idx32[sel[:2000]], 72)
+        counts_o = oracle.sphere_count(co, sph, 1.5)
+        np.testing.assert_array_equal(cn[j].astype(np.int64), counts_o)
+        assert bi[j] == int(np.argmax(counts_o))                           # first maximum
+        np.testing.assert_array_equal(bd[j], sph[bi[j]])
+        _, (up, down) = oracle.axis_sign(ob["pc"], ob["normals"], idx32[sel], heads[sel, 2 + j], sph[bi[j]])
+        assert sg[j, 2] == 2500
+        np.testing.assert_allclose([sg[j, 0] / 2500, sg[j, 1] / 2500], [up, down], rtol=1e-12)
+    if n_dirs == 1:                                                        # the second direction's outputs are not touched
+        assert not cn[1].any() and bi[1] == -1 and (bd[1] == 9.0).all() and (sg[1] == 9.0).all()
+    assert sc[3] == 2500
+    np.testing.assert_allclose(sc[:3], heads[sel, 4:7].astype(np.float64).sum(0), rtol=1e-12)
+
+
 # ------------------------------------------------------------------------------------ end to end
 @pytest.mark.parametrize("cat", ["bottle", "camera"])
 def test_estimate_pose_matches_oracle_chain(oracle, golden, dev, cat):
