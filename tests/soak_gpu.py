@@ -19,6 +19,8 @@ CATS = ["bottle", "bowl", "camera", "can", "laptop", "mug", "bed", "sofa"]
 def run(budget, seed, dev=None):
     import test_gpu_parity as T
     import cppf_amd.synthetic as syn
+    from cppf_amd import _lib
+    from cppf_amd._torch_util import stream_ptr
     from cppf_amd.models import voting
     from cppf_amd.models.model import PointEncoder
     from oracle import oracle as O
@@ -79,6 +81,21 @@ def run(budget, seed, dev=None):
                                (T.t(ob["pc"], dev), T.t(outputs, dev), out_d, T.t(idx32, dev), T.t(corner, dev), np.float32(res),
                                 P, nr, int(dims[0]), int(dims[1]), int(dims[2]), T.t(center, dev), tol))
         assert np.array_equal(out_d.cpu().numpy(), oo), tag
+        # the pipelines' form: mask + survivors per chunk of 1 024 pairs, then the scatter that needs no scan
+        L = _lib.lib()
+        nch = (P + 1023) // 1024
+        m_d = torch.empty(P, dtype=torch.uint8, device=dev)
+        cc_d = torch.zeros(nch, dtype=torch.int32, device=dev)
+        sv_d = torch.empty(P, dtype=torch.int32, device=dev)
+        ct_d = torch.empty(1, dtype=torch.int32, device=dev)
+        pc_d, o_d, i_d, c_d, g_d = T.t(ob["pc"], dev), T.t(outputs, dev), T.t(idx32, dev), T.t(corner, dev), T.t(center, dev)
+        _lib.check(L.cppf_backvote_count(pc_d.data_ptr(), o_d.data_ptr(), i_d.data_ptr(), c_d.data_ptr(), float(np.float32(res)), P, nr,
+                                         int(dims[0]), int(dims[1]), int(dims[2]), None, g_d.data_ptr(), float(tol), m_d.data_ptr(),
+                                         cc_d.data_ptr(), None, stream_ptr(dev)), "backvote_count")
+        _lib.check(L.cppf_compact_scatter(m_d.data_ptr(), P, cc_d.data_ptr(), sv_d.data_ptr(), ct_d.data_ptr(), stream_ptr(dev)),
+                   "compact_scatter")
+        ref = np.nonzero(np.any(oo != 0, -1))[0]
+        assert int(ct_d.item()) == ref.size and np.array_equal(sv_d.cpu().numpy()[:ref.size], ref), tag
         n_b += 1
 
         # neighbour sets, with a few exact duplicates
