@@ -47,9 +47,15 @@ struct VoteTiling {
     int ntx, nty, T;  // tiles per axis, total (T = 1 << 30: no decomposition fits)
 };
 
+// Fewest tiles first; among the decompositions with that many, the one with the least cut area between tiles: a vote
+// circle is a curve, and the number of tiles a curve passes through grows with the area of the cuts it can cross.  (The
+// first decomposition found used to win: 7x76x52 slabs for the 52x152x52 grid of BASELINE config 5, which a pair's circle
+// visits 10.2 times on average where 26x19x52 tiles are visited 5.3 times; 13x76x26 instead of 26x38x26 for config 2:
+// scratch/cull_estimate3.py.)
 __host__ __device__ inline VoteTiling vote_tiling(int gx, int gy, int gz)
 {
     VoteTiling p = {0, 0, 0, 0, 1 << 30};
+    int64_t best_cut = 0;
     if ((int64_t)gz <= VOTE_TILE_FLOATS) {
         for (int nty = 1; nty <= gy; ++nty) {
             int ty = (gy + nty - 1) / nty;
@@ -58,8 +64,13 @@ __host__ __device__ inline VoteTiling vote_tiling(int gx, int gy, int gz)
             if (txmax > gx) txmax = gx;
             int ntx = (gx + txmax - 1) / txmax;
             int tx = (gx + ntx - 1) / ntx;
-            int T = ntx * ((gy + ty - 1) / ty);
-            if (T < p.T) { p.T = T; p.tx = tx; p.ty = ty; p.ntx = ntx; p.nty = (gy + ty - 1) / ty; }
+            const int nty_eff = (gy + ty - 1) / ty;
+            int T = ntx * nty_eff;
+            const int64_t cut = ((int64_t)(ntx - 1) * gy + (int64_t)(nty_eff - 1) * gx) * gz;
+            if (T < p.T || (T == p.T && cut < best_cut)) {
+                p.T = T; p.tx = tx; p.ty = ty; p.ntx = ntx; p.nty = nty_eff;
+                best_cut = cut;
+            }
             if (ntx == 1) break;  // more y cuts can only add tiles
         }
     }
@@ -505,8 +516,12 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
     if (tid < 16) ctrl[tid] = 0;
     if (tid < 128) dummy[tid] = 0u;
     if (TILED) {
-        t = blockIdx.x % pT;
+        // Workgroup b takes chunk c = b / T of tile (b + c) mod T -- not b mod T: workgroups go to XCD b mod 8 (and round the
+        // CUs of an XCD) in launch order, so with T = 16 every workgroup of a tile landed on the same XCD and the same few
+        // CUs, and the tiles around the vote peak, which hold most of the work, ran on a sixteenth of the chip (52x152x52 grid,
+        // known-answer inputs: 2.3 ms against 1.1 ms with the rotation; T = 17 or 18 never had the problem).
         c = blockIdx.x / pT;
+        t = (blockIdx.x + c) % pT;
         int tix = t / pnty, tiy = t % pnty;
         x0 = tix * ptx;
         y0 = tiy * pty;
@@ -594,6 +609,9 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
     const float blx = fmaxf(0.01f, (float)(x0 - 1)), bhx = fminf((float)gx - 1.01f, (float)(x0 + tx));
     const float bly = fmaxf(0.01f, (float)(y0 - 1)), bhy = fminf((float)gy - 1.01f, (float)(y0 + ty));
     const float blz = 0.01f, bhz = (float)gz - 1.01f;
+    // the same box as centre and half extents, for the plane and shell tests of the pair culling
+    const float bcx = 0.5f * (blx + bhx), bcy = 0.5f * (bly + bhy), bcz = 0.5f * (blz + bhz);
+    const float bhx_ = 0.5f * (bhx - blx), bhy_ = 0.5f * (bhy - bly), bhz_ = 0.5f * (bhz - blz);
 
     // one pair per lane (`valid` lanes), all of its rotations: screen, queue, deposit
     auto process = [&](const int64_t p, const bool valid) {
@@ -795,9 +813,22 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
                     const float sx = sl + 8e-6f * (fabsf(cc.x) + fabsf(cr.x)) * rinv, sy = sl + 8e-6f * (fabsf(cc.y) + fabsf(cr.y)) * rinv,
                                 sz = sl + 8e-6f * (fabsf(cc.z) + fabsf(cr.z)) * rinv;
                     const float qx = (cc.x - cr.x) * rinv, qy = (cc.y - cr.y) * rinv, qz = (cc.z - cr.z) * rinv;
+                    // The circle is the intersection of a plane (through q, normal u) and a sphere (centre q, radius R), so
+                    // besides its bounding box two more necessary conditions are cheap: the acceptance box (centre bc,
+                    // half extents bh_) must reach the plane, and R must lie between the box's nearest and farthest
+                    // distance from q.  A circle larger than the object (most of them, for a network that has not learnt
+                    // the object) has a bounding box that covers every tile while the curve itself passes through few.
+                    const float dx = bcx - qx, dy = bcy - qy, dz = bcz - qz, sall = sl + (sx - sl) + (sy - sl) + (sz - sl);
+                    const float off_plane = fabsf((dx * u.x + dy * u.y) + dz * u.z);
+                    const float reach = (fabsf(u.x) * bhx_ + fabsf(u.y) * bhy_) + fabsf(u.z) * bhz_;
+                    const float nx = fmaxf(fabsf(dx) - bhx_, 0.f), ny = fmaxf(fabsf(dy) - bhy_, 0.f), nz = fmaxf(fabsf(dz) - bhz_, 0.f);
+                    const float fx = fabsf(dx) + bhx_, fy = fabsf(dy) + bhy_, fz = fabsf(dz) + bhz_;
+                    const float dmin2 = (nx * nx + ny * ny) + nz * nz, dmax2 = (fx * fx + fy * fy) + fz * fz;
+                    const float r_hi = R + sall, r_lo = fmaxf(R - sall, 0.f);
                     pass = (L >= 9e-8f) & (!A.adaptive | (R >= 0.15f)) &
                            (qx + ex_ + sx >= blx) & (qx - ex_ - sx < bhx) & (qy + ey_ + sy >= bly) & (qy - ey_ - sy < bhy) &
-                           (qz + ez_ + sz >= blz) & (qz - ez_ - sz < bhz);
+                           (qz + ez_ + sz >= blz) & (qz - ez_ - sz < bhz) &
+                           (off_plane <= reach + sall) & (dmin2 <= r_hi * r_hi * 1.0001f) & (dmax2 * 1.0001f >= r_lo * r_lo);
                 }
                 const unsigned long long m = __ballot(pass);
                 if (pass)
