@@ -80,9 +80,18 @@ __host__ __device__ inline VoteTiling vote_tiling(int gx, int gy, int gz)
 // one workgroup per CU (tile ~115 KiB): T*chunks ~ 256 workgroups, chunks of >= 1024 pairs.  With many tiles the
 // votes pile up in the few tiles around the peak, so the chunks are made 8x smaller and the hardware scheduler
 // balances ~2 000 workgroups over the CUs (measured 2.4x on a 14-tile grid with a sharp peak).
+// Every workgroup pays for zeroing and dumping a tile (and its share of the reduce), so the many-tile class takes only as many as
+// the balance needs: 512 up to 8 tiles, 1 024 / 2 048 beyond by the number of pairs (sweep on 5..32-tile grids after the rotated
+// workgroup -> tile mapping went in: with 2 048 workgroups a 5-tile grid took 163 us on uniform-bin inputs, 86 us with 512).
+__host__ __device__ inline int vote_wgs(int64_t n_ppfs, int T)
+{
+    if (T < 4) return VOTE_WGS_FEW;
+    if (T <= 8) return 512;
+    return n_ppfs >= (1 << 20) ? VOTE_WGS_MANY : 1024;
+}
 __host__ __device__ inline int vote_chunks(int64_t n_ppfs, int T, int64_t* chunk_pairs)
 {
-    int64_t c = (T >= 4 ? VOTE_WGS_MANY : VOTE_WGS_FEW) / T;
+    int64_t c = vote_wgs(n_ppfs, T) / T;
     int64_t cmax = (n_ppfs + 1023) / 1024;
     if (c > cmax) c = cmax;
     if (c < 1) c = 1;
