@@ -1417,7 +1417,7 @@ __global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__
         if (mask) mask[idx] = nz;
         if (chunk_counts) count_survivor(idx, nz);
     };
-    auto rotations = [&](const int64_t idx) {   // the reference's loop (:97-110) for one pair that passed stage 1
+    auto rotations = [&](const int64_t idx) {   // the reference's loop (:97-110) for one pair that passed stage 1, one pair per lane: full batches of 64 (throughput)
         const float2 o = reinterpret_cast<const float2*>(outputs)[idx];
         const int2 ij = reinterpret_cast<const int2*>(point_idxs)[idx];
         f3 a, ab, xd;
@@ -1441,10 +1441,64 @@ __global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__
         }
         finish(idx, found);
     };
+    // The same for the pairs left in the queue when the wave's share of the input ends -- on inputs where few pairs pass stage 1
+    // (the benchmark's: 0.3 %) that is all of them, and the kernel's duration was this loop's latency.  Frames one pair per lane
+    // (one round of dependent loads for all of them), then the rotations EIGHT LANES PER PAIR: in trip f lane 8g + s tests rotations s, s + 8, ... of pair
+    // f + g, whose frame it pulls from lane f + g (ds_bpermute).  One pair per lane walked up to 72 dependent iterations of ~60
+    // instructions -- 10 us of pure latency however few pairs there were (19 us for 100 k pairs and for 524 k alike); a group
+    // of eight walks 9, stops as soon as one of its lanes hits (the lowest rotation index of that trip is the reference's
+    // first hit), and a trip ends when its eight groups are done rather than a wave's 64 pairs.  (For full batches it measured
+    // 40 % slower than one pair per lane: two ballots per iteration, and every group waits for the slowest of its trip.)
+    auto stage2 = [&](const int first, const int count) {
+        f3 cc_l = {0.f, 0.f, 0.f}, x_l = cc_l, y_l = cc_l;
+        int n_l = 0;
+        const int idx_l = lane < count ? (int)q[first + lane] : 0;
+        if (lane < count) {
+            const float2 o = reinterpret_cast<const float2*>(outputs)[idx_l];
+            const int2 ij = reinterpret_cast<const int2*>(point_idxs)[idx_l];
+            f3 a, ab, xd;
+            pair_frame(points, ij.x, ij.y, a, ab, xd);
+            const float proj_len = o.x, odist = o.y;
+            cc_l = sub3(a, scl3(ab, proj_len));
+            x_l = scl3(xd, odist);
+            y_l = cross3(x_l, ab);
+            n_l = min((int)((double)(odist / res) * (2 * CPPF_PI)), n_rots);      // :97
+        }
+        const int g = lane >> 3, s8 = lane & 7;
+        for (int f = 0; f < count; f += 8) {
+            const int src = f + g;
+            const f3 cc = {__shfl(cc_l.x, src, 64), __shfl(cc_l.y, src, 64), __shfl(cc_l.z, src, 64)};
+            const f3 x = {__shfl(x_l.x, src, 64), __shfl(x_l.y, src, 64), __shfl(x_l.z, src, 64)};
+            const f3 y = {__shfl(y_l.x, src, 64), __shfl(y_l.y, src, 64), __shfl(y_l.z, src, 64)};
+            const int n_s = __shfl(n_l, src, 64);   // (unconditional: a bpermute reads nothing from a lane that is switched off)
+            const int n = src < count ? n_s : 0;
+            const int64_t idx = (int64_t)(uint32_t)__shfl(idx_l, src, 64);
+            const int tbase = n * (n - 1) / 2;
+            bool open = src < count;   // the group has not found its rotation yet
+            for (int i0 = 0; __ballot(open && i0 < n) != 0ull; i0 += 8) {
+                const int i = i0 + s8;
+                bool ok = false;
+                f3 offset = {0.f, 0.f, 0.f};
+                if (open && i < n) {
+                    const float2 cs = in_lds ? ltab[tbase + i] : rot_cs(i, n);
+                    offset = add3(scl3(x, cs.x), scl3(y, cs.y));
+                    const f3 pc = add3(cc, offset);
+                    const f3 gq = div3(sub3(pc, cr), res);
+                    ok = !(len3(sub3(pc, gt)) > tol) &&                                       // :101
+                         !(gq.x < 0.f || gq.y < 0.f || gq.z < 0.f || gq.x >= bx || gq.y >= by || gq.z >= bz);  // :103-107
+                }
+                const unsigned hits = (unsigned)(__ballot(ok) >> (8 * g)) & 0xffu;   // this group's lanes
+                if (open && hits) {
+                    if (s8 == __builtin_ctz(hits)) finish(idx, neg3(offset));                  // :108, the first such rotation
+                    open = false;
+                }
+            }
+            if (open && s8 == 0) finish(idx, f3{0.f, 0.f, 0.f});                              // :96, no rotation passed
+        }
+    };
     // A wave takes BV_U x 64 consecutive pairs per trip and has all their loads in flight before it looks at any of them
     // (one pair per lane per trip was two dependent round trips to memory per pair with nothing else to do: 27 us for 9 MB).
     constexpr int BV_U = 4;
-    constexpr int BV_COOP_MAX = 6;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x * BV_U;
     for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63)) * BV_U;; base += stride) {
         const bool more = base < n_ppfs;   // wave-uniform
@@ -1523,47 +1577,12 @@ __global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__
             }
         }
         if (!more) {
-            // A handful of pairs left in the queue are taken
-            // one at a time by the WHOLE wave, lane i testing rotation i: the first rotation that passes is the lowest set
-            // bit of a ballot -- a lane walking up to 72 rotations of ~60 instructions alone was a third of the launch.
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (qn > BV_COOP_MAX) {   // enough of them to fill lanes: one pair per lane as above
+            if (qn > 16) {   // many left (dense inputs): throughput counts, one pair per lane as for the full batches
                 const uint32_t pidx = lane < qn ? q[lane] : 0u;
                 if (lane < qn) rotations((int64_t)pidx);
-                qn = 0;
-            }
-            for (int e = 0; e < qn; ++e) {
-                const int64_t idx = (int64_t)q[e];
-                const float2 o = reinterpret_cast<const float2*>(outputs)[idx];
-                const int2 ij = reinterpret_cast<const int2*>(point_idxs)[idx];
-                f3 a, ab, xd;
-                pair_frame(points, ij.x, ij.y, a, ab, xd);
-                const float proj_len = o.x, odist = o.y;
-                const f3 cc = sub3(a, scl3(ab, proj_len));
-                const f3 x = scl3(xd, odist);
-                const f3 y = cross3(x, ab);
-                const int n = min((int)((double)(odist / res) * (2 * CPPF_PI)), n_rots);      // :97
-                const int tbase = n * (n - 1) / 2;
-                bool done = false;
-                for (int i0 = 0; i0 < n && !done; i0 += 64) {
-                    const int i = i0 + lane;
-                    bool ok = false;
-                    f3 offset = {0.f, 0.f, 0.f};
-                    if (i < n) {
-                        const float2 cs = in_lds ? ltab[tbase + i] : rot_cs(i, n);
-                        offset = add3(scl3(x, cs.x), scl3(y, cs.y));
-                        const f3 pc = add3(cc, offset);
-                        const f3 g = div3(sub3(pc, cr), res);
-                        ok = !(len3(sub3(pc, gt)) > tol) &&                                     // :101
-                             !(g.x < 0.f || g.y < 0.f || g.z < 0.f || g.x >= bx || g.y >= by || g.z >= bz);  // :103-107
-                    }
-                    const unsigned long long hit = __ballot(ok);
-                    if (hit) {
-                        if (lane == __builtin_ctzll(hit)) finish(idx, neg3(offset));            // :108, the first such rotation
-                        done = true;
-                    }
-                }
-                if (!done && lane == 0) finish(idx, f3{0.f, 0.f, 0.f});
+            } else if (qn > 0) {
+                stage2(0, qn);
             }
             break;
         }
