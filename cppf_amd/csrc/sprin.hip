@@ -205,6 +205,7 @@ struct ConvArgs {
     int N, k, n_in, out_stride;
     float* mixed_out;       // optional [N][32 * n_in]: the contraction, kept for the backward (training)
     const int32_t* n_dev;   // *_dyn: point count in memory (N is then the capacity the launch is sized for)
+    uint32_t* glob;         // the per-channel maxima sprin_glob_kernel accumulates after this launch: zeroed here (64 words)
 };
 
 // hidden = {32, 64, 32, 32}, rank 32, n_out 32 (train.py:34).  Dynamic LDS: the workgroup's weight image
@@ -213,6 +214,7 @@ __global__ __launch_bounds__(SP_WAVES_MAX * 64) void sprin_conv_kernel(ConvArgs 
 {
     extern __shared__ __attribute__((aligned(16))) float sp_lds[];
     const int w = threadIdx.x >> 6, lane = lane_id();
+    if (blockIdx.x == 0 && threadIdx.x < 64) A.glob[threadIdx.x] = 0u;   // (instead of a memset node per layer)
     const int n_in = A.n_in, k = A.k;
     const int per_wave = sp_per_wave(n_in);
     float* Wl = sp_lds;                                   // 16-byte aligned image
@@ -508,12 +510,11 @@ static int sp_forward(const float* pc, const float* nrm, const int32_t* nbrs, in
         const int n_in = l == 0 ? n_nbr_feats : W;
         float* dst = ((num_layers - 1 - l) & 1) ? ping : out;
         const float* src = l == 0 ? nullptr : (dst == out ? ping : out);
-        ConvArgs A{pc, nrm, src, nbrs, p, images + (size_t)l * SPW_FLOATS, dst, n_points, k, n_in, W, l == 0 ? mixed_out : nullptr, n_dev};
+        ConvArgs A{pc, nrm, src, nbrs, p, images + (size_t)l * SPW_FLOATS, dst, n_points, k, n_in, W, l == 0 ? mixed_out : nullptr, n_dev,
+                   glob};
         const int waves = sp_waves(n_in);
         const size_t lds = ((size_t)SPW_FLOATS + (size_t)waves * sp_per_wave(n_in)) * sizeof(float);
         hipError_t e = hipFuncSetAttribute((const void*)sprin_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        e = hipMemsetAsync(glob, 0, 256, st);
         if (e != hipSuccess) return (int)e;
         sprin_conv_kernel<<<(n_points + waves - 1) / waves, waves * 64, lds, st>>>(A);
         p += conv_params(hidden, n_hidden, rank, n_in, n_out);

@@ -1365,8 +1365,19 @@ __global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__
                                                               const float* __restrict__ gt_center, float tol,
                                                               uint8_t* __restrict__ mask, const int32_t* __restrict__ shape,
                                                               const unsigned long long* __restrict__ vote_ws,
-                                                              int32_t* __restrict__ chunk_counts)
+                                                              int32_t* __restrict__ chunk_counts,
+                                                              const long long* __restrict__ idx64,
+                                                              int32_t* __restrict__ idx32_out)
 {
+    // cppf_backvote_count64: the pair list as the caller holds it (int64, nocs/inference.py:177); the int32 copy the later
+    // launches of the tail read is written on the way (this kernel touches every pair anyway)
+    auto load_ij = [&](const int64_t c) -> int2 {
+        if (idx64) {
+            const longlong2 v = reinterpret_cast<const longlong2*>(idx64)[c];
+            return make_int2((int)v.x, (int)v.y);
+        }
+        return reinterpret_cast<const int2*>(point_idxs)[c];
+    };
     if (shape) { gx = shape[1]; gy = shape[2]; gz = shape[3]; }   // dims record in memory (*_dyn)
     // (cos,sin) table for every n <= n_rots, built per block in LDS when it fits.
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1419,7 +1430,7 @@ __global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__
     };
     auto rotations = [&](const int64_t idx) {   // the reference's loop (:97-110) for one pair that passed stage 1, one pair per lane: full batches of 64 (throughput)
         const float2 o = reinterpret_cast<const float2*>(outputs)[idx];
-        const int2 ij = reinterpret_cast<const int2*>(point_idxs)[idx];
+        const int2 ij = load_ij(idx);
         f3 a, ab, xd;
         pair_frame(points, ij.x, ij.y, a, ab, xd);
         const float proj_len = o.x, odist = o.y;
@@ -1455,7 +1466,7 @@ __global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__
         const int idx_l = lane < count ? (int)q[first + lane] : 0;
         if (lane < count) {
             const float2 o = reinterpret_cast<const float2*>(outputs)[idx_l];
-            const int2 ij = reinterpret_cast<const int2*>(point_idxs)[idx_l];
+            const int2 ij = load_ij(idx_l);
             f3 a, ab, xd;
             pair_frame(points, ij.x, ij.y, a, ab, xd);
             const float proj_len = o.x, odist = o.y;
@@ -1511,7 +1522,8 @@ __global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__
                 const int64_t i = base + u * 64 + lane;
                 const int64_t c = i < n_ppfs ? i : n_ppfs - 1;
                 o_[u] = reinterpret_cast<const float2*>(outputs)[c];
-                ij_[u] = reinterpret_cast<const int2*>(point_idxs)[c];
+                ij_[u] = load_ij(c);
+                if (idx32_out && i < n_ppfs) reinterpret_cast<int2*>(idx32_out)[i] = ij_[u];
             }
 #pragma unroll
             for (int u = 0; u < BV_U; ++u) { pa_[u] = ld3(points, ij_[u].x); pb_[u] = ld3(points, ij_[u].y); }
@@ -1592,18 +1604,19 @@ __global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__
 static int backvote_impl(const float* points, const float* outputs, float* out_offsets,
                          const int32_t* point_idxs, const float* corner, float res, int64_t n_ppfs, int n_rots,
                          int gx, int gy, int gz, const float* gt_center, float tol, uint8_t* mask, void* stream,
-                         const int32_t* shape_dev, const void* vote_workspace = nullptr, int32_t* chunk_counts = nullptr)
+                         const int32_t* shape_dev, const void* vote_workspace = nullptr, int32_t* chunk_counts = nullptr,
+                         const long long* idx64 = nullptr, int32_t* idx32_out = nullptr)
 {
     if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || n_ppfs < 0 || n_ppfs > 0xffffffffll) return CPPF_EINVAL;
     if (n_ppfs == 0) return 0;
-    if (!points || !outputs || (!out_offsets && !mask) || !point_idxs || !corner || !gt_center) return CPPF_EINVAL;
+    if (!points || !outputs || (!out_offsets && !mask) || (!point_idxs && !idx64) || !corner || !gt_center) return CPPF_EINVAL;
     const int entries = tri(n_rots);
     const size_t lds = (entries <= VOTE_TAB_LDS_MAX ? (size_t)entries * sizeof(float2) : 0) + 4 * 128 * sizeof(uint32_t);
     int64_t nb = (n_ppfs + 4 * 256 - 1) / (4 * 256);   // BV_U = 4 pairs per thread and trip
     if (nb > 1024) nb = 1024;
     hipLaunchKernelGGL(backvote_kernel, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, points,
                        outputs, out_offsets, point_idxs, corner, res, n_ppfs, n_rots, gx, gy, gz, gt_center, tol,
-                       mask, shape_dev, static_cast<const unsigned long long*>(vote_workspace), chunk_counts);
+                       mask, shape_dev, static_cast<const unsigned long long*>(vote_workspace), chunk_counts, idx64, idx32_out);
     CPPF_CHECK_LAUNCH();
     return 0;
 }
@@ -1636,6 +1649,18 @@ extern "C" int cppf_backvote_count(const float* points, const float* outputs, co
     return backvote_impl(points, outputs, nullptr, point_idxs, corner, res, n_ppfs, n_rots, shape_dev ? 1 : gx,
                          shape_dev ? 1 : gy, shape_dev ? 1 : gz, gt_center, tol, mask, stream, shape_dev, vote_workspace,
                          chunk_counts);
+}
+
+extern "C" int cppf_backvote_count64(const float* points, const float* outputs, const long long* point_idxs64,
+                                     int32_t* idx32_out, const float* corner, float res, int64_t n_ppfs, int n_rots, int gx,
+                                     int gy, int gz, const int32_t* shape_dev, const float* gt_center, float tol, uint8_t* mask,
+                                     int32_t* chunk_counts, const void* vote_workspace, void* stream)
+{
+    if (!mask || !chunk_counts || !point_idxs64) return CPPF_EINVAL;
+    if (!shape_dev && (gx < 1 || gy < 1 || gz < 1)) return CPPF_EINVAL;
+    return backvote_impl(points, outputs, nullptr, nullptr, corner, res, n_ppfs, n_rots, shape_dev ? 1 : gx,
+                         shape_dev ? 1 : gy, shape_dev ? 1 : gz, gt_center, tol, mask, stream, shape_dev, vote_workspace,
+                         chunk_counts, point_idxs64, idx32_out);
 }
 
 extern "C" int cppf_backvote_dyn(const float* points, const float* outputs, float* out_offsets,
@@ -2154,7 +2179,7 @@ struct PoseSumsArgs {
 };
 __global__ __launch_bounds__(RED_THREADS) void pose_sums_kernel(PoseSumsArgs A)
 {
-    __shared__ double sh[RED_THREADS / 64];
+    __shared__ double shc[RED_THREADS / 64][PS_COMP];
     __shared__ unsigned long long best[PS_MAX_DIRS][RED_THREADS / 64];
     __shared__ double bdir[PS_MAX_DIRS][3];
     __shared__ unsigned drawn;
@@ -2211,12 +2236,22 @@ __global__ __launch_bounds__(RED_THREADS) void pose_sums_kernel(PoseSumsArgs A)
         }
     }
     double* mine = A.partial + (size_t)PS_COMP * blockIdx.x;
+    // the seven block sums with one barrier: butterflies inside the wave, then thread c adds the four wave sums of component c
+    // in wave order (the order block_sum uses)
 #pragma unroll
     for (int c = 0; c < PS_COMP - 1; ++c) {
-        const double v = block_sum(acc[c], sh);
-        // device-scope atomic stores and loads: the block that sums them runs on another CU, maybe another XCD
-        if (tid == 0) __hip_atomic_store(mine + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double v = acc[c];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((tid & 63) == 0) shc[tid >> 6][c] = v;
     }
+    __syncthreads();
+    if (tid < PS_COMP - 1) {
+        double v = 0.0;
+        for (int w = 0; w < RED_THREADS / 64; ++w) v += shc[w][tid];
+        // device-scope atomic stores and loads: the block that sums them runs on another CU, maybe another XCD
+        __hip_atomic_store(mine + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();   // (workgroup scope: the seven stores are ordered before thread 0's release below)
     if (tid == 0) drawn = __hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (drawn != RED_BLOCKS - 1) return;

@@ -352,12 +352,13 @@ def estimate_pose(encoder, pc, pc_normal, feat, point_idxs, u_tr, u_rot, cfg, sp
 
 
 def _enqueue_tail(ws, pc, pc_normal, idx32, outputs, heads, corner, cfg, dims, num_rots, angle_tol, max_rot_pairs,
-                  sph32_d, sph64_d, sorted_y, shape=None, second_pass=None):
+                  sph32_d, sph64_d, sorted_y, shape=None, second_pass=None, idx64=None):
     """nocs/inference.py:209-303,335 after the centre vote, all on the current stream; leaves the 21-double
     result record in ws.rec (T[3], best_dir[2,3], sign sums[2,3], scale sums[4], argmax, peak).  `shape`: the device
     dims record of a shape-polymorphic pipeline (then `dims` is unused).  `second_pass` = (encoder, feat, point_idxs, u_rot):
     the heads of the surviving pairs are computed here, after the compaction, like the reference's second
-    ppf_encoder call (:236-256); without it `heads` must already hold them."""
+    ppf_encoder call (:236-256); without it `heads` must already hold them.  `idx64`: the pair list as int64 -- then `idx32`
+    is an OUTPUT, filled by the back-vote launch for the launches after it (no conversion pass)."""
     dev = pc.device
     L = _lib.lib()
     st = stream_ptr(dev)
@@ -377,11 +378,20 @@ def _enqueue_tail(ws, pc, pc_normal, idx32, outputs, heads, corner, cfg, dims, n
         # back-vote filter (:216-231) --------------------------------------------------------------
         # mask only: the offsets themselves (:220-228) are consumed nowhere else, so no buffer is zeroed or written
         tol = float(np.float32(3 * cfg.res))
-        if 0 < P <= 8192 * 1024:     # survivors counted per chunk by the back-vote itself: the compaction is one launch
-            _lib.check(L.cppf_backvote_count(pc.data_ptr(), outputs.data_ptr(), idx32.data_ptr(), corner.data_ptr(),
-                                             float(cfg.res), P, num_rots, gx, gy, gz, shape_ptr, ws.T32.data_ptr(), tol,
-                                             ws.mask.data_ptr(), ws.chunk_counts.data_ptr(), vws_ptr, st),
-                       "cppf_backvote_count")
+        fused = 0 < P <= 8192 * 1024
+        if idx64 is not None and not fused:
+            idx32.copy_(idx64)
+        if fused:                    # survivors counted per chunk by the back-vote itself: the compaction is one launch
+            if idx64 is not None:
+                _lib.check(L.cppf_backvote_count64(pc.data_ptr(), outputs.data_ptr(), idx64.data_ptr(), idx32.data_ptr(),
+                                                   corner.data_ptr(), float(cfg.res), P, num_rots, gx, gy, gz, shape_ptr,
+                                                   ws.T32.data_ptr(), tol, ws.mask.data_ptr(), ws.chunk_counts.data_ptr(),
+                                                   vws_ptr, st), "cppf_backvote_count64")
+            else:
+                _lib.check(L.cppf_backvote_count(pc.data_ptr(), outputs.data_ptr(), idx32.data_ptr(), corner.data_ptr(),
+                                                 float(cfg.res), P, num_rots, gx, gy, gz, shape_ptr, ws.T32.data_ptr(), tol,
+                                                 ws.mask.data_ptr(), ws.chunk_counts.data_ptr(), vws_ptr, st),
+                           "cppf_backvote_count")
             _lib.check(L.cppf_compact_scatter(ws.mask.data_ptr(), P, ws.chunk_counts.data_ptr(), ws.surv.data_ptr(),
                                               ws.count.data_ptr(), st), "cppf_compact_scatter")
         else:
@@ -495,12 +505,12 @@ class PosePipeline(CenterPipeline):
 
     def _chain(self):
         super()._chain()
-        self.idx32.copy_(self.idx)                                            # the pose-tail kernels take int32 indices
         self.heads = self.ws.heads
         _enqueue_tail(self.ws, self.pc, self.nrm, self.idx32, self.outputs, self.heads, self.corner, self.cfg,
                       self.dims, self.num_rots, self.angle_tol, self.max_rot_pairs, *self._sph,
                       shape=self.shape if self.dynamic else None,
-                      second_pass=(self.encoder, self.feat, self.idx, self.u_rot))
+                      second_pass=(self.encoder, self.feat, self.idx, self.u_rot),
+                      idx64=self.idx)             # the tail's kernels take int32 indices: written by the back-vote launch
 
     def run(self, rng=None, check_weights=True):
         super().run(check_weights)

@@ -290,6 +290,12 @@ int cppf_backvote_count(const float* points, const float* outputs, const int32_t
                         float res, int64_t n_ppfs, int n_rots, int gx, int gy, int gz, const int32_t* shape_dev,
                         const float* gt_center, float tol, uint8_t* mask, int32_t* chunk_counts,
                         const void* vote_workspace, void* stream);
+/* cppf_backvote_count reading the pair list as int64 (the caller's np.random.randint array, nocs/inference.py:177) and leaving
+ * its int32 copy in idx32_out (int32[n_ppfs][2], may be null) for the launches that follow. */
+int cppf_backvote_count64(const float* points, const float* outputs, const long long* point_idxs64, int32_t* idx32_out,
+                          const float* corner, float res, int64_t n_ppfs, int n_rots, int gx, int gy, int gz,
+                          const int32_t* shape_dev, const float* gt_center, float tol, uint8_t* mask, int32_t* chunk_counts,
+                          const void* vote_workspace, void* stream);
 int cppf_compact_scatter(const uint8_t* mask, int64_t n, const int32_t* chunk_counts, int32_t* surv, int32_t* count,
                          void* stream);
 int cppf_rot_sphere_count_dirs(const float* points, const float* preds_rot, int rot_stride, int rot_dir_step, int n_dirs,

@@ -582,6 +582,17 @@ def test_backvote_count_and_scatter_match_oracle(oracle, dev, n_pairs_per_point,
     _lib.check(L.cppf_compact_scatter(m.data_ptr(), P, chunk_counts.data_ptr(), surv.data_ptr(), cnt.data_ptr(),
                                       stream_ptr(dev)), "compact_scatter")
     torch.cuda.synchronize()
+    # the same from the int64 pair list, leaving the int32 copy behind
+    m64 = torch.empty(P, dtype=torch.uint8, device=dev)
+    cc64 = torch.zeros(n_chunks, dtype=torch.int32, device=dev)
+    idx64_d, idx32_out = t(idx.astype(np.int64), dev), torch.full((P, 2), -1, dtype=torch.int32, device=dev)
+    _lib.check(L.cppf_backvote_count64(pc_d.data_ptr(), out_d.data_ptr(), idx64_d.data_ptr(), idx32_out.data_ptr(),
+                                       cor_d.data_ptr(), cfg.res, P, 72, int(dims[0]), int(dims[1]), int(dims[2]), None,
+                                       T32.data_ptr(), float(np.float32(3 * cfg.res)), m64.data_ptr(), cc64.data_ptr(), None,
+                                       stream_ptr(dev)), "backvote_count64")
+    torch.cuda.synchronize()
+    assert torch.equal(m64, m) and torch.equal(cc64, chunk_counts)
+    np.testing.assert_array_equal(idx32_out.cpu().numpy(), idx32)
     np.testing.assert_array_equal(T64.cpu().numpy()[:3], T)
     np.testing.assert_array_equal(T32.cpu().numpy(), center)
     np.testing.assert_array_equal(ip.cpu().numpy(), [flat, 7.5])
