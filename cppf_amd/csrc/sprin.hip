@@ -4,8 +4,8 @@
 //   knn_kernel           torch.topk(dist, k, largest=False)            models/model.py:47
 //   sprin_conv_kernel    gather, rifeat, conv_kernel MLP, rank contraction, outnet, LayerNorm
 //                                                                      models/model.py:48-57, models/sprin.py:40-107
-//   sprin_glob_kernel /  GlobalInfoProp: linear, max over points, concat models/sprin.py:75-84
-//   sprin_fill_kernel
+//                        + GlobalInfoProp's linear and the workgroup's channel maxima (models/sprin.py:75-84)
+//   sprin_fill_kernel    GlobalInfoProp: maximum over the workgroups, concat           models/sprin.py:75-84
 //
 // Arithmetic follows oracle/sprin_oracle.c to the bit (-ffp-contract=off, bias-seeded fmaf chains over
 // ascending input index, sequential sums over ascending neighbour index, correctly rounded sqrt/divide),
@@ -205,7 +205,11 @@ struct ConvArgs {
     int N, k, n_in, out_stride;
     float* mixed_out;       // optional [N][32 * n_in]: the contraction, kept for the backward (training)
     const int32_t* n_dev;   // *_dyn: point count in memory (N is then the capacity the launch is sized for)
-    uint32_t* glob;         // the per-channel maxima sprin_glob_kernel accumulates after this launch: zeroed here (64 words)
+    // GlobalInfoProp (models/sprin.py:75-84) in the epilogue: linear(n_out -> n_glob) per point, maximum over the workgroup's
+    // points to wgmax[blockIdx][32] (plain stores: no atomics, nothing to zero); sprin_fill_kernel finishes the maximum
+    const float* glob_w;    // Wa[n_glob][n_out], ba[n_glob]
+    uint32_t* wgmax;
+    int n_glob;
 };
 
 // hidden = {32, 64, 32, 32}, rank 32, n_out 32 (train.py:34).  Dynamic LDS: the workgroup's weight image
@@ -214,7 +218,10 @@ __global__ __launch_bounds__(SP_WAVES_MAX * 64) void sprin_conv_kernel(ConvArgs 
 {
     extern __shared__ __attribute__((aligned(16))) float sp_lds[];
     const int w = threadIdx.x >> 6, lane = lane_id();
-    if (blockIdx.x == 0 && threadIdx.x < 64) A.glob[threadIdx.x] = 0u;   // (instead of a memset node per layer)
+    __shared__ uint32_t gmax[32];
+    __shared__ float gw[32 * SP_NOUT + 32];   // GlobalInfoProp's weights and bias, read in the epilogue
+    if (threadIdx.x < 32) gmax[threadIdx.x] = 0u;
+    for (int i = threadIdx.x; i < A.n_glob * (SP_NOUT + 1); i += blockDim.x) gw[i] = A.glob_w[i];
     const int n_in = A.n_in, k = A.k;
     const int per_wave = sp_per_wave(n_in);
     float* Wl = sp_lds;                                   // 16-byte aligned image
@@ -330,43 +337,58 @@ __global__ __launch_bounds__(SP_WAVES_MAX * 64) void sprin_conv_kernel(ConvArgs 
     const float inv = 1.0f / sqrtf(v / (float)SP_NOUT + 1e-5f);
     const float z = ((acc - mean) * inv) * bo[SP_NOUT + o] + bo[2 * SP_NOUT + o];
     if (live && lane < SP_NOUT) A.out[(size_t)n * A.out_stride + lane] = z;
+    // GlobalInfoProp's linear on the row just written: lane g owns channel g, a bias-seeded fmaf chain over ascending input
+    // index (what sprin_glob_kernel did with one thread per point and 32 strided reads of the row), then the maximum -- exact
+    // in any order -- over the workgroup's points
+    if (lane < SP_NOUT) yv[lane] = z;     // (this wave's reads of yv above are done: LDS operations of a wave stay in order)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int gch = lane < A.n_glob ? lane : 0;
+    const float* Wa = gw + gch * SP_NOUT;
+    float ga = gw[A.n_glob * SP_NOUT + gch];
+#pragma unroll 8
+    for (int q = 0; q < SP_NOUT; ++q) ga = fmaf(Wa[q], yv[q], ga);
+    if (live && lane < A.n_glob) atomicMax(&gmax[lane], f2ord(ga));
+    __syncthreads();
+    if (threadIdx.x < 32) A.wgmax[(size_t)blockIdx.x * 32 + threadIdx.x] = gmax[threadIdx.x];
 }
 
-// GlobalInfoProp (models/sprin.py:75-84): one thread per point computes linear(n_out -> n_glob), the
-// per-channel maximum goes to glob[] as an order-preserving uint (max is exact in any order).
-__global__ __launch_bounds__(256) void sprin_glob_kernel(const float* __restrict__ feat, int N, int stride, int n_glob,
-                                                         const float* __restrict__ Wa, uint32_t* __restrict__ glob,
+// GlobalInfoProp (models/sprin.py:75-84), second half: the maximum over the workgroups' maxima (every block recomputes it from
+// L2: <= N/4 x 32 words) and the broadcast into columns n_out.. of every point's row.
+__global__ __launch_bounds__(256) void sprin_fill_kernel(float* __restrict__ out, int N, int stride, int n_glob,
+                                                         const uint32_t* __restrict__ wgmax, int waves,
                                                          const int32_t* __restrict__ n_dev)
 {
     if (n_dev) N = min(*n_dev, N);
-    if ((int)blockIdx.x * 256 >= N) return;
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    const int nc = n < N ? n : N - 1;
-    float x[SP_NOUT];
-#pragma unroll
-    for (int o = 0; o < SP_NOUT; ++o) x[o] = feat[(size_t)nc * stride + o];
-    const float* ba = Wa + n_glob * SP_NOUT;
-    for (int g = 0; g < n_glob; ++g) {
-        float acc = ba[g];
-#pragma unroll
-        for (int o = 0; o < SP_NOUT; ++o) acc = fmaf(Wa[g * SP_NOUT + o], x[o], acc);
-        uint32_t key = f2ord(acc);
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const uint32_t other = (uint32_t)__shfl_xor((int)key, d);
-            key = other > key ? other : key;
+    if ((int64_t)blockIdx.x * 256 >= (int64_t)N * n_glob) return;
+    __shared__ uint32_t part[256];
+    __shared__ uint32_t gl[32];
+    const int n_wgs = (N + waves - 1) / waves;        // the conv launch's workgroups that held points
+    const int pad = n_glob <= 8 ? 8 : (n_glob <= 16 ? 16 : 32), rows = 256 / pad;   // thread = (row r, channel g)
+    const int g = threadIdx.x & (pad - 1), r = threadIdx.x / pad;
+    uint32_t m = 0u;
+    if (g < n_glob) {
+        int b = r;
+        for (; b + 3 * rows < n_wgs; b += 4 * rows) {   // four independent loads in flight
+            const uint32_t v0 = wgmax[(size_t)b * 32 + g], v1 = wgmax[(size_t)(b + rows) * 32 + g],
+                           v2 = wgmax[(size_t)(b + 2 * rows) * 32 + g], v3 = wgmax[(size_t)(b + 3 * rows) * 32 + g];
+            const uint32_t a = v0 > v1 ? v0 : v1, c = v2 > v3 ? v2 : v3;
+            m = a > m ? a : m;
+            m = c > m ? c : m;
         }
-        if ((threadIdx.x & 63) == 0) atomicMax(&glob[g], key);
+        for (; b < n_wgs; b += rows) { const uint32_t v = wgmax[(size_t)b * 32 + g]; m = v > m ? v : m; }
     }
-}
-__global__ __launch_bounds__(256) void sprin_fill_kernel(float* __restrict__ out, int N, int stride, int n_glob,
-                                                         const uint32_t* __restrict__ glob, const int32_t* __restrict__ n_dev)
-{
-    if (n_dev) N = min(*n_dev, N);
+    part[threadIdx.x] = m;
+    __syncthreads();
+    if (threadIdx.x < n_glob) {
+        uint32_t v = part[threadIdx.x];
+        for (int k = 1; k < rows; ++k) { const uint32_t o = part[k * pad + threadIdx.x]; v = o > v ? o : v; }
+        gl[threadIdx.x] = v;
+    }
+    __syncthreads();
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= N * n_glob) return;
-    const int n = t / n_glob, g = t - n * n_glob;
-    out[(size_t)n * stride + SP_NOUT + g] = ord2f(glob[g]);
+    const int n = t / n_glob, c = t - n * n_glob;
+    out[(size_t)n * stride + SP_NOUT + c] = ord2f(gl[c]);
 }
 
 int64_t conv_params(const int32_t* hidden, int n_hidden, int rank, int n_in, int n_out)
@@ -448,9 +470,10 @@ int cppf_point_encoder_pack(const float* natural, const int32_t* hidden, int n_h
 
 size_t cppf_point_encoder_workspace_bytes(int n_points, int n_out, int n_glob, int num_layers)
 {
-    // 256 B of per-channel maxima + (multi-layer only) one [N, n_out+n_glob] ping buffer
+    // 256 B (spare) + (multi-layer only) one [N, n_out+n_glob] ping buffer + the conv workgroups' channel maxima
     size_t b = 256;
-    if (num_layers > 1) b += (size_t)n_points * (n_out + n_glob) * sizeof(float);
+    if (num_layers > 1) b += ((size_t)n_points * (n_out + n_glob) * sizeof(float) + 255) / 256 * 256;
+    b += (size_t)((n_points + 3) / 4) * 32 * sizeof(uint32_t);
     return b;
 }
 
@@ -501,8 +524,9 @@ static int sp_forward(const float* pc, const float* nrm, const int32_t* nbrs, in
         return CPPF_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int W = n_out + n_glob;
-    uint32_t* glob = (uint32_t*)workspace;
     float* ping = (float*)((char*)workspace + 256);
+    uint32_t* wgmax = (uint32_t*)((char*)workspace + 256 +
+                                  (num_layers > 1 ? ((size_t)n_points * W * sizeof(float) + 255) / 256 * 256 : 0));
     const float* p = packed;
     const float* images = packed + sp_natural_floats(hidden, n_hidden, rank, n_nbr_feats, n_out, n_glob, num_layers);
     // layer l writes `dst`; the last layer must land in `out`
@@ -510,16 +534,16 @@ static int sp_forward(const float* pc, const float* nrm, const int32_t* nbrs, in
         const int n_in = l == 0 ? n_nbr_feats : W;
         float* dst = ((num_layers - 1 - l) & 1) ? ping : out;
         const float* src = l == 0 ? nullptr : (dst == out ? ping : out);
+        const float* glob_w = p + conv_params(hidden, n_hidden, rank, n_in, n_out);
         ConvArgs A{pc, nrm, src, nbrs, p, images + (size_t)l * SPW_FLOATS, dst, n_points, k, n_in, W, l == 0 ? mixed_out : nullptr, n_dev,
-                   glob};
+                   glob_w, wgmax, n_glob};
         const int waves = sp_waves(n_in);
         const size_t lds = ((size_t)SPW_FLOATS + (size_t)waves * sp_per_wave(n_in)) * sizeof(float);
         hipError_t e = hipFuncSetAttribute((const void*)sprin_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         sprin_conv_kernel<<<(n_points + waves - 1) / waves, waves * 64, lds, st>>>(A);
         p += conv_params(hidden, n_hidden, rank, n_in, n_out);
-        sprin_glob_kernel<<<(n_points + 255) / 256, 256, 0, st>>>(dst, n_points, W, n_glob, p, glob, n_dev);
-        sprin_fill_kernel<<<(n_points * n_glob + 255) / 256, 256, 0, st>>>(dst, n_points, W, n_glob, glob, n_dev);
+        sprin_fill_kernel<<<(n_points * n_glob + 255) / 256, 256, 0, st>>>(dst, n_points, W, n_glob, wgmax, waves, n_dev);
         p += (size_t)n_glob * n_out + n_glob;
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;

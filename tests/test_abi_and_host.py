@@ -218,8 +218,9 @@ def test_point_encoder_and_backward_abi_without_a_device(golden):
     hid = (C.c_int * 4)(32, 64, 32, 32)
     assert L.cppf_point_encoder_packed_floats(hid, 4, 32, 2, 32, 8, 1) == 9256 + 6912   # parameters of train.py:34 + MFMA image
     assert L.cppf_point_encoder_packed_floats((C.c_int * 2)(16, 24), 2, 32, 2, 32, 8, 1) == 3808        # other shapes: natural block only
-    assert L.cppf_point_encoder_workspace_bytes(4096, 32, 8, 1) == 256
-    assert L.cppf_point_encoder_workspace_bytes(4096, 32, 8, 2) == 256 + 4096 * 40 * 4
+    # 256 spare bytes (+ a [N, 40] ping buffer when layers alternate) + 32 channel maxima per conv workgroup of >= 4 points
+    assert L.cppf_point_encoder_workspace_bytes(4096, 32, 8, 1) == 256 + 1024 * 32 * 4
+    assert L.cppf_point_encoder_workspace_bytes(4096, 32, 8, 2) == 256 + 4096 * 40 * 4 + 1024 * 32 * 4
     assert L.cppf_knn(None, None, 10, 3, None, None) == -1                               # no points, no matrix
     assert L.cppf_knn(None, None, 0, 3, None, None) == 0                                 # empty cloud: legal no-op
     assert L.cppf_knn(None, None, 10, 0, None, None) == -1
