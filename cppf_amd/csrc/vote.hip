@@ -1932,7 +1932,7 @@ __global__ __launch_bounds__(SPH_THREADS) void rot_sphere_kernel(const float* __
 // utils/util.py:102-118 is): a candidate c can only match bins with |s.y - c.y| < sqrt(2 - 2 thr), so
 // each lane takes candidates and tests only that band of bins (~14 of 480 at 1.5 deg) instead of every
 // lane sweeping every candidate.  Same dot product, same threshold test -> identical counts.
-#define SPHB_PPB 8
+#define SPHB_PPB 8   // most pairs per group; few survivors are taken 2 at a time, see the kernel
 __global__ __launch_bounds__(256) void rot_sphere_band_kernel(const float* __restrict__ points,
                                                               const float* __restrict__ preds_rot, int rot_stride,
                                                               const int32_t* __restrict__ point_idxs,
@@ -1952,20 +1952,26 @@ __global__ __launch_bounds__(256) void rot_sphere_band_kernel(const float* __res
     float2* row = reinterpret_cast<float2*>(cnt + n_sphere);      // [n_rots]
     int64_t n_sel = n_sel_dev ? (int64_t)*n_sel_dev : n_sel_host;
     if (n_sel > max_pairs) n_sel = max_pairs;
-    const int64_t k0 = (int64_t)blockIdx.x * SPHB_PPB;
-    if (k0 >= n_sel) return;
-    const int np = (int)min((int64_t)SPHB_PPB, n_sel - k0);
+    const int ppb = n_sel > 4096 ? SPHB_PPB : 2;   // (uniform over the launch)
+    if ((int64_t)blockIdx.x * ppb >= n_sel) return;
     for (int i = threadIdx.x; i < 3 * n_sphere; i += 256) sph[i] = sphere[i];
     for (int i = threadIdx.x; i < n_sphere; i += 256) cnt[i] = 0;
     for (int i = threadIdx.x; i < n_rots; i += 256) row[i] = rot_cs(i, n_rots);
+    float band = 2.f - 2.f * thr;
+    band = sqrtf(fminf(fmaxf(band, 0.f), 4.f) + 1e-5f) + 1e-4f;
+    // A block takes groups of ppb pairs, blockIdx, + gridDim, ...  A group's time is a chain (frame with an fp64 tangent ->
+    // candidate -> binary search -> ~14 dependent band steps) that only more groups in flight hide, so few survivors go 2 to a
+    // group (the ~2 000 of the benchmark object: 15.7 -> 12.2 us; 500: 13.4 -> 8.5), many go 8 to a group for throughput, and the
+    // grid is bounded so that the block's set-up (bins, rotation row) is paid once when it has several groups.
+    for (int64_t k0 = (int64_t)blockIdx.x * ppb; k0 < n_sel; k0 += (int64_t)gridDim.x * ppb) {
+    const int np = (int)min((int64_t)ppb, n_sel - k0);
+    __syncthreads();   // (previous group's frames are no longer read; first trip: the tables above are complete)
     if ((int)threadIdx.x < np) {
         const int p = sel ? sel[k0 + threadIdx.x] : (int)(k0 + threadIdx.x);
         const int2 ij = reinterpret_cast<const int2*>(point_idxs)[p];
         frames[threadIdx.x] = rot_frame(points, ij.x, ij.y, preds_rot[(int64_t)p * rot_stride]);
     }
     __syncthreads();
-    float band = 2.f - 2.f * thr;
-    band = sqrtf(fminf(fmaxf(band, 0.f), 4.f) + 1e-5f) + 1e-4f;
     const int items = np * n_rots;
     for (int k = threadIdx.x; k < items; k += 256) {
         const int pl = k / n_rots, i = k - pl * n_rots;
@@ -1987,6 +1993,7 @@ __global__ __launch_bounds__(256) void rot_sphere_band_kernel(const float* __res
             if (d > thr) atomicAdd(&cnt[j], 1);
         }
     }
+    }
     __syncthreads();
     for (int j = threadIdx.x; j < n_sphere; j += 256)
         if (cnt[j]) atomicAdd(&counts[j], cnt[j]);
@@ -2004,7 +2011,8 @@ static int rot_sphere_impl(const float* points, const float* preds_rot, int rot_
     int64_t bound = n_sel_host < max_pairs ? n_sel_host : max_pairs;
     if (bound == 0) return 0;
     if (sphere_sorted_by_y != 0 && n_sphere <= 4096) {
-        const int64_t nb = (bound + SPHB_PPB - 1) / SPHB_PPB;
+        int64_t nb = (bound + 1) / 2;
+        if (nb > 2048) nb = 2048;
         const size_t lds = (size_t)(4 * n_sphere + 2 * n_rots) * sizeof(float);
         hipLaunchKernelGGL(rot_sphere_band_kernel, dim3((unsigned)nb, (unsigned)n_dirs), dim3(256), lds, (hipStream_t)stream, points,
                            preds_rot, rot_stride, point_idxs, sel, n_sel_dev, n_sel_host, max_pairs, n_rots, sphere,
