@@ -2192,6 +2192,26 @@ __global__ __launch_bounds__(RED_THREADS) void pose_sums_kernel(PoseSumsArgs A)
     __shared__ double bdir[PS_MAX_DIRS][3];
     __shared__ unsigned drawn;
     const int tid = threadIdx.x;
+    // A thread's first pair (with <= 65 536 survivors its only one) is fetched BEFORE the arg-max of the bin counts: three
+    // levels of dependent loads (sel -> pair -> points) that do not depend on best_dir and used to start after two barriers.
+    struct Item { f3 pa, pb, nn; float aux[PS_MAX_DIRS]; float sl[3]; };
+    auto load_item = [&](const int64_t k) -> Item {
+        Item it;
+        const int p = A.sel ? A.sel[k] : (int)k;
+        const int2 ij = reinterpret_cast<const int2*>(A.point_idxs)[p];
+        it.pa = ld3(A.pc, ij.x); it.pb = ld3(A.pc, ij.y); it.nn = ld3(A.nrm, ij.x);
+#pragma unroll
+        for (int j = 0; j < PS_MAX_DIRS; ++j) it.aux[j] = j < A.n_dirs ? A.aux[(int64_t)p * A.aux_stride + j] : 0.f;
+        it.sl[0] = it.sl[1] = it.sl[2] = 0.f;
+        if (A.scale_logits) {
+            const float* sl = A.scale_logits + (int64_t)p * A.scale_stride;
+            it.sl[0] = sl[0]; it.sl[1] = sl[1]; it.sl[2] = sl[2];
+        }
+        return it;
+    };
+    const int64_t n_sel = A.n_sel_dev ? (int64_t)*A.n_sel_dev : A.n_sel_host;
+    Item it = {};
+    if ((int64_t)blockIdx.x * RED_THREADS + tid < n_sel) it = load_item((int64_t)blockIdx.x * RED_THREADS + tid);
     for (int j = 0; j < A.n_dirs; ++j) {   // key = count << 32 | ~index: the largest count at the lowest index (:283)
         const int32_t* cj = A.counts + (int64_t)j * A.counts_dir_step;
         unsigned long long k = 0ull;
@@ -2216,16 +2236,14 @@ __global__ __launch_bounds__(RED_THREADS) void pose_sums_kernel(PoseSumsArgs A)
         }
     }
     __syncthreads();
-    const int64_t n_sel = A.n_sel_dev ? (int64_t)*A.n_sel_dev : A.n_sel_host;
     double acc[PS_COMP] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     for (int64_t k = (int64_t)blockIdx.x * RED_THREADS + tid; k < n_sel; k += (int64_t)RED_BLOCKS * RED_THREADS) {
-        const int p = A.sel ? A.sel[k] : (int)k;
-        const int2 ij = reinterpret_cast<const int2*>(A.point_idxs)[p];
-        const f3 ab = sub3(ld3(A.pc, ij.x), ld3(A.pc, ij.y));
+        if (k != (int64_t)blockIdx.x * RED_THREADS + tid) it = load_item(k);   // (the first one is already here)
+        const f3 ab = sub3(it.pa, it.pb);
         const float distsq = (ab.x * ab.x + ab.y * ab.y) + ab.z * ab.z;
         const float den = sqrtf(distsq) + 1e-7f;
         const f3 abn = {ab.x / den, ab.y / den, ab.z / den};
-        f3 n = ld3(A.nrm, ij.x);
+        f3 n = it.nn;
         const float d = (n.x * abn.x + n.y * abn.y) + n.z * abn.z;
         if (d < 0.f) n = neg3(n);
 #pragma unroll
@@ -2233,15 +2251,12 @@ __global__ __launch_bounds__(RED_THREADS) void pose_sums_kernel(PoseSumsArgs A)
             if (j >= A.n_dirs) break;
             const double proj = ((double)n.x * bdir[j][0] + (double)n.y * bdir[j][1]) + (double)n.z * bdir[j][2];
             const double t = proj > 0.0 ? 1.0 : 0.0;
-            const double x = (double)A.aux[(int64_t)p * A.aux_stride + j];
+            const double x = (double)it.aux[j];
             const double sp = (x > 0.0 ? x : 0.0) + log1p(exp(-fabs(x)));
             acc[2 * j] += sp - x * t;
             acc[2 * j + 1] += sp - x * (1.0 - t);
         }
-        if (A.scale_logits) {
-            const float* sl = A.scale_logits + (int64_t)p * A.scale_stride;
-            acc[4] += (double)sl[0]; acc[5] += (double)sl[1]; acc[6] += (double)sl[2];
-        }
+        if (A.scale_logits) { acc[4] += (double)it.sl[0]; acc[5] += (double)it.sl[1]; acc[6] += (double)it.sl[2]; }
     }
     double* mine = A.partial + (size_t)PS_COMP * blockIdx.x;
     // the seven block sums with one barrier: butterflies inside the wave, then thread c adds the four wave sums of component c
@@ -2266,9 +2281,16 @@ __global__ __launch_bounds__(RED_THREADS) void pose_sums_kernel(PoseSumsArgs A)
     static_assert(RED_THREADS == 32 * PS_COMP && RED_BLOCKS == 32 * 8, "final sum: 8 components x 32 lanes x 8 partials");
     const int c = tid >> 5, l = tid & 31;
     double s = 0.0;
-    if (c < PS_COMP - 1)
-        for (int b = 8 * l; b < 8 * l + 8; ++b)
-            s += __hip_atomic_load(A.partial + (size_t)PS_COMP * b + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // every block's partials were stored (device scope) before its ticket; this block drew the last one: an acquire fence, then
+    // plain loads, eight per lane, all in flight at once
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (c < PS_COMP - 1) {
+        double v[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) v[b] = A.partial[(size_t)PS_COMP * (8 * l + b) + c];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) s += v[b];
+    }
     for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     if (l == 0) {
         if (c < 4) { if (c < 2 * A.n_dirs) A.sign[3 * (c >> 1) + (c & 1)] = s; }
