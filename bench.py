@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary stage timings (counter-collection passes)")
-    ap.add_argument("--streams", type=int, default=2, help="instances in flight per GPU: step k runs on HIP stream k mod S with its "
+    ap.add_argument("--streams", type=int, default=3, help="instances in flight per GPU: step k runs on HIP stream k mod S with its "
                     "own buffers and captured graph (1 = strictly one instance at a time)")
     ap.add_argument("--no-graph", action="store_true", help="launch the chain eagerly instead of replaying a hipGraph")
     ap.add_argument("--n-points", type=int, default=4096, help="exploration only; the headline is 4096")
@@ -192,58 +192,50 @@ def main():
     ws = PoseWorkspace(dev, P, dims, 1)
     ws.probs = pipe.probs
     n_ev = max(args.steps, 5)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    def bracket(fn, n):
+        """fn launched n times back to back between two HIP events, so that the device queue stays full and the quotient is
+        the kernels' own duration (no host-side launch gaps inside the bracket); the smallest of three brackets, because one
+        host hiccup inside a bracket (an allocator or collector pause between two launches) idles the device and inflated a
+        20-launch average by 25 % on one run"""
+        best = None
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            fn()
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) / n
+            best = t if best is None else min(best, t)
+        return best
+
+    settle()
     with torch.no_grad():
-        # each stage is launched n_ev times back to back between two events, so the device queue stays full and
-        # the quotient is the kernels' own duration (no host-side launch gaps inside the bracket)
         outputs, heads = enc.forward_decode(pc, nrm, feat, idx_d, utr_d, cfg.vote_range, urot_d, cfg.tr_num_bins,
                                             cfg.rot_num_bins)
-        ev[0].record()
-        for _ in range(n_ev):
-            outputs, heads = enc.forward_decode(pc, nrm, feat, idx_d, utr_d, cfg.vote_range, urot_d,
-                                                cfg.tr_num_bins, cfg.rot_num_bins)
-        ev[1].record()
-        voting.vote_argmax(pc, outputs, ws.probs, idx_d, ws.grid, corner_d, cfg.res, NUM_ROTS, True,
-                           ws.out_idx, ws.out_val, accumulate=False)
-        ev[2].record()
-        for _ in range(n_ev):
-            voting.vote_argmax(pc, outputs, ws.probs, idx_d, ws.grid, corner_d, cfg.res, NUM_ROTS, True,
-                               ws.out_idx, ws.out_val, accumulate=False)
-        ev[3].record()
-    torch.cuda.synchronize()
-    t_mlp = ev[0].elapsed_time(ev[1]) / n_ev     # ms
-    t_vote = ev[2].elapsed_time(ev[3]) / n_ev
+        t_mlp = bracket(lambda: enc.forward_decode(pc, nrm, feat, idx_d, utr_d, cfg.vote_range, urot_d, cfg.tr_num_bins,
+                                                   cfg.rot_num_bins), n_ev)     # ms
+        t_vote = bracket(lambda: voting.vote_argmax(pc, outputs, ws.probs, idx_d, ws.grid, corner_d, cfg.res, NUM_ROTS, True,
+                                                    ws.out_idx, ws.out_val, accumulate=False), n_ev)
 
-    # secondary (untimed for `value`): the vote stage alone on known-answer inputs -- every vote circle
-    # passes through the object centre, so most samples land in the grid (the atomic-heavy regime a
-    # trained network produces), unlike the near-uniform bins of a random-weight MLP above.
     # secondary: the pair encoder decoding only the two centre heads (all the centre vote consumes; the reference
     # computes the other 77 logits in this pass too and throws them away, nocs/inference.py:182-188).  Not the headline:
     # `value` is measured with all heads decoded.
     t_mlp_tr = None
     if rank == 0 and world == 1 and not args.no_secondary:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.no_grad():
-            enc.forward_decode(pc, nrm, feat, idx_d, utr_d, cfg.vote_range, None, cfg.tr_num_bins, cfg.rot_num_bins)
-            e0.record()
-            for _ in range(n_ev):
-                enc.forward_decode(pc, nrm, feat, idx_d, utr_d, cfg.vote_range, None, cfg.tr_num_bins, cfg.rot_num_bins)
-            e1.record()
-        torch.cuda.synchronize()
-        t_mlp_tr = e0.elapsed_time(e1) / n_ev
+            t_mlp_tr = bracket(lambda: enc.forward_decode(pc, nrm, feat, idx_d, utr_d, cfg.vote_range, None, cfg.tr_num_bins,
+                                                          cfg.rot_num_bins), n_ev)
 
+    # secondary (untimed for `value`): the vote stage alone on known-answer inputs -- every vote circle
+    # passes through the object centre, so most samples land in the grid (the atomic-heavy regime a
+    # trained network produces), unlike the near-uniform bins of a random-weight MLP above.
     t_vote_ka = None
     if rank == 0 and world == 1 and not args.no_secondary:
         out_ka = d(syn.closed_form_outputs(ob["pc"], ob["center"], idx, cfg, quantise=True))
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for it in range(6):
-            if it == 1:
-                e0.record()
-            voting.vote_argmax(pc, out_ka, ws.probs, idx_d, ws.grid, corner_d, cfg.res, NUM_ROTS, True,
-                               ws.out_idx, ws.out_val, accumulate=False)
-        e1.record()
-        torch.cuda.synchronize()
-        t_vote_ka = e0.elapsed_time(e1) / 5
+        t_vote_ka = bracket(lambda: voting.vote_argmax(pc, out_ka, ws.probs, idx_d, ws.grid, corner_d, cfg.res, NUM_ROTS, True,
+                                                       ws.out_idx, ws.out_val, accumulate=False), 5)
 
     # secondary metric (SURVEY.md 8d): the same object through the FULL pose (centre chain + back-vote +
     # orientation vote + axis sign + scale + one read-back), one hipGraph replay per object
@@ -292,6 +284,7 @@ def main():
         from cppf_amd.models.model import PointEncoder
         torch.manual_seed(1)
         penc = PointEncoder(k=60, spfcs=[32, 64, 32, 32], num_layers=1, out_dim=32).eval().to(dev)
+        settle()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.no_grad():
             for it in range(6):
@@ -311,6 +304,7 @@ def main():
         Rt = torch.randn((Pt, cfg.out_dim), device=dev)
         feat_t = feat.clone().requires_grad_(True)
         enc.train()
+        settle()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for it in range(11):
             if it == 1:
@@ -326,6 +320,7 @@ def main():
         import copy
         enc_t = copy.deepcopy(enc)
         opt = torch.optim.Adam(enc_t.parameters(), lr=1e-4)
+        settle()
         for it in range(11):
             if it == 1:
                 e0.record()
@@ -342,6 +337,7 @@ def main():
         penc_t = PointEncoder(k=60, spfcs=[32, 64, 32, 32], num_layers=1, out_dim=32).to(dev).train()
         opt2 = torch.optim.Adam([*penc_t.parameters(), *enc_t.parameters()], lr=1e-4)
         pcs_b, nrm_b = pc[None], nrm[None]
+        settle()
         for it in range(11):
             if it == 1:
                 e0.record()
@@ -374,7 +370,7 @@ def main():
             "config": {"workload": f"single object N={N_POINTS} K={PAIRS_PER_POINT} (P={P} pairs), bottle config, res 4e-3, "
                                    f"grid {dims[0]}x{dims[1]}x{dims[2]}, num_rots 72 adaptive, fused PPF+MLP(MFMA f32)+decode -> "
                                    "LDS-tiled vote -> argmax; one object per GPU per step, " +
-                                   (f"{n_streams} independent objects in flight on {n_streams} HIP streams (double-buffered); "
+                                   (f"{n_streams} independent objects in flight on {n_streams} HIP streams (each with its own buffers and captured graph); "
                                     if n_streams > 1 else "one object at a time; ") +
                                    ("four launches per step replayed from a hipGraph" if not args.no_graph else "eager launches"),
                        "pairs_per_step_per_gpu": P, "parallelism": f"objects x{world}"},
@@ -399,7 +395,7 @@ def main():
                                  f"{FLOP_PER_PAIR_EXECUTED} MFMA FLOP per pair because the two 40-wide feature blocks of layer 0 "
                                  "are projected once per point; fp32 MFMA shares the VALU datapath on gfx950, so the in-register "
                                  "decode (about 480 VALU per 16 pairs) is paid on the same pipe; the duration is that of launches "
-                                 "without a neighbour (back to back on one stream) -- in the timed region two objects are in flight, "
+                                 "without a neighbour (back to back on one stream) -- in the timed region several objects are in flight, "
                                  "so a kernel trace of this command also holds launches that overlap another object's vote and take longer",
                          "executed_mfma_tflops": FLOP_PER_PAIR_EXECUTED * P / (t_mlp * 1e-3) / 1e12},
         }
