@@ -315,21 +315,36 @@ __device__ __forceinline__ float ppf_from(f3 pa, f3 pb, f3 na, f3 nb, int g)
 }
 
 // Layer-0 projections of every point: T[n][r] = (r < 64 ? bias[r] : 0) + sum_{k<40} WPT[k][r] * feat[n][k],
-// one fmaf chain per output in k order.  One block per 2 points, a thread per column.
+// one fmaf chain per output in k order.  One block per PROJ_PPB points, a thread per column and PROJ_PPB / 2 points: a
+// weight is loaded once for the thread's points (one block per 2 points re-read the 20 KB of weights 2 048 times at N = 4096).
+#define PROJ_PPB 8
 __global__ __launch_bounds__(256) void point_proj_kernel(const float* __restrict__ feat,
                                                          const float* __restrict__ packed, float* __restrict__ T,
                                                          int64_t N)
 {
-    __shared__ float f[2][STD_F];
+    __shared__ float f[PROJ_PPB][STD_F];
     const int half = threadIdx.x >> 7, r = threadIdx.x & 127;
-    const int64_t n = (int64_t)blockIdx.x * 2 + half;
-    if (r < STD_F && n < N) f[half][r] = feat[n * STD_F + r];
+    const int64_t n0 = (int64_t)blockIdx.x * PROJ_PPB;
+    for (int i = threadIdx.x; i < PROJ_PPB * STD_F; i += 256) {
+        const int64_t n = n0 + i / STD_F;
+        f[i / STD_F][i % STD_F] = n < N ? feat[n * STD_F + i % STD_F] : 0.f;
+    }
     __syncthreads();
-    if (n >= N) return;
-    float acc = r < 64 ? packed[OFF_BPT + r] : 0.f;
+    float acc[PROJ_PPB / 2];
+    const float b = r < 64 ? packed[OFF_BPT + r] : 0.f;
+#pragma unroll
+    for (int q = 0; q < PROJ_PPB / 2; ++q) acc[q] = b;
 #pragma unroll 8
-    for (int k = 0; k < STD_F; ++k) acc = fmaf(packed[OFF_WPT + k * PROJ_COLS + r], f[half][k], acc);
-    T[n * PROJ_COLS + r] = acc;
+    for (int k = 0; k < STD_F; ++k) {
+        const float w = packed[OFF_WPT + k * PROJ_COLS + r];
+#pragma unroll
+        for (int q = 0; q < PROJ_PPB / 2; ++q) acc[q] = fmaf(w, f[half + 2 * q][k], acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < PROJ_PPB / 2; ++q) {
+        const int64_t n = n0 + half + 2 * q;
+        if (n < N) T[n * PROJ_COLS + r] = acc[q];
+    }
 }
 
 template <bool LOGITS, bool DECODE, bool HEADS, bool SEL = false>
@@ -807,7 +822,7 @@ static int launch_std(MlpArgs& A, int64_t N, void* workspace, size_t workspace_b
     if (!workspace || workspace_bytes < (size_t)N * PROJ_COLS * sizeof(float)) return CPPF_EWORKSPACE;
     float* table = static_cast<float*>(workspace);
     if (!SEL) {   // (the SEL pass reuses the table the first pass left in the same workspace)
-        hipLaunchKernelGGL(point_proj_kernel, dim3((unsigned)((N + 1) / 2)), dim3(256), 0, st, A.feat, A.packed, table, N);
+        hipLaunchKernelGGL(point_proj_kernel, dim3((unsigned)((N + PROJ_PPB - 1) / PROJ_PPB)), dim3(256), 0, st, A.feat, A.packed, table, N);
         CPPF_CHECK_LAUNCH();
     }
     A.table = table;
