@@ -190,7 +190,6 @@ def main():
     pc, nrm, feat, idx_d, utr_d, urot_d, corner_d = (pipe.pc, pipe.nrm, pipe.feat, pipe.idx, pipe.u_tr, pipe.u_rot,
                                                        pipe.corner)
     ws = PoseWorkspace(dev, P, dims, 1)
-    ws.probs = pipe.probs
     n_ev = max(args.steps, 5)
     def bracket(fn, n):
         """fn launched n times back to back between two HIP events, so that the device queue stays full and the quotient is
@@ -216,7 +215,7 @@ def main():
                                             cfg.rot_num_bins)
         t_mlp = bracket(lambda: enc.forward_decode(pc, nrm, feat, idx_d, utr_d, cfg.vote_range, urot_d, cfg.tr_num_bins,
                                                    cfg.rot_num_bins), n_ev)     # ms
-        t_vote = bracket(lambda: voting.vote_argmax(pc, outputs, ws.probs, idx_d, ws.grid, corner_d, cfg.res, NUM_ROTS, True,
+        t_vote = bracket(lambda: voting.vote_argmax(pc, outputs, None, idx_d, ws.grid, corner_d, cfg.res, NUM_ROTS, True,
                                                     ws.out_idx, ws.out_val, accumulate=False), n_ev)
 
     # secondary: the pair encoder decoding only the two centre heads (all the centre vote consumes; the reference
@@ -234,7 +233,7 @@ def main():
     t_vote_ka = None
     if rank == 0 and world == 1 and not args.no_secondary:
         out_ka = d(syn.closed_form_outputs(ob["pc"], ob["center"], idx, cfg, quantise=True))
-        t_vote_ka = bracket(lambda: voting.vote_argmax(pc, out_ka, ws.probs, idx_d, ws.grid, corner_d, cfg.res, NUM_ROTS, True,
+        t_vote_ka = bracket(lambda: voting.vote_argmax(pc, out_ka, None, idx_d, ws.grid, corner_d, cfg.res, NUM_ROTS, True,
                                                        ws.out_idx, ws.out_val, accumulate=False), 5)
 
     # secondary metric: the same object through the FULL pose (centre chain + back-vote +

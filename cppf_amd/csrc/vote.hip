@@ -497,9 +497,10 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
     // being zeroed; every wave leaves its summary of the probs in its own words of LDS instead of meeting at an atomic.
     // largest prob (weights are w * max(probs[a], probs[b]) <= max(probs)); any negative or non-finite value disables the
     // fixed-point path for this workgroup
-    float pm = 0.f;
+    // (probs == null: all ones, what every caller of the reference passes, nocs/inference.py:201 -- no scan, no gathers)
+    float pm = A.probs ? 0.f : 1.f;
     int bad = 0, nonunit = 0;
-    if (TILED) {
+    if (TILED && A.probs) {
         for (int64_t k0 = tid; k0 < n_points; k0 += 4 * VOTE_THREADS) {   // four independent loads in flight per trip
             float pv[4];
 #pragma unroll
@@ -633,7 +634,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
             if (pair_frame(A.points, ij.x, ij.y, a, ab, xd)) {
                 const float proj_len = o.x, odist = o.y;
                 F.cc = sub3(a, scl3(ab, proj_len));                    // :23
-                F.prob = fmaxf(A.probs[ij.x], A.probs[ij.y]);         // :25
+                F.prob = A.probs ? fmaxf(A.probs[ij.x], A.probs[ij.y]) : 1.f;   // :25
                 F.x = scl3(xd, odist);                                 // :28
                 F.y = cross3(F.x, ab);                                 // :29
                 F.n = A.n_rots;
@@ -1105,7 +1106,7 @@ static int vote_impl(const float* points, const float* outputs, const float* pro
                      void* workspace, size_t workspace_bytes, hipStream_t st, const int32_t* shape_dev = nullptr,
                      int64_t grid_cap = 0, int many_tiles = 0)
 {
-    if (!points || !probs || !grid_obj || !corner) return CPPF_EINVAL;
+    if (!points || !grid_obj || !corner) return CPPF_EINVAL;   // (probs may be null: all ones)
     if (n_ppfs > 0 && (!outputs || !point_idxs)) return CPPF_EINVAL;
     if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || gx < 1 || gy < 1 || gz < 1 || n_ppfs < 0 || n_points < 1) return CPPF_EINVAL;
     if ((int64_t)gx * gy * gz > 0x7fffffffll) return CPPF_EINVAL;

@@ -99,10 +99,7 @@ def estimate_center(encoder, pc, pc_normal, feat, point_idxs, u_tr, cfg, corner,
         ws = PoseWorkspace(dev, P, dims, 1)
     if idx32 is None:
         idx32 = point_idxs.to(I32)
-    if probs is None:
-        if ws.probs is None or ws.probs.numel() != pc.shape[0]:
-            ws.probs = torch.ones(pc.shape[0], dtype=F32, device=dev)   # nocs/inference.py:201
-        probs = ws.probs
+    # probs=None: all ones (nocs/inference.py:201) -- the vote then reads no probs at all
     outputs, heads = encoder.forward_decode(pc, pc_normal, feat, point_idxs, u_tr, cfg.vote_range, u_rot,
                                             cfg.tr_num_bins, cfg.rot_num_bins)
     # grid = votes (overwrite mode replaces the zero-initialisation of :196)
@@ -173,7 +170,7 @@ class CenterPipeline:
         self._u = z(2, n_pairs, 2)                     # one buffer: device-side sampling fills both with one launch
         self.u_tr, self.u_rot = self._u[0], self._u[1]
         self.corner = self._in[6 * n:6 * n + 3]
-        self.probs = torch.ones(n_points, dtype=F32, device=device)           # nocs/inference.py:201
+        self.probs = None       # all ones (nocs/inference.py:201): the vote takes None for that and reads nothing
         if self.dynamic:
             if isinstance(dims, (bool, np.bool_)):
                 self.many_tiles = bool(dims)
@@ -259,11 +256,11 @@ class CenterPipeline:
             self.u_rot if self.with_heads else None, self.cfg.tr_num_bins, self.cfg.rot_num_bins)
         # the vote reads the int64 pair list directly (the reference copies it to int32 first, nocs/inference.py:202)
         if self.dynamic:
-            voting.vote_argmax_dyn(self.pc, self.outputs, self.probs, self.idx, self.grid_flat, shape, self.corner,
+            voting.vote_argmax_dyn(self.pc, self.outputs, None, self.idx, self.grid_flat, shape, self.corner,
                                    self.cfg.res, self.num_rots, self.adaptive, self.out_idx, self.out_val,
                                    many_tiles=self.many_tiles, accumulate=False)
         else:
-            voting.vote_argmax(self.pc, self.outputs, self.probs, self.idx, self.grid, self.corner, self.cfg.res,
+            voting.vote_argmax(self.pc, self.outputs, None, self.idx, self.grid, self.corner, self.cfg.res,
                                self.num_rots, self.adaptive, self.out_idx, self.out_val, accumulate=False)
 
     def _weight_images(self):

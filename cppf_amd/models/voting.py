@@ -85,14 +85,15 @@ def vote_argmax(points, outputs, probs, point_idxs, grid_obj, corner, res, n_rot
     Returns (out_idx i64[1], out_val f32[1]) device tensors."""
     dev = dev_tensor(points, F32, "points", (3,)).device
     dev_tensor(outputs, F32, "outputs", (2,), dev)
-    dev_tensor(probs, F32, "probs", None, dev)
+    if probs is not None:                         # None: all ones (nocs/inference.py:201), no tensor is read
+        dev_tensor(probs, F32, "probs", None, dev)
     i64 = isinstance(point_idxs, torch.Tensor) and point_idxs.dtype == torch.int64
     dev_tensor(point_idxs, torch.int64 if i64 else I32, "point_idxs", (2,), dev)
     dev_tensor(grid_obj, F32, "grid_obj", None, dev)
     dev_tensor(corner, F32, "corner", None, dev)
     if grid_obj.dim() != 3:
         raise ValueError("grid_obj must be [gx,gy,gz]")
-    if probs.numel() != points.shape[0]:
+    if probs is not None and probs.numel() != points.shape[0]:
         raise ValueError("probs must have one entry per point")
     gx, gy, gz = grid_obj.shape
     n_ppfs = point_idxs.shape[0]
@@ -106,7 +107,7 @@ def vote_argmax(points, outputs, probs, point_idxs, grid_obj, corner, res, n_rot
         raise ValueError(f"n_rots must be in 1..360, got {n_rots}")
     ws = workspace(need, dev, "vote")
     with torch.cuda.device(dev):
-        rc = L.cppf_vote_argmax(points.data_ptr(), outputs.data_ptr(), probs.data_ptr(), point_idxs.data_ptr(),
+        rc = L.cppf_vote_argmax(points.data_ptr(), outputs.data_ptr(), None if probs is None else probs.data_ptr(), point_idxs.data_ptr(),
                                 1 if i64 else 0, grid_obj.data_ptr(), corner.data_ptr(), float(scalar(res)), points.shape[0], n_ppfs,
                                 int(n_rots), gx, gy, gz, 1 if adaptive else 0, 1 if accumulate else 0,
                                 out_idx.data_ptr(), out_val.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr(dev))
@@ -122,18 +123,19 @@ def vote_argmax_dyn(points, outputs, probs, point_idxs, grid_flat, shape, corner
     the real shape.  A record exceeding a capacity yields out_idx = -1."""
     dev = dev_tensor(points, F32, "points", (3,)).device
     dev_tensor(outputs, F32, "outputs", (2,), dev)
-    dev_tensor(probs, F32, "probs", None, dev)
+    if probs is not None:
+        dev_tensor(probs, F32, "probs", None, dev)
     i64 = point_idxs.dtype == torch.int64
     dev_tensor(point_idxs, torch.int64 if i64 else I32, "point_idxs", (2,), dev)
     dev_tensor(grid_flat, F32, "grid_flat", None, dev)
     dev_tensor(shape, I32, "shape", None, dev)
     dev_tensor(corner, F32, "corner", None, dev)
-    if shape.numel() < 4 or probs.numel() != points.shape[0]:
+    if shape.numel() < 4 or (probs is not None and probs.numel() != points.shape[0]):
         raise ValueError("shape must be i32[4]; probs must have one entry per (capacity) point")
     L = _lib.lib()
     ws = workspace(L.cppf_vote_workspace_bytes_dyn(1 if many_tiles else 0), dev, "vote_dyn")
     with torch.cuda.device(dev):
-        rc = L.cppf_vote_argmax_dyn(points.data_ptr(), outputs.data_ptr(), probs.data_ptr(), point_idxs.data_ptr(),
+        rc = L.cppf_vote_argmax_dyn(points.data_ptr(), outputs.data_ptr(), None if probs is None else probs.data_ptr(), point_idxs.data_ptr(),
                                     1 if i64 else 0, grid_flat.data_ptr(), grid_flat.numel(), corner.data_ptr(),
                                     float(scalar(res)), points.shape[0], point_idxs.shape[0], int(n_rots), shape.data_ptr(),
                                     1 if many_tiles else 0, 1 if adaptive else 0, 1 if accumulate else 0,

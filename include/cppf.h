@@ -42,7 +42,8 @@ const char* cppf_error_string(int code);
  * Centre vote.  Replaces the CuPy RawKernel `ppf_kernel` = CUDA `ppf_voting`
  * (models/voting.py:4-67), launched at nocs/inference.py:192-205.
  *   points      device f32[N,3]        outputs  device f32[n_ppfs,2] = (mu, nu)
- *   probs       device f32[N]          point_idxs device i32[n_ppfs,2]
+ *   probs       device f32[N], or NULL for all ones (every caller of the reference passes ones, nocs/inference.py:201:
+ *               then nothing is read)              point_idxs device i32[n_ppfs,2]
  *   grid_obj    device f32[gx,gy,gz]   in/out, accumulated (+=) like the reference's atomicAdd
  *   corner      device f32[3]          res, n_rots (1..CPPF_MAX_ROTS), adaptive: as the reference
  *   n_points    N (the reference kernel never needs it; here it bounds the scan for max(probs))

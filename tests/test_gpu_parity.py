@@ -247,6 +247,31 @@ def test_vote_grid_and_argmax_match_oracle(oracle, dev, cat, adaptive, quantise)
     assert abs(peak - opeak) <= 2e-5 * opeak
 
 
+def test_vote_null_probs_equals_ones(dev):
+    """probs = NULL is the all-ones tensor every caller of the reference passes (nocs/inference.py:201): same grid, bit for bit,
+    on the tiled path and on the global-atomics fallback (> 64 tiles)"""
+    for res_scale, n in ((1.0, 1024), (0.12, 256)):
+        ob = syn.make_object("bottle", n, 3)
+        cfg = ob["cfg"]
+        res = float(np.float32(cfg.res * res_scale))
+        idx = syn.make_pairs(n, 16, 3)
+        outputs = syn.closed_form_outputs(ob["pc"], ob["center"], idx, cfg)
+        from cppf_amd.inference import grid_shape
+        corners, dims = grid_shape(ob["pc"], res)
+        args = (t(ob["pc"], dev), t(outputs, dev))
+        g1 = torch.zeros(tuple(int(d) for d in dims), dtype=torch.float32, device=dev)
+        g0 = torch.zeros_like(g1)
+        i1, v1 = voting.vote_argmax(*args, torch.ones(n, device=dev), t(idx, dev), g1, t(corners[0], dev), res, 72, True)
+        i0, v0 = voting.vote_argmax(*args, None, t(idx, dev), g0, t(corners[0], dev), res, 72, True)
+        torch.cuda.synchronize()
+        if res_scale == 1.0:     # (the fallback's fp32 atomics are order-dependent: compared with a tolerance there)
+            assert torch.equal(g0, g1) and int(i0.item()) == int(i1.item()) and float(v0.item()) == float(v1.item())
+        else:
+            assert _lib.lib().cppf_vote_tiles(int(dims[0]), int(dims[1]), int(dims[2])) == 0      # no LDS plan: global atomics
+            torch.testing.assert_close(g0, g1, rtol=2e-5, atol=1e-6)
+        assert float(g1.sum().item()) > 100
+
+
 def test_vote_tiling_paths(oracle, dev):
     # fine grid -> x and y tiles; very fine grid -> global-atomic fallback; coarse -> single tile
     for res_scale, expect in ((1.0, "tiles"), (0.5, "tiles"), (0.2, "global"), (4.0, "one")):
