@@ -395,7 +395,8 @@ def main():
                                  "are projected once per point; fp32 MFMA shares the VALU datapath on gfx950, so the in-register "
                                  "decode (about 480 VALU per 16 pairs) is paid on the same pipe; the duration is that of launches "
                                  "without a neighbour (back to back on one stream) -- in the timed region several objects are in flight, "
-                                 "so a kernel trace of this command also holds launches that overlap another object's vote and take longer",
+                                 "so a kernel trace of this command also holds launches that overlap another object's vote and take longer "
+                                 "(profiles/r*_kernel_trace_stats_one_stream.txt: the same command with --streams 1, whose averages agree)",
                          "executed_mfma_tflops": FLOP_PER_PAIR_EXECUTED * P / (t_mlp * 1e-3) / 1e12},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
 #   1. --kernel-trace --stats of the default benchmark command  -> gpurun_out/prof/kernel_trace_stats.txt
+#      (and with --streams 1: each launch alone on the chip      -> gpurun_out/prof/kernel_trace_stats_one_stream.txt)
 #   2. PMC passes, one counter group per pass, no trace domains -> gpurun_out/prof/pmc_counters.txt
 #   3. the HBM-traffic summary bench.py reads                   -> gpurun_out/prof/pmc_traffic.json
 # Copy the three files into profiles/ (renamed r<round>_*) to have them judged.
@@ -11,6 +12,10 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt -- $BENCH > $OUT/bench_under_trace.log 2>&1
 python $R/profiles/kstats.py $(find /tmp/kt -name '*.db' | head -1) > $OUT/kernel_trace_stats.txt 2>&1
+# the same chain with ONE object in flight: every launch alone on the chip, so a kernel's average here is its own duration (in the
+# default command three objects are in flight and a launch that shares the chip with a neighbour's head or tail lasts longer)
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt1 -- $BENCH --streams 1 --no-secondary > $OUT/bench_under_trace_one_stream.log 2>&1
+python $R/profiles/kstats.py $(find /tmp/kt1 -name '*.db' | head -1) > $OUT/kernel_trace_stats_one_stream.txt 2>&1
 : > $OUT/pmc_counters.txt
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" \
