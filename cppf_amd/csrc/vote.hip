@@ -391,7 +391,7 @@ __device__ __forceinline__ void vote_pop(const VoteTile& VT, const PairFrame& F,
 // slack (1e-4 in the cosine, 2e-3 rad in the angle, far above their error), never a dropped vote.  A pair costs ~300
 // instructions for its masks instead of ~45 per pair of rotations in a loop over all of them.
 #ifndef VOTE_SERIAL_MAX
-#define VOTE_SERIAL_MAX 28   // pairs with a non-empty mask up to which a batch is expanded pair by pair
+#define VOTE_SERIAL_MAX 40   // pairs with a non-empty mask up to which a batch is expanded pair by pair (sweep 16..64 after the plane/shell cull: 40)
 #endif
 #define VOTE_BELOW_N 97   // BELOW[j] = bits [0, j) set, j = 0..96, as uint4 (x, y, z = three words)
 
