@@ -1429,7 +1429,17 @@ __global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__
         if (mask) mask[idx] = nz;
         if (chunk_counts) count_survivor(idx, nz);
     };
-    auto rotations = [&](const int64_t idx) {   // the reference's loop (:97-110) for one pair that passed stage 1, one pair per lane: full batches of 64 (throughput)
+    // The reference's loop (:97-110) for one pair that passed stage 1, one pair per lane -- over the ARC of rotations that can
+    // pass :101 only, in index order.  With offset = cos(t) x + sin(t) y, |x| = |y| = rho and x, y, ab orthogonal,
+    //   |cc + offset - gt|^2 = |w|^2 + rho^2 - 2 (A cos t + B sin t),   w = gt - cc, A = w.x, B = w.y,
+    // so the distance test holds exactly where cos(t - phi) >= K / M, phi = atan2(B, A), M = |(A, B)|,
+    // K = (|w|^2 + rho^2 - tol^2) / 2: a run of indices around phi n / 2 pi, about 2 tol / res + 3 of them instead of n <= 72.
+    // The run is a superset (approximate acos / atan2 with their error bounds, one index of margin on either side, K lowered
+    // by the deviations of |offset|^2 from rho^2: roundings and the 1e-7 regulariser, which shortens ab by 1e-7 / L -- pairs
+    // closer than 1e-3 scan everything); each candidate still goes through the reference's exact arithmetic and the first
+    // one in index order wins, so the result is the reference's.  On inputs where every pair survives stage 1 (a trained
+    // network) the full loop was the kernel: 100 us at C2, a lane walking on average 36 rotations and a wave its slowest lane's.
+    auto rotations = [&](const int64_t idx) {
         const float2 o = reinterpret_cast<const float2*>(outputs)[idx];
         const int2 ij = load_ij(idx);
         f3 a, ab, xd;
@@ -1441,7 +1451,36 @@ __global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__
         f3 found = {0.f, 0.f, 0.f};                                                   // :96
         const int n = min((int)((double)(odist / res) * (2 * CPPF_PI)), n_rots);      // :97
         const int tbase = n * (n - 1) / 2;
-        for (int i = 0; i < n; ++i) {
+        int lo = 0, cnt = n;
+        {
+            const f3 pb_ = ld3(points, ij.y);
+            const f3 dd = sub3(a, pb_);
+            const float L2 = dot3(dd, dd);
+            const f3 w = sub3(gt, cc);
+            const float A_ = dot3(w, x), B_ = dot3(w, y), w2 = dot3(w, w), rho2 = dot3(x, x);
+            const float M = __builtin_amdgcn_sqrtf(A_ * A_ + B_ * B_);
+            const float K = 0.5f * (w2 + rho2 - tol * tol) - (3e-4f * rho2 + 4e-6f * (w2 + rho2 + tol * tol));
+            if (n > 0 && L2 >= 1e-6f && M > 1e-30f) {
+                const float c = K * __builtin_amdgcn_rcpf(M);
+                if (c > 1.0005f) {
+                    cnt = 0;                                   // no rotation comes within tol of the centre
+                } else if (c > -0.9995f) {
+                    const float alpha = acos_approx(fminf(c, 1.f)) + 8e-4f;        // acos / atan2 errors, rcp, table angles
+                    const float phi = atan2_approx(B_, A_);
+                    const float k = (float)n * 0.159154943f;                       // n / 2 pi
+                    const float ic = phi * k, hw = fmaf(alpha, k, 1.0f);
+                    const int i_lo = (int)floorf(ic - hw), i_hi = (int)ceilf(ic + hw);
+                    if (i_hi - i_lo + 1 < n) {
+                        cnt = i_hi - i_lo + 1;
+                        lo = i_lo % n;
+                        lo = lo < 0 ? lo + n : lo;
+                    }
+                }
+            }
+        }
+        const int p1 = max(0, lo + cnt - n);     // candidates that wrap past n - 1 come first in index order: 0 .. p1 - 1
+        for (int kk = 0; kk < cnt; ++kk) {
+            const int i = kk < p1 ? kk : lo + (kk - p1);
             const float2 cs = in_lds ? ltab[tbase + i] : rot_cs(i, n);
             const f3 offset = add3(scl3(x, cs.x), scl3(y, cs.y));
             const f3 pc = add3(cc, offset);
@@ -1452,61 +1491,6 @@ __global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__
             break;
         }
         finish(idx, found);
-    };
-    // The same for the pairs left in the queue when the wave's share of the input ends -- on inputs where few pairs pass stage 1
-    // (the benchmark's: 0.3 %) that is all of them, and the kernel's duration was this loop's latency.  Frames one pair per lane
-    // (one round of dependent loads for all of them), then the rotations EIGHT LANES PER PAIR: in trip f lane 8g + s tests rotations s, s + 8, ... of pair
-    // f + g, whose frame it pulls from lane f + g (ds_bpermute).  One pair per lane walked up to 72 dependent iterations of ~60
-    // instructions -- 10 us of pure latency however few pairs there were (19 us for 100 k pairs and for 524 k alike); a group
-    // of eight walks 9, stops as soon as one of its lanes hits (the lowest rotation index of that trip is the reference's
-    // first hit), and a trip ends when its eight groups are done rather than a wave's 64 pairs.  (For full batches it measured
-    // 40 % slower than one pair per lane: two ballots per iteration, and every group waits for the slowest of its trip.)
-    auto stage2 = [&](const int first, const int count) {
-        f3 cc_l = {0.f, 0.f, 0.f}, x_l = cc_l, y_l = cc_l;
-        int n_l = 0;
-        const int idx_l = lane < count ? (int)q[first + lane] : 0;
-        if (lane < count) {
-            const float2 o = reinterpret_cast<const float2*>(outputs)[idx_l];
-            const int2 ij = load_ij(idx_l);
-            f3 a, ab, xd;
-            pair_frame(points, ij.x, ij.y, a, ab, xd);
-            const float proj_len = o.x, odist = o.y;
-            cc_l = sub3(a, scl3(ab, proj_len));
-            x_l = scl3(xd, odist);
-            y_l = cross3(x_l, ab);
-            n_l = min((int)((double)(odist / res) * (2 * CPPF_PI)), n_rots);      // :97
-        }
-        const int g = lane >> 3, s8 = lane & 7;
-        for (int f = 0; f < count; f += 8) {
-            const int src = f + g;
-            const f3 cc = {__shfl(cc_l.x, src, 64), __shfl(cc_l.y, src, 64), __shfl(cc_l.z, src, 64)};
-            const f3 x = {__shfl(x_l.x, src, 64), __shfl(x_l.y, src, 64), __shfl(x_l.z, src, 64)};
-            const f3 y = {__shfl(y_l.x, src, 64), __shfl(y_l.y, src, 64), __shfl(y_l.z, src, 64)};
-            const int n_s = __shfl(n_l, src, 64);   // (unconditional: a bpermute reads nothing from a lane that is switched off)
-            const int n = src < count ? n_s : 0;
-            const int64_t idx = (int64_t)(uint32_t)__shfl(idx_l, src, 64);
-            const int tbase = n * (n - 1) / 2;
-            bool open = src < count;   // the group has not found its rotation yet
-            for (int i0 = 0; __ballot(open && i0 < n) != 0ull; i0 += 8) {
-                const int i = i0 + s8;
-                bool ok = false;
-                f3 offset = {0.f, 0.f, 0.f};
-                if (open && i < n) {
-                    const float2 cs = in_lds ? ltab[tbase + i] : rot_cs(i, n);
-                    offset = add3(scl3(x, cs.x), scl3(y, cs.y));
-                    const f3 pc = add3(cc, offset);
-                    const f3 gq = div3(sub3(pc, cr), res);
-                    ok = !(len3(sub3(pc, gt)) > tol) &&                                       // :101
-                         !(gq.x < 0.f || gq.y < 0.f || gq.z < 0.f || gq.x >= bx || gq.y >= by || gq.z >= bz);  // :103-107
-                }
-                const unsigned hits = (unsigned)(__ballot(ok) >> (8 * g)) & 0xffu;   // this group's lanes
-                if (open && hits) {
-                    if (s8 == __builtin_ctz(hits)) finish(idx, neg3(offset));                  // :108, the first such rotation
-                    open = false;
-                }
-            }
-            if (open && s8 == 0) finish(idx, f3{0.f, 0.f, 0.f});                              // :96, no rotation passed
-        }
     };
     // A wave takes BV_U x 64 consecutive pairs per trip and has all their loads in flight before it looks at any of them
     // (one pair per lane per trip was two dependent round trips to memory per pair with nothing else to do: 27 us for 9 MB).
@@ -1591,11 +1575,9 @@ __global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__
         }
         if (!more) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (qn > 16) {   // many left (dense inputs): throughput counts, one pair per lane as for the full batches
+            if (qn > 0) {
                 const uint32_t pidx = lane < qn ? q[lane] : 0u;
                 if (lane < qn) rotations((int64_t)pidx);
-            } else if (qn > 0) {
-                stage2(0, qn);
             }
             break;
         }
