@@ -137,7 +137,7 @@ class BatchPoseRunner:
         `seed` and its index: then only the cloud itself crosses PCIe."""
         mine = sharding.shard_objects(len(objects), rank, world)
         raw = torch.zeros((max(len(mine), 1), 21), dtype=torch.float64, device=self.device)
-        cfgs = []
+        cfgs, used = [], []
         # n_lanes instances in flight: consecutive instances rotate over the HIP streams, each with its own pipelines
         # (buffers + captured graph), so one instance's head overlaps the previous one's tail
         if self._streams is None:
@@ -165,9 +165,12 @@ class BatchPoseRunner:
                     pipe.sample_inputs(gen, n_points=obj["pc"].shape[0])
                 pipe.run_async(raw[slot], check_weights=id(pipe) not in checked)
                 checked.add(id(pipe))
+                used.append(pipe)
             cfgs.append(obj["cfg"])
         for st in self._streams:
             main.wait_stream(st)
         host = raw.cpu().numpy()                       # the batch's only synchronisation
+        for slot, pipe in enumerate(used):             # split / full-first form of each pipeline's next instance (PosePipeline.adapt)
+            pipe.adapt(host[slot, 18])
         local = torch.from_numpy(assemble_batch(host[:len(mine)], cfgs, mine, sharding.RECORD)).to(self.device)
         return sharding.gather_records(local, len(objects), rank, world, self.device)

@@ -499,20 +499,51 @@ class PosePipeline(CenterPipeline):
         self.ws.out_idx, self.ws.out_val = self.out_idx, self.out_val
         self._sph = self.ws.sphere(sph64)
         self.angle_tol, self.max_rot_pairs = angle_tol, max_rot_pairs
+        self.full_first = False
+        self._graphs = {}
+
+    # Two captured forms of the same computation.  Split (the reference's own order, nocs/inference.py:182-256): the first MLP
+    # pass decodes the two centre heads only, the survivors of the back-vote get a second pass for the orientation / scale heads
+    # -- 86 + 8 us at C2 when 0.4 % survive (a network that has not learnt the object), but 86 + 94 us when all do (a trained
+    # one).  Full first: the first pass decodes every head of every pair (107 us) and there is no second pass.  Per pair the
+    # arithmetic is the same, so the heads rows of the survivors, hence the pose, are identical; the choice follows the share
+    # of survivors of the instance that ran last on this pipeline (break-even ~0.15, with hysteresis), seen in the record the
+    # host reads back anyway.
+    FULL_FIRST_ON, FULL_FIRST_OFF = 0.25, 0.10
+
+    def adapt(self, n_surv):
+        """choose the form for the next instance from the survivors of the last one"""
+        share = float(n_surv) / max(self.idx.shape[0], 1)
+        want = self.full_first
+        if share > self.FULL_FIRST_ON:
+            want = True
+        elif share < self.FULL_FIRST_OFF:
+            want = False
+        if want != self.full_first:
+            self._graphs[self.full_first] = (self._graph, self._images)
+            self.full_first = want
+            self._graph, self._images = self._graphs.get(want, (None, self._images))
+
+    def release(self):
+        self._graphs = {}
+        super().release()
 
     def _chain(self):
-        super()._chain()
-        self.heads = self.ws.heads
+        self.with_heads = self.full_first
+        super()._chain()                          # (full first: self.heads = every pair's heads row, from the first pass)
+        if not self.full_first:
+            self.heads = self.ws.heads
         _enqueue_tail(self.ws, self.pc, self.nrm, self.idx32, self.outputs, self.heads, self.corner, self.cfg,
                       self.dims, self.num_rots, self.angle_tol, self.max_rot_pairs, *self._sph,
                       shape=self.shape if self.dynamic else None,
-                      second_pass=(self.encoder, self.feat, self.idx, self.u_rot),
+                      second_pass=None if self.full_first else (self.encoder, self.feat, self.idx, self.u_rot),
                       idx64=self.idx)             # the tail's kernels take int32 indices: written by the back-vote launch
 
     def run(self, rng=None, check_weights=True):
         super().run(check_weights)
         out = _assemble(self.ws.rec.cpu().numpy(), self.cfg, rng)
         out.update(dims=self.dims, ws=self.ws, outputs=self.outputs, heads=self.heads)
+        self.adapt(out["n_surv"])
         return out
 
     def run_async(self, record_out, check_weights=True):

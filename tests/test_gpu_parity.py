@@ -734,6 +734,46 @@ def test_estimate_pose_matches_oracle_chain(oracle, golden, dev, cat):
     np.testing.assert_allclose(r["peak"], o["peak"], rtol=2e-5)
 
 
+def test_pose_pipeline_split_and_full_first_forms_agree(oracle, golden, dev):
+    """PosePipeline's two captured forms (centre heads + second pass on the survivors | every head in the first pass) give the
+    same pose record and the same heads rows for the survivors; the form follows the survivors' share of the last instance"""
+    from cppf_amd.inference import PosePipeline, grid_shape
+    ob = syn.make_object("camera", 1024, 5)
+    cfg = ob["cfg"]
+    idx = syn.make_pairs(1024, 24, 5)
+    P = idx.shape[0]
+    u_tr, u_rot = syn.make_uniforms(P, 5)
+    sd = seeded_sd(0)
+    for k in ("final.weight", "final.bias"):
+        sd[k] = sd[k] * 4
+    enc = make_encoder(sd, [84, 32, 32, 16], 141, dev)
+    sph = golden("sphere.npz")["pts"]
+    corners, dims = grid_shape(ob["pc"], cfg.res)
+    pp = PosePipeline(enc, cfg, 1024, P, dims, dev, sph, 72)
+    pp.load(ob["pc"], ob["normals"], ob["feat"], idx, u_tr, u_rot, corners[0].copy())
+    recs, heads = [], []
+    for form in (False, True, False, True):
+        pp.adapt(P if form else 0)                       # force the form
+        assert pp.full_first == form
+        r = pp.run()
+        mask = r["ws"].mask.cpu().numpy().astype(bool)
+        recs.append(r["ws"].rec.cpu().numpy().copy())
+        heads.append(r["heads"].cpu().numpy()[mask].copy())
+        assert r["n_surv"] == mask.sum() > 0
+    for k in (1, 2, 3):
+        np.testing.assert_array_equal(recs[k], recs[0])
+        np.testing.assert_array_equal(heads[k], heads[0])
+    # the form chosen after a run follows the share of survivors (hysteresis 0.10 / 0.25)
+    share = r["n_surv"] / P
+    assert pp.full_first == (share >= 0.10)                                # (the last forced form was full-first)
+    ocfg = dict(res=cfg.res, tr_num_bins=32, rot_num_bins=36, vote_range=cfg.vote_range, scale_mean=cfg.scale_mean,
+                regress_right=cfg.regress_right, ppffcs=[84, 32, 32, 16], out_dim=141)
+    o = oracle.estimate_pose(ob["pc"], ob["normals"], ob["feat"], idx, sd, ocfg, u_tr, u_rot, sph)
+    assert r["argmax"] == o["argmax"] and r["n_surv"] == int(o["mask"].sum())
+    np.testing.assert_array_equal(heads[0], o["heads"][o["mask"]])
+    np.testing.assert_allclose(r["up"], o["up"], atol=1e-12)
+
+
 # ------------------------------------------------------------------------------------ full-size properties
 def test_full_size_properties_c2(dev):
     """N=4096, K=128 (BASELINE.json config 2): size-independent properties, no oracle."""
