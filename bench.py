@@ -236,6 +236,25 @@ def main():
         t_vote_ka = bracket(lambda: voting.vote_argmax(pc, out_ka, None, idx_d, ws.grid, corner_d, cfg.res, NUM_ROTS, True,
                                                        ws.out_idx, ws.out_val, accumulate=False), 5)
 
+    # secondary: centre vote + the whole pose tail on the same known-answer inputs, where (nearly) every pair survives the
+    # back-vote -- the trained-network regime of the tail, which the random-weight network above (0.4 % survivors) never
+    # enters.  Heads of every pair from one full first pass (PosePipeline's "full first" form), launches eager, back to back.
+    t_tail_ka, n_surv_ka = None, None
+    if rank == 0 and world == 1 and not args.no_secondary:
+        from cppf_amd.inference import _enqueue_tail
+        from cppf_amd.utils.util import fibonacci_sphere
+        ws_ka = PoseWorkspace(dev, P, dims, 480)
+        sph_ka = ws_ka.sphere(np.array(fibonacci_sphere(480)))
+        idx32_ka = idx_d.to(torch.int32)
+
+        def tail_ka():
+            voting.vote_argmax(pc, out_ka, None, idx_d, ws_ka.grid, corner_d, cfg.res, NUM_ROTS, True, ws_ka.out_idx,
+                               ws_ka.out_val, accumulate=False)
+            _enqueue_tail(ws_ka, pc, nrm, idx32_ka, out_ka, heads, corner_d, cfg, dims, NUM_ROTS, 1.5, 10000, *sph_ka)
+        with torch.no_grad():
+            t_tail_ka = bracket(tail_ka, 5)
+        n_surv_ka = int(ws_ka.count.item())
+
     # secondary metric: the same object through the FULL pose (centre chain + back-vote +
     # orientation vote + axis sign + scale + one read-back), one hipGraph replay per object
     t_pose, pose = None, {"n_surv": None}
@@ -377,6 +396,7 @@ def main():
             "ms_per_step_one_instance_at_a_time": ms_single,
             "stage_ms": {"ppf_mlp_decode": t_mlp, "ppf_mlp_decode_centre_heads_only": t_mlp_tr, "vote_reduce_argmax": t_vote,
                          "vote_reduce_argmax_known_answer_inputs": t_vote_ka,
+                         "vote_plus_pose_tail_known_answer_inputs": t_tail_ka, "pose_tail_known_answer_n_surv": n_surv_ka,
                          "full_pose_incl_readback": t_pose, "full_pose_n_surv": pose["n_surv"],
                          "batch_of_8_instances_knn_sprin_full_pose_per_instance": t_batch,
                          "point_encoder_knn60_sprin": t_penc,
