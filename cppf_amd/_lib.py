@@ -57,6 +57,8 @@ _SIGS = {
     "cppf_backvote_count64": (C.c_int, [vp, vp, vp, vp, vp, f32, i64, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp]),
     "cppf_compact_scatter": (C.c_int, [vp, i64, vp, vp, vp, vp]),
     "cppf_rot_sphere_count_dirs": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp, i64, i64, i32, vp, i32, f32, i32, vp, i32, vp]),
+    "cppf_rot_sphere_count_dirs_order": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp, i64, vp, i64, i64, i32, vp, i32, f32, i32, vp,
+                                                   i32, vp]),
     "cppf_pose_sums_workspace_bytes": (sz, []),
     "cppf_pose_sums": (C.c_int, [vp, vp, vp, vp, vp, i64, vp, i32, i32, vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, sz, vp, vp]),
     "cppf_axis_sign": (C.c_int, [vp, vp, vp, vp, vp, i64, vp, i32, vp, vp, vp, sz, vp]),

@@ -143,6 +143,14 @@ class BatchPoseRunner:
         if self._streams is None:
             self._streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n_lanes)]
         main = torch.cuda.current_stream(self.device)
+        # weight images: looked at ONCE per batch, here on the caller's stream, before the lanes fan out -- a parameter update
+        # since the last batch is re-packed (in place) now, and every lane's replays are ordered after it by the wait below
+        # (a lane that found the change itself would rebuild the image on its own stream while its neighbours replay)
+        for cat in {objects[j]["cfg"].category for j in mine}:
+            if cat in self.encoders:
+                self.encoders[cat]._packed_weights(self.device)
+            if cat in self.point_encoders:
+                self.point_encoders[cat]._packed_weights(self.device)
         for st in self._streams:
             st.wait_stream(main)
         checked = set()          # pipelines whose weight images were looked at in this batch (once is enough: nothing

@@ -901,6 +901,7 @@ extern "C" int cppf_pair_mlp_decode_sel(const float* pc, const float* nrm, const
     if (P < 0 || max_sel < 0 || !dims) return CPPF_EINVAL;
     if (!is_std(F, dims, n_res, out_dim) || tr_bins != 32 || rot_bins != 36 || out_dim != 141) return CPPF_EUNSUPPORTED;
     if (P == 0 || max_sel == 0) return 0;
+    if (P >= (1ll << 27)) return CPPF_EUNSUPPORTED;   // rows come from sel[] and range over the whole pair list: 32-bit offsets
     if (!pc || !nrm || !feat || !idxs || !packed || !u_rot || !sel || !n_sel_dev || !heads) return CPPF_EINVAL;
     MlpArgs A = {};
     A.pc = pc; A.nrm = nrm; A.feat = feat; A.idxs = idxs; A.packed = packed; A.out_dim = out_dim;

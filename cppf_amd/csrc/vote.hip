@@ -28,6 +28,21 @@ __device__ __forceinline__ void fill_rot_table(float2* ltab, int entries, int ti
     }
 }
 
+// A cached table is trusted only if its stamp matches AND its 72 known entries are in place: rotation 0 of every n is
+// exactly (1, 0), at offsets n(n-1)/2 spread over the whole table.  The stamp alone would survive a caller that reuses one
+// arena for several entry points (or an allocator that recycles the block) and overwrites table bytes but not byte 248.
+// Wave-uniform result; every wave of a launch reads the same memory and reaches the same verdict.
+__device__ __forceinline__ bool rot_table_intact(const float2* wtab, int n_rots)
+{
+    const int lane = threadIdx.x & 63;
+    bool ok = true;
+    for (int n = lane + 1; n <= n_rots; n += 64) {
+        const float2 v = wtab[n * (n - 1) / 2];
+        ok = ok && v.x == 1.0f && v.y == 0.0f;
+    }
+    return !__any(!ok);
+}
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int tri(int n) { return n * (n + 1) / 2; }
 
@@ -516,7 +531,8 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
     }
     // rotation table: from the workspace when the previous launch on it left one for this n_rots, else built below
     float2* wtab = reinterpret_cast<float2*>(reinterpret_cast<char*>(A.packed) + VOTE_WS_TAB);
-    const bool tab_cached = TAB_LDS && A.packed[31] == (VOTE_TAB_STAMP ^ (unsigned long long)A.n_rots);
+    const bool tab_cached = TAB_LDS && A.packed[31] == (VOTE_TAB_STAMP ^ (unsigned long long)A.n_rots) &&
+                            rot_table_intact(wtab, A.n_rots);
     float2 tab_in[(VOTE_TAB_LDS_MAX + VOTE_THREADS - 1) / VOTE_THREADS];
     if (tab_cached) {
 #pragma unroll
@@ -1388,8 +1404,8 @@ __global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__
     if (in_lds) {
         // the vote that produced gt_center left the same table in its workspace (VOTE_TAB_STAMP): 21 KB to load instead of
         // 2 628 fp64 sincos per block
-        if (vote_ws && vote_ws[31] == (VOTE_TAB_STAMP ^ (unsigned long long)n_rots)) {
-            const float2* wtab = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(vote_ws) + VOTE_WS_TAB);
+        const float2* wtab = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(vote_ws) + VOTE_WS_TAB);
+        if (vote_ws && vote_ws[31] == (VOTE_TAB_STAMP ^ (unsigned long long)n_rots) && rot_table_intact(wtab, n_rots)) {
             for (int e = threadIdx.x; e < entries; e += blockDim.x) ltab[e] = wtab[e];
         } else {
             fill_rot_table(ltab, entries, threadIdx.x, blockDim.x);
@@ -1802,6 +1818,7 @@ __device__ __forceinline__ RotFrame rot_frame(const float* __restrict__ points, 
 {
     RotFrame fr;
     f3 a, ab, xd;
+    fr.pad = 0;   // 1 = slot without a pair (an `order` entry beyond the survivor list): contributes nothing
     fr.ok = pair_frame(points, ia, ib, a, ab, xd);
     if (fr.ok) {
         fr.x = xd;
@@ -1871,7 +1888,8 @@ __global__ __launch_bounds__(SPH_THREADS) void rot_sphere_kernel(const float* __
                                                                  int64_t n_sel_host, int64_t max_pairs, int n_rots,
                                                                  const float* __restrict__ sphere, int n_sphere,
                                                                  float thr, int32_t* __restrict__ counts,
-                                                                 int rot_dir_step, int counts_dir_step)
+                                                                 int rot_dir_step, int counts_dir_step,
+                                                                 const int32_t* __restrict__ order, int64_t n_order)
 {
     preds_rot += (int64_t)blockIdx.y * rot_dir_step;
     counts += (int64_t)blockIdx.y * counts_dir_step;
@@ -1879,16 +1897,23 @@ __global__ __launch_bounds__(SPH_THREADS) void rot_sphere_kernel(const float* __
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float4* cand = reinterpret_cast<float4*>(lds);                       // [SPH_PPB*n_rots]
     float2* row = reinterpret_cast<float2*>(lds + 4 * SPH_PPB * n_rots);  // [n_rots]
-    int64_t n_sel = n_sel_dev ? (int64_t)*n_sel_dev : n_sel_host;
+    const int64_t n_avail = n_sel_dev ? (int64_t)*n_sel_dev : n_sel_host;   // entries of sel (or pairs, sel == null)
+    int64_t n_sel = order ? n_order : n_avail;                               // slots of this count
     if (n_sel > max_pairs) n_sel = max_pairs;
     const int64_t k0 = (int64_t)blockIdx.x * SPH_PPB;
     if (k0 >= n_sel) return;
     const int np = (int)min((int64_t)SPH_PPB, n_sel - k0);
     for (int i = threadIdx.x; i < n_rots; i += SPH_THREADS) row[i] = rot_cs(i, n_rots);
     if ((int)threadIdx.x < np) {
-        const int p = sel ? sel[k0 + threadIdx.x] : (int)(k0 + threadIdx.x);
-        const int2 ij = reinterpret_cast<const int2*>(point_idxs)[p];
-        frames[threadIdx.x] = rot_frame(points, ij.x, ij.y, preds_rot[(int64_t)p * rot_stride]);
+        const int64_t sl = order ? (int64_t)order[k0 + threadIdx.x] : k0 + threadIdx.x;   // position in the survivor list
+        if (sl >= 0 && sl < n_avail) {
+            const int p = sel ? sel[sl] : (int)sl;
+            const int2 ij = reinterpret_cast<const int2*>(point_idxs)[p];
+            frames[threadIdx.x] = rot_frame(points, ij.x, ij.y, preds_rot[(int64_t)p * rot_stride]);
+        } else {
+            frames[threadIdx.x].ok = 0;
+            frames[threadIdx.x].pad = 1;
+        }
     }
     __syncthreads();
     const int items = np * n_rots;
@@ -1896,7 +1921,7 @@ __global__ __launch_bounds__(SPH_THREADS) void rot_sphere_kernel(const float* __
         const int pl = k / n_rots, i = k - pl * n_rots;
         f3 up = {0.f, 0.f, 0.f};  // degenerate pair: the reference leaves zeros, which still count if thr < 0
         if (frames[pl].ok) up = rot_candidate(frames[pl], row[i]);
-        cand[k] = make_float4(up.x, up.y, up.z, 0.f);
+        cand[k] = make_float4(up.x, up.y, up.z, frames[pl].pad ? 1.f : 0.f);
     }
     __syncthreads();
     for (int j = threadIdx.x; j < n_sphere; j += SPH_THREADS) {
@@ -1905,7 +1930,7 @@ __global__ __launch_bounds__(SPH_THREADS) void rot_sphere_kernel(const float* __
         for (int k = 0; k < items; ++k) {
             const float4 c = cand[k];
             const float d = fmaf(c.z, sz, fmaf(c.y, sy, c.x * sx));
-            cnt += d > thr;
+            cnt += (d > thr) && c.w == 0.f;
         }
         if (cnt) atomicAdd(&counts[j], cnt);
     }
@@ -1924,7 +1949,8 @@ __global__ __launch_bounds__(256) void rot_sphere_band_kernel(const float* __res
                                                               int64_t max_pairs, int n_rots,
                                                               const float* __restrict__ sphere, int n_sphere, float thr,
                                                               int32_t* __restrict__ counts, int descending,
-                                                              int rot_dir_step, int counts_dir_step)
+                                                              int rot_dir_step, int counts_dir_step,
+                                                              const int32_t* __restrict__ order, int64_t n_order)
 {
     preds_rot += (int64_t)blockIdx.y * rot_dir_step;   // cppf_rot_sphere_count_dirs: direction blockIdx.y of the launch
     counts += (int64_t)blockIdx.y * counts_dir_step;
@@ -1933,7 +1959,8 @@ __global__ __launch_bounds__(256) void rot_sphere_band_kernel(const float* __res
     float* sph = lds;                                             // [n_sphere][3]
     int* cnt = reinterpret_cast<int*>(lds + 3 * n_sphere);        // [n_sphere]
     float2* row = reinterpret_cast<float2*>(cnt + n_sphere);      // [n_rots]
-    int64_t n_sel = n_sel_dev ? (int64_t)*n_sel_dev : n_sel_host;
+    const int64_t n_avail = n_sel_dev ? (int64_t)*n_sel_dev : n_sel_host;   // entries of sel (or pairs, sel == null)
+    int64_t n_sel = order ? n_order : n_avail;                               // slots of this count
     if (n_sel > max_pairs) n_sel = max_pairs;
     const int ppb = n_sel > 4096 ? SPHB_PPB : 2;   // (uniform over the launch)
     if ((int64_t)blockIdx.x * ppb >= n_sel) return;
@@ -1950,14 +1977,21 @@ __global__ __launch_bounds__(256) void rot_sphere_band_kernel(const float* __res
     const int np = (int)min((int64_t)ppb, n_sel - k0);
     __syncthreads();   // (previous group's frames are no longer read; first trip: the tables above are complete)
     if ((int)threadIdx.x < np) {
-        const int p = sel ? sel[k0 + threadIdx.x] : (int)(k0 + threadIdx.x);
-        const int2 ij = reinterpret_cast<const int2*>(point_idxs)[p];
-        frames[threadIdx.x] = rot_frame(points, ij.x, ij.y, preds_rot[(int64_t)p * rot_stride]);
+        const int64_t sl = order ? (int64_t)order[k0 + threadIdx.x] : k0 + threadIdx.x;   // position in the survivor list
+        if (sl >= 0 && sl < n_avail) {
+            const int p = sel ? sel[sl] : (int)sl;
+            const int2 ij = reinterpret_cast<const int2*>(point_idxs)[p];
+            frames[threadIdx.x] = rot_frame(points, ij.x, ij.y, preds_rot[(int64_t)p * rot_stride]);
+        } else {
+            frames[threadIdx.x].ok = 0;
+            frames[threadIdx.x].pad = 1;
+        }
     }
     __syncthreads();
     const int items = np * n_rots;
     for (int k = threadIdx.x; k < items; k += 256) {
         const int pl = k / n_rots, i = k - pl * n_rots;
+        if (frames[pl].pad) continue;
         f3 up = {0.f, 0.f, 0.f};
         if (frames[pl].ok) up = rot_candidate(frames[pl], row[i]);
         // bins with y in [up.y - band, up.y + band]: binary searches on the sorted y column
@@ -1985,13 +2019,17 @@ __global__ __launch_bounds__(256) void rot_sphere_band_kernel(const float* __res
 static int rot_sphere_impl(const float* points, const float* preds_rot, int rot_stride, int rot_dir_step, int n_dirs,
                            const int32_t* point_idxs, const int32_t* sel, const int32_t* n_sel_dev,
                            int64_t n_sel_host, int64_t max_pairs, int n_rots, const float* sphere,
-                           int n_sphere, float thr, int sphere_sorted_by_y, int32_t* counts, int counts_dir_step, void* stream)
+                           int n_sphere, float thr, int sphere_sorted_by_y, int32_t* counts, int counts_dir_step, void* stream,
+                           const int32_t* order = nullptr, int64_t n_order = 0)
 {
     if (!points || !preds_rot || !point_idxs || !sphere || !counts) return CPPF_EINVAL;
+    if (n_order < 0) return CPPF_EINVAL;
+    if (!order) n_order = 0;
     if (n_rots < 1 || n_rots > 512 || n_sphere < 1 || max_pairs < 0 || n_sel_host < 0 || rot_stride < 1 || n_dirs < 1 ||
         n_dirs > 16)
         return CPPF_EINVAL;
-    int64_t bound = n_sel_host < max_pairs ? n_sel_host : max_pairs;
+    const int64_t slots = order ? n_order : n_sel_host;      // (with an order the slots are the order's)
+    int64_t bound = slots < max_pairs ? slots : max_pairs;
     if (bound == 0) return 0;
     if (sphere_sorted_by_y != 0 && n_sphere <= 4096) {
         int64_t nb = (bound + 1) / 2;
@@ -1999,7 +2037,7 @@ static int rot_sphere_impl(const float* points, const float* preds_rot, int rot_
         const size_t lds = (size_t)(4 * n_sphere + 2 * n_rots) * sizeof(float);
         hipLaunchKernelGGL(rot_sphere_band_kernel, dim3((unsigned)nb, (unsigned)n_dirs), dim3(256), lds, (hipStream_t)stream, points,
                            preds_rot, rot_stride, point_idxs, sel, n_sel_dev, n_sel_host, max_pairs, n_rots, sphere,
-                           n_sphere, thr, counts, sphere_sorted_by_y > 0 ? 1 : 0, rot_dir_step, counts_dir_step);
+                           n_sphere, thr, counts, sphere_sorted_by_y > 0 ? 1 : 0, rot_dir_step, counts_dir_step, order, n_order);
         CPPF_CHECK_LAUNCH();
         return 0;
     }
@@ -2007,7 +2045,7 @@ static int rot_sphere_impl(const float* points, const float* preds_rot, int rot_
     const size_t lds = (size_t)(4 * SPH_PPB * n_rots + 2 * n_rots) * sizeof(float);
     hipLaunchKernelGGL(rot_sphere_kernel, dim3((unsigned)nb, (unsigned)n_dirs), dim3(SPH_THREADS), lds, (hipStream_t)stream, points,
                        preds_rot, rot_stride, point_idxs, sel, n_sel_dev, n_sel_host, max_pairs, n_rots, sphere,
-                       n_sphere, thr, counts, rot_dir_step, counts_dir_step);
+                       n_sphere, thr, counts, rot_dir_step, counts_dir_step, order, n_order);
     CPPF_CHECK_LAUNCH();
     return 0;
 }
@@ -2030,6 +2068,20 @@ extern "C" int cppf_rot_sphere_count_dirs(const float* points, const float* pred
     if (n_dirs > 1 && (rot_dir_step < 1 || counts_dir_step < n_sphere)) return CPPF_EINVAL;
     return rot_sphere_impl(points, preds_rot, rot_stride, rot_dir_step, n_dirs, point_idxs, sel, n_sel_dev, n_sel_host,
                            max_pairs, n_rots, sphere, n_sphere, thr, sphere_sorted_by_y, counts, counts_dir_step, stream);
+}
+
+extern "C" int cppf_rot_sphere_count_dirs_order(const float* points, const float* preds_rot, int rot_stride, int rot_dir_step,
+                                                int n_dirs, const int32_t* point_idxs, const int32_t* sel,
+                                                const int32_t* n_sel_dev, int64_t n_sel_host, const int32_t* order,
+                                                int64_t n_order, int64_t max_pairs, int n_rots, const float* sphere,
+                                                int n_sphere, float thr, int sphere_sorted_by_y, int32_t* counts,
+                                                int counts_dir_step, void* stream)
+{
+    if (n_dirs > 1 && (rot_dir_step < 1 || counts_dir_step < n_sphere)) return CPPF_EINVAL;
+    if (!order) return CPPF_EINVAL;
+    return rot_sphere_impl(points, preds_rot, rot_stride, rot_dir_step, n_dirs, point_idxs, sel, n_sel_dev, n_sel_host,
+                           max_pairs, n_rots, sphere, n_sphere, thr, sphere_sorted_by_y, counts, counts_dir_step, stream,
+                           order, n_order);
 }
 
 // ----------------------------------------------------------------------------- pose-tail reductions

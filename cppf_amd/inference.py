@@ -297,8 +297,23 @@ class CenterPipeline:
                 with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
                     self._chain()
                 self._images = images
+            self._await_images()
             self._graph.replay()
+            self._note_images_read()
         return self.out_idx, self.out_val
+
+    def _await_images(self):
+        """another stream may have rebuilt a weight image in place since this pipeline last replayed: wait for it"""
+        seen = self.__dict__.setdefault("_image_gens", {})
+        for enc in (self.encoder, self.point_encoder):
+            if enc is not None:
+                seen[id(enc)] = enc._await_image(self.device, seen.get(id(enc)))
+
+    def _note_images_read(self):
+        """... and a later rebuild (on any stream) must wait for this replay"""
+        for enc in (self.encoder, self.point_encoder):
+            if enc is not None:
+                enc._note_image_read(self.device)
 
     def release(self):
         """drop the captured graph and this pipeline's scratch buffers (BatchPoseRunner's cache eviction)"""
@@ -313,12 +328,15 @@ class CenterPipeline:
 
 
 def estimate_pose(encoder, pc, pc_normal, feat, point_idxs, u_tr, u_rot, cfg, sphere_pts, pc_host=None, num_rots=72,
-                  adaptive=True, angle_tol=1.5, max_rot_pairs=10000, ws=None, rng=None):
+                  adaptive=True, angle_tol=1.5, max_rot_pairs=10000, ws=None, rng=None, rot_order=None):
     """Full per-instance pose (nocs/inference.py:177-339 minus dataset I/O and the laptop segmenter).
 
     encoder: cppf_amd.models.model.PPFEncoder on `pc.device`, eval mode.
     pc, pc_normal f32[N,3], feat f32[N,F], point_idxs i64/i32[P,2], u_tr/u_rot f32[P,2]: device tensors.
     sphere_pts: fp64 array [S,3] (np.array(fibonacci_sphere(S)), :100-102).
+    rot_order: optional i32 array / device tensor of positions in the survivor list -- the reference's shuffled subsample for
+    the orientation vote (:277-280: `np.random.shuffle(arange(P'))[:10000]`); entries beyond the survivor count are skipped,
+    so a caller that does not know P' yet may pass a longer list.  None: the first `max_rot_pairs` survivors.
     Returns a dict of host values: T f64[3], up/right f64[3], R f64[3,3], scale f64[3], scale_norm,
     argmax (flat grid index), peak, n_surv, counts_up/right (i32[S])."""
     require_cuda()
@@ -336,26 +354,34 @@ def estimate_pose(encoder, pc, pc_normal, feat, point_idxs, u_tr, u_rot, cfg, sp
         ws = PoseWorkspace(dev, P, dims, S)
     sph32_d, sph64_d, sorted_y = ws.sphere(sph64)                             # :276 (uploaded once per workspace)
     idx32 = point_idxs.to(I32)
+    if rot_order is not None:
+        rot_order = torch.as_tensor(rot_order).to(device=dev, dtype=I32).contiguous()
 
     # centre ------------------------------------------------------------------------------------------
-    _, _, outputs, _, _ = estimate_center(encoder, pc, pc_normal, feat, point_idxs, u_tr, cfg, corner, dims,
-                                          num_rots, adaptive, None, ws, idx32)
-    heads = ws.heads
+    split = encoder.fused_decode_supported(cfg.tr_num_bins, cfg.rot_num_bins)
+    _, _, outputs, heads, _ = estimate_center(encoder, pc, pc_normal, feat, point_idxs, u_tr, cfg, corner, dims,
+                                              num_rots, adaptive, None if split else u_rot, ws, idx32)
+    if split:       # the reference's own order: a second pass for the survivors (:236-256)
+        heads = ws.heads
+    # (other bin counts / architectures: every head of every pair came from the first pass, through the logits + decode kernels)
     _enqueue_tail(ws, pc, pc_normal, idx32, outputs, heads, corner, cfg, dims, num_rots, angle_tol, max_rot_pairs,
-                  sph32_d, sph64_d, sorted_y, second_pass=(encoder, feat, point_idxs, u_rot))
+                  sph32_d, sph64_d, sorted_y, second_pass=(encoder, feat, point_idxs, u_rot) if split else None,
+                  rot_order=rot_order)
     out = _assemble(ws.rec.cpu().numpy(), cfg, rng)                           # the one read-back
     out.update(dims=dims, corner=corners[0], ws=ws, outputs=outputs, heads=heads)
     return out
 
 
 def _enqueue_tail(ws, pc, pc_normal, idx32, outputs, heads, corner, cfg, dims, num_rots, angle_tol, max_rot_pairs,
-                  sph32_d, sph64_d, sorted_y, shape=None, second_pass=None, idx64=None):
+                  sph32_d, sph64_d, sorted_y, shape=None, second_pass=None, idx64=None, rot_order=None):
     """nocs/inference.py:209-303,335 after the centre vote, all on the current stream; leaves the 21-double
     result record in ws.rec (T[3], best_dir[2,3], sign sums[2,3], scale sums[4], argmax, peak).  `shape`: the device
     dims record of a shape-polymorphic pipeline (then `dims` is unused).  `second_pass` = (encoder, feat, point_idxs, u_rot):
     the heads of the surviving pairs are computed here, after the compaction, like the reference's second
     ppf_encoder call (:236-256); without it `heads` must already hold them.  `idx64`: the pair list as int64 -- then `idx32`
-    is an OUTPUT, filled by the back-vote launch for the launches after it (no conversion pass)."""
+    is an OUTPUT, filled by the back-vote launch for the launches after it (no conversion pass).  `rot_order`: device i32[m],
+    positions in the survivor list whose pairs feed the orientation vote (the reference's shuffled subsample, :277-280);
+    None = the first `max_rot_pairs` survivors."""
     dev = pc.device
     L = _lib.lib()
     st = stream_ptr(dev)
@@ -407,10 +433,17 @@ def _enqueue_tail(ws, pc, pc_normal, idx32, outputs, heads, corner, cfg, dims, n
         # one launch; np.argmax(counts), sphere_pts[...] (:283-284), the sign sums (:287-301) and the scale sums in another
         thr = float(np.float32(np.cos(angle_tol / 180 * np.pi)))
         n_dirs = 2 if cfg.regress_right else 1
-        _lib.check(L.cppf_rot_sphere_count_dirs(pc.data_ptr(), heads.data_ptr(), 8, 1, n_dirs, idx32.data_ptr(),
-                                                ws.surv.data_ptr(), ws.count.data_ptr(), P, max_rot_pairs, num_rots,
-                                                sph32_d.data_ptr(), S, thr, sorted_y, ws.counts.data_ptr(), S, st),
-                   "cppf_rot_sphere_count_dirs")
+        if rot_order is None:
+            _lib.check(L.cppf_rot_sphere_count_dirs(pc.data_ptr(), heads.data_ptr(), 8, 1, n_dirs, idx32.data_ptr(),
+                                                    ws.surv.data_ptr(), ws.count.data_ptr(), P, max_rot_pairs, num_rots,
+                                                    sph32_d.data_ptr(), S, thr, sorted_y, ws.counts.data_ptr(), S, st),
+                       "cppf_rot_sphere_count_dirs")
+        else:
+            _lib.check(L.cppf_rot_sphere_count_dirs_order(pc.data_ptr(), heads.data_ptr(), 8, 1, n_dirs, idx32.data_ptr(),
+                                                          ws.surv.data_ptr(), ws.count.data_ptr(), P, rot_order.data_ptr(),
+                                                          rot_order.numel(), max_rot_pairs, num_rots, sph32_d.data_ptr(), S,
+                                                          thr, sorted_y, ws.counts.data_ptr(), S, st),
+                       "cppf_rot_sphere_count_dirs_order")
         pws = workspace(L.cppf_pose_sums_workspace_bytes(), dev, "pose_sums")
         _lib.check(L.cppf_pose_sums(pc.data_ptr(), pc_normal.data_ptr(), idx32.data_ptr(), ws.surv.data_ptr(),
                                     ws.count.data_ptr(), P, heads.data_ptr() + 4 * 2, 8, n_dirs, ws.counts.data_ptr(), S, S,
@@ -491,15 +524,22 @@ class PosePipeline(CenterPipeline):
     reads back the 21-double record (one sync)."""
 
     def __init__(self, encoder, cfg, n_points, n_pairs, dims, device, sphere_pts, num_rots=72, adaptive=True,
-                 angle_tol=1.5, max_rot_pairs=10000, use_graph=True, point_encoder=None, dynamic=False):
+                 angle_tol=1.5, max_rot_pairs=10000, use_graph=True, point_encoder=None, dynamic=False, rot_order_len=0):
+        """rot_order_len > 0: the pipeline owns a static i32[rot_order_len] buffer `rot_order` (positions in the survivor
+        list, see estimate_pose) that the captured orientation vote reads -- fill it before run() to reproduce the reference's
+        shuffled subsample (nocs/inference.py:277-280); it starts as 0, 1, 2, ... (= the first survivors)."""
         super().__init__(encoder, cfg, n_points, n_pairs, dims, device, num_rots, adaptive, False, use_graph, point_encoder,
                          dynamic)
+        self.rot_order = (torch.arange(int(rot_order_len), dtype=I32, device=device) if rot_order_len else None)
         sph64 = np.asarray(sphere_pts, dtype=np.float64)
         self.ws = PoseWorkspace(device, n_pairs, self.dims, sph64.shape[0], grid=self.grid_flat if self.dynamic else self.grid)
         self.ws.out_idx, self.ws.out_val = self.out_idx, self.out_val
         self._sph = self.ws.sphere(sph64)
         self.angle_tol, self.max_rot_pairs = angle_tol, max_rot_pairs
-        self.full_first = False
+        # bin counts / architectures the fused second pass (cppf_pair_mlp_decode_sel) does not serve run the full-first form
+        # only: every head of every pair from the first pass, whose logits + decode-kernel fallback serves any configuration
+        self._split_ok = encoder.fused_decode_supported(cfg.tr_num_bins, cfg.rot_num_bins)
+        self.full_first = not self._split_ok
         self._graphs = {}
 
     # Two captured forms of the same computation.  Split (the reference's own order, nocs/inference.py:182-256): the first MLP
@@ -519,10 +559,15 @@ class PosePipeline(CenterPipeline):
             want = True
         elif share < self.FULL_FIRST_OFF:
             want = False
+        if not self._split_ok:
+            want = True
         if want != self.full_first:
-            self._graphs[self.full_first] = (self._graph, self._images)
+            # a captured form owns the tensors its launches write: outputs / heads / feat are part of what is switched
+            self._graphs[self.full_first] = (self._graph, self._images, self.outputs, self.heads, self.feat)
             self.full_first = want
-            self._graph, self._images = self._graphs.get(want, (None, self._images))
+            self._graph, self._images, outputs, heads, feat = self._graphs.get(want, (None, self._images, None, None, None))
+            if self._graph is not None:
+                self.outputs, self.heads, self.feat = outputs, heads, feat
 
     def release(self):
         self._graphs = {}
@@ -537,7 +582,8 @@ class PosePipeline(CenterPipeline):
                       self.dims, self.num_rots, self.angle_tol, self.max_rot_pairs, *self._sph,
                       shape=self.shape if self.dynamic else None,
                       second_pass=None if self.full_first else (self.encoder, self.feat, self.idx, self.u_rot),
-                      idx64=self.idx)             # the tail's kernels take int32 indices: written by the back-vote launch
+                      idx64=self.idx,             # the tail's kernels take int32 indices: written by the back-vote launch
+                      rot_order=self.rot_order)
 
     def run(self, rng=None, check_weights=True):
         super().run(check_weights)

@@ -87,6 +87,47 @@ class _DeviceWeights:
     def _param_key(self, device):
         return (str(device), self.__dict__.get("_cppf_epoch", 0)) + tuple((p.data_ptr(), p._version) for p in _params_of(self))
 
+    # Several HIP streams may share one encoder (inference.CenterPipeline lanes, batch.BatchPoseRunner).  The image is rebuilt
+    # in place on whichever stream notices the parameter change, so both directions are ordered with events: a rebuild waits for
+    # every replay that was still reading the old image (`_note_image_read`), and a reader on another stream waits for the
+    # rebuild before its next replay (`_await_image`).  A training loop on one stream never registers a reader and pays nothing.
+    def _image_rebuild_begins(self, dev):
+        """called right before the weight image is rewritten in place on the current stream of `dev`"""
+        readers = self.__dict__.get("_cppf_readers")
+        if readers:
+            cur = torch.cuda.current_stream(dev)
+            for sid, ev in readers.items():
+                if sid != cur.cuda_stream:
+                    cur.wait_event(ev)
+
+    def _image_rebuilt(self, dev):
+        """called right after the rebuild was enqueued: later readers on other streams wait for this event"""
+        if not self.__dict__.get("_cppf_readers"):
+            return                                   # nobody replays captured chains on this encoder
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self.__dict__["_cppf_image_ev"] = (ev, torch.cuda.current_stream(dev).cuda_stream,
+                                            self.__dict__.get("_cppf_image_ev", (None, None, 0))[2] + 1)
+
+    def _await_image(self, dev, seen_gen):
+        """reader side, before a replay on the current stream: wait for the newest rebuild if this reader has not yet;
+        returns the rebuild generation to remember"""
+        ev, sid, gen = self.__dict__.get("_cppf_image_ev", (None, None, 0))
+        if ev is not None and gen != seen_gen:
+            cur = torch.cuda.current_stream(dev)
+            if cur.cuda_stream != sid:
+                cur.wait_event(ev)
+        return gen
+
+    def _note_image_read(self, dev):
+        """reader side, after a replay was enqueued on the current stream"""
+        readers = self.__dict__.setdefault("_cppf_readers", {})
+        cur = torch.cuda.current_stream(dev)
+        ev = readers.get(cur.cuda_stream)
+        if ev is None:
+            ev = readers[cur.cuda_stream] = torch.cuda.Event()
+        ev.record(cur)
+
 
 class _PairMlpFunction(torch.autograd.Function):
     """forward_with_idx with a HIP backward (train.py:66,91).  Saves only the inputs; the backward kernel
@@ -338,6 +379,8 @@ class PointEncoder(_DeviceWeights, nn.Module):
             hid = (C.c_int * 4)(*self.spfcs)
             n = int(L.cppf_point_encoder_packed_floats(hid, 4, 32, 2, 32, desc["n_glob"], 1))
             packed = old if old is not None and old.numel() == n else torch.empty(n, dtype=torch.float32, device=dev)
+            if packed is old:
+                self._image_rebuild_begins(dev)
             with torch.cuda.device(dev):
                 rc = L.cppf_point_encoder_pack_device(nat.data_ptr(), hid, 4, 32, 2, 32, desc["n_glob"], 1, packed.data_ptr(),
                                                       stream_ptr(dev))
@@ -354,11 +397,14 @@ class PointEncoder(_DeviceWeights, nn.Module):
                                                  image.ctypes.data), "cppf_point_encoder_pack")
             if old is not None and old.numel() == image.size:
                 packed = old
+                self._image_rebuild_begins(dev)
                 packed.copy_(torch.from_numpy(image))
             else:
                 packed = torch.from_numpy(image).to(device)
         self._packed = (packed, desc)
         self._packed_key = key
+        if dev.type == "cuda":
+            self._image_rebuilt(dev)
         return self._packed
 
     def forward_dyn(self, pc, pc_normal, n_dev, out=None, nbrs=None):
@@ -479,6 +525,13 @@ class PPFEncoder(_DeviceWeights, nn.Module):
         _lib.check(rc, "cppf_pair_mlp_decode")
         return outputs, heads
 
+    def fused_decode_supported(self, tr_num_bins=32, rot_num_bins=36):
+        """True when cppf_pair_mlp_decode / cppf_pair_mlp_decode_sel serve this encoder and these bin counts in one fused
+        launch (train.py:35's architecture with config/config.yaml's 32 / 36 bins); other configurations go through the logits
+        and the stand-alone decode kernels."""
+        return (self.ppffcs == [84, 32, 32, 16] and self.out_dim == 141 and int(tr_num_bins) == 32
+                and int(rot_num_bins) == 36)
+
     def forward_decode_sel(self, pc, pc_normal, feat, idxs, u_rot, sel, n_sel, heads, max_sel=None, tr_num_bins=32,
                            rot_num_bins=36):
         """The second MLP pass of nocs/inference.py:236-256 on the pairs that survived the back-vote: for i < min(n_sel[0],
@@ -498,6 +551,20 @@ class PPFEncoder(_DeviceWeights, nn.Module):
                 self._packed_weights(pc.device).data_ptr(), pc.shape[0], feat.shape[1], dims, len(self.ppffcs) - 1, P,
                 self.out_dim, tr_num_bins, rot_num_bins, u_rot.data_ptr(), sel.data_ptr(), n_sel.data_ptr(), max_sel,
                 heads.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr(pc.device))
+            if rc == -3:
+                # architecture / bin counts outside the fused kernel: the logits of the selected pairs + cppf_decode_rot, rows
+                # scattered back.  The count is read on the host (one sync; not capturable -- the pose pipelines run such
+                # configurations in their full-first form instead, see inference.PosePipeline).
+                n = min(int(n_sel.item()), max_sel)
+                if n > 0:
+                    rows = sel[:n].long()
+                    logits = self._forward_device(pc, pc_normal, feat, idxs[rows].contiguous())
+                    sub = torch.empty((n, 8), dtype=torch.float32, device=pc.device)
+                    rc = _lib.lib().cppf_decode_rot(logits.data_ptr(), n, self.out_dim, self.out_dim, tr_num_bins, rot_num_bins,
+                                                    u_rot[rows].contiguous().data_ptr(), sub.data_ptr(), stream_ptr(pc.device))
+                    _lib.check(rc, "cppf_decode_rot")
+                    heads[rows] = sub
+                rc = 0
         _lib.check(rc, "cppf_pair_mlp_decode_sel")
         return heads
 
@@ -622,6 +689,8 @@ class PPFEncoder(_DeviceWeights, nn.Module):
         if dev.type == "cuda" and self.ppffcs == [84, 32, 32, 16] and self.out_dim <= 144:
             flat, offs_c = self._flat_params(dev)
             packed = old if old is not None else torch.empty(n, dtype=torch.float32, device=dev)
+            if old is not None:
+                self._image_rebuild_begins(dev)
             with torch.cuda.device(dev):
                 rc = L.cppf_pair_mlp_pack_device(flat.data_ptr(), offs_c, F_, dims, n_res, self.out_dim, packed.data_ptr(),
                                                  stream_ptr(dev))
@@ -635,11 +704,15 @@ class PPFEncoder(_DeviceWeights, nn.Module):
                                       packed.ctypes.data)
             _lib.check(rc, "cppf_pair_mlp_pack")
             if old is not None:
+                if dev.type == "cuda":
+                    self._image_rebuild_begins(dev)
                 old.copy_(torch.from_numpy(packed))
                 self._packed = old
             else:
                 self._packed = torch.from_numpy(packed).to(device)
         self._packed_key = key
+        if dev.type == "cuda":
+            self._image_rebuilt(dev)
         return self._packed
 
 

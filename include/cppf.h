@@ -19,6 +19,13 @@
  *     in place.
  *   - workspaces are caller-provided device scratch; size them with the *_workspace_bytes()
  *     queries.  The library allocates nothing and keeps no global state.
+ *   - ONE exception to "plain scratch": the workspace of the centre vote (cppf_vote_argmax*, cppf_ppf_voting_ws, and the
+ *     back-vote entry points that take `vote_workspace`) caches the (cos, sin) rotation table of its last launch in bytes
+ *     [248, 256 + 21 KB) so that the next launch with the same n_rots loads it instead of rebuilding it.  Give the vote a
+ *     DEDICATED workspace (do not hand the same bytes to other entry points between two votes), or zero its first 32 KB
+ *     before reuse.  The kernels re-validate the cache on every launch (stamp + the 72 entries whose value is known) and
+ *     rebuild it when the check fails, so a recycled or partially overwritten block costs time, not correctness -- short of
+ *     an overwrite that restores all 73 checked words.
  */
 #ifndef CPPF_H
 #define CPPF_H
@@ -303,6 +310,16 @@ int cppf_rot_sphere_count_dirs(const float* points, const float* preds_rot, int 
                                const int32_t* point_idxs, const int32_t* sel, const int32_t* n_sel_dev,
                                int64_t n_sel_host, int64_t max_pairs, int n_rots, const float* sphere, int n_sphere,
                                float thr, int sphere_sorted_by_y, int32_t* counts, int counts_dir_step, void* stream);
+/* cppf_rot_sphere_count_dirs on a caller-chosen subsample: slot k < min(n_order, max_pairs) takes the survivor at position
+ * order[k] of `sel` (positions outside [0, *n_sel_dev) contribute nothing).  The reference draws its 10 000 pairs by shuffling
+ * the survivors (nocs/inference.py:277-280: idxs = arange(P'); np.random.shuffle(idxs); idxs[:10000]); passing that shuffled
+ * prefix as `order` (device int32[n_order]) reproduces its subsample exactly.  Without it the first max_pairs survivors in
+ * pair order are taken -- the same distribution, since pairs are i.i.d. */
+int cppf_rot_sphere_count_dirs_order(const float* points, const float* preds_rot, int rot_stride, int rot_dir_step, int n_dirs,
+                                     const int32_t* point_idxs, const int32_t* sel, const int32_t* n_sel_dev,
+                                     int64_t n_sel_host, const int32_t* order, int64_t n_order, int64_t max_pairs, int n_rots,
+                                     const float* sphere, int n_sphere, float thr, int sphere_sorted_by_y, int32_t* counts,
+                                     int counts_dir_step, void* stream);
 size_t cppf_pose_sums_workspace_bytes(void);
 int cppf_pose_sums(const float* pc, const float* nrm, const int32_t* point_idxs, const int32_t* sel,
                    const int32_t* n_sel_dev, int64_t n_sel_host, const float* aux, int aux_stride, int n_dirs,

@@ -299,12 +299,13 @@ def closed_form_targets(pc, point_idxs):
 
 
 def estimate_pose(pc, nrm, feat, point_idxs, sd, cfg, u_tr, u_rot, sphere_pts, num_rots=72, adaptive=True,
-                  angle_tol=1.5, max_rot_pairs=10000, order=1):
+                  angle_tol=1.5, max_rot_pairs=10000, order=1, rot_order=None):
     """The glue of nocs/inference.py:177-335 chained from the pieces above, with the stochastic
     draws supplied: u_tr[P,2] (centre bins), u_rot[P,2] (up/right bins, indexed by ORIGINAL pair so
     the second MLP pass of :236 is a gather of first-pass rows -- the MLP is deterministic in eval
     mode), and the 10 000-pair subsample of :278-280 taken as the first survivors in pair order
-    (pairs are i.i.d. uniform, so this is the same distribution as the reference's shuffle).
+    (pairs are i.i.d. uniform, so this is the same distribution as the reference's shuffle) -- or, with `rot_order`, exactly
+    the positions of the survivor list the caller names (the reference's `idxs = arange(P'); shuffle(idxs); idxs[:10000]`).
     cfg: dict(res, tr_num_bins, rot_num_bins, vote_range, scale_mean, regress_right, ppffcs, out_dim)."""
     res = float(cfg["res"])
     tb, rb = cfg["tr_num_bins"], cfg["rot_num_bins"]
@@ -320,7 +321,11 @@ def estimate_pose(pc, nrm, feat, point_idxs, sd, cfg, u_tr, u_rot, sphere_pts, n
     surv = np.nonzero(mask)[0]
     heads, _ = decode_rot(logits, u_rot, tb, rb)
     sidx = idx32[surv]
-    sel = surv[:max_rot_pairs]
+    if rot_order is None:
+        sel = surv[:max_rot_pairs]
+    else:        # the caller's shuffled subsample (:277-280): positions in the survivor list; out-of-range entries are skipped
+        ro = np.asarray(rot_order)[:max_rot_pairs]
+        sel = surv[ro[(ro >= 0) & (ro < surv.size)]]
     dirs = []
     for j in range(2):
         if j == 1 and not cfg["regress_right"]:

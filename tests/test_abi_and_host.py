@@ -339,3 +339,30 @@ def test_weight_image_invalidation_keys():
         first.bias = torch.nn.Parameter(torch.zeros_like(first.bias))     # a replaced Parameter object
         enc.invalidate()
         assert len(enc._param_key("cpu")) == n_before and any(p is first.bias for p in enc.parameters())
+
+
+def test_error_codes_surface_as_readable_cppf_errors():
+    """include/cppf.h: return value 0, a NEGATIVE CPPF_E* code, or a POSITIVE hipError_t when a HIP call failed -- both kinds
+    must reach Python as a CppfError that names the call and carries the runtime's own text"""
+    import pytest
+    from cppf_amd import _lib
+    L = _lib.lib()
+    _lib.check(0, "cppf_nothing")                                    # success raises nothing
+    for code, word in ((-1, "invalid argument"), (-2, "workspace"), (-3, "unsupported")):
+        with pytest.raises(_lib.CppfError, match=word) as e:
+            _lib.check(code, "cppf_some_call")
+        assert "cppf_some_call" in str(e.value) and f"({code})" in str(e.value)
+    # positive codes are hipError_t values: 1 = hipErrorInvalidValue, 2 = hipErrorOutOfMemory, 98 = hipErrorInvalidDeviceFunction
+    # (hipGetErrorString is a table lookup: it needs no device)
+    texts = {}
+    for code in (1, 2, 98, 719):
+        with pytest.raises(_lib.CppfError) as e:
+            _lib.check(code, "cppf_vote_argmax")
+        msg = str(e.value)
+        assert "cppf_vote_argmax" in msg and f"({code})" in msg
+        texts[code] = msg
+        raw = L.cppf_error_string(code)
+        assert raw and raw.decode() in msg and raw.decode().strip() not in ("", "?", "cppf: unknown error")
+    assert "invalid" in texts[1].lower() and "memory" in texts[2].lower()
+    assert len(set(texts.values())) == len(texts)
+    assert b"unknown" in L.cppf_error_string(-77)
