@@ -73,3 +73,35 @@ def closed_form_outputs(pc, center, point_idxs, cfg, quantise=True):
         mu = k0 / (nb - 1) * 2 * v0 - v0
         nu = k1 / (nb - 1) * v1
     return np.stack([mu, nu], -1).astype(np.float32)
+
+
+def closed_form_heads(pc, normals, point_idxs, cfg, quantise=True, seed=0, aux_logit=4.0, scale_noise=0.05):
+    """Known-answer orientation / scale heads of every pair for the synthetic objects above, whose axes are the world axes (up =
+    +y, right = +x; +z with z_right): theta = arccos(u . axis) with u the unit vector of a-b, folded by the category's up
+    symmetry, the sign targets from the flipped normal of point a (reference utils/dataset.py:38-60), optionally snapped to the
+    rot_num_bins values by inverting nocs/inference.py:251,255.  Returns f32[P,8] rows {theta_up, theta_right, aux_up, aux_right,
+    sx, sy, sz, 0}: aux = +-aux_logit, scale logits = small noise around 0 (exp(0) * scale_mean * 2 = the object's extent,
+    nocs/inference.py:335).  With closed_form_outputs this is what a perfectly trained network would emit."""
+    a = pc[point_idxs[:, 0]].astype(np.float64)
+    b = pc[point_idxs[:, 1]].astype(np.float64)
+    d = a - b
+    u = d / (np.linalg.norm(d, axis=-1, keepdims=True) + 1e-7)
+    up = np.array([0.0, 1.0, 0.0])
+    right = np.array([0.0, 0.0, 1.0]) if cfg.z_right else np.array([1.0, 0.0, 0.0])
+    th_up = np.arccos(np.clip(u @ up, -1, 1))
+    if cfg.up_sym:
+        th_up = np.minimum(th_up, np.arccos(np.clip(-(u @ up), -1, 1)))
+    th_right = np.arccos(np.clip(u @ right, -1, 1))
+    if quantise:
+        nb = cfg.rot_num_bins
+        th_up = np.rint(th_up / np.pi * (nb - 1)) / (nb - 1) * np.pi
+        th_right = np.rint(th_right / np.pi * (nb - 1)) / (nb - 1) * np.pi
+    n = normals[point_idxs[:, 0]].astype(np.float64).copy()
+    n[np.sum(n * u, -1) < 0] *= -1
+    rng = np.random.default_rng(seed + 3000003)
+    heads = np.zeros((point_idxs.shape[0], 8), np.float32)
+    heads[:, 0], heads[:, 1] = th_up, th_right
+    heads[:, 2] = np.where(n @ up > 0, aux_logit, -aux_logit)
+    heads[:, 3] = np.where(n @ right > 0, aux_logit, -aux_logit)
+    heads[:, 4:7] = scale_noise * rng.standard_normal((point_idxs.shape[0], 3))
+    return heads

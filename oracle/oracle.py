@@ -25,7 +25,8 @@ _pu8 = C.POINTER(C.c_uint8)
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("cppf_oracle.c", "sprin_oracle.c", "backward_oracle.c", "preproc_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("cppf_oracle.c", "sprin_oracle.c", "backward_oracle.c", "preproc_oracle.c",
+                                             "sprin_bwd_oracle.c", "voting_variants.c")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -243,6 +244,98 @@ def rot_voting(points, preds_rot, point_idxs, n_rots):
     lib().orc_rot_voting(_p(points, _pf), _p(preds_rot, _pf), _p(out, _pf), _p(point_idxs, _pi32), C.c_int64(P),
                          C.c_int(n_rots))
     return out
+
+
+# --------------------------------------------------------------------------- arithmetic variants (voting_variants.c)
+# The reference's kernels run under NVRTC defaults (--fmad=true, CUDA's device libm): which products are fused and the last
+# bits of cos / sin / tan are the toolchain's choice.  variant 0 = this oracle's own member of that family.
+FMAD_LEFT, FMAD_RIGHT, LIBM, ULP_UP, ULP_DOWN, ULP_HASH = 1, 2, 4, 8, 16, 32
+VARIANTS = {
+    "fmad_left": FMAD_LEFT, "fmad_right": FMAD_RIGHT, "libm": LIBM, "fmad_left+libm": FMAD_LEFT | LIBM,
+    "fmad_right+libm": FMAD_RIGHT | LIBM, "ulp_up": ULP_UP, "ulp_down": ULP_DOWN, "ulp_hash": ULP_HASH,
+    "fmad_left+ulp_hash": FMAD_LEFT | ULP_HASH, "fmad_right+ulp_hash2": FMAD_RIGHT | ULP_HASH | (2 << 8),
+}
+
+
+def ppf_voting_variant(points, outputs, probs, point_idxs, dims, corner, res, n_rots, adaptive, variant, threads=None):
+    """models/voting.py:8-66 under an arithmetic variant -> the exact (fp64) vote grid."""
+    points, outputs, probs = _c(points, _f), _c(outputs, _f), _c(probs, _f)
+    point_idxs, corner = _c(point_idxs, np.int32), _c(corner, _f)
+    gx, gy, gz = (int(d) for d in dims)
+    grid = np.zeros((gx, gy, gz), np.float64)
+    if threads is None:
+        threads = max(1, min(num_threads(), 16, int(2 ** 31 // max(grid.nbytes, 1))))
+    lib().orv_ppf_voting_f64(_p(points, _pf), _p(outputs, _pf), _p(probs, _pf), _p(point_idxs, _pi32), _p(grid, _pd),
+                             _p(corner, _pf), C.c_float(res), C.c_int64(point_idxs.shape[0]), C.c_int(n_rots), C.c_int(gx),
+                             C.c_int(gy), C.c_int(gz), C.c_int(1 if adaptive else 0), C.c_int(int(variant)), C.c_int(threads))
+    return grid
+
+
+def vote_flips(points, outputs, point_idxs, dims, corner, res, n_rots, adaptive, variant):
+    """per-sample discrete outcomes of ppf_voting under `variant` against variant 0 -> dict of counts (voting_variants.c)"""
+    points, outputs = _c(points, _f), _c(outputs, _f)
+    point_idxs, corner = _c(point_idxs, np.int32), _c(corner, _f)
+    out = np.zeros(8, np.int64)
+    dmax = np.zeros(1, np.float64)
+    lib().orv_vote_flips(_p(points, _pf), _p(outputs, _pf), _p(point_idxs, _pi32), _p(corner, _pf), C.c_float(res),
+                         C.c_int64(point_idxs.shape[0]), C.c_int(n_rots), C.c_int(int(dims[0])), C.c_int(int(dims[1])),
+                         C.c_int(int(dims[2])), C.c_int(1 if adaptive else 0), C.c_int(int(variant)), _p(out, _pi64),
+                         _p(dmax, _pd))
+    return dict(degenerate_flips=int(out[0]), trip_count_flips=int(out[1]), samples=int(out[2]), in_grid=int(out[3]),
+                in_grid_flips=int(out[4]), floor_cell_flips=int(out[5]), max_coord_diff_cells=float(dmax[0]))
+
+
+def backvote_variant(points, outputs, point_idxs, corner, res, n_rots, dims, gt_center, tol, variant):
+    points, outputs = _c(points, _f), _c(outputs, _f)
+    point_idxs, corner, gt = _c(point_idxs, np.int32), _c(corner, _f), _c(gt_center, _f)
+    P = point_idxs.shape[0]
+    oo = np.zeros((P, 3), _f)
+    mask = np.zeros(P, np.uint8)
+    lib().orv_backvote(_p(points, _pf), _p(outputs, _pf), _p(oo, _pf), _p(point_idxs, _pi32), _p(corner, _pf),
+                       C.c_float(res), C.c_int64(P), C.c_int(n_rots), C.c_int(int(dims[0])), C.c_int(int(dims[1])),
+                       C.c_int(int(dims[2])), _p(gt, _pf), C.c_float(tol), _p(mask, _pu8), C.c_int(int(variant)))
+    return oo, mask.astype(bool)
+
+
+def rot_voting_variant(points, preds_rot, point_idxs, n_rots, variant):
+    points, preds_rot, point_idxs = _c(points, _f), _c(preds_rot, _f), _c(point_idxs, np.int32)
+    P = point_idxs.shape[0]
+    out = np.zeros((P, n_rots, 3), _f)
+    lib().orv_rot_voting(_p(points, _pf), _p(preds_rot, _pf), _p(out, _pf), _p(point_idxs, _pi32), C.c_int64(P),
+                         C.c_int(n_rots), C.c_int(int(variant)))
+    return out
+
+
+def pose_tail_variant(pc, nrm, point_idxs, outputs, heads, cfg, sphere_pts, variant, num_rots=72, adaptive=True,
+                      angle_tol=1.5, max_rot_pairs=10000):
+    """nocs/inference.py:191-303,335 from given (mu, nu) and heads, every vote kernel under `variant` and the centre grid
+    accumulated exactly (fp64): what the arithmetic freedom of the reference's toolchain does to the POSE."""
+    res = float(cfg["res"])
+    corner, dims = grid_setup(pc, res)
+    idx32 = point_idxs.astype(np.int32)
+    grid = ppf_voting_variant(pc, outputs, np.ones(pc.shape[0], _f), idx32, dims, corner, res, num_rots, adaptive, variant)
+    flat = int(np.argmax(grid))
+    top2 = np.partition(grid.reshape(-1), -2)[-2:]
+    T = center_from_argmax(flat, dims, corner, res)
+    _, mask = backvote_variant(pc, outputs, idx32, corner, res, num_rots, dims, T.astype(_f), np.float32(3 * res), variant)
+    surv = np.nonzero(mask)[0]
+    sel = surv[:max_rot_pairs]
+    dirs, bests, counts_all = [], [], []
+    for j in range(2):
+        if j == 1 and not cfg["regress_right"]:
+            continue
+        cands = rot_voting_variant(pc, heads[sel, j], idx32[sel], num_rots, variant)
+        counts = sphere_count(cands, sphere_pts, angle_tol)
+        bi = int(np.argmax(counts))
+        best = np.asarray(sphere_pts[bi], np.float64)
+        flip, _ = axis_sign(pc, nrm, idx32[surv], heads[surv, 2 + j], best)
+        dirs.append(-best if flip else best)
+        bests.append(bi)
+        counts_all.append(counts)
+    sc = scale(heads[surv, 4:7], cfg["scale_mean"]) if surv.size else np.zeros(3)
+    return dict(T=T, argmax=flat, peak=float(top2[1]), margin=float(top2[1] - top2[0]), grid=grid, mask=mask,
+                up=dirs[0] if dirs else None, right=dirs[1] if len(dirs) > 1 else None, scale=sc, sphere_argmax=bests,
+                counts=counts_all, corner=corner, dims=dims)
 
 
 def sphere_count(cands, sphere_pts, angle_tol_deg):

@@ -231,19 +231,19 @@ def test_rot_vote_on_a_shuffled_subsample_like_the_reference(oracle, golden, dev
     sph = golden("sphere.npz")["pts"]
     ocfg = dict(res=cfg.res, tr_num_bins=32, rot_num_bins=36, vote_range=cfg.vote_range, scale_mean=cfg.scale_mean,
                 regress_right=cfg.regress_right, ppffcs=cfg.ppffcs, out_dim=cfg.out_dim)
-    o0 = oracle.estimate_pose(ob["pc"], ob["normals"], ob["feat"], idx, sd, ocfg, u_tr, u_rot, sph, max_rot_pairs=300)
+    o0 = oracle.estimate_pose(ob["pc"], ob["normals"], ob["feat"], idx, sd, ocfg, u_tr, u_rot, sph, max_rot_pairs=150)
     n_surv = int(o0["mask"].sum())
-    assert n_surv > 600
+    assert n_surv > 300
     rng = np.random.RandomState(5)
     order = np.arange(n_surv)
     rng.shuffle(order)                                        # the reference's own three lines
-    order = order[:300].astype(np.int32)
+    order = order[:150].astype(np.int32)
     args = (enc, t(ob["pc"], dev), t(ob["normals"], dev), t(ob["feat"], dev), t(idx, dev), t(u_tr, dev), t(u_rot, dev), cfg, sph)
     for ro in (order, np.concatenate([order[:100], [n_surv + 5, -1, 2 ** 30], order[100:]]).astype(np.int32)):
-        o = oracle.estimate_pose(ob["pc"], ob["normals"], ob["feat"], idx, sd, ocfg, u_tr, u_rot, sph, max_rot_pairs=303,
+        o = oracle.estimate_pose(ob["pc"], ob["normals"], ob["feat"], idx, sd, ocfg, u_tr, u_rot, sph, max_rot_pairs=153,
                                  rot_order=ro)
         with torch.no_grad():
-            r = estimate_pose(*args, pc_host=ob["pc"], max_rot_pairs=303, rot_order=ro)
+            r = estimate_pose(*args, pc_host=ob["pc"], max_rot_pairs=153, rot_order=ro)
         cands = oracle.rot_voting(ob["pc"], o["heads"][np.nonzero(o["mask"])[0][ro[(ro >= 0) & (ro < n_surv)]], 0],
                                   idx.astype(np.int32)[np.nonzero(o["mask"])[0][ro[(ro >= 0) & (ro < n_surv)]]], 72)
         counts = oracle.sphere_count(cands, sph, 1.5)
@@ -252,18 +252,18 @@ def test_rot_vote_on_a_shuffled_subsample_like_the_reference(oracle, golden, dev
         assert r["n_surv"] == n_surv
     # a different subsample gives different counts (the order is really honoured)
     with torch.no_grad():
-        r_first = estimate_pose(*args, pc_host=ob["pc"], max_rot_pairs=300)
+        r_first = estimate_pose(*args, pc_host=ob["pc"], max_rot_pairs=150)
     assert not np.array_equal(r_first["ws"].counts[0].cpu().numpy(), counts)
     np.testing.assert_allclose(r_first["up"], o0["up"], atol=1e-12)
     # captured pipeline with a static order buffer
     corners, dims = grid_shape(ob["pc"], cfg.res)
-    pp = PosePipeline(enc, cfg, 1024, P, dims, dev, sph, max_rot_pairs=300, rot_order_len=300)
+    pp = PosePipeline(enc, cfg, 1024, P, dims, dev, sph, max_rot_pairs=150, rot_order_len=150)
     pp.load(ob["pc"], ob["normals"], ob["feat"], idx, u_tr, u_rot, corners[0].copy())
     q0 = pp.run()
     np.testing.assert_allclose(q0["up"], o0["up"], atol=1e-12)                            # default order = first survivors
     pp.rot_order.copy_(t(order, dev))
     q = pp.run()
-    o = oracle.estimate_pose(ob["pc"], ob["normals"], ob["feat"], idx, sd, ocfg, u_tr, u_rot, sph, max_rot_pairs=300,
+    o = oracle.estimate_pose(ob["pc"], ob["normals"], ob["feat"], idx, sd, ocfg, u_tr, u_rot, sph, max_rot_pairs=150,
                              rot_order=order)
     np.testing.assert_allclose(q["up"], o["up"], atol=1e-12)
     np.testing.assert_array_equal(pp.ws.counts[0].cpu().numpy(),
