@@ -6,15 +6,21 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot path over one object (N=4096 points, K=128 pairs/point ->
-P=524 288 pairs; BASELINE.json configs[1] sizes, fused HIP path): inputs (points, normals, 40-d
-point features, int64 pair indices, uniforms, packed weights) already resident in HBM; per step four
-kernels run (per-point layer-0 projection, fused PPF+MLP+decode of all 141 logits, LDS-tiled vote reading
-the int64 pair list directly, reduce+arg-max), replayed from a hipGraph.  With N GPUs every rank processes
-its own object per step (weak scaling) and ONE all_gather of the K result records closes the batch inside
-the timed region.
+A step = one pass of the hot path over one object (default --config c2: N=4096 points, K=128 pairs/point -> P=524 288 pairs;
+BASELINE.json configs[1] sizes, fused HIP path): inputs (points, normals, 40-d point features, int64 pair indices, uniforms,
+packed weights) already resident in HBM; per step four kernels run (per-point layer-0 projection, fused PPF+MLP+decode of all
+141 logits, LDS-tiled vote reading the int64 pair list directly, reduce+arg-max), replayed from a hipGraph.  Steps ROTATE over
+9 distinct objects (own seeds, own buffers, ~70 MB each: more than the 256 MB Infinity Cache holds), so every step streams its
+pair list and uniforms from HBM.  With N GPUs every rank processes its own objects (weak scaling) and ONE all_gather of the K
+result records closes the batch inside the timed region.
+
+  --config c3 | c5   the same chain at BASELINE.json configs[2] (N=4096 K=256) / configs[4] (N=8192 K=256, res 2e-3) sizes
+  --config c4        BASELINE.json configs[3]: a batch of 64 mixed-category objects (C2 size) sharded round-robin over the ranks
+                     through BatchPoseRunner (full pose per object), one gather at the end; strong scaling
+The default run reports c3 / c5 / c4-share timings as secondaries next to the c2 headline.
 """
 import argparse
+import dataclasses
 import gc
 import json
 import os
@@ -29,6 +35,7 @@ sys.path.insert(0, ROOT)
 
 import cppf_amd.synthetic as syn                      # noqa: E402
 from cppf_amd import sharding                         # noqa: E402
+from cppf_amd.config import NOCS_CATEGORIES           # noqa: E402
 from cppf_amd.inference import CenterPipeline, PoseWorkspace, grid_shape   # noqa: E402
 from cppf_amd.models import voting                    # noqa: E402
 from cppf_amd.models.model import PPFEncoder         # noqa: E402
@@ -38,6 +45,12 @@ FLOP_PER_PAIR = 23968            # 2 x 11 984 MAC of the pair MLP
 FLOP_PER_PAIR_EXECUTED = 13728   # what the pair kernel issues after hoisting 2x40 layer-0 columns to a per-point table
 PEAK_F32_MFMA = 157.3            # TFLOP/s, MI355X_MICROARCH.md
 PEAK_HBM = 8000.0                # GB/s
+METRIC = "point-pairs/sec (PPF+MLP+vote+argmax), N=4096 K=128; 1/2/4/8 GPU"
+CONFIGS = {                      # BASELINE.json `configs`: single-object chains
+    "c2": dict(n_points=4096, k=128, res=None, what="BASELINE.json configs[1] sizes on the fused path of configs[2]"),
+    "c3": dict(n_points=4096, k=256, res=None, what="BASELINE.json configs[2]"),
+    "c5": dict(n_points=8192, k=256, res=2e-3, what="BASELINE.json configs[4] per-instance size, fine grid"),
+}
 
 
 def settle():
@@ -61,80 +74,131 @@ def pmc_traffic(kernel):
     return None
 
 
-def cpu_baseline(ob, idx, u_tr, u_rot, sd, cfg, corner, dims, N_POINTS, PAIRS_PER_POINT, budget_s=12.0):
-    """The oracle (CPU restatement, all host cores via OpenMP) timed on the same workload."""
+def host_threads():
+    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+
+def oracle_center(o, sd, budget_s=0.0, max_reps=1):
+    """The oracle chain (CPU restatement, all host cores via OpenMP) on one object: (arg-max, pairs/s, repetitions)."""
     from oracle import oracle as O
-    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = host_threads()
     O.set_threads(threads)
-    P = idx.shape[0]
+    cfg, idx = o["cfg"], o["idx"]
     idx32 = idx.astype(np.int32)
-    probs = np.ones(ob["pc"].shape[0], np.float32)
+    probs = np.ones(o["ob"]["pc"].shape[0], np.float32)
     reps, t_total, flat = 0, 0.0, -1
-    while reps < 1 or (t_total < budget_s and reps < 8):
+    while reps < 1 or (t_total < budget_s and reps < max_reps):
         t0 = time.perf_counter()
-        logits = O.pair_mlp(ob["pc"], ob["normals"], ob["feat"], idx, sd, cfg.ppffcs, cfg.out_dim, order=1)
-        outputs, _ = O.decode_center(logits, u_tr, cfg.tr_num_bins, cfg.vote_range)
-        O.decode_rot(logits, u_rot, cfg.tr_num_bins, cfg.rot_num_bins)
-        grid = np.zeros(dims, np.float32)
-        O.ppf_voting(ob["pc"], outputs, probs, idx32, grid, corner, cfg.res, NUM_ROTS, True, threads=threads)
+        logits = O.pair_mlp(o["ob"]["pc"], o["ob"]["normals"], o["ob"]["feat"], idx, sd, cfg.ppffcs, cfg.out_dim, order=1)
+        outputs, _ = O.decode_center(logits, o["u_tr"], cfg.tr_num_bins, cfg.vote_range)
+        O.decode_rot(logits, o["u_rot"], cfg.tr_num_bins, cfg.rot_num_bins)
+        grid = np.zeros(o["dims"], np.float32)
+        O.ppf_voting(o["ob"]["pc"], outputs, probs, idx32, grid, o["corners"][0], cfg.res, NUM_ROTS, True, threads=threads)
         flat, _ = O.grid_argmax(grid)
         t_total += time.perf_counter() - t0
         reps += 1
-    return dict(value=P * reps / t_total, unit="pairs/s", cores=threads, kind="port",
-                sample=f"{reps} x full workload (N={N_POINTS}, K={PAIRS_PER_POINT}, P={P}), oracle with OpenMP"), flat
+    return flat, idx.shape[0] * reps / t_total, reps
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary stage timings (counter-collection passes)")
-    ap.add_argument("--streams", type=int, default=3, help="instances in flight per GPU: step k runs on HIP stream k mod S with its "
-                    "own buffers and captured graph (1 = strictly one instance at a time)")
-    ap.add_argument("--no-graph", action="store_true", help="launch the chain eagerly instead of replaying a hipGraph")
-    ap.add_argument("--n-points", type=int, default=4096, help="exploration only; the headline is 4096")
-    ap.add_argument("--pairs-per-point", type=int, default=128, help="exploration only; the headline is 128")
-    args = ap.parse_args()
-
-    N_POINTS, PAIRS_PER_POINT = args.n_points, args.pairs_per_point
-    rank, world, local = sharding.init_distributed()
-    assert world == args.gpus, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
-
-    # ---- inputs: one object per rank (seed = rank), resident in HBM ----------------------------------
-    ob = syn.make_object("bottle", N_POINTS, seed=rank)
-    cfg = ob["cfg"]
-    idx = syn.make_pairs(N_POINTS, PAIRS_PER_POINT, seed=rank)
-    P = idx.shape[0]
-    u_tr, u_rot = syn.make_uniforms(P, seed=rank)
-    torch.manual_seed(0)
+def torch_cpu_mlp(o, sd, n_sample=131072, budget_s=4.0):
+    """'MLP via torch-CPU with the same weights': the composite of models/model.py:118-137 in torch ops on the
+    host (all threads), on a bounded prefix of the pair list -> pairs/s"""
+    cfg = o["cfg"]
     enc = PPFEncoder(cfg.ppffcs, cfg.out_dim).eval()
-    sd = {k: v.detach().numpy().copy() for k, v in enc.state_dict().items()}
-    enc = enc.to(dev)
-    corners, dims = grid_shape(ob["pc"], cfg.res)
-    d = lambda a: torch.from_numpy(a).to(dev)
-    # static device buffers + the four launches of the chain captured once in a hipGraph
-    # S instances in flight: independent objects, so step k + 1 (other buffers, other stream) may start while step k's
-    # vote / arg-max tail drains -- the pair kernel is MFMA/VALU-bound, the vote LDS-atomic-bound, and every launch has
-    # a head and a tail that do not fill the chip
-    n_streams = max(1, args.streams)
-    pipes = []
-    for _ in range(n_streams):
-        p_ = CenterPipeline(enc, cfg, N_POINTS, P, dims, dev, NUM_ROTS, adaptive=True, with_heads=True,
-                            use_graph=not args.no_graph)
-        p_.load(ob["pc"], ob["normals"], ob["feat"], idx, u_tr, u_rot, corners[0].copy())
-        pipes.append(p_)
-    pipe = pipes[0]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
-    res_all = torch.zeros((args.steps, 16), dtype=torch.uint8, device=dev)   # {i64 arg-max, f32 peak} of every step
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    pc, nrm, feat = (torch.from_numpy(o["ob"][k]) for k in ("pc", "normals", "feat"))
+    idx = torch.from_numpy(o["idx"][:n_sample])
+    reps, t_total = 0, 0.0
+    with torch.no_grad():
+        enc._composite(pc, nrm, feat, idx)
+        while reps < 1 or (t_total < budget_s and reps < 20):
+            t0 = time.perf_counter()
+            enc._composite(pc, nrm, feat, idx)
+            t_total += time.perf_counter() - t0
+            reps += 1
+    return idx.shape[0] * reps / t_total, torch.get_num_threads(), idx.shape[0]
 
-    # record skeleton (object indices), built once: closing a batch is one clone + two converting column copies
-    rec_tmpl = torch.zeros((args.steps, sharding.RECORD), dtype=torch.float64, device=dev)
-    rec_tmpl[:, 15] = torch.arange(rank * args.steps, (rank + 1) * args.steps, device=dev).double()
-    res_i64, res_f32 = res_all.view(torch.int64), res_all.view(torch.float32)      # [K,2] / [K,4] views of the 16-byte results
+
+def make_center_set(enc, dev, n_points, k, res, n_obj, seed0, with_heads=True, use_graph=True, cat="bottle"):
+    """n_obj distinct objects (seed0 + i), each with its own CenterPipeline (static buffers + captured graph), loaded"""
+    out = []
+    for i in range(n_obj):
+        ob = syn.make_object(cat, n_points, seed=seed0 + i)
+        cfg = ob["cfg"] if res is None else dataclasses.replace(ob["cfg"], res=res)
+        idx = syn.make_pairs(n_points, k, seed=seed0 + i)
+        u_tr, u_rot = syn.make_uniforms(idx.shape[0], seed=seed0 + i)
+        corners, dims = grid_shape(ob["pc"], cfg.res)
+        pipe = CenterPipeline(enc, cfg, n_points, idx.shape[0], dims, dev, NUM_ROTS, adaptive=True, with_heads=with_heads,
+                              use_graph=use_graph)
+        pipe.load(ob["pc"], ob["normals"], ob["feat"], idx, u_tr, u_rot, corners[0].copy())
+        out.append(dict(ob=ob, cfg=cfg, idx=idx, u_tr=u_tr, u_rot=u_rot, corners=corners, dims=dims, pipe=pipe))
+    return out
+
+
+class TrainedRegimePipeline(CenterPipeline):
+    """The same four launches with the vote fed by KNOWN-ANSWER (mu, nu) (every vote circle passes through the object centre:
+    what a trained network emits, and the expensive regime of the vote) instead of the random-weight network's near-uniform bins.
+    The pair stage still runs in full (its outputs go unused), so the step costs what a deployed model's step costs."""
+
+    def set_known_answer(self, out_ka):
+        self.out_ka = out_ka
+
+    def _chain(self):
+        self.outputs, self.heads = self.encoder.forward_decode(self.pc, self.nrm, self.feat, self.idx, self.u_tr,
+                                                               self.cfg.vote_range, self.u_rot, self.cfg.tr_num_bins,
+                                                               self.cfg.rot_num_bins)
+        voting.vote_argmax(self.pc, self.out_ka, None, self.idx, self.grid, self.corner, self.cfg.res, self.num_rots,
+                           self.adaptive, self.out_idx, self.out_val, accumulate=False)
+
+
+def events_per_chain(dev, pipes, n):
+    """n chains strictly one at a time, each bracketed by its own pair of HIP events on the launch stream (SURVEY.md 8d:
+    'hipEvents around the whole chain on one object, median of >= 20 runs'); objects rotate.  Returns the sorted list (ms)."""
+    ts = []
+    for i in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        pipes[i % len(pipes)].run(check_weights=False)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ts.append(e0.elapsed_time(e1))
+    return sorted(ts)
+
+
+def bracket(fns, n):
+    """the closures of `fns` (one per object, cycled) launched n times back to back between two HIP events on the launch stream,
+    so that the device queue stays full and the quotient is the kernels' own duration (no host-side launch gaps inside the
+    bracket); the smallest of three brackets, because one host hiccup inside a bracket idles the device"""
+    best = None
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fns[0]()
+        e0.record()
+        for i in range(n):
+            fns[i % len(fns)]()
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / n
+        best = t if best is None else min(best, t)
+    return best
+
+
+def run_center_config(name, enc, sd, dev, rank, world, args):
+    """the timed region of a single-object config + its per-chain latencies; returns a dict of measurements"""
+    c = CONFIGS[name]
+    n_points, k = (args.n_points or c["n_points"]), (args.pairs_per_point or c["k"])
+    n_streams = max(1, args.streams)
+    n_obj = max(n_streams, -(-args.objects // n_streams) * n_streams)      # a multiple of the streams: pipe j stays on stream j mod S
+    objs = make_center_set(enc, dev, n_points, k, c["res"], n_obj, seed0=100 * rank, use_graph=not args.no_graph)
+    pipes = [o["pipe"] for o in objs]
+    P = objs[0]["idx"].shape[0]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+    steps = args.steps
+    res_all = torch.zeros((steps, 16), dtype=torch.uint8, device=dev)   # {i64 arg-max, f32 peak} of every step
+    rec_tmpl = torch.zeros((steps, sharding.RECORD), dtype=torch.float64, device=dev)
+    rec_tmpl[:, 15] = torch.arange(rank * steps, (rank + 1) * steps, device=dev).double()
+    res_i64, res_f32 = res_all.view(torch.int64), res_all.view(torch.float32)
 
     def close_batch():
         """Pack the K per-step results into records and run the single end-of-batch collective."""
@@ -142,30 +206,30 @@ def main():
         records[:, 12] = res_i64[:, 0]          # arg-max index  (int64 -> f64 in the copy)
         records[:, 13] = res_f32[:, 2]          # peak value     (f32 -> f64 in the copy)
         if world > 1:
-            return sharding.gather_records(records, world * args.steps, rank, world, dev)   # the one collective
+            return sharding.gather_records(records, world * steps, rank, world, dev)   # the one collective
         return records
 
-    def run_steps(n, first_slot=0):
-        """n steps, step k on stream k mod S; every step's result is kept (one 16-byte device copy on its stream); the
-        caller's stream waits for all of them at the end"""
+    def run_steps(n):
+        """n steps, step k = object k mod n_obj on stream k mod S; every step's result is kept (one 16-byte device copy on its
+        stream); the caller's stream waits for all of them at the end"""
         main = torch.cuda.current_stream(dev)
         for st in streams:
             st.wait_stream(main)
-        for k in range(n):
-            with torch.cuda.stream(streams[k % n_streams]):
-                pipes[k % n_streams].run()
-                res_all[(first_slot + k) % args.steps].copy_(pipes[k % n_streams].result, non_blocking=True)
+        for j in range(n):
+            with torch.cuda.stream(streams[j % n_streams]):
+                pipes[j % n_obj].run(check_weights=j < n_obj)
+                res_all[j % steps].copy_(pipes[j % n_obj].result, non_blocking=True)
         for st in streams:
             main.wait_stream(st)
 
-    run_steps(max(args.warmup, n_streams))
-    close_batch()            # warm-up of the gather too (RCCL communicators are created on first use)
+    run_steps(max(args.warmup, n_obj))      # every object's graph is captured and replayed at least once
+    close_batch()                           # warm-up of the gather too (RCCL communicators are created on first use)
     settle()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_steps(args.steps)
+    run_steps(steps)
     allrec = close_batch()
     if world > 1:
         torch.distributed.barrier()
@@ -175,94 +239,219 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    lat = events_per_chain(dev, pipes, max(20, steps))
+    return dict(objs=objs, pipes=pipes, P=P, n_points=n_points, k=k, n_obj=n_obj, n_streams=n_streams, elapsed=elapsed,
+                allrec=allrec, lat=lat, what=c["what"])
 
-    # the same K steps strictly one at a time on one stream (per-instance latency), reported next to the headline
-    torch.cuda.synchronize()
-    ts0 = time.perf_counter()
-    for k in range(args.steps):
-        pipe.run()
-        res_all[k].copy_(pipe.result, non_blocking=True)
-    torch.cuda.synchronize()
-    ms_single = (time.perf_counter() - ts0) / args.steps * 1e3
 
-    # per-kernel durations (HIP events on the stream the C ABI launches on), measured eagerly right after
-    # the timed region with the same buffers: the dominant kernel alone between two events
-    pc, nrm, feat, idx_d, utr_d, urot_d, corner_d = (pipe.pc, pipe.nrm, pipe.feat, pipe.idx, pipe.u_tr, pipe.u_rot,
-                                                       pipe.corner)
-    ws = PoseWorkspace(dev, P, dims, 1)
-    n_ev = max(args.steps, 5)
-    def bracket(fn, n):
-        """fn launched n times back to back between two HIP events, so that the device queue stays full and the quotient is
-        the kernels' own duration (no host-side launch gaps inside the bracket); the smallest of three brackets, because one
-        host hiccup inside a bracket (an allocator or collector pause between two launches) idles the device and inflated a
-        20-launch average by 25 % on one run"""
-        best = None
-        for _ in range(3):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            fn()
-            e0.record()
-            for _ in range(n):
-                fn()
-            e1.record()
-            torch.cuda.synchronize()
-            t = e0.elapsed_time(e1) / n
-            best = t if best is None else min(best, t)
-        return best
+def workload_text(name, m, args):
+    d = m["objs"][0]["dims"]
+    return (f"{name}: single object N={m['n_points']} K={m['k']} (P={m['P']} pairs), bottle config, res {m['objs'][0]['cfg'].res:g}, "
+            f"grid {d[0]}x{d[1]}x{d[2]}, num_rots 72 adaptive, fused PPF+MLP(MFMA f32)+decode -> LDS-tiled vote -> argmax "
+            f"({m['what']}); one object per GPU per step, steps rotate over {m['n_obj']} distinct objects (own buffers: inputs come "
+            "from HBM, not the Infinity Cache), " +
+            (f"{m['n_streams']} independent objects in flight on {m['n_streams']} HIP streams; " if m["n_streams"] > 1
+             else "one object at a time; ") +
+            ("four launches per step replayed from a hipGraph" if not args.no_graph else "eager launches"))
 
+
+def c4_objects(n_objects, n_points, k, seed0=500):
+    """BASELINE.json configs[3]: mixed NOCS categories, C2-size clouds; pairs and bin uniforms are drawn on the device"""
+    objs = []
+    for j in range(n_objects):
+        ob = syn.make_object(NOCS_CATEGORIES[j % len(NOCS_CATEGORIES)], n_points, seed0 + j)
+        objs.append(dict(pc=ob["pc"], normals=ob["normals"], feat=ob["feat"], cfg=ob["cfg"], n_pairs=n_points * k))
+    return objs
+
+
+def run_c4(dev, rank, world, args, n_objects=64):
+    """64 mixed-category objects sharded round-robin over the ranks, full pose per object, ONE gather inside the timed region"""
+    from cppf_amd.batch import BatchPoseRunner
+    n_points, k = (args.n_points or 4096), (args.pairs_per_point or 128)
+    encs = {}
+    for i, c in enumerate(NOCS_CATEGORIES):
+        torch.manual_seed(i)
+        cfg = syn.make_object(c, 8, 0)["cfg"]
+        encs[c] = PPFEncoder(cfg.ppffcs, cfg.out_dim).eval().to(dev)
+    runner = BatchPoseRunner(encs, dev, n_lanes=max(1, args.streams))
+    objects = c4_objects(n_objects, n_points, k)
+    for _ in range(max(2, min(args.warmup, 3))):
+        runner.run(objects, rank, world)
     settle()
+    reps = max(1, args.steps // 8)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        recs = runner.run(objects, rank, world)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert recs.shape[0] == n_objects and bool(torch.isfinite(recs[:, :12]).all())
+    return dict(elapsed=elapsed, reps=reps, n_objects=n_objects, P=n_points * k, n_points=n_points, k=k)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2",
+                    help="BASELINE.json configuration (default c2 = the headline; see the module docstring)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary stage timings (counter-collection passes)")
+    ap.add_argument("--streams", type=int, default=3, help="instances in flight per GPU: step k runs on HIP stream k mod S "
+                    "(1 = strictly one instance at a time)")
+    ap.add_argument("--objects", type=int, default=9, help="distinct objects the steps rotate over (rounded up to a multiple of "
+                    "--streams); 9 x ~70 MB of buffers exceed the 256 MB Infinity Cache")
+    ap.add_argument("--no-graph", action="store_true", help="launch the chain eagerly instead of replaying a hipGraph")
+    ap.add_argument("--n-points", type=int, default=0, help="exploration only; overrides the config's N")
+    ap.add_argument("--pairs-per-point", type=int, default=0, help="exploration only; overrides the config's K")
+    args = ap.parse_args()
+
+    rank, world, local = sharding.init_distributed()
+    assert world == args.gpus, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    if args.config == "c4":
+        m = run_c4(dev, rank, world, args)
+        if rank == 0:
+            total_pairs = m["reps"] * m["n_objects"] * m["P"]
+            print(json.dumps({
+                "metric": METRIC, "value": total_pairs / m["elapsed"], "unit": "pairs/s", "n_gpus": world,
+                "steps": m["reps"] * m["n_objects"], "warmup": args.warmup,
+                "ms_per_step": m["elapsed"] / (m["reps"] * m["n_objects"]) * 1e3, "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"c4: batch of {m['n_objects']} objects of mixed NOCS categories (N={m['n_points']} K={m['k']}, "
+                                       f"P={m['P']} pairs each; BASELINE.json configs[3]), object j on rank j mod {world}, FULL pose per "
+                                       "object (centre chain + back-vote + second pass + orientation vote + sign + scale) through "
+                                       "BatchPoseRunner: clouds and features staged from pinned host memory, pairs and bin uniforms drawn "
+                                       "on the device, one all_gather of the 160-byte records closes the batch; a step = one object",
+                           "objects": m["n_objects"], "objects_per_gpu": m["n_objects"] / world, "parallelism": f"objects x{world}"},
+                "objects_per_s": m["reps"] * m["n_objects"] / m["elapsed"]}))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    torch.manual_seed(0)
+    enc = PPFEncoder([84, 32, 32, 16], 141).eval()
+    sd = {k_: v.detach().numpy().copy() for k_, v in enc.state_dict().items()}
+    enc = enc.to(dev)
+    m = run_center_config(args.config, enc, sd, dev, rank, world, args)
+    objs, pipes, P, steps = m["objs"], m["pipes"], m["P"], args.steps
+    o0, pipe = objs[0], pipes[0]
+    cfg, dims = o0["cfg"], o0["dims"]
+    elapsed = m["elapsed"]
+    d = lambda a: torch.from_numpy(a).to(dev)
+    secondary = rank == 0 and world == 1 and not args.no_secondary
+
+    # ---- per-kernel durations (HIP events on the stream the C ABI launches on), eagerly right after the timed region with the
+    # same rotating buffers: the dominant kernel alone between two events
+    n_ev = max(steps, 5)
+    wss = [PoseWorkspace(dev, P, o["dims"], 1) for o in objs]
+    settle()
+
+    def mlp_fn(o, u_rot=True):
+        p_ = o["pipe"]
+        return lambda: enc.forward_decode(p_.pc, p_.nrm, p_.feat, p_.idx, p_.u_tr, o["cfg"].vote_range,
+                                          p_.u_rot if u_rot else None, o["cfg"].tr_num_bins, o["cfg"].rot_num_bins)
+
+    def vote_fn(o, ws, outputs):
+        p_ = o["pipe"]
+        return lambda: voting.vote_argmax(p_.pc, outputs, None, p_.idx, ws.grid, p_.corner, o["cfg"].res, NUM_ROTS, True,
+                                          ws.out_idx, ws.out_val, accumulate=False)
+
     with torch.no_grad():
-        outputs, heads = enc.forward_decode(pc, nrm, feat, idx_d, utr_d, cfg.vote_range, urot_d, cfg.tr_num_bins,
-                                            cfg.rot_num_bins)
-        t_mlp = bracket(lambda: enc.forward_decode(pc, nrm, feat, idx_d, utr_d, cfg.vote_range, urot_d, cfg.tr_num_bins,
-                                                   cfg.rot_num_bins), n_ev)     # ms
-        t_vote = bracket(lambda: voting.vote_argmax(pc, outputs, None, idx_d, ws.grid, corner_d, cfg.res, NUM_ROTS, True,
-                                                    ws.out_idx, ws.out_val, accumulate=False), n_ev)
+        t_mlp = bracket([mlp_fn(o) for o in objs], n_ev)     # ms
+        t_vote = bracket([vote_fn(o, ws, o["pipe"].outputs) for o, ws in zip(objs, wss)], n_ev)
 
-    # secondary: the pair encoder decoding only the two centre heads (all the centre vote consumes; the reference
-    # computes the other 77 logits in this pass too and throws them away, nocs/inference.py:182-188).  Not the headline:
-    # `value` is measured with all heads decoded.
+    # secondary: the pair encoder decoding only the two centre heads (all the centre vote consumes; the reference computes the
+    # other 77 logits in this pass too and throws them away, nocs/inference.py:182-188).  `value` is measured with all heads.
     t_mlp_tr = None
-    if rank == 0 and world == 1 and not args.no_secondary:
+    if secondary:
         with torch.no_grad():
-            t_mlp_tr = bracket(lambda: enc.forward_decode(pc, nrm, feat, idx_d, utr_d, cfg.vote_range, None, cfg.tr_num_bins,
-                                                          cfg.rot_num_bins), n_ev)
+            t_mlp_tr = bracket([mlp_fn(o, False) for o in objs], n_ev)
 
-    # secondary (untimed for `value`): the vote stage alone on known-answer inputs -- every vote circle
-    # passes through the object centre, so most samples land in the grid (the atomic-heavy regime a
-    # trained network produces), unlike the near-uniform bins of a random-weight MLP above.
-    t_vote_ka = None
-    if rank == 0 and world == 1 and not args.no_secondary:
-        out_ka = d(syn.closed_form_outputs(ob["pc"], ob["center"], idx, cfg, quantise=True))
-        t_vote_ka = bracket(lambda: voting.vote_argmax(pc, out_ka, None, idx_d, ws.grid, corner_d, cfg.res, NUM_ROTS, True,
-                                                       ws.out_idx, ws.out_val, accumulate=False), 5)
+    # secondary: the vote stage alone, and then the whole step, on known-answer inputs -- every vote circle passes through the
+    # object centre, so most samples land in the grid (what a trained network produces), unlike the near-uniform bins of the
+    # random-weight MLP of the headline.
+    t_vote_ka = t_tail_ka = n_surv_ka = trained = None
+    if secondary:
+        outs_ka = [d(syn.closed_form_outputs(o["ob"]["pc"], o["ob"]["center"], o["idx"], o["cfg"], quantise=True)) for o in objs]
+        t_vote_ka = bracket([vote_fn(o, ws, ka) for o, ws, ka in zip(objs, wss, outs_ka)], 9)
+        # trained-network regime of the WHOLE step: pair stage + known-answer vote in one captured graph per object
+        tr_pipes = []
+        for o, ka in zip(objs, outs_ka):
+            tp = TrainedRegimePipeline(enc, o["cfg"], m["n_points"], P, o["dims"], dev, NUM_ROTS, adaptive=True, with_heads=True,
+                                       use_graph=not args.no_graph)
+            tp.load(o["ob"]["pc"], o["ob"]["normals"], o["ob"]["feat"], o["idx"], o["u_tr"], o["u_rot"], o["corners"][0].copy())
+            tp.set_known_answer(ka)
+            tr_pipes.append(tp)
+        streams = [torch.cuda.Stream(device=dev) for _ in range(m["n_streams"])]
 
-    # secondary: centre vote + the whole pose tail on the same known-answer inputs, where (nearly) every pair survives the
-    # back-vote -- the trained-network regime of the tail, which the random-weight network above (0.4 % survivors) never
-    # enters.  Heads of every pair from one full first pass (PosePipeline's "full first" form), launches eager, back to back.
-    t_tail_ka, n_surv_ka = None, None
-    if rank == 0 and world == 1 and not args.no_secondary:
+        def tr_steps(n):
+            main = torch.cuda.current_stream(dev)
+            for st in streams:
+                st.wait_stream(main)
+            for j in range(n):
+                with torch.cuda.stream(streams[j % len(streams)]):
+                    tr_pipes[j % len(tr_pipes)].run(check_weights=False)
+            for st in streams:
+                main.wait_stream(st)
+        for tp in tr_pipes:
+            tp.run()
+        tr_steps(len(tr_pipes))
+        settle()
+        torch.cuda.synchronize()
+        tt0 = time.perf_counter()
+        tr_steps(steps)
+        torch.cuda.synchronize()
+        t_tr = (time.perf_counter() - tt0) / steps * 1e3
+        lat_tr = events_per_chain(dev, tr_pipes, 20)
+        cell = np.array(np.unravel_index(int(tr_pipes[0].out_idx.item()), o0["dims"]))
+        trained = {"ms_per_step": t_tr, "pairs_per_s": P / (t_tr * 1e-3), "median_ms_one_instance": lat_tr[len(lat_tr) // 2],
+                   "argmax_is_the_true_centre_cell": bool(np.all(np.abs(cell - (o0["ob"]["center"] - o0["corners"][0]) / cfg.res) <= 1.0)),
+                   "note": "same four launches per step, the vote fed by known-answer (mu, nu) -- the regime a trained network "
+                           "produces; the pair stage runs in full"}
+        del tr_pipes
+
+    # secondary: centre vote + the whole pose tail on known-answer inputs, where (nearly) every pair survives the back-vote
+    if secondary:
         from cppf_amd.inference import _enqueue_tail
         from cppf_amd.utils.util import fibonacci_sphere
         ws_ka = PoseWorkspace(dev, P, dims, 480)
         sph_ka = ws_ka.sphere(np.array(fibonacci_sphere(480)))
-        idx32_ka = idx_d.to(torch.int32)
+        idx32_ka = pipe.idx.to(torch.int32)
+        heads_ka = d(syn.closed_form_heads(o0["ob"]["pc"], o0["ob"]["normals"], o0["idx"], cfg))
 
         def tail_ka():
-            voting.vote_argmax(pc, out_ka, None, idx_d, ws_ka.grid, corner_d, cfg.res, NUM_ROTS, True, ws_ka.out_idx,
+            voting.vote_argmax(pipe.pc, outs_ka[0], None, pipe.idx, ws_ka.grid, pipe.corner, cfg.res, NUM_ROTS, True, ws_ka.out_idx,
                                ws_ka.out_val, accumulate=False)
-            _enqueue_tail(ws_ka, pc, nrm, idx32_ka, out_ka, heads, corner_d, cfg, dims, NUM_ROTS, 1.5, 10000, *sph_ka)
+            _enqueue_tail(ws_ka, pipe.pc, pipe.nrm, idx32_ka, outs_ka[0], heads_ka, pipe.corner, cfg, dims, NUM_ROTS, 1.5, 10000,
+                          *sph_ka)
         with torch.no_grad():
-            t_tail_ka = bracket(tail_ka, 5)
+            t_tail_ka = bracket([tail_ka], 5)
         n_surv_ka = int(ws_ka.count.item())
+        del ws_ka, heads_ka
+    if secondary:
+        del outs_ka
+    del wss
 
-    # secondary metric (SURVEY.md 8d): the same object through the FULL pose (centre chain + back-vote +
-    # orientation vote + axis sign + scale + one read-back), one hipGraph replay per object
+    # secondary metric (SURVEY.md 8d): the same object through the FULL pose (centre chain + back-vote + orientation vote + axis
+    # sign + scale + one read-back), one hipGraph replay per object
     t_pose, pose = None, {"n_surv": None}
-    if rank == 0 and world == 1 and not args.no_secondary:
+    if secondary:
         from cppf_amd.inference import PosePipeline
         from cppf_amd.utils.util import fibonacci_sphere
-        pp = PosePipeline(enc, cfg, N_POINTS, P, dims, dev, np.array(fibonacci_sphere(480)), NUM_ROTS)
-        pp.load(ob["pc"], ob["normals"], ob["feat"], idx, u_tr, u_rot, corners[0].copy())
+        pp = PosePipeline(enc, cfg, m["n_points"], P, dims, dev, np.array(fibonacci_sphere(480)), NUM_ROTS)
+        pp.load(o0["ob"]["pc"], o0["ob"]["normals"], o0["ob"]["feat"], o0["idx"], o0["u_tr"], o0["u_rot"], o0["corners"][0].copy())
         for _ in range(3):
             pose = pp.run()
         settle()
@@ -271,11 +460,36 @@ def main():
         for _ in range(10):
             pose = pp.run()
         t_pose = (time.perf_counter() - tp0) / 10 * 1e3
+        del pp
 
-    # secondary (BASELINE config 4, one GPU's share): 8 instances through BatchPoseRunner -- cloud in from the host, pairs and
-    # bin uniforms drawn on the device, kNN + SPRIN + full pose per instance, one read-back for the batch
+    # secondaries: the other BASELINE.json configurations, each through the same code as a --config run of its own
+    other = {}
+    if secondary and args.config == "c2":
+        keep = (args.steps, args.objects)
+        for name in ("c3", "c5"):
+            args.steps, args.objects = 12, 3 if name == "c5" else 6
+            mm = run_center_config(name, enc, sd, dev, rank, world, args)
+            entry = {"workload": workload_text(name, mm, args), "ms_per_step": mm["elapsed"] / args.steps * 1e3,
+                     "pairs_per_s": args.steps * mm["P"] / mm["elapsed"],
+                     "median_ms_one_instance": mm["lat"][len(mm["lat"]) // 2]}
+            if not args.no_cpu_baseline:
+                flat_cpu, _, _ = oracle_center(mm["objs"][0], sd)
+                entry["argmax_matches_oracle"] = bool(flat_cpu == int(mm["allrec"][0, 12].item()))
+            other[name] = entry
+            del mm
+        args.steps, args.objects = keep
+        args.steps = 8
+        m4 = run_c4(dev, rank, world, args, n_objects=8)          # one GPU's share of the 64-object batch
+        other["c4_one_gpu_share"] = {"workload": "8 mixed-category objects (N=4096 K=128), full pose each, BatchPoseRunner, pairs "
+                                                 "drawn on the device, one read-back per batch",
+                                     "ms_per_object": m4["elapsed"] / (m4["reps"] * 8) * 1e3,
+                                     "pairs_per_s": m4["reps"] * 8 * m4["P"] / m4["elapsed"]}
+        args.steps = keep[0]
+
+    # secondary (BASELINE config 4 with the point encoder in front): 8 instances through BatchPoseRunner -- cloud in from the
+    # host, pairs and bin uniforms drawn on the device, kNN + SPRIN + full pose per instance, one read-back for the batch
     t_batch = None
-    if rank == 0 and world == 1 and not args.no_secondary:
+    if secondary:
         from cppf_amd.batch import BatchPoseRunner
         from cppf_amd.models.model import PointEncoder
         torch.manual_seed(3)
@@ -283,7 +497,7 @@ def main():
         runner = BatchPoseRunner({cfg.category: enc}, dev, point_encoders={cfg.category: penc_b})
         batch = []
         for j in range(8):
-            obj_j = syn.make_object("bottle", N_POINTS, seed=100 + j)
+            obj_j = syn.make_object("bottle", m["n_points"], seed=100 + j)
             batch.append(dict(pc=obj_j["pc"], normals=obj_j["normals"], cfg=obj_j["cfg"], n_pairs=P))
         for _ in range(2):
             runner.run(batch)
@@ -294,11 +508,12 @@ def main():
             runner.run(batch)
         torch.cuda.synchronize()
         t_batch = (time.perf_counter() - tb0) / 3 / 8 * 1e3
+        del runner
 
     # secondary: the step before the path -- kNN(60) + SPRIN point encoder producing `feat`
     # (nocs/inference.py:180-181), random-init weights of the reference's configuration (train.py:34)
     t_penc = None
-    if rank == 0 and world == 1 and not args.no_secondary:
+    if secondary:
         from cppf_amd.models.model import PointEncoder
         torch.manual_seed(1)
         penc = PointEncoder(k=60, spfcs=[32, 64, 32, 32], num_layers=1, out_dim=32).eval().to(dev)
@@ -308,7 +523,7 @@ def main():
             for it in range(6):
                 if it == 1:
                     e0.record()
-                penc(pc[None], nrm[None])
+                penc(pipe.pc[None], pipe.nrm[None])
             e1.record()
         torch.cuda.synchronize()
         t_penc = e0.elapsed_time(e1) / 5
@@ -316,11 +531,13 @@ def main():
     # secondary: one training-size forward + backward of the pair encoder (train.py:66,91:
     # 200 000 pairs, dL/dlogits given), HIP forward + HIP backward through the autograd.Function
     t_train = t_step = t_full = None
-    if rank == 0 and world == 1 and not args.no_secondary:
+    if secondary:
         Pt = 200000
-        idx_t = d(syn.make_pairs(N_POINTS, (Pt + N_POINTS - 1) // N_POINTS, 7)[:Pt])
+        n_pts = m["n_points"]
+        idx_t = d(syn.make_pairs(n_pts, (Pt + n_pts - 1) // n_pts, 7)[:Pt])
         Rt = torch.randn((Pt, cfg.out_dim), device=dev)
-        feat_t = feat.clone().requires_grad_(True)
+        pc, nrm = pipe.pc, pipe.nrm
+        feat_t = pipe.feat.clone().requires_grad_(True)
         enc.train()
         settle()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -371,29 +588,28 @@ def main():
         enc.eval()
 
     if rank == 0:
-        argmax_gpu = int(allrec[0, 12].item())
+        argmax_gpu = int(m["allrec"][0, 12].item())
+        lat = m["lat"]
         out = {
-            "metric": "point-pairs/sec (PPF+MLP+vote+argmax), N=4096 K=128; 1/2/4/8 GPU",
-            "value": world * args.steps * P / elapsed,
+            "metric": METRIC,
+            "value": world * steps * P / elapsed,
             "unit": "pairs/s",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"single object N={N_POINTS} K={PAIRS_PER_POINT} (P={P} pairs), bottle config, res 4e-3, "
-                                   f"grid {dims[0]}x{dims[1]}x{dims[2]}, num_rots 72 adaptive, fused PPF+MLP(MFMA f32)+decode -> "
-                                   "LDS-tiled vote -> argmax; one object per GPU per step, " +
-                                   (f"{n_streams} independent objects in flight on {n_streams} HIP streams (each with its own buffers and captured graph); "
-                                    if n_streams > 1 else "one object at a time; ") +
-                                   ("four launches per step replayed from a hipGraph" if not args.no_graph else "eager launches"),
-                       "pairs_per_step_per_gpu": P, "parallelism": f"objects x{world}"},
-            "pairs_per_ms_per_gpu": args.steps * P / elapsed / 1e3,
-            "ms_per_step_one_instance_at_a_time": ms_single,
+            "config": {"workload": workload_text(args.config, m, args), "pairs_per_step_per_gpu": P,
+                       "parallelism": f"objects x{world}"},
+            "pairs_per_ms_per_gpu": steps * P / elapsed / 1e3,
+            # hipEvents around the whole chain on one object, one at a time, objects rotating
+            "median_ms_one_instance": lat[len(lat) // 2],
+            "one_instance_ms_min_max": [lat[0], lat[-1]], "one_instance_runs": len(lat),
+            "trained_regime": trained,
             "stage_ms": {"ppf_mlp_decode": t_mlp, "ppf_mlp_decode_centre_heads_only": t_mlp_tr, "vote_reduce_argmax": t_vote,
                          "vote_reduce_argmax_known_answer_inputs": t_vote_ka,
                          "vote_plus_pose_tail_known_answer_inputs": t_tail_ka, "pose_tail_known_answer_n_surv": n_surv_ka,
@@ -403,6 +619,7 @@ def main():
                          "pair_encoder_fwd_bwd_200k_pairs": t_train,
                          "pair_encoder_fwd_bwd_adam_step_200k_pairs": t_step,
                          "train_step_both_encoders_adam_200k_pairs": t_full},
+            "other_configs": other or None,
             # dominant kernel = the fused pair encoder (one launch between the two events): exact-fp32
             # MFMA, 23 968 algorithmic FLOP per pair
             "roofline": {"bound": "mfma", "kernel": "pair_mlp_kernel<false,true,true>",
@@ -414,14 +631,22 @@ def main():
                                  f"{FLOP_PER_PAIR_EXECUTED} MFMA FLOP per pair because the two 40-wide feature blocks of layer 0 "
                                  "are projected once per point; fp32 MFMA shares the VALU datapath on gfx950, so the in-register "
                                  "decode (about 480 VALU per 16 pairs) is paid on the same pipe; the duration is that of launches "
-                                 "without a neighbour (back to back on one stream) -- in the timed region several objects are in flight, "
-                                 "so a kernel trace of this command also holds launches that overlap another object's vote and take longer "
-                                 "(profiles/r*_kernel_trace_stats_one_stream.txt: the same command with --streams 1, whose averages agree)",
+                                 "without a neighbour (back to back on one stream, inputs rotating over the objects) -- in the timed "
+                                 "region several objects are in flight, so a kernel trace of this command also holds launches that "
+                                 "overlap another object's vote and take longer (profiles/r*_kernel_trace_stats_one_stream.txt: the "
+                                 "same command with --streams 1, whose averages agree)",
                          "executed_mfma_tflops": FLOP_PER_PAIR_EXECUTED * P / (t_mlp * 1e-3) / 1e12},
         }
         if world == 1 and not args.no_cpu_baseline:
-            cb, flat_cpu = cpu_baseline(ob, idx, u_tr, u_rot, sd, cfg, corners[0], dims, N_POINTS, PAIRS_PER_POINT)
-            out["cpu_baseline"] = cb
+            flat_cpu, pps, reps = oracle_center(o0, sd, budget_s=12.0, max_reps=8)
+            tps, tthreads, tn = torch_cpu_mlp(o0, sd)
+            out["cpu_baseline"] = dict(
+                value=pps, unit="pairs/s", cores=host_threads(), kind="port",
+                sample=f"{reps} x full workload (N={m['n_points']}, K={m['k']}, P={P}): the repo's C oracle with OpenMP -- AVX2 fmaf-chain "
+                       "MLP + decode + vote + arg-max (the reference has no CPU vote path)",
+                mlp_torch_cpu={"value": tps, "unit": "pairs/s", "threads": tthreads,
+                               "sample": f"PPF + gather + ResLayers + final as torch ops on the host (models/model.py:118-137), "
+                                         f"{tn} pairs, same weights; MLP leg only"})
             out["argmax_matches_oracle"] = bool(flat_cpu == argmax_gpu)
         print(json.dumps(out))
     if world > 1:

@@ -58,11 +58,14 @@ def gather_records(local_records, n_objects, rank, world, device=None):
     else:
         n_max = (n_objects + world - 1) // world
         dev = device if device is not None else local_records.device
+        out_dev = dev
+        if dist.get_backend() == "gloo":      # CPU collective (tests; two ranks sharing one GPU): stage through the host
+            dev = torch.device("cpu")
         buf = torch.full((n_max, RECORD), -1.0, dtype=torch.float64, device=dev)
         buf[:local_records.shape[0]] = local_records.to(dev)
         allb = torch.empty((world * n_max, RECORD), dtype=torch.float64, device=dev)   # rank-major concatenation
         dist.all_gather_into_tensor(allb, buf)
-        out = allb
+        out = allb.to(out_dev)
         out = out[out[:, 15] >= 0]
     order = torch.argsort(out[:, 15])
     out = out[order]

@@ -1,0 +1,104 @@
+"""The product's world > 1 path executed for real: two ranks (processes) share GPU 0, rendezvous over gloo
+(CPPF_DIST_BACKEND=gloo -- RCCL needs one GPU per rank), each runs BatchPoseRunner.run(objects, rank, world) on the SAME
+mixed-category batch and must end up with the records of the single-rank run, bit for bit, in object order.  The reference's
+analogue is its per-instance loop (nocs/inference.py:120); the collective is sharding.gather_records' one all_gather."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _batch(n_objects=8, n_points=768, k=24):
+    import cppf_amd.synthetic as syn
+    from cppf_amd.config import NOCS_CATEGORIES
+    objects = []
+    for j in range(n_objects):
+        ob = syn.make_object(NOCS_CATEGORIES[j % 6], n_points + 64 * (j % 3), 300 + j)      # ragged N: shape-polymorphic pipelines
+        idx = syn.make_pairs(ob["pc"].shape[0], k, 300 + j)[:n_points * k]
+        u_tr, u_rot = syn.make_uniforms(idx.shape[0], 300 + j)
+        objects.append(dict(pc=ob["pc"], normals=ob["normals"], feat=ob["feat"], point_idxs=idx, u_tr=u_tr, u_rot=u_rot,
+                            cfg=ob["cfg"]))
+    return objects
+
+
+def _encoders(dev):
+    from cppf_amd.config import NOCS_CATEGORIES
+    from cppf_amd.models.model import PPFEncoder
+    encs = {}
+    for i, c in enumerate(NOCS_CATEGORIES):
+        torch.manual_seed(i)
+        e = PPFEncoder([84, 32, 32, 16], 141)
+        with torch.no_grad():
+            e.final.weight.mul_(4)
+            e.final.bias.mul_(4)
+        encs[c] = e.eval().to(dev)
+    return encs
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      CPPF_DIST_BACKEND="gloo")
+    from cppf_amd import sharding
+    from cppf_amd.batch import BatchPoseRunner
+    r, w, local = sharding.init_distributed()
+    assert (r, w, local) == (rank, world, 0)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    runner = BatchPoseRunner(_encoders(dev), dev)
+    objects = _batch()
+    recs = runner.run(objects, rank, world)
+    recs2 = runner.run(objects, rank, world)             # replays (and adapted forms) give the same records
+    assert torch.equal(recs, recs2)
+    torch.save(recs.cpu(), os.path.join(out_dir, f"rank{rank}.pt"))
+    # device-drawn pairs: (seed, object index) fixes the draw whatever rank runs the object
+    objs_dev = [dict(pc=o["pc"], normals=o["normals"], feat=o["feat"], cfg=o["cfg"], n_pairs=o["point_idxs"].shape[0])
+                for o in objects]
+    torch.save(runner.run(objs_dev, rank, world, seed=11).cpu(), os.path.join(out_dir, f"dev_rank{rank}.pt"))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_equal_the_single_rank_batch(oracle, golden, dev, tmp_path):
+    from cppf_amd.batch import BatchPoseRunner
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    objects = _batch()
+    runner = BatchPoseRunner(_encoders(dev), dev)
+    single = runner.run(objects).cpu()
+    assert single.shape == (8, 20) and single[:, 15].tolist() == list(range(8))
+    objs_dev = [dict(pc=o["pc"], normals=o["normals"], feat=o["feat"], cfg=o["cfg"], n_pairs=o["point_idxs"].shape[0])
+                for o in objects]
+    single_dev = runner.run(objs_dev, seed=11).cpu()
+    for rank in range(world):
+        got = torch.load(os.path.join(tmp_path, f"rank{rank}.pt"))
+        assert torch.equal(got, single), rank                     # every rank, object order, bit for bit
+        assert torch.equal(torch.load(os.path.join(tmp_path, f"dev_rank{rank}.pt")), single_dev), rank
+    # ... and the single-rank records are the oracle's poses (so the two-rank ones are too)
+    sph = golden("sphere.npz")["pts"]
+    sd = {k: v.detach().cpu().numpy() for k, v in _encoders(torch.device("cpu"))["bottle"].state_dict().items()}
+    from cppf_amd.config import NOCS_CATEGORIES
+    sds = {c: {k: v.detach().cpu().numpy() for k, v in e.state_dict().items()} for c, e in _encoders(torch.device("cpu")).items()}
+    recs = single.numpy()
+    for j, obj in enumerate(objects):
+        cfg = obj["cfg"]
+        ocfg = dict(res=cfg.res, tr_num_bins=32, rot_num_bins=36, vote_range=cfg.vote_range, scale_mean=cfg.scale_mean,
+                    regress_right=cfg.regress_right, ppffcs=[84, 32, 32, 16], out_dim=141)
+        o = oracle.estimate_pose(obj["pc"], obj["normals"], obj["feat"], obj["point_idxs"], sds[cfg.category], ocfg, obj["u_tr"],
+                                 obj["u_rot"], sph)
+        assert int(recs[j, 12]) == o["argmax"] and int(recs[j, 14]) == int(o["mask"].sum())
+        np.testing.assert_allclose(recs[j, 0:3], o["T"], atol=1e-12)
+        np.testing.assert_allclose(recs[j, 3:6], o["up"], atol=1e-12)
+        np.testing.assert_allclose(recs[j, 9:12], o["scale"], rtol=1e-6)
