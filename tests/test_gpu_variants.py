@@ -65,7 +65,8 @@ def test_device_results_hold_under_every_variant(oracle, golden, dev, case):
     for name, v in variants.items():
         p = O.pose_tail_variant(ob["pc"], ob["normals"], idx, outputs, heads, ocfg, sph, v)
         assert p["argmax"] == r["argmax"], name                                   # bit-exact vote-grid arg-max index
-        assert np.abs(p["grid"] - base["grid"]).max() < 0.5 * base["margin"], name
+        if mode == "ka":      # a grid with a real peak: no cell moved by half the top-1 / top-2 margin -> provably the same cell
+            assert np.abs(p["grid"] - base["grid"]).max() < 0.5 * base["margin"], name
         np.testing.assert_allclose(p["T"], r["T"], atol=1e-12, err_msg=name)
         assert abs(int(p["mask"].sum()) - n0) <= max(3, 2e-3 * n0), (name, int(p["mask"].sum()), n0)
         assert int((p["mask"] != r["mask"]).sum()) <= max(4, 4e-3 * n0), name
