@@ -23,6 +23,7 @@ Under `no_grad` it is kNN selection + one fused HIP kernel per layer (csrc/sprin
 accepted as an extension and selects neighbours from exact squared distances without an N x N matrix.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 import torch
@@ -63,6 +64,9 @@ def _params_of(module):
     return plist
 
 
+_STREAM_STATE = weakref.WeakKeyDictionary()   # encoder -> {"readers": {stream: event}, "image_ev": (event, stream, generation)}
+
+
 class _DeviceWeights:
     """What both encoders share about their device-side weight images.
 
@@ -91,9 +95,16 @@ class _DeviceWeights:
     # in place on whichever stream notices the parameter change, so both directions are ordered with events: a rebuild waits for
     # every replay that was still reading the old image (`_note_image_read`), and a reader on another stream waits for the
     # rebuild before its next replay (`_await_image`).  A training loop on one stream never registers a reader and pays nothing.
+    # (the events live outside the module: copy.deepcopy / pickling of an encoder must not meet a HIP event)
+    def _stream_state(self):
+        st = _STREAM_STATE.get(self)
+        if st is None:
+            st = _STREAM_STATE[self] = {"readers": {}, "image_ev": (None, None, 0)}
+        return st
+
     def _image_rebuild_begins(self, dev):
         """called right before the weight image is rewritten in place on the current stream of `dev`"""
-        readers = self.__dict__.get("_cppf_readers")
+        readers = self._stream_state()["readers"]
         if readers:
             cur = torch.cuda.current_stream(dev)
             for sid, ev in readers.items():
@@ -102,17 +113,17 @@ class _DeviceWeights:
 
     def _image_rebuilt(self, dev):
         """called right after the rebuild was enqueued: later readers on other streams wait for this event"""
-        if not self.__dict__.get("_cppf_readers"):
+        st = self._stream_state()
+        if not st["readers"]:
             return                                   # nobody replays captured chains on this encoder
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
-        self.__dict__["_cppf_image_ev"] = (ev, torch.cuda.current_stream(dev).cuda_stream,
-                                            self.__dict__.get("_cppf_image_ev", (None, None, 0))[2] + 1)
+        st["image_ev"] = (ev, torch.cuda.current_stream(dev).cuda_stream, st["image_ev"][2] + 1)
 
     def _await_image(self, dev, seen_gen):
         """reader side, before a replay on the current stream: wait for the newest rebuild if this reader has not yet;
         returns the rebuild generation to remember"""
-        ev, sid, gen = self.__dict__.get("_cppf_image_ev", (None, None, 0))
+        ev, sid, gen = self._stream_state()["image_ev"]
         if ev is not None and gen != seen_gen:
             cur = torch.cuda.current_stream(dev)
             if cur.cuda_stream != sid:
@@ -121,7 +132,7 @@ class _DeviceWeights:
 
     def _note_image_read(self, dev):
         """reader side, after a replay was enqueued on the current stream"""
-        readers = self.__dict__.setdefault("_cppf_readers", {})
+        readers = self._stream_state()["readers"]
         cur = torch.cuda.current_stream(dev)
         ev = readers.get(cur.cuda_stream)
         if ev is None:
