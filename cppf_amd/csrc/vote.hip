@@ -474,6 +474,48 @@ __device__ __forceinline__ Mask96 axis_arc_mask(const uint4* __restrict__ below,
     return {O.a & ~I.a & keep, O.b & ~I.b & keep, O.c & ~I.c & keep};
 }
 
+// ----------------------------------------------------------------------------- run walk (see vote_kernel)
+// index of the lowest set bit of the 96-bit word (a, b, c), 96 when it is empty (v_ffbl_b32 returns -1 for 0: the OR keeps it)
+__device__ __forceinline__ int ctz96(uint32_t a, uint32_t b, uint32_t c)
+{
+    const uint32_t f0 = (uint32_t)(__ffs((int)a) - 1), f1 = (uint32_t)(__ffs((int)b) - 1) | 32u, f2 = (uint32_t)(__ffs((int)c) - 1) | 64u;
+    return (int)min(min(f0, f1), min(f2, 96u));
+}
+// one past the highest set bit, 0 when empty
+__device__ __forceinline__ int top96(uint32_t a, uint32_t b, uint32_t c)
+{
+    const int ea = 32 - __clz((int)a), tb = 32 - __clz((int)b), tc = 32 - __clz((int)c);
+    return max(ea, max(tb ? tb + 32 : 0, tc ? tc + 64 : 0));
+}
+// A mask of rotation indices as up to three runs [s, e) in ascending order: the first two runs of set bits exactly, the
+// third = the hull of everything above them.  Empty runs come out as s = e (or e < s for the third: callers clamp).
+__device__ __forceinline__ void mask_runs(const uint4* __restrict__ below, uint32_t m0, uint32_t m1, uint32_t m2, int& s0, int& e0,
+                                          int& s1, int& e1, int& s2, int& e2)
+{
+    s0 = ctz96(m0, m1, m2);
+    uint4 B = below[s0];
+    e0 = ctz96(~(m0 | B.x), ~(m1 | B.y), ~(m2 | B.z));   // first clear bit at or above s0 (bits >= n are clear: e0 <= n)
+    B = below[e0];
+    s1 = ctz96(m0 & ~B.x, m1 & ~B.y, m2 & ~B.z);
+    B = below[s1];
+    e1 = ctz96(~(m0 | B.x), ~(m1 | B.y), ~(m2 | B.z));
+    B = below[e1];
+    const uint32_t r0 = m0 & ~B.x, r1 = m1 & ~B.y, r2 = m2 & ~B.z;
+    s2 = ctz96(r0, r1, r2);
+    e2 = top96(r0, r1, r2);
+}
+// inclusive prefix sum over the 64 lanes: four row_shr steps inside each row of 16, then the row totals (row_bcast 15 / 31)
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 template <bool TILED, bool TAB_LDS>
 __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
 {
@@ -671,88 +713,70 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
                     hiz1 = __uint_as_float(__float_as_uint(hiz) - 1u);
         int qhead = 0, qtail = 0;  // wave-uniform ring cursors, the ring is drained at the end of every batch
         if (TAB_LDS) {
-            // arc screen (n <= 72 rotations): three per-axis masks, their AND, then the set bits go to the ring two per
-            // trip in ballot order
+            // arc screen (n <= 72 rotations): three per-axis masks, their AND
             const float nf = (float)n * 0.159154943f;
             const Mask96 mx = axis_arc_mask(below, cq.x, xq.x, yq.x, lox, hix, nf, n);
             const Mask96 my = axis_arc_mask(below, cq.y, xq.y, yq.y, loy, hiy, nf, n);
             const Mask96 mz = axis_arc_mask(below, cq.z, xq.z, yq.z, loz, hiz, nf, n);
             const uint32_t live = n > 0 ? 0xffffffffu : 0u;
             const uint32_t mw0 = mx.a & my.a & mz.a & live, mw1 = mx.b & my.b & mz.b & live, mw2 = mx.c & my.c & mz.c & live;
-            // Expansion of the masks into the candidate ring, two ways (wave-uniform choice per batch of 64 pairs):
-            //  * few pairs with any bit set (three quarters of the lanes are empty on the benchmark's inputs): one PAIR per
-            //    step with the lanes standing for its rotations -- the pair's mask, read into scalar registers, IS the ballot
-            //    of "lane i queues rotation i": no bit extraction, no compare, empty pairs cost nothing;
-            //  * most lanes busy (a trained network: every circle passes near the centre): every lane queues two of its own
-            //    bits per step, word by word, in ballot order.
-            // A loop over the lanes' own bits alone ran max-over-lanes trips of ~30 instructions with an eighth of the lane
-            // slots doing anything on the benchmark's inputs; the pair-serial form alone lost 10 % on dense masks
-            // (profiles/r2_vote_phases.txt).
-            unsigned long long todo = __ballot((mw0 | mw1 | mw2) != 0u);
-            if (__popcll(todo) <= VOTE_SERIAL_MAX) {
-                while (todo) {
-                    const int src = __builtin_ctzll(todo);
-                    todo &= todo - 1ull;
-                    const unsigned long long lo = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mw0, src) |
-                                                  ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mw1, src) << 32);
-                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)mw2, src);
-                    if (lo) {
-                        if (__builtin_amdgcn_inverse_ballot_w64(lo)) {
-                            const int pos = qtail + __builtin_amdgcn_mbcnt_hi((unsigned)(lo >> 32),
-                                                                              __builtin_amdgcn_mbcnt_lo((unsigned)lo, 0));
-                            ring[pos & (VOTE_RING - 1)] = (uint16_t)(src | (lane << 6));
-                        }
-                        qtail += __popcll(lo);
-                    }
-                    if (hi) {
-                        if (__builtin_amdgcn_inverse_ballot_w64((unsigned long long)hi)) {
-                            const int pos = qtail + __builtin_amdgcn_mbcnt_lo(hi, 0);
-                            ring[pos & (VOTE_RING - 1)] = (uint16_t)(src | ((64 + lane) << 6));
-                        }
-                        qtail += __popc(hi);
-                    }
-                    while (qtail - qhead >= 64) {  // at most two pops: <= 63 queued + <= 72 pushed
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        vote_pop<TILED, TAB_LDS>(VT, F, cr, ltab, ring, qhead, lane, 64);
-                        qhead += 64;
-                    }
-                }
-            } else {
-                uint32_t mw[3] = {mw0, mw1, mw2};
+            // RUN WALK (round 3; replaces the candidate ring for n <= 72).  A pair's mask is an arc or two (90 % / 9 % of the
+            // pair-tile visits on known-answer inputs), so it is turned into up to three index runs -- the first two exact, the
+            // third the hull of whatever remains: a superset (+0.8 % candidates), and the deposit's exact tests decide as
+            // before.  A batch's candidates are then the concatenation of the lanes' runs, total = sum of their lengths
+            // (one DPP scan), and deposit lane j takes the CONTIGUOUS block [j B, (j+1) B), B = ceil(total / 64): it finds the
+            // source lane of its first candidate once (binary search over the scan), then walks -- rotation = run base + k,
+            // next source when the current one is exhausted -- pulling the source's frame with ds_bpermute as before.  No
+            // ring, no per-candidate queueing: the expansion was ~64 of the kernel's 255 VALU per 64 candidates on
+            // known-answer inputs (profiles/r2_vote_phases.txt: 133 trips of ~30 VALU per wave) and is ~20 now, and all 64
+            // lanes finish within one step of each other by construction.
+            int s0, e0, s1, e1, s2, e2;
+            mask_runs(below, mw0, mw1, mw2, s0, e0, s1, e1, s2, e2);
+            const int l0 = e0 - s0, l1 = e1 - s1, l2 = max(e2 - s2, 0);
+            const int cnt = l0 + l1 + l2;
+            const int incl = wave_incl_scan(cnt);
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            if (total > 0) {
+                const unsigned long long nz = __ballot(cnt > 0);
+                const unsigned long long above = nz & ~((2ull << lane) - 1ull);   // (lane 63: 2 << 63 wraps to 0, above = 0)
+                const int nxt = above ? __builtin_ctzll(above) : 64;
+                // byte fields: wA = {run 0 start, end of run 0 in candidate order, end of run 1, count}, wB = {gap between runs 0
+                // and 1, gap between runs 1 and 2, next non-empty lane}: candidate k of the lane is rotation
+                // s0 + k + (k >= t1 ? g1 : 0) + (k >= t2 ? g2 : 0)
+                const uint32_t wA = (uint32_t)s0 | ((uint32_t)l0 << 8) | ((uint32_t)(l0 + l1) << 16) | ((uint32_t)cnt << 24);
+                const uint32_t wB = (uint32_t)(s1 - e0) | ((uint32_t)max(s2 - e1, 0) << 8) | ((uint32_t)nxt << 16);
+                const int rowS = __mul24(n, n - 1) >> 1;   // the pair's row of the rotation table
+                const int Bn = (total + 63) >> 6;
+                const int q0 = __mul24(lane, Bn);
+                const int mine = min(max(total - q0, 0), Bn);
+                int src = 0;
 #pragma unroll
-                for (int w = 0; w < 3; ++w) {
-                    uint32_t m = mw[w];
-                    while (__any(m != 0u)) {
-                        const bool acc0 = m != 0u;
-                        const int b0 = __builtin_ctz(m | 0x80000000u);
-                        m &= m - 1u;
-                        const bool acc1 = m != 0u;
-                        const int b1 = __builtin_ctz(m | 0x80000000u);
-                        m &= m - 1u;
-                        const unsigned long long q0 = __ballot(acc0), q1 = __ballot(acc1);
-                        const int n0 = __popcll(q0);
-                        if (acc0) {
-                            const int pos = qtail + __builtin_amdgcn_mbcnt_hi((unsigned)(q0 >> 32),
-                                                                              __builtin_amdgcn_mbcnt_lo((unsigned)q0, 0));
-                            ring[pos & (VOTE_RING - 1)] = (uint16_t)(lane | ((32 * w + b0) << 6));
-                        }
-                        if (acc1) {
-                            const int pos = qtail + n0 + __builtin_amdgcn_mbcnt_hi((unsigned)(q1 >> 32),
-                                                                                   __builtin_amdgcn_mbcnt_lo((unsigned)q1, 0));
-                            ring[pos & (VOTE_RING - 1)] = (uint16_t)(lane | ((32 * w + b1) << 6));
-                        }
-                        qtail += n0 + __popcll(q1);
-                        while (qtail - qhead >= 64) {  // at most two pops: <= 63 queued + <= 128 pushed
-                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                            vote_pop<TILED, TAB_LDS>(VT, F, cr, ltab, ring, qhead, lane, 64);
-                            qhead += 64;
-                        }
+                for (int step = 32; step > 0; step >>= 1) src += (__shfl(incl, src + step - 1, 64) <= q0) ? step : 0;
+                src = min(src, 63);
+                int k = q0 - (__shfl(incl, src, 64) - __shfl(cnt, src, 64));
+                for (int it = 0; it < Bn; ++it) {
+                    // all 64 lanes execute the pulls (an inactive source lane would read as 0); only `mine` deposit
+                    f3 cc, x, y;
+                    cc.x = __shfl(F.cc.x, src, 64); cc.y = __shfl(F.cc.y, src, 64); cc.z = __shfl(F.cc.z, src, 64);
+                    x.x = __shfl(F.x.x, src, 64); x.y = __shfl(F.x.y, src, 64); x.z = __shfl(F.x.z, src, 64);
+                    y.x = __shfl(F.y.x, src, 64); y.y = __shfl(F.y.y, src, 64); y.z = __shfl(F.y.z, src, 64);
+                    const float prob = VT.unit_probs ? 1.0f : __shfl(F.prob, src, 64);
+                    const uint32_t a = (uint32_t)__shfl((int)wA, src, 64), b = (uint32_t)__shfl((int)wB, src, 64);
+                    const int row = __shfl(rowS, src, 64);
+                    const int t1 = (int)((a >> 8) & 0xffu), t2 = (int)((a >> 16) & 0xffu);
+                    // (masks, not selects: the compiler turned a nested ?: into three exec-masked regions)
+                    const int rot = k + (int)(a & 0xffu) + ((int)(b & 0xffu) & -(int)(k >= t1)) + ((int)((b >> 8) & 0xffu) & -(int)(k >= t2));
+                    if (it < mine) {
+                        const float2 cs = ltab[row + rot];
+                        const f3 offset = add3(scl3(x, cs.x), scl3(y, cs.y));      // :34
+                        const f3 v = sub3(add3(cc, offset), cr);                   // numerator of :35
+                        vote_deposit<TILED>(VT, v, prob);
                     }
+                    k += 1;
+                    const bool adv = k >= (int)(a >> 24);
+                    src = adv ? (int)((b >> 16) & 0xffu) : src;
+                    k = adv ? 0 : k;
                 }
-            }
-            if (qtail != qhead) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                vote_pop<TILED, TAB_LDS>(VT, F, cr, ltab, ring, qhead, lane, qtail - qhead);
             }
         } else {
         // more than 72 rotations: the rotation loop.  Two rotations per trip: half the loop/scalar overhead and two
