@@ -73,13 +73,19 @@ def release_scope(owner):
         del _ws_cache[key]
 
 
-def workspace(nbytes, device, tag="ws"):
+def workspace(nbytes, device, tag="ws", zero=False):
     """Grow-only scratch per (device, owner, tag); owner = the enclosing workspace_scope, else the current stream (reuse on
-    one stream is stream-ordered)."""
+    one stream is stream-ordered).  zero=True: a fresh allocation starts zero-filled (the vote's workspace keeps a header
+    between calls that must start at zero, include/cppf.h: cppf_vote_workspace_init_bytes)."""
     owner = ("scope", _ws_scope) if _ws_scope is not None else torch.cuda.current_stream(device).cuda_stream
     key = (device, owner, tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        n = max(int(nbytes), 256)
+        if zero:
+            buf = torch.empty(n, dtype=torch.uint8, device=device)
+            buf[:min(n, 65536)].zero_()
+        else:
+            buf = torch.empty(n, dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf

@@ -1,6 +1,7 @@
 // Centre vote, arg-max, back-vote, compaction, orientation vote and the pose-tail reductions
 // for gfx950 (MI355X).  C ABI in include/cppf.h; reference semantics cited per kernel.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -193,10 +194,24 @@ extern "C" size_t cppf_vote_workspace_bytes_dyn(int many_tiles)
     return VOTE_WS_PART + (size_t)(many_tiles ? VOTE_WGS_MANY : VOTE_WGS_FEW) * VOTE_TILE_FLOATS * sizeof(float);
 }
 
+static bool v3_eligible(int64_t n_ppfs, int n_rots, int gx, int gy, int gz);
+static size_t v3_workspace_bytes(int64_t n_ppfs, int gx, int gy, int gz);
+static size_t v3_workspace_bytes_dyn(int many_tiles, int64_t n_ppfs);
 extern "C" size_t cppf_vote_workspace_bytes(int64_t n_ppfs, int n_rots, int gx, int gy, int gz)
 {
     if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || gx < 1 || gy < 1 || gz < 1 || n_ppfs < 0) return 0;
-    return make_vote_plan(n_ppfs, n_rots, gx, gy, gz).total;
+    const size_t legacy = make_vote_plan(n_ppfs, n_rots, gx, gy, gz).total;
+    if (!v3_eligible(n_ppfs, n_rots, gx, gy, gz)) return legacy;
+    const size_t v3 = v3_workspace_bytes(n_ppfs, gx, gy, gz);
+    return v3 > legacy ? v3 : legacy;
+}
+// the *_dyn launch with room for the pair -> tile queues of the binned path (n_ppfs pairs, every tile of the class); a
+// workspace of only cppf_vote_workspace_bytes_dyn() bytes selects the round-2 kernels
+extern "C" size_t cppf_vote_workspace_bytes_dyn_pairs(int many_tiles, int64_t n_ppfs)
+{
+    if (n_ppfs < 0) return 0;
+    const size_t legacy = cppf_vote_workspace_bytes_dyn(many_tiles), v3 = v3_workspace_bytes_dyn(many_tiles, n_ppfs);
+    return v3 > legacy ? v3 : legacy;
 }
 
 // ----------------------------------------------------------------------------- centre vote
@@ -312,7 +327,7 @@ __device__ __forceinline__ void vote_deposit(const VoteTile& T, f3 v, float prob
             lll = ll * w0z * ps; llh = ll * rz * ps; lhl = lh * w0z * ps; lhh = lh * rz * ps;
             hll = hl * w0z * ps; hlh = hl * rz * ps; hhl = hh * w0z * ps; hhh = hh * rz * ps;
         }
-        const int b = __mul24(__mul24(lx, T.ty) + ly, T.gz) + fz;   // all < 2^24
+        const int b = __mul24(lx, T.ltyz) + (__mul24(ly, T.gz) + fz);   // all |.| < 2^23: two v_mad_i32_i24
         const int dm = T.dummy;
         const int a0 = (x0in && y0in) ? b : dm, a2 = (x0in && y1in) ? b + T.gz : dm;
         const int a4 = (x1in && y0in) ? b + T.ltyz : dm, a6 = (x1in && y1in) ? b + T.ltyz + T.gz : dm;
@@ -740,12 +755,12 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
                 const unsigned long long nz = __ballot(cnt > 0);
                 const unsigned long long above = nz & ~((2ull << lane) - 1ull);   // (lane 63: 2 << 63 wraps to 0, above = 0)
                 const int nxt = above ? __builtin_ctzll(above) : 64;
-                // byte fields: wA = {run 0 start, end of run 0 in candidate order, end of run 1, count}, wB = {gap between runs 0
-                // and 1, gap between runs 1 and 2, next non-empty lane}: candidate k of the lane is rotation
+                // wA bytes = {next non-empty lane, end of run 0 in candidate order, end of run 1, count}, wB halves = {gap between
+                // runs 0 and 1, gap between runs 1 and 2} (x 8: table byte offsets): candidate k of the lane is rotation
                 // s0 + k + (k >= t1 ? g1 : 0) + (k >= t2 ? g2 : 0)
-                const uint32_t wA = (uint32_t)s0 | ((uint32_t)l0 << 8) | ((uint32_t)(l0 + l1) << 16) | ((uint32_t)cnt << 24);
-                const uint32_t wB = (uint32_t)(s1 - e0) | ((uint32_t)max(s2 - e1, 0) << 8) | ((uint32_t)nxt << 16);
-                const int rowS = __mul24(n, n - 1) >> 1;   // the pair's row of the rotation table
+                const uint32_t wA = (uint32_t)nxt | ((uint32_t)l0 << 8) | ((uint32_t)(l0 + l1) << 16) | ((uint32_t)cnt << 24);
+                const uint32_t wB = ((uint32_t)(s1 - e0) << 3) | ((uint32_t)max(s2 - e1, 0) << 19);   // gaps as table byte offsets
+                const int tabS = ((__mul24(n, n - 1) >> 1) + s0) << 3;   // byte offset of the pair's first candidate in the rotation table
                 const int Bn = (total + 63) >> 6;
                 const int q0 = __mul24(lane, Bn);
                 const int mine = min(max(total - q0, 0), Bn);
@@ -754,28 +769,44 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
                 for (int step = 32; step > 0; step >>= 1) src += (__shfl(incl, src + step - 1, 64) <= q0) ? step : 0;
                 src = min(src, 63);
                 int k = q0 - (__shfl(incl, src, 64) - __shfl(cnt, src, 64));
+                const char* ltab_b = reinterpret_cast<const char*>(ltab);
+                // A step's pulls (the source lane's frame and run words) are requested one step AHEAD, right after the walk has
+                // advanced and before the previous candidate's deposit: the LDS crossbar round trip then overlaps the deposit's
+                // arithmetic and its eight returning atomics instead of heading every step's dependency chain.
+                struct Pulled { f3 cc, x, y; float prob; uint32_t a, b; int tab; };
+                auto pull = [&](const int from) {
+                    // all 64 lanes execute the pulls (an inactive source lane would read as 0)
+                    Pulled q;
+                    q.cc.x = __shfl(F.cc.x, from, 64); q.cc.y = __shfl(F.cc.y, from, 64); q.cc.z = __shfl(F.cc.z, from, 64);
+                    q.x.x = __shfl(F.x.x, from, 64); q.x.y = __shfl(F.x.y, from, 64); q.x.z = __shfl(F.x.z, from, 64);
+                    q.y.x = __shfl(F.y.x, from, 64); q.y.y = __shfl(F.y.y, from, 64); q.y.z = __shfl(F.y.z, from, 64);
+                    q.prob = VT.unit_probs ? 1.0f : __shfl(F.prob, from, 64);
+                    q.a = (uint32_t)__shfl((int)wA, from, 64);
+                    q.b = (uint32_t)__shfl((int)wB, from, 64);
+                    q.tab = __shfl(tabS, from, 64);
+                    return q;
+                };
+                Pulled cur = pull(src);
                 for (int it = 0; it < Bn; ++it) {
-                    // all 64 lanes execute the pulls (an inactive source lane would read as 0); only `mine` deposit
-                    f3 cc, x, y;
-                    cc.x = __shfl(F.cc.x, src, 64); cc.y = __shfl(F.cc.y, src, 64); cc.z = __shfl(F.cc.z, src, 64);
-                    x.x = __shfl(F.x.x, src, 64); x.y = __shfl(F.x.y, src, 64); x.z = __shfl(F.x.z, src, 64);
-                    y.x = __shfl(F.y.x, src, 64); y.y = __shfl(F.y.y, src, 64); y.z = __shfl(F.y.z, src, 64);
-                    const float prob = VT.unit_probs ? 1.0f : __shfl(F.prob, src, 64);
-                    const uint32_t a = (uint32_t)__shfl((int)wA, src, 64), b = (uint32_t)__shfl((int)wB, src, 64);
-                    const int row = __shfl(rowS, src, 64);
+                    const uint32_t a = cur.a, b = cur.b;
                     const int t1 = (int)((a >> 8) & 0xffu), t2 = (int)((a >> 16) & 0xffu);
                     // (masks, not selects: the compiler turned a nested ?: into three exec-masked regions)
-                    const int rot = k + (int)(a & 0xffu) + ((int)(b & 0xffu) & -(int)(k >= t1)) + ((int)((b >> 8) & 0xffu) & -(int)(k >= t2));
-                    if (it < mine) {
-                        const float2 cs = ltab[row + rot];
-                        const f3 offset = add3(scl3(x, cs.x), scl3(y, cs.y));      // :34
-                        const f3 v = sub3(add3(cc, offset), cr);                   // numerator of :35
-                        vote_deposit<TILED>(VT, v, prob);
-                    }
+                    const int toff = cur.tab + (k << 3) + ((int)(b & 0xffffu) & -(int)(k >= t1)) + ((int)(b >> 16) & -(int)(k >= t2));
                     k += 1;
                     const bool adv = k >= (int)(a >> 24);
-                    src = adv ? (int)((b >> 16) & 0xffu) : src;
+                    src = adv ? (int)(a & 0xffu) : src;
                     k = adv ? 0 : k;
+                    // LDS returns in order: this step's table entry is requested first, the next step's pulls behind it
+                    const float2 cs = *reinterpret_cast<const float2*>(ltab_b + (it < mine ? toff : 0));
+                    __builtin_amdgcn_sched_barrier(0);
+                    const Pulled nx = pull(src);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (it < mine) {
+                        const f3 offset = add3(scl3(cur.x, cs.x), scl3(cur.y, cs.y));      // :34
+                        const f3 v = sub3(add3(cur.cc, offset), cr);                       // numerator of :35
+                        vote_deposit<TILED>(VT, v, cur.prob);
+                    }
+                    cur = nx;
                 }
             }
         } else {
@@ -1134,6 +1165,863 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void reduce_tiles_kernel(RedArgs R
     }
 }
 
+// ============================================================================ binned tiled vote ("v3", round 3)
+// The tiled vote for n_rots <= 72 and <= 64 tiles, rebuilt around three observations from round 2's counters (the kernel is
+// bound by VALU issue at 97 %: every stage is priced by instruction count):
+//   1. Per PAIR work -- the exact pair frame, the three arc masks -- was repeated by every (tile, chunk) workgroup that met
+//      the pair, after a culling test that every workgroup of every tile ran over every pair of its chunk (T x P tests).
+//      `v3_bin_kernel` now walks the pairs ONCE: frame, per-axis arc parameters, then the masks of only the tiles the
+//      circle's bounding box touches (the x mask of a tile column, the y mask of a tile row, one z mask), turned into index
+//      runs (mask_runs) and appended as a 12-byte record {pair, runs} to that tile's queue in HBM -- through an LDS staging
+//      area, so that a workgroup spends one global atomic per tile per flush.
+//   2. Tiles OWN candidates by their floor cell and carry a one-cell halo on their cut sides (x0 + tx, y0 + ty), so the owner
+//      deposits all eight corners: no in-tile tests, no zeroed factors, no dummy words, and a candidate next to a cut is no
+//      longer processed by two to four tiles.  The ownership test is folded into the bounds of the reference's in-grid test
+//      (floor(g) >= x0  <=>  g >= x0): it costs nothing.
+//   3. Partial tiles leave the chip as RAW 32-bit fixed point and `v3_reduce_kernel` adds them as 64-bit integers (halo
+//      rows of the neighbours included, logged 2^32 wrap-arounds added back) before ONE conversion to fp32: the grid is the
+//      exact sum of the quantised deposits whatever workgroup took whichever record -- results are bit-identical from run to
+//      run and between the by-value, *_dyn and pair-sharded forms although the queues fill in a racy order.
+// `v3_vote_kernel`, workgroup (tile t, chunk c), consumes records [c n_t / C, (c+1) n_t / C) of tile t's queue: exact frame
+// again (12 B/record of HBM traffic instead of 52), then the run walk of vote_kernel.
+#define V3_TILE_FLOATS 32768      // 128 KiB of LDS for the tile incl. its halo
+#define V3_STAGE 5120             // staged records per flush (16 B each in LDS)
+#define V3_MAGIC 0x43503356u
+#define V3_CARRY_MAX 4096
+#define V3_THREADS 1024
+struct V3Hdr {                    // workspace + VOTE_WS_PART; all zero (or left by a previous call) when a launch starts
+    unsigned int tile_count[VOTE_MAX_TILES];   // records in each tile's queue
+    unsigned int flags;           // 1: the workspace was not initialised / a capacity was exceeded -> arg-max -1, peak NaN
+    unsigned int carry_n;         // entries of carry[]
+    unsigned int magic;           // 0 (fresh, zeroed) or V3_MAGIC
+    unsigned int fmt;             // partial tiles: 0 = raw fixed point, 1 = fp32 (negative / non-finite probs)
+    float quantum;                // value of one fixed-point unit (p2 / 2^kk)
+    unsigned int done;            // ticket of the reduce blocks (the last one re-zeroes this header)
+    unsigned int pad[2];
+    unsigned int carry[V3_CARRY_MAX];          // grid cell of every 2^32 wrap-around of a partial tile
+};
+#define V3_HDR_BYTES ((sizeof(V3Hdr) + 255) / 256 * 256)
+
+struct V3Tiling { int tx, ty, ntx, nty, T, hx, hy; };   // hx / hy: the grid is cut along x / y (tiles carry a halo column / row)
+// fewest tiles, then least cut area (see vote_tiling); a tile of tx x ty owned cells occupies (tx + hx)(ty + hy) gz words
+__host__ __device__ inline V3Tiling v3_tiling(int gx, int gy, int gz)
+{
+    V3Tiling p = {0, 0, 0, 0, 1 << 30, 0, 0};
+    int64_t best_cut = 0;
+    if (gz > V3_TILE_FLOATS) return p;
+    for (int nty0 = 1; nty0 <= gy; ++nty0) {
+        const int ty = (gy + nty0 - 1) / nty0;
+        const int nty = (gy + ty - 1) / ty;
+        const int hy = nty > 1 ? 1 : 0;
+        if ((int64_t)(ty + hy) * gz > V3_TILE_FLOATS) continue;
+        const int cols = (int)(V3_TILE_FLOATS / ((int64_t)(ty + hy) * gz));   // columns of the LDS tile, halo included
+        int tx, ntx, hx;
+        if (cols >= gx) { tx = gx; ntx = 1; hx = 0; }
+        else {
+            if (cols < 2) continue;
+            ntx = (gx + cols - 2) / (cols - 1);
+            tx = (gx + ntx - 1) / ntx;
+            ntx = (gx + tx - 1) / tx;
+            hx = 1;
+        }
+        const int T = ntx * nty;
+        const int64_t cut = ((int64_t)(ntx - 1) * gy + (int64_t)(nty - 1) * gx) * gz;
+        if (T < p.T || (T == p.T && cut < best_cut)) {
+            p.T = T; p.tx = tx; p.ty = ty; p.ntx = ntx; p.nty = nty; p.hx = hx; p.hy = hy;
+            best_cut = cut;
+        }
+        if (ntx == 1) break;   // more y cuts can only add tiles
+    }
+    return p;
+}
+__host__ __device__ inline int v3_slot_words(const V3Tiling& t, int gz) { return ((t.tx + t.hx) * (t.ty + t.hy) * gz + 3) & ~3; }
+// chunks per tile: ~one workgroup per CU for a few tiles, 512 / 1024 workgroups when the votes pile up in the few tiles around
+// the peak (see vote_wgs), never more than one per 1 024 pairs
+__host__ __device__ inline int v3_chunks(int64_t n_ppfs, int T)
+{
+    int64_t c = (T < 4 ? 256 : (T <= 8 ? 512 : 1024)) / T;
+    const int64_t cmax = (n_ppfs + 1023) / 1024;
+    if (c > cmax) c = cmax;
+    return (int)(c < 1 ? 1 : c);
+}
+// record range of chunk c of a tile holding n records: boundaries at multiples of 64
+__host__ __device__ inline unsigned v3_bound(unsigned n, int c, int C)
+{
+    if (c >= C) return n;
+    const unsigned b = (unsigned)(((unsigned long long)n * (unsigned)c / (unsigned)C + 63ull) & ~63ull);
+    return b < n ? b : n;
+}
+// fixed-point bits: a workgroup deposits at most (records of its chunk) x n_rots weights <= 1; every 2^32 quanta of that is one
+// carry-log entry (VOTE_CARRY_CAP of them per workgroup)
+__host__ __device__ inline int v3_bits(unsigned chunk_records, int n_rots) { return vote_fixed_bits_of((int64_t)chunk_records + 64, n_rots); }
+
+struct V3Plan { V3Tiling t; int C, slot; size_t pool_off, part_off, total; int64_t pool_cap; };
+// pool: T queues of `cap` records (12 B) each -- every pair can visit every tile, and the HBM is there (288 GB)
+static V3Plan v3_plan(int64_t n_ppfs, const V3Tiling& t, int gz, int C, int64_t cap)
+{
+    V3Plan p;
+    p.t = t; p.C = C; p.slot = v3_slot_words(t, gz); p.pool_cap = cap;
+    p.pool_off = VOTE_WS_PART + V3_HDR_BYTES;
+    p.part_off = p.pool_off + align_up((size_t)t.T * (size_t)cap * 12, 256);
+    p.total = p.part_off + (size_t)C * t.T * p.slot * sizeof(uint32_t);
+    (void)n_ppfs;
+    return p;
+}
+
+struct V3Args {
+    const float* points;
+    const float* outputs;
+    const float* probs;
+    const void* point_idxs;
+    int idx64;
+    const float* corner;
+    float res;
+    int64_t n_ppfs, n_points;
+    int n_rots, adaptive, gx, gy, gz;
+    V3Tiling t;
+    int C;                 // chunks per tile (by-value launches)
+    int wgs;               // workgroups of the vote launch (*_dyn: chunks per tile = min(v3_chunks, wgs / T))
+    int t_cap;             // *_dyn: most tiles this launch serves
+    const int32_t* shape;  // {n_points, gx, gy, gz} in device memory, or null
+    int64_t grid_cap;
+    V3Hdr* hdr;
+    uint32_t* pool;        // [T][pool_cap][3]
+    int64_t pool_cap;
+    uint32_t* partials;    // [C][T][slot]
+    unsigned long long* packed;
+    float* grid;
+    int accumulate;
+    long long* out_idx;
+    float* out_val;
+    int tab_entries;
+};
+
+// *_dyn: the plan from the dims record, identically in all three kernels; false = the record does not fit the launch
+__device__ __forceinline__ bool v3_resolve(const V3Args& A, int& gx, int& gy, int& gz, int64_t& n_points, V3Tiling& t, int& C)
+{
+    gx = A.gx; gy = A.gy; gz = A.gz; n_points = A.n_points; t = A.t; C = A.C;
+    if (!A.shape) return true;
+    n_points = A.shape[0]; gx = A.shape[1]; gy = A.shape[2]; gz = A.shape[3];
+    if (n_points < 1 || n_points > A.n_points || gx < 1 || gy < 1 || gz < 1 || (int64_t)gx * gy * gz > A.grid_cap) return false;
+    t = v3_tiling(gx, gy, gz);
+    if (t.T > A.t_cap) return false;
+    const int c = v3_chunks(A.n_ppfs, t.T), cw = A.wgs / t.T;
+    C = c < cw ? c : cw;
+    return C >= 1;
+}
+
+__device__ __forceinline__ int2 v3_pair_idx(const V3Args& A, int64_t p)
+{
+    if (A.idx64) {
+        const longlong2 v = reinterpret_cast<const longlong2*>(A.point_idxs)[p];
+        return make_int2((int)v.x, (int)v.y);
+    }
+    return reinterpret_cast<const int2*>(A.point_idxs)[p];
+}
+
+// the part of axis_arc_mask that does not depend on the tile: amplitude, its reciprocal, phase in index units
+struct AxisArc { float c, rA, f; };
+__device__ __forceinline__ AxisArc axis_arc_prep(float c, float x, float y, float nf)
+{
+    const float A = __builtin_amdgcn_sqrtf(fmaf(x, x, y * y));
+    AxisArc a;
+    a.c = c;
+    a.rA = __builtin_amdgcn_rcpf(fmaxf(A, 1e-20f));
+    a.f = atan2_approx(y, x) * nf;
+    return a;
+}
+__device__ __forceinline__ Mask96 axis_arc_eval(const uint4* __restrict__ below, const AxisArc& a, float lo, float hi, float nf, int n)
+{
+    const float u1 = fmaf(lo - a.c, a.rA, -1e-4f);   // cos(theta - phi) >= u1
+    const float u2 = fmaf(hi - a.c, a.rA, 1e-4f);    // cos(theta - phi) <= u2
+    const bool none = !(u1 <= 1.f) || !(u2 >= -1.f);
+    const float a1 = u1 <= -1.f ? 3.14159265f : acos_approx(fminf(u1, 1.f));
+    const float a2 = u2 >= 1.f ? 0.f : acos_approx(fmaxf(u2, -1.f));
+    const float W1 = (a1 + 2e-3f) * nf, W2 = (a2 - 2e-3f) * nf;
+    const Mask96 O = arc_run(below, (int)ceilf(a.f - W1), (int)floorf(a.f + W1), n);
+    const Mask96 I = arc_run(below, (int)floorf(a.f - W2) + 1, W2 > 0.f ? (int)ceilf(a.f + W2) - 1 : -(1 << 20), n);
+    const uint32_t keep = none ? 0u : 0xffffffffu;
+    return {O.a & ~I.a & keep, O.b & ~I.b & keep, O.c & ~I.c & keep};
+}
+
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------------------- v3_bin_kernel
+// One pass over the pairs: exact frame (the same arithmetic as the consumer's, so both agree on which pairs are alive and on
+// their rotation counts), per-axis arc parameters, z mask; then for every tile of the circle's bounding box the x / y masks
+// of its column / row, AND, runs, and a record into the tile's queue.  Rounds of 1 024 pairs per workgroup; records are staged
+// in LDS (slot within the tile's share of the flush from an LDS atomic) and flushed with one global atomic per tile.
+__global__ __launch_bounds__(V3_THREADS) void v3_bin_kernel(V3Args A)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
+    uint4* stage = reinterpret_cast<uint4*>(lds_u);                          // [V3_STAGE] {pair, runs a, runs b | tile << 24, slot}
+    uint4* below = reinterpret_cast<uint4*>(stage + V3_STAGE);               // [VOTE_BELOW_N]
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(below + VOTE_BELOW_N);       // [64] records of each tile in this flush
+    uint32_t* gbase = cnt + VOTE_MAX_TILES;                                   // [64] their place in the tile's queue
+    uint32_t* ctl = gbase + VOTE_MAX_TILES;                                   // [0] staged, [1] again
+    const int tid = threadIdx.x;
+    int gx, gy, gz, C;
+    int64_t n_points;
+    V3Tiling t;
+    if (!v3_resolve(A, gx, gy, gz, n_points, t, C)) return;   // (the reduce kernel reports it)
+    if (blockIdx.x == 0 && tid < 2 + 2 * 8) A.packed[tid] = 0ull;   // arg-max keys + tickets of the reduce kernel
+    {
+        const unsigned m = A.hdr->magic;
+        if (m != 0u && m != V3_MAGIC) { if (tid == 0) atomicOr(&A.hdr->flags, 1u); return; }
+    }
+    if (tid < VOTE_BELOW_N) {
+        const int j = tid;
+        auto w = [](int c) { return c <= 0 ? 0u : (c >= 32 ? 0xffffffffu : ((1u << c) - 1u)); };
+        below[j] = make_uint4(w(j), w(j - 32), w(j - 64), 0u);
+    }
+    const f3 cr = {A.corner[0], A.corner[1], A.corner[2]};
+    const float res = A.res, rinv = 1.0f / res;
+    const float ptxf = (float)t.tx, ptyf = (float)t.ty;
+    const float rtx = 1.0f / ptxf, rty = 1.0f / ptyf;
+    const int64_t rounds = (A.n_ppfs + V3_THREADS - 1) / V3_THREADS;
+    for (int64_t r = blockIdx.x; r < rounds; r += gridDim.x) {
+        const int64_t p = r * V3_THREADS + tid;
+        // ---- per pair
+        f3 Fcc = {0.f, 0.f, 0.f}, Fx = Fcc, Fy = Fcc;
+        int n = 0;
+        if (p < A.n_ppfs) {
+            const float2 o = reinterpret_cast<const float2*>(A.outputs)[p];
+            const int2 ij = v3_pair_idx(A, p);
+            f3 a, ab, xd;
+            if (pair_frame(A.points, ij.x, ij.y, a, ab, xd)) {
+                Fcc = sub3(a, scl3(ab, o.x));                      // :23
+                Fx = scl3(xd, o.y);                                // :28
+                Fy = cross3(Fx, ab);                               // :29
+                n = A.n_rots;
+                if (A.adaptive) n = min((int)((double)(o.y / res) * (2 * CPPF_PI)), A.n_rots);   // :31
+                n = max(n, 0);
+            }
+        }
+        const f3 cq = scl3(sub3(Fcc, cr), rinv), xq = scl3(Fx, rinv), yq = scl3(Fy, rinv);
+        const float ex = fmaf((fabsf(Fcc.x) + fabsf(cr.x) + fabsf(Fx.x) + fabsf(Fy.x)) * rinv, 1e-6f, 1e-3f);
+        const float ey = fmaf((fabsf(Fcc.y) + fabsf(cr.y) + fabsf(Fx.y) + fabsf(Fy.y)) * rinv, 1e-6f, 1e-3f);
+        const float ez = fmaf((fabsf(Fcc.z) + fabsf(cr.z) + fabsf(Fx.z) + fabsf(Fy.z)) * rinv, 1e-6f, 1e-3f);
+        const float nf = (float)n * 0.159154943f;
+        const AxisArc ax = axis_arc_prep(cq.x, xq.x, yq.x, nf), ay = axis_arc_prep(cq.y, xq.y, yq.y, nf),
+                      az = axis_arc_prep(cq.z, xq.z, yq.z, nf);
+        const Mask96 mz = axis_arc_eval(below, az, 0.01f - ez, (float)gz - 1.01f + ez, nf, n);
+        // tiles the circle's bounding box touches: coordinate range [c - A, c + A] (+ slack) against owned ranges [x0, x0 + tx)
+        const float Ax = __builtin_amdgcn_sqrtf(fmaf(xq.x, xq.x, yq.x * yq.x)) * 1.0001f + ex + 2e-3f;
+        const float Ay = __builtin_amdgcn_sqrtf(fmaf(xq.y, xq.y, yq.y * yq.y)) * 1.0001f + ey + 2e-3f;
+        const float xlo = fmaxf(cq.x - Ax, 0.f), xhi = fminf(cq.x + Ax, (float)gx - 1.f);
+        const float ylo = fmaxf(cq.y - Ay, 0.f), yhi = fminf(cq.y + Ay, (float)gy - 1.f);
+        const bool alive = n > 0 && (mz.a | mz.b | mz.c) != 0u && xlo <= xhi && ylo <= yhi;   // (NaN coordinates: not alive)
+        int ix0 = 0, ix1 = -1, iy0 = 0, iy1 = -1;
+        if (alive) {
+            // (a float quotient may land one tile off at a boundary: one extra tile either side costs an empty mask, never a vote)
+            ix0 = max((int)(xlo * rtx) - 1, 0); ix1 = min((int)(xhi * rtx) + 1, t.ntx - 1);
+            iy0 = max((int)(ylo * rty) - 1, 0); iy1 = min((int)(yhi * rty) + 1, t.nty - 1);
+            // trim: a column / row the box does not reach
+            ix0 += ((float)((ix0 + 1) * t.tx) <= xlo) ? 1 : 0;
+            ix1 -= ((float)(ix1 * t.tx) > xhi) ? 1 : 0;
+            iy0 += ((float)((iy0 + 1) * t.ty) <= ylo) ? 1 : 0;
+            iy1 -= ((float)(iy1 * t.ty) > yhi) ? 1 : 0;
+        }
+        const int nxw = wave_max_i32(ix1 - ix0 + 1), nyw = wave_max_i32(iy1 - iy0 + 1);   // this wave's loop bounds
+        int resume = 0;   // first (dx, dy) step of this lane that has not been staged yet
+        for (;;) {
+            __syncthreads();   // (previous flush done; first trip: the tables above are complete)
+            if (tid < VOTE_MAX_TILES) cnt[tid] = 0u;
+            if (tid == 0) { ctl[0] = 0u; ctl[1] = 0u; }
+            __syncthreads();
+            bool stuck = false;
+            int step = 0;
+            for (int dx = 0; dx < nxw; ++dx) {
+                const int ix = ix0 + dx;
+                const bool xin = ix <= ix1;
+                Mask96 mx = {0u, 0u, 0u};
+                if (xin) {
+                    const float x0f = (float)(ix * t.tx);
+                    mx = axis_arc_eval(below, ax, fmaxf(0.01f, x0f) - ex, fminf((float)gx - 1.01f, x0f + ptxf) + ex, nf, n);
+                    mx.a &= mz.a; mx.b &= mz.b; mx.c &= mz.c;
+                }
+                for (int dy = 0; dy < nyw; ++dy, ++step) {
+                    const int iy = iy0 + dy;
+                    if (!(xin && iy <= iy1) || step < resume || stuck) continue;
+                    const float y0f = (float)(iy * t.ty);
+                    const Mask96 my = axis_arc_eval(below, ay, fmaxf(0.01f, y0f) - ey, fminf((float)gy - 1.01f, y0f + ptyf) + ey, nf, n);
+                    const uint32_t m0 = mx.a & my.a, m1 = mx.b & my.b, m2 = mx.c & my.c;
+                    if ((m0 | m1 | m2) == 0u) continue;
+                    int s0, e0, s1, e1, s2, e2;
+                    mask_runs(below, m0, m1, m2, s0, e0, s1, e1, s2, e2);
+                    const int l2 = max(e2 - s2, 0);
+                    const uint32_t fi = atomicAdd(&ctl[0], 1u);
+                    if (fi >= V3_STAGE) { stuck = true; resume = step; ctl[1] = 1u; continue; }
+                    const int tile = ix * t.nty + iy;
+                    const uint32_t slot = atomicAdd(&cnt[tile], 1u);
+                    const uint32_t ra = (uint32_t)s0 | ((uint32_t)(e0 - s0) << 8) | ((uint32_t)s1 << 16) | ((uint32_t)(e1 - s1) << 24);
+                    const uint32_t rb = (uint32_t)s2 | ((uint32_t)l2 << 8) | ((uint32_t)tile << 24);
+                    stage[fi] = make_uint4((uint32_t)p, ra, rb, slot);
+                }
+            }
+            if (!stuck) resume = 1 << 30;
+            __syncthreads();
+            const uint32_t staged = min(ctl[0], (uint32_t)V3_STAGE);
+            const bool again = ctl[1] != 0u;
+            if (tid < t.T && cnt[tid] != 0u) {
+                // (a failed stage attempt bumped ctl[0] but not cnt[]: cnt[] counts exactly the staged records)
+                const uint32_t b = atomicAdd(&A.hdr->tile_count[tid], cnt[tid]);
+                gbase[tid] = b;
+                if ((int64_t)b + cnt[tid] > A.pool_cap) atomicOr(&A.hdr->flags, 1u);
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < staged; i += V3_THREADS) {
+                const uint4 rec = stage[i];
+                const uint32_t tile = rec.z >> 24;
+                const int64_t pos = (int64_t)gbase[tile] + rec.w;
+                if (pos < A.pool_cap) {
+                    uint32_t* dst = A.pool + ((int64_t)tile * A.pool_cap + pos) * 3;
+                    dst[0] = rec.x; dst[1] = rec.y; dst[2] = rec.z & 0xffffffu;
+                }
+            }
+            if (!again) break;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------- v3_vote_kernel
+struct V3Tile {
+    uint32_t* tile;        // LDS tile, (tx + hx) x (ty + hy) x gz words
+    uint32_t* carry_log;
+    int* carry_n;
+    int x0, y0, gz, ltyz;  // ltyz: words per x column of the LDS tile
+    float res, rres, S;    // S > 0: fixed-point scale; S == 0: fp32 atomics
+    int unit_probs;
+    float lox, hix, loy, hiy, loz, hiz;   // the reference's in-grid bounds intersected with the cells this tile owns
+};
+
+// models/voting.py:35-63 for one sample whose floor cell this tile owns: every corner lies in the LDS tile (halo included)
+__device__ __forceinline__ void v3_deposit(const V3Tile& T, f3 v, float prob)
+{
+    const f3 g = {div_by(v.x, T.res, T.rres), div_by(v.y, T.res, T.rres), div_by(v.z, T.res, T.rres)};   // :35
+    // :36-39 (fp64 tests folded to fp32 thresholds) and the ownership of the floor cell (floor(g) >= x0 <=> g >= x0) in one test
+    if (!(g.x >= T.lox && g.x < T.hix && g.y >= T.loy && g.y < T.hiy && g.z >= T.loz && g.z < T.hiz)) return;
+    const int fx = (int)g.x, fy = (int)g.y, fz = (int)g.z;         // :40
+    const float rx = __builtin_amdgcn_fractf(g.x), ry = __builtin_amdgcn_fractf(g.y), rz = __builtin_amdgcn_fractf(g.z);
+    const float w0x = 1.f - rx, w0y = 1.f - ry, w0z = 1.f - rz;
+    const float ll = w0x * w0y, lh = w0x * ry, hl = rx * w0y, hh = rx * ry;
+    const int b = __mul24(fx - T.x0, T.ltyz) + (__mul24(fy - T.y0, T.gz) + fz);
+    if (T.S > 0.f) {
+        // fixed point: inc = rn(weight * S), S a power of two riding on the last factor (see vote_deposit)
+        float lll, llh, lhl, lhh, hll, hlh, hhl, hhh;
+        if (T.unit_probs) {
+            const float z0 = w0z * T.S, z1 = rz * T.S;
+            lll = ll * z0; llh = ll * z1; lhl = lh * z0; lhh = lh * z1;
+            hll = hl * z0; hlh = hl * z1; hhl = hh * z0; hhh = hh * z1;
+        } else {
+            const float ps = prob * T.S;
+            lll = ll * w0z * ps; llh = ll * rz * ps; lhl = lh * w0z * ps; lhh = lh * rz * ps;
+            hll = hl * w0z * ps; hlh = hl * rz * ps; hhl = hh * w0z * ps; hhh = hh * rz * ps;
+        }
+        uint32_t* t0 = T.tile + b;
+        uint32_t* t2 = t0 + T.gz;
+        uint32_t* t4 = t0 + T.ltyz;
+        uint32_t* t6 = t4 + T.gz;
+        const uint32_t i0 = rpi_u32(lll), i1 = rpi_u32(llh), i2 = rpi_u32(lhl), i3 = rpi_u32(lhh);
+        const uint32_t i4 = rpi_u32(hll), i5 = rpi_u32(hlh), i6 = rpi_u32(hhl), i7 = rpi_u32(hhh);
+        const uint32_t o0 = atomicAdd(t0, i0), o1 = atomicAdd(t0 + 1, i1), o2 = atomicAdd(t2, i2), o3 = atomicAdd(t2 + 1, i3),
+                       o4 = atomicAdd(t4, i4), o5 = atomicAdd(t4 + 1, i5), o6 = atomicAdd(t6, i6), o7 = atomicAdd(t6 + 1, i7);
+        const uint32_t om = max(max(max(o0, o1), max(o2, o3)), max(max(o4, o5), max(o6, o7)));
+        if (om >= 0xfe000000u) {   // a wrap needs old >= 2^32 - inc with inc <= 2^24
+            auto wrapped = [&](uint32_t o, uint32_t inc, int a) {
+                if (o + inc < o) {
+                    const int slot = atomicAdd(T.carry_n, 1);
+                    if (slot < VOTE_CARRY_CAP) T.carry_log[slot] = (uint32_t)a;
+                }
+            };
+            wrapped(o0, i0, b); wrapped(o1, i1, b + 1); wrapped(o2, i2, b + T.gz); wrapped(o3, i3, b + T.gz + 1);
+            wrapped(o4, i4, b + T.ltyz); wrapped(o5, i5, b + T.ltyz + 1); wrapped(o6, i6, b + T.ltyz + T.gz);
+            wrapped(o7, i7, b + T.ltyz + T.gz + 1);
+        }
+        return;
+    }
+    float* t = reinterpret_cast<float*>(T.tile) + b;
+    atomicAdd(t, ll * w0z * prob); atomicAdd(t + 1, ll * rz * prob);
+    atomicAdd(t + T.gz, lh * w0z * prob); atomicAdd(t + T.gz + 1, lh * rz * prob);
+    atomicAdd(t + T.ltyz, hl * w0z * prob); atomicAdd(t + T.ltyz + 1, hl * rz * prob);
+    atomicAdd(t + T.ltyz + T.gz, hh * w0z * prob); atomicAdd(t + T.ltyz + T.gz + 1, hh * rz * prob);
+}
+
+#define V3_LDS_HEAD (VOTE_CARRY_CAP * 4 + 64 + VOTE_BELOW_N * 16)
+__global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // LDS: [carry log 8 KiB][ctrl 64 B][arc-mask table 97 x 16 B][rotation table (+2 spare)][tile incl. halo]
+    uint32_t* carry_log = reinterpret_cast<uint32_t*>(lds);
+    int* ctrl = reinterpret_cast<int*>(carry_log + VOTE_CARRY_CAP);   // [0] carry count, [4] next batch of 64 records, [8..] probs summary
+    uint4* below = reinterpret_cast<uint4*>(ctrl + 16);
+    float2* ltab = reinterpret_cast<float2*>(below + VOTE_BELOW_N);
+    uint32_t* tile = reinterpret_cast<uint32_t*>(ltab + A.tab_entries + 2);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int gx, gy, gz, C;
+    int64_t n_points;
+    V3Tiling pt;
+    if (!v3_resolve(A, gx, gy, gz, n_points, pt, C)) return;
+    if (A.hdr->flags & 1u) return;
+    // workgroup b takes chunk c = b / T of tile (b + c) mod T (not b mod T: workgroups go to XCD b mod 8 in launch order, see vote_kernel)
+    const int c = blockIdx.x / pt.T;
+    if (c >= C) return;
+    const int t = (blockIdx.x + c) % pt.T;
+    const int tix = t / pt.nty, tiy = t - tix * pt.nty;
+    const int x0 = tix * pt.tx, y0 = tiy * pt.ty;
+    const int tx = min(pt.tx, gx - x0), ty = min(pt.ty, gy - y0);
+    const int tyh = pt.ty + pt.hy;                 // LDS rows per column: uniform over the tiles (the slot layout of the partials)
+    const int ltyz = tyh * gz;
+    const int nwords = (tx + pt.hx) * ltyz;
+    const unsigned n_t = min(A.hdr->tile_count[t], (unsigned)A.pool_cap);
+    const unsigned r0 = v3_bound(n_t, c, C), r1 = v3_bound(n_t, c + 1, C);
+    if (r0 >= r1 && blockIdx.x != 0) return;   // nothing queued for this chunk: no tile to zero or dump (the reduce kernel skips it too)
+    // chunk size that fixes the fixed-point bits: the largest chunk of the launch (every workgroup must use the same scale)
+    unsigned n_max = 0;
+    for (int k = 0; k < pt.T; ++k) n_max = max(n_max, min(A.hdr->tile_count[k], (unsigned)A.pool_cap));
+    const int kk = v3_bits((n_max + C - 1) / C, A.n_rots);
+
+    // prologue (as vote_kernel): probs scan and rotation table loads first, tile zeroed meanwhile, one barrier
+    float pm = A.probs ? 0.f : 1.f;
+    int bad = 0, nonunit = 0;
+    if (A.probs) {
+        for (int64_t k0 = tid; k0 < n_points; k0 += 4 * V3_THREADS) {
+            float pv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pv[u] = k0 + u * V3_THREADS < n_points ? A.probs[k0 + u * V3_THREADS] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool there = k0 + u * V3_THREADS < n_points;
+                bad |= !(pv[u] >= 0.f) || !(pv[u] < INFINITY);
+                nonunit |= there && pv[u] != 1.0f;
+                pm = fmaxf(pm, pv[u]);
+            }
+        }
+    }
+    float2* wtab = reinterpret_cast<float2*>(reinterpret_cast<char*>(A.packed) + VOTE_WS_TAB);
+    const bool tab_cached = A.packed[31] == (VOTE_TAB_STAMP ^ (unsigned long long)A.n_rots) && rot_table_intact(wtab, A.n_rots);
+    float2 tab_in[(VOTE_TAB_LDS_MAX + V3_THREADS - 1) / V3_THREADS];
+    if (tab_cached) {
+#pragma unroll
+        for (int u = 0; u < (VOTE_TAB_LDS_MAX + V3_THREADS - 1) / V3_THREADS; ++u)
+            if (tid + u * V3_THREADS < A.tab_entries) tab_in[u] = wtab[tid + u * V3_THREADS];
+    }
+    if (tid < 16) ctrl[tid] = 0;
+    for (int k = tid; k < (nwords + 3) >> 2; k += V3_THREADS) reinterpret_cast<uint4*>(tile)[k] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < VOTE_BELOW_N) {
+        const int j = tid;
+        auto w = [](int c_) { return c_ <= 0 ? 0u : (c_ >= 32 ? 0xffffffffu : ((1u << c_) - 1u)); };
+        below[j] = make_uint4(w(j), w(j - 32), w(j - 64), 0u);
+    }
+    if (tab_cached) {
+#pragma unroll
+        for (int u = 0; u < (VOTE_TAB_LDS_MAX + V3_THREADS - 1) / V3_THREADS; ++u)
+            if (tid + u * V3_THREADS < A.tab_entries) ltab[tid + u * V3_THREADS] = tab_in[u];
+    } else {
+        fill_rot_table(ltab, A.tab_entries, tid, V3_THREADS);
+        if (blockIdx.x == 0) {   // leave a copy for the next launch (visible to it: kernel boundary)
+            __syncthreads();
+            for (int e = tid; e < A.tab_entries; e += V3_THREADS) wtab[e] = ltab[e];
+            if (tid == 0) A.packed[31] = VOTE_TAB_PENDING ^ (unsigned long long)A.n_rots;
+        }
+    }
+    if (tid < 2) ltab[A.tab_entries + tid] = make_float2(0.f, 0.f);
+    // the waves' summaries of the probs go to the (still unused) carry log: two words per wave
+    for (int off = 32; off > 0; off >>= 1) pm = fmaxf(pm, __shfl_xor(pm, off, 64));
+    {
+        const int flags = (__any(bad) ? 1 : 0) | (__any(nonunit) ? 2 : 0);
+        if (lane == 0) { reinterpret_cast<float*>(carry_log)[2 * wave] = pm; carry_log[2 * wave + 1] = (uint32_t)flags; }
+    }
+    __syncthreads();
+    float S = 0.f;
+    int unit_probs = 0;
+    {
+        float pmax = 0.f;
+        int flags = 0;
+        for (int w = 0; w < V3_THREADS / 64; ++w) {
+            pmax = fmaxf(pmax, reinterpret_cast<const float*>(carry_log)[2 * w]);
+            flags |= (int)carry_log[2 * w + 1];
+        }
+        unit_probs = !(flags & 2);
+        if (!(flags & 1)) {
+            int e = 127;
+            if (pmax > 0.f) {
+                const unsigned bits = __float_as_uint(pmax);
+                e = (int)(bits >> 23) + ((bits & 0x7fffffu) ? 1 : 0);
+                if (e < 1) e = 1;
+            }
+            const int se = 127 + kk - (e - 127);
+            S = (se >= 1 && se <= 254) ? __uint_as_float((unsigned)se << 23) : 0.f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __syncthreads();   // (the summaries live in the carry log: nobody logs a wrap before everybody has read them)
+    }
+    if (blockIdx.x == 0 && tid == 0) {   // what the partial tiles hold, for the reduce kernel
+        A.hdr->fmt = S > 0.f ? 0u : 1u;
+        A.hdr->quantum = S > 0.f ? 1.0f / S : 0.f;
+    }
+
+    const f3 cr = {A.corner[0], A.corner[1], A.corner[2]};
+    const float res = A.res;
+    V3Tile VT;
+    VT.tile = tile; VT.carry_log = carry_log; VT.carry_n = ctrl;
+    VT.x0 = x0; VT.y0 = y0; VT.gz = gz; VT.ltyz = ltyz; VT.res = res; VT.rres = refined_rcp(res); VT.S = S;
+    VT.unit_probs = unit_probs;
+    // (double)g < 0.01 <=> g < ceil_to_float(0.01); integers are exact in fp32: max / min with the owned range is exact
+    VT.lox = fmaxf(ceil_to_float(0.01), (float)x0); VT.hix = fminf(ceil_to_float((double)gx - 1.01), (float)(x0 + tx));
+    VT.loy = fmaxf(ceil_to_float(0.01), (float)y0); VT.hiy = fminf(ceil_to_float((double)gy - 1.01), (float)(y0 + ty));
+    VT.loz = ceil_to_float(0.01); VT.hiz = ceil_to_float((double)gz - 1.01);
+    const uint32_t* queue = A.pool + (int64_t)t * A.pool_cap * 3;
+    const char* ltab_b = reinterpret_cast<const char*>(ltab);
+
+    for (;;) {
+        int blk = 0;
+        if (lane == 0) blk = atomicAdd(&ctrl[4], 1);
+        const unsigned rb0 = r0 + 64u * (unsigned)__builtin_amdgcn_readfirstlane(blk);
+        if (rb0 >= r1) break;
+        const unsigned rq = rb0 + lane;
+        // ---- one record per lane: exact frame again, runs from the record
+        f3 Fcc = {0.f, 0.f, 0.f}, Fx = Fcc, Fy = Fcc;
+        float Fprob = 1.f;
+        int n = 0;
+        uint32_t ra = 0u, rb = 0u;
+        if (rq < r1) {
+            const uint32_t* rec = queue + (int64_t)rq * 3;
+            const uint32_t p = rec[0];
+            ra = rec[1]; rb = rec[2];
+            const float2 o = reinterpret_cast<const float2*>(A.outputs)[p];
+            const int2 ij = v3_pair_idx(A, p);
+            f3 a, ab, xd;
+            if (pair_frame(A.points, ij.x, ij.y, a, ab, xd)) {
+                Fcc = sub3(a, scl3(ab, o.x));
+                Fprob = A.probs ? fmaxf(A.probs[ij.x], A.probs[ij.y]) : 1.f;
+                Fx = scl3(xd, o.y);
+                Fy = cross3(Fx, ab);
+                n = A.n_rots;
+                if (A.adaptive) n = min((int)((double)(o.y / res) * (2 * CPPF_PI)), A.n_rots);
+                n = max(n, 0);
+            }
+        }
+        const int s0 = (int)(ra & 0xffu), l0 = (int)((ra >> 8) & 0xffu), s1 = (int)((ra >> 16) & 0xffu), l1 = (int)(ra >> 24);
+        const int s2 = (int)(rb & 0xffu), l2 = (int)((rb >> 8) & 0xffu);
+        const int cnt = n > 0 ? l0 + l1 + l2 : 0;
+        const int incl = wave_incl_scan(cnt);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        if (total > 0) {
+            const unsigned long long nz = __ballot(cnt > 0);
+            const unsigned long long above = nz & ~((2ull << lane) - 1ull);
+            const int nxt = above ? __builtin_ctzll(above) : 64;
+            const uint32_t wA = (uint32_t)nxt | ((uint32_t)l0 << 8) | ((uint32_t)(l0 + l1) << 16) | ((uint32_t)cnt << 24);
+            const uint32_t wB = ((uint32_t)max(s1 - s0 - l0, 0) << 3) | ((uint32_t)max(s2 - s1 - l1, 0) << 19);
+            const int tabS = ((__mul24(n, n - 1) >> 1) + s0) << 3;
+            const int Bn = (total + 63) >> 6;
+            const int q0 = __mul24(lane, Bn);
+            const int mine = min(max(total - q0, 0), Bn);
+            int src = 0;
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1) src += (__shfl(incl, src + step - 1, 64) <= q0) ? step : 0;
+            src = min(src, 63);
+            int k = q0 - (__shfl(incl, src, 64) - __shfl(cnt, src, 64));
+            struct Pulled { f3 cc, x, y; float prob; uint32_t a, b; int tab; };
+            auto pull = [&](const int from) {
+                Pulled q;
+                q.cc.x = __shfl(Fcc.x, from, 64); q.cc.y = __shfl(Fcc.y, from, 64); q.cc.z = __shfl(Fcc.z, from, 64);
+                q.x.x = __shfl(Fx.x, from, 64); q.x.y = __shfl(Fx.y, from, 64); q.x.z = __shfl(Fx.z, from, 64);
+                q.y.x = __shfl(Fy.x, from, 64); q.y.y = __shfl(Fy.y, from, 64); q.y.z = __shfl(Fy.z, from, 64);
+                q.prob = unit_probs ? 1.0f : __shfl(Fprob, from, 64);
+                q.a = (uint32_t)__shfl((int)wA, from, 64);
+                q.b = (uint32_t)__shfl((int)wB, from, 64);
+                q.tab = __shfl(tabS, from, 64);
+                return q;
+            };
+            Pulled cur = pull(src);
+            for (int it = 0; it < Bn; ++it) {
+                const uint32_t a = cur.a, b = cur.b;
+                const int t1 = (int)((a >> 8) & 0xffu), t2 = (int)((a >> 16) & 0xffu);
+                const int toff = cur.tab + (k << 3) + ((int)(b & 0xffffu) & -(int)(k >= t1)) + ((int)(b >> 16) & -(int)(k >= t2));
+                k += 1;
+                const bool adv = k >= (int)(a >> 24);
+                src = adv ? (int)(a & 0xffu) : src;
+                k = adv ? 0 : k;
+                const float2 cs = *reinterpret_cast<const float2*>(ltab_b + (it < mine ? toff : 0));
+                __builtin_amdgcn_sched_barrier(0);
+                const Pulled nx = pull(src);
+                __builtin_amdgcn_sched_barrier(0);
+                if (it < mine) {
+                    const f3 offset = add3(scl3(cur.x, cs.x), scl3(cur.y, cs.y));      // :34
+                    const f3 v = sub3(add3(cur.cc, offset), cr);                       // numerator of :35
+                    v3_deposit(VT, v, cur.prob);
+                }
+                cur = nx;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+
+    // ---- dump: raw fixed point (the reduce kernel adds the partial tiles as integers), wrap-arounds to the global carry list
+    __syncthreads();
+    const int slot = v3_slot_words(pt, gz);
+    uint4* part4 = reinterpret_cast<uint4*>(A.partials + ((int64_t)c * pt.T + t) * slot);
+    const uint4* t4 = reinterpret_cast<const uint4*>(tile);
+    for (int k = tid; k < (nwords + 3) >> 2; k += V3_THREADS) part4[k] = t4[k];
+    if (S > 0.f) {
+        const int nc = min(ctrl[0], VOTE_CARRY_CAP);
+        if (ctrl[0] > VOTE_CARRY_CAP && tid == 0) atomicOr(&A.hdr->flags, 1u);
+        for (int k = tid; k < nc; k += V3_THREADS) {
+            const int w = (int)carry_log[k];   // word of the LDS tile -> grid cell
+            const int lx = w / ltyz, rem = w - lx * ltyz, ly = rem / gz, z = rem - ly * gz;
+            const unsigned cell = (unsigned)(((int64_t)(x0 + lx) * gy + (y0 + ly)) * gz + z);
+            const unsigned at = atomicAdd(&A.hdr->carry_n, 1u);
+            if (at < V3_CARRY_MAX) A.hdr->carry[at] = cell; else atomicOr(&A.hdr->flags, 1u);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------- v3_reduce_kernel
+// grid[cell] (+)= the exact sum of every partial tile's quanta for that cell -- the owner tile's word and the halo words of
+// its x / y / diagonal neighbours, over all chunks, plus 2^32 per logged wrap-around -- converted to fp32 ONCE; arg-max as in
+// reduce_tiles_kernel.  A block = 16 waves = one run of 256 words of one tile's slot (LDS order); wave g adds chunks g, g + 16, ...
+// The block that draws the last ticket re-zeroes the queue header for the next launch on this workspace.
+__device__ __forceinline__ bool v3_chunk_live(unsigned n_t, int t, int c, int C)
+{
+    return (t == 0 && c == 0) || v3_bound(n_t, c, C) < v3_bound(n_t, c + 1, C);   // (tile 0 / chunk 0 = workgroup 0: always dumps)
+}
+__device__ __forceinline__ void v3_rezero(V3Hdr* h)
+{
+    for (int k = 0; k < VOTE_MAX_TILES; ++k) h->tile_count[k] = 0u;
+    h->flags = 0u; h->carry_n = 0u; h->done = 0u; h->magic = V3_MAGIC;
+    __threadfence();
+}
+__global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, int bps)
+{
+    __shared__ unsigned long long part[RED_GROUPS][RED_CELLS];
+    __shared__ unsigned long long wkey[RED_CELLS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, cg = tid >> 6;
+    if (blockIdx.x == 0 && tid == 0) {   // rotation table left by the vote kernel of this call: valid from the next launch on
+        const unsigned long long st = A.packed[31];
+        if ((st & ~0xfffull) == VOTE_TAB_PENDING) A.packed[31] = st ^ (VOTE_TAB_PENDING ^ VOTE_TAB_STAMP);
+    }
+    int gx, gy, gz, C;
+    int64_t n_points;
+    V3Tiling pt;
+    const bool fits = v3_resolve(A, gx, gy, gz, n_points, pt, C);
+    if (!fits || (A.hdr->flags & 1u)) {   // nothing valid was voted: say so (index -1, NaN) and leave a clean header
+        if (tid == 0) {
+            const unsigned tk = atomicAdd(&A.hdr->done, 1u);
+            if (tk == gridDim.x - 1) {
+                if (A.out_idx) *A.out_idx = -1;
+                if (A.out_val) *A.out_val = __uint_as_float(0x7fc00000u);
+                v3_rezero(A.hdr);
+            }
+        }
+        return;
+    }
+    const int T = pt.T;
+    const int slot = v3_slot_words(pt, gz);
+    const int t = blockIdx.x / bps, j = blockIdx.x - t * bps;
+    if (t >= T) return;
+    const int tix = t / pt.nty, tiy = t - tix * pt.nty;
+    const int x0 = tix * pt.tx, y0 = tiy * pt.ty;
+    const int tx = min(pt.tx, gx - x0), ty = min(pt.ty, gy - y0);
+    const int tyh = pt.ty + pt.hy, ltyz = tyh * gz;
+    const int nwords = (tx + pt.hx) * ltyz;
+    if (j * RED_CELLS >= nwords) return;
+    const bool raw = A.hdr->fmt == 0u;
+    const unsigned n_own = min(A.hdr->tile_count[t], (unsigned)A.pool_cap);
+    const unsigned n_nx = tix > 0 ? min(A.hdr->tile_count[t - pt.nty], (unsigned)A.pool_cap) : 0u;
+    const unsigned n_ny = tiy > 0 ? min(A.hdr->tile_count[t - 1], (unsigned)A.pool_cap) : 0u;
+    const unsigned n_nxy = (tix > 0 && tiy > 0) ? min(A.hdr->tile_count[t - pt.nty - 1], (unsigned)A.pool_cap) : 0u;
+    // the lane's four words of the slot: owned cells gather their neighbours' halo words (nb* = word in that tile's slot, -1: none)
+    const int k0 = j * RED_CELLS + lane * 4;
+    int nbx[4], nby[4], nbxy[4];
+    bool any_nb = false;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u;
+        const int lx = k / ltyz, rem = k - lx * ltyz, ly = rem / gz, z = rem - ly * gz;
+        const bool owned = k < nwords && lx < tx && ly < ty;
+        nbx[u] = (owned && lx == 0 && tix > 0) ? pt.tx * ltyz + ly * gz + z : -1;
+        nby[u] = (owned && ly == 0 && tiy > 0) ? lx * ltyz + pt.ty * gz + z : -1;
+        nbxy[u] = (owned && lx == 0 && ly == 0 && tix > 0 && tiy > 0) ? pt.tx * ltyz + pt.ty * gz + z : -1;
+        any_nb |= nbx[u] >= 0 || nby[u] >= 0;
+    }
+    unsigned long long acc[4] = {0ull, 0ull, 0ull, 0ull};
+    float facc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int64_t cstride = (int64_t)T * slot;
+    if (k0 < nwords) {   // (k0 + 3 < slot: both are multiples of 4)
+        const uint32_t* base = A.partials + (int64_t)t * slot + k0;
+        for (int c = cg; c < C; c += RED_GROUPS) {
+            if (!v3_chunk_live(n_own, t, c, C)) continue;
+            const uint4 v = *reinterpret_cast<const uint4*>(base + (int64_t)c * cstride);
+            if (raw) { acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w; }
+            else { facc[0] += __uint_as_float(v.x); facc[1] += __uint_as_float(v.y); facc[2] += __uint_as_float(v.z); facc[3] += __uint_as_float(v.w); }
+        }
+    }
+    if (__any(any_nb)) {
+        for (int c = cg; c < C; c += RED_GROUPS) {
+            const int64_t cb = (int64_t)c * cstride;
+            const bool lx_ = tix > 0 && v3_chunk_live(n_nx, t - pt.nty, c, C), ly_ = tiy > 0 && v3_chunk_live(n_ny, t - 1, c, C),
+                       lxy_ = tix > 0 && tiy > 0 && v3_chunk_live(n_nxy, t - pt.nty - 1, c, C);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                uint32_t a = 0u, b = 0u, d = 0u;
+                if (lx_ && nbx[u] >= 0) a = A.partials[cb + (int64_t)(t - pt.nty) * slot + nbx[u]];
+                if (ly_ && nby[u] >= 0) b = A.partials[cb + (int64_t)(t - 1) * slot + nby[u]];
+                if (lxy_ && nbxy[u] >= 0) d = A.partials[cb + (int64_t)(t - pt.nty - 1) * slot + nbxy[u]];
+                if (raw) acc[u] += (unsigned long long)a + b + d;
+                else facc[u] += (__uint_as_float(a) + __uint_as_float(b)) + __uint_as_float(d);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) part[cg][lane * 4 + u] = raw ? acc[u] : (unsigned long long)__float_as_uint(facc[u]);
+    __syncthreads();
+    unsigned long long key = 0ull;
+    const int k = j * RED_CELLS + tid;
+    if (tid < RED_CELLS && k < nwords) {
+        const int lx = k / ltyz, rem = k - lx * ltyz, ly = rem / gz, z = rem - ly * gz;
+        if (lx < tx && ly < ty) {
+            const int64_t cell = ((int64_t)(x0 + lx) * gy + (y0 + ly)) * gz + z;
+            float v;
+            if (raw) {
+                unsigned long long s = 0ull;
+#pragma unroll
+                for (int g = 0; g < RED_GROUPS; ++g) s += part[g][tid];
+                const unsigned nc = min(A.hdr->carry_n, (unsigned)V3_CARRY_MAX);
+                for (unsigned i = 0; i < nc; ++i) s += A.hdr->carry[i] == (unsigned)cell ? 4294967296ull : 0ull;
+                v = (float)((double)s * (double)A.hdr->quantum);   // s < 2^53, the quantum a power of two: one rounding
+            } else {
+                v = 0.f;
+#pragma unroll
+                for (int g = 0; g < RED_GROUPS; ++g) v = v + __uint_as_float((uint32_t)part[g][tid]);
+            }
+            if (A.accumulate) v = A.grid[cell] + v;
+            A.grid[cell] = v;
+            key = ((unsigned long long)f2ord(v) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)cell);
+        }
+    }
+    if (tid < RED_CELLS) {
+        key = wave_max_u64(key);
+        if (lane == 0) wkey[cg] = key;
+    }
+    // blocks that report to this block's arg-max group, and groups in use (see reduce_tiles_kernel): tile t sends its blocks
+    // j = g, g + 8, ... < nb_t to group g
+    unsigned n_group = 0, n_groups_used = 0;
+    if (cg == 0) {
+        unsigned nb = 0;
+        if (lane < T) {
+            const int ax = lane / pt.nty;
+            nb = (unsigned)(((min(pt.tx, gx - ax * pt.tx) + pt.hx) * ltyz + RED_CELLS - 1) / RED_CELLS);
+        }
+        const unsigned gsel = blockIdx.x & (RED_FANIN - 1);
+        unsigned mine = nb > gsel ? (nb - gsel + RED_FANIN - 1) / RED_FANIN : 0u, most = nb;
+        for (int off = 32; off > 0; off >>= 1) {
+            mine += __shfl_xor(mine, off, 64);
+            const unsigned o = __shfl_xor(most, off, 64);
+            most = o > most ? o : most;
+        }
+        n_group = mine;
+        n_groups_used = most < RED_FANIN ? most : RED_FANIN;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < RED_CELLS / 64; ++w) key = wkey[w] > key ? wkey[w] : key;
+        auto report = [](unsigned long long* slot_, unsigned long long k_) -> unsigned {
+            const unsigned long long old = atomicMax(slot_, k_);
+            unsigned d1 = (unsigned)old, d2;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(d2) : "v"(d1));
+            return atomicAdd(reinterpret_cast<unsigned*>(slot_ + 1), 1u + (d1 ^ d2));
+        };
+        const unsigned g = blockIdx.x & (RED_FANIN - 1);
+        unsigned long long* gslot = A.packed + 2 + 2 * g;
+        if (report(gslot, key) == n_group - 1) {
+            const unsigned long long gbest = atomicMax(gslot, 0ull);
+            if (report(A.packed, gbest) == n_groups_used - 1) {
+                const unsigned long long best = atomicMax(A.packed, 0ull);
+                if (A.out_idx) *A.out_idx = (long long)(0xffffffffu - (uint32_t)(best & 0xffffffffull));
+                if (A.out_val) *A.out_val = ord2f((uint32_t)(best >> 32));
+                v3_rezero(A.hdr);   // every block has finished reading the header: its report came after its last read
+            }
+        }
+    }
+}
+
+extern "C" size_t cppf_vote_workspace_init_bytes(void) { return VOTE_WS_PART + V3_HDR_BYTES; }
+
+// host side of the binned path; returns a negative CPPF_E* / positive hipError_t, or 0
+static bool v3_eligible(int64_t n_ppfs, int n_rots, int gx, int gy, int gz)
+{
+    static const bool legacy = getenv("CPPF_VOTE_LEGACY") != nullptr;   // A/B switch for tests and profiles
+    if (legacy || n_ppfs < 1 || tri(n_rots) > VOTE_TAB_LDS_MAX) return false;
+    return v3_tiling(gx, gy, gz).T <= VOTE_MAX_TILES;
+}
+static size_t v3_workspace_bytes(int64_t n_ppfs, int gx, int gy, int gz)
+{
+    const V3Tiling t = v3_tiling(gx, gy, gz);
+    return v3_plan(n_ppfs, t, gz, v3_chunks(n_ppfs, t.T), n_ppfs).total;
+}
+static size_t v3_workspace_bytes_dyn(int many_tiles, int64_t n_ppfs)
+{
+    const int t_cap = many_tiles ? VOTE_MAX_TILES : 3, wgs = many_tiles ? 1024 : 256;
+    return VOTE_WS_PART + V3_HDR_BYTES + align_up((size_t)t_cap * (size_t)n_ppfs * 12, 256) + (size_t)wgs * V3_TILE_FLOATS * sizeof(uint32_t);
+}
+static int v3_launch(const float* points, const float* outputs, const float* probs, const void* point_idxs, int idx_is_i64,
+                     float* grid_obj, const float* corner, float res, int64_t n_points, int64_t n_ppfs, int n_rots, int gx, int gy,
+                     int gz, int adaptive, int accumulate, bool want_argmax, long long* out_idx, float* out_val, void* workspace,
+                     hipStream_t st, const int32_t* shape_dev, int64_t grid_cap, int many_tiles)
+{
+    char* ws = static_cast<char*>(workspace);
+    V3Args A = {};
+    A.points = points; A.outputs = outputs; A.probs = probs; A.point_idxs = point_idxs; A.idx64 = idx_is_i64;
+    A.corner = corner; A.res = res; A.n_ppfs = n_ppfs; A.n_points = n_points; A.n_rots = n_rots; A.adaptive = adaptive;
+    A.gx = gx; A.gy = gy; A.gz = gz; A.shape = shape_dev; A.grid_cap = grid_cap;
+    A.hdr = reinterpret_cast<V3Hdr*>(ws + VOTE_WS_PART);
+    A.packed = reinterpret_cast<unsigned long long*>(ws);
+    A.grid = grid_obj; A.accumulate = accumulate;
+    A.out_idx = want_argmax ? out_idx : nullptr; A.out_val = want_argmax ? out_val : nullptr;
+    A.tab_entries = tri(n_rots);
+    A.pool_cap = n_ppfs;
+    A.pool = reinterpret_cast<uint32_t*>(ws + VOTE_WS_PART + V3_HDR_BYTES);
+    int red_blocks;
+    if (shape_dev) {
+        A.t_cap = many_tiles ? VOTE_MAX_TILES : 3;
+        A.wgs = many_tiles ? 1024 : 256;
+        A.partials = reinterpret_cast<uint32_t*>(ws + VOTE_WS_PART + V3_HDR_BYTES + align_up((size_t)A.t_cap * (size_t)n_ppfs * 12, 256));
+        const int bps = ((V3_TILE_FLOATS + RED_CELLS - 1) / RED_CELLS + RED_FANIN - 1) / RED_FANIN * RED_FANIN;
+        red_blocks = A.t_cap * bps;
+    } else {
+        A.t = v3_tiling(gx, gy, gz);
+        A.C = v3_chunks(n_ppfs, A.t.T);
+        A.wgs = A.t.T * A.C;
+        A.t_cap = A.t.T;
+        const V3Plan pl = v3_plan(n_ppfs, A.t, gz, A.C, n_ppfs);
+        A.partials = reinterpret_cast<uint32_t*>(ws + pl.part_off);
+        const int bps = ((pl.slot + RED_CELLS - 1) / RED_CELLS + RED_FANIN - 1) / RED_FANIN * RED_FANIN;
+        red_blocks = A.t.T * bps;
+    }
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&v3_bin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&v3_vote_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    const int64_t rounds = (n_ppfs + V3_THREADS - 1) / V3_THREADS;
+    const size_t lds_bin = (size_t)V3_STAGE * 16 + VOTE_BELOW_N * 16 + 2 * VOTE_MAX_TILES * 4 + 64;
+    hipLaunchKernelGGL(v3_bin_kernel, dim3((unsigned)(rounds < 512 ? rounds : 512)), dim3(V3_THREADS), lds_bin, st, A);
+    CPPF_CHECK_LAUNCH();
+    const size_t lds_vote = V3_LDS_HEAD + (size_t)(A.tab_entries + 2) * sizeof(float2) + (size_t)V3_TILE_FLOATS * sizeof(float);
+    hipLaunchKernelGGL(v3_vote_kernel, dim3((unsigned)A.wgs), dim3(V3_THREADS), lds_vote, st, A);
+    CPPF_CHECK_LAUNCH();
+    const int bps = red_blocks / A.t_cap;
+    hipLaunchKernelGGL(v3_reduce_kernel, dim3((unsigned)red_blocks), dim3(64 * RED_GROUPS), 0, st, A, bps);
+    CPPF_CHECK_LAUNCH();
+    return 0;
+}
+
 __global__ void zero_u64x2_kernel(unsigned long long* p) { p[0] = 0ull; p[1] = 0ull; }
 
 #define VOTE_LDS_HEAD ((VOTE_THREADS / 64) * VOTE_RING * 2 + VOTE_CARRY_CAP * 4 + (VOTE_THREADS / 64) * VOTE_PAIRQ * 4 + 64 + 512 + VOTE_BELOW_N * 16)
@@ -1150,6 +2038,11 @@ static int vote_impl(const float* points, const float* outputs, const float* pro
     if (n_ppfs > 0 && (!outputs || !point_idxs)) return CPPF_EINVAL;
     if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || gx < 1 || gy < 1 || gz < 1 || n_ppfs < 0 || n_points < 1) return CPPF_EINVAL;
     if ((int64_t)gx * gy * gz > 0x7fffffffll) return CPPF_EINVAL;
+    if (shape_dev ? (n_ppfs >= 1 && grid_cap >= 1 && grid_cap <= 0x7fffffffll && tri(n_rots) <= VOTE_TAB_LDS_MAX &&
+                     getenv("CPPF_VOTE_LEGACY") == nullptr && workspace && workspace_bytes >= v3_workspace_bytes_dyn(many_tiles, n_ppfs))
+                  : (v3_eligible(n_ppfs, n_rots, gx, gy, gz) && workspace && workspace_bytes >= v3_workspace_bytes(n_ppfs, gx, gy, gz)))
+        return v3_launch(points, outputs, probs, point_idxs, idx_is_i64, grid_obj, corner, res, n_points, n_ppfs, n_rots, gx, gy, gz,
+                         adaptive, accumulate, want_argmax, out_idx, out_val, workspace, st, shape_dev, grid_cap, many_tiles);
     VotePlan pl;
     if (shape_dev) {
         if (n_ppfs < 1 || grid_cap < 1 || grid_cap > 0x7fffffffll) return CPPF_EINVAL;
@@ -1269,13 +2162,16 @@ extern "C" int cppf_vote_argmax_dyn(const float* points, const float* outputs, c
                      grid_capacity, many_tiles);
 }
 
-extern "C" int cppf_vote_tile_cells(void) { return VOTE_TILE_FLOATS; }
+extern "C" int cppf_vote_tile_cells(void) { return V3_TILE_FLOATS > VOTE_TILE_FLOATS ? V3_TILE_FLOATS : VOTE_TILE_FLOATS; }
 
+// tiles of the grid in the tiled vote: the larger of the two kernels' decompositions (binned path: 128 KiB tiles with a halo;
+// round-2 kernels, n_rots > 72: 113 KiB), so that a capacity class chosen from it serves both; 0: global-atomics path
 extern "C" int cppf_vote_tiles(int gx, int gy, int gz)
 {
     if (gx < 1 || gy < 1 || gz < 1) return CPPF_EINVAL;
-    const VoteTiling t = vote_tiling(gx, gy, gz);
-    return t.T <= VOTE_MAX_TILES ? t.T : 0;
+    const int a = vote_tiling(gx, gy, gz).T, b = v3_tiling(gx, gy, gz).T;
+    const int T = a > b ? a : b;
+    return T <= VOTE_MAX_TILES ? T : 0;
 }
 
 extern "C" int cppf_grid_argmax(const float* grid, int64_t n, long long* out_idx, float* out_val, void* workspace,

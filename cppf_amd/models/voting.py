@@ -67,7 +67,7 @@ def _ppf_voting(points, outputs, probs, point_idxs, grid_obj, corner, res, n_ppf
     need = L.cppf_vote_workspace_bytes(n_ppfs, n_rots, gx, gy, gz)
     if need == 0:
         raise ValueError(f"n_rots must be in 1..360, got {n_rots}")
-    ws = workspace(need, dev, "vote")
+    ws = workspace(need, dev, "vote", zero=True)
     with torch.cuda.device(dev):
         rc = L.cppf_ppf_voting(points.data_ptr(), outputs.data_ptr(), probs.data_ptr(), point_idxs.data_ptr(),
                                grid_obj.data_ptr(), corner.data_ptr(), float(scalar(res)), points.shape[0], n_ppfs,
@@ -105,7 +105,7 @@ def vote_argmax(points, outputs, probs, point_idxs, grid_obj, corner, res, n_rot
     need = L.cppf_vote_workspace_bytes(n_ppfs, int(n_rots), gx, gy, gz)
     if need == 0:
         raise ValueError(f"n_rots must be in 1..360, got {n_rots}")
-    ws = workspace(need, dev, "vote")
+    ws = workspace(need, dev, "vote", zero=True)
     with torch.cuda.device(dev):
         rc = L.cppf_vote_argmax(points.data_ptr(), outputs.data_ptr(), None if probs is None else probs.data_ptr(), point_idxs.data_ptr(),
                                 1 if i64 else 0, grid_obj.data_ptr(), corner.data_ptr(), float(scalar(res)), points.shape[0], n_ppfs,
@@ -133,7 +133,7 @@ def vote_argmax_dyn(points, outputs, probs, point_idxs, grid_flat, shape, corner
     if shape.numel() < 4 or (probs is not None and probs.numel() != points.shape[0]):
         raise ValueError("shape must be i32[4]; probs must have one entry per (capacity) point")
     L = _lib.lib()
-    ws = workspace(L.cppf_vote_workspace_bytes_dyn(1 if many_tiles else 0), dev, "vote_dyn")
+    ws = workspace(L.cppf_vote_workspace_bytes_dyn_pairs(1 if many_tiles else 0, int(point_idxs.shape[0])), dev, "vote_dyn", zero=True)
     with torch.cuda.device(dev):
         rc = L.cppf_vote_argmax_dyn(points.data_ptr(), outputs.data_ptr(), None if probs is None else probs.data_ptr(), point_idxs.data_ptr(),
                                     1 if i64 else 0, grid_flat.data_ptr(), grid_flat.numel(), corner.data_ptr(),

@@ -147,6 +147,15 @@ int cppf_compact_mask(const uint8_t* mask, int64_t n, int32_t* surv, int32_t* co
 int cppf_vote_tiles(int gx, int gy, int gz);
 int cppf_vote_tile_cells(void);   /* cells of one LDS tile: a launch serves grids of up to 3 (64 with many_tiles) times that */
 size_t cppf_vote_workspace_bytes_dyn(int many_tiles);
+/* The same with room for the pair -> tile queues of the binned vote path (n_ppfs records of 12 B for every tile of the class):
+ * give cppf_vote_argmax_dyn this many bytes to run the round-3 kernels; with only cppf_vote_workspace_bytes_dyn() bytes it
+ * runs the round-2 kernels. */
+size_t cppf_vote_workspace_bytes_dyn_pairs(int many_tiles, int64_t n_ppfs);
+/* The vote workspace keeps a small header between calls (queue counters, see the note on workspaces above): its first
+ * cppf_vote_workspace_init_bytes() bytes must be ZERO before the first call on a fresh allocation (hipMemsetAsync once);
+ * every call leaves the header ready for the next one.  A call on an uninitialised workspace reports arg-max -1 / peak NaN
+ * (and leaves the workspace usable). */
+size_t cppf_vote_workspace_init_bytes(void);
 int cppf_vote_argmax_dyn(const float* points, const float* outputs, const float* probs, const void* point_idxs,
                          int idx_is_i64, float* grid_obj, int64_t grid_capacity, const float* corner, float res,
                          int64_t n_points_cap, int64_t n_ppfs, int n_rots, const int32_t* shape_dev, int many_tiles,

@@ -32,6 +32,7 @@ def bracket(fn, n=10):
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    regime = sys.argv[2] if len(sys.argv) > 2 else "all"       # known-answer | uniform-bin
     dev = torch.device("cuda:0")
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     for name, (N, K, res) in (("c2", (4096, 128, None)), ("c5", (8192, 256, 2e-3))):
@@ -50,6 +51,8 @@ def main():
         pc, idx_d, corner = d(ob["pc"]), d(idx), d(corners[0])
         ws = PoseWorkspace(dev, P, dims, 1)
         for tag, out in (("known-answer", ka), ("uniform-bin", un)):
+            if regime not in ("all", tag):
+                continue
             o = d(out)
             fn = lambda: voting.vote_argmax(pc, o, None, idx_d, ws.grid, corner, r, 72, True, ws.out_idx, ws.out_val, accumulate=False)
             t = bracket(fn)

@@ -27,10 +27,17 @@ def test_library_loads_and_exports_every_declared_symbol():
 def test_workspace_queries_and_argument_errors_without_a_device():
     from cppf_amd import _lib
     L = _lib.lib()
-    # bottle grid of BASELINE config 2: two x slabs x 128 pair chunks of partial grids
+    # bottle grid of BASELINE config 2 on the binned path: two tiles of 26 x 38 x 26 owned cells (+ one halo row), 128 chunks of
+    # raw partial tiles, and a queue of 12-byte records per tile with room for every pair
     need = L.cppf_vote_workspace_bytes(524288, 72, 26, 76, 26)
+    slot = 26 * 39 * 26
+    lo = 128 * 2 * slot * 4 + 2 * 524288 * 12
+    assert lo <= need < lo + (1 << 17)
+    assert L.cppf_vote_workspace_init_bytes() < 65536 <= need
+    # n_rots > 72 keeps the round-2 kernels: 128 chunks of fp32 partial grids, no queues
     G = 26 * 76 * 26
-    assert need >= 128 * G * 4 and need < 129 * G * 4
+    need2 = L.cppf_vote_workspace_bytes(524288, 100, 26, 76, 26)
+    assert need2 >= 128 * G * 4 and need2 < 129 * G * 4
     assert L.cppf_vote_workspace_bytes(100, 0, 26, 76, 26) == 0          # n_rots out of range
     assert L.cppf_vote_workspace_bytes(100, 361, 26, 76, 26) == 0
     # huge grid -> global-atomic path: only table + scratch
@@ -301,12 +308,13 @@ def test_shape_polymorphic_plan_queries_without_a_device():
     assert L.cppf_vote_tiles(10, 10, 10) == 1
     assert L.cppf_vote_tiles(0, 10, 10) < 0
     assert L.cppf_vote_tiles(600, 600, 600) == 0                         # beyond the tiled vote: global atomics only
-    for dims in ((26, 76, 26), (52, 152, 52), (100, 49, 76), (5, 5, cells)):
+    for dims in ((26, 76, 26), (52, 152, 52), (100, 49, 76), (5, 5, 8000)):
         T, many, cap = grid_class(dims)
         assert T * cells >= dims[0] * dims[1] * dims[2] and many == (T >= 4) and cap == (64 if many else 3) * cells
     # the dyn workspace holds the partial tiles of ANY plan its launch geometry can meet
-    few, many = L.cppf_vote_workspace_bytes_dyn(0), L.cppf_vote_workspace_bytes_dyn(1)
+    few, many = L.cppf_vote_workspace_bytes_dyn_pairs(0, 524288), L.cppf_vote_workspace_bytes_dyn_pairs(1, 2 ** 21)
     assert few >= L.cppf_vote_workspace_bytes(524288, 72, 26, 76, 26) and many >= L.cppf_vote_workspace_bytes(2 ** 21, 72, 52, 152, 52)
+    assert few > L.cppf_vote_workspace_bytes_dyn(0) >= L.cppf_vote_workspace_bytes(524288, 100, 26, 76, 26)   # (round-2 kernels)
     # entry points reject a missing shape record before any HIP call
     assert L.cppf_vote_argmax_dyn(None, None, None, None, 0, None, 100, None, 0.004, 4, 10, 72, None, 0, 1, 0, None, None,
                                   None, 0, None) == -1
