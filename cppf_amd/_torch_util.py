@@ -84,7 +84,7 @@ def workspace(nbytes, device, tag="ws", zero=False):
         n = max(int(nbytes), 256)
         if zero:
             buf = torch.empty(n, dtype=torch.uint8, device=device)
-            buf[:min(n, 65536)].zero_()
+            buf[:min(n, int(_lib.lib().cppf_vote_workspace_init_bytes()))].zero_()
         else:
             buf = torch.empty(n, dtype=torch.uint8, device=device)
         _ws_cache[key] = buf

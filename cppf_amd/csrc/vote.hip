@@ -137,6 +137,10 @@ __host__ __device__ inline int vote_fixed_bits_of(int64_t chunk_pairs, int n_rot
 // outside the caller's workspace.  [VOTE_WS_PART, ...) the partial grids.
 #define VOTE_WS_TAB 256
 #define VOTE_WS_PART (256 + ((VOTE_TAB_LDS_MAX + 2) * 8 + 255) / 256 * 256)
+// [VOTE_WS_PART, VOTE_WS_PART + VOTE_WS_V3_STATE): the binned path's state between calls (queue header + carry plane, see V3Hdr);
+// the round-2 kernels' partial grids start behind it, so a call that takes them (n_rots > 72, an empty pair list) leaves it intact
+#define VOTE_WS_V3_STATE (8704 + 64 * 32768 * 4)
+#define VOTE_WS_LEGACY_PART (VOTE_WS_PART + VOTE_WS_V3_STATE)
 #define VOTE_TAB_STAMP 0x43505046726f7400ull   // "CPPFrot\0" ^ n_rots: table valid
 // The launch that builds the table must not be able to read it back: workgroups of that same launch that start late
 // (more workgroups than the chip holds at once) would see workgroup 0's stamp without any guarantee of seeing its table
@@ -170,8 +174,9 @@ static VotePlan make_vote_plan(int64_t n_ppfs, int n_rots, int gx, int gy, int g
         p.chunk_pairs = 0;
     }
     p.packed_off = 0;   // u64 packed arg-max key + u32 ticket counter
-    p.part_off = VOTE_WS_PART;
-    p.total = p.part_off + (size_t)p.chunks * (size_t)p.T * (p.tiled ? vote_slot_floats(t, gz) : 0) * sizeof(float);
+    p.part_off = VOTE_WS_LEGACY_PART;
+    p.total = p.tiled ? p.part_off + (size_t)p.chunks * (size_t)p.T * vote_slot_floats(t, gz) * sizeof(float)
+                      : (size_t)VOTE_WS_PART;   // global atomics: the arg-max keys and the rotation table only
     (void)G;
     return p;
 }
@@ -191,7 +196,7 @@ extern "C" int cppf_vote_fixed_point_bits(int64_t n_ppfs, int n_rots, int gx, in
 // any plan a *_dyn launch can meet writes chunks * G <= workgroups * VOTE_TILE_FLOATS partial cells (G <= T * tile)
 extern "C" size_t cppf_vote_workspace_bytes_dyn(int many_tiles)
 {
-    return VOTE_WS_PART + (size_t)(many_tiles ? VOTE_WGS_MANY : VOTE_WGS_FEW) * VOTE_TILE_FLOATS * sizeof(float);
+    return VOTE_WS_LEGACY_PART + (size_t)(many_tiles ? VOTE_WGS_MANY : VOTE_WGS_FEW) * VOTE_TILE_FLOATS * sizeof(float);
 }
 
 static bool v3_eligible(int64_t n_ppfs, int n_rots, int gx, int gy, int gz);
@@ -1185,22 +1190,27 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void reduce_tiles_kernel(RedArgs R
 // `v3_vote_kernel`, workgroup (tile t, chunk c), consumes records [c n_t / C, (c+1) n_t / C) of tile t's queue: exact frame
 // again (12 B/record of HBM traffic instead of 52), then the run walk of vote_kernel.
 #define V3_TILE_FLOATS 32768      // 128 KiB of LDS for the tile incl. its halo
-#define V3_STAGE 5120             // staged records per flush (16 B each in LDS)
+#define V3_STAGE 3072             // staged records per flush (16 B each in LDS: 48 KiB, two to three workgroups per CU)
 #define V3_MAGIC 0x43503356u
-#define V3_CARRY_MAX 4096
 #define V3_THREADS 1024
+#define V3_BIN_THREADS 512
+#define V3_CNT_STRIDE 32
 struct V3Hdr {                    // workspace + VOTE_WS_PART; all zero (or left by a previous call) when a launch starts
-    unsigned int tile_count[VOTE_MAX_TILES];   // records in each tile's queue
+    unsigned int tile_count[VOTE_MAX_TILES * V3_CNT_STRIDE];   // records in each tile's queue, one counter per 128-byte line
     unsigned int flags;           // 1: the workspace was not initialised / a capacity was exceeded -> arg-max -1, peak NaN
-    unsigned int carry_n;         // entries of carry[]
+    unsigned int any_carry;       // some partial tile logged a 2^32 wrap-around in this launch (see the carry plane)
     unsigned int magic;           // 0 (fresh, zeroed) or V3_MAGIC
     unsigned int fmt;             // partial tiles: 0 = raw fixed point, 1 = fp32 (negative / non-finite probs)
     float quantum;                // value of one fixed-point unit (p2 / 2^kk)
     unsigned int done;            // ticket of the reduce blocks (the last one re-zeroes this header)
     unsigned int pad[2];
-    unsigned int carry[V3_CARRY_MAX];          // grid cell of every 2^32 wrap-around of a partial tile
 };
+// Behind the header: the CARRY PLANE, one u32 per grid cell = the 2^32 wrap-arounds the partial tiles logged for that cell
+// (a handful of cells around the vote peak, a few per workgroup).  Zero between launches: the reduce kernel reads it with the
+// cell and clears what it finds.
 #define V3_HDR_BYTES ((sizeof(V3Hdr) + 255) / 256 * 256)
+#define V3_PLANE_BYTES ((size_t)VOTE_MAX_TILES * V3_TILE_FLOATS * sizeof(uint32_t))
+static_assert(V3_HDR_BYTES + V3_PLANE_BYTES <= VOTE_WS_V3_STATE, "VOTE_WS_V3_STATE too small");
 
 struct V3Tiling { int tx, ty, ntx, nty, T, hx, hy; };   // hx / hy: the grid is cut along x / y (tiles carry a halo column / row)
 // fewest tiles, then least cut area (see vote_tiling); a tile of tx x ty owned cells occupies (tx + hx)(ty + hy) gz words
@@ -1235,16 +1245,16 @@ __host__ __device__ inline V3Tiling v3_tiling(int gx, int gy, int gz)
     return p;
 }
 __host__ __device__ inline int v3_slot_words(const V3Tiling& t, int gz) { return ((t.tx + t.hx) * (t.ty + t.hy) * gz + 3) & ~3; }
-// chunks per tile: ~one workgroup per CU for a few tiles, 512 / 1024 workgroups when the votes pile up in the few tiles around
-// the peak (see vote_wgs), never more than one per 1 024 pairs
-__host__ __device__ inline int v3_chunks(int64_t n_ppfs, int T)
+// workgroups of the vote launch: ~one per CU for a few tiles, 512 / 1024 when the votes pile up in the few tiles around the peak
+// (see vote_wgs), never more than one per 512 pairs and tile
+__host__ __device__ inline int v3_wgs(int64_t n_ppfs, int T)
 {
-    int64_t c = (T < 4 ? 256 : (T <= 8 ? 512 : 1024)) / T;
-    const int64_t cmax = (n_ppfs + 1023) / 1024;
-    if (c > cmax) c = cmax;
-    return (int)(c < 1 ? 1 : c);
+    int64_t w = T < 4 ? 256 : (T <= 8 ? 512 : 1024);
+    const int64_t wmax = ((n_ppfs + 511) / 512) * T;
+    if (w > wmax) w = wmax;
+    return (int)(w < T ? T : w);
 }
-// record range of chunk c of a tile holding n records: boundaries at multiples of 64
+// record range of chunk c of a tile holding n records cut into C chunks: boundaries at multiples of 64
 __host__ __device__ inline unsigned v3_bound(unsigned n, int c, int C)
 {
     if (c >= C) return n;
@@ -1255,15 +1265,18 @@ __host__ __device__ inline unsigned v3_bound(unsigned n, int c, int C)
 // carry-log entry (VOTE_CARRY_CAP of them per workgroup)
 __host__ __device__ inline int v3_bits(unsigned chunk_records, int n_rots) { return vote_fixed_bits_of((int64_t)chunk_records + 64, n_rots); }
 
-struct V3Plan { V3Tiling t; int C, slot; size_t pool_off, part_off, total; int64_t pool_cap; };
+struct V3Plan { V3Tiling t; int wgs, slot; size_t pool_off, part_off, total; int64_t pool_cap; };
 // pool: T queues of `cap` records (12 B) each -- every pair can visit every tile, and the HBM is there (288 GB)
-static V3Plan v3_plan(int64_t n_ppfs, const V3Tiling& t, int gz, int C, int64_t cap)
+static V3Plan v3_plan(int64_t n_ppfs, const V3Tiling& t, int gz, int wgs, int64_t cap, int64_t cells)
 {
     V3Plan p;
-    p.t = t; p.C = C; p.slot = v3_slot_words(t, gz); p.pool_cap = cap;
-    p.pool_off = VOTE_WS_PART + V3_HDR_BYTES;
+    p.t = t; p.wgs = wgs; p.slot = v3_slot_words(t, gz); p.pool_cap = cap;
+    // (the carry plane has a FIXED place and size -- the most cells a tiled grid can have -- whatever the grid: a workspace serves
+    // calls with different grids, and the plane's "zero between launches" invariant must not depend on the previous layout)
+    p.pool_off = VOTE_WS_PART + V3_HDR_BYTES + V3_PLANE_BYTES;
+    (void)cells;
     p.part_off = p.pool_off + align_up((size_t)t.T * (size_t)cap * 12, 256);
-    p.total = p.part_off + (size_t)C * t.T * p.slot * sizeof(uint32_t);
+    p.total = p.part_off + (size_t)wgs * p.slot * sizeof(uint32_t);   // one partial tile per workgroup
     (void)n_ppfs;
     return p;
 }
@@ -1279,15 +1292,15 @@ struct V3Args {
     int64_t n_ppfs, n_points;
     int n_rots, adaptive, gx, gy, gz;
     V3Tiling t;
-    int C;                 // chunks per tile (by-value launches)
-    int wgs;               // workgroups of the vote launch (*_dyn: chunks per tile = min(v3_chunks, wgs / T))
+    int wgs;               // workgroups of the vote launch = partial tiles; the tiles share them in proportion to their queues
     int t_cap;             // *_dyn: most tiles this launch serves
     const int32_t* shape;  // {n_points, gx, gy, gz} in device memory, or null
     int64_t grid_cap;
     V3Hdr* hdr;
+    uint32_t* plane;       // carry plane, one word per grid cell
     uint32_t* pool;        // [T][pool_cap][3]
     int64_t pool_cap;
-    uint32_t* partials;    // [C][T][slot]
+    uint32_t* partials;    // [wgs][slot]: workgroup b's tile
     unsigned long long* packed;
     float* grid;
     int accumulate;
@@ -1297,18 +1310,39 @@ struct V3Args {
 };
 
 // *_dyn: the plan from the dims record, identically in all three kernels; false = the record does not fit the launch
-__device__ __forceinline__ bool v3_resolve(const V3Args& A, int& gx, int& gy, int& gz, int64_t& n_points, V3Tiling& t, int& C)
+__device__ __forceinline__ bool v3_resolve(const V3Args& A, int& gx, int& gy, int& gz, int64_t& n_points, V3Tiling& t)
 {
-    gx = A.gx; gy = A.gy; gz = A.gz; n_points = A.n_points; t = A.t; C = A.C;
+    gx = A.gx; gy = A.gy; gz = A.gz; n_points = A.n_points; t = A.t;
     if (!A.shape) return true;
     n_points = A.shape[0]; gx = A.shape[1]; gy = A.shape[2]; gz = A.shape[3];
     if (n_points < 1 || n_points > A.n_points || gx < 1 || gy < 1 || gz < 1 || (int64_t)gx * gy * gz > A.grid_cap) return false;
     t = v3_tiling(gx, gy, gz);
-    if (t.T > A.t_cap) return false;
-    const int c = v3_chunks(A.n_ppfs, t.T), cw = A.wgs / t.T;
-    C = c < cw ? c : cw;
-    return C >= 1;
+    return t.T <= A.t_cap && t.T <= A.wgs;
 }
+
+// The tiles share the launch's workgroups in proportion to their queues: tile t gets C_t = 1 + floor(n_t E / W) chunks (E =
+// workgroups minus non-empty tiles, W = all records; an empty tile gets none), workgroup b = base_t + c works on chunk c of tile t
+// and owns partial tile b.  Evaluated by the first wavefront of a workgroup into LDS (sp[0..63] = C_t, [64..127] = base_t,
+// [128..191] = n_t, [192] = largest chunk in records); the vote and the reduce kernel evaluate the same function of the same counters.
+__device__ __forceinline__ void v3_split(const V3Args& A, int T, int* sp)
+{
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < 64) {
+        const unsigned n = lane < T ? min(A.hdr->tile_count[lane * V3_CNT_STRIDE], (unsigned)A.pool_cap) : 0u;
+        const int nonempty = __popcll(__ballot(n > 0u));
+        unsigned long long W = n;
+        for (int off = 32; off > 0; off >>= 1) W += __shfl_xor(W, off, 64);
+        const unsigned long long E = (unsigned long long)max(A.wgs - nonempty, 0);
+        const int C = n > 0u ? 1 + (int)((unsigned long long)n * E / (W > 0ull ? W : 1ull)) : 0;
+        const int incl = wave_incl_scan(C);
+        int big = C > 0 ? (int)((n + (unsigned)C - 1u) / (unsigned)C) : 0;
+        for (int off = 32; off > 0; off >>= 1) big = max(big, __shfl_xor(big, off, 64));
+        sp[lane] = C; sp[64 + lane] = incl - C; sp[128 + lane] = (int)n;
+        if (lane == 0) sp[192] = big;
+    }
+}
+// (chunk c of a tile of n records in C chunks is empty unless its boundaries differ; workgroup 0 always dumps its tile)
+__device__ __forceinline__ bool v3_chunk_live(unsigned n, int c, int C, int b) { return b == 0 || v3_bound(n, c, C) < v3_bound(n, c + 1, C); }
 
 __device__ __forceinline__ int2 v3_pair_idx(const V3Args& A, int64_t p)
 {
@@ -1355,19 +1389,19 @@ __device__ __forceinline__ int wave_max_i32(int v)
 // their rotation counts), per-axis arc parameters, z mask; then for every tile of the circle's bounding box the x / y masks
 // of its column / row, AND, runs, and a record into the tile's queue.  Rounds of 1 024 pairs per workgroup; records are staged
 // in LDS (slot within the tile's share of the flush from an LDS atomic) and flushed with one global atomic per tile.
-__global__ __launch_bounds__(V3_THREADS) void v3_bin_kernel(V3Args A)
+__global__ __launch_bounds__(V3_BIN_THREADS) void v3_bin_kernel(V3Args A)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
     uint4* stage = reinterpret_cast<uint4*>(lds_u);                          // [V3_STAGE] {pair, runs a, runs b | tile << 24, slot}
     uint4* below = reinterpret_cast<uint4*>(stage + V3_STAGE);               // [VOTE_BELOW_N]
     uint32_t* cnt = reinterpret_cast<uint32_t*>(below + VOTE_BELOW_N);       // [64] records of each tile in this flush
     uint32_t* gbase = cnt + VOTE_MAX_TILES;                                   // [64] their place in the tile's queue
-    uint32_t* ctl = gbase + VOTE_MAX_TILES;                                   // [0] staged, [1] again
+    uint32_t* ctl = gbase + VOTE_MAX_TILES;                                   // [0] staged (attempts), [1] a lane could not stage
     const int tid = threadIdx.x;
-    int gx, gy, gz, C;
+    int gx, gy, gz;
     int64_t n_points;
     V3Tiling t;
-    if (!v3_resolve(A, gx, gy, gz, n_points, t, C)) return;   // (the reduce kernel reports it)
+    if (!v3_resolve(A, gx, gy, gz, n_points, t)) return;   // (the reduce kernel reports it)
     if (blockIdx.x == 0 && tid < 2 + 2 * 8) A.packed[tid] = 0ull;   // arg-max keys + tickets of the reduce kernel
     {
         const unsigned m = A.hdr->magic;
@@ -1378,13 +1412,17 @@ __global__ __launch_bounds__(V3_THREADS) void v3_bin_kernel(V3Args A)
         auto w = [](int c) { return c <= 0 ? 0u : (c >= 32 ? 0xffffffffu : ((1u << c) - 1u)); };
         below[j] = make_uint4(w(j), w(j - 32), w(j - 64), 0u);
     }
+    if (tid < VOTE_MAX_TILES) cnt[tid] = 0u;
+    if (tid == 0) { ctl[0] = 0u; ctl[1] = 0u; }
     const f3 cr = {A.corner[0], A.corner[1], A.corner[2]};
     const float res = A.res, rinv = 1.0f / res;
     const float ptxf = (float)t.tx, ptyf = (float)t.ty;
     const float rtx = 1.0f / ptxf, rty = 1.0f / ptyf;
-    const int64_t rounds = (A.n_ppfs + V3_THREADS - 1) / V3_THREADS;
+    const int64_t rounds = (A.n_ppfs + V3_BIN_THREADS - 1) / V3_BIN_THREADS;
+    __syncthreads();
     for (int64_t r = blockIdx.x; r < rounds; r += gridDim.x) {
-        const int64_t p = r * V3_THREADS + tid;
+        const int64_t p = r * V3_BIN_THREADS + tid;
+        const bool last_round = r + gridDim.x >= rounds;
         // ---- per pair
         f3 Fcc = {0.f, 0.f, 0.f}, Fx = Fcc, Fy = Fcc;
         int n = 0;
@@ -1428,11 +1466,9 @@ __global__ __launch_bounds__(V3_THREADS) void v3_bin_kernel(V3Args A)
         }
         const int nxw = wave_max_i32(ix1 - ix0 + 1), nyw = wave_max_i32(iy1 - iy0 + 1);   // this wave's loop bounds
         int resume = 0;   // first (dx, dy) step of this lane that has not been staged yet
+        // Records are staged in LDS across rounds and flushed -- one global atomic per tile -- when the area is half full,
+        // when a lane could not stage (it resumes after the flush), and after the workgroup's last round.
         for (;;) {
-            __syncthreads();   // (previous flush done; first trip: the tables above are complete)
-            if (tid < VOTE_MAX_TILES) cnt[tid] = 0u;
-            if (tid == 0) { ctl[0] = 0u; ctl[1] = 0u; }
-            __syncthreads();
             bool stuck = false;
             int step = 0;
             for (int dx = 0; dx < nxw; ++dx) {
@@ -1467,22 +1503,28 @@ __global__ __launch_bounds__(V3_THREADS) void v3_bin_kernel(V3Args A)
             __syncthreads();
             const uint32_t staged = min(ctl[0], (uint32_t)V3_STAGE);
             const bool again = ctl[1] != 0u;
-            if (tid < t.T && cnt[tid] != 0u) {
-                // (a failed stage attempt bumped ctl[0] but not cnt[]: cnt[] counts exactly the staged records)
-                const uint32_t b = atomicAdd(&A.hdr->tile_count[tid], cnt[tid]);
-                gbase[tid] = b;
-                if ((int64_t)b + cnt[tid] > A.pool_cap) atomicOr(&A.hdr->flags, 1u);
+            if (again || last_round || staged >= V3_STAGE / 2) {
+                if (tid < t.T && cnt[tid] != 0u) {
+                    // (a failed attempt bumped ctl[0] but not cnt[]: cnt[] counts exactly the staged records)
+                    const uint32_t b = atomicAdd(&A.hdr->tile_count[tid * V3_CNT_STRIDE], cnt[tid]);
+                    gbase[tid] = b;
+                    if ((int64_t)b + cnt[tid] > A.pool_cap) atomicOr(&A.hdr->flags, 1u);
+                }
+                __syncthreads();
+                for (uint32_t i = tid; i < staged; i += V3_BIN_THREADS) {
+                    const uint4 rec = stage[i];
+                    const uint32_t tile = rec.z >> 24;
+                    const int64_t pos = (int64_t)gbase[tile] + rec.w;
+                    if (pos < A.pool_cap) {
+                        uint32_t* dst = A.pool + ((int64_t)tile * A.pool_cap + pos) * 3;
+                        dst[0] = rec.x; dst[1] = rec.y; dst[2] = rec.z & 0xffffffu;
+                    }
+                }
+                __syncthreads();
+                if (tid < VOTE_MAX_TILES) cnt[tid] = 0u;
+                if (tid == 0) { ctl[0] = 0u; ctl[1] = 0u; }
             }
             __syncthreads();
-            for (uint32_t i = tid; i < staged; i += V3_THREADS) {
-                const uint4 rec = stage[i];
-                const uint32_t tile = rec.z >> 24;
-                const int64_t pos = (int64_t)gbase[tile] + rec.w;
-                if (pos < A.pool_cap) {
-                    uint32_t* dst = A.pool + ((int64_t)tile * A.pool_cap + pos) * 3;
-                    dst[0] = rec.x; dst[1] = rec.y; dst[2] = rec.z & 0xffffffu;
-                }
-            }
             if (!again) break;
         }
     }
@@ -1562,28 +1604,33 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
     float2* ltab = reinterpret_cast<float2*>(below + VOTE_BELOW_N);
     uint32_t* tile = reinterpret_cast<uint32_t*>(ltab + A.tab_entries + 2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int gx, gy, gz, C;
+    int gx, gy, gz;
     int64_t n_points;
     V3Tiling pt;
-    if (!v3_resolve(A, gx, gy, gz, n_points, pt, C)) return;
+    if (!v3_resolve(A, gx, gy, gz, n_points, pt)) return;
     if (A.hdr->flags & 1u) return;
-    // workgroup b takes chunk c = b / T of tile (b + c) mod T (not b mod T: workgroups go to XCD b mod 8 in launch order, see vote_kernel)
-    const int c = blockIdx.x / pt.T;
-    if (c >= C) return;
-    const int t = (blockIdx.x + c) % pt.T;
+    int* sp = reinterpret_cast<int*>(carry_log);   // (the carry log is unused until the main loop)
+    v3_split(A, pt.T, sp);
+    __syncthreads();
+    // this workgroup's tile and chunk (a uniform scan of <= 64 tiles)
+    int t = -1, c = 0, Ct = 0;
+    unsigned n_t = 0u;
+    for (int k = 0; k < pt.T; ++k) {
+        const int ck = sp[k], bk = sp[64 + k];
+        if ((int)blockIdx.x >= bk && (int)blockIdx.x < bk + ck) { t = k; c = (int)blockIdx.x - bk; Ct = ck; n_t = (unsigned)sp[128 + k]; }
+    }
+    const int kk = v3_bits((unsigned)sp[192], A.n_rots);   // every workgroup must use the same scale: the launch's largest chunk
+    __syncthreads();   // (sp is the carry log: everybody has read it)
+    if (t < 0 && blockIdx.x != 0) return;            // more workgroups than chunks
+    const unsigned r0 = t >= 0 ? v3_bound(n_t, c, Ct) : 0u, r1 = t >= 0 ? v3_bound(n_t, c + 1, Ct) : 0u;
+    if (r0 >= r1 && blockIdx.x != 0) return;         // nothing queued for this chunk: no tile to zero or dump (the reduce kernel skips it too)
+    if (t < 0) t = 0;                                // (workgroup 0 of a launch without a single record: an empty tile, the launch-wide duties)
     const int tix = t / pt.nty, tiy = t - tix * pt.nty;
     const int x0 = tix * pt.tx, y0 = tiy * pt.ty;
     const int tx = min(pt.tx, gx - x0), ty = min(pt.ty, gy - y0);
     const int tyh = pt.ty + pt.hy;                 // LDS rows per column: uniform over the tiles (the slot layout of the partials)
     const int ltyz = tyh * gz;
     const int nwords = (tx + pt.hx) * ltyz;
-    const unsigned n_t = min(A.hdr->tile_count[t], (unsigned)A.pool_cap);
-    const unsigned r0 = v3_bound(n_t, c, C), r1 = v3_bound(n_t, c + 1, C);
-    if (r0 >= r1 && blockIdx.x != 0) return;   // nothing queued for this chunk: no tile to zero or dump (the reduce kernel skips it too)
-    // chunk size that fixes the fixed-point bits: the largest chunk of the launch (every workgroup must use the same scale)
-    unsigned n_max = 0;
-    for (int k = 0; k < pt.T; ++k) n_max = max(n_max, min(A.hdr->tile_count[k], (unsigned)A.pool_cap));
-    const int kk = v3_bits((n_max + C - 1) / C, A.n_rots);
 
     // prologue (as vote_kernel): probs scan and rotation table loads first, tile zeroed meanwhile, one barrier
     float pm = A.probs ? 0.f : 1.f;
@@ -1765,18 +1812,17 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
     // ---- dump: raw fixed point (the reduce kernel adds the partial tiles as integers), wrap-arounds to the global carry list
     __syncthreads();
     const int slot = v3_slot_words(pt, gz);
-    uint4* part4 = reinterpret_cast<uint4*>(A.partials + ((int64_t)c * pt.T + t) * slot);
+    uint4* part4 = reinterpret_cast<uint4*>(A.partials + (int64_t)blockIdx.x * slot);
     const uint4* t4 = reinterpret_cast<const uint4*>(tile);
     for (int k = tid; k < (nwords + 3) >> 2; k += V3_THREADS) part4[k] = t4[k];
     if (S > 0.f) {
         const int nc = min(ctrl[0], VOTE_CARRY_CAP);
         if (ctrl[0] > VOTE_CARRY_CAP && tid == 0) atomicOr(&A.hdr->flags, 1u);
+        if (nc > 0 && tid == 0) A.hdr->any_carry = 1u;
         for (int k = tid; k < nc; k += V3_THREADS) {
             const int w = (int)carry_log[k];   // word of the LDS tile -> grid cell
             const int lx = w / ltyz, rem = w - lx * ltyz, ly = rem / gz, z = rem - ly * gz;
-            const unsigned cell = (unsigned)(((int64_t)(x0 + lx) * gy + (y0 + ly)) * gz + z);
-            const unsigned at = atomicAdd(&A.hdr->carry_n, 1u);
-            if (at < V3_CARRY_MAX) A.hdr->carry[at] = cell; else atomicOr(&A.hdr->flags, 1u);
+            atomicAdd(&A.plane[((int64_t)(x0 + lx) * gy + (y0 + ly)) * gz + z], 1u);
         }
     }
 }
@@ -1786,29 +1832,30 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
 // its x / y / diagonal neighbours, over all chunks, plus 2^32 per logged wrap-around -- converted to fp32 ONCE; arg-max as in
 // reduce_tiles_kernel.  A block = 16 waves = one run of 256 words of one tile's slot (LDS order); wave g adds chunks g, g + 16, ...
 // The block that draws the last ticket re-zeroes the queue header for the next launch on this workspace.
-__device__ __forceinline__ bool v3_chunk_live(unsigned n_t, int t, int c, int C)
-{
-    return (t == 0 && c == 0) || v3_bound(n_t, c, C) < v3_bound(n_t, c + 1, C);   // (tile 0 / chunk 0 = workgroup 0: always dumps)
-}
 __device__ __forceinline__ void v3_rezero(V3Hdr* h)
 {
-    for (int k = 0; k < VOTE_MAX_TILES; ++k) h->tile_count[k] = 0u;
-    h->flags = 0u; h->carry_n = 0u; h->done = 0u; h->magic = V3_MAGIC;
+    for (int k = 0; k < VOTE_MAX_TILES; ++k) h->tile_count[k * V3_CNT_STRIDE] = 0u;
+    h->flags = 0u; h->any_carry = 0u; h->done = 0u; h->magic = V3_MAGIC;
     __threadfence();
 }
+#define V3_RED_NB 768   // halo words the 256 cells of a block can have to gather: x, y and diagonal neighbour each
 __global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, int bps)
 {
     __shared__ unsigned long long part[RED_GROUPS][RED_CELLS];
+    __shared__ unsigned long long extra[RED_CELLS];      // halo words of the neighbour tiles, per cell of the block
     __shared__ unsigned long long wkey[RED_CELLS / 64];
+    __shared__ int sp[200];
+    __shared__ int nb_cell[V3_RED_NB], nb_word[V3_RED_NB], nb_tile[V3_RED_NB];   // (cell of the block, word in that tile's slot, tile)
+    __shared__ int nb_n;
     const int tid = threadIdx.x, lane = tid & 63, cg = tid >> 6;
     if (blockIdx.x == 0 && tid == 0) {   // rotation table left by the vote kernel of this call: valid from the next launch on
         const unsigned long long st = A.packed[31];
         if ((st & ~0xfffull) == VOTE_TAB_PENDING) A.packed[31] = st ^ (VOTE_TAB_PENDING ^ VOTE_TAB_STAMP);
     }
-    int gx, gy, gz, C;
+    int gx, gy, gz;
     int64_t n_points;
     V3Tiling pt;
-    const bool fits = v3_resolve(A, gx, gy, gz, n_points, pt, C);
+    const bool fits = v3_resolve(A, gx, gy, gz, n_points, pt);
     if (!fits || (A.hdr->flags & 1u)) {   // nothing valid was voted: say so (index -1, NaN) and leave a clean header
         if (tid == 0) {
             const unsigned tk = atomicAdd(&A.hdr->done, 1u);
@@ -1830,79 +1877,104 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, in
     const int tyh = pt.ty + pt.hy, ltyz = tyh * gz;
     const int nwords = (tx + pt.hx) * ltyz;
     if (j * RED_CELLS >= nwords) return;
+    v3_split(A, T, sp);
+    if (tid < RED_CELLS) extra[tid] = 0ull;
+    if (tid == 0) nb_n = 0;
+    __syncthreads();
     const bool raw = A.hdr->fmt == 0u;
-    const unsigned n_own = min(A.hdr->tile_count[t], (unsigned)A.pool_cap);
-    const unsigned n_nx = tix > 0 ? min(A.hdr->tile_count[t - pt.nty], (unsigned)A.pool_cap) : 0u;
-    const unsigned n_ny = tiy > 0 ? min(A.hdr->tile_count[t - 1], (unsigned)A.pool_cap) : 0u;
-    const unsigned n_nxy = (tix > 0 && tiy > 0) ? min(A.hdr->tile_count[t - pt.nty - 1], (unsigned)A.pool_cap) : 0u;
-    // the lane's four words of the slot: owned cells gather their neighbours' halo words (nb* = word in that tile's slot, -1: none)
+    const bool any_carry = A.hdr->any_carry != 0u;
+    const int C = sp[t], base_b = sp[64 + t];
+    const unsigned n_own = (unsigned)sp[128 + t];
+
+    // ---- the tile's own words: wave g adds chunks g, g + 16, ... (16-byte loads, 8 in flight when no chunk can be empty)
     const int k0 = j * RED_CELLS + lane * 4;
-    int nbx[4], nby[4], nbxy[4];
-    bool any_nb = false;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int k = k0 + u;
-        const int lx = k / ltyz, rem = k - lx * ltyz, ly = rem / gz, z = rem - ly * gz;
-        const bool owned = k < nwords && lx < tx && ly < ty;
-        nbx[u] = (owned && lx == 0 && tix > 0) ? pt.tx * ltyz + ly * gz + z : -1;
-        nby[u] = (owned && ly == 0 && tiy > 0) ? lx * ltyz + pt.ty * gz + z : -1;
-        nbxy[u] = (owned && lx == 0 && ly == 0 && tix > 0 && tiy > 0) ? pt.tx * ltyz + pt.ty * gz + z : -1;
-        any_nb |= nbx[u] >= 0 || nby[u] >= 0;
-    }
     unsigned long long acc[4] = {0ull, 0ull, 0ull, 0ull};
     float facc[4] = {0.f, 0.f, 0.f, 0.f};
-    const int64_t cstride = (int64_t)T * slot;
     if (k0 < nwords) {   // (k0 + 3 < slot: both are multiples of 4)
-        const uint32_t* base = A.partials + (int64_t)t * slot + k0;
-        for (int c = cg; c < C; c += RED_GROUPS) {
-            if (!v3_chunk_live(n_own, t, c, C)) continue;
-            const uint4 v = *reinterpret_cast<const uint4*>(base + (int64_t)c * cstride);
+        const uint32_t* base = A.partials + (int64_t)base_b * slot + k0;
+        auto add = [&](const uint4 v) {
             if (raw) { acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w; }
             else { facc[0] += __uint_as_float(v.x); facc[1] += __uint_as_float(v.y); facc[2] += __uint_as_float(v.z); facc[3] += __uint_as_float(v.w); }
-        }
-    }
-    if (__any(any_nb)) {
-        for (int c = cg; c < C; c += RED_GROUPS) {
-            const int64_t cb = (int64_t)c * cstride;
-            const bool lx_ = tix > 0 && v3_chunk_live(n_nx, t - pt.nty, c, C), ly_ = tiy > 0 && v3_chunk_live(n_ny, t - 1, c, C),
-                       lxy_ = tix > 0 && tiy > 0 && v3_chunk_live(n_nxy, t - pt.nty - 1, c, C);
+        };
+        const bool full = n_own >= 64u * (unsigned)C;   // >= 64 records per chunk: none is empty
+        int c = cg;
+        if (full) {
+            for (; c + 7 * RED_GROUPS < C; c += 8 * RED_GROUPS) {
+                uint4 v[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                uint32_t a = 0u, b = 0u, d = 0u;
-                if (lx_ && nbx[u] >= 0) a = A.partials[cb + (int64_t)(t - pt.nty) * slot + nbx[u]];
-                if (ly_ && nby[u] >= 0) b = A.partials[cb + (int64_t)(t - 1) * slot + nby[u]];
-                if (lxy_ && nbxy[u] >= 0) d = A.partials[cb + (int64_t)(t - pt.nty - 1) * slot + nbxy[u]];
-                if (raw) acc[u] += (unsigned long long)a + b + d;
-                else facc[u] += (__uint_as_float(a) + __uint_as_float(b)) + __uint_as_float(d);
+                for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const uint4*>(base + (int64_t)(c + q * RED_GROUPS) * slot);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) add(v[q]);
             }
         }
+        for (; c < C; c += RED_GROUPS)
+            if (full || v3_chunk_live(n_own, c, C, base_b + c)) add(*reinterpret_cast<const uint4*>(base + (int64_t)c * slot));
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) part[cg][lane * 4 + u] = raw ? acc[u] : (unsigned long long)__float_as_uint(facc[u]);
+
+    // ---- which cells of this block gather halo words (x / y / diagonal neighbour's column tx, row ty)
+    const int k = j * RED_CELLS + tid;
+    int lx = 0, ly = 0, z = 0;
+    bool owned = false;
+    if (tid < RED_CELLS && k < nwords) {
+        lx = k / ltyz;
+        const int rem = k - lx * ltyz;
+        ly = rem / gz; z = rem - ly * gz;
+        owned = lx < tx && ly < ty;
+        if (owned) {
+            const bool bx = lx == 0 && tix > 0, by = ly == 0 && tiy > 0;
+            const int cnt = (bx ? 1 : 0) + (by ? 1 : 0) + (bx && by ? 1 : 0);
+            if (cnt) {
+                int at = atomicAdd(&nb_n, cnt);
+                if (bx && at < V3_RED_NB) { nb_cell[at] = tid; nb_word[at] = pt.tx * ltyz + ly * gz + z; nb_tile[at] = t - pt.nty; ++at; }
+                if (by && at < V3_RED_NB) { nb_cell[at] = tid; nb_word[at] = lx * ltyz + pt.ty * gz + z; nb_tile[at] = t - 1; ++at; }
+                if (bx && by && at < V3_RED_NB) { nb_cell[at] = tid; nb_word[at] = pt.tx * ltyz + pt.ty * gz + z; nb_tile[at] = t - pt.nty - 1; }
+            }
+        }
+    }
+    __syncthreads();
+    // (halo word, chunk) pairs spread over all 1 024 threads; LDS atomics (64-bit) collect them per cell
+    {
+        const int nn = min(nb_n, V3_RED_NB);
+        int Cm = 1;
+        if (tix > 0) Cm = max(Cm, sp[t - pt.nty]);
+        if (tiy > 0) Cm = max(Cm, sp[t - 1]);
+        if (tix > 0 && tiy > 0) Cm = max(Cm, sp[t - pt.nty - 1]);
+        const int items = nn * Cm;
+        for (int it = tid; it < items; it += 64 * RED_GROUPS) {
+            const int e = it / Cm, c = it - e * Cm;
+            const int tn = nb_tile[e];
+            const int Cn = sp[tn], bn = sp[64 + tn];
+            const unsigned nn_rec = (unsigned)sp[128 + tn];
+            if (c >= Cn || !(nn_rec >= 64u * (unsigned)Cn || v3_chunk_live(nn_rec, c, Cn, bn + c))) continue;
+            const uint32_t v = A.partials[(int64_t)(bn + c) * slot + nb_word[e]];
+            if (raw) { if (v) atomicAdd(&extra[nb_cell[e]], (unsigned long long)v); }
+            else if (v) atomicAdd(reinterpret_cast<float*>(&extra[nb_cell[e]]), __uint_as_float(v));
+        }
+    }
     __syncthreads();
     unsigned long long key = 0ull;
-    const int k = j * RED_CELLS + tid;
-    if (tid < RED_CELLS && k < nwords) {
-        const int lx = k / ltyz, rem = k - lx * ltyz, ly = rem / gz, z = rem - ly * gz;
-        if (lx < tx && ly < ty) {
-            const int64_t cell = ((int64_t)(x0 + lx) * gy + (y0 + ly)) * gz + z;
-            float v;
-            if (raw) {
-                unsigned long long s = 0ull;
+    if (owned) {
+        const int64_t cell = ((int64_t)(x0 + lx) * gy + (y0 + ly)) * gz + z;
+        float v;
+        if (raw) {
+            unsigned long long s_ = extra[tid];
 #pragma unroll
-                for (int g = 0; g < RED_GROUPS; ++g) s += part[g][tid];
-                const unsigned nc = min(A.hdr->carry_n, (unsigned)V3_CARRY_MAX);
-                for (unsigned i = 0; i < nc; ++i) s += A.hdr->carry[i] == (unsigned)cell ? 4294967296ull : 0ull;
-                v = (float)((double)s * (double)A.hdr->quantum);   // s < 2^53, the quantum a power of two: one rounding
-            } else {
-                v = 0.f;
-#pragma unroll
-                for (int g = 0; g < RED_GROUPS; ++g) v = v + __uint_as_float((uint32_t)part[g][tid]);
+            for (int g = 0; g < RED_GROUPS; ++g) s_ += part[g][tid];
+            if (any_carry) {   // 2^32 per logged wrap-around of this cell; the plane is left clean for the next launch
+                const unsigned wraps = A.plane[cell];
+                if (wraps) { s_ += (unsigned long long)wraps << 32; A.plane[cell] = 0u; }
             }
-            if (A.accumulate) v = A.grid[cell] + v;
-            A.grid[cell] = v;
-            key = ((unsigned long long)f2ord(v) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)cell);
+            v = (float)((double)s_ * (double)A.hdr->quantum);   // s < 2^53, the quantum a power of two: one rounding
+        } else {
+            v = __uint_as_float((uint32_t)extra[tid]);
+#pragma unroll
+            for (int g = 0; g < RED_GROUPS; ++g) v = v + __uint_as_float((uint32_t)part[g][tid]);
         }
+        if (A.accumulate) v = A.grid[cell] + v;
+        A.grid[cell] = v;
+        key = ((unsigned long long)f2ord(v) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)cell);
     }
     if (tid < RED_CELLS) {
         key = wave_max_u64(key);
@@ -1950,7 +2022,11 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, in
     }
 }
 
-extern "C" size_t cppf_vote_workspace_init_bytes(void) { return VOTE_WS_PART + V3_HDR_BYTES; }
+// header + the largest carry plane a tiled grid can have (64 tiles): what must be zero before the first call on a fresh workspace
+extern "C" size_t cppf_vote_workspace_init_bytes(void)
+{
+    return VOTE_WS_PART + V3_HDR_BYTES + V3_PLANE_BYTES;
+}
 
 // host side of the binned path; returns a negative CPPF_E* / positive hipError_t, or 0
 static bool v3_eligible(int64_t n_ppfs, int n_rots, int gx, int gy, int gz)
@@ -1962,12 +2038,13 @@ static bool v3_eligible(int64_t n_ppfs, int n_rots, int gx, int gy, int gz)
 static size_t v3_workspace_bytes(int64_t n_ppfs, int gx, int gy, int gz)
 {
     const V3Tiling t = v3_tiling(gx, gy, gz);
-    return v3_plan(n_ppfs, t, gz, v3_chunks(n_ppfs, t.T), n_ppfs).total;
+    return v3_plan(n_ppfs, t, gz, v3_wgs(n_ppfs, t.T), n_ppfs, (int64_t)gx * gy * gz).total;
 }
 static size_t v3_workspace_bytes_dyn(int many_tiles, int64_t n_ppfs)
 {
     const int t_cap = many_tiles ? VOTE_MAX_TILES : 3, wgs = many_tiles ? 1024 : 256;
-    return VOTE_WS_PART + V3_HDR_BYTES + align_up((size_t)t_cap * (size_t)n_ppfs * 12, 256) + (size_t)wgs * V3_TILE_FLOATS * sizeof(uint32_t);
+    return VOTE_WS_PART + V3_HDR_BYTES + V3_PLANE_BYTES + align_up((size_t)t_cap * (size_t)n_ppfs * 12, 256) +
+           (size_t)wgs * V3_TILE_FLOATS * sizeof(uint32_t);
 }
 static int v3_launch(const float* points, const float* outputs, const float* probs, const void* point_idxs, int idx_is_i64,
                      float* grid_obj, const float* corner, float res, int64_t n_points, int64_t n_ppfs, int n_rots, int gx, int gy,
@@ -1985,20 +2062,22 @@ static int v3_launch(const float* points, const float* outputs, const float* pro
     A.out_idx = want_argmax ? out_idx : nullptr; A.out_val = want_argmax ? out_val : nullptr;
     A.tab_entries = tri(n_rots);
     A.pool_cap = n_ppfs;
-    A.pool = reinterpret_cast<uint32_t*>(ws + VOTE_WS_PART + V3_HDR_BYTES);
+    A.plane = reinterpret_cast<uint32_t*>(ws + VOTE_WS_PART + V3_HDR_BYTES);
     int red_blocks;
     if (shape_dev) {
         A.t_cap = many_tiles ? VOTE_MAX_TILES : 3;
         A.wgs = many_tiles ? 1024 : 256;
-        A.partials = reinterpret_cast<uint32_t*>(ws + VOTE_WS_PART + V3_HDR_BYTES + align_up((size_t)A.t_cap * (size_t)n_ppfs * 12, 256));
+        if (grid_cap > (int64_t)A.t_cap * V3_TILE_FLOATS) return CPPF_EINVAL;   // (a grid of the class has at most that many cells)
+        A.pool = reinterpret_cast<uint32_t*>(ws + VOTE_WS_PART + V3_HDR_BYTES + V3_PLANE_BYTES);
+        A.partials = A.pool + align_up((size_t)A.t_cap * (size_t)n_ppfs * 12, 256) / 4;
         const int bps = ((V3_TILE_FLOATS + RED_CELLS - 1) / RED_CELLS + RED_FANIN - 1) / RED_FANIN * RED_FANIN;
         red_blocks = A.t_cap * bps;
     } else {
         A.t = v3_tiling(gx, gy, gz);
-        A.C = v3_chunks(n_ppfs, A.t.T);
-        A.wgs = A.t.T * A.C;
+        A.wgs = v3_wgs(n_ppfs, A.t.T);
         A.t_cap = A.t.T;
-        const V3Plan pl = v3_plan(n_ppfs, A.t, gz, A.C, n_ppfs);
+        const V3Plan pl = v3_plan(n_ppfs, A.t, gz, A.wgs, n_ppfs, (int64_t)gx * gy * gz);
+        A.pool = reinterpret_cast<uint32_t*>(ws + pl.pool_off);
         A.partials = reinterpret_cast<uint32_t*>(ws + pl.part_off);
         const int bps = ((pl.slot + RED_CELLS - 1) / RED_CELLS + RED_FANIN - 1) / RED_FANIN * RED_FANIN;
         red_blocks = A.t.T * bps;
@@ -2009,9 +2088,9 @@ static int v3_launch(const float* points, const float* outputs, const float* pro
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&v3_vote_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    const int64_t rounds = (n_ppfs + V3_THREADS - 1) / V3_THREADS;
+    const int64_t rounds = (n_ppfs + V3_BIN_THREADS - 1) / V3_BIN_THREADS;
     const size_t lds_bin = (size_t)V3_STAGE * 16 + VOTE_BELOW_N * 16 + 2 * VOTE_MAX_TILES * 4 + 64;
-    hipLaunchKernelGGL(v3_bin_kernel, dim3((unsigned)(rounds < 512 ? rounds : 512)), dim3(V3_THREADS), lds_bin, st, A);
+    hipLaunchKernelGGL(v3_bin_kernel, dim3((unsigned)(rounds < 512 ? rounds : 512)), dim3(V3_BIN_THREADS), lds_bin, st, A);
     CPPF_CHECK_LAUNCH();
     const size_t lds_vote = V3_LDS_HEAD + (size_t)(A.tab_entries + 2) * sizeof(float2) + (size_t)V3_TILE_FLOATS * sizeof(float);
     hipLaunchKernelGGL(v3_vote_kernel, dim3((unsigned)A.wgs), dim3(V3_THREADS), lds_vote, st, A);
@@ -2051,7 +2130,7 @@ static int vote_impl(const float* points, const float* outputs, const float* pro
         pl.tab_entries = tri(n_rots);
         pl.T = many_tiles ? VOTE_MAX_TILES : 3;                       // most tiles this launch geometry serves
         pl.chunks = (many_tiles ? VOTE_WGS_MANY : VOTE_WGS_FEW);      // workgroups launched (>= T * chunks of any plan)
-        pl.part_off = VOTE_WS_PART;
+        pl.part_off = VOTE_WS_LEGACY_PART;
         pl.total = cppf_vote_workspace_bytes_dyn(many_tiles);
     } else {
         pl = make_vote_plan(n_ppfs, n_rots, gx, gy, gz);

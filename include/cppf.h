@@ -151,10 +151,10 @@ size_t cppf_vote_workspace_bytes_dyn(int many_tiles);
  * give cppf_vote_argmax_dyn this many bytes to run the round-3 kernels; with only cppf_vote_workspace_bytes_dyn() bytes it
  * runs the round-2 kernels. */
 size_t cppf_vote_workspace_bytes_dyn_pairs(int many_tiles, int64_t n_ppfs);
-/* The vote workspace keeps a small header between calls (queue counters, see the note on workspaces above): its first
- * cppf_vote_workspace_init_bytes() bytes must be ZERO before the first call on a fresh allocation (hipMemsetAsync once);
- * every call leaves the header ready for the next one.  A call on an uninitialised workspace reports arg-max -1 / peak NaN
- * (and leaves the workspace usable). */
+/* The vote workspace keeps state between calls (queue counters and the plane of fixed-point wrap-arounds, see the note on
+ * workspaces above): its first min(cppf_vote_workspace_init_bytes(), size) bytes must be ZERO before the first call on a
+ * fresh allocation (one hipMemsetAsync); every call leaves them ready for the next one.  A call on a workspace whose header
+ * was never initialised reports arg-max -1 / peak NaN. */
 size_t cppf_vote_workspace_init_bytes(void);
 int cppf_vote_argmax_dyn(const float* points, const float* outputs, const float* probs, const void* point_idxs,
                          int idx_is_i64, float* grid_obj, int64_t grid_capacity, const float* corner, float res,
