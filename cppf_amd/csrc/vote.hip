@@ -139,7 +139,7 @@ __host__ __device__ inline int vote_fixed_bits_of(int64_t chunk_pairs, int n_rot
 #define VOTE_WS_PART (256 + ((VOTE_TAB_LDS_MAX + 2) * 8 + 255) / 256 * 256)
 // [VOTE_WS_PART, VOTE_WS_PART + VOTE_WS_V3_STATE): the binned path's state between calls (queue header + carry plane, see V3Hdr);
 // the round-2 kernels' partial grids start behind it, so a call that takes them (n_rots > 72, an empty pair list) leaves it intact
-#define VOTE_WS_V3_STATE (8704 + 64 * 32768 * 4)
+#define VOTE_WS_V3_STATE (8704 + 64 * 30720 * 8)
 #define VOTE_WS_LEGACY_PART (VOTE_WS_PART + VOTE_WS_V3_STATE)
 #define VOTE_TAB_STAMP 0x43505046726f7400ull   // "CPPFrot\0" ^ n_rots: table valid
 // The launch that builds the table must not be able to read it back: workgroups of that same launch that start late
@@ -1189,7 +1189,7 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void reduce_tiles_kernel(RedArgs R
 //      run and between the by-value, *_dyn and pair-sharded forms although the queues fill in a racy order.
 // `v3_vote_kernel`, workgroup (tile t, chunk c), consumes records [c n_t / C, (c+1) n_t / C) of tile t's queue: exact frame
 // again (12 B/record of HBM traffic instead of 52), then the run walk of vote_kernel.
-#define V3_TILE_FLOATS 32768      // 128 KiB of LDS for the tile incl. its halo
+#define V3_TILE_FLOATS 30720      // 120 KiB of LDS for the tile incl. its halo
 #define V3_STAGE 3072             // staged records per flush (16 B each in LDS: 48 KiB, two to three workgroups per CU)
 #define V3_MAGIC 0x43503356u
 #define V3_THREADS 1024
@@ -1198,18 +1198,19 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void reduce_tiles_kernel(RedArgs R
 struct V3Hdr {                    // workspace + VOTE_WS_PART; all zero (or left by a previous call) when a launch starts
     unsigned int tile_count[VOTE_MAX_TILES * V3_CNT_STRIDE];   // records in each tile's queue, one counter per 128-byte line
     unsigned int flags;           // 1: the workspace was not initialised / a capacity was exceeded -> arg-max -1, peak NaN
-    unsigned int any_carry;       // some partial tile logged a 2^32 wrap-around in this launch (see the carry plane)
+    unsigned int any_extra;       // some workgroup added to the extra plane in this launch
     unsigned int magic;           // 0 (fresh, zeroed) or V3_MAGIC
     unsigned int fmt;             // partial tiles: 0 = raw fixed point, 1 = fp32 (negative / non-finite probs)
     float quantum;                // value of one fixed-point unit (p2 / 2^kk)
     unsigned int done;            // ticket of the reduce blocks (the last one re-zeroes this header)
     unsigned int pad[2];
 };
-// Behind the header: the CARRY PLANE, one u32 per grid cell = the 2^32 wrap-arounds the partial tiles logged for that cell
-// (a handful of cells around the vote peak, a few per workgroup).  Zero between launches: the reduce kernel reads it with the
-// cell and clears what it finds.
+// Behind the header: the EXTRA PLANE, one u64 per grid cell, for what a workgroup's partial tile cannot hand to the reduce
+// kernel in place: the words of its HALO (cells the neighbour tile owns; non-zero ones only, a few hundred per workgroup) and
+// 2^32 per logged wrap-around of a 32-bit cell.  Added with device-scope 64-bit atomics when the tile is dumped; zero between
+// launches: the reduce kernel reads it with the cell and clears what it finds.  (fp32 partial tiles: the low word is a float.)
 #define V3_HDR_BYTES ((sizeof(V3Hdr) + 255) / 256 * 256)
-#define V3_PLANE_BYTES ((size_t)VOTE_MAX_TILES * V3_TILE_FLOATS * sizeof(uint32_t))
+#define V3_PLANE_BYTES ((size_t)VOTE_MAX_TILES * V3_TILE_FLOATS * sizeof(unsigned long long))
 static_assert(V3_HDR_BYTES + V3_PLANE_BYTES <= VOTE_WS_V3_STATE, "VOTE_WS_V3_STATE too small");
 
 struct V3Tiling { int tx, ty, ntx, nty, T, hx, hy; };   // hx / hy: the grid is cut along x / y (tiles carry a halo column / row)
@@ -1271,7 +1272,7 @@ static V3Plan v3_plan(int64_t n_ppfs, const V3Tiling& t, int gz, int wgs, int64_
 {
     V3Plan p;
     p.t = t; p.wgs = wgs; p.slot = v3_slot_words(t, gz); p.pool_cap = cap;
-    // (the carry plane has a FIXED place and size -- the most cells a tiled grid can have -- whatever the grid: a workspace serves
+    // (the extra plane has a FIXED place and size -- the most cells a tiled grid can have -- whatever the grid: a workspace serves
     // calls with different grids, and the plane's "zero between launches" invariant must not depend on the previous layout)
     p.pool_off = VOTE_WS_PART + V3_HDR_BYTES + V3_PLANE_BYTES;
     (void)cells;
@@ -1297,7 +1298,7 @@ struct V3Args {
     const int32_t* shape;  // {n_points, gx, gy, gz} in device memory, or null
     int64_t grid_cap;
     V3Hdr* hdr;
-    uint32_t* plane;       // carry plane, one word per grid cell
+    unsigned long long* plane;   // extra plane, one u64 per grid cell
     uint32_t* pool;        // [T][pool_cap][3]
     int64_t pool_cap;
     uint32_t* partials;    // [wgs][slot]: workgroup b's tile
@@ -1307,6 +1308,8 @@ struct V3Args {
     long long* out_idx;
     float* out_val;
     int tab_entries;
+    int fused;             // < 4 tiles: no queues, workgroup (tile, chunk) culls and screens its own pairs (chunks = wgs / T)
+    int kk;                // fused, by-value launches: fixed-point bits (the chunks are static)
 };
 
 // *_dyn: the plan from the dims record, identically in all three kernels; false = the record does not fit the launch
@@ -1327,6 +1330,14 @@ __device__ __forceinline__ bool v3_resolve(const V3Args& A, int& gx, int& gy, in
 __device__ __forceinline__ void v3_split(const V3Args& A, int T, int* sp)
 {
     const int lane = threadIdx.x & 63;
+    if (A.fused) {   // static chunks of the pair list, the same number for every tile; "records" = pairs of a chunk (never empty)
+        if (threadIdx.x < 64) {
+            const int C = lane < T ? A.wgs / T : 0;
+            sp[lane] = C; sp[64 + lane] = lane * C; sp[128 + lane] = 0x7fffffff;
+            if (lane == 0) sp[192] = (int)((A.n_ppfs + C - 1) / C);
+        }
+        return;
+    }
     if (threadIdx.x < 64) {
         const unsigned n = lane < T ? min(A.hdr->tile_count[lane * V3_CNT_STRIDE], (unsigned)A.pool_cap) : 0u;
         const int nonempty = __popcll(__ballot(n > 0u));
@@ -1593,13 +1604,16 @@ __device__ __forceinline__ void v3_deposit(const V3Tile& T, f3 v, float prob)
     atomicAdd(t + T.ltyz + T.gz, hh * w0z * prob); atomicAdd(t + T.ltyz + T.gz + 1, hh * rz * prob);
 }
 
-#define V3_LDS_HEAD (VOTE_CARRY_CAP * 4 + 64 + VOTE_BELOW_N * 16)
+#define V3_LDS_HEAD (VOTE_CARRY_CAP * 4 + (V3_THREADS / 64) * VOTE_PAIRQ * 4 + 64 + VOTE_BELOW_N * 16)
+template <bool FUSED>
 __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    // LDS: [carry log 8 KiB][ctrl 64 B][arc-mask table 97 x 16 B][rotation table (+2 spare)][tile incl. halo]
+    // LDS: [carry log 8 KiB][pair queues 16 x 128 x u32 = 8 KiB (fused mode)][ctrl 64 B][arc-mask table 97 x 16 B]
+    //      [rotation table (+2 spare)][tile incl. halo]
     uint32_t* carry_log = reinterpret_cast<uint32_t*>(lds);
-    int* ctrl = reinterpret_cast<int*>(carry_log + VOTE_CARRY_CAP);   // [0] carry count, [4] next batch of 64 records, [8..] probs summary
+    uint32_t* pairq = carry_log + VOTE_CARRY_CAP + (threadIdx.x >> 6) * VOTE_PAIRQ;
+    int* ctrl = reinterpret_cast<int*>(carry_log + VOTE_CARRY_CAP + (V3_THREADS / 64) * VOTE_PAIRQ);   // [0] carry count, [4] next batch
     uint4* below = reinterpret_cast<uint4*>(ctrl + 16);
     float2* ltab = reinterpret_cast<float2*>(below + VOTE_BELOW_N);
     uint32_t* tile = reinterpret_cast<uint32_t*>(ltab + A.tab_entries + 2);
@@ -1608,6 +1622,10 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
     int64_t n_points;
     V3Tiling pt;
     if (!v3_resolve(A, gx, gy, gz, n_points, pt)) return;
+    if (FUSED) {   // (binned: the bin kernel checked)
+        const unsigned m = A.hdr->magic;
+        if (m != 0u && m != V3_MAGIC) { if (tid == 0) atomicOr(&A.hdr->flags, 1u); return; }   // workspace never initialised
+    }
     if (A.hdr->flags & 1u) return;
     int* sp = reinterpret_cast<int*>(carry_log);   // (the carry log is unused until the main loop)
     v3_split(A, pt.T, sp);
@@ -1619,11 +1637,21 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
         const int ck = sp[k], bk = sp[64 + k];
         if ((int)blockIdx.x >= bk && (int)blockIdx.x < bk + ck) { t = k; c = (int)blockIdx.x - bk; Ct = ck; n_t = (unsigned)sp[128 + k]; }
     }
-    const int kk = v3_bits((unsigned)sp[192], A.n_rots);   // every workgroup must use the same scale: the launch's largest chunk
+    // every workgroup must use the same scale: the launch's largest chunk (fused, by-value: fixed on the host, like the plan)
+    const int kk = (FUSED && !A.shape) ? A.kk : v3_bits((unsigned)sp[192], A.n_rots);
     __syncthreads();   // (sp is the carry log: everybody has read it)
     if (t < 0 && blockIdx.x != 0) return;            // more workgroups than chunks
-    const unsigned r0 = t >= 0 ? v3_bound(n_t, c, Ct) : 0u, r1 = t >= 0 ? v3_bound(n_t, c + 1, Ct) : 0u;
-    if (r0 >= r1 && blockIdx.x != 0) return;         // nothing queued for this chunk: no tile to zero or dump (the reduce kernel skips it too)
+    // binned: records [r0, r1) of the tile's queue; fused: pairs [p0, p1) of the pair list
+    unsigned r0 = 0u, r1 = 0u;
+    int64_t p0 = 0, p1 = 0;
+    if (FUSED) {
+        const int64_t cp = (A.n_ppfs + Ct - 1) / (Ct > 0 ? Ct : 1);
+        p0 = min((int64_t)c * cp, A.n_ppfs); p1 = min(p0 + cp, A.n_ppfs);
+        if (p0 >= p1 && blockIdx.x != 0) return;
+    } else {
+        if (t >= 0) { r0 = v3_bound(n_t, c, Ct); r1 = v3_bound(n_t, c + 1, Ct); }
+        if (r0 >= r1 && blockIdx.x != 0) return;     // nothing queued for this chunk: no tile to zero or dump (the reduce kernel skips it too)
+    }
     if (t < 0) t = 0;                                // (workgroup 0 of a launch without a single record: an empty tile, the launch-wide duties)
     const int tix = t / pt.nty, tiy = t - tix * pt.nty;
     const int x0 = tix * pt.tx, y0 = tiy * pt.ty;
@@ -1677,6 +1705,7 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
         }
     }
     if (tid < 2) ltab[A.tab_entries + tid] = make_float2(0.f, 0.f);
+    if (FUSED && blockIdx.x == 0 && tid < 2 + 2 * 8) A.packed[tid] = 0ull;   // arg-max keys + tickets of the reduce kernel (binned: the bin kernel did)
     // the waves' summaries of the probs go to the (still unused) carry log: two words per wave
     for (int off = 32; off > 0; off >>= 1) pm = fmaxf(pm, __shfl_xor(pm, off, 64));
     {
@@ -1713,7 +1742,7 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
     }
 
     const f3 cr = {A.corner[0], A.corner[1], A.corner[2]};
-    const float res = A.res;
+    const float res = A.res, rinv = 1.0f / res;
     V3Tile VT;
     VT.tile = tile; VT.carry_log = carry_log; VT.carry_n = ctrl;
     VT.x0 = x0; VT.y0 = y0; VT.gz = gz; VT.ltyz = ltyz; VT.res = res; VT.rres = refined_rcp(res); VT.S = S;
@@ -1724,22 +1753,20 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
     VT.loz = ceil_to_float(0.01); VT.hiz = ceil_to_float((double)gz - 1.01);
     const uint32_t* queue = A.pool + (int64_t)t * A.pool_cap * 3;
     const char* ltab_b = reinterpret_cast<const char*>(ltab);
+    // acceptance box of the coordinates whose floor cell this tile owns (fused mode's cull and arc screen)
+    const float blx = fmaxf(0.01f, (float)x0), bhx = fminf((float)gx - 1.01f, (float)(x0 + tx));
+    const float bly = fmaxf(0.01f, (float)y0), bhy = fminf((float)gy - 1.01f, (float)(y0 + ty));
+    const float blz = 0.01f, bhz = (float)gz - 1.01f;
+    const float bcx = 0.5f * (blx + bhx), bcy = 0.5f * (bly + bhy), bcz = 0.5f * (blz + bhz);
+    const float bhx_ = 0.5f * (bhx - blx), bhy_ = 0.5f * (bhy - bly), bhz_ = 0.5f * (bhz - blz);
 
-    for (;;) {
-        int blk = 0;
-        if (lane == 0) blk = atomicAdd(&ctrl[4], 1);
-        const unsigned rb0 = r0 + 64u * (unsigned)__builtin_amdgcn_readfirstlane(blk);
-        if (rb0 >= r1) break;
-        const unsigned rq = rb0 + lane;
-        // ---- one record per lane: exact frame again, runs from the record
+    // one pair per lane (`valid` lanes): exact frame, then its candidate runs -- from the record (binned) or from the arc
+    // screen against this tile (fused) -- and the run walk
+    auto process = [&](const int64_t p, const bool valid, const uint32_t ra_in, const uint32_t rb_in) {
         f3 Fcc = {0.f, 0.f, 0.f}, Fx = Fcc, Fy = Fcc;
         float Fprob = 1.f;
         int n = 0;
-        uint32_t ra = 0u, rb = 0u;
-        if (rq < r1) {
-            const uint32_t* rec = queue + (int64_t)rq * 3;
-            const uint32_t p = rec[0];
-            ra = rec[1]; rb = rec[2];
+        if (valid) {
             const float2 o = reinterpret_cast<const float2*>(A.outputs)[p];
             const int2 ij = v3_pair_idx(A, p);
             f3 a, ab, xd;
@@ -1753,8 +1780,24 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
                 n = max(n, 0);
             }
         }
-        const int s0 = (int)(ra & 0xffu), l0 = (int)((ra >> 8) & 0xffu), s1 = (int)((ra >> 16) & 0xffu), l1 = (int)(ra >> 24);
-        const int s2 = (int)(rb & 0xffu), l2 = (int)((rb >> 8) & 0xffu);
+        int s0, l0, s1, l1, s2, l2;
+        if (FUSED) {
+            const f3 cq = scl3(sub3(Fcc, cr), rinv), xq = scl3(Fx, rinv), yq = scl3(Fy, rinv);
+            const float ex = fmaf((fabsf(Fcc.x) + fabsf(cr.x) + fabsf(Fx.x) + fabsf(Fy.x)) * rinv, 1e-6f, 1e-3f);
+            const float ey = fmaf((fabsf(Fcc.y) + fabsf(cr.y) + fabsf(Fx.y) + fabsf(Fy.y)) * rinv, 1e-6f, 1e-3f);
+            const float ez = fmaf((fabsf(Fcc.z) + fabsf(cr.z) + fabsf(Fx.z) + fabsf(Fy.z)) * rinv, 1e-6f, 1e-3f);
+            const float nf = (float)n * 0.159154943f;
+            const Mask96 mx = axis_arc_mask(below, cq.x, xq.x, yq.x, blx - ex, bhx + ex, nf, n);
+            const Mask96 my = axis_arc_mask(below, cq.y, xq.y, yq.y, bly - ey, bhy + ey, nf, n);
+            const Mask96 mz = axis_arc_mask(below, cq.z, xq.z, yq.z, blz - ez, bhz + ez, nf, n);
+            const uint32_t live = n > 0 ? 0xffffffffu : 0u;
+            int e0, e1, e2;
+            mask_runs(below, mx.a & my.a & mz.a & live, mx.b & my.b & mz.b & live, mx.c & my.c & mz.c & live, s0, e0, s1, e1, s2, e2);
+            l0 = e0 - s0; l1 = e1 - s1; l2 = max(e2 - s2, 0);
+        } else {
+            s0 = (int)(ra_in & 0xffu); l0 = (int)((ra_in >> 8) & 0xffu); s1 = (int)((ra_in >> 16) & 0xffu); l1 = (int)(ra_in >> 24);
+            s2 = (int)(rb_in & 0xffu); l2 = (int)((rb_in >> 8) & 0xffu);
+        }
         const int cnt = n > 0 ? l0 + l1 + l2 : 0;
         const int incl = wave_incl_scan(cnt);
         const int total = __builtin_amdgcn_readlane(incl, 63);
@@ -1807,24 +1850,108 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
+
+    if (!FUSED) {
+        for (;;) {
+            int blk = 0;
+            if (lane == 0) blk = atomicAdd(&ctrl[4], 1);
+            const unsigned rb0 = r0 + 64u * (unsigned)__builtin_amdgcn_readfirstlane(blk);
+            if (rb0 >= r1) break;
+            const unsigned rq = rb0 + lane;
+            uint32_t p = 0u, ra = 0u, rb = 0u;
+            if (rq < r1) {
+                const uint32_t* rec = queue + (int64_t)rq * 3;
+                p = rec[0]; ra = rec[1]; rb = rec[2];
+            }
+            process((int64_t)p, rq < r1, ra, rb);
+        }
+    } else {
+        // cull (vote_kernel's, against the owned box) + compaction through a per-wave queue, blocks of 64 pairs from an LDS counter
+        int qn = 0;
+        for (;;) {
+            int blk = 0;
+            if (lane == 0) blk = atomicAdd(&ctrl[4], 1);
+            const int64_t pb = p0 + 64 * (int64_t)__builtin_amdgcn_readfirstlane(blk);
+            const bool more = pb < p1;
+            if (more) {
+                const int64_t p = pb + lane;
+                bool pass = false;
+                if (p < p1) {
+                    const float2 o = reinterpret_cast<const float2*>(A.outputs)[p];
+                    const int2 ij = v3_pair_idx(A, p);
+                    const f3 a = ld3(A.points, ij.x), b = ld3(A.points, ij.y);
+                    const f3 d = sub3(a, b);
+                    const float L = sqrtf(dot3(d, d));
+                    const float inv = __builtin_amdgcn_rcpf(L + 1e-7f);
+                    const f3 u = scl3(d, inv);
+                    const f3 cc = sub3(a, scl3(u, o.x));
+                    const float R = fabsf(o.y) * rinv;
+                    const float ex_ = R * __builtin_amdgcn_sqrtf(fmaxf(0.f, 1.f - u.x * u.x));
+                    const float ey_ = R * __builtin_amdgcn_sqrtf(fmaxf(0.f, 1.f - u.y * u.y));
+                    const float ez_ = R * __builtin_amdgcn_sqrtf(fmaxf(0.f, 1.f - u.z * u.z));
+                    const float sl = fmaf(R, 1.1e-3f, 4e-3f);
+                    const float sx = sl + 8e-6f * (fabsf(cc.x) + fabsf(cr.x)) * rinv, sy = sl + 8e-6f * (fabsf(cc.y) + fabsf(cr.y)) * rinv,
+                                sz = sl + 8e-6f * (fabsf(cc.z) + fabsf(cr.z)) * rinv;
+                    const float qx = (cc.x - cr.x) * rinv, qy = (cc.y - cr.y) * rinv, qz = (cc.z - cr.z) * rinv;
+                    const float dx = bcx - qx, dy = bcy - qy, dz = bcz - qz, sall = sl + (sx - sl) + (sy - sl) + (sz - sl);
+                    const float off_plane = fabsf((dx * u.x + dy * u.y) + dz * u.z);
+                    const float reach = (fabsf(u.x) * bhx_ + fabsf(u.y) * bhy_) + fabsf(u.z) * bhz_;
+                    const float nx = fmaxf(fabsf(dx) - bhx_, 0.f), ny = fmaxf(fabsf(dy) - bhy_, 0.f), nz = fmaxf(fabsf(dz) - bhz_, 0.f);
+                    const float fx = fabsf(dx) + bhx_, fy = fabsf(dy) + bhy_, fz = fabsf(dz) + bhz_;
+                    const float dmin2 = (nx * nx + ny * ny) + nz * nz, dmax2 = (fx * fx + fy * fy) + fz * fz;
+                    const float r_hi = R + sall, r_lo = fmaxf(R - sall, 0.f);
+                    pass = (L >= 9e-8f) & (!A.adaptive | (R >= 0.15f)) &
+                           (qx + ex_ + sx >= blx) & (qx - ex_ - sx < bhx) & (qy + ey_ + sy >= bly) & (qy - ey_ - sy < bhy) &
+                           (qz + ez_ + sz >= blz) & (qz - ez_ - sz < bhz) &
+                           (off_plane <= reach + sall) & (dmin2 <= r_hi * r_hi * 1.0001f) & (dmax2 * 1.0001f >= r_lo * r_lo);
+                }
+                const unsigned long long m = __ballot(pass);
+                if (pass)
+                    pairq[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] = (uint32_t)(p - p0);
+                qn += __popcll(m);
+            }
+            while (qn >= 64 || (!more && qn > 0)) {
+                const int take = qn < 64 ? qn : 64;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const uint32_t off = lane < take ? pairq[qn - take + lane] : 0u;
+                qn -= take;
+                process(p0 + off, lane < take, 0u, 0u);
+            }
+            if (!more) break;
+        }
     }
 
-    // ---- dump: raw fixed point (the reduce kernel adds the partial tiles as integers), wrap-arounds to the global carry list
+    // ---- dump: raw fixed point (the reduce kernel adds the partial tiles as integers); the halo's non-zero words and the logged
+    // wrap-arounds go to the extra plane instead (device-scope 64-bit atomics, a few hundred per workgroup)
     __syncthreads();
     const int slot = v3_slot_words(pt, gz);
     uint4* part4 = reinterpret_cast<uint4*>(A.partials + (int64_t)blockIdx.x * slot);
     const uint4* t4 = reinterpret_cast<const uint4*>(tile);
     for (int k = tid; k < (nwords + 3) >> 2; k += V3_THREADS) part4[k] = t4[k];
+    bool wrote = false;
+    auto to_plane = [&](const int w, const int lx, const int ly, const int z) {
+        const uint32_t v = tile[w];
+        if (v == 0u) return;
+        unsigned long long* dst = &A.plane[((int64_t)(x0 + lx) * gy + (y0 + ly)) * gz + z];
+        if (S > 0.f) atomicAdd(dst, (unsigned long long)v); else atomicAdd(reinterpret_cast<float*>(dst), __uint_as_float(v));
+        wrote = true;
+    };
+    if (pt.hx && x0 + tx < gx)       // halo column lx = tx (rows 0..ty, the diagonal cell included)
+        for (int k = tid; k < (ty + 1) * gz && k < ltyz; k += V3_THREADS) { const int ly = k / gz; to_plane(tx * ltyz + k, tx, ly, k - ly * gz); }
+    if (pt.hy && y0 + ty < gy)       // halo row ly = ty of the owned columns
+        for (int k = tid; k < tx * gz; k += V3_THREADS) { const int lx = k / gz, z = k - lx * gz; to_plane(lx * ltyz + ty * gz + z, lx, ty, z); }
     if (S > 0.f) {
         const int nc = min(ctrl[0], VOTE_CARRY_CAP);
         if (ctrl[0] > VOTE_CARRY_CAP && tid == 0) atomicOr(&A.hdr->flags, 1u);
-        if (nc > 0 && tid == 0) A.hdr->any_carry = 1u;
         for (int k = tid; k < nc; k += V3_THREADS) {
-            const int w = (int)carry_log[k];   // word of the LDS tile -> grid cell
+            const int w = (int)carry_log[k];   // word of the LDS tile -> grid cell (a halo word: the neighbour's cell)
             const int lx = w / ltyz, rem = w - lx * ltyz, ly = rem / gz, z = rem - ly * gz;
-            atomicAdd(&A.plane[((int64_t)(x0 + lx) * gy + (y0 + ly)) * gz + z], 1u);
+            atomicAdd(&A.plane[((int64_t)(x0 + lx) * gy + (y0 + ly)) * gz + z], 1ull << 32);
+            wrote = true;
         }
     }
+    if (__any(wrote) && lane == 0) A.hdr->any_extra = 1u;
 }
 
 // ---------------------------------------------------------------------------- v3_reduce_kernel
@@ -1835,18 +1962,14 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
 __device__ __forceinline__ void v3_rezero(V3Hdr* h)
 {
     for (int k = 0; k < VOTE_MAX_TILES; ++k) h->tile_count[k * V3_CNT_STRIDE] = 0u;
-    h->flags = 0u; h->any_carry = 0u; h->done = 0u; h->magic = V3_MAGIC;
+    h->flags = 0u; h->any_extra = 0u; h->done = 0u; h->magic = V3_MAGIC;
     __threadfence();
 }
-#define V3_RED_NB 768   // halo words the 256 cells of a block can have to gather: x, y and diagonal neighbour each
 __global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, int bps)
 {
     __shared__ unsigned long long part[RED_GROUPS][RED_CELLS];
-    __shared__ unsigned long long extra[RED_CELLS];      // halo words of the neighbour tiles, per cell of the block
     __shared__ unsigned long long wkey[RED_CELLS / 64];
     __shared__ int sp[200];
-    __shared__ int nb_cell[V3_RED_NB], nb_word[V3_RED_NB], nb_tile[V3_RED_NB];   // (cell of the block, word in that tile's slot, tile)
-    __shared__ int nb_n;
     const int tid = threadIdx.x, lane = tid & 63, cg = tid >> 6;
     if (blockIdx.x == 0 && tid == 0) {   // rotation table left by the vote kernel of this call: valid from the next launch on
         const unsigned long long st = A.packed[31];
@@ -1878,11 +2001,9 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, in
     const int nwords = (tx + pt.hx) * ltyz;
     if (j * RED_CELLS >= nwords) return;
     v3_split(A, T, sp);
-    if (tid < RED_CELLS) extra[tid] = 0ull;
-    if (tid == 0) nb_n = 0;
     __syncthreads();
     const bool raw = A.hdr->fmt == 0u;
-    const bool any_carry = A.hdr->any_carry != 0u;
+    const bool any_extra = A.hdr->any_extra != 0u;
     const int C = sp[t], base_b = sp[64 + t];
     const unsigned n_own = (unsigned)sp[128 + t];
 
@@ -1913,7 +2034,6 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, in
 #pragma unroll
     for (int u = 0; u < 4; ++u) part[cg][lane * 4 + u] = raw ? acc[u] : (unsigned long long)__float_as_uint(facc[u]);
 
-    // ---- which cells of this block gather halo words (x / y / diagonal neighbour's column tx, row ty)
     const int k = j * RED_CELLS + tid;
     int lx = 0, ly = 0, z = 0;
     bool owned = false;
@@ -1922,53 +2042,22 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, in
         const int rem = k - lx * ltyz;
         ly = rem / gz; z = rem - ly * gz;
         owned = lx < tx && ly < ty;
-        if (owned) {
-            const bool bx = lx == 0 && tix > 0, by = ly == 0 && tiy > 0;
-            const int cnt = (bx ? 1 : 0) + (by ? 1 : 0) + (bx && by ? 1 : 0);
-            if (cnt) {
-                int at = atomicAdd(&nb_n, cnt);
-                if (bx && at < V3_RED_NB) { nb_cell[at] = tid; nb_word[at] = pt.tx * ltyz + ly * gz + z; nb_tile[at] = t - pt.nty; ++at; }
-                if (by && at < V3_RED_NB) { nb_cell[at] = tid; nb_word[at] = lx * ltyz + pt.ty * gz + z; nb_tile[at] = t - 1; ++at; }
-                if (bx && by && at < V3_RED_NB) { nb_cell[at] = tid; nb_word[at] = pt.tx * ltyz + pt.ty * gz + z; nb_tile[at] = t - pt.nty - 1; }
-            }
-        }
-    }
-    __syncthreads();
-    // (halo word, chunk) pairs spread over all 1 024 threads; LDS atomics (64-bit) collect them per cell
-    {
-        const int nn = min(nb_n, V3_RED_NB);
-        int Cm = 1;
-        if (tix > 0) Cm = max(Cm, sp[t - pt.nty]);
-        if (tiy > 0) Cm = max(Cm, sp[t - 1]);
-        if (tix > 0 && tiy > 0) Cm = max(Cm, sp[t - pt.nty - 1]);
-        const int items = nn * Cm;
-        for (int it = tid; it < items; it += 64 * RED_GROUPS) {
-            const int e = it / Cm, c = it - e * Cm;
-            const int tn = nb_tile[e];
-            const int Cn = sp[tn], bn = sp[64 + tn];
-            const unsigned nn_rec = (unsigned)sp[128 + tn];
-            if (c >= Cn || !(nn_rec >= 64u * (unsigned)Cn || v3_chunk_live(nn_rec, c, Cn, bn + c))) continue;
-            const uint32_t v = A.partials[(int64_t)(bn + c) * slot + nb_word[e]];
-            if (raw) { if (v) atomicAdd(&extra[nb_cell[e]], (unsigned long long)v); }
-            else if (v) atomicAdd(reinterpret_cast<float*>(&extra[nb_cell[e]]), __uint_as_float(v));
-        }
     }
     __syncthreads();
     unsigned long long key = 0ull;
     if (owned) {
         const int64_t cell = ((int64_t)(x0 + lx) * gy + (y0 + ly)) * gz + z;
         float v;
+        // what the neighbours' halos and the wrap-arounds added for this cell; the plane is left clean for the next launch
+        unsigned long long ext = 0ull;
+        if (any_extra) { ext = A.plane[cell]; if (ext) A.plane[cell] = 0ull; }
         if (raw) {
-            unsigned long long s_ = extra[tid];
+            unsigned long long s_ = ext;
 #pragma unroll
             for (int g = 0; g < RED_GROUPS; ++g) s_ += part[g][tid];
-            if (any_carry) {   // 2^32 per logged wrap-around of this cell; the plane is left clean for the next launch
-                const unsigned wraps = A.plane[cell];
-                if (wraps) { s_ += (unsigned long long)wraps << 32; A.plane[cell] = 0u; }
-            }
             v = (float)((double)s_ * (double)A.hdr->quantum);   // s < 2^53, the quantum a power of two: one rounding
         } else {
-            v = __uint_as_float((uint32_t)extra[tid]);
+            v = __uint_as_float((uint32_t)ext);
 #pragma unroll
             for (int g = 0; g < RED_GROUPS; ++g) v = v + __uint_as_float((uint32_t)part[g][tid]);
         }
@@ -2038,12 +2127,12 @@ static bool v3_eligible(int64_t n_ppfs, int n_rots, int gx, int gy, int gz)
 static size_t v3_workspace_bytes(int64_t n_ppfs, int gx, int gy, int gz)
 {
     const V3Tiling t = v3_tiling(gx, gy, gz);
-    return v3_plan(n_ppfs, t, gz, v3_wgs(n_ppfs, t.T), n_ppfs, (int64_t)gx * gy * gz).total;
+    return v3_plan(n_ppfs, t, gz, v3_wgs(n_ppfs, t.T), t.T < 4 ? 0 : n_ppfs, (int64_t)gx * gy * gz).total;   // (< 4 tiles: no queues)
 }
 static size_t v3_workspace_bytes_dyn(int many_tiles, int64_t n_ppfs)
 {
     const int t_cap = many_tiles ? VOTE_MAX_TILES : 3, wgs = many_tiles ? 1024 : 256;
-    return VOTE_WS_PART + V3_HDR_BYTES + V3_PLANE_BYTES + align_up((size_t)t_cap * (size_t)n_ppfs * 12, 256) +
+    return VOTE_WS_PART + V3_HDR_BYTES + V3_PLANE_BYTES + (many_tiles ? align_up((size_t)t_cap * (size_t)n_ppfs * 12, 256) : 0) +
            (size_t)wgs * V3_TILE_FLOATS * sizeof(uint32_t);
 }
 static int v3_launch(const float* points, const float* outputs, const float* probs, const void* point_idxs, int idx_is_i64,
@@ -2062,21 +2151,27 @@ static int v3_launch(const float* points, const float* outputs, const float* pro
     A.out_idx = want_argmax ? out_idx : nullptr; A.out_val = want_argmax ? out_val : nullptr;
     A.tab_entries = tri(n_rots);
     A.pool_cap = n_ppfs;
-    A.plane = reinterpret_cast<uint32_t*>(ws + VOTE_WS_PART + V3_HDR_BYTES);
+    A.plane = reinterpret_cast<unsigned long long*>(ws + VOTE_WS_PART + V3_HDR_BYTES);
     int red_blocks;
     if (shape_dev) {
         A.t_cap = many_tiles ? VOTE_MAX_TILES : 3;
         A.wgs = many_tiles ? 1024 : 256;
+        A.fused = many_tiles ? 0 : 1;
         if (grid_cap > (int64_t)A.t_cap * V3_TILE_FLOATS) return CPPF_EINVAL;   // (a grid of the class has at most that many cells)
         A.pool = reinterpret_cast<uint32_t*>(ws + VOTE_WS_PART + V3_HDR_BYTES + V3_PLANE_BYTES);
-        A.partials = A.pool + align_up((size_t)A.t_cap * (size_t)n_ppfs * 12, 256) / 4;
+        A.partials = A.pool + (many_tiles ? align_up((size_t)A.t_cap * (size_t)n_ppfs * 12, 256) / 4 : 0);
         const int bps = ((V3_TILE_FLOATS + RED_CELLS - 1) / RED_CELLS + RED_FANIN - 1) / RED_FANIN * RED_FANIN;
         red_blocks = A.t_cap * bps;
     } else {
         A.t = v3_tiling(gx, gy, gz);
         A.wgs = v3_wgs(n_ppfs, A.t.T);
+        A.fused = A.t.T < 4 ? 1 : 0;
+        if (A.fused) {   // static chunks: the same number for every tile
+            A.wgs = (A.wgs / A.t.T) * A.t.T;
+            A.kk = v3_bits((unsigned)((n_ppfs + A.wgs / A.t.T - 1) / (A.wgs / A.t.T)), n_rots);
+        }
         A.t_cap = A.t.T;
-        const V3Plan pl = v3_plan(n_ppfs, A.t, gz, A.wgs, n_ppfs, (int64_t)gx * gy * gz);
+        const V3Plan pl = v3_plan(n_ppfs, A.t, gz, v3_wgs(n_ppfs, A.t.T), A.fused ? 0 : n_ppfs, (int64_t)gx * gy * gz);
         A.pool = reinterpret_cast<uint32_t*>(ws + pl.pool_off);
         A.partials = reinterpret_cast<uint32_t*>(ws + pl.part_off);
         const int bps = ((pl.slot + RED_CELLS - 1) / RED_CELLS + RED_FANIN - 1) / RED_FANIN * RED_FANIN;
@@ -2085,16 +2180,22 @@ static int v3_launch(const float* points, const float* outputs, const float* pro
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&v3_bin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&v3_vote_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&v3_vote_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&v3_vote_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    const int64_t rounds = (n_ppfs + V3_BIN_THREADS - 1) / V3_BIN_THREADS;
-    const size_t lds_bin = (size_t)V3_STAGE * 16 + VOTE_BELOW_N * 16 + 2 * VOTE_MAX_TILES * 4 + 64;
-    hipLaunchKernelGGL(v3_bin_kernel, dim3((unsigned)(rounds < 512 ? rounds : 512)), dim3(V3_BIN_THREADS), lds_bin, st, A);
-    CPPF_CHECK_LAUNCH();
     const size_t lds_vote = V3_LDS_HEAD + (size_t)(A.tab_entries + 2) * sizeof(float2) + (size_t)V3_TILE_FLOATS * sizeof(float);
-    hipLaunchKernelGGL(v3_vote_kernel, dim3((unsigned)A.wgs), dim3(V3_THREADS), lds_vote, st, A);
-    CPPF_CHECK_LAUNCH();
+    if (A.fused) {
+        hipLaunchKernelGGL(v3_vote_kernel<true>, dim3((unsigned)A.wgs), dim3(V3_THREADS), lds_vote, st, A);
+        CPPF_CHECK_LAUNCH();
+    } else {
+        const int64_t rounds = (n_ppfs + V3_BIN_THREADS - 1) / V3_BIN_THREADS;
+        const size_t lds_bin = (size_t)V3_STAGE * 16 + VOTE_BELOW_N * 16 + 2 * VOTE_MAX_TILES * 4 + 64;
+        hipLaunchKernelGGL(v3_bin_kernel, dim3((unsigned)(rounds < 512 ? rounds : 512)), dim3(V3_BIN_THREADS), lds_bin, st, A);
+        CPPF_CHECK_LAUNCH();
+        hipLaunchKernelGGL(v3_vote_kernel<false>, dim3((unsigned)A.wgs), dim3(V3_THREADS), lds_vote, st, A);
+        CPPF_CHECK_LAUNCH();
+    }
     const int bps = red_blocks / A.t_cap;
     hipLaunchKernelGGL(v3_reduce_kernel, dim3((unsigned)red_blocks), dim3(64 * RED_GROUPS), 0, st, A, bps);
     CPPF_CHECK_LAUNCH();

@@ -31,13 +31,13 @@ def test_workspace_queries_and_argument_errors_without_a_device():
     # raw partial tiles, and a queue of 12-byte records per tile with room for every pair
     need = L.cppf_vote_workspace_bytes(524288, 72, 26, 76, 26)
     slot = 26 * 39 * 26
-    lo = 128 * 2 * slot * 4 + 2 * 524288 * 12 + 64 * 32768 * 4      # + the carry plane, sized for any tiled grid
+    lo = 256 * slot * 4 + 64 * 30720 * 8      # fewer than 4 tiles: no queues; + the extra plane, sized for any tiled grid
     assert lo <= need < lo + (1 << 17)
     assert 65536 < L.cppf_vote_workspace_init_bytes() <= need
     # n_rots > 72 keeps the round-2 kernels: 128 chunks of fp32 partial grids, no queues
     G = 26 * 76 * 26
     need2 = L.cppf_vote_workspace_bytes(524288, 100, 26, 76, 26)
-    state = 64 * 32768 * 4 + 8704                                        # (behind the binned path's state, which they leave intact)
+    state = 64 * 30720 * 8 + 8704                                        # (behind the binned path's state, which they leave intact)
     assert need2 >= 128 * G * 4 + state and need2 < 129 * G * 4 + state
     assert L.cppf_vote_workspace_bytes(100, 0, 26, 76, 26) == 0          # n_rots out of range
     assert L.cppf_vote_workspace_bytes(100, 361, 26, 76, 26) == 0
@@ -309,7 +309,7 @@ def test_shape_polymorphic_plan_queries_without_a_device():
     assert L.cppf_vote_tiles(10, 10, 10) == 1
     assert L.cppf_vote_tiles(0, 10, 10) < 0
     assert L.cppf_vote_tiles(600, 600, 600) == 0                         # beyond the tiled vote: global atomics only
-    for dims in ((26, 76, 26), (52, 152, 52), (100, 49, 76), (5, 5, 8000)):
+    for dims in ((26, 76, 26), (52, 152, 52), (100, 49, 76), (5, 5, 4000)):
         T, many, cap = grid_class(dims)
         assert T * cells >= dims[0] * dims[1] * dims[2] and many == (T >= 4) and cap == (64 if many else 3) * cells
     # the dyn workspace holds the partial tiles of ANY plan its launch geometry can meet
