@@ -2017,7 +2017,9 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, in
             if (raw) { acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w; }
             else { facc[0] += __uint_as_float(v.x); facc[1] += __uint_as_float(v.y); facc[2] += __uint_as_float(v.z); facc[3] += __uint_as_float(v.w); }
         };
-        const bool full = n_own >= 64u * (unsigned)C;   // >= 64 records per chunk: none is empty
+        // binned: >= 64 records per chunk, none is empty; fused: chunks of cp pairs, empty from ceil(P / cp) on
+        const int64_t cp = A.fused ? (A.n_ppfs + C - 1) / (C > 0 ? C : 1) : 0;
+        const bool full = A.fused ? (int64_t)(C - 1) * cp < A.n_ppfs : n_own >= 64u * (unsigned)C;
         int c = cg;
         if (full) {
             for (; c + 7 * RED_GROUPS < C; c += 8 * RED_GROUPS) {
@@ -2029,7 +2031,8 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, in
             }
         }
         for (; c < C; c += RED_GROUPS)
-            if (full || v3_chunk_live(n_own, c, C, base_b + c)) add(*reinterpret_cast<const uint4*>(base + (int64_t)c * slot));
+            if (full || (A.fused ? (base_b + c == 0 || (int64_t)c * cp < A.n_ppfs) : v3_chunk_live(n_own, c, C, base_b + c)))
+                add(*reinterpret_cast<const uint4*>(base + (int64_t)c * slot));
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) part[cg][lane * 4 + u] = raw ? acc[u] : (unsigned long long)__float_as_uint(facc[u]);
