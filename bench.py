@@ -8,8 +8,11 @@
 
 A step = one pass of the hot path over one object (default --config c2: N=4096 points, K=128 pairs/point -> P=524 288 pairs;
 BASELINE.json configs[1] sizes, fused HIP path): inputs (points, normals, 40-d point features, int64 pair indices, uniforms,
-packed weights) already resident in HBM; per step four kernels run (per-point layer-0 projection, fused PPF+MLP+decode of all
-141 logits, LDS-tiled vote reading the int64 pair list directly, reduce+arg-max), replayed from a hipGraph.  Steps ROTATE over
+packed weights) already resident in HBM; per step four kernels run (per-point layer-0 projection, fused PPF+MLP+decode of the
+two centre heads -- the 64 logits nocs/inference.py:185-188 consumes up to the arg-max; the orientation / scale heads belong to the
+second pass on the back-vote's survivors, :236-256, as in the reference and in PosePipeline -- LDS-tiled vote reading the int64
+pair list directly, reduce+arg-max), replayed from a hipGraph.  `--all-heads` decodes all 141 logits of every pair in the first
+pass instead (round 1-2's headline; reported as a secondary by the default run).  Steps ROTATE over
 9 distinct objects (own seeds, own buffers, ~70 MB each: more than the 256 MB Infinity Cache holds), so every step streams its
 pair list and uniforms from HBM.  With N GPUs every rank processes its own objects (weak scaling) and ONE all_gather of the K
 result records closes the batch inside the timed region.
@@ -41,8 +44,10 @@ from cppf_amd.models import voting                    # noqa: E402
 from cppf_amd.models.model import PPFEncoder         # noqa: E402
 
 NUM_ROTS = 72
-FLOP_PER_PAIR = 23968            # 2 x 11 984 MAC of the pair MLP: the algorithmic work of the path
-FLOP_PER_PAIR_EXECUTED = 13728   # what the pair kernel issues after hoisting 2x40 layer-0 columns to a per-point table
+FLOP_PER_PAIR = 23968            # 2 x 11 984 MAC of the pair MLP with all 141 outputs
+FLOP_PER_PAIR_CENTRE = 21504     # the same with the 64 centre-bin outputs only (final layer 16 x 64 instead of 16 x 141): 2 x 10 752 MAC
+FLOP_PER_PAIR_EXECUTED = 13728   # what the all-heads pair kernel issues after hoisting 2x40 layer-0 columns to a per-point table
+FLOP_PER_PAIR_CENTRE_EXECUTED = 11168   # ... and the centre-heads kernel (20 of the 108 MFMAs per 16-pair tile fewer)
 PEAK_F32_MFMA = 157.3            # TFLOP/s, MI355X_MICROARCH.md
 PEAK_HBM = 8000.0                # GB/s
 METRIC = "point-pairs/sec (PPF+MLP+vote+argmax), N=4096 K=128; 1/2/4/8 GPU"
@@ -78,7 +83,7 @@ def host_threads():
     return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 
 
-def oracle_center(o, sd, budget_s=0.0, max_reps=1):
+def oracle_center(o, sd, budget_s=0.0, max_reps=1, all_heads=False):
     """The oracle chain (CPU restatement, all host cores via OpenMP) on one object: (arg-max, pairs/s, repetitions)."""
     from oracle import oracle as O
     threads = host_threads()
@@ -91,7 +96,8 @@ def oracle_center(o, sd, budget_s=0.0, max_reps=1):
         t0 = time.perf_counter()
         logits = O.pair_mlp(o["ob"]["pc"], o["ob"]["normals"], o["ob"]["feat"], idx, sd, cfg.ppffcs, cfg.out_dim, order=1)
         outputs, _ = O.decode_center(logits, o["u_tr"], cfg.tr_num_bins, cfg.vote_range)
-        O.decode_rot(logits, o["u_rot"], cfg.tr_num_bins, cfg.rot_num_bins)
+        if all_heads:
+            O.decode_rot(logits, o["u_rot"], cfg.tr_num_bins, cfg.rot_num_bins)
         grid = np.zeros(o["dims"], np.float32)
         O.ppf_voting(o["ob"]["pc"], outputs, probs, idx32, grid, o["corners"][0], cfg.res, NUM_ROTS, True, threads=threads)
         flat, _ = O.grid_argmax(grid)
@@ -145,8 +151,8 @@ class TrainedRegimePipeline(CenterPipeline):
 
     def _chain(self):
         self.outputs, self.heads = self.encoder.forward_decode(self.pc, self.nrm, self.feat, self.idx, self.u_tr,
-                                                               self.cfg.vote_range, self.u_rot, self.cfg.tr_num_bins,
-                                                               self.cfg.rot_num_bins)
+                                                               self.cfg.vote_range, self.u_rot if self.with_heads else None,
+                                                               self.cfg.tr_num_bins, self.cfg.rot_num_bins)
         voting.vote_argmax(self.pc, self.out_ka, None, self.idx, self.grid, self.corner, self.cfg.res, self.num_rots,
                            self.adaptive, self.out_idx, self.out_val, accumulate=False)
 
@@ -190,7 +196,8 @@ def run_center_config(name, enc, sd, dev, rank, world, args):
     n_points, k = (args.n_points or c["n_points"]), (args.pairs_per_point or c["k"])
     n_streams = max(1, args.streams)
     n_obj = max(n_streams, -(-args.objects // n_streams) * n_streams)      # a multiple of the streams: pipe j stays on stream j mod S
-    objs = make_center_set(enc, dev, n_points, k, c["res"], n_obj, seed0=100 * rank, use_graph=not args.no_graph)
+    objs = make_center_set(enc, dev, n_points, k, c["res"], n_obj, seed0=100 * rank, with_heads=args.all_heads,
+                           use_graph=not args.no_graph)
     pipes = [o["pipe"] for o in objs]
     P = objs[0]["idx"].shape[0]
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
@@ -247,7 +254,9 @@ def run_center_config(name, enc, sd, dev, rank, world, args):
 def workload_text(name, m, args):
     d = m["objs"][0]["dims"]
     return (f"{name}: single object N={m['n_points']} K={m['k']} (P={m['P']} pairs), bottle config, res {m['objs'][0]['cfg'].res:g}, "
-            f"grid {d[0]}x{d[1]}x{d[2]}, num_rots 72 adaptive, fused PPF+MLP(MFMA f32)+decode -> LDS-tiled vote -> argmax "
+            f"grid {d[0]}x{d[1]}x{d[2]}, num_rots 72 adaptive, fused PPF+MLP(MFMA f32)+decode of " +
+            ("all 141 logits" if args.all_heads else "the 64 centre-bin logits (what the chain consumes up to the arg-max; the other heads "
+             "belong to the second pass on the survivors)") + " -> LDS-tiled vote -> argmax "
             f"({m['what']}); one object per GPU per step, steps rotate over {m['n_obj']} distinct objects (own buffers: inputs come "
             "from HBM, not the Infinity Cache), " +
             (f"{m['n_streams']} independent objects in flight on {m['n_streams']} HIP streams; " if m["n_streams"] > 1
@@ -311,6 +320,8 @@ def main():
     ap.add_argument("--objects", type=int, default=9, help="distinct objects the steps rotate over (rounded up to a multiple of "
                     "--streams); 9 x ~70 MB of buffers exceed the 256 MB Infinity Cache")
     ap.add_argument("--no-graph", action="store_true", help="launch the chain eagerly instead of replaying a hipGraph")
+    ap.add_argument("--all-heads", action="store_true", help="first pass decodes all 141 logits of every pair (round 1-2's headline) "
+                    "instead of the two centre heads")
     ap.add_argument("--n-points", type=int, default=0, help="exploration only; overrides the config's N")
     ap.add_argument("--pairs-per-point", type=int, default=0, help="exploration only; overrides the config's K")
     args = ap.parse_args()
@@ -369,15 +380,37 @@ def main():
                                           ws.out_idx, ws.out_val, accumulate=False)
 
     with torch.no_grad():
-        t_mlp = bracket([mlp_fn(o) for o in objs], n_ev)     # ms
+        t_mlp_all = bracket([mlp_fn(o, True) for o in objs], n_ev) if (args.all_heads or secondary) else None     # ms
+        t_mlp_tr = bracket([mlp_fn(o, False) for o in objs], n_ev) if (not args.all_heads or secondary) else None
+        t_mlp = t_mlp_all if args.all_heads else t_mlp_tr          # the pair stage of the timed chain
         t_vote = bracket([vote_fn(o, ws, o["pipe"].outputs) for o, ws in zip(objs, wss)], n_ev)
 
-    # secondary: the pair encoder decoding only the two centre heads (all the centre vote consumes; the reference computes the
-    # other 77 logits in this pass too and throws them away, nocs/inference.py:182-188).  `value` is measured with all heads.
-    t_mlp_tr = None
-    if secondary:
-        with torch.no_grad():
-            t_mlp_tr = bracket([mlp_fn(o, False) for o in objs], n_ev)
+    # secondary: the chain with all 141 logits decoded in the first pass (round 1-2's headline): its own pipelines, same objects
+    all_heads_step = None
+    if secondary and not args.all_heads:
+        ah = make_center_set(enc, dev, m["n_points"], m["k"], CONFIGS[args.config]["res"], m["n_obj"], seed0=100 * rank,
+                             with_heads=True, use_graph=not args.no_graph)
+        sts = [torch.cuda.Stream(device=dev) for _ in range(m["n_streams"])]
+
+        def ah_steps(n):
+            main = torch.cuda.current_stream(dev)
+            for st in sts:
+                st.wait_stream(main)
+            for j in range(n):
+                with torch.cuda.stream(sts[j % len(sts)]):
+                    ah[j % len(ah)]["pipe"].run(check_weights=j < len(ah))
+            for st in sts:
+                main.wait_stream(st)
+        ah_steps(len(ah))
+        settle()
+        torch.cuda.synchronize()
+        ta0 = time.perf_counter()
+        ah_steps(steps)
+        torch.cuda.synchronize()
+        t_ah = (time.perf_counter() - ta0) / steps * 1e3
+        lat_ah = events_per_chain(dev, [o["pipe"] for o in ah], 20)
+        all_heads_step = {"ms_per_step": t_ah, "pairs_per_s": P / (t_ah * 1e-3), "median_ms_one_instance": lat_ah[len(lat_ah) // 2]}
+        del ah
 
     # secondary: the vote stage alone, and then the whole step, on known-answer inputs -- every vote circle passes through the
     # object centre, so most samples land in the grid (what a trained network produces), unlike the near-uniform bins of the
@@ -389,8 +422,8 @@ def main():
         # trained-network regime of the WHOLE step: pair stage + known-answer vote in one captured graph per object
         tr_pipes = []
         for o, ka in zip(objs, outs_ka):
-            tp = TrainedRegimePipeline(enc, o["cfg"], m["n_points"], P, o["dims"], dev, NUM_ROTS, adaptive=True, with_heads=True,
-                                       use_graph=not args.no_graph)
+            tp = TrainedRegimePipeline(enc, o["cfg"], m["n_points"], P, o["dims"], dev, NUM_ROTS, adaptive=True,
+                                       with_heads=args.all_heads, use_graph=not args.no_graph)
             tp.load(o["ob"]["pc"], o["ob"]["normals"], o["ob"]["feat"], o["idx"], o["u_tr"], o["u_rot"], o["corners"][0].copy())
             tp.set_known_answer(ka)
             tr_pipes.append(tp)
@@ -588,6 +621,8 @@ def main():
         enc.eval()
 
     if rank == 0:
+        flop_pair = FLOP_PER_PAIR if args.all_heads else FLOP_PER_PAIR_CENTRE
+        flop_exec = FLOP_PER_PAIR_EXECUTED if args.all_heads else FLOP_PER_PAIR_CENTRE_EXECUTED
         argmax_gpu = int(m["allrec"][0, 12].item())
         lat = m["lat"]
         out = {
@@ -610,7 +645,8 @@ def main():
             "median_ms_one_instance": lat[len(lat) // 2],
             "one_instance_ms_min_max": [lat[0], lat[-1]], "one_instance_runs": len(lat),
             "trained_regime": trained,
-            "stage_ms": {"ppf_mlp_decode": t_mlp, "ppf_mlp_decode_centre_heads_only": t_mlp_tr, "vote_reduce_argmax": t_vote,
+            "all_heads_first_pass": all_heads_step,
+            "stage_ms": {"ppf_mlp_decode_all_heads": t_mlp_all, "ppf_mlp_decode_centre_heads": t_mlp_tr, "vote_reduce_argmax": t_vote,
                          "vote_reduce_argmax_known_answer_inputs": t_vote_ka,
                          "vote_plus_pose_tail_known_answer_inputs": t_tail_ka, "pose_tail_known_answer_n_surv": n_surv_ka,
                          "full_pose_incl_readback": t_pose, "full_pose_n_surv": pose["n_surv"],
@@ -620,25 +656,28 @@ def main():
                          "pair_encoder_fwd_bwd_adam_step_200k_pairs": t_step,
                          "train_step_both_encoders_adam_200k_pairs": t_full},
             "other_configs": other or None,
-            # dominant kernel = the fused pair encoder (one launch between the two events): exact-fp32
-            # MFMA, 23 968 algorithmic FLOP per pair
-            "roofline": {"bound": "mfma", "kernel": "pair_mlp_kernel<false,true,true>",
-                         "achieved": FLOP_PER_PAIR * P / (t_mlp * 1e-3) / 1e12, "peak": PEAK_F32_MFMA,
-                         "unit": "TFLOP/s", "frac": FLOP_PER_PAIR * P / (t_mlp * 1e-3) / 1e12 / PEAK_F32_MFMA,
-                         "traffic": pmc_traffic("pair_mlp_kernel<false, true, true>"),
-                         "note": "achieved = algorithmic FLOP of the reference path (23 968 per pair) / duration of the "
-                                 "pair-encoder stage (point_proj_kernel + pair_mlp_kernel); the pair kernel itself issues "
-                                 f"{FLOP_PER_PAIR_EXECUTED} MFMA FLOP per pair because the two 40-wide feature blocks of layer 0 "
-                                 "are projected once per point; fp32 MFMA shares the VALU datapath on gfx950, so the in-register "
-                                 "decode (about 480 VALU per 16 pairs) is paid on the same pipe; the duration is that of launches "
-                                 "without a neighbour (back to back on one stream, inputs rotating over the objects) -- in the timed "
-                                 "region several objects are in flight, so a kernel trace of this command also holds launches that "
-                                 "overlap another object's vote and take longer (profiles/r*_kernel_trace_stats_one_stream.txt: the "
-                                 "same command with --streams 1, whose averages agree)",
-                         "executed_mfma_tflops": FLOP_PER_PAIR_EXECUTED * P / (t_mlp * 1e-3) / 1e12},
+            # dominant kernel = the fused pair encoder (one launch between the two events): exact-fp32 MFMA
+            "roofline": {"bound": "mfma", "kernel": "pair_mlp_kernel<false,true,%s>" % ("true" if args.all_heads else "false"),
+                         "achieved": flop_pair * P / (t_mlp * 1e-3) / 1e12, "peak": PEAK_F32_MFMA,
+                         "unit": "TFLOP/s", "frac": flop_pair * P / (t_mlp * 1e-3) / 1e12 / PEAK_F32_MFMA,
+                         "traffic": pmc_traffic("pair_mlp_kernel<false, true, %s>" % ("true" if args.all_heads else "false")),
+                         "flop_per_pair": flop_pair,
+                         "note": "achieved = algorithmic FLOP of the reference's layers for the outputs this pass produces (" +
+                                 ("23 968 per pair: all 141 logits" if args.all_heads else
+                                  "21 504 per pair: the MLP with the 64 centre-bin logits; 23 968 with all 141") +
+                                 ") / duration of the pair-encoder stage (point_proj_kernel + pair_mlp_kernel); the pair kernel itself "
+                                 f"issues {flop_exec} MFMA FLOP per pair because the two 40-wide feature blocks of layer 0 are "
+                                 "projected once per point (executed_mfma_tflops / peak is the fraction of the MFMA pipe's peak actually "
+                                 "issued); fp32 MFMA shares the VALU datapath on gfx950, so the in-register decode is paid on the same "
+                                 "pipe; the duration is that of launches without a neighbour (back to back on one stream, inputs "
+                                 "rotating over the objects) -- in the timed region several objects are in flight, so a kernel trace of "
+                                 "this command also holds launches that overlap another object's vote and take longer "
+                                 "(profiles/r*_kernel_trace_stats_one_stream.txt: the same command with --streams 1, whose averages agree)",
+                         "executed_mfma_tflops": flop_exec * P / (t_mlp * 1e-3) / 1e12,
+                         "executed_frac": flop_exec * P / (t_mlp * 1e-3) / 1e12 / PEAK_F32_MFMA},
         }
         if world == 1 and not args.no_cpu_baseline:
-            flat_cpu, pps, reps = oracle_center(o0, sd, budget_s=12.0, max_reps=8)
+            flat_cpu, pps, reps = oracle_center(o0, sd, budget_s=12.0, max_reps=8, all_heads=args.all_heads)
             tps, tthreads, tn = torch_cpu_mlp(o0, sd)
             out["cpu_baseline"] = dict(
                 value=pps, unit="pairs/s", cores=host_threads(), kind="port",

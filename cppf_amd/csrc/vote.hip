@@ -448,13 +448,16 @@ __device__ __forceinline__ float atan2_approx(float y, float x)   // (-pi, pi], 
     r = x < 0.f ? 3.14159265f - r : r;
     return __builtin_copysignf(r, y);
 }
-__device__ __forceinline__ float acos_approx(float u)   // u in [-1, 1]; |error| < 2e-4
+__device__ __forceinline__ float acos_approx(float u)   // u in [-1, 1]; |error| < 1e-4 (callers budget 2e-4)
 {
-    const float sn = __builtin_amdgcn_sqrtf(fmaxf(0.f, (1.f - u) * (1.f + u)));
+    // Abramowitz & Stegun 4.4.45: acos(x) = sqrt(1 - x) (a0 + a1 x + a2 x^2 + a3 x^3) on [0, 1], |error| <= 6.7e-5; acos(-x) = pi - acos(x).
+    // The square root carries the singularity at 1, so the error bound holds up to the end points (round 3: 9 instructions
+    // instead of the 16 of the atan form -- every arc mask takes two).
     const float ax = fabsf(u);
-    const float mx = fmaxf(ax, sn), mn = fminf(ax, sn);
-    float r = atan01_approx(mn * __builtin_amdgcn_rcpf(fmaxf(mx, 1e-30f)));
-    r = sn > ax ? 1.57079633f - r : r;
+    float p = fmaf(ax, -0.0187293f, 0.0742610f);
+    p = fmaf(p, ax, -0.2121144f);
+    p = fmaf(p, ax, 1.5707288f);
+    const float r = p * __builtin_amdgcn_sqrtf(fmaxf(1.f - ax, 0.f));
     return u < 0.f ? 3.14159265f - r : r;
 }
 
@@ -1434,26 +1437,41 @@ __global__ __launch_bounds__(V3_BIN_THREADS) void v3_bin_kernel(V3Args A)
     for (int64_t r = blockIdx.x; r < rounds; r += gridDim.x) {
         const int64_t p = r * V3_BIN_THREADS + tid;
         const bool last_round = r + gridDim.x >= rounds;
-        // ---- per pair
+        // ---- per pair: the frame in APPROXIMATE arithmetic (reciprocal / rsqrt, ~45 instructions instead of the ~180 of the exact
+        // frame with its IEEE divisions and square roots).  It only feeds the arc screen, whose acceptance boxes are widened by
+        // more than its error (relative ~1e-6 on every component: below); the consumer recomputes the exact frame.  What must
+        // agree exactly between the two kernels is the rotation count n (:31: a division and a product of the stored (mu, nu),
+        // no frame involved); a pair the consumer finds degenerate (:21) deposits nothing whatever was queued for it, and the test
+        // here keeps every pair the exact test can keep (L >= 0.9e-7 for the exact L >= 1e-7).
         f3 Fcc = {0.f, 0.f, 0.f}, Fx = Fcc, Fy = Fcc;
         int n = 0;
         if (p < A.n_ppfs) {
             const float2 o = reinterpret_cast<const float2*>(A.outputs)[p];
             const int2 ij = v3_pair_idx(A, p);
-            f3 a, ab, xd;
-            if (pair_frame(A.points, ij.x, ij.y, a, ab, xd)) {
-                Fcc = sub3(a, scl3(ab, o.x));                      // :23
-                Fx = scl3(xd, o.y);                                // :28
-                Fy = cross3(Fx, ab);                               // :29
+            const f3 a = ld3(A.points, ij.x), b = ld3(A.points, ij.y);
+            const f3 d = sub3(a, b);
+            const float L2 = fmaf(d.z, d.z, fmaf(d.y, d.y, d.x * d.x));
+            const float L = __builtin_amdgcn_sqrtf(L2);
+            if (L >= 0.9e-7f) {
+                const f3 u = scl3(d, __builtin_amdgcn_rcpf(L + 1e-7f));
+                Fcc = {fmaf(-u.x, o.x, a.x), fmaf(-u.y, o.x, a.y), fmaf(-u.z, o.x, a.z)};                 // :23
+                f3 co = {0.f, -u.z, u.y};                                                                 // :26-27
+                float lc = __builtin_amdgcn_sqrtf(fmaf(u.y, u.y, u.z * u.z));
+                if (lc < 1e-6f) { co = {-u.y, u.x, 0.f}; lc = __builtin_amdgcn_sqrtf(fmaf(u.y, u.y, u.x * u.x)); }
+                Fx = scl3(co, o.y * __builtin_amdgcn_rcpf(lc + 1e-7f));                                   // :28
+                Fy = {fmaf(Fx.y, u.z, -Fx.z * u.y), fmaf(Fx.z, u.x, -Fx.x * u.z), fmaf(Fx.x, u.y, -Fx.y * u.x)};   // :29
                 n = A.n_rots;
                 if (A.adaptive) n = min((int)((double)(o.y / res) * (2 * CPPF_PI)), A.n_rots);   // :31
                 n = max(n, 0);
             }
         }
         const f3 cq = scl3(sub3(Fcc, cr), rinv), xq = scl3(Fx, rinv), yq = scl3(Fy, rinv);
-        const float ex = fmaf((fabsf(Fcc.x) + fabsf(cr.x) + fabsf(Fx.x) + fabsf(Fy.x)) * rinv, 1e-6f, 1e-3f);
-        const float ey = fmaf((fabsf(Fcc.y) + fabsf(cr.y) + fabsf(Fx.y) + fabsf(Fy.y)) * rinv, 1e-6f, 1e-3f);
-        const float ez = fmaf((fabsf(Fcc.z) + fabsf(cr.z) + fabsf(Fx.z) + fabsf(Fy.z)) * rinv, 1e-6f, 1e-3f);
+        // slack of the screen: the exact-frame form (1e-6 of the terms + 1e-3 cells, see vote_kernel) plus the approximate frame's
+        // own error -- rcp / sqrt are good to 1 ulp, so u, x, y carry a few 1e-7 relative: <= ~5e-7 m on a sample for |mu|, nu up to
+        // 0.3 m (1e-6 m at the 1.9 m of the SUN RGB-D categories), i.e. <= 2.5e-4 cells at res 2e-3 -- hence 4e-6 and 2e-3
+        const float ex = fmaf((fabsf(Fcc.x) + fabsf(cr.x) + fabsf(Fx.x) + fabsf(Fy.x)) * rinv, 4e-6f, 2e-3f);
+        const float ey = fmaf((fabsf(Fcc.y) + fabsf(cr.y) + fabsf(Fx.y) + fabsf(Fy.y)) * rinv, 4e-6f, 2e-3f);
+        const float ez = fmaf((fabsf(Fcc.z) + fabsf(cr.z) + fabsf(Fx.z) + fabsf(Fy.z)) * rinv, 4e-6f, 2e-3f);
         const float nf = (float)n * 0.159154943f;
         const AxisArc ax = axis_arc_prep(cq.x, xq.x, yq.x, nf), ay = axis_arc_prep(cq.y, xq.y, yq.y, nf),
                       az = axis_arc_prep(cq.z, xq.z, yq.z, nf);
