@@ -27,4 +27,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_s
   python $R/profiles/pmcstats.py $f >> $OUT/pmc_counters.txt
 done
 python $R/profiles/make_traffic_json.py $OUT/pmc_counters.txt > $OUT/pmc_traffic.json
+# the vote stage alone per configuration and regime (known-answer = what a trained network emits)
+bash $R/profiles/vote_ktrace.sh c2 > $OUT/vote_regimes_ktrace.txt 2>&1
+bash $R/profiles/vote_ktrace.sh c5 >> $OUT/vote_regimes_ktrace.txt 2>&1
 tail -3 $OUT/bench_under_trace.log | cut -c1-300
