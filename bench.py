@@ -366,6 +366,7 @@ def main():
     # ---- per-kernel durations (HIP events on the stream the C ABI launches on), eagerly right after the timed region with the
     # same rotating buffers: the dominant kernel alone between two events
     n_ev = max(steps, 5)
+    res_sec = torch.zeros((steps, 16), dtype=torch.uint8, device=dev)
     wss = [PoseWorkspace(dev, P, o["dims"], 1) for o in objs]
     settle()
 
@@ -399,6 +400,7 @@ def main():
             for j in range(n):
                 with torch.cuda.stream(sts[j % len(sts)]):
                     ah[j % len(ah)]["pipe"].run(check_weights=j < len(ah))
+                    res_sec[j % steps].copy_(ah[j % len(ah)]["pipe"].result, non_blocking=True)   # (every step's result is kept, as in the headline)
             for st in sts:
                 main.wait_stream(st)
         ah_steps(len(ah))
@@ -436,6 +438,7 @@ def main():
             for j in range(n):
                 with torch.cuda.stream(streams[j % len(streams)]):
                     tr_pipes[j % len(tr_pipes)].run(check_weights=False)
+                    res_sec[j % steps].copy_(tr_pipes[j % len(tr_pipes)].result, non_blocking=True)
             for st in streams:
                 main.wait_stream(st)
         for tp in tr_pipes:

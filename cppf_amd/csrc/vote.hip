@@ -187,9 +187,14 @@ static int vote_fixed_bits(const VotePlan& pl, int n_rots)
     return vote_fixed_bits_of(pl.chunk_pairs, n_rots);
 }
 
+static int v3_fixed_bits_bound(int64_t n_ppfs, int n_rots, int gx, int gy, int gz);
+static bool v3_eligible(int64_t n_ppfs, int n_rots, int gx, int gy, int gz);
+// fixed-point bits of the largest weight in the tiled vote of this launch: exact for < 4 tiles and for the round-2 kernels; a LOWER
+// bound for the binned path, whose scale follows the queues' lengths (a finer quantum than reported, never a coarser one)
 extern "C" int cppf_vote_fixed_point_bits(int64_t n_ppfs, int n_rots, int gx, int gy, int gz)
 {
     if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || gx < 1 || gy < 1 || gz < 1 || n_ppfs < 0) return -1;
+    if (v3_eligible(n_ppfs, n_rots, gx, gy, gz)) return v3_fixed_bits_bound(n_ppfs, n_rots, gx, gy, gz);
     return vote_fixed_bits(make_vote_plan(n_ppfs, n_rots, gx, gy, gz), n_rots);
 }
 
@@ -2144,6 +2149,16 @@ static bool v3_eligible(int64_t n_ppfs, int n_rots, int gx, int gy, int gz)
     static const bool legacy = getenv("CPPF_VOTE_LEGACY") != nullptr;   // A/B switch for tests and profiles
     if (legacy || n_ppfs < 1 || tri(n_rots) > VOTE_TAB_LDS_MAX) return false;
     return v3_tiling(gx, gy, gz).T <= VOTE_MAX_TILES;
+}
+static int v3_fixed_bits_bound(int64_t n_ppfs, int n_rots, int gx, int gy, int gz)
+{
+    const V3Tiling t = v3_tiling(gx, gy, gz);
+    const int wgs = v3_wgs(n_ppfs, t.T);
+    if (t.T < 4) { const int C = wgs / t.T; return v3_bits((unsigned)((n_ppfs + C - 1) / C), n_rots); }   // (what v3_launch passes)
+    // binned: chunk <= W / E <= P T / (wgs - T) records (C_t = 1 + floor(n_t E / W) >= n_t E / W)
+    const int64_t E = wgs - t.T > 0 ? wgs - t.T : 1;
+    const int64_t worst = (n_ppfs * t.T + E - 1) / E + 1;
+    return v3_bits((unsigned)(worst > 0x7fffffff ? 0x7fffffff : worst), n_rots);
 }
 static size_t v3_workspace_bytes(int64_t n_ppfs, int gx, int gy, int gz)
 {

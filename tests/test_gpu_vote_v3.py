@@ -1,0 +1,123 @@
+"""The round-3 tiled vote (csrc/vote.hip: v3_bin_kernel / v3_vote_kernel<FUSED> / v3_reduce_kernel): halo tiles cut along x, along y
+and along both, the fused (< 4 tiles) and the binned (>= 4 tiles) forms on the same inputs, run-to-run bit reproducibility although
+the tile queues fill in a racy order, state kept in the workspace between calls, and a workspace that was never initialised."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import cppf_amd.synthetic as syn
+from cppf_amd import _lib
+from cppf_amd._torch_util import stream_ptr
+from cppf_amd.models import voting
+from test_gpu_parity import check_grid, run_vote, t
+
+pytestmark = pytest.mark.gpu
+
+
+def case(n=1500, k=40, seed=3, cat="bottle", quantise=True):
+    ob = syn.make_object(cat, n, seed)
+    idx = syn.make_pairs(n, k, seed)
+    out = syn.closed_form_outputs(ob["pc"], ob["center"], idx, ob["cfg"], quantise=quantise)
+    return ob, idx.astype(np.int32), out
+
+
+@pytest.mark.parametrize("dims,res,expect_tiles", [
+    ((76, 26, 26), 4e-3, 2),        # cut along x only (fused)
+    ((26, 76, 26), 4e-3, 2),        # cut along y only (fused)
+    ((60, 60, 52), 2.5e-3, None),   # cut along x and y: many tiles (binned)
+    ((150, 30, 40), 3e-3, None),    # long in x
+    ((20, 20, 20), 8e-3, 1),        # one tile, no halo
+])
+def test_halo_tiles_every_cut_direction(oracle, dev, dims, res, expect_tiles):
+    """every cell -- also those next to a cut, which the owner tile's halo and the extra plane hand to the neighbour -- equals the
+    exact fp64 vote sum within half a quantum per deposit; arg-max identical to the exact grid's"""
+    L = _lib.lib()
+    T = L.cppf_vote_tiles(*dims)
+    assert T > 0 and (expect_tiles is None or T == expect_tiles)
+    ob, idx, out = case()
+    # put the object in the middle of the requested grid, and once more straddling the central cuts
+    for shift in (0.0, 0.37):
+        corner = (ob["center"] - 0.5 * np.array(dims) * res + shift * res * np.array([5, 7, 3])).astype(np.float32)
+        gg, flat, peak = run_vote(dev, ob["pc"], out, idx, corner, dims, res, 72, True)
+        g64, cnt = check_grid(oracle, gg, ob["pc"], out, idx, corner, dims, res, 72, True)
+        assert flat == int(np.argmax(g64)) and g64.max() > 100
+        assert peak == gg.max()
+        # += into a pre-filled grid (the reference's semantics) on the same workspace
+        g0 = np.random.default_rng(1).random(dims).astype(np.float32)
+        gg2, flat2, _ = run_vote(dev, ob["pc"], out, idx, corner, dims, res, 72, True, grid0=g0)
+        np.testing.assert_allclose(gg2, g0 + gg, rtol=1e-6, atol=1e-6)
+
+
+def test_fused_and_binned_forms_give_the_same_bits(dev):
+    """a 2-tile grid through the fused kernel (by-value launch and the few-tile *_dyn class) and through the binned kernels (the
+    many-tile *_dyn class serves small grids too): the grids are the exact sum of the same quantised deposits -> bit-identical"""
+    from cppf_amd.inference import grid_class, grid_shape
+    ob, idx, out = case(n=3000, k=60, seed=5)
+    res = ob["cfg"].res
+    corners, dims = grid_shape(ob["pc"], res)
+    Tn, many, cap = grid_class(dims)
+    assert Tn == 2 and not many
+    pc, o, i64, corner = t(ob["pc"], dev), t(out, dev), t(idx.astype(np.int64), dev), t(corners[0], dev)
+    grid = torch.empty(dims, dtype=torch.float32, device=dev)
+    i0, v0 = voting.vote_argmax(pc, o, None, i64, grid, corner, res, 72, True, accumulate=False)
+    shape = torch.tensor([ob["pc"].shape[0], *dims], dtype=torch.int32, device=dev)
+    G = int(np.prod(dims))
+    for many_tiles in (False, True):
+        flat = torch.zeros(64 * _lib.lib().cppf_vote_tile_cells() if many_tiles else cap, dtype=torch.float32, device=dev)
+        oi, ov = torch.zeros(1, dtype=torch.int64, device=dev), torch.zeros(1, dtype=torch.float32, device=dev)
+        voting.vote_argmax_dyn(pc, o, None, i64, flat, shape, corner, res, 72, True, oi, ov, many_tiles=many_tiles)
+        assert torch.equal(flat[:G].view(dims), grid) and int(oi) == int(i0) and float(ov) == float(v0)
+
+
+def test_many_tile_vote_is_bit_reproducible(dev):
+    """the binned path's queues fill in whatever order the workgroups of the bin kernel reach their atomics; the grid must not care"""
+    ob, idx, out = case(n=4096, k=64, seed=9)
+    res = 2e-3
+    from cppf_amd.inference import grid_shape
+    corners, dims = grid_shape(ob["pc"], res)
+    assert _lib.lib().cppf_vote_tiles(*dims) >= 4
+    pc, o, i32, corner = t(ob["pc"], dev), t(out, dev), t(idx, dev), t(corners[0], dev)
+    grids = []
+    for rep in range(6):
+        grid = torch.empty(dims, dtype=torch.float32, device=dev)
+        oi, ov = voting.vote_argmax(pc, o, None, i32, grid, corner, res, 72, True, accumulate=False)
+        grids.append((grid.clone(), int(oi), float(ov)))
+    for g, i, v in grids[1:]:
+        assert torch.equal(g, grids[0][0]) and i == grids[0][1] and v == grids[0][2]
+    assert grids[0][0].sum().item() > 1e5
+
+
+def test_uninitialised_workspace_is_reported_then_usable(oracle, dev):
+    """include/cppf.h: the vote workspace must start zeroed.  One that never was (garbage header) must not be used silently:
+    the call reports arg-max -1 / peak NaN and leaves the workspace in a usable state for the next call"""
+    L = _lib.lib()
+    ob, idx, out = case(n=1200, k=30, seed=2)
+    res = ob["cfg"].res
+    from cppf_amd.inference import grid_shape
+    corners, dims = grid_shape(ob["pc"], res)
+    for dims_, res_ in ((dims, res), (grid_shape(ob["pc"], res / 2.2)[1], res / 2.2)):      # fused and binned
+        corner = t(grid_shape(ob["pc"], res_)[0][0], dev)
+        P = idx.shape[0]
+        need = L.cppf_vote_workspace_bytes(P, 72, *dims_)
+        ws = torch.randint(1, 255, (need,), dtype=torch.uint8, device=dev)            # garbage, no zero byte
+        pc, o, i32 = t(ob["pc"], dev), t(out, dev), t(idx, dev)
+        grid = torch.zeros(dims_, dtype=torch.float32, device=dev)
+        oi, ov = torch.zeros(1, dtype=torch.int64, device=dev), torch.zeros(1, dtype=torch.float32, device=dev)
+
+        def call():
+            rc = L.cppf_vote_argmax(pc.data_ptr(), o.data_ptr(), None, i32.data_ptr(), 0, grid.data_ptr(), corner.data_ptr(),
+                                    float(res_), pc.shape[0], P, 72, *[int(d) for d in dims_], 1, 0, oi.data_ptr(), ov.data_ptr(),
+                                    ws.data_ptr(), ws.numel(), stream_ptr(dev))
+            assert rc == 0
+            torch.cuda.synchronize()
+        call()
+        assert int(oi) == -1 and np.isnan(float(ov))
+        # the caller follows the header's rule now (zero once) and everything works, repeatedly
+        ws[:min(int(L.cppf_vote_workspace_init_bytes()), need)].zero_()
+        for _ in range(2):
+            call()
+            gg = grid.cpu().numpy()
+            g64, cnt = check_grid(oracle, gg, ob["pc"], out, idx, grid_shape(ob["pc"], res_)[0][0], dims_, res_, 72, True)
+            assert int(oi) == int(np.argmax(g64))
