@@ -1420,8 +1420,8 @@ __global__ __launch_bounds__(V3_BIN_THREADS) void v3_bin_kernel(V3Args A)
     int gx, gy, gz;
     int64_t n_points;
     V3Tiling t;
+    if (blockIdx.x == 0 && tid < 20) A.packed[tid] = 0ull;   // arg-max keys + tickets of the reduce kernel, its error-path ticket [18]
     if (!v3_resolve(A, gx, gy, gz, n_points, t)) return;   // (the reduce kernel reports it)
-    if (blockIdx.x == 0 && tid < 2 + 2 * 8) A.packed[tid] = 0ull;   // arg-max keys + tickets of the reduce kernel
     {
         const unsigned m = A.hdr->magic;
         if (m != 0u && m != V3_MAGIC) { if (tid == 0) atomicOr(&A.hdr->flags, 1u); return; }
@@ -1644,6 +1644,7 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
     int gx, gy, gz;
     int64_t n_points;
     V3Tiling pt;
+    if (FUSED && blockIdx.x == 0 && tid < 20) A.packed[tid] = 0ull;   // arg-max keys + tickets of the reduce kernel (binned: the bin kernel did)
     if (!v3_resolve(A, gx, gy, gz, n_points, pt)) return;
     if (FUSED) {   // (binned: the bin kernel checked)
         const unsigned m = A.hdr->magic;
@@ -1728,7 +1729,6 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
         }
     }
     if (tid < 2) ltab[A.tab_entries + tid] = make_float2(0.f, 0.f);
-    if (FUSED && blockIdx.x == 0 && tid < 2 + 2 * 8) A.packed[tid] = 0ull;   // arg-max keys + tickets of the reduce kernel (binned: the bin kernel did)
     // the waves' summaries of the probs go to the (still unused) carry log: two words per wave
     for (int off = 32; off > 0; off >>= 1) pm = fmaxf(pm, __shfl_xor(pm, off, 64));
     {
@@ -2003,8 +2003,8 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, in
     V3Tiling pt;
     const bool fits = v3_resolve(A, gx, gy, gz, n_points, pt);
     if (!fits || (A.hdr->flags & 1u)) {   // nothing valid was voted: say so (index -1, NaN) and leave a clean header
-        if (tid == 0) {
-            const unsigned tk = atomicAdd(&A.hdr->done, 1u);
+        if (tid == 0) {   // (the ticket lives with the arg-max keys, which the vote / bin kernel zeroed before looking at the header)
+            const unsigned tk = atomicAdd(reinterpret_cast<unsigned*>(A.packed + 18), 1u);
             if (tk == gridDim.x - 1) {
                 if (A.out_idx) *A.out_idx = -1;
                 if (A.out_val) *A.out_val = __uint_as_float(0x7fc00000u);
