@@ -1202,6 +1202,7 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void reduce_tiles_kernel(RedArgs R
 #define V3_MAGIC 0x43503356u
 #define V3_THREADS 1024
 #define V3_BIN_THREADS 512
+#define V3_IRING 256              // per-wave ring of (lane, tile) items: <= 63 waiting + 64 pushed
 #define V3_CNT_STRIDE 32
 struct V3Hdr {                    // workspace + VOTE_WS_PART; all zero (or left by a previous call) when a launch starts
     unsigned int tile_count[VOTE_MAX_TILES * V3_CNT_STRIDE];   // records in each tile's queue, one counter per 128-byte line
@@ -1415,8 +1416,9 @@ __global__ __launch_bounds__(V3_BIN_THREADS) void v3_bin_kernel(V3Args A)
     uint4* below = reinterpret_cast<uint4*>(stage + V3_STAGE);               // [VOTE_BELOW_N]
     uint32_t* cnt = reinterpret_cast<uint32_t*>(below + VOTE_BELOW_N);       // [64] records of each tile in this flush
     uint32_t* gbase = cnt + VOTE_MAX_TILES;                                   // [64] their place in the tile's queue
-    uint32_t* ctl = gbase + VOTE_MAX_TILES;                                   // [0] staged (attempts), [1] a lane could not stage
-    const int tid = threadIdx.x;
+    uint32_t* ctl = gbase + VOTE_MAX_TILES;                                   // [0] staged, [1] a wave could not stage
+    uint16_t* iring = reinterpret_cast<uint16_t*>(ctl + 16) + (threadIdx.x >> 6) * V3_IRING;   // this wave's (lane, tile) items
+    const int tid = threadIdx.x, lane = tid & 63;
     int gx, gy, gz;
     int64_t n_points;
     V3Tiling t;
@@ -1433,6 +1435,7 @@ __global__ __launch_bounds__(V3_BIN_THREADS) void v3_bin_kernel(V3Args A)
     }
     if (tid < VOTE_MAX_TILES) cnt[tid] = 0u;
     if (tid == 0) { ctl[0] = 0u; ctl[1] = 0u; }
+    for (int i = tid; i < V3_STAGE; i += V3_BIN_THREADS) stage[i].w = 0xffffffffu;   // "empty" mark of a staging slot
     const f3 cr = {A.corner[0], A.corner[1], A.corner[2]};
     const float res = A.res, rinv = 1.0f / res;
     const float ptxf = (float)t.tx, ptyf = (float)t.ty;
@@ -1448,7 +1451,8 @@ __global__ __launch_bounds__(V3_BIN_THREADS) void v3_bin_kernel(V3Args A)
         // agree exactly between the two kernels is the rotation count n (:31: a division and a product of the stored (mu, nu),
         // no frame involved); a pair the consumer finds degenerate (:21) deposits nothing whatever was queued for it, and the test
         // here keeps every pair the exact test can keep (L >= 0.9e-7 for the exact L >= 1e-7).
-        f3 Fcc = {0.f, 0.f, 0.f}, Fx = Fcc, Fy = Fcc;
+        f3 Fcc = {0.f, 0.f, 0.f}, Fx = Fcc, Fy = Fcc, Fu = Fcc;
+        float Rq = 0.f;   // the circle's radius in cells
         int n = 0;
         if (p < A.n_ppfs) {
             const float2 o = reinterpret_cast<const float2*>(A.outputs)[p];
@@ -1459,6 +1463,8 @@ __global__ __launch_bounds__(V3_BIN_THREADS) void v3_bin_kernel(V3Args A)
             const float L = __builtin_amdgcn_sqrtf(L2);
             if (L >= 0.9e-7f) {
                 const f3 u = scl3(d, __builtin_amdgcn_rcpf(L + 1e-7f));
+                Fu = u;
+                Rq = fabsf(o.y) * rinv;
                 Fcc = {fmaf(-u.x, o.x, a.x), fmaf(-u.y, o.x, a.y), fmaf(-u.z, o.x, a.z)};                 // :23
                 f3 co = {0.f, -u.z, u.y};                                                                 // :26-27
                 float lc = __builtin_amdgcn_sqrtf(fmaf(u.y, u.y, u.z * u.z));
@@ -1498,48 +1504,110 @@ __global__ __launch_bounds__(V3_BIN_THREADS) void v3_bin_kernel(V3Args A)
             iy0 += ((float)((iy0 + 1) * t.ty) <= ylo) ? 1 : 0;
             iy1 -= ((float)(iy1 * t.ty) > yhi) ? 1 : 0;
         }
-        const int nxw = wave_max_i32(ix1 - ix0 + 1), nyw = wave_max_i32(iy1 - iy0 + 1);   // this wave's loop bounds
-        int resume = 0;   // first (dx, dy) step of this lane that has not been staged yet
-        // Records are staged in LDS across rounds and flushed -- one global atomic per tile -- when the area is half full,
-        // when a lane could not stage (it resumes after the flush), and after the workgroup's last round.
+        // ---- (pair, tile) items.  A circle's bounding box covers many tiles while the curve passes through few (all of them against
+        // 0.75 on uniform-bin inputs at C5, 12 against 3.4 on known-answer inputs), and a per-lane loop over the box runs every lane
+        // to the wave's longest range.  So the box is walked with a CHEAP test only -- the tile's box must reach the circle's plane,
+        // and the radius must lie between the box's nearest and farthest distance from the centre (vote_kernel's plane / shell test,
+        // ~35 instructions) -- and the (lane, tile) pairs that pass go through a per-wave ring in LDS; whenever 64 are queued every
+        // lane takes one, pulls the owning lane's arc parameters (ds_bpermute) and does the expensive part with full lanes: the x and
+        // y masks of that tile, AND with the z mask, runs, record.  Records are staged in LDS across rounds and flushed -- one global
+        // atomic per tile -- when the area is half full, when a wave finds it full (it retries its batch after the flush), and after
+        // the workgroup's last round.
+        const int nxw = wave_max_i32(ix1 - ix0 + 1), nyw = wave_max_i32(iy1 - iy0 + 1);   // this wave's walk
+        const int nsteps = nxw * nyw;
+        const float slq = fmaf(Rq, 1.1e-3f, 4e-3f);
+        int step = 0, qhead = 0, qtail = 0;
+        auto produce = [&]() {
+            const int dx = step / nyw, dy = step - dx * nyw;
+            const int ix = ix0 + dx, iy = iy0 + dy;
+            bool pass = false;
+            if (ix <= ix1 && iy <= iy1) {
+                const float x0f = (float)(ix * t.tx), y0f = (float)(iy * t.ty);
+                const float bx0 = fmaxf(0.01f, x0f), bx1 = fminf((float)gx - 1.01f, x0f + ptxf);
+                const float by0 = fmaxf(0.01f, y0f), by1 = fminf((float)gy - 1.01f, y0f + ptyf);
+                const float hx_ = 0.5f * (bx1 - bx0) + ex, hy_ = 0.5f * (by1 - by0) + ey, hz_ = 0.5f * ((float)gz - 1.02f) + ez;
+                const float ddx = 0.5f * (bx0 + bx1) - cq.x, ddy = 0.5f * (by0 + by1) - cq.y, ddz = 0.5f * ((float)gz - 1.f) - cq.z;
+                const float off_plane = fabsf(fmaf(ddz, Fu.z, fmaf(ddy, Fu.y, ddx * Fu.x)));
+                const float reach = fmaf(fabsf(Fu.z), hz_, fmaf(fabsf(Fu.y), hy_, fabsf(Fu.x) * hx_));
+                const float nx_ = fmaxf(fabsf(ddx) - hx_, 0.f), ny_ = fmaxf(fabsf(ddy) - hy_, 0.f), nz_ = fmaxf(fabsf(ddz) - hz_, 0.f);
+                const float fx_ = fabsf(ddx) + hx_, fy_ = fabsf(ddy) + hy_, fz_ = fabsf(ddz) + hz_;
+                const float dmin2 = fmaf(nz_, nz_, fmaf(ny_, ny_, nx_ * nx_)), dmax2 = fmaf(fz_, fz_, fmaf(fy_, fy_, fx_ * fx_));
+                const float r_hi = Rq + slq, r_lo = fmaxf(Rq - slq, 0.f);
+                pass = (bx0 < bx1) & (by0 < by1) & (off_plane <= reach + slq) & (dmin2 <= r_hi * r_hi * 1.0001f) &
+                       (dmax2 * 1.0001f >= r_lo * r_lo);
+            }
+            const unsigned long long m = __ballot(pass);
+            if (pass) {
+                const int pos = qtail + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                iring[pos & (V3_IRING - 1)] = (uint16_t)(lane | ((ix * t.nty + iy) << 6));
+            }
+            qtail += __popcll(m);
+            ++step;
+        };
+        // one item per lane: masks of its tile, runs, record; false (nothing consumed) when the staging area cannot take the batch
+        auto consume = [&](const int count) -> bool {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const unsigned code = iring[(qhead + lane) & (V3_IRING - 1)];
+            const int src = (int)(code & 63u), tile = (int)(code >> 6);
+            // (all 64 lanes execute the pulls)
+            AxisArc bx_, by_;
+            bx_.c = __shfl(ax.c, src, 64); bx_.rA = __shfl(ax.rA, src, 64); bx_.f = __shfl(ax.f, src, 64);
+            by_.c = __shfl(ay.c, src, 64); by_.rA = __shfl(ay.rA, src, 64); by_.f = __shfl(ay.f, src, 64);
+            const float sex = __shfl(ex, src, 64), sey = __shfl(ey, src, 64);
+            const int sn = __shfl(n, src, 64);
+            const uint32_t z0 = (uint32_t)__shfl((int)mz.a, src, 64), z1 = (uint32_t)__shfl((int)mz.b, src, 64), z2 = (uint32_t)__shfl((int)mz.c, src, 64);
+            const uint32_t sp_ = (uint32_t)__shfl((int)(uint32_t)p, src, 64);
+            uint32_t m0 = 0u, m1 = 0u, m2 = 0u;
+            if (lane < count) {
+                const int ix = tile / t.nty, iy = tile - ix * t.nty;
+                const float x0f = (float)(ix * t.tx), y0f = (float)(iy * t.ty);
+                const float snf = (float)sn * 0.159154943f;
+                const Mask96 mx = axis_arc_eval(below, bx_, fmaxf(0.01f, x0f) - sex, fminf((float)gx - 1.01f, x0f + ptxf) + sex, snf, sn);
+                const Mask96 my = axis_arc_eval(below, by_, fmaxf(0.01f, y0f) - sey, fminf((float)gy - 1.01f, y0f + ptyf) + sey, snf, sn);
+                m0 = mx.a & my.a & z0; m1 = mx.b & my.b & z1; m2 = mx.c & my.c & z2;
+            }
+            const bool have = (m0 | m1 | m2) != 0u;
+            const unsigned long long hm = __ballot(have);
+            const int nh = __popcll(hm);
+            if (nh == 0) return true;
+            int base = 0;
+            if (lane == 0) base = (int)atomicAdd(&ctl[0], (uint32_t)nh);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base + nh > V3_STAGE) {   // full: ask for a flush and retry this batch afterwards (the slots it drew stay empty: the
+                if (lane == 0) ctl[1] = 1u;   // flush copies marked entries only)
+                return false;
+            }
+            if (have) {
+                int s0, e0, s1, e1, s2, e2;
+                mask_runs(below, m0, m1, m2, s0, e0, s1, e1, s2, e2);
+                const int l2 = max(e2 - s2, 0);
+                const uint32_t slot = atomicAdd(&cnt[tile], 1u);
+                const uint32_t ra = (uint32_t)s0 | ((uint32_t)(e0 - s0) << 8) | ((uint32_t)s1 << 16) | ((uint32_t)(e1 - s1) << 24);
+                const uint32_t rb = (uint32_t)s2 | ((uint32_t)l2 << 8) | ((uint32_t)tile << 24);
+                const int fi = base + __builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0));
+                stage[fi] = make_uint4(sp_, ra, rb, slot);
+            }
+            return true;
+        };
         for (;;) {
+            // this wave: walk and consume until its items are done or the staging area is full
             bool stuck = false;
-            int step = 0;
-            for (int dx = 0; dx < nxw; ++dx) {
-                const int ix = ix0 + dx;
-                const bool xin = ix <= ix1;
-                Mask96 mx = {0u, 0u, 0u};
-                if (xin) {
-                    const float x0f = (float)(ix * t.tx);
-                    mx = axis_arc_eval(below, ax, fmaxf(0.01f, x0f) - ex, fminf((float)gx - 1.01f, x0f + ptxf) + ex, nf, n);
-                    mx.a &= mz.a; mx.b &= mz.b; mx.c &= mz.c;
-                }
-                for (int dy = 0; dy < nyw; ++dy, ++step) {
-                    const int iy = iy0 + dy;
-                    if (!(xin && iy <= iy1) || step < resume || stuck) continue;
-                    const float y0f = (float)(iy * t.ty);
-                    const Mask96 my = axis_arc_eval(below, ay, fmaxf(0.01f, y0f) - ey, fminf((float)gy - 1.01f, y0f + ptyf) + ey, nf, n);
-                    const uint32_t m0 = mx.a & my.a, m1 = mx.b & my.b, m2 = mx.c & my.c;
-                    if ((m0 | m1 | m2) == 0u) continue;
-                    int s0, e0, s1, e1, s2, e2;
-                    mask_runs(below, m0, m1, m2, s0, e0, s1, e1, s2, e2);
-                    const int l2 = max(e2 - s2, 0);
-                    const uint32_t fi = atomicAdd(&ctl[0], 1u);
-                    if (fi >= V3_STAGE) { stuck = true; resume = step; ctl[1] = 1u; continue; }
-                    const int tile = ix * t.nty + iy;
-                    const uint32_t slot = atomicAdd(&cnt[tile], 1u);
-                    const uint32_t ra = (uint32_t)s0 | ((uint32_t)(e0 - s0) << 8) | ((uint32_t)s1 << 16) | ((uint32_t)(e1 - s1) << 24);
-                    const uint32_t rb = (uint32_t)s2 | ((uint32_t)l2 << 8) | ((uint32_t)tile << 24);
-                    stage[fi] = make_uint4((uint32_t)p, ra, rb, slot);
+            while (!stuck) {
+                const int queued = qtail - qhead;
+                if (queued >= 64 || (step >= nsteps && queued > 0)) {
+                    const int take = queued < 64 ? queued : 64;
+                    if (consume(take)) qhead += take; else stuck = true;
+                } else if (step < nsteps) {
+                    produce();
+                } else {
+                    break;
                 }
             }
-            if (!stuck) resume = 1 << 30;
             __syncthreads();
             const uint32_t staged = min(ctl[0], (uint32_t)V3_STAGE);
             const bool again = ctl[1] != 0u;
             if (again || last_round || staged >= V3_STAGE / 2) {
                 if (tid < t.T && cnt[tid] != 0u) {
-                    // (a failed attempt bumped ctl[0] but not cnt[]: cnt[] counts exactly the staged records)
                     const uint32_t b = atomicAdd(&A.hdr->tile_count[tid * V3_CNT_STRIDE], cnt[tid]);
                     gbase[tid] = b;
                     if ((int64_t)b + cnt[tid] > A.pool_cap) atomicOr(&A.hdr->flags, 1u);
@@ -1547,12 +1615,14 @@ __global__ __launch_bounds__(V3_BIN_THREADS) void v3_bin_kernel(V3Args A)
                 __syncthreads();
                 for (uint32_t i = tid; i < staged; i += V3_BIN_THREADS) {
                     const uint4 rec = stage[i];
+                    if (rec.w == 0xffffffffu) continue;   // a slot a refused batch drew
                     const uint32_t tile = rec.z >> 24;
                     const int64_t pos = (int64_t)gbase[tile] + rec.w;
                     if (pos < A.pool_cap) {
                         uint32_t* dst = A.pool + ((int64_t)tile * A.pool_cap + pos) * 3;
                         dst[0] = rec.x; dst[1] = rec.y; dst[2] = rec.z & 0xffffffu;
                     }
+                    stage[i].w = 0xffffffffu;
                 }
                 __syncthreads();
                 if (tid < VOTE_MAX_TILES) cnt[tid] = 0u;
@@ -2226,7 +2296,7 @@ static int v3_launch(const float* points, const float* outputs, const float* pro
         CPPF_CHECK_LAUNCH();
     } else {
         const int64_t rounds = (n_ppfs + V3_BIN_THREADS - 1) / V3_BIN_THREADS;
-        const size_t lds_bin = (size_t)V3_STAGE * 16 + VOTE_BELOW_N * 16 + 2 * VOTE_MAX_TILES * 4 + 64;
+        const size_t lds_bin = (size_t)V3_STAGE * 16 + VOTE_BELOW_N * 16 + 2 * VOTE_MAX_TILES * 4 + 64 + (V3_BIN_THREADS / 64) * V3_IRING * 2;
         hipLaunchKernelGGL(v3_bin_kernel, dim3((unsigned)(rounds < 512 ? rounds : 512)), dim3(V3_BIN_THREADS), lds_bin, st, A);
         CPPF_CHECK_LAUNCH();
         hipLaunchKernelGGL(v3_vote_kernel<false>, dim3((unsigned)A.wgs), dim3(V3_THREADS), lds_vote, st, A);
