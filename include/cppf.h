@@ -55,10 +55,14 @@ const char* cppf_error_string(int code);
  *   corner      device f32[3]          res, n_rots (1..CPPF_MAX_ROTS), adaptive: as the reference
  *   n_points    N (the reference kernel never needs it; here it bounds the scan for max(probs))
  * The reference's launch geometry (grid, block) is not part of the ABI.
- * Strategy: the grid is cut into tiles that fit LDS; every workgroup accumulates one tile for one
- * chunk of pairs with 32-bit fixed-point LDS atomics (fp32-exact quantum, see csrc/vote.hip), tiles
- * are written to `workspace` and summed into grid_obj by a second kernel that also yields the
- * arg-max (cppf_vote_argmax).  Grids that would need too many tiles fall back to global fp32 atomics.
+ * Strategy: the grid is cut into tiles that fit LDS (each owning the samples whose floor cell it holds, plus a one-cell halo);
+ * every workgroup accumulates one tile for one chunk of pairs -- or, for grids of 4 tiles and more, for one chunk of the
+ * tile's queue of (pair, candidate runs) records that a binning kernel filled -- with 32-bit fixed-point LDS atomics
+ * (fp32-exact quantum, see csrc/vote.hip); the raw tiles are written to `workspace` and summed AS INTEGERS into grid_obj by a
+ * last kernel that also yields the arg-max (cppf_vote_argmax): the grid is the exact sum of the quantised deposits, the same
+ * bits on every run.  Grids that would need more than 64 tiles fall back to global fp32 atomics.
+ * `workspace`: cppf_vote_workspace_bytes() bytes, DEDICATED to the vote and zero on first use (see the note on workspaces at
+ * the top and cppf_vote_workspace_init_bytes below).
  * ------------------------------------------------------------------------------------------- */
 #define CPPF_MAX_ROTS 360
 size_t cppf_vote_workspace_bytes(int64_t n_ppfs, int n_rots, int gx, int gy, int gz);
