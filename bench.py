@@ -515,9 +515,11 @@ def main():
             del mm
         args.steps, args.objects = keep
         args.steps = 8
-        m4 = run_c4(dev, rank, world, args, n_objects=8)          # one GPU's share of the 64-object batch
+        # one GPU's share of the 64-object batch; the smallest of three batches (a batch is ~2 ms of mostly host work: one
+        # scheduler hiccup on the box triples it)
+        m4 = min((run_c4(dev, rank, world, args, n_objects=8) for _ in range(3)), key=lambda q: q["elapsed"])
         other["c4_one_gpu_share"] = {"workload": "8 mixed-category objects (N=4096 K=128), full pose each, BatchPoseRunner, pairs "
-                                                 "drawn on the device, one read-back per batch",
+                                                 "drawn on the device, one read-back per batch; smallest of three batches",
                                      "ms_per_object": m4["elapsed"] / (m4["reps"] * 8) * 1e3,
                                      "pairs_per_s": m4["reps"] * 8 * m4["P"] / m4["elapsed"]}
         args.steps = keep[0]

@@ -121,3 +121,25 @@ def test_uninitialised_workspace_is_reported_then_usable(oracle, dev):
             gg = grid.cpu().numpy()
             g64, cnt = check_grid(oracle, gg, ob["pc"], out, idx, grid_shape(ob["pc"], res_)[0][0], dims_, res_, 72, True)
             assert int(oi) == int(np.argmax(g64))
+
+
+@pytest.mark.parametrize("dims,res", [((26, 76, 26), 4e-3), ((60, 60, 52), 2.5e-3)])
+def test_negative_probs_on_cut_grids(oracle, dev, dims, res):
+    """negative / non-finite probs switch the launch to fp32 LDS atomics and fp32 partial tiles; the halo words then reach the
+    neighbour's cells through the extra plane as floats -- on a fused (2-tile) and a binned (many-tile) grid"""
+    from test_gpu_parity import oracle_vote
+    ob, idx, out = case(n=900, k=20, seed=4)
+    corner = (ob["center"] - 0.5 * np.array(dims) * res).astype(np.float32)
+    rng = np.random.default_rng(3)
+    for bad in (-0.75, np.inf):
+        probs = rng.uniform(0.25, 2.0, ob["pc"].shape[0]).astype(np.float32)
+        probs[rng.integers(0, probs.size, 40)] = bad
+        go, na = oracle_vote(oracle, ob["pc"], out, idx, corner, dims, res, 72, True, probs)
+        gg, flat, peak = run_vote(dev, ob["pc"], out, idx, corner, dims, res, 72, True, probs)
+        fin = np.isfinite(go)
+        assert np.array_equal(fin, np.isfinite(gg))
+        np.testing.assert_allclose(gg[fin], go[fin], rtol=2e-4, atol=2e-5 * float(np.abs(go[fin]).max()))
+    # and back to the fixed-point path on the same workspace: the plane must be clean again
+    gg, flat, peak = run_vote(dev, ob["pc"], out, idx, corner, dims, res, 72, True)
+    g64, cnt = check_grid(oracle, gg, ob["pc"], out, idx, corner, dims, res, 72, True)
+    assert flat == int(np.argmax(g64))
