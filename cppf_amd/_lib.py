@@ -24,6 +24,7 @@ _SIGS = {
     "cppf_vote_workspace_bytes_dyn": (sz, [i32]),
     "cppf_vote_workspace_bytes_dyn_pairs": (sz, [i32, i64]),
     "cppf_vote_workspace_init_bytes": (sz, []),
+    "cppf_vote_plan_query": (C.c_int, [i64, i32, i32, i32, i32, vp]),
     "cppf_vote_argmax_dyn": (C.c_int, [vp, vp, vp, vp, i32, vp, i64, vp, f32, i64, i64, i32, vp, i32, i32, i32, vp, vp, vp, sz,
                                        vp]),
     "cppf_center_from_argmax_dyn": (C.c_int, [vp, vp, C.c_double, vp, vp, vp, vp, vp, vp]),

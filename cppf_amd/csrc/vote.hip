@@ -2241,6 +2241,26 @@ static size_t v3_workspace_bytes_dyn(int many_tiles, int64_t n_ppfs)
     return VOTE_WS_PART + V3_HDR_BYTES + V3_PLANE_BYTES + (many_tiles ? align_up((size_t)t_cap * (size_t)n_ppfs * 12, 256) : 0) +
            (size_t)wgs * V3_TILE_FLOATS * sizeof(uint32_t);
 }
+// What a by-value launch will do for this problem (tests, tools): out = {path, T, tx, ty, ntx, nty, hx, hy, workgroups, bits};
+// path 0: global fp32 atomics (> 64 tiles), 1: round-2 tiled kernels (n_rots > 72), 2: fused round-3 kernel (< 4 tiles), 3: binned
+extern "C" int cppf_vote_plan_query(int64_t n_ppfs, int n_rots, int gx, int gy, int gz, int32_t* out)
+{
+    if (!out || n_rots < 1 || n_rots > CPPF_MAX_ROTS || gx < 1 || gy < 1 || gz < 1 || n_ppfs < 0) return CPPF_EINVAL;
+    for (int k = 0; k < 10; ++k) out[k] = 0;
+    if (v3_eligible(n_ppfs, n_rots, gx, gy, gz)) {
+        const V3Tiling t = v3_tiling(gx, gy, gz);
+        int wgs = v3_wgs(n_ppfs, t.T);
+        if (t.T < 4) wgs = (wgs / t.T) * t.T;
+        const int o[10] = {t.T < 4 ? 2 : 3, t.T, t.tx, t.ty, t.ntx, t.nty, t.hx, t.hy, wgs, v3_fixed_bits_bound(n_ppfs, n_rots, gx, gy, gz)};
+        for (int k = 0; k < 10; ++k) out[k] = o[k];
+        return 0;
+    }
+    const VotePlan pl = make_vote_plan(n_ppfs, n_rots, gx, gy, gz);
+    const int o[10] = {pl.tiled ? 1 : 0, pl.T, pl.tx, pl.ty, pl.ntx, pl.nty, 0, 0, pl.tiled ? pl.T * pl.chunks : 0, vote_fixed_bits(pl, n_rots)};
+    for (int k = 0; k < 10; ++k) out[k] = o[k];
+    return 0;
+}
+
 static int v3_launch(const float* points, const float* outputs, const float* probs, const void* point_idxs, int idx_is_i64,
                      float* grid_obj, const float* corner, float res, int64_t n_points, int64_t n_ppfs, int n_rots, int gx, int gy,
                      int gz, int adaptive, int accumulate, bool want_argmax, long long* out_idx, float* out_val, void* workspace,

@@ -160,6 +160,10 @@ size_t cppf_vote_workspace_bytes_dyn_pairs(int many_tiles, int64_t n_ppfs);
  * fresh allocation (one hipMemsetAsync); every call leaves them ready for the next one.  A call on a workspace whose header
  * was never initialised reports arg-max -1 / peak NaN. */
 size_t cppf_vote_workspace_init_bytes(void);
+/* What a by-value vote launch will do for this problem (tests, tools): out int32[10] = {path, tiles, tx, ty, ntx, nty, halo_x,
+ * halo_y, workgroups, fixed-point bits}; path 0: global fp32 atomics (> 64 tiles), 1: round-2 tiled kernels (n_rots > 72),
+ * 2: fused kernel (< 4 tiles), 3: binning + queue-consuming kernels (>= 4 tiles).  Host only, no device needed. */
+int cppf_vote_plan_query(int64_t n_ppfs, int n_rots, int gx, int gy, int gz, int32_t* out);
 int cppf_vote_argmax_dyn(const float* points, const float* outputs, const float* probs, const void* point_idxs,
                          int idx_is_i64, float* grid_obj, int64_t grid_capacity, const float* corner, float res,
                          int64_t n_points_cap, int64_t n_ppfs, int n_rots, const int32_t* shape_dev, int many_tiles,

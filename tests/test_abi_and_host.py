@@ -375,3 +375,40 @@ def test_error_codes_surface_as_readable_cppf_errors():
     assert "invalid" in texts[1].lower() and "memory" in texts[2].lower()
     assert len(set(texts.values())) == len(texts)
     assert b"unknown" in L.cppf_error_string(-77)
+
+
+def test_vote_plans_respect_their_invariants_without_a_device():
+    """the round-3 tilings (owned cells + halo) over a sweep of grids: every tile with its halo fits the LDS tile, the tiles cover
+    the grid, the path follows the tile count, the workspace holds one partial tile per workgroup (+ the queues for >= 4 tiles)"""
+    import numpy as np
+    from cppf_amd import _lib
+    L = _lib.lib()
+    cells = L.cppf_vote_tile_cells()
+    out = (C.c_int32 * 10)()
+    rng = np.random.default_rng(0)
+    seen = set()
+    cases = [(26, 76, 26), (52, 152, 52), (67, 34, 67), (1, 1, 1), (300, 3, 40), (3, 300, 40), (120, 120, 120), (20, 20, 3000)]
+    cases += [tuple(int(v) for v in rng.integers(1, 160, 3)) for _ in range(200)]
+    for gx, gy, gz in cases:
+        P = int(rng.integers(1, 3_000_000))
+        assert L.cppf_vote_plan_query(P, 72, gx, gy, gz, out) == 0
+        path, T, tx, ty, ntx, nty, hx, hy, wgs, bits = list(out)
+        seen.add(path)
+        need = L.cppf_vote_workspace_bytes(P, 72, gx, gy, gz)
+        if path in (2, 3):
+            assert T == ntx * nty and 1 <= T <= 64 and (path == 2) == (T < 4)
+            assert (tx + hx) * (ty + hy) * gz <= cells                       # a tile with its halo fits the LDS tile
+            assert ntx * tx >= gx > (ntx - 1) * tx and nty * ty >= gy > (nty - 1) * ty     # the tiles cover the grid, none is empty
+            assert hx == (1 if ntx > 1 else 0) and hy == (1 if nty > 1 else 0)
+            assert T <= wgs <= 1024 and 8 <= bits <= 24
+            slot = ((tx + hx) * (ty + hy) * gz + 3) // 4 * 4
+            assert need >= wgs * slot * 4 + (T * P * 12 if path == 3 else 0)
+            assert T == L.cppf_vote_tiles(gx, gy, gz) or L.cppf_vote_tiles(gx, gy, gz) > T     # (the query reports the larger of the two kernels' needs)
+        elif path == 1:                      # a tall grid whose tile + halo does not fit but round 2's halo-less tile does
+            assert 1 <= T <= 64 and wgs >= T and need > 1 << 20
+        else:
+            assert path == 0 and need < 1 << 20                              # > 64 tiles: global atomics
+        # n_rots > 72 never takes the round-3 kernels
+        assert L.cppf_vote_plan_query(P, 100, gx, gy, gz, out) == 0 and out[0] in (0, 1)
+    assert {2, 3} <= seen
+    assert L.cppf_vote_plan_query(10, 72, 0, 4, 4, out) == -1 and L.cppf_vote_plan_query(10, 72, 4, 4, 4, None) == -1
