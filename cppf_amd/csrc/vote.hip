@@ -1961,12 +1961,20 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
         }
     } else {
         // cull (vote_kernel's, against the owned box) + compaction through a per-wave queue, blocks of 64 pairs from an LDS counter
-        int qn = 0;
+        // The cull pays when it removes pairs (a random-weight network: three quarters of them); on a trained network's inputs
+        // nearly every circle passes and it is ~5 % of the kernel for nothing.  So a wave whose last culled block kept >= 48 of 64
+        // pairs takes its next blocks as they are -- a pair the cull would have dropped only yields an empty mask -- and culls
+        // every eighth block again to notice a change.
+        int qn = 0, direct = 0, since = 0;
         for (;;) {
             int blk = 0;
             if (lane == 0) blk = atomicAdd(&ctrl[4], 1);
             const int64_t pb = p0 + 64 * (int64_t)__builtin_amdgcn_readfirstlane(blk);
             const bool more = pb < p1;
+            if (more && direct && (++since & 7) != 0) {
+                process(pb + lane, pb + lane < p1, 0u, 0u);
+                continue;
+            }
             if (more) {
                 const int64_t p = pb + lane;
                 bool pass = false;
@@ -2003,6 +2011,7 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
                 if (pass)
                     pairq[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] = (uint32_t)(p - p0);
                 qn += __popcll(m);
+                direct = __popcll(m) >= 48 ? 1 : 0;
             }
             while (qn >= 64 || (!more && qn > 0)) {
                 const int take = qn < 64 ? qn : 64;
