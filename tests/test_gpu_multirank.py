@@ -102,3 +102,30 @@ def test_two_ranks_on_one_gpu_equal_the_single_rank_batch(oracle, golden, dev, t
         np.testing.assert_allclose(recs[j, 0:3], o["T"], atol=1e-12)
         np.testing.assert_allclose(recs[j, 3:6], o["up"], atol=1e-12)
         np.testing.assert_allclose(recs[j, 9:12], o["scale"], rtol=1e-6)
+
+
+def test_bench_runs_with_two_ranks_on_one_gpu(tmp_path):
+    """the driver's scaling run launches `bench.py --gpus N` with one rank per GPU over RCCL; here the same code path (object per rank
+    per step, barrier-bracketed timed region, max over ranks, ONE gather of the records, rank 0 prints the JSON line) with two ranks
+    sharing GPU 0 over gloo -- for the single-object chain and for the 64-object batch of BASELINE.json configs[3]"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in (["--steps", "6", "--objects", "3"], ["--config", "c4", "--steps", "8", "--n-points", "1024", "--pairs-per-point", "32"]):
+        port = _free_port()
+        procs = []
+        for rank in range(2):
+            env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       CPPF_DIST_BACKEND="gloo")
+            procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--warmup", "1",
+                                           "--no-secondary", "--no-cpu-baseline"] + extra, env=env, stdout=subprocess.PIPE,
+                                          stderr=subprocess.PIPE, text=True))
+        outs = [p.communicate(timeout=600) for p in procs]
+        assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+        lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
+        assert len(lines) == 1 and not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]      # rank 0 alone prints
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["value"] > 0 and d["unit"] == "pairs/s" and d["higher_is_better"] is True
+        assert d["metric"].startswith("point-pairs/sec") and "workload" in d["config"]
+        assert d["scaling"] == ("strong" if "c4" in extra else "weak")
