@@ -1255,11 +1255,13 @@ __host__ __device__ inline V3Tiling v3_tiling(int gx, int gy, int gz)
     return p;
 }
 __host__ __device__ inline int v3_slot_words(const V3Tiling& t, int gz) { return ((t.tx + t.hx) * (t.ty + t.hy) * gz + 3) & ~3; }
-// workgroups of the vote launch: ~one per CU for a few tiles, 512 / 1024 when the votes pile up in the few tiles around the peak
-// (see vote_wgs), never more than one per 512 pairs and tile
+// workgroups of the vote launch: one per CU (a workgroup fills a CU's LDS, so 256 of them run as ONE round: with two to four rounds
+// the per-workgroup prologue / dump and the quantisation of the last round cost 7 % (known-answer) to 19 % (uniform bins) of the
+// C5 vote, profiles/r3_vote_phases.txt), never more than one per 512 pairs and tile
+#define V3_WGS 256
 __host__ __device__ inline int v3_wgs(int64_t n_ppfs, int T)
 {
-    int64_t w = T < 4 ? 256 : (T <= 8 ? 512 : 1024);
+    int64_t w = V3_WGS;
     const int64_t wmax = ((n_ppfs + 511) / 512) * T;
     if (w > wmax) w = wmax;
     return (int)(w < T ? T : w);
@@ -1274,6 +1276,14 @@ __host__ __device__ inline unsigned v3_bound(unsigned n, int c, int C)
 // fixed-point bits: a workgroup deposits at most (records of its chunk) x n_rots weights <= 1; every 2^32 quanta of that is one
 // carry-log entry (VOTE_CARRY_CAP of them per workgroup)
 __host__ __device__ inline int v3_bits(unsigned chunk_records, int n_rots) { return vote_fixed_bits_of((int64_t)chunk_records + 64, n_rots); }
+
+// fused form: the pair list is dealt to a tile's C workgroups in blocks of 64, block b to workgroup b mod C (neighbouring pairs share
+// their first point, so contiguous chunks would inherit the cloud's unevenness); the most pairs a workgroup can get
+__host__ __device__ inline int64_t v3_fused_chunk_pairs(int64_t n_ppfs, int C)
+{
+    const int64_t nb = (n_ppfs + 63) / 64;
+    return (nb + C - 1) / (C > 0 ? C : 1) * 64;
+}
 
 struct V3Plan { V3Tiling t; int wgs, slot; size_t pool_off, part_off, total; int64_t pool_cap; };
 // pool: T queues of `cap` records (12 B) each -- every pair can visit every tile, and the HBM is there (288 GB)
@@ -1343,7 +1353,7 @@ __device__ __forceinline__ void v3_split(const V3Args& A, int T, int* sp)
         if (threadIdx.x < 64) {
             const int C = lane < T ? A.wgs / T : 0;
             sp[lane] = C; sp[64 + lane] = lane * C; sp[128 + lane] = 0x7fffffff;
-            if (lane == 0) sp[192] = (int)((A.n_ppfs + C - 1) / C);
+            if (lane == 0) sp[192] = (int)v3_fused_chunk_pairs(A.n_ppfs, C);
         }
         return;
     }
@@ -1711,6 +1721,10 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
     float2* ltab = reinterpret_cast<float2*>(below + VOTE_BELOW_N);
     uint32_t* tile = reinterpret_cast<uint32_t*>(ltab + A.tab_entries + 2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef V3_TRACE   // development aid (profiles/microbench/vote_trace.py): wall-clock stamps per workgroup in the unused tail of the extra plane
+    unsigned long long* trace = A.plane + 1500000 + (int64_t)blockIdx.x * 32;
+    if (tid == 0) trace[0] = wall_clock64();
+#endif
     int gx, gy, gz;
     int64_t n_points;
     V3Tiling pt;
@@ -1738,10 +1752,9 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
     // binned: records [r0, r1) of the tile's queue; fused: pairs [p0, p1) of the pair list
     unsigned r0 = 0u, r1 = 0u;
     int64_t p0 = 0, p1 = 0;
-    if (FUSED) {
-        const int64_t cp = (A.n_ppfs + Ct - 1) / (Ct > 0 ? Ct : 1);
-        p0 = min((int64_t)c * cp, A.n_ppfs); p1 = min(p0 + cp, A.n_ppfs);
-        if (p0 >= p1 && blockIdx.x != 0) return;
+    if (FUSED) {   // blocks c, c + Ct, c + 2 Ct, ... of 64 pairs (v3_fused_chunk_pairs)
+        p0 = 0; p1 = A.n_ppfs;
+        if ((int64_t)c * 64 >= p1 && blockIdx.x != 0) return;
     } else {
         if (t >= 0) { r0 = v3_bound(n_t, c, Ct); r1 = v3_bound(n_t, c + 1, Ct); }
         if (r0 >= r1 && blockIdx.x != 0) return;     // nothing queued for this chunk: no tile to zero or dump (the reduce kernel skips it too)
@@ -1834,6 +1847,9 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
         A.hdr->quantum = S > 0.f ? 1.0f / S : 0.f;
     }
 
+#ifdef V3_TRACE
+    if (tid == 0) trace[1] = wall_clock64();
+#endif
     const f3 cr = {A.corner[0], A.corner[1], A.corner[2]};
     const float res = A.res, rinv = 1.0f / res;
     V3Tile VT;
@@ -1902,6 +1918,9 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
             const uint32_t wB = ((uint32_t)max(s1 - s0 - l0, 0) << 3) | ((uint32_t)max(s2 - s1 - l1, 0) << 19);
             const int tabS = ((__mul24(n, n - 1) >> 1) + s0) << 3;
             const int Bn = (total + 63) >> 6;
+#ifdef V3_TRACE
+            if (lane == 0) { atomicAdd(&ctrl[8], Bn); atomicAdd(&ctrl[9], 1); }
+#endif
             const int q0 = __mul24(lane, Bn);
             const int mine = min(max(total - q0, 0), Bn);
             int src = 0;
@@ -1921,25 +1940,30 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
                 q.tab = __shfl(tabS, from, 64);
                 return q;
             };
-            Pulled cur = pull(src);
-            for (int it = 0; it < Bn; ++it) {
-                const uint32_t a = cur.a, b = cur.b;
+            // two steps per trip, the frames ping-ponging between `cur` and `nx` (a single-step loop copies the 13 pulled registers
+            // every step); each step requests the next step's frame (behind its own table read) before it deposits
+            auto step = [&](const int it, const Pulled& use, Pulled& next) {
+                const uint32_t a = use.a, b = use.b;
                 const int t1 = (int)((a >> 8) & 0xffu), t2 = (int)((a >> 16) & 0xffu);
-                const int toff = cur.tab + (k << 3) + ((int)(b & 0xffffu) & -(int)(k >= t1)) + ((int)(b >> 16) & -(int)(k >= t2));
+                const int toff = use.tab + (k << 3) + ((int)(b & 0xffffu) & -(int)(k >= t1)) + ((int)(b >> 16) & -(int)(k >= t2));
                 k += 1;
                 const bool adv = k >= (int)(a >> 24);
                 src = adv ? (int)(a & 0xffu) : src;
                 k = adv ? 0 : k;
                 const float2 cs = *reinterpret_cast<const float2*>(ltab_b + (it < mine ? toff : 0));
                 __builtin_amdgcn_sched_barrier(0);
-                const Pulled nx = pull(src);
+                next = pull(src);
                 __builtin_amdgcn_sched_barrier(0);
                 if (it < mine) {
-                    const f3 offset = add3(scl3(cur.x, cs.x), scl3(cur.y, cs.y));      // :34
-                    const f3 v = sub3(add3(cur.cc, offset), cr);                       // numerator of :35
-                    v3_deposit(VT, v, cur.prob);
+                    const f3 offset = add3(scl3(use.x, cs.x), scl3(use.y, cs.y));      // :34
+                    const f3 v = sub3(add3(use.cc, offset), cr);                       // numerator of :35
+                    v3_deposit(VT, v, use.prob);
                 }
-                cur = nx;
+            };
+            Pulled cur = pull(src), nx;
+            for (int it = 0; it < Bn; it += 2) {
+                step(it, cur, nx);
+                if (it + 1 < Bn) step(it + 1, nx, cur);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1969,7 +1993,7 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
         for (;;) {
             int blk = 0;
             if (lane == 0) blk = atomicAdd(&ctrl[4], 1);
-            const int64_t pb = p0 + 64 * (int64_t)__builtin_amdgcn_readfirstlane(blk);
+            const int64_t pb = 64 * ((int64_t)c + (int64_t)__builtin_amdgcn_readfirstlane(blk) * Ct);
             const bool more = pb < p1;
             if (more && direct && (++since & 7) != 0) {
                 process(pb + lane, pb + lane < p1, 0u, 0u);
@@ -2026,7 +2050,13 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
 
     // ---- dump: raw fixed point (the reduce kernel adds the partial tiles as integers); the halo's non-zero words and the logged
     // wrap-arounds go to the extra plane instead (device-scope 64-bit atomics, a few hundred per workgroup)
+#ifdef V3_TRACE
+    if (lane == 0) { trace[8 + wave] = wall_clock64(); unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); if (wave < 8) trace[24 + wave] = hw; }
+#endif
     __syncthreads();
+#ifdef V3_TRACE
+    if (tid == 0) { trace[2] = wall_clock64(); trace[4] = (unsigned long long)t; trace[5] = (unsigned long long)c; trace[6] = (unsigned long long)ctrl[8]; trace[7] = (unsigned long long)ctrl[9]; }
+#endif
     const int slot = v3_slot_words(pt, gz);
     uint4* part4 = reinterpret_cast<uint4*>(A.partials + (int64_t)blockIdx.x * slot);
     const uint4* t4 = reinterpret_cast<const uint4*>(tile);
@@ -2054,6 +2084,10 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
         }
     }
     if (__any(wrote) && lane == 0) A.hdr->any_extra = 1u;
+#ifdef V3_TRACE
+    __syncthreads();
+    if (tid == 0) trace[3] = wall_clock64();
+#endif
 }
 
 // ---------------------------------------------------------------------------- v3_reduce_kernel
@@ -2119,8 +2153,8 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, in
             if (raw) { acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w; }
             else { facc[0] += __uint_as_float(v.x); facc[1] += __uint_as_float(v.y); facc[2] += __uint_as_float(v.z); facc[3] += __uint_as_float(v.w); }
         };
-        // binned: >= 64 records per chunk, none is empty; fused: chunks of cp pairs, empty from ceil(P / cp) on
-        const int64_t cp = A.fused ? (A.n_ppfs + C - 1) / (C > 0 ? C : 1) : 0;
+        // binned: >= 64 records per chunk, none is empty; fused: workgroup c owns the blocks c, c + C, ...: empty from ceil(P / 64) on
+        const int64_t cp = 64;
         const bool full = A.fused ? (int64_t)(C - 1) * cp < A.n_ppfs : n_own >= 64u * (unsigned)C;
         int c = cg;
         if (full) {
@@ -2226,17 +2260,17 @@ extern "C" size_t cppf_vote_workspace_init_bytes(void)
 static bool v3_eligible(int64_t n_ppfs, int n_rots, int gx, int gy, int gz)
 {
     static const bool legacy = getenv("CPPF_VOTE_LEGACY") != nullptr;   // A/B switch for tests and profiles
-    if (legacy || n_ppfs < 1 || tri(n_rots) > VOTE_TAB_LDS_MAX) return false;
+    if (legacy || n_ppfs < 1 || n_ppfs > 0xffffffffll || tri(n_rots) > VOTE_TAB_LDS_MAX) return false;   // (pair numbers travel as u32)
     return v3_tiling(gx, gy, gz).T <= VOTE_MAX_TILES;
 }
 static int v3_fixed_bits_bound(int64_t n_ppfs, int n_rots, int gx, int gy, int gz)
 {
     const V3Tiling t = v3_tiling(gx, gy, gz);
     const int wgs = v3_wgs(n_ppfs, t.T);
-    if (t.T < 4) { const int C = wgs / t.T; return v3_bits((unsigned)((n_ppfs + C - 1) / C), n_rots); }   // (what v3_launch passes)
-    // binned: chunk <= W / E <= P T / (wgs - T) records (C_t = 1 + floor(n_t E / W) >= n_t E / W)
+    if (t.T < 4) return v3_bits((unsigned)v3_fused_chunk_pairs(n_ppfs, wgs / t.T), n_rots);   // (what v3_launch passes)
+    // binned: chunk <= W / E <= P T / (wgs - T) records (C_t = 1 + floor(n_t E / W) >= n_t E / W), and never more than a tile's queue (<= P)
     const int64_t E = wgs - t.T > 0 ? wgs - t.T : 1;
-    const int64_t worst = (n_ppfs * t.T + E - 1) / E + 1;
+    const int64_t worst = min(n_ppfs, (n_ppfs * t.T + E - 1) / E + 1);
     return v3_bits((unsigned)(worst > 0x7fffffff ? 0x7fffffff : worst), n_rots);
 }
 static size_t v3_workspace_bytes(int64_t n_ppfs, int gx, int gy, int gz)
@@ -2246,7 +2280,7 @@ static size_t v3_workspace_bytes(int64_t n_ppfs, int gx, int gy, int gz)
 }
 static size_t v3_workspace_bytes_dyn(int many_tiles, int64_t n_ppfs)
 {
-    const int t_cap = many_tiles ? VOTE_MAX_TILES : 3, wgs = many_tiles ? 1024 : 256;
+    const int t_cap = many_tiles ? VOTE_MAX_TILES : 3, wgs = V3_WGS;
     return VOTE_WS_PART + V3_HDR_BYTES + V3_PLANE_BYTES + (many_tiles ? align_up((size_t)t_cap * (size_t)n_ppfs * 12, 256) : 0) +
            (size_t)wgs * V3_TILE_FLOATS * sizeof(uint32_t);
 }
@@ -2290,7 +2324,7 @@ static int v3_launch(const float* points, const float* outputs, const float* pro
     int red_blocks;
     if (shape_dev) {
         A.t_cap = many_tiles ? VOTE_MAX_TILES : 3;
-        A.wgs = many_tiles ? 1024 : 256;
+        A.wgs = V3_WGS;
         A.fused = many_tiles ? 0 : 1;
         if (grid_cap > (int64_t)A.t_cap * V3_TILE_FLOATS) return CPPF_EINVAL;   // (a grid of the class has at most that many cells)
         A.pool = reinterpret_cast<uint32_t*>(ws + VOTE_WS_PART + V3_HDR_BYTES + V3_PLANE_BYTES);
@@ -2303,7 +2337,7 @@ static int v3_launch(const float* points, const float* outputs, const float* pro
         A.fused = A.t.T < 4 ? 1 : 0;
         if (A.fused) {   // static chunks: the same number for every tile
             A.wgs = (A.wgs / A.t.T) * A.t.T;
-            A.kk = v3_bits((unsigned)((n_ppfs + A.wgs / A.t.T - 1) / (A.wgs / A.t.T)), n_rots);
+            A.kk = v3_bits((unsigned)v3_fused_chunk_pairs(n_ppfs, A.wgs / A.t.T), n_rots);
         }
         A.t_cap = A.t.T;
         const V3Plan pl = v3_plan(n_ppfs, A.t, gz, v3_wgs(n_ppfs, A.t.T), A.fused ? 0 : n_ppfs, (int64_t)gx * gy * gz);
