@@ -1202,6 +1202,7 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void reduce_tiles_kernel(RedArgs R
 #define V3_MAGIC 0x43503356u
 #define V3_THREADS 1024
 #define V3_BIN_THREADS 512
+#define V3_BIN_SR 8               // blocks of 64 pairs a wave culls per super-round
 #define V3_IRING 256              // per-wave ring of (lane, tile) items: <= 63 waiting + 64 pushed
 #define V3_CNT_STRIDE 32
 struct V3Hdr {                    // workspace + VOTE_WS_PART; all zero (or left by a previous call) when a launch starts
@@ -1327,6 +1328,7 @@ struct V3Args {
     long long* out_idx;
     float* out_val;
     int tab_entries;
+    int bin_sr;            // bin kernel: blocks of 64 pairs a wave culls per super-round
     int fused;             // < 4 tiles: no queues, workgroup (tile, chunk) culls and screens its own pairs (chunks = wgs / T)
     int kk;                // fused, by-value launches: fixed-point bits (the chunks are static)
 };
@@ -1428,6 +1430,7 @@ __global__ __launch_bounds__(V3_BIN_THREADS) void v3_bin_kernel(V3Args A)
     uint32_t* gbase = cnt + VOTE_MAX_TILES;                                   // [64] their place in the tile's queue
     uint32_t* ctl = gbase + VOTE_MAX_TILES;                                   // [0] staged, [1] a wave could not stage
     uint16_t* iring = reinterpret_cast<uint16_t*>(ctl + 16) + (threadIdx.x >> 6) * V3_IRING;   // this wave's (lane, tile) items
+    uint32_t* pq = reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(ctl + 16) + (V3_BIN_THREADS / 64) * V3_IRING) + (threadIdx.x >> 6) * (64 * V3_BIN_SR + 64);   // this wave's culled pairs
     const int tid = threadIdx.x, lane = tid & 63;
     int gx, gy, gz;
     int64_t n_points;
@@ -1444,165 +1447,244 @@ __global__ __launch_bounds__(V3_BIN_THREADS) void v3_bin_kernel(V3Args A)
         below[j] = make_uint4(w(j), w(j - 32), w(j - 64), 0u);
     }
     if (tid < VOTE_MAX_TILES) cnt[tid] = 0u;
-    if (tid == 0) { ctl[0] = 0u; ctl[1] = 0u; }
+    if (tid == 0) { ctl[0] = 0u; ctl[1] = 0u; ctl[2] = 0u; }
     for (int i = tid; i < V3_STAGE; i += V3_BIN_THREADS) stage[i].w = 0xffffffffu;   // "empty" mark of a staging slot
     const f3 cr = {A.corner[0], A.corner[1], A.corner[2]};
     const float res = A.res, rinv = 1.0f / res;
     const float ptxf = (float)t.tx, ptyf = (float)t.ty;
     const float rtx = 1.0f / ptxf, rty = 1.0f / ptyf;
-    const int64_t rounds = (A.n_ppfs + V3_BIN_THREADS - 1) / V3_BIN_THREADS;
     __syncthreads();
-    for (int64_t r = blockIdx.x; r < rounds; r += gridDim.x) {
-        const int64_t p = r * V3_BIN_THREADS + tid;
-        const bool last_round = r + gridDim.x >= rounds;
-        // ---- per pair: the frame in APPROXIMATE arithmetic (reciprocal / rsqrt, ~45 instructions instead of the ~180 of the exact
-        // frame with its IEEE divisions and square roots).  It only feeds the arc screen, whose acceptance boxes are widened by
-        // more than its error (relative ~1e-6 on every component: below); the consumer recomputes the exact frame.  What must
-        // agree exactly between the two kernels is the rotation count n (:31: a division and a product of the stored (mu, nu),
-        // no frame involved); a pair the consumer finds degenerate (:21) deposits nothing whatever was queued for it, and the test
-        // here keeps every pair the exact test can keep (L >= 0.9e-7 for the exact L >= 1e-7).
-        f3 Fcc = {0.f, 0.f, 0.f}, Fx = Fcc, Fy = Fcc, Fu = Fcc;
-        float Rq = 0.f;   // the circle's radius in cells
-        int n = 0;
-        if (p < A.n_ppfs) {
-            const float2 o = reinterpret_cast<const float2*>(A.outputs)[p];
-            const int2 ij = v3_pair_idx(A, p);
-            const f3 a = ld3(A.points, ij.x), b = ld3(A.points, ij.y);
-            const f3 d = sub3(a, b);
-            const float L2 = fmaf(d.z, d.z, fmaf(d.y, d.y, d.x * d.x));
-            const float L = __builtin_amdgcn_sqrtf(L2);
-            if (L >= 0.9e-7f) {
-                const f3 u = scl3(d, __builtin_amdgcn_rcpf(L + 1e-7f));
-                Fu = u;
-                Rq = fabsf(o.y) * rinv;
-                Fcc = {fmaf(-u.x, o.x, a.x), fmaf(-u.y, o.x, a.y), fmaf(-u.z, o.x, a.z)};                 // :23
-                f3 co = {0.f, -u.z, u.y};                                                                 // :26-27
-                float lc = __builtin_amdgcn_sqrtf(fmaf(u.y, u.y, u.z * u.z));
-                if (lc < 1e-6f) { co = {-u.y, u.x, 0.f}; lc = __builtin_amdgcn_sqrtf(fmaf(u.y, u.y, u.x * u.x)); }
-                Fx = scl3(co, o.y * __builtin_amdgcn_rcpf(lc + 1e-7f));                                   // :28
-                Fy = {fmaf(Fx.y, u.z, -Fx.z * u.y), fmaf(Fx.z, u.x, -Fx.x * u.z), fmaf(Fx.x, u.y, -Fx.y * u.x)};   // :29
-                n = A.n_rots;
-                if (A.adaptive) n = min((int)((double)(o.y / res) * (2 * CPPF_PI)), A.n_rots);   // :31
-                n = max(n, 0);
+    // per-lane state of the batch a wave is working on (one pair per lane), set by setup()
+    int64_t p = 0;
+    bool valid = false;
+    f3 Fcc = {0.f, 0.f, 0.f}, Fx = Fcc, Fy = Fcc, Fu = Fcc, cq = Fcc, xq = Fcc, yq = Fcc;
+    float Rq = 0.f, ex = 0.f, ey = 0.f, ez = 0.f, nf = 0.f, slq = 0.f;   // Rq: the circle's radius in cells
+    int n = 0, ix0 = 0, ix1 = -1, iy0 = 0, iy1 = -1, nxw = 0, nyw = 0, nsteps = 0, step = 0, wdx = 0, wdy = 0, qhead = 0, qtail = 0;
+    AxisArc ax = {0.f, 0.f, 0.f}, ay = ax;
+    Mask96 mz = {0u, 0u, 0u};
+    // ---- cull: a pair whose circle cannot reach the grid at all (a random-weight network: half of them at C5) is dropped before any
+    // of the above is computed -- bounding box, plane and shell against the whole grid (vote_kernel's test, ~60 instructions) -- and the
+    // survivors are compacted through a per-wave queue so that the frame, the arc parameters and the tile walk run with full lanes.
+    // On a trained network's inputs nearly every circle passes: a wave whose last culled block kept >= 48 of 64 takes its next seven
+    // blocks as they are (v3_vote_kernel<true> does the same).
+    const float gbx = 0.5f * ((float)gx - 1.f), gby = 0.5f * ((float)gy - 1.f), gbz = 0.5f * ((float)gz - 1.f);       // box centre
+    const float ghx = 0.5f * ((float)gx - 1.02f), ghy = 0.5f * ((float)gy - 1.02f), ghz = 0.5f * ((float)gz - 1.02f);   // half extents
+    auto cull = [&](const int64_t q) -> bool {
+        const float2 o = reinterpret_cast<const float2*>(A.outputs)[q];
+        const int2 ij = v3_pair_idx(A, q);
+        const f3 a = ld3(A.points, ij.x), b = ld3(A.points, ij.y);
+        const f3 d = sub3(a, b);
+        const float L = __builtin_amdgcn_sqrtf(fmaf(d.z, d.z, fmaf(d.y, d.y, d.x * d.x)));
+        const f3 u = scl3(d, __builtin_amdgcn_rcpf(L + 1e-7f));
+        const f3 cc = {fmaf(-u.x, o.x, a.x), fmaf(-u.y, o.x, a.y), fmaf(-u.z, o.x, a.z)};
+        const float R = fabsf(o.y) * rinv;
+        const float ax_ = R * __builtin_amdgcn_sqrtf(fmaxf(0.f, 1.f - u.x * u.x)), ay_ = R * __builtin_amdgcn_sqrtf(fmaxf(0.f, 1.f - u.y * u.y)),
+                    az_ = R * __builtin_amdgcn_sqrtf(fmaxf(0.f, 1.f - u.z * u.z));
+        const float sl = fmaf(R, 1.1e-3f, 4e-3f);
+        const float sx = sl + 8e-6f * (fabsf(cc.x) + fabsf(cr.x)) * rinv, sy = sl + 8e-6f * (fabsf(cc.y) + fabsf(cr.y)) * rinv,
+                    sz = sl + 8e-6f * (fabsf(cc.z) + fabsf(cr.z)) * rinv;
+        const float qx = (cc.x - cr.x) * rinv, qy = (cc.y - cr.y) * rinv, qz = (cc.z - cr.z) * rinv;
+        const float dx = gbx - qx, dy = gby - qy, dz = gbz - qz, sall = sl + (sx - sl) + (sy - sl) + (sz - sl);
+        const float off_plane = fabsf((dx * u.x + dy * u.y) + dz * u.z);
+        const float reach = (fabsf(u.x) * ghx + fabsf(u.y) * ghy) + fabsf(u.z) * ghz;
+        const float nx = fmaxf(fabsf(dx) - ghx, 0.f), ny = fmaxf(fabsf(dy) - ghy, 0.f), nz = fmaxf(fabsf(dz) - ghz, 0.f);
+        const float fx = fabsf(dx) + ghx, fy = fabsf(dy) + ghy, fz = fabsf(dz) + ghz;
+        const float dmin2 = (nx * nx + ny * ny) + nz * nz, dmax2 = (fx * fx + fy * fy) + fz * fz;
+        const float r_hi = R + sall, r_lo = fmaxf(R - sall, 0.f);
+        return (L >= 0.9e-7f) & (!A.adaptive | (R >= 0.15f)) &
+               (qx + ax_ + sx >= 0.01f) & (qx - ax_ - sx < (float)gx - 1.01f) & (qy + ay_ + sy >= 0.01f) & (qy - ay_ - sy < (float)gy - 1.01f) &
+               (qz + az_ + sz >= 0.01f) & (qz - az_ - sz < (float)gz - 1.01f) &
+               (off_plane <= reach + sall) & (dmin2 <= r_hi * r_hi * 1.0001f) & (dmax2 * 1.0001f >= r_lo * r_lo);
+    };
+    auto setup = [&]() {
+            // ---- per pair: the frame in APPROXIMATE arithmetic (reciprocal / rsqrt, ~45 instructions instead of the ~180 of the exact
+            // frame with its IEEE divisions and square roots).  It only feeds the arc screen, whose acceptance boxes are widened by
+            // more than its error (relative ~1e-6 on every component: below); the consumer recomputes the exact frame.  What must
+            // agree exactly between the two kernels is the rotation count n (:31: a division and a product of the stored (mu, nu),
+            // no frame involved); a pair the consumer finds degenerate (:21) deposits nothing whatever was queued for it, and the test
+            // here keeps every pair the exact test can keep (L >= 0.9e-7 for the exact L >= 1e-7).
+            Fcc = {0.f, 0.f, 0.f}; Fx = Fcc; Fy = Fcc; Fu = Fcc;
+            Rq = 0.f;
+            n = 0;
+            if (valid) {
+                const float2 o = reinterpret_cast<const float2*>(A.outputs)[p];
+                const int2 ij = v3_pair_idx(A, p);
+                const f3 a = ld3(A.points, ij.x), b = ld3(A.points, ij.y);
+                const f3 d = sub3(a, b);
+                const float L2 = fmaf(d.z, d.z, fmaf(d.y, d.y, d.x * d.x));
+                const float L = __builtin_amdgcn_sqrtf(L2);
+                if (L >= 0.9e-7f) {
+                    const f3 u = scl3(d, __builtin_amdgcn_rcpf(L + 1e-7f));
+                    Fu = u;
+                    Rq = fabsf(o.y) * rinv;
+                    Fcc = {fmaf(-u.x, o.x, a.x), fmaf(-u.y, o.x, a.y), fmaf(-u.z, o.x, a.z)};                 // :23
+                    f3 co = {0.f, -u.z, u.y};                                                                 // :26-27
+                    float lc = __builtin_amdgcn_sqrtf(fmaf(u.y, u.y, u.z * u.z));
+                    if (lc < 1e-6f) { co = {-u.y, u.x, 0.f}; lc = __builtin_amdgcn_sqrtf(fmaf(u.y, u.y, u.x * u.x)); }
+                    Fx = scl3(co, o.y * __builtin_amdgcn_rcpf(lc + 1e-7f));                                   // :28
+                    Fy = {fmaf(Fx.y, u.z, -Fx.z * u.y), fmaf(Fx.z, u.x, -Fx.x * u.z), fmaf(Fx.x, u.y, -Fx.y * u.x)};   // :29
+                    n = A.n_rots;
+                    if (A.adaptive) n = min((int)((double)(o.y / res) * (2 * CPPF_PI)), A.n_rots);   // :31
+                    n = max(n, 0);
+                }
             }
-        }
-        const f3 cq = scl3(sub3(Fcc, cr), rinv), xq = scl3(Fx, rinv), yq = scl3(Fy, rinv);
-        // slack of the screen: the exact-frame form (1e-6 of the terms + 1e-3 cells, see vote_kernel) plus the approximate frame's
-        // own error -- rcp / sqrt are good to 1 ulp, so u, x, y carry a few 1e-7 relative: <= ~5e-7 m on a sample for |mu|, nu up to
-        // 0.3 m (1e-6 m at the 1.9 m of the SUN RGB-D categories), i.e. <= 2.5e-4 cells at res 2e-3 -- hence 4e-6 and 2e-3
-        const float ex = fmaf((fabsf(Fcc.x) + fabsf(cr.x) + fabsf(Fx.x) + fabsf(Fy.x)) * rinv, 4e-6f, 2e-3f);
-        const float ey = fmaf((fabsf(Fcc.y) + fabsf(cr.y) + fabsf(Fx.y) + fabsf(Fy.y)) * rinv, 4e-6f, 2e-3f);
-        const float ez = fmaf((fabsf(Fcc.z) + fabsf(cr.z) + fabsf(Fx.z) + fabsf(Fy.z)) * rinv, 4e-6f, 2e-3f);
-        const float nf = (float)n * 0.159154943f;
-        const AxisArc ax = axis_arc_prep(cq.x, xq.x, yq.x, nf), ay = axis_arc_prep(cq.y, xq.y, yq.y, nf),
-                      az = axis_arc_prep(cq.z, xq.z, yq.z, nf);
-        const Mask96 mz = axis_arc_eval(below, az, 0.01f - ez, (float)gz - 1.01f + ez, nf, n);
-        // tiles the circle's bounding box touches: coordinate range [c - A, c + A] (+ slack) against owned ranges [x0, x0 + tx)
-        const float Ax = __builtin_amdgcn_sqrtf(fmaf(xq.x, xq.x, yq.x * yq.x)) * 1.0001f + ex + 2e-3f;
-        const float Ay = __builtin_amdgcn_sqrtf(fmaf(xq.y, xq.y, yq.y * yq.y)) * 1.0001f + ey + 2e-3f;
-        const float xlo = fmaxf(cq.x - Ax, 0.f), xhi = fminf(cq.x + Ax, (float)gx - 1.f);
-        const float ylo = fmaxf(cq.y - Ay, 0.f), yhi = fminf(cq.y + Ay, (float)gy - 1.f);
-        const bool alive = n > 0 && (mz.a | mz.b | mz.c) != 0u && xlo <= xhi && ylo <= yhi;   // (NaN coordinates: not alive)
-        int ix0 = 0, ix1 = -1, iy0 = 0, iy1 = -1;
-        if (alive) {
-            // (a float quotient may land one tile off at a boundary: one extra tile either side costs an empty mask, never a vote)
-            ix0 = max((int)(xlo * rtx) - 1, 0); ix1 = min((int)(xhi * rtx) + 1, t.ntx - 1);
-            iy0 = max((int)(ylo * rty) - 1, 0); iy1 = min((int)(yhi * rty) + 1, t.nty - 1);
-            // trim: a column / row the box does not reach
-            ix0 += ((float)((ix0 + 1) * t.tx) <= xlo) ? 1 : 0;
-            ix1 -= ((float)(ix1 * t.tx) > xhi) ? 1 : 0;
-            iy0 += ((float)((iy0 + 1) * t.ty) <= ylo) ? 1 : 0;
-            iy1 -= ((float)(iy1 * t.ty) > yhi) ? 1 : 0;
-        }
-        // ---- (pair, tile) items.  A circle's bounding box covers many tiles while the curve passes through few (all of them against
-        // 0.75 on uniform-bin inputs at C5, 12 against 3.4 on known-answer inputs), and a per-lane loop over the box runs every lane
-        // to the wave's longest range.  So the box is walked with a CHEAP test only -- the tile's box must reach the circle's plane,
-        // and the radius must lie between the box's nearest and farthest distance from the centre (vote_kernel's plane / shell test,
-        // ~35 instructions) -- and the (lane, tile) pairs that pass go through a per-wave ring in LDS; whenever 64 are queued every
-        // lane takes one, pulls the owning lane's arc parameters (ds_bpermute) and does the expensive part with full lanes: the x and
-        // y masks of that tile, AND with the z mask, runs, record.  Records are staged in LDS across rounds and flushed -- one global
-        // atomic per tile -- when the area is half full, when a wave finds it full (it retries its batch after the flush), and after
-        // the workgroup's last round.
-        const int nxw = wave_max_i32(ix1 - ix0 + 1), nyw = wave_max_i32(iy1 - iy0 + 1);   // this wave's walk
-        const int nsteps = nxw * nyw;
-        const float slq = fmaf(Rq, 1.1e-3f, 4e-3f);
-        int step = 0, qhead = 0, qtail = 0;
-        auto produce = [&]() {
-            const int dx = step / nyw, dy = step - dx * nyw;
-            const int ix = ix0 + dx, iy = iy0 + dy;
-            bool pass = false;
-            if (ix <= ix1 && iy <= iy1) {
-                const float x0f = (float)(ix * t.tx), y0f = (float)(iy * t.ty);
-                const float bx0 = fmaxf(0.01f, x0f), bx1 = fminf((float)gx - 1.01f, x0f + ptxf);
-                const float by0 = fmaxf(0.01f, y0f), by1 = fminf((float)gy - 1.01f, y0f + ptyf);
-                const float hx_ = 0.5f * (bx1 - bx0) + ex, hy_ = 0.5f * (by1 - by0) + ey, hz_ = 0.5f * ((float)gz - 1.02f) + ez;
-                const float ddx = 0.5f * (bx0 + bx1) - cq.x, ddy = 0.5f * (by0 + by1) - cq.y, ddz = 0.5f * ((float)gz - 1.f) - cq.z;
-                const float off_plane = fabsf(fmaf(ddz, Fu.z, fmaf(ddy, Fu.y, ddx * Fu.x)));
-                const float reach = fmaf(fabsf(Fu.z), hz_, fmaf(fabsf(Fu.y), hy_, fabsf(Fu.x) * hx_));
-                const float nx_ = fmaxf(fabsf(ddx) - hx_, 0.f), ny_ = fmaxf(fabsf(ddy) - hy_, 0.f), nz_ = fmaxf(fabsf(ddz) - hz_, 0.f);
-                const float fx_ = fabsf(ddx) + hx_, fy_ = fabsf(ddy) + hy_, fz_ = fabsf(ddz) + hz_;
-                const float dmin2 = fmaf(nz_, nz_, fmaf(ny_, ny_, nx_ * nx_)), dmax2 = fmaf(fz_, fz_, fmaf(fy_, fy_, fx_ * fx_));
-                const float r_hi = Rq + slq, r_lo = fmaxf(Rq - slq, 0.f);
-                pass = (bx0 < bx1) & (by0 < by1) & (off_plane <= reach + slq) & (dmin2 <= r_hi * r_hi * 1.0001f) &
-                       (dmax2 * 1.0001f >= r_lo * r_lo);
+            cq = scl3(sub3(Fcc, cr), rinv); xq = scl3(Fx, rinv); yq = scl3(Fy, rinv);
+            // slack of the screen: the exact-frame form (1e-6 of the terms + 1e-3 cells, see vote_kernel) plus the approximate frame's
+            // own error -- rcp / sqrt are good to 1 ulp, so u, x, y carry a few 1e-7 relative: <= ~5e-7 m on a sample for |mu|, nu up to
+            // 0.3 m (1e-6 m at the 1.9 m of the SUN RGB-D categories), i.e. <= 2.5e-4 cells at res 2e-3 -- hence 4e-6 and 2e-3
+            ex = fmaf((fabsf(Fcc.x) + fabsf(cr.x) + fabsf(Fx.x) + fabsf(Fy.x)) * rinv, 4e-6f, 2e-3f);
+            ey = fmaf((fabsf(Fcc.y) + fabsf(cr.y) + fabsf(Fx.y) + fabsf(Fy.y)) * rinv, 4e-6f, 2e-3f);
+            ez = fmaf((fabsf(Fcc.z) + fabsf(cr.z) + fabsf(Fx.z) + fabsf(Fy.z)) * rinv, 4e-6f, 2e-3f);
+            nf = (float)n * 0.159154943f;
+            ax = axis_arc_prep(cq.x, xq.x, yq.x, nf); ay = axis_arc_prep(cq.y, xq.y, yq.y, nf);
+            const AxisArc az = axis_arc_prep(cq.z, xq.z, yq.z, nf);
+            mz = axis_arc_eval(below, az, 0.01f - ez, (float)gz - 1.01f + ez, nf, n);
+            // tiles the circle's bounding box touches: coordinate range [c - A, c + A] (+ slack) against owned ranges [x0, x0 + tx)
+            const float Ax = __builtin_amdgcn_sqrtf(fmaf(xq.x, xq.x, yq.x * yq.x)) * 1.0001f + ex + 2e-3f;
+            const float Ay = __builtin_amdgcn_sqrtf(fmaf(xq.y, xq.y, yq.y * yq.y)) * 1.0001f + ey + 2e-3f;
+            const float xlo = fmaxf(cq.x - Ax, 0.f), xhi = fminf(cq.x + Ax, (float)gx - 1.f);
+            const float ylo = fmaxf(cq.y - Ay, 0.f), yhi = fminf(cq.y + Ay, (float)gy - 1.f);
+            const bool alive = n > 0 && (mz.a | mz.b | mz.c) != 0u && xlo <= xhi && ylo <= yhi;   // (NaN coordinates: not alive)
+            ix0 = 0; ix1 = -1; iy0 = 0; iy1 = -1;
+            if (alive) {
+                // (a float quotient may land one tile off at a boundary: one extra tile either side costs an empty mask, never a vote)
+                ix0 = max((int)(xlo * rtx) - 1, 0); ix1 = min((int)(xhi * rtx) + 1, t.ntx - 1);
+                iy0 = max((int)(ylo * rty) - 1, 0); iy1 = min((int)(yhi * rty) + 1, t.nty - 1);
+                // trim: a column / row the box does not reach
+                ix0 += ((float)((ix0 + 1) * t.tx) <= xlo) ? 1 : 0;
+                ix1 -= ((float)(ix1 * t.tx) > xhi) ? 1 : 0;
+                iy0 += ((float)((iy0 + 1) * t.ty) <= ylo) ? 1 : 0;
+                iy1 -= ((float)(iy1 * t.ty) > yhi) ? 1 : 0;
             }
+            nxw = __builtin_amdgcn_readfirstlane(wave_max_i32(ix1 - ix0 + 1));       // this wave's walk (wave-uniform: scalar registers,
+            nyw = __builtin_amdgcn_readfirstlane(wave_max_i32(iy1 - iy0 + 1));       // scalar branches in the walk below)
+            nsteps = nxw * nyw; wdx = 0; wdy = 0;
+            slq = fmaf(Rq, 1.1e-3f, 4e-3f);
+            step = 0; qhead = 0; qtail = 0;
+    };
+    // ---- (pair, tile) items.  A circle's bounding box covers many tiles while the curve passes through few (all of them against
+    // 0.75 on uniform-bin inputs at C5, 12 against 3.4 on known-answer inputs), and a per-lane loop over the box runs every lane
+    // to the wave's longest range.  So the box is walked with a CHEAP test only -- the tile's box must reach the circle's plane,
+    // and the radius must lie between the box's nearest and farthest distance from the centre (vote_kernel's plane / shell test,
+    // ~35 instructions) -- and the (lane, tile) pairs that pass go through a per-wave ring in LDS; whenever 64 are queued every
+    // lane takes one, pulls the owning lane's arc parameters (ds_bpermute) and does the expensive part with full lanes: the x and
+    // y masks of that tile, AND with the z mask, runs, record.  Records are staged in LDS across rounds and flushed -- one global
+    // atomic per tile -- when the area is half full, when a wave finds it full (it retries its batch after the flush), and after
+    // the workgroup's last round.
+    auto produce = [&]() {
+        const int ix = ix0 + wdx, iy = iy0 + wdy;   // step = wdx nyw + wdy
+        bool pass = false;
+        if (ix <= ix1 && iy <= iy1) {
+            const float x0f = (float)(ix * t.tx), y0f = (float)(iy * t.ty);
+            const float bx0 = fmaxf(0.01f, x0f), bx1 = fminf((float)gx - 1.01f, x0f + ptxf);
+            const float by0 = fmaxf(0.01f, y0f), by1 = fminf((float)gy - 1.01f, y0f + ptyf);
+            const float hx_ = 0.5f * (bx1 - bx0) + ex, hy_ = 0.5f * (by1 - by0) + ey, hz_ = 0.5f * ((float)gz - 1.02f) + ez;
+            const float ddx = 0.5f * (bx0 + bx1) - cq.x, ddy = 0.5f * (by0 + by1) - cq.y, ddz = 0.5f * ((float)gz - 1.f) - cq.z;
+            const float off_plane = fabsf(fmaf(ddz, Fu.z, fmaf(ddy, Fu.y, ddx * Fu.x)));
+            const float reach = fmaf(fabsf(Fu.z), hz_, fmaf(fabsf(Fu.y), hy_, fabsf(Fu.x) * hx_));
+            const float nx_ = fmaxf(fabsf(ddx) - hx_, 0.f), ny_ = fmaxf(fabsf(ddy) - hy_, 0.f), nz_ = fmaxf(fabsf(ddz) - hz_, 0.f);
+            const float fx_ = fabsf(ddx) + hx_, fy_ = fabsf(ddy) + hy_, fz_ = fabsf(ddz) + hz_;
+            const float dmin2 = fmaf(nz_, nz_, fmaf(ny_, ny_, nx_ * nx_)), dmax2 = fmaf(fz_, fz_, fmaf(fy_, fy_, fx_ * fx_));
+            const float r_hi = Rq + slq, r_lo = fmaxf(Rq - slq, 0.f);
+            pass = (bx0 < bx1) & (by0 < by1) & (off_plane <= reach + slq) & (dmin2 <= r_hi * r_hi * 1.0001f) &
+                   (dmax2 * 1.0001f >= r_lo * r_lo);
+        }
+        const unsigned long long m = __ballot(pass);
+        if (pass) {
+            const int pos = qtail + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+            iring[pos & (V3_IRING - 1)] = (uint16_t)(lane | ((ix * t.nty + iy) << 6));
+        }
+        qtail += __popcll(m);
+        ++step;
+        if (++wdy == nyw) { wdy = 0; ++wdx; }
+    };
+    // one item per lane: masks of its tile, runs, record; false (nothing consumed) when the staging area cannot take the batch
+    auto consume = [&](const int count) -> bool {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const unsigned code = iring[(qhead + lane) & (V3_IRING - 1)];
+        const int src = (int)(code & 63u), tile = (int)(code >> 6);
+        // (all 64 lanes execute the pulls)
+        AxisArc bx_, by_;
+        bx_.c = __shfl(ax.c, src, 64); bx_.rA = __shfl(ax.rA, src, 64); bx_.f = __shfl(ax.f, src, 64);
+        by_.c = __shfl(ay.c, src, 64); by_.rA = __shfl(ay.rA, src, 64); by_.f = __shfl(ay.f, src, 64);
+        const float sex = __shfl(ex, src, 64), sey = __shfl(ey, src, 64);
+        const int sn = __shfl(n, src, 64);
+        const uint32_t z0 = (uint32_t)__shfl((int)mz.a, src, 64), z1 = (uint32_t)__shfl((int)mz.b, src, 64), z2 = (uint32_t)__shfl((int)mz.c, src, 64);
+        const uint32_t sp_ = (uint32_t)__shfl((int)(uint32_t)p, src, 64);
+        uint32_t m0 = 0u, m1 = 0u, m2 = 0u;
+        if (lane < count) {
+            const int ix = tile / t.nty, iy = tile - ix * t.nty;
+            const float x0f = (float)(ix * t.tx), y0f = (float)(iy * t.ty);
+            const float snf = (float)sn * 0.159154943f;
+            const Mask96 mx = axis_arc_eval(below, bx_, fmaxf(0.01f, x0f) - sex, fminf((float)gx - 1.01f, x0f + ptxf) + sex, snf, sn);
+            const Mask96 my = axis_arc_eval(below, by_, fmaxf(0.01f, y0f) - sey, fminf((float)gy - 1.01f, y0f + ptyf) + sey, snf, sn);
+            m0 = mx.a & my.a & z0; m1 = mx.b & my.b & z1; m2 = mx.c & my.c & z2;
+        }
+        const bool have = (m0 | m1 | m2) != 0u;
+        const unsigned long long hm = __ballot(have);
+        const int nh = __popcll(hm);
+        if (nh == 0) return true;
+        int base = 0;
+        if (lane == 0) base = (int)atomicAdd(&ctl[0], (uint32_t)nh);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base + nh > V3_STAGE) {   // full: ask for a flush and retry this batch afterwards (the slots it drew stay empty: the
+            if (lane == 0) ctl[1] = 1u;   // flush copies marked entries only)
+            return false;
+        }
+        if (have) {
+            int s0, e0, s1, e1, s2, e2;
+            mask_runs(below, m0, m1, m2, s0, e0, s1, e1, s2, e2);
+            const int l2 = max(e2 - s2, 0);
+            const uint32_t slot = atomicAdd(&cnt[tile], 1u);
+            const uint32_t ra = (uint32_t)s0 | ((uint32_t)(e0 - s0) << 8) | ((uint32_t)s1 << 16) | ((uint32_t)(e1 - s1) << 24);
+            const uint32_t rb = (uint32_t)s2 | ((uint32_t)l2 << 8) | ((uint32_t)tile << 24);
+            const int fi = base + __builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0));
+            stage[fi] = make_uint4(sp_, ra, rb, slot);
+        }
+        return true;
+    };
+    // Super-rounds of bin_sr x 512 pairs per workgroup: every wave first culls its 64 bin_sr pairs into its queue (independent
+    // load chains back to back: the latency is paid once, not per 64 pairs), then the workgroup runs batch rounds -- one full batch of
+    // the queue per wave and round, the flush protocol between them -- until no wave has 64 left (none at all after the last super-round).
+    int qn = 0;
+    const int srb = A.bin_sr;   // blocks of 64 pairs per wave and super-round (<= V3_BIN_SR; fewer when the pair list is short)
+    const int64_t n_sr = (A.n_ppfs + (int64_t)V3_BIN_THREADS * srb - 1) / ((int64_t)V3_BIN_THREADS * srb);
+    for (int64_t sr = blockIdx.x; sr < n_sr; sr += gridDim.x) {
+        const bool last_sr = sr + gridDim.x >= n_sr;
+        const int64_t base = sr * ((int64_t)V3_BIN_THREADS * srb) + (int64_t)(tid >> 6) * (64 * srb);
+        int dense = 0;   // the super-round's first block kept >= 48 of 64: the others are queued as they are
+#pragma unroll 2
+        for (int blk = 0; blk < srb; ++blk) {
+            const int64_t pin = base + blk * 64 + lane;
+            if (base + blk * 64 >= A.n_ppfs) break;
+            bool pass = pin < A.n_ppfs && (dense || cull(pin));
+            if (blk == 0 && __popcll(__ballot(pass)) >= 48) { dense = 1; pass = pin < A.n_ppfs; }   // (whole blocks: the batches stay full)
             const unsigned long long m = __ballot(pass);
-            if (pass) {
-                const int pos = qtail + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                iring[pos & (V3_IRING - 1)] = (uint16_t)(lane | ((ix * t.nty + iy) << 6));
-            }
-            qtail += __popcll(m);
-            ++step;
-        };
-        // one item per lane: masks of its tile, runs, record; false (nothing consumed) when the staging area cannot take the batch
-        auto consume = [&](const int count) -> bool {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            const unsigned code = iring[(qhead + lane) & (V3_IRING - 1)];
-            const int src = (int)(code & 63u), tile = (int)(code >> 6);
-            // (all 64 lanes execute the pulls)
-            AxisArc bx_, by_;
-            bx_.c = __shfl(ax.c, src, 64); bx_.rA = __shfl(ax.rA, src, 64); bx_.f = __shfl(ax.f, src, 64);
-            by_.c = __shfl(ay.c, src, 64); by_.rA = __shfl(ay.rA, src, 64); by_.f = __shfl(ay.f, src, 64);
-            const float sex = __shfl(ex, src, 64), sey = __shfl(ey, src, 64);
-            const int sn = __shfl(n, src, 64);
-            const uint32_t z0 = (uint32_t)__shfl((int)mz.a, src, 64), z1 = (uint32_t)__shfl((int)mz.b, src, 64), z2 = (uint32_t)__shfl((int)mz.c, src, 64);
-            const uint32_t sp_ = (uint32_t)__shfl((int)(uint32_t)p, src, 64);
-            uint32_t m0 = 0u, m1 = 0u, m2 = 0u;
-            if (lane < count) {
-                const int ix = tile / t.nty, iy = tile - ix * t.nty;
-                const float x0f = (float)(ix * t.tx), y0f = (float)(iy * t.ty);
-                const float snf = (float)sn * 0.159154943f;
-                const Mask96 mx = axis_arc_eval(below, bx_, fmaxf(0.01f, x0f) - sex, fminf((float)gx - 1.01f, x0f + ptxf) + sex, snf, sn);
-                const Mask96 my = axis_arc_eval(below, by_, fmaxf(0.01f, y0f) - sey, fminf((float)gy - 1.01f, y0f + ptyf) + sey, snf, sn);
-                m0 = mx.a & my.a & z0; m1 = mx.b & my.b & z1; m2 = mx.c & my.c & z2;
-            }
-            const bool have = (m0 | m1 | m2) != 0u;
-            const unsigned long long hm = __ballot(have);
-            const int nh = __popcll(hm);
-            if (nh == 0) return true;
-            int base = 0;
-            if (lane == 0) base = (int)atomicAdd(&ctl[0], (uint32_t)nh);
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (base + nh > V3_STAGE) {   // full: ask for a flush and retry this batch afterwards (the slots it drew stay empty: the
-                if (lane == 0) ctl[1] = 1u;   // flush copies marked entries only)
-                return false;
-            }
-            if (have) {
-                int s0, e0, s1, e1, s2, e2;
-                mask_runs(below, m0, m1, m2, s0, e0, s1, e1, s2, e2);
-                const int l2 = max(e2 - s2, 0);
-                const uint32_t slot = atomicAdd(&cnt[tile], 1u);
-                const uint32_t ra = (uint32_t)s0 | ((uint32_t)(e0 - s0) << 8) | ((uint32_t)s1 << 16) | ((uint32_t)(e1 - s1) << 24);
-                const uint32_t rb = (uint32_t)s2 | ((uint32_t)l2 << 8) | ((uint32_t)tile << 24);
-                const int fi = base + __builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0));
-                stage[fi] = make_uint4(sp_, ra, rb, slot);
-            }
-            return true;
-        };
+            if (pass) pq[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] = (uint32_t)pin;
+            qn += __popcll(m);
+        }
+        const int nb = (qn >> 6) + ((last_sr && (qn & 63)) ? 1 : 0);   // this wave's batches
+        if (lane == 0) atomicMax(&ctl[2], (uint32_t)nb);
+        __syncthreads();
+        const int nbmax = (int)ctl[2];
+        for (int round = 0; round < nbmax; ++round) {
+        const bool last_round = last_sr && round == nbmax - 1;
+        bool todo = round < nb, busy = false;
         for (;;) {
-            // this wave: walk and consume until its items are done or the staging area is full
+            // this wave: its batch of the round, walked and consumed until its items are done or the staging area is full
             bool stuck = false;
             while (!stuck) {
+                if (!busy) {
+                    if (!todo) break;
+                    todo = false;
+                    const int take = qn < 64 ? qn : 64;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    valid = lane < take;
+                    p = valid ? (int64_t)pq[qn - take + lane] : 0;
+                    qn -= take;
+                    setup();
+                    busy = true;
+                }
                 const int queued = qtail - qhead;
                 if (queued >= 64 || (step >= nsteps && queued > 0)) {
                     const int take = queued < 64 ? queued : 64;
@@ -1610,7 +1692,7 @@ __global__ __launch_bounds__(V3_BIN_THREADS) void v3_bin_kernel(V3Args A)
                 } else if (step < nsteps) {
                     produce();
                 } else {
-                    break;
+                    busy = false;
                 }
             }
             __syncthreads();
@@ -1641,6 +1723,9 @@ __global__ __launch_bounds__(V3_BIN_THREADS) void v3_bin_kernel(V3Args A)
             __syncthreads();
             if (!again) break;
         }
+        }
+        if (tid == 0) ctl[2] = 0u;   // (read by everybody before the rounds' barriers; the next super-round's atomicMax comes after them)
+        __syncthreads();
     }
 }
 
@@ -2358,8 +2443,12 @@ static int v3_launch(const float* points, const float* outputs, const float* pro
         hipLaunchKernelGGL(v3_vote_kernel<true>, dim3((unsigned)A.wgs), dim3(V3_THREADS), lds_vote, st, A);
         CPPF_CHECK_LAUNCH();
     } else {
-        const int64_t rounds = (n_ppfs + V3_BIN_THREADS - 1) / V3_BIN_THREADS;
-        const size_t lds_bin = (size_t)V3_STAGE * 16 + VOTE_BELOW_N * 16 + 2 * VOTE_MAX_TILES * 4 + 64 + (V3_BIN_THREADS / 64) * V3_IRING * 2;
+        // super-rounds of bin_sr x 512 pairs: as long as possible, but two workgroups for every CU first
+        int64_t srb = n_ppfs / ((int64_t)V3_BIN_THREADS * 512);
+        srb = srb < 1 ? 1 : (srb > V3_BIN_SR ? V3_BIN_SR : srb);
+        A.bin_sr = (int)srb;
+        const int64_t rounds = (n_ppfs + V3_BIN_THREADS * srb - 1) / (V3_BIN_THREADS * srb);
+        const size_t lds_bin = (size_t)V3_STAGE * 16 + VOTE_BELOW_N * 16 + 2 * VOTE_MAX_TILES * 4 + 64 + (V3_BIN_THREADS / 64) * (V3_IRING * 2 + (64 * V3_BIN_SR + 64) * 4);
         hipLaunchKernelGGL(v3_bin_kernel, dim3((unsigned)(rounds < 512 ? rounds : 512)), dim3(V3_BIN_THREADS), lds_bin, st, A);
         CPPF_CHECK_LAUNCH();
         hipLaunchKernelGGL(v3_vote_kernel<false>, dim3((unsigned)A.wgs), dim3(V3_THREADS), lds_vote, st, A);
