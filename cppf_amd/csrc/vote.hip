@@ -2200,7 +2200,12 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, in
     int64_t n_points;
     V3Tiling pt;
     const bool fits = v3_resolve(A, gx, gy, gz, n_points, pt);
-    if (!fits || (A.hdr->flags & 1u)) {   // nothing valid was voted: say so (index -1, NaN) and leave a clean header
+    // everything this block needs from the header in ONE round trip (a block's life is a chain of dependent HBM round trips -- header,
+    // queue counters, partial tiles, extra plane, the two reports -- of ~1.5 us each; the first two and the middle two now overlap)
+    const unsigned hflags = A.hdr->flags, hextra = A.hdr->any_extra, hfmt = A.hdr->fmt;
+    const float hquantum = A.hdr->quantum;
+    if (fits) v3_split(A, pt.T, sp);
+    if (!fits || (hflags & 1u)) {   // nothing valid was voted: say so (index -1, NaN) and leave a clean header
         if (tid == 0) {   // (the ticket lives with the arg-max keys, which the vote / bin kernel zeroed before looking at the header)
             const unsigned tk = atomicAdd(reinterpret_cast<unsigned*>(A.packed + 18), 1u);
             if (tk == gridDim.x - 1) {
@@ -2213,18 +2218,20 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, in
     }
     const int T = pt.T;
     const int slot = v3_slot_words(pt, gz);
-    const int t = blockIdx.x / bps, j = blockIdx.x - t * bps;
-    if (t >= T) return;
+    __syncthreads();   // (sp)
+    const bool raw = hfmt == 0u;
+    const bool any_extra = hextra != 0u;
+    unsigned long long best = 0ull;   // this thread's arg-max key over the block's items
+    // a block takes the items (tile t, run j of RED_CELLS words) blockIdx, blockIdx + gridDim, ...: header, split and the two reports
+    // once per block, not once per item (a grid of 16 tiles has 1 760 items)
+    for (int item = blockIdx.x; item < T * bps; item += gridDim.x) {
+    const int t = item / bps, j = item - t * bps;
     const int tix = t / pt.nty, tiy = t - tix * pt.nty;
     const int x0 = tix * pt.tx, y0 = tiy * pt.ty;
     const int tx = min(pt.tx, gx - x0), ty = min(pt.ty, gy - y0);
     const int tyh = pt.ty + pt.hy, ltyz = tyh * gz;
     const int nwords = (tx + pt.hx) * ltyz;
-    if (j * RED_CELLS >= nwords) return;
-    v3_split(A, T, sp);
-    __syncthreads();
-    const bool raw = A.hdr->fmt == 0u;
-    const bool any_extra = A.hdr->any_extra != 0u;
+    if (j * RED_CELLS >= nwords) continue;
     const int C = sp[t], base_b = sp[64 + t];
     const unsigned n_own = (unsigned)sp[128 + t];
 
@@ -2267,51 +2274,43 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, in
         ly = rem / gz; z = rem - ly * gz;
         owned = lx < tx && ly < ty;
     }
+    // what the neighbours' halos and the wrap-arounds added for this cell (requested before the barrier: it travels with the partial
+    // tiles); the plane is left clean for the next launch
+    const int64_t cell = ((int64_t)(x0 + lx) * gy + (y0 + ly)) * gz + z;
+    unsigned long long ext = 0ull;
+    float prev = 0.f;
+    if (owned && any_extra) ext = A.plane[cell];
+    if (owned && A.accumulate) prev = A.grid[cell];
     __syncthreads();
-    unsigned long long key = 0ull;
     if (owned) {
-        const int64_t cell = ((int64_t)(x0 + lx) * gy + (y0 + ly)) * gz + z;
         float v;
-        // what the neighbours' halos and the wrap-arounds added for this cell; the plane is left clean for the next launch
-        unsigned long long ext = 0ull;
-        if (any_extra) { ext = A.plane[cell]; if (ext) A.plane[cell] = 0ull; }
+        if (ext) A.plane[cell] = 0ull;
         if (raw) {
             unsigned long long s_ = ext;
 #pragma unroll
             for (int g = 0; g < RED_GROUPS; ++g) s_ += part[g][tid];
-            v = (float)((double)s_ * (double)A.hdr->quantum);   // s < 2^53, the quantum a power of two: one rounding
+            v = (float)((double)s_ * (double)hquantum);   // s < 2^53, the quantum a power of two: one rounding
         } else {
             v = __uint_as_float((uint32_t)ext);
 #pragma unroll
             for (int g = 0; g < RED_GROUPS; ++g) v = v + __uint_as_float((uint32_t)part[g][tid]);
         }
-        if (A.accumulate) v = A.grid[cell] + v;
+        if (A.accumulate) v = prev + v;
         A.grid[cell] = v;
-        key = ((unsigned long long)f2ord(v) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)cell);
+        const unsigned long long key = ((unsigned long long)f2ord(v) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)cell);
+        best = key > best ? key : best;
     }
+    __syncthreads();   // (part: the next item's sums)
+    }
+    unsigned long long key = best;
     if (tid < RED_CELLS) {
         key = wave_max_u64(key);
         if (lane == 0) wkey[cg] = key;
     }
-    // blocks that report to this block's arg-max group, and groups in use (see reduce_tiles_kernel): tile t sends its blocks
-    // j = g, g + 8, ... < nb_t to group g
-    unsigned n_group = 0, n_groups_used = 0;
-    if (cg == 0) {
-        unsigned nb = 0;
-        if (lane < T) {
-            const int ax = lane / pt.nty;
-            nb = (unsigned)(((min(pt.tx, gx - ax * pt.tx) + pt.hx) * ltyz + RED_CELLS - 1) / RED_CELLS);
-        }
-        const unsigned gsel = blockIdx.x & (RED_FANIN - 1);
-        unsigned mine = nb > gsel ? (nb - gsel + RED_FANIN - 1) / RED_FANIN : 0u, most = nb;
-        for (int off = 32; off > 0; off >>= 1) {
-            mine += __shfl_xor(mine, off, 64);
-            const unsigned o = __shfl_xor(most, off, 64);
-            most = o > most ? o : most;
-        }
-        n_group = mine;
-        n_groups_used = most < RED_FANIN ? most : RED_FANIN;
-    }
+    // two-level arg-max (see reduce_tiles_kernel): block b reports to group b mod RED_FANIN, a group's last reporter reports for it
+    const unsigned gsel = blockIdx.x & (RED_FANIN - 1);
+    const unsigned n_group = (gridDim.x - gsel + RED_FANIN - 1) / RED_FANIN;
+    const unsigned n_groups_used = gridDim.x < RED_FANIN ? gridDim.x : RED_FANIN;
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < RED_CELLS / 64; ++w) key = wkey[w] > key ? wkey[w] : key;
@@ -2321,14 +2320,13 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, in
             asm volatile("v_mov_b32 %0, %1" : "=v"(d2) : "v"(d1));
             return atomicAdd(reinterpret_cast<unsigned*>(slot_ + 1), 1u + (d1 ^ d2));
         };
-        const unsigned g = blockIdx.x & (RED_FANIN - 1);
-        unsigned long long* gslot = A.packed + 2 + 2 * g;
+        unsigned long long* gslot = A.packed + 2 + 2 * gsel;
         if (report(gslot, key) == n_group - 1) {
             const unsigned long long gbest = atomicMax(gslot, 0ull);
             if (report(A.packed, gbest) == n_groups_used - 1) {
-                const unsigned long long best = atomicMax(A.packed, 0ull);
-                if (A.out_idx) *A.out_idx = (long long)(0xffffffffu - (uint32_t)(best & 0xffffffffull));
-                if (A.out_val) *A.out_val = ord2f((uint32_t)(best >> 32));
+                const unsigned long long best_all = atomicMax(A.packed, 0ull);
+                if (A.out_idx) *A.out_idx = (long long)(0xffffffffu - (uint32_t)(best_all & 0xffffffffull));
+                if (A.out_val) *A.out_val = ord2f((uint32_t)(best_all >> 32));
                 v3_rezero(A.hdr);   // every block has finished reading the header: its report came after its last read
             }
         }
@@ -2455,7 +2453,8 @@ static int v3_launch(const float* points, const float* outputs, const float* pro
         CPPF_CHECK_LAUNCH();
     }
     const int bps = red_blocks / A.t_cap;
-    hipLaunchKernelGGL(v3_reduce_kernel, dim3((unsigned)red_blocks), dim3(64 * RED_GROUPS), 0, st, A, bps);
+    // (two workgroups of 16 waves fill a CU: at most one round of blocks, each looping over its items)
+    hipLaunchKernelGGL(v3_reduce_kernel, dim3((unsigned)(red_blocks < 2 * V3_WGS ? red_blocks : 2 * V3_WGS)), dim3(64 * RED_GROUPS), 0, st, A, bps);
     CPPF_CHECK_LAUNCH();
     return 0;
 }
