@@ -1813,15 +1813,25 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
     int gx, gy, gz;
     int64_t n_points;
     V3Tiling pt;
+    // Everything the prologue reads from HBM is requested HERE, in one round trip (header words, the cached rotation table's stamp,
+    // probe entries and -- speculatively -- the table itself, the queue counters inside v3_split): read one after the other behind the
+    // branches that use them they were four dependent round trips, 5 us of a 38 us launch.
+    float2* wtab = reinterpret_cast<float2*>(reinterpret_cast<char*>(A.packed) + VOTE_WS_TAB);
+    const unsigned hmagic = A.hdr->magic, hflags = A.hdr->flags;
+    const unsigned long long tstamp = A.packed[31];
+    float2 probe[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const int n_ = lane + 1 + 64 * u; probe[u] = n_ <= A.n_rots ? wtab[n_ * (n_ - 1) / 2] : make_float2(1.f, 0.f); }
+    float2 tab_in[(VOTE_TAB_LDS_MAX + V3_THREADS - 1) / V3_THREADS];
+#pragma unroll
+    for (int u = 0; u < (VOTE_TAB_LDS_MAX + V3_THREADS - 1) / V3_THREADS; ++u)
+        tab_in[u] = tid + u * V3_THREADS < A.tab_entries ? wtab[tid + u * V3_THREADS] : make_float2(0.f, 0.f);
     if (FUSED && blockIdx.x == 0 && tid < 20) A.packed[tid] = 0ull;   // arg-max keys + tickets of the reduce kernel (binned: the bin kernel did)
     if (!v3_resolve(A, gx, gy, gz, n_points, pt)) return;
-    if (FUSED) {   // (binned: the bin kernel checked)
-        const unsigned m = A.hdr->magic;
-        if (m != 0u && m != V3_MAGIC) { if (tid == 0) atomicOr(&A.hdr->flags, 1u); return; }   // workspace never initialised
-    }
-    if (A.hdr->flags & 1u) return;
     int* sp = reinterpret_cast<int*>(carry_log);   // (the carry log is unused until the main loop)
     v3_split(A, pt.T, sp);
+    if (FUSED && hmagic != 0u && hmagic != V3_MAGIC) { if (tid == 0) atomicOr(&A.hdr->flags, 1u); return; }   // workspace never initialised (binned: the bin kernel checked)
+    if (hflags & 1u) return;
     __syncthreads();
     // this workgroup's tile and chunk (a uniform scan of <= 64 tiles)
     int t = -1, c = 0, Ct = 0;
@@ -1869,14 +1879,9 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
             }
         }
     }
-    float2* wtab = reinterpret_cast<float2*>(reinterpret_cast<char*>(A.packed) + VOTE_WS_TAB);
-    const bool tab_cached = A.packed[31] == (VOTE_TAB_STAMP ^ (unsigned long long)A.n_rots) && rot_table_intact(wtab, A.n_rots);
-    float2 tab_in[(VOTE_TAB_LDS_MAX + V3_THREADS - 1) / V3_THREADS];
-    if (tab_cached) {
-#pragma unroll
-        for (int u = 0; u < (VOTE_TAB_LDS_MAX + V3_THREADS - 1) / V3_THREADS; ++u)
-            if (tid + u * V3_THREADS < A.tab_entries) tab_in[u] = wtab[tid + u * V3_THREADS];
-    }
+    // (the cached table is trusted if its stamp matches and rotation 0 of every n is exactly (1, 0): rot_table_intact's test)
+    const bool probe_ok = probe[0].x == 1.0f && probe[0].y == 0.0f && probe[1].x == 1.0f && probe[1].y == 0.0f;
+    const bool tab_cached = tstamp == (VOTE_TAB_STAMP ^ (unsigned long long)A.n_rots) && !__any(!probe_ok);
     if (tid < 16) ctrl[tid] = 0;
     for (int k = tid; k < (nwords + 3) >> 2; k += V3_THREADS) reinterpret_cast<uint4*>(tile)[k] = make_uint4(0u, 0u, 0u, 0u);
     if (tid < VOTE_BELOW_N) {
