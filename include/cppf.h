@@ -140,7 +140,8 @@ int cppf_compact_mask(const uint8_t* mask, int64_t n, int32_t* surv, int32_t* co
  * by-value entry points for the same real shape, bit for bit: the kernels evaluate the same plan function on the device;
  * capacities only size allocations and launch geometry.
  *   cppf_vote_tiles           LDS tiles the vote needs for a grid (0: more than the tiled path serves) -- lets the caller
- *                             pick `many_tiles` (needed when any instance can need >= 4 tiles; costs a 2 048-workgroup launch)
+ *                             pick `many_tiles` (needed when any instance can need >= 4 tiles; costs the binning launch and the
+ *                             room for the pair -> tile queues, see cppf_vote_workspace_bytes_dyn_pairs)
  *   cppf_vote_argmax_dyn      cppf_vote_argmax; grid_obj holds grid_capacity cells, the real grid f32[gx,gy,gz] occupies its
  *                             first gx*gy*gz cells; probs/points rows beyond n_points are never read.  A record that exceeds
  *                             a capacity (cells, n_points_cap, tiles) writes out_idx = -1, out_val = NaN and votes nothing.
