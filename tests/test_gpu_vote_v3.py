@@ -143,3 +143,25 @@ def test_negative_probs_on_cut_grids(oracle, dev, dims, res):
     gg, flat, peak = run_vote(dev, ob["pc"], out, idx, corner, dims, res, 72, True)
     g64, cnt = check_grid(oracle, gg, ob["pc"], out, idx, corner, dims, res, 72, True)
     assert flat == int(np.argmax(g64))
+
+
+@pytest.mark.parametrize("n_pairs", [700, 262144 + 77, 3 * 262144 + 1000, 5 * 262144 - 3])
+def test_binned_vote_super_round_lengths(oracle, dev, n_pairs):
+    """v3_bin_kernel culls and queues its pairs in super-rounds of bin_sr x 512 per workgroup, bin_sr = 1 .. 8 by the length of the pair
+    list (ragged tails included): many-tile grid, a trained network's regime (every block dense: queued unculled) and a random-weight
+    network's (half of the circles miss the grid: culled, compacted), every cell against the exact sum"""
+    n, k = 4096, 320
+    ob = syn.make_object("bottle", n, 11)
+    idx = syn.make_pairs(n, k, 11)[:n_pairs].astype(np.int32)
+    cfg = ob["cfg"]
+    res = 2.2e-3
+    dims = (48, 140, 48)
+    assert _lib.lib().cppf_vote_tiles(*dims) >= 4
+    corner = (ob["center"] - 0.5 * np.array(dims) * res).astype(np.float32)
+    ka = syn.closed_form_outputs(ob["pc"], ob["center"], idx, cfg, quantise=True)
+    kb = np.random.default_rng(5).integers(0, 32, (n_pairs, 2))
+    un = np.stack([kb[:, 0] / 31 * 2 * cfg.vote_range[0] - cfg.vote_range[0], kb[:, 1] / 31 * cfg.vote_range[1]], -1).astype(np.float32)
+    for out in (ka, un):
+        gg, flat, peak = run_vote(dev, ob["pc"], out, idx, corner, dims, res, 72, True)
+        g64, cnt = check_grid(oracle, gg, ob["pc"], out, idx, corner, dims, res, 72, True)
+        assert flat == int(np.argmax(g64)) and peak == gg.max()
