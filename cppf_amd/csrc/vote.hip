@@ -1736,6 +1736,7 @@ struct V3Tile {
     int* carry_n;
     int x0, y0, gz, ltyz;  // ltyz: words per x column of the LDS tile
     float res, rres, S;    // S > 0: fixed-point scale; S == 0: fp32 atomics
+    double rres64;         // 1 / res in fp64
     int unit_probs;
     float lox, hix, loy, hiy, loz, hiz;   // the reference's in-grid bounds intersected with the cells this tile owns
 };
@@ -1743,7 +1744,11 @@ struct V3Tile {
 // models/voting.py:35-63 for one sample whose floor cell this tile owns: every corner lies in the LDS tile (halo included)
 __device__ __forceinline__ void v3_deposit(const V3Tile& T, f3 v, float prob)
 {
-    const f3 g = {div_by(v.x, T.res, T.rres), div_by(v.y, T.res, T.rres), div_by(v.z, T.res, T.rres)};   // :35
+    // :35, the IEEE fp32 quotient through ONE fp64 product: fl32(fl64(v * fl64(1 / res))) -- for fp32 operands the exact quotient is at
+    // least 2^-49 (relative) away from every fp32 rounding boundary while the two fp64 roundings err by < 2^-52, so the result is the
+    // correctly rounded v / res; v_cvt_f64_f32 + v_mul_f64 + v_cvt_f32_f64 issue in 15 cycles against the 20 of div_by's mul + 4 fma
+    // (profiles/r3_valu_rates.txt; exhaustive comparison with `/`: profiles/microbench/div_check.hip)
+    const f3 g = {(float)((double)v.x * T.rres64), (float)((double)v.y * T.rres64), (float)((double)v.z * T.rres64)};
     // :36-39 (fp64 tests folded to fp32 thresholds) and the ownership of the floor cell (floor(g) >= x0 <=> g >= x0) in one test
     if (!(g.x >= T.lox && g.x < T.hix && g.y >= T.loy && g.y < T.hiy && g.z >= T.loz && g.z < T.hiz)) return;
     const int fx = (int)g.x, fy = (int)g.y, fz = (int)g.z;         // :40
@@ -1945,6 +1950,7 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
     V3Tile VT;
     VT.tile = tile; VT.carry_log = carry_log; VT.carry_n = ctrl;
     VT.x0 = x0; VT.y0 = y0; VT.gz = gz; VT.ltyz = ltyz; VT.res = res; VT.rres = refined_rcp(res); VT.S = S;
+    VT.rres64 = 1.0 / (double)res;
     VT.unit_probs = unit_probs;
     // (double)g < 0.01 <=> g < ceil_to_float(0.01); integers are exact in fp32: max / min with the owned range is exact
     VT.lox = fmaxf(ceil_to_float(0.01), (float)x0); VT.hix = fminf(ceil_to_float((double)gx - 1.01), (float)(x0 + tx));

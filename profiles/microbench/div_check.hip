@@ -8,6 +8,25 @@ __device__ __forceinline__ float div_by(float a, float b, float y)
     const float q0 = a * y; const float r0 = fmaf(-b, q0, a); const float q1 = fmaf(r0, y, q0); const float r1 = fmaf(-b, q1, a);
     return fmaf(r1, y, q1);
 }
+// round 3: the tiled vote's deposit divides through one fp64 product, fl32(fl64(a * fl64(1 / res))) (csrc/vote.hip: v3_deposit)
+__global__ void check64(float res, uint32_t e_lo, uint32_t e_hi, unsigned long long* bad, unsigned long long* n)
+{
+    const double y = 1.0 / (double)res;
+    unsigned long long mism = 0, cnt = 0;
+    const uint64_t total = (uint64_t)(e_hi - e_lo + 1) << 23;
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < total; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t bits = (uint32_t)(((uint64_t)e_lo << 23) + k);
+        for (int sgn = 0; sgn < 2; ++sgn) {
+            const float a = __uint_as_float(bits | (sgn ? 0x80000000u : 0u));
+            const float q = (float)((double)a * y);
+            volatile float rr = res;
+            const float ref = a / rr;
+            mism += __float_as_uint(q) != __float_as_uint(ref);
+            ++cnt;
+        }
+    }
+    atomicAdd(bad, mism); atomicAdd(n, cnt);
+}
 __global__ void check(float res, uint32_t e_lo, uint32_t e_hi, unsigned long long* bad, unsigned long long* n)
 {
     const float y = refined_rcp(res);
@@ -88,6 +107,15 @@ int main()
         check<<<4096, 256>>>(res, 127 - 40, 127 + 6, d, d + 1);   // |a| in [2^-40, 2^7)
         hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
         printf("res %.9g: %llu values of a (both signs, |a| in [2^-40, 2^7)), %llu differ from a / res\n", res, h[1], h[0]);
+    }
+    // the fp64-product form: every normal a (both signs, |a| in [2^-100, 2^100)) for the same divisors and a few awkward ones
+    const float rs64[] = {4e-3f, 1e-2f, 3e-2f, 2e-3f, 1.2e-3f, 0.0123f, 0.1f, 1.5e-2f, 8e-3f, 1e-3f, 0.25f, 7.77e-3f, 3.0f, 0.33333334f, 1.1754944e-3f,
+                          0.99999994f, 1.0000001f, 5.9604645e-8f, 1.9999999f, 123.456f};
+    for (float res : rs64) {
+        hipMemset(d, 0, 16);
+        check64<<<8192, 256>>>(res, 127 - 100, 127 + 99, d, d + 1);
+        hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+        printf("fp64-product form, res %.9g: %llu values of a (both signs, |a| in [2^-100, 2^100)), %llu differ from a / res\n", res, h[1], h[0]);
     }
     return 0;
 }
