@@ -1198,7 +1198,7 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void reduce_tiles_kernel(RedArgs R
 // `v3_vote_kernel`, workgroup (tile t, chunk c), consumes records [c n_t / C, (c+1) n_t / C) of tile t's queue: exact frame
 // again (12 B/record of HBM traffic instead of 52), then the run walk of vote_kernel.
 #define V3_TILE_FLOATS 30720      // 120 KiB of LDS for the tile incl. its halo
-#define V3_STAGE 3072             // staged records per flush (16 B each in LDS: 48 KiB, two to three workgroups per CU)
+#define V3_STAGE 3072             // staged records per flush (16 B each in LDS: 48 KiB; 72 KiB with the rings and pair queues: two workgroups per CU)
 #define V3_MAGIC 0x43503356u
 #define V3_THREADS 1024
 #define V3_BIN_THREADS 512
@@ -1417,10 +1417,11 @@ __device__ __forceinline__ int wave_max_i32(int v)
 }
 
 // ---------------------------------------------------------------------------- v3_bin_kernel
-// One pass over the pairs: exact frame (the same arithmetic as the consumer's, so both agree on which pairs are alive and on
-// their rotation counts), per-axis arc parameters, z mask; then for every tile of the circle's bounding box the x / y masks
-// of its column / row, AND, runs, and a record into the tile's queue.  Rounds of 1 024 pairs per workgroup; records are staged
-// in LDS (slot within the tile's share of the flush from an LDS atomic) and flushed with one global atomic per tile.
+// One pass over the pairs, in super-rounds of bin_sr x 512 per workgroup: cull against the whole grid and queue the survivors (per
+// wave, LDS); then in batches of 64 survivors: frame in approximate arithmetic, per-axis arc parameters, z mask; the tiles of the
+// circle's bounding box walked with a cheap plane / shell test, the (lane, tile) items that pass compacted through a per-wave ring;
+// per item the x / y masks of its column / row, AND, runs, and a record into the tile's queue.  Records are staged in LDS (slot
+// within the tile's share of the flush from an LDS atomic) and flushed with one global atomic per tile.
 __global__ __launch_bounds__(V3_BIN_THREADS) void v3_bin_kernel(V3Args A)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
