@@ -165,3 +165,40 @@ def test_binned_vote_super_round_lengths(oracle, dev, n_pairs):
         gg, flat, peak = run_vote(dev, ob["pc"], out, idx, corner, dims, res, 72, True)
         g64, cnt = check_grid(oracle, gg, ob["pc"], out, idx, corner, dims, res, 72, True)
         assert flat == int(np.argmax(g64)) and peak == gg.max()
+
+
+def test_bin_kernel_staging_overflow_path(oracle, dev):
+    """horizontal circles of 30-95 cells radius on a 35-tile grid (tiles of 29 x 40 cells): a pair visits ~10 tiles, so one batch round
+    of a workgroup (512 pairs) produces more records than the LDS staging area holds -- waves find it full, ask for a flush and retry
+    their batch (`stuck` / `again` in v3_bin_kernel)"""
+    dims, res = (200, 200, 24), 4e-3
+    out10 = (C.c_int32 * 10)()
+    half, k = 1024, 24
+    rng = np.random.default_rng(9)
+    base = rng.uniform(-0.03, 0.03, (half, 3)).astype(np.float32) * np.array([1, 1, 0.2], np.float32)
+    pc = np.concatenate([base, base + np.array([0, 0, 0.02], np.float32)]).astype(np.float32)      # point i + half sits right above point i
+    idx = np.stack([np.repeat(np.arange(half), k), np.repeat(np.arange(half), k) + half], -1).astype(np.int32)
+    P = idx.shape[0]
+    assert _lib.lib().cppf_vote_plan_query(P, 72, *dims, out10) == 0 and out10[0] == 3 and out10[1] >= 16
+    tx, ty, nty = out10[2], out10[3], out10[5]
+    out = np.stack([rng.uniform(-0.02, 0.02, P), rng.uniform(0.12, 0.38, P)], -1).astype(np.float32)
+    corner = (-0.5 * np.array(dims) * res).astype(np.float32)
+    gg, flat, peak = run_vote(dev, pc, out, idx, corner, dims, res, 72, True)
+    g64, cnt = check_grid(oracle, gg, pc, out, idx, corner, dims, res, 72, True)
+    # tiles a pair's samples fall into (numpy, the reference's formula in fp64): enough for a round's records to overflow the staging area
+    a, b = pc[idx[:, 0]].astype(np.float64), pc[idx[:, 1]].astype(np.float64)
+    u = (a - b) / (np.linalg.norm(a - b, axis=1, keepdims=True) + 1e-7)
+    co = np.stack([np.zeros(P), -u[:, 2], u[:, 1]], -1)
+    co /= np.linalg.norm(co, axis=1, keepdims=True) + 1e-7
+    x = co * out[:, 1:2]
+    y = np.cross(x, u)
+    th = np.arange(72) * 2 * np.pi / 72
+    g = ((a - u * out[:, :1])[:, None, :] + x[:, None, :] * np.cos(th)[None, :, None] + y[:, None, :] * np.sin(th)[None, :, None] - corner) / res
+    ok = np.all((g >= 0.01) & (g < np.array(dims) - 1.01), axis=2)
+    tile = np.where(ok, (np.floor(g[..., 0]) // tx) * nty + np.floor(g[..., 1]) // ty, -1)
+    visits = np.mean([len(set(t[t >= 0])) for t in tile[:2000]])
+    assert visits * 512 > 3072 * 1.2, visits
+    assert peak == gg.max()
+    gg2, flat2, _ = run_vote(dev, pc, out, idx, corner, dims, res, 72, True)
+    np.testing.assert_array_equal(gg, gg2)
+    assert flat == flat2
