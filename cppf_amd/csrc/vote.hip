@@ -1205,8 +1205,10 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void reduce_tiles_kernel(RedArgs R
 #define V3_BIN_SR 8               // blocks of 64 pairs a wave culls per super-round
 #define V3_IRING 256              // per-wave ring of (lane, tile) items: <= 63 waiting + 64 pushed
 #define V3_CNT_STRIDE 32
+#define V3_RED_FANIN 16              // arg-max groups of v3_reduce_kernel (power of two, <= VOTE_MAX_TILES)
 struct V3Hdr {                    // workspace + VOTE_WS_PART; all zero (or left by a previous call) when a launch starts
-    unsigned int tile_count[VOTE_MAX_TILES * V3_CNT_STRIDE];   // records in each tile's queue, one counter per 128-byte line
+    unsigned int tile_count[VOTE_MAX_TILES * V3_CNT_STRIDE];   // records in each tile's queue, one counter per 128-byte line; words 2..5
+                                  // of lines 0..V3_RED_FANIN-1: {key, count} of the reduce kernel's arg-max groups (zero between launches)
     unsigned int flags;           // 1: the workspace was not initialised / a capacity was exceeded -> arg-max -1, peak NaN
     unsigned int any_extra;       // some workgroup added to the extra plane in this launch
     unsigned int magic;           // 0 (fresh, zeroed) or V3_MAGIC
@@ -2195,6 +2197,8 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
 __device__ __forceinline__ void v3_rezero(V3Hdr* h)
 {
     for (int k = 0; k < VOTE_MAX_TILES; ++k) h->tile_count[k * V3_CNT_STRIDE] = 0u;
+    for (int k = 0; k < V3_RED_FANIN; ++k)   // the arg-max groups of v3_reduce_kernel
+        for (int w = 2; w < 6; ++w) h->tile_count[k * V3_CNT_STRIDE + w] = 0u;
     h->flags = 0u; h->any_extra = 0u; h->done = 0u; h->magic = V3_MAGIC;
     __threadfence();
 }
@@ -2319,10 +2323,13 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, in
         key = wave_max_u64(key);
         if (lane == 0) wkey[cg] = key;
     }
-    // two-level arg-max (see reduce_tiles_kernel): block b reports to group b mod RED_FANIN, a group's last reporter reports for it
-    const unsigned gsel = blockIdx.x & (RED_FANIN - 1);
-    const unsigned n_group = (gridDim.x - gsel + RED_FANIN - 1) / RED_FANIN;
-    const unsigned n_groups_used = gridDim.x < RED_FANIN ? gridDim.x : RED_FANIN;
+    // two-level arg-max (see reduce_tiles_kernel): block b reports to group b mod V3_RED_FANIN, a group's last reporter reports for it.
+    // A group's {key, count} sits in the spare words 2..5 of queue-counter line g of the header -- one 128-byte line, i.e. one L2 channel,
+    // per group: in the caller's `packed` array the eight groups of round 2 shared one line and their atomics queued behind each other
+    // (the reports were 4.7 of the kernel's 12.6 us at C2: profiles/r3_vote_phases.txt section 8)
+    const unsigned gsel = blockIdx.x & (V3_RED_FANIN - 1);
+    const unsigned n_group = (gridDim.x - gsel + V3_RED_FANIN - 1) / V3_RED_FANIN;
+    const unsigned n_groups_used = gridDim.x < V3_RED_FANIN ? gridDim.x : V3_RED_FANIN;
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < RED_CELLS / 64; ++w) key = wkey[w] > key ? wkey[w] : key;
@@ -2332,7 +2339,7 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, in
             asm volatile("v_mov_b32 %0, %1" : "=v"(d2) : "v"(d1));
             return atomicAdd(reinterpret_cast<unsigned*>(slot_ + 1), 1u + (d1 ^ d2));
         };
-        unsigned long long* gslot = A.packed + 2 + 2 * gsel;
+        unsigned long long* gslot = reinterpret_cast<unsigned long long*>(&A.hdr->tile_count[gsel * V3_CNT_STRIDE + 2]);
         if (report(gslot, key) == n_group - 1) {
             const unsigned long long gbest = atomicMax(gslot, 0ull);
             if (report(A.packed, gbest) == n_groups_used - 1) {
