@@ -17,6 +17,8 @@ pass instead (round 1-2's headline; reported as a secondary by the default run).
 pair list and uniforms from HBM.  With N GPUs every rank processes its own objects (weak scaling) and ONE all_gather of the K
 result records closes the batch inside the timed region.
 
+  --config c1        BASELINE.json configs[0] (N=1024 K=64, "reference CPU voting.py path (no GPU)"): a CPU-only line -- the oracle
+                     chain swept over thread counts -- with the GPU's time for the same workload beside it when a GPU is there
   --config c3 | c5   the same chain at BASELINE.json configs[2] (N=4096 K=256) / configs[4] (N=8192 K=256, res 2e-3) sizes
   --config c4        BASELINE.json configs[3]: a batch of 64 mixed-category objects (C2 size) sharded round-robin over the ranks
                      through BatchPoseRunner (full pose per object), one gather at the end; strong scaling
@@ -51,7 +53,10 @@ FLOP_PER_PAIR_CENTRE_EXECUTED = 11168   # ... and the centre-heads kernel (20 of
 PEAK_F32_MFMA = 157.3            # TFLOP/s, MI355X_MICROARCH.md
 PEAK_HBM = 8000.0                # GB/s
 METRIC = "point-pairs/sec (PPF+MLP+vote+argmax), N=4096 K=128; 1/2/4/8 GPU"
+PEAK_LDS_ATOMICS = 1.757         # T lane-atomics/s: measured ceiling of ds_add_rtn_u32 on random cells of a 26 k-cell LDS tile, all 256 CUs
+                                 # (profiles/r1_atomics_microbench.txt; source profiles/microbench/atomics_bench.hip)
 CONFIGS = {                      # BASELINE.json `configs`: single-object chains
+    "c1": dict(n_points=1024, k=64, res=None, what="BASELINE.json configs[0] sizes"),
     "c2": dict(n_points=4096, k=128, res=None, what="BASELINE.json configs[1] sizes on the fused path of configs[2]"),
     "c3": dict(n_points=4096, k=256, res=None, what="BASELINE.json configs[2]"),
     "c5": dict(n_points=8192, k=256, res=2e-3, what="BASELINE.json configs[4] per-instance size, fine grid"),
@@ -83,46 +88,109 @@ def host_threads():
     return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 
 
-def oracle_center(o, sd, budget_s=0.0, max_reps=1, all_heads=False):
-    """The oracle chain (CPU restatement, all host cores via OpenMP) on one object: (arg-max, pairs/s, repetitions)."""
+def oracle_center(o, sd, threads=None, all_heads=False):
+    """The oracle chain (CPU restatement, `threads` host threads via OpenMP) on one object, ONE pass, timed leg by leg:
+    (arg-max, {"mlp": s, "decode": s, "vote_argmax": s})"""
     from oracle import oracle as O
-    threads = host_threads()
+    threads = threads or host_threads()
     O.set_threads(threads)
     cfg, idx = o["cfg"], o["idx"]
     idx32 = idx.astype(np.int32)
     probs = np.ones(o["ob"]["pc"].shape[0], np.float32)
-    reps, t_total, flat = 0, 0.0, -1
-    while reps < 1 or (t_total < budget_s and reps < max_reps):
-        t0 = time.perf_counter()
-        logits = O.pair_mlp(o["ob"]["pc"], o["ob"]["normals"], o["ob"]["feat"], idx, sd, cfg.ppffcs, cfg.out_dim, order=1)
-        outputs, _ = O.decode_center(logits, o["u_tr"], cfg.tr_num_bins, cfg.vote_range)
-        if all_heads:
-            O.decode_rot(logits, o["u_rot"], cfg.tr_num_bins, cfg.rot_num_bins)
-        grid = np.zeros(o["dims"], np.float32)
-        O.ppf_voting(o["ob"]["pc"], outputs, probs, idx32, grid, o["corners"][0], cfg.res, NUM_ROTS, True, threads=threads)
-        flat, _ = O.grid_argmax(grid)
-        t_total += time.perf_counter() - t0
-        reps += 1
-    return flat, idx.shape[0] * reps / t_total, reps
+    t0 = time.perf_counter()
+    logits = O.pair_mlp(o["ob"]["pc"], o["ob"]["normals"], o["ob"]["feat"], idx, sd, cfg.ppffcs, cfg.out_dim, order=1)
+    t1 = time.perf_counter()
+    outputs, _ = O.decode_center(logits, o["u_tr"], cfg.tr_num_bins, cfg.vote_range)
+    if all_heads:
+        O.decode_rot(logits, o["u_rot"], cfg.tr_num_bins, cfg.rot_num_bins)
+    t2 = time.perf_counter()
+    grid = np.zeros(o["dims"], np.float32)
+    O.ppf_voting(o["ob"]["pc"], outputs, probs, idx32, grid, o["corners"][0], cfg.res, NUM_ROTS, True, threads=threads)
+    flat, _ = O.grid_argmax(grid)
+    t3 = time.perf_counter()
+    return flat, {"mlp": t1 - t0, "decode": t2 - t1, "vote_argmax": t3 - t2}
 
 
-def torch_cpu_mlp(o, sd, n_sample=131072, budget_s=4.0):
+def thread_ladder():
+    """8, 16, 32, ... up to every hardware thread this process may use (the ends included)"""
+    n = host_threads()
+    ladder = sorted({t for t in (1, 8, 16, 32, 64, 128, 256, 512) if 8 <= t < n} | {n})
+    return ladder
+
+
+def cpu_sweep(o, sd, all_heads=False, budget_s=25.0):
+    """The CPU baseline is the CPU's BEST: the oracle chain at every thread count of the ladder (the vote leg keeps one private
+    grid per thread and sums them, so more threads are not monotonically better: 256 threads were 3x slower than 8 on round 3's
+    box), best of up to three passes each while the budget lasts.  Returns (arg-max, best entry, all entries)."""
+    P = o["idx"].shape[0]
+    t_start, entries, flat = time.perf_counter(), [], -1
+    oracle_center(o, sd, threads=min(8, host_threads()), all_heads=all_heads)       # page in the library, the tables, the pools
+    for th in thread_ladder():
+        best = None
+        for _ in range(3):
+            flat, legs = oracle_center(o, sd, threads=th, all_heads=all_heads)
+            tot = sum(legs.values())
+            if best is None or tot < best[0]:
+                best = (tot, legs)
+            if time.perf_counter() - t_start > budget_s:
+                break
+        entries.append({"threads": th, "pairs_per_s": P / best[0], "legs_ms": {k_: v * 1e3 for k_, v in best[1].items()}})
+        if time.perf_counter() - t_start > budget_s:
+            break
+    return flat, max(entries, key=lambda e: e["pairs_per_s"]), entries
+
+
+def torch_cpu_mlp(o, sd, n_sample=131072, budget_s=6.0):
     """'MLP via torch-CPU with the same weights': the composite of models/model.py:118-137 in torch ops on the
-    host (all threads), on a bounded prefix of the pair list -> pairs/s"""
+    host, on a bounded prefix of the pair list, at every thread count of the ladder -> best entry, all entries"""
     cfg = o["cfg"]
     enc = PPFEncoder(cfg.ppffcs, cfg.out_dim).eval()
     enc.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     pc, nrm, feat = (torch.from_numpy(o["ob"][k]) for k in ("pc", "normals", "feat"))
     idx = torch.from_numpy(o["idx"][:n_sample])
-    reps, t_total = 0, 0.0
+    keep = torch.get_num_threads()
+    entries, t_start = [], time.perf_counter()
     with torch.no_grad():
-        enc._composite(pc, nrm, feat, idx)
-        while reps < 1 or (t_total < budget_s and reps < 20):
-            t0 = time.perf_counter()
+        for th in thread_ladder():
+            torch.set_num_threads(th)
             enc._composite(pc, nrm, feat, idx)
-            t_total += time.perf_counter() - t0
-            reps += 1
-    return idx.shape[0] * reps / t_total, torch.get_num_threads(), idx.shape[0]
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                enc._composite(pc, nrm, feat, idx)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            entries.append({"threads": th, "pairs_per_s": idx.shape[0] / best})
+            if time.perf_counter() - t_start > budget_s:
+                break
+    torch.set_num_threads(keep)
+    return max(entries, key=lambda e: e["pairs_per_s"]), entries, idx.shape[0]
+
+
+def cpu_object(n_points, k, seed, res=None, cat="bottle"):
+    """a synthetic object with everything the oracle chain needs, no device involved"""
+    ob = syn.make_object(cat, n_points, seed=seed)
+    cfg = ob["cfg"] if res is None else dataclasses.replace(ob["cfg"], res=res)
+    idx = syn.make_pairs(n_points, k, seed=seed)
+    u_tr, u_rot = syn.make_uniforms(idx.shape[0], seed=seed)
+    corners, dims = grid_shape(ob["pc"], cfg.res)
+    return dict(ob=ob, cfg=cfg, idx=idx, u_tr=u_tr, u_rot=u_rot, corners=corners, dims=dims)
+
+
+def cpu_baseline_block(o, sd, n_points, k, all_heads=False, budget_s=25.0):
+    P = o["idx"].shape[0]
+    flat, best, entries = cpu_sweep(o, sd, all_heads=all_heads, budget_s=budget_s)
+    tbest, tentries, tn = torch_cpu_mlp(o, sd)
+    return flat, dict(
+        value=best["pairs_per_s"], unit="pairs/s", cores=best["threads"], kind="port",
+        best_threads=best["threads"], host_threads_available=host_threads(), legs=best["legs_ms"],
+        sweep=entries,
+        sample=f"full workload (N={n_points}, K={k}, P={P}), best of up to 3 passes at each thread count of {thread_ladder()}: the repo's "
+               "C oracle with OpenMP -- AVX2 fmaf-chain MLP + decode + vote (private grid per thread) + arg-max (the reference has "
+               "no CPU vote path); value = the best thread count's pairs/s, legs in ms",
+        mlp_torch_cpu={"value": tbest["pairs_per_s"], "unit": "pairs/s", "threads": tbest["threads"], "sweep": tentries,
+                       "sample": f"PPF + gather + ResLayers + final as torch ops on the host (models/model.py:118-137), "
+                                 f"{tn} pairs, same weights; MLP leg only; best thread count of the same ladder"})
 
 
 def make_center_set(enc, dev, n_points, k, res, n_obj, seed0, with_heads=True, use_graph=True, cat="bottle"):
@@ -195,6 +263,7 @@ def run_center_config(name, enc, sd, dev, rank, world, args):
     c = CONFIGS[name]
     n_points, k = (args.n_points or c["n_points"]), (args.pairs_per_point or c["k"])
     n_streams = max(1, args.streams)
+    group = torch.distributed.is_initialized()       # world > 1, or ONE rank with CPPF_FORCE_DIST=1 (the RCCL branches on one GPU)
     n_obj = max(n_streams, -(-args.objects // n_streams) * n_streams)      # a multiple of the streams: pipe j stays on stream j mod S
     objs = make_center_set(enc, dev, n_points, k, c["res"], n_obj, seed0=100 * rank, with_heads=args.all_heads,
                            use_graph=not args.no_graph)
@@ -204,7 +273,7 @@ def run_center_config(name, enc, sd, dev, rank, world, args):
     steps = args.steps
     res_all = torch.zeros((steps, 16), dtype=torch.uint8, device=dev)   # {i64 arg-max, f32 peak} of every step
     rec_tmpl = torch.zeros((steps, sharding.RECORD), dtype=torch.float64, device=dev)
-    rec_tmpl[:, 15] = torch.arange(rank * steps, (rank + 1) * steps, device=dev).double()
+    rec_tmpl[:, 15] = (rank + world * torch.arange(steps, device=dev)).double()     # step i of rank r = object r + i * world
     res_i64, res_f32 = res_all.view(torch.int64), res_all.view(torch.float32)
 
     def close_batch():
@@ -212,7 +281,7 @@ def run_center_config(name, enc, sd, dev, rank, world, args):
         records = rec_tmpl.clone()
         records[:, 12] = res_i64[:, 0]          # arg-max index  (int64 -> f64 in the copy)
         records[:, 13] = res_f32[:, 2]          # peak value     (f32 -> f64 in the copy)
-        if world > 1:
+        if world > 1 or group:
             return sharding.gather_records(records, world * steps, rank, world, dev)   # the one collective
         return records
 
@@ -232,23 +301,42 @@ def run_center_config(name, enc, sd, dev, rank, world, args):
     run_steps(max(args.warmup, n_obj))      # every object's graph is captured and replayed at least once
     close_batch()                           # warm-up of the gather too (RCCL communicators are created on first use)
     settle()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(steps)
-    allrec = close_batch()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+
+    def region():
+        """the contract's timed region: EXACTLY `steps` steps + the one gather, barrier + synchronize on both sides"""
+        if group:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(steps)
+        rec = close_batch()
+        if group:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, rec
+
+    regions, allrec = timed_regions(region, args, group, dev)
+    elapsed = regions[len(regions) // 2]
     lat = events_per_chain(dev, pipes, max(20, steps))
     return dict(objs=objs, pipes=pipes, P=P, n_points=n_points, k=k, n_obj=n_obj, n_streams=n_streams, elapsed=elapsed,
-                allrec=allrec, lat=lat, what=c["what"])
+                regions=regions, allrec=allrec, lat=lat, what=c["what"])
+
+
+def timed_regions(region, args, group, dev):
+    """The timed region repeated: at least 5 times and until --min-seconds of regions have run (one region of 20 steps is ~3 ms:
+    too short for one host hiccup not to matter and for anything outside the process to see the GPU busy).  Every region's time is
+    the MAX over the ranks; the sorted list is returned and the caller reports its MEDIAN (`region_ms_min_max` beside it).
+    All ranks run the same number of regions: the decision to stop is taken on rank-reduced times."""
+    times, total, rec = [], 0.0, None
+    while len(times) < max(5, args.regions) or (args.regions == 0 and total < args.min_seconds and len(times) < 100000):
+        t, rec = region()
+        if group:
+            tmax = torch.tensor([t], dtype=torch.float64, device=sharding.collective_device(dev))
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+            t = float(tmax.item())
+        times.append(t)
+        total += t
+    return sorted(times), rec
 
 
 def workload_text(name, m, args):
@@ -273,7 +361,7 @@ def c4_objects(n_objects, n_points, k, seed0=500):
     return objs
 
 
-def run_c4(dev, rank, world, args, n_objects=64):
+def run_c4(dev, rank, world, args, n_objects=64, n_regions=0):
     """64 mixed-category objects sharded round-robin over the ranks, full pose per object, ONE gather inside the timed region"""
     from cppf_amd.batch import BatchPoseRunner
     n_points, k = (args.n_points or 4096), (args.pairs_per_point or 128)
@@ -288,22 +376,62 @@ def run_c4(dev, rank, world, args, n_objects=64):
         runner.run(objects, rank, world)
     settle()
     reps = max(1, args.steps // 8)
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    group = torch.distributed.is_initialized()
+
+    def region():
+        if group:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            recs = runner.run(objects, rank, world)
+        if group:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, recs
+
+    if n_regions == 1:
+        regions, recs = [region()[0]], None
         recs = runner.run(objects, rank, world)
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    else:
+        regions, recs = timed_regions(region, args, group, dev)
     assert recs.shape[0] == n_objects and bool(torch.isfinite(recs[:, :12]).all())
-    return dict(elapsed=elapsed, reps=reps, n_objects=n_objects, P=n_points * k, n_points=n_points, k=k)
+    return dict(elapsed=regions[len(regions) // 2], regions=regions, reps=reps, n_objects=n_objects, P=n_points * k,
+                n_points=n_points, k=k)
+
+
+def run_c1(args):
+    """BASELINE.json configs[0]: single 1024-point cloud, K=64, bottle, the CPU path.  value = the CPU's best pairs/s."""
+    torch.manual_seed(0)
+    enc = PPFEncoder([84, 32, 32, 16], 141).eval()
+    sd = {k_: v.detach().numpy().copy() for k_, v in enc.state_dict().items()}
+    o1 = cpu_object(1024, 64, seed=0)
+    P = o1["idx"].shape[0]
+    flat, cb = cpu_baseline_block(o1, sd, 1024, 64)
+    out = {"metric": METRIC, "value": cb["value"], "unit": "pairs/s", "n_gpus": 0, "steps": 3, "warmup": 1,
+           "ms_per_step": P / cb["value"] * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic",
+           "config": {"workload": f"c1: single object N=1024 K=64 (P={P} pairs), bottle config, res {o1['cfg'].res:g}, grid "
+                                  f"{'x'.join(str(int(v)) for v in o1['dims'])}, num_rots 72 adaptive: PPF + MLP + decode + centre vote + "
+                                  "arg-max on the HOST cores (BASELINE.json configs[0]: the CPU path, no GPU); a step = one pass over "
+                                  "the object at the best thread count", "pairs_per_step": P, "parallelism": "host threads"},
+           "cpu_baseline": cb, "argmax_cpu": int(flat)}
+    if torch.cuda.is_available():       # the same workload on the GPU, for the ratio
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        args.regions, args.min_seconds = 0, 1.0
+        m = run_center_config("c1", enc.to(dev), sd, dev, 0, 1, args)
+        out["gpu_same_workload"] = {"ms_per_step": m["elapsed"] / args.steps * 1e3, "pairs_per_s": args.steps * m["P"] / m["elapsed"],
+                                    "median_ms_one_instance": m["lat"][len(m["lat"]) // 2],
+                                    "argmax_matches_cpu": bool(int(m["allrec"][0, 12].item()) == int(flat))}
+    print(json.dumps(out))
+
+
+def dist_info(world):
+    """which collective library carried the gather / barrier / max-over-ranks of this run (None: no process group)"""
+    if not torch.distributed.is_initialized():
+        return None
+    return {"backend": torch.distributed.get_backend(), "forced_single_rank": world == 1}
 
 
 def main():
@@ -311,8 +439,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2",
+    ap.add_argument("--config", choices=["c1", "c2", "c3", "c4", "c5"], default="c2",
                     help="BASELINE.json configuration (default c2 = the headline; see the module docstring)")
+    ap.add_argument("--regions", type=int, default=0, help="timed regions of --steps steps each (the median is reported); 0 = at "
+                    "least 5 and until --min-seconds of regions have run")
+    ap.add_argument("--min-seconds", type=float, default=6.0, help="with --regions 0: keep repeating the timed region until this "
+                    "much region time has accumulated")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary stage timings (counter-collection passes)")
     ap.add_argument("--streams", type=int, default=3, help="instances in flight per GPU: step k runs on HIP stream k mod S "
@@ -326,6 +458,8 @@ def main():
     ap.add_argument("--pairs-per-point", type=int, default=0, help="exploration only; overrides the config's K")
     args = ap.parse_args()
 
+    if args.config == "c1":
+        return run_c1(args)
     rank, world, local = sharding.init_distributed()
     assert world == args.gpus, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
     dev = torch.device("cuda", local)
@@ -346,8 +480,10 @@ def main():
                                        "BatchPoseRunner: clouds and features staged from pinned host memory, pairs and bin uniforms drawn "
                                        "on the device, one all_gather of the 160-byte records closes the batch; a step = one object",
                            "objects": m["n_objects"], "objects_per_gpu": m["n_objects"] / world, "parallelism": f"objects x{world}"},
-                "objects_per_s": m["reps"] * m["n_objects"] / m["elapsed"]}))
-        if world > 1:
+                "objects_per_s": m["reps"] * m["n_objects"] / m["elapsed"],
+                "regions": len(m["regions"]), "region_ms_min_max": [m["regions"][0] * 1e3, m["regions"][-1] * 1e3],
+                "dist": dist_info(world)}))
+        if torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
         return
 
@@ -386,6 +522,38 @@ def main():
         t_mlp = t_mlp_all if args.all_heads else t_mlp_tr          # the pair stage of the timed chain
         t_vote = bracket([vote_fn(o, ws, o["pipe"].outputs) for o, ws in zip(objs, wss)], n_ev)
 
+    def landed_samples(outs):
+        """samples that land in the grid, averaged over the objects: a sample deposits trilinear weights that sum to 1 (probs are all
+        ones), so it is the grid's total mass (fp64 sum of the exact fixed-point grid)"""
+        tot = 0.0
+        for o, ws, ou in zip(objs, wss, outs):
+            vote_fn(o, ws, ou)()
+            tot += float(ws.grid.double().sum().item())
+        return tot / len(objs)
+
+    def vote_regime(t_ms, landed):
+        rate = landed * 8 / (t_ms * 1e-3) / 1e12
+        return {"stage_ms": t_ms, "landed_samples": round(landed), "lane_atomics": round(landed) * 8, "achieved": rate,
+                "frac": rate / PEAK_LDS_ATOMICS}
+
+    G_cells = int(np.prod(dims))
+    tr_vote = [pmc_traffic("v3_vote_kernel<true>"), pmc_traffic("v3_reduce_kernel")]
+    alg_bytes = 24 * P + 4 * G_cells          # (mu, nu) 8 B + int64 pair 16 B read per pair, the grid written once
+    vote_roofline = {"bound": "lds_atomics", "kernel": "v3_vote_kernel<true> (+ v3_reduce_kernel in the time)", "unit": "T lane-atomics/s",
+                     "peak": PEAK_LDS_ATOMICS,
+                     "benchmark_inputs": vote_regime(t_vote, landed_samples([o["pipe"].outputs for o in objs])),
+                     "traffic": (tr_vote[0] + tr_vote[1]) if all(tr_vote) else None, "algorithmic_bytes": alg_bytes,
+                     "traffic_ratio": ((tr_vote[0] + tr_vote[1]) / alg_bytes) if all(tr_vote) else None,
+                     "note": "the vote is bound by LDS read-modify-writes, not by HBM or MFMA (SURVEY.md 8d): achieved = samples that land in "
+                             "the grid x 8 trilinear corners (one returning ds_add_u32 each) / time of vote + reduce kernels (HIP events "
+                             "around the C-ABI call; the call is both kernels) / the measured ds_add_rtn_u32 ceiling of the chip "
+                             "(profiles/r1_atomics_microbench.txt).  Conservative: the reduce kernel's share of the time does no "
+                             "atomics (kernel-only durations: profiles/r*_vote_regimes_ktrace.txt).  traffic = HBM bytes of the two "
+                             "kernels per call from the committed PMC passes (benchmark inputs) against the algorithmic 24 B/pair + "
+                             "the grid: the surplus is the 256 partial tiles written by the vote and read back by the reduce kernel"}
+    if args.config not in ("c2", "c1"):       # the committed PMC passes are of the default (c2) command
+        vote_roofline["traffic"] = vote_roofline["traffic_ratio"] = None
+
     # secondary: the chain with all 141 logits decoded in the first pass (round 1-2's headline): its own pipelines, same objects
     all_heads_step = None
     if secondary and not args.all_heads:
@@ -421,6 +589,7 @@ def main():
     if secondary:
         outs_ka = [d(syn.closed_form_outputs(o["ob"]["pc"], o["ob"]["center"], o["idx"], o["cfg"], quantise=True)) for o in objs]
         t_vote_ka = bracket([vote_fn(o, ws, ka) for o, ws, ka in zip(objs, wss, outs_ka)], 9)
+        vote_roofline["known_answer_inputs"] = vote_regime(t_vote_ka, landed_samples(outs_ka))
         # trained-network regime of the WHOLE step: pair stage + known-answer vote in one captured graph per object
         tr_pipes = []
         for o, ka in zip(objs, outs_ka):
@@ -502,6 +671,8 @@ def main():
     other = {}
     if secondary and args.config == "c2":
         keep = (args.steps, args.objects)
+        keep_r = (args.regions, args.min_seconds)
+        args.regions, args.min_seconds = 0, 0.5
         for name in ("c3", "c5"):
             args.steps, args.objects = 12, 3 if name == "c5" else 6
             mm = run_center_config(name, enc, sd, dev, rank, world, args)
@@ -509,7 +680,7 @@ def main():
                      "pairs_per_s": args.steps * mm["P"] / mm["elapsed"],
                      "median_ms_one_instance": mm["lat"][len(mm["lat"]) // 2]}
             if not args.no_cpu_baseline:
-                flat_cpu, _, _ = oracle_center(mm["objs"][0], sd)
+                flat_cpu, _ = oracle_center(mm["objs"][0], sd, threads=min(32, host_threads()))
                 entry["argmax_matches_oracle"] = bool(flat_cpu == int(mm["allrec"][0, 12].item()))
             other[name] = entry
             del mm
@@ -517,12 +688,13 @@ def main():
         args.steps = 8
         # one GPU's share of the 64-object batch; the smallest of three batches (a batch is ~2 ms of mostly host work: one
         # scheduler hiccup on the box triples it)
-        m4 = min((run_c4(dev, rank, world, args, n_objects=8) for _ in range(3)), key=lambda q: q["elapsed"])
+        m4 = min((run_c4(dev, rank, world, args, n_objects=8, n_regions=1) for _ in range(3)), key=lambda q: q["elapsed"])
         other["c4_one_gpu_share"] = {"workload": "8 mixed-category objects (N=4096 K=128), full pose each, BatchPoseRunner, pairs "
                                                  "drawn on the device, one read-back per batch; smallest of three batches",
                                      "ms_per_object": m4["elapsed"] / (m4["reps"] * 8) * 1e3,
                                      "pairs_per_s": m4["reps"] * 8 * m4["P"] / m4["elapsed"]}
         args.steps = keep[0]
+        args.regions, args.min_seconds = keep_r
 
     # secondary (BASELINE config 4 with the point encoder in front): 8 instances through BatchPoseRunner -- cloud in from the
     # host, pairs and bin uniforms drawn on the device, kNN + SPRIN + full pose per instance, one read-back for the batch
@@ -646,6 +818,10 @@ def main():
             "config": {"workload": workload_text(args.config, m, args), "pairs_per_step_per_gpu": P,
                        "parallelism": f"objects x{world}"},
             "pairs_per_ms_per_gpu": steps * P / elapsed / 1e3,
+            # the timed region (exactly `steps` steps + the gather, barrier + synchronize on both sides) was run `regions` times;
+            # value / ms_per_step come from the MEDIAN region (max over ranks per region)
+            "regions": len(m["regions"]), "region_ms_min_max": [m["regions"][0] * 1e3, m["regions"][-1] * 1e3],
+            "dist": dist_info(world),
             # hipEvents around the whole chain on one object, one at a time, objects rotating
             "median_ms_one_instance": lat[len(lat) // 2],
             "one_instance_ms_min_max": [lat[0], lat[-1]], "one_instance_runs": len(lat),
@@ -661,39 +837,39 @@ def main():
                          "pair_encoder_fwd_bwd_adam_step_200k_pairs": t_step,
                          "train_step_both_encoders_adam_200k_pairs": t_full},
             "other_configs": other or None,
-            # dominant kernel = the fused pair encoder (one launch between the two events): exact-fp32 MFMA
+            # dominant kernel = the fused pair encoder (one launch between the two events): exact-fp32 MFMA.
+            # frac is BOUNDED: the MFMA FLOP the kernel EXECUTES over the fp32-MFMA peak.  (Rounds 1-3 divided the reference's
+            # algorithmic FLOP -- 80 of the 188 MFMAs per tile are hoisted to a per-point table and never executed per pair -- by
+            # the same time and called that a fraction: it reached 1.01 at C5.  It is kept as `algorithmic_tflops`, a rate.)
             "roofline": {"bound": "mfma", "kernel": "pair_mlp_kernel<false,true,%s>" % ("true" if args.all_heads else "false"),
-                         "achieved": flop_pair * P / (t_mlp * 1e-3) / 1e12, "peak": PEAK_F32_MFMA,
-                         "unit": "TFLOP/s", "frac": flop_pair * P / (t_mlp * 1e-3) / 1e12 / PEAK_F32_MFMA,
+                         "achieved": flop_exec * P / (t_mlp * 1e-3) / 1e12, "peak": PEAK_F32_MFMA,
+                         "unit": "TFLOP/s", "frac": flop_exec * P / (t_mlp * 1e-3) / 1e12 / PEAK_F32_MFMA,
                          "traffic": pmc_traffic("pair_mlp_kernel<false, true, %s>" % ("true" if args.all_heads else "false")),
-                         "flop_per_pair": flop_pair,
-                         "note": "achieved = algorithmic FLOP of the reference's layers for the outputs this pass produces (" +
-                                 ("23 968 per pair: all 141 logits" if args.all_heads else
-                                  "21 504 per pair: the MLP with the 64 centre-bin logits; 23 968 with all 141") +
-                                 ") / duration of the pair-encoder stage (point_proj_kernel + pair_mlp_kernel); the pair kernel itself "
-                                 f"issues {flop_exec} MFMA FLOP per pair because the two 40-wide feature blocks of layer 0 are "
-                                 "projected once per point (executed_mfma_tflops / peak is the fraction of the MFMA pipe's peak actually "
-                                 "issued); fp32 MFMA shares the VALU datapath on gfx950, so the in-register decode is paid on the same "
-                                 "pipe; the duration is that of launches without a neighbour (back to back on one stream, inputs "
-                                 "rotating over the objects) -- in the timed region several objects are in flight, so a kernel trace of "
-                                 "this command also holds launches that overlap another object's vote and take longer "
-                                 "(profiles/r*_kernel_trace_stats_one_stream.txt: the same command with --streams 1, whose averages agree)",
-                         "executed_mfma_tflops": flop_exec * P / (t_mlp * 1e-3) / 1e12,
-                         "executed_frac": flop_exec * P / (t_mlp * 1e-3) / 1e12 / PEAK_F32_MFMA},
+                         "executed_flop_per_pair": flop_exec, "launch_ms": t_mlp,
+                         "algorithmic_tflops": flop_pair * P / (t_mlp * 1e-3) / 1e12, "algorithmic_flop_per_pair": flop_pair,
+                         "note": f"achieved = MFMA FLOP the kernel issues ({flop_exec} per pair: 2 x 16x16x4 x the tile's MFMAs / 16 pairs) "
+                                 "x pairs / duration of the pair-encoder stage (point_proj_kernel + pair_mlp_kernel, HIP events on the "
+                                 "launch stream, launches back to back on one stream, inputs rotating over the objects); "
+                                 f"algorithmic_tflops = the reference's layers for the outputs this pass produces ({flop_pair} FLOP per "
+                                 "pair) over the same time -- larger, because the two 40-wide feature blocks of layer 0 are projected "
+                                 "once per POINT; fp32 MFMA shares the VALU datapath on gfx950 (32 cycles per MFMA, 4 per VALU "
+                                 "instruction, no co-issue), so the rest of the pipe's time is the in-register PPF / residual / decode "
+                                 "VALU work; profiles/r*_kernel_trace_stats_one_stream.txt holds the rocprofv3 durations of the same "
+                                 "command with --streams 1, whose averages agree"},
+            "roofline_vote": dict(vote_roofline, **{k_: (vote_roofline.get("known_answer_inputs") or vote_roofline["benchmark_inputs"])[k_]
+                                                    for k_ in ("achieved", "frac")},
+                                  regime_of_achieved="known_answer_inputs" if "known_answer_inputs" in vote_roofline else "benchmark_inputs"),
         }
         if world == 1 and not args.no_cpu_baseline:
-            flat_cpu, pps, reps = oracle_center(o0, sd, budget_s=12.0, max_reps=8, all_heads=args.all_heads)
-            tps, tthreads, tn = torch_cpu_mlp(o0, sd)
-            out["cpu_baseline"] = dict(
-                value=pps, unit="pairs/s", cores=host_threads(), kind="port",
-                sample=f"{reps} x full workload (N={m['n_points']}, K={m['k']}, P={P}): the repo's C oracle with OpenMP -- AVX2 fmaf-chain "
-                       "MLP + decode + vote + arg-max (the reference has no CPU vote path)",
-                mlp_torch_cpu={"value": tps, "unit": "pairs/s", "threads": tthreads,
-                               "sample": f"PPF + gather + ResLayers + final as torch ops on the host (models/model.py:118-137), "
-                                         f"{tn} pairs, same weights; MLP leg only"})
+            flat_cpu, out["cpu_baseline"] = cpu_baseline_block(o0, sd, m["n_points"], m["k"], all_heads=args.all_heads)
             out["argmax_matches_oracle"] = bool(flat_cpu == argmax_gpu)
+            if args.config == "c2" and not args.no_secondary:
+                # BASELINE.json configs[0]: N=1024 K=64, "reference CPU voting.py path (no GPU)" -- the same sweep at that size
+                o1 = cpu_object(1024, 64, seed=0)
+                _, c1 = cpu_baseline_block(o1, sd, 1024, 64, budget_s=6.0)
+                out["cpu_baseline"]["c1"] = {kk: c1[kk] for kk in ("value", "unit", "best_threads", "legs", "sample")}
         print(json.dumps(out))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

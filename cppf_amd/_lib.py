@@ -19,6 +19,8 @@ _SIGS = {
     "cppf_ppf_voting": (C.c_int, [vp, vp, vp, vp, vp, vp, f32, i64, i64, i32, i32, i32, i32, i32, vp, sz, vp]),
     "cppf_vote_argmax": (C.c_int, [vp, vp, vp, vp, i32, vp, vp, f32, i64, i64, i32, i32, i32, i32, i32, i32, vp, vp, vp, sz,
                                    vp]),
+    "cppf_vote_grid_raw": (C.c_int, [vp, vp, vp, vp, i32, vp, vp, vp, f32, i64, i64, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "cppf_grid_from_raw": (C.c_int, [vp, i64, vp, vp, vp, vp, vp, sz, vp]),
     "cppf_vote_tiles": (C.c_int, [i32, i32, i32]),
     "cppf_vote_tile_cells": (C.c_int, []),
     "cppf_vote_workspace_bytes_dyn": (sz, [i32]),
@@ -51,7 +53,6 @@ _SIGS = {
                                        f32, f32, vp, vp, vp, vp, vp, sz, vp]),
     "cppf_pair_mlp_decode_sel": (C.c_int, [vp, vp, vp, vp, i32, vp, i64, i32, C.POINTER(C.c_int), i32, i64, i32, i32, i32, vp, vp, vp,
                                            i64, vp, vp, sz, vp]),
-    "cppf_debug_mlp_chain_only": (C.c_int, [vp, vp, vp, vp, i32, vp, i64, i64, vp, vp, sz, vp]),
     "cppf_decode_center": (C.c_int, [vp, i64, i32, i32, f32, f32, vp, vp, vp]),
     "cppf_decode_rot": (C.c_int, [vp, i64, i32, i32, i32, i32, vp, vp, vp]),
     "cppf_reduce_workspace_bytes": (sz, []),
@@ -89,7 +90,7 @@ _SIGS = {
                                              vp, vp, sz, vp]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2     # include/cppf.h CPPF_ABI_VERSION: the vote workspace contract + cppf_vote_grid_raw
 
 
 class CppfError(RuntimeError):
@@ -123,7 +124,8 @@ def lib():
             fn = getattr(L, name)  # AttributeError = ABI mismatch, also loud
             fn.restype, fn.argtypes = res, args
         if L.cppf_abi_version() != ABI_VERSION:
-            raise CppfError("libcppf_hip.so ABI version mismatch")
+            raise CppfError(f"libcppf_hip.so has ABI version {L.cppf_abi_version()}, this binding needs {ABI_VERSION}: "
+                            "rebuild with `make -C cppf_amd/csrc`")
         _lib = L
     return _lib
 

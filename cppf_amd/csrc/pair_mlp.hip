@@ -910,7 +910,8 @@ extern "C" int cppf_pair_mlp_decode_sel(const float* pc, const float* nrm, const
     return launch_std<false, true, true, true>(A, N, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-// Profiling aid (not part of the drop-in surface): the PPF + gather + MFMA chain with no epilogue.
+#ifdef CPPF_DEBUG_ENTRY
+// Profiling aid (built with -DCPPF_DEBUG_ENTRY only, not in the shipped library): the PPF + gather + MFMA chain with no epilogue.
 extern "C" int cppf_debug_mlp_chain_only(const float* pc, const float* nrm, const float* feat, const void* idxs,
                                          int idx_is_i64, const float* packed, int64_t N, int64_t P, float* scratch,
                                          void* workspace, size_t workspace_bytes, void* stream)
@@ -921,6 +922,7 @@ extern "C" int cppf_debug_mlp_chain_only(const float* pc, const float* nrm, cons
     A.idx64 = idx_is_i64; A.outputs = scratch;
     return launch_std<false, false, false>(A, N, workspace, workspace_bytes, (hipStream_t)stream);
 }
+#endif
 
 extern "C" int cppf_decode_center(const float* logits, int64_t P, int ld, int tr_bins, float vr0, float vr1,
                                   const float* u_tr, float* outputs, void* stream)

@@ -1333,6 +1333,9 @@ struct V3Args {
     int bin_sr;            // bin kernel: blocks of 64 pairs a wave culls per super-round
     int fused;             // < 4 tiles: no queues, workgroup (tile, chunk) culls and screens its own pairs (chunks = wgs / T)
     int kk;                // fused, by-value launches: fixed-point bits (the chunks are static)
+    int kk_force;          // != 0: the caller fixes the fixed-point bits (pair-sharded votes: every rank must quantise alike)
+    long long* grid_raw;   // != null: the reduce kernel also stores every cell's exact sum of quanta (i64[gx*gy*gz]; grid may be null)
+    float* quantum_out;    // != null: value of one quantum of grid_raw (0: fp32 partial tiles, grid_raw is not valid)
 };
 
 // *_dyn: the plan from the dims record, identically in all three kernels; false = the record does not fit the launch
@@ -1849,7 +1852,7 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
         if ((int)blockIdx.x >= bk && (int)blockIdx.x < bk + ck) { t = k; c = (int)blockIdx.x - bk; Ct = ck; n_t = (unsigned)sp[128 + k]; }
     }
     // every workgroup must use the same scale: the launch's largest chunk (fused, by-value: fixed on the host, like the plan)
-    const int kk = (FUSED && !A.shape) ? A.kk : v3_bits((unsigned)sp[192], A.n_rots);
+    const int kk = A.kk_force ? A.kk_force : ((FUSED && !A.shape) ? A.kk : v3_bits((unsigned)sp[192], A.n_rots));
     __syncthreads();   // (sp is the carry log: everybody has read it)
     if (t < 0 && blockIdx.x != 0) return;            // more workgroups than chunks
     // binned: records [r0, r1) of the tile's queue; fused: pairs [p0, p1) of the pair list
@@ -2218,20 +2221,35 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, in
     const bool fits = v3_resolve(A, gx, gy, gz, n_points, pt);
     // everything this block needs from the header in ONE round trip (a block's life is a chain of dependent HBM round trips -- header,
     // queue counters, partial tiles, extra plane, the two reports -- of ~1.5 us each; the first two and the middle two now overlap)
-    const unsigned hflags = A.hdr->flags, hextra = A.hdr->any_extra, hfmt = A.hdr->fmt;
+    const unsigned hflags = A.hdr->flags, hextra = A.hdr->any_extra, hfmt = A.hdr->fmt, hmagic = A.hdr->magic;
     const float hquantum = A.hdr->quantum;
     if (fits) v3_split(A, pt.T, sp);
-    if (!fits || (hflags & 1u)) {   // nothing valid was voted: say so (index -1, NaN) and leave a clean header
+    if (!fits || (hflags & 1u)) {   // nothing valid was voted: say so (index -1, NaN)
+        // Two ways here.  (a) The workspace was never initialised (garbage magic): its extra plane is garbage too, so the header
+        // stays POISONED -- every call on it reports the error until the caller zeroes cppf_vote_workspace_init_bytes() bytes.
+        // (b) A valid workspace whose launch gave up (carry log overflow, a shape record beyond the capacities): workgroups may have
+        // added to the plane before the flag went up, so all of it is cleared here -- the "zero between launches" invariant the next
+        // call relies on -- and only then the header is reset.
+        const bool poisoned = hmagic != 0u && hmagic != V3_MAGIC;
+        if (!poisoned) {
+            uint4* p4 = reinterpret_cast<uint4*>(A.plane);
+            const int64_t n16 = (int64_t)(V3_PLANE_BYTES / 16);
+            for (int64_t i = (int64_t)blockIdx.x * blockDim.x + tid; i < n16; i += (int64_t)gridDim.x * blockDim.x) p4[i] = make_uint4(0u, 0u, 0u, 0u);
+            __threadfence();
+            __syncthreads();
+        }
         if (tid == 0) {   // (the ticket lives with the arg-max keys, which the vote / bin kernel zeroed before looking at the header)
             const unsigned tk = atomicAdd(reinterpret_cast<unsigned*>(A.packed + 18), 1u);
             if (tk == gridDim.x - 1) {
                 if (A.out_idx) *A.out_idx = -1;
                 if (A.out_val) *A.out_val = __uint_as_float(0x7fc00000u);
-                v3_rezero(A.hdr);
+                if (A.quantum_out) *A.quantum_out = 0.f;
+                if (!poisoned) v3_rezero(A.hdr);
             }
         }
         return;
     }
+    if (A.quantum_out && blockIdx.x == 0 && tid == 0) *A.quantum_out = hfmt == 0u ? hquantum : 0.f;
     const int T = pt.T;
     const int slot = v3_slot_words(pt, gz);
     __syncthreads();   // (sp)
@@ -2296,7 +2314,7 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, in
     unsigned long long ext = 0ull;
     float prev = 0.f;
     if (owned && any_extra) ext = A.plane[cell];
-    if (owned && A.accumulate) prev = A.grid[cell];
+    if (owned && A.accumulate && A.grid) prev = A.grid[cell];
     __syncthreads();
     if (owned) {
         float v;
@@ -2305,6 +2323,7 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, in
             unsigned long long s_ = ext;
 #pragma unroll
             for (int g = 0; g < RED_GROUPS; ++g) s_ += part[g][tid];
+            if (A.grid_raw) A.grid_raw[cell] = (long long)s_ + (A.accumulate ? A.grid_raw[cell] : 0ll);
             v = (float)((double)s_ * (double)hquantum);   // s < 2^53, the quantum a power of two: one rounding
         } else {
             v = __uint_as_float((uint32_t)ext);
@@ -2312,7 +2331,7 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, in
             for (int g = 0; g < RED_GROUPS; ++g) v = v + __uint_as_float((uint32_t)part[g][tid]);
         }
         if (A.accumulate) v = prev + v;
-        A.grid[cell] = v;
+        if (A.grid) A.grid[cell] = v;
         const unsigned long long key = ((unsigned long long)f2ord(v) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)cell);
         best = key > best ? key : best;
     }
@@ -2406,13 +2425,17 @@ extern "C" int cppf_vote_plan_query(int64_t n_ppfs, int n_rots, int gx, int gy, 
     return 0;
 }
 
+// what cppf_vote_grid_raw adds to a vote: the exact integer image of the grid, its quantum, and bits fixed by the caller
+struct VoteExtras { long long* grid_raw; float* quantum_out; int fixed_bits; };
+
 static int v3_launch(const float* points, const float* outputs, const float* probs, const void* point_idxs, int idx_is_i64,
                      float* grid_obj, const float* corner, float res, int64_t n_points, int64_t n_ppfs, int n_rots, int gx, int gy,
                      int gz, int adaptive, int accumulate, bool want_argmax, long long* out_idx, float* out_val, void* workspace,
-                     hipStream_t st, const int32_t* shape_dev, int64_t grid_cap, int many_tiles)
+                     hipStream_t st, const int32_t* shape_dev, int64_t grid_cap, int many_tiles, const VoteExtras* ex = nullptr)
 {
     char* ws = static_cast<char*>(workspace);
     V3Args A = {};
+    if (ex) { A.grid_raw = ex->grid_raw; A.quantum_out = ex->quantum_out; A.kk_force = ex->fixed_bits; }
     A.points = points; A.outputs = outputs; A.probs = probs; A.point_idxs = point_idxs; A.idx64 = idx_is_i64;
     A.corner = corner; A.res = res; A.n_ppfs = n_ppfs; A.n_points = n_points; A.n_rots = n_rots; A.adaptive = adaptive;
     A.gx = gx; A.gy = gy; A.gz = gz; A.shape = shape_dev; A.grid_cap = grid_cap;
@@ -2488,9 +2511,9 @@ static int vote_impl(const float* points, const float* outputs, const float* pro
                      float* grid_obj, const float* corner, float res, int64_t n_points, int64_t n_ppfs, int n_rots,
                      int gx, int gy, int gz, int adaptive, int accumulate, bool want_argmax, long long* out_idx, float* out_val,
                      void* workspace, size_t workspace_bytes, hipStream_t st, const int32_t* shape_dev = nullptr,
-                     int64_t grid_cap = 0, int many_tiles = 0)
+                     int64_t grid_cap = 0, int many_tiles = 0, const VoteExtras* ex = nullptr)
 {
-    if (!points || !grid_obj || !corner) return CPPF_EINVAL;   // (probs may be null: all ones)
+    if (!points || (!grid_obj && !(ex && ex->grid_raw)) || !corner) return CPPF_EINVAL;   // (probs may be null: all ones)
     if (n_ppfs > 0 && (!outputs || !point_idxs)) return CPPF_EINVAL;
     if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || gx < 1 || gy < 1 || gz < 1 || n_ppfs < 0 || n_points < 1) return CPPF_EINVAL;
     if ((int64_t)gx * gy * gz > 0x7fffffffll) return CPPF_EINVAL;
@@ -2498,7 +2521,8 @@ static int vote_impl(const float* points, const float* outputs, const float* pro
                      getenv("CPPF_VOTE_LEGACY") == nullptr && workspace && workspace_bytes >= v3_workspace_bytes_dyn(many_tiles, n_ppfs))
                   : (v3_eligible(n_ppfs, n_rots, gx, gy, gz) && workspace && workspace_bytes >= v3_workspace_bytes(n_ppfs, gx, gy, gz)))
         return v3_launch(points, outputs, probs, point_idxs, idx_is_i64, grid_obj, corner, res, n_points, n_ppfs, n_rots, gx, gy, gz,
-                         adaptive, accumulate, want_argmax, out_idx, out_val, workspace, st, shape_dev, grid_cap, many_tiles);
+                         adaptive, accumulate, want_argmax, out_idx, out_val, workspace, st, shape_dev, grid_cap, many_tiles, ex);
+    if (ex) return workspace && n_ppfs > 0 ? CPPF_EUNSUPPORTED : CPPF_EWORKSPACE;   // the integer image exists on the tiled integer path only
     VotePlan pl;
     if (shape_dev) {
         if (n_ppfs < 1 || grid_cap < 1 || grid_cap > 0x7fffffffll) return CPPF_EINVAL;
@@ -2616,6 +2640,37 @@ extern "C" int cppf_vote_argmax_dyn(const float* points, const float* outputs, c
     return vote_impl(points, outputs, probs, point_idxs, idx_is_i64, grid_obj, corner, res, n_points_cap, n_ppfs, n_rots, 1, 1, 1,
                      adaptive, accumulate, true, out_idx, out_val, workspace, workspace_bytes, (hipStream_t)stream, shape_dev,
                      grid_capacity, many_tiles);
+}
+
+// ---- the vote as exact integers (pair-sharded votes: cppf_amd/sharding.py) ----
+extern "C" int cppf_vote_grid_raw(const float* points, const float* outputs, const float* probs, const void* point_idxs,
+                                  int idx_is_i64, long long* grid_raw, float* quantum_out, const float* corner, float res,
+                                  int64_t n_points, int64_t n_ppfs, int n_rots, int gx, int gy, int gz, int adaptive, int accumulate,
+                                  int fixed_bits, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!grid_raw || !quantum_out || fixed_bits < 0 || (fixed_bits != 0 && (fixed_bits < 8 || fixed_bits > 24))) return CPPF_EINVAL;
+    const VoteExtras ex = {grid_raw, quantum_out, fixed_bits};
+    return vote_impl(points, outputs, probs, point_idxs, idx_is_i64, nullptr, corner, res, n_points, n_ppfs, n_rots, gx, gy, gz,
+                     adaptive, accumulate, false, nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream, nullptr, 0, 0, &ex);
+}
+
+// grid = raw * quantum (one rounding per cell: the conversion v3_reduce_kernel applies), then the arg-max
+__global__ __launch_bounds__(256) void grid_from_raw_kernel(const long long* __restrict__ raw, int64_t n, const float* __restrict__ quantum,
+                                                            float* __restrict__ grid)
+{
+    const float q = *quantum;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        grid[i] = (q > 0.f && q < INFINITY) ? (float)((double)raw[i] * (double)q)      // (q = +inf: "nothing was voted", an all-zero image)
+                                            : (q > 0.f && raw[i] == 0ll ? 0.f : __uint_as_float(0x7fc00000u));
+}
+extern "C" int cppf_grid_from_raw(const long long* grid_raw, int64_t n, const float* quantum, float* grid, long long* out_idx,
+                                  float* out_val, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!grid_raw || !quantum || !grid || n < 1 || n > 0x7fffffffll) return CPPF_EINVAL;
+    int64_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(grid_from_raw_kernel, dim3((unsigned)(nb > 2048 ? 2048 : nb)), dim3(256), 0, (hipStream_t)stream, grid_raw, n, quantum, grid);
+    CPPF_CHECK_LAUNCH();
+    return out_idx ? cppf_grid_argmax(grid, n, out_idx, out_val, workspace, workspace_bytes, stream) : 0;
 }
 
 extern "C" int cppf_vote_tile_cells(void) { return V3_TILE_FLOATS > VOTE_TILE_FLOATS ? V3_TILE_FLOATS : VOTE_TILE_FLOATS; }

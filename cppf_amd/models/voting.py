@@ -18,7 +18,8 @@ import torch
 from .. import _lib
 from .._torch_util import dev_tensor, require_cuda, scalar, stream_ptr, workspace
 
-__all__ = ["ppf_kernel", "backvote_kernel", "rot_voting_kernel", "vote_argmax", "vote_argmax_dyn", "grid_argmax"]
+__all__ = ["ppf_kernel", "backvote_kernel", "rot_voting_kernel", "vote_argmax", "vote_argmax_dyn", "grid_argmax",
+           "vote_grid_raw", "grid_from_raw", "vote_fixed_point_bits"]
 
 F32, I32 = torch.float32, torch.int32
 
@@ -142,6 +143,64 @@ def vote_argmax_dyn(points, outputs, probs, point_idxs, grid_flat, shape, corner
                                     out_idx.data_ptr(), out_val.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr(dev))
     _lib.check(rc, "cppf_vote_argmax_dyn")
     return out_idx, out_val
+
+
+def vote_fixed_point_bits(n_ppfs, n_rots, dims):
+    """fixed-point bits the tiled vote would choose (a lower bound on the binned path) for a pair list of n_ppfs pairs"""
+    return int(_lib.lib().cppf_vote_fixed_point_bits(int(n_ppfs), int(n_rots), int(dims[0]), int(dims[1]), int(dims[2])))
+
+
+def vote_grid_raw(points, outputs, probs, point_idxs, grid_raw, quantum, corner, res, n_rots, adaptive, fixed_bits=0,
+                  accumulate=False):
+    """The centre vote as exact integers (cppf_vote_grid_raw): grid_raw i64[gx,gy,gz] = every cell's sum of deposited
+    quanta, quantum f32[1] = value of one quantum (0: not valid).  Ranks voting slices of one pair list pass the same
+    fixed_bits, all-reduce grid_raw as integers and convert once (grid_from_raw): the multi-GPU grid is then the
+    single-GPU grid bit for bit (cppf_amd/sharding.py)."""
+    dev = dev_tensor(points, F32, "points", (3,)).device
+    dev_tensor(outputs, F32, "outputs", (2,), dev)
+    if probs is not None:
+        dev_tensor(probs, F32, "probs", None, dev)
+    i64 = point_idxs.dtype == torch.int64
+    dev_tensor(point_idxs, torch.int64 if i64 else I32, "point_idxs", (2,), dev)
+    dev_tensor(grid_raw, torch.int64, "grid_raw", None, dev)
+    dev_tensor(quantum, F32, "quantum", None, dev)
+    dev_tensor(corner, F32, "corner", None, dev)
+    if grid_raw.dim() != 3:
+        raise ValueError("grid_raw must be [gx,gy,gz]")
+    gx, gy, gz = grid_raw.shape
+    n_ppfs = point_idxs.shape[0]
+    L = _lib.lib()
+    need = L.cppf_vote_workspace_bytes(n_ppfs, int(n_rots), gx, gy, gz)
+    if need == 0:
+        raise ValueError(f"n_rots must be in 1..360, got {n_rots}")
+    ws = workspace(need, dev, "vote", zero=True)
+    with torch.cuda.device(dev):
+        rc = L.cppf_vote_grid_raw(points.data_ptr(), outputs.data_ptr(), None if probs is None else probs.data_ptr(),
+                                  point_idxs.data_ptr(), 1 if i64 else 0, grid_raw.data_ptr(), quantum.data_ptr(), corner.data_ptr(),
+                                  float(scalar(res)), points.shape[0], n_ppfs, int(n_rots), gx, gy, gz, 1 if adaptive else 0,
+                                  1 if accumulate else 0, int(fixed_bits), ws.data_ptr(), ws.numel(), stream_ptr(dev))
+    _lib.check(rc, "cppf_vote_grid_raw")
+
+
+def grid_from_raw(grid_raw, quantum, grid=None, out_idx=None, out_val=None):
+    """grid = (float)(grid_raw * quantum) -- the one rounding vote_argmax applies -- and its arg-max: (grid, idx, val)"""
+    dev = dev_tensor(grid_raw, torch.int64, "grid_raw").device
+    dev_tensor(quantum, F32, "quantum", None, dev)
+    if grid is None:
+        grid = torch.empty(grid_raw.shape, dtype=F32, device=dev)
+    dev_tensor(grid, F32, "grid", None, dev)
+    if grid.numel() != grid_raw.numel():
+        raise ValueError("grid and grid_raw must have the same number of cells")
+    if out_idx is None:
+        out_idx = torch.empty(1, dtype=torch.int64, device=dev)
+    if out_val is None:
+        out_val = torch.empty(1, dtype=F32, device=dev)
+    ws = workspace(256, dev, "argmax")
+    with torch.cuda.device(dev):
+        rc = _lib.lib().cppf_grid_from_raw(grid_raw.data_ptr(), grid_raw.numel(), quantum.data_ptr(), grid.data_ptr(),
+                                           out_idx.data_ptr(), out_val.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr(dev))
+    _lib.check(rc, "cppf_grid_from_raw")
+    return grid, out_idx, out_val
 
 
 def grid_argmax(grid, out_idx=None, out_val=None):

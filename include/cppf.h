@@ -19,13 +19,20 @@
  *     in place.
  *   - workspaces are caller-provided device scratch; size them with the *_workspace_bytes()
  *     queries.  The library allocates nothing and keeps no global state.
- *   - ONE exception to "plain scratch": the workspace of the centre vote (cppf_vote_argmax*, cppf_ppf_voting_ws, and the
- *     back-vote entry points that take `vote_workspace`) caches the (cos, sin) rotation table of its last launch in bytes
- *     [248, 256 + 21 KB) so that the next launch with the same n_rots loads it instead of rebuilding it.  Give the vote a
- *     DEDICATED workspace (do not hand the same bytes to other entry points between two votes), or zero its first 32 KB
- *     before reuse.  The kernels re-validate the cache on every launch (stamp + the 72 entries whose value is known) and
- *     rebuild it when the check fails, so a recycled or partially overwritten block costs time, not correctness -- short of
- *     an overwrite that restores all 73 checked words.
+ *   - ONE exception to "plain scratch": the workspace of the centre vote (cppf_vote_argmax*, cppf_ppf_voting, cppf_vote_grid_raw,
+ *     and the back-vote entry points that take `vote_workspace`) carries STATE between calls in its first
+ *     cppf_vote_workspace_init_bytes() bytes (~15.7 MB): the (cos, sin) rotation table of its last launch, the queue counters
+ *     of the binned path, and the "extra plane" (one u64 per grid cell for halo words and fixed-point wrap-arounds) that every
+ *     call leaves zero for the next one.  The contract (ABI version 2):
+ *       * give the vote a DEDICATED allocation: never hand the same bytes to another entry point between two votes;
+ *       * ZERO its first min(cppf_vote_workspace_init_bytes(), size) bytes once, before the first call (one hipMemsetAsync);
+ *       * to recycle a block of a shared arena, zero that many bytes again -- zeroing less (the header alone) makes the header
+ *         look fresh while foreign bytes sit in the plane, which the next vote would add to the grid.
+ *     What the kernels check for themselves: a header that was never initialised (neither zero nor left by a previous call)
+ *     makes EVERY call report arg-max -1 / peak NaN until the caller zeroes the block; the rotation-table cache is re-validated
+ *     on every launch (stamp + the 72 entries whose value is known) and rebuilt when the check fails.  A launch that gives up
+ *     on a valid workspace (a wrap-around log that overflowed under cppf_vote_grid_raw's fixed_bits, or a *_dyn shape record beyond the capacities) reports
+ *     -1 / NaN once, clears the plane itself and leaves the workspace ready for the next call.
  */
 #ifndef CPPF_H
 #define CPPF_H
@@ -36,7 +43,7 @@
 extern "C" {
 #endif
 
-#define CPPF_ABI_VERSION 1
+#define CPPF_ABI_VERSION 2   /* 2: vote workspace contract (state in its first cppf_vote_workspace_init_bytes() bytes), cppf_vote_grid_raw */
 
 #define CPPF_EINVAL (-1)     /* bad argument (null pointer, negative size, n_rots out of range) */
 #define CPPF_EWORKSPACE (-2) /* workspace too small / missing */
@@ -85,6 +92,26 @@ int cppf_vote_argmax(const float* points, const float* outputs, const float* pro
                      int idx_is_i64, float* grid_obj, const float* corner, float res, int64_t n_points, int64_t n_ppfs, int n_rots,
                      int gx, int gy, int gz, int adaptive, int accumulate, long long* out_idx, float* out_val,
                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same vote as EXACT INTEGERS, for a pair list that is split over several GPUs (BASELINE.json
+ * configs[4] "8-GPU shard"; no counterpart in the reference, whose atomicAdd order is whatever the hardware makes it):
+ *   grid_raw     device i64[gx,gy,gz]: every cell's sum of deposited quanta (accumulate != 0: added to what is there)
+ *   quantum_out  device f32[1]: value of one quantum, p2 * 2^-bits (0: probs held negative / non-finite weights, the
+ *                launch accumulated in fp32 and grid_raw is NOT valid)
+ *   fixed_bits   0: the launch chooses (as cppf_vote_argmax does); 8..24: every deposit is rounded to p2 * 2^-fixed_bits.
+ *                Ranks that vote slices of ONE pair list pass the same value -- cppf_vote_fixed_point_bits() of the WHOLE
+ *                list is always safe -- so that the integer sum of their grids is the single-GPU grid bit for bit,
+ *                whatever the order of the all-reduce.  More bits than the launch would choose can overflow the
+ *                wrap-around log of a workgroup: reported as quantum 0.
+ * Needs the tiled integer path (a grid of <= 64 tiles): CPPF_EUNSUPPORTED otherwise.
+ * cppf_grid_from_raw: grid[i] = (float)(raw[i] * quantum) -- the one rounding cppf_vote_argmax applies -- then the arg-max
+ * (out_idx / out_val may be NULL; workspace as cppf_grid_argmax). */
+int cppf_vote_grid_raw(const float* points, const float* outputs, const float* probs, const void* point_idxs, int idx_is_i64,
+                       long long* grid_raw, float* quantum_out, const float* corner, float res, int64_t n_points,
+                       int64_t n_ppfs, int n_rots, int gx, int gy, int gz, int adaptive, int accumulate, int fixed_bits,
+                       void* workspace, size_t workspace_bytes, void* stream);
+int cppf_grid_from_raw(const long long* grid_raw, int64_t n, const float* quantum, float* grid, long long* out_idx,
+                       float* out_val, void* workspace, size_t workspace_bytes, void* stream);
 
 /* np.argmax(grid, axis=None) on device (nocs/inference.py:208).  n cells; ties -> lowest index.
  * workspace: >= 16 bytes of device scratch. */
@@ -158,8 +185,8 @@ size_t cppf_vote_workspace_bytes_dyn(int many_tiles);
 size_t cppf_vote_workspace_bytes_dyn_pairs(int many_tiles, int64_t n_ppfs);
 /* The vote workspace keeps state between calls (queue counters and the plane of fixed-point wrap-arounds, see the note on
  * workspaces above): its first min(cppf_vote_workspace_init_bytes(), size) bytes must be ZERO before the first call on a
- * fresh allocation (one hipMemsetAsync); every call leaves them ready for the next one.  A call on a workspace whose header
- * was never initialised reports arg-max -1 / peak NaN. */
+ * fresh allocation (one hipMemsetAsync); every call leaves them ready for the next one.  Calls on a workspace whose header
+ * was never initialised report arg-max -1 / peak NaN -- every one of them, until the caller zeroes those bytes. */
 size_t cppf_vote_workspace_init_bytes(void);
 /* What a by-value vote launch will do for this problem (tests, tools): out int32[10] = {path, tiles, tx, ty, ntx, nty, halo_x,
  * halo_y, workgroups, fixed-point bits}; path 0: global fp32 atomics (> 64 tiles), 1: round-2 tiled kernels (n_rots > 72),
@@ -259,12 +286,14 @@ int cppf_pair_mlp_decode_sel(const float* pc, const float* nrm, const float* fea
                              int tr_bins, int rot_bins, const float* u_rot, const int32_t* sel, const int32_t* n_sel_dev,
                              int64_t max_sel, float* heads, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Profiling aid, not part of the drop-in surface: the PPF + gather + MFMA chain of the standard
- * architecture with no epilogue (isolates the matrix pipeline when reading rocprof counters).
+#ifdef CPPF_DEBUG_ENTRY
+/* Profiling aid, compiled only with -DCPPF_DEBUG_ENTRY (not in the shipped library): the PPF + gather + MFMA chain of the
+ * standard architecture with no epilogue (isolates the matrix pipeline when reading rocprof counters).
  * scratch: >= 4 bytes of device memory (never written in practice). */
 int cppf_debug_mlp_chain_only(const float* pc, const float* nrm, const float* feat, const void* idxs, int idx_is_i64,
                               const float* packed, int64_t N, int64_t P, float* scratch, void* workspace,
                               size_t workspace_bytes, void* stream);
+#endif
 
 /* Decode from logits already in memory (generic architectures / bin counts). */
 int cppf_decode_center(const float* logits, int64_t P, int ld, int tr_bins, float vr0, float vr1,

@@ -611,6 +611,52 @@ void orc_ppf_voting_f64(const float* points, const float* outputs, const float* 
     }
 }
 
+/* Same votes as EXACT INTEGERS: every deposit rounded to a multiple of the quantum p2 * 2^-bits, q = floor(w * 2^bits / p2 + 1/2)
+ * with w the reference's fp32 weight (:47-63, product left to right), summed as int64.  This is the specification of
+ * cppf_vote_grid_raw (the image the pair-sharded vote all-reduces, cppf_amd/sharding.py): integer sums are order-independent,
+ * so the HIP path must reproduce it bit for bit whichever workgroup / rank took whichever pair.  grid is added to. */
+void orc_ppf_voting_fixed(const float* points, const float* outputs, const float* probs, const int32_t* point_idxs,
+                          int64_t* grid, const float* corner, float res, int64_t n_ppfs, int n_rots, int gx, int gy, int gz,
+                          int adaptive, int bits, double p2)
+{
+    f3 cr = {corner[0], corner[1], corner[2]};
+    const double S = ldexp(1.0, bits) / p2;
+    for (int64_t idx = 0; idx < n_ppfs; ++idx) {
+        float proj_len = outputs[2 * idx], odist = outputs[2 * idx + 1];
+        f3 a, ab, xd;
+        if (!pair_frame(points, point_idxs, idx, &a, &ab, &xd)) continue;
+        f3 c = sub3(a, scl3(ab, proj_len));
+        float pa = probs[point_idxs[2 * idx]], pb = probs[point_idxs[2 * idx + 1]];
+        float prob = pa > pb ? pa : pb;
+        f3 x = scl3(xd, odist);
+        f3 y = cross3(x, ab);
+        int n = n_rots;
+        if (adaptive) {
+            int m = sat_int((double)(odist / res) * (2 * ORC_PI));
+            n = m < n_rots ? m : n_rots;
+        }
+        for (int i = 0; i < n; ++i) {
+            float cs, sn;
+            rot_cs(i, n, &cs, &sn);
+            f3 offset = add3(scl3(x, cs), scl3(y, sn));
+            f3 g = div3(sub3(add3(c, offset), cr), res);
+            if ((double)g.x < 0.01 || (double)g.y < 0.01 || (double)g.z < 0.01 ||
+                (double)g.x >= (double)gx - 1.01 || (double)g.y >= (double)gy - 1.01 ||
+                (double)g.z >= (double)gz - 1.01)
+                continue;
+            int fx = (int)g.x, fy = (int)g.y, fz = (int)g.z;
+            float rx = g.x - floorf(g.x), ry = g.y - floorf(g.y), rz = g.z - floorf(g.z);
+            float w0x = 1.f - rx, w0y = 1.f - ry, w0z = 1.f - rz;
+            float w[8] = {w0x * w0y * w0z * prob, w0x * w0y * rz * prob, w0x * ry * w0z * prob, w0x * ry * rz * prob,
+                          rx * w0y * w0z * prob,  rx * w0y * rz * prob,  rx * ry * w0z * prob,  rx * ry * rz * prob};
+            int64_t syz = (int64_t)gy * gz;
+            int64_t b = fx * syz + fy * gz + fz;
+            int64_t off[8] = {0, 1, gz, gz + 1, syz, syz + 1, syz + gz, syz + gz + 1};
+            for (int k = 0; k < 8; ++k) grid[b + off[k]] += (int64_t)floor((double)w[k] * S + 0.5);
+        }
+    }
+}
+
 /* Multi-threaded variant for the timed CPU baseline: per-thread private grids, summed at the end
  * (summation order differs from the serial one; same tolerance class as the GPU's atomics). */
 void orc_ppf_voting_mt(const float* points, const float* outputs, const float* probs,

@@ -206,6 +206,23 @@ def ppf_voting_f64(points, outputs, probs, point_idxs, dims, corner, res, n_rots
     return grid, counts
 
 
+def ppf_voting_fixed(points, outputs, probs, point_idxs, dims, corner, res, n_rots, adaptive, bits, grid=None):
+    """models/voting.py:8-66 with every deposit rounded to p2 * 2^-bits (p2 = max(probs) rounded up to a power of two) and
+    summed as int64: the specification of cppf_vote_grid_raw.  Returns (grid i64[dims], quantum)."""
+    points, outputs, probs = _c(points, _f), _c(outputs, _f), _c(probs, _f)
+    point_idxs, corner = _c(point_idxs, np.int32), _c(corner, _f)
+    gx, gy, gz = (int(d) for d in dims)
+    if grid is None:
+        grid = np.zeros((gx, gy, gz), np.int64)
+    pmax = float(np.max(probs)) if probs.size else 1.0
+    p2 = float(2.0 ** np.ceil(np.log2(pmax))) if pmax > 0 else 1.0
+    lib().orc_ppf_voting_fixed(_p(points, _pf), _p(outputs, _pf), _p(probs, _pf), _p(point_idxs, _pi32),
+                               grid.ctypes.data_as(C.POINTER(C.c_int64)), _p(corner, _pf), C.c_float(res),
+                               C.c_int64(point_idxs.shape[0]), C.c_int(n_rots), C.c_int(gx), C.c_int(gy), C.c_int(gz),
+                               C.c_int(1 if adaptive else 0), C.c_int(int(bits)), C.c_double(p2))
+    return grid, p2 * 2.0 ** -int(bits)
+
+
 def grid_argmax(grid):
     """np.argmax(grid) (first maximum, C order), nocs/inference.py:208"""
     g = _c(grid, _f).reshape(-1)

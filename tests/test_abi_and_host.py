@@ -14,13 +14,15 @@ from conftest import ROOT, sd_from_npz
 def test_library_loads_and_exports_every_declared_symbol():
     from cppf_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "cppf.h")).read()
+    hdr = re.sub(r"#ifdef CPPF_DEBUG_ENTRY.*?#endif", "", hdr, flags=re.S)       # profiling aids are not in the shipped library
     declared = sorted(set(re.findall(r"\b(cppf_[a-z0-9_]+)\s*\(", hdr)))
     assert len(declared) >= 20
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/cppf.h but not exported"
     assert set(declared) == set(_lib.exported_symbols())
-    assert L.cppf_abi_version() == 1
+    assert not hasattr(L, "cppf_debug_mlp_chain_only")
+    assert L.cppf_abi_version() == 2 == _lib.ABI_VERSION and "#define CPPF_ABI_VERSION 2" in hdr
     assert b"workspace" in L.cppf_error_string(-2)
 
 

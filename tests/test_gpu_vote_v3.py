@@ -89,9 +89,9 @@ def test_many_tile_vote_is_bit_reproducible(dev):
     assert grids[0][0].sum().item() > 1e5
 
 
-def test_uninitialised_workspace_is_reported_then_usable(oracle, dev):
+def test_uninitialised_workspace_is_reported_until_zeroed(oracle, dev):
     """include/cppf.h: the vote workspace must start zeroed.  One that never was (garbage header) must not be used silently:
-    the call reports arg-max -1 / peak NaN and leaves the workspace in a usable state for the next call"""
+    every call on it reports arg-max -1 / peak NaN until the caller zeroes cppf_vote_workspace_init_bytes() bytes"""
     L = _lib.lib()
     ob, idx, out = case(n=1200, k=30, seed=2)
     res = ob["cfg"].res
@@ -112,8 +112,12 @@ def test_uninitialised_workspace_is_reported_then_usable(oracle, dev):
                                     ws.data_ptr(), ws.numel(), stream_ptr(dev))
             assert rc == 0
             torch.cuda.synchronize()
-        call()
-        assert int(oi) == -1 and np.isnan(float(ov))
+        for _ in range(3):     # EVERY call on the garbage block says so (round 3 stamped the header valid after the first report and
+            oi.zero_()         # the next call silently added the garbage "extra plane" to the grid): the header stays poisoned
+            ov.zero_()
+            call()
+            assert int(oi) == -1 and np.isnan(float(ov))
+        # zeroing the header alone is NOT the contract (include/cppf.h, ABI 2): the whole state -- header + plane -- is
         # the caller follows the header's rule now (zero once) and everything works, repeatedly
         ws[:min(int(L.cppf_vote_workspace_init_bytes()), need)].zero_()
         for _ in range(2):
@@ -202,3 +206,86 @@ def test_bin_kernel_staging_overflow_path(oracle, dev):
     gg2, flat2, _ = run_vote(dev, pc, out, idx, corner, dims, res, 72, True)
     np.testing.assert_array_equal(gg, gg2)
     assert flat == flat2
+
+
+# --------------------------------------------------------------------------- the vote as exact integers (cppf_vote_grid_raw)
+@pytest.mark.parametrize("n,k,res,bits,unit", [(1500, 40, 4e-3, 0, True), (1500, 40, 4e-3, 20, True), (3000, 50, 2e-3, 0, True),
+                                              (3000, 50, 2e-3, 17, False), (1200, 30, 4e-3, 24, False)])
+def test_integer_grid_equals_the_oracles_fixed_point_vote(oracle, dev, n, k, res, bits, unit):
+    """cppf_vote_grid_raw: every cell's sum of quanta, fused (2 tiles) and binned (many tiles), chosen and forced bits, unit and
+    non-unit probs -- EQUAL to oracle.ppf_voting_fixed (floor(w 2^bits / p2 + 1/2) per deposit, summed as int64), and
+    grid_from_raw of it equal to what cppf_vote_argmax writes when it chooses the same bits"""
+    from cppf_amd.inference import grid_shape
+    ob, idx, out = case(n=n, k=k, seed=6)
+    corners, dims = grid_shape(ob["pc"], res)
+    rng = np.random.default_rng(8)
+    probs = None if unit else rng.uniform(0.3, 1.7, n).astype(np.float32)
+    pc, o, i32, corner = t(ob["pc"], dev), t(out, dev), t(idx, dev), t(corners[0], dev)
+    pr = None if unit else t(probs, dev)
+    raw = torch.full(dims, -7, dtype=torch.int64, device=dev)
+    q = torch.zeros(1, dtype=torch.float32, device=dev)
+    voting.vote_grid_raw(pc, o, pr, i32, raw, q, corner, res, 72, True, fixed_bits=bits)
+    qv = float(q)
+    p2 = 1.0 if unit else 2.0
+    used = int(round(np.log2(p2 / qv)))
+    assert qv > 0 and (bits == 0 or used == bits) and 8 <= used <= 24
+    assert used >= voting.vote_fixed_point_bits(idx.shape[0], 72, dims)          # the query is a lower bound of what a launch chooses
+    want, qo = oracle.ppf_voting_fixed(ob["pc"], out, np.ones(n, np.float32) if unit else probs, idx, dims, corners[0], res, 72, True, used)
+    assert qo == qv
+    got = raw.cpu().numpy()
+    assert np.array_equal(got, want), f"{np.count_nonzero(got != want)} of {want.size} cells differ"
+    assert want.sum() > 1e6
+    # += (accumulate) adds the integers
+    voting.vote_grid_raw(pc, o, pr, i32, raw, q, corner, res, 72, True, fixed_bits=used, accumulate=True)
+    assert np.array_equal(raw.cpu().numpy(), 2 * want)
+    # one conversion, the arg-max of the converted grid
+    grid, gi, gv = voting.grid_from_raw(torch.from_numpy(want).to(dev), q)
+    assert np.array_equal(grid.cpu().numpy(), (want.astype(np.float64) * qv).astype(np.float32))
+    assert int(gi) == int(np.argmax(grid.cpu().numpy())) and float(gv) == float(grid.max())
+    if bits == 0:
+        g2 = torch.empty(dims, dtype=torch.float32, device=dev)
+        i2, v2 = voting.vote_argmax(pc, o, pr, i32, g2, corner, res, 72, True, accumulate=False)
+        assert torch.equal(g2, grid) and int(i2) == int(gi) and float(v2) == float(gv)
+
+
+def test_integer_grids_of_pair_slices_add_up_to_the_whole_lists_grid(dev):
+    """pair-sharded vote, ranks emulated on one device: with the bits of the WHOLE list forced, the slices' integer grids sum to
+    the whole list's integer grid exactly, for any number of slices (C5-like fine grid: the binned path, racy queues)"""
+    from cppf_amd import sharding
+    from cppf_amd.inference import grid_shape
+    ob, idx, out = case(n=4096, k=96, seed=12)
+    res = 2e-3
+    corners, dims = grid_shape(ob["pc"], res)
+    pc, o, i32, corner = t(ob["pc"], dev), t(out, dev), t(idx, dev), t(corners[0], dev)
+    P = idx.shape[0]
+    i0, v0, g0, q0 = sharding.vote_sharded(pc, o, i32, corner, dims, res, P, 1)
+    assert float(q0) > 0 and float(v0) > 50
+    bits = voting.vote_fixed_point_bits(P, 72, dims)
+    for world in (2, 3, 8):
+        total = torch.zeros(dims, dtype=torch.int64, device=dev)
+        q = torch.zeros(1, dtype=torch.float32, device=dev)
+        for r in range(world):
+            lo, hi = sharding.shard_pairs(P, r, world)
+            voting.vote_grid_raw(pc, o[lo:hi].contiguous(), None, i32[lo:hi].contiguous(), total, q, corner, res, 72, True,
+                                 fixed_bits=bits, accumulate=True)
+        g, gi, gv = voting.grid_from_raw(total, q)
+        assert float(q) == float(q0) and torch.equal(g, g0) and int(gi) == int(i0) and float(gv) == float(v0), world
+
+
+def test_integer_vote_rejects_what_it_cannot_serve(dev):
+    L = _lib.lib()
+    ob, idx, out = case(n=600, k=10, seed=1)
+    pc, o, i32 = t(ob["pc"], dev), t(out, dev), t(idx, dev)
+    corner = t(np.zeros(3, np.float32), dev)
+    raw = torch.zeros((8, 8, 8), dtype=torch.int64, device=dev)
+    q = torch.zeros(1, dtype=torch.float32, device=dev)
+    with pytest.raises(_lib.CppfError):
+        voting.vote_grid_raw(pc, o, None, i32, raw, q, corner, 4e-3, 72, True, fixed_bits=25)      # bits beyond fp32 deposits
+    with pytest.raises(_lib.CppfError):
+        voting.vote_grid_raw(pc, o, None, i32, raw, q, corner, 4e-3, 100, True)                    # n_rots > 72: no integer path yet
+    # negative probs: the launch accumulates in fp32 -> quantum 0 flags the image as not valid, the converted grid is NaN
+    probs = torch.full((600,), -1.0, dtype=torch.float32, device=dev)
+    voting.vote_grid_raw(pc, o, probs, i32, raw, q, corner, 4e-3, 72, True)
+    assert float(q) == 0.0
+    g, gi, gv = voting.grid_from_raw(raw, q)
+    assert bool(torch.isnan(g).all())
