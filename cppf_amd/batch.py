@@ -23,12 +23,16 @@ from .utils.util import fibonacci_sphere, num_sphere_bins
 
 class BatchPoseRunner:
     def __init__(self, encoders, device, num_rots=72, adaptive=True, angle_tol=1.5, max_rot_pairs=10000,
-                 use_graph=True, point_encoders=None, n_bucket=1024, max_pipelines=24, dynamic=True, n_lanes=3):
+                 use_graph=True, point_encoders=None, n_bucket=1024, max_pipelines=24, dynamic=True, n_lanes=3,
+                 max_scratch_bytes=16 << 30):
         """encoders: {category name: PPFEncoder on `device`} (the reference keeps one per category,
         nocs/inference.py:79-90).  point_encoders: optional {category name: PointEncoder}; objects of those
         categories need no `feat` -- kNN + SPRIN run at the head of the captured graph (:180-181).
         n_bucket: point capacities are multiples of it; max_pipelines: bound of the pipeline cache;
         dynamic=False: one exact-shape pipeline per distinct instance shape (fixed-shape workloads only);
+        max_scratch_bytes: second bound of the cache, on the pipelines' estimated device footprint (buffers + the vote's workspace,
+        whose pair -> tile queues are sized for the worst case, every pair in every tile of the grid class: 64 x 12 B per pair for
+        many-tile grids, i.e. ~0.45 GB per pipeline at 524 288 pairs, ~1.7 GB at 2 M; INTEGRATION.md "Memory");
         n_lanes: instances in flight (HIP streams, each with its own pipelines).  Three measured best on a ragged batch of
         small instances (N 400-2000, 100 k pairs: 0.216 / 0.136 / 0.115 / 0.144 ms per instance with 1 / 2 / 3 / 4 lanes): the
         neighbours fill the gaps between an instance's ~15 short dependent launches."""
@@ -38,6 +42,7 @@ class BatchPoseRunner:
                        use_graph=use_graph)
         self.sphere = np.array(fibonacci_sphere(num_sphere_bins(angle_tol)))      # :100-102
         self.n_bucket, self.max_pipelines, self.dynamic = int(n_bucket), int(max_pipelines), bool(dynamic)
+        self.max_scratch_bytes, self._bytes = int(max_scratch_bytes), {}
         self.n_lanes = max(1, int(n_lanes))
         self._pipes = OrderedDict()    # LRU: key -> PosePipeline
         self._staging = {}         # pinned host staging sets for the small per-instance arrays, see _stage()
@@ -56,11 +61,13 @@ class BatchPoseRunner:
             key = (cfg.category, n_points, n_pairs, tuple(dims), lane)
         pipe = self._pipes.get(key)
         if pipe is None:
-            while len(self._pipes) >= self.max_pipelines:
+            need = self.footprint_bytes(n_cap if dyn else n_points, n_pairs, many if dyn else None, dims)
+            while self._pipes and (len(self._pipes) >= self.max_pipelines or sum(self._bytes.values()) + need > self.max_scratch_bytes):
                 # the victim may still have a replay in flight on its lane's stream: drain before its buffers go back
                 # to the allocator (evictions are rare: a new shape bucket beyond the cache bound)
                 torch.cuda.synchronize(self.device)
-                _, old = self._pipes.popitem(last=False)
+                old_key, old = self._pipes.popitem(last=False)
+                self._bytes.pop(old_key, None)
                 old.release()
             if dyn:
                 pipe = PosePipeline(self.encoders[cfg.category], cfg, n_cap, n_pairs, many, self.device, self.sphere,
@@ -69,9 +76,24 @@ class BatchPoseRunner:
                 pipe = PosePipeline(self.encoders[cfg.category], cfg, n_points, n_pairs, dims, self.device,
                                     self.sphere, point_encoder=self.point_encoders.get(cfg.category), **self.kw)
             self._pipes[key] = pipe
+            self._bytes[key] = need
         else:
             self._pipes.move_to_end(key)
         return pipe
+
+    @staticmethod
+    def footprint_bytes(n_points, n_pairs, many_tiles, dims):
+        """estimated device bytes of one pipeline: per-pair buffers (pairs i64 + i32, uniforms, (mu, nu), heads, masks, survivor
+        list: ~100 B per pair), per-point buffers, the grid, and the vote's workspace (many_tiles None: an exact-shape pipeline)"""
+        from . import _lib
+        L = _lib.lib()
+        if many_tiles is None:
+            ws = L.cppf_vote_workspace_bytes(int(n_pairs), 72, int(dims[0]), int(dims[1]), int(dims[2]))
+            grid = 4 * int(dims[0]) * int(dims[1]) * int(dims[2])
+        else:
+            ws = L.cppf_vote_workspace_bytes_dyn_pairs(1 if many_tiles else 0, int(n_pairs))
+            grid = 4 * (64 if many_tiles else 3) * int(L.cppf_vote_tile_cells())
+        return int(ws) + grid + 100 * int(n_pairs) + 1400 * int(n_points)
 
     _RING = 4
 

@@ -304,10 +304,11 @@ class CenterPipeline:
 
     def _await_images(self):
         """another stream may have rebuilt a weight image in place since this pipeline last replayed: wait for it"""
-        seen = self.__dict__.setdefault("_image_gens", {})
+        seen = self.__dict__.setdefault("_image_gens", {})     # per (encoder, stream): a pipeline replayed on a NEW stream must wait too
+        sid = torch.cuda.current_stream(self.device).cuda_stream
         for enc in (self.encoder, self.point_encoder):
             if enc is not None:
-                seen[id(enc)] = enc._await_image(self.device, seen.get(id(enc)))
+                seen[(id(enc), sid)] = enc._await_image(self.device, seen.get((id(enc), sid)))
 
     def _note_images_read(self):
         """... and a later rebuild (on any stream) must wait for this replay"""

@@ -94,7 +94,7 @@ class _DeviceWeights:
     # Several HIP streams may share one encoder (inference.CenterPipeline lanes, batch.BatchPoseRunner).  The image is rebuilt
     # in place on whichever stream notices the parameter change, so both directions are ordered with events: a rebuild waits for
     # every replay that was still reading the old image (`_note_image_read`), and a reader on another stream waits for the
-    # rebuild before its next replay (`_await_image`).  A training loop on one stream never registers a reader and pays nothing.
+    # rebuild before its next replay (`_await_image`).  A training loop on one stream pays one event record per re-pack.
     # (the events live outside the module: copy.deepcopy / pickling of an encoder must not meet a HIP event)
     def _stream_state(self):
         st = _STREAM_STATE.get(self)
@@ -114,8 +114,10 @@ class _DeviceWeights:
     def _image_rebuilt(self, dev):
         """called right after the rebuild was enqueued: later readers on other streams wait for this event"""
         st = self._stream_state()
-        if not st["readers"]:
-            return                                   # nobody replays captured chains on this encoder
+        # recorded after EVERY pack, also the very first one (no reader registered yet): a pipeline that is captured or replayed on
+        # another stream right afterwards finds the key unchanged and would otherwise never learn that it has to wait
+        if torch.cuda.is_current_stream_capturing():
+            return                                   # (packs happen before a capture begins; an event record would become a graph node)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
         st["image_ev"] = (ev, torch.cuda.current_stream(dev).cuda_stream, st["image_ev"][2] + 1)

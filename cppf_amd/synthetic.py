@@ -105,3 +105,110 @@ def closed_form_heads(pc, normals, point_idxs, cfg, quantise=True, seed=0, aux_l
     heads[:, 3] = np.where(n @ right > 0, aux_logit, -aux_logit)
     heads[:, 4:7] = scale_noise * rng.standard_normal((point_idxs.shape[0], 3))
     return heads
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Posed objects with a known answer for the WHOLE pose (training targets and held-out checks, cppf_amd/training.py): the
+# shapes above in a random rigid pose and size.  Cylinder categories get a NECK (upper 30 % of the height at 45 % of the
+# radius, with a shoulder), so that up and down can be told apart from the geometry; boxes stay boxes (their axes are
+# defined up to sign).  The reference trains on ShapeNet renders brought back to the canonical frame
+# (utils/dataset.py:202-212); its targets are functions of (cloud, centre, axes, extents) only, which is what is returned.
+def random_rotation(rng):
+    q = rng.standard_normal(4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _box_surface(rng, n, ext):
+    """n points on the surface of the box [-ext, ext] with outward normals, faces picked by area"""
+    ext = np.asarray(ext, np.float64)
+    areas = np.array([ext[1] * ext[2], ext[0] * ext[2], ext[0] * ext[1]])
+    axis = rng.choice(3, n, p=areas / areas.sum())
+    sign = np.where(rng.random(n) < 0.5, 1.0, -1.0)
+    pts = rng.uniform(-1, 1, (n, 3)) * ext
+    pts[np.arange(n), axis] = sign * ext[axis]
+    nrm = np.zeros((n, 3))
+    nrm[np.arange(n), axis] = sign
+    return pts, nrm
+
+
+def _cyl_surface(rng, n, r, h, r2=None, y_sh=None):
+    """n points on a capped cylinder of radius r, y in [-h, h]; with r2 / y_sh: a NECK of radius r2 above the shoulder y_sh"""
+    neck = r2 is not None
+    if not neck:
+        r2, y_sh = r, h
+    parts = [2 * np.pi * r * (y_sh + h), np.pi * r * r]   # body side, bottom cap
+    if neck:
+        parts += [np.pi * (r * r - r2 * r2), 2 * np.pi * r2 * (h - y_sh), np.pi * r2 * r2]   # shoulder ring, neck side, top cap
+    else:
+        parts += [np.pi * r * r]
+    which = rng.choice(len(parts), n, p=np.array(parts) / np.sum(parts))
+    th = rng.uniform(0, 2 * np.pi, n)
+    u = rng.random(n)
+    c, s_ = np.cos(th), np.sin(th)
+    pts, nrm = np.zeros((n, 3)), np.zeros((n, 3))
+    m = which == 0
+    pts[m] = np.stack([r * c[m], -h + u[m] * (y_sh + h), r * s_[m]], -1)
+    nrm[m] = np.stack([c[m], 0 * c[m], s_[m]], -1)
+    m = which == 1
+    rad = r * np.sqrt(u[m])
+    pts[m] = np.stack([rad * c[m], np.full(m.sum(), -h), rad * s_[m]], -1)
+    nrm[m] = [0, -1, 0]
+    if neck:
+        m = which == 2
+        rad = np.sqrt(r2 * r2 + u[m] * (r * r - r2 * r2))
+        pts[m] = np.stack([rad * c[m], np.full(m.sum(), y_sh), rad * s_[m]], -1)
+        nrm[m] = [0, 1, 0]
+        m = which == 3
+        pts[m] = np.stack([r2 * c[m], y_sh + u[m] * (h - y_sh), r2 * s_[m]], -1)
+        nrm[m] = np.stack([c[m], 0 * c[m], s_[m]], -1)
+        m = which == 4
+        rad = r2 * np.sqrt(u[m])
+    else:
+        m = which == 2
+        rad = r * np.sqrt(u[m])
+    pts[m] = np.stack([rad * c[m], np.full(m.sum(), h), rad * s_[m]], -1)
+    nrm[m] = [0, 1, 0]
+    return pts, nrm, float(np.sum(parts))
+
+
+def make_posed_object(category="bottle", n_points=2048, seed=0, size_range=(0.8, 1.2), rotate=True, neck=True):
+    """-> dict(pc f32[N,3], normals f32[N,3], center f64[3] (centre of the bounding box in the object's frame, like
+    utils/dataset.py:162-164), R f64[3,3] (columns = the object's x, y (up), z axes in the world), half_extents f64[3] (what
+    exp(scale head) * scale_mean should give, nocs/inference.py:335 / 2), cfg, category).
+    bottle / can / bowl: a cylinder with a neck (up and down differ); mug: a cylinder with a HANDLE plate towards +x (the
+    `right` axis of the category is defined by it); everything else: a box with the category's extents."""
+    cfg = CATEGORIES[category]
+    rng = np.random.default_rng(seed + 7000003)
+    size = rng.uniform(*size_range)
+    sx, sy, sz = (np.array(cfg.scale_mean) * size).tolist()
+    n = n_points
+    if category == "mug":
+        r, h = sz, sy                                            # the body's radius is the z half extent; x also holds the handle
+        hx, hy, hz = (sx - r), 0.6 * h, 0.13 * r               # handle plate: half extents
+        body_area = 2 * np.pi * r * 2 * h + 2 * np.pi * r * r
+        plate_area = 8 * (hx * hy + hx * hz + hy * hz)
+        nb = int(rng.binomial(n, body_area / (body_area + plate_area)))
+        pb, nb_ = _cyl_surface(rng, nb, r, h)[:2]
+        pb[:, 0] -= (sx - r)                                     # bounding box centred: body axis at x = -(sx - r)
+        ph, nh = _box_surface(rng, n - nb, [hx, hy, hz])
+        ph[:, 0] += sx - hx                                      # the plate reaches x = +sx
+        pts, nrm = np.concatenate([pb, ph]), np.concatenate([nb_, nh])
+        perm = rng.permutation(n)
+        pts, nrm = pts[perm], nrm[perm]
+    elif category in _CYL:
+        if neck:
+            pts, nrm, _ = _cyl_surface(rng, n, sx, sy, 0.45 * sx, 0.4 * sy)     # the neck: upper 30 % of the height at 45 % radius
+        else:
+            pts, nrm, _ = _cyl_surface(rng, n, sx, sy)
+    else:
+        pts, nrm = _box_surface(rng, n, [sx, sy, sz])
+    R = random_rotation(rng) if rotate else np.eye(3)
+    center = rng.uniform(-0.2, 0.2, 3) + np.array([0.0, 0.0, 0.8])
+    pc = pts @ R.T + center
+    pc = pc + np.clip(cfg.res / 4 * rng.standard_normal(pc.shape), -cfg.res / 2, cfg.res / 2)     # nocs/inference.py:134
+    return dict(pc=pc.astype(np.float32), normals=(nrm @ R.T).astype(np.float32), center=center, R=R,
+                half_extents=np.array([sx, sy, sz]), cfg=cfg, category=category)

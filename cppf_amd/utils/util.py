@@ -122,3 +122,70 @@ def sparse_quantize(pc, return_index=True, quantization_size=1.0):
     if was_np:
         idx, coords = idx.cpu().numpy(), coords.cpu().numpy()
     return (coords, idx) if return_index else coords
+
+
+# --------------------------------------------------------------------------- depth image I/O
+def read_depth_png(path):
+    """The depth read of nocs/inference.py:110 -- `cv2.imread(path, -1)` on a NOCS `*_depth.png` -- without OpenCV: an
+    8- or 16-bit greyscale, non-interlaced PNG -> uint8 / uint16 [H,W] (millimetres in the NOCS frames).  PNG filtering
+    (types 0-4) undone with numpy; anything else the format allows (palette, colour, interlacing) is refused."""
+    import struct
+    import zlib
+    with open(path, "rb") as f:
+        b = f.read()
+    if b[:8] != b"\x89PNG\r\n\x1a\n":
+        raise ValueError(f"{path}: not a PNG file")
+    pos, idat, hdr = 8, [], None
+    while pos + 8 <= len(b):
+        n, = struct.unpack(">I", b[pos:pos + 4])
+        typ = b[pos + 4:pos + 8]
+        body = b[pos + 8:pos + 8 + n]
+        if typ == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        elif typ == b"IDAT":
+            idat.append(body)
+        elif typ == b"IEND":
+            break
+        pos += 12 + n
+    if hdr is None:
+        raise ValueError(f"{path}: no IHDR chunk")
+    W, H, depth, colour, _, _, interlace = hdr
+    if colour != 0 or interlace != 0 or depth not in (8, 16):
+        raise ValueError(f"{path}: only non-interlaced 8/16-bit greyscale PNGs are depth images (colour type {colour}, "
+                         f"bit depth {depth}, interlace {interlace})")
+    bpp = depth // 8
+    stride = W * bpp
+    raw = np.frombuffer(zlib.decompress(b"".join(idat)), dtype=np.uint8)
+    if raw.size != H * (stride + 1):
+        raise ValueError(f"{path}: {raw.size} bytes of image data, expected {H * (stride + 1)}")
+    raw = raw.reshape(H, stride + 1)
+    out = np.zeros((H, stride), dtype=np.uint8)
+    prev = np.zeros(stride, dtype=np.int32)
+    for y in range(H):
+        ft, line = int(raw[y, 0]), raw[y, 1:].astype(np.int32)
+        if ft == 0:
+            cur = line
+        elif ft == 2:                                   # Up
+            cur = (line + prev) & 255
+        elif ft == 1:                                   # Sub: a running sum per byte lane
+            cur = (np.cumsum(line.reshape(-1, bpp), axis=0) & 255).reshape(-1)
+        elif ft in (3, 4):                              # Average / Paeth depend on the reconstructed left neighbour: byte by byte
+            cur = np.zeros(stride, dtype=np.int32)
+            for i in range(stride):
+                a = int(cur[i - bpp]) if i >= bpp else 0
+                up = int(prev[i])
+                if ft == 3:
+                    pred = (a + up) >> 1
+                else:
+                    c = int(prev[i - bpp]) if i >= bpp else 0
+                    p = a + up - c
+                    pa, pb, pc_ = abs(p - a), abs(p - up), abs(p - c)
+                    pred = a if (pa <= pb and pa <= pc_) else (up if pb <= pc_ else c)
+                cur[i] = (int(line[i]) + pred) & 255
+        else:
+            raise ValueError(f"{path}: bad filter type {ft} in row {y}")
+        out[y] = cur
+        prev = cur
+    if bpp == 1:
+        return out
+    return (out[:, 0::2].astype(np.uint16) << 8) | out[:, 1::2].astype(np.uint16)     # PNG samples are big-endian

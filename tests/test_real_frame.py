@@ -1,0 +1,122 @@
+"""One real frame.  tests/golden/demo_0000_depth.png is the reference's demo depth image (data/demo/0000_depth.png, a NOCS
+REAL275-style Kinect frame: holes, depth noise, no analytic normals), read without OpenCV, cut into a few rectangular
+"instances" (a detector's masks are upstream of the path), and taken through nocs/inference.py:131-142 on the device --
+back-projection, voxel de-duplication, PCA normals, each against the oracle on this real data -- then kNN + SPRIN + the whole
+pose with the networks trained on synthetic objects (tests/golden/trained_*.npz)."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+DEPTH = os.path.join(GOLDEN, "demo_0000_depth.png")
+# (category, rows, cols, depth window in mm around the rectangle's median depth): the mug in front of the laptop, the two bowls,
+# the mug with the red handle, the can, and the laptop itself
+RECTS = [("mug", (262, 356), (124, 206), 90), ("bowl", (184, 246), (288, 366), 90), ("bowl", (194, 250), (370, 442), 90),
+         ("mug", (186, 250), (436, 504), 90), ("can", (112, 184), (376, 408), 60), ("laptop", (118, 322), (92, 302), 260)]
+
+
+def instances(depth):
+    out = []
+    for cat, (r0, r1), (c0, c1), win in RECTS:
+        m = np.zeros(depth.shape, bool)
+        patch = depth[r0:r1, c0:c1]
+        med = np.median(patch[patch > 0])
+        m[r0:r1, c0:c1] = np.abs(patch.astype(np.int64) - med) <= win
+        out.append((cat, m))
+    return out
+
+
+def test_depth_png_reader_without_opencv():
+    from cppf_amd.utils.util import read_depth_png
+    d = read_depth_png(DEPTH)
+    assert d.dtype == np.uint16 and d.shape == (480, 640)
+    assert int(d.max()) == 1409 and int(d.astype(np.int64).sum()) == 244066561 and abs(float((d == 0).mean()) - 0.2979) < 1e-3
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    assert np.array_equal(d, np.array(Image.open(DEPTH)))
+    # every PNG filter type, 8 and 16 bit, against PIL's encoder
+    import io
+    import tempfile
+    rng = np.random.default_rng(0)
+    for arr in (rng.integers(0, 65535, (37, 53)).astype(np.uint16), (np.arange(40 * 64).reshape(40, 64) * 13 % 251).astype(np.uint8),
+                np.cumsum(rng.integers(0, 9, (64, 48)), 1).astype(np.uint16)):
+        with tempfile.NamedTemporaryFile(suffix=".png") as f:
+            Image.fromarray(arr).save(f.name, optimize=True)
+            assert np.array_equal(read_depth_png(f.name), arr)
+    with tempfile.NamedTemporaryFile(suffix=".png") as f:
+        Image.fromarray(rng.integers(0, 255, (8, 8, 3)).astype(np.uint8)).save(f.name)
+        with pytest.raises(ValueError):
+            read_depth_png(f.name)
+
+
+def test_oracle_preprocessing_on_the_real_frame(oracle):
+    """CPU: the oracle's back-projection / voxel de-duplication / normals on real depth (what the device path is held to below)"""
+    from cppf_amd.frames import NOCS_INTRINSICS
+    from cppf_amd.utils.util import read_depth_png
+    depth = read_depth_png(DEPTH)
+    sizes = []
+    for cat, m in instances(depth):
+        pts, (rows, cols) = oracle.backproject(depth, NOCS_INTRINSICS, m)
+        assert pts.shape[0] == int((m & (depth > 0)).sum()) and np.all(depth[rows, cols] > 0)
+        pc = pts / 1000
+        pc[:, 0] = -pc[:, 0]
+        pc[:, 1] = -pc[:, 1]
+        keep = oracle.voxel_dedupe(pc.astype(np.float32), 4e-3 if cat != "laptop" else 1e-2)
+        sizes.append(len(keep))
+        assert 0.3 < pc[:, 2].mean() < 1.5 and len(keep) <= pts.shape[0]
+    assert min(sizes) > 150 and max(sizes) < 20000, sizes
+
+
+@pytest.mark.gpu
+def test_real_frame_preprocessing_equals_oracle_and_poses_are_sane(oracle, dev):
+    import torch
+    from cppf_amd import training
+    from cppf_amd.config import CATEGORIES
+    from cppf_amd.frames import NOCS_INTRINSICS, frame_poses, instance_cloud
+    from cppf_amd.utils.util import read_depth_png
+    depth = read_depth_png(DEPTH)
+    inst = instances(depth)
+    d_dev = torch.from_numpy(depth.view(np.int16)).to(dev)
+    # ---- device pre-processing == oracle, instance by instance, on the real data
+    for cat, m in inst:
+        cfg = CATEGORIES[cat]
+        pc, nrm = instance_cloud(d_dev, NOCS_INTRINSICS, m, cfg)
+        pts, _ = oracle.backproject(depth, NOCS_INTRINSICS, m)
+        p = pts / 1000.0
+        p = np.stack([-p[:, 0], -p[:, 1], p[:, 2]], -1)
+        keep = oracle.voxel_dedupe(p.astype(np.float32), cfg.res)
+        want = p[keep].astype(np.float32)
+        assert np.array_equal(pc.cpu().numpy(), want), cat
+        assert np.array_equal(nrm.cpu().numpy(), oracle.estimate_normals(want, oracle.knn(want, cfg.knn))), cat
+    # ---- the whole loop with trained networks (synthetic training: bottle weights stand in for can / bowl)
+    nets = {}
+    for cat, src in (("mug", "mug"), ("laptop", "laptop"), ("bowl", "bottle"), ("can", "bottle")):
+        penc, enc = training.load_weights(os.path.join(GOLDEN, f"trained_{src}.npz"), CATEGORIES[src], dev)
+        nets[cat] = (enc, penc)
+    encs = {c: v[0] for c, v in nets.items()}
+    pencs = {c: v[1] for c, v in nets.items()}
+    poses = frame_poses(depth, inst, encs, pencs, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    poses = frame_poses(depth, inst, encs, pencs, device=dev)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / len(inst) * 1e3
+    print(f"real frame: {len(inst)} instances, {ms:.2f} ms per instance incl. pre-processing (eager, one at a time)")
+    for (cat, m), pose in zip(inst, poses):
+        assert pose is not None and pose["n_surv"] > 0 and np.all(np.isfinite(pose["T"])) and np.all(np.isfinite(pose["scale"]))
+        cfg = CATEGORIES[cat]
+        pc, _ = instance_cloud(d_dev, NOCS_INTRINSICS, m, cfg)
+        lo, hi = pc.min(0).values.cpu().numpy(), pc.max(0).values.cpu().numpy()
+        assert np.all(pose["T"] >= lo - cfg.res) and np.all(pose["T"] <= hi + cfg.res)          # the centre is a grid cell of the cloud's box
+        assert abs(np.linalg.norm(pose["up"]) - 1) < 1e-6 and 0.02 < pose["scale_norm"] < 1.5
+    # the front mug (a real mug seen by a real sensor, network trained on synthetic cylinders with a handle): the voted centre
+    # falls inside the mug -- within its radius of the cloud's centroid axis -- and its size comes out as a mug's
+    pc, _ = instance_cloud(d_dev, NOCS_INTRINSICS, inst[0][1], CATEGORIES["mug"])
+    c = pc.mean(0).cpu().numpy()
+    assert np.linalg.norm(poses[0]["T"] - c) < 0.08, (poses[0]["T"], c)
+    assert 0.05 < poses[0]["scale_norm"] < 0.4
