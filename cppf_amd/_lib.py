@@ -23,7 +23,6 @@ _SIGS = {
     "cppf_grid_from_raw": (C.c_int, [vp, i64, vp, vp, vp, vp, vp, sz, vp]),
     "cppf_vote_tiles": (C.c_int, [i32, i32, i32]),
     "cppf_vote_tile_cells": (C.c_int, []),
-    "cppf_vote_workspace_bytes_dyn": (sz, [i32]),
     "cppf_vote_workspace_bytes_dyn_pairs": (sz, [i32, i64]),
     "cppf_vote_workspace_init_bytes": (sz, []),
     "cppf_vote_plan_query": (C.c_int, [i64, i32, i32, i32, i32, vp]),

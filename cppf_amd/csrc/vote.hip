@@ -48,77 +48,14 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 static inline int tri(int n) { return n * (n + 1) / 2; }
 
 // ----------------------------------------------------------------------------- vote plan
-#define VOTE_TILE_FLOATS 28960  // 113 KiB of the CU's 160 KiB LDS for the grid tile (8 KiB rings, 8 KiB carry log, 8 KiB pair queues, 1.5 KiB arc-mask table, 21 KiB rotation table)
-#define VOTE_TAB_LDS_MAX 2628   // (cos,sin) pairs kept in LDS (n_rots <= 72); else computed per sample
+// ONE tiled implementation serves every n_rots (1..360) and every grid of up to 64 LDS tiles: v3_bin_kernel / v3_vote_kernel /
+// v3_reduce_kernel further down (round 4 removed round 2's vote_kernel / reduce_tiles_kernel, which had survived for n_rots > 72);
+// beyond 64 tiles -- none of the reference's categories -- vote_global_kernel restates the reference's own kernel with global
+// fp32 atomics.  The plan (tiling, workgroups, fixed-point bits) is a pure function of (n_ppfs, n_rots, grid dims): host code
+// evaluates it for a by-value launch, the *_dyn kernels evaluate the SAME functions on the device from a dims record.
+#define VOTE_TAB_LDS_MAX 2628   // (cos,sin) pairs kept in LDS: the triangular table of n_rots <= 72; more rotations: see WIDE
 #define VOTE_MAX_TILES 64       // beyond this the grid goes to global atomics (measured: 32 tiles still beat them 4-9x)
-#define VOTE_THREADS 1024
-#define VOTE_WGS_FEW 256        // workgroups of a launch with < 4 tiles (one per CU)
-#define VOTE_WGS_MANY 2048      // ... with >= 4 tiles: the hardware scheduler balances the peak tiles
-
-// The plan is a pure function of (n_ppfs, n_rots, grid dims): host code evaluates it for a launch with by-value
-// dims, the *_dyn kernels evaluate the SAME function on the device from a dims record in memory (one captured
-// graph then serves every instance shape up to its capacities, with results identical to the by-value launch).
-struct VoteTiling {
-    int tx, ty;       // tile extent in x and y (z is never cut)
-    int ntx, nty, T;  // tiles per axis, total (T = 1 << 30: no decomposition fits)
-};
-
-// Fewest tiles first; among the decompositions with that many, the one with the least cut area between tiles: a vote
-// circle is a curve, and the number of tiles a curve passes through grows with the area of the cuts it can cross.  (The
-// first decomposition found used to win: 7x76x52 slabs for the 52x152x52 grid of BASELINE config 5, which a pair's circle
-// visits 10.2 times on average where 26x19x52 tiles are visited 5.3 times; 13x76x26 instead of 26x38x26 for config 2:
-// scratch/cull_estimate3.py.)
-__host__ __device__ inline VoteTiling vote_tiling(int gx, int gy, int gz)
-{
-    VoteTiling p = {0, 0, 0, 0, 1 << 30};
-    int64_t best_cut = 0;
-    if ((int64_t)gz <= VOTE_TILE_FLOATS) {
-        for (int nty = 1; nty <= gy; ++nty) {
-            int ty = (gy + nty - 1) / nty;
-            if ((int64_t)ty * gz > VOTE_TILE_FLOATS) continue;
-            int txmax = (int)(VOTE_TILE_FLOATS / ((int64_t)ty * gz));
-            if (txmax > gx) txmax = gx;
-            int ntx = (gx + txmax - 1) / txmax;
-            int tx = (gx + ntx - 1) / ntx;
-            const int nty_eff = (gy + ty - 1) / ty;
-            int T = ntx * nty_eff;
-            const int64_t cut = ((int64_t)(ntx - 1) * gy + (int64_t)(nty_eff - 1) * gx) * gz;
-            if (T < p.T || (T == p.T && cut < best_cut)) {
-                p.T = T; p.tx = tx; p.ty = ty; p.ntx = ntx; p.nty = nty_eff;
-                best_cut = cut;
-            }
-            if (ntx == 1) break;  // more y cuts can only add tiles
-        }
-    }
-    return p;
-}
-
-// one workgroup per CU (tile ~115 KiB): T*chunks ~ 256 workgroups, chunks of >= 1024 pairs.  With many tiles the
-// votes pile up in the few tiles around the peak, so the chunks are made 8x smaller and the hardware scheduler
-// balances ~2 000 workgroups over the CUs (measured 2.4x on a 14-tile grid with a sharp peak).
-// Every workgroup pays for zeroing and dumping a tile (and its share of the reduce), so the many-tile class takes only as many as
-// the balance needs: 512 up to 8 tiles, 1 024 / 2 048 beyond by the number of pairs (sweep on 5..32-tile grids after the rotated
-// workgroup -> tile mapping went in: with 2 048 workgroups a 5-tile grid took 163 us on uniform-bin inputs, 86 us with 512).
-__host__ __device__ inline int vote_wgs(int64_t n_ppfs, int T)
-{
-    if (T < 4) return VOTE_WGS_FEW;
-    if (T <= 8) return 512;
-    return n_ppfs >= (1 << 20) ? VOTE_WGS_MANY : 1024;
-}
-__host__ __device__ inline int vote_chunks(int64_t n_ppfs, int T, int64_t* chunk_pairs)
-{
-    int64_t c = vote_wgs(n_ppfs, T) / T;
-    int64_t cmax = (n_ppfs + 1023) / 1024;
-    if (c > cmax) c = cmax;
-    if (c < 1) c = 1;
-    *chunk_pairs = (n_ppfs + c - 1) / c;
-    return (int)c;
-}
-
-// Partial grids are TILE-MAJOR: partial c = T slots of `slot` floats (the largest tile's cells rounded up to 4), slot t =
-// the tile in its LDS order (x, y, z within the tile).  A workgroup dumps its tile with aligned 16-byte stores and the
-// reduce kernel reads every chunk's copy of a tile with aligned 16-byte loads.
-__host__ __device__ inline int vote_slot_floats(const VoteTiling& t, int gz) { return (t.tx * t.ty * gz + 3) & ~3; }
+#define VOTE_WIN 72             // rotations of a pair one launch serves (the arc masks are 96-bit words): n_rots > 72 takes ceil(n_rots / 72) passes
 
 // fixed-point bits of the largest weight: a workgroup deposits at most chunk_pairs*n_rots*(2^kk + 4) in
 // total, and every 2^32 of that is one carry-log entry (VOTE_CARRY_CAP of them)
@@ -132,15 +69,13 @@ __host__ __device__ inline int vote_fixed_bits_of(int64_t chunk_pairs, int n_rot
 
 // Workspace layout: [0, 256) arg-max keys and tickets; [256, VOTE_WS_PART) the (cos, sin) rotation table of the LAST launch
 // that used this workspace, stamped with its n_rots at byte 248 -- building the table (2 628 fp64 sincos for 72 rotations)
-// cost every workgroup ~5 us of its prologue, so the first launch on a workspace builds it in LDS as before and workgroup 0
+// cost every workgroup ~5 us of its prologue, so the first launch on a workspace builds it in LDS and workgroup 0
 // also leaves a copy here; later launches with the same n_rots find the stamp and load the 21 KB instead.  Nothing is kept
-// outside the caller's workspace.  [VOTE_WS_PART, ...) the partial grids.
+// outside the caller's workspace.  [VOTE_WS_PART, VOTE_WS_PART + VOTE_WS_V3_STATE): the queue header and the extra plane (V3Hdr);
+// behind them the tile queues and the partial tiles.
 #define VOTE_WS_TAB 256
 #define VOTE_WS_PART (256 + ((VOTE_TAB_LDS_MAX + 2) * 8 + 255) / 256 * 256)
-// [VOTE_WS_PART, VOTE_WS_PART + VOTE_WS_V3_STATE): the binned path's state between calls (queue header + carry plane, see V3Hdr);
-// the round-2 kernels' partial grids start behind it, so a call that takes them (n_rots > 72, an empty pair list) leaves it intact
 #define VOTE_WS_V3_STATE (8704 + 64 * 30720 * 8)
-#define VOTE_WS_LEGACY_PART (VOTE_WS_PART + VOTE_WS_V3_STATE)
 #define VOTE_TAB_STAMP 0x43505046726f7400ull   // "CPPFrot\0" ^ n_rots: table valid
 // The launch that builds the table must not be able to read it back: workgroups of that same launch that start late
 // (more workgroups than the chip holds at once) would see workgroup 0's stamp without any guarantee of seeing its table
@@ -148,147 +83,43 @@ __host__ __device__ inline int vote_fixed_bits_of(int64_t chunk_pairs, int n_rot
 // that follows it -- a kernel boundary later -- turns it into the valid one.
 #define VOTE_TAB_PENDING 0x43505046726f5000ull
 
-struct VotePlan {
-    int tiled;            // 1: LDS tiles + partial grids, 0: global atomics
-    int tx, ty;           // tile extent in x and y (z is never cut)
-    int ntx, nty, T;      // tiles per axis, total
-    int chunks;           // pair chunks (= partial grids)
-    int64_t chunk_pairs;  // pairs per chunk
-    size_t packed_off, part_off, total;
-    int tab_entries;
-};
-
-static VotePlan make_vote_plan(int64_t n_ppfs, int n_rots, int gx, int gy, int gz)
-{
-    VotePlan p = {};
-    int64_t G = (int64_t)gx * gy * gz;
-    p.tab_entries = tri(n_rots);
-    const VoteTiling t = vote_tiling(gx, gy, gz);
-    p.tx = t.tx; p.ty = t.ty; p.ntx = t.ntx; p.nty = t.nty;
-    p.tiled = t.T <= VOTE_MAX_TILES && n_ppfs > 0;
-    p.T = p.tiled ? t.T : 1;
-    if (p.tiled) {
-        p.chunks = vote_chunks(n_ppfs, p.T, &p.chunk_pairs);
-    } else {
-        p.chunks = 0;
-        p.chunk_pairs = 0;
-    }
-    p.packed_off = 0;   // u64 packed arg-max key + u32 ticket counter
-    p.part_off = VOTE_WS_LEGACY_PART;
-    p.total = p.tiled ? p.part_off + (size_t)p.chunks * (size_t)p.T * vote_slot_floats(t, gz) * sizeof(float)
-                      : (size_t)VOTE_WS_PART;   // global atomics: the arg-max keys and the rotation table only
-    (void)G;
-    return p;
-}
-
-static int vote_fixed_bits(const VotePlan& pl, int n_rots)
-{
-    if (!pl.tiled) return 0;
-    return vote_fixed_bits_of(pl.chunk_pairs, n_rots);
-}
-
 static int v3_fixed_bits_bound(int64_t n_ppfs, int n_rots, int gx, int gy, int gz);
-static bool v3_eligible(int64_t n_ppfs, int n_rots, int gx, int gy, int gz);
-// fixed-point bits of the largest weight in the tiled vote of this launch: exact for < 4 tiles and for the round-2 kernels; a LOWER
-// bound for the binned path, whose scale follows the queues' lengths (a finer quantum than reported, never a coarser one)
-extern "C" int cppf_vote_fixed_point_bits(int64_t n_ppfs, int n_rots, int gx, int gy, int gz)
-{
-    if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || gx < 1 || gy < 1 || gz < 1 || n_ppfs < 0) return -1;
-    if (v3_eligible(n_ppfs, n_rots, gx, gy, gz)) return v3_fixed_bits_bound(n_ppfs, n_rots, gx, gy, gz);
-    return vote_fixed_bits(make_vote_plan(n_ppfs, n_rots, gx, gy, gz), n_rots);
-}
-
-// any plan a *_dyn launch can meet writes chunks * G <= workgroups * VOTE_TILE_FLOATS partial cells (G <= T * tile)
-extern "C" size_t cppf_vote_workspace_bytes_dyn(int many_tiles)
-{
-    return VOTE_WS_LEGACY_PART + (size_t)(many_tiles ? VOTE_WGS_MANY : VOTE_WGS_FEW) * VOTE_TILE_FLOATS * sizeof(float);
-}
-
 static bool v3_eligible(int64_t n_ppfs, int n_rots, int gx, int gy, int gz);
 static size_t v3_workspace_bytes(int64_t n_ppfs, int gx, int gy, int gz);
 static size_t v3_workspace_bytes_dyn(int many_tiles, int64_t n_ppfs);
+// fixed-point bits of the largest weight in the tiled vote of this launch: exact for < 4 tiles; a LOWER bound for the binned path,
+// whose scale follows the queues' lengths (a finer quantum than reported, never a coarser one); 0: global fp32 atomics, no quantisation
+extern "C" int cppf_vote_fixed_point_bits(int64_t n_ppfs, int n_rots, int gx, int gy, int gz)
+{
+    if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || gx < 1 || gy < 1 || gz < 1 || n_ppfs < 0) return -1;
+    return v3_eligible(n_ppfs, n_rots, gx, gy, gz) ? v3_fixed_bits_bound(n_ppfs, n_rots, gx, gy, gz) : 0;
+}
+
 extern "C" size_t cppf_vote_workspace_bytes(int64_t n_ppfs, int n_rots, int gx, int gy, int gz)
 {
     if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || gx < 1 || gy < 1 || gz < 1 || n_ppfs < 0) return 0;
-    const size_t legacy = make_vote_plan(n_ppfs, n_rots, gx, gy, gz).total;
-    if (!v3_eligible(n_ppfs, n_rots, gx, gy, gz)) return legacy;
-    const size_t v3 = v3_workspace_bytes(n_ppfs, gx, gy, gz);
-    return v3 > legacy ? v3 : legacy;
+    // (global-atomics path and empty pair lists: the arg-max keys only -- but never less than the state a later tiled call on the same
+    // allocation would need to find zeroed, so that one allocation sized for its largest call is always valid)
+    if (!v3_eligible(n_ppfs, n_rots, gx, gy, gz)) return cppf_vote_workspace_init_bytes();
+    return v3_workspace_bytes(n_ppfs, gx, gy, gz);
 }
-// the *_dyn launch with room for the pair -> tile queues of the binned path (n_ppfs pairs, every tile of the class); a
-// workspace of only cppf_vote_workspace_bytes_dyn() bytes selects the round-2 kernels
+// the *_dyn launch: room for the pair -> tile queues (n_ppfs pairs, every tile of the class) and one partial tile per workgroup
 extern "C" size_t cppf_vote_workspace_bytes_dyn_pairs(int many_tiles, int64_t n_ppfs)
 {
     if (n_ppfs < 0) return 0;
-    const size_t legacy = cppf_vote_workspace_bytes_dyn(many_tiles), v3 = v3_workspace_bytes_dyn(many_tiles, n_ppfs);
-    return v3 > legacy ? v3 : legacy;
+    return v3_workspace_bytes_dyn(many_tiles, n_ppfs);
 }
-
 // ----------------------------------------------------------------------------- centre vote
 // Reference: CUDA ppf_voting, models/voting.py:8-66.
-// TILED: the workgroup owns grid tile (x0..x0+tx, y0..y0+ty, all z) in LDS and pair chunk c; every
-// corner of every vote that falls into the tile is accumulated there; the tile is then stored to
-// partial grid c.  Cells belong to exactly one tile, so a partial grid is written exactly once.
-// !TILED: global_atomic_add_f32 straight into grid_obj (large grids).
-//
-// LDS accumulation is 32-bit FIXED POINT: on gfx950 ds_add_f32 costs ~195 cycles per wave
-// instruction (3 cycles/lane, any address pattern) while ds_add_rtn_u32 costs ~22
-// (profiles/microbench/atomics_bench.hip).  A weight w is deposited as rn(w * S), S = 2^kk / p2 with
-// p2 = max(probs) rounded up to a power of two and kk <= 24 chosen by the host so that the number of
-// 32-bit wrap-arounds a workgroup can produce fits the carry log; a wrap-around (detected on the
-// returned old value) appends the cell to that log and is added back as 2^32/S when the tile is
-// converted to fp32.  With kk = 24 the quantum is 2^-24 of the largest weight: each deposit is
-// exact to fp32 precision and the sum is order-independent, i.e. at least as accurate as any order
-// of the reference's fp32 atomicAdd.  Negative / non-finite probs fall back to ds_add_f32.
-//
-// Two stages per wave, decoupled by a 256-entry ring of 16-bit codes in LDS so that the expensive
-// stage always runs with full lanes (a plain one-pair-per-lane loop executes the union of all lanes'
-// branches):
-//   screen  one pair per lane, rotations in a loop, everything pre-scaled by ~1/res:
-//           q = cq + cos*xq + sin*yq against the tile's acceptance box widened by more than the
-//           approximation error (no sample the exact test accepts is ever dropped); survivors push
-//           (lane, rotation) to the ring in ballot order;
-//   deposit whenever the ring holds >= 64 codes every lane pops one, pulls the owning lane's pair
-//           frame with ds_bpermute, and does the exact work of the reference: offset, the three
-//           correctly rounded divisions, the bound tests, trilinear weights, 8 atomics.
-#define VOTE_RING 256  // >= 63 queued + 128 pushed per trip
+// LDS accumulation is 32-bit FIXED POINT: on gfx950 ds_add_f32 costs ~195 cycles per wave instruction (3 cycles/lane, any address
+// pattern) while ds_add_rtn_u32 costs ~22 (profiles/microbench/atomics_bench.hip).  A weight w is deposited as rn(w * S),
+// S = 2^kk / p2 with p2 = max(probs) rounded up to a power of two and kk <= 24 chosen so that the number of 32-bit wrap-arounds a
+// workgroup can produce fits the carry log; a wrap-around (detected on the returned old value) appends the cell to that log and
+// is added back as 2^32 quanta when the tile is reduced.  With kk = 24 the quantum is 2^-24 of the largest weight: each deposit
+// is exact to fp32 precision and the sum is order-independent, i.e. at least as accurate as any order of the reference's fp32
+// atomicAdd.  Negative / non-finite probs fall back to ds_add_f32.
 #define VOTE_PAIRQ 128  // per-wave queue of culled pair offsets: <= 63 waiting + 64 pushed
 #define VOTE_CARRY_CAP 2048
-struct VoteArgs {
-    const float* points;
-    const float* outputs;
-    const float* probs;
-    const void* point_idxs;  // i32[P,2] or i64[P,2] (idx64)
-    int idx64;
-    float* grid;       // !TILED target
-    float* partials;   // TILED target [chunks][T][slot], see vote_slot_floats
-    const float* corner;
-    unsigned long long* packed;  // arg-max key + ticket, zeroed here for the reduce kernel
-    float res;
-    int64_t n_ppfs, n_points;
-    int n_rots, gx, gy, gz, adaptive;
-    int tx, ty, ntx, nty, T;
-    int64_t chunk_pairs;
-    int tab_entries;
-    int kk;            // fixed-point bits of the largest weight
-    // *_dyn launches: {n_points, gx, gy, gz} in device memory; the by-value n_points / T / grid_cap are then CAPACITIES
-    // (n_points bounds the probs scan, T the tile count this launch geometry serves, grid_cap the cells of grid_obj)
-    const int32_t* shape;
-    int64_t grid_cap;
-};
-
-struct VoteTile {
-    float* tile;   // LDS tile (TILED) or grid_obj (!TILED)
-    uint32_t* carry_log;
-    int* carry_n;
-    int x0, y0, tx, ty, gz, ltyz, syz;
-    float res, S;  // S > 0: fixed-point scale; S == 0: fp32 atomics
-    float rres;    // 1/res refined the way the IEEE division sequence refines it, see div_by()
-    int dummy;     // index (relative to `tile`, in words) of this lane's two dummy words: the target of out-of-tile corners
-    int unit_probs;  // every prob is exactly 1.0f (all the reference's callers, nocs/inference.py:201): w * 1.0f == w
-    float lo, hx, hy, hz;  // fp32 thresholds equivalent to the reference's fp64 tests
-};
-
 // floor(x + 0.5) evaluated exactly, one instruction (x in [0, 2^24]: checked exhaustively, profiles/r2_div_check.txt); the
 // fixed-point deposit's rounding (ties go up; any nearest rounding keeps the half-quantum error bound)
 __device__ __forceinline__ uint32_t rpi_u32(float x)
@@ -304,121 +135,6 @@ __device__ __forceinline__ float ceil_to_float(double d)
     float f = (float)d;
     if ((double)f < d) f = __uint_as_float(__float_as_uint(f) + (f > 0.f ? 1u : -1u));
     return f;
-}
-
-template <bool TILED>
-__device__ __forceinline__ void vote_deposit(const VoteTile& T, f3 v, float prob)
-{
-    const f3 g = {div_by(v.x, T.res, T.rres), div_by(v.y, T.res, T.rres), div_by(v.z, T.res, T.rres)};   // :35
-    if (g.x < T.lo || g.y < T.lo || g.z < T.lo || g.x >= T.hx || g.y >= T.hy || g.z >= T.hz)
-        return;                                                    // :36-39, fp64 tests folded to fp32 thresholds
-    const int fx = (int)g.x, fy = (int)g.y, fz = (int)g.z;         // :40
-    // g - floorf(g) for g >= 0.01: the difference is exact, which is what v_fract_f32 returns
-    const float rx = __builtin_amdgcn_fractf(g.x), ry = __builtin_amdgcn_fractf(g.y), rz = __builtin_amdgcn_fractf(g.z);
-    const float w0x = 1.f - rx, w0y = 1.f - ry, w0z = 1.f - rz;
-    if (TILED && T.S > 0.f) {
-        // Fixed point: inc = rn(weight * S), S a power of two, so S can ride on the last factor:
-        // rn((ll * w0z) * (prob * S)) == rn((ll * w0z) * prob) * S, and with unit probs rn(ll * (w0z * S)) == rn(ll * w0z) * S.
-        // All eight accumulations are issued back to back and waited for once (a returning LDS atomic is ~100 cycles away).
-        // A corner outside the tile is not branched around: its x or y factor is zeroed (the increment becomes 0) and its
-        // address is the lane's own pair of dummy words.
-        const int lx = fx - T.x0, ly = fy - T.y0;
-        const bool x0in = (unsigned)lx < (unsigned)T.tx, x1in = (unsigned)(lx + 1) < (unsigned)T.tx;
-        const bool y0in = (unsigned)ly < (unsigned)T.ty, y1in = (unsigned)(ly + 1) < (unsigned)T.ty;
-        const float ax0 = x0in ? w0x : 0.f, ax1 = x1in ? rx : 0.f, ay0 = y0in ? w0y : 0.f, ay1 = y1in ? ry : 0.f;
-        const float ll = ax0 * ay0, lh = ax0 * ay1, hl = ax1 * ay0, hh = ax1 * ay1;
-        float lll, llh, lhl, lhh, hll, hlh, hhl, hhh;
-        if (T.unit_probs) {
-            const float z0 = w0z * T.S, z1 = rz * T.S;
-            lll = ll * z0; llh = ll * z1; lhl = lh * z0; lhh = lh * z1;
-            hll = hl * z0; hlh = hl * z1; hhl = hh * z0; hhh = hh * z1;
-        } else {
-            const float ps = prob * T.S;
-            lll = ll * w0z * ps; llh = ll * rz * ps; lhl = lh * w0z * ps; lhh = lh * rz * ps;
-            hll = hl * w0z * ps; hlh = hl * rz * ps; hhl = hh * w0z * ps; hhh = hh * rz * ps;
-        }
-        const int b = __mul24(lx, T.ltyz) + (__mul24(ly, T.gz) + fz);   // all |.| < 2^23: two v_mad_i32_i24
-        const int dm = T.dummy;
-        const int a0 = (x0in && y0in) ? b : dm, a2 = (x0in && y1in) ? b + T.gz : dm;
-        const int a4 = (x1in && y0in) ? b + T.ltyz : dm, a6 = (x1in && y1in) ? b + T.ltyz + T.gz : dm;
-        uint32_t* tu = reinterpret_cast<uint32_t*>(T.tile);
-        const uint32_t i0 = rpi_u32(lll), i1 = rpi_u32(llh), i2 = rpi_u32(lhl), i3 = rpi_u32(lhh);
-        const uint32_t i4 = rpi_u32(hll), i5 = rpi_u32(hlh), i6 = rpi_u32(hhl), i7 = rpi_u32(hhh);
-        const uint32_t o0 = atomicAdd(tu + a0, i0), o1 = atomicAdd(tu + a0 + 1, i1), o2 = atomicAdd(tu + a2, i2),
-                       o3 = atomicAdd(tu + a2 + 1, i3), o4 = atomicAdd(tu + a4, i4), o5 = atomicAdd(tu + a4 + 1, i5),
-                       o6 = atomicAdd(tu + a6, i6), o7 = atomicAdd(tu + a6 + 1, i7);
-        // a wrap needs old >= 2^32 - inc with inc <= 2^24: one compare of the largest old value screens all eight
-        const uint32_t om = max(max(max(o0, o1), max(o2, o3)), max(max(o4, o5), max(o6, o7)));
-        if (om >= 0xfe000000u) {
-            auto wrapped = [&](uint32_t o, uint32_t inc, int a) {   // remember the cell, 2^32/S is added back at the flush
-                if (o + inc < o) {
-                    const int slot = atomicAdd(T.carry_n, 1);
-                    if (slot < VOTE_CARRY_CAP) T.carry_log[slot] = (uint32_t)a;
-                }
-            };
-            wrapped(o0, i0, a0); wrapped(o1, i1, a0 + 1); wrapped(o2, i2, a2); wrapped(o3, i3, a2 + 1);
-            wrapped(o4, i4, a4); wrapped(o5, i5, a4 + 1); wrapped(o6, i6, a6); wrapped(o7, i7, a6 + 1);
-        }
-        return;
-    }
-    const float ll = w0x * w0y, lh = w0x * ry, hl = rx * w0y, hh = rx * ry;
-    const float lll = ll * w0z * prob, llh = ll * rz * prob, lhl = lh * w0z * prob, lhh = lh * rz * prob;
-    const float hll = hl * w0z * prob, hlh = hl * rz * prob, hhl = hh * w0z * prob, hhh = hh * rz * prob;
-    if (TILED) {
-        const int lx = fx - T.x0, ly = fy - T.y0;
-        const bool x0in = (unsigned)lx < (unsigned)T.tx, x1in = (unsigned)(lx + 1) < (unsigned)T.tx;
-        const bool y0in = (unsigned)ly < (unsigned)T.ty, y1in = (unsigned)(ly + 1) < (unsigned)T.ty;
-        const int b = (lx * T.ty + ly) * T.gz + fz;
-        float* t = T.tile + b;
-        if (x0in & y0in) { atomicAdd(t, lll); atomicAdd(t + 1, llh); }
-        if (x0in & y1in) { atomicAdd(t + T.gz, lhl); atomicAdd(t + T.gz + 1, lhh); }
-        if (x1in & y0in) { atomicAdd(t + T.ltyz, hll); atomicAdd(t + T.ltyz + 1, hlh); }
-        if (x1in & y1in) { atomicAdd(t + T.ltyz + T.gz, hhl); atomicAdd(t + T.ltyz + T.gz + 1, hhh); }
-    } else {
-        float* b = T.tile + ((int64_t)fx * T.syz + fy * T.gz + fz);
-        atomicAdd(b, lll);
-        atomicAdd(b + 1, llh);
-        atomicAdd(b + T.gz, lhl);
-        atomicAdd(b + T.gz + 1, lhh);
-        atomicAdd(b + T.syz, hll);
-        atomicAdd(b + T.syz + 1, hlh);
-        atomicAdd(b + T.syz + T.gz, hhl);
-        atomicAdd(b + T.syz + T.gz + 1, hhh);
-    }
-}
-
-__device__ __forceinline__ int2 vote_pair_idx(const VoteArgs& A, int64_t p)
-{
-    if (A.idx64) {
-        const longlong2 v = reinterpret_cast<const longlong2*>(A.point_idxs)[p];
-        return make_int2((int)v.x, (int)v.y);
-    }
-    return reinterpret_cast<const int2*>(A.point_idxs)[p];
-}
-
-// one pair frame per lane, pulled across lanes by the deposit stage
-struct PairFrame { f3 cc, x, y; float prob; int n; };   // (n: rotation count; the pop pulls n*(n-1)/2, the table row)
-
-template <bool TILED, bool TAB_LDS>
-__device__ __forceinline__ void vote_pop(const VoteTile& VT, const PairFrame& F, const f3 cr, const float2* ltab,
-                                         const uint16_t* ring, int qhead, int lane, int count)
-{
-    // all 64 lanes execute the pulls (an inactive source lane would read as 0); only `count` deposit
-    const unsigned code = ring[(qhead + lane) & (VOTE_RING - 1)];
-    const int src = (int)(code & 63u), i = (int)(code >> 6);
-    f3 cc, x, y;
-    cc.x = __shfl(F.cc.x, src, 64); cc.y = __shfl(F.cc.y, src, 64); cc.z = __shfl(F.cc.z, src, 64);
-    x.x = __shfl(F.x.x, src, 64); x.y = __shfl(F.x.y, src, 64); x.z = __shfl(F.x.z, src, 64);
-    y.x = __shfl(F.y.x, src, 64); y.y = __shfl(F.y.y, src, 64); y.z = __shfl(F.y.z, src, 64);
-    const float prob = VT.unit_probs ? 1.0f : __shfl(F.prob, src, 64);
-    // TAB_LDS: the source lane's table row n*(n-1)/2 (computed once per pair), else n itself
-    const int n = __shfl(TAB_LDS ? __mul24(F.n, F.n - 1) >> 1 : F.n, src, 64);
-    if (lane < count) {
-        const float2 cs = TAB_LDS ? ltab[n + i] : rot_cs(i, n);
-        const f3 offset = add3(scl3(x, cs.x), scl3(y, cs.y));      // :34
-        const f3 v = sub3(add3(cc, offset), cr);                   // numerator of :35
-        vote_deposit<TILED>(VT, v, prob);
-    }
 }
 
 // ----------------------------------------------------------------------------- arc screen
@@ -468,8 +184,12 @@ __device__ __forceinline__ float acos_approx(float u)   // u in [-1, 1]; |error|
 
 struct Mask96 { uint32_t a, b, c; };
 
-// bits of the cyclic index run [ia, ib] (mod n) -- all of [0, n) when it has n or more members, none when ib < ia
-__device__ __forceinline__ Mask96 arc_run(const uint4* __restrict__ below, int ia, int ib, int n)
+// bits of the cyclic index run [ia, ib] (mod n) -- all of [0, n) when it has n or more members, none when ib < ia.
+// WIDE (n_rots > 72: a pair has up to 360 rotations, a launch serves the WINDOW [win_base, win_base + 72) of them, see v3_launch):
+// the caller has shifted the run by -win_base, bit k stands for rotation win_base + k, and only the first L = min(n - win_base, 72)
+// bits exist -- the run, still cyclic mod n, is clipped to [0, L).
+template <bool WIDE = false>
+__device__ __forceinline__ Mask96 arc_run(const uint4* __restrict__ below, int ia, int ib, int n, int L = 0)
 {
     int len = ib - ia + 1;
     len = len < 0 ? 0 : len;
@@ -478,13 +198,24 @@ __device__ __forceinline__ Mask96 arc_run(const uint4* __restrict__ below, int i
     s0 = s0 >= n ? s0 - n : s0;
     s0 = full ? 0 : (s0 < 0 ? 0 : s0);
     const int e = full ? n : s0 + len;
+    if (WIDE) {
+        const uint4 B1 = below[min(e, L)], B0 = below[min(s0, L)], B2 = below[min(max(e - n, 0), L)];
+        return {(B1.x & ~B0.x) | B2.x, (B1.y & ~B0.y) | B2.y, (B1.z & ~B0.z) | B2.z};
+    }
     const uint4 B1 = below[e < n ? e : n], B0 = below[s0], B2 = below[e > n ? e - n : 0];
     return {(B1.x & ~B0.x) | B2.x, (B1.y & ~B0.y) | B2.y, (B1.z & ~B0.z) | B2.z};
 }
+// WIDE: the arc's centre in window-local index units, wrapped to (-n/2, n/2] like the unshifted one
+__device__ __forceinline__ float arc_shift(float f, int n, int win_base)
+{
+    const float g = f - (float)win_base;
+    return g <= -0.5f * (float)n ? g + (float)n : g;
+}
 
 // rotations i of n whose coordinate c + x cos(theta_i) + y sin(theta_i) can lie in [lo, hi]; nf = n / (2 pi)
+template <bool WIDE = false>
 __device__ __forceinline__ Mask96 axis_arc_mask(const uint4* __restrict__ below, float c, float x, float y, float lo, float hi,
-                                                float nf, int n)
+                                                float nf, int n, int win_base = 0, int L = 0)
 {
     const float A = __builtin_amdgcn_sqrtf(fmaf(x, x, y * y));
     const float rA = __builtin_amdgcn_rcpf(fmaxf(A, 1e-20f));
@@ -493,16 +224,17 @@ __device__ __forceinline__ Mask96 axis_arc_mask(const uint4* __restrict__ below,
     const bool none = !(u1 <= 1.f) || !(u2 >= -1.f);   // (NaN-safe: a NaN coordinate drops the pair like the exact test does)
     const float a1 = u1 <= -1.f ? 3.14159265f : acos_approx(fminf(u1, 1.f));
     const float a2 = u2 >= 1.f ? 0.f : acos_approx(fmaxf(u2, -1.f));
-    const float f = atan2_approx(y, x) * nf;
+    float f = atan2_approx(y, x) * nf;
+    if (WIDE) f = arc_shift(f, n, win_base);
     const float W1 = (a1 + 2e-3f) * nf, W2 = (a2 - 2e-3f) * nf;
-    const Mask96 O = arc_run(below, (int)ceilf(f - W1), (int)floorf(f + W1), n);
+    const Mask96 O = arc_run<WIDE>(below, (int)ceilf(f - W1), (int)floorf(f + W1), n, L);
     // excluded: the integers strictly inside (f - W2, f + W2)
-    const Mask96 I = arc_run(below, (int)floorf(f - W2) + 1, W2 > 0.f ? (int)ceilf(f + W2) - 1 : -(1 << 20), n);
+    const Mask96 I = arc_run<WIDE>(below, (int)floorf(f - W2) + 1, W2 > 0.f ? (int)ceilf(f + W2) - 1 : -(1 << 20), n, L);
     const uint32_t keep = none ? 0u : 0xffffffffu;
     return {O.a & ~I.a & keep, O.b & ~I.b & keep, O.c & ~I.c & keep};
 }
 
-// ----------------------------------------------------------------------------- run walk (see vote_kernel)
+// ----------------------------------------------------------------------------- run walk (see v3_vote_kernel)
 // index of the lowest set bit of the 96-bit word (a, b, c), 96 when it is empty (v_ffbl_b32 returns -1 for 0: the OR keeps it)
 __device__ __forceinline__ int ctz96(uint32_t a, uint32_t b, uint32_t c)
 {
@@ -542,431 +274,6 @@ __device__ __forceinline__ int wave_incl_scan(int v)
     v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
     return v;
-}
-
-template <bool TILED, bool TAB_LDS>
-__global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(VoteArgs A)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    // LDS: [rings: 16 waves x 256 x u16 = 8 KiB][carry log 8 KiB][pair queues: 16 x 128 x u32 = 8 KiB][ctrl 64 B]
-    //      [128 dummy words][arc-mask table 97 x 16 B][rotation table (+1 spare)][tile]
-    uint16_t* ring = reinterpret_cast<uint16_t*>(lds) + (threadIdx.x >> 6) * VOTE_RING;
-    uint32_t* carry_log = reinterpret_cast<uint32_t*>(lds) + (VOTE_THREADS / 64) * VOTE_RING / 2;
-    uint32_t* pairq = carry_log + VOTE_CARRY_CAP + (threadIdx.x >> 6) * VOTE_PAIRQ;
-    int* ctrl = reinterpret_cast<int*>(carry_log + VOTE_CARRY_CAP + (VOTE_THREADS / 64) * VOTE_PAIRQ);  // [0] carry count, [4] next block of 64 pairs
-    uint32_t* dummy = reinterpret_cast<uint32_t*>(ctrl + 16);   // 2 words per lane, see vote_deposit
-    uint4* below = reinterpret_cast<uint4*>(dummy + 128);   // arc-mask table, see axis_arc_mask
-    float2* ltab = reinterpret_cast<float2*>(below + VOTE_BELOW_N);
-    float* tile = reinterpret_cast<float*>(ltab + (TAB_LDS ? A.tab_entries + 2 : 0));  // +2: spare entry, 16-B alignment
-    const int tid = threadIdx.x, lane = tid & 63;
-    int gz = A.gz, gy = A.gy, gx = A.gx;
-    int pT = A.T, pnty = A.nty, ptx = A.tx, pty = A.ty, kk = A.kk;
-    int64_t chunk_pairs = A.chunk_pairs, n_points = A.n_points;
-    if (blockIdx.x == 0 && tid < 2 + 2 * 8) A.packed[tid] = 0ull;   // arg-max keys + tickets of the reduce kernel (root + 8 groups)
-    if (TILED && A.shape) {
-        // dims record in memory: the plan of make_vote_plan(), evaluated here (uniform, scalar unit).  A record that does
-        // not fit the launch's capacities stops every workgroup; reduce_argmax_kernel reports it (index -1).
-        n_points = A.shape[0]; gx = A.shape[1]; gy = A.shape[2]; gz = A.shape[3];
-        if (n_points < 1 || n_points > A.n_points || gx < 1 || gy < 1 || gz < 1 || (int64_t)gx * gy * gz > A.grid_cap) return;
-        const VoteTiling vt = vote_tiling(gx, gy, gz);
-        if (vt.T > A.T) return;
-        pT = vt.T; pnty = vt.nty; ptx = vt.tx; pty = vt.ty;
-        const int chunks = vote_chunks(A.n_ppfs, pT, &chunk_pairs);
-        kk = vote_fixed_bits_of(chunk_pairs, A.n_rots);
-        if ((int)blockIdx.x >= pT * chunks) return;
-    }
-
-    int t = 0, c = 0, x0 = 0, y0 = 0, tx = gx, ty = gy;
-    int64_t p_begin, p_end, p_step;
-    // Prologue, one barrier: the global loads (probs scan, rotation table) are issued first and land while the tile is
-    // being zeroed; every wave leaves its summary of the probs in its own words of LDS instead of meeting at an atomic.
-    // largest prob (weights are w * max(probs[a], probs[b]) <= max(probs)); any negative or non-finite value disables the
-    // fixed-point path for this workgroup
-    // (probs == null: all ones, what every caller of the reference passes, nocs/inference.py:201 -- no scan, no gathers)
-    float pm = A.probs ? 0.f : 1.f;
-    int bad = 0, nonunit = 0;
-    if (TILED && A.probs) {
-        for (int64_t k0 = tid; k0 < n_points; k0 += 4 * VOTE_THREADS) {   // four independent loads in flight per trip
-            float pv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) pv[u] = k0 + u * VOTE_THREADS < n_points ? A.probs[k0 + u * VOTE_THREADS] : 0.f;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool there = k0 + u * VOTE_THREADS < n_points;
-                bad |= !(pv[u] >= 0.f) || !(pv[u] < INFINITY);
-                nonunit |= there && pv[u] != 1.0f;
-                pm = fmaxf(pm, pv[u]);
-            }
-        }
-    }
-    // rotation table: from the workspace when the previous launch on it left one for this n_rots, else built below
-    float2* wtab = reinterpret_cast<float2*>(reinterpret_cast<char*>(A.packed) + VOTE_WS_TAB);
-    const bool tab_cached = TAB_LDS && A.packed[31] == (VOTE_TAB_STAMP ^ (unsigned long long)A.n_rots) &&
-                            rot_table_intact(wtab, A.n_rots);
-    float2 tab_in[(VOTE_TAB_LDS_MAX + VOTE_THREADS - 1) / VOTE_THREADS];
-    if (tab_cached) {
-#pragma unroll
-        for (int u = 0; u < (VOTE_TAB_LDS_MAX + VOTE_THREADS - 1) / VOTE_THREADS; ++u)
-            if (tid + u * VOTE_THREADS < A.tab_entries) tab_in[u] = wtab[tid + u * VOTE_THREADS];
-    }
-    if (tid < 16) ctrl[tid] = 0;
-    if (tid < 128) dummy[tid] = 0u;
-    if (TILED) {
-        // Workgroup b takes chunk c = b / T of tile (b + c) mod T -- not b mod T: workgroups go to XCD b mod 8 (and round the
-        // CUs of an XCD) in launch order, so with T = 16 every workgroup of a tile landed on the same XCD and the same few
-        // CUs, and the tiles around the vote peak, which hold most of the work, ran on a sixteenth of the chip (52x152x52 grid,
-        // known-answer inputs: 2.3 ms against 1.1 ms with the rotation; T = 17 or 18 never had the problem).
-        c = blockIdx.x / pT;
-        t = (blockIdx.x + c) % pT;
-        int tix = t / pnty, tiy = t % pnty;
-        x0 = tix * ptx;
-        y0 = tiy * pty;
-        tx = min(ptx, gx - x0);
-        ty = min(pty, gy - y0);
-        p_begin = (int64_t)c * chunk_pairs;
-        p_end = min((int64_t)(c + 1) * chunk_pairs, A.n_ppfs);
-        p_step = VOTE_THREADS;
-        const int nt4 = (tx * ty * gz + 3) >> 2;   // (the tile buffer is a multiple of 4 floats; the pad cells stay zero)
-        for (int k = tid; k < nt4; k += VOTE_THREADS) reinterpret_cast<uint4*>(tile)[k] = make_uint4(0u, 0u, 0u, 0u);  // +0.0f == 0u
-    } else {
-        p_begin = (int64_t)blockIdx.x * VOTE_THREADS;
-        p_end = A.n_ppfs;
-        p_step = (int64_t)gridDim.x * VOTE_THREADS;
-    }
-    if (tid < VOTE_BELOW_N) {
-        const int j = tid;
-        auto w = [](int c) { return c <= 0 ? 0u : (c >= 32 ? 0xffffffffu : ((1u << c) - 1u)); };
-        below[j] = make_uint4(w(j), w(j - 32), w(j - 64), 0u);
-    }
-    if (TAB_LDS) {
-        if (tab_cached) {
-#pragma unroll
-            for (int u = 0; u < (VOTE_TAB_LDS_MAX + VOTE_THREADS - 1) / VOTE_THREADS; ++u)
-                if (tid + u * VOTE_THREADS < A.tab_entries) ltab[tid + u * VOTE_THREADS] = tab_in[u];
-        } else {
-            fill_rot_table(ltab, A.tab_entries, tid, VOTE_THREADS);
-            if (blockIdx.x == 0) {   // leave a copy for the next launch (visible to it: kernel boundary)
-                __syncthreads();
-                for (int e = tid; e < A.tab_entries; e += VOTE_THREADS) wtab[e] = ltab[e];
-                if (tid == 0) A.packed[31] = VOTE_TAB_PENDING ^ (unsigned long long)A.n_rots;
-            }
-        }
-        if (tid < 2) ltab[A.tab_entries + tid] = make_float2(0.f, 0.f);  // spare entries
-    }
-    float S = 0.f;
-    int unit_probs = 0;
-    if (TILED) {
-        // the wave's summary goes to the first two words of its (still unused) candidate ring
-        for (int off = 32; off > 0; off >>= 1) pm = fmaxf(pm, __shfl_xor(pm, off, 64));
-        const int flags = (__any(bad) ? 1 : 0) | (__any(nonunit) ? 2 : 0);
-        if (lane == 0) { reinterpret_cast<float*>(ring)[0] = pm; reinterpret_cast<int*>(ring)[1] = flags; }
-    }
-    __syncthreads();
-    if (TILED) {
-        float pmax = 0.f;
-        int flags = 0;
-        for (int w = 0; w < VOTE_THREADS / 64; ++w) {
-            const uint16_t* rw = reinterpret_cast<const uint16_t*>(lds) + w * VOTE_RING;
-            pmax = fmaxf(pmax, reinterpret_cast<const float*>(rw)[0]);
-            flags |= reinterpret_cast<const int*>(rw)[1];
-        }
-        unit_probs = !(flags & 2);
-        if (!(flags & 1)) {
-            // p2 = pmax rounded up to a power of two (1 when pmax == 0); S = 2^kk / p2, exact
-            int e = 127;
-            if (pmax > 0.f) {
-                const unsigned bits = __float_as_uint(pmax);
-                e = (int)(bits >> 23) + ((bits & 0x7fffffu) ? 1 : 0);
-                if (e < 1) e = 1;  // subnormal pmax: treat as the smallest normal
-            }
-            const int se = 127 + kk - (e - 127);
-            S = (se >= 1 && se <= 254) ? __uint_as_float((unsigned)se << 23) : 0.f;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __syncthreads();   // (the summaries live in the rings: nobody pushes a candidate before everybody has read them)
-    }
-
-    const f3 cr = {A.corner[0], A.corner[1], A.corner[2]};
-    const float res = A.res;
-    const float rinv = 1.0f / res;
-    VoteTile VT;
-    VT.tile = TILED ? tile : A.grid;
-    VT.carry_log = carry_log; VT.carry_n = ctrl;
-    VT.x0 = x0; VT.y0 = y0; VT.tx = tx; VT.ty = ty; VT.gz = gz; VT.ltyz = ty * gz; VT.syz = gy * gz; VT.res = res;
-    VT.S = S;
-    VT.rres = refined_rcp(res);
-    VT.dummy = (int)(dummy + 2 * lane - reinterpret_cast<uint32_t*>(tile));
-    VT.unit_probs = unit_probs;
-    VT.lo = ceil_to_float(0.01);
-    VT.hx = ceil_to_float((double)gx - 1.01); VT.hy = ceil_to_float((double)gy - 1.01);
-    VT.hz = ceil_to_float((double)gz - 1.01);
-    // acceptance box of exact grid coordinates that can touch this tile: valid in the grid
-    // ([0.01, dim-1.01)) and floor in [x0-1, x0+tx-1]
-    const float blx = fmaxf(0.01f, (float)(x0 - 1)), bhx = fminf((float)gx - 1.01f, (float)(x0 + tx));
-    const float bly = fmaxf(0.01f, (float)(y0 - 1)), bhy = fminf((float)gy - 1.01f, (float)(y0 + ty));
-    const float blz = 0.01f, bhz = (float)gz - 1.01f;
-    // the same box as centre and half extents, for the plane and shell tests of the pair culling
-    const float bcx = 0.5f * (blx + bhx), bcy = 0.5f * (bly + bhy), bcz = 0.5f * (blz + bhz);
-    const float bhx_ = 0.5f * (bhx - blx), bhy_ = 0.5f * (bhy - bly), bhz_ = 0.5f * (bhz - blz);
-
-    // one pair per lane (`valid` lanes), all of its rotations: screen, queue, deposit
-    auto process = [&](const int64_t p, const bool valid) {
-        PairFrame F;
-        F.cc = {0.f, 0.f, 0.f}; F.x = F.cc; F.y = F.cc; F.prob = 0.f; F.n = 0;
-        if (valid) {
-            const float2 o = reinterpret_cast<const float2*>(A.outputs)[p];
-            const int2 ij = vote_pair_idx(A, p);
-            f3 a, ab, xd;
-            if (pair_frame(A.points, ij.x, ij.y, a, ab, xd)) {
-                const float proj_len = o.x, odist = o.y;
-                F.cc = sub3(a, scl3(ab, proj_len));                    // :23
-                F.prob = A.probs ? fmaxf(A.probs[ij.x], A.probs[ij.y]) : 1.f;   // :25
-                F.x = scl3(xd, odist);                                 // :28
-                F.y = cross3(F.x, ab);                                 // :29
-                F.n = A.n_rots;
-                if (A.adaptive) F.n = min((int)((double)(odist / res) * (2 * CPPF_PI)), A.n_rots);  // :31
-            }
-        }
-        const int n = F.n;
-        // screen in grid units: q = cq + cos*xq + sin*yq.  It differs from the exact coordinate of :35
-        // by a few roundings of terms no larger than `mag`, so the acceptance box is widened per pair
-        // by 1e-6*mag + 1e-3 cells (>= 16 ulp of the largest term).
-        const f3 cq = scl3(sub3(F.cc, cr), rinv), xq = scl3(F.x, rinv), yq = scl3(F.y, rinv);
-        const float ex = fmaf((fabsf(F.cc.x) + fabsf(cr.x) + fabsf(F.x.x) + fabsf(F.y.x)) * rinv, 1e-6f, 1e-3f);
-        const float ey = fmaf((fabsf(F.cc.y) + fabsf(cr.y) + fabsf(F.x.y) + fabsf(F.y.y)) * rinv, 1e-6f, 1e-3f);
-        const float ez = fmaf((fabsf(F.cc.z) + fabsf(cr.z) + fabsf(F.x.z) + fabsf(F.y.z)) * rinv, 1e-6f, 1e-3f);
-        const float lox = blx - ex, hix = bhx + ex, loy = bly - ey, hiy = bhy + ey, loz = blz - ez, hiz = bhz + ez;
-        // largest floats below the (positive) upper bounds
-        const float hix1 = __uint_as_float(__float_as_uint(hix) - 1u), hiy1 = __uint_as_float(__float_as_uint(hiy) - 1u),
-                    hiz1 = __uint_as_float(__float_as_uint(hiz) - 1u);
-        int qhead = 0, qtail = 0;  // wave-uniform ring cursors, the ring is drained at the end of every batch
-        if (TAB_LDS) {
-            // arc screen (n <= 72 rotations): three per-axis masks, their AND
-            const float nf = (float)n * 0.159154943f;
-            const Mask96 mx = axis_arc_mask(below, cq.x, xq.x, yq.x, lox, hix, nf, n);
-            const Mask96 my = axis_arc_mask(below, cq.y, xq.y, yq.y, loy, hiy, nf, n);
-            const Mask96 mz = axis_arc_mask(below, cq.z, xq.z, yq.z, loz, hiz, nf, n);
-            const uint32_t live = n > 0 ? 0xffffffffu : 0u;
-            const uint32_t mw0 = mx.a & my.a & mz.a & live, mw1 = mx.b & my.b & mz.b & live, mw2 = mx.c & my.c & mz.c & live;
-            // RUN WALK (round 3; replaces the candidate ring for n <= 72).  A pair's mask is an arc or two (90 % / 9 % of the
-            // pair-tile visits on known-answer inputs), so it is turned into up to three index runs -- the first two exact, the
-            // third the hull of whatever remains: a superset (+0.8 % candidates), and the deposit's exact tests decide as
-            // before.  A batch's candidates are then the concatenation of the lanes' runs, total = sum of their lengths
-            // (one DPP scan), and deposit lane j takes the CONTIGUOUS block [j B, (j+1) B), B = ceil(total / 64): it finds the
-            // source lane of its first candidate once (binary search over the scan), then walks -- rotation = run base + k,
-            // next source when the current one is exhausted -- pulling the source's frame with ds_bpermute as before.  No
-            // ring, no per-candidate queueing: the expansion was ~64 of the kernel's 255 VALU per 64 candidates on
-            // known-answer inputs (profiles/r2_vote_phases.txt: 133 trips of ~30 VALU per wave) and is ~20 now, and all 64
-            // lanes finish within one step of each other by construction.
-            int s0, e0, s1, e1, s2, e2;
-            mask_runs(below, mw0, mw1, mw2, s0, e0, s1, e1, s2, e2);
-            const int l0 = e0 - s0, l1 = e1 - s1, l2 = max(e2 - s2, 0);
-            const int cnt = l0 + l1 + l2;
-            const int incl = wave_incl_scan(cnt);
-            const int total = __builtin_amdgcn_readlane(incl, 63);
-            if (total > 0) {
-                const unsigned long long nz = __ballot(cnt > 0);
-                const unsigned long long above = nz & ~((2ull << lane) - 1ull);   // (lane 63: 2 << 63 wraps to 0, above = 0)
-                const int nxt = above ? __builtin_ctzll(above) : 64;
-                // wA bytes = {next non-empty lane, end of run 0 in candidate order, end of run 1, count}, wB halves = {gap between
-                // runs 0 and 1, gap between runs 1 and 2} (x 8: table byte offsets): candidate k of the lane is rotation
-                // s0 + k + (k >= t1 ? g1 : 0) + (k >= t2 ? g2 : 0)
-                const uint32_t wA = (uint32_t)nxt | ((uint32_t)l0 << 8) | ((uint32_t)(l0 + l1) << 16) | ((uint32_t)cnt << 24);
-                const uint32_t wB = ((uint32_t)(s1 - e0) << 3) | ((uint32_t)max(s2 - e1, 0) << 19);   // gaps as table byte offsets
-                const int tabS = ((__mul24(n, n - 1) >> 1) + s0) << 3;   // byte offset of the pair's first candidate in the rotation table
-                const int Bn = (total + 63) >> 6;
-                const int q0 = __mul24(lane, Bn);
-                const int mine = min(max(total - q0, 0), Bn);
-                int src = 0;
-#pragma unroll
-                for (int step = 32; step > 0; step >>= 1) src += (__shfl(incl, src + step - 1, 64) <= q0) ? step : 0;
-                src = min(src, 63);
-                int k = q0 - (__shfl(incl, src, 64) - __shfl(cnt, src, 64));
-                const char* ltab_b = reinterpret_cast<const char*>(ltab);
-                // A step's pulls (the source lane's frame and run words) are requested one step AHEAD, right after the walk has
-                // advanced and before the previous candidate's deposit: the LDS crossbar round trip then overlaps the deposit's
-                // arithmetic and its eight returning atomics instead of heading every step's dependency chain.
-                struct Pulled { f3 cc, x, y; float prob; uint32_t a, b; int tab; };
-                auto pull = [&](const int from) {
-                    // all 64 lanes execute the pulls (an inactive source lane would read as 0)
-                    Pulled q;
-                    q.cc.x = __shfl(F.cc.x, from, 64); q.cc.y = __shfl(F.cc.y, from, 64); q.cc.z = __shfl(F.cc.z, from, 64);
-                    q.x.x = __shfl(F.x.x, from, 64); q.x.y = __shfl(F.x.y, from, 64); q.x.z = __shfl(F.x.z, from, 64);
-                    q.y.x = __shfl(F.y.x, from, 64); q.y.y = __shfl(F.y.y, from, 64); q.y.z = __shfl(F.y.z, from, 64);
-                    q.prob = VT.unit_probs ? 1.0f : __shfl(F.prob, from, 64);
-                    q.a = (uint32_t)__shfl((int)wA, from, 64);
-                    q.b = (uint32_t)__shfl((int)wB, from, 64);
-                    q.tab = __shfl(tabS, from, 64);
-                    return q;
-                };
-                Pulled cur = pull(src);
-                for (int it = 0; it < Bn; ++it) {
-                    const uint32_t a = cur.a, b = cur.b;
-                    const int t1 = (int)((a >> 8) & 0xffu), t2 = (int)((a >> 16) & 0xffu);
-                    // (masks, not selects: the compiler turned a nested ?: into three exec-masked regions)
-                    const int toff = cur.tab + (k << 3) + ((int)(b & 0xffffu) & -(int)(k >= t1)) + ((int)(b >> 16) & -(int)(k >= t2));
-                    k += 1;
-                    const bool adv = k >= (int)(a >> 24);
-                    src = adv ? (int)(a & 0xffu) : src;
-                    k = adv ? 0 : k;
-                    // LDS returns in order: this step's table entry is requested first, the next step's pulls behind it
-                    const float2 cs = *reinterpret_cast<const float2*>(ltab_b + (it < mine ? toff : 0));
-                    __builtin_amdgcn_sched_barrier(0);
-                    const Pulled nx = pull(src);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (it < mine) {
-                        const f3 offset = add3(scl3(cur.x, cs.x), scl3(cur.y, cs.y));      // :34
-                        const f3 v = sub3(add3(cur.cc, offset), cr);                       // numerator of :35
-                        vote_deposit<TILED>(VT, v, cur.prob);
-                    }
-                    cur = nx;
-                }
-            }
-        } else {
-        // more than 72 rotations: the rotation loop.  Two rotations per trip: half the loop/scalar overhead and two
-        // independent fma chains in flight (the loop is issue- and latency-bound, not bandwidth-bound)
-        for (int i = 0; __any(i < n); i += 2) {
-            // every lane evaluates (no exec-masked region to leave); lanes past their n are masked by the i < n terms
-            bool acc0, acc1;
-            {
-                const int nn = n > 0 ? n : 1;
-                const float2 c0 = rot_cs(i, nn), c1 = rot_cs(i + 1, nn);
-                const float qx0 = fmaf(c0.y, yq.x, fmaf(c0.x, xq.x, cq.x)), qx1 = fmaf(c1.y, yq.x, fmaf(c1.x, xq.x, cq.x));
-                const float qy0 = fmaf(c0.y, yq.y, fmaf(c0.x, xq.y, cq.y)), qy1 = fmaf(c1.y, yq.y, fmaf(c1.x, xq.y, cq.y));
-                const float qz0 = fmaf(c0.y, yq.z, fmaf(c0.x, xq.z, cq.z)), qz1 = fmaf(c1.y, yq.z, fmaf(c1.x, xq.z, cq.z));
-                // lo <= q < hi as med3(q, lo, pred(hi)) == q: one SGPR-writing compare per coordinate instead of two
-                acc0 = (i < n) & (__builtin_amdgcn_fmed3f(qx0, lox, hix1) == qx0) & (__builtin_amdgcn_fmed3f(qy0, loy, hiy1) == qy0) &
-                       (__builtin_amdgcn_fmed3f(qz0, loz, hiz1) == qz0);
-                acc1 = (i + 1 < n) & (__builtin_amdgcn_fmed3f(qx1, lox, hix1) == qx1) &
-                       (__builtin_amdgcn_fmed3f(qy1, loy, hiy1) == qy1) & (__builtin_amdgcn_fmed3f(qz1, loz, hiz1) == qz1);
-            }
-            const unsigned long long m0 = __ballot(acc0), m1 = __ballot(acc1);
-            if ((m0 | m1) == 0ull) continue;
-            const int n0 = __popcll(m0);
-            if (acc0) {
-                const int pos = qtail + __builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32),
-                                                                  __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0));
-                ring[pos & (VOTE_RING - 1)] = (uint16_t)(lane | (i << 6));
-            }
-            if (acc1) {
-                const int pos = qtail + n0 + __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32),
-                                                                       __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0));
-                ring[pos & (VOTE_RING - 1)] = (uint16_t)(lane | ((i + 1) << 6));
-            }
-            qtail += n0 + __popcll(m1);
-            while (qtail - qhead >= 64) {  // at most two pops: <= 63 queued + <= 128 pushed
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                vote_pop<TILED, TAB_LDS>(VT, F, cr, ltab, ring, qhead, lane, 64);
-                qhead += 64;
-            }
-        }
-        if (qtail != qhead) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            vote_pop<TILED, TAB_LDS>(VT, F, cr, ltab, ring, qhead, lane, qtail - qhead);
-        }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    };
-
-    if (!TILED) {
-        for (int64_t pb = p_begin; pb < p_end; pb += p_step) process(pb + tid, pb + tid < p_end);  // uniform trip count per wave
-    } else {
-        // Pair culling: a pair whose whole vote circle misses this tile's acceptance box is dropped before the
-        // rotation loop (with many tiles, or outputs that point away from the object, that is most pairs), and the
-        // survivors are compacted through a per-wave LDS queue so that the rotation loop runs with full lanes.
-        // The circle of pair (a, b) has centre cc = a - u*mu, radius |nu| and lies in the plane normal to u, so its
-        // extent along axis k is |nu|*sqrt(1 - u_k^2); the test uses approximate arithmetic and a slack far above
-        // both its own error and the widening of the rotation screen, so no depositing pair is ever dropped.
-        // Blocks of 64 pairs are handed out through an LDS counter: the work per block varies (culling, trip counts), and
-        // with a fixed interleave the slowest of the 16 waves kept the others waiting at the final barrier for a quarter of
-        // the kernel (s_memtime trace, profiles/r2_vote_phases.txt).  Fixed-point deposits commute, so who takes which
-        // block does not change the result.
-        int qn = 0;
-        for (;;) {
-            int blk = 0;
-            if (lane == 0) blk = atomicAdd(&ctrl[4], 1);
-            const int64_t pb = p_begin + 64 * (int64_t)__builtin_amdgcn_readfirstlane(blk);
-            const bool more = pb < p_end;
-            if (more) {
-                const int64_t p = pb + lane;
-                bool pass = false;
-                if (p < p_end) {
-                    const float2 o = reinterpret_cast<const float2*>(A.outputs)[p];
-                    const int2 ij = vote_pair_idx(A, p);
-                    const f3 a = ld3(A.points, ij.x), b = ld3(A.points, ij.y);
-                    const f3 d = sub3(a, b);
-                    const float L = sqrtf(dot3(d, d));
-                    const float inv = __builtin_amdgcn_rcpf(L + 1e-7f);
-                    const f3 u = scl3(d, inv);
-                    const f3 cc = sub3(a, scl3(u, o.x));
-                    const float R = fabsf(o.y) * rinv;
-                    const float ex_ = R * __builtin_amdgcn_sqrtf(fmaxf(0.f, 1.f - u.x * u.x));
-                    const float ey_ = R * __builtin_amdgcn_sqrtf(fmaxf(0.f, 1.f - u.y * u.y));
-                    const float ez_ = R * __builtin_amdgcn_sqrtf(fmaxf(0.f, 1.f - u.z * u.z));
-                    const float sl = fmaf(R, 1.1e-3f, 4e-3f);
-                    const float sx = sl + 8e-6f * (fabsf(cc.x) + fabsf(cr.x)) * rinv, sy = sl + 8e-6f * (fabsf(cc.y) + fabsf(cr.y)) * rinv,
-                                sz = sl + 8e-6f * (fabsf(cc.z) + fabsf(cr.z)) * rinv;
-                    const float qx = (cc.x - cr.x) * rinv, qy = (cc.y - cr.y) * rinv, qz = (cc.z - cr.z) * rinv;
-                    // The circle is the intersection of a plane (through q, normal u) and a sphere (centre q, radius R), so
-                    // besides its bounding box two more necessary conditions are cheap: the acceptance box (centre bc,
-                    // half extents bh_) must reach the plane, and R must lie between the box's nearest and farthest
-                    // distance from q.  A circle larger than the object (most of them, for a network that has not learnt
-                    // the object) has a bounding box that covers every tile while the curve itself passes through few.
-                    const float dx = bcx - qx, dy = bcy - qy, dz = bcz - qz, sall = sl + (sx - sl) + (sy - sl) + (sz - sl);
-                    const float off_plane = fabsf((dx * u.x + dy * u.y) + dz * u.z);
-                    const float reach = (fabsf(u.x) * bhx_ + fabsf(u.y) * bhy_) + fabsf(u.z) * bhz_;
-                    const float nx = fmaxf(fabsf(dx) - bhx_, 0.f), ny = fmaxf(fabsf(dy) - bhy_, 0.f), nz = fmaxf(fabsf(dz) - bhz_, 0.f);
-                    const float fx = fabsf(dx) + bhx_, fy = fabsf(dy) + bhy_, fz = fabsf(dz) + bhz_;
-                    const float dmin2 = (nx * nx + ny * ny) + nz * nz, dmax2 = (fx * fx + fy * fy) + fz * fz;
-                    const float r_hi = R + sall, r_lo = fmaxf(R - sall, 0.f);
-                    pass = (L >= 9e-8f) & (!A.adaptive | (R >= 0.15f)) &
-                           (qx + ex_ + sx >= blx) & (qx - ex_ - sx < bhx) & (qy + ey_ + sy >= bly) & (qy - ey_ - sy < bhy) &
-                           (qz + ez_ + sz >= blz) & (qz - ez_ - sz < bhz) &
-                           (off_plane <= reach + sall) & (dmin2 <= r_hi * r_hi * 1.0001f) & (dmax2 * 1.0001f >= r_lo * r_lo);
-                }
-                const unsigned long long m = __ballot(pass);
-                if (pass)
-                    pairq[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] =
-                        (uint32_t)(p - p_begin);
-                qn += __popcll(m);
-            }
-            while (qn >= 64 || (!more && qn > 0)) {
-                const int take = qn < 64 ? qn : 64;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                const uint32_t off = lane < take ? pairq[qn - take + lane] : 0u;
-                qn -= take;
-                process(p_begin + off, lane < take);
-            }
-            if (!more) break;
-        }
-    }
-
-    if (TILED) {
-        __syncthreads();
-        const int nt = tx * ty * gz, nt4 = (nt + 3) >> 2;
-        const int slot = (ptx * pty * gz + 3) & ~3;
-        float4* part4 = reinterpret_cast<float4*>(A.partials + ((int64_t)c * pT + t) * slot);
-        const int nc = min(ctrl[0], VOTE_CARRY_CAP);   // logged 32-bit wrap-arounds (none, normally)
-        if (S > 0.f && nc == 0) {   // fixed point -> fp32 on the way out: one pass, 16 bytes per lane
-            const float invS = 1.0f / S;  // exact: S is a power of two
-            const uint4* tu4 = reinterpret_cast<const uint4*>(tile);
-            for (int k = tid; k < nt4; k += VOTE_THREADS) {
-                const uint4 u = tu4[k];
-                part4[k] = make_float4((float)u.x * invS, (float)u.y * invS, (float)u.z * invS, (float)u.w * invS);
-            }
-        } else {
-            if (S > 0.f) {  // fixed point -> fp32 in place, then the logged wrap-arounds
-                const float invS = 1.0f / S;
-                uint32_t* tu = reinterpret_cast<uint32_t*>(tile);
-                for (int k = tid; k < nt; k += VOTE_THREADS) tile[k] = (float)tu[k] * invS;
-                __syncthreads();
-                for (int k = tid; k < nc; k += VOTE_THREADS) atomicAdd(&tile[carry_log[k]], 4294967296.0f * invS);
-                __syncthreads();
-            }
-            const float4* t4 = reinterpret_cast<const float4*>(tile);
-            for (int k = tid; k < nt4; k += VOTE_THREADS) part4[k] = t4[k];
-        }
-    }
 }
 
 // ----------------------------------------------------------------------------- reduce + arg-max
@@ -1043,140 +350,8 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void reduce_argmax_kernel(float* _
     }
 }
 
-// Tiled vote: grid[cell] (+)= sum over chunks of the tile-major partials (vote_slot_floats), same fixed order as above
-// (chunk c goes to group c % 16; groups added in order), plus the arg-max.  A block = 16 waves = one run of 256 cells of
-// one tile: wave g adds the copies of chunks g, g + 16, ... with 16-byte loads, 8 in flight per lane; 256 threads then
-// add the 16 group sums of their cell, find its place in the grid and write it.  *_dyn launches re-derive the plan the
-// vote kernel used from the dims record.
-struct RedArgs {
-    float* grid;
-    const float* partials;
-    unsigned long long* packed;
-    long long* out_idx;
-    float* out_val;
-    int gx, gy, gz, tx, ty, nty, T, chunks, accumulate, bps;   // bps: blocks per tile of this launch
-    const int32_t* shape;  // {n_points, gx, gy, gz} or null
-    int64_t n_ppfs, grid_cap, n_points_cap;
-    int t_max;
-};
-
 #define RED_CELLS 256
 #define RED_FANIN 8   // groups of the two-level arg-max (power of two)
-__global__ __launch_bounds__(64 * RED_GROUPS) void reduce_tiles_kernel(RedArgs R)
-{
-    __shared__ __attribute__((aligned(16))) float part[RED_GROUPS][RED_CELLS];
-    __shared__ unsigned long long wkey[RED_CELLS / 64];
-    const int tid = threadIdx.x, lane = tid & 63, cg = tid >> 6;
-    if (blockIdx.x == 0 && tid == 0) {   // rotation table left by the vote kernel of this call: valid from the next launch on
-        const unsigned long long st = R.packed[31];
-        if ((st & ~0xfffull) == VOTE_TAB_PENDING) R.packed[31] = st ^ (VOTE_TAB_PENDING ^ VOTE_TAB_STAMP);
-    }
-    int gx = R.gx, gy = R.gy, gz = R.gz, ptx = R.tx, pty = R.ty, pnty = R.nty, T = R.T, chunks = R.chunks;
-    if (R.shape) {
-        const int64_t np = R.shape[0];
-        gx = R.shape[1]; gy = R.shape[2]; gz = R.shape[3];
-        const bool dims_ok = np >= 1 && np <= R.n_points_cap && gx >= 1 && gy >= 1 && gz >= 1 && (int64_t)gx * gy * gz <= R.grid_cap;
-        const VoteTiling vt = dims_ok ? vote_tiling(gx, gy, gz) : VoteTiling{0, 0, 0, 0, 1 << 30};
-        if (!dims_ok || vt.T > R.t_max) {   // the vote kernel did nothing: say so instead of reducing stale partials
-            if (blockIdx.x == 0 && tid == 0) {
-                if (R.out_idx) *R.out_idx = -1;
-                if (R.out_val) *R.out_val = __uint_as_float(0x7fc00000u);
-            }
-            return;
-        }
-        ptx = vt.tx; pty = vt.ty; pnty = vt.nty; T = vt.T;
-        int64_t cp;
-        chunks = vote_chunks(R.n_ppfs, T, &cp);
-    }
-    const int slot = (ptx * pty * gz + 3) & ~3;
-    const int t = blockIdx.x / R.bps, j = blockIdx.x - t * R.bps;
-    if (t >= T) return;
-    const int tix = t / pnty, tiy = t - tix * pnty;
-    const int x0 = tix * ptx, y0 = tiy * pty;
-    const int tx = min(ptx, gx - x0), ty = min(pty, gy - y0);
-    const int nt = tx * ty * gz;
-    if (j * RED_CELLS >= nt) return;
-    const int k0 = j * RED_CELLS + lane * 4;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (k0 < nt) {   // (k0 + 3 < slot: both are multiples of 4)
-        const int64_t cstride = (int64_t)T * slot;
-        const float* base = R.partials + (int64_t)t * slot + k0;
-        int c = cg;
-        for (; c + 7 * RED_GROUPS < chunks; c += 8 * RED_GROUPS) {  // 8 independent 16-byte loads in flight per lane
-            float4 v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4*>(base + (int64_t)(c + k * RED_GROUPS) * cstride);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { s.x = s.x + v[k].x; s.y = s.y + v[k].y; s.z = s.z + v[k].z; s.w = s.w + v[k].w; }
-        }
-        for (; c < chunks; c += RED_GROUPS) {
-            const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)c * cstride);
-            s.x = s.x + v.x; s.y = s.y + v.y; s.z = s.z + v.z; s.w = s.w + v.w;
-        }
-    }
-    *reinterpret_cast<float4*>(&part[cg][lane * 4]) = s;
-    __syncthreads();
-    unsigned long long key = 0ull;
-    const int k = j * RED_CELLS + tid;
-    if (tid < RED_CELLS && k < nt) {
-        const int row = ty * gz;
-        const int lx = k / row, r = k - lx * row;
-        const int64_t cell = (int64_t)(x0 + lx) * ((int64_t)gy * gz) + (int64_t)y0 * gz + r;
-        float v = R.accumulate ? R.grid[cell] : 0.f;
-#pragma unroll
-        for (int g = 0; g < RED_GROUPS; ++g) v = v + part[g][tid];
-        R.grid[cell] = v;
-        key = ((unsigned long long)f2ord(v) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)cell);
-    }
-    if (tid < RED_CELLS) {
-        key = wave_max_u64(key);
-        if (lane == 0) wkey[cg] = key;
-    }
-    // how many blocks report to this block's group, and how many groups are in use: block ids are t * bps + j with bps a
-    // multiple of RED_FANIN, so tile t sends its blocks j = g, g + 8, ... < nb_t to group g (lane t of wave 0 counts tile t)
-    unsigned n_group = 0, n_groups_used = 0;
-    if (cg == 0) {
-        unsigned nb = 0;
-        if (lane < T) {
-            const int ax = lane / pnty, ay = lane - ax * pnty;
-            nb = (unsigned)((min(ptx, gx - ax * ptx) * min(pty, gy - ay * pty) * gz + RED_CELLS - 1) / RED_CELLS);
-        }
-        const unsigned gsel = blockIdx.x & (RED_FANIN - 1);
-        unsigned mine = nb > gsel ? (nb - gsel + RED_FANIN - 1) / RED_FANIN : 0u, most = nb;
-        for (int off = 32; off > 0; off >>= 1) {
-            mine += __shfl_xor(mine, off, 64);
-            const unsigned o = __shfl_xor(most, off, 64);
-            most = o > most ? o : most;
-        }
-        n_group = mine;
-        n_groups_used = most < RED_FANIN ? most : RED_FANIN;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < RED_CELLS / 64; ++w) key = wkey[w] > key ? wkey[w] : key;
-        // Arg-max across blocks, two levels: same-address atomics serialise chip-wide (~12 ns each, and every block
-        // arrives at about the same time), so block b reports to group b % 8 -- {key, ticket} pairs packed[2 + 2g] --
-        // and the last block of a group carries the group's maximum to the root pair packed[0..1].  Every access is a
-        // device-scope atomic whose result is consumed before the next one is issued (data dependence), so no cache
-        // maintenance is needed.
-        auto report = [](unsigned long long* slot, unsigned long long k) -> unsigned {   // returns the ticket drawn
-            const unsigned long long old = atomicMax(slot, k);          // returning: completes before the ticket
-            unsigned d1 = (unsigned)old, d2;
-            asm volatile("v_mov_b32 %0, %1" : "=v"(d2) : "v"(d1));
-            return atomicAdd(reinterpret_cast<unsigned*>(slot + 1), 1u + (d1 ^ d2));   // d1 ^ d2 == 0, depends on `old`
-        };
-        const unsigned g = blockIdx.x & (RED_FANIN - 1);
-        unsigned long long* slot = R.packed + 2 + 2 * g;
-        if (report(slot, key) == n_group - 1) {
-            const unsigned long long gbest = atomicMax(slot, 0ull);
-            if (report(R.packed, gbest) == n_groups_used - 1) {
-                const unsigned long long best = atomicMax(R.packed, 0ull);
-                if (R.out_idx) *R.out_idx = (long long)(0xffffffffu - (uint32_t)(best & 0xffffffffull));
-                if (R.out_val) *R.out_val = ord2f((uint32_t)(best >> 32));
-            }
-        }
-    }
-}
 
 // ============================================================================ binned tiled vote ("v3", round 3)
 // The tiled vote for n_rots <= 72 and <= 64 tiles, rebuilt around three observations from round 2's counters (the kernel is
@@ -1278,7 +453,8 @@ __host__ __device__ inline unsigned v3_bound(unsigned n, int c, int C)
 }
 // fixed-point bits: a workgroup deposits at most (records of its chunk) x n_rots weights <= 1; every 2^32 quanta of that is one
 // carry-log entry (VOTE_CARRY_CAP of them per workgroup)
-__host__ __device__ inline int v3_bits(unsigned chunk_records, int n_rots) { return vote_fixed_bits_of((int64_t)chunk_records + 64, n_rots); }
+// (a launch deposits at most VOTE_WIN rotations of a pair: the passes of n_rots > 72 each choose their own scale)
+__host__ __device__ inline int v3_bits(unsigned chunk_records, int n_rots) { return vote_fixed_bits_of((int64_t)chunk_records + 64, n_rots > VOTE_WIN ? VOTE_WIN : n_rots); }
 
 // fused form: the pair list is dealt to a tile's C workgroups in blocks of 64, block b to workgroup b mod C (neighbouring pairs share
 // their first point, so contiguous chunks would inherit the cloud's unevenness); the most pairs a workgroup can get
@@ -1333,6 +509,7 @@ struct V3Args {
     int bin_sr;            // bin kernel: blocks of 64 pairs a wave culls per super-round
     int fused;             // < 4 tiles: no queues, workgroup (tile, chunk) culls and screens its own pairs (chunks = wgs / T)
     int kk;                // fused, by-value launches: fixed-point bits (the chunks are static)
+    int win_base;          // n_rots > 72 (WIDE kernels): this launch serves rotations [win_base, win_base + 72) of every pair
     int kk_force;          // != 0: the caller fixes the fixed-point bits (pair-sharded votes: every rank must quantise alike)
     long long* grid_raw;   // != null: the reduce kernel also stores every cell's exact sum of quanta (i64[gx*gy*gz]; grid may be null)
     float* quantum_out;    // != null: value of one quantum of grid_raw (0: fp32 partial tiles, grid_raw is not valid)
@@ -1392,16 +569,20 @@ __device__ __forceinline__ int2 v3_pair_idx(const V3Args& A, int64_t p)
 
 // the part of axis_arc_mask that does not depend on the tile: amplitude, its reciprocal, phase in index units
 struct AxisArc { float c, rA, f; };
-__device__ __forceinline__ AxisArc axis_arc_prep(float c, float x, float y, float nf)
+template <bool WIDE = false>
+__device__ __forceinline__ AxisArc axis_arc_prep(float c, float x, float y, float nf, int n = 0, int win_base = 0)
 {
     const float A = __builtin_amdgcn_sqrtf(fmaf(x, x, y * y));
     AxisArc a;
     a.c = c;
     a.rA = __builtin_amdgcn_rcpf(fmaxf(A, 1e-20f));
     a.f = atan2_approx(y, x) * nf;
+    if (WIDE) a.f = arc_shift(a.f, n, win_base);
     return a;
 }
-__device__ __forceinline__ Mask96 axis_arc_eval(const uint4* __restrict__ below, const AxisArc& a, float lo, float hi, float nf, int n)
+template <bool WIDE = false>
+__device__ __forceinline__ Mask96 axis_arc_eval(const uint4* __restrict__ below, const AxisArc& a, float lo, float hi, float nf, int n,
+                                                int L = 0)
 {
     const float u1 = fmaf(lo - a.c, a.rA, -1e-4f);   // cos(theta - phi) >= u1
     const float u2 = fmaf(hi - a.c, a.rA, 1e-4f);    // cos(theta - phi) <= u2
@@ -1409,8 +590,8 @@ __device__ __forceinline__ Mask96 axis_arc_eval(const uint4* __restrict__ below,
     const float a1 = u1 <= -1.f ? 3.14159265f : acos_approx(fminf(u1, 1.f));
     const float a2 = u2 >= 1.f ? 0.f : acos_approx(fmaxf(u2, -1.f));
     const float W1 = (a1 + 2e-3f) * nf, W2 = (a2 - 2e-3f) * nf;
-    const Mask96 O = arc_run(below, (int)ceilf(a.f - W1), (int)floorf(a.f + W1), n);
-    const Mask96 I = arc_run(below, (int)floorf(a.f - W2) + 1, W2 > 0.f ? (int)ceilf(a.f + W2) - 1 : -(1 << 20), n);
+    const Mask96 O = arc_run<WIDE>(below, (int)ceilf(a.f - W1), (int)floorf(a.f + W1), n, L);
+    const Mask96 I = arc_run<WIDE>(below, (int)floorf(a.f - W2) + 1, W2 > 0.f ? (int)ceilf(a.f + W2) - 1 : -(1 << 20), n, L);
     const uint32_t keep = none ? 0u : 0xffffffffu;
     return {O.a & ~I.a & keep, O.b & ~I.b & keep, O.c & ~I.c & keep};
 }
@@ -1427,6 +608,7 @@ __device__ __forceinline__ int wave_max_i32(int v)
 // circle's bounding box walked with a cheap plane / shell test, the (lane, tile) items that pass compacted through a per-wave ring;
 // per item the x / y masks of its column / row, AND, runs, and a record into the tile's queue.  Records are staged in LDS (slot
 // within the tile's share of the flush from an LDS atomic) and flushed with one global atomic per tile.
+template <bool WIDE>
 __global__ __launch_bounds__(V3_BIN_THREADS) void v3_bin_kernel(V3Args A)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
@@ -1466,6 +648,7 @@ __global__ __launch_bounds__(V3_BIN_THREADS) void v3_bin_kernel(V3Args A)
     f3 Fcc = {0.f, 0.f, 0.f}, Fx = Fcc, Fy = Fcc, Fu = Fcc, cq = Fcc, xq = Fcc, yq = Fcc;
     float Rq = 0.f, ex = 0.f, ey = 0.f, ez = 0.f, nf = 0.f, slq = 0.f;   // Rq: the circle's radius in cells
     int n = 0, ix0 = 0, ix1 = -1, iy0 = 0, iy1 = -1, nxw = 0, nyw = 0, nsteps = 0, step = 0, wdx = 0, wdy = 0, qhead = 0, qtail = 0;
+    const int wb = WIDE ? A.win_base : 0;   // WIDE: this launch bins rotations [wb, wb + 72) of every pair (bit k of a mask = rotation wb + k)
     AxisArc ax = {0.f, 0.f, 0.f}, ay = ax;
     Mask96 mz = {0u, 0u, 0u};
     // ---- cull: a pair whose circle cannot reach the grid at all (a random-weight network: half of them at C5) is dropped before any
@@ -1497,7 +680,7 @@ __global__ __launch_bounds__(V3_BIN_THREADS) void v3_bin_kernel(V3Args A)
         const float fx = fabsf(dx) + ghx, fy = fabsf(dy) + ghy, fz = fabsf(dz) + ghz;
         const float dmin2 = (nx * nx + ny * ny) + nz * nz, dmax2 = (fx * fx + fy * fy) + fz * fz;
         const float r_hi = R + sall, r_lo = fmaxf(R - sall, 0.f);
-        return (L >= 0.9e-7f) & (!A.adaptive | (R >= 0.15f)) &
+        return (L >= 0.9e-7f) & (!A.adaptive | (R >= 0.15f)) & (!WIDE | !A.adaptive | (fmaf(R, 6.2832f, 1.f) > (float)wb)) &   // (n > win_base, generously)
                (qx + ax_ + sx >= 0.01f) & (qx - ax_ - sx < (float)gx - 1.01f) & (qy + ay_ + sy >= 0.01f) & (qy - ay_ - sy < (float)gy - 1.01f) &
                (qz + az_ + sz >= 0.01f) & (qz - az_ - sz < (float)gz - 1.01f) &
                (off_plane <= reach + sall) & (dmin2 <= r_hi * r_hi * 1.0001f) & (dmax2 * 1.0001f >= r_lo * r_lo);
@@ -1532,8 +715,10 @@ __global__ __launch_bounds__(V3_BIN_THREADS) void v3_bin_kernel(V3Args A)
                     n = A.n_rots;
                     if (A.adaptive) n = min((int)((double)(o.y / res) * (2 * CPPF_PI)), A.n_rots);   // :31
                     n = max(n, 0);
+                    if (WIDE && n <= wb) n = 0;   // no rotation of this pair in the window
                 }
             }
+            const int Lw = WIDE ? max(min(n - wb, 72), 0) : n;   // bits of this pair's masks
             cq = scl3(sub3(Fcc, cr), rinv); xq = scl3(Fx, rinv); yq = scl3(Fy, rinv);
             // slack of the screen: the exact-frame form (1e-6 of the terms + 1e-3 cells, see vote_kernel) plus the approximate frame's
             // own error -- rcp / sqrt are good to 1 ulp, so u, x, y carry a few 1e-7 relative: <= ~5e-7 m on a sample for |mu|, nu up to
@@ -1542,9 +727,9 @@ __global__ __launch_bounds__(V3_BIN_THREADS) void v3_bin_kernel(V3Args A)
             ey = fmaf((fabsf(Fcc.y) + fabsf(cr.y) + fabsf(Fx.y) + fabsf(Fy.y)) * rinv, 4e-6f, 2e-3f);
             ez = fmaf((fabsf(Fcc.z) + fabsf(cr.z) + fabsf(Fx.z) + fabsf(Fy.z)) * rinv, 4e-6f, 2e-3f);
             nf = (float)n * 0.159154943f;
-            ax = axis_arc_prep(cq.x, xq.x, yq.x, nf); ay = axis_arc_prep(cq.y, xq.y, yq.y, nf);
-            const AxisArc az = axis_arc_prep(cq.z, xq.z, yq.z, nf);
-            mz = axis_arc_eval(below, az, 0.01f - ez, (float)gz - 1.01f + ez, nf, n);
+            ax = axis_arc_prep<WIDE>(cq.x, xq.x, yq.x, nf, n, wb); ay = axis_arc_prep<WIDE>(cq.y, xq.y, yq.y, nf, n, wb);
+            const AxisArc az = axis_arc_prep<WIDE>(cq.z, xq.z, yq.z, nf, n, wb);
+            mz = axis_arc_eval<WIDE>(below, az, 0.01f - ez, (float)gz - 1.01f + ez, nf, n, Lw);
             // tiles the circle's bounding box touches: coordinate range [c - A, c + A] (+ slack) against owned ranges [x0, x0 + tx)
             const float Ax = __builtin_amdgcn_sqrtf(fmaf(xq.x, xq.x, yq.x * yq.x)) * 1.0001f + ex + 2e-3f;
             const float Ay = __builtin_amdgcn_sqrtf(fmaf(xq.y, xq.y, yq.y * yq.y)) * 1.0001f + ey + 2e-3f;
@@ -1622,8 +807,9 @@ __global__ __launch_bounds__(V3_BIN_THREADS) void v3_bin_kernel(V3Args A)
             const int ix = tile / t.nty, iy = tile - ix * t.nty;
             const float x0f = (float)(ix * t.tx), y0f = (float)(iy * t.ty);
             const float snf = (float)sn * 0.159154943f;
-            const Mask96 mx = axis_arc_eval(below, bx_, fmaxf(0.01f, x0f) - sex, fminf((float)gx - 1.01f, x0f + ptxf) + sex, snf, sn);
-            const Mask96 my = axis_arc_eval(below, by_, fmaxf(0.01f, y0f) - sey, fminf((float)gy - 1.01f, y0f + ptyf) + sey, snf, sn);
+            const int sL = WIDE ? max(min(sn - wb, 72), 0) : sn;
+            const Mask96 mx = axis_arc_eval<WIDE>(below, bx_, fmaxf(0.01f, x0f) - sex, fminf((float)gx - 1.01f, x0f + ptxf) + sex, snf, sn, sL);
+            const Mask96 my = axis_arc_eval<WIDE>(below, by_, fmaxf(0.01f, y0f) - sey, fminf((float)gy - 1.01f, y0f + ptyf) + sey, snf, sn, sL);
             m0 = mx.a & my.a & z0; m1 = mx.b & my.b & z1; m2 = mx.c & my.c & z2;
         }
         const bool have = (m0 | m1 | m2) != 0u;
@@ -1804,7 +990,7 @@ __device__ __forceinline__ void v3_deposit(const V3Tile& T, f3 v, float prob)
 }
 
 #define V3_LDS_HEAD (VOTE_CARRY_CAP * 4 + (V3_THREADS / 64) * VOTE_PAIRQ * 4 + 64 + VOTE_BELOW_N * 16)
-template <bool FUSED>
+template <bool FUSED, bool WIDE>
 __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1832,11 +1018,14 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
     const unsigned long long tstamp = A.packed[31];
     float2 probe[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) { const int n_ = lane + 1 + 64 * u; probe[u] = n_ <= A.n_rots ? wtab[n_ * (n_ - 1) / 2] : make_float2(1.f, 0.f); }
+    for (int u = 0; u < 2; ++u) { const int n_ = lane + 1 + 64 * u; probe[u] = (!WIDE && n_ <= A.n_rots) ? wtab[n_ * (n_ - 1) / 2] : make_float2(1.f, 0.f); }
+    // (WIDE, n_rots > 72: the table of every (n, i) would not fit LDS -- 520 KB at 360 -- so tab_entries = 0 and a sample's (cos, sin)
+    // comes from rot_cs(), the same fp64 evaluation the table is filled with; a rarely used knob, nocs/inference.py:39)
     float2 tab_in[(VOTE_TAB_LDS_MAX + V3_THREADS - 1) / V3_THREADS];
 #pragma unroll
     for (int u = 0; u < (VOTE_TAB_LDS_MAX + V3_THREADS - 1) / V3_THREADS; ++u)
         tab_in[u] = tid + u * V3_THREADS < A.tab_entries ? wtab[tid + u * V3_THREADS] : make_float2(0.f, 0.f);
+    const int wb = WIDE ? A.win_base : 0;
     if (FUSED && blockIdx.x == 0 && tid < 20) A.packed[tid] = 0ull;   // arg-max keys + tickets of the reduce kernel (binned: the bin kernel did)
     if (!v3_resolve(A, gx, gy, gz, n_points, pt)) return;
     int* sp = reinterpret_cast<int*>(carry_log);   // (the carry log is unused until the main loop)
@@ -1892,7 +1081,7 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
     }
     // (the cached table is trusted if its stamp matches and rotation 0 of every n is exactly (1, 0): rot_table_intact's test)
     const bool probe_ok = probe[0].x == 1.0f && probe[0].y == 0.0f && probe[1].x == 1.0f && probe[1].y == 0.0f;
-    const bool tab_cached = tstamp == (VOTE_TAB_STAMP ^ (unsigned long long)A.n_rots) && !__any(!probe_ok);
+    const bool tab_cached = WIDE || (tstamp == (VOTE_TAB_STAMP ^ (unsigned long long)A.n_rots) && !__any(!probe_ok));   // (WIDE: no table at all)
     if (tid < 16) ctrl[tid] = 0;
     for (int k = tid; k < (nwords + 3) >> 2; k += V3_THREADS) reinterpret_cast<uint4*>(tile)[k] = make_uint4(0u, 0u, 0u, 0u);
     if (tid < VOTE_BELOW_N) {
@@ -1989,8 +1178,10 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
                 n = A.n_rots;
                 if (A.adaptive) n = min((int)((double)(o.y / res) * (2 * CPPF_PI)), A.n_rots);
                 n = max(n, 0);
+                if (WIDE && n <= wb) n = 0;   // no rotation of this pair in the launch's window
             }
         }
+        const int Lw = WIDE ? max(min(n - wb, 72), 0) : n;
         int s0, l0, s1, l1, s2, l2;
         if (FUSED) {
             const f3 cq = scl3(sub3(Fcc, cr), rinv), xq = scl3(Fx, rinv), yq = scl3(Fy, rinv);
@@ -1998,9 +1189,9 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
             const float ey = fmaf((fabsf(Fcc.y) + fabsf(cr.y) + fabsf(Fx.y) + fabsf(Fy.y)) * rinv, 1e-6f, 1e-3f);
             const float ez = fmaf((fabsf(Fcc.z) + fabsf(cr.z) + fabsf(Fx.z) + fabsf(Fy.z)) * rinv, 1e-6f, 1e-3f);
             const float nf = (float)n * 0.159154943f;
-            const Mask96 mx = axis_arc_mask(below, cq.x, xq.x, yq.x, blx - ex, bhx + ex, nf, n);
-            const Mask96 my = axis_arc_mask(below, cq.y, xq.y, yq.y, bly - ey, bhy + ey, nf, n);
-            const Mask96 mz = axis_arc_mask(below, cq.z, xq.z, yq.z, blz - ez, bhz + ez, nf, n);
+            const Mask96 mx = axis_arc_mask<WIDE>(below, cq.x, xq.x, yq.x, blx - ex, bhx + ex, nf, n, wb, Lw);
+            const Mask96 my = axis_arc_mask<WIDE>(below, cq.y, xq.y, yq.y, bly - ey, bhy + ey, nf, n, wb, Lw);
+            const Mask96 mz = axis_arc_mask<WIDE>(below, cq.z, xq.z, yq.z, blz - ez, bhz + ez, nf, n, wb, Lw);
             const uint32_t live = n > 0 ? 0xffffffffu : 0u;
             int e0, e1, e2;
             mask_runs(below, mx.a & my.a & mz.a & live, mx.b & my.b & mz.b & live, mx.c & my.c & mz.c & live, s0, e0, s1, e1, s2, e2);
@@ -2018,7 +1209,9 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
             const int nxt = above ? __builtin_ctzll(above) : 64;
             const uint32_t wA = (uint32_t)nxt | ((uint32_t)l0 << 8) | ((uint32_t)(l0 + l1) << 16) | ((uint32_t)cnt << 24);
             const uint32_t wB = ((uint32_t)max(s1 - s0 - l0, 0) << 3) | ((uint32_t)max(s2 - s1 - l1, 0) << 19);
-            const int tabS = ((__mul24(n, n - 1) >> 1) + s0) << 3;
+            // where the run walk finds (cos, sin) of the lane's first candidate: a byte offset into the LDS table, row n(n-1)/2;
+            // WIDE: {n, rotation index} packed as n << 16 | index << 3 -- the walk's increments are multiples of 8 either way
+            const int tabS = WIDE ? ((n << 16) | ((wb + s0) << 3)) : (((__mul24(n, n - 1) >> 1) + s0) << 3);
             const int Bn = (total + 63) >> 6;
 #ifdef V3_TRACE
             if (lane == 0) { atomicAdd(&ctrl[8], Bn); atomicAdd(&ctrl[9], 1); }
@@ -2052,7 +1245,9 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
                 const bool adv = k >= (int)(a >> 24);
                 src = adv ? (int)(a & 0xffu) : src;
                 k = adv ? 0 : k;
-                const float2 cs = *reinterpret_cast<const float2*>(ltab_b + (it < mine ? toff : 0));
+                float2 cs;
+                if (WIDE) cs = it < mine ? rot_cs((toff & 0xffff) >> 3, toff >> 16) : make_float2(1.f, 0.f);
+                else cs = *reinterpret_cast<const float2*>(ltab_b + (it < mine ? toff : 0));
                 __builtin_amdgcn_sched_barrier(0);
                 next = pull(src);
                 __builtin_amdgcn_sched_barrier(0);
@@ -2128,7 +1323,7 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
                     const float fx = fabsf(dx) + bhx_, fy = fabsf(dy) + bhy_, fz = fabsf(dz) + bhz_;
                     const float dmin2 = (nx * nx + ny * ny) + nz * nz, dmax2 = (fx * fx + fy * fy) + fz * fz;
                     const float r_hi = R + sall, r_lo = fmaxf(R - sall, 0.f);
-                    pass = (L >= 9e-8f) & (!A.adaptive | (R >= 0.15f)) &
+                    pass = (L >= 9e-8f) & (!A.adaptive | (R >= 0.15f)) & (!WIDE | !A.adaptive | (fmaf(R, 6.2832f, 1.f) > (float)wb)) &
                            (qx + ex_ + sx >= blx) & (qx - ex_ - sx < bhx) & (qy + ey_ + sy >= bly) & (qy - ey_ - sy < bhy) &
                            (qz + ez_ + sz >= blz) & (qz - ez_ - sz < bhz) &
                            (off_plane <= reach + sall) & (dmin2 <= r_hi * r_hi * 1.0001f) & (dmax2 * 1.0001f >= r_lo * r_lo);
@@ -2380,8 +1575,8 @@ extern "C" size_t cppf_vote_workspace_init_bytes(void)
 // host side of the binned path; returns a negative CPPF_E* / positive hipError_t, or 0
 static bool v3_eligible(int64_t n_ppfs, int n_rots, int gx, int gy, int gz)
 {
-    static const bool legacy = getenv("CPPF_VOTE_LEGACY") != nullptr;   // A/B switch for tests and profiles
-    if (legacy || n_ppfs < 1 || n_ppfs > 0xffffffffll || tri(n_rots) > VOTE_TAB_LDS_MAX) return false;   // (pair numbers travel as u32)
+    (void)n_rots;                                                           // (any 1..360: more than 72 takes several passes)
+    if (n_ppfs < 1 || n_ppfs > 0xffffffffll) return false;                  // (pair numbers travel as u32)
     return v3_tiling(gx, gy, gz).T <= VOTE_MAX_TILES;
 }
 static int v3_fixed_bits_bound(int64_t n_ppfs, int n_rots, int gx, int gy, int gz)
@@ -2406,7 +1601,8 @@ static size_t v3_workspace_bytes_dyn(int many_tiles, int64_t n_ppfs)
            (size_t)wgs * V3_TILE_FLOATS * sizeof(uint32_t);
 }
 // What a by-value launch will do for this problem (tests, tools): out = {path, T, tx, ty, ntx, nty, hx, hy, workgroups, bits};
-// path 0: global fp32 atomics (> 64 tiles), 1: round-2 tiled kernels (n_rots > 72), 2: fused round-3 kernel (< 4 tiles), 3: binned
+// path 0: global fp32 atomics (> 64 tiles), 2: fused kernel (< 4 tiles), 3: binned; (1 was round 2's kernels, gone); for n_rots > 72
+// the tiled paths run ceil(n_rots / 72) passes of the same launches
 extern "C" int cppf_vote_plan_query(int64_t n_ppfs, int n_rots, int gx, int gy, int gz, int32_t* out)
 {
     if (!out || n_rots < 1 || n_rots > CPPF_MAX_ROTS || gx < 1 || gy < 1 || gz < 1 || n_ppfs < 0) return CPPF_EINVAL;
@@ -2419,10 +1615,7 @@ extern "C" int cppf_vote_plan_query(int64_t n_ppfs, int n_rots, int gx, int gy, 
         for (int k = 0; k < 10; ++k) out[k] = o[k];
         return 0;
     }
-    const VotePlan pl = make_vote_plan(n_ppfs, n_rots, gx, gy, gz);
-    const int o[10] = {pl.tiled ? 1 : 0, pl.T, pl.tx, pl.ty, pl.ntx, pl.nty, 0, 0, pl.tiled ? pl.T * pl.chunks : 0, vote_fixed_bits(pl, n_rots)};
-    for (int k = 0; k < 10; ++k) out[k] = o[k];
-    return 0;
+    return 0;   // path 0: everything else stays 0
 }
 
 // what cppf_vote_grid_raw adds to a vote: the exact integer image of the grid, its quantum, and bits fixed by the caller
@@ -2443,7 +1636,8 @@ static int v3_launch(const float* points, const float* outputs, const float* pro
     A.packed = reinterpret_cast<unsigned long long*>(ws);
     A.grid = grid_obj; A.accumulate = accumulate;
     A.out_idx = want_argmax ? out_idx : nullptr; A.out_val = want_argmax ? out_val : nullptr;
-    A.tab_entries = tri(n_rots);
+    const bool wide = n_rots > VOTE_WIN;
+    A.tab_entries = wide ? 0 : tri(n_rots);
     A.pool_cap = n_ppfs;
     A.plane = reinterpret_cast<unsigned long long*>(ws + VOTE_WS_PART + V3_HDR_BYTES);
     int red_blocks;
@@ -2451,6 +1645,7 @@ static int v3_launch(const float* points, const float* outputs, const float* pro
         A.t_cap = many_tiles ? VOTE_MAX_TILES : 3;
         A.wgs = V3_WGS;
         A.fused = many_tiles ? 0 : 1;
+        if (ex && ex->grid_raw) return CPPF_EINVAL;
         if (grid_cap > (int64_t)A.t_cap * V3_TILE_FLOATS) return CPPF_EINVAL;   // (a grid of the class has at most that many cells)
         A.pool = reinterpret_cast<uint32_t*>(ws + VOTE_WS_PART + V3_HDR_BYTES + V3_PLANE_BYTES);
         A.partials = A.pool + (many_tiles ? align_up((size_t)A.t_cap * (size_t)n_ppfs * 12, 256) / 4 : 0);
@@ -2473,37 +1668,90 @@ static int v3_launch(const float* points, const float* outputs, const float* pro
     }
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&v3_bin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&v3_vote_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&v3_vote_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const void* ks[] = {reinterpret_cast<const void*>(&v3_bin_kernel<false>), reinterpret_cast<const void*>(&v3_bin_kernel<true>),
+                            reinterpret_cast<const void*>(&v3_vote_kernel<false, false>), reinterpret_cast<const void*>(&v3_vote_kernel<true, false>),
+                            reinterpret_cast<const void*>(&v3_vote_kernel<false, true>), reinterpret_cast<const void*>(&v3_vote_kernel<true, true>)};
+        for (const void* k : ks) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     const size_t lds_vote = V3_LDS_HEAD + (size_t)(A.tab_entries + 2) * sizeof(float2) + (size_t)V3_TILE_FLOATS * sizeof(float);
-    if (A.fused) {
-        hipLaunchKernelGGL(v3_vote_kernel<true>, dim3((unsigned)A.wgs), dim3(V3_THREADS), lds_vote, st, A);
-        CPPF_CHECK_LAUNCH();
-    } else {
-        // super-rounds of bin_sr x 512 pairs: as long as possible, but two workgroups for every CU first
-        int64_t srb = n_ppfs / ((int64_t)V3_BIN_THREADS * 512);
-        srb = srb < 1 ? 1 : (srb > V3_BIN_SR ? V3_BIN_SR : srb);
-        A.bin_sr = (int)srb;
-        const int64_t rounds = (n_ppfs + V3_BIN_THREADS * srb - 1) / (V3_BIN_THREADS * srb);
-        const size_t lds_bin = (size_t)V3_STAGE * 16 + VOTE_BELOW_N * 16 + 2 * VOTE_MAX_TILES * 4 + 64 + (V3_BIN_THREADS / 64) * (V3_IRING * 2 + (64 * V3_BIN_SR + 64) * 4);
-        hipLaunchKernelGGL(v3_bin_kernel, dim3((unsigned)(rounds < 512 ? rounds : 512)), dim3(V3_BIN_THREADS), lds_bin, st, A);
-        CPPF_CHECK_LAUNCH();
-        hipLaunchKernelGGL(v3_vote_kernel<false>, dim3((unsigned)A.wgs), dim3(V3_THREADS), lds_vote, st, A);
-        CPPF_CHECK_LAUNCH();
-    }
+    // super-rounds of bin_sr x 512 pairs: as long as possible, but two workgroups for every CU first
+    int64_t srb = n_ppfs / ((int64_t)V3_BIN_THREADS * 512);
+    srb = srb < 1 ? 1 : (srb > V3_BIN_SR ? V3_BIN_SR : srb);
+    A.bin_sr = (int)srb;
+    const int64_t rounds = (n_ppfs + V3_BIN_THREADS * srb - 1) / (V3_BIN_THREADS * srb);
+    const size_t lds_bin = (size_t)V3_STAGE * 16 + VOTE_BELOW_N * 16 + 2 * VOTE_MAX_TILES * 4 + 64 + (V3_BIN_THREADS / 64) * (V3_IRING * 2 + (64 * V3_BIN_SR + 64) * 4);
+    const dim3 bin_grid((unsigned)(rounds < 512 ? rounds : 512));
     const int bps = red_blocks / A.t_cap;
     // (two workgroups of 16 waves fill a CU: at most one round of blocks, each looping over its items)
-    hipLaunchKernelGGL(v3_reduce_kernel, dim3((unsigned)(red_blocks < 2 * V3_WGS ? red_blocks : 2 * V3_WGS)), dim3(64 * RED_GROUPS), 0, st, A, bps);
-    CPPF_CHECK_LAUNCH();
+    const dim3 red_grid((unsigned)(red_blocks < 2 * V3_WGS ? red_blocks : 2 * V3_WGS));
+    // n_rots <= 72: one pass.  More (a reference knob, nocs/inference.py:39 --num_rots): pass w votes rotations [72 w, 72 w + 72) of
+    // every pair with the WIDE kernels and ADDS to the grid of the passes before it; the arg-max the last pass reports is the
+    // arg-max of the whole vote.  Integer images (grid_raw) need one scale for all passes: fixed here unless the caller fixed it.
+    if (wide && A.grid_raw && !A.kk_force) A.kk_force = v3_fixed_bits_bound(n_ppfs, n_rots, gx, gy, gz);
+    for (int wb = 0; wb < n_rots; wb += VOTE_WIN) {
+        A.win_base = wb;
+        if (wb > 0) A.accumulate = 1;
+        if (A.fused) {
+            if (wide) hipLaunchKernelGGL((v3_vote_kernel<true, true>), dim3((unsigned)A.wgs), dim3(V3_THREADS), lds_vote, st, A);
+            else hipLaunchKernelGGL((v3_vote_kernel<true, false>), dim3((unsigned)A.wgs), dim3(V3_THREADS), lds_vote, st, A);
+            CPPF_CHECK_LAUNCH();
+        } else {
+            if (wide) hipLaunchKernelGGL(v3_bin_kernel<true>, bin_grid, dim3(V3_BIN_THREADS), lds_bin, st, A);
+            else hipLaunchKernelGGL(v3_bin_kernel<false>, bin_grid, dim3(V3_BIN_THREADS), lds_bin, st, A);
+            CPPF_CHECK_LAUNCH();
+            if (wide) hipLaunchKernelGGL((v3_vote_kernel<false, true>), dim3((unsigned)A.wgs), dim3(V3_THREADS), lds_vote, st, A);
+            else hipLaunchKernelGGL((v3_vote_kernel<false, false>), dim3((unsigned)A.wgs), dim3(V3_THREADS), lds_vote, st, A);
+            CPPF_CHECK_LAUNCH();
+        }
+        hipLaunchKernelGGL(v3_reduce_kernel, red_grid, dim3(64 * RED_GROUPS), 0, st, A, bps);
+        CPPF_CHECK_LAUNCH();
+    }
     return 0;
 }
 
 __global__ void zero_u64x2_kernel(unsigned long long* p) { p[0] = 0ull; p[1] = 0ull; }
 
-#define VOTE_LDS_HEAD ((VOTE_THREADS / 64) * VOTE_RING * 2 + VOTE_CARRY_CAP * 4 + (VOTE_THREADS / 64) * VOTE_PAIRQ * 4 + 64 + 512 + VOTE_BELOW_N * 16)
+// Grids that would need more than 64 LDS tiles (> 1.9 M cells; none of the reference's categories comes close): the reference's own
+// formulation, models/voting.py:8-66 line by line -- one thread per pair, a loop over its rotations, global fp32 atomicAdd.  Same
+// arithmetic as the tiled path (exact frame, correctly rounded division, fp64 bound tests), so the same votes land in the same
+// cells; the sums differ from the tiled path's by fp32 atomic order, like the reference's own.
+__global__ __launch_bounds__(256) void vote_global_kernel(const float* __restrict__ points, const float* __restrict__ outputs,
+                                                          const float* __restrict__ probs, const void* __restrict__ point_idxs, int idx64,
+                                                          float* __restrict__ grid, const float* __restrict__ corner, float res,
+                                                          int64_t n_ppfs, int n_rots, int gx, int gy, int gz, int adaptive)
+{
+    const f3 cr = {corner[0], corner[1], corner[2]};
+    const int64_t syz = (int64_t)gy * gz;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_ppfs; p += (int64_t)gridDim.x * blockDim.x) {
+        const float2 o = reinterpret_cast<const float2*>(outputs)[p];
+        int2 ij;
+        if (idx64) { const longlong2 v = reinterpret_cast<const longlong2*>(point_idxs)[p]; ij = make_int2((int)v.x, (int)v.y); }
+        else ij = reinterpret_cast<const int2*>(point_idxs)[p];
+        f3 a, ab, xd;
+        if (!pair_frame(points, ij.x, ij.y, a, ab, xd)) continue;                                  // :21
+        const f3 cc = sub3(a, scl3(ab, o.x));                                                      // :23
+        const float prob = probs ? fmaxf(probs[ij.x], probs[ij.y]) : 1.f;                          // :25
+        const f3 x = scl3(xd, o.y), y = cross3(x, ab);                                             // :28-29
+        int n = n_rots;
+        if (adaptive) n = min((int)((double)(o.y / res) * (2 * CPPF_PI)), n_rots);                 // :31
+        for (int i = 0; i < n; ++i) {
+            const float2 cs = rot_cs(i, n);                                                        // :33
+            const f3 v = sub3(add3(cc, add3(scl3(x, cs.x), scl3(y, cs.y))), cr);                   // :34, numerator of :35
+            const f3 g = {v.x / res, v.y / res, v.z / res};                                        // :35 (IEEE division)
+            if ((double)g.x < 0.01 || (double)g.y < 0.01 || (double)g.z < 0.01 || (double)g.x >= (double)gx - 1.01 ||
+                (double)g.y >= (double)gy - 1.01 || (double)g.z >= (double)gz - 1.01) continue;    // :36-39
+            const int fx = (int)g.x, fy = (int)g.y, fz = (int)g.z;                                 // :40
+            const float rx = g.x - floorf(g.x), ry = g.y - floorf(g.y), rz = g.z - floorf(g.z);    // :42
+            const float w0x = 1.f - rx, w0y = 1.f - ry, w0z = 1.f - rz;
+            float* b = grid + ((int64_t)fx * syz + (int64_t)fy * gz + fz);
+            atomicAdd(b, w0x * w0y * w0z * prob);                 atomicAdd(b + 1, w0x * w0y * rz * prob);          // :47-63
+            atomicAdd(b + gz, w0x * ry * w0z * prob);             atomicAdd(b + gz + 1, w0x * ry * rz * prob);
+            atomicAdd(b + syz, rx * w0y * w0z * prob);            atomicAdd(b + syz + 1, rx * w0y * rz * prob);
+            atomicAdd(b + syz + gz, rx * ry * w0z * prob);        atomicAdd(b + syz + gz + 1, rx * ry * rz * prob);
+        }
+    }
+}
 
 // shape_dev != null: gx, gy, gz, n_points are CAPACITIES (gx*gy*gz = cells of grid_obj) and the real values come from the
 // device record; only the tiled path exists in that mode.
@@ -2517,95 +1765,39 @@ static int vote_impl(const float* points, const float* outputs, const float* pro
     if (n_ppfs > 0 && (!outputs || !point_idxs)) return CPPF_EINVAL;
     if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || gx < 1 || gy < 1 || gz < 1 || n_ppfs < 0 || n_points < 1) return CPPF_EINVAL;
     if ((int64_t)gx * gy * gz > 0x7fffffffll) return CPPF_EINVAL;
-    if (shape_dev ? (n_ppfs >= 1 && grid_cap >= 1 && grid_cap <= 0x7fffffffll && tri(n_rots) <= VOTE_TAB_LDS_MAX &&
-                     getenv("CPPF_VOTE_LEGACY") == nullptr && workspace && workspace_bytes >= v3_workspace_bytes_dyn(many_tiles, n_ppfs))
-                  : (v3_eligible(n_ppfs, n_rots, gx, gy, gz) && workspace && workspace_bytes >= v3_workspace_bytes(n_ppfs, gx, gy, gz)))
+    if (shape_dev) {
+        if (n_ppfs < 1 || n_ppfs > 0xffffffffll || grid_cap < 1 || grid_cap > 0x7fffffffll) return CPPF_EINVAL;
+        if (!workspace || workspace_bytes < v3_workspace_bytes_dyn(many_tiles, n_ppfs)) return CPPF_EWORKSPACE;
         return v3_launch(points, outputs, probs, point_idxs, idx_is_i64, grid_obj, corner, res, n_points, n_ppfs, n_rots, gx, gy, gz,
                          adaptive, accumulate, want_argmax, out_idx, out_val, workspace, st, shape_dev, grid_cap, many_tiles, ex);
+    }
+    if (v3_eligible(n_ppfs, n_rots, gx, gy, gz)) {
+        if (!workspace || workspace_bytes < v3_workspace_bytes(n_ppfs, gx, gy, gz)) return CPPF_EWORKSPACE;
+        return v3_launch(points, outputs, probs, point_idxs, idx_is_i64, grid_obj, corner, res, n_points, n_ppfs, n_rots, gx, gy, gz,
+                         adaptive, accumulate, want_argmax, out_idx, out_val, workspace, st, nullptr, 0, 0, ex);
+    }
     if (ex) return workspace && n_ppfs > 0 ? CPPF_EUNSUPPORTED : CPPF_EWORKSPACE;   // the integer image exists on the tiled integer path only
-    VotePlan pl;
-    if (shape_dev) {
-        if (n_ppfs < 1 || grid_cap < 1 || grid_cap > 0x7fffffffll) return CPPF_EINVAL;
-        pl = VotePlan{};
-        pl.tiled = 1;
-        pl.tab_entries = tri(n_rots);
-        pl.T = many_tiles ? VOTE_MAX_TILES : 3;                       // most tiles this launch geometry serves
-        pl.chunks = (many_tiles ? VOTE_WGS_MANY : VOTE_WGS_FEW);      // workgroups launched (>= T * chunks of any plan)
-        pl.part_off = VOTE_WS_LEGACY_PART;
-        pl.total = cppf_vote_workspace_bytes_dyn(many_tiles);
-    } else {
-        pl = make_vote_plan(n_ppfs, n_rots, gx, gy, gz);
+    // ---- no pairs, or a grid beyond 64 tiles: global atomics (+ the plain arg-max kernel)
+    if (!workspace || workspace_bytes < 256) return CPPF_EWORKSPACE;
+    const int64_t G = (int64_t)gx * gy * gz;
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(grid_obj, 0, (size_t)G * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
     }
-    if (!workspace || workspace_bytes < pl.total) return CPPF_EWORKSPACE;
-    char* ws = static_cast<char*>(workspace);
-    unsigned long long* packed = reinterpret_cast<unsigned long long*>(ws + pl.packed_off);
-    float* partials = reinterpret_cast<float*>(ws + pl.part_off);
-    const int64_t G = shape_dev ? grid_cap : (int64_t)gx * gy * gz;
-
-    VoteArgs A;
-    A.points = points; A.outputs = outputs; A.probs = probs; A.point_idxs = point_idxs; A.idx64 = idx_is_i64;
-    A.grid = grid_obj; A.partials = partials; A.corner = corner; A.packed = packed;
-    A.res = res; A.n_ppfs = n_ppfs; A.n_rots = n_rots; A.gx = gx; A.gy = gy; A.gz = gz; A.adaptive = adaptive;
-    A.tx = pl.tx; A.ty = pl.ty; A.ntx = pl.ntx; A.nty = pl.nty; A.T = pl.T; A.chunk_pairs = pl.chunk_pairs;
-    A.tab_entries = pl.tab_entries;
-    A.n_points = n_points;
-    A.kk = shape_dev ? 0 : vote_fixed_bits(pl, n_rots);
-    A.shape = shape_dev; A.grid_cap = grid_cap;
-    const bool tab_lds = pl.tab_entries <= VOTE_TAB_LDS_MAX;
-    const size_t tab_bytes = tab_lds ? (size_t)(pl.tab_entries + 2) * sizeof(float2) : 0;
-    if (pl.tiled) {
-        const size_t lds = VOTE_LDS_HEAD + VOTE_TILE_FLOATS * sizeof(float) + tab_bytes;
-        dim3 grid(shape_dev ? pl.chunks : pl.T * pl.chunks);
-        if (tab_lds) {
-            static bool attr_done = false;
-            if (!attr_done) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vote_kernel<true, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                attr_done = true;
-            }
-            hipLaunchKernelGGL((vote_kernel<true, true>), grid, dim3(VOTE_THREADS), lds, st, A);
-        } else {
-            static bool attr_done = false;
-            if (!attr_done) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vote_kernel<true, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                attr_done = true;
-            }
-            hipLaunchKernelGGL((vote_kernel<true, false>), grid, dim3(VOTE_THREADS), lds, st, A);
-        }
-    } else {
-        if (!accumulate) {  // global atomics add into the grid: an overwrite request zeroes it first
-            hipError_t e = hipMemsetAsync(grid_obj, 0, (size_t)G * sizeof(float), st);
-            if (e != hipSuccess) return (int)e;
-        }
-        int64_t nb = (n_ppfs + VOTE_THREADS - 1) / VOTE_THREADS;
-        if (nb > 2048) nb = 2048;
-        if (nb < 1) nb = 1;
-        if (tab_lds)
-            hipLaunchKernelGGL((vote_kernel<false, true>), dim3((unsigned)nb), dim3(VOTE_THREADS),
-                               VOTE_LDS_HEAD + tab_bytes, st, A);
-        else
-            hipLaunchKernelGGL((vote_kernel<false, false>), dim3((unsigned)nb), dim3(VOTE_THREADS), VOTE_LDS_HEAD, st, A);
-    }
-    CPPF_CHECK_LAUNCH();
-
-    if (pl.tiled) {
-        RedArgs R;
-        R.grid = grid_obj; R.partials = partials; R.packed = packed;
-        R.out_idx = want_argmax ? out_idx : nullptr; R.out_val = want_argmax ? out_val : nullptr;
-        R.gx = gx; R.gy = gy; R.gz = gz; R.tx = pl.tx; R.ty = pl.ty; R.nty = pl.nty; R.T = pl.T; R.chunks = pl.chunks;
-        R.accumulate = accumulate;
-        R.shape = shape_dev; R.n_ppfs = n_ppfs; R.grid_cap = grid_cap; R.n_points_cap = n_points; R.t_max = pl.T;
-        // blocks per tile: the largest tile's cells (a *_dyn launch cannot know them: a full LDS tile)
-        const int slot = shape_dev ? VOTE_TILE_FLOATS : ((pl.tx * pl.ty * gz + 3) & ~3);
-        R.bps = ((slot + RED_CELLS - 1) / RED_CELLS + RED_FANIN - 1) / RED_FANIN * RED_FANIN;   // a multiple of the arg-max fan-in
-        hipLaunchKernelGGL(reduce_tiles_kernel, dim3((unsigned)(pl.T * R.bps)), dim3(64 * RED_GROUPS), 0, st, R);
+    if (n_ppfs > 0) {
+        int64_t nb = (n_ppfs + 255) / 256;
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(vote_global_kernel, dim3((unsigned)nb), dim3(256), 0, st, points, outputs, probs, point_idxs, idx_is_i64, grid_obj,
+                           corner, res, n_ppfs, n_rots, gx, gy, gz, adaptive);
         CPPF_CHECK_LAUNCH();
-    } else if (want_argmax) {
+    }
+    if (want_argmax) {
+        unsigned long long* packed = static_cast<unsigned long long*>(workspace);
+        hipLaunchKernelGGL(zero_u64x2_kernel, dim3(1), dim3(1), 0, st, packed);
         int64_t nb = (G + 63) / 64;
         if (nb > RED_MAX_BLOCKS) nb = RED_MAX_BLOCKS;
-        hipLaunchKernelGGL(reduce_argmax_kernel, dim3((unsigned)nb), dim3(64 * RED_GROUPS), 0, st, grid_obj,
-                           (const float*)nullptr, 0, G, packed, 1, 0, out_idx, out_val);
+        hipLaunchKernelGGL(reduce_argmax_kernel, dim3((unsigned)nb), dim3(64 * RED_GROUPS), 0, st, grid_obj, (const float*)nullptr, 0, G,
+                           packed, 1, 0, out_idx, out_val);
         CPPF_CHECK_LAUNCH();
     }
     return 0;
@@ -2673,15 +1865,13 @@ extern "C" int cppf_grid_from_raw(const long long* grid_raw, int64_t n, const fl
     return out_idx ? cppf_grid_argmax(grid, n, out_idx, out_val, workspace, workspace_bytes, stream) : 0;
 }
 
-extern "C" int cppf_vote_tile_cells(void) { return V3_TILE_FLOATS > VOTE_TILE_FLOATS ? V3_TILE_FLOATS : VOTE_TILE_FLOATS; }
+extern "C" int cppf_vote_tile_cells(void) { return V3_TILE_FLOATS; }
 
-// tiles of the grid in the tiled vote: the larger of the two kernels' decompositions (binned path: 128 KiB tiles with a halo;
-// round-2 kernels, n_rots > 72: 113 KiB), so that a capacity class chosen from it serves both; 0: global-atomics path
+// tiles of the grid in the tiled vote (120 KiB LDS tiles with a one-cell halo on their cut sides); 0: global-atomics path
 extern "C" int cppf_vote_tiles(int gx, int gy, int gz)
 {
     if (gx < 1 || gy < 1 || gz < 1) return CPPF_EINVAL;
-    const int a = vote_tiling(gx, gy, gz).T, b = v3_tiling(gx, gy, gz).T;
-    const int T = a > b ? a : b;
+    const int T = v3_tiling(gx, gy, gz).T;
     return T <= VOTE_MAX_TILES ? T : 0;
 }
 

@@ -67,7 +67,9 @@ const char* cppf_error_string(int code);
  * tile's queue of (pair, candidate runs) records that a binning kernel filled -- with 32-bit fixed-point LDS atomics
  * (fp32-exact quantum, see csrc/vote.hip); the raw tiles are written to `workspace` and summed AS INTEGERS into grid_obj by a
  * last kernel that also yields the arg-max (cppf_vote_argmax): the grid is the exact sum of the quantised deposits, the same
- * bits on every run.  Grids that would need more than 64 tiles fall back to global fp32 atomics.
+ * bits on every run.  n_rots > 72 (nocs/inference.py:39 --num_rots) runs ceil(n_rots / 72) passes of the same kernels, pass w voting
+ * rotations [72 w, 72 w + 72) of every pair and adding to the grid.  Grids that would need more than 64 tiles fall back to the
+ * reference's own formulation with global fp32 atomics.
  * `workspace`: cppf_vote_workspace_bytes() bytes, DEDICATED to the vote and zero on first use (see the note on workspaces at
  * the top and cppf_vote_workspace_init_bytes below).
  * ------------------------------------------------------------------------------------------- */
@@ -178,10 +180,9 @@ int cppf_compact_mask(const uint8_t* mask, int64_t n, int32_t* surv, int32_t* co
  * ------------------------------------------------------------------------------------------- */
 int cppf_vote_tiles(int gx, int gy, int gz);
 int cppf_vote_tile_cells(void);   /* cells of one LDS tile: a launch serves grids of up to 3 (64 with many_tiles) times that */
-size_t cppf_vote_workspace_bytes_dyn(int many_tiles);
-/* The same with room for the pair -> tile queues of the binned vote path (n_ppfs records of 12 B for every tile of the class):
- * give cppf_vote_argmax_dyn this many bytes to run the round-3 kernels; with only cppf_vote_workspace_bytes_dyn() bytes it
- * runs the round-2 kernels. */
+/* Workspace of a *_dyn vote launch: the state block, the pair -> tile queues of the many-tile class (n_ppfs records of 12 B for
+ * every tile of the class: sized for the worst case, every pair in every tile) and one partial tile per workgroup.
+ * (ABI 1 had a second, smaller size that selected round 2's kernels; those are gone.) */
 size_t cppf_vote_workspace_bytes_dyn_pairs(int many_tiles, int64_t n_ppfs);
 /* The vote workspace keeps state between calls (queue counters and the plane of fixed-point wrap-arounds, see the note on
  * workspaces above): its first min(cppf_vote_workspace_init_bytes(), size) bytes must be ZERO before the first call on a
@@ -189,8 +190,8 @@ size_t cppf_vote_workspace_bytes_dyn_pairs(int many_tiles, int64_t n_ppfs);
  * was never initialised report arg-max -1 / peak NaN -- every one of them, until the caller zeroes those bytes. */
 size_t cppf_vote_workspace_init_bytes(void);
 /* What a by-value vote launch will do for this problem (tests, tools): out int32[10] = {path, tiles, tx, ty, ntx, nty, halo_x,
- * halo_y, workgroups, fixed-point bits}; path 0: global fp32 atomics (> 64 tiles), 1: round-2 tiled kernels (n_rots > 72),
- * 2: fused kernel (< 4 tiles), 3: binning + queue-consuming kernels (>= 4 tiles).  Host only, no device needed. */
+ * halo_y, workgroups, fixed-point bits}; path 0: global fp32 atomics (> 64 tiles), 2: fused kernel (< 4 tiles), 3: binning +
+ * queue-consuming kernels (>= 4 tiles); (1 was round 2's kernels: gone).  Host only, no device needed. */
 int cppf_vote_plan_query(int64_t n_ppfs, int n_rots, int gx, int gy, int gz, int32_t* out);
 int cppf_vote_argmax_dyn(const float* points, const float* outputs, const float* probs, const void* point_idxs,
                          int idx_is_i64, float* grid_obj, int64_t grid_capacity, const float* corner, float res,

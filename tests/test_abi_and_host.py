@@ -36,15 +36,16 @@ def test_workspace_queries_and_argument_errors_without_a_device():
     lo = 256 * slot * 4 + 64 * 30720 * 8      # fewer than 4 tiles: no queues; + the extra plane, sized for any tiled grid
     assert lo <= need < lo + (1 << 17)
     assert 65536 < L.cppf_vote_workspace_init_bytes() <= need
-    # n_rots > 72 keeps the round-2 kernels: 128 chunks of fp32 partial grids, no queues
-    G = 26 * 76 * 26
-    need2 = L.cppf_vote_workspace_bytes(524288, 100, 26, 76, 26)
-    state = 64 * 30720 * 8 + 8704                                        # (behind the binned path's state, which they leave intact)
-    assert need2 >= 128 * G * 4 + state and need2 < 129 * G * 4 + state
+    # n_rots > 72 runs the same kernels in ceil(n_rots / 72) passes: the same workspace (round 2's kernels are gone)
+    assert L.cppf_vote_workspace_bytes(524288, 100, 26, 76, 26) == need == L.cppf_vote_workspace_bytes(524288, 360, 26, 76, 26)
+    plan = (C.c_int32 * 10)()
+    assert L.cppf_vote_plan_query(524288, 144, 26, 76, 26, plan) == 0 and plan[0] == 2 and plan[1] == 2      # fused, two tiles
+    assert L.cppf_vote_plan_query(2097152, 144, 52, 152, 52, plan) == 0 and plan[0] == 3 and plan[1] == 16   # binned
+    assert L.cppf_vote_plan_query(1000, 72, 400, 400, 400, plan) == 0 and plan[0] == 0                      # global atomics
     assert L.cppf_vote_workspace_bytes(100, 0, 26, 76, 26) == 0          # n_rots out of range
     assert L.cppf_vote_workspace_bytes(100, 361, 26, 76, 26) == 0
-    # huge grid -> global-atomic path: only table + scratch
-    assert L.cppf_vote_workspace_bytes(524288, 72, 400, 400, 400) < 1 << 20
+    # huge grid -> global-atomic path: the arg-max keys only, but never less than the state a tiled call would want zeroed
+    assert L.cppf_vote_workspace_bytes(524288, 72, 400, 400, 400) == L.cppf_vote_workspace_init_bytes()
     assert L.cppf_compact_workspace_bytes(0) > 0 and L.cppf_reduce_workspace_bytes() > 0
     # null pointers / bad sizes are rejected before any HIP call
     assert L.cppf_ppf_voting(None, None, None, None, None, None, 0.004, 4, 10, 72, 4, 4, 4, 1, None, 0, None) == -1
@@ -317,7 +318,7 @@ def test_shape_polymorphic_plan_queries_without_a_device():
     # the dyn workspace holds the partial tiles of ANY plan its launch geometry can meet
     few, many = L.cppf_vote_workspace_bytes_dyn_pairs(0, 524288), L.cppf_vote_workspace_bytes_dyn_pairs(1, 2 ** 21)
     assert few >= L.cppf_vote_workspace_bytes(524288, 72, 26, 76, 26) and many >= L.cppf_vote_workspace_bytes(2 ** 21, 72, 52, 152, 52)
-    assert few > L.cppf_vote_workspace_bytes_dyn(0) >= L.cppf_vote_workspace_bytes(524288, 100, 26, 76, 26)   # (round-2 kernels)
+    assert few >= L.cppf_vote_workspace_bytes(524288, 100, 26, 76, 26)     # (n_rots > 72: the same kernels, several passes)
     # entry points reject a missing shape record before any HIP call
     assert L.cppf_vote_argmax_dyn(None, None, None, None, 0, None, 100, None, 0.004, 4, 10, 72, None, 0, 1, 0, None, None,
                                   None, 0, None) == -1
@@ -405,12 +406,12 @@ def test_vote_plans_respect_their_invariants_without_a_device():
             assert T <= wgs <= 1024 and 8 <= bits <= 24
             slot = ((tx + hx) * (ty + hy) * gz + 3) // 4 * 4
             assert need >= wgs * slot * 4 + (T * P * 12 if path == 3 else 0)
-            assert T == L.cppf_vote_tiles(gx, gy, gz) or L.cppf_vote_tiles(gx, gy, gz) > T     # (the query reports the larger of the two kernels' needs)
-        elif path == 1:                      # a tall grid whose tile + halo does not fit but round 2's halo-less tile does
-            assert 1 <= T <= 64 and wgs >= T and need > 1 << 20
+            assert T == L.cppf_vote_tiles(gx, gy, gz)
         else:
-            assert path == 0 and need < 1 << 20                              # > 64 tiles: global atomics
-        # n_rots > 72 never takes the round-3 kernels
-        assert L.cppf_vote_plan_query(P, 100, gx, gy, gz, out) == 0 and out[0] in (0, 1)
+            assert path == 0 and need == L.cppf_vote_workspace_init_bytes()  # > 64 tiles: global atomics
+        # n_rots > 72 takes the same path (several passes of the same kernels), with the same workspace
+        first = list(out)
+        assert L.cppf_vote_plan_query(P, 100, gx, gy, gz, out) == 0 and list(out)[:9] == first[:9]
+        assert L.cppf_vote_workspace_bytes(P, 100, gx, gy, gz) == need
     assert {2, 3} <= seen
     assert L.cppf_vote_plan_query(10, 72, 0, 4, 4, out) == -1 and L.cppf_vote_plan_query(10, 72, 4, 4, 4, None) == -1

@@ -281,11 +281,47 @@ def test_integer_vote_rejects_what_it_cannot_serve(dev):
     q = torch.zeros(1, dtype=torch.float32, device=dev)
     with pytest.raises(_lib.CppfError):
         voting.vote_grid_raw(pc, o, None, i32, raw, q, corner, 4e-3, 72, True, fixed_bits=25)      # bits beyond fp32 deposits
+    big = torch.zeros((300, 300, 300), dtype=torch.int64, device=dev)
     with pytest.raises(_lib.CppfError):
-        voting.vote_grid_raw(pc, o, None, i32, raw, q, corner, 4e-3, 100, True)                    # n_rots > 72: no integer path yet
+        voting.vote_grid_raw(pc, o, None, i32, big, q, corner, 4e-3, 72, True)                     # > 64 tiles: no integer path (global fp32 atomics)
     # negative probs: the launch accumulates in fp32 -> quantum 0 flags the image as not valid, the converted grid is NaN
     probs = torch.full((600,), -1.0, dtype=torch.float32, device=dev)
     voting.vote_grid_raw(pc, o, probs, i32, raw, q, corner, 4e-3, 72, True)
     assert float(q) == 0.0
     g, gi, gv = voting.grid_from_raw(raw, q)
     assert bool(torch.isnan(g).all())
+
+
+# --------------------------------------------------------------------------- more than 72 rotations (nocs/inference.py:39 --num_rots)
+@pytest.mark.parametrize("n,k,res,n_rots,adaptive", [(4096, 128, 4e-3, 144, True), (4096, 64, 4e-3, 360, False), (8192, 64, 2e-3, 144, True),
+                                                     (2048, 40, 2e-3, 100, False), (1500, 40, 4e-3, 73, True)])
+def test_more_than_72_rotations_run_as_passes_of_the_same_kernels(oracle, dev, n, k, res, n_rots, adaptive):
+    """n_rots > 72 = ceil(n_rots / 72) passes of the fused / binned kernels over windows of 72 rotation indices (round 2's kernels, kept
+    for this until round 3, are gone): config-size clouds, fused and binned grids, adaptive on and off.  Every cell against the exact
+    fp64 vote sum (half a quantum per deposit), the arg-max identical, and the integer image EQUAL to the oracle's fixed-point vote."""
+    from cppf_amd.inference import grid_shape
+    ob, idx, out = case(n=n, k=k, seed=21)
+    corners, dims = grid_shape(ob["pc"], res)
+    P = idx.shape[0]
+    L = _lib.lib()
+    plan = (C.c_int32 * 10)()
+    assert L.cppf_vote_plan_query(P, n_rots, *[int(d) for d in dims], plan) == 0 and plan[0] in (2, 3)
+    gg, flat, peak = run_vote(dev, ob["pc"], out, idx, corners[0], dims, res, n_rots, adaptive)
+    g64, cnt = oracle.ppf_voting_f64(ob["pc"], out, np.ones(n, np.float32), idx, dims, corners[0], res, n_rots, adaptive)
+    passes = -(-n_rots // 72)
+    q = 2.0 ** -8                                            # (the coarsest quantum any pass may have chosen)
+    bits = voting.vote_fixed_point_bits(P, n_rots, dims)
+    tol = 2e-6 * np.abs(g64) * passes + cnt * 0.5 * 2.0 ** -bits + 1e-30
+    err = np.abs(gg.astype(np.float64) - g64)
+    assert np.all(err <= tol), f"max excess {np.max(err - tol)} at {np.unravel_index(np.argmax(err - tol), err.shape)}"
+    assert flat == int(np.argmax(g64)) and peak == gg.max() and g64.max() > 100
+    if not adaptive:
+        assert cnt.sum() > 72 * 8 * P * 0.05                 # far more deposits than 72 rotations could make
+    # the integer image: one scale for all passes, equal to the oracle's statement
+    pc, o, i32, corner = t(ob["pc"], dev), t(out, dev), t(idx, dev), t(corners[0], dev)
+    raw = torch.empty(dims, dtype=torch.int64, device=dev)
+    qd = torch.zeros(1, dtype=torch.float32, device=dev)
+    voting.vote_grid_raw(pc, o, None, i32, raw, qd, corner, res, n_rots, adaptive)
+    used = int(round(-np.log2(float(qd))))
+    want, _ = oracle.ppf_voting_fixed(ob["pc"], out, np.ones(n, np.float32), idx, dims, corners[0], res, n_rots, adaptive, used)
+    assert np.array_equal(raw.cpu().numpy(), want)
