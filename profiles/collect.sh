@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+BENCH="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --min-seconds 0.3"
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt -- $BENCH > $OUT/bench_under_trace.log 2>&1
 python $R/profiles/kstats.py $(find /tmp/kt -name '*.db' | head -1) > $OUT/kernel_trace_stats.txt 2>&1
 # the same chain with ONE object in flight: every launch alone on the chip, so a kernel's average here is its own duration (in the
@@ -22,7 +22,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_s
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" \
            "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAVE_CYCLES"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc$i -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > /tmp/pmc$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc$i -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --regions 5 > /tmp/pmc$i.log 2>&1
   f=$(find /tmp/pmc$i -name '*counter_collection.csv' | head -1)
   python $R/profiles/pmcstats.py $f >> $OUT/pmc_counters.txt
 done
