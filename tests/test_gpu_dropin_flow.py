@@ -115,3 +115,25 @@ def test_script_style_instance_equals_fused_pipeline(dev, cat):
     np.testing.assert_allclose(fused["scale"], scale, rtol=2e-5)              # fp32 mean in torch vs fp64 sums here
     if cfg.regress_right:
         np.testing.assert_allclose(fused["best_right"] * np.sign(fused["best_right"] @ axes["right"]), axes["right"], atol=1e-9)
+
+
+def test_reference_call_sequence_recovers_a_trained_pose(dev):
+    """cppf_amd/dropin.py -- the per-instance body of nocs/inference.py:177-339 with its own stage order, launch tuples, host round
+    trips, torch.multinomial and np.random.shuffle, only the two imports switched -- on a held-out posed object with the trained
+    networks: the pose it finds is the true one, like the fused estimate_pose (same networks, its own random draws)."""
+    import os
+    from conftest import GOLDEN
+    from cppf_amd import training
+    from cppf_amd.dropin import reference_style_instance
+    sph = np.array(fibonacci_sphere(num_sphere_bins(TOL_DEG)))
+    for cat, seed in (("bottle", 900011), ("mug", 900012)):
+        cfg = syn.CATEGORIES[cat]
+        penc, enc = training.load_weights(os.path.join(GOLDEN, f"trained_{cat}.npz"), cfg, dev)
+        ob = syn.make_posed_object(cat, 1400, seed)
+        torch.manual_seed(1)
+        pose = reference_style_instance(penc, enc, ob["pc"], ob["normals"], cfg, sph, n_pairs=100000, rng=np.random.RandomState(3))
+        e1 = training.pose_errors(pose, ob)
+        e2 = training.pose_errors(training.infer(penc, enc, ob, dev, seed=5, sphere=sph), ob)
+        for e in (e1, e2):
+            assert e["t_cells"] <= 3.0 and e["up_deg_mod_sign"] <= 10.0 and e["scale_rel"] <= 0.2, (cat, e1, e2)
+        assert pose["n_surv"] > 5000
