@@ -433,7 +433,26 @@ def run_c1(args):
         out["gpu_same_workload"] = {"ms_per_step": m["elapsed"] / args.steps * 1e3, "pairs_per_s": args.steps * m["P"] / m["elapsed"],
                                     "median_ms_one_instance": m["lat"][len(m["lat"]) // 2],
                                     "argmax_matches_cpu": bool(int(m["allrec"][0, 12].item()) == int(flat))}
-    print(json.dumps(out))
+    emit(out)
+
+
+def emit(line):
+    """rank 0's ONE JSON line, as the LAST line of stdout: RCCL prints a version banner through C stdio when its first communicator
+    is created; with stdout redirected that text sits in libc's buffer until exit and would land BEHIND the JSON line -- so the
+    C buffers are flushed first, then the line is written and flushed."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    if torch.distributed.is_initialized():       # (anything the collective library says on its way out comes first, too)
+        torch.distributed.destroy_process_group()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+    sys.stdout.write(json.dumps(line) + "\n")
+    sys.stdout.flush()
 
 
 def dist_info(world):
@@ -478,7 +497,7 @@ def main():
         m = run_c4(dev, rank, world, args)
         if rank == 0:
             total_pairs = m["reps"] * m["n_objects"] * m["P"]
-            print(json.dumps({
+            emit({
                 "metric": METRIC, "value": total_pairs / m["elapsed"], "unit": "pairs/s", "n_gpus": world,
                 "steps": m["reps"] * m["n_objects"], "warmup": args.warmup,
                 "ms_per_step": m["elapsed"] / (m["reps"] * m["n_objects"]) * 1e3, "higher_is_better": True, "scaling": "strong",
@@ -491,7 +510,7 @@ def main():
                            "objects": m["n_objects"], "objects_per_gpu": m["n_objects"] / world, "parallelism": f"objects x{world}"},
                 "objects_per_s": m["reps"] * m["n_objects"] / m["elapsed"],
                 "regions": len(m["regions"]), "region_ms_min_max": [m["regions"][0] * 1e3, m["regions"][-1] * 1e3],
-                "dist": dist_info(world)}))
+                "dist": dist_info(world)})
         if torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
         return
@@ -964,7 +983,7 @@ def main():
                 o1 = cpu_object(1024, 64, seed=0)
                 _, c1 = cpu_baseline_block(o1, sd, 1024, 64, budget_s=6.0)
                 out["cpu_baseline"]["c1"] = {kk: c1[kk] for kk in ("value", "unit", "best_threads", "legs", "sample")}
-        print(json.dumps(out))
+        emit(out)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
