@@ -29,7 +29,8 @@ def run(budget, seed, dev=None):
     dev = dev or torch.device("cuda:0")
     rng = np.random.default_rng(seed)
     t0 = time.time()
-    n_v = n_b = n_k = 0
+    n_v = n_b = n_k = n_i = 0
+    L = _lib.lib()
     while time.time() - t0 < budget:
         cat = CATS[rng.integers(len(CATS))]
         n = int(rng.choice([64, 200, 512, 1024, 2048]))
@@ -57,7 +58,7 @@ def run(budget, seed, dev=None):
         corner = (corner + np.float32(rng.choice([0.0, 0.0, 0.03, -0.05]))).astype(np.float32)
         if int(np.prod(dims)) > 3_000_000:
             continue
-        n_rots = int(rng.choice([1, 7, 36, 72, 72, 72, 90]))
+        n_rots = int(rng.choice([1, 7, 36, 72, 72, 72, 73, 90, 144, 200, 360]))    # > 72: passes over windows of 72 rotations
         adaptive = bool(rng.integers(2))
         probs = None if rng.integers(3) else rng.uniform(0.1, 2.0, n).astype(np.float32)
         tag = (cat, n, k, case_seed, res, mode, n_rots, adaptive)
@@ -70,6 +71,21 @@ def run(budget, seed, dev=None):
         if srt[-1] > 0 and srt[-1] - srt[-2] > 1e-4 * srt[-1]:
             assert flat == O.grid_argmax(go)[0], tag
         n_v += 1
+        # the same vote as exact integers (tiled grids): EQUAL to the oracle's fixed-point statement, cell by cell
+        if L.cppf_vote_tiles(int(dims[0]), int(dims[1]), int(dims[2])) > 0 and P > 0:
+            raw = torch.full(tuple(int(d) for d in dims), -3, dtype=torch.int64, device=dev)
+            q = torch.zeros(1, dtype=torch.float32, device=dev)
+            fb = int(rng.choice([0, 0, 12, 24]))
+            voting.vote_grid_raw(T.t(ob["pc"], dev), T.t(outputs, dev), None if probs is None else T.t(probs, dev), T.t(idx32, dev), raw, q,
+                                 T.t(corner, dev), res, n_rots, adaptive, fixed_bits=fb)
+            qv = float(q)
+            pr = np.ones(n, np.float32) if probs is None else probs
+            p2 = 2.0 ** np.ceil(np.log2(float(pr.max())))
+            used = int(round(np.log2(p2 / qv)))
+            assert qv > 0 and (fb == 0 or used == fb), tag
+            want, qo = O.ppf_voting_fixed(ob["pc"], outputs, pr, idx32, dims, corner, res, n_rots, adaptive, used)
+            assert qo == qv and np.array_equal(raw.cpu().numpy(), want), tag
+            n_i += 1
 
         # back-vote around a plausible centre: offsets bit-exact
         center = (ob["center"] + rng.normal(0, 1.0, 3) * res).astype(np.float32)
@@ -82,7 +98,6 @@ def run(budget, seed, dev=None):
                                 P, nr, int(dims[0]), int(dims[1]), int(dims[2]), T.t(center, dev), tol))
         assert np.array_equal(out_d.cpu().numpy(), oo), tag
         # the pipelines' form: mask + survivors per chunk of 1 024 pairs, then the scatter that needs no scan
-        L = _lib.lib()
         nch = (P + 1023) // 1024
         m_d = torch.empty(P, dtype=torch.uint8, device=dev)
         cc_d = torch.zeros(nch, dtype=torch.int32, device=dev)
@@ -108,10 +123,10 @@ def run(budget, seed, dev=None):
         got = enc.neighbours(torch.from_numpy(pc2).to(dev)).cpu().numpy()
         assert np.array_equal(got, O.knn(pc2, kk)), ("knn", n, kk, case_seed)
         n_k += 1
-    return n_v, n_b, n_k
+    return n_v, n_b, n_k, n_i
 
 
 if __name__ == "__main__":
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     s = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    print("soak ok: %d vote, %d back-vote, %d kNN cases" % run(seconds, s))
+    print("soak ok: %d vote, %d back-vote, %d kNN, %d integer-image cases" % run(seconds, s))
