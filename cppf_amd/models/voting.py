@@ -5,7 +5,8 @@ they replace (models/voting.py:4,70,115):
     kernel((grid, 1, 1), (block, 1, 1), (arg0, arg1, ...))   ->   None
 
 with the same positional argument order.  Differences a caller sees:
-  * array arguments are torch tensors on a HIP device (replace `cp.asarray(x)` by a torch tensor);
+  * array arguments are torch tensors on a HIP device (replace `cp.asarray(x)` by a torch tensor) or any object exposing
+    `__cuda_array_interface__` (wrapped zero-copy);
     dtype/shape/contiguity mistakes raise TypeError/ValueError instead of corrupting memory;
   * the (grid, block) tuples are accepted and ignored -- launch geometry is the library's business
     (the reference's own grid for ppf_voting is sized by N**2, nocs/inference.py:192);
@@ -24,6 +25,15 @@ __all__ = ["ppf_kernel", "backvote_kernel", "rot_voting_kernel", "vote_argmax", 
 F32, I32 = torch.float32, torch.int32
 
 
+def _as_device_tensor(a):
+    """array arguments may be any object that exposes device memory -- a torch tensor, or anything with
+    `__cuda_array_interface__` (CuPy-style arrays, numba device arrays, rocm-aware buffers): wrapped zero-copy, so in-place
+    outputs (grid_obj, output_ocs, candidates) land in the caller's memory.  Scalars and host objects pass through unchanged."""
+    if isinstance(a, torch.Tensor) or not hasattr(a, "__cuda_array_interface__"):
+        return a
+    return torch.as_tensor(a, device="cuda")
+
+
 class _Kernel:
     def __init__(self, name, nargs, fn):
         self.name, self._nargs, self._fn = name, nargs, fn
@@ -34,7 +44,7 @@ class _Kernel:
         if len(args) != self._nargs:
             raise TypeError(f"{self.name}: expected {self._nargs} kernel arguments, got {len(args)}")
         require_cuda()
-        self._fn(*args)
+        self._fn(*(_as_device_tensor(a) for a in args))
         return None
 
     def __repr__(self):

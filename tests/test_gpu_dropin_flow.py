@@ -137,3 +137,42 @@ def test_reference_call_sequence_recovers_a_trained_pose(dev):
         for e in (e1, e2):
             assert e["t_cells"] <= 3.0 and e["up_deg_mod_sign"] <= 10.0 and e["scale_rel"] <= 0.2, (cat, e1, e2)
         assert pose["n_surv"] > 5000
+
+
+def test_kernels_accept_any_cuda_array_interface_object(dev):
+    """"accepting torch tensors (any object with data_ptr() / __cuda_array_interface__)": a foreign device array
+    (here a minimal stand-in for a CuPy array) goes through the three callables zero-copy, outputs updated in place"""
+    class Foreign:
+        def __init__(self, t):
+            self._t = t          # keeps the memory alive
+            kinds = {torch.float32: "<f4", torch.int32: "<i4"}
+            self.__cuda_array_interface__ = {"shape": tuple(t.shape), "typestr": kinds[t.dtype], "data": (t.data_ptr(), False),
+                                             "version": 2, "strides": None}
+    obj = syn.make_object("bottle", 600, 5)
+    cfg = obj["cfg"]
+    pairs = syn.make_pairs(600, 20, 5).astype(np.int32)
+    mu_nu = syn.closed_form_outputs(obj["pc"], obj["center"], pairs, cfg)
+    lo = obj["pc"].min(0)
+    dims = ((obj["pc"].max(0) - lo) / cfg.res).astype(np.int32) + 1
+    P = pairs.shape[0]
+    args_t = (_gpu(obj["pc"]), _gpu(mu_nu), torch.ones(600, device="cuda"), _gpu(pairs), None, _gpu(lo), np.float32(cfg.res), P, ROTS,
+              int(dims[0]), int(dims[1]), int(dims[2]), True)
+    g_t = torch.zeros(tuple(int(v) for v in dims), device="cuda")
+    g_f = torch.zeros_like(g_t)
+    ppf_kernel(_blocks(P), (THREADS, 1, 1), args_t[:4] + (g_t,) + args_t[5:])
+    ppf_kernel(_blocks(P), (THREADS, 1, 1), tuple(Foreign(a) if isinstance(a, torch.Tensor) else a for a in args_t[:4]) + (Foreign(g_f),) +
+               (Foreign(args_t[5]),) + args_t[6:])
+    assert torch.equal(g_t, g_f) and float(g_f.sum()) > 1000
+    centre = _gpu((lo + np.array(np.unravel_index(int(g_t.argmax()), g_t.shape)) * cfg.res).astype(np.float32))
+    o_t, o_f = torch.zeros((P, 3), device="cuda"), torch.zeros((P, 3), device="cuda")
+    for out, wrap in ((o_t, lambda a: a), (o_f, Foreign)):
+        backvote_kernel(_blocks(P), (THREADS, 1, 1), (wrap(args_t[0]), wrap(args_t[1]), wrap(out), wrap(args_t[3]), wrap(args_t[5]),
+                                                       np.float32(cfg.res), P, ROTS, int(dims[0]), int(dims[1]), int(dims[2]),
+                                                       wrap(centre), np.float32(3 * cfg.res)))
+    assert torch.equal(o_t, o_f) and bool((o_f != 0).any())
+    rot = torch.rand(P, device="cuda") * 3.14
+    c_t, c_f = torch.zeros((P, ROTS, 3), device="cuda"), torch.zeros((P, ROTS, 3), device="cuda")
+    for out, wrap in ((c_t, lambda a: a), (c_f, Foreign)):
+        rot_voting_kernel(_blocks(P), (THREADS, 1, 1), (wrap(args_t[0]), wrap(args_t[1]), wrap(rot), wrap(out), wrap(args_t[3]),
+                                                         wrap(args_t[5]), np.float32(cfg.res), P, ROTS, int(dims[0]), int(dims[1]), int(dims[2])))
+    assert torch.equal(c_t, c_f)
