@@ -38,9 +38,9 @@ def reference_style_instance(point_encoder, ppf_encoder, pc, pc_normal, cfg, sph
     preds_tr = torch.stack([_sample_bins(preds[0, :, :tb], 2 * cfg.vote_range[0], cfg.vote_range[0]),
                             _sample_bins(preds[0, :, tb:2 * tb], cfg.vote_range[1])], -1)                  # :185-188
     # ---- centre vote: grid on the device, read back, arg-max on the host (:191-211)
-    corners = np.stack([np.min(pc, 0), np.max(pc, 0)])
-    grid_res = ((corners[1] - corners[0]) / cfg.res).astype(np.int32) + 1
-    grid_obj = torch.zeros(tuple(int(v) for v in grid_res), dtype=torch.float32, device=dev)
+    corners = np.stack([pc.min(0), pc.max(0)])                                                             # :194-196
+    grid_obj = torch.zeros(tuple(int(v) for v in ((corners[1] - corners[0]) / cfg.res).astype(np.int32) + 1), dtype=torch.float32,
+                           device=dev)
     tr_dev = torch.from_numpy(preds_tr.cpu().numpy()).cuda().contiguous()                                  # the script's host bounce (:200)
     idx32 = torch.from_numpy(point_idxs).cuda().to(torch.int32)
     pc_dev, corner_dev = torch.from_numpy(pc).cuda(), torch.from_numpy(corners[0]).cuda()
@@ -83,21 +83,18 @@ def reference_style_instance(point_encoder, ppf_encoder, pc, pc_normal, cfg, sph
         rng.shuffle(start)
         sub = (start[:10000, None] + np.arange(num_rots)[None]).reshape(-1)
         cos = candidates.reshape(-1, 3)[torch.from_numpy(sub).cuda()].mm(sph)
-        counts = torch.sum(cos > np.cos(angle_tol / 180 * np.pi), 0).cpu().numpy()
-        best_dir = np.array(sphere_pts[int(np.argmax(counts))])
-        ab = pc[point_idxs[:, 0]] - pc[point_idxs[:, 1]]
-        ab_normed = ab / (np.sqrt(np.sum(ab ** 2, -1)) + 1e-7)[..., None]
-        pairwise_normals = pc_normal[point_idxs[:, 0]].copy()
-        pairwise_normals[np.sum(pairwise_normals * ab_normed, -1) < 0] *= -1
-        with torch.no_grad():
-            target = torch.from_numpy((np.sum(pairwise_normals * best_dir, -1) > 0).astype(np.float32)).cuda()
-            up_loss, down_loss = bce(aux[j], target).item(), bce(aux[j], 1. - target).item()
+        hits = (cos > np.cos(np.deg2rad(angle_tol))).sum(0).cpu().numpy()                                 # :282-283
+        best_dir = np.array(sphere_pts[int(np.argmax(hits))])
+        d_ab = pc[point_idxs[:, 0]] - pc[point_idxs[:, 1]]                                                # :287-293
+        u_ab = d_ab / (np.linalg.norm(d_ab, axis=-1) + 1e-7)[:, None]
+        n_first = pc_normal[point_idxs[:, 0]].copy()
+        n_first[(n_first * u_ab).sum(-1) < 0] *= -1
+        with torch.no_grad():                                                                             # :295-298
+            side = torch.from_numpy(((n_first * best_dir).sum(-1) > 0).astype(np.float32)).cuda()
+            up_loss, down_loss = bce(aux[j], side).item(), bce(aux[j], 1. - side).item()
         dirs.append(-best_dir if down_loss < up_loss else best_dir)
     up = dirs[0]
-    if cfg.regress_right:
-        right = dirs[1] - np.dot(up, dirs[1]) * up
-    else:
-        right = np.array([0, -up[2], up[1]])
+    right = dirs[1] - np.dot(up, dirs[1]) * up if cfg.regress_right else np.array([0.0, -up[2], up[1]])    # :305-312
     right = right / (np.linalg.norm(right) + 1e-9)
     R = np.stack([np.cross(up, right), up, right], -1) if cfg.z_right else np.stack([right, up, np.cross(right, up)], -1)
     scale = np.exp(preds_scale.mean(0).cpu().numpy()) * np.asarray(cfg.scale_mean) * 2                     # :335
