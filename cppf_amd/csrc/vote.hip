@@ -146,9 +146,6 @@ __device__ __forceinline__ float ceil_to_float(double d)
 // axes is a superset of the rotations the exact test of the deposit stage accepts -- cheap approximations with explicit
 // slack (1e-4 in the cosine, 2e-3 rad in the angle, far above their error), never a dropped vote.  A pair costs ~300
 // instructions for its masks instead of ~45 per pair of rotations in a loop over all of them.
-#ifndef VOTE_SERIAL_MAX
-#define VOTE_SERIAL_MAX 40   // pairs with a non-empty mask up to which a batch is expanded pair by pair (sweep 16..64 after the plane/shell cull: 40)
-#endif
 #define VOTE_BELOW_N 97   // BELOW[j] = bits [0, j) set, j = 0..96, as uint4 (x, y, z = three words)
 
 __device__ __forceinline__ float atan01_approx(float t)   // atan on [0, 1], |error| < 2e-5
@@ -401,7 +398,8 @@ struct V3Hdr {                    // workspace + VOTE_WS_PART; all zero (or left
 static_assert(V3_HDR_BYTES + V3_PLANE_BYTES <= VOTE_WS_V3_STATE, "VOTE_WS_V3_STATE too small");
 
 struct V3Tiling { int tx, ty, ntx, nty, T, hx, hy; };   // hx / hy: the grid is cut along x / y (tiles carry a halo column / row)
-// fewest tiles, then least cut area (see vote_tiling); a tile of tx x ty owned cells occupies (tx + hx)(ty + hy) gz words
+// fewest tiles, then least cut area between tiles (a vote circle is a curve: the tiles it passes through grow with the area of the cuts
+// it can cross: 26x19x52 rather than 7x76x52 for the 52x152x52 grid of config 5); a tile of tx x ty owned cells occupies (tx + hx)(ty + hy) gz words
 __host__ __device__ inline V3Tiling v3_tiling(int gx, int gy, int gz)
 {
     V3Tiling p = {0, 0, 0, 0, 1 << 30, 0, 0};
