@@ -932,6 +932,9 @@ def main():
             "config": {"workload": workload_text(args.config, m, args), "pairs_per_step_per_gpu": P,
                        "parallelism": f"objects x{world}"},
             "pairs_per_ms_per_gpu": steps * P / elapsed / 1e3,
+            "metric_note": ("all 141 logits decoded in the first pass (rounds 1-2's definition of the step)" if args.all_heads else
+                            "since round 3 the timed step decodes the 64 centre-bin logits the chain consumes up to the arg-max (like the "
+                            "reference's first pass); rounds 1-2 decoded all 141: compare their numbers with `all_heads_first_pass`"),
             # the timed region (exactly `steps` steps + the gather, barrier + synchronize on both sides) was run `regions` times;
             # value / ms_per_step come from the MEDIAN region (max over ranks per region)
             "regions": len(m["regions"]), "region_ms_min_max": [m["regions"][0] * 1e3, m["regions"][-1] * 1e3],
