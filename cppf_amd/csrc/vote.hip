@@ -1709,6 +1709,7 @@ static int v3_launch(const float* points, const float* outputs, const float* pro
 }
 
 __global__ void zero_u64x2_kernel(unsigned long long* p) { p[0] = 0ull; p[1] = 0ull; }
+__global__ void set_f32_kernel(float* p, float v) { *p = v; }
 
 // Grids that would need more than 64 LDS tiles (> 1.9 M cells; none of the reference's categories comes close): the reference's own
 // formulation, models/voting.py:8-66 line by line -- one thread per pair, a loop over its rotations, global fp32 atomicAdd.  Same
@@ -1774,7 +1775,18 @@ static int vote_impl(const float* points, const float* outputs, const float* pro
         return v3_launch(points, outputs, probs, point_idxs, idx_is_i64, grid_obj, corner, res, n_points, n_ppfs, n_rots, gx, gy, gz,
                          adaptive, accumulate, want_argmax, out_idx, out_val, workspace, st, nullptr, 0, 0, ex);
     }
-    if (ex) return workspace && n_ppfs > 0 ? CPPF_EUNSUPPORTED : CPPF_EWORKSPACE;   // the integer image exists on the tiled integer path only
+    if (ex) {
+        if (n_ppfs > 0) return CPPF_EUNSUPPORTED;   // the integer image exists on the tiled integer path only (<= 64 tiles)
+        // an empty pair list (a rank's slice of a short list): nothing was voted -- an all-zero image whose quantum is +inf, which
+        // the MIN over the ranks' quanta ignores and cppf_grid_from_raw converts to an all-zero grid
+        if (!accumulate) {
+            hipError_t e = hipMemsetAsync(ex->grid_raw, 0, (size_t)gx * gy * gz * sizeof(long long), st);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(set_f32_kernel, dim3(1), dim3(1), 0, st, ex->quantum_out, __uint_as_float(0x7f800000u));
+        CPPF_CHECK_LAUNCH();
+        return 0;
+    }
     // ---- no pairs, or a grid beyond 64 tiles: global atomics (+ the plain arg-max kernel)
     if (!workspace || workspace_bytes < 256) return CPPF_EWORKSPACE;
     const int64_t G = (int64_t)gx * gy * gz;

@@ -151,11 +151,8 @@ def vote_sharded(pc, outputs, point_idxs, corner, dims, res, n_pairs_total, worl
     bits = voting.vote_fixed_point_bits(n_pairs_total, num_rots, dims)      # of the WHOLE list: safe for every slice
     raw = torch.empty(tuple(int(d) for d in dims), dtype=torch.int64, device=dev)
     quantum = torch.empty(1, dtype=torch.float32, device=dev)
-    if point_idxs.shape[0] > 0:
-        voting.vote_grid_raw(pc, outputs, probs, point_idxs, raw, quantum, corner, res, num_rots, adaptive, fixed_bits=bits)
-    else:                                                                      # an empty slice (more ranks than pairs)
-        raw.zero_()
-        quantum.fill_(float(2.0 ** -bits) if probs is None else 0.0)
+    # (an empty slice -- more ranks than pairs -- yields a zero image with quantum +inf, which the MIN below ignores)
+    voting.vote_grid_raw(pc, outputs, probs, point_idxs, raw, quantum, corner, res, num_rots, adaptive, fixed_bits=bits)
     allreduce_grid(raw, world, force_collective)
     if world > 1 or force_collective or (force_collective is None and forced() and dist.is_initialized()):
         qmin = quantum.clone()                                                 # a rank that fell back to fp32 poisons the result

@@ -105,7 +105,9 @@ int cppf_vote_argmax(const float* points, const float* outputs, const float* pro
  *                list is always safe -- so that the integer sum of their grids is the single-GPU grid bit for bit,
  *                whatever the order of the all-reduce.  More bits than the launch would choose can overflow the
  *                wrap-around log of a workgroup: reported as quantum 0.
- * Needs the tiled integer path (a grid of <= 64 tiles): CPPF_EUNSUPPORTED otherwise.
+ * Needs the tiled integer path (a grid of <= 64 tiles): CPPF_EUNSUPPORTED otherwise; by-value launches only (no `_dyn` form).
+ * n_ppfs == 0 (a rank's slice of a short list) is legal: the image is zero (unchanged with accumulate) and the quantum +infinity,
+ * which a MIN over the ranks' quanta ignores and cppf_grid_from_raw turns into an all-zero grid.
  * cppf_grid_from_raw: grid[i] = (float)(raw[i] * quantum) -- the one rounding cppf_vote_argmax applies -- then the arg-max
  * (out_idx / out_val may be NULL; workspace as cppf_grid_argmax). */
 int cppf_vote_grid_raw(const float* points, const float* outputs, const float* probs, const void* point_idxs, int idx_is_i64,

@@ -284,6 +284,15 @@ def test_integer_vote_rejects_what_it_cannot_serve(dev):
     big = torch.zeros((300, 300, 300), dtype=torch.int64, device=dev)
     with pytest.raises(_lib.CppfError):
         voting.vote_grid_raw(pc, o, None, i32, big, q, corner, 4e-3, 72, True)                     # > 64 tiles: no integer path (global fp32 atomics)
+    # an empty slice (more ranks than pairs): zero image, quantum +inf -> ignored by the MIN over ranks, converts to a zero grid
+    raw.fill_(5)
+    voting.vote_grid_raw(pc, o[:0].contiguous(), None, i32[:0].contiguous(), raw, q, corner, 4e-3, 72, True)
+    assert int(raw.abs().sum()) == 0 and float(q) == float("inf")
+    g, gi, gv = voting.grid_from_raw(raw, q)
+    assert float(g.abs().sum()) == 0.0
+    from cppf_amd import sharding
+    i_, v_, g_, q_ = sharding.vote_sharded(pc, o[:0].contiguous(), i32[:0].contiguous(), corner, (8, 8, 8), 4e-3, idx.shape[0], 1)
+    assert float(g_.abs().sum()) == 0.0
     # negative probs: the launch accumulates in fp32 -> quantum 0 flags the image as not valid, the converted grid is NaN
     probs = torch.full((600,), -1.0, dtype=torch.float32, device=dev)
     voting.vote_grid_raw(pc, o, probs, i32, raw, q, corner, 4e-3, 72, True)
