@@ -1783,7 +1783,7 @@ static int vote_impl(const float* points, const float* outputs, const float* pro
             hipError_t e = hipMemsetAsync(ex->grid_raw, 0, (size_t)gx * gy * gz * sizeof(long long), st);
             if (e != hipSuccess) return (int)e;
         }
-        hipLaunchKernelGGL(set_f32_kernel, dim3(1), dim3(1), 0, st, ex->quantum_out, __uint_as_float(0x7f800000u));
+        hipLaunchKernelGGL(set_f32_kernel, dim3(1), dim3(1), 0, st, ex->quantum_out, HUGE_VALF);
         CPPF_CHECK_LAUNCH();
         return 0;
     }
