@@ -390,3 +390,38 @@ def test_backproject_oracle_matches_the_reference_function(oracle, golden):
             np.testing.assert_allclose(pts, g[f"pts_{tag}_{k}"], rtol=1e-13, atol=0)
     pts, (rows, cols) = oracle.backproject(g["depth"], g["intrinsics"], np.zeros_like(g["masks"][0]))
     assert pts.shape == (0, 3) and rows.size == 0
+
+
+def test_training_targets_and_loss_equal_the_references(golden):
+    """cppf_amd/training.py against the reference's own generate_target + real2prob (executed from their source by
+    tests/golden/make_golden_train.py) and the loss of train.py:68-87 (same library calls on those outputs): the soft bin targets
+    of a cloud in the canonical frame (centre 0, axes = world axes) and the loss of seeded logits, for plain / up-symmetric /
+    z-right categories"""
+    import dataclasses
+    import torch
+    from cppf_amd import training
+    from cppf_amd.config import CATEGORIES
+    g = golden("train_targets.npz")
+    pc, nrm = torch.from_numpy(g["pc"]), torch.from_numpy(g["nrm"])
+    preds = torch.from_numpy(g["preds"])
+    for tag in ("plain", "upsym", "zright"):
+        up_sym, z_right, regress_right = (bool(v) for v in g[f"{tag}.flags"])
+        cfg = dataclasses.replace(CATEGORIES["bottle"], up_sym=up_sym, z_right=z_right, regress_right=regress_right)
+        idx = torch.from_numpy(g[f"{tag}.point_idxs"])
+        tr, rot, aux, scale = training.targets(pc, nrm, idx, np.zeros(3), np.eye(3), g["half_extents"], cfg)
+        np.testing.assert_array_equal(aux.numpy(), g[f"{tag}.aux"])
+        np.testing.assert_allclose(scale.numpy(), g[f"{tag}.scale"], atol=1e-6)
+        # soft bins: two neighbouring bins share weight 1; fp32 here vs the reference's fp64 -> fp32: 1e-4 on a weight
+        np.testing.assert_allclose(tr.numpy(), g[f"{tag}.tr_soft"], atol=2e-4)
+        np.testing.assert_allclose(rot.numpy(), g[f"{tag}.rot_soft"], atol=2e-4)
+        assert np.allclose(tr.sum(-1).numpy(), 1.0, atol=1e-5) and np.allclose(rot.sum(-1).numpy(), 1.0, atol=1e-5)
+        loss = training.loss_fn(preds, tr, rot, aux, scale, cfg)
+        assert abs(float(loss) - float(g[f"{tag}.loss"])) < 2e-4 * float(g[f"{tag}.loss"]), (tag, float(loss), float(g[f"{tag}.loss"]))
+        # with the reference's own soft targets the loss is the reference's to fp32 rounding
+        loss_ref_t = training.loss_fn(preds, torch.from_numpy(g[f"{tag}.tr_soft"]), torch.from_numpy(g[f"{tag}.rot_soft"]),
+                                      torch.from_numpy(g[f"{tag}.aux"]), torch.from_numpy(g[f"{tag}.scale"]), cfg)
+        assert abs(float(loss_ref_t) - float(g[f"{tag}.loss"])) < 1e-5 * float(g[f"{tag}.loss"])
+    # real2prob alone, incl. the end points
+    v = torch.tensor([0.0, 0.1, 0.49999, 0.5])
+    p = training.real2prob(v, 0.5, 6)
+    assert torch.allclose(p.sum(-1), torch.ones(4)) and p[0, 0] == 1 and p[3, 5] == 1 and abs(float(p[1, 1]) - 1.0) < 1e-6
