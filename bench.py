@@ -741,6 +741,39 @@ def main():
                   "level3_records_finite": bool(torch.isfinite(r3[:, :12]).all())}
         del runner
 
+    # secondary: one REAL depth frame (the reference's demo image, tests/golden/demo_0000_depth.png: Kinect noise and holes) through
+    # nocs/inference.py:131-142,177-339 -- back-projection, voxel de-duplication, PCA normals, kNN + SPRIN, the whole pose -- per
+    # instance, eager launches one at a time, pre-processing included (cppf_amd/frames.py; six rectangular "instances")
+    real_frame = None
+    depth_png = os.path.join(ROOT, "tests", "golden", "demo_0000_depth.png")
+    if secondary and os.path.exists(depth_png) and os.path.exists(TRAINED_WEIGHTS.format("laptop")):
+        from cppf_amd import training
+        from cppf_amd.frames import frame_poses
+        from cppf_amd.utils.util import read_depth_png
+        depth = read_depth_png(depth_png)
+        rects = [("mug", (262, 356), (124, 206), 90), ("bowl", (184, 246), (288, 366), 90), ("bowl", (194, 250), (370, 442), 90),
+                 ("mug", (186, 250), (436, 504), 90), ("can", (112, 184), (376, 408), 60), ("laptop", (118, 322), (92, 302), 260)]
+        inst = []
+        for cat, (r0, r1), (c0, c1), win in rects:
+            msk = np.zeros(depth.shape, bool)
+            patch = depth[r0:r1, c0:c1]
+            msk[r0:r1, c0:c1] = np.abs(patch.astype(np.int64) - np.median(patch[patch > 0])) <= win
+            inst.append((cat, msk))
+        src = {"mug": "mug", "laptop": "laptop", "bowl": "bottle", "can": "bottle"}       # (bottle weights stand in for bowl / can)
+        nets_f = {c: training.load_weights(TRAINED_WEIGHTS.format(w_), syn.CATEGORIES[w_], dev) for c, w_ in src.items()}
+        encs_f, pencs_f = {c: v[1] for c, v in nets_f.items()}, {c: v[0] for c, v in nets_f.items()}
+        for _ in range(2):
+            poses_f = frame_poses(depth, inst, encs_f, pencs_f, device=dev)
+        settle()
+        torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        for _ in range(5):
+            poses_f = frame_poses(depth, inst, encs_f, pencs_f, device=dev)
+        torch.cuda.synchronize()
+        real_frame = {"instances": len(inst), "points_per_instance": [int(p_["n_points"]) for p_ in poses_f], "pairs_per_instance": 100000,
+                      "ms_per_instance_incl_preprocessing": (time.perf_counter() - tf0) / 5 / len(inst) * 1e3,
+                      "n_surv": [int(p_["n_surv"]) for p_ in poses_f]}
+
     # secondary: centre vote + the whole pose tail on known-answer inputs, where (nearly) every pair survives the back-vote
     if secondary:
         from cppf_amd.inference import _enqueue_tail
@@ -945,6 +978,7 @@ def main():
             "trained_regime": trained,
             "all_heads_first_pass": all_heads_step,
             "dropin_flow_reference_defaults": dropin,
+            "real_frame": real_frame,
             "stage_ms": {"ppf_mlp_decode_all_heads": t_mlp_all, "ppf_mlp_decode_centre_heads": t_mlp_tr, "vote_reduce_argmax": t_vote,
                          "vote_reduce_argmax_known_answer_inputs": t_vote_ka,
                          "vote_plus_pose_tail_known_answer_inputs": t_tail_ka, "pose_tail_known_answer_n_surv": n_surv_ka,
