@@ -63,3 +63,43 @@ def test_committed_trained_weights_recover_held_out_poses(dev, cat):
         assert _med(errs, "right_deg_mod_sign") <= 10.0, errs
     # a trained network's back-vote keeps a large share of the pairs (a random-weight one: 0.4 %)
     assert min(e["n_surv"] for e in errs) > 0.05 * 100000
+
+
+def test_synthetic_scenes_through_the_batch_runner_and_the_nocs_metric(dev):
+    """BASELINE.json configs[4] end to end on data that has a ground truth: scenes of posed synthetic objects -> trained networks ->
+    BatchPoseRunner (kNN + SPRIN + whole pose per instance, captured pipelines) -> nocs_result (the pickle layout of
+    nocs/inference.py:338-345) -> compute_degree_cm_mAP (nocs/eval.py:44-49).  The necked bottle has a well-defined pose up to its
+    rotational symmetry, which the metric knows about: its AP must be high.  (Mug body and laptop box leave the sign of `up` open --
+    a 180 degree error for the metric half of the time -- so their rows are only reported.)"""
+    from cppf_amd import evaluation as E
+    from cppf_amd.batch import BatchPoseRunner
+    from cppf_amd.inference import nocs_result
+    cats = ["bottle", "mug", "laptop"]
+    nets = {c: training.load_weights(os.path.join(GOLDEN, f"trained_{c}.npz"), syn.CATEGORIES[c], dev) for c in cats}
+    runner = BatchPoseRunner({c: nets[c][1] for c in cats}, dev, point_encoders={c: nets[c][0] for c in cats})
+    n_img, results = 6, []
+    for img in range(n_img):
+        obs = [syn.make_posed_object(c, 1200 + 150 * k, 920000 + 10 * img + k) for k, c in enumerate(cats)]
+        recs = runner.run([dict(pc=o["pc"], normals=o["normals"], cfg=o["cfg"], n_pairs=100000) for o in obs], seed=img).cpu().numpy()
+        poses, gt_RTs, gt_scales = [], [], []
+        for o, r in zip(obs, recs):
+            up, right, scale = r[3:6], r[6:9], r[9:12]
+            R = np.stack([np.cross(up, right), up, right], -1) if o["cfg"].z_right else np.stack([right, up, np.cross(right, up)], -1)
+            poses.append({"T": r[0:3], "R": R, "scale": scale, "scale_norm": float(np.linalg.norm(scale))})
+            full = 2 * o["half_extents"]
+            RT = np.eye(4)
+            RT[:3, :3], RT[:3, 3] = o["R"] * np.linalg.norm(full), o["center"]
+            gt_RTs.append(RT)
+            gt_scales.append(full / np.linalg.norm(full))
+        cls = np.array([E.SYNSET_NAMES.index(c) for c in cats], np.int32)
+        res = nocs_result(poses, {"pred_class_ids": cls, "pred_scores": np.full(3, 0.9), "pred_bboxes": np.zeros((3, 4), np.int32)})
+        res.update(gt_class_ids=cls, gt_RTs=np.array(gt_RTs), gt_scales=np.array(gt_scales), gt_handle_visibility=np.ones(3, np.int32))
+        E.mark_up_symmetry(res)
+        results.append(res)
+    iou_aps, pose_aps, _, _ = E.compute_degree_cm_mAP(results, E.SYNSET_NAMES, None, [5, 10, 15], [2, 5], [0.25, 0.5], 0.25, True)
+    b = E.SYNSET_NAMES.index("bottle")
+    print("bottle: IoU25 / IoU50", iou_aps[b], "AP(deg x cm)", pose_aps[b].round(2).tolist())
+    print("mug:", iou_aps[E.SYNSET_NAMES.index("mug")], "laptop:", iou_aps[E.SYNSET_NAMES.index("laptop")])
+    assert iou_aps[b, 0] == 1.0 and iou_aps[b, 1] >= 0.8                     # 3D IoU at 0.25 / 0.5
+    assert pose_aps[b, 1, 1] >= 0.8 and pose_aps[b, 2, 1] == 1.0            # 10 deg 5 cm, 15 deg 5 cm
+    assert iou_aps[E.SYNSET_NAMES.index("laptop"), 0] >= 0.8 and iou_aps[E.SYNSET_NAMES.index("mug"), 0] >= 0.8
