@@ -54,47 +54,27 @@ __device__ __forceinline__ f3 ld3(const float* __restrict__ p, int i)
     return {p[3 * i], p[3 * i + 1], p[3 * i + 2]};
 }
 
-// exp(x) for x <= 0 (softmax after the max subtraction; callers guarantee -3e38 < x <= 0):
-// 2^(x*log2e) = 2^n * p(f), n = rint(x*log2e), f = x*log2e - n in [-0.5, 0.5], p = degree-4 minimax of 2^f.
-// n comes from the float's own rounding: t = fma(x, log2e, 1.5*2^23) has unit spacing, so t - 1.5*2^23 = n exactly and
-// the low bits of t's pattern hold n in two's complement -- (bits(t) << 23) IS n << 23, no rint, no float->int conversion;
-// f = fma(x, log2e, -n) is rounded once.  Max relative error 3e-6 -- far below what an inverse-CDF draw can resolve -- at
-// 8 VALU (5.5 per value on the packed pipe): on gfx950 fp32 MFMA and VALU share one datapath, so every decode
-// instruction is paid in full.  oracle/cppf_oracle.c:orc_expf is the same sequence.
-#define CPPF_EXP_MAGIC 12582912.0f   // 1.5 * 2^23
-__device__ __forceinline__ float det_expf(float x)
+// Softmax weight of a logit l under the shift c = -(max logit * log2e):  w = 2^y,  y = fma(l, log2e, c)  (<= 0 up to the
+// rounding of the product), evaluated as ldexp(p(f), floor(y)) with f = y - floor(y) in [0, 1) and p the degree-4 minimax of
+// 2^f on [0, 1] (relative error 2.7e-6 in fp32 Horner form -- far below what an inverse-CDF draw can resolve).
+// Eight VALU per weight: the fma (max subtraction and log2e scale in one), v_fract_f32, v_cvt_flr_i32_f32, four fma, v_ldexp_f32
+// -- no clamp (ldexp underflows through the subnormals to 0 by itself) and no separate subtraction (round 1-3's form -- rint
+// through a magic add, exponent bits patched in by hand, x clamped at -86 -- took eleven).  On gfx950 fp32 MFMA and VALU
+// share one datapath, so every decode instruction is paid in full.  The three instructions are checked exhaustively against
+// their plain-arithmetic definitions (profiles/microbench/exp2_check.hip, profiles/r4_exp2_check.txt), which is what
+// oracle/cppf_oracle.c:orc_exp2w evaluates.
+#define CPPF_LOG2E 1.44269504088896341f
+__device__ __forceinline__ float det_exp2w(float l, float c)
 {
-    x = fmaxf(x, -86.0f);  // keeps 2^n a normal number for the exponent arithmetic below
-    const float t = fmaf(x, 1.44269504088896341f, CPPF_EXP_MAGIC);
-    const float n = t - CPPF_EXP_MAGIC;
-    const float f = fmaf(x, 1.44269504088896341f, -n);
-    float p = 9.570102207e-03f;
-    p = fmaf(p, f, 5.591785908e-02f);
-    p = fmaf(p, f, 2.402474433e-01f);
-    p = fmaf(p, f, 6.931217909e-01f);
-    p = fmaf(p, f, 9.999992847e-01f);
-    return __uint_as_float(__float_as_uint(p) + (__float_as_uint(t) << 23));
-}
-
-// Two det_expf at once on the packed-fp32 pipe (v_pk_add_f32 / v_pk_fma_f32 are IEEE per component, so each half is
-// bit-identical to det_expf).
-typedef float cppf_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ cppf_f32x2 det_expf2(cppf_f32x2 x)
-{
-    x[0] = fmaxf(x[0], -86.0f); x[1] = fmaxf(x[1], -86.0f);
-    const cppf_f32x2 L = {1.44269504088896341f, 1.44269504088896341f}, M = {CPPF_EXP_MAGIC, CPPF_EXP_MAGIC};
-    const cppf_f32x2 t = __builtin_elementwise_fma(x, L, M);
-    const cppf_f32x2 n = t - M;
-    const cppf_f32x2 f = __builtin_elementwise_fma(x, L, -n);
-    cppf_f32x2 p = {9.570102207e-03f, 9.570102207e-03f};
-    p = __builtin_elementwise_fma(p, f, cppf_f32x2{5.591785908e-02f, 5.591785908e-02f});
-    p = __builtin_elementwise_fma(p, f, cppf_f32x2{2.402474433e-01f, 2.402474433e-01f});
-    p = __builtin_elementwise_fma(p, f, cppf_f32x2{6.931217909e-01f, 6.931217909e-01f});
-    p = __builtin_elementwise_fma(p, f, cppf_f32x2{9.999992847e-01f, 9.999992847e-01f});
-    cppf_f32x2 r;
-    r[0] = __uint_as_float(__float_as_uint(p[0]) + (__float_as_uint(t[0]) << 23));
-    r[1] = __uint_as_float(__float_as_uint(p[1]) + (__float_as_uint(t[1]) << 23));
-    return r;
+    const float y = fmaf(l, CPPF_LOG2E, c);
+    const float f = __builtin_amdgcn_fractf(y);          // min(y - floor(y), 0x1.fffffep-1f)
+    const int e = (int)floorf(y);                        // v_cvt_flr_i32_f32 (selected under -fno-honor-nans: csrc/Makefile)
+    float p = 1.353416778e-02f;
+    p = fmaf(p, f, 5.201146007e-02f);
+    p = fmaf(p, f, 2.414427549e-01f);
+    p = fmaf(p, f, 6.930038333e-01f);
+    p = fmaf(p, f, 1.000002623e+00f);
+    return __builtin_amdgcn_ldexpf(p, e);
 }
 
 // fp64 sin/cos: Cody-Waite by pi/2 + degree-13/14 kernels on [-pi/4, pi/4].

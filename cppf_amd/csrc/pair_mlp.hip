@@ -139,16 +139,24 @@ extern "C" int cppf_pair_mlp_pack_device(const float* params, const int64_t* off
 #define MLP_THREADS 1024
 #define MLP_WAVES_PER_SIMD 4
 #define PB 1  // 16-pair blocks per wave tile
+#ifndef MLP_EARLY_GATHER
+#define MLP_EARLY_GATHER 0
+#endif
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
 {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+// max(v, 0) as ONE v_max_f32.  On a value the compiler cannot prove to be no signalling NaN (an MFMA result, a crossbar
+// exchange) fmaxf / `v > 0 ? v : 0` is preceded by a canonicalising v_max_f32 v, v -- 20 extra instructions per tile on the
+// pipe the MFMAs share -- unless the file is built with -fno-honor-nans (Makefile).  Not inline assembly: the compiler
+// does not count an asm statement as a VALU instruction when it places the wait states an MFMA result needs before its
+// first VALU reader, so an asm v_max_f32 on an accumulator reads it early (seen: run-to-run differences in the logits).
+__device__ __forceinline__ float relu1(float v) { return fmaxf(v, 0.f); }
 __device__ __forceinline__ f32x4 relu4(f32x4 v)
 {
     f32x4 r;
-    r[0] = v[0] > 0.f ? v[0] : 0.f; r[1] = v[1] > 0.f ? v[1] : 0.f;
-    r[2] = v[2] > 0.f ? v[2] : 0.f; r[3] = v[3] > 0.f ? v[3] : 0.f;
+    r[0] = relu1(v[0]); r[1] = relu1(v[1]); r[2] = relu1(v[2]); r[3] = relu1(v[3]);
     return r;
 }
 __device__ __forceinline__ f32x4 ldb4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -192,17 +200,20 @@ __device__ __forceinline__ float xor32f(float v, int lane) { return __uint_as_fl
 template <int NL>
 __device__ __forceinline__ bool sample_seg(const float (&v)[NL], float u, int g, int lane, int& bin)
 {
+    static_assert(NL == 8 || NL == 9, "the draw below searches 7 running sums + at most one more");
     float m = v[0];
 #pragma unroll
-    for (int k = 1; k < NL; ++k) m = fmaxf(m, v[k]);
+    for (int k = 1; k < NL; ++k) m = fmaxf(m, v[k]);   // (v_max3_f32 pairs; no canonicalising moves under -fno-honor-nans)
     float mall = fmaxf(m, xor16f(m, lane));
     mall = fmaxf(mall, xor32f(mall, lane));
+    // softmax weights 2^(l log2e - max log2e): the max subtraction rides on the exponent's fma (cppf_math.h:det_exp2w)
+    const float c = -(mall * CPPF_LOG2E);
     float e[NL];
     // (scalar instructions on purpose: beside the fp32 MFMAs, which run on the same datapath, a v_pk_fma_f32 costs as much as
     //  the two v_fma_f32 it replaces or more -- packed exponentials and the compiler's SLP packing measured 2.5-3 % slower,
     //  profiles/r2_pair_mlp_phases.txt; the Makefile passes -fno-slp-vectorize)
 #pragma unroll
-    for (int k = 0; k < NL; ++k) e[k] = det_expf(v[k] - mall);
+    for (int k = 0; k < NL; ++k) e[k] = det_exp2w(v[k], c);
     // running sums of the lane's segment: the last one is the segment total, and the draw compares them with the
     // threshold moved into the segment (t - off) -- one chain of NL - 1 additions serves both
     float b[NL];
@@ -215,20 +226,31 @@ __device__ __forceinline__ bool sample_seg(const float (&v)[NL], float u, int g,
     const float oth = xor32f(half, lane);
     const float off = ((g & 2) ? oth : 0.f) + ((g & 1) ? Tp : 0.f);
     const float t = u * ((g & 2) ? oth + half : half + oth) - off;   // u * ((T0 + T1) + (T2 + T3)) - off_g
-    const bool hit = b[NL - 1] > t;
-    int kk = NL - 1;
-#pragma unroll
-    for (int k = NL - 2; k >= 0; --k) kk = b[k] > t ? k : kk;
-    const unsigned long long hm = (__ballot(hit) >> (lane & 15)) & 0x0001000100010001ull;
-    const int gsel = hm ? ((__ffsll((long long)hm) - 1) >> 4) : 3;   // first lane with a hit, else the last bin
-    bool owner = g == gsel;
-    bin = NL * g + (hm ? kk : NL - 1);
+    // first k with b[k] > t, NL - 1 when there is none.  The weights are >= 0, so the running sums never decrease and the
+    // oracle's scan in k order finds what a bisection finds: three compares over b[0..6] instead of seven (+ one for NL = 9).
+    const bool c1 = b[3] > t;
+    const bool c2 = (c1 ? b[1] : b[5]) > t;
+    const float lo = c2 ? b[0] : b[2], hi = c2 ? b[4] : b[6];
+    const bool c3 = (c1 ? lo : hi) > t;
+    int kk = (c1 ? 0 : 4) + (c2 ? 0 : 2) + (c3 ? 0 : 1);
+    if (NL == 9) kk = b[7] > t ? kk : 8;
+    // the pair's first segment with a hit owns the draw (none: the last bin, which lane 3's search has found by itself).
+    // The ballot is wave-uniform, so "first of the four lanes j, j + 16, j + 32, j + 48" is scalar arithmetic on its four
+    // 16-bit quarters, and the owner's predicate goes straight back into a lane mask: no VALU instruction after the compare
+    // (the per-lane shift / and / find-first-bit form took thirteen).
+    const unsigned long long hm = __ballot(b[NL - 1] > t);
+    const unsigned h0 = (unsigned)hm & 0xffffu, h1 = (unsigned)(hm >> 16) & 0xffffu, h2 = (unsigned)(hm >> 32) & 0xffffu;
+    const unsigned o1 = h1 & ~h0, o2 = h2 & ~(h0 | h1), o3 = ~(h0 | h1 | h2) & 0xffffu;
+    const unsigned long long own = (unsigned long long)(h0 | (o1 << 16)) | ((unsigned long long)(o2 | (o3 << 16)) << 32);
+    bool owner = __builtin_amdgcn_inverse_ballot_w64(own);
+    bin = NL * g + kk;
     if (__any(u < 0.f)) {  // arg-max mode (rare, wave-uniform test so the common path really skips it)
         asm volatile("" ::: "memory");
-        int am = 0x7fffffff;
-#pragma unroll
+        int ak = 64;   // (position inside the segment first, its base added once: `am = NL * g + k` per k made the compiler keep
+#pragma unroll     //  NL loop-invariant registers per head for this rarely taken path -- the all-heads variant spilled)
         for (int k = NL - 1; k >= 0; --k)
-            if (v[k] == mall) am = NL * g + k;
+            if (v[k] == mall) ak = k;
+        const int am = NL * g + ak;   // a lane without the maximum: >= 64, above every bin
         int best = min(am, (int)xor16u((unsigned)am, lane));
         best = min(best, (int)xor32u((unsigned)best, lane));
         if (u < 0.f) { bin = best; owner = am == best; }
@@ -273,20 +295,22 @@ __device__ __forceinline__ T& at_off(void* base, unsigned byte_off)
 }
 __device__ __forceinline__ f3 ld3o(const float* __restrict__ base, int i)
 {
-    const unsigned o = (unsigned)i * 12u;
+    const unsigned o = __umul24((unsigned)i, 12u);   // (N < 2^23 on this path: the full-rate 24-bit multiply; v_mul_lo_u32 takes four issue slots)
     return {at_off<float>(base, o), at_off<float>(base, o + 4u), at_off<float>(base, o + 8u)};
 }
 
 // slot of the launch -> row of the pair arrays (identity unless SEL)
+// (slots, tiles and pair counts are 32-bit inside the kernel -- P < 2^27, launch_std -- : 64-bit compares and selects were a
+//  dozen instructions per tile)
 template <bool SEL>
-__device__ __forceinline__ unsigned pair_row(const MlpArgs& A, int64_t slot, int64_t Pn)
+__device__ __forceinline__ unsigned pair_row(const MlpArgs& A, int slot, int Pn)
 {
-    const unsigned s = (unsigned)(slot < Pn ? slot : Pn - 1);
+    const unsigned s = (unsigned)min(slot, Pn - 1);
     return SEL ? (unsigned)at_off<int>(A.sel, s * 4u) : s;
 }
 
 template <bool SEL>
-__device__ __forceinline__ void load_pair_idx(const MlpArgs& A, int64_t slot, int64_t Pn, int& ia, int& ib)
+__device__ __forceinline__ void load_pair_idx(const MlpArgs& A, int slot, int Pn, int& ia, int& ib)
 {
     // two 4-byte loads of the low words whatever the index width: an i32 / i64 branch around the loads ends in a
     // wait for ALL outstanding loads (the gathers of the next tile that are in flight at this point)
@@ -296,11 +320,29 @@ __device__ __forceinline__ void load_pair_idx(const MlpArgs& A, int64_t slot, in
     ib = at_off<int>(A.idxs, o + (A.idx64 ? 8u : 4u));
 }
 
+// sqrtf for x = 0 or x >= 2^-96 (the squared distance of two points of a cloud: coincident, or >= 3.6e-15 m apart): the
+// compiler's correctly rounded fp32 square root -- v_sqrt_f32 (1 ulp), then the neighbour below / above if its residual says
+// so -- without the parts that only act below 2^-96 (rescaling by 2^32 and back: there the residual leaves the normal
+// range) and on infinite or NaN arguments (the class test): 10 instructions instead of 17.  x = 0: the lower neighbour is
+// kept at 0 (integer max), both residuals are zeros, the result is 0.  Checked against sqrtf for x = 0 and every float in
+// [2^-96, 2^40]: profiles/microbench/exp2_check.hip, profiles/r4_exp2_check.txt (below 2^-96 it differs by an ulp for 1.6 % of
+// the arguments; the oracle's sqrtf is exact there too -- such pairs do not occur in metric clouds).
+__device__ __forceinline__ float sqrt_rn(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const unsigned sb = __float_as_uint(s);
+    const float dn = __uint_as_float(max(sb, 1u) - 1u), up = __uint_as_float(sb + 1u);
+    const float rdn = fmaf(-dn, s, x), rup = fmaf(-up, s, x);
+    float r = rdn <= 0.f ? dn : s;
+    r = rup > 0.f ? up : r;
+    return r;
+}
+
 // PPF of one pair from already loaded points/normals (models/model.py:118-129); component `g`.
 __device__ __forceinline__ float ppf_from(f3 pa, f3 pb, f3 na, f3 nb, int g)
 {
     const f3 xy = sub3(pa, pb);
-    const float d = sqrtf((xy.x * xy.x + xy.y * xy.y) + xy.z * xy.z);
+    const float d = sqrt_rn((xy.x * xy.x + xy.y * xy.y) + xy.z * xy.z);
     const float den = d + 1e-7f;                       // fp32 add (torch), unlike the vote kernels
     // three IEEE divisions by one denominator (den in [1e-7, ~2], |xy| <= d: no rescaling or fix-up would apply): div_by()
     const float rden = refined_rcp(den);
@@ -308,10 +350,14 @@ __device__ __forceinline__ float ppf_from(f3 pa, f3 pb, f3 na, f3 nb, int g)
     const float p0 = (na.x * u.x + na.y * u.y) + na.z * u.z;
     const float p1 = (nb.x * u.x + nb.y * u.y) + nb.z * u.z;
     const float p2 = (na.x * nb.x + na.y * nb.y) + na.z * nb.z;
-    // branch-free 4-way select (a ?: chain becomes divergent branches that split the MFMA schedule)
-    const unsigned m0 = g == 0 ? ~0u : 0u, m1 = g == 1 ? ~0u : 0u, m2 = g == 2 ? ~0u : 0u, m3 = g == 3 ? ~0u : 0u;
-    return __uint_as_float((__float_as_uint(p0) & m0) | (__float_as_uint(p1) & m1) | (__float_as_uint(p2) & m2) |
-                           (__float_as_uint(d) & m3));
+    // 4-way select by lane group: g = lane >> 4, so "g == k" is a constant lane mask -- three v_cndmask on scalar masks
+    // (the and / or form on per-lane masks took eleven; a ?: chain on g itself becomes divergent branches that split the
+    // MFMA schedule)
+    (void)g;
+    const bool g0 = __builtin_amdgcn_inverse_ballot_w64(0x000000000000ffffull), g1 = __builtin_amdgcn_inverse_ballot_w64(0x00000000ffff0000ull),
+               g2 = __builtin_amdgcn_inverse_ballot_w64(0x0000ffff00000000ull);
+    const float s23 = g2 ? p2 : d, s123 = g1 ? p1 : s23;
+    return g0 ? p0 : s123;
 }
 
 // Layer-0 projections of every point: T[n][r] = (r < 64 ? bias[r] : 0) + sum_{k<40} WPT[k][r] * feat[n][k],
@@ -381,25 +427,25 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
     const int lane = threadIdx.x & 63;
     const int j = lane & 15, g = lane >> 4;
     __builtin_assume(g >= 0 && g < 4);
-    int64_t Pn = A.P;
-    if (SEL) { const int64_t ns = *A.n_sel; Pn = ns < A.P ? ns : A.P; }
-    const int64_t n_tiles = (Pn + 16 * PB - 1) / (16 * PB);
+    int Pn = (int)A.P;
+    if (SEL) Pn = min(max(*A.n_sel, 0), Pn);
+    const int n_tiles = (Pn + 16 * PB - 1) / (16 * PB);
     // Tiles are handed out per workgroup through an LDS counter.  With a fixed share (8 tiles per wave at the benchmark's
     // size) the waves of a SIMD -- arbitrated oldest first -- ran the same work in 119k ... 211k cycles and the kernel
     // waited for the slowest with a fifth of its issue slots idle (s_memtime trace, profiles/r2_pair_mlp_phases.txt).
     // A workgroup owns a contiguous range of tiles; a wave claims tile t+2 (whose pair indices it prefetches) while
     // tile t runs, so the claim's latency is never waited for.
-    const int64_t per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
-    const int64_t wg_begin = (int64_t)blockIdx.x * per_wg;
-    const int64_t wg_end = wg_begin + per_wg < n_tiles ? wg_begin + per_wg : n_tiles;
-    auto claim = [&]() -> int64_t {
+    const int per_wg = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int wg_begin = (int)blockIdx.x * per_wg;
+    const int wg_end = min(wg_begin + per_wg, n_tiles);
+    auto claim = [&]() -> int {
         int v = 0;
         if (lane == 0) v = atomicAdd(tile_ctr, 1);
         return wg_begin + __builtin_amdgcn_readfirstlane(v);
     };
-    int64_t cur = claim();
+    int cur = claim();
     if (cur >= wg_end) return;
-    int64_t nxt = claim();
+    int nxt = claim();
 
     // Software pipeline over the tiles this wave claims: while tile t runs through the
     // MFMA chain, the gathers of tile t+1 are in flight (indices were fetched one tile earlier still),
@@ -423,7 +469,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
             for (int ob = 0; ob < 4; ++ob) { ta[pb][ob] = at_off<f32x4>(A.table, oa + 64u * ob); tb[pb][ob] = at_off<f32x4>(A.table, ob_ + 64u * ob); }
             xp[pb] = ppf_from(ld3o(A.pc, ia[pb]), ld3o(A.pc, ib[pb]), ld3o(A.nrm, ia[pb]), ld3o(A.nrm, ib[pb]), g);
         }
-        const int64_t nt = nxt < wg_end ? nxt : cur;   // (no next tile: reload this one, the values are never used)
+        const int nt = nxt < wg_end ? nxt : cur;   // (no next tile: reload this one, the values are never used)
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) load_pair_idx<SEL>(A, nt * (16 * PB) + pb * 16 + j, Pn, ia1[pb], ib1[pb]);
         const f32x4 w = ldb4(W + OFF_W0P + lane * 4);
@@ -434,11 +480,11 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
     }
 
     for (;;) {
-        const int64_t tile = cur;
+        const int tile = cur;
         // The packed weights are loop-invariant LDS data: without this compiler barrier LICM hoists
         // all ~200 weight registers out of the tile loop and the kernel spills.
         asm volatile("" ::: "memory");
-        int64_t pair[PB];
+        int pair[PB];
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) pair[pb] = tile * (16 * PB) + pb * 16 + j;   // slot of the launch
         unsigned row[PB];                                                              // row of the pair arrays
@@ -452,6 +498,18 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
             npa[pb] = ld3o(A.pc, ia1[pb]); npb[pb] = ld3o(A.pc, ib1[pb]);
             nna[pb] = ld3o(A.nrm, ia1[pb]); nnb[pb] = ld3o(A.nrm, ib1[pb]);
         }
+#if MLP_EARLY_GATHER
+        // ---- next tile: its two table rows requested now, a whole tile ahead of their use (32 registers that are live
+        //      through the three layers, where the pressure is lowest; the decode, where it peaks, comes after their use)
+        f32x4 ta[PB][4], tb[PB][4];
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            const unsigned oa = (unsigned)ia1[pb] * (PROJ_COLS * 4u) + 16u * g, ob_ = (unsigned)ib1[pb] * (PROJ_COLS * 4u) + 256u + 16u * g;
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) { ta[pb][ob] = at_off<f32x4>(A.table, oa + 64u * ob); tb[pb][ob] = at_off<f32x4>(A.table, ob_ + 64u * ob); }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // (left alone, the scheduler sinks the requests to just before their use)
+#endif
         f32x2 ut[PB], ur[PB];
         if (DECODE) {
 #pragma unroll
@@ -519,18 +577,22 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
         }
         // ---- next tile: PPF from the landed points, table gathers (consumed after the final layer),
         //      and the indices of the tile after it ---------------------------------------------------
+#if !MLP_EARLY_GATHER
         f32x4 ta[PB][4], tb[PB][4];
+#endif
         float xp[PB];
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
             xp[pb] = ppf_from(npa[pb], npb[pb], nna[pb], nnb[pb], g);
+#if !MLP_EARLY_GATHER
             const unsigned oa = (unsigned)ia1[pb] * (PROJ_COLS * 4u) + 16u * g, ob_ = (unsigned)ib1[pb] * (PROJ_COLS * 4u) + 256u + 16u * g;
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob) { ta[pb][ob] = at_off<f32x4>(A.table, oa + 64u * ob); tb[pb][ob] = at_off<f32x4>(A.table, ob_ + 64u * ob); }
+#endif
         }
-        const int64_t nxt2 = claim();
+        const int nxt2 = claim();
         {
-            const int64_t nt = nxt2 < wg_end ? nxt2 : tile;
+            const int nt = nxt2 < wg_end ? nxt2 : tile;
 #pragma unroll
             for (int pb = 0; pb < PB; ++pb) load_pair_idx<SEL>(A, nt * (16 * PB) + pb * 16 + j, Pn, ia1[pb], ib1[pb]);
         }
@@ -602,7 +664,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
                 if (live) {
                     // the lane holds 4 consecutive logits per output block: one 16-byte store each (rows are
                     // only 4-byte aligned when out_dim % 4 != 0; global dwordx4 stores allow that)
-                    float* o = A.out + pair[pb] * A.out_dim + 4 * g;
+                    float* o = A.out + (int64_t)pair[pb] * A.out_dim + 4 * g;
 #pragma unroll
                     for (int ob = 0; ob < STD_NOB; ++ob) {
                         const int c0 = 16 * ob + 4 * g;
@@ -743,11 +805,12 @@ __device__ int sample_bin_mem(const float* __restrict__ l, int nb, float u, int 
         if (l[k] > m) { m = l[k]; am = k; }
     if (u < 0.f) return am;
     const int NL = (nb + 3) / 4;
+    const float c = -(m * CPPF_LOG2E);
     float T[4];
     for (int g = 0; g < 4; ++g) {
         float acc = 0.f;
         for (int k = g * NL; k < (g + 1) * NL && k < nb; ++k) {
-            const float ek = det_expf(l[k] - m);
+            const float ek = det_exp2w(l[k], c);
             acc = k == g * NL ? ek : acc + ek;
         }
         T[g] = acc;
@@ -759,7 +822,7 @@ __device__ int sample_bin_mem(const float* __restrict__ l, int nb, float u, int 
         const float t = tt - off[g];
         float b = 0.f;
         for (int k = g * NL; k < (g + 1) * NL && k < nb; ++k) {
-            const float ek = det_expf(l[k] - m);
+            const float ek = det_exp2w(l[k], c);
             b = k == g * NL ? ek : b + ek;
             if (b > t) return k;
         }

@@ -84,25 +84,30 @@ static inline int sat_int(double v)
 static inline float bits_f(int32_t b) { float f; memcpy(&f, &b, 4); return f; }
 static inline int32_t f_bits(float f) { int32_t b; memcpy(&b, &f, 4); return b; }
 
-/* exp(x) for x <= 0 (softmax after the max subtraction; callers guarantee x <= 0):
- * 2^(x*log2e) = 2^n * p(f), n = rint(x*log2e) taken from the rounding of fma(x, log2e, 1.5*2^23),
- * f = fma(x, log2e, -n) in [-0.5, 0.5], p = degree-4 minimax of 2^f.  Max relative error 3e-6 (far below what an
- * inverse-CDF draw can resolve).  Same instruction sequence as csrc/cppf_math.h:det_expf. */
-float orc_expf(float x)
+/* Softmax weight of a logit l under the shift c = -(max logit * log2e):  w = 2^y, y = fmaf(l, log2e, c) (<= 0 up to the
+ * rounding of the product), as ldexp(p(f), floor(y)): f = y - floor(y), kept below 1 the way v_fract_f32 keeps it (the
+ * difference rounds to 1.0 for tiny negative y), p = degree-4 minimax of 2^f on [0, 1] in Horner form, one fmaf per step
+ * (relative error 2.7e-6: far below what an inverse-CDF draw can resolve).  ldexpf rounds a subnormal result once, to
+ * nearest even, like v_ldexp_f32; no clamp anywhere.  The device form (csrc/cppf_math.h:det_exp2w) uses v_fract_f32,
+ * v_cvt_flr_i32_f32 and v_ldexp_f32 for the three non-fma steps; profiles/microbench/exp2_check.hip checks those three
+ * instructions against exactly the expressions below for every float y in [-200, 2]. */
+#define ORC_LOG2E 1.44269504088896341f
+float orc_exp2w(float l, float c)
 {
-    x = x < -86.0f ? -86.0f : x;   /* keeps 2^n a normal number for the exponent arithmetic below */
-    /* t has unit spacing: t - 1.5*2^23 = n = rint(x*log2e) exactly, and the low bits of t's pattern hold n */
-    const float magic = 12582912.0f;
-    float t = fmaf(x, 1.44269504088896341f, magic);
-    float n = t - magic;
-    float f = fmaf(x, 1.44269504088896341f, -n);
-    float p = 9.570102207e-03f;
-    p = fmaf(p, f, 5.591785908e-02f);
-    p = fmaf(p, f, 2.402474433e-01f);
-    p = fmaf(p, f, 6.931217909e-01f);
-    p = fmaf(p, f, 9.999992847e-01f);
-    return bits_f((int32_t)((uint32_t)f_bits(p) + ((uint32_t)f_bits(t) << 23)));
+    const float y = fmaf(l, ORC_LOG2E, c);
+    const float fl = floorf(y);
+    float f = y - fl;
+    if (f >= 1.0f) f = 0x1.fffffep-1f;
+    const int e = fl < -100000.0f ? -100000 : (fl > 100000.0f ? 100000 : (int)fl);
+    float p = 1.353416778e-02f;
+    p = fmaf(p, f, 5.201146007e-02f);
+    p = fmaf(p, f, 2.414427549e-01f);
+    p = fmaf(p, f, 6.930038333e-01f);
+    p = fmaf(p, f, 1.000002623e+00f);
+    return ldexpf(p, e);
 }
+/* exp(x) through the same core (x <= 0): what a softmax weight is for a maximum of 0 */
+float orc_expf(float x) { return orc_exp2w(x, 0.0f); }
 
 /* sin and cos of x in fp64: Cody-Waite reduction by pi/2 (two terms; exact for |x| < ~1e5)
  * and the classic degree-13/14 minimax kernels on [-pi/4, pi/4].  < 1 ulp(fp64). */
@@ -395,7 +400,7 @@ int orc_pair_mlp(const float* pc, const float* nrm, const float* feat, const int
  * can build it with two cross-lane exchanges and no serial 32-long dependency: the nb bins are cut into four
  * consecutive segments of NL = ceil(nb/4) bins (one per lane; the final layer's output columns are permuted at
  * pack time so that a lane's registers hold exactly its segment).
- *   e_k   = orc_expf(l_k - max l)
+ *   e_k   = orc_exp2w(l_k, -(max l * log2e))        = 2^((l_k - max l) log2e), the subtraction inside the fma
  *   T_g   = e summed sequentially over segment g;  total = (T0 + T1) + (T2 + T3);  t = u * total
  *   off_g = 0, T0, T0 + T1, (T0 + T1) + T2
  *   the bin is the first k of the first segment g with (e summed over the segment up to and including k) > t - off_g
@@ -410,11 +415,12 @@ int orc_sample_bin(const float* l, int nb, float u, int col0)
         if (l[k] > m) { m = l[k]; am = k; }
     if (u < 0.0f) return am;
     const int NL = (nb + 3) / 4;
+    const float c = -(m * ORC_LOG2E);
     float e[ORC_MAXD], T[4];
     for (int g = 0; g < 4; ++g) {
         float acc = 0.0f;
         for (int k = g * NL; k < (g + 1) * NL && k < nb; ++k) {
-            e[k] = orc_expf(l[k] - m);
+            e[k] = orc_exp2w(l[k], c);
             acc = k == g * NL ? e[k] : acc + e[k];
         }
         T[g] = acc;
