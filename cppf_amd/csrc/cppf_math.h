@@ -54,6 +54,24 @@ __device__ __forceinline__ f3 ld3(const float* __restrict__ p, int i)
     return {p[3 * i], p[3 * i + 1], p[3 * i + 2]};
 }
 
+// sqrtf for x = 0 or x >= 2^-96 (the squared distance of two points of a cloud: coincident, or >= 3.6e-15 m apart): the
+// compiler's correctly rounded fp32 square root -- v_sqrt_f32 (1 ulp), then the neighbour below / above if its residual says
+// so -- without the parts that only act below 2^-96 (rescaling by 2^32 and back: there the residual leaves the normal
+// range) and on infinite or NaN arguments (the class test): 10 instructions instead of 17.  x = 0: the lower neighbour is
+// kept at 0 (integer max), both residuals are zeros, the result is 0.  Checked against sqrtf for x = 0 and every float in
+// [2^-96, 2^40]: profiles/microbench/exp2_check.hip, profiles/r4_exp2_check.txt (below 2^-96 it differs by an ulp for 1.6 % of
+// the arguments; the oracle's sqrtf is exact there too -- such pairs do not occur in metric clouds).
+__device__ __forceinline__ float sqrt_rn(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const unsigned sb = __float_as_uint(s);
+    const float dn = __uint_as_float(max(sb, 1u) - 1u), up = __uint_as_float(sb + 1u);
+    const float rdn = fmaf(-dn, s, x), rup = fmaf(-up, s, x);
+    float r = rdn <= 0.f ? dn : s;
+    r = rup > 0.f ? up : r;
+    return r;
+}
+
 // Softmax weight of a logit l under the shift c = -(max logit * log2e):  w = 2^y,  y = fma(l, log2e, c)  (<= 0 up to the
 // rounding of the product), evaluated as ldexp(p(f), floor(y)) with f = y - floor(y) in [0, 1) and p the degree-4 minimax of
 // 2^f on [0, 1] (relative error 2.7e-6 in fp32 Horner form -- far below what an inverse-CDF draw can resolve).
@@ -131,12 +149,22 @@ __device__ __forceinline__ bool pair_frame(const float* __restrict__ points, int
     a = ld3(points, a_idx);
     f3 b = ld3(points, b_idx);
     ab = sub3(a, b);
-    float L = len3(ab);
+    // length() and the divisions of :20-:28 in the forms that are exact on this domain and cost half: sqrt_rn (the radicand is 0 or
+    // far above 2^-96 wherever the value is more than compared with 1e-7) and refined_rcp + div_by (numerators of at most a few
+    // metres, denominators in [1e-7, ~2]: the PPF's case, checked exhaustively) -- 60 of the ~180 instructions of a pair's frame
+    float L = sqrt_rn(dot3(ab, ab));
     if ((double)L < 1e-7) return false;
-    ab = div3(ab, (float)((double)L + 1e-7));
+    {
+        const float den = (float)((double)L + 1e-7), r = refined_rcp(den);
+        ab = {div_by(ab.x, den, r), div_by(ab.y, den, r), div_by(ab.z, den, r)};
+    }
     f3 co = {0.f, -ab.z, ab.y};
-    if ((double)len3(co) < 1e-7) co = {-ab.y, ab.x, 0.f};
-    xdir = div3(co, (float)((double)len3(co) + 1e-7));
+    float lc = sqrt_rn(dot3(co, co));
+    if ((double)lc < 1e-7) { co = {-ab.y, ab.x, 0.f}; lc = sqrt_rn(dot3(co, co)); }
+    {
+        const float den = (float)((double)lc + 1e-7), r = refined_rcp(den);
+        xdir = {div_by(co.x, den, r), div_by(co.y, den, r), div_by(co.z, den, r)};
+    }
     return true;
 }
 

@@ -139,8 +139,8 @@ extern "C" int cppf_pair_mlp_pack_device(const float* params, const int64_t* off
 #define MLP_THREADS 1024
 #define MLP_WAVES_PER_SIMD 4
 #define PB 1  // 16-pair blocks per wave tile
-#ifndef MLP_EARLY_GATHER
-#define MLP_EARLY_GATHER 0
+#ifndef MLP_WARM_L2
+#define MLP_WARM_L2 0
 #endif
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
@@ -271,6 +271,7 @@ struct MlpArgs {
     float* outputs;  // [P,2]                (DECODE)
     float* heads;    // [P,8] or null        (DECODE)
     int64_t P;
+    int64_t n_points;
     int out_dim;
     int idx64;
     float vr0, vr1;
@@ -296,7 +297,9 @@ __device__ __forceinline__ T& at_off(void* base, unsigned byte_off)
 __device__ __forceinline__ f3 ld3o(const float* __restrict__ base, int i)
 {
     const unsigned o = __umul24((unsigned)i, 12u);   // (N < 2^23 on this path: the full-rate 24-bit multiply; v_mul_lo_u32 takes four issue slots)
-    return {at_off<float>(base, o), at_off<float>(base, o + 4u), at_off<float>(base, o + 8u)};
+    // (the +4 / +8 ride on the uniform base, i.e. in the instruction's immediate offset: added to the 32-bit lane offset they are
+    //  two v_add_u32 per index, because unsigned wrap-around has to be preserved)
+    return {at_off<float>(base, o), at_off<float>(base + 1, o), at_off<float>(base + 2, o)};
 }
 
 // slot of the launch -> row of the pair arrays (identity unless SEL)
@@ -317,25 +320,7 @@ __device__ __forceinline__ void load_pair_idx(const MlpArgs& A, int slot, int Pn
     const unsigned p = pair_row<SEL>(A, slot, Pn);
     const unsigned o = p * (A.idx64 ? 16u : 8u);
     ia = at_off<int>(A.idxs, o);
-    ib = at_off<int>(A.idxs, o + (A.idx64 ? 8u : 4u));
-}
-
-// sqrtf for x = 0 or x >= 2^-96 (the squared distance of two points of a cloud: coincident, or >= 3.6e-15 m apart): the
-// compiler's correctly rounded fp32 square root -- v_sqrt_f32 (1 ulp), then the neighbour below / above if its residual says
-// so -- without the parts that only act below 2^-96 (rescaling by 2^32 and back: there the residual leaves the normal
-// range) and on infinite or NaN arguments (the class test): 10 instructions instead of 17.  x = 0: the lower neighbour is
-// kept at 0 (integer max), both residuals are zeros, the result is 0.  Checked against sqrtf for x = 0 and every float in
-// [2^-96, 2^40]: profiles/microbench/exp2_check.hip, profiles/r4_exp2_check.txt (below 2^-96 it differs by an ulp for 1.6 % of
-// the arguments; the oracle's sqrtf is exact there too -- such pairs do not occur in metric clouds).
-__device__ __forceinline__ float sqrt_rn(float x)
-{
-    const float s = __builtin_amdgcn_sqrtf(x);
-    const unsigned sb = __float_as_uint(s);
-    const float dn = __uint_as_float(max(sb, 1u) - 1u), up = __uint_as_float(sb + 1u);
-    const float rdn = fmaf(-dn, s, x), rup = fmaf(-up, s, x);
-    float r = rdn <= 0.f ? dn : s;
-    r = rup > 0.f ? up : r;
-    return r;
+    ib = at_off<int>(static_cast<const char*>(A.idxs) + (A.idx64 ? 8 : 4), o);   // (second column through the uniform base)
 }
 
 // PPF of one pair from already loaded points/normals (models/model.py:118-129); component `g`.
@@ -397,6 +382,20 @@ template <bool LOGITS, bool DECODE, bool HEADS, bool SEL = false>
 __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kernel(MlpArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float W[];
+#if MLP_WARM_L2
+    // Every XCD has its own L2 and the table was written by another kernel: the first gathers of every wave miss it, all at once
+    // and at random.  Workgroup b runs on XCD b mod 8, so the 32 workgroups of an XCD stream a 32nd of the table each (coalesced
+    // 16-byte loads, requested together with the weights below and waited for with them) and the XCD's L2 holds all of it
+    // before the first tile gathers.
+    float warm = 0.f;
+    {
+        const f32x4* tv = reinterpret_cast<const f32x4*>(A.table);
+        const unsigned total = (unsigned)A.n_points * (PROJ_COLS / 4);
+        const unsigned stride = ((gridDim.x + 7u) >> 3) * MLP_THREADS;
+#pragma unroll 4
+        for (unsigned v = (blockIdx.x >> 3) * MLP_THREADS + threadIdx.x; v < total; v += stride) { const f32x4 q = tv[v]; warm += q[0]; }
+    }
+#endif
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(A.packed);
         f32x4* dst = reinterpret_cast<f32x4*>(W);
@@ -422,6 +421,9 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
         else v = (float)(k - 64) / 35.0f * (float)CPPF_PI;
         lut[k] = v;
     }
+#if MLP_WARM_L2
+    if (warm == 1.2345e30f) lut[101] = warm;   // (never true: keeps the loads)
+#endif
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -498,18 +500,6 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
             npa[pb] = ld3o(A.pc, ia1[pb]); npb[pb] = ld3o(A.pc, ib1[pb]);
             nna[pb] = ld3o(A.nrm, ia1[pb]); nnb[pb] = ld3o(A.nrm, ib1[pb]);
         }
-#if MLP_EARLY_GATHER
-        // ---- next tile: its two table rows requested now, a whole tile ahead of their use (32 registers that are live
-        //      through the three layers, where the pressure is lowest; the decode, where it peaks, comes after their use)
-        f32x4 ta[PB][4], tb[PB][4];
-#pragma unroll
-        for (int pb = 0; pb < PB; ++pb) {
-            const unsigned oa = (unsigned)ia1[pb] * (PROJ_COLS * 4u) + 16u * g, ob_ = (unsigned)ib1[pb] * (PROJ_COLS * 4u) + 256u + 16u * g;
-#pragma unroll
-            for (int ob = 0; ob < 4; ++ob) { ta[pb][ob] = at_off<f32x4>(A.table, oa + 64u * ob); tb[pb][ob] = at_off<f32x4>(A.table, ob_ + 64u * ob); }
-        }
-        __builtin_amdgcn_sched_barrier(0);   // (left alone, the scheduler sinks the requests to just before their use)
-#endif
         f32x2 ut[PB], ur[PB];
         if (DECODE) {
 #pragma unroll
@@ -577,18 +567,14 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
         }
         // ---- next tile: PPF from the landed points, table gathers (consumed after the final layer),
         //      and the indices of the tile after it ---------------------------------------------------
-#if !MLP_EARLY_GATHER
         f32x4 ta[PB][4], tb[PB][4];
-#endif
         float xp[PB];
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
             xp[pb] = ppf_from(npa[pb], npb[pb], nna[pb], nnb[pb], g);
-#if !MLP_EARLY_GATHER
             const unsigned oa = (unsigned)ia1[pb] * (PROJ_COLS * 4u) + 16u * g, ob_ = (unsigned)ib1[pb] * (PROJ_COLS * 4u) + 256u + 16u * g;
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob) { ta[pb][ob] = at_off<f32x4>(A.table, oa + 64u * ob); tb[pb][ob] = at_off<f32x4>(A.table, ob_ + 64u * ob); }
-#endif
         }
         const int nxt2 = claim();
         {
@@ -889,6 +875,7 @@ static int launch_std(MlpArgs& A, int64_t N, void* workspace, size_t workspace_b
         CPPF_CHECK_LAUNCH();
     }
     A.table = table;
+    A.n_points = N;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mlp_kernel<LOGITS, DECODE, HEADS, SEL>),
