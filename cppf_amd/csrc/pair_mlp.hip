@@ -139,9 +139,6 @@ extern "C" int cppf_pair_mlp_pack_device(const float* params, const int64_t* off
 #define MLP_THREADS 1024
 #define MLP_WAVES_PER_SIMD 4
 #define PB 1  // 16-pair blocks per wave tile
-#ifndef MLP_WARM_L2
-#define MLP_WARM_L2 0
-#endif
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
 {
@@ -271,7 +268,6 @@ struct MlpArgs {
     float* outputs;  // [P,2]                (DECODE)
     float* heads;    // [P,8] or null        (DECODE)
     int64_t P;
-    int64_t n_points;
     int out_dim;
     int idx64;
     float vr0, vr1;
@@ -382,20 +378,6 @@ template <bool LOGITS, bool DECODE, bool HEADS, bool SEL = false>
 __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kernel(MlpArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float W[];
-#if MLP_WARM_L2
-    // Every XCD has its own L2 and the table was written by another kernel: the first gathers of every wave miss it, all at once
-    // and at random.  Workgroup b runs on XCD b mod 8, so the 32 workgroups of an XCD stream a 32nd of the table each (coalesced
-    // 16-byte loads, requested together with the weights below and waited for with them) and the XCD's L2 holds all of it
-    // before the first tile gathers.
-    float warm = 0.f;
-    {
-        const f32x4* tv = reinterpret_cast<const f32x4*>(A.table);
-        const unsigned total = (unsigned)A.n_points * (PROJ_COLS / 4);
-        const unsigned stride = ((gridDim.x + 7u) >> 3) * MLP_THREADS;
-#pragma unroll 4
-        for (unsigned v = (blockIdx.x >> 3) * MLP_THREADS + threadIdx.x; v < total; v += stride) { const f32x4 q = tv[v]; warm += q[0]; }
-    }
-#endif
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(A.packed);
         f32x4* dst = reinterpret_cast<f32x4*>(W);
@@ -421,9 +403,6 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
         else v = (float)(k - 64) / 35.0f * (float)CPPF_PI;
         lut[k] = v;
     }
-#if MLP_WARM_L2
-    if (warm == 1.2345e30f) lut[101] = warm;   // (never true: keeps the loads)
-#endif
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -875,7 +854,6 @@ static int launch_std(MlpArgs& A, int64_t N, void* workspace, size_t workspace_b
         CPPF_CHECK_LAUNCH();
     }
     A.table = table;
-    A.n_points = N;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mlp_kernel<LOGITS, DECODE, HEADS, SEL>),
