@@ -271,7 +271,12 @@ int cppf_pair_mlp_forward(const float* pc, const float* nrm, const float* feat, 
  *   u_tr  device f32[P,2]   -> outputs device f32[P,2] = (mu, nu)
  *   u_rot device f32[P,2]   -> heads   device f32[P,8] = {theta_up, theta_right, aux_up, aux_right,
  *                                                         sx, sy, sz, 0}    (both NULL to skip)
- * Requires the MFMA architecture above with tr_bins = 32, rot_bins = 36, out_dim = 141. */
+ * Requires the MFMA architecture above with tr_bins = 32, rot_bins = 36, out_dim = 141.
+ * Arithmetic of the draw (restated in oracle/cppf_oracle.c:orc_sample_bin / orc_exp2w, bit for bit): weights
+ * 2^(l log2e - max log2e) from a fixed degree-4 core (2.7e-6 relative, through the subnormals to zero for spreads beyond ~87),
+ * summed in four consecutive segments of the bins, first bin whose running sum exceeds u * total.
+ * Inputs of the pair-encoder entry points (clouds, normals, features, weights) must be finite: the file is built with
+ * -fno-honor-nans, a NaN or infinity gives unspecified outputs (never a fault). */
 int cppf_pair_mlp_decode(const float* pc, const float* nrm, const float* feat, const void* idxs, int idx_is_i64,
                          const float* packed, int64_t N, int F, const int* dims, int n_res, int64_t P,
                          int out_dim, int tr_bins, int rot_bins, float vr0, float vr1, const float* u_tr,
