@@ -72,10 +72,11 @@ def settle():
     gc.freeze()
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r<round>_pmc_traffic.json, newest round)."""
+def pmc_traffic(kernel, which="pmc_traffic"):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r<round>_pmc_traffic.json, newest round; every kernel at
+    full width; `which` = "pmc_traffic_timed_width": the default command's timed regions, whose vote is launched narrower)."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s.json" % which)), reverse=True):
         try:
             with open(path) as f:
                 return json.load(f)[kernel]["hbm_bytes"]
@@ -193,7 +194,22 @@ def cpu_baseline_block(o, sd, n_points, k, all_heads=False, budget_s=25.0):
                                  f"{tn} pairs, same weights; MLP leg only; best thread count of the same ladder"})
 
 
-def make_center_set(enc, dev, n_points, k, res, n_obj, seed0, with_heads=True, use_graph=True, cat="bottle"):
+def vote_width(args, n_pairs=524288, dims=(26, 76, 26)):
+    """The vote launch width of a timed pipeline (cppf.h CPPF_VOTE_WORKGROUPS).  With several instances in flight fewer, longer-lived
+    vote workgroups pay fewer 113 KB tiles per instance (zeroed, dumped, read back by the reduce kernel) and leave the rest of the chip
+    to the neighbours: about 8 192 pairs per workgroup and tile (profiles/r4_vote_workgroups.txt), i.e. 128 at N=4096 K=128 on the
+    bottle's two tiles, 192 on three, the full 256 from a million pairs on.  One instance at a time: one workgroup per CU (0)."""
+    if args.vote_workgroups >= 0:
+        return args.vote_workgroups
+    if args.streams <= 1:
+        return 0
+    from cppf_amd.inference import grid_class
+    T = max(1, grid_class(dims)[0])
+    w = -(-int(n_pairs) // 8192) * T
+    return 0 if w >= 256 else max(64, w)
+
+
+def make_center_set(enc, dev, n_points, k, res, n_obj, seed0, with_heads=True, use_graph=True, cat="bottle", vote_workgroups=0):
     """n_obj distinct objects (seed0 + i), each with its own CenterPipeline (static buffers + captured graph), loaded"""
     out = []
     for i in range(n_obj):
@@ -203,7 +219,7 @@ def make_center_set(enc, dev, n_points, k, res, n_obj, seed0, with_heads=True, u
         u_tr, u_rot = syn.make_uniforms(idx.shape[0], seed=seed0 + i)
         corners, dims = grid_shape(ob["pc"], cfg.res)
         pipe = CenterPipeline(enc, cfg, n_points, idx.shape[0], dims, dev, NUM_ROTS, adaptive=True, with_heads=with_heads,
-                              use_graph=use_graph)
+                              use_graph=use_graph, vote_workgroups=vote_workgroups(idx.shape[0], dims) if callable(vote_workgroups) else vote_workgroups)
         pipe.load(ob["pc"], ob["normals"], ob["feat"], idx, u_tr, u_rot, corners[0].copy())
         out.append(dict(ob=ob, cfg=cfg, idx=idx, u_tr=u_tr, u_rot=u_rot, corners=corners, dims=dims, pipe=pipe))
     return out
@@ -212,7 +228,7 @@ def make_center_set(enc, dev, n_points, k, res, n_obj, seed0, with_heads=True, u
 TRAINED_WEIGHTS = os.path.join(ROOT, "tests", "golden", "trained_{}.npz")   # scripts/train_synthetic.py on one MI355X
 
 
-def make_trained_set(dev, n_points, k, n_obj, seed0, rotate, use_graph=True, cat="bottle"):
+def make_trained_set(dev, n_points, k, n_obj, seed0, rotate, use_graph=True, cat="bottle", vote_workgroups=0):
     """The headline chain in the regime a DEPLOYED model produces: the networks of tests/golden/trained_<cat>.npz (trained with
     the HIP forward + backward on posed synthetic objects, cppf_amd/training.py), per-point features from the trained SPRIN
     encoder, n_obj held-out posed objects (seeds no training step saw), each with its own CenterPipeline.  A trained network's
@@ -228,7 +244,8 @@ def make_trained_set(dev, n_points, k, n_obj, seed0, rotate, use_graph=True, cat
         idx = syn.make_pairs(n_points, k, seed=seed0 + i)
         u_tr, u_rot = syn.make_uniforms(idx.shape[0], seed=seed0 + i)
         corners, dims = grid_shape(ob["pc"], cfg.res)
-        pipe = CenterPipeline(enc, cfg, n_points, idx.shape[0], dims, dev, NUM_ROTS, adaptive=True, with_heads=False, use_graph=use_graph)
+        pipe = CenterPipeline(enc, cfg, n_points, idx.shape[0], dims, dev, NUM_ROTS, adaptive=True, with_heads=False, use_graph=use_graph,
+                              vote_workgroups=vote_workgroups(idx.shape[0], dims) if callable(vote_workgroups) else vote_workgroups)
         pipe.load(ob["pc"], ob["normals"], feat, idx, u_tr, u_rot, corners[0].copy())
         out.append(dict(ob=ob, cfg=cfg, idx=idx, u_tr=u_tr, u_rot=u_rot, corners=corners, dims=dims, pipe=pipe, feat=feat))
     return out, penc, enc
@@ -237,6 +254,12 @@ def make_trained_set(dev, n_points, k, n_obj, seed0, rotate, use_graph=True, cat
 def events_per_chain(dev, pipes, n):
     """n chains strictly one at a time, each bracketed by its own pair of HIP events on the launch stream (SURVEY.md 8d:
     'hipEvents around the whole chain on one object, median of >= 20 runs'); objects rotate.  Returns the sorted list (ms)."""
+    widths = [p.vote_workgroups for p in pipes]
+    for p in pipes:                      # one instance alone on the chip: the vote one workgroup per CU (re-captured, warmed)
+        p.set_vote_workgroups(0)
+    if any(widths):
+        for p in pipes:
+            p.run(check_weights=False)
     ts = []
     for i in range(n):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -246,6 +269,12 @@ def events_per_chain(dev, pipes, n):
         e1.record()
         torch.cuda.synchronize(dev)
         ts.append(e0.elapsed_time(e1))
+    for p, w in zip(pipes, widths):
+        p.set_vote_workgroups(w)
+    if any(widths):
+        for p in pipes:
+            p.run(check_weights=False)
+        torch.cuda.synchronize(dev)
     return sorted(ts)
 
 
@@ -275,7 +304,7 @@ def run_center_config(name, enc, sd, dev, rank, world, args):
     group = torch.distributed.is_initialized()       # world > 1, or ONE rank with CPPF_FORCE_DIST=1 (the RCCL branches on one GPU)
     n_obj = max(n_streams, -(-args.objects // n_streams) * n_streams)      # a multiple of the streams: pipe j stays on stream j mod S
     objs = make_center_set(enc, dev, n_points, k, c["res"], n_obj, seed0=100 * rank, with_heads=args.all_heads,
-                           use_graph=not args.no_graph)
+                           use_graph=not args.no_graph, vote_workgroups=lambda P_, d_: vote_width(args, P_, d_))
     pipes = [o["pipe"] for o in objs]
     P = objs[0]["idx"].shape[0]
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
@@ -356,7 +385,8 @@ def workload_text(name, m, args):
              "belong to the second pass on the survivors)") + " -> LDS-tiled vote -> argmax "
             f"({m['what']}); one object per GPU per step, steps rotate over {m['n_obj']} distinct objects (own buffers: inputs come "
             "from HBM, not the Infinity Cache), " +
-            (f"{m['n_streams']} independent objects in flight on {m['n_streams']} HIP streams; " if m["n_streams"] > 1
+            (f"{m['n_streams']} independent objects in flight on {m['n_streams']} HIP streams" +
+             (f", each vote launched {m['objs'][0]['pipe'].vote_workgroups} workgroups wide; " if m['objs'][0]['pipe'].vote_workgroups else "; ") if m["n_streams"] > 1
              else "one object at a time; ") +
             ("four launches per step replayed from a hipGraph" if not args.no_graph else "eager launches"))
 
@@ -379,7 +409,8 @@ def run_c4(dev, rank, world, args, n_objects=64, n_regions=0):
         torch.manual_seed(i)
         cfg = syn.make_object(c, 8, 0)["cfg"]
         encs[c] = PPFEncoder(cfg.ppffcs, cfg.out_dim).eval().to(dev)
-    runner = BatchPoseRunner(encs, dev, n_lanes=max(1, args.streams))
+    runner = BatchPoseRunner(encs, dev, n_lanes=max(1, args.streams),
+                             vote_workgroups=None if args.vote_workgroups < 0 else args.vote_workgroups)
     objects = c4_objects(n_objects, n_points, k)
     for _ in range(max(6, args.warmup)):     # capture, the first (slow) replays of fresh graphs, form adaptation: ~4 batches
         runner.run(objects, rank, world)
@@ -475,6 +506,9 @@ def main():
                     "much region time has accumulated")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary stage timings (counter-collection passes)")
+    ap.add_argument("--vote-workgroups", type=int, default=-1, help="width of the vote launches of the timed pipelines: 0 = one "
+                    "workgroup per CU, 64..256 = at most that many (cppf.h CPPF_VOTE_WORKGROUPS); -1 = 128 when more than one "
+                    "instance is in flight (--streams > 1), one per CU otherwise")
     ap.add_argument("--streams", type=int, default=3, help="instances in flight per GPU: step k runs on HIP stream k mod S "
                     "(1 = strictly one instance at a time)")
     ap.add_argument("--objects", type=int, default=9, help="distinct objects the steps rotate over (rounded up to a multiple of "
@@ -566,27 +600,33 @@ def main():
 
     G_cells = int(np.prod(dims))
     tr_vote = [pmc_traffic("v3_vote_kernel<true>"), pmc_traffic("v3_reduce_kernel")]
+    tr_vote_w = [pmc_traffic("v3_vote_kernel<true>", "pmc_traffic_timed_width"), pmc_traffic("v3_reduce_kernel", "pmc_traffic_timed_width")]
     alg_bytes = 24 * P + 4 * G_cells          # (mu, nu) 8 B + int64 pair 16 B read per pair, the grid written once
     vote_roofline = {"bound": "lds_atomics", "kernel": "v3_vote_kernel<true> (+ v3_reduce_kernel in the time)", "unit": "T lane-atomics/s",
                      "peak": PEAK_LDS_ATOMICS,
                      "benchmark_inputs": vote_regime(t_vote, landed_samples([o["pipe"].outputs for o in objs])),
                      "traffic": (tr_vote[0] + tr_vote[1]) if all(tr_vote) else None, "algorithmic_bytes": alg_bytes,
                      "traffic_ratio": ((tr_vote[0] + tr_vote[1]) / alg_bytes) if all(tr_vote) else None,
+                     # the timed regions launch the vote `vote_workgroups` wide (half the partial tiles at 128): their own PMC passes
+                     "traffic_timed_regions": ({"vote_workgroups": objs[0]["pipe"].vote_workgroups, "bytes": tr_vote_w[0] + tr_vote_w[1],
+                                                "ratio": (tr_vote_w[0] + tr_vote_w[1]) / alg_bytes} if all(tr_vote_w) else None),
                      "note": "the vote is bound by LDS read-modify-writes, not by HBM or MFMA (SURVEY.md 8d): achieved = samples that land in "
                              "the grid x 8 trilinear corners (one returning ds_add_u32 each) / time of vote + reduce kernels (HIP events "
                              "around the C-ABI call; the call is both kernels) / the measured ds_add_rtn_u32 ceiling of the chip "
                              "(profiles/r1_atomics_microbench.txt).  Conservative: the reduce kernel's share of the time does no "
                              "atomics (kernel-only durations: profiles/r*_vote_regimes_ktrace.txt).  traffic = HBM bytes of the two "
                              "kernels per call from the committed PMC passes (benchmark inputs) against the algorithmic 24 B/pair + "
-                             "the grid: the surplus is the 256 partial tiles written by the vote and read back by the reduce kernel"}
+                             "the grid: the surplus is the partial tiles -- one per vote workgroup, 256 at full width -- written by the vote and read "
+                             "back by the reduce kernel.  Times and `traffic` are of the launch at full width (one workgroup per CU, one "
+                             "instance alone on the chip); `traffic_timed_regions`: the narrower launch the timed regions use"}
     if args.config not in ("c2", "c1"):       # the committed PMC passes are of the default (c2) command
-        vote_roofline["traffic"] = vote_roofline["traffic_ratio"] = None
+        vote_roofline["traffic"] = vote_roofline["traffic_ratio"] = vote_roofline["traffic_timed_regions"] = None
 
     # secondary: the chain with all 141 logits decoded in the first pass (round 1-2's headline): its own pipelines, same objects
     all_heads_step = None
     if secondary and not args.all_heads:
         ah = make_center_set(enc, dev, m["n_points"], m["k"], CONFIGS[args.config]["res"], m["n_obj"], seed0=100 * rank,
-                             with_heads=True, use_graph=not args.no_graph)
+                             with_heads=True, use_graph=not args.no_graph, vote_workgroups=lambda P_, d_: vote_width(args, P_, d_))
         sts = [torch.cuda.Stream(device=dev) for _ in range(m["n_streams"])]
 
         def ah_steps(n):
@@ -634,7 +674,8 @@ def main():
                            "sign and scale through PosePipeline on one object"}
         sph = np.array(fibonacci_sphere(480))
         for tag, rotate in (("axis_aligned", False), ("random_poses", True)):
-            tobjs, penc_t, enc_t = make_trained_set(dev, m["n_points"], m["k"], m["n_obj"], 900100, rotate, use_graph=not args.no_graph)
+            tobjs, penc_t, enc_t = make_trained_set(dev, m["n_points"], m["k"], m["n_obj"], 900100, rotate, use_graph=not args.no_graph,
+                                                    vote_workgroups=lambda P_, d_: vote_width(args, P_, d_))
             tpipes = [o["pipe"] for o in tobjs]
             streams = [torch.cuda.Stream(device=dev) for _ in range(m["n_streams"])]
 
@@ -973,8 +1014,12 @@ def main():
             "regions": len(m["regions"]), "region_ms_min_max": [m["regions"][0] * 1e3, m["regions"][-1] * 1e3],
             "dist": dist_info(world),
             # hipEvents around the whole chain on one object, one at a time, objects rotating
+            # (one instance alone on the chip: measured with the vote one workgroup per CU, whatever width the timed regions use)
             "median_ms_one_instance": lat[len(lat) // 2],
             "one_instance_ms_min_max": [lat[0], lat[-1]], "one_instance_runs": len(lat),
+            # width of the vote launches in the timed regions (cppf.h CPPF_VOTE_WORKGROUPS; 0 = one per CU): with several instances
+            # in flight fewer, longer-lived vote workgroups pay fewer 113 KB tiles (zeroed, dumped, reduced) per instance
+            "vote_workgroups": m["objs"][0]["pipe"].vote_workgroups,
             "trained_regime": trained,
             "all_heads_first_pass": all_heads_step,
             "dropin_flow_reference_defaults": dropin,

@@ -24,7 +24,7 @@ from .utils.util import fibonacci_sphere, num_sphere_bins
 class BatchPoseRunner:
     def __init__(self, encoders, device, num_rots=72, adaptive=True, angle_tol=1.5, max_rot_pairs=10000,
                  use_graph=True, point_encoders=None, n_bucket=1024, max_pipelines=24, dynamic=True, n_lanes=3,
-                 max_scratch_bytes=16 << 30):
+                 max_scratch_bytes=16 << 30, vote_workgroups=None):
         """encoders: {category name: PPFEncoder on `device`} (the reference keeps one per category,
         nocs/inference.py:79-90).  point_encoders: optional {category name: PointEncoder}; objects of those
         categories need no `feat` -- kNN + SPRIN run at the head of the captured graph (:180-181).
@@ -35,15 +35,20 @@ class BatchPoseRunner:
         many-tile grids, i.e. ~0.45 GB per pipeline at 524 288 pairs, ~1.7 GB at 2 M; INTEGRATION.md "Memory");
         n_lanes: instances in flight (HIP streams, each with its own pipelines).  Three measured best on a ragged batch of
         small instances (N 400-2000, 100 k pairs: 0.216 / 0.136 / 0.115 / 0.144 ms per instance with 1 / 2 / 3 / 4 lanes): the
-        neighbours fill the gaps between an instance's ~15 short dependent launches."""
+        neighbours fill the gaps between an instance's ~15 short dependent launches.
+        vote_workgroups: width of the vote launches (CenterPipeline).  None = chosen per pipeline: with more than one lane, 128 for
+        few-tile grids of up to half a million pairs -- every vote workgroup pays for a 113 KB tile whatever it deposits, so with
+        neighbours in flight half the chip per vote moves more instances per second (profiles/r4_vote_workgroups.txt) -- and one
+        workgroup per CU otherwise (longer pair lists, many-tile grids, a single lane)."""
         self.encoders, self.device = encoders, device
         self.point_encoders = point_encoders or {}
+        self.n_lanes = max(1, int(n_lanes))
+        self.vote_workgroups = None if vote_workgroups is None else int(vote_workgroups)
         self.kw = dict(num_rots=num_rots, adaptive=adaptive, angle_tol=angle_tol, max_rot_pairs=max_rot_pairs,
                        use_graph=use_graph)
         self.sphere = np.array(fibonacci_sphere(num_sphere_bins(angle_tol)))      # :100-102
         self.n_bucket, self.max_pipelines, self.dynamic = int(n_bucket), int(max_pipelines), bool(dynamic)
         self.max_scratch_bytes, self._bytes = int(max_scratch_bytes), {}
-        self.n_lanes = max(1, int(n_lanes))
         self._pipes = OrderedDict()    # LRU: key -> PosePipeline
         self._staging = {}         # pinned host staging sets for the small per-instance arrays, see _stage()
         self._stage_pos = 0
@@ -69,12 +74,16 @@ class BatchPoseRunner:
                 old_key, old = self._pipes.popitem(last=False)
                 self._bytes.pop(old_key, None)
                 old.release()
+            width = self.vote_workgroups
+            if width is None:
+                few = (not many) if dyn else (0 < T < 4)
+                width = 128 if (self.n_lanes > 1 and few and n_pairs <= (1 << 19)) else 0
             if dyn:
                 pipe = PosePipeline(self.encoders[cfg.category], cfg, n_cap, n_pairs, many, self.device, self.sphere,
-                                    point_encoder=self.point_encoders.get(cfg.category), dynamic=True, **self.kw)
+                                    point_encoder=self.point_encoders.get(cfg.category), dynamic=True, vote_workgroups=width, **self.kw)
             else:
                 pipe = PosePipeline(self.encoders[cfg.category], cfg, n_points, n_pairs, dims, self.device,
-                                    self.sphere, point_encoder=self.point_encoders.get(cfg.category), **self.kw)
+                                    self.sphere, point_encoder=self.point_encoders.get(cfg.category), vote_workgroups=width, **self.kw)
             self._pipes[key] = pipe
             self._bytes[key] = need
         else:

@@ -1622,8 +1622,16 @@ struct VoteExtras { long long* grid_raw; float* quantum_out; int fixed_bits; };
 static int v3_launch(const float* points, const float* outputs, const float* probs, const void* point_idxs, int idx_is_i64,
                      float* grid_obj, const float* corner, float res, int64_t n_points, int64_t n_ppfs, int n_rots, int gx, int gy,
                      int gz, int adaptive, int accumulate, bool want_argmax, long long* out_idx, float* out_val, void* workspace,
-                     hipStream_t st, const int32_t* shape_dev, int64_t grid_cap, int many_tiles, const VoteExtras* ex = nullptr)
+                     hipStream_t st, const int32_t* shape_dev, int64_t grid_cap, int many_tiles, const VoteExtras* ex = nullptr,
+                     int wg_cap = 0)
 {
+    // Workgroups of the vote launch.  One per CU is the fastest launch on an idle chip, but every workgroup pays for its tile whatever
+    // it deposits -- zeroed, dumped (113 KB) and read back by the reduce kernel: 27 of the 72 MB a C2 call moves -- so a caller that
+    // keeps several instances in flight does better with fewer, longer-lived workgroups and the rest of the chip left to its other
+    // streams (profiles/r4_vote_workgroups.txt: 128 instead of 256 at C2, three instances in flight: +5 % pairs/s, the instance alone
+    // 7 % slower).  The hint never goes below 64 or the number of tiles; chunking follows it, the grid stays the exact sum of the
+    // deposits (the fixed-point scale follows the chunk length: one bit coarser at C2 with 128).
+    const int wgs_max = wg_cap > 0 ? (wg_cap < 64 ? 64 : (wg_cap > V3_WGS ? V3_WGS : wg_cap)) : V3_WGS;
     char* ws = static_cast<char*>(workspace);
     V3Args A = {};
     if (ex) { A.grid_raw = ex->grid_raw; A.quantum_out = ex->quantum_out; A.kk_force = ex->fixed_bits; }
@@ -1641,7 +1649,7 @@ static int v3_launch(const float* points, const float* outputs, const float* pro
     int red_blocks;
     if (shape_dev) {
         A.t_cap = many_tiles ? VOTE_MAX_TILES : 3;
-        A.wgs = V3_WGS;
+        A.wgs = wgs_max;
         A.fused = many_tiles ? 0 : 1;
         if (ex && ex->grid_raw) return CPPF_EINVAL;
         if (grid_cap > (int64_t)A.t_cap * V3_TILE_FLOATS) return CPPF_EINVAL;   // (a grid of the class has at most that many cells)
@@ -1652,6 +1660,7 @@ static int v3_launch(const float* points, const float* outputs, const float* pro
     } else {
         A.t = v3_tiling(gx, gy, gz);
         A.wgs = v3_wgs(n_ppfs, A.t.T);
+        if (A.wgs > wgs_max) A.wgs = wgs_max > A.t.T ? wgs_max : A.t.T;
         A.fused = A.t.T < 4 ? 1 : 0;
         if (A.fused) {   // static chunks: the same number for every tile
             A.wgs = (A.wgs / A.t.T) * A.t.T;
@@ -1760,6 +1769,12 @@ static int vote_impl(const float* points, const float* outputs, const float* pro
                      void* workspace, size_t workspace_bytes, hipStream_t st, const int32_t* shape_dev = nullptr,
                      int64_t grid_cap = 0, int many_tiles = 0, const VoteExtras* ex = nullptr)
 {
+    // `accumulate` is a flags word (include/cppf.h): bit 0 = add to the grid, CPPF_VOTE_WORKGROUPS(n) in bits 8..16 = launch at most n
+    // vote workgroups (a scheduling hint for callers that keep several instances in flight; 0 = one per CU)
+    const int wg_cap = (accumulate >> 8) & 0x1ff;
+    if ((accumulate & ~(1 | (0x1ff << 8))) != 0) return CPPF_EINVAL;
+    accumulate &= 1;
+    if (wg_cap != 0 && ex) return CPPF_EINVAL;   // (integer images fix their bits from the default plan: no hint there)
     if (!points || (!grid_obj && !(ex && ex->grid_raw)) || !corner) return CPPF_EINVAL;   // (probs may be null: all ones)
     if (n_ppfs > 0 && (!outputs || !point_idxs)) return CPPF_EINVAL;
     if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || gx < 1 || gy < 1 || gz < 1 || n_ppfs < 0 || n_points < 1) return CPPF_EINVAL;
@@ -1768,12 +1783,12 @@ static int vote_impl(const float* points, const float* outputs, const float* pro
         if (n_ppfs < 1 || n_ppfs > 0xffffffffll || grid_cap < 1 || grid_cap > 0x7fffffffll) return CPPF_EINVAL;
         if (!workspace || workspace_bytes < v3_workspace_bytes_dyn(many_tiles, n_ppfs)) return CPPF_EWORKSPACE;
         return v3_launch(points, outputs, probs, point_idxs, idx_is_i64, grid_obj, corner, res, n_points, n_ppfs, n_rots, gx, gy, gz,
-                         adaptive, accumulate, want_argmax, out_idx, out_val, workspace, st, shape_dev, grid_cap, many_tiles, ex);
+                         adaptive, accumulate, want_argmax, out_idx, out_val, workspace, st, shape_dev, grid_cap, many_tiles, ex, wg_cap);
     }
     if (v3_eligible(n_ppfs, n_rots, gx, gy, gz)) {
         if (!workspace || workspace_bytes < v3_workspace_bytes(n_ppfs, gx, gy, gz)) return CPPF_EWORKSPACE;
         return v3_launch(points, outputs, probs, point_idxs, idx_is_i64, grid_obj, corner, res, n_points, n_ppfs, n_rots, gx, gy, gz,
-                         adaptive, accumulate, want_argmax, out_idx, out_val, workspace, st, nullptr, 0, 0, ex);
+                         adaptive, accumulate, want_argmax, out_idx, out_val, workspace, st, nullptr, 0, 0, ex, wg_cap);
     }
     if (ex) {
         if (n_ppfs > 0) return CPPF_EUNSUPPORTED;   // the integer image exists on the tiled integer path only (<= 64 tiles)

@@ -151,8 +151,12 @@ class CenterPipeline:
     is re-packed into the same device buffer, which the captured launches read; a moved / resized image re-captures."""
 
     def __init__(self, encoder, cfg, n_points, n_pairs, dims, device, num_rots=72, adaptive=True, with_heads=True,
-                 use_graph=True, point_encoder=None, dynamic=False):
+                 use_graph=True, point_encoder=None, dynamic=False, vote_workgroups=0):
+        """vote_workgroups: 0 = the vote launches one workgroup per CU (fastest for ONE instance on an idle chip); 64..256 = at
+        most that many (cppf.h: CPPF_VOTE_WORKGROUPS) -- for callers that keep several pipelines in flight on different streams,
+        where fewer, longer-lived vote workgroups leave the rest of the chip to the other streams (bench.py, BatchPoseRunner)."""
         require_cuda()
+        self.vote_workgroups = int(vote_workgroups or 0)
         self.encoder, self.cfg, self.device = encoder, cfg, device
         self.point_encoder = point_encoder
         self.num_rots, self.adaptive, self.with_heads = num_rots, adaptive, with_heads
@@ -258,10 +262,11 @@ class CenterPipeline:
         if self.dynamic:
             voting.vote_argmax_dyn(self.pc, self.outputs, None, self.idx, self.grid_flat, shape, self.corner,
                                    self.cfg.res, self.num_rots, self.adaptive, self.out_idx, self.out_val,
-                                   many_tiles=self.many_tiles, accumulate=False)
+                                   many_tiles=self.many_tiles, accumulate=False, workgroups=self.vote_workgroups)
         else:
             voting.vote_argmax(self.pc, self.outputs, None, self.idx, self.grid, self.corner, self.cfg.res,
-                               self.num_rots, self.adaptive, self.out_idx, self.out_val, accumulate=False)
+                               self.num_rots, self.adaptive, self.out_idx, self.out_val, accumulate=False,
+                               workgroups=self.vote_workgroups)
 
     def _weight_images(self):
         """(re)build the encoders' weight images if a parameter changed; returns their identity (addresses)"""
@@ -315,6 +320,15 @@ class CenterPipeline:
         for enc in (self.encoder, self.point_encoder):
             if enc is not None:
                 enc._note_image_read(self.device)
+
+    def set_vote_workgroups(self, n):
+        """change the vote's launch width (see __init__); the chain is captured again on the next run"""
+        n = int(n or 0)
+        if n != self.vote_workgroups:
+            self.vote_workgroups = n
+            self._graph = None
+            if hasattr(self, "_graphs"):
+                self._graphs = {}
 
     def release(self):
         """drop the captured graph and this pipeline's scratch buffers (BatchPoseRunner's cache eviction)"""
@@ -525,12 +539,13 @@ class PosePipeline(CenterPipeline):
     reads back the 21-double record (one sync)."""
 
     def __init__(self, encoder, cfg, n_points, n_pairs, dims, device, sphere_pts, num_rots=72, adaptive=True,
-                 angle_tol=1.5, max_rot_pairs=10000, use_graph=True, point_encoder=None, dynamic=False, rot_order_len=0):
+                 angle_tol=1.5, max_rot_pairs=10000, use_graph=True, point_encoder=None, dynamic=False, rot_order_len=0,
+                 vote_workgroups=0):
         """rot_order_len > 0: the pipeline owns a static i32[rot_order_len] buffer `rot_order` (positions in the survivor
         list, see estimate_pose) that the captured orientation vote reads -- fill it before run() to reproduce the reference's
         shuffled subsample (nocs/inference.py:277-280); it starts as 0, 1, 2, ... (= the first survivors)."""
         super().__init__(encoder, cfg, n_points, n_pairs, dims, device, num_rots, adaptive, False, use_graph, point_encoder,
-                         dynamic)
+                         dynamic, vote_workgroups)
         self.rot_order = (torch.arange(int(rot_order_len), dtype=I32, device=device) if rot_order_len else None)
         sph64 = np.asarray(sphere_pts, dtype=np.float64)
         self.ws = PoseWorkspace(device, n_pairs, self.dims, sph64.shape[0], grid=self.grid_flat if self.dynamic else self.grid)

@@ -87,11 +87,21 @@ def _ppf_voting(points, outputs, probs, point_idxs, grid_obj, corner, res, n_ppf
     _lib.check(rc, "cppf_ppf_voting")
 
 
+def _vote_flags(accumulate, workgroups):
+    """the flags word of cppf_vote_argmax / _dyn (include/cppf.h): CPPF_VOTE_ACCUMULATE | CPPF_VOTE_WORKGROUPS(n)"""
+    w = int(workgroups or 0)
+    if w and not 64 <= w <= 256:
+        raise ValueError(f"workgroups must be 0 (one per CU) or in 64..256, got {workgroups}")
+    return (1 if accumulate else 0) | (w << 8)
+
+
 def vote_argmax(points, outputs, probs, point_idxs, grid_obj, corner, res, n_rots, adaptive, out_idx=None,
-                out_val=None, accumulate=True):
+                out_val=None, accumulate=True, workgroups=0):
     """ppf_voting + np.argmax (nocs/inference.py:197-208) without the host round trip.
     accumulate=True: grid_obj += votes (reference semantics, grid zero-initialised by the caller);
     accumulate=False: grid_obj = votes (no memset needed).
+    workgroups: 0 = one vote workgroup per CU (fastest for one instance on an idle chip); 64..256 = at most that many, for
+    callers that keep several instances in flight on different streams (cppf.h: CPPF_VOTE_WORKGROUPS).
     point_idxs may be int32 (as the reference passes it) or the original int64 pair list.
     Returns (out_idx i64[1], out_val f32[1]) device tensors."""
     dev = dev_tensor(points, F32, "points", (3,)).device
@@ -120,14 +130,14 @@ def vote_argmax(points, outputs, probs, point_idxs, grid_obj, corner, res, n_rot
     with torch.cuda.device(dev):
         rc = L.cppf_vote_argmax(points.data_ptr(), outputs.data_ptr(), None if probs is None else probs.data_ptr(), point_idxs.data_ptr(),
                                 1 if i64 else 0, grid_obj.data_ptr(), corner.data_ptr(), float(scalar(res)), points.shape[0], n_ppfs,
-                                int(n_rots), gx, gy, gz, 1 if adaptive else 0, 1 if accumulate else 0,
+                                int(n_rots), gx, gy, gz, 1 if adaptive else 0, _vote_flags(accumulate, workgroups),
                                 out_idx.data_ptr(), out_val.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr(dev))
     _lib.check(rc, "cppf_vote_argmax")
     return out_idx, out_val
 
 
 def vote_argmax_dyn(points, outputs, probs, point_idxs, grid_flat, shape, corner, res, n_rots, adaptive, out_idx, out_val,
-                    many_tiles=False, accumulate=False):
+                    many_tiles=False, accumulate=False, workgroups=0):
     """vote_argmax for a captured, shape-polymorphic chain (cppf_vote_argmax_dyn): `shape` is a device i32[4]
     {n_points, gx, gy, gz}; `points`/`probs` are capacity-sized (rows beyond n_points are never read), `grid_flat` is a
     flat f32 buffer whose first gx*gy*gz cells receive the grid in the usual C order.  Same results as vote_argmax on
@@ -149,7 +159,7 @@ def vote_argmax_dyn(points, outputs, probs, point_idxs, grid_flat, shape, corner
         rc = L.cppf_vote_argmax_dyn(points.data_ptr(), outputs.data_ptr(), None if probs is None else probs.data_ptr(), point_idxs.data_ptr(),
                                     1 if i64 else 0, grid_flat.data_ptr(), grid_flat.numel(), corner.data_ptr(),
                                     float(scalar(res)), points.shape[0], point_idxs.shape[0], int(n_rots), shape.data_ptr(),
-                                    1 if many_tiles else 0, 1 if adaptive else 0, 1 if accumulate else 0,
+                                    1 if many_tiles else 0, 1 if adaptive else 0, _vote_flags(accumulate, workgroups),
                                     out_idx.data_ptr(), out_val.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr(dev))
     _lib.check(rc, "cppf_vote_argmax_dyn")
     return out_idx, out_val

@@ -86,10 +86,17 @@ int cppf_ppf_voting(const float* points, const float* outputs, const float* prob
 /* Same vote, plus the arg-max that the reference takes on the host (nocs/inference.py:207-208:
  * grid_obj.get(); np.argmax -> first maximum in C order).  out_idx: device i64[1] flat index,
  * out_val: device f32[1] peak value (either may be NULL).
- * accumulate != 0: grid_obj += votes (the reference's semantics, caller zero-initialises, :196);
- * accumulate == 0: grid_obj  = votes (spares the caller's memset).
+ * accumulate is a flags word: bit 0 (CPPF_VOTE_ACCUMULATE) set: grid_obj += votes (the reference's semantics, caller
+ * zero-initialises, :196); clear: grid_obj = votes (spares the caller's memset).  CPPF_VOTE_WORKGROUPS(n), n in 64..256, or'ed in:
+ * launch at most n vote workgroups instead of one per CU -- a scheduling hint for callers that keep several instances in flight
+ * on different streams (every workgroup pays for a 113 KB tile it zeroes, dumps and the reduce kernel reads back, whatever it
+ * deposits: at N = 4096, K = 128 with three instances in flight 128 workgroups give +5 % pairs/s, the instance alone runs 7 %
+ * longer).  The grid stays the exact sum of the quantised deposits; the quantum follows the chunk length
+ * (cppf_vote_fixed_point_bits describes the default launch).  Other bits must be zero (CPPF_EINVAL).
  * point_idxs: device i32[n_ppfs,2] (idx_is_i64 == 0, what the reference passes after `.astype(cp.int32)`,
  * nocs/inference.py:202) or the original i64[n_ppfs,2] of np.random.randint (idx_is_i64 != 0; spares the copy). */
+#define CPPF_VOTE_ACCUMULATE 1
+#define CPPF_VOTE_WORKGROUPS(n) (((n) & 0x1ff) << 8)
 int cppf_vote_argmax(const float* points, const float* outputs, const float* probs, const void* point_idxs,
                      int idx_is_i64, float* grid_obj, const float* corner, float res, int64_t n_points, int64_t n_ppfs, int n_rots,
                      int gx, int gy, int gz, int adaptive, int accumulate, long long* out_idx, float* out_val,

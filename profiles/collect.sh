@@ -3,7 +3,8 @@
 #   1. --kernel-trace --stats of the default benchmark command  -> gpurun_out/prof/kernel_trace_stats.txt
 #      (and with --streams 1: each launch alone on the chip      -> gpurun_out/prof/kernel_trace_stats_one_stream.txt)
 #   2. PMC passes, one counter group per pass, no trace domains -> gpurun_out/prof/pmc_counters.txt
-#   3. the HBM-traffic summary bench.py reads                   -> gpurun_out/prof/pmc_traffic.json
+#   3. the HBM-traffic summary bench.py reads                   -> gpurun_out/prof/pmc_traffic.json  (kernels at full width)
+#      and the same for the default command's narrower vote     -> gpurun_out/prof/pmc_traffic_timed_width.json
 # Copy the three files into profiles/ (renamed r<round>_*) to have them judged.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
@@ -22,11 +23,22 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_s
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" \
            "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAVE_CYCLES"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc$i -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --regions 5 > /tmp/pmc$i.log 2>&1
+  # (--vote-workgroups 0: every kernel at its full width, one workgroup per CU -- the launches bench.py's stage timings and
+  #  rooflines are about; the timed regions' narrower vote is counted separately below)
+  timeout 600 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc$i -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --regions 5 --vote-workgroups 0 > /tmp/pmc$i.log 2>&1
   f=$(find /tmp/pmc$i -name '*counter_collection.csv' | head -1)
   python $R/profiles/pmcstats.py $f >> $OUT/pmc_counters.txt
 done
 python $R/profiles/make_traffic_json.py $OUT/pmc_counters.txt > $OUT/pmc_traffic.json
+# the same two traffic counters for the default command: its timed regions launch the vote 128 workgroups wide (three instances in flight)
+: > $OUT/pmc_counters_timed_width.txt
+for set in "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc$i -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --regions 5 > /tmp/pmc$i.log 2>&1
+  f=$(find /tmp/pmc$i -name '*counter_collection.csv' | head -1)
+  python $R/profiles/pmcstats.py $f >> $OUT/pmc_counters_timed_width.txt
+done
+python $R/profiles/make_traffic_json.py $OUT/pmc_counters_timed_width.txt > $OUT/pmc_traffic_timed_width.json
 # the vote stage alone per configuration and regime (known-answer = what a trained network emits)
 bash $R/profiles/vote_ktrace.sh c2 > $OUT/vote_regimes_ktrace.txt 2>&1
 bash $R/profiles/vote_ktrace.sh c5 >> $OUT/vote_regimes_ktrace.txt 2>&1

@@ -192,6 +192,14 @@ def test_voting_module_surface_and_loud_failure_without_device():
                 torch.zeros(4, 4, 4), torch.zeros(3), 0.004, 8, 72, 4, 4, 4, True)
         with pytest.raises(_lib.CppfError):
             voting.ppf_kernel((1, 1, 1), (512, 1, 1), args)
+    # the flags word of cppf_vote_argmax / _dyn (cppf.h: CPPF_VOTE_ACCUMULATE, CPPF_VOTE_WORKGROUPS)
+    hdr = open(os.path.join(ROOT, "include", "cppf.h")).read()
+    assert "#define CPPF_VOTE_ACCUMULATE 1" in hdr and "#define CPPF_VOTE_WORKGROUPS(n) (((n) & 0x1ff) << 8)" in hdr
+    assert voting._vote_flags(True, 0) == 1 and voting._vote_flags(False, 128) == 128 << 8
+    assert voting._vote_flags(True, 256) == (256 << 8) | 1
+    for bad in (1, 63, 257):
+        with pytest.raises(ValueError):
+            voting._vote_flags(False, bad)
 
 
 def test_host_utilities(golden):

@@ -334,3 +334,58 @@ def test_more_than_72_rotations_run_as_passes_of_the_same_kernels(oracle, dev, n
     used = int(round(-np.log2(float(qd))))
     want, _ = oracle.ppf_voting_fixed(ob["pc"], out, np.ones(n, np.float32), idx, dims, corners[0], res, n_rots, adaptive, used)
     assert np.array_equal(raw.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("n,k", [(1500, 40), (4096, 128)])
+def test_vote_workgroup_hint(oracle, dev, n, k):
+    """CPPF_VOTE_WORKGROUPS (cppf.h): fewer, longer-lived vote workgroups for callers with several instances in flight.  Chunking
+    and the fixed-point scale follow the width (up to two bits coarser than the default launch describes); the grid stays the sum
+    of the quantised deposits -- every cell against the exact fp64 sum, arg-max identical -- by value and through the *_dyn form;
+    undefined flag bits and a hint on the integer-image entry point are refused."""
+    from cppf_amd.inference import grid_class, grid_shape
+    ob, idx, out = case(n=n, k=k, seed=21)
+    res = ob["cfg"].res
+    corners, dims = grid_shape(ob["pc"], res)
+    pc, o, i64, corner = t(ob["pc"], dev), t(out, dev), t(idx.astype(np.int64), dev), t(corners[0], dev)
+    g64, cnt = oracle.ppf_voting_f64(ob["pc"], out, np.ones(n, np.float32), idx, dims, corners[0], res, 72, True)
+    bits = _lib.lib().cppf_vote_fixed_point_bits(idx.shape[0], 72, *[int(d) for d in dims])
+    grid0 = torch.empty(dims, dtype=torch.float32, device=dev)
+    i0, _ = voting.vote_argmax(pc, o, None, i64, grid0, corner, res, 72, True, accumulate=False)
+    assert int(i0) == int(np.argmax(g64))
+    Tn, many, cap = grid_class(dims)
+    shape = torch.tensor([n, *dims], dtype=torch.int32, device=dev)
+    G = int(np.prod(dims))
+    for w in (64, 128, 200, 256):
+        tol = 2e-6 * np.abs(g64) + cnt * (0.5 * 2.0 ** -(bits - 2)) + 1e-30
+        grid = torch.full(dims, float("nan"), dtype=torch.float32, device=dev)
+        oi, ov = voting.vote_argmax(pc, o, None, i64, grid, corner, res, 72, True, accumulate=False, workgroups=w)
+        gg = grid.cpu().numpy()
+        assert np.all(np.abs(gg.astype(np.float64) - g64) <= tol) and int(oi) == int(i0) and float(ov) == gg.max()
+        if w == 256:
+            assert torch.equal(grid, grid0)            # the default width, spelled out
+        flat = torch.zeros(cap, dtype=torch.float32, device=dev)
+        oi2, ov2 = torch.zeros(1, dtype=torch.int64, device=dev), torch.zeros(1, dtype=torch.float32, device=dev)
+        voting.vote_argmax_dyn(pc, o, None, i64, flat, shape, corner, res, 72, True, oi2, ov2, many_tiles=many, workgroups=w)
+        gd = flat[:G].view(dims).cpu().numpy()
+        assert np.all(np.abs(gd.astype(np.float64) - g64) <= tol) and int(oi2) == int(i0)
+        # += semantics with the hint
+        g1 = torch.ones(dims, dtype=torch.float32, device=dev)
+        voting.vote_argmax(pc, o, None, i64, g1, corner, res, 72, True, accumulate=True, workgroups=w)
+        np.testing.assert_allclose(g1.cpu().numpy(), gg + 1.0, rtol=1e-6, atol=1e-6)
+    with pytest.raises(ValueError):
+        voting.vote_argmax(pc, o, None, i64, grid0, corner, res, 72, True, workgroups=32)
+    L = _lib.lib()
+    need = L.cppf_vote_workspace_bytes(idx.shape[0], 72, *[int(d) for d in dims])
+    ws = torch.zeros(need, dtype=torch.uint8, device=dev)
+    oi, ov = torch.zeros(1, dtype=torch.int64, device=dev), torch.zeros(1, dtype=torch.float32, device=dev)
+    args = [pc.data_ptr(), o.data_ptr(), None, i64.data_ptr(), 1, grid0.data_ptr(), corner.data_ptr(), float(res), n, idx.shape[0], 72,
+            int(dims[0]), int(dims[1]), int(dims[2]), 1]
+    tail = [oi.data_ptr(), ov.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr(dev)]
+    assert L.cppf_vote_argmax(*args, 2, *tail) == -1           # bit 1 is not defined
+    assert L.cppf_vote_argmax(*args, 1 << 20, *tail) == -1
+    raw = torch.zeros(dims, dtype=torch.int64, device=dev)
+    q = torch.zeros(1, dtype=torch.float32, device=dev)
+    rc = L.cppf_vote_grid_raw(pc.data_ptr(), o.data_ptr(), None, i64.data_ptr(), 1, raw.data_ptr(), q.data_ptr(), corner.data_ptr(),
+                              float(res), n, idx.shape[0], 72, int(dims[0]), int(dims[1]), int(dims[2]), 1, (128 << 8), 0,
+                              ws.data_ptr(), ws.numel(), stream_ptr(dev))
+    assert rc == -1                                            # integer images keep the default plan's bits
