@@ -71,6 +71,12 @@ def run(budget, seed, dev=None):
         if srt[-1] > 0 and srt[-1] - srt[-2] > 1e-4 * srt[-1]:
             assert flat == O.grid_argmax(go)[0], tag
         n_v += 1
+        if rng.integers(3) == 0:    # the same vote launched narrower (CPPF_VOTE_WORKGROUPS): longer chunks, possibly a coarser quantum
+            w = int(rng.choice([64, 128, 200]))
+            gw, flat_w, _ = T.run_vote(dev, ob["pc"], outputs, idx32, corner, dims, res, n_rots, adaptive, probs, workgroups=w)
+            T.check_grid(O, gw, ob["pc"], outputs, idx32, corner, dims, res, n_rots, adaptive, probs, bits_slack=2)
+            if srt[-1] > 0 and srt[-1] - srt[-2] > 1e-4 * srt[-1]:
+                assert flat_w == O.grid_argmax(go)[0], tag + (w,)
         # the same vote as exact integers (tiled grids): EQUAL to the oracle's fixed-point statement, cell by cell
         if L.cppf_vote_tiles(int(dims[0]), int(dims[1]), int(dims[2])) > 0 and P > 0:
             raw = torch.full(tuple(int(d) for d in dims), -3, dtype=torch.int64, device=dev)

@@ -179,17 +179,17 @@ def test_second_pass_on_selected_pairs(oracle, dev):
 
 
 # ------------------------------------------------------------------------------------ centre vote
-def run_vote(dev, pc, outputs, idx32, corner, dims, res, n_rots, adaptive, probs=None, grid0=None):
+def run_vote(dev, pc, outputs, idx32, corner, dims, res, n_rots, adaptive, probs=None, grid0=None, workgroups=0):
     N = pc.shape[0]
     probs = np.ones(N, np.float32) if probs is None else probs
     if grid0 is not None:       # += into a pre-filled grid (the reference's semantics)
         grid = t(grid0, dev).clone()
         oi, ov = voting.vote_argmax(t(pc, dev), t(outputs, dev), t(probs, dev), t(idx32, dev), grid, t(corner, dev),
-                                    res, n_rots, adaptive)
+                                    res, n_rots, adaptive, workgroups=workgroups)
     else:                       # overwrite mode on a poisoned grid must equal += on a zeroed one
         grid = torch.full(tuple(int(d) for d in dims), float("nan"), dtype=torch.float32, device=dev)
         oi, ov = voting.vote_argmax(t(pc, dev), t(outputs, dev), t(probs, dev), t(idx32, dev), grid, t(corner, dev),
-                                    res, n_rots, adaptive, accumulate=False)
+                                    res, n_rots, adaptive, accumulate=False, workgroups=workgroups)
     torch.cuda.synchronize()
     return grid.cpu().numpy(), int(oi.item()), float(ov.item())
 
@@ -201,7 +201,7 @@ def oracle_vote(oracle, pc, outputs, idx32, corner, dims, res, n_rots, adaptive,
     return grid, na
 
 
-def check_grid(oracle, gg, pc, outputs, idx32, corner, dims, res, n_rots, adaptive, probs=None, grid0=None):
+def check_grid(oracle, gg, pc, outputs, idx32, corner, dims, res, n_rots, adaptive, probs=None, grid0=None, bits_slack=0):
     """GPU grid vs the exact (fp64) vote sum.  Tiled path: each deposit is rounded to the fixed-point
     quantum p2*2^-bits (csrc/vote.hip), so |gpu - exact| <= deposits/2 quanta + fp32 rounding of the
     chunk partial sums.  Global-atomics path: fp32 atomic order noise, like the reference itself."""
@@ -210,12 +210,13 @@ def check_grid(oracle, gg, pc, outputs, idx32, corner, dims, res, n_rots, adapti
     if grid0 is not None:
         g64 = g64 + grid0
     bits = _lib.lib().cppf_vote_fixed_point_bits(idx32.shape[0], n_rots, int(dims[0]), int(dims[1]), int(dims[2]))
+    bits = bits - bits_slack if bits > 0 else bits       # (a narrower launch, CPPF_VOTE_WORKGROUPS: longer chunks, up to two bits coarser)
     pmax = float(np.max(probs))
     if bits > 0 and np.all(np.isfinite(probs)) and np.all(probs >= 0):
         p2 = 2.0 ** np.ceil(np.log2(pmax)) if pmax > 0 else 1.0
         tol = 2e-6 * np.abs(g64) + cnt * (0.5 * p2 * 2.0 ** -bits) + 1e-30
-    else:
-        tol = 2e-5 * np.abs(g64) + 1e-6 * max(pmax, 1e-30)
+    else:   # fp32 atomics in whatever order they land: the rounding of n additions into one cell grows like sqrt(n) ulps of the sum
+        tol = (2e-5 + 1.2e-7 * np.sqrt(cnt)) * np.abs(g64) + 1e-6 * max(pmax, 1e-30)
     err = np.abs(gg.astype(np.float64) - g64)
     worst = np.unravel_index(np.argmax(err - tol), err.shape)
     assert np.all(err <= tol), f"cell {worst}: gpu {gg[worst]} exact {g64[worst]} tol {tol[worst]} deposits {cnt[worst]}"
