@@ -72,6 +72,15 @@ __device__ __forceinline__ float sqrt_rn(float x)
     return r;
 }
 
+// 1 / sqrtf(x) as the two correctly rounded operations it is (the LayerNorm's `1.0f / sqrtf(var + eps)`), for x >= 2^-20: sqrt_rn, then the
+// quotient through refined_rcp + div_by -- 18 instructions instead of the 27 of sqrtf + the compiler's IEEE division; the same bits
+// (the square root: every float of the range, above; the reciprocal: every float in [2^-10, 2^20], profiles/r4_exp2_check.txt)
+__device__ __forceinline__ float inv_sqrt_rn(float x)
+{
+    const float s = sqrt_rn(x);
+    return div_by(1.0f, s, refined_rcp(s));
+}
+
 // Softmax weight of a logit l under the shift c = -(max logit * log2e):  w = 2^y,  y = fma(l, log2e, c)  (<= 0 up to the
 // rounding of the product), evaluated as ldexp(p(f), floor(y)) with f = y - floor(y) in [0, 1) and p the degree-4 minimax of
 // 2^f on [0, 1] (relative error 2.7e-6 in fp32 Horner form -- far below what an inverse-CDF draw can resolve).

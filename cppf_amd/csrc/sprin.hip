@@ -334,7 +334,7 @@ __global__ __launch_bounds__(SP_WAVES_MAX * 64) void sprin_conv_kernel(ConvArgs 
     float v = 0.f;
 #pragma unroll
     for (int q = 0; q < SP_NOUT; ++q) { const float dd = yv[q] - mean; v = v + dd * dd; }
-    const float inv = 1.0f / sqrtf(v / (float)SP_NOUT + 1e-5f);
+    const float inv = inv_sqrt_rn(v / (float)SP_NOUT + 1e-5f);   // = 1.0f / sqrtf(.), bit for bit
     const float z = ((acc - mean) * inv) * bo[SP_NOUT + o] + bo[2 * SP_NOUT + o];
     if (live && lane < SP_NOUT) A.out[(size_t)n * A.out_stride + lane] = z;
     // GlobalInfoProp's linear on the row just written: lane g owns channel g, a bias-seeded fmaf chain over ascending input

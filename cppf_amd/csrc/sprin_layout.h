@@ -65,7 +65,7 @@ __device__ __forceinline__ void sp_ln_relu4(f32x4 (&y)[NOB], const float* __rest
         for (int r = 0; r < 4; ++r) { const float d = y[ob][r] - mean; q = q + d * d; }
     q = q + sp_xor16(q);
     q = q + sp_xor32(q, lane);
-    const float inv = 1.0f / sqrtf(q / H + 1e-5f);
+    const float inv = cppf::inv_sqrt_rn(q / H + 1e-5f);   // = 1.0f / sqrtf(.), bit for bit (cppf_math.h)
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) {
         const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 16 * ob + 4 * g);

@@ -53,6 +53,21 @@ __device__ __forceinline__ float sqrt_rn(float x)
     r = rup > 0.f ? up : r;
     return r;
 }
+// cppf_math.h:inv_sqrt_rn's reciprocal step (refined_rcp + div_by with numerator 1) against the IEEE division 1.0f / s
+__device__ __forceinline__ float refined_rcp_(float b) { const float y0 = __builtin_amdgcn_rcpf(b); const float e = fmaf(-b, y0, 1.0f); return fmaf(e, y0, y0); }
+__device__ __forceinline__ float div_by_(float a, float b, float y)
+{
+    const float q0 = a * y; const float r0 = fmaf(-b, q0, a); const float q1 = fmaf(r0, y, q0); const float r1 = fmaf(-b, q1, a);
+    return fmaf(r1, y, q1);
+}
+__global__ __launch_bounds__(256) void rcp_kernel(uint32_t first, uint32_t count, unsigned long long* bad)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < count;
+    const float x = __uint_as_float(first + (uint32_t)(live ? i : 0));
+    const unsigned long long m = __ballot(live && __float_as_uint(div_by_(1.0f, x, refined_rcp_(x))) != __float_as_uint(1.0f / x));
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&bad[7], (unsigned long long)__popcll(m));
+}
 __global__ __launch_bounds__(256) void sqrt_kernel(uint32_t first, uint32_t count, unsigned long long* bad, int slot)
 {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -65,8 +80,8 @@ __global__ __launch_bounds__(256) void sqrt_kernel(uint32_t first, uint32_t coun
 int main()
 {
     unsigned long long* bad;
-    hipMalloc(&bad, 7 * sizeof(unsigned long long));
-    hipMemset(bad, 0, 7 * sizeof(unsigned long long));
+    hipMalloc(&bad, 8 * sizeof(unsigned long long));
+    hipMemset(bad, 0, 8 * sizeof(unsigned long long));
     struct { uint32_t lo, hi; const char* what; } ranges[2] = {
         {0x80000000u, 0xC3480000u, "[-200, -0]"},
         {0x00000000u, 0x40000000u, "[+0, 2]"},
@@ -91,7 +106,15 @@ int main()
             }
         }
     }
-    unsigned long long h[7];
+    {   // every float in [2^-10, 2^20]
+        const uint32_t lo = 0x3a800000u, hi = 0x49800000u;
+        const uint64_t n = (uint64_t)hi - lo + 1;
+        for (uint64_t off = 0; off < n; off += (1u << 30)) {
+            const uint32_t cnt = (uint32_t)((n - off) < (1u << 30) ? (n - off) : (1u << 30));
+            hipLaunchKernelGGL(rcp_kernel, dim3((cnt + 255) / 256), dim3(256), 0, 0, (uint32_t)(lo + off), cnt, bad);
+        }
+    }
+    unsigned long long h[8];
     hipMemcpy(h, bad, sizeof(h), hipMemcpyDeviceToHost);
     printf("floats checked: %llu (y in [-200, -0] and [+0, 2])\n", total);
     printf("v_fract_f32 != y - floorf(y)                      : %llu\n", h[0]);
@@ -100,5 +123,6 @@ int main()
     printf("v_ldexp_f32(p, e) != RNE(p * 2^e)                 : %llu  (subnormal results seen: %llu)\n", h[3], h[4]);
     printf("sqrt_rn(x) != sqrtf(x), x = 0 and [2^-96, 2^40]   : %llu\n", h[5]);
     printf("sqrt_rn(x) != sqrtf(x), [2^-126, 2^-96), not claimed: %llu of %u\n", h[6], 0x0f7fffffu - 0x00800000u + 1u);
-    return (h[1] == 0 || h[0] == 0) && h[2] == 0 && h[3] == 0 && h[5] == 0 ? 0 : 1;
+    printf("div_by(1, s, refined_rcp(s)) != 1.0f / s, [2^-10, 2^20] : %llu\n", h[7]);
+    return (h[1] == 0 || h[0] == 0) && h[2] == 0 && h[3] == 0 && h[5] == 0 && h[7] == 0 ? 0 : 1;
 }
