@@ -3,9 +3,9 @@
 //   v_fract_f32(y)        vs  min(y - floorf(y), 0x1.fffffep-1f)      (and vs the unclamped difference)
 //   v_cvt_flr_i32_f32(y)  vs  (int)floorf(y)
 //   v_ldexp_f32(p, e)     vs  the correctly rounded p * 2^e, subnormal results included (fp64 product, one conversion)
-// and of csrc/pair_mlp.hip:sqrt_rn against sqrtf for x = 0 and every float in [2^-96, 2^40].
+// and of csrc/cppf_math.h:sqrt_rn against sqrtf for x = 0 and every float in [2^-96, 2^40], and inv_sqrt_rn's reciprocal step against 1.0f / s on [2^-10, 2^20],
 // over every float y in [-200, 2] (2.2e9 values; p = a mantissa in [1, 2.0000052) derived from y's bits).
-// Build + run:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off exp2_check.hip -o exp2_check && ./exp2_check
+// Build + run:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-honor-nans exp2_check.hip -o exp2_check && ./exp2_check
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void check_kernel(uint32_t first, uint32_t cou
     tally(4, ra != 0.f && ra < 1.17549435e-38f);   // how many subnormal results were seen
 }
 
-// csrc/pair_mlp.hip:sqrt_rn (the compiler's correctly rounded fp32 square root without its subnormal / inf / NaN handling) against sqrtf
+// csrc/cppf_math.h:sqrt_rn (the compiler's correctly rounded fp32 square root without its subnormal / inf / NaN handling) against sqrtf
 __device__ __forceinline__ float sqrt_rn(float x)
 {
     const float s = __builtin_amdgcn_sqrtf(x);
