@@ -423,3 +423,19 @@ def test_vote_plans_respect_their_invariants_without_a_device():
         assert L.cppf_vote_workspace_bytes(P, 100, gx, gy, gz) == need
     assert {2, 3} <= seen
     assert L.cppf_vote_plan_query(10, 72, 0, 4, 4, out) == -1 and L.cppf_vote_plan_query(10, 72, 4, 4, 4, None) == -1
+
+
+def test_bench_vote_width_rule():
+    """bench.py's timed pipelines: ~8 192 pairs per vote workgroup and tile when several instances are in flight (cppf.h
+    CPPF_VOTE_WORKGROUPS), one workgroup per CU for one instance at a time or from a million pairs on; an explicit flag wins"""
+    import sys
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    a = types.SimpleNamespace(vote_workgroups=-1, streams=3)
+    assert bench.vote_width(a, 524288, (26, 76, 26)) == 128      # C2: two tiles
+    assert bench.vote_width(a, 524288, (29, 83, 29)) == 192      # three tiles
+    assert bench.vote_width(a, 1048576, (26, 76, 26)) == 0       # C3: the full width
+    assert bench.vote_width(a, 100000, (20, 20, 20)) == 64       # never below 64
+    assert bench.vote_width(types.SimpleNamespace(vote_workgroups=-1, streams=1)) == 0
+    assert bench.vote_width(types.SimpleNamespace(vote_workgroups=200, streams=3)) == 200
