@@ -34,7 +34,7 @@
  * Arithmetic conventions (they are what makes the HIP path comparable bit-for-bit):
  *   - compiled with -ffp-contract=off; every fused multiply-add is an explicit fmaf()/fma().
  *   - fp64 sub-expressions of the CUDA text (1e-7, 0.01, 1.01, M_PI literals) are kept in fp64.
- *   - cos/sin/tan/exp are NOT libm: orc_sincos()/orc_expf() are fixed polynomial evaluations
+ *   - cos/sin/tan/exp are NOT libm: orc_sincos()/orc_exp2w() are fixed polynomial evaluations
  *     (sin/cos: < 1 ulp of fp64; exp: 2.7e-6 relative, it only feeds a softmax sampler) so that CPU and GPU produce the same bits and therefore the same
  *     discrete outcomes (trip counts, in/out-of-grid tests, sampled bins).
  *   - the MLP accumulates each output with an fmaf chain seeded by the bias.  order=0 walks
