@@ -1,0 +1,23 @@
+#!/bin/bash
+# Full evidence pass of a round on the GPU box (gpurun -- bash profiles/collect_all.sh): the GPU suite, the bench line of every
+# BASELINE.json config, then profiles/collect.sh (rocprofv3 kernel traces and PMC passes); outputs under gpurun_out/{final,prof}/,
+# copied into profiles/ as r<round>_* by hand.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $R/gpurun_out/final
+cd $R
+python -m pytest tests -m gpu -x -q 2>&1 | tail -5 > gpurun_out/final/gputest.txt
+python bench.py --steps 20 --warmup 5 > gpurun_out/final/bench_default.json 2> gpurun_out/final/bench_default.err
+python bench.py --steps 20 --warmup 5 --all-heads --no-cpu-baseline > gpurun_out/final/bench_all_heads.json 2>/dev/null
+for c in c3 c5; do python bench.py --steps 20 --warmup 5 --config $c --no-cpu-baseline > gpurun_out/final/bench_$c.json 2>/dev/null; done
+python bench.py --config c4 --no-cpu-baseline > gpurun_out/final/bench_c4.json 2>/dev/null
+python bench.py --config c1 > gpurun_out/final/bench_c1.json 2>/dev/null
+bash profiles/collect.sh > gpurun_out/final/collect.log 2>&1
+cat gpurun_out/final/gputest.txt
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob("gpurun_out/final/bench_*.json")):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1])
+        print(f.split("/")[-1], "value %.4g"%d["value"], "ms %.5f"%d["ms_per_step"], (d.get("roofline") or {}).get("frac"), (d.get("roofline") or {}).get("launch_ms"))
+    except Exception as e: print(f, "failed", e)
+PY
