@@ -50,6 +50,7 @@ _SIGS = {
                                         sz, vp]),
     "cppf_pair_mlp_decode": (C.c_int, [vp, vp, vp, vp, i32, vp, i64, i32, C.POINTER(C.c_int), i32, i64, i32, i32, i32,
                                        f32, f32, vp, vp, vp, vp, vp, sz, vp]),
+    "cppf_pair_mlp_decode_batch": (C.c_int, [i32, vp, i32, C.POINTER(C.c_int), i32, i32, i32, i32, vp]),
     "cppf_pair_mlp_decode_sel": (C.c_int, [vp, vp, vp, vp, i32, vp, i64, i32, C.POINTER(C.c_int), i32, i64, i32, i32, i32, vp, vp, vp,
                                            i64, vp, vp, sz, vp]),
     "cppf_decode_center": (C.c_int, [vp, i64, i32, i32, f32, f32, vp, vp, vp]),
@@ -88,6 +89,14 @@ _SIGS = {
     "cppf_point_encoder_forward": (C.c_int, [vp, vp, vp, i32, i32, vp, C.POINTER(C.c_int), i32, i32, i32, i32, i32, i32,
                                              vp, vp, sz, vp]),
 }
+
+class PairMlpItem(C.Structure):
+    """include/cppf.h: CppfPairMlpItem (one pair list of cppf_pair_mlp_decode_batch)"""
+    _fields_ = [("pc", C.c_void_p), ("nrm", C.c_void_p), ("feat", C.c_void_p), ("idxs", C.c_void_p), ("packed", C.c_void_p),
+                ("u_tr", C.c_void_p), ("u_rot", C.c_void_p), ("outputs", C.c_void_p), ("heads", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("n_points", C.c_int64), ("n_pairs", C.c_int64),
+                ("vr0", C.c_float), ("vr1", C.c_float), ("idx_is_i64", C.c_int)]
+
 
 ABI_VERSION = 2     # include/cppf.h CPPF_ABI_VERSION: the vote workspace contract + cppf_vote_grid_raw
 

@@ -374,8 +374,10 @@ __global__ __launch_bounds__(256) void point_proj_kernel(const float* __restrict
     }
 }
 
-template <bool LOGITS, bool DECODE, bool HEADS, bool SEL = false>
-__global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kernel(MlpArgs A)
+// The kernel's body for workgroup `wg` of the `n_wg` that share the pair list of `A` (one launch = one list: wg = blockIdx.x of
+// gridDim.x; a batched launch = several lists, each with its own workgroups: pair_mlp_batch_kernel).
+template <bool LOGITS, bool DECODE, bool HEADS, bool SEL>
+__device__ __forceinline__ void pair_mlp_body(const MlpArgs& A, const int wg, const int n_wg)
 {
     extern __shared__ __attribute__((aligned(16))) float W[];
     {
@@ -416,8 +418,8 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
     // waited for the slowest with a fifth of its issue slots idle (s_memtime trace, profiles/r2_pair_mlp_phases.txt).
     // A workgroup owns a contiguous range of tiles; a wave claims tile t+2 (whose pair indices it prefetches) while
     // tile t runs, so the claim's latency is never waited for.
-    const int per_wg = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int wg_begin = (int)blockIdx.x * per_wg;
+    const int per_wg = (n_tiles + n_wg - 1) / n_wg;
+    const int wg_begin = wg * per_wg;
     const int wg_end = min(wg_begin + per_wg, n_tiles);
     auto claim = [&]() -> int {
         int v = 0;
@@ -678,6 +680,30 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kern
     }
 }
 
+template <bool LOGITS, bool DECODE, bool HEADS, bool SEL = false>
+__global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_kernel(MlpArgs A)
+{
+    pair_mlp_body<LOGITS, DECODE, HEADS, SEL>(A, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Several pair lists in ONE launch (cppf_pair_mlp_decode_batch): workgroups [wg_begin[i], wg_begin[i + 1]) work on list i, so every
+// base pointer -- and the weight image: the lists may belong to different networks -- stays workgroup-uniform and the tile loop is
+// the single-list one.  What it buys: the ~9 us before a workgroup's first MFMA (weights -> LDS, the first cold index -> gather
+// chain) are paid per LAUNCH, not per list.
+#define MLP_BATCH_MAX 8
+struct MlpBatch {
+    MlpArgs item[MLP_BATCH_MAX];
+    int wg_begin[MLP_BATCH_MAX + 1];
+    int n;
+};
+template <bool HEADS>
+__global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_batch_kernel(MlpBatch B)
+{
+    int i = 0;
+    while (i + 1 < B.n && (int)blockIdx.x >= B.wg_begin[i + 1]) ++i;
+    pair_mlp_body<false, true, HEADS, false>(B.item[i], (int)blockIdx.x - B.wg_begin[i], B.wg_begin[i + 1] - B.wg_begin[i]);
+}
+
 // ----------------------------------------------------------------------------- generic kernel
 // Any ResLayer stack up to 128 units wide: one pair per lane, activations in LDS ([k][lane], no
 // bank conflicts), weights read through the scalar path (wave-uniform addresses), natural k order
@@ -918,6 +944,60 @@ extern "C" int cppf_pair_mlp_decode(const float* pc, const float* nrm, const flo
     A.idx64 = idx_is_i64; A.u_tr = u_tr; A.u_rot = u_rot; A.outputs = outputs; A.heads = heads; A.vr0 = vr0; A.vr1 = vr1;
     return heads ? launch_std<false, true, true>(A, N, workspace, workspace_bytes, (hipStream_t)stream)
                  : launch_std<false, true, false>(A, N, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int cppf_pair_mlp_decode_batch(int n_items, const CppfPairMlpItem* items, int F, const int* dims, int n_res, int out_dim,
+                                          int tr_bins, int rot_bins, void* stream)
+{
+    if (n_items < 1 || n_items > MLP_BATCH_MAX || !items || !dims) return CPPF_EINVAL;
+    if (!is_std(F, dims, n_res, out_dim) || tr_bins != 32 || rot_bins != 36 || out_dim != 141) return CPPF_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    MlpBatch B = {};
+    B.n = n_items;
+    const bool heads = items[0].heads != nullptr;
+    int64_t tiles_all = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const CppfPairMlpItem& it = items[i];
+        if (it.n_pairs < 1 || it.n_points < 1) return CPPF_EINVAL;
+        if (!it.pc || !it.nrm || !it.feat || !it.idxs || !it.packed || !it.u_tr || !it.outputs) return CPPF_EINVAL;
+        if ((it.heads != nullptr) != heads || (it.heads != nullptr) != (it.u_rot != nullptr)) return CPPF_EINVAL;
+        if (it.n_points >= (1ll << 23) || it.n_pairs >= (1ll << 27)) return CPPF_EUNSUPPORTED;
+        if (!it.workspace || it.workspace_bytes < (size_t)it.n_points * PROJ_COLS * sizeof(float)) return CPPF_EWORKSPACE;
+        tiles_all += (it.n_pairs + 15) / 16;
+    }
+    // workgroups in proportion to the lists' tiles, at least one each, as many in all as one list alone would get
+    const int total = mlp_grid(tiles_all * 16) < n_items ? n_items : mlp_grid(tiles_all * 16);
+    int given = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const CppfPairMlpItem& it = items[i];
+        const int64_t tiles = (it.n_pairs + 15) / 16;
+        int w = (int)((tiles * total + tiles_all - 1) / tiles_all);
+        const int left = total - given - (n_items - 1 - i);
+        if (w > left) w = left;
+        if (w < 1) w = 1;
+        B.wg_begin[i] = given;
+        given += w;
+        float* table = static_cast<float*>(it.workspace);
+        hipLaunchKernelGGL(point_proj_kernel, dim3((unsigned)((it.n_points + PROJ_PPB - 1) / PROJ_PPB)), dim3(256), 0, st, it.feat, it.packed,
+                           table, it.n_points);
+        CPPF_CHECK_LAUNCH();
+        MlpArgs& A = B.item[i];
+        A.pc = it.pc; A.nrm = it.nrm; A.feat = it.feat; A.idxs = it.idxs; A.packed = it.packed; A.P = it.n_pairs; A.out_dim = out_dim;
+        A.idx64 = it.idx_is_i64; A.u_tr = it.u_tr; A.u_rot = it.u_rot; A.outputs = it.outputs; A.heads = it.heads;
+        A.vr0 = it.vr0; A.vr1 = it.vr1; A.table = table;
+    }
+    B.wg_begin[n_items] = given;
+    static bool attr_done[2] = {false, false};
+    const void* fn = heads ? reinterpret_cast<const void*>(&pair_mlp_batch_kernel<true>) : reinterpret_cast<const void*>(&pair_mlp_batch_kernel<false>);
+    if (!attr_done[heads]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (STD_LDS + 128) * sizeof(float));
+        if (e != hipSuccess) return (int)e;
+        attr_done[heads] = true;
+    }
+    if (heads) hipLaunchKernelGGL((pair_mlp_batch_kernel<true>), dim3((unsigned)given), dim3(MLP_THREADS), (STD_LDS + 128) * sizeof(float), st, B);
+    else hipLaunchKernelGGL((pair_mlp_batch_kernel<false>), dim3((unsigned)given), dim3(MLP_THREADS), (STD_LDS + 128) * sizeof(float), st, B);
+    CPPF_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int cppf_pair_mlp_decode_sel(const float* pc, const float* nrm, const float* feat, const void* idxs,

@@ -747,3 +747,50 @@ def flatten_state_dict(sd, ppffcs):
         offs.append(pos)
         pos += a.size
     return np.concatenate(chunks).astype(np.float32), np.asarray(offs, dtype=np.int64)
+
+
+def forward_decode_batch(items, tr_num_bins=32, rot_num_bins=36):
+    """PPFEncoder.forward_decode for up to 8 pair lists in ONE launch (cppf_pair_mlp_decode_batch): the instances of a frame, each
+    with its own cloud, pair list and encoder (the reference keeps one network per category, nocs/inference.py:79-90).  `items`:
+    dicts {encoder, pc, pc_normal, feat, idxs, u_tr, vote_range[, u_rot]}; all with u_rot or none.  Returns [(outputs, heads)] in
+    order -- the same bits as one forward_decode call per item; what the batch saves is the ~9 us a launch spends before its
+    first MFMA (weights -> LDS, the first cold index -> gather chain), paid once instead of once per list."""
+    if not 1 <= len(items) <= 8:
+        raise ValueError("1 to 8 pair lists per launch")
+    enc0 = items[0]["encoder"]
+    dev = items[0]["pc"].device
+    dims = (C.c_int * len(enc0.ppffcs))(*enc0.ppffcs)
+    arr = (_lib.PairMlpItem * len(items))()
+    keep, outs = [], []
+    for i, it in enumerate(items):
+        enc = it["encoder"]
+        if enc.ppffcs != enc0.ppffcs or enc.out_dim != enc0.out_dim:
+            raise ValueError("the encoders of one launch must share an architecture")
+        idxs = enc._as_index_tensor(it["idxs"], dev)
+        pc, nrm, feat = enc._check_inputs(it["pc"], it["pc_normal"], it["feat"])
+        P = idxs.shape[0]
+        u_tr, u_rot = it["u_tr"], it.get("u_rot")
+        for nm, u in (("u_tr", u_tr), ("u_rot", u_rot)):
+            if u is not None and (u.dtype != torch.float32 or not u.is_contiguous() or tuple(u.shape) != (P, 2) or u.device != dev):
+                raise ValueError(f"{nm} must be a contiguous f32[P,2] tensor on {dev}")
+        outputs = torch.empty((P, 2), dtype=torch.float32, device=dev)
+        heads = torch.empty((P, 8), dtype=torch.float32, device=dev) if u_rot is not None else None
+        need = _lib.lib().cppf_pair_mlp_workspace_bytes(pc.shape[0], feat.shape[1], dims, len(enc.ppffcs) - 1, enc.out_dim)
+        ws = workspace(max(int(need), 256), dev, f"pair_mlp_batch{i}")       # (each list its own per-point table)
+        packed = enc._packed_weights(dev)
+        a = arr[i]
+        a.pc, a.nrm, a.feat, a.idxs, a.packed = pc.data_ptr(), nrm.data_ptr(), feat.data_ptr(), idxs.data_ptr(), packed.data_ptr()
+        a.u_tr, a.u_rot = u_tr.data_ptr(), (u_rot.data_ptr() if u_rot is not None else None)
+        a.outputs, a.heads = outputs.data_ptr(), (heads.data_ptr() if heads is not None else None)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        a.n_points, a.n_pairs = pc.shape[0], P
+        a.vr0, a.vr1 = float(it["vote_range"][0]), float(it["vote_range"][1])
+        a.idx_is_i64 = 1 if idxs.dtype == torch.int64 else 0
+        keep.append((idxs, pc, nrm, feat, ws, packed))
+        outs.append((outputs, heads))
+    with torch.cuda.device(dev):
+        rc = _lib.lib().cppf_pair_mlp_decode_batch(len(items), C.cast(arr, C.c_void_p), items[0]["feat"].shape[1], dims,
+                                                   len(enc0.ppffcs) - 1, enc0.out_dim, tr_num_bins, rot_num_bins, stream_ptr(dev))
+    _lib.check(rc, "cppf_pair_mlp_decode_batch")
+    return outs
+

@@ -290,6 +290,29 @@ int cppf_pair_mlp_decode(const float* pc, const float* nrm, const float* feat, c
                          const float* u_rot, float* outputs, float* heads, void* workspace, size_t workspace_bytes,
                          void* stream);
 
+/* The same call for up to 8 pair lists in ONE launch -- the instances of a frame (nocs/inference.py:120 loops over them), each with
+ * its own cloud, pair list, outputs, per-point workspace and weight image (the reference keeps one network per category, :79-90).
+ * The lists get workgroups in proportion to their lengths; the ~9 us a launch spends before its first MFMA are paid once.
+ * Results are those of n_items cppf_pair_mlp_decode calls, bit for bit.  All items with heads / u_rot or none. */
+typedef struct CppfPairMlpItem {
+    const float* pc;        /* device f32[n_points,3] */
+    const float* nrm;       /* device f32[n_points,3] */
+    const float* feat;      /* device f32[n_points,F] */
+    const void* idxs;       /* device i32 / i64 [n_pairs,2] */
+    const float* packed;    /* device weight image (cppf_pair_mlp_pack) */
+    const float* u_tr;      /* device f32[n_pairs,2] */
+    const float* u_rot;     /* device f32[n_pairs,2] or NULL */
+    float* outputs;         /* device f32[n_pairs,2] */
+    float* heads;           /* device f32[n_pairs,8] or NULL */
+    void* workspace;        /* device, cppf_pair_mlp_workspace_bytes(n_points, ...) */
+    size_t workspace_bytes;
+    int64_t n_points, n_pairs;
+    float vr0, vr1;
+    int idx_is_i64;
+} CppfPairMlpItem;
+int cppf_pair_mlp_decode_batch(int n_items, const CppfPairMlpItem* items_host, int F, const int* dims, int n_res, int out_dim,
+                               int tr_bins, int rot_bins, void* stream);
+
 /* The second MLP pass of nocs/inference.py:236-256 -- ppf_encoder(..., idxs=point_idxs[mask]) followed by the decode of the
  * rotation bins, the sign logits and the log-scales -- on the surviving pairs only, without materialising point_idxs[mask]:
  * slot i < min(*n_sel_dev, max_sel) works on pair sel[i] (cppf_compact_mask's output) and writes heads[sel[i]]; u_rot is

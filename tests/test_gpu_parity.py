@@ -1004,3 +1004,40 @@ def test_batch_runner_lanes_do_not_share_scratch(golden, dev):
         for j, a in enumerate(alone):
             got = np.concatenate([recs[j, 0:3], recs[j, 3:6], recs[j, 9:12], recs[j, 12:13], recs[j, 14:15]])
             assert np.array_equal(got, a), (rep, j, got, a)
+
+
+@pytest.mark.parametrize("with_heads", [False, True])
+def test_batched_decode_equals_per_list_calls(dev, with_heads):
+    """cppf_pair_mlp_decode_batch: several pair lists -- own clouds, sizes, index widths, two different networks -- in ONE launch give
+    the bits of one cppf_pair_mlp_decode call each; argument errors are reported"""
+    from cppf_amd.models.model import forward_decode_batch
+    encs = [make_encoder(seeded_sd(s), [84, 32, 32, 16], 141, dev) for s in (0, 5)]
+    items, want = [], []
+    for j, (n, k, seed) in enumerate([(700, 9, 1), (2048, 40, 2), (64, 1, 3), (1500, 33, 4), (300, 5, 5)]):
+        ob = syn.make_object(["bottle", "mug", "can", "laptop", "bowl"][j], n, seed)
+        idx = syn.make_pairs(n, k, seed)
+        if j % 2:
+            idx = idx.astype(np.int32)
+        u_tr, u_rot = syn.make_uniforms(idx.shape[0], seed)
+        u_tr[:3] = -1.0
+        enc = encs[j % 2]
+        it = dict(encoder=enc, pc=t(ob["pc"], dev), pc_normal=t(ob["normals"], dev), feat=t(ob["feat"], dev), idxs=t(idx, dev),
+                  u_tr=t(u_tr, dev), vote_range=ob["cfg"].vote_range)
+        if with_heads:
+            it["u_rot"] = t(u_rot, dev)
+        items.append(it)
+        with torch.no_grad():
+            want.append(enc.forward_decode(it["pc"], it["pc_normal"], it["feat"], it["idxs"], it["u_tr"], it["vote_range"],
+                                           it.get("u_rot")))
+    for lo, hi in ((0, 5), (0, 1), (1, 3)):
+        with torch.no_grad():
+            got = forward_decode_batch(items[lo:hi])
+        for j, (o, h) in enumerate(got):
+            wo, wh = want[lo + j]
+            assert torch.equal(o, wo) and (h is None) == (wh is None) and (h is None or torch.equal(h, wh))
+    mixed = [dict(items[0]), dict(items[1])]
+    mixed[1]["u_rot"] = None if with_heads else t(syn.make_uniforms(items[1]["idxs"].shape[0], 9)[1], dev)
+    with pytest.raises(_lib.CppfError):
+        forward_decode_batch(mixed)
+    with pytest.raises(ValueError):
+        forward_decode_batch(items + items)
