@@ -209,6 +209,45 @@ def vote_width(args, n_pairs=524288, dims=(26, 76, 26)):
     return 0 if w >= 256 else max(64, w)
 
 
+def mlp_batch(args):
+    if args.mlp_batch >= 1:
+        return min(args.mlp_batch, 8)
+    return 3 if args.streams > 1 and not args.no_graph else 1
+
+
+def make_stepper(dev, pipes, streams, res_buf, steps, B):
+    """-> run(n): n steps, step k = object k mod len(pipes).  B = 1: every step is its own chain on stream k mod S.  B > 1: B
+    consecutive objects form ONE chain -- their pair lists in one launch of the pair kernel, then each object's vote + arg-max
+    (CenterBatchPipeline) -- on stream (k / B) mod S; a remainder of n mod B steps runs as single chains, so that EXACTLY n objects
+    are processed.  Every step's 16-byte result is kept (one device copy on its stream); the caller's stream waits for all of them."""
+    from cppf_amd.inference import CenterBatchPipeline
+    n_obj, S = len(pipes), len(streams)
+    B = max(1, min(B, n_obj // S))      # at least one chain per stream (a captured chain does not run beside itself)
+    batches = [CenterBatchPipeline(pipes[i:i + B]) for i in range(0, n_obj - n_obj % B, B)] if B > 1 else []
+
+    def run(n):
+        main = torch.cuda.current_stream(dev)
+        for st in streams:
+            st.wait_stream(main)
+        j = 0
+        if batches:
+            for c in range(n // B):
+                bp = batches[c % len(batches)]
+                with torch.cuda.stream(streams[c % S]):
+                    bp.run(check_weights=c < len(batches))
+                    for q, p in enumerate(bp.pipes):
+                        res_buf[(c * B + q) % steps].copy_(p.result, non_blocking=True)
+            j = (n // B) * B
+        for k in range(j, n):
+            with torch.cuda.stream(streams[k % S]):
+                pipes[k % n_obj].run(check_weights=k < n_obj + j)
+                res_buf[k % steps].copy_(pipes[k % n_obj].result, non_blocking=True)
+        for st in streams:
+            main.wait_stream(st)
+    run.batch = B
+    return run
+
+
 def make_center_set(enc, dev, n_points, k, res, n_obj, seed0, with_heads=True, use_graph=True, cat="bottle", vote_workgroups=0):
     """n_obj distinct objects (seed0 + i), each with its own CenterPipeline (static buffers + captured graph), loaded"""
     out = []
@@ -323,20 +362,12 @@ def run_center_config(name, enc, sd, dev, rank, world, args):
             return sharding.gather_records(records, world * steps, rank, world, dev)   # the one collective
         return records
 
-    def run_steps(n):
-        """n steps, step k = object k mod n_obj on stream k mod S; every step's result is kept (one 16-byte device copy on its
-        stream); the caller's stream waits for all of them at the end"""
-        main = torch.cuda.current_stream(dev)
-        for st in streams:
-            st.wait_stream(main)
-        for j in range(n):
-            with torch.cuda.stream(streams[j % n_streams]):
-                pipes[j % n_obj].run(check_weights=j < n_obj)
-                res_all[j % steps].copy_(pipes[j % n_obj].result, non_blocking=True)
-        for st in streams:
-            main.wait_stream(st)
-
-    run_steps(max(args.warmup, n_obj))      # every object's graph is captured and replayed at least once
+    B = mlp_batch(args)
+    run_steps = make_stepper(dev, pipes, streams, res_all, steps, B)
+    if B > 1:
+        for p_ in pipes:                    # the single chains too (a remainder of steps mod B, the one-instance latency)
+            p_.run()
+    run_steps(max(args.warmup, 2 * n_obj))  # every chain is captured and replayed at least once
     close_batch()                           # warm-up of the gather too (RCCL communicators are created on first use)
     settle()
 
@@ -357,6 +388,7 @@ def run_center_config(name, enc, sd, dev, rank, world, args):
     elapsed = regions[len(regions) // 2]
     lat = events_per_chain(dev, pipes, max(20, steps))
     return dict(objs=objs, pipes=pipes, P=P, n_points=n_points, k=k, n_obj=n_obj, n_streams=n_streams, elapsed=elapsed,
+                mlp_batch=run_steps.batch,
                 regions=regions, allrec=allrec, lat=lat, what=c["what"])
 
 
@@ -388,7 +420,9 @@ def workload_text(name, m, args):
             (f"{m['n_streams']} independent objects in flight on {m['n_streams']} HIP streams" +
              (f", each vote launched {m['objs'][0]['pipe'].vote_workgroups} workgroups wide; " if m['objs'][0]['pipe'].vote_workgroups else "; ") if m["n_streams"] > 1
              else "one object at a time; ") +
-            ("four launches per step replayed from a hipGraph" if not args.no_graph else "eager launches"))
+            (f"the pair lists of {m['mlp_batch']} consecutive objects share one launch of the pair kernel (cppf_pair_mlp_decode_batch), "
+             "each object then its own vote and reduce launch; chains replayed from hipGraphs" if m.get("mlp_batch", 1) > 1 else
+             ("four launches per step replayed from a hipGraph" if not args.no_graph else "eager launches")))
 
 
 def c4_objects(n_objects, n_points, k, seed0=500):
@@ -509,6 +543,9 @@ def main():
     ap.add_argument("--vote-workgroups", type=int, default=-1, help="width of the vote launches of the timed pipelines: 0 = one "
                     "workgroup per CU, 64..256 = at most that many (cppf.h CPPF_VOTE_WORKGROUPS); -1 = 128 when more than one "
                     "instance is in flight (--streams > 1), one per CU otherwise")
+    ap.add_argument("--mlp-batch", type=int, default=-1, help="objects whose pair lists share ONE launch of the pair kernel "
+                    "(cppf_pair_mlp_decode_batch / CenterBatchPipeline: the ~9 us a launch spends before its first MFMA are paid once "
+                    "per launch); 1 = one launch per object; -1 = 3 when more than one instance is in flight (--streams > 1), else 1")
     ap.add_argument("--streams", type=int, default=3, help="instances in flight per GPU: step k runs on HIP stream k mod S "
                     "(1 = strictly one instance at a time)")
     ap.add_argument("--objects", type=int, default=9, help="distinct objects the steps rotate over (rounded up to a multiple of "
@@ -629,23 +666,19 @@ def main():
                              with_heads=True, use_graph=not args.no_graph, vote_workgroups=lambda P_, d_: vote_width(args, P_, d_))
         sts = [torch.cuda.Stream(device=dev) for _ in range(m["n_streams"])]
 
-        def ah_steps(n):
-            main = torch.cuda.current_stream(dev)
-            for st in sts:
-                st.wait_stream(main)
-            for j in range(n):
-                with torch.cuda.stream(sts[j % len(sts)]):
-                    ah[j % len(ah)]["pipe"].run(check_weights=j < len(ah))
-                    res_sec[j % steps].copy_(ah[j % len(ah)]["pipe"].result, non_blocking=True)   # (every step's result is kept, as in the headline)
-            for st in sts:
-                main.wait_stream(st)
-        ah_steps(len(ah))
+        ah_steps = make_stepper(dev, [o["pipe"] for o in ah], sts, res_sec, steps, m["mlp_batch"])
+        for o in ah:
+            o["pipe"].run()
+        ah_steps(2 * len(ah))
         settle()
-        torch.cuda.synchronize()
-        ta0 = time.perf_counter()
-        ah_steps(steps)
-        torch.cuda.synchronize()
-        t_ah = (time.perf_counter() - ta0) / steps * 1e3
+        regs_ah = []
+        for _ in range(9):
+            torch.cuda.synchronize()
+            ta0 = time.perf_counter()
+            ah_steps(steps)
+            torch.cuda.synchronize()
+            regs_ah.append((time.perf_counter() - ta0) / steps * 1e3)
+        t_ah = sorted(regs_ah)[len(regs_ah) // 2]
         lat_ah = events_per_chain(dev, [o["pipe"] for o in ah], 20)
         all_heads_step = {"ms_per_step": t_ah, "pairs_per_s": P / (t_ah * 1e-3), "median_ms_one_instance": lat_ah[len(lat_ah) // 2]}
         del ah
@@ -679,16 +712,9 @@ def main():
             tpipes = [o["pipe"] for o in tobjs]
             streams = [torch.cuda.Stream(device=dev) for _ in range(m["n_streams"])]
 
-            def tr_steps(n):
-                main = torch.cuda.current_stream(dev)
-                for st in streams:
-                    st.wait_stream(main)
-                for j in range(n):
-                    with torch.cuda.stream(streams[j % len(streams)]):
-                        tpipes[j % len(tpipes)].run(check_weights=j < len(tpipes))
-                        res_sec[j % steps].copy_(tpipes[j % len(tpipes)].result, non_blocking=True)
-                for st in streams:
-                    main.wait_stream(st)
+            tr_steps = make_stepper(dev, tpipes, streams, res_sec, steps, m["mlp_batch"])
+            for p_ in tpipes:
+                p_.run()
             tr_steps(2 * len(tpipes))
             settle()
             reg = []
@@ -1020,6 +1046,8 @@ def main():
             # width of the vote launches in the timed regions (cppf.h CPPF_VOTE_WORKGROUPS; 0 = one per CU): with several instances
             # in flight fewer, longer-lived vote workgroups pay fewer 113 KB tiles (zeroed, dumped, reduced) per instance
             "vote_workgroups": m["objs"][0]["pipe"].vote_workgroups,
+            # objects per launch of the pair kernel in the timed regions (1 = a launch per object)
+            "mlp_batch": m["mlp_batch"],
             "trained_regime": trained,
             "all_heads_first_pass": all_heads_step,
             "dropin_flow_reference_defaults": dropin,

@@ -533,6 +533,76 @@ def nocs_result(poses, res=None):
     return res
 
 
+class CenterBatchPipeline:
+    """Several CenterPipelines replayed as ONE captured chain: the pair lists of all members in one launch of the pair kernel
+    (models.model.forward_decode_batch: the ~9 us a launch spends before its first MFMA are paid once, 70.9 -> 64.0 us per C2
+    list in threes), then every member's vote + arg-max.  Members keep their buffers and results (`pipes[i].out_idx`, `.result`,
+    `.outputs`, `.grid`): load them as usual, run the batch instead of the members.  Static-shape members on one device, no point
+    encoder in front, all with the rotation heads or none; up to 8."""
+
+    def __init__(self, pipes, use_graph=True):
+        pipes = list(pipes)
+        if not 1 <= len(pipes) <= 8:
+            raise ValueError("1 to 8 pipelines per batch")
+        if any(p.dynamic or p.point_encoder is not None or p.device != pipes[0].device or p.with_heads != pipes[0].with_heads
+               for p in pipes):
+            raise _lib.CppfError("CenterBatchPipeline takes static-shape CenterPipelines on one device, without a point encoder")
+        self.pipes, self.device = pipes, pipes[0].device
+        self._use_graph, self._graph, self._images = use_graph, None, None
+
+    def _chain(self):
+        from .models.model import forward_decode_batch
+        p0 = self.pipes[0]
+        items = []
+        for p in self.pipes:
+            it = dict(encoder=p.encoder, pc=p.pc, pc_normal=p.nrm, feat=p.feat, idxs=p.idx, u_tr=p.u_tr, vote_range=p.cfg.vote_range)
+            if p.with_heads:
+                it["u_rot"] = p.u_rot
+            items.append(it)
+        outs = forward_decode_batch(items, p0.cfg.tr_num_bins, p0.cfg.rot_num_bins)
+        for p, (o, h) in zip(self.pipes, outs):
+            p.outputs, p.heads = o, h
+            voting.vote_argmax(p.pc, o, None, p.idx, p.grid, p.corner, p.cfg.res, p.num_rots, p.adaptive, p.out_idx, p.out_val,
+                               accumulate=False, workgroups=p.vote_workgroups)
+
+    def run(self, check_weights=True):
+        """-> [(out_idx, out_val)] of the members (device tensors, as CenterPipeline.run returns them)"""
+        with torch.no_grad(), workspace_scope(id(self)):
+            if not self._use_graph:
+                self._chain()
+            else:
+                images = tuple(tuple(p._weight_images()) for p in self.pipes) if check_weights or self._graph is None else self._images
+                if self._graph is not None and images != self._images:
+                    self._graph = None
+                if self._graph is None:
+                    s = torch.cuda.Stream(device=self.device)
+                    s.wait_stream(torch.cuda.current_stream(self.device))
+                    with torch.cuda.stream(s):
+                        self._chain()
+                        self._chain()
+                    torch.cuda.current_stream(self.device).wait_stream(s)
+                    self._graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
+                        self._chain()
+                    self._images = images
+                for p in self.pipes:
+                    p._await_images()
+                self._graph.replay()
+                for p in self.pipes:
+                    p._note_images_read()
+        return [(p.out_idx, p.out_val) for p in self.pipes]
+
+    def release(self):
+        self._graph = None
+        release_scope(id(self))
+
+    def __del__(self):
+        try:
+            release_scope(id(self))
+        except Exception:
+            pass
+
+
 class PosePipeline(CenterPipeline):
     """Full per-instance pose for a fixed problem shape (or, with dynamic=True, for every shape up to its capacities, see
     CenterPipeline): the centre chain plus the pose tail, captured together in one hipGraph; `run()` replays it and

@@ -1041,3 +1041,46 @@ def test_batched_decode_equals_per_list_calls(dev, with_heads):
         forward_decode_batch(mixed)
     with pytest.raises(ValueError):
         forward_decode_batch(items + items)
+
+
+def test_center_batch_pipeline_equals_member_pipelines(golden, dev):
+    """CenterBatchPipeline: the members' pair lists in one launch of the pair kernel, then each member's vote -- the same (mu, nu),
+    grid and arg-max as every member run on its own; replay after new data; argument checks"""
+    from cppf_amd.inference import CenterBatchPipeline, CenterPipeline, grid_shape
+    enc = make_encoder(seeded_sd(3), [84, 32, 32, 16], 141, dev)
+    pipes, data = [], []
+    for j, (cat, n, k) in enumerate([("bottle", 1200, 24), ("mug", 800, 40), ("bowl", 1500, 16)]):
+        ob = syn.make_object(cat, n, 30 + j)
+        idx = syn.make_pairs(n, k, 30 + j)
+        u_tr, u_rot = syn.make_uniforms(idx.shape[0], 30 + j)
+        corners, dims = grid_shape(ob["pc"], ob["cfg"].res)
+        p = CenterPipeline(enc, ob["cfg"], n, idx.shape[0], dims, dev, 72, adaptive=True, with_heads=False,
+                           vote_workgroups=128 if j == 1 else 0)
+        p.load(ob["pc"], ob["normals"], ob["feat"], idx, u_tr, u_rot, corners[0].copy())
+        pipes.append(p)
+        data.append((ob, idx, u_tr, u_rot, corners))
+    want = []
+    for p in pipes:
+        p.run()
+        want.append((p.outputs.clone(), p.grid.clone(), int(p.out_idx), float(p.out_val)))
+    bp = CenterBatchPipeline(pipes)
+    for rep in range(3):
+        res = bp.run()
+        torch.cuda.synchronize()
+        for p, (o, g, i, v), (oi, ov) in zip(pipes, want, res):
+            assert torch.equal(p.outputs, o) and torch.equal(p.grid, g) and int(oi) == i and float(ov) == v
+    # new uniforms for one member: the captured chain reads the static buffers (member.outputs is the tensor of whichever chain
+    # was captured last -- here the batch's)
+    ob, idx, u_tr, u_rot, corners = data[0]
+    u2, _ = syn.make_uniforms(idx.shape[0], 777)
+    pipes[0].load(None, None, None, None, u2, None, None)
+    bp.run()
+    torch.cuda.synchronize()
+    fresh = CenterPipeline(enc, ob["cfg"], ob["pc"].shape[0], idx.shape[0], pipes[0].dims, dev, 72, adaptive=True, with_heads=False)
+    fresh.load(ob["pc"], ob["normals"], ob["feat"], idx, u2, u_rot, corners[0].copy())
+    fresh.run()
+    torch.cuda.synchronize()
+    assert torch.equal(pipes[0].outputs, fresh.outputs) and torch.equal(pipes[0].grid, fresh.grid)
+    assert int(pipes[0].out_idx) == int(fresh.out_idx) and not torch.equal(fresh.outputs, want[0][0])
+    with pytest.raises(ValueError):
+        CenterBatchPipeline([])
