@@ -209,10 +209,13 @@ def vote_width(args, n_pairs=524288, dims=(26, 76, 26)):
     return 0 if w >= 256 else max(64, w)
 
 
-def mlp_batch(args):
+def mlp_batch(args, n_pairs=524288):
+    """objects per launch of the pair kernel in the timed regions: 4 with several instances in flight (1, 2, 4 or 8 lists of equal
+    length keep each list on its own XCDs: cppf_pair_mlp_decode_batch), 1 beyond a million pairs per object -- a launch's fixed
+    cost is under 2 % of it there and the longer chains overlap worse (C5: 0.449 against 0.441 ms per step)"""
     if args.mlp_batch >= 1:
         return min(args.mlp_batch, 8)
-    return 3 if args.streams > 1 and not args.no_graph else 1
+    return 4 if args.streams > 1 and not args.no_graph and n_pairs <= (1 << 20) else 1
 
 
 def make_stepper(dev, pipes, streams, res_buf, steps, B):
@@ -341,7 +344,8 @@ def run_center_config(name, enc, sd, dev, rank, world, args):
     n_points, k = (args.n_points or c["n_points"]), (args.pairs_per_point or c["k"])
     n_streams = max(1, args.streams)
     group = torch.distributed.is_initialized()       # world > 1, or ONE rank with CPPF_FORCE_DIST=1 (the RCCL branches on one GPU)
-    n_obj = max(n_streams, -(-args.objects // n_streams) * n_streams)      # a multiple of the streams: pipe j stays on stream j mod S
+    B = mlp_batch(args, n_points * k)
+    n_obj = max(n_streams * B, -(-args.objects // (n_streams * B)) * n_streams * B)   # whole chains of B objects, a multiple of the streams
     objs = make_center_set(enc, dev, n_points, k, c["res"], n_obj, seed0=100 * rank, with_heads=args.all_heads,
                            use_graph=not args.no_graph, vote_workgroups=lambda P_, d_: vote_width(args, P_, d_))
     pipes = [o["pipe"] for o in objs]
@@ -362,7 +366,6 @@ def run_center_config(name, enc, sd, dev, rank, world, args):
             return sharding.gather_records(records, world * steps, rank, world, dev)   # the one collective
         return records
 
-    B = mlp_batch(args)
     run_steps = make_stepper(dev, pipes, streams, res_all, steps, B)
     if B > 1:
         for p_ in pipes:                    # the single chains too (a remainder of steps mod B, the one-instance latency)
@@ -545,7 +548,8 @@ def main():
                     "instance is in flight (--streams > 1), one per CU otherwise")
     ap.add_argument("--mlp-batch", type=int, default=-1, help="objects whose pair lists share ONE launch of the pair kernel "
                     "(cppf_pair_mlp_decode_batch / CenterBatchPipeline: the ~9 us a launch spends before its first MFMA are paid once "
-                    "per launch); 1 = one launch per object; -1 = 3 when more than one instance is in flight (--streams > 1), else 1")
+                    "per launch); 1 = one launch per object; -1 = 4 when more than one instance is in flight (--streams > 1) and an "
+                    "object has at most a million pairs, else 1")
     ap.add_argument("--streams", type=int, default=3, help="instances in flight per GPU: step k runs on HIP stream k mod S "
                     "(1 = strictly one instance at a time)")
     ap.add_argument("--objects", type=int, default=9, help="distinct objects the steps rotate over (rounded up to a multiple of "
@@ -618,7 +622,24 @@ def main():
     with torch.no_grad():
         t_mlp_all = bracket([mlp_fn(o, True) for o in objs], n_ev) if (args.all_heads or secondary) else None     # ms
         t_mlp_tr = bracket([mlp_fn(o, False) for o in objs], n_ev) if (not args.all_heads or secondary) else None
-        t_mlp = t_mlp_all if args.all_heads else t_mlp_tr          # the pair stage of the timed chain
+        t_mlp = t_mlp_all if args.all_heads else t_mlp_tr          # the pair stage of a single chain
+        # ... and of the timed regions' chains when the pair lists of several objects share a launch (per LAUNCH of B lists)
+        n_lists = m["mlp_batch"]
+        t_mlp_launch = t_mlp
+        if n_lists > 1:
+            from cppf_amd.models.model import forward_decode_batch
+
+            def mlp_batch_fn(group):
+                items = []
+                for o in group:
+                    p_ = o["pipe"]
+                    it = dict(encoder=enc, pc=p_.pc, pc_normal=p_.nrm, feat=p_.feat, idxs=p_.idx, u_tr=p_.u_tr, vote_range=o["cfg"].vote_range)
+                    if args.all_heads:
+                        it["u_rot"] = p_.u_rot
+                    items.append(it)
+                return lambda: forward_decode_batch(items, group[0]["cfg"].tr_num_bins, group[0]["cfg"].rot_num_bins)
+            groups = [objs[i:i + n_lists] for i in range(0, len(objs) - len(objs) % n_lists, n_lists)]
+            t_mlp_launch = bracket([mlp_batch_fn(g) for g in groups], max(n_ev // n_lists, 3))
         t_vote = bracket([vote_fn(o, ws, o["pipe"].outputs) for o, ws in zip(objs, wss)], n_ev)
 
     def landed_samples(outs):
@@ -1066,15 +1087,23 @@ def main():
             # frac is BOUNDED: the MFMA FLOP the kernel EXECUTES over the fp32-MFMA peak.  (Rounds 1-3 divided the reference's
             # algorithmic FLOP -- 80 of the 188 MFMAs per tile are hoisted to a per-point table and never executed per pair -- by
             # the same time and called that a fraction: it reached 1.01 at C5.  It is kept as `algorithmic_tflops`, a rate.)
-            "roofline": {"bound": "mfma", "kernel": "pair_mlp_kernel<false,true,%s>" % ("true" if args.all_heads else "false"),
-                         "achieved": flop_exec * P / (t_mlp * 1e-3) / 1e12, "peak": PEAK_F32_MFMA,
-                         "unit": "TFLOP/s", "frac": flop_exec * P / (t_mlp * 1e-3) / 1e12 / PEAK_F32_MFMA,
-                         "traffic": pmc_traffic("pair_mlp_kernel<false, true, %s>" % ("true" if args.all_heads else "false")),
-                         "executed_flop_per_pair": flop_exec, "launch_ms": t_mlp,
-                         "algorithmic_tflops": flop_pair * P / (t_mlp * 1e-3) / 1e12, "algorithmic_flop_per_pair": flop_pair,
+            # With --mlp-batch B > 1 the timed regions launch the pair kernel once per B objects (pair_mlp_batch_kernel): the launch the
+            # roofline is about is that one -- B lists, B x P pairs, between the two events -- and the single-list launch is kept beside it.
+            "roofline": {"bound": "mfma", "kernel": ("pair_mlp_batch_kernel<%s>" if n_lists > 1 else "pair_mlp_kernel<false,true,%s>")
+                                                    % ("true" if args.all_heads else "false"),
+                         "achieved": flop_exec * P * n_lists / (t_mlp_launch * 1e-3) / 1e12, "peak": PEAK_F32_MFMA,
+                         "unit": "TFLOP/s", "frac": flop_exec * P * n_lists / (t_mlp_launch * 1e-3) / 1e12 / PEAK_F32_MFMA,
+                         "traffic": (pmc_traffic("pair_mlp_batch_kernel<%s>" % ("true" if args.all_heads else "false")) if n_lists > 1 else None)
+                                    or (lambda tr_: None if tr_ is None else tr_ * n_lists)(
+                                        pmc_traffic("pair_mlp_kernel<false, true, %s>" % ("true" if args.all_heads else "false"))),
+                         "executed_flop_per_pair": flop_exec, "launch_ms": t_mlp_launch, "lists_per_launch": n_lists,
+                         "pairs_per_launch": P * n_lists, "single_list_launch_ms": t_mlp,
+                         "single_list_frac": flop_exec * P / (t_mlp * 1e-3) / 1e12 / PEAK_F32_MFMA,
+                         "algorithmic_tflops": flop_pair * P * n_lists / (t_mlp_launch * 1e-3) / 1e12, "algorithmic_flop_per_pair": flop_pair,
                          "note": f"achieved = MFMA FLOP the kernel issues ({flop_exec} per pair: 2 x 16x16x4 x the tile's MFMAs / 16 pairs) "
-                                 "x pairs / duration of the pair-encoder stage (point_proj_kernel + pair_mlp_kernel, HIP events on the "
-                                 "launch stream, launches back to back on one stream, inputs rotating over the objects); "
+                                 "x pairs / duration of the pair-encoder stage (point_proj_kernel per list + ONE pair kernel launch for "
+                                 "`lists_per_launch` lists, HIP events on the launch stream, launches back to back on one stream, inputs "
+                                 "rotating over the objects; traffic = the launch's PMC bytes, or the single-list launch's x lists); "
                                  f"algorithmic_tflops = the reference's layers for the outputs this pass produces ({flop_pair} FLOP per "
                                  "pair) over the same time -- larger, because the two 40-wide feature blocks of layer 0 are projected "
                                  "once per POINT; fp32 MFMA shares the VALU datapath on gfx950 (32 cycles per MFMA, 4 per VALU "
