@@ -51,6 +51,7 @@ _SIGS = {
     "cppf_pair_mlp_decode": (C.c_int, [vp, vp, vp, vp, i32, vp, i64, i32, C.POINTER(C.c_int), i32, i64, i32, i32, i32,
                                        f32, f32, vp, vp, vp, vp, vp, sz, vp]),
     "cppf_pair_mlp_decode_batch": (C.c_int, [i32, vp, i32, C.POINTER(C.c_int), i32, i32, i32, i32, vp]),
+    "cppf_pair_mlp_batch_plan": (C.c_int, [i32, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "cppf_pair_mlp_decode_sel": (C.c_int, [vp, vp, vp, vp, i32, vp, i64, i32, C.POINTER(C.c_int), i32, i64, i32, i32, i32, vp, vp, vp,
                                            i64, vp, vp, sz, vp]),
     "cppf_decode_center": (C.c_int, [vp, i64, i32, i32, f32, f32, vp, vp, vp]),

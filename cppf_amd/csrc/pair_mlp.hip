@@ -956,6 +956,49 @@ extern "C" int cppf_pair_mlp_decode(const float* pc, const float* nrm, const flo
                  : launch_std<false, true, false>(A, N, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+// The launch geometry of cppf_pair_mlp_decode_batch for lists of n_pairs[i] pairs: workgroups in proportion to the lists' tiles, at
+// least one each, as many in all as one list alone would get (wg_begin[n + 1]); with 1, 2, 4 or 8 lists within 10 % of each other
+// and a grid of at least 8 the XCD-aware form (per_xcd = 8 / n > 0, the grid rounded down to a multiple of 8).
+static void batch_plan(int n_items, const int64_t* n_pairs, int* wg_begin, int* per_xcd, int* grid)
+{
+    int64_t tiles_all = 0, tmin = INT64_MAX, tmax = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const int64_t tiles = (n_pairs[i] + 15) / 16;
+        tiles_all += tiles;
+        tmin = tiles < tmin ? tiles : tmin; tmax = tiles > tmax ? tiles : tmax;
+    }
+    const int total = mlp_grid(tiles_all * 16) < n_items ? n_items : mlp_grid(tiles_all * 16);
+    int given = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const int64_t tiles = (n_pairs[i] + 15) / 16;
+        int w = (int)((tiles * total + tiles_all - 1) / tiles_all);
+        const int left = total - given - (n_items - 1 - i);
+        if (w > left) w = left;
+        if (w < 1) w = 1;
+        wg_begin[i] = given;
+        given += w;
+    }
+    wg_begin[n_items] = given;
+    *per_xcd = 0;
+    if (8 % n_items == 0 && tmax * 10 <= tmin * 11 && given >= 8) {
+        *per_xcd = 8 / n_items;
+        given = given / 8 * 8;
+    }
+    *grid = given;
+}
+
+extern "C" int cppf_pair_mlp_batch_plan(int n_items, const int64_t* n_pairs, int* per_xcd, int* grid, int* wg_begin)
+{
+    if (n_items < 1 || n_items > MLP_BATCH_MAX || !n_pairs || !per_xcd || !grid) return CPPF_EINVAL;
+    for (int i = 0; i < n_items; ++i)
+        if (n_pairs[i] < 1 || n_pairs[i] >= (1ll << 27)) return CPPF_EINVAL;
+    int wb[MLP_BATCH_MAX + 1];
+    batch_plan(n_items, n_pairs, wb, per_xcd, grid);
+    if (wg_begin)
+        for (int i = 0; i <= n_items; ++i) wg_begin[i] = wb[i];
+    return 0;
+}
+
 extern "C" int cppf_pair_mlp_decode_batch(int n_items, const CppfPairMlpItem* items, int F, const int* dims, int n_res, int out_dim,
                                           int tr_bins, int rot_bins, void* stream)
 {
@@ -965,28 +1008,20 @@ extern "C" int cppf_pair_mlp_decode_batch(int n_items, const CppfPairMlpItem* it
     MlpBatch B = {};
     B.n = n_items;
     const bool heads = items[0].heads != nullptr;
-    int64_t tiles_all = 0;
+    int64_t n_pairs[MLP_BATCH_MAX];
+    int given = 0;
     for (int i = 0; i < n_items; ++i) {
         const CppfPairMlpItem& it = items[i];
+        n_pairs[i] = it.n_pairs;
         if (it.n_pairs < 1 || it.n_points < 1) return CPPF_EINVAL;
         if (!it.pc || !it.nrm || !it.feat || !it.idxs || !it.packed || !it.u_tr || !it.outputs) return CPPF_EINVAL;
         if ((it.heads != nullptr) != heads || (it.heads != nullptr) != (it.u_rot != nullptr)) return CPPF_EINVAL;
         if (it.n_points >= (1ll << 23) || it.n_pairs >= (1ll << 27)) return CPPF_EUNSUPPORTED;
         if (!it.workspace || it.workspace_bytes < (size_t)it.n_points * PROJ_COLS * sizeof(float)) return CPPF_EWORKSPACE;
-        tiles_all += (it.n_pairs + 15) / 16;
     }
-    // workgroups in proportion to the lists' tiles, at least one each, as many in all as one list alone would get
-    const int total = mlp_grid(tiles_all * 16) < n_items ? n_items : mlp_grid(tiles_all * 16);
-    int given = 0;
+    batch_plan(n_items, n_pairs, B.wg_begin, &B.per_xcd, &given);
     for (int i = 0; i < n_items; ++i) {
         const CppfPairMlpItem& it = items[i];
-        const int64_t tiles = (it.n_pairs + 15) / 16;
-        int w = (int)((tiles * total + tiles_all - 1) / tiles_all);
-        const int left = total - given - (n_items - 1 - i);
-        if (w > left) w = left;
-        if (w < 1) w = 1;
-        B.wg_begin[i] = given;
-        given += w;
         float* table = static_cast<float*>(it.workspace);
         hipLaunchKernelGGL(point_proj_kernel, dim3((unsigned)((it.n_points + PROJ_PPB - 1) / PROJ_PPB)), dim3(256), 0, st, it.feat, it.packed,
                            table, it.n_points);
@@ -995,18 +1030,6 @@ extern "C" int cppf_pair_mlp_decode_batch(int n_items, const CppfPairMlpItem* it
         A.pc = it.pc; A.nrm = it.nrm; A.feat = it.feat; A.idxs = it.idxs; A.packed = it.packed; A.P = it.n_pairs; A.out_dim = out_dim;
         A.idx64 = it.idx_is_i64; A.u_tr = it.u_tr; A.u_rot = it.u_rot; A.outputs = it.outputs; A.heads = it.heads;
         A.vr0 = it.vr0; A.vr1 = it.vr1; A.table = table;
-    }
-    B.wg_begin[n_items] = given;
-    {   // XCD-aware form: 8 % n == 0, lists within 10 % of each other, a grid that is a multiple of 8
-        int64_t tmin = INT64_MAX, tmax = 0;
-        for (int i = 0; i < n_items; ++i) {
-            const int64_t tiles = (items[i].n_pairs + 15) / 16;
-            tmin = tiles < tmin ? tiles : tmin; tmax = tiles > tmax ? tiles : tmax;
-        }
-        if (8 % n_items == 0 && tmax * 10 <= tmin * 11 && given >= 8) {
-            B.per_xcd = 8 / n_items;
-            given = given / 8 * 8;
-        }
     }
     static bool attr_done[2] = {false, false};
     const void* fn = heads ? reinterpret_cast<const void*>(&pair_mlp_batch_kernel<true>) : reinterpret_cast<const void*>(&pair_mlp_batch_kernel<false>);

@@ -749,6 +749,16 @@ def flatten_state_dict(sd, ppffcs):
     return np.concatenate(chunks).astype(np.float32), np.asarray(offs, dtype=np.int64)
 
 
+def batch_plan(n_pairs):
+    """geometry of forward_decode_batch for lists of these lengths (cppf_pair_mlp_batch_plan): dict(per_xcd, grid, wg_begin) --
+    per_xcd > 0: the XCD-pinned mapping (1, 2, 4 or 8 lists of nearly equal length), 0: contiguous workgroup ranges"""
+    n = len(n_pairs)
+    arr = (C.c_int64 * n)(*[int(v) for v in n_pairs])
+    per_xcd, grid, wb = C.c_int(0), C.c_int(0), (C.c_int * (n + 1))()
+    _lib.check(_lib.lib().cppf_pair_mlp_batch_plan(n, arr, C.byref(per_xcd), C.byref(grid), wb), "cppf_pair_mlp_batch_plan")
+    return dict(per_xcd=per_xcd.value, grid=grid.value, wg_begin=list(wb))
+
+
 def forward_decode_batch(items, tr_num_bins=32, rot_num_bins=36):
     """PPFEncoder.forward_decode for up to 8 pair lists in ONE launch (cppf_pair_mlp_decode_batch): the instances of a frame, each
     with its own cloud, pair list and encoder (the reference keeps one network per category, nocs/inference.py:79-90).  `items`:

@@ -21,16 +21,23 @@ def forced():
 
 
 def init_distributed(backend=None, force=None):
-    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the environment (torchrun contract).  The group is created when
-    WORLD_SIZE > 1, or when `force` (default: CPPF_FORCE_DIST) asks for it with a single rank."""
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / LOCAL_WORLD_SIZE / MASTER_* from the environment (torchrun contract).  The group is
+    created when WORLD_SIZE > 1, or when `force` (default: CPPF_FORCE_DIST) asks for it with a single rank.  Returns (rank, world,
+    device index): LOCAL_RANK -- or, when this node has fewer GPUs than local ranks, LOCAL_RANK mod the GPUs present: the ranks then
+    share devices and rendezvous over gloo (RCCL needs a GPU per rank), so that a one-GPU box runs the whole multi-rank path."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "0") or 0) or (local + 1)
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    shared = 0 < n_dev < local_world
+    if shared:
+        local = local % n_dev
     if force is None:
         force = forced()
     if (world > 1 or force) and not dist.is_initialized():
         if backend is None:   # RCCL on GPUs; CPPF_DIST_BACKEND=gloo lets two ranks share one GPU when debugging on a small box
-            backend = os.environ.get("CPPF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+            backend = os.environ.get("CPPF_DIST_BACKEND") or ("nccl" if n_dev > 0 and not shared else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":

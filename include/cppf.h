@@ -312,6 +312,11 @@ typedef struct CppfPairMlpItem {
 } CppfPairMlpItem;
 int cppf_pair_mlp_decode_batch(int n_items, const CppfPairMlpItem* items_host, int F, const int* dims, int n_res, int out_dim,
                                int tr_bins, int rot_bins, void* stream);
+/* The geometry that launch takes for lists of n_pairs[i] pairs (host arrays; no device work): *grid workgroups; *per_xcd > 0 = the
+ * XCD-pinned mapping (1, 2, 4 or 8 lists within 10 % of each other: list i runs on XCDs [i per_xcd, (i + 1) per_xcd), so each
+ * XCD's L2 holds ONE list's per-point table), 0 = contiguous workgroup ranges wg_begin[0..n_items] (optional output, may be NULL).
+ * For callers that size batches and for tests that must know which mapping a launch exercised. */
+int cppf_pair_mlp_batch_plan(int n_items, const int64_t* n_pairs, int* per_xcd, int* grid, int* wg_begin);
 
 /* The second MLP pass of nocs/inference.py:236-256 -- ppf_encoder(..., idxs=point_idxs[mask]) followed by the decode of the
  * rotation bins, the sign logits and the log-scales -- on the surviving pairs only, without materialising point_idxs[mask]:

@@ -113,5 +113,6 @@ def test_bench_with_the_rccl_group_forced_on(extra):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["unit"] == "pairs/s"
-    assert d["dist"] == {"backend": "nccl", "forced_single_rank": True}
+    assert d["dist"]["backend"] == "nccl" and d["dist"]["forced_single_rank"] is True
+    assert d["dist"]["ranks_seen"] == 1 and d["dist"]["device_per_rank"] == [0] and d["dist"]["shared_gpu"] is False
     assert d["regions"] >= 5 and d["region_ms_min_max"][0] <= d["ms_per_step"] * d["steps"] <= d["region_ms_min_max"][1]
