@@ -257,7 +257,7 @@ def mlp_batch(args, n_pairs=524288):
     return 4 if args.streams > 1 and not args.no_graph and n_pairs <= (1 << 20) else 1
 
 
-def make_stepper(dev, pipes, streams, res_buf, steps, B):
+def make_stepper(dev, pipes, streams, res_buf, steps, B, vote_batch=True, vote_batch_wgs=0):
     """-> run(n): n steps, step k = object k mod len(pipes).  B = 1: every step is its own chain on stream k mod S.  B > 1: B
     consecutive objects form ONE chain -- their pair lists in one launch of the pair kernel, then each object's vote + arg-max
     (CenterBatchPipeline) -- on stream (k / B) mod S; a remainder of n mod B steps runs as single chains, so that EXACTLY n objects
@@ -265,7 +265,8 @@ def make_stepper(dev, pipes, streams, res_buf, steps, B):
     from cppf_amd.inference import CenterBatchPipeline
     n_obj, S = len(pipes), len(streams)
     B = max(1, min(B, n_obj // S))      # at least one chain per stream (a captured chain does not run beside itself)
-    batches = [CenterBatchPipeline(pipes[i:i + B]) for i in range(0, n_obj - n_obj % B, B)] if B > 1 else []
+    batches = [CenterBatchPipeline(pipes[i:i + B], vote_batch=vote_batch, vote_workgroups=vote_batch_wgs)
+               for i in range(0, n_obj - n_obj % B, B)] if B > 1 else []
 
     def run(n):
         main = torch.cuda.current_stream(dev)
@@ -405,7 +406,7 @@ def run_center_config(name, enc, sd, dev, rank, world, args):
             return sharding.gather_records(records, world * steps, rank, world, dev)   # the one collective
         return records
 
-    run_steps = make_stepper(dev, pipes, streams, res_all, steps, B)
+    run_steps = make_stepper(dev, pipes, streams, res_all, steps, B, not args.no_vote_batch, args.vote_batch_workgroups)
     if B > 1:
         for p_ in pipes:                    # the single chains too (a remainder of steps mod B, the one-instance latency)
             p_.run()
@@ -670,6 +671,10 @@ def main():
                     "(cppf_pair_mlp_decode_batch / CenterBatchPipeline: the ~9 us a launch spends before its first MFMA are paid once "
                     "per launch); 1 = one launch per object; -1 = 4 when more than one instance is in flight (--streams > 1) and an "
                     "object has at most a million pairs, else 1")
+    ap.add_argument("--no-vote-batch", action="store_true", help="with --mlp-batch > 1: a vote + reduce launch per object (round 4's chain) "
+                    "instead of ONE vote launch and ONE reduce launch for the objects of a chain (cppf_vote_argmax_batch)")
+    ap.add_argument("--vote-batch-workgroups", type=int, default=0, help="workgroups per object of the batched vote (0 = 256 / objects per "
+                    "chain, at least 32)")
     ap.add_argument("--streams", type=int, default=3, help="instances in flight per GPU: step k runs on HIP stream k mod S "
                     "(1 = strictly one instance at a time)")
     ap.add_argument("--objects", type=int, default=9, help="distinct objects the steps rotate over (rounded up to a multiple of "
@@ -816,7 +821,7 @@ def main():
                              with_heads=True, use_graph=not args.no_graph, vote_workgroups=lambda P_, d_: vote_width(args, P_, d_))
         sts = [torch.cuda.Stream(device=dev) for _ in range(m["n_streams"])]
 
-        ah_steps = make_stepper(dev, [o["pipe"] for o in ah], sts, res_sec, steps, m["mlp_batch"])
+        ah_steps = make_stepper(dev, [o["pipe"] for o in ah], sts, res_sec, steps, m["mlp_batch"], not args.no_vote_batch, args.vote_batch_workgroups)
         for o in ah:
             o["pipe"].run()
         ah_steps(2 * len(ah))
@@ -862,7 +867,7 @@ def main():
             tpipes = [o["pipe"] for o in tobjs]
             streams = [torch.cuda.Stream(device=dev) for _ in range(m["n_streams"])]
 
-            tr_steps = make_stepper(dev, tpipes, streams, res_sec, steps, m["mlp_batch"])
+            tr_steps = make_stepper(dev, tpipes, streams, res_sec, steps, m["mlp_batch"], not args.no_vote_batch, args.vote_batch_workgroups)
             for p_ in tpipes:
                 p_.run()
             tr_steps(2 * len(tpipes))

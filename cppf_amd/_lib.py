@@ -28,6 +28,8 @@ _SIGS = {
     "cppf_vote_plan_query": (C.c_int, [i64, i32, i32, i32, i32, vp]),
     "cppf_vote_argmax_dyn": (C.c_int, [vp, vp, vp, vp, i32, vp, i64, vp, f32, i64, i64, i32, vp, i32, i32, i32, vp, vp, vp, sz,
                                        vp]),
+    "cppf_vote_batch_workgroups": (C.c_int, [i32, i32]),
+    "cppf_vote_argmax_batch": (C.c_int, [i32, vp, i32, i32, i32, vp]),
     "cppf_center_from_argmax_dyn": (C.c_int, [vp, vp, C.c_double, vp, vp, vp, vp, vp, vp]),
     "cppf_backvote_ws": (C.c_int, [vp, vp, vp, vp, vp, f32, i64, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp]),
     "cppf_backvote_dyn": (C.c_int, [vp, vp, vp, vp, vp, f32, i64, i32, vp, vp, f32, vp, vp]),
@@ -99,7 +101,16 @@ class PairMlpItem(C.Structure):
                 ("vr0", C.c_float), ("vr1", C.c_float), ("idx_is_i64", C.c_int)]
 
 
-ABI_VERSION = 2     # include/cppf.h CPPF_ABI_VERSION: the vote workspace contract + cppf_vote_grid_raw
+class VoteItem(C.Structure):
+    """include/cppf.h: CppfVoteItem (one object of cppf_vote_argmax_batch)"""
+    _fields_ = [("points", C.c_void_p), ("outputs", C.c_void_p), ("probs", C.c_void_p), ("point_idxs", C.c_void_p), ("grid", C.c_void_p),
+                ("corner", C.c_void_p), ("out_idx", C.c_void_p), ("out_val", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t), ("shape_dev", C.c_void_p), ("grid_capacity", C.c_int64), ("n_points", C.c_int64),
+                ("n_ppfs", C.c_int64), ("res", C.c_float), ("gx", C.c_int), ("gy", C.c_int), ("gz", C.c_int), ("idx_is_i64", C.c_int),
+                ("many_tiles", C.c_int)]
+
+
+ABI_VERSION = 3     # include/cppf.h CPPF_ABI_VERSION: batched votes (CppfVoteItem), cppf_pair_mlp_batch_plan
 
 
 class CppfError(RuntimeError):

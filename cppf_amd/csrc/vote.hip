@@ -622,6 +622,7 @@ __global__ __launch_bounds__(V3_BIN_THREADS) void v3_bin_kernel(V3Args A)
     int64_t n_points;
     V3Tiling t;
     if (blockIdx.x == 0 && tid < 20) A.packed[tid] = 0ull;   // arg-max keys + tickets of the reduce kernel, its error-path ticket [18]
+    if (blockIdx.x == 0 && tid == 20 && A.win_base == 0) A.packed[20] = 0ull;   // "an earlier pass of this call gave up" (n_rots > 72)
     if (!v3_resolve(A, gx, gy, gz, n_points, t)) return;   // (the reduce kernel reports it)
     {
         const unsigned m = A.hdr->magic;
@@ -988,8 +989,10 @@ __device__ __forceinline__ void v3_deposit(const V3Tile& T, f3 v, float prob)
 }
 
 #define V3_LDS_HEAD (VOTE_CARRY_CAP * 4 + (V3_THREADS / 64) * VOTE_PAIRQ * 4 + 64 + VOTE_BELOW_N * 16)
+// `bid`: this workgroup's index within ITS launch -- blockIdx.x, or blockIdx.x minus the first workgroup of its item when the votes
+// of several objects share one launch (v3_vote_batch_kernel)
 template <bool FUSED, bool WIDE>
-__global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
+__device__ __forceinline__ void v3_vote_body(const V3Args& A, const int bid)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // LDS: [carry log 8 KiB][pair queues 16 x 128 x u32 = 8 KiB (fused mode)][ctrl 64 B][arc-mask table 97 x 16 B]
@@ -1002,7 +1005,7 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
     uint32_t* tile = reinterpret_cast<uint32_t*>(ltab + A.tab_entries + 2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef V3_TRACE   // development aid (profiles/microbench/vote_trace.py): wall-clock stamps per workgroup in the unused tail of the extra plane
-    unsigned long long* trace = A.plane + 1500000 + (int64_t)blockIdx.x * 32;
+    unsigned long long* trace = A.plane + 1500000 + (int64_t)bid * 32;
     if (tid == 0) trace[0] = wall_clock64();
 #endif
     int gx, gy, gz;
@@ -1024,7 +1027,8 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
     for (int u = 0; u < (VOTE_TAB_LDS_MAX + V3_THREADS - 1) / V3_THREADS; ++u)
         tab_in[u] = tid + u * V3_THREADS < A.tab_entries ? wtab[tid + u * V3_THREADS] : make_float2(0.f, 0.f);
     const int wb = WIDE ? A.win_base : 0;
-    if (FUSED && blockIdx.x == 0 && tid < 20) A.packed[tid] = 0ull;   // arg-max keys + tickets of the reduce kernel (binned: the bin kernel did)
+    if (FUSED && bid == 0 && tid < 20) A.packed[tid] = 0ull;   // arg-max keys + tickets of the reduce kernel (binned: the bin kernel did)
+    if (FUSED && bid == 0 && tid == 20 && wb == 0) A.packed[20] = 0ull;   // "an earlier pass of this call gave up" (n_rots > 72)
     if (!v3_resolve(A, gx, gy, gz, n_points, pt)) return;
     int* sp = reinterpret_cast<int*>(carry_log);   // (the carry log is unused until the main loop)
     v3_split(A, pt.T, sp);
@@ -1036,21 +1040,21 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
     unsigned n_t = 0u;
     for (int k = 0; k < pt.T; ++k) {
         const int ck = sp[k], bk = sp[64 + k];
-        if ((int)blockIdx.x >= bk && (int)blockIdx.x < bk + ck) { t = k; c = (int)blockIdx.x - bk; Ct = ck; n_t = (unsigned)sp[128 + k]; }
+        if (bid >= bk && bid < bk + ck) { t = k; c = bid - bk; Ct = ck; n_t = (unsigned)sp[128 + k]; }
     }
     // every workgroup must use the same scale: the launch's largest chunk (fused, by-value: fixed on the host, like the plan)
     const int kk = A.kk_force ? A.kk_force : ((FUSED && !A.shape) ? A.kk : v3_bits((unsigned)sp[192], A.n_rots));
     __syncthreads();   // (sp is the carry log: everybody has read it)
-    if (t < 0 && blockIdx.x != 0) return;            // more workgroups than chunks
+    if (t < 0 && bid != 0) return;            // more workgroups than chunks
     // binned: records [r0, r1) of the tile's queue; fused: pairs [p0, p1) of the pair list
     unsigned r0 = 0u, r1 = 0u;
     int64_t p0 = 0, p1 = 0;
     if (FUSED) {   // blocks c, c + Ct, c + 2 Ct, ... of 64 pairs (v3_fused_chunk_pairs)
         p0 = 0; p1 = A.n_ppfs;
-        if ((int64_t)c * 64 >= p1 && blockIdx.x != 0) return;
+        if ((int64_t)c * 64 >= p1 && bid != 0) return;
     } else {
         if (t >= 0) { r0 = v3_bound(n_t, c, Ct); r1 = v3_bound(n_t, c + 1, Ct); }
-        if (r0 >= r1 && blockIdx.x != 0) return;     // nothing queued for this chunk: no tile to zero or dump (the reduce kernel skips it too)
+        if (r0 >= r1 && bid != 0) return;     // nothing queued for this chunk: no tile to zero or dump (the reduce kernel skips it too)
     }
     if (t < 0) t = 0;                                // (workgroup 0 of a launch without a single record: an empty tile, the launch-wide duties)
     const int tix = t / pt.nty, tiy = t - tix * pt.nty;
@@ -1093,7 +1097,7 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
             if (tid + u * V3_THREADS < A.tab_entries) ltab[tid + u * V3_THREADS] = tab_in[u];
     } else {
         fill_rot_table(ltab, A.tab_entries, tid, V3_THREADS);
-        if (blockIdx.x == 0) {   // leave a copy for the next launch (visible to it: kernel boundary)
+        if (bid == 0) {   // leave a copy for the next launch (visible to it: kernel boundary)
             __syncthreads();
             for (int e = tid; e < A.tab_entries; e += V3_THREADS) wtab[e] = ltab[e];
             if (tid == 0) A.packed[31] = VOTE_TAB_PENDING ^ (unsigned long long)A.n_rots;
@@ -1130,7 +1134,7 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __syncthreads();   // (the summaries live in the carry log: nobody logs a wrap before everybody has read them)
     }
-    if (blockIdx.x == 0 && tid == 0) {   // what the partial tiles hold, for the reduce kernel
+    if (bid == 0 && tid == 0) {   // what the partial tiles hold, for the reduce kernel
         A.hdr->fmt = S > 0.f ? 0u : 1u;
         A.hdr->quantum = S > 0.f ? 1.0f / S : 0.f;
     }
@@ -1353,7 +1357,7 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
     if (tid == 0) { trace[2] = wall_clock64(); trace[4] = (unsigned long long)t; trace[5] = (unsigned long long)c; trace[6] = (unsigned long long)ctrl[8]; trace[7] = (unsigned long long)ctrl[9]; }
 #endif
     const int slot = v3_slot_words(pt, gz);
-    uint4* part4 = reinterpret_cast<uint4*>(A.partials + (int64_t)blockIdx.x * slot);
+    uint4* part4 = reinterpret_cast<uint4*>(A.partials + (int64_t)bid * slot);
     const uint4* t4 = reinterpret_cast<const uint4*>(tile);
     for (int k = tid; k < (nwords + 3) >> 2; k += V3_THREADS) part4[k] = t4[k];
     bool wrote = false;
@@ -1385,6 +1389,33 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
 #endif
 }
 
+template <bool FUSED, bool WIDE>
+__global__ __launch_bounds__(V3_THREADS) void v3_vote_kernel(V3Args A)
+{
+    v3_vote_body<FUSED, WIDE>(A, (int)blockIdx.x);
+}
+
+// The votes of several objects in ONE launch (cppf_vote_argmax_batch): workgroups [wg_begin[i], wg_begin[i + 1]) are object i's vote
+// launch -- its own pair list, grid, workspace (header, extra plane, partial tiles, cached rotation table) -- so every pointer stays
+// workgroup-uniform and the body is the single-object one.  What it buys: one launch instead of n, each object on fewer, longer-lived
+// workgroups (a workgroup zeroes, dumps and has read back its 113 KB tile whatever it deposits: a quarter of the partial-tile traffic
+// per object with four objects on 64 workgroups each) without leaving three quarters of the chip idle.  Fused form only (< 4 tiles,
+// n_rots <= 72: five of the six NOCS categories need one tile, the bottle two).
+#define V3_BATCH_MAX 8
+struct V3Batch {
+    V3Args item[V3_BATCH_MAX];
+    int wg_begin[V3_BATCH_MAX + 1];    // vote launch
+    int red_begin[V3_BATCH_MAX + 1];   // reduce launch
+    int bps[V3_BATCH_MAX];
+    int n;
+};
+__global__ __launch_bounds__(V3_THREADS) void v3_vote_batch_kernel(V3Batch B)
+{
+    int i = 0;
+    while (i + 1 < B.n && (int)blockIdx.x >= B.wg_begin[i + 1]) ++i;
+    v3_vote_body<true, false>(B.item[i], (int)blockIdx.x - B.wg_begin[i]);
+}
+
 // ---------------------------------------------------------------------------- v3_reduce_kernel
 // grid[cell] (+)= the exact sum of every partial tile's quanta for that cell -- the owner tile's word and the halo words of
 // its x / y / diagonal neighbours, over all chunks, plus 2^32 per logged wrap-around -- converted to fp32 ONCE; arg-max as in
@@ -1398,13 +1429,14 @@ __device__ __forceinline__ void v3_rezero(V3Hdr* h)
     h->flags = 0u; h->any_extra = 0u; h->done = 0u; h->magic = V3_MAGIC;
     __threadfence();
 }
-__global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, int bps)
+// `bid` / `nblocks`: this block's index within, and the size of, ITS launch (see v3_vote_body)
+__device__ __forceinline__ void v3_reduce_body(const V3Args& A, const int bps, const int bid, const int nblocks)
 {
     __shared__ unsigned long long part[RED_GROUPS][RED_CELLS];
     __shared__ unsigned long long wkey[RED_CELLS / 64];
     __shared__ int sp[200];
     const int tid = threadIdx.x, lane = tid & 63, cg = tid >> 6;
-    if (blockIdx.x == 0 && tid == 0) {   // rotation table left by the vote kernel of this call: valid from the next launch on
+    if (bid == 0 && tid == 0) {   // rotation table left by the vote kernel of this call: valid from the next launch on
         const unsigned long long st = A.packed[31];
         if ((st & ~0xfffull) == VOTE_TAB_PENDING) A.packed[31] = st ^ (VOTE_TAB_PENDING ^ VOTE_TAB_STAMP);
     }
@@ -1427,22 +1459,26 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, in
         if (!poisoned) {
             uint4* p4 = reinterpret_cast<uint4*>(A.plane);
             const int64_t n16 = (int64_t)(V3_PLANE_BYTES / 16);
-            for (int64_t i = (int64_t)blockIdx.x * blockDim.x + tid; i < n16; i += (int64_t)gridDim.x * blockDim.x) p4[i] = make_uint4(0u, 0u, 0u, 0u);
+            for (int64_t i = (int64_t)bid * blockDim.x + tid; i < n16; i += (int64_t)nblocks * blockDim.x) p4[i] = make_uint4(0u, 0u, 0u, 0u);
             __threadfence();
             __syncthreads();
         }
         if (tid == 0) {   // (the ticket lives with the arg-max keys, which the vote / bin kernel zeroed before looking at the header)
             const unsigned tk = atomicAdd(reinterpret_cast<unsigned*>(A.packed + 18), 1u);
-            if (tk == gridDim.x - 1) {
+            if (tk == (unsigned)nblocks - 1u) {
                 if (A.out_idx) *A.out_idx = -1;
                 if (A.out_val) *A.out_val = __uint_as_float(0x7fc00000u);
                 if (A.quantum_out) *A.quantum_out = 0.f;
+                // n_rots > 72 runs one pass per window of 72 rotations: a pass that gave up leaves the grid without its window, so the
+                // failure is STICKY for the rest of the call -- later passes vote on but report -1 / NaN / quantum 0 again
+                A.packed[20] = 1ull;
                 if (!poisoned) v3_rezero(A.hdr);
             }
         }
         return;
     }
-    if (A.quantum_out && blockIdx.x == 0 && tid == 0) *A.quantum_out = hfmt == 0u ? hquantum : 0.f;
+    const bool earlier_pass_failed = A.win_base > 0 && A.packed[20] != 0ull;   // (written a kernel boundary ago, see the error path)
+    if (A.quantum_out && bid == 0 && tid == 0) *A.quantum_out = (hfmt == 0u && !earlier_pass_failed) ? hquantum : 0.f;
     const int T = pt.T;
     const int slot = v3_slot_words(pt, gz);
     __syncthreads();   // (sp)
@@ -1451,7 +1487,7 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, in
     unsigned long long best = 0ull;   // this thread's arg-max key over the block's items
     // a block takes the items (tile t, run j of RED_CELLS words) blockIdx, blockIdx + gridDim, ...: header, split and the two reports
     // once per block, not once per item (a grid of 16 tiles has 1 760 items)
-    for (int item = blockIdx.x; item < T * bps; item += gridDim.x) {
+    for (int item = bid; item < T * bps; item += nblocks) {
     const int t = item / bps, j = item - t * bps;
     const int tix = t / pt.nty, tiy = t - tix * pt.nty;
     const int x0 = tix * pt.tx, y0 = tiy * pt.ty;
@@ -1539,9 +1575,9 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, in
     // A group's {key, count} sits in the spare words 2..5 of queue-counter line g of the header -- one 128-byte line, i.e. one L2 channel,
     // per group: in the caller's `packed` array the eight groups of round 2 shared one line and their atomics queued behind each other
     // (the reports were 4.7 of the kernel's 12.6 us at C2: profiles/r3_vote_phases.txt section 8)
-    const unsigned gsel = blockIdx.x & (V3_RED_FANIN - 1);
-    const unsigned n_group = (gridDim.x - gsel + V3_RED_FANIN - 1) / V3_RED_FANIN;
-    const unsigned n_groups_used = gridDim.x < V3_RED_FANIN ? gridDim.x : V3_RED_FANIN;
+    const unsigned gsel = (unsigned)bid & (V3_RED_FANIN - 1);
+    const unsigned n_group = ((unsigned)nblocks - gsel + V3_RED_FANIN - 1) / V3_RED_FANIN;
+    const unsigned n_groups_used = (unsigned)nblocks < V3_RED_FANIN ? (unsigned)nblocks : V3_RED_FANIN;
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < RED_CELLS / 64; ++w) key = wkey[w] > key ? wkey[w] : key;
@@ -1556,12 +1592,23 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, in
             const unsigned long long gbest = atomicMax(gslot, 0ull);
             if (report(A.packed, gbest) == n_groups_used - 1) {
                 const unsigned long long best_all = atomicMax(A.packed, 0ull);
-                if (A.out_idx) *A.out_idx = (long long)(0xffffffffu - (uint32_t)(best_all & 0xffffffffull));
-                if (A.out_val) *A.out_val = ord2f((uint32_t)(best_all >> 32));
+                if (A.out_idx) *A.out_idx = earlier_pass_failed ? -1ll : (long long)(0xffffffffu - (uint32_t)(best_all & 0xffffffffull));
+                if (A.out_val) *A.out_val = earlier_pass_failed ? __uint_as_float(0x7fc00000u) : ord2f((uint32_t)(best_all >> 32));
                 v3_rezero(A.hdr);   // every block has finished reading the header: its report came after its last read
             }
         }
     }
+}
+
+__global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_kernel(V3Args A, int bps)
+{
+    v3_reduce_body(A, bps, (int)blockIdx.x, (int)gridDim.x);
+}
+__global__ __launch_bounds__(64 * RED_GROUPS) void v3_reduce_batch_kernel(V3Batch B)
+{
+    int i = 0;
+    while (i + 1 < B.n && (int)blockIdx.x >= B.red_begin[i + 1]) ++i;
+    v3_reduce_body(B.item[i], B.bps[i], (int)blockIdx.x - B.red_begin[i], B.red_begin[i + 1] - B.red_begin[i]);
 }
 
 // header + the largest carry plane a tiled grid can have (64 tiles): what must be zero before the first call on a fresh workspace
@@ -1619,21 +1666,24 @@ extern "C" int cppf_vote_plan_query(int64_t n_ppfs, int n_rots, int gx, int gy, 
 // what cppf_vote_grid_raw adds to a vote: the exact integer image of the grid, its quantum, and bits fixed by the caller
 struct VoteExtras { long long* grid_raw; float* quantum_out; int fixed_bits; };
 
-static int v3_launch(const float* points, const float* outputs, const float* probs, const void* point_idxs, int idx_is_i64,
-                     float* grid_obj, const float* corner, float res, int64_t n_points, int64_t n_ppfs, int n_rots, int gx, int gy,
-                     int gz, int adaptive, int accumulate, bool want_argmax, long long* out_idx, float* out_val, void* workspace,
-                     hipStream_t st, const int32_t* shape_dev, int64_t grid_cap, int many_tiles, const VoteExtras* ex = nullptr,
-                     int wg_cap = 0)
+struct V3Launch { V3Args A; int red_blocks, bps; };
+
+// the by-value arguments of the three kernels for one object: plan, workspace layout, fixed-point bits (see the comment on widths below)
+static int v3_prepare(V3Launch& Lc, const float* points, const float* outputs, const float* probs, const void* point_idxs, int idx_is_i64,
+                      float* grid_obj, const float* corner, float res, int64_t n_points, int64_t n_ppfs, int n_rots, int gx, int gy,
+                      int gz, int adaptive, int accumulate, bool want_argmax, long long* out_idx, float* out_val, void* workspace,
+                      const int32_t* shape_dev, int64_t grid_cap, int many_tiles, const VoteExtras* ex, int wg_cap, int wg_floor = 64)
 {
     // Workgroups of the vote launch.  One per CU is the fastest launch on an idle chip, but every workgroup pays for its tile whatever
     // it deposits -- zeroed, dumped (113 KB) and read back by the reduce kernel: 27 of the 72 MB a C2 call moves -- so a caller that
     // keeps several instances in flight does better with fewer, longer-lived workgroups and the rest of the chip left to its other
     // streams (profiles/r4_vote_workgroups.txt: 128 instead of 256 at C2, three instances in flight: +5 % pairs/s, the instance alone
-    // 7 % slower).  The hint never goes below 64 or the number of tiles; chunking follows it, the grid stays the exact sum of the
-    // deposits (the fixed-point scale follows the chunk length: one bit coarser at C2 with 128).
-    const int wgs_max = wg_cap > 0 ? (wg_cap < 64 ? 64 : (wg_cap > V3_WGS ? V3_WGS : wg_cap)) : V3_WGS;
+    // 7 % slower).  The hint never goes below 64 (32 when several objects share a launch) or the number of tiles; chunking follows it,
+    // the grid stays the exact sum of the deposits (the fixed-point scale follows the chunk length: one bit coarser at C2 with 128).
+    const int wgs_max = wg_cap > 0 ? (wg_cap < wg_floor ? wg_floor : (wg_cap > V3_WGS ? V3_WGS : wg_cap)) : V3_WGS;
     char* ws = static_cast<char*>(workspace);
-    V3Args A = {};
+    V3Args& A = Lc.A;
+    A = V3Args{};
     if (ex) { A.grid_raw = ex->grid_raw; A.quantum_out = ex->quantum_out; A.kk_force = ex->fixed_bits; }
     A.points = points; A.outputs = outputs; A.probs = probs; A.point_idxs = point_idxs; A.idx64 = idx_is_i64;
     A.corner = corner; A.res = res; A.n_ppfs = n_ppfs; A.n_points = n_points; A.n_rots = n_rots; A.adaptive = adaptive;
@@ -1646,7 +1696,6 @@ static int v3_launch(const float* points, const float* outputs, const float* pro
     A.tab_entries = wide ? 0 : tri(n_rots);
     A.pool_cap = n_ppfs;
     A.plane = reinterpret_cast<unsigned long long*>(ws + VOTE_WS_PART + V3_HDR_BYTES);
-    int red_blocks;
     if (shape_dev) {
         A.t_cap = many_tiles ? VOTE_MAX_TILES : 3;
         A.wgs = wgs_max;
@@ -1656,7 +1705,7 @@ static int v3_launch(const float* points, const float* outputs, const float* pro
         A.pool = reinterpret_cast<uint32_t*>(ws + VOTE_WS_PART + V3_HDR_BYTES + V3_PLANE_BYTES);
         A.partials = A.pool + (many_tiles ? align_up((size_t)A.t_cap * (size_t)n_ppfs * 12, 256) / 4 : 0);
         const int bps = ((V3_TILE_FLOATS + RED_CELLS - 1) / RED_CELLS + RED_FANIN - 1) / RED_FANIN * RED_FANIN;
-        red_blocks = A.t_cap * bps;
+        Lc.red_blocks = A.t_cap * bps;
     } else {
         A.t = v3_tiling(gx, gy, gz);
         A.wgs = v3_wgs(n_ppfs, A.t.T);
@@ -1671,17 +1720,41 @@ static int v3_launch(const float* points, const float* outputs, const float* pro
         A.pool = reinterpret_cast<uint32_t*>(ws + pl.pool_off);
         A.partials = reinterpret_cast<uint32_t*>(ws + pl.part_off);
         const int bps = ((pl.slot + RED_CELLS - 1) / RED_CELLS + RED_FANIN - 1) / RED_FANIN * RED_FANIN;
-        red_blocks = A.t.T * bps;
+        Lc.red_blocks = A.t.T * bps;
     }
+    Lc.bps = Lc.red_blocks / A.t_cap;
+    return 0;
+}
+
+static size_t v3_vote_lds(const V3Args& A) { return V3_LDS_HEAD + (size_t)(A.tab_entries + 2) * sizeof(float2) + (size_t)V3_TILE_FLOATS * sizeof(float); }
+static void v3_set_attrs()
+{
     static bool attr_done = false;
     if (!attr_done) {
         const void* ks[] = {reinterpret_cast<const void*>(&v3_bin_kernel<false>), reinterpret_cast<const void*>(&v3_bin_kernel<true>),
                             reinterpret_cast<const void*>(&v3_vote_kernel<false, false>), reinterpret_cast<const void*>(&v3_vote_kernel<true, false>),
-                            reinterpret_cast<const void*>(&v3_vote_kernel<false, true>), reinterpret_cast<const void*>(&v3_vote_kernel<true, true>)};
+                            reinterpret_cast<const void*>(&v3_vote_kernel<false, true>), reinterpret_cast<const void*>(&v3_vote_kernel<true, true>),
+                            reinterpret_cast<const void*>(&v3_vote_batch_kernel)};
         for (const void* k : ks) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    const size_t lds_vote = V3_LDS_HEAD + (size_t)(A.tab_entries + 2) * sizeof(float2) + (size_t)V3_TILE_FLOATS * sizeof(float);
+}
+
+static int v3_launch(const float* points, const float* outputs, const float* probs, const void* point_idxs, int idx_is_i64,
+                     float* grid_obj, const float* corner, float res, int64_t n_points, int64_t n_ppfs, int n_rots, int gx, int gy,
+                     int gz, int adaptive, int accumulate, bool want_argmax, long long* out_idx, float* out_val, void* workspace,
+                     hipStream_t st, const int32_t* shape_dev, int64_t grid_cap, int many_tiles, const VoteExtras* ex = nullptr,
+                     int wg_cap = 0)
+{
+    V3Launch Lc;
+    const int rc = v3_prepare(Lc, points, outputs, probs, point_idxs, idx_is_i64, grid_obj, corner, res, n_points, n_ppfs, n_rots, gx, gy, gz,
+                              adaptive, accumulate, want_argmax, out_idx, out_val, workspace, shape_dev, grid_cap, many_tiles, ex, wg_cap);
+    if (rc != 0) return rc;
+    V3Args& A = Lc.A;
+    const int red_blocks = Lc.red_blocks;
+    const bool wide = n_rots > VOTE_WIN;
+    v3_set_attrs();
+    const size_t lds_vote = v3_vote_lds(A);
     // super-rounds of bin_sr x 512 pairs: as long as possible, but two workgroups for every CU first
     int64_t srb = n_ppfs / ((int64_t)V3_BIN_THREADS * 512);
     srb = srb < 1 ? 1 : (srb > V3_BIN_SR ? V3_BIN_SR : srb);
@@ -1689,12 +1762,13 @@ static int v3_launch(const float* points, const float* outputs, const float* pro
     const int64_t rounds = (n_ppfs + V3_BIN_THREADS * srb - 1) / (V3_BIN_THREADS * srb);
     const size_t lds_bin = (size_t)V3_STAGE * 16 + VOTE_BELOW_N * 16 + 2 * VOTE_MAX_TILES * 4 + 64 + (V3_BIN_THREADS / 64) * (V3_IRING * 2 + (64 * V3_BIN_SR + 64) * 4);
     const dim3 bin_grid((unsigned)(rounds < 512 ? rounds : 512));
-    const int bps = red_blocks / A.t_cap;
+    const int bps = Lc.bps;
     // (two workgroups of 16 waves fill a CU: at most one round of blocks, each looping over its items)
     const dim3 red_grid((unsigned)(red_blocks < 2 * V3_WGS ? red_blocks : 2 * V3_WGS));
     // n_rots <= 72: one pass.  More (a reference knob, nocs/inference.py:39 --num_rots): pass w votes rotations [72 w, 72 w + 72) of
     // every pair with the WIDE kernels and ADDS to the grid of the passes before it; the arg-max the last pass reports is the
-    // arg-max of the whole vote.  Integer images (grid_raw) need one scale for all passes: fixed here unless the caller fixed it.
+    // arg-max of the whole vote (a pass that gives up makes the call's report -1 / NaN / quantum 0: sticky, see v3_reduce_body).
+    // Integer images (grid_raw) need one scale for all passes: fixed here unless the caller fixed it.
     if (wide && A.grid_raw && !A.kk_force) A.kk_force = v3_fixed_bits_bound(n_ppfs, n_rots, gx, gy, gz);
     for (int wb = 0; wb < n_rots; wb += VOTE_WIN) {
         A.win_base = wb;
@@ -1857,6 +1931,79 @@ extern "C" int cppf_vote_argmax_dyn(const float* points, const float* outputs, c
     return vote_impl(points, outputs, probs, point_idxs, idx_is_i64, grid_obj, corner, res, n_points_cap, n_ppfs, n_rots, 1, 1, 1,
                      adaptive, accumulate, true, out_idx, out_val, workspace, workspace_bytes, (hipStream_t)stream, shape_dev,
                      grid_capacity, many_tiles);
+}
+
+// ---- the votes of several objects in one launch ----
+// Items whose vote takes the fused kernel (< 4 tiles; dims by value or, shape_dev != NULL, the few-tiles class from a device
+// record) and n_rots <= 72 share ONE vote launch and ONE reduce launch; every other item (>= 4 tiles, a grid beyond the tiled path,
+// an empty pair list) gets its own launches exactly as cppf_vote_argmax* would issue them.  Results per item are those of its own
+// cppf_vote_argmax call at the same width, bit for bit.
+extern "C" int cppf_vote_batch_workgroups(int n_items, int flags)
+{
+    if (n_items < 1 || n_items > V3_BATCH_MAX) return CPPF_EINVAL;
+    const int wg_cap = (flags >> 8) & 0x1ff;
+    int w = wg_cap > 0 ? wg_cap : V3_WGS / n_items;     // default: the batch as ONE round of workgroups, one per CU
+    if (w < 32) w = 32;
+    if (w > V3_WGS) w = V3_WGS;
+    return w;
+}
+
+extern "C" int cppf_vote_argmax_batch(int n_items, const CppfVoteItem* items, int n_rots, int adaptive, int flags, void* stream)
+{
+    if (n_items < 1 || n_items > V3_BATCH_MAX || !items) return CPPF_EINVAL;
+    if ((flags & ~(1 | (0x1ff << 8))) != 0) return CPPF_EINVAL;
+    if (n_rots < 1 || n_rots > CPPF_MAX_ROTS) return CPPF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int accumulate = flags & 1;
+    const int width = cppf_vote_batch_workgroups(n_items, flags);
+    V3Batch B = {};
+    int vote_wgs = 0, red_blocks = 0;
+    size_t lds_vote = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const CppfVoteItem& it = items[i];
+        const bool dyn = it.shape_dev != nullptr;
+        bool batched = n_rots <= VOTE_WIN && it.n_ppfs >= 1 && it.points && it.grid && it.corner && it.outputs && it.point_idxs &&
+                       it.out_idx && it.out_val && it.workspace && it.n_points >= 1;
+        if (batched && dyn) batched = !it.many_tiles && it.n_ppfs <= 0xffffffffll && it.grid_capacity >= 1 &&
+                                      it.grid_capacity <= 3ll * V3_TILE_FLOATS && it.workspace_bytes >= v3_workspace_bytes_dyn(0, it.n_ppfs);
+        if (batched && !dyn) batched = it.gx >= 1 && it.gy >= 1 && it.gz >= 1 && v3_eligible(it.n_ppfs, n_rots, it.gx, it.gy, it.gz) &&
+                                       v3_tiling(it.gx, it.gy, it.gz).T < 4 && it.workspace_bytes >= v3_workspace_bytes(it.n_ppfs, it.gx, it.gy, it.gz);
+        if (!batched) {   // its own launches (and its own argument checks)
+            const int rc = dyn ? cppf_vote_argmax_dyn(it.points, it.outputs, it.probs, it.point_idxs, it.idx_is_i64, it.grid, it.grid_capacity,
+                                                      it.corner, it.res, it.n_points, it.n_ppfs, n_rots, it.shape_dev, it.many_tiles, adaptive,
+                                                      flags, it.out_idx, it.out_val, it.workspace, it.workspace_bytes, stream)
+                               : cppf_vote_argmax(it.points, it.outputs, it.probs, it.point_idxs, it.idx_is_i64, it.grid, it.corner, it.res,
+                                                  it.n_points, it.n_ppfs, n_rots, it.gx, it.gy, it.gz, adaptive, flags, it.out_idx, it.out_val,
+                                                  it.workspace, it.workspace_bytes, stream);
+            if (rc != 0) return rc;
+            continue;
+        }
+        V3Launch Lc;
+        const int rc = v3_prepare(Lc, it.points, it.outputs, it.probs, it.point_idxs, it.idx_is_i64, it.grid, it.corner, it.res, it.n_points,
+                                  it.n_ppfs, n_rots, dyn ? 1 : it.gx, dyn ? 1 : it.gy, dyn ? 1 : it.gz, adaptive, accumulate, true, it.out_idx,
+                                  it.out_val, it.workspace, it.shape_dev, dyn ? it.grid_capacity : 0, 0, nullptr, width, 32);
+        if (rc != 0) return rc;
+        const int k = B.n++;
+        B.item[k] = Lc.A;
+        B.bps[k] = Lc.bps;
+        B.wg_begin[k] = vote_wgs;
+        B.red_begin[k] = red_blocks;
+        vote_wgs += Lc.A.wgs;
+        // reduce blocks: the batch as about one round of the chip (two 16-wave blocks per CU), never fewer than 64 per object
+        int rb = 2 * V3_WGS / n_items;
+        rb = rb < 64 ? 64 : rb;
+        red_blocks += Lc.red_blocks < rb ? Lc.red_blocks : rb;
+        lds_vote = v3_vote_lds(Lc.A);
+    }
+    if (B.n == 0) return 0;
+    B.wg_begin[B.n] = vote_wgs;
+    B.red_begin[B.n] = red_blocks;
+    v3_set_attrs();
+    hipLaunchKernelGGL(v3_vote_batch_kernel, dim3((unsigned)vote_wgs), dim3(V3_THREADS), lds_vote, st, B);
+    CPPF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(v3_reduce_batch_kernel, dim3((unsigned)red_blocks), dim3(64 * RED_GROUPS), 0, st, B);
+    CPPF_CHECK_LAUNCH();
+    return 0;
 }
 
 // ---- the vote as exact integers (pair-sharded votes: cppf_amd/sharding.py) ----

@@ -536,19 +536,28 @@ def nocs_result(poses, res=None):
 class CenterBatchPipeline:
     """Several CenterPipelines replayed as ONE captured chain: the pair lists of all members in one launch of the pair kernel
     (models.model.forward_decode_batch: the ~9 us a launch spends before its first MFMA are paid once, 70.9 -> 64.0 us per C2
-    list in threes), then every member's vote + arg-max.  Members keep their buffers and results (`pipes[i].out_idx`, `.result`,
-    `.outputs`, `.grid`): load them as usual, run the batch instead of the members.  Static-shape members on one device, no point
-    encoder in front, all with the rotation heads or none; up to 8."""
+    list in threes), then the members' votes -- by default in ONE vote launch and ONE reduce launch as well
+    (models.voting.vote_argmax_batch: every object on 256 / n workgroups, a quarter of the partial-tile traffic per object in
+    fours), `vote_batch=False`: a vote + reduce launch per member at the member's own width.  Members keep their buffers and results
+    (`pipes[i].out_idx`, `.result`, `.outputs`, `.grid`): load them as usual, run the batch instead of the members.  Static-shape
+    members on one device, no point encoder in front, all with the rotation heads or none, the same num_rots / adaptive; up to 8.
+    vote_workgroups: workgroups per object of the batched vote (None / 0: 256 / n, at least 32)."""
 
-    def __init__(self, pipes, use_graph=True):
+    def __init__(self, pipes, use_graph=True, vote_batch=True, vote_workgroups=None):
         pipes = list(pipes)
         if not 1 <= len(pipes) <= 8:
             raise ValueError("1 to 8 pipelines per batch")
         if any(p.dynamic or p.point_encoder is not None or p.device != pipes[0].device or p.with_heads != pipes[0].with_heads
-               for p in pipes):
-            raise _lib.CppfError("CenterBatchPipeline takes static-shape CenterPipelines on one device, without a point encoder")
+               or p.num_rots != pipes[0].num_rots or p.adaptive != pipes[0].adaptive for p in pipes):
+            raise _lib.CppfError("CenterBatchPipeline takes static-shape CenterPipelines on one device, without a point encoder, "
+                                 "with the same num_rots / adaptive")
         self.pipes, self.device = pipes, pipes[0].device
+        self.vote_batch, self.vote_workgroups = bool(vote_batch), int(vote_workgroups or 0)
         self._use_graph, self._graph, self._images = use_graph, None, None
+
+    def _capture_key(self):
+        """what the captured launches bake in besides the weight images: the vote widths and the members' buffers"""
+        return (self.vote_batch, self.vote_workgroups) + tuple((p.vote_workgroups, p.idx.data_ptr(), p.grid.data_ptr()) for p in self.pipes)
 
     def _chain(self):
         from .models.model import forward_decode_batch
@@ -562,8 +571,14 @@ class CenterBatchPipeline:
         outs = forward_decode_batch(items, p0.cfg.tr_num_bins, p0.cfg.rot_num_bins)
         for p, (o, h) in zip(self.pipes, outs):
             p.outputs, p.heads = o, h
-            voting.vote_argmax(p.pc, o, None, p.idx, p.grid, p.corner, p.cfg.res, p.num_rots, p.adaptive, p.out_idx, p.out_val,
-                               accumulate=False, workgroups=p.vote_workgroups)
+        if self.vote_batch:
+            voting.vote_argmax_batch([dict(points=p.pc, outputs=p.outputs, point_idxs=p.idx, grid=p.grid, corner=p.corner, res=p.cfg.res,
+                                           out_idx=p.out_idx, out_val=p.out_val) for p in self.pipes],
+                                     p0.num_rots, p0.adaptive, accumulate=False, workgroups=self.vote_workgroups)
+        else:
+            for p in self.pipes:
+                voting.vote_argmax(p.pc, p.outputs, None, p.idx, p.grid, p.corner, p.cfg.res, p.num_rots, p.adaptive, p.out_idx, p.out_val,
+                                   accumulate=False, workgroups=p.vote_workgroups)
 
     def run(self, check_weights=True):
         """-> [(out_idx, out_val)] of the members (device tensors, as CenterPipeline.run returns them)"""
@@ -571,7 +586,10 @@ class CenterBatchPipeline:
             if not self._use_graph:
                 self._chain()
             else:
-                images = tuple(tuple(p._weight_images()) for p in self.pipes) if check_weights or self._graph is None else self._images
+                # the vote widths / member buffers the launches baked in are compared on every run (cheap), the weight images
+                # when asked: a moved image or a member's set_vote_workgroups() captures again
+                images = ((tuple(tuple(p._weight_images()) for p in self.pipes) if check_weights or self._graph is None else self._images[0]),
+                          self._capture_key())
                 if self._graph is not None and images != self._images:
                     self._graph = None
                 if self._graph is None:

@@ -165,6 +165,78 @@ def vote_argmax_dyn(points, outputs, probs, point_idxs, grid_flat, shape, corner
     return out_idx, out_val
 
 
+def vote_batch_workgroups(n_items, workgroups=0):
+    """vote workgroups each object of a vote_argmax_batch call gets (256 / n_items, at least 32, unless `workgroups` says otherwise)"""
+    w = int(workgroups or 0)
+    if w and not 32 <= w <= 256:
+        raise ValueError(f"workgroups must be 0 or in 32..256, got {workgroups}")
+    return int(_lib.lib().cppf_vote_batch_workgroups(int(n_items), w << 8))
+
+
+def vote_argmax_batch(items, n_rots, adaptive, accumulate=False, workgroups=0, ws_tag="vote_b"):
+    """vote_argmax / vote_argmax_dyn for up to 8 objects enqueued together (cppf_vote_argmax_batch): the objects whose grids take
+    the fused vote (< 4 LDS tiles: every NOCS category) share ONE vote launch and ONE reduce launch, each on
+    vote_batch_workgroups(len(items), workgroups) workgroups; the others get their own launches.  `items`: dicts
+    {points, outputs, point_idxs, grid, corner, res, out_idx, out_val[, probs][, shape, many_tiles]} -- `grid` f32[gx,gy,gz], or with
+    `shape` (device i32[4] {n_points, gx, gy, gz}) a flat capacity buffer as for vote_argmax_dyn.  Every object keeps its own vote
+    workspace (scratch tag ws_tag + index in the current workspace scope).  Same grids, arg-max and peaks as the single calls at the
+    same width."""
+    if not 1 <= len(items) <= 8:
+        raise ValueError("1 to 8 objects per call")
+    L = _lib.lib()
+    w = int(workgroups or 0)
+    if w and not 32 <= w <= 256:
+        raise ValueError(f"workgroups must be 0 or in 32..256, got {workgroups}")
+    flags = (1 if accumulate else 0) | (w << 8)
+    arr = (_lib.VoteItem * len(items))()
+    keep = []
+    dev = items[0]["points"].device
+    for i, it in enumerate(items):
+        points = dev_tensor(it["points"], F32, "points", (3,), dev)
+        outputs = dev_tensor(it["outputs"], F32, "outputs", (2,), dev)
+        probs = it.get("probs")
+        if probs is not None:
+            dev_tensor(probs, F32, "probs", None, dev)
+            if probs.numel() != points.shape[0]:
+                raise ValueError("probs must have one entry per point")
+        idx = it["point_idxs"]
+        i64 = isinstance(idx, torch.Tensor) and idx.dtype == torch.int64
+        dev_tensor(idx, torch.int64 if i64 else I32, "point_idxs", (2,), dev)
+        grid = dev_tensor(it["grid"], F32, "grid", None, dev)
+        corner = dev_tensor(it["corner"], F32, "corner", None, dev)
+        out_idx = dev_tensor(it["out_idx"], torch.int64, "out_idx", None, dev)
+        out_val = dev_tensor(it["out_val"], F32, "out_val", None, dev)
+        shape = it.get("shape")
+        n_ppfs = idx.shape[0]
+        a = arr[i]
+        if shape is not None:
+            dev_tensor(shape, I32, "shape", None, dev)
+            many = 1 if it.get("many_tiles") else 0
+            ws = workspace(L.cppf_vote_workspace_bytes_dyn_pairs(many, int(n_ppfs)), dev, f"{ws_tag}dyn{i}", zero=True)
+            a.shape_dev, a.grid_capacity, a.many_tiles = shape.data_ptr(), grid.numel(), many
+            a.gx = a.gy = a.gz = 1
+        else:
+            if grid.dim() != 3:
+                raise ValueError("grid must be [gx,gy,gz] (or pass `shape` for a capacity buffer)")
+            gx, gy, gz = (int(v) for v in grid.shape)
+            need = L.cppf_vote_workspace_bytes(n_ppfs, int(n_rots), gx, gy, gz)
+            if need == 0:
+                raise ValueError(f"n_rots must be in 1..360, got {n_rots}")
+            ws = workspace(need, dev, f"{ws_tag}{i}", zero=True)
+            a.shape_dev, a.grid_capacity, a.many_tiles = None, 0, 0
+            a.gx, a.gy, a.gz = gx, gy, gz
+        a.points, a.outputs, a.probs = points.data_ptr(), outputs.data_ptr(), (None if probs is None else probs.data_ptr())
+        a.point_idxs, a.idx_is_i64, a.grid, a.corner = idx.data_ptr(), (1 if i64 else 0), grid.data_ptr(), corner.data_ptr()
+        a.out_idx, a.out_val, a.workspace, a.workspace_bytes = out_idx.data_ptr(), out_val.data_ptr(), ws.data_ptr(), ws.numel()
+        a.n_points, a.n_ppfs, a.res = points.shape[0], n_ppfs, float(scalar(it["res"]))
+        keep.append(ws)
+    import ctypes as C
+    with torch.cuda.device(dev):
+        rc = L.cppf_vote_argmax_batch(len(items), C.cast(arr, C.c_void_p), int(n_rots), 1 if adaptive else 0, flags, stream_ptr(dev))
+    _lib.check(rc, "cppf_vote_argmax_batch")
+    return [(it["out_idx"], it["out_val"]) for it in items]
+
+
 def vote_fixed_point_bits(n_ppfs, n_rots, dims):
     """fixed-point bits the tiled vote would choose (a lower bound on the binned path) for a pair list of n_ppfs pairs"""
     return int(_lib.lib().cppf_vote_fixed_point_bits(int(n_ppfs), int(n_rots), int(dims[0]), int(dims[1]), int(dims[2])))

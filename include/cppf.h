@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define CPPF_ABI_VERSION 2   /* 2: vote workspace contract (state in its first cppf_vote_workspace_init_bytes() bytes), cppf_vote_grid_raw */
+#define CPPF_ABI_VERSION 3   /* 2: vote workspace contract (state in its first cppf_vote_workspace_init_bytes() bytes), cppf_vote_grid_raw; 3: batched votes (CppfVoteItem), cppf_pair_mlp_batch_plan */
 
 #define CPPF_EINVAL (-1)     /* bad argument (null pointer, negative size, n_rots out of range) */
 #define CPPF_EWORKSPACE (-2) /* workspace too small / missing */
@@ -207,6 +207,38 @@ int cppf_vote_argmax_dyn(const float* points, const float* outputs, const float*
                          int64_t n_points_cap, int64_t n_ppfs, int n_rots, const int32_t* shape_dev, int many_tiles,
                          int adaptive, int accumulate, long long* out_idx, float* out_val, void* workspace,
                          size_t workspace_bytes, void* stream);
+
+/* The votes of up to 8 objects -- the instances of a frame (nocs/inference.py:120 loops over them), each with its own cloud, pair
+ * list, grid, results and vote workspace -- enqueued together.  Items whose vote takes the fused kernel (a grid of < 4 LDS tiles:
+ * every NOCS category; dims by value, or from a device record when shape_dev != NULL and many_tiles == 0) and n_rots <= 72 share
+ * ONE vote launch and ONE reduce launch: workgroups [w_i, w_{i+1}) are item i's launch.  Each object then runs on fewer,
+ * longer-lived workgroups -- cppf_vote_batch_workgroups(n_items, flags) each: 256 / n_items (at least 32) unless
+ * CPPF_VOTE_WORKGROUPS(n) in `flags` says otherwise -- which divides the partial-tile traffic per object (a workgroup zeroes, dumps
+ * and has read back its 113 KB tile whatever it deposits) without idling the rest of the chip, and the launch prologue is paid once.
+ * Every other item gets the launches cppf_vote_argmax / cppf_vote_argmax_dyn would issue for it.  Per item the grid, arg-max and
+ * peak are those of its own cppf_vote_argmax* call with the same CPPF_VOTE_WORKGROUPS, bit for bit.  flags: as `accumulate` of
+ * cppf_vote_argmax.  Replaces n launches of `ppf_kernel` (models/voting.py:8-66, nocs/inference.py:192-205) + np.argmax (:207-208). */
+typedef struct CppfVoteItem {
+    const float* points;      /* device f32[n_points,3] */
+    const float* outputs;     /* device f32[n_ppfs,2] (mu, nu) */
+    const float* probs;       /* device f32[n_points] or NULL (all ones) */
+    const void* point_idxs;   /* device i32 / i64 [n_ppfs,2] */
+    float* grid;              /* device f32[gx,gy,gz] (by value) or f32[grid_capacity] (shape_dev) */
+    const float* corner;      /* device f32[3] */
+    long long* out_idx;       /* device i64[1] */
+    float* out_val;           /* device f32[1] */
+    void* workspace;          /* cppf_vote_workspace_bytes(...) / cppf_vote_workspace_bytes_dyn_pairs(...), initialised as for the single calls */
+    size_t workspace_bytes;
+    const int32_t* shape_dev; /* NULL: gx, gy, gz, n_points by value; else device i32[4] {n_points, gx, gy, gz}, n_points = capacity */
+    int64_t grid_capacity;    /* shape_dev only */
+    int64_t n_points, n_ppfs;
+    float res;
+    int gx, gy, gz;
+    int idx_is_i64;
+    int many_tiles;           /* shape_dev only */
+} CppfVoteItem;
+int cppf_vote_batch_workgroups(int n_items, int flags);
+int cppf_vote_argmax_batch(int n_items, const CppfVoteItem* items_host, int n_rots, int adaptive, int flags, void* stream);
 int cppf_center_from_argmax_dyn(const long long* idx, const float* corner, double res, const int32_t* shape_dev, double* T64,
                                 float* T32, const float* peak, double* idx_peak_f64, void* stream);
 int cppf_backvote_dyn(const float* points, const float* outputs, float* out_offsets, const int32_t* point_idxs,

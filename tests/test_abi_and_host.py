@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} declared in include/cppf.h but not exported"
     assert set(declared) == set(_lib.exported_symbols())
     assert not hasattr(L, "cppf_debug_mlp_chain_only")
-    assert L.cppf_abi_version() == 2 == _lib.ABI_VERSION and "#define CPPF_ABI_VERSION 2" in hdr
+    assert L.cppf_abi_version() == 3 == _lib.ABI_VERSION and "#define CPPF_ABI_VERSION 3" in hdr
     assert b"workspace" in L.cppf_error_string(-2)
 
 

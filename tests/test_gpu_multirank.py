@@ -129,3 +129,35 @@ def test_bench_runs_with_two_ranks_on_one_gpu(tmp_path):
         assert d["n_gpus"] == 2 and d["value"] > 0 and d["unit"] == "pairs/s" and d["higher_is_better"] is True
         assert d["metric"].startswith("point-pairs/sec") and "workload" in d["config"]
         assert d["scaling"] == ("strong" if "c4" in extra else "weak")
+
+
+@pytest.mark.parametrize("extra", [["--steps", "6", "--objects", "3"],
+                                   ["--config", "c4", "--steps", "8", "--n-points", "1024", "--pairs-per-point", "32"]])
+def test_bench_launches_its_own_ranks(extra):
+    """`python bench.py --gpus 2` with a CLEAN environment (no launcher: the shape of the driver's 1-GPU command with another N):
+    bench.py re-runs itself as two ranks under torch.distributed.run; this box has one GPU, so the ranks share it over gloo and say
+    so -- one JSON line, as the last line of stdout, n_gpus 2, ranks_seen 2"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT") and not k.startswith("CPPF_")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--warmup", "1", "--no-secondary",
+                        "--no-cpu-baseline", "--min-seconds", "0.2"] + extra, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out_lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    lines = [ln for ln in out_lines if ln.startswith("{")]
+    assert len(lines) == 1 and out_lines[-1] == lines[0]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["unit"] == "pairs/s"
+    n_dev = torch.cuda.device_count()
+    assert d["dist"]["ranks_seen"] == 2 and len(d["dist"]["device_per_rank"]) == 2
+    if n_dev < 2:
+        assert d["dist"] == {"backend": "gloo", "forced_single_rank": False, "ranks_seen": 2, "device_per_rank": [0, 0], "shared_gpu": True}
+    else:
+        assert d["dist"]["backend"] == "nccl" and d["dist"]["device_per_rank"] == [0, 1] and d["dist"]["shared_gpu"] is False
+    # a launcher's environment with the wrong size is an error message and exit code 2, not an assertion trace
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-secondary", "--no-cpu-baseline"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert bad.returncode == 2 and "WORLD_SIZE=1" in bad.stderr and "Traceback" not in bad.stderr

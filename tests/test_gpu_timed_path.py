@@ -97,10 +97,11 @@ def test_nearly_equal_lists_take_the_pinned_branch_too(oracle, dev):
     assert batch_plan([P, P // 2, P, P])["per_xcd"] == 0 and batch_plan([P] * 3)["per_xcd"] == 0
 
 
-@pytest.mark.parametrize("vote_workgroups", [128, 0])
-def test_center_batch_pipeline_of_four_c2_objects(oracle, dev, vote_workgroups):
-    """the headline's captured chain: 4 C2 objects, one pair-kernel launch, four votes (128 workgroups wide as in the timed
-    regions, and at full width), replayed -- every pair's (mu, nu), every grid cell, the four arg-maxes"""
+@pytest.mark.parametrize("vote_batch,vote_workgroups", [(True, 0), (True, 128), (False, 128), (False, 0)])
+def test_center_batch_pipeline_of_four_c2_objects(oracle, dev, vote_batch, vote_workgroups):
+    """the headline's captured chain: 4 C2 objects, one pair-kernel launch, then the four votes -- in ONE vote + ONE reduce launch
+    (64 workgroups per object: the timed regions' default; 128), or a launch per object (round 4's chain: 128 wide, full width) --
+    replayed: every pair's (mu, nu), every grid cell, the four arg-maxes"""
     from cppf_amd.inference import CenterBatchPipeline, CenterPipeline, grid_shape
     sd = seeded_sd(0)
     enc = make_encoder(sd, dev)
@@ -111,7 +112,7 @@ def test_center_batch_pipeline_of_four_c2_objects(oracle, dev, vote_workgroups):
         p = CenterPipeline(enc, o["cfg"], N_POINTS, P, dims, dev, 72, adaptive=True, with_heads=False, vote_workgroups=vote_workgroups)
         p.load(o["ob"]["pc"], o["ob"]["normals"], o["ob"]["feat"], o["idx"], o["u_tr"], o["u_rot"], corners[0].copy())
         pipes.append((p, corners, dims))
-    bp = CenterBatchPipeline([p for p, _, _ in pipes])
+    bp = CenterBatchPipeline([p for p, _, _ in pipes], vote_batch=vote_batch, vote_workgroups=vote_workgroups)
     for rep in range(3):                 # capture, replay, replay
         res = bp.run()
     torch.cuda.synchronize()
@@ -119,7 +120,7 @@ def test_center_batch_pipeline_of_four_c2_objects(oracle, dev, vote_workgroups):
         np.testing.assert_array_equal(p.outputs.cpu().numpy(), o["outputs"])
         idx32 = o["idx"].astype(np.int32)
         g64, _ = check_grid(oracle, p.grid.cpu().numpy(), o["ob"]["pc"], o["outputs"], idx32, corners[0], dims, o["cfg"].res, 72, True,
-                            bits_slack=2 if vote_workgroups else 0)
+                            bits_slack=2 if (vote_workgroups or vote_batch) else 0)
         go = np.zeros(dims, np.float32)
         oracle.ppf_voting(o["ob"]["pc"], o["outputs"], np.ones(N_POINTS, np.float32), idx32, go, corners[0], o["cfg"].res, 72, True)
         oflat, opeak = oracle.grid_argmax(go)
