@@ -257,15 +257,23 @@ def mlp_batch(args, n_pairs=524288):
     return 4 if args.streams > 1 and not args.no_graph and n_pairs <= (1 << 20) else 1
 
 
+VOTE_BATCH_WIDTHS = (64, 96, 128)
+
+
 def make_stepper(dev, pipes, streams, res_buf, steps, B, vote_batch=True, vote_batch_wgs=0):
     """-> run(n): n steps, step k = object k mod len(pipes).  B = 1: every step is its own chain on stream k mod S.  B > 1: B
-    consecutive objects form ONE chain -- their pair lists in one launch of the pair kernel, then each object's vote + arg-max
-    (CenterBatchPipeline) -- on stream (k / B) mod S; a remainder of n mod B steps runs as single chains, so that EXACTLY n objects
-    are processed.  Every step's 16-byte result is kept (one device copy on its stream); the caller's stream waits for all of them."""
+    consecutive objects form ONE chain -- their pair lists in one launch of the pair kernel, then their votes in one vote + one reduce
+    launch (CenterBatchPipeline; vote_batch=False: a vote + reduce launch per object) -- on a stream of its own; a remainder of
+    n mod B steps runs as single chains, so that EXACTLY n objects are processed.  Every step's 16-byte result is kept (one device
+    copy on its stream); the caller's stream waits for all of them.
+    vote_batch_wgs: workgroups per object of a chain's vote launch; 0 = 256 / B; -1 = CALIBRATED (run.calibrate(), called by the
+    warm-up): the stepper times VOTE_BATCH_WIDTHS on this workload with all streams in flight and keeps the fastest -- which width wins
+    depends on how many samples land in the grid (few: the launch is mostly prologue / tile dump, 64 wins; a trained network: the
+    launch is deposit arithmetic, 128 wins), and nothing but a run of the workload knows that."""
     from cppf_amd.inference import CenterBatchPipeline
     n_obj, S = len(pipes), len(streams)
     B = max(1, min(B, n_obj // S))      # at least one chain per stream (a captured chain does not run beside itself)
-    batches = [CenterBatchPipeline(pipes[i:i + B], vote_batch=vote_batch, vote_workgroups=vote_batch_wgs)
+    batches = [CenterBatchPipeline(pipes[i:i + B], vote_batch=vote_batch, vote_workgroups=max(vote_batch_wgs, 0))
                for i in range(0, n_obj - n_obj % B, B)] if B > 1 else []
 
     def run(n):
@@ -287,7 +295,34 @@ def make_stepper(dev, pipes, streams, res_buf, steps, B, vote_batch=True, vote_b
                 res_buf[k % steps].copy_(pipes[k % n_obj].result, non_blocking=True)
         for st in streams:
             main.wait_stream(st)
+
+    def calibrate(n_steps=None):
+        """-> {width: ms per step}; leaves the fastest width set (no-op unless vote_batch_wgs == -1 and the votes are batched)"""
+        if not (batches and vote_batch and vote_batch_wgs < 0):
+            return None
+        n_steps = n_steps or max(2 * len(batches) * B, 24)
+        seen = {}
+        for w in VOTE_BATCH_WIDTHS:
+            for bp in batches:
+                bp.vote_workgroups = w
+            run(2 * len(batches) * B)                # capture + the slow first replays
+            ts = []
+            for _ in range(5):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                run(n_steps)
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) / n_steps * 1e3)
+            seen[w] = sorted(ts)[2]
+        best = min(seen, key=seen.get)
+        for bp in batches:
+            bp.vote_workgroups = best
+        run(2 * len(batches) * B)
+        run.vote_batch_workgroups = best
+        return seen
     run.batch = B
+    run.calibrate = calibrate
+    run.vote_batch_workgroups = (batches[0].vote_workgroups or 256 // B) if (batches and vote_batch) else None
     return run
 
 
@@ -360,6 +395,22 @@ def events_per_chain(dev, pipes, n):
     return sorted(ts)
 
 
+def repeated(fn, inner, n=5, per=1.0):
+    """a secondary host-clocked timing, REPEATED: n regions of `inner` calls of fn (synchronize on both sides of each region) ->
+    (median ms per unit, [min, max]); `per` = units per call.  One unrepeated region is a coin toss on a shared box: round 4
+    committed an 8.78 ms full pose where six other runs said 0.25."""
+    ts = []
+    for _ in range(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(inner):
+            fn()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / inner / per * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2], [ts[0], ts[-1]]
+
+
 def bracket(fns, n):
     """the closures of `fns` (one per object, cycled) launched n times back to back between two HIP events on the launch stream,
     so that the device queue stays full and the quotient is the kernels' own duration (no host-side launch gaps inside the
@@ -411,6 +462,7 @@ def run_center_config(name, enc, sd, dev, rank, world, args):
         for p_ in pipes:                    # the single chains too (a remainder of steps mod B, the one-instance latency)
             p_.run()
     run_steps(max(args.warmup, 2 * n_obj))  # every chain is captured and replayed at least once
+    calib = run_steps.calibrate()           # (--vote-batch-workgroups -1: the chains' vote width, timed on this workload)
     close_batch()                           # warm-up of the gather too (RCCL communicators are created on first use)
     settle()
 
@@ -431,7 +483,7 @@ def run_center_config(name, enc, sd, dev, rank, world, args):
     elapsed = regions[len(regions) // 2]
     lat = events_per_chain(dev, pipes, max(20, steps))
     return dict(objs=objs, pipes=pipes, P=P, n_points=n_points, k=k, n_obj=n_obj, n_streams=n_streams, elapsed=elapsed,
-                mlp_batch=run_steps.batch,
+                mlp_batch=run_steps.batch, vote_batch_workgroups=run_steps.vote_batch_workgroups, vote_batch_calibration=calib,
                 regions=regions, allrec=allrec, lat=lat, what=c["what"])
 
 
@@ -469,8 +521,10 @@ def workload_text(name, m, args):
             (f"{m['n_streams']} independent objects in flight on {m['n_streams']} HIP streams" +
              (f", each vote launched {m['objs'][0]['pipe'].vote_workgroups} workgroups wide; " if m['objs'][0]['pipe'].vote_workgroups else "; ") if m["n_streams"] > 1
              else "one object at a time; ") +
-            (f"the pair lists of {m['mlp_batch']} consecutive objects share one launch of the pair kernel (cppf_pair_mlp_decode_batch), "
-             "each object then its own vote and reduce launch; chains replayed from hipGraphs" if m.get("mlp_batch", 1) > 1 else
+            (f"the pair lists of {m['mlp_batch']} consecutive objects share one launch of the pair kernel (cppf_pair_mlp_decode_batch), " +
+             (f"their votes one vote launch and one reduce launch (cppf_vote_argmax_batch, {m['vote_batch_workgroups']} workgroups per object"
+              + (": calibrated during the warm-up)" if args.vote_batch_workgroups < 0 else ")") if m.get("vote_batch_workgroups") else
+              "each object then its own vote and reduce launch") + "; chains replayed from hipGraphs" if m.get("mlp_batch", 1) > 1 else
              ("four launches per step replayed from a hipGraph" if not args.no_graph else "eager launches")))
 
 
@@ -603,6 +657,7 @@ def run_c1(args):
                                   "arg-max on the HOST cores (BASELINE.json configs[0]: the CPU path, no GPU); a step = one pass over "
                                   "the object at the best thread count", "pairs_per_step": P, "parallelism": "host threads"},
            "cpu_baseline": cb, "argmax_cpu": int(flat)}
+    out_args = args
     if torch.cuda.is_available():       # the same workload on the GPU, for the ratio
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(dev)
@@ -611,14 +666,27 @@ def run_c1(args):
         out["gpu_same_workload"] = {"ms_per_step": m["elapsed"] / args.steps * 1e3, "pairs_per_s": args.steps * m["P"] / m["elapsed"],
                                     "median_ms_one_instance": m["lat"][len(m["lat"]) // 2],
                                     "argmax_matches_cpu": bool(int(m["allrec"][0, 12].item()) == int(flat))}
-    emit(out)
+    emit(out, out_args)
 
 
-def emit(line):
+def emit(line, args=None):
     """rank 0's ONE JSON line, as the LAST line of stdout: RCCL prints a version banner through C stdio when its first communicator
     is created; with stdout redirected that text sits in libc's buffer until exit and would land BEHIND the JSON line -- so the
-    C buffers are flushed first, then the line is written and flushed."""
+    C buffers are flushed first, then the line is written and flushed.  The printed line is the compact one (compact()) unless
+    --full-line; the full record is written to --full-record (default bench_full.json beside bench.py) and named in the line."""
     import ctypes
+    if args is not None:
+        path = args.full_record
+        if path:
+            try:
+                with open(path, "w") as f:
+                    json.dump(line, f, indent=1)
+                    f.write("\n")
+            except OSError:
+                path = None
+        if not args.full_line:
+            line = compact(line)
+            line["full_record"] = os.path.basename(path) if path else None
     try:
         ctypes.CDLL(None).fflush(None)
     except OSError:
@@ -673,8 +741,8 @@ def main():
                     "object has at most a million pairs, else 1")
     ap.add_argument("--no-vote-batch", action="store_true", help="with --mlp-batch > 1: a vote + reduce launch per object (round 4's chain) "
                     "instead of ONE vote launch and ONE reduce launch for the objects of a chain (cppf_vote_argmax_batch)")
-    ap.add_argument("--vote-batch-workgroups", type=int, default=0, help="workgroups per object of the batched vote (0 = 256 / objects per "
-                    "chain, at least 32)")
+    ap.add_argument("--vote-batch-workgroups", type=int, default=-1, help="workgroups per object of the batched vote: 0 = 256 / objects per "
+                    "chain (at least 32); 32..256; -1 = calibrated during the warm-up (64 / 96 / 128 timed on the workload, fastest kept)")
     ap.add_argument("--streams", type=int, default=3, help="instances in flight per GPU: step k runs on HIP stream k mod S "
                     "(1 = strictly one instance at a time)")
     ap.add_argument("--objects", type=int, default=9, help="distinct objects the steps rotate over (rounded up to a multiple of "
@@ -684,6 +752,8 @@ def main():
                     "instead of the two centre heads")
     ap.add_argument("--n-points", type=int, default=0, help="exploration only; overrides the config's N")
     ap.add_argument("--pairs-per-point", type=int, default=0, help="exploration only; overrides the config's K")
+    ap.add_argument("--full-line", action="store_true", help="print the full record (~15 KB) instead of the compact line")
+    ap.add_argument("--full-record", default=os.path.join(ROOT, "bench_full.json"), help="where rank 0 writes the full record ('' = nowhere)")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -719,7 +789,7 @@ def main():
                            "objects": m["n_objects"], "objects_per_gpu": m["n_objects"] / world, "parallelism": f"objects x{world}"},
                 "objects_per_s": m["reps"] * m["n_objects"] / m["elapsed"],
                 "regions": len(m["regions"]), "region_ms_min_max": [m["regions"][0] * 1e3, m["regions"][-1] * 1e3],
-                "dist": dinfo})
+                "dist": dinfo}, args)
         if torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
         return
@@ -825,6 +895,7 @@ def main():
         for o in ah:
             o["pipe"].run()
         ah_steps(2 * len(ah))
+        ah_calib = ah_steps.calibrate()
         settle()
         regs_ah = []
         for _ in range(9):
@@ -835,7 +906,8 @@ def main():
             regs_ah.append((time.perf_counter() - ta0) / steps * 1e3)
         t_ah = sorted(regs_ah)[len(regs_ah) // 2]
         lat_ah = events_per_chain(dev, [o["pipe"] for o in ah], 20)
-        all_heads_step = {"ms_per_step": t_ah, "pairs_per_s": P / (t_ah * 1e-3), "median_ms_one_instance": lat_ah[len(lat_ah) // 2]}
+        all_heads_step = {"vote_batch_workgroups": ah_steps.vote_batch_workgroups, "vote_batch_calibration": ah_calib, "ms_per_step": t_ah, "ms_per_step_min_max": [min(regs_ah), max(regs_ah)], "regions": len(regs_ah),
+                          "pairs_per_s": P / (t_ah * 1e-3), "median_ms_one_instance": lat_ah[len(lat_ah) // 2]}
         del ah
 
     # secondary: the vote stage alone, and then the whole step, on known-answer inputs -- every vote circle passes through the
@@ -871,6 +943,7 @@ def main():
             for p_ in tpipes:
                 p_.run()
             tr_steps(2 * len(tpipes))
+            tr_calib = tr_steps.calibrate()
             settle()
             reg = []
             for _ in range(15):
@@ -888,8 +961,9 @@ def main():
                 cell = np.array(np.unravel_index(int(o["pipe"].out_idx.item()), o["dims"]))
                 cell_err.append(float(np.max(np.abs(cell - (o["ob"]["center"] - o["corners"][0]) / o["cfg"].res))))
             landed = float(np.mean([float(o["pipe"].grid.double().sum().item()) for o in tobjs]))
-            entry = {"ms_per_step": t_tr, "pairs_per_s": P / (t_tr * 1e-3), "median_ms_one_instance": lat_tr[len(lat_tr) // 2],
-                     "regions": len(reg), "grid_dims": [list(map(int, o["dims"])) for o in tobjs[:3]],
+            entry = {"vote_batch_workgroups": tr_steps.vote_batch_workgroups, "vote_batch_calibration": tr_calib,
+                     "ms_per_step": t_tr, "pairs_per_s": P / (t_tr * 1e-3), "median_ms_one_instance": lat_tr[len(lat_tr) // 2],
+                     "regions": len(reg), "ms_per_step_min_max": [reg[0], reg[-1]], "grid_dims": [list(map(int, o["dims"])) for o in tobjs[:3]],
                      "argmax_error_cells_max_over_objects": max(cell_err), "landed_samples_per_object": round(landed),
                      "share_of_samples_in_grid": landed / (P * 72.0)}
             # the full pose on the first object of the set
@@ -898,11 +972,8 @@ def main():
             pp.load(o["ob"]["pc"], o["ob"]["normals"], o["feat"], o["idx"], o["u_tr"], o["u_rot"], o["corners"][0].copy())
             for _ in range(4):
                 pose_t = pp.run()
-            torch.cuda.synchronize()
-            tp0 = time.perf_counter()
-            for _ in range(10):
-                pose_t = pp.run()
-            entry["full_pose_ms_incl_readback"] = (time.perf_counter() - tp0) / 10 * 1e3
+            entry["full_pose_ms_incl_readback"], entry["full_pose_ms_min_max"] = repeated(pp.run, 10, 7)
+            pose_t = pp.run()
             entry["full_pose_n_surv"] = pose_t["n_surv"]
             entry["full_pose_errors"] = training.pose_errors(pose_t, o["ob"])
             trained[tag] = entry
@@ -942,23 +1013,20 @@ def main():
         batch = [dict(pc=o["pc"], normals=o["normals"], cfg=o["cfg"], n_pairs=Pd) for o in robjs]
 
         def timed(fn, reps):
-            fn()
+            r_ = fn()
             settle()
-            torch.cuda.synchronize()
-            t0_ = time.perf_counter()
-            for _ in range(reps):
-                r_ = fn()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0_) / reps / len(robjs) * 1e3, r_
-        t1, r1 = timed(level1, 2)
-        t2, r2 = timed(level2, 3)
+            med, mm = repeated(fn, reps, 5, per=len(robjs))
+            return med, mm, r_
+        t1, mm1, r1 = timed(level1, 1)
+        t2, mm2, r2 = timed(level2, 2)
         for _ in range(6):      # a freshly captured graph's first replays are slow (the runtime instantiates it lazily), and the
             runner.run(batch)   # pipelines settle on their split / full-first form after the first instances: 4 batches measured
-        t3, r3 = timed(lambda: runner.run(batch), 10)
+        t3, mm3, r3 = timed(lambda: runner.run(batch), 6)
         err = lambda poses: float(np.median([training.pose_errors(p_, o)["t_cells"] for p_, o in zip(poses, robjs)]))
         dropin = {"workload": f"{len(robjs)} held-out posed objects (bottle / mug / laptop, trained networks), N = {list(sizes)}, "
                               f"{Pd} pairs each (the reference's default), kNN + SPRIN + full pose per instance; ms per instance",
                   "level1_reference_call_sequence_ms": t1, "level2_estimate_pose_eager_ms": t2, "level3_batch_runner_captured_ms": t3,
+                  "min_max_ms": {"level1": mm1, "level2": mm2, "level3": mm3}, "timing": "median of 5 repeated regions each",
                   "median_centre_error_cells": {"level1": err(r1), "level2": err(r2)},
                   "level3_records_finite": bool(torch.isfinite(r3[:, :12]).all())}
         del runner
@@ -987,13 +1055,10 @@ def main():
         for _ in range(2):
             poses_f = frame_poses(depth, inst, encs_f, pencs_f, device=dev)
         settle()
-        torch.cuda.synchronize()
-        tf0 = time.perf_counter()
-        for _ in range(5):
-            poses_f = frame_poses(depth, inst, encs_f, pencs_f, device=dev)
-        torch.cuda.synchronize()
+        t_rf, mm_rf = repeated(lambda: frame_poses(depth, inst, encs_f, pencs_f, device=dev), 2, 5, per=len(inst))
+        poses_f = frame_poses(depth, inst, encs_f, pencs_f, device=dev)
         real_frame = {"instances": len(inst), "points_per_instance": [int(p_["n_points"]) for p_ in poses_f], "pairs_per_instance": 100000,
-                      "ms_per_instance_incl_preprocessing": (time.perf_counter() - tf0) / 5 / len(inst) * 1e3,
+                      "ms_per_instance_incl_preprocessing": t_rf, "ms_per_instance_min_max": mm_rf,
                       "n_surv": [int(p_["n_surv"]) for p_ in poses_f]}
 
     # secondary: centre vote + the whole pose tail on known-answer inputs, where (nearly) every pair survives the back-vote
@@ -1020,7 +1085,7 @@ def main():
 
     # secondary metric: the same object through the FULL pose (centre chain + back-vote + orientation vote + axis
     # sign + scale + one read-back), one hipGraph replay per object
-    t_pose, pose = None, {"n_surv": None}
+    t_pose, mm_pose, pose = None, None, {"n_surv": None}
     if secondary:
         from cppf_amd.inference import PosePipeline
         from cppf_amd.utils.util import fibonacci_sphere
@@ -1029,11 +1094,8 @@ def main():
         for _ in range(3):
             pose = pp.run()
         settle()
-        torch.cuda.synchronize()
-        tp0 = time.perf_counter()
-        for _ in range(10):
-            pose = pp.run()
-        t_pose = (time.perf_counter() - tp0) / 10 * 1e3
+        t_pose, mm_pose = repeated(pp.run, 10, 7)
+        pose = pp.run()
         del pp
 
     # secondaries: the other BASELINE.json configurations, each through the same code as a --config run of its own
@@ -1058,17 +1120,19 @@ def main():
         args.steps = 8
         # one GPU's share of the 64-object batch; the smallest of three batches (a batch is ~2 ms of mostly host work: one
         # scheduler hiccup on the box triples it)
-        m4 = min((run_c4(dev, rank, world, args, n_objects=8, n_regions=1) for _ in range(3)), key=lambda q: q["elapsed"])
+        args.regions, args.min_seconds = 7, 0.0
+        m4 = run_c4(dev, rank, world, args, n_objects=8)
         other["c4_one_gpu_share"] = {"workload": "8 mixed-category objects (N=4096 K=128), full pose each, BatchPoseRunner, pairs "
-                                                 "drawn on the device, one read-back per batch; smallest of three batches",
+                                                 "drawn on the device, one read-back per batch; median of 7 batches",
                                      "ms_per_object": m4["elapsed"] / (m4["reps"] * 8) * 1e3,
+                                     "ms_per_object_min_max": [m4["regions"][0] / (m4["reps"] * 8) * 1e3, m4["regions"][-1] / (m4["reps"] * 8) * 1e3],
                                      "pairs_per_s": m4["reps"] * 8 * m4["P"] / m4["elapsed"]}
         args.steps = keep[0]
         args.regions, args.min_seconds = keep_r
 
     # secondary (BASELINE config 4 with the point encoder in front): 8 instances through BatchPoseRunner -- cloud in from the
     # host, pairs and bin uniforms drawn on the device, kNN + SPRIN + full pose per instance, one read-back for the batch
-    t_batch = None
+    t_batch = mm_batch = None
     if secondary:
         from cppf_amd.batch import BatchPoseRunner
         from cppf_amd.models.model import PointEncoder
@@ -1082,12 +1146,7 @@ def main():
         for _ in range(6):
             runner.run(batch)
         settle()
-        torch.cuda.synchronize()
-        tb0 = time.perf_counter()
-        for _ in range(3):
-            runner.run(batch)
-        torch.cuda.synchronize()
-        t_batch = (time.perf_counter() - tb0) / 3 / 8 * 1e3
+        t_batch, mm_batch = repeated(lambda: runner.run(batch), 2, 5, per=8)
         del runner
 
     # secondary: the step before the path -- kNN(60) + SPRIN point encoder producing `feat`
@@ -1205,6 +1264,9 @@ def main():
             "vote_workgroups": m["objs"][0]["pipe"].vote_workgroups,
             # objects per launch of the pair kernel in the timed regions (1 = a launch per object)
             "mlp_batch": m["mlp_batch"],
+            # ... and whether the votes of a chain's objects share ONE vote + ONE reduce launch (cppf_vote_argmax_batch)
+            "vote_batch": bool(m["mlp_batch"] > 1 and not args.no_vote_batch),
+            "vote_batch_workgroups": m["vote_batch_workgroups"], "vote_batch_calibration_ms_per_step": m["vote_batch_calibration"],
             "trained_regime": trained,
             "all_heads_first_pass": all_heads_step,
             "dropin_flow_reference_defaults": dropin,
@@ -1212,8 +1274,9 @@ def main():
             "stage_ms": {"ppf_mlp_decode_all_heads": t_mlp_all, "ppf_mlp_decode_centre_heads": t_mlp_tr, "vote_reduce_argmax": t_vote,
                          "vote_reduce_argmax_known_answer_inputs": t_vote_ka,
                          "vote_plus_pose_tail_known_answer_inputs": t_tail_ka, "pose_tail_known_answer_n_surv": n_surv_ka,
-                         "full_pose_incl_readback": t_pose, "full_pose_n_surv": pose["n_surv"],
+                         "full_pose_incl_readback": t_pose, "full_pose_incl_readback_min_max": mm_pose, "full_pose_n_surv": pose["n_surv"],
                          "batch_of_8_instances_knn_sprin_full_pose_per_instance": t_batch,
+                         "batch_of_8_instances_min_max": mm_batch,
                          "point_encoder_knn60_sprin": t_penc,
                          "pair_encoder_fwd_bwd_200k_pairs": t_train,
                          "pair_encoder_fwd_bwd_adam_step_200k_pairs": t_step,
@@ -1287,9 +1350,70 @@ def main():
             if args.config == "c2" and not args.no_secondary:
                 c1 = res_w[-1]["cpu_baseline"]
                 out["cpu_baseline"]["c1"] = {kk: c1[kk] for kk in ("value", "unit", "best_threads", "legs", "spread", "sample")}
-        emit(out)
+        emit(out, args)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+
+
+def compact(out):
+    """The line rank 0 prints (< 4 KB): the contract's fields, the two rooflines, the CPU baseline's summary and the secondaries a
+    reader needs first.  The full record (every stage, sweep and note: ~15 KB) goes to bench_full.json -- a harness that keeps
+    the tail of stdout loses the head of a long line, and with it everything but the key names (BENCH_r04)."""
+    pick = lambda d, keys: None if d is None else {k_: d[k_] for k_ in keys if k_ in d}
+    line = {k_: out[k_] for k_ in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                   "vs_baseline", "dtype", "data") if k_ in out}
+    cfg = dict(out["config"])
+    if len(cfg.get("workload", "")) > 700:
+        cfg["workload"] = cfg["workload"][:700] + " ..."
+    line["config"] = cfg
+    for k_ in ("pairs_per_ms_per_gpu", "regions", "region_ms_min_max", "median_ms_one_instance", "vote_workgroups", "mlp_batch", "vote_batch",
+               "vote_batch_workgroups", "vote_batch_calibration_ms_per_step", "dist", "argmax_matches_oracle", "argmax_objects_matching_oracle", "argmax_steps_matching_oracle", "objects_per_s"):
+        if k_ in out:
+            line[k_] = out[k_]
+    line["roofline"] = pick(out.get("roofline"), ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "lists_per_launch",
+                                                  "pairs_per_launch", "executed_flop_per_pair", "algorithmic_tflops"))
+    rv = out.get("roofline_vote")
+    if rv is not None:
+        line["roofline_vote"] = pick(rv, ("bound", "kernel", "achieved", "peak", "unit", "frac", "regime_of_achieved", "traffic",
+                                          "algorithmic_bytes", "traffic_ratio"))
+        for reg in ("benchmark_inputs", "known_answer_inputs"):
+            if rv.get(reg):
+                line["roofline_vote"][reg] = pick(rv[reg], ("stage_ms", "landed_samples", "achieved", "frac"))
+        if rv.get("traffic_timed_regions"):
+            line["roofline_vote"]["traffic_timed_regions"] = rv["traffic_timed_regions"]
+    cb = out.get("cpu_baseline")
+    if cb is not None:
+        line["cpu_baseline"] = pick(cb, ("value", "unit", "cores", "kind", "spread", "passes", "omp_binding", "physical_cores",
+                                         "host_threads_available", "legs"))
+        line["cpu_baseline"]["sample"] = cb["sample"][:300]
+        line["cpu_baseline"]["sweep_pairs_per_s"] = {str(e["threads"]): round(e["pairs_per_s"]) for e in cb.get("sweep", [])}
+        if cb.get("other_binding"):
+            line["cpu_baseline"]["other_binding"] = pick(cb["other_binding"], ("value", "cores", "spread", "omp_binding"))
+        if cb.get("c1"):
+            line["cpu_baseline"]["c1"] = pick(cb["c1"], ("value", "unit", "best_threads"))
+    tr = out.get("trained_regime")
+    if tr:
+        line["trained_regime"] = {"ms_per_step": tr.get("ms_per_step"), "pairs_per_s": tr.get("pairs_per_s")}
+        for tag in ("axis_aligned", "random_poses"):
+            if tr.get(tag):
+                line["trained_regime"][tag] = pick(tr[tag], ("vote_batch_workgroups", "ms_per_step", "ms_per_step_min_max", "median_ms_one_instance",
+                                                             "full_pose_ms_incl_readback", "argmax_error_cells_max_over_objects"))
+    if out.get("all_heads_first_pass"):
+        line["all_heads_first_pass"] = pick(out["all_heads_first_pass"], ("ms_per_step", "ms_per_step_min_max", "pairs_per_s"))
+    if out.get("stage_ms"):
+        line["stage_ms"] = pick(out["stage_ms"], ("ppf_mlp_decode_centre_heads", "ppf_mlp_decode_all_heads", "vote_reduce_argmax",
+                                                  "vote_reduce_argmax_known_answer_inputs", "full_pose_incl_readback",
+                                                  "full_pose_incl_readback_min_max", "point_encoder_knn60_sprin"))
+    if out.get("other_configs"):
+        line["other_configs"] = {nm: pick(v, ("ms_per_step", "ms_per_object", "ms_per_object_min_max", "pairs_per_s", "median_ms_one_instance",
+                                              "argmax_steps_matching_oracle")) for nm, v in out["other_configs"].items()}
+    if out.get("dropin_flow_reference_defaults"):
+        line["dropin_flow_reference_defaults"] = pick(out["dropin_flow_reference_defaults"],
+                                                      ("level1_reference_call_sequence_ms", "level2_estimate_pose_eager_ms",
+                                                       "level3_batch_runner_captured_ms", "min_max_ms"))
+    if out.get("real_frame"):
+        line["real_frame"] = pick(out["real_frame"], ("instances", "ms_per_instance_incl_preprocessing", "ms_per_instance_min_max"))
+    return line
 
 
 if __name__ == "__main__":

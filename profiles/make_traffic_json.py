@@ -18,6 +18,7 @@ names = {"point_proj_kernel": "point_proj_kernel", "pair_mlp_kernel<false, true,
          "pair_mlp_batch_kernel<false>": "pair_mlp_batch_kernel<false>", "pair_mlp_batch_kernel<true>": "pair_mlp_batch_kernel<true>",
          "reduce_argmax_kernel": "reduce_argmax_kernel", "v3_vote_kernel<true, false>": "v3_vote_kernel<true>",
          "v3_vote_kernel<false, false>": "v3_vote_kernel<false>", "v3_bin_kernel<false>": "v3_bin_kernel", "v3_reduce_kernel": "v3_reduce_kernel",
+         "v3_vote_batch_kernel": "v3_vote_batch_kernel", "v3_reduce_batch_kernel": "v3_reduce_batch_kernel",
          "sprin_conv_kernel": "sprin_conv_kernel", "knn_kernel<false>": "knn_kernel<false>"}
 out = {"_source": "rocprofv3 --pmc <one counter group per pass> -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline "
                   "(MI355X; profiles/collect.sh); per-launch averages; FETCH_SIZE/WRITE_SIZE in KiB as reported; gfx950: "
