@@ -28,6 +28,7 @@ _SIGS = {
     "cppf_vote_plan_query": (C.c_int, [i64, i32, i32, i32, i32, vp]),
     "cppf_vote_argmax_dyn": (C.c_int, [vp, vp, vp, vp, i32, vp, i64, vp, f32, i64, i64, i32, vp, i32, i32, i32, vp, vp, vp, sz,
                                        vp]),
+    "cppf_pose_tail_batch": (C.c_int, [i32, vp, i32, C.POINTER(C.c_int), i32, i32, i32, i32, i32, vp, vp, i32, i32, f32, i64, vp]),
     "cppf_vote_batch_workgroups": (C.c_int, [i32, i32]),
     "cppf_vote_argmax_batch": (C.c_int, [i32, vp, i32, i32, i32, vp]),
     "cppf_center_from_argmax_dyn": (C.c_int, [vp, vp, C.c_double, vp, vp, vp, vp, vp, vp]),
@@ -53,6 +54,7 @@ _SIGS = {
     "cppf_pair_mlp_decode": (C.c_int, [vp, vp, vp, vp, i32, vp, i64, i32, C.POINTER(C.c_int), i32, i64, i32, i32, i32,
                                        f32, f32, vp, vp, vp, vp, vp, sz, vp]),
     "cppf_pair_mlp_decode_batch": (C.c_int, [i32, vp, i32, C.POINTER(C.c_int), i32, i32, i32, i32, vp]),
+    "cppf_pair_mlp_decode_sel_batch": (C.c_int, [i32, vp, i32, C.POINTER(C.c_int), i32, i32, i32, i32, vp]),
     "cppf_pair_mlp_batch_plan": (C.c_int, [i32, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "cppf_pair_mlp_decode_sel": (C.c_int, [vp, vp, vp, vp, i32, vp, i64, i32, C.POINTER(C.c_int), i32, i64, i32, i32, i32, vp, vp, vp,
                                            i64, vp, vp, sz, vp]),
@@ -98,7 +100,21 @@ class PairMlpItem(C.Structure):
     _fields_ = [("pc", C.c_void_p), ("nrm", C.c_void_p), ("feat", C.c_void_p), ("idxs", C.c_void_p), ("packed", C.c_void_p),
                 ("u_tr", C.c_void_p), ("u_rot", C.c_void_p), ("outputs", C.c_void_p), ("heads", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("n_points", C.c_int64), ("n_pairs", C.c_int64),
-                ("vr0", C.c_float), ("vr1", C.c_float), ("idx_is_i64", C.c_int)]
+                ("vr0", C.c_float), ("vr1", C.c_float), ("idx_is_i64", C.c_int),
+                ("sel", C.c_void_p), ("n_sel_dev", C.c_void_p), ("max_sel", C.c_int64)]
+
+
+class PoseTailItem(C.Structure):
+    """include/cppf.h: CppfPoseTailItem (one object of cppf_pose_tail_batch)"""
+    _fields_ = [("pc", C.c_void_p), ("nrm", C.c_void_p), ("feat", C.c_void_p), ("idx64", C.c_void_p), ("idx32", C.c_void_p),
+                ("outputs", C.c_void_p), ("u_rot", C.c_void_p), ("heads", C.c_void_p), ("corner", C.c_void_p), ("shape_dev", C.c_void_p),
+                ("argmax_idx", C.c_void_p), ("peak", C.c_void_p), ("packed", C.c_void_p), ("mlp_workspace", C.c_void_p),
+                ("mlp_workspace_bytes", C.c_size_t), ("vote_workspace", C.c_void_p), ("rec", C.c_void_p), ("T32", C.c_void_p),
+                ("tail0", C.c_void_p), ("tail0_bytes", C.c_size_t), ("mask", C.c_void_p), ("chunk_counts", C.c_void_p), ("surv", C.c_void_p),
+                ("count", C.c_void_p), ("counts", C.c_void_p), ("best_idx", C.c_void_p), ("ticket", C.c_void_p),
+                ("sums_workspace", C.c_void_p), ("sums_workspace_bytes", C.c_size_t), ("n_points", C.c_int64), ("n_pairs", C.c_int64),
+                ("res64", C.c_double), ("res", C.c_float), ("tol", C.c_float), ("gx", C.c_int), ("gy", C.c_int), ("gz", C.c_int),
+                ("n_dirs", C.c_int), ("second_pass", C.c_int)]
 
 
 class VoteItem(C.Structure):

@@ -17,14 +17,14 @@ import numpy as np
 import torch
 
 from . import sharding
-from .inference import PosePipeline, assemble_batch, grid_class, grid_shape
+from .inference import PoseChain, PosePipeline, assemble_batch, grid_class, grid_shape
 from .utils.util import fibonacci_sphere, num_sphere_bins
 
 
 class BatchPoseRunner:
     def __init__(self, encoders, device, num_rots=72, adaptive=True, angle_tol=1.5, max_rot_pairs=10000,
                  use_graph=True, point_encoders=None, n_bucket=1024, max_pipelines=24, dynamic=True, n_lanes=3,
-                 max_scratch_bytes=16 << 30, vote_workgroups=None):
+                 max_scratch_bytes=16 << 30, vote_workgroups=None, chain_len=None, max_chains=24):
         """encoders: {category name: PPFEncoder on `device`} (the reference keeps one per category,
         nocs/inference.py:79-90).  point_encoders: optional {category name: PointEncoder}; objects of those
         categories need no `feat` -- kNN + SPRIN run at the head of the captured graph (:180-181).
@@ -39,7 +39,12 @@ class BatchPoseRunner:
         vote_workgroups: width of the vote launches (CenterPipeline).  None = chosen per pipeline: with more than one lane, 128 for
         few-tile grids of up to half a million pairs -- every vote workgroup pays for a 113 KB tile whatever it deposits, so with
         neighbours in flight half the chip per vote moves more instances per second (profiles/r4_vote_workgroups.txt) -- and one
-        workgroup per CU otherwise (longer pair lists, many-tile grids, a single lane)."""
+        workgroup per CU otherwise (longer pair lists, many-tile grids, a single lane).
+        chain_len: instances whose launches are SHARED (inference.PoseChain: one pair-kernel launch, one vote + one reduce launch and
+        six tail launches for the whole chain instead of ~15 launches per instance).  None = the rank's instances split evenly over
+        the lanes, at most 8 per chain; 1 = every instance its own captured pipeline (round 4).  A chain is captured the SECOND time
+        its combination of pipelines (category, point bucket, pair count, grid class per position) comes up -- a one-off combination
+        runs its members' own graphs -- and at most `max_chains` captured chains are kept (least recently used first out)."""
         self.encoders, self.device = encoders, device
         self.point_encoders = point_encoders or {}
         self.n_lanes = max(1, int(n_lanes))
@@ -49,21 +54,23 @@ class BatchPoseRunner:
         self.sphere = np.array(fibonacci_sphere(num_sphere_bins(angle_tol)))      # :100-102
         self.n_bucket, self.max_pipelines, self.dynamic = int(n_bucket), int(max_pipelines), bool(dynamic)
         self.max_scratch_bytes, self._bytes = int(max_scratch_bytes), {}
+        self.chain_len, self.max_chains = (None if chain_len is None else max(1, min(8, int(chain_len)))), int(max_chains)
+        self._chains, self._chain_seen = OrderedDict(), {}     # LRU: tuple of member ids -> PoseChain; sightings of a combination
         self._pipes = OrderedDict()    # LRU: key -> PosePipeline
         self._staging = {}         # pinned host staging sets for the small per-instance arrays, see _stage()
         self._stage_pos = 0
         self._streams = None
 
     # ------------------------------------------------------------------ pipeline cache
-    def _pipe(self, cfg, n_points, n_pairs, dims, lane=0):
-        """The pipeline that serves this instance shape on this lane (created on first use, LRU-bounded)."""
+    def _pipe(self, cfg, n_points, n_pairs, dims, lane=0, slot=0):
+        """The pipeline that serves this instance shape at position `slot` of a chain on this lane (created on first use, LRU-bounded)."""
         T, many, _ = grid_class(dims)
         dyn = self.dynamic and T > 0
         if dyn:
             n_cap = -(-int(n_points) // self.n_bucket) * self.n_bucket
-            key = (cfg.category, n_cap, n_pairs, many, lane)
+            key = (cfg.category, n_cap, n_pairs, many, lane, slot)
         else:
-            key = (cfg.category, n_points, n_pairs, tuple(dims), lane)
+            key = (cfg.category, n_points, n_pairs, tuple(dims), lane, slot)
         pipe = self._pipes.get(key)
         if pipe is None:
             need = self.footprint_bytes(n_cap if dyn else n_points, n_pairs, many if dyn else None, dims)
@@ -73,6 +80,8 @@ class BatchPoseRunner:
                 torch.cuda.synchronize(self.device)
                 old_key, old = self._pipes.popitem(last=False)
                 self._bytes.pop(old_key, None)
+                for ck in [ck for ck in self._chains if id(old) in ck]:      # chains the victim is a member of go with it
+                    self._chains.pop(ck).release()
                 old.release()
             width = self.vote_workgroups
             if width is None:
@@ -89,6 +98,29 @@ class BatchPoseRunner:
         else:
             self._pipes.move_to_end(key)
         return pipe
+
+    def _chain_for(self, pipes):
+        """the captured chain of these pipelines, or None (a single instance; a member the chain cannot take; a combination seen for
+        the first time: its members run their own graphs)"""
+        if len(pipes) < 2 or any(not p._split_ok or p.rot_order is not None or p._sph[2] == 0 for p in pipes):
+            return None
+        key = tuple(id(p) for p in pipes)
+        chain = self._chains.get(key)
+        if chain is not None:
+            self._chains.move_to_end(key)
+            return chain
+        seen = self._chain_seen.get(key, 0) + 1
+        if len(self._chain_seen) > 4096:
+            self._chain_seen.clear()
+        self._chain_seen[key] = seen
+        if seen < 2:
+            return None
+        while len(self._chains) >= self.max_chains:
+            torch.cuda.synchronize(self.device)
+            self._chains.popitem(last=False)[1].release()
+        chain = self._chains[key] = PoseChain(pipes, use_graph=self.kw["use_graph"],
+                                              vote_workgroups=0 if self.vote_workgroups is None else self.vote_workgroups)
+        return chain
 
     @staticmethod
     def footprint_bytes(n_points, n_pairs, many_tiles, dims):
@@ -185,31 +217,49 @@ class BatchPoseRunner:
         for st in self._streams:
             st.wait_stream(main)
         checked = set()          # pipelines whose weight images were looked at in this batch (once is enough: nothing
-        for slot, j in enumerate(mine):   # updates parameters while run() is on the stack)
-            obj = objects[j]
-            self._check(j, obj)
-            corners, dims = grid_shape(obj["pc"], obj["cfg"].res)
-            on_device = obj.get("point_idxs") is None
-            n_pairs = int(obj["n_pairs"]) if on_device else obj["point_idxs"].shape[0]
-            lane = slot % self.n_lanes
-            pipe = self._pipe(obj["cfg"], obj["pc"].shape[0], n_pairs, dims, lane)
+        #                          updates parameters while run() is on the stack)
+        L = self.chain_len or max(1, min(8, -(-len(mine) // self.n_lanes)))
+        groups = [list(range(g, min(g + L, len(mine)))) for g in range(0, len(mine), L)]     # consecutive instances share a chain
+        ran = []                 # (chain or None, pipelines, slots) per group, for adapt()
+        for gi, slots in enumerate(groups):
+            lane = gi % self.n_lanes
+            pipes = []
             with torch.cuda.stream(self._streams[lane]):
-                self._stage(pipe, obj["pc"], obj["normals"], obj.get("feat") if pipe.point_encoder is None else None,
-                            corners[0], dims)
-                if not on_device:
-                    pipe.load(None, None, None, obj["point_idxs"], obj["u_tr"], obj["u_rot"], None)
-                if on_device:
-                    gen = torch.Generator(device=self.device)
-                    gen.manual_seed(int(seed) * 1000003 + j)
-                    pipe.sample_inputs(gen, n_points=obj["pc"].shape[0])
-                pipe.run_async(raw[slot], check_weights=id(pipe) not in checked)
-                checked.add(id(pipe))
-                used.append(pipe)
-            cfgs.append(obj["cfg"])
+                for q, slot in enumerate(slots):
+                    j = mine[slot]
+                    obj = objects[j]
+                    self._check(j, obj)
+                    corners, dims = grid_shape(obj["pc"], obj["cfg"].res)
+                    on_device = obj.get("point_idxs") is None
+                    n_pairs = int(obj["n_pairs"]) if on_device else obj["point_idxs"].shape[0]
+                    pipe = self._pipe(obj["cfg"], obj["pc"].shape[0], n_pairs, dims, lane, q)
+                    self._stage(pipe, obj["pc"], obj["normals"], obj.get("feat") if pipe.point_encoder is None else None,
+                                corners[0], dims)
+                    if not on_device:
+                        pipe.load(None, None, None, obj["point_idxs"], obj["u_tr"], obj["u_rot"], None)
+                    else:
+                        gen = torch.Generator(device=self.device)
+                        gen.manual_seed(int(seed) * 1000003 + j)
+                        pipe.sample_inputs(gen, n_points=obj["pc"].shape[0])
+                    pipes.append(pipe)
+                    cfgs.append(obj["cfg"])
+                chain = self._chain_for(pipes)
+                fresh = any(id(p) not in checked for p in pipes)
+                if chain is not None:
+                    chain.run_async([raw[slot] for slot in slots], check_weights=fresh)
+                else:
+                    for pipe, slot in zip(pipes, slots):
+                        pipe.run_async(raw[slot], check_weights=id(pipe) not in checked)
+                checked.update(id(p) for p in pipes)
+                ran.append((chain, pipes, slots))
         for st in self._streams:
             main.wait_stream(st)
         host = raw.cpu().numpy()                       # the batch's only synchronisation
-        for slot, pipe in enumerate(used):             # split / full-first form of each pipeline's next instance (PosePipeline.adapt)
-            pipe.adapt(host[slot, 18])
+        for chain, pipes, slots in ran:                # split / full-first form of the next run (PosePipeline.adapt / PoseChain.adapt)
+            if chain is not None:
+                chain.adapt([host[slot, 18] for slot in slots])
+            else:
+                for pipe, slot in zip(pipes, slots):
+                    pipe.adapt(host[slot, 18])
         local = torch.from_numpy(assemble_batch(host[:len(mine)], cfgs, mine, sharding.RECORD)).to(self.device)
         return sharding.gather_records(local, len(objects), rank, world, self.device)

@@ -697,10 +697,10 @@ struct MlpBatch {
     int n;
     int per_xcd;   // > 0: lists of (nearly) equal length, 8 % n == 0: list i on XCDs [i per_xcd, (i + 1) per_xcd) -- see below
 };
-template <bool HEADS>
+template <bool HEADS, bool SEL = false>
 __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_batch_kernel(MlpBatch B)
 {
-    if (B.per_xcd > 0) {
+    if (!SEL && B.per_xcd > 0) {
         // Workgroups go to XCD blockIdx mod 8 and every XCD has its own 4 MB L2: with a list's workgroups spread over all XCDs each L2
         // sees every list's 2 MB table and thrashes (PMC: 4.5x the HBM / MALL fetches of one launch per list).  With 1, 2, 4 or 8
         // lists of equal length a list keeps to its own XCDs.
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_batc
     }
     int i = 0;
     while (i + 1 < B.n && (int)blockIdx.x >= B.wg_begin[i + 1]) ++i;
-    pair_mlp_body<false, true, HEADS, false>(B.item[i], (int)blockIdx.x - B.wg_begin[i], B.wg_begin[i + 1] - B.wg_begin[i]);
+    pair_mlp_body<false, true, HEADS, SEL>(B.item[i], (int)blockIdx.x - B.wg_begin[i], B.wg_begin[i + 1] - B.wg_begin[i]);
 }
 
 // ----------------------------------------------------------------------------- generic kernel
@@ -1040,6 +1040,51 @@ extern "C" int cppf_pair_mlp_decode_batch(int n_items, const CppfPairMlpItem* it
     }
     if (heads) hipLaunchKernelGGL((pair_mlp_batch_kernel<true>), dim3((unsigned)given), dim3(MLP_THREADS), (STD_LDS + 128) * sizeof(float), st, B);
     else hipLaunchKernelGGL((pair_mlp_batch_kernel<false>), dim3((unsigned)given), dim3(MLP_THREADS), (STD_LDS + 128) * sizeof(float), st, B);
+    CPPF_CHECK_LAUNCH();
+    return 0;
+}
+
+// The second pass (cppf_pair_mlp_decode_sel) for several pair lists in ONE launch: workgroups [w_i, w_{i+1}) work on list i's
+// survivors; every list's per-point table is the one its first pass left in item.workspace.  Items with max_sel == 0 are skipped.
+extern "C" int cppf_pair_mlp_decode_sel_batch(int n_items, const CppfPairMlpItem* items, int F, const int* dims, int n_res, int out_dim,
+                                              int tr_bins, int rot_bins, void* stream)
+{
+    if (n_items < 1 || n_items > MLP_BATCH_MAX || !items || !dims) return CPPF_EINVAL;
+    if (!is_std(F, dims, n_res, out_dim) || tr_bins != 32 || rot_bins != 36 || out_dim != 141) return CPPF_EUNSUPPORTED;
+    MlpBatch B = {};
+    int given = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const CppfPairMlpItem& it = items[i];
+        if (it.n_pairs < 0 || it.max_sel < 0) return CPPF_EINVAL;
+        if (it.n_pairs == 0 || it.max_sel == 0) continue;
+        if (it.n_pairs >= (1ll << 27) || it.n_points >= (1ll << 23)) return CPPF_EUNSUPPORTED;
+        if (!it.pc || !it.nrm || !it.feat || !it.idxs || !it.packed || !it.u_rot || !it.sel || !it.n_sel_dev || !it.heads) return CPPF_EINVAL;
+        if (!it.workspace || it.workspace_bytes < (size_t)it.n_points * PROJ_COLS * sizeof(float)) return CPPF_EWORKSPACE;
+        MlpArgs& A = B.item[B.n];
+        A.pc = it.pc; A.nrm = it.nrm; A.feat = it.feat; A.idxs = it.idxs; A.packed = it.packed; A.out_dim = out_dim;
+        A.P = it.max_sel < it.n_pairs ? it.max_sel : it.n_pairs;
+        A.idx64 = it.idx_is_i64; A.u_rot = it.u_rot; A.heads = it.heads; A.sel = it.sel; A.n_sel = it.n_sel_dev;
+        A.table = static_cast<const float*>(it.workspace);
+        B.wg_begin[B.n] = given;
+        // (a launch cannot know the survivor counts: every list gets the workgroups of its capacity, at most a quarter of the chip's
+        // round when several lists share it; surplus workgroups exit at once)
+        int w = mlp_grid(A.P);
+        const int cap = mlp_grid(1ll << 26) / (n_items > 1 ? 2 : 1);
+        if (w > cap) w = cap;
+        given += w;
+        ++B.n;
+    }
+    if (B.n == 0) return 0;
+    B.wg_begin[B.n] = given;
+    static bool attr_done = false;
+    const void* fn = reinterpret_cast<const void*>(&pair_mlp_batch_kernel<true, true>);
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (STD_LDS + 128) * sizeof(float));
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((pair_mlp_batch_kernel<true, true>), dim3((unsigned)given), dim3(MLP_THREADS), (STD_LDS + 128) * sizeof(float),
+                       (hipStream_t)stream, B);
     CPPF_CHECK_LAUNCH();
     return 0;
 }

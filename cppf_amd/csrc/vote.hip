@@ -1,51 +1,7 @@
-// Centre vote, arg-max, back-vote, compaction, orientation vote and the pose-tail reductions
-// for gfx950 (MI355X).  C ABI in include/cppf.h; reference semantics cited per kernel.
-#include <hip/hip_runtime.h>
-#include <cstdlib>
-#include <stdint.h>
-#include <stdio.h>
-
-#include "../../include/cppf.h"
-#include "cppf_math.h"
-
-using namespace cppf;
-
-#define CPPF_CHECK_LAUNCH()                         \
-    do {                                            \
-        hipError_t e__ = hipGetLastError();         \
-        if (e__ != hipSuccess) return (int)e__;     \
-    } while (0)
-
-// ----------------------------------------------------------------------------- rotation table
-// tab[n*(n-1)/2 + i] = (cos, sin) of rotation i of n, n = 1..n_rots: every workgroup that needs it
-// builds it in LDS in its prologue (2 628 entries for n_rots = 72, ~3 fp64 sincos per thread).
-__device__ __forceinline__ void fill_rot_table(float2* ltab, int entries, int tid, int nthreads)
-{
-    for (int e = tid; e < entries; e += nthreads) {
-        int n = (int)((sqrtf(8.f * (float)e + 1.f) + 1.f) * 0.5f);
-        while (n * (n - 1) / 2 > e) --n;
-        while ((n + 1) * n / 2 <= e) ++n;
-        ltab[e] = rot_cs(e - n * (n - 1) / 2, n);
-    }
-}
-
-// A cached table is trusted only if its stamp matches AND its 72 known entries are in place: rotation 0 of every n is
-// exactly (1, 0), at offsets n(n-1)/2 spread over the whole table.  The stamp alone would survive a caller that reuses one
-// arena for several entry points (or an allocator that recycles the block) and overwrites table bytes but not byte 248.
-// Wave-uniform result; every wave of a launch reads the same memory and reaches the same verdict.
-__device__ __forceinline__ bool rot_table_intact(const float2* wtab, int n_rots)
-{
-    const int lane = threadIdx.x & 63;
-    bool ok = true;
-    for (int n = lane + 1; n <= n_rots; n += 64) {
-        const float2 v = wtab[n * (n - 1) / 2];
-        ok = ok && v.x == 1.0f && v.y == 0.0f;
-    }
-    return !__any(!ok);
-}
-
-static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-static inline int tri(int n) { return n * (n + 1) / 2; }
+// Centre vote + arg-max for gfx950 (MI355X): plan, arc screen, run walk, v3_bin / v3_vote / v3_reduce kernels, the batched and the
+// integer forms.  C ABI in include/cppf.h; reference semantics cited per kernel (models/voting.py:8-66, nocs/inference.py:192-208).
+// The rest of the pose chain (back-vote, compaction, orientation vote, reductions) lives in pose_tail.hip.
+#include "vote_common.h"
 
 // ----------------------------------------------------------------------------- vote plan
 // ONE tiled implementation serves every n_rots (1..360) and every grid of up to 64 LDS tiles: v3_bin_kernel / v3_vote_kernel /
@@ -53,7 +9,6 @@ static inline int tri(int n) { return n * (n + 1) / 2; }
 // beyond 64 tiles -- none of the reference's categories -- vote_global_kernel restates the reference's own kernel with global
 // fp32 atomics.  The plan (tiling, workgroups, fixed-point bits) is a pure function of (n_ppfs, n_rots, grid dims): host code
 // evaluates it for a by-value launch, the *_dyn kernels evaluate the SAME functions on the device from a dims record.
-#define VOTE_TAB_LDS_MAX 2628   // (cos,sin) pairs kept in LDS: the triangular table of n_rots <= 72; more rotations: see WIDE
 #define VOTE_MAX_TILES 64       // beyond this the grid goes to global atomics (measured: 32 tiles still beat them 4-9x)
 #define VOTE_WIN 72             // rotations of a pair one launch serves (the arc masks are 96-bit words): n_rots > 72 takes ceil(n_rots / 72) passes
 
@@ -67,21 +22,6 @@ __host__ __device__ inline int vote_fixed_bits_of(int64_t chunk_pairs, int n_rot
     return kk;
 }
 
-// Workspace layout: [0, 256) arg-max keys and tickets; [256, VOTE_WS_PART) the (cos, sin) rotation table of the LAST launch
-// that used this workspace, stamped with its n_rots at byte 248 -- building the table (2 628 fp64 sincos for 72 rotations)
-// cost every workgroup ~5 us of its prologue, so the first launch on a workspace builds it in LDS and workgroup 0
-// also leaves a copy here; later launches with the same n_rots find the stamp and load the 21 KB instead.  Nothing is kept
-// outside the caller's workspace.  [VOTE_WS_PART, VOTE_WS_PART + VOTE_WS_V3_STATE): the queue header and the extra plane (V3Hdr);
-// behind them the tile queues and the partial tiles.
-#define VOTE_WS_TAB 256
-#define VOTE_WS_PART (256 + ((VOTE_TAB_LDS_MAX + 2) * 8 + 255) / 256 * 256)
-#define VOTE_WS_V3_STATE (8704 + 64 * 30720 * 8)
-#define VOTE_TAB_STAMP 0x43505046726f7400ull   // "CPPFrot\0" ^ n_rots: table valid
-// The launch that builds the table must not be able to read it back: workgroups of that same launch that start late
-// (more workgroups than the chip holds at once) would see workgroup 0's stamp without any guarantee of seeing its table
-// (no release/acquire between workgroups of one kernel).  So the vote kernel leaves a PENDING stamp and the reduce kernel
-// that follows it -- a kernel boundary later -- turns it into the valid one.
-#define VOTE_TAB_PENDING 0x43505046726f5000ull
 
 static int v3_fixed_bits_bound(int64_t n_ppfs, int n_rots, int gx, int gy, int gz);
 static bool v3_eligible(int64_t n_ppfs, int n_rots, int gx, int gy, int gz);
@@ -147,37 +87,6 @@ __device__ __forceinline__ float ceil_to_float(double d)
 // slack (1e-4 in the cosine, 2e-3 rad in the angle, far above their error), never a dropped vote.  A pair costs ~300
 // instructions for its masks instead of ~45 per pair of rotations in a loop over all of them.
 #define VOTE_BELOW_N 97   // BELOW[j] = bits [0, j) set, j = 0..96, as uint4 (x, y, z = three words)
-
-__device__ __forceinline__ float atan01_approx(float t)   // atan on [0, 1], |error| < 2e-5
-{
-    const float t2 = t * t;
-    float p = fmaf(t2, 0.0208351f, -0.0851330f);
-    p = fmaf(t2, p, 0.1801410f);
-    p = fmaf(t2, p, -0.3302995f);
-    p = fmaf(t2, p, 0.9998660f);
-    return p * t;
-}
-__device__ __forceinline__ float atan2_approx(float y, float x)   // (-pi, pi], |error| < 1e-4; atan2(0, 0) = 0
-{
-    const float ax = fabsf(x), ay = fabsf(y);
-    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-    float r = atan01_approx(mn * __builtin_amdgcn_rcpf(fmaxf(mx, 1e-30f)));
-    r = ay > ax ? 1.57079633f - r : r;
-    r = x < 0.f ? 3.14159265f - r : r;
-    return __builtin_copysignf(r, y);
-}
-__device__ __forceinline__ float acos_approx(float u)   // u in [-1, 1]; |error| < 1e-4 (callers budget 2e-4)
-{
-    // Abramowitz & Stegun 4.4.45: acos(x) = sqrt(1 - x) (a0 + a1 x + a2 x^2 + a3 x^3) on [0, 1], |error| <= 6.7e-5; acos(-x) = pi - acos(x).
-    // The square root carries the singularity at 1, so the error bound holds up to the end points (round 3: 9 instructions
-    // instead of the 16 of the atan form -- every arc mask takes two).
-    const float ax = fabsf(u);
-    float p = fmaf(ax, -0.0187293f, 0.0742610f);
-    p = fmaf(p, ax, -0.2121144f);
-    p = fmaf(p, ax, 1.5707288f);
-    const float r = p * __builtin_amdgcn_sqrtf(fmaxf(1.f - ax, 0.f));
-    return u < 0.f ? 3.14159265f - r : r;
-}
 
 struct Mask96 { uint32_t a, b, c; };
 
@@ -262,34 +171,6 @@ __device__ __forceinline__ void mask_runs(const uint4* __restrict__ below, uint3
     e2 = top96(r0, r1, r2);
 }
 // inclusive prefix sum over the 64 lanes: four row_shr steps inside each row of 16, then the row totals (row_bcast 15 / 31)
-__device__ __forceinline__ int wave_incl_scan(int v)
-{
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
-    return v;
-}
-
-// ----------------------------------------------------------------------------- reduce + arg-max
-// grid[cell] (+)= sum_c partials[c][cell] in a fixed order, and the arg-max of the result with
-// numpy's tie rule (first maximum in C order, nocs/inference.py:208): key = ord(value) << 32 |
-// ~index, max-reduced in the wave, then one returning atomicMax per block.  A block = 64 cells x 16
-// chunk groups (chunk c goes to group c % 16) with 8 loads in flight per lane, so the ~100 partial
-// grids stream at L2/HBM rate instead of one dependent load at a time.  The last block to take a ticket unpacks the key into out_idx / out_val: every access to
-// the key and the ticket is a device-scope atomic whose result is consumed before the next one is
-// issued, so no cache maintenance is needed.
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
-{
-    for (int off = 32; off > 0; off >>= 1) {
-        unsigned long long o = __shfl_xor(k, off, 64);
-        k = o > k ? o : k;
-    }
-    return k;
-}
-
 #define RED_GROUPS 16
 #define RED_MAX_BLOCKS 256
 __global__ __launch_bounds__(64 * RED_GROUPS) void reduce_argmax_kernel(float* __restrict__ grid,
@@ -461,6 +342,19 @@ __host__ __device__ inline int64_t v3_fused_chunk_pairs(int64_t n_ppfs, int C)
     const int64_t nb = (n_ppfs + 63) / 64;
     return (nb + C - 1) / (C > 0 ? C : 1) * 64;
 }
+// The fixed-point scale of the fused vote does NOT follow the launch's width: it is the scale of the NARROWEST launch an object can
+// get (64 workgroups: cppf_vote_argmax's smallest CPPF_VOTE_WORKGROUPS and the width of an object in a batch of four or more) or of
+// the actual one if that is narrower still (short pair lists).  Every width a caller can choose then quantises every deposit alike,
+// and since the grid is the exact integer sum of the quantised deposits it is the SAME BITS whether an object is voted alone on 256
+// workgroups, on 128 beside its neighbours or as one of eight in a batched launch (round 4: one bit per halving of the width, so a
+// pose record's peak depended on how the batch was cut).  Cost: two bits at full width -- 2^-22 instead of 2^-24 of the largest
+// weight per deposit at C2, still an order of magnitude below the fp32 rounding of the reference's own atomicAdd sums.
+#define V3_BITS_WGS 64
+__host__ __device__ inline int64_t v3_fused_bits_pairs(int64_t n_ppfs, int C, int T)
+{
+    const int Cc = V3_BITS_WGS / (T > 0 ? T : 1) > 0 ? V3_BITS_WGS / (T > 0 ? T : 1) : 1;
+    return v3_fused_chunk_pairs(n_ppfs, C < Cc ? C : Cc);
+}
 
 struct V3Plan { V3Tiling t; int wgs, slot; size_t pool_off, part_off, total; int64_t pool_cap; };
 // pool: T queues of `cap` records (12 B) each -- every pair can visit every tile, and the HBM is there (288 GB)
@@ -535,7 +429,7 @@ __device__ __forceinline__ void v3_split(const V3Args& A, int T, int* sp)
         if (threadIdx.x < 64) {
             const int C = lane < T ? A.wgs / T : 0;
             sp[lane] = C; sp[64 + lane] = lane * C; sp[128 + lane] = 0x7fffffff;
-            if (lane == 0) sp[192] = (int)v3_fused_chunk_pairs(A.n_ppfs, C);
+            if (lane == 0) sp[192] = (int)v3_fused_bits_pairs(A.n_ppfs, A.wgs / T, T);   // (what the fixed-point scale follows)
         }
         return;
     }
@@ -1628,7 +1522,7 @@ static int v3_fixed_bits_bound(int64_t n_ppfs, int n_rots, int gx, int gy, int g
 {
     const V3Tiling t = v3_tiling(gx, gy, gz);
     const int wgs = v3_wgs(n_ppfs, t.T);
-    if (t.T < 4) return v3_bits((unsigned)v3_fused_chunk_pairs(n_ppfs, wgs / t.T), n_rots);   // (what v3_launch passes)
+    if (t.T < 4) return v3_bits((unsigned)v3_fused_bits_pairs(n_ppfs, wgs / t.T, t.T), n_rots);   // (what v3_prepare passes)
     // binned: chunk <= W / E <= P T / (wgs - T) records (C_t = 1 + floor(n_t E / W) >= n_t E / W), and never more than a tile's queue (<= P)
     const int64_t E = wgs - t.T > 0 ? wgs - t.T : 1;
     const int64_t worst = min(n_ppfs, (n_ppfs * t.T + E - 1) / E + 1);
@@ -1672,14 +1566,14 @@ struct V3Launch { V3Args A; int red_blocks, bps; };
 static int v3_prepare(V3Launch& Lc, const float* points, const float* outputs, const float* probs, const void* point_idxs, int idx_is_i64,
                       float* grid_obj, const float* corner, float res, int64_t n_points, int64_t n_ppfs, int n_rots, int gx, int gy,
                       int gz, int adaptive, int accumulate, bool want_argmax, long long* out_idx, float* out_val, void* workspace,
-                      const int32_t* shape_dev, int64_t grid_cap, int many_tiles, const VoteExtras* ex, int wg_cap, int wg_floor = 64)
+                      const int32_t* shape_dev, int64_t grid_cap, int many_tiles, const VoteExtras* ex, int wg_cap, int wg_floor = V3_BITS_WGS)
 {
     // Workgroups of the vote launch.  One per CU is the fastest launch on an idle chip, but every workgroup pays for its tile whatever
     // it deposits -- zeroed, dumped (113 KB) and read back by the reduce kernel: 27 of the 72 MB a C2 call moves -- so a caller that
     // keeps several instances in flight does better with fewer, longer-lived workgroups and the rest of the chip left to its other
     // streams (profiles/r4_vote_workgroups.txt: 128 instead of 256 at C2, three instances in flight: +5 % pairs/s, the instance alone
-    // 7 % slower).  The hint never goes below 64 (32 when several objects share a launch) or the number of tiles; chunking follows it,
-    // the grid stays the exact sum of the deposits (the fixed-point scale follows the chunk length: one bit coarser at C2 with 128).
+    // 7 % slower).  The hint never goes below 64 or the number of tiles; chunking follows it, the grid does NOT change with it: the
+    // fixed-point scale of the fused vote is that of a 64-wide launch whatever the width (v3_fused_bits_pairs).
     const int wgs_max = wg_cap > 0 ? (wg_cap < wg_floor ? wg_floor : (wg_cap > V3_WGS ? V3_WGS : wg_cap)) : V3_WGS;
     char* ws = static_cast<char*>(workspace);
     V3Args& A = Lc.A;
@@ -1713,7 +1607,7 @@ static int v3_prepare(V3Launch& Lc, const float* points, const float* outputs, c
         A.fused = A.t.T < 4 ? 1 : 0;
         if (A.fused) {   // static chunks: the same number for every tile
             A.wgs = (A.wgs / A.t.T) * A.t.T;
-            A.kk = v3_bits((unsigned)v3_fused_chunk_pairs(n_ppfs, A.wgs / A.t.T), n_rots);
+            A.kk = v3_bits((unsigned)v3_fused_bits_pairs(n_ppfs, A.wgs / A.t.T, A.t.T), n_rots);
         }
         A.t_cap = A.t.T;
         const V3Plan pl = v3_plan(n_ppfs, A.t, gz, v3_wgs(n_ppfs, A.t.T), A.fused ? 0 : n_ppfs, (int64_t)gx * gy * gz);
@@ -1942,8 +1836,8 @@ extern "C" int cppf_vote_batch_workgroups(int n_items, int flags)
 {
     if (n_items < 1 || n_items > V3_BATCH_MAX) return CPPF_EINVAL;
     const int wg_cap = (flags >> 8) & 0x1ff;
-    int w = wg_cap > 0 ? wg_cap : V3_WGS / n_items;     // default: the batch as ONE round of workgroups, one per CU
-    if (w < 32) w = 32;
+    int w = wg_cap > 0 ? wg_cap : V3_WGS / n_items;     // default: the batch as ONE round of workgroups, one per CU (up to four objects)
+    if (w < V3_BITS_WGS) w = V3_BITS_WGS;               // (never narrower than the width the fixed-point scale is chosen for)
     if (w > V3_WGS) w = V3_WGS;
     return w;
 }
@@ -1981,7 +1875,7 @@ extern "C" int cppf_vote_argmax_batch(int n_items, const CppfVoteItem* items, in
         V3Launch Lc;
         const int rc = v3_prepare(Lc, it.points, it.outputs, it.probs, it.point_idxs, it.idx_is_i64, it.grid, it.corner, it.res, it.n_points,
                                   it.n_ppfs, n_rots, dyn ? 1 : it.gx, dyn ? 1 : it.gy, dyn ? 1 : it.gz, adaptive, accumulate, true, it.out_idx,
-                                  it.out_val, it.workspace, it.shape_dev, dyn ? it.grid_capacity : 0, 0, nullptr, width, 32);
+                                  it.out_val, it.workspace, it.shape_dev, dyn ? it.grid_capacity : 0, 0, nullptr, width);
         if (rc != 0) return rc;
         const int k = B.n++;
         B.item[k] = Lc.A;
@@ -2059,1137 +1953,6 @@ extern "C" int cppf_grid_argmax(const float* grid, int64_t n, long long* out_idx
     if (nb > RED_MAX_BLOCKS) nb = RED_MAX_BLOCKS;
     hipLaunchKernelGGL(reduce_argmax_kernel, dim3((unsigned)nb), dim3(64 * RED_GROUPS), 0, st, const_cast<float*>(grid),
                        (const float*)nullptr, 0, n, packed, 1, 0, out_idx, out_val);
-    CPPF_CHECK_LAUNCH();
-    return 0;
-}
-
-// nocs/inference.py:209-210: cand = unravel_index(argmax); T = corners[0] + cand * res in fp64;
-// T32 is the float32 copy handed to backvote (:225).
-__global__ void center_from_argmax_kernel(const long long* __restrict__ idx, const float* __restrict__ corner, double res,
-                                          int gy, int gz, double* __restrict__ T64, float* __restrict__ T32,
-                                          const float* __restrict__ peak, double* __restrict__ idx_peak,
-                                          const int32_t* __restrict__ shape, uint4* __restrict__ zero16 = nullptr,
-                                          int n_zero16 = 0)
-{
-    // cppf_pose_tail_begin: the accumulators of the launches that follow (sphere-bin counts, chunk counts, ticket, record)
-    // start at zero; T64 / idx_peak may lie inside the region, so the zeroing comes first
-    for (int k = threadIdx.x; k < n_zero16; k += blockDim.x) zero16[k] = make_uint4(0u, 0u, 0u, 0u);
-    if (n_zero16) __syncthreads();
-    if (shape) { gy = max(shape[2], 1); gz = max(shape[3], 1); }   // dims record in memory (*_dyn)
-    const long long flat = *idx;
-    const long long syz = (long long)gy * gz;
-    const long long c[3] = {flat / syz, (flat % syz) / gz, (flat % syz) % gz};
-    const int j = threadIdx.x;
-    if (j < 3) {
-        const double t = (double)corner[j] + (double)c[j] * res;
-        if (T64) T64[j] = t;
-        if (T32) T32[j] = (float)t;
-    }
-    if (j == 3 && idx_peak) {   // the arg-max index and its value as doubles, for the pose record
-        idx_peak[0] = (double)flat;
-        idx_peak[1] = peak ? (double)*peak : 0.0;
-    }
-}
-
-// np.argmax(counts) (first maximum, nocs/inference.py:283) and best_dir = sphere_pts[argmax] (fp64) in one launch
-__global__ __launch_bounds__(256) void counts_argmax_select_kernel(const int32_t* __restrict__ counts, int n,
-                                                                   const double* __restrict__ sphere64,
-                                                                   long long* __restrict__ best_idx, double* __restrict__ best_dir)
-{
-    __shared__ unsigned long long best[4];
-    // key = count << 32 | ~index: the largest key is the largest count at the lowest index
-    unsigned long long k = 0ull;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const unsigned long long ki = ((unsigned long long)(uint32_t)counts[i] << 32) | (uint32_t)(~(uint32_t)i);
-        k = ki > k ? ki : k;
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_xor(k, off, 64);
-        k = o > k ? o : k;
-    }
-    if ((threadIdx.x & 63) == 0) best[threadIdx.x >> 6] = k;
-    __syncthreads();
-    if (threadIdx.x < 3) {
-        unsigned long long b = best[0];
-        for (int w = 1; w < 4; ++w) b = best[w] > b ? best[w] : b;
-        const int bi = (int)(~(uint32_t)(b & 0xffffffffull));
-        best_dir[threadIdx.x] = sphere64[3 * (size_t)bi + threadIdx.x];
-        if (threadIdx.x == 0 && best_idx) *best_idx = bi;
-    }
-}
-
-extern "C" int cppf_center_from_argmax(const long long* idx, const float* corner, double res, int gy, int gz,
-                                       double* T64, float* T32, const float* peak, double* idx_peak_f64, void* stream)
-{
-    if (!idx || !corner || gy < 1 || gz < 1) return CPPF_EINVAL;
-    hipLaunchKernelGGL(center_from_argmax_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, idx, corner, res, gy, gz,
-                       T64, T32, peak, idx_peak_f64, (const int32_t*)nullptr);
-    CPPF_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int cppf_center_from_argmax_dyn(const long long* idx, const float* corner, double res, const int32_t* shape_dev,
-                                           double* T64, float* T32, const float* peak, double* idx_peak_f64, void* stream)
-{
-    if (!idx || !corner || !shape_dev) return CPPF_EINVAL;
-    hipLaunchKernelGGL(center_from_argmax_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, idx, corner, res, 1, 1,
-                       T64, T32, peak, idx_peak_f64, shape_dev);
-    CPPF_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int cppf_pose_tail_begin(const long long* idx, const float* corner, double res, int gy, int gz,
-                                    const int32_t* shape_dev, double* T64, float* T32, const float* peak,
-                                    double* idx_peak_f64, void* zero_ptr, size_t zero_bytes, void* stream)
-{
-    if (!idx || !corner || (!shape_dev && (gy < 1 || gz < 1))) return CPPF_EINVAL;
-    if (zero_bytes && (!zero_ptr || (zero_bytes & 15) || (reinterpret_cast<uintptr_t>(zero_ptr) & 15) || zero_bytes > (1u << 26)))
-        return CPPF_EINVAL;
-    hipLaunchKernelGGL(center_from_argmax_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, idx, corner, res,
-                       shape_dev ? 1 : gy, shape_dev ? 1 : gz, T64, T32, peak, idx_peak_f64, shape_dev,
-                       static_cast<uint4*>(zero_ptr), (int)(zero_bytes / 16));
-    CPPF_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int cppf_counts_argmax_select(const int32_t* counts, int n, const double* sphere64, long long* best_idx,
-                                         double* best_dir, void* stream)
-{
-    if (!counts || !sphere64 || !best_dir || n < 1) return CPPF_EINVAL;
-    hipLaunchKernelGGL(counts_argmax_select_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, counts, n, sphere64,
-                       best_idx, best_dir);
-    CPPF_CHECK_LAUNCH();
-    return 0;
-}
-
-// ----------------------------------------------------------------------------- back-vote
-// Reference: CUDA backvote, models/voting.py:74-112 (always adaptive, bounds [0, dim-1)).
-// The reference's 13-argument shape has no workspace, so each (persistent, grid-stride) block
-// builds the (cos,sin) table for every n <= n_rots in LDS when it fits.
-__global__ __launch_bounds__(256) void backvote_kernel(const float* __restrict__ points,
-                                                              const float* __restrict__ outputs,
-                                                              float* __restrict__ out_offsets,
-                                                              const int32_t* __restrict__ point_idxs,
-                                                              const float* __restrict__ corner, float res, int64_t n_ppfs,
-                                                              int n_rots, int gx, int gy, int gz,
-                                                              const float* __restrict__ gt_center, float tol,
-                                                              uint8_t* __restrict__ mask, const int32_t* __restrict__ shape,
-                                                              const unsigned long long* __restrict__ vote_ws,
-                                                              int32_t* __restrict__ chunk_counts,
-                                                              const long long* __restrict__ idx64,
-                                                              int32_t* __restrict__ idx32_out)
-{
-    // cppf_backvote_count64: the pair list as the caller holds it (int64, nocs/inference.py:177); the int32 copy the later
-    // launches of the tail read is written on the way (this kernel touches every pair anyway)
-    auto load_ij = [&](const int64_t c) -> int2 {
-        if (idx64) {
-            const longlong2 v = reinterpret_cast<const longlong2*>(idx64)[c];
-            return make_int2((int)v.x, (int)v.y);
-        }
-        return reinterpret_cast<const int2*>(point_idxs)[c];
-    };
-    if (shape) { gx = shape[1]; gy = shape[2]; gz = shape[3]; }   // dims record in memory (*_dyn)
-    // (cos,sin) table for every n <= n_rots, built per block in LDS when it fits.
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float2* ltab = reinterpret_cast<float2*>(lds);
-    const int entries = n_rots * (n_rots + 1) / 2;
-    const bool in_lds = entries <= VOTE_TAB_LDS_MAX;
-    if (in_lds) {
-        // the vote that produced gt_center left the same table in its workspace (VOTE_TAB_STAMP): 21 KB to load instead of
-        // 2 628 fp64 sincos per block
-        const float2* wtab = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(vote_ws) + VOTE_WS_TAB);
-        if (vote_ws && vote_ws[31] == (VOTE_TAB_STAMP ^ (unsigned long long)n_rots) && rot_table_intact(wtab, n_rots)) {
-            for (int e = threadIdx.x; e < entries; e += blockDim.x) ltab[e] = wtab[e];
-        } else {
-            fill_rot_table(ltab, entries, threadIdx.x, blockDim.x);
-        }
-        __syncthreads();
-    }
-    const f3 cr = {corner[0], corner[1], corner[2]};
-    const f3 gt = {gt_center[0], gt_center[1], gt_center[2]};
-    const float bx = (float)(gx - 1), by = (float)(gy - 1), bz = (float)(gz - 1);
-    const float rinv_res = 1.0f / res;
-    // Two stages per wave.  Stage 1, one pair per lane: frame, rotation count, and the skip test -- every sample
-    // lies at distance |offset| = rho (1 +- 1e-6) from cc, hence at least | |cc - gt| - rho | from gt; when that
-    // exceeds tol (with a margin far above the rounding) no rotation can pass :101 and the pair is finished
-    // (offset 0).  The other pairs go to a per-wave LDS queue and stage 2 runs their rotation loops 64 at a time,
-    // so a wave never walks 72 rotations for the sake of one lane.
-    uint32_t* q = reinterpret_cast<uint32_t*>(lds + (in_lds ? 2 * entries : 0)) + (threadIdx.x >> 6) * 128;
-    const int lane = threadIdx.x & 63;
-    int qn = 0;
-    // cppf_backvote_count: survivors per chunk of CMP_BLOCK pairs (integer atomics: the counts do not depend on the
-    // order), so the compaction that follows needs no counting pass.  The lanes that call this together mostly hold pairs
-    // of one chunk: those send one atomic, the others their own.
-    auto count_survivor = [&](const int64_t idx, const bool nz) {
-        const int ch = (int)(idx >> 10);
-        const int ch0 = __builtin_amdgcn_readfirstlane(ch);
-        const unsigned long long m = __ballot(nz && ch == ch0);
-        if (nz) {
-            if (ch != ch0) atomicAdd(&chunk_counts[ch], 1);
-            else if ((threadIdx.x & 63) == __builtin_ctzll(m)) atomicAdd(&chunk_counts[ch0], __popcll(m));
-        }
-    };
-    auto finish = [&](const int64_t idx, const f3 found) {
-        if (out_offsets) {
-            float* oo = out_offsets + 3 * idx;
-            oo[0] = found.x; oo[1] = found.y; oo[2] = found.z;
-        }
-        const bool nz = (found.x != 0.f) || (found.y != 0.f) || (found.z != 0.f);
-        if (mask) mask[idx] = nz;
-        if (chunk_counts) count_survivor(idx, nz);
-    };
-    // The reference's loop (:97-110) for one pair that passed stage 1, one pair per lane -- over the ARC of rotations that can
-    // pass :101 only, in index order.  With offset = cos(t) x + sin(t) y, |x| = |y| = rho and x, y, ab orthogonal,
-    //   |cc + offset - gt|^2 = |w|^2 + rho^2 - 2 (A cos t + B sin t),   w = gt - cc, A = w.x, B = w.y,
-    // so the distance test holds exactly where cos(t - phi) >= K / M, phi = atan2(B, A), M = |(A, B)|,
-    // K = (|w|^2 + rho^2 - tol^2) / 2: a run of indices around phi n / 2 pi, about 2 tol / res + 3 of them instead of n <= 72.
-    // The run is a superset (approximate acos / atan2 with their error bounds, one index of margin on either side, K lowered
-    // by the deviations of |offset|^2 from rho^2: roundings and the 1e-7 regulariser, which shortens ab by 1e-7 / L -- pairs
-    // closer than 1e-3 scan everything); each candidate still goes through the reference's exact arithmetic and the first
-    // one in index order wins, so the result is the reference's.  On inputs where every pair survives stage 1 (a trained
-    // network) the full loop was the kernel: 100 us at C2, a lane walking on average 36 rotations and a wave its slowest lane's.
-    auto rotations = [&](const int64_t idx) {
-        const float2 o = reinterpret_cast<const float2*>(outputs)[idx];
-        const int2 ij = load_ij(idx);
-        f3 a, ab, xd;
-        pair_frame(points, ij.x, ij.y, a, ab, xd);
-        const float proj_len = o.x, odist = o.y;
-        const f3 cc = sub3(a, scl3(ab, proj_len));
-        const f3 x = scl3(xd, odist);
-        const f3 y = cross3(x, ab);
-        f3 found = {0.f, 0.f, 0.f};                                                   // :96
-        const int n = min((int)((double)(odist / res) * (2 * CPPF_PI)), n_rots);      // :97
-        const int tbase = n * (n - 1) / 2;
-        int lo = 0, cnt = n;
-        {
-            const f3 pb_ = ld3(points, ij.y);
-            const f3 dd = sub3(a, pb_);
-            const float L2 = dot3(dd, dd);
-            const f3 w = sub3(gt, cc);
-            const float A_ = dot3(w, x), B_ = dot3(w, y), w2 = dot3(w, w), rho2 = dot3(x, x);
-            const float M = __builtin_amdgcn_sqrtf(A_ * A_ + B_ * B_);
-            const float K = 0.5f * (w2 + rho2 - tol * tol) - (3e-4f * rho2 + 4e-6f * (w2 + rho2 + tol * tol));
-            if (n > 0 && L2 >= 1e-6f && M > 1e-30f) {
-                const float c = K * __builtin_amdgcn_rcpf(M);
-                if (c > 1.0005f) {
-                    cnt = 0;                                   // no rotation comes within tol of the centre
-                } else if (c > -0.9995f) {
-                    const float alpha = acos_approx(fminf(c, 1.f)) + 8e-4f;        // acos / atan2 errors, rcp, table angles
-                    const float phi = atan2_approx(B_, A_);
-                    const float k = (float)n * 0.159154943f;                       // n / 2 pi
-                    const float ic = phi * k, hw = fmaf(alpha, k, 1.0f);
-                    const int i_lo = (int)floorf(ic - hw), i_hi = (int)ceilf(ic + hw);
-                    if (i_hi - i_lo + 1 < n) {
-                        cnt = i_hi - i_lo + 1;
-                        lo = i_lo % n;
-                        lo = lo < 0 ? lo + n : lo;
-                    }
-                }
-            }
-        }
-        const int p1 = max(0, lo + cnt - n);     // candidates that wrap past n - 1 come first in index order: 0 .. p1 - 1
-        for (int kk = 0; kk < cnt; ++kk) {
-            const int i = kk < p1 ? kk : lo + (kk - p1);
-            const float2 cs = in_lds ? ltab[tbase + i] : rot_cs(i, n);
-            const f3 offset = add3(scl3(x, cs.x), scl3(y, cs.y));
-            const f3 pc = add3(cc, offset);
-            if (len3(sub3(pc, gt)) > tol) continue;                                   // :101
-            const f3 g = div3(sub3(pc, cr), res);
-            if (g.x < 0.f || g.y < 0.f || g.z < 0.f || g.x >= bx || g.y >= by || g.z >= bz) continue;  // :103-107
-            found = neg3(offset);                                                      // :108
-            break;
-        }
-        finish(idx, found);
-    };
-    // A wave takes BV_U x 64 consecutive pairs per trip and has all their loads in flight before it looks at any of them
-    // (one pair per lane per trip was two dependent round trips to memory per pair with nothing else to do: 27 us for 9 MB).
-    constexpr int BV_U = 4;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x * BV_U;
-    for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63)) * BV_U;; base += stride) {
-        const bool more = base < n_ppfs;   // wave-uniform
-        if (more) {
-            float2 o_[BV_U];
-            int2 ij_[BV_U];
-            f3 pa_[BV_U], pb_[BV_U];
-#pragma unroll
-            for (int u = 0; u < BV_U; ++u) {
-                const int64_t i = base + u * 64 + lane;
-                const int64_t c = i < n_ppfs ? i : n_ppfs - 1;
-                o_[u] = reinterpret_cast<const float2*>(outputs)[c];
-                ij_[u] = load_ij(c);
-                if (idx32_out && i < n_ppfs) reinterpret_cast<int2*>(idx32_out)[i] = ij_[u];
-            }
-#pragma unroll
-            for (int u = 0; u < BV_U; ++u) { pa_[u] = ld3(points, ij_[u].x); pb_[u] = ld3(points, ij_[u].y); }
-#pragma unroll
-            for (int u = 0; u < BV_U; ++u) {
-                const int64_t idx = base + u * 64 + lane;
-                bool pass = false;
-                if (idx < n_ppfs) {
-                    const float2 o = o_[u];
-                    const int2 ij = ij_[u];
-                    const f3 pa = pa_[u], pb = pb_[u];
-                    const f3 dd = sub3(pa, pb);
-                    const float L2 = dot3(dd, dd);
-                    if (L2 >= 1e-13f) {
-                        // approximate arithmetic (v_sqrt / v_rcp, no exact divisions) and a slack far above its error: a pair
-                        // that fails here cannot pass :101 for any rotation; the others get the reference's exact
-                        // arithmetic in stage 2
-                        const float L = __builtin_amdgcn_sqrtf(L2);
-                        const float inv = __builtin_amdgcn_rcpf(L + 1e-7f);
-                        const float proj_len = o.x, odist = o.y;
-                        const f3 u = scl3(dd, inv);
-                        const f3 cc = sub3(pa, scl3(u, proj_len));
-                        // distance from gt to the vote CIRCLE (centre cc, axis u, radius |nu|): h along the axis, r in the
-                        // circle's plane; every sample lies on that circle (to 1e-6), so none can be nearer than this
-                        const f3 w = sub3(gt, cc);
-                        const float h = dot3(w, u), w2 = dot3(w, w), rho = fabsf(odist);
-                        const float r = __builtin_amdgcn_sqrtf(fmaxf(w2 - h * h, 0.f));
-                        const float dist = __builtin_amdgcn_sqrtf((r - rho) * (r - rho) + h * h);
-                        const float mag = __builtin_amdgcn_sqrtf(w2) + rho + tol;
-                        // ab = (a-b)/(L + 1e-7) is shorter than a unit vector by 1e-7/L: the samples sit on an ellipse inside
-                        // that circle and cc is off the ideal axis point, both by at most (|nu| + |mu|) * 1e-7 / L
-                        const float squash = (rho + fabsf(proj_len)) * 2e-7f * inv;
-                        pass = (odist * rinv_res * 6.2831855f >= 0.9999f) && !(dist > tol + 2e-4f * mag + 1e-6f + squash);
-                        if (!pass) finish(idx, f3{0.f, 0.f, 0.f});
-                    } else {   // (nearly) coincident points: the exact test decides what is degenerate
-                        f3 a, ab, xd;
-                        if (pair_frame(points, ij.x, ij.y, a, ab, xd)) {
-                            const float proj_len = o.x, odist = o.y;
-                            const f3 cc = sub3(a, scl3(ab, proj_len));
-                            const f3 x = scl3(xd, odist);
-                            const int n = min((int)((double)(odist / res) * (2 * CPPF_PI)), n_rots);
-                            const float dc = len3(sub3(cc, gt)), rho = len3(x);
-                            pass = n > 0 && !(fabsf(dc - rho) > tol + 1e-5f * (dc + rho + tol) + 1e-7f);
-                            if (!pass) finish(idx, f3{0.f, 0.f, 0.f});
-                        } else if (mask) {   // degenerate pair: out_offsets keeps the caller's value (:87 returns early)
-                            const float* oo = out_offsets ? out_offsets + 3 * idx : nullptr;
-                            const bool nz = oo ? ((oo[0] != 0.f) || (oo[1] != 0.f) || (oo[2] != 0.f)) : false;   // mask-only: as if zero-initialised (:220)
-                            mask[idx] = nz;
-                            if (chunk_counts) count_survivor(idx, nz);
-                        }
-                    }
-                }
-                const unsigned long long m = __ballot(pass);
-                if (pass)
-                    q[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] = (uint32_t)idx;
-                qn += __popcll(m);
-                while (qn >= 64) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    const uint32_t pidx = q[qn - 64 + lane];
-                    qn -= 64;
-                    rotations((int64_t)pidx);
-                }
-            }
-        }
-        if (!more) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (qn > 0) {
-                const uint32_t pidx = lane < qn ? q[lane] : 0u;
-                if (lane < qn) rotations((int64_t)pidx);
-            }
-            break;
-        }
-    }
-}
-
-static int backvote_impl(const float* points, const float* outputs, float* out_offsets,
-                         const int32_t* point_idxs, const float* corner, float res, int64_t n_ppfs, int n_rots,
-                         int gx, int gy, int gz, const float* gt_center, float tol, uint8_t* mask, void* stream,
-                         const int32_t* shape_dev, const void* vote_workspace = nullptr, int32_t* chunk_counts = nullptr,
-                         const long long* idx64 = nullptr, int32_t* idx32_out = nullptr)
-{
-    if (n_rots < 1 || n_rots > CPPF_MAX_ROTS || n_ppfs < 0 || n_ppfs > 0xffffffffll) return CPPF_EINVAL;
-    if (n_ppfs == 0) return 0;
-    if (!points || !outputs || (!out_offsets && !mask) || (!point_idxs && !idx64) || !corner || !gt_center) return CPPF_EINVAL;
-    const int entries = tri(n_rots);
-    const size_t lds = (entries <= VOTE_TAB_LDS_MAX ? (size_t)entries * sizeof(float2) : 0) + 4 * 128 * sizeof(uint32_t);
-    int64_t nb = (n_ppfs + 4 * 256 - 1) / (4 * 256);   // BV_U = 4 pairs per thread and trip
-    if (nb > 1024) nb = 1024;
-    hipLaunchKernelGGL(backvote_kernel, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, points,
-                       outputs, out_offsets, point_idxs, corner, res, n_ppfs, n_rots, gx, gy, gz, gt_center, tol,
-                       mask, shape_dev, static_cast<const unsigned long long*>(vote_workspace), chunk_counts, idx64, idx32_out);
-    CPPF_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int cppf_backvote(const float* points, const float* outputs, float* out_offsets,
-                             const int32_t* point_idxs, const float* corner, float res, int64_t n_ppfs, int n_rots,
-                             int gx, int gy, int gz, const float* gt_center, float tol, uint8_t* mask, void* stream)
-{
-    return backvote_impl(points, outputs, out_offsets, point_idxs, corner, res, n_ppfs, n_rots, gx, gy, gz, gt_center, tol,
-                         mask, stream, nullptr);
-}
-
-extern "C" int cppf_backvote_ws(const float* points, const float* outputs, float* out_offsets,
-                                const int32_t* point_idxs, const float* corner, float res, int64_t n_ppfs, int n_rots,
-                                int gx, int gy, int gz, const int32_t* shape_dev, const float* gt_center, float tol,
-                                uint8_t* mask, const void* vote_workspace, void* stream)
-{
-    if (!shape_dev && (gx < 1 || gy < 1 || gz < 1)) return CPPF_EINVAL;
-    return backvote_impl(points, outputs, out_offsets, point_idxs, corner, res, n_ppfs, n_rots, shape_dev ? 1 : gx,
-                         shape_dev ? 1 : gy, shape_dev ? 1 : gz, gt_center, tol, mask, stream, shape_dev, vote_workspace);
-}
-
-extern "C" int cppf_backvote_count(const float* points, const float* outputs, const int32_t* point_idxs, const float* corner,
-                                   float res, int64_t n_ppfs, int n_rots, int gx, int gy, int gz, const int32_t* shape_dev,
-                                   const float* gt_center, float tol, uint8_t* mask, int32_t* chunk_counts,
-                                   const void* vote_workspace, void* stream)
-{
-    if (!mask || !chunk_counts) return CPPF_EINVAL;
-    if (!shape_dev && (gx < 1 || gy < 1 || gz < 1)) return CPPF_EINVAL;
-    return backvote_impl(points, outputs, nullptr, point_idxs, corner, res, n_ppfs, n_rots, shape_dev ? 1 : gx,
-                         shape_dev ? 1 : gy, shape_dev ? 1 : gz, gt_center, tol, mask, stream, shape_dev, vote_workspace,
-                         chunk_counts);
-}
-
-extern "C" int cppf_backvote_count64(const float* points, const float* outputs, const long long* point_idxs64,
-                                     int32_t* idx32_out, const float* corner, float res, int64_t n_ppfs, int n_rots, int gx,
-                                     int gy, int gz, const int32_t* shape_dev, const float* gt_center, float tol, uint8_t* mask,
-                                     int32_t* chunk_counts, const void* vote_workspace, void* stream)
-{
-    if (!mask || !chunk_counts || !point_idxs64) return CPPF_EINVAL;
-    if (!shape_dev && (gx < 1 || gy < 1 || gz < 1)) return CPPF_EINVAL;
-    return backvote_impl(points, outputs, nullptr, nullptr, corner, res, n_ppfs, n_rots, shape_dev ? 1 : gx,
-                         shape_dev ? 1 : gy, shape_dev ? 1 : gz, gt_center, tol, mask, stream, shape_dev, vote_workspace,
-                         chunk_counts, point_idxs64, idx32_out);
-}
-
-extern "C" int cppf_backvote_dyn(const float* points, const float* outputs, float* out_offsets,
-                                 const int32_t* point_idxs, const float* corner, float res, int64_t n_ppfs, int n_rots,
-                                 const int32_t* shape_dev, const float* gt_center, float tol, uint8_t* mask, void* stream)
-{
-    if (!shape_dev) return CPPF_EINVAL;
-    return backvote_impl(points, outputs, out_offsets, point_idxs, corner, res, n_ppfs, n_rots, 1, 1, 1, gt_center, tol,
-                         mask, stream, shape_dev);
-}
-
-// ----------------------------------------------------------------------------- compaction
-// surv = nonzero(mask) in increasing order (point_idxs[mask], nocs/inference.py:231).
-// Three small kernels: per-block counts, one-block scan of the counts, scatter.
-#define CMP_BLOCK 1024
-__global__ __launch_bounds__(CMP_BLOCK) void compact_count_kernel(const uint8_t* __restrict__ mask, int64_t n,
-                                                                   int32_t* __restrict__ block_counts)
-{
-    __shared__ int wsum[CMP_BLOCK / 64];
-    const int64_t i = (int64_t)blockIdx.x * CMP_BLOCK + threadIdx.x;
-    const bool f = i < n && mask[i] != 0;
-    const unsigned long long b = __ballot(f);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(b);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int s = 0;
-        for (int w = 0; w < CMP_BLOCK / 64; ++w) s += wsum[w];
-        block_counts[blockIdx.x] = s;
-    }
-}
-
-__global__ __launch_bounds__(1024) void compact_scan_kernel(int32_t* __restrict__ block_counts, int64_t nblocks,
-                                                            int32_t* __restrict__ total)
-{
-    // exclusive scan in place, 1024 entries per sweep with a running carry
-    __shared__ int buf[1024];
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int64_t base = 0; base < nblocks; base += 1024) {
-        const int64_t i = base + threadIdx.x;
-        const int v = i < nblocks ? block_counts[i] : 0;
-        buf[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            int t = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
-            __syncthreads();
-            buf[threadIdx.x] += t;
-            __syncthreads();
-        }
-        const int incl = buf[threadIdx.x];
-        const int c = carry;
-        if (i < nblocks) block_counts[i] = c + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = c + incl;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *total = carry;
-}
-
-__global__ __launch_bounds__(CMP_BLOCK) void compact_scatter_kernel(const uint8_t* __restrict__ mask, int64_t n,
-                                                                     const int32_t* __restrict__ block_offs,
-                                                                     int32_t* __restrict__ surv)
-{
-    __shared__ int wsum[CMP_BLOCK / 64];
-    const int64_t i = (int64_t)blockIdx.x * CMP_BLOCK + threadIdx.x;
-    const bool f = i < n && mask[i] != 0;
-    const unsigned long long b = __ballot(f);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) wsum[w] = __popcll(b);
-    __syncthreads();
-    int woff = 0;
-    for (int k = 0; k < w; ++k) woff += wsum[k];
-    if (f) {
-        const int rank = __popcll(b & ((1ull << lane) - 1ull));
-        surv[block_offs[blockIdx.x] + woff + rank] = (int32_t)i;
-    }
-}
-
-// cppf_compact_scatter: the scatter step alone, for chunk counts that already exist (cppf_backvote_count): every block sums
-// the counts of the chunks before its own (<= CMP_SELF_MAX of them, from L2) instead of waiting for a scan kernel.
-#define CMP_SELF_MAX 8192
-static_assert(CMP_BLOCK == 1024, "backvote_kernel counts survivors per chunk of 1 << 10 pairs");
-__global__ __launch_bounds__(CMP_BLOCK) void compact_scatter_self_kernel(const uint8_t* __restrict__ mask, int64_t n,
-                                                                          const int32_t* __restrict__ chunk_counts,
-                                                                          int32_t* __restrict__ surv, int32_t* __restrict__ total)
-{
-    __shared__ int wsum[CMP_BLOCK / 64];
-    __shared__ int wpre[CMP_BLOCK / 64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int before = 0;
-    for (int k = threadIdx.x; k < (int)blockIdx.x; k += CMP_BLOCK) before += chunk_counts[k];
-    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
-    const int64_t i = (int64_t)blockIdx.x * CMP_BLOCK + threadIdx.x;
-    const bool f = i < n && mask[i] != 0;
-    const unsigned long long b = __ballot(f);
-    if (lane == 0) { wsum[w] = __popcll(b); wpre[w] = before; }
-    __syncthreads();
-    int woff = 0, base = 0;
-    for (int k = 0; k < CMP_BLOCK / 64; ++k) { base += wpre[k]; woff += k < w ? wsum[k] : 0; }
-    if (f) surv[base + woff + __popcll(b & ((1ull << lane) - 1ull))] = (int32_t)i;
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-        int own = 0;
-        for (int k = 0; k < CMP_BLOCK / 64; ++k) own += wsum[k];
-        *total = base + own;
-    }
-}
-
-extern "C" int cppf_compact_scatter(const uint8_t* mask, int64_t n, const int32_t* chunk_counts, int32_t* surv,
-                                    int32_t* count, void* stream)
-{
-    if (n < 1 || !mask || !surv || !count || !chunk_counts) return CPPF_EINVAL;
-    const int64_t nb = (n + CMP_BLOCK - 1) / CMP_BLOCK;
-    if (nb > CMP_SELF_MAX) return CPPF_EUNSUPPORTED;   // use cppf_compact_mask
-    hipLaunchKernelGGL(compact_scatter_self_kernel, dim3((unsigned)nb), dim3(CMP_BLOCK), 0, (hipStream_t)stream, mask, n,
-                       chunk_counts, surv, count);
-    CPPF_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" size_t cppf_compact_workspace_bytes(int64_t n)
-{
-    if (n < 0) return 0;
-    return align_up((size_t)((n + CMP_BLOCK - 1) / CMP_BLOCK + 1) * sizeof(int32_t), 256);
-}
-
-extern "C" int cppf_compact_mask(const uint8_t* mask, int64_t n, int32_t* surv, int32_t* count, void* workspace,
-                                 size_t workspace_bytes, void* stream)
-{
-    if ((n > 0 && (!mask || !surv)) || !count || n < 0 || n > 0x7fffffffll) return CPPF_EINVAL;
-    if (!workspace || workspace_bytes < cppf_compact_workspace_bytes(n)) return CPPF_EWORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    int32_t* bc = static_cast<int32_t*>(workspace);
-    const int64_t nb = (n + CMP_BLOCK - 1) / CMP_BLOCK;
-    if (nb > 0) {
-        hipLaunchKernelGGL(compact_count_kernel, dim3((unsigned)nb), dim3(CMP_BLOCK), 0, st, mask, n, bc);
-        CPPF_CHECK_LAUNCH();
-    }
-    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, st, bc, nb, count);
-    CPPF_CHECK_LAUNCH();
-    if (nb > 0) {
-        hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)nb), dim3(CMP_BLOCK), 0, st, mask, n, bc, surv);
-        CPPF_CHECK_LAUNCH();
-    }
-    return 0;
-}
-
-// ----------------------------------------------------------------------------- orientation vote
-// Reference: CUDA rot_voting, models/voting.py:119-147.  A block takes ROT_PPB pairs: their frames
-// are computed once into LDS, then the (pair, rotation) items are spread over the lanes so that the
-// 12-byte candidates of consecutive lanes are consecutive in memory.
-#define ROT_PPB 32
-struct RotFrame { f3 x, y, base; float t; int ok; int pad; };  // 48 B: keeps the dynamic LDS base 16-B aligned
-
-__device__ __forceinline__ RotFrame rot_frame(const float* __restrict__ points, int ia, int ib, float rot)
-{
-    RotFrame fr;
-    f3 a, ab, xd;
-    fr.pad = 0;   // 1 = slot without a pair (an `order` entry beyond the survivor list): contributes nothing
-    fr.ok = pair_frame(points, ia, ib, a, ab, xd);
-    if (fr.ok) {
-        fr.x = xd;
-        fr.y = cross3(xd, ab);                 // :135
-        fr.t = det_tanf(rot);
-        fr.base = fr.t > 0.f ? ab : neg3(ab);  // :142
-    }
-    return fr;
-}
-__device__ __forceinline__ f3 rot_candidate(const RotFrame& fr, float2 cs)
-{
-    const f3 offset = add3(scl3(fr.x, cs.x), scl3(fr.y, cs.y));                  // :141
-    f3 up = add3(scl3(offset, fr.t), fr.base);                                     // :142
-    return div3(up, (float)((double)len3(up) + 1e-7));                            // :143
-}
-
-__global__ __launch_bounds__(256) void rot_voting_kernel(const float* __restrict__ points,
-                                                         const float* __restrict__ preds_rot,
-                                                         float* __restrict__ outputs_up,
-                                                         const int32_t* __restrict__ point_idxs, int64_t n_ppfs,
-                                                         int n_rots)
-{
-    __shared__ RotFrame frames[ROT_PPB];
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float2* row = reinterpret_cast<float2*>(lds);  // (cos,sin) of the n_rots rotations
-    const int64_t p0 = (int64_t)blockIdx.x * ROT_PPB;
-    const int np = (int)min((int64_t)ROT_PPB, n_ppfs - p0);
-    for (int i = threadIdx.x; i < n_rots; i += blockDim.x) row[i] = rot_cs(i, n_rots);
-    if ((int)threadIdx.x < np) {
-        const int2 ij = reinterpret_cast<const int2*>(point_idxs)[p0 + threadIdx.x];
-        frames[threadIdx.x] = rot_frame(points, ij.x, ij.y, preds_rot[p0 + threadIdx.x]);
-    }
-    __syncthreads();
-    const int items = np * n_rots;
-    float* out = outputs_up + p0 * n_rots * 3;
-    for (int k = threadIdx.x; k < items; k += blockDim.x) {
-        const int pl = k / n_rots, i = k - pl * n_rots;
-        if (!frames[pl].ok) continue;  // caller's zeros stay (:131)
-        const f3 up = rot_candidate(frames[pl], row[i]);
-        out[3 * k] = up.x; out[3 * k + 1] = up.y; out[3 * k + 2] = up.z;
-    }
-}
-
-extern "C" int cppf_rot_voting(const float* points, const float* preds_rot, float* outputs_up,
-                               const int32_t* point_idxs, int64_t n_ppfs, int n_rots, void* stream)
-{
-    if (n_rots < 1 || n_rots > 4096 || n_ppfs < 0) return CPPF_EINVAL;
-    if (n_ppfs == 0) return 0;
-    if (!points || !preds_rot || !outputs_up || !point_idxs) return CPPF_EINVAL;
-    const int64_t nb = (n_ppfs + ROT_PPB - 1) / ROT_PPB;
-    hipLaunchKernelGGL(rot_voting_kernel, dim3((unsigned)nb), dim3(256), (size_t)n_rots * sizeof(float2),
-                       (hipStream_t)stream, points, preds_rot, outputs_up, point_idxs, n_ppfs, n_rots);
-    CPPF_CHECK_LAUNCH();
-    return 0;
-}
-
-// Fused rot_voting + sphere count (nocs/inference.py:265-284): candidates of SPH_PPB pairs go to
-// LDS, then every lane owns sphere bins and sweeps the block's candidates (broadcast LDS reads),
-// cos = fma(c.z,s.z, fma(c.y,s.y, c.x*s.x)) > thr.  Integer atomics: deterministic counts.
-#define SPH_PPB 16
-#define SPH_THREADS 512
-__global__ __launch_bounds__(SPH_THREADS) void rot_sphere_kernel(const float* __restrict__ points,
-                                                                 const float* __restrict__ preds_rot, int rot_stride,
-                                                                 const int32_t* __restrict__ point_idxs,
-                                                                 const int32_t* __restrict__ sel,
-                                                                 const int32_t* __restrict__ n_sel_dev,
-                                                                 int64_t n_sel_host, int64_t max_pairs, int n_rots,
-                                                                 const float* __restrict__ sphere, int n_sphere,
-                                                                 float thr, int32_t* __restrict__ counts,
-                                                                 int rot_dir_step, int counts_dir_step,
-                                                                 const int32_t* __restrict__ order, int64_t n_order)
-{
-    preds_rot += (int64_t)blockIdx.y * rot_dir_step;
-    counts += (int64_t)blockIdx.y * counts_dir_step;
-    __shared__ RotFrame frames[SPH_PPB];
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float4* cand = reinterpret_cast<float4*>(lds);                       // [SPH_PPB*n_rots]
-    float2* row = reinterpret_cast<float2*>(lds + 4 * SPH_PPB * n_rots);  // [n_rots]
-    const int64_t n_avail = n_sel_dev ? (int64_t)*n_sel_dev : n_sel_host;   // entries of sel (or pairs, sel == null)
-    int64_t n_sel = order ? n_order : n_avail;                               // slots of this count
-    if (n_sel > max_pairs) n_sel = max_pairs;
-    const int64_t k0 = (int64_t)blockIdx.x * SPH_PPB;
-    if (k0 >= n_sel) return;
-    const int np = (int)min((int64_t)SPH_PPB, n_sel - k0);
-    for (int i = threadIdx.x; i < n_rots; i += SPH_THREADS) row[i] = rot_cs(i, n_rots);
-    if ((int)threadIdx.x < np) {
-        const int64_t sl = order ? (int64_t)order[k0 + threadIdx.x] : k0 + threadIdx.x;   // position in the survivor list
-        if (sl >= 0 && sl < n_avail) {
-            const int p = sel ? sel[sl] : (int)sl;
-            const int2 ij = reinterpret_cast<const int2*>(point_idxs)[p];
-            frames[threadIdx.x] = rot_frame(points, ij.x, ij.y, preds_rot[(int64_t)p * rot_stride]);
-        } else {
-            frames[threadIdx.x].ok = 0;
-            frames[threadIdx.x].pad = 1;
-        }
-    }
-    __syncthreads();
-    const int items = np * n_rots;
-    for (int k = threadIdx.x; k < items; k += SPH_THREADS) {
-        const int pl = k / n_rots, i = k - pl * n_rots;
-        f3 up = {0.f, 0.f, 0.f};  // degenerate pair: the reference leaves zeros, which still count if thr < 0
-        if (frames[pl].ok) up = rot_candidate(frames[pl], row[i]);
-        cand[k] = make_float4(up.x, up.y, up.z, frames[pl].pad ? 1.f : 0.f);
-    }
-    __syncthreads();
-    for (int j = threadIdx.x; j < n_sphere; j += SPH_THREADS) {
-        const float sx = sphere[3 * j], sy = sphere[3 * j + 1], sz = sphere[3 * j + 2];
-        int cnt = 0;
-        for (int k = 0; k < items; ++k) {
-            const float4 c = cand[k];
-            const float d = fmaf(c.z, sz, fmaf(c.y, sy, c.x * sx));
-            cnt += (d > thr) && c.w == 0.f;
-        }
-        if (cnt) atomicAdd(&counts[j], cnt);
-    }
-}
-
-// Same count when the sphere bins are unit vectors sorted by y (the Fibonacci sphere of
-// utils/util.py:102-118 is): a candidate c can only match bins with |s.y - c.y| < sqrt(2 - 2 thr), so
-// each lane takes candidates and tests only that band of bins (~14 of 480 at 1.5 deg) instead of every
-// lane sweeping every candidate.  Same dot product, same threshold test -> identical counts.
-#define SPHB_PPB 8   // most pairs per group; few survivors are taken 2 at a time, see the kernel
-__global__ __launch_bounds__(256) void rot_sphere_band_kernel(const float* __restrict__ points,
-                                                              const float* __restrict__ preds_rot, int rot_stride,
-                                                              const int32_t* __restrict__ point_idxs,
-                                                              const int32_t* __restrict__ sel,
-                                                              const int32_t* __restrict__ n_sel_dev, int64_t n_sel_host,
-                                                              int64_t max_pairs, int n_rots,
-                                                              const float* __restrict__ sphere, int n_sphere, float thr,
-                                                              int32_t* __restrict__ counts, int descending,
-                                                              int rot_dir_step, int counts_dir_step,
-                                                              const int32_t* __restrict__ order, int64_t n_order)
-{
-    preds_rot += (int64_t)blockIdx.y * rot_dir_step;   // cppf_rot_sphere_count_dirs: direction blockIdx.y of the launch
-    counts += (int64_t)blockIdx.y * counts_dir_step;
-    __shared__ RotFrame frames[SPHB_PPB];
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* sph = lds;                                             // [n_sphere][3]
-    int* cnt = reinterpret_cast<int*>(lds + 3 * n_sphere);        // [n_sphere]
-    float2* row = reinterpret_cast<float2*>(cnt + n_sphere);      // [n_rots]
-    const int64_t n_avail = n_sel_dev ? (int64_t)*n_sel_dev : n_sel_host;   // entries of sel (or pairs, sel == null)
-    int64_t n_sel = order ? n_order : n_avail;                               // slots of this count
-    if (n_sel > max_pairs) n_sel = max_pairs;
-    const int ppb = n_sel > 4096 ? SPHB_PPB : 2;   // (uniform over the launch)
-    if ((int64_t)blockIdx.x * ppb >= n_sel) return;
-    for (int i = threadIdx.x; i < 3 * n_sphere; i += 256) sph[i] = sphere[i];
-    for (int i = threadIdx.x; i < n_sphere; i += 256) cnt[i] = 0;
-    for (int i = threadIdx.x; i < n_rots; i += 256) row[i] = rot_cs(i, n_rots);
-    float band = 2.f - 2.f * thr;
-    band = sqrtf(fminf(fmaxf(band, 0.f), 4.f) + 1e-5f) + 1e-4f;
-    // A block takes groups of ppb pairs, blockIdx, + gridDim, ...  A group's time is a chain (frame with an fp64 tangent ->
-    // candidate -> binary search -> ~14 dependent band steps) that only more groups in flight hide, so few survivors go 2 to a
-    // group (the ~2 000 of the benchmark object: 15.7 -> 12.2 us; 500: 13.4 -> 8.5), many go 8 to a group for throughput, and the
-    // grid is bounded so that the block's set-up (bins, rotation row) is paid once when it has several groups.
-    for (int64_t k0 = (int64_t)blockIdx.x * ppb; k0 < n_sel; k0 += (int64_t)gridDim.x * ppb) {
-    const int np = (int)min((int64_t)ppb, n_sel - k0);
-    __syncthreads();   // (previous group's frames are no longer read; first trip: the tables above are complete)
-    if ((int)threadIdx.x < np) {
-        const int64_t sl = order ? (int64_t)order[k0 + threadIdx.x] : k0 + threadIdx.x;   // position in the survivor list
-        if (sl >= 0 && sl < n_avail) {
-            const int p = sel ? sel[sl] : (int)sl;
-            const int2 ij = reinterpret_cast<const int2*>(point_idxs)[p];
-            frames[threadIdx.x] = rot_frame(points, ij.x, ij.y, preds_rot[(int64_t)p * rot_stride]);
-        } else {
-            frames[threadIdx.x].ok = 0;
-            frames[threadIdx.x].pad = 1;
-        }
-    }
-    __syncthreads();
-    const int items = np * n_rots;
-    for (int k = threadIdx.x; k < items; k += 256) {
-        const int pl = k / n_rots, i = k - pl * n_rots;
-        if (frames[pl].pad) continue;
-        f3 up = {0.f, 0.f, 0.f};
-        if (frames[pl].ok) up = rot_candidate(frames[pl], row[i]);
-        // bins with y in [up.y - band, up.y + band]: binary searches on the sorted y column
-        const float ylo = up.y - band, yhi = up.y + band;
-        int lo = 0, hi = n_sphere;  // first bin inside the band
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            const float y = sph[3 * mid + 1];
-            const bool before = descending ? (y > yhi) : (y < ylo);
-            if (before) lo = mid + 1; else hi = mid;
-        }
-        for (int j = lo; j < n_sphere; ++j) {
-            const float sy = sph[3 * j + 1];
-            if (descending ? (sy < ylo) : (sy > yhi)) break;
-            const float d = fmaf(up.z, sph[3 * j + 2], fmaf(up.y, sy, up.x * sph[3 * j]));
-            if (d > thr) atomicAdd(&cnt[j], 1);
-        }
-    }
-    }
-    __syncthreads();
-    for (int j = threadIdx.x; j < n_sphere; j += 256)
-        if (cnt[j]) atomicAdd(&counts[j], cnt[j]);
-}
-
-static int rot_sphere_impl(const float* points, const float* preds_rot, int rot_stride, int rot_dir_step, int n_dirs,
-                           const int32_t* point_idxs, const int32_t* sel, const int32_t* n_sel_dev,
-                           int64_t n_sel_host, int64_t max_pairs, int n_rots, const float* sphere,
-                           int n_sphere, float thr, int sphere_sorted_by_y, int32_t* counts, int counts_dir_step, void* stream,
-                           const int32_t* order = nullptr, int64_t n_order = 0)
-{
-    if (!points || !preds_rot || !point_idxs || !sphere || !counts) return CPPF_EINVAL;
-    if (n_order < 0) return CPPF_EINVAL;
-    if (!order) n_order = 0;
-    if (n_rots < 1 || n_rots > 512 || n_sphere < 1 || max_pairs < 0 || n_sel_host < 0 || rot_stride < 1 || n_dirs < 1 ||
-        n_dirs > 16)
-        return CPPF_EINVAL;
-    const int64_t slots = order ? n_order : n_sel_host;      // (with an order the slots are the order's)
-    int64_t bound = slots < max_pairs ? slots : max_pairs;
-    if (bound == 0) return 0;
-    if (sphere_sorted_by_y != 0 && n_sphere <= 4096) {
-        int64_t nb = (bound + 1) / 2;
-        if (nb > 2048) nb = 2048;
-        const size_t lds = (size_t)(4 * n_sphere + 2 * n_rots) * sizeof(float);
-        hipLaunchKernelGGL(rot_sphere_band_kernel, dim3((unsigned)nb, (unsigned)n_dirs), dim3(256), lds, (hipStream_t)stream, points,
-                           preds_rot, rot_stride, point_idxs, sel, n_sel_dev, n_sel_host, max_pairs, n_rots, sphere,
-                           n_sphere, thr, counts, sphere_sorted_by_y > 0 ? 1 : 0, rot_dir_step, counts_dir_step, order, n_order);
-        CPPF_CHECK_LAUNCH();
-        return 0;
-    }
-    const int64_t nb = (bound + SPH_PPB - 1) / SPH_PPB;
-    const size_t lds = (size_t)(4 * SPH_PPB * n_rots + 2 * n_rots) * sizeof(float);
-    hipLaunchKernelGGL(rot_sphere_kernel, dim3((unsigned)nb, (unsigned)n_dirs), dim3(SPH_THREADS), lds, (hipStream_t)stream, points,
-                       preds_rot, rot_stride, point_idxs, sel, n_sel_dev, n_sel_host, max_pairs, n_rots, sphere,
-                       n_sphere, thr, counts, rot_dir_step, counts_dir_step, order, n_order);
-    CPPF_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int cppf_rot_sphere_count(const float* points, const float* preds_rot, int rot_stride,
-                                     const int32_t* point_idxs, const int32_t* sel, const int32_t* n_sel_dev,
-                                     int64_t n_sel_host, int64_t max_pairs, int n_rots, const float* sphere,
-                                     int n_sphere, float thr, int sphere_sorted_by_y, int32_t* counts, void* stream)
-{
-    return rot_sphere_impl(points, preds_rot, rot_stride, 0, 1, point_idxs, sel, n_sel_dev, n_sel_host, max_pairs, n_rots,
-                           sphere, n_sphere, thr, sphere_sorted_by_y, counts, 0, stream);
-}
-
-extern "C" int cppf_rot_sphere_count_dirs(const float* points, const float* preds_rot, int rot_stride, int rot_dir_step,
-                                          int n_dirs, const int32_t* point_idxs, const int32_t* sel,
-                                          const int32_t* n_sel_dev, int64_t n_sel_host, int64_t max_pairs, int n_rots,
-                                          const float* sphere, int n_sphere, float thr, int sphere_sorted_by_y,
-                                          int32_t* counts, int counts_dir_step, void* stream)
-{
-    if (n_dirs > 1 && (rot_dir_step < 1 || counts_dir_step < n_sphere)) return CPPF_EINVAL;
-    return rot_sphere_impl(points, preds_rot, rot_stride, rot_dir_step, n_dirs, point_idxs, sel, n_sel_dev, n_sel_host,
-                           max_pairs, n_rots, sphere, n_sphere, thr, sphere_sorted_by_y, counts, counts_dir_step, stream);
-}
-
-extern "C" int cppf_rot_sphere_count_dirs_order(const float* points, const float* preds_rot, int rot_stride, int rot_dir_step,
-                                                int n_dirs, const int32_t* point_idxs, const int32_t* sel,
-                                                const int32_t* n_sel_dev, int64_t n_sel_host, const int32_t* order,
-                                                int64_t n_order, int64_t max_pairs, int n_rots, const float* sphere,
-                                                int n_sphere, float thr, int sphere_sorted_by_y, int32_t* counts,
-                                                int counts_dir_step, void* stream)
-{
-    if (n_dirs > 1 && (rot_dir_step < 1 || counts_dir_step < n_sphere)) return CPPF_EINVAL;
-    if (!order) return CPPF_EINVAL;
-    return rot_sphere_impl(points, preds_rot, rot_stride, rot_dir_step, n_dirs, point_idxs, sel, n_sel_dev, n_sel_host,
-                           max_pairs, n_rots, sphere, n_sphere, thr, sphere_sorted_by_y, counts, counts_dir_step, stream,
-                           order, n_order);
-}
-
-// ----------------------------------------------------------------------------- pose-tail reductions
-#define RED_BLOCKS 256
-#define RED_THREADS 256
-extern "C" size_t cppf_reduce_workspace_bytes(void) { return (size_t)RED_BLOCKS * 4 * sizeof(double); }
-
-__device__ __forceinline__ double block_sum(double v, double* sh)
-{
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    double s = 0.0;
-    for (int w = 0; w < RED_THREADS / 64; ++w) s += sh[w];
-    return s;
-}
-
-// nocs/inference.py:287-301
-__global__ __launch_bounds__(RED_THREADS) void axis_sign_kernel(const float* __restrict__ pc,
-                                                                const float* __restrict__ nrm,
-                                                                const int32_t* __restrict__ point_idxs,
-                                                                const int32_t* __restrict__ sel,
-                                                                const int32_t* __restrict__ n_sel_dev, int64_t n_sel_host,
-                                                                const float* __restrict__ aux, int aux_stride,
-                                                                const double* __restrict__ best_dir,
-                                                                double* __restrict__ partial)
-{
-    __shared__ double sh[RED_THREADS / 64];
-    const int64_t n_sel = n_sel_dev ? (int64_t)*n_sel_dev : n_sel_host;
-    const double bx = best_dir[0], by = best_dir[1], bz = best_dir[2];
-    double up = 0.0, down = 0.0;
-    for (int64_t k = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x; k < n_sel; k += (int64_t)RED_BLOCKS * RED_THREADS) {
-        const int p = sel ? sel[k] : (int)k;
-        const int2 ij = reinterpret_cast<const int2*>(point_idxs)[p];
-        const f3 ab = sub3(ld3(pc, ij.x), ld3(pc, ij.y));
-        const float distsq = (ab.x * ab.x + ab.y * ab.y) + ab.z * ab.z;
-        const float den = sqrtf(distsq) + 1e-7f;
-        const f3 abn = {ab.x / den, ab.y / den, ab.z / den};
-        f3 n = ld3(nrm, ij.x);
-        const float d = (n.x * abn.x + n.y * abn.y) + n.z * abn.z;
-        if (d < 0.f) n = neg3(n);
-        const double proj = ((double)n.x * bx + (double)n.y * by) + (double)n.z * bz;
-        const double t = proj > 0.0 ? 1.0 : 0.0;
-        const double x = (double)aux[(int64_t)p * aux_stride];
-        const double sp = (x > 0.0 ? x : 0.0) + log1p(exp(-fabs(x)));
-        up += sp - x * t;
-        down += sp - x * (1.0 - t);
-    }
-    const double su = block_sum(up, sh);
-    const double sd = block_sum(down, sh);
-    if (threadIdx.x == 0) {
-        partial[4 * blockIdx.x] = su;
-        partial[4 * blockIdx.x + 1] = sd;
-    }
-}
-
-// nocs/inference.py:335 (sums; the caller finishes exp(mean)*scale_mean*2)
-__global__ __launch_bounds__(RED_THREADS) void scale_sum_kernel(const float* __restrict__ scale_logits, int stride,
-                                                                const int32_t* __restrict__ sel,
-                                                                const int32_t* __restrict__ n_sel_dev, int64_t n_sel_host,
-                                                                double* __restrict__ partial)
-{
-    __shared__ double sh[RED_THREADS / 64];
-    const int64_t n_sel = n_sel_dev ? (int64_t)*n_sel_dev : n_sel_host;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int64_t k = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x; k < n_sel; k += (int64_t)RED_BLOCKS * RED_THREADS) {
-        const int64_t p = sel ? sel[k] : k;
-        const float* s = scale_logits + p * stride;
-        s0 += (double)s[0]; s1 += (double)s[1]; s2 += (double)s[2];
-    }
-    const double a = block_sum(s0, sh), b = block_sum(s1, sh), c = block_sum(s2, sh);
-    if (threadIdx.x == 0) {
-        partial[4 * blockIdx.x] = a;
-        partial[4 * blockIdx.x + 1] = b;
-        partial[4 * blockIdx.x + 2] = c;
-    }
-}
-
-__global__ void reduce_final_kernel(const double* __restrict__ partial, int ncomp, const int32_t* n_sel_dev,
-                                    int64_t n_sel_host, double* __restrict__ out)
-{
-    if (threadIdx.x < ncomp) {
-        double s = 0.0;
-        for (int b = 0; b < RED_BLOCKS; ++b) s += partial[4 * b + threadIdx.x];
-        out[threadIdx.x] = s;
-    }
-    if (threadIdx.x == 0) out[ncomp] = (double)(n_sel_dev ? (int64_t)*n_sel_dev : n_sel_host);
-}
-
-extern "C" int cppf_axis_sign(const float* pc, const float* nrm, const int32_t* point_idxs, const int32_t* sel,
-                              const int32_t* n_sel_dev, int64_t n_sel_host, const float* aux, int aux_stride,
-                              const double* best_dir, double* out, void* workspace, size_t workspace_bytes,
-                              void* stream)
-{
-    if (!pc || !nrm || !point_idxs || !aux || !best_dir || !out || aux_stride < 1 || n_sel_host < 0) return CPPF_EINVAL;
-    if (!workspace || workspace_bytes < cppf_reduce_workspace_bytes()) return CPPF_EWORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    double* partial = static_cast<double*>(workspace);
-    hipLaunchKernelGGL(axis_sign_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, pc, nrm, point_idxs, sel,
-                       n_sel_dev, n_sel_host, aux, aux_stride, best_dir, partial);
-    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(64), 0, st, partial, 2, n_sel_dev, n_sel_host, out);
-    CPPF_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int cppf_scale_sum(const float* scale_logits, int stride, const int32_t* sel, const int32_t* n_sel_dev,
-                              int64_t n_sel_host, double* out, void* workspace, size_t workspace_bytes, void* stream)
-{
-    if (!scale_logits || !out || stride < 3 || n_sel_host < 0) return CPPF_EINVAL;
-    if (!workspace || workspace_bytes < cppf_reduce_workspace_bytes()) return CPPF_EWORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    double* partial = static_cast<double*>(workspace);
-    hipLaunchKernelGGL(scale_sum_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, scale_logits, stride, sel,
-                       n_sel_dev, n_sel_host, partial);
-    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(64), 0, st, partial, 3, n_sel_dev, n_sel_host, out);
-    CPPF_CHECK_LAUNCH();
-    return 0;
-}
-
-// One launch for what follows the orientation vote (nocs/inference.py:283-301,335): np.argmax of every direction's bin
-// counts and best_dir = sphere_pts[argmax] (every block, from L2: 480 integers per direction), the two BCE sums per
-// direction and the three scale sums over the surviving pairs, and -- in the block that draws the last ticket -- the sum
-// of the per-block partials.  Replaces counts_argmax_select + (axis_sign + reduce_final) per direction + scale_sum +
-// reduce_final: 4 n_dirs + 2 launches.  Per block and per pair the arithmetic is that of axis_sign_kernel and
-// scale_sum_kernel; the partials are summed 8 per lane and then across 32 lanes (fixed order).
-#define PS_MAX_DIRS 2
-#define PS_COMP 8   // doubles per block partial: {up, down} x 2 directions, 3 scale sums, unused
-struct PoseSumsArgs {
-    const float *pc, *nrm, *aux, *scale_logits;
-    const int32_t *point_idxs, *sel, *n_sel_dev, *counts;
-    const double* sphere64;
-    int64_t n_sel_host;
-    int aux_stride, scale_stride, n_dirs, n_sphere, counts_dir_step;
-    long long* best_idx;
-    double *best_dir, *sign, *scale_out, *partial;
-    unsigned* ticket;
-};
-__global__ __launch_bounds__(RED_THREADS) void pose_sums_kernel(PoseSumsArgs A)
-{
-    __shared__ double shc[RED_THREADS / 64][PS_COMP];
-    __shared__ unsigned long long best[PS_MAX_DIRS][RED_THREADS / 64];
-    __shared__ double bdir[PS_MAX_DIRS][3];
-    __shared__ unsigned drawn;
-    const int tid = threadIdx.x;
-    // A thread's first pair (with <= 65 536 survivors its only one) is fetched BEFORE the arg-max of the bin counts: three
-    // levels of dependent loads (sel -> pair -> points) that do not depend on best_dir and used to start after two barriers.
-    struct Item { f3 pa, pb, nn; float aux[PS_MAX_DIRS]; float sl[3]; };
-    auto load_item = [&](const int64_t k) -> Item {
-        Item it;
-        const int p = A.sel ? A.sel[k] : (int)k;
-        const int2 ij = reinterpret_cast<const int2*>(A.point_idxs)[p];
-        it.pa = ld3(A.pc, ij.x); it.pb = ld3(A.pc, ij.y); it.nn = ld3(A.nrm, ij.x);
-#pragma unroll
-        for (int j = 0; j < PS_MAX_DIRS; ++j) it.aux[j] = j < A.n_dirs ? A.aux[(int64_t)p * A.aux_stride + j] : 0.f;
-        it.sl[0] = it.sl[1] = it.sl[2] = 0.f;
-        if (A.scale_logits) {
-            const float* sl = A.scale_logits + (int64_t)p * A.scale_stride;
-            it.sl[0] = sl[0]; it.sl[1] = sl[1]; it.sl[2] = sl[2];
-        }
-        return it;
-    };
-    const int64_t n_sel = A.n_sel_dev ? (int64_t)*A.n_sel_dev : A.n_sel_host;
-    Item it = {};
-    if ((int64_t)blockIdx.x * RED_THREADS + tid < n_sel) it = load_item((int64_t)blockIdx.x * RED_THREADS + tid);
-    for (int j = 0; j < A.n_dirs; ++j) {   // key = count << 32 | ~index: the largest count at the lowest index (:283)
-        const int32_t* cj = A.counts + (int64_t)j * A.counts_dir_step;
-        unsigned long long k = 0ull;
-        for (int i = tid; i < A.n_sphere; i += RED_THREADS) {
-            const unsigned long long ki = ((unsigned long long)(uint32_t)cj[i] << 32) | (uint32_t)(~(uint32_t)i);
-            k = ki > k ? ki : k;
-        }
-        k = wave_max_u64(k);
-        if ((tid & 63) == 0) best[j][tid >> 6] = k;
-    }
-    __syncthreads();
-    if (tid < 3 * A.n_dirs) {
-        const int j = tid / 3, c = tid - 3 * j;
-        unsigned long long b = best[j][0];
-        for (int w = 1; w < RED_THREADS / 64; ++w) b = best[j][w] > b ? best[j][w] : b;
-        const int bi = (int)(~(uint32_t)(b & 0xffffffffull));
-        const double v = A.sphere64[3 * (size_t)bi + c];
-        bdir[j][c] = v;
-        if (blockIdx.x == 0) {
-            A.best_dir[3 * j + c] = v;
-            if (c == 0 && A.best_idx) A.best_idx[j] = bi;
-        }
-    }
-    __syncthreads();
-    double acc[PS_COMP] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int64_t k = (int64_t)blockIdx.x * RED_THREADS + tid; k < n_sel; k += (int64_t)RED_BLOCKS * RED_THREADS) {
-        if (k != (int64_t)blockIdx.x * RED_THREADS + tid) it = load_item(k);   // (the first one is already here)
-        const f3 ab = sub3(it.pa, it.pb);
-        const float distsq = (ab.x * ab.x + ab.y * ab.y) + ab.z * ab.z;
-        const float den = sqrtf(distsq) + 1e-7f;
-        const f3 abn = {ab.x / den, ab.y / den, ab.z / den};
-        f3 n = it.nn;
-        const float d = (n.x * abn.x + n.y * abn.y) + n.z * abn.z;
-        if (d < 0.f) n = neg3(n);
-#pragma unroll
-        for (int j = 0; j < PS_MAX_DIRS; ++j) {
-            if (j >= A.n_dirs) break;
-            const double proj = ((double)n.x * bdir[j][0] + (double)n.y * bdir[j][1]) + (double)n.z * bdir[j][2];
-            const double t = proj > 0.0 ? 1.0 : 0.0;
-            const double x = (double)it.aux[j];
-            const double sp = (x > 0.0 ? x : 0.0) + log1p(exp(-fabs(x)));
-            acc[2 * j] += sp - x * t;
-            acc[2 * j + 1] += sp - x * (1.0 - t);
-        }
-        if (A.scale_logits) { acc[4] += (double)it.sl[0]; acc[5] += (double)it.sl[1]; acc[6] += (double)it.sl[2]; }
-    }
-    double* mine = A.partial + (size_t)PS_COMP * blockIdx.x;
-    // the seven block sums with one barrier: butterflies inside the wave, then thread c adds the four wave sums of component c
-    // in wave order (the order block_sum uses)
-#pragma unroll
-    for (int c = 0; c < PS_COMP - 1; ++c) {
-        double v = acc[c];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        if ((tid & 63) == 0) shc[tid >> 6][c] = v;
-    }
-    __syncthreads();
-    if (tid < PS_COMP - 1) {
-        double v = 0.0;
-        for (int w = 0; w < RED_THREADS / 64; ++w) v += shc[w][tid];
-        // device-scope atomic stores and loads: the block that sums them runs on another CU, maybe another XCD
-        __hip_atomic_store(mine + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();   // (workgroup scope: the seven stores are ordered before thread 0's release below)
-    if (tid == 0) drawn = __hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (drawn != RED_BLOCKS - 1) return;
-    static_assert(RED_THREADS == 32 * PS_COMP && RED_BLOCKS == 32 * 8, "final sum: 8 components x 32 lanes x 8 partials");
-    const int c = tid >> 5, l = tid & 31;
-    double s = 0.0;
-    // every block's partials were stored (device scope) before its ticket; this block drew the last one: an acquire fence, then
-    // plain loads, eight per lane, all in flight at once
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (c < PS_COMP - 1) {
-        double v[8];
-#pragma unroll
-        for (int b = 0; b < 8; ++b) v[b] = A.partial[(size_t)PS_COMP * (8 * l + b) + c];
-#pragma unroll
-        for (int b = 0; b < 8; ++b) s += v[b];
-    }
-    for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (l == 0) {
-        if (c < 4) { if (c < 2 * A.n_dirs) A.sign[3 * (c >> 1) + (c & 1)] = s; }
-        else if (c < 7 && A.scale_logits) A.scale_out[c - 4] = s;
-    }
-    if (tid < A.n_dirs) A.sign[3 * tid + 2] = (double)n_sel;
-    if (tid == 0 && A.scale_logits) A.scale_out[3] = (double)n_sel;
-    if (tid == 0) __hip_atomic_store(A.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
-}
-
-extern "C" size_t cppf_pose_sums_workspace_bytes(void) { return (size_t)RED_BLOCKS * PS_COMP * sizeof(double) + 16; }
-
-extern "C" int cppf_pose_sums(const float* pc, const float* nrm, const int32_t* point_idxs, const int32_t* sel,
-                              const int32_t* n_sel_dev, int64_t n_sel_host, const float* aux, int aux_stride, int n_dirs,
-                              const int32_t* counts, int n_sphere, int counts_dir_step, const double* sphere64,
-                              const float* scale_logits, int scale_stride, long long* best_idx, double* best_dir,
-                              double* sign, double* scale_out, void* workspace, size_t workspace_bytes, unsigned* ticket,
-                              void* stream)
-{
-    if (!pc || !nrm || !point_idxs || !aux || !counts || !sphere64 || !best_dir || !sign || !ticket) return CPPF_EINVAL;
-    if (n_dirs < 1 || n_dirs > PS_MAX_DIRS || aux_stride < n_dirs || n_sphere < 1 || n_sel_host < 0 ||
-        (n_dirs > 1 && counts_dir_step < n_sphere) || (scale_logits && (scale_stride < 3 || !scale_out)))
-        return CPPF_EINVAL;
-    if (!workspace || workspace_bytes < cppf_pose_sums_workspace_bytes()) return CPPF_EWORKSPACE;
-    PoseSumsArgs A;
-    A.pc = pc; A.nrm = nrm; A.aux = aux; A.scale_logits = scale_logits;
-    A.point_idxs = point_idxs; A.sel = sel; A.n_sel_dev = n_sel_dev; A.counts = counts;
-    A.sphere64 = sphere64; A.n_sel_host = n_sel_host;
-    A.aux_stride = aux_stride; A.scale_stride = scale_stride; A.n_dirs = n_dirs; A.n_sphere = n_sphere;
-    A.counts_dir_step = counts_dir_step;
-    A.best_idx = best_idx; A.best_dir = best_dir; A.sign = sign; A.scale_out = scale_out;
-    A.partial = static_cast<double*>(workspace); A.ticket = ticket;
-    hipLaunchKernelGGL(pose_sums_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, (hipStream_t)stream, A);
-    CPPF_CHECK_LAUNCH();
-    return 0;
-}
-
-// ----------------------------------------------------------------------------- grid setup
-// nocs/inference.py:194-195: corners = [min(pc), max(pc)]; grid_res = int32((max-min)/res) + 1
-__global__ __launch_bounds__(1024) void grid_setup_kernel(const float* __restrict__ pc, int64_t N, float res,
-                                                          float* __restrict__ corner, int32_t* __restrict__ dims)
-{
-    __shared__ float slo[16][3], shi[16][3];
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int64_t i = threadIdx.x; i < N; i += 1024)
-        for (int j = 0; j < 3; ++j) {
-            const float v = pc[3 * i + j];
-            lo[j] = fminf(lo[j], v);
-            hi[j] = fmaxf(hi[j], v);
-        }
-    for (int j = 0; j < 3; ++j)
-        for (int off = 32; off > 0; off >>= 1) {
-            lo[j] = fminf(lo[j], __shfl_xor(lo[j], off, 64));
-            hi[j] = fmaxf(hi[j], __shfl_xor(hi[j], off, 64));
-        }
-    if ((threadIdx.x & 63) == 0)
-        for (int j = 0; j < 3; ++j) { slo[threadIdx.x >> 6][j] = lo[j]; shi[threadIdx.x >> 6][j] = hi[j]; }
-    __syncthreads();
-    if (threadIdx.x < 3) {
-        const int j = threadIdx.x;
-        float l = slo[0][j], h = shi[0][j];
-        for (int w = 1; w < 16; ++w) { l = fminf(l, slo[w][j]); h = fmaxf(h, shi[w][j]); }
-        corner[j] = l;
-        dims[j] = (int32_t)((h - l) / res) + 1;
-    }
-}
-
-extern "C" int cppf_grid_setup(const float* pc, int64_t N, float res, float* corner, int32_t* dims, void* stream)
-{
-    if (!pc || !corner || !dims || N < 1) return CPPF_EINVAL;
-    hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pc, N, res, corner, dims);
     CPPF_CHECK_LAUNCH();
     return 0;
 }

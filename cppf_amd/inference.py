@@ -712,6 +712,169 @@ class PosePipeline(CenterPipeline):
         self._u.uniform_(0.0, 1.0, generator=generator)
 
 
+class PoseChain:
+    """Up to 8 PosePipelines -- the instances of a frame on one HIP stream (the reference loops over them, nocs/inference.py:120) --
+    replayed as ONE captured chain with the launches SHARED between the members: their point encoders one after the other, then ONE
+    launch of the pair kernel for all pair lists (forward_decode_batch), ONE vote + ONE reduce launch (vote_argmax_batch) and the six
+    launches of the batched tail (cppf_pose_tail_batch: T, back-vote, compaction, second pass, orientation vote, sums) -- about
+    10 + n launches for n instances instead of ~15 each.  At the reference's own size (100 000 pairs, :177) a launch is half prologue,
+    so the launches were what an instance cost.  Members keep their buffers (load / stage them as usual) and their result records
+    (`pipes[i].ws.rec`); records equal the members' own runs bit for bit (at the chain's vote width).
+
+    Members: pose pipelines of ONE device with the standard fused pair encoder, the same num_rots / adaptive / angle_tol /
+    max_rot_pairs / sphere bins, no rot_order, grids of the tiled vote; static or shape-polymorphic, any categories.  Like a
+    PosePipeline the chain has two captured forms -- split (second pass on the survivors) and full-first (every head in the first
+    pass) -- chosen from the survivor share of its last run (adapt)."""
+
+    FULL_FIRST_ON, FULL_FIRST_OFF = PosePipeline.FULL_FIRST_ON, PosePipeline.FULL_FIRST_OFF
+
+    def __init__(self, pipes, use_graph=True, vote_workgroups=0):
+        pipes = list(pipes)
+        if not 1 <= len(pipes) <= 8:
+            raise ValueError("1 to 8 pipelines per chain")
+        p0 = pipes[0]
+        for p in pipes:
+            if (not isinstance(p, PosePipeline) or p.device != p0.device or not p._split_ok or p.rot_order is not None
+                    or (p.num_rots, p.adaptive, p.angle_tol, p.max_rot_pairs) != (p0.num_rots, p0.adaptive, p0.angle_tol, p0.max_rot_pairs)
+                    or p.ws._sph_key != p0.ws._sph_key or p._sph[2] == 0):
+                raise _lib.CppfError("PoseChain takes PosePipelines of one device with the standard pair encoder and the same vote / "
+                                     "orientation settings (no rot_order)")
+        if len({id(p) for p in pipes}) != len(pipes):
+            raise ValueError("a pipeline can be a member once")
+        self.pipes, self.device = pipes, p0.device
+        self.vote_workgroups = int(vote_workgroups or 0)
+        self.full_first = False
+        self._use_graph, self._graphs, self._owned, self.tensors = use_graph, {}, {}, None
+
+    def _chain(self):
+        from .models.model import forward_decode_batch
+        import ctypes as C
+        pipes, p0 = self.pipes, self.pipes[0]
+        L = _lib.lib()
+        feats = []            # (the members' own attributes are left alone: a member may also run on its own captured graph)
+        for p in pipes:                                                          # nocs/inference.py:180-181
+            if p.point_encoder is None:
+                feats.append(p.feat)
+            elif p.dynamic:
+                feats.append(p.point_encoder.forward_dyn(p.pc, p.nrm, p.shape, out=p._feat_out, nbrs=p._nbrs))
+            else:
+                feats.append(p.point_encoder(p.pc[None], p.nrm[None])[0])
+        items = []
+        for p, f in zip(pipes, feats):
+            it = dict(encoder=p.encoder, pc=p.pc, pc_normal=p.nrm, feat=f, idxs=p.idx, u_tr=p.u_tr, vote_range=p.cfg.vote_range)
+            if self.full_first:
+                it["u_rot"] = p.u_rot
+            items.append(it)
+        tables = []
+        outs = forward_decode_batch(items, p0.cfg.tr_num_bins, p0.cfg.rot_num_bins, tables_out=tables)          # :182-188
+        outputs = [o for o, _ in outs]
+        heads = [(h if self.full_first else p.ws.heads) for p, (_, h) in zip(pipes, outs)]
+        self.tensors = [dict(outputs=o, heads=h, feat=f) for o, h, f in zip(outputs, heads, feats)]
+        vws = []
+        voting.vote_argmax_batch([dict(points=p.pc, outputs=o, point_idxs=p.idx, corner=p.corner, res=p.cfg.res, out_idx=p.out_idx,
+                                       out_val=p.out_val, **(dict(grid=p.grid_flat, shape=p.shape, many_tiles=p.many_tiles) if p.dynamic
+                                                             else dict(grid=p.grid))) for p, o in zip(pipes, outputs)],
+                                 p0.num_rots, p0.adaptive, accumulate=False, workgroups=self.vote_workgroups, workspaces_out=vws)   # :191-208
+        arr = (_lib.PoseTailItem * len(pipes))()
+        keep = []
+        sph32, sph64, sorted_y = p0._sph
+        for i, p in enumerate(pipes):
+            ws, a = p.ws, arr[i]
+            pws = workspace(L.cppf_pose_sums_workspace_bytes(), self.device, f"pose_sums{i}")
+            packed = p.encoder._packed_weights(self.device)
+            a.pc, a.nrm, a.feat, a.idx64, a.idx32 = p.pc.data_ptr(), p.nrm.data_ptr(), feats[i].data_ptr(), p.idx.data_ptr(), p.idx32.data_ptr()
+            a.outputs, a.u_rot, a.heads, a.corner = outputs[i].data_ptr(), p.u_rot.data_ptr(), heads[i].data_ptr(), p.corner.data_ptr()
+            a.shape_dev = p.shape.data_ptr() if p.dynamic else None
+            a.argmax_idx, a.peak = p.out_idx.data_ptr(), p.out_val.data_ptr()
+            a.packed, a.mlp_workspace, a.mlp_workspace_bytes = packed.data_ptr(), tables[i].data_ptr(), tables[i].numel()
+            a.vote_workspace = vws[i].data_ptr() if vws[i].numel() >= 32768 else None
+            a.rec, a.T32, a.tail0, a.tail0_bytes = ws.rec.data_ptr(), ws.T32.data_ptr(), ws._tail0.data_ptr(), ws._tail0.numel()
+            a.mask, a.chunk_counts, a.surv, a.count = ws.mask.data_ptr(), ws.chunk_counts.data_ptr(), ws.surv.data_ptr(), ws.count.data_ptr()
+            a.counts, a.best_idx, a.ticket = ws.counts.data_ptr(), ws.best_idx.data_ptr(), ws.ticket.data_ptr()
+            a.sums_workspace, a.sums_workspace_bytes = pws.data_ptr(), pws.numel()
+            a.n_points, a.n_pairs = p.pc.shape[0], p.idx.shape[0]
+            a.res64, a.res, a.tol = float(p.cfg.res), float(p.cfg.res), float(np.float32(3 * p.cfg.res))
+            a.gx, a.gy, a.gz = (1, 1, 1) if p.dynamic else p.dims
+            a.n_dirs, a.second_pass = (2 if p.cfg.regress_right else 1), (0 if self.full_first else 1)
+            keep.append((pws, packed))
+        dims = (C.c_int * len(p0.encoder.ppffcs))(*p0.encoder.ppffcs)
+        thr = float(np.float32(np.cos(p0.angle_tol / 180 * np.pi)))
+        with torch.cuda.device(self.device):
+            rc = L.cppf_pose_tail_batch(len(pipes), C.cast(arr, C.c_void_p), feats[0].shape[1], dims, len(p0.encoder.ppffcs) - 1,
+                                        p0.encoder.out_dim, p0.cfg.tr_num_bins, p0.cfg.rot_num_bins, p0.num_rots, sph32.data_ptr(),
+                                        sph64.data_ptr(), sph32.shape[0], sorted_y, thr, p0.max_rot_pairs, stream_ptr(self.device))
+        _lib.check(rc, "cppf_pose_tail_batch")                                                                  # :209-303,335
+
+    def _key(self):
+        return (self.vote_workgroups,) + tuple((p.idx.data_ptr(), p.pc.data_ptr()) for p in self.pipes)
+
+    def run_async(self, records_out, check_weights=True):
+        """Replay the chain and copy every member's 21-double record into records_out[i] (device f64[21]) on the current stream."""
+        with torch.no_grad(), workspace_scope(id(self)):
+            if not self._use_graph:
+                self._chain()
+            else:
+                form = self.full_first
+                graph, images = self._graphs.get(form, (None, None))
+                now = ((tuple(tuple(p._weight_images()) for p in self.pipes) if check_weights or graph is None else images[0]), self._key())
+                if graph is not None and now != images:
+                    graph = None
+                if graph is None:
+                    s = torch.cuda.Stream(device=self.device)
+                    s.wait_stream(torch.cuda.current_stream(self.device))
+                    with torch.cuda.stream(s):
+                        self._chain()
+                        self._chain()
+                    torch.cuda.current_stream(self.device).wait_stream(s)
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                        self._chain()
+                    # (a captured form owns the tensors its launches write: `tensors` = outputs / heads / feat per member of THIS form)
+                    self._graphs[form] = (graph, now)
+                    self._owned[form] = self.tensors
+                self.tensors = self._owned[form]
+                for p in self.pipes:
+                    p._await_images()
+                graph.replay()
+                for p in self.pipes:
+                    p._note_images_read()
+        for p, r in zip(self.pipes, records_out):
+            r.copy_(p.ws.rec, non_blocking=True)
+
+    def run(self, check_weights=True):
+        """-> the members' pose dicts (one host synchronisation for all of them)"""
+        recs = torch.empty((len(self.pipes), 21), dtype=torch.float64, device=self.device)
+        self.run_async(list(recs), check_weights)
+        host = recs.cpu().numpy()
+        out = []
+        for p, r in zip(self.pipes, host):
+            d = _assemble(r, p.cfg)
+            d.update(dims=p.dims, ws=p.ws)
+            out.append(d)
+        for d, tn in zip(out, self.tensors):
+            d.update(outputs=tn["outputs"], heads=tn["heads"])
+        self.adapt([d["n_surv"] for d in out])
+        return out
+
+    def adapt(self, n_survs):
+        """choose the form of the next run from the survivor shares of the last one (see PosePipeline.adapt)"""
+        share = float(np.mean([float(n) / max(p.idx.shape[0], 1) for n, p in zip(n_survs, self.pipes)]))
+        if share > self.FULL_FIRST_ON:
+            self.full_first = True
+        elif share < self.FULL_FIRST_OFF:
+            self.full_first = False
+
+    def release(self):
+        self._graphs, self._owned, self.tensors = {}, {}, None
+        release_scope(id(self))
+
+    def __del__(self):
+        try:
+            release_scope(id(self))
+        except Exception:
+            pass
+
+
 def assemble_batch(recs, cfgs, object_ids, n_cols):
     """_assemble + sharding.pack_record for a whole batch in one numpy pass: recs f64[n,21] (read back from the device),
     cfgs a list of n category configs -> f64[n, n_cols] = {T, up, right, scale, argmax, peak, n_surv, object id}.

@@ -759,7 +759,7 @@ def batch_plan(n_pairs):
     return dict(per_xcd=per_xcd.value, grid=grid.value, wg_begin=list(wb))
 
 
-def forward_decode_batch(items, tr_num_bins=32, rot_num_bins=36):
+def forward_decode_batch(items, tr_num_bins=32, rot_num_bins=36, tables_out=None):
     """PPFEncoder.forward_decode for up to 8 pair lists in ONE launch (cppf_pair_mlp_decode_batch): the instances of a frame, each
     with its own cloud, pair list and encoder (the reference keeps one network per category, nocs/inference.py:79-90).  `items`:
     dicts {encoder, pc, pc_normal, feat, idxs, u_tr, vote_range[, u_rot]}; all with u_rot or none.  Returns [(outputs, heads)] in
@@ -802,5 +802,7 @@ def forward_decode_batch(items, tr_num_bins=32, rot_num_bins=36):
         rc = _lib.lib().cppf_pair_mlp_decode_batch(len(items), C.cast(arr, C.c_void_p), items[0]["feat"].shape[1], dims,
                                                    len(enc0.ppffcs) - 1, enc0.out_dim, tr_num_bins, rot_num_bins, stream_ptr(dev))
     _lib.check(rc, "cppf_pair_mlp_decode_batch")
+    if tables_out is not None:      # the per-point tables this pass left (a batched second pass reuses them: cppf_pose_tail_batch)
+        tables_out[:] = [k[4] for k in keep]
     return outs
 

@@ -166,27 +166,27 @@ def vote_argmax_dyn(points, outputs, probs, point_idxs, grid_flat, shape, corner
 
 
 def vote_batch_workgroups(n_items, workgroups=0):
-    """vote workgroups each object of a vote_argmax_batch call gets (256 / n_items, at least 32, unless `workgroups` says otherwise)"""
+    """vote workgroups each object of a vote_argmax_batch call gets (256 / n_items, at least 64, unless `workgroups` says otherwise)"""
     w = int(workgroups or 0)
-    if w and not 32 <= w <= 256:
-        raise ValueError(f"workgroups must be 0 or in 32..256, got {workgroups}")
+    if w and not 64 <= w <= 256:
+        raise ValueError(f"workgroups must be 0 or in 64..256, got {workgroups}")
     return int(_lib.lib().cppf_vote_batch_workgroups(int(n_items), w << 8))
 
 
-def vote_argmax_batch(items, n_rots, adaptive, accumulate=False, workgroups=0, ws_tag="vote_b"):
+def vote_argmax_batch(items, n_rots, adaptive, accumulate=False, workgroups=0, ws_tag="vote_b", workspaces_out=None):
     """vote_argmax / vote_argmax_dyn for up to 8 objects enqueued together (cppf_vote_argmax_batch): the objects whose grids take
     the fused vote (< 4 LDS tiles: every NOCS category) share ONE vote launch and ONE reduce launch, each on
     vote_batch_workgroups(len(items), workgroups) workgroups; the others get their own launches.  `items`: dicts
     {points, outputs, point_idxs, grid, corner, res, out_idx, out_val[, probs][, shape, many_tiles]} -- `grid` f32[gx,gy,gz], or with
     `shape` (device i32[4] {n_points, gx, gy, gz}) a flat capacity buffer as for vote_argmax_dyn.  Every object keeps its own vote
-    workspace (scratch tag ws_tag + index in the current workspace scope).  Same grids, arg-max and peaks as the single calls at the
-    same width."""
+    workspace (scratch tag ws_tag + index in the current workspace scope).  Same grids, arg-max and peaks as the single calls, at
+    any width (the fixed-point scale of the fused vote does not follow the width)."""
     if not 1 <= len(items) <= 8:
         raise ValueError("1 to 8 objects per call")
     L = _lib.lib()
     w = int(workgroups or 0)
-    if w and not 32 <= w <= 256:
-        raise ValueError(f"workgroups must be 0 or in 32..256, got {workgroups}")
+    if w and not 64 <= w <= 256:
+        raise ValueError(f"workgroups must be 0 or in 64..256, got {workgroups}")
     flags = (1 if accumulate else 0) | (w << 8)
     arr = (_lib.VoteItem * len(items))()
     keep = []
@@ -234,6 +234,8 @@ def vote_argmax_batch(items, n_rots, adaptive, accumulate=False, workgroups=0, w
     with torch.cuda.device(dev):
         rc = L.cppf_vote_argmax_batch(len(items), C.cast(arr, C.c_void_p), int(n_rots), 1 if adaptive else 0, flags, stream_ptr(dev))
     _lib.check(rc, "cppf_vote_argmax_batch")
+    if workspaces_out is not None:  # (the back-vote loads the rotation table a vote left in its workspace)
+        workspaces_out[:] = keep
     return [(it["out_idx"], it["out_val"]) for it in items]
 
 

@@ -91,8 +91,9 @@ int cppf_ppf_voting(const float* points, const float* outputs, const float* prob
  * launch at most n vote workgroups instead of one per CU -- a scheduling hint for callers that keep several instances in flight
  * on different streams (every workgroup pays for a 113 KB tile it zeroes, dumps and the reduce kernel reads back, whatever it
  * deposits: at N = 4096, K = 128 with three instances in flight 128 workgroups give +5 % pairs/s, the instance alone runs 7 %
- * longer).  The grid stays the exact sum of the quantised deposits; the quantum follows the chunk length
- * (cppf_vote_fixed_point_bits describes the default launch).  Other bits must be zero (CPPF_EINVAL).
+ * longer).  The hint changes the schedule, not the result: the grid is the exact sum of the quantised deposits
+ * and, for grids of < 4 LDS tiles, the quantum is that of a 64-wide launch at EVERY width (cppf_vote_fixed_point_bits), so a call at
+ * 256, at 128 and as one object of cppf_vote_argmax_batch return the same bits.  Other bits must be zero (CPPF_EINVAL).
  * point_idxs: device i32[n_ppfs,2] (idx_is_i64 == 0, what the reference passes after `.astype(cp.int32)`,
  * nocs/inference.py:202) or the original i64[n_ppfs,2] of np.random.randint (idx_is_i64 != 0; spares the copy). */
 #define CPPF_VOTE_ACCUMULATE 1
@@ -140,6 +141,45 @@ int cppf_center_from_argmax(const long long* idx, const float* corner, double re
  * counts device i32[n], sphere64 device f64[n,3], best_idx device i64[1] (optional), best_dir device f64[3]. */
 int cppf_counts_argmax_select(const int32_t* counts, int n, const double* sphere64, long long* best_idx,
                               double* best_dir, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The pose tail of up to 8 objects -- everything between the centre vote's arg-max and the pose record, nocs/inference.py:209-303,335,
+ * for the instances of a frame (:120 loops over them) -- in SIX launches instead of six per object:
+ *   1. T = corner + unravel(arg-max) * res (:209-210)  [cppf_pose_tail_begin]     4. second MLP pass on the survivors (:236-256)
+ *   2. back-vote filter (:216-231)                     [cppf_backvote_count64]       [cppf_pair_mlp_decode_sel], items with second_pass
+ *   3. survivor compaction (:231)                      [cppf_compact_scatter]     5. orientation vote + sphere-bin count (:259-284)
+ *                                                                                     [cppf_rot_sphere_count_dirs]
+ *                                                                                 6. best_dir, sign and scale sums (:283-301,335) [cppf_pose_sums]
+ * Every launch runs the single-object kernel's body on item blockIdx.y of a by-value item array: per object the results are those
+ * of the six single calls in brackets, bit for bit.  Buffers are the caller's (cppf_amd.inference.PoseWorkspace lays them out):
+ *   rec      device f64[21]: T[3] | best_dir[2][3] | sign sums[2][3] | scale sums[4] | arg-max index, peak -- the pose record
+ *   tail0    the region zeroed by launch 1 (16-byte multiple): record, sphere-bin counts, ticket, per-chunk survivor counts
+ *   counts   device i32[2][n_sphere] (inside tail0); chunk_counts i32[ceil(n_pairs / 1024)] (inside tail0); ticket u32 (inside tail0)
+ *   heads    device f32[n_pairs,8]: rows of the survivors are written by launch 4 (second_pass = 1), or hold every pair's heads
+ *            from an all-heads first pass (second_pass = 0)
+ *   mlp_workspace  the per-point table the first pass (cppf_pair_mlp_decode / _batch) left for this object
+ * Common to the batch: the pair-encoder architecture (standard fused one only), n_rots, the sphere bins (unit vectors with a monotone y
+ * column: fibonacci_sphere; sphere_sorted_by_y = +1 descending / -1 ascending), thr = cos(angle_tol), max_rot_pairs (:277-280). */
+typedef struct CppfPoseTailItem {
+    const float* pc; const float* nrm; const float* feat;          /* device f32[n_points,3], f32[n_points,3], f32[n_points,F] */
+    const long long* idx64; int32_t* idx32;                         /* pair list i64[n_pairs,2]; its i32 copy (OUTPUT of launch 2) */
+    const float* outputs; const float* u_rot; float* heads;         /* (mu, nu) f32[n_pairs,2]; uniforms f32[n_pairs,2]; see above */
+    const float* corner; const int32_t* shape_dev;                  /* f32[3]; NULL (dims by value) or device i32[4] {n_points, gx, gy, gz} */
+    const long long* argmax_idx; const float* peak;                 /* the vote's outputs */
+    const float* packed; void* mlp_workspace; size_t mlp_workspace_bytes;
+    const void* vote_workspace;                                     /* the vote's workspace (its cached rotation table) or NULL */
+    double* rec; float* T32;
+    void* tail0; size_t tail0_bytes;
+    uint8_t* mask; int32_t* chunk_counts; int32_t* surv; int32_t* count; int32_t* counts;
+    long long* best_idx; unsigned* ticket; void* sums_workspace; size_t sums_workspace_bytes;
+    int64_t n_points, n_pairs;
+    double res64;                                                   /* res as the caller holds it (fp64: T = corner + cand * res, :210) */
+    float res, tol;                                                 /* fp32 res of the kernels; back-vote tolerance (3 * res) */
+    int gx, gy, gz, n_dirs, second_pass;
+} CppfPoseTailItem;
+int cppf_pose_tail_batch(int n_items, const CppfPoseTailItem* items_host, int F, const int* dims, int n_res, int out_dim, int tr_bins,
+                         int rot_bins, int n_rots, const float* sphere32, const double* sphere64, int n_sphere, int sphere_sorted_by_y,
+                         float thr, int64_t max_rot_pairs, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Back-vote filter.  Replaces `backvote_kernel` = CUDA `backvote` (models/voting.py:70-113),
@@ -212,11 +252,12 @@ int cppf_vote_argmax_dyn(const float* points, const float* outputs, const float*
  * list, grid, results and vote workspace -- enqueued together.  Items whose vote takes the fused kernel (a grid of < 4 LDS tiles:
  * every NOCS category; dims by value, or from a device record when shape_dev != NULL and many_tiles == 0) and n_rots <= 72 share
  * ONE vote launch and ONE reduce launch: workgroups [w_i, w_{i+1}) are item i's launch.  Each object then runs on fewer,
- * longer-lived workgroups -- cppf_vote_batch_workgroups(n_items, flags) each: 256 / n_items (at least 32) unless
+ * longer-lived workgroups -- cppf_vote_batch_workgroups(n_items, flags) each: 256 / n_items (at least 64) unless
  * CPPF_VOTE_WORKGROUPS(n) in `flags` says otherwise -- which divides the partial-tile traffic per object (a workgroup zeroes, dumps
  * and has read back its 113 KB tile whatever it deposits) without idling the rest of the chip, and the launch prologue is paid once.
  * Every other item gets the launches cppf_vote_argmax / cppf_vote_argmax_dyn would issue for it.  Per item the grid, arg-max and
- * peak are those of its own cppf_vote_argmax* call with the same CPPF_VOTE_WORKGROUPS, bit for bit.  flags: as `accumulate` of
+ * peak are those of its own cppf_vote_argmax* call, bit for bit, whatever either call's width: the grid is the exact integer sum of the
+ * quantised deposits and the fixed-point scale of the fused vote is that of a 64-wide launch at every width.  flags: as `accumulate` of
  * cppf_vote_argmax.  Replaces n launches of `ppf_kernel` (models/voting.py:8-66, nocs/inference.py:192-205) + np.argmax (:207-208). */
 typedef struct CppfVoteItem {
     const float* points;      /* device f32[n_points,3] */
@@ -341,6 +382,10 @@ typedef struct CppfPairMlpItem {
     int64_t n_points, n_pairs;
     float vr0, vr1;
     int idx_is_i64;
+    /* cppf_pair_mlp_decode_sel_batch only (the first-pass entry ignores them): */
+    const int32_t* sel;       /* device i32[>= max_sel]: the surviving pairs (cppf_compact_*'s output) */
+    const int32_t* n_sel_dev; /* device i32[1]: how many */
+    int64_t max_sel;          /* slots of the launch for this list (capacity; 0: skip the list) */
 } CppfPairMlpItem;
 int cppf_pair_mlp_decode_batch(int n_items, const CppfPairMlpItem* items_host, int F, const int* dims, int n_res, int out_dim,
                                int tr_bins, int rot_bins, void* stream);
@@ -349,6 +394,10 @@ int cppf_pair_mlp_decode_batch(int n_items, const CppfPairMlpItem* items_host, i
  * XCD's L2 holds ONE list's per-point table), 0 = contiguous workgroup ranges wg_begin[0..n_items] (optional output, may be NULL).
  * For callers that size batches and for tests that must know which mapping a launch exercised. */
 int cppf_pair_mlp_batch_plan(int n_items, const int64_t* n_pairs, int* per_xcd, int* grid, int* wg_begin);
+/* The second pass (cppf_pair_mlp_decode_sel, below) for up to 8 lists in one launch: list i's surviving pairs sel[0 .. min(*n_sel_dev,
+ * max_sel)) get their heads rows; item.workspace must hold the per-point table its first pass left.  u_tr / outputs are not used. */
+int cppf_pair_mlp_decode_sel_batch(int n_items, const CppfPairMlpItem* items_host, int F, const int* dims, int n_res, int out_dim,
+                                   int tr_bins, int rot_bins, void* stream);
 
 /* The second MLP pass of nocs/inference.py:236-256 -- ppf_encoder(..., idxs=point_idxs[mask]) followed by the decode of the
  * rotation bins, the sign logits and the log-scales -- on the surviving pairs only, without materialising point_idxs[mask]:
