@@ -1052,13 +1052,25 @@ def main():
         src = {"mug": "mug", "laptop": "laptop", "bowl": "bottle", "can": "bottle"}       # (bottle weights stand in for bowl / can)
         nets_f = {c: training.load_weights(TRAINED_WEIGHTS.format(w_), syn.CATEGORIES[w_], dev) for c, w_ in src.items()}
         encs_f, pencs_f = {c: v[1] for c, v in nets_f.items()}, {c: v[0] for c, v in nets_f.items()}
+        from cppf_amd.frames import FrameRunner
         for _ in range(2):
-            poses_f = frame_poses(depth, inst, encs_f, pencs_f, device=dev)
+            poses_e = frame_poses(depth, inst, encs_f, pencs_f, device=dev)
         settle()
-        t_rf, mm_rf = repeated(lambda: frame_poses(depth, inst, encs_f, pencs_f, device=dev), 2, 5, per=len(inst))
-        poses_f = frame_poses(depth, inst, encs_f, pencs_f, device=dev)
+        t_rf_e, mm_rf_e = repeated(lambda: frame_poses(depth, inst, encs_f, pencs_f, device=dev), 1, 5, per=len(inst))
+        frunner = FrameRunner(encs_f, pencs_f, dev)
+        for _ in range(5):              # first sighting (members' own graphs), capture of the chains, their slow first replays
+            poses_f = frunner.run(depth, inst)
+        settle()
+        t_rf, mm_rf = repeated(lambda: frunner.run(depth, inst), 4, 7, per=len(inst))
+        poses_f = frunner.run(depth, inst)
+        same = all((a is None) == (b is None) and (a is None or (a["argmax"] == b["argmax"] and np.array_equal(a["T"], b["T"])
+                                                                   and np.array_equal(a["up"], b["up"]) and a["n_surv"] == b["n_surv"]))
+                   for a, b in zip(poses_e, poses_f))
         real_frame = {"instances": len(inst), "points_per_instance": [int(p_["n_points"]) for p_ in poses_f], "pairs_per_instance": 100000,
                       "ms_per_instance_incl_preprocessing": t_rf, "ms_per_instance_min_max": mm_rf,
+                      "path": "FrameRunner: depth + one label image uploaded per frame, per-instance pre-processing count-driven on the "
+                              "device (cppf_frame_cloud_dyn) at the head of captured chains, one read-back per frame",
+                      "eager_loop_ms_per_instance": t_rf_e, "eager_loop_min_max": mm_rf_e, "poses_equal_eager_loop": bool(same),
                       "n_surv": [int(p_["n_surv"]) for p_ in poses_f]}
 
     # secondary: centre vote + the whole pose tail on known-answer inputs, where (nearly) every pair survives the back-vote
@@ -1363,15 +1375,15 @@ def compact(out):
     line = {k_: out[k_] for k_ in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                    "vs_baseline", "dtype", "data") if k_ in out}
     cfg = dict(out["config"])
-    if len(cfg.get("workload", "")) > 700:
-        cfg["workload"] = cfg["workload"][:700] + " ..."
+    if len(cfg.get("workload", "")) > 420:
+        cfg["workload"] = cfg["workload"][:330] + " ... (full text: bench_full.json)"
     line["config"] = cfg
     for k_ in ("pairs_per_ms_per_gpu", "regions", "region_ms_min_max", "median_ms_one_instance", "vote_workgroups", "mlp_batch", "vote_batch",
                "vote_batch_workgroups", "vote_batch_calibration_ms_per_step", "dist", "argmax_matches_oracle", "argmax_objects_matching_oracle", "argmax_steps_matching_oracle", "objects_per_s"):
         if k_ in out:
             line[k_] = out[k_]
     line["roofline"] = pick(out.get("roofline"), ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "lists_per_launch",
-                                                  "pairs_per_launch", "executed_flop_per_pair", "algorithmic_tflops"))
+                                                  "executed_flop_per_pair"))
     rv = out.get("roofline_vote")
     if rv is not None:
         line["roofline_vote"] = pick(rv, ("bound", "kernel", "achieved", "peak", "unit", "frac", "regime_of_achieved", "traffic",
@@ -1380,15 +1392,15 @@ def compact(out):
             if rv.get(reg):
                 line["roofline_vote"][reg] = pick(rv[reg], ("stage_ms", "landed_samples", "achieved", "frac"))
         if rv.get("traffic_timed_regions"):
-            line["roofline_vote"]["traffic_timed_regions"] = rv["traffic_timed_regions"]
+            line["roofline_vote"]["traffic_timed_regions"] = pick(rv["traffic_timed_regions"], ("bytes", "ratio"))
     cb = out.get("cpu_baseline")
     if cb is not None:
         line["cpu_baseline"] = pick(cb, ("value", "unit", "cores", "kind", "spread", "passes", "omp_binding", "physical_cores",
-                                         "host_threads_available", "legs"))
-        line["cpu_baseline"]["sample"] = cb["sample"][:300]
-        line["cpu_baseline"]["sweep_pairs_per_s"] = {str(e["threads"]): round(e["pairs_per_s"]) for e in cb.get("sweep", [])}
+                                         "host_threads_available"))
+        line["cpu_baseline"]["sample"] = cb["sample"][:100] + " ..."
+        line["cpu_baseline"]["sweep_Mpairs_per_s"] = {str(e["threads"]): round(e["pairs_per_s"] / 1e6, 2) for e in cb.get("sweep", [])}
         if cb.get("other_binding"):
-            line["cpu_baseline"]["other_binding"] = pick(cb["other_binding"], ("value", "cores", "spread", "omp_binding"))
+            line["cpu_baseline"]["other_binding"] = pick(cb["other_binding"], ("value", "cores", "omp_binding"))
         if cb.get("c1"):
             line["cpu_baseline"]["c1"] = pick(cb["c1"], ("value", "unit", "best_threads"))
     tr = out.get("trained_regime")
@@ -1396,24 +1408,31 @@ def compact(out):
         line["trained_regime"] = {"ms_per_step": tr.get("ms_per_step"), "pairs_per_s": tr.get("pairs_per_s")}
         for tag in ("axis_aligned", "random_poses"):
             if tr.get(tag):
-                line["trained_regime"][tag] = pick(tr[tag], ("vote_batch_workgroups", "ms_per_step", "ms_per_step_min_max", "median_ms_one_instance",
-                                                             "full_pose_ms_incl_readback", "argmax_error_cells_max_over_objects"))
+                line["trained_regime"][tag] = pick(tr[tag], ("vote_batch_workgroups", "ms_per_step", "ms_per_step_min_max",
+                                                             "full_pose_ms_incl_readback"))
     if out.get("all_heads_first_pass"):
         line["all_heads_first_pass"] = pick(out["all_heads_first_pass"], ("ms_per_step", "ms_per_step_min_max", "pairs_per_s"))
     if out.get("stage_ms"):
-        line["stage_ms"] = pick(out["stage_ms"], ("ppf_mlp_decode_centre_heads", "ppf_mlp_decode_all_heads", "vote_reduce_argmax",
-                                                  "vote_reduce_argmax_known_answer_inputs", "full_pose_incl_readback",
-                                                  "full_pose_incl_readback_min_max", "point_encoder_knn60_sprin"))
+        line["stage_ms"] = pick(out["stage_ms"], ("ppf_mlp_decode_centre_heads", "vote_reduce_argmax", "vote_reduce_argmax_known_answer_inputs",
+                                                  "full_pose_incl_readback"))
     if out.get("other_configs"):
-        line["other_configs"] = {nm: pick(v, ("ms_per_step", "ms_per_object", "ms_per_object_min_max", "pairs_per_s", "median_ms_one_instance",
-                                              "argmax_steps_matching_oracle")) for nm, v in out["other_configs"].items()}
+        line["other_configs"] = {nm: pick(v, ("ms_per_step", "ms_per_object", "argmax_steps_matching_oracle")) for nm, v in out["other_configs"].items()}
     if out.get("dropin_flow_reference_defaults"):
         line["dropin_flow_reference_defaults"] = pick(out["dropin_flow_reference_defaults"],
                                                       ("level1_reference_call_sequence_ms", "level2_estimate_pose_eager_ms",
-                                                       "level3_batch_runner_captured_ms", "min_max_ms"))
+                                                       "level3_batch_runner_captured_ms"))
     if out.get("real_frame"):
-        line["real_frame"] = pick(out["real_frame"], ("instances", "ms_per_instance_incl_preprocessing", "ms_per_instance_min_max"))
-    return line
+        line["real_frame"] = pick(out["real_frame"], ("instances", "ms_per_instance_incl_preprocessing", "ms_per_instance_min_max",
+                                                      "eager_loop_ms_per_instance", "poses_equal_eager_loop"))
+    def rounded(x):          # 6 significant digits are plenty beside a spread; the contract's own numbers stay as measured
+        if isinstance(x, float):
+            return float(f"{x:.6g}")
+        if isinstance(x, dict):
+            return {k_: rounded(v) for k_, v in x.items()}
+        if isinstance(x, (list, tuple)):
+            return [rounded(v) for v in x]
+        return x
+    return {k_: (v if k_ in ("value", "ms_per_step") else rounded(v)) for k_, v in line.items()}
 
 
 if __name__ == "__main__":

@@ -136,6 +136,146 @@ __global__ __launch_bounds__(256) void normals_kernel(const float* __restrict__ 
     for (int i = 0; i < 3; ++i) normals[3 * n + i] = (float)v[i];
 }
 
+// ---- the whole per-instance pre-processing as ONE count-driven stage (cppf_frame_cloud_dyn): no size ever visits the host.
+// valid pixel = bit `bit` of the frame's label image set and depth > 0 (utils/util.py:609-610 with instance_mask = that bit)
+template <typename T, typename LT>
+__global__ __launch_bounds__(256) void fc_valid_kernel(const T* __restrict__ depth, const LT* __restrict__ labels, unsigned bit, int64_t n,
+                                                       uint8_t* __restrict__ valid)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) valid[i] = ((labels[i] >> bit) & 1) && (depth[i] > (T)0);
+}
+// back-projection of the compacted pixels (bp_points_kernel's arithmetic), nocs/inference.py:132 `pc = pts / 1000.0` (fp64), the axis
+// flips of :136-137 (negations of utils/util.py:629-630's negations: exact), `.float()` of :140 -- and the voxel key of every slot:
+// slots beyond the count get the all-ones key, which sorts behind every real one
+template <typename T>
+__global__ __launch_bounds__(256) void fc_points_kernel(const T* __restrict__ depth, const int32_t* __restrict__ pix,
+                                                        const int32_t* __restrict__ count, int W, Kinv K, double divisor, double res,
+                                                        int n_cap, float* __restrict__ pcf, unsigned long long* __restrict__ keys,
+                                                        int32_t* __restrict__ vals)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_cap) return;
+    vals[i] = i;
+    if (i >= min(*count, n_cap)) { keys[i] = ~0ull; return; }
+    const int p = pix[i];
+    const double u = (double)(p % W), v = (double)(p / W), z = (double)depth[p];
+    double xyz[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xyz[c] = fma(K.k[3 * c + 1], v, K.k[3 * c] * u) + K.k[3 * c + 2];
+    const double pts[3] = {-(xyz[0] * z / xyz[2]), -(xyz[1] * z / xyz[2]), xyz[2] * z / xyz[2]};
+    const float f[3] = {(float)-(pts[0] / divisor), (float)-(pts[1] / divisor), (float)(pts[2] / divisor)};
+    unsigned long long k = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        pcf[3 * i + c] = f[c];
+        const int64_t q = (int64_t)floor((double)f[c] / res) + (1 << 20);     // (vox_keys_kernel)
+        k = (k << 21) | (unsigned long long)(q & ((1 << 21) - 1));
+    }
+    keys[i] = k;
+}
+__global__ __launch_bounds__(256) void fc_mark_kernel(const unsigned long long* __restrict__ skeys, const int32_t* __restrict__ svals,
+                                                      const int32_t* __restrict__ count, int n_cap, uint8_t* __restrict__ mask)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= min(*count, n_cap)) return;
+    if (i == 0 || skeys[i] != skeys[i - 1]) mask[svals[i]] = 1;
+}
+// pc = pc[keep] (:141) into the pipeline's cloud buffer; the instance's point count N (0 when it is below k_min: the reference
+// skips such instances, :121-123) goes to shape[0], where the kernels behind this stage read it
+__global__ __launch_bounds__(256) void fc_gather_kernel(const float* __restrict__ pcf, const int32_t* __restrict__ keep,
+                                                        const int32_t* __restrict__ count, int k_min, int n_cap, float* __restrict__ pc_out,
+                                                        int32_t* __restrict__ shape)
+{
+    const int n = min(*count, n_cap);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) shape[0] = n >= k_min ? n : 0;
+    if (i >= n) return;
+    const int s = keep[i];
+    pc_out[3 * i] = pcf[3 * s]; pc_out[3 * i + 1] = pcf[3 * s + 1]; pc_out[3 * i + 2] = pcf[3 * s + 2];
+}
+__global__ __launch_bounds__(256) void fc_normals_kernel(const float* __restrict__ pc, const int32_t* __restrict__ nbrs,
+                                                         const int32_t* __restrict__ n_dev, int k, float* __restrict__ normals)
+{
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= *n_dev) return;
+    double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < k; ++j) {
+        const float* p = pc + 3 * (int64_t)nbrs[n * k + j];
+        const double x = p[0], y = p[1], z = p[2];
+        c[0] += x; c[1] += y; c[2] += z;
+        c[3] += x * x; c[4] += x * y; c[5] += x * z; c[6] += y * y; c[7] += y * z; c[8] += z * z;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c[i] /= (double)k;
+    double v[3];
+    smallest_eigvec(c[3] - c[0] * c[0], c[4] - c[0] * c[1], c[5] - c[0] * c[2], c[6] - c[1] * c[1], c[7] - c[1] * c[2],
+                    c[8] - c[2] * c[2], v);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) normals[3 * n + i] = (float)v[i];
+}
+// nocs/inference.py:194-195 from the device count: corner = min(pc), dims = int32((max - min) / res) + 1 -> shape[1..3]
+__global__ __launch_bounds__(1024) void fc_grid_kernel(const float* __restrict__ pc, float res, float* __restrict__ corner,
+                                                       int32_t* __restrict__ shape)
+{
+    __shared__ float slo[16][3], shi[16][3];
+    const int N = shape[0];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = threadIdx.x; i < N; i += 1024)
+        for (int j = 0; j < 3; ++j) {
+            const float v = pc[3 * i + j];
+            lo[j] = fminf(lo[j], v);
+            hi[j] = fmaxf(hi[j], v);
+        }
+    for (int j = 0; j < 3; ++j)
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[j] = fminf(lo[j], __shfl_xor(lo[j], off, 64));
+            hi[j] = fmaxf(hi[j], __shfl_xor(hi[j], off, 64));
+        }
+    if ((threadIdx.x & 63) == 0)
+        for (int j = 0; j < 3; ++j) { slo[threadIdx.x >> 6][j] = lo[j]; shi[threadIdx.x >> 6][j] = hi[j]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int j = threadIdx.x;
+        float l = slo[0][j], h = shi[0][j];
+        for (int w = 1; w < 16; ++w) { l = fminf(l, slo[w][j]); h = fmaxf(h, shi[w][j]); }
+        corner[j] = N > 0 ? l : 0.f;
+        shape[1 + j] = N > 0 ? (int32_t)((h - l) / res) + 1 : 1;
+    }
+}
+// idx = idx mod N (both columns): pairs drawn as full-range integers on the device before the instance's N is known anywhere but here
+__global__ __launch_bounds__(256) void mod_pairs_kernel(long long* __restrict__ idx, int64_t n2, const int32_t* __restrict__ n_dev)
+{
+    const long long N = (long long)*n_dev;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) {
+        const unsigned long long r = (unsigned long long)idx[i];
+        idx[i] = N > 0 ? (long long)(r % (unsigned long long)N) : 0ll;
+    }
+}
+
+struct FcLayout { size_t valid, cmp1, pix, count, pcf, keys, vals, mask2, cmp2, keep, nbrs, temp, temp_bytes, total; };
+FcLayout fc_layout(int H, int W, int n_cap, int k)
+{
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t n = (size_t)H * W;
+    FcLayout L;
+    L.valid = 0;
+    L.cmp1 = L.valid + up(n);
+    L.pix = L.cmp1 + up(cppf_compact_workspace_bytes((int64_t)n));
+    L.count = L.pix + up(n * sizeof(int32_t));
+    L.pcf = L.count + 256;                                        // count1 at +0, count2 at +64
+    L.keys = L.pcf + up((size_t)n_cap * 3 * sizeof(float));
+    L.vals = L.keys + up(2 * (size_t)n_cap * sizeof(unsigned long long));
+    L.mask2 = L.vals + up(2 * (size_t)n_cap * sizeof(int32_t));
+    L.cmp2 = L.mask2 + up((size_t)n_cap);
+    L.keep = L.cmp2 + up(cppf_compact_workspace_bytes(n_cap));
+    L.nbrs = L.keep + up((size_t)n_cap * sizeof(int32_t));
+    L.temp = L.nbrs + up((size_t)n_cap * (size_t)k * sizeof(int32_t));
+    L.temp_bytes = up((size_t)48 * n_cap + (1u << 20));
+    L.total = L.temp + L.temp_bytes;
+    return L;
+}
+
 struct VoxLayout { size_t keys, vals, mask, compact, temp, temp_bytes, total; };
 VoxLayout vox_layout(int64_t N)
 {
@@ -211,6 +351,79 @@ int cppf_backproject(const void* depth, int depth_is_u16, const uint8_t* mask, i
     for (int i = 0; i < 9; ++i) K.k[i] = kinv_host[i];
     if (depth_is_u16) bp_points_kernel<uint16_t><<<nb, 256, 0, st>>>((const uint16_t*)depth, pix, count, W, K, pts);
     else bp_points_kernel<float><<<nb, 256, 0, st>>>((const float*)depth, pix, count, W, K, pts);
+    return (int)hipGetLastError();
+}
+
+size_t cppf_frame_cloud_workspace_bytes(int H, int W, int n_cap, int knn_k)
+{
+    if (H < 1 || W < 1 || n_cap < 1 || knn_k < 1) return 0;
+    return fc_layout(H, W, n_cap, knn_k).total;
+}
+
+int cppf_frame_cloud_dyn(const void* depth, int depth_is_u16, const void* labels, int label_bytes, int label_bit, int H, int W,
+                         const double* kinv_host, double divisor, double res, int knn_k, int k_min, int n_cap, float* pc_out,
+                         float* nrm_out, float* corner_out, int32_t* shape_out, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (H < 1 || W < 1 || (int64_t)H * W > 0x7fffffffll || !depth || !labels || !kinv_host || !pc_out || !nrm_out || !corner_out || !shape_out)
+        return CPPF_EINVAL;
+    if ((label_bytes != 1 && label_bytes != 2 && label_bytes != 4) || label_bit < 0 || label_bit >= 8 * label_bytes) return CPPF_EINVAL;
+    if (n_cap < 1 || knn_k < 1 || knn_k > 64 || knn_k > n_cap || k_min < knn_k || !(res > 0.0) || !(divisor > 0.0)) return CPPF_EINVAL;
+    const FcLayout L = fc_layout(H, W, n_cap, knn_k);
+    if (!workspace || workspace_bytes < L.total) return CPPF_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = static_cast<char*>(workspace);
+    const int64_t n = (int64_t)H * W;
+    uint8_t* valid = (uint8_t*)(ws + L.valid);
+    int32_t* pix = (int32_t*)(ws + L.pix);
+    int32_t *count1 = (int32_t*)(ws + L.count), *count2 = (int32_t*)(ws + L.count + 64);
+    float* pcf = (float*)(ws + L.pcf);
+    unsigned long long *keys = (unsigned long long*)(ws + L.keys), *skeys = keys + n_cap;
+    int32_t *vals = (int32_t*)(ws + L.vals), *svals = vals + n_cap;
+    uint8_t* mask2 = (uint8_t*)(ws + L.mask2);
+    int32_t *keep = (int32_t*)(ws + L.keep), *nbrs = (int32_t*)(ws + L.nbrs);
+    const int nbp = (int)((n + 255) / 256), nbc = (n_cap + 255) / 256;
+    const unsigned bit = (unsigned)label_bit;
+#define FC_VALID(T)                                                                                                                       \
+    do {                                                                                                                                  \
+        if (label_bytes == 1) fc_valid_kernel<T, uint8_t><<<nbp, 256, 0, st>>>((const T*)depth, (const uint8_t*)labels, bit, n, valid);   \
+        else if (label_bytes == 2) fc_valid_kernel<T, uint16_t><<<nbp, 256, 0, st>>>((const T*)depth, (const uint16_t*)labels, bit, n, valid); \
+        else fc_valid_kernel<T, uint32_t><<<nbp, 256, 0, st>>>((const T*)depth, (const uint32_t*)labels, bit, n, valid);                  \
+    } while (0)
+    if (depth_is_u16) FC_VALID(uint16_t); else FC_VALID(float);
+#undef FC_VALID
+    int rc = cppf_compact_mask(valid, n, pix, count1, ws + L.cmp1, cppf_compact_workspace_bytes(n), stream);        // np.where order (:612)
+    if (rc) return rc;
+    Kinv K;
+    for (int i = 0; i < 9; ++i) K.k[i] = kinv_host[i];
+    if (depth_is_u16) fc_points_kernel<uint16_t><<<nbc, 256, 0, st>>>((const uint16_t*)depth, pix, count1, W, K, divisor, res, n_cap, pcf, keys, vals);
+    else fc_points_kernel<float><<<nbc, 256, 0, st>>>((const float*)depth, pix, count1, W, K, divisor, res, n_cap, pcf, keys, vals);
+    size_t need = 0;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, need, keys, skeys, vals, svals, n_cap, 0, 64, st);
+    if (e != hipSuccess) return (int)e;
+    if (need > L.temp_bytes) return CPPF_EWORKSPACE;
+    need = L.temp_bytes;
+    e = hipcub::DeviceRadixSort::SortPairs(ws + L.temp, need, keys, skeys, vals, svals, n_cap, 0, 64, st);           // stable: lowest index first
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(mask2, 0, (size_t)n_cap, st);
+    if (e != hipSuccess) return (int)e;
+    fc_mark_kernel<<<nbc, 256, 0, st>>>(skeys, svals, count1, n_cap, mask2);
+    rc = cppf_compact_mask(mask2, n_cap, keep, count2, ws + L.cmp2, cppf_compact_workspace_bytes(n_cap), stream);     // :140
+    if (rc) return rc;
+    fc_gather_kernel<<<nbc, 256, 0, st>>>(pcf, keep, count2, k_min, n_cap, pc_out, shape_out);                       // :141
+    rc = cppf_knn_dyn(pc_out, n_cap, shape_out, knn_k, nbrs, stream);                                                 // :142
+    if (rc) return rc;
+    fc_normals_kernel<<<nbc, 256, 0, st>>>(pc_out, nbrs, shape_out, knn_k, nrm_out);
+    fc_grid_kernel<<<1, 1024, 0, st>>>(pc_out, (float)res, corner_out, shape_out);                                    // :194-195
+    return (int)hipGetLastError();
+}
+
+int cppf_mod_pairs_dyn(long long* idx, int64_t n_pairs, const int32_t* n_dev, void* stream)
+{
+    if (n_pairs < 0 || (n_pairs > 0 && (!idx || !n_dev))) return CPPF_EINVAL;
+    if (n_pairs == 0) return 0;
+    int64_t nb = (2 * n_pairs + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    mod_pairs_kernel<<<(int)nb, 256, 0, (hipStream_t)stream>>>(idx, 2 * n_pairs, n_dev);
     return (int)hipGetLastError();
 }
 

@@ -27,11 +27,25 @@ def instance_cloud(depth_dev, intrinsics, mask, cfg, jitter=None):
     return pc, estimate_normals(pc, cfg.knn)                                       # :142
 
 
+def draw_pairs(gen, seed, i, n_pairs, dev, idx=None, u=None):
+    """The pair list and the bin uniforms of instance i of a frame, drawn on the device BEFORE the instance's point count N is known
+    to the host: full-range non-negative integers (reduced mod N where N is known: `idx % n` here, cppf_mod_pairs_dyn inside a
+    captured chain) and uniforms f32[2, n_pairs, 2] (stand-ins for torch.multinomial's draws, nocs/inference.py:186,250).  Same
+    distribution as np.random.randint(0, N, (n_pairs, 2)) (:177) up to a bias of N / 2^63."""
+    gen.manual_seed(int(seed) * 1000003 + int(i))
+    idx = torch.empty((n_pairs, 2), dtype=torch.int64, device=dev) if idx is None else idx
+    u = torch.empty((2, n_pairs, 2), dtype=torch.float32, device=dev) if u is None else u
+    idx.random_(generator=gen)
+    u.uniform_(0.0, 1.0, generator=gen)
+    return idx, u
+
+
 def frame_poses(depth, instances, encoders, point_encoders, intrinsics=NOCS_INTRINSICS, n_pairs=100000, seed=0, device=None,
-                angle_tol=1.5, num_rots=72, cfgs=None):
+                angle_tol=1.5, num_rots=72, cfgs=None, index_of=None):
     """depth: uint16 [H,W]; instances: list of (category name, mask [H,W]); encoders / point_encoders: {category: module on the
     device}; cfgs: {category: CategoryConfig} (default: cppf_amd.config.CATEGORIES, the reference's yaml values).  Returns a list of pose dicts (None for an instance with fewer points than the kNN needs, like the reference's
-    skip at :121-123), each with `n_points` added."""
+    skip at :121-123), each with `n_points` added.  index_of: the instances' positions in their frame (default 0, 1, ...): the pair
+    draws are a function of (seed, position)."""
     dev = device or torch.device("cuda", 0)
     d_dev = torch.from_numpy(np.ascontiguousarray(depth).view(np.int16)).to(dev)   # one upload per frame
     sphere = np.array(fibonacci_sphere(num_sphere_bins(angle_tol)))                # :100-102
@@ -44,12 +58,183 @@ def frame_poses(depth, instances, encoders, point_encoders, intrinsics=NOCS_INTR
         if n < cfg.knn + 1:
             out.append(None)
             continue
-        gen.manual_seed(seed * 1000003 + i)
-        idx = torch.randint(0, n, (n_pairs, 2), device=dev, generator=gen)         # :177
-        u = torch.rand((2, n_pairs, 2), device=dev, generator=gen)                 # stands in for torch.multinomial's draws (:186,250)
+        idx, u = draw_pairs(gen, seed, i if index_of is None else index_of[i], n_pairs, dev)     # :177, and the draws of :186,250
+        idx = idx % n
         with torch.no_grad():
             feat = penc(pc[None], nrm[None])[0]                                    # :180-181
             pose = estimate_pose(enc, pc, nrm, feat, idx, u[0], u[1], cfg, sphere, num_rots=num_rots, angle_tol=angle_tol)
         pose["n_points"] = n
         out.append(pose)
     return out
+
+
+class FrameRunner:
+    """frame_poses() through captured chains: depth and ONE label image (bit i = instance i's mask) uploaded per frame, every
+    instance's pre-processing (back-projection, /1000, flips, voxel de-duplication, PCA normals, grid set-up: cppf_frame_cloud_dyn,
+    count-driven on the device) at the head of a shape-polymorphic PosePipeline, the instances of a lane sharing their launches
+    (inference.PoseChain), one read-back per frame.  The reference's loop is nocs/inference.py:108-142,177-339.
+
+        runner = FrameRunner(encoders, point_encoders, device)
+        poses = runner.run(depth_u16, [(category, mask), ...])        # list of pose dicts / None, as frame_poses
+
+    Poses equal frame_poses' (the eager path: same kernels, same pairs) bit for bit.  An instance the captured chain cannot serve
+    (a cloud whose grid needs >= 4 vote tiles; more than `max_instances` instances) goes through the eager path; an instance with
+    fewer points than the kNN needs is skipped like the reference's (:121-123)."""
+
+    def __init__(self, encoders, point_encoders, device, intrinsics=NOCS_INTRINSICS, n_pairs=100000, angle_tol=1.5, num_rots=72,
+                 cfgs=None, n_lanes=3, chain_len=None, cap_bucket=4096, max_members=48):
+        from collections import OrderedDict
+        self.encoders, self.point_encoders, self.device = encoders, point_encoders, device
+        self.intrinsics = np.asarray(intrinsics, np.float64)
+        self.kinv = np.ascontiguousarray(np.linalg.inv(self.intrinsics))
+        self.n_pairs, self.angle_tol, self.num_rots = int(n_pairs), angle_tol, num_rots
+        self.cfgs = cfgs or CATEGORIES
+        self.n_lanes, self.chain_len, self.cap_bucket = max(1, int(n_lanes)), chain_len, int(cap_bucket)
+        self.sphere = np.array(fibonacci_sphere(num_sphere_bins(angle_tol)))
+        self.max_instances = 16                       # bits of the u16 label image
+        self._members, self.max_members = OrderedDict(), int(max_members)
+        self._chains, self._seen = OrderedDict(), {}
+        self._hw = None
+        self._streams = [torch.cuda.Stream(device=device) for _ in range(self.n_lanes)]
+        self._gen = torch.Generator(device=device)
+
+    def _frame_buffers(self, H, W):
+        if self._hw != (H, W):
+            self._hw = (H, W)
+            self._depth_host = torch.empty((H, W), dtype=torch.int16).pin_memory()
+            self._labels_host = torch.empty((H, W), dtype=torch.int16).pin_memory()
+            self._depth = torch.empty((H, W), dtype=torch.int16, device=self.device)
+            self._labels = torch.empty((H, W), dtype=torch.int16, device=self.device)
+            for ch in self._chains.values():
+                ch.release()
+            self._members.clear()
+            self._chains.clear()
+
+    def _member(self, cat, n_mask, lane, slot, bit):
+        """(pipeline, prestage) for an instance of `cat` with n_mask label pixels at this position"""
+        from . import _lib
+        from ._torch_util import stream_ptr
+        from .inference import PosePipeline
+        cap = max(self.cap_bucket, 1 << int(np.ceil(np.log2(max(n_mask, 1)))))
+        key = (cat, cap, lane, slot, bit)
+        hit = self._members.get(key)
+        if hit is not None:
+            self._members.move_to_end(key)
+            return hit
+        while len(self._members) >= self.max_members:
+            torch.cuda.synchronize(self.device)
+            _, (old, _) = self._members.popitem(last=False)
+            for ck in [ck for ck in self._chains if id(old) in ck]:
+                self._chains.pop(ck).release()
+            old.release()
+        cfg, H, W = self.cfgs[cat], self._hw[0], self._hw[1]
+        pipe = PosePipeline(self.encoders[cat], cfg, cap, self.n_pairs, False, self.device, self.sphere, num_rots=self.num_rots,
+                            angle_tol=self.angle_tol, point_encoder=self.point_encoders[cat], dynamic=True)
+        L = _lib.lib()
+        ws = torch.empty(int(L.cppf_frame_cloud_workspace_bytes(H, W, cap, cfg.knn)), dtype=torch.uint8, device=self.device)
+        dev, depth, labels, kinv = self.device, self._depth, self._labels, self.kinv
+
+        def prestage():
+            with torch.cuda.device(dev):
+                _lib.check(L.cppf_frame_cloud_dyn(depth.data_ptr(), 1, labels.data_ptr(), 2, bit, H, W, kinv.ctypes.data, 1000.0,
+                                                  float(cfg.res), cfg.knn, cfg.knn + 1, cap, pipe.pc.data_ptr(), pipe.nrm.data_ptr(),
+                                                  pipe.corner.data_ptr(), pipe.shape.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                  stream_ptr(dev)), "cppf_frame_cloud_dyn")
+                _lib.check(L.cppf_mod_pairs_dyn(pipe.idx.data_ptr(), pipe.idx.shape[0], pipe.shape.data_ptr(), stream_ptr(dev)),
+                           "cppf_mod_pairs_dyn")
+        pipe._frame_ws = ws
+        self._members[key] = (pipe, prestage)
+        return pipe, prestage
+
+    def _chain_for(self, pipes, pres):
+        from .inference import PoseChain
+        key = tuple(id(p) for p in pipes)
+        ch = self._chains.get(key)
+        if ch is not None:
+            self._chains.move_to_end(key)
+            return ch
+        n = self._seen[key] = self._seen.get(key, 0) + 1
+        if len(self._seen) > 4096:
+            self._seen.clear()
+        if n < 2:
+            return None
+        while len(self._chains) >= 16:
+            torch.cuda.synchronize(self.device)
+            self._chains.popitem(last=False)[1].release()
+        ch = self._chains[key] = PoseChain(pipes, prestages=pres)
+        return ch
+
+    def run(self, depth, instances, seed=0):
+        from .inference import assemble_record
+        dev = self.device
+        depth = np.ascontiguousarray(depth)
+        H, W = depth.shape
+        self._frame_buffers(H, W)
+        n_inst = len(instances)
+        out = [None] * n_inst
+        on_chain = list(range(min(n_inst, self.max_instances)))
+        labels = self._labels_host.numpy().view(np.uint16)
+        labels[...] = 0
+        counts = []
+        for i in on_chain:
+            m = np.asarray(instances[i][1]) != 0
+            labels[m] |= np.uint16(1 << i)
+            counts.append(int(np.count_nonzero(m)))
+        self._depth_host.numpy()[...] = depth.view(np.int16)
+        main = torch.cuda.current_stream(dev)
+        self._depth.copy_(self._depth_host, non_blocking=True)          # one upload per frame (two images)
+        self._labels.copy_(self._labels_host, non_blocking=True)
+        for cat in {instances[i][0] for i in on_chain}:
+            self.encoders[cat]._packed_weights(dev)
+            self.point_encoders[cat]._packed_weights(dev)
+        for st in self._streams:
+            st.wait_stream(main)
+        raw = torch.zeros((max(len(on_chain), 1), 21), dtype=torch.float64, device=dev)
+        shapes = torch.zeros((max(len(on_chain), 1), 4), dtype=torch.int32, device=dev)
+        Lc = self.chain_len or max(1, min(8, -(-len(on_chain) // self.n_lanes)))
+        groups = [on_chain[g:g + Lc] for g in range(0, len(on_chain), Lc)]
+        ran = []
+        for gi, slots in enumerate(groups):
+            lane = gi % self.n_lanes
+            with torch.cuda.stream(self._streams[lane]):
+                pipes, pres = [], []
+                for q, i in enumerate(slots):
+                    pipe, pre = self._member(instances[i][0], counts[i], lane, q, i)
+                    draw_pairs(self._gen, seed, i, self.n_pairs, dev, idx=pipe.idx, u=pipe._u)
+                    pipes.append(pipe)
+                    pres.append(pre)
+                ch = self._chain_for(pipes, pres)
+                if ch is not None:
+                    ch.run_async([raw[i] for i in slots], check_weights=False)
+                else:
+                    for pipe, pre, i in zip(pipes, pres, slots):
+                        pre()
+                        pipe.run_async(raw[i], check_weights=False)
+                for pipe, i in zip(pipes, slots):
+                    shapes[i].copy_(pipe.shape, non_blocking=True)
+                ran.append((ch, pipes, slots))
+        for st in self._streams:
+            main.wait_stream(st)
+        host, shp = raw.cpu().numpy(), shapes.cpu().numpy()             # the frame's one synchronisation
+        eager = list(range(len(on_chain), n_inst))
+        for ch, pipes, slots in ran:
+            if ch is not None:
+                ch.adapt([host[i, 18] for i in slots])
+            for pipe, i in zip(pipes, slots):
+                if ch is None:
+                    pipe.adapt(host[i, 18])
+                n = int(shp[i, 0])
+                if n == 0:
+                    continue                                             # fewer points than the kNN needs: skipped (:121-123)
+                if host[i, 19] < 0:
+                    eager.append(i)                                      # the chain could not serve this shape
+                    continue
+                pose = assemble_record(host[i], pipe.cfg)
+                pose.update(n_points=n, dims=tuple(int(v) for v in shp[i, 1:4]))
+                out[i] = pose
+        if eager:
+            sub = frame_poses(depth, [instances[i] for i in eager], self.encoders, self.point_encoders, self.intrinsics, self.n_pairs,
+                              seed, dev, self.angle_tol, self.num_rots, self.cfgs, index_of=eager)
+            for i, p in zip(eager, sub):
+                out[i] = p
+        return out

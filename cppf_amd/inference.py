@@ -728,10 +728,16 @@ class PoseChain:
 
     FULL_FIRST_ON, FULL_FIRST_OFF = PosePipeline.FULL_FIRST_ON, PosePipeline.FULL_FIRST_OFF
 
-    def __init__(self, pipes, use_graph=True, vote_workgroups=0):
+    def __init__(self, pipes, use_graph=True, vote_workgroups=0, prestages=None):
+        """prestages: optional list of callables, one per member (or None): launches enqueued at the head of the chain, in front of
+        the member's point encoder -- e.g. the count-driven pre-processing that fills the member's cloud, normals, corner and shape
+        record from a depth frame (cppf_amd.frames.FrameRunner)."""
         pipes = list(pipes)
         if not 1 <= len(pipes) <= 8:
             raise ValueError("1 to 8 pipelines per chain")
+        self.prestages = list(prestages) if prestages is not None else [None] * len(pipes)
+        if len(self.prestages) != len(pipes):
+            raise ValueError("one prestage (or None) per pipeline")
         p0 = pipes[0]
         for p in pipes:
             if (not isinstance(p, PosePipeline) or p.device != p0.device or not p._split_ok or p.rot_order is not None
@@ -751,6 +757,9 @@ class PoseChain:
         import ctypes as C
         pipes, p0 = self.pipes, self.pipes[0]
         L = _lib.lib()
+        for pre in self.prestages:                                               # nocs/inference.py:131-142 (FrameRunner)
+            if pre is not None:
+                pre()
         feats = []            # (the members' own attributes are left alone: a member may also run on its own captured graph)
         for p in pipes:                                                          # nocs/inference.py:180-181
             if p.point_encoder is None:

@@ -612,6 +612,22 @@ int cppf_point_encoder_forward_train(const float* pc, const float* nrm, const in
  *                        u16[H,W] (depth_is_u16 != 0; NOCS depth PNGs) or f32[H,W]; mask device u8[H,W]; kinv_host: HOST
  *                        f64[9], row-major inverse of the 3x3 intrinsics.
  * ------------------------------------------------------------------------------------------- */
+/* The whole per-instance pre-processing of nocs/inference.py:131-142 + the grid set-up of :194-195 as ONE count-driven stage for
+ * captured, shape-polymorphic chains: no size visits the host.  A frame's depth image and a LABEL image (bit `label_bit` of pixel p
+ * set <=> p belongs to the instance: up to 8 / 16 / 32 possibly overlapping instance masks in one upload) stay on the device;
+ * the stage back-projects the instance's valid pixels (cppf_backproject's arithmetic), divides by `divisor` (1000: millimetres,
+ * :132), flips x and y (:136-137), de-duplicates per voxel of edge `res` (cppf_voxel_dedupe's definition, :140-141), writes the cloud
+ * to pc_out f32[n_cap,3], its PCA normals over knn_k neighbours (cppf_knn + cppf_estimate_normals, :142) to nrm_out f32[n_cap,3], the
+ * grid corner to corner_out f32[3] and the instance's shape record to shape_out i32[4] = {N, gx, gy, gz} -- what the *_dyn entry
+ * points read.  N = 0 (and a 1x1x1 grid) when fewer than k_min points are left: the reference skips such instances (:121-123);
+ * the *_dyn vote then reports arg-max -1.  n_cap >= the number of set label pixels (the caller counts them on the host) bounds
+ * every buffer; rows >= N of pc_out / nrm_out are left untouched.  Results equal the four single calls on the same inputs, bit for
+ * bit.  cppf_mod_pairs_dyn: idx[i] <- idx[i] mod N for pairs drawn as full-range non-negative integers before N was known (:177). */
+size_t cppf_frame_cloud_workspace_bytes(int H, int W, int n_cap, int knn_k);
+int cppf_frame_cloud_dyn(const void* depth, int depth_is_u16, const void* labels, int label_bytes, int label_bit, int H, int W,
+                         const double* kinv_host, double divisor, double res, int knn_k, int k_min, int n_cap, float* pc_out,
+                         float* nrm_out, float* corner_out, int32_t* shape_out, void* workspace, size_t workspace_bytes, void* stream);
+int cppf_mod_pairs_dyn(long long* idx, int64_t n_pairs, const int32_t* n_dev, void* stream);
 size_t cppf_backproject_workspace_bytes(int H, int W);
 int cppf_backproject(const void* depth, int depth_is_u16, const uint8_t* mask, int H, int W, const double* kinv_host,
                      double* pts, int32_t* pix, int32_t* count, void* workspace, size_t workspace_bytes, void* stream);

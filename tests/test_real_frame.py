@@ -120,3 +120,64 @@ def test_real_frame_preprocessing_equals_oracle_and_poses_are_sane(oracle, dev):
     c = pc.mean(0).cpu().numpy()
     assert np.linalg.norm(poses[0]["T"] - c) < 0.08, (poses[0]["T"], c)
     assert 0.05 < poses[0]["scale_norm"] < 0.4
+
+
+@pytest.mark.gpu
+def test_frame_runner_equals_the_eager_loop(oracle, dev):
+    """FrameRunner (depth + one label image uploaded per frame, every instance's pre-processing count-driven on the device at the
+    head of a captured, shape-polymorphic chain, the instances of a lane sharing their launches, ONE read-back per frame) gives
+    frame_poses' poses -- the eager per-instance loop, nocs/inference.py:108-142,177-339 -- bit for bit: first sighting (members'
+    own graphs), captured chains, replays; overlapping masks, an instance too small for the kNN (skipped like :121-123), an empty
+    mask; the device stage's cloud / normals / grid record equal the oracle's pre-processing."""
+    import torch
+    from cppf_amd import training
+    from cppf_amd.config import CATEGORIES
+    from cppf_amd.frames import NOCS_INTRINSICS, FrameRunner, frame_poses
+    from cppf_amd.inference import grid_shape
+    from cppf_amd.utils.util import read_depth_png
+    depth = read_depth_png(DEPTH)
+    inst = instances(depth)
+    tiny = np.zeros(depth.shape, bool)
+    tiny[300:304, 150:156] = True                          # 24 pixels: fewer points than the 60-neighbour kNN needs
+    inst = inst + [("mug", tiny), ("can", np.zeros(depth.shape, bool))]
+    inst[1] = ("bowl", inst[1][1] | inst[2][1])            # overlapping masks: the label image carries both bits
+    nets = {}
+    for cat, src in (("mug", "mug"), ("laptop", "laptop"), ("bowl", "bottle"), ("can", "bottle")):
+        penc, enc = training.load_weights(os.path.join(GOLDEN, f"trained_{src}.npz"), CATEGORIES[src], dev)
+        nets[cat] = (enc, penc)
+    encs = {c: v[0] for c, v in nets.items()}
+    pencs = {c: v[1] for c, v in nets.items()}
+    want = frame_poses(depth, inst, encs, pencs, device=dev, seed=3)
+    assert want[6] is None and want[7] is None and all(w is not None for w in want[:6])
+    runner = FrameRunner(encs, pencs, dev)
+    for rep in range(4):                                   # solo graphs, chains captured, replayed, replayed
+        got = runner.run(depth, inst, seed=3)
+        assert len(runner._chains) == (0 if rep == 0 else 3)
+        for i, (w, g) in enumerate(zip(want, got)):
+            assert (w is None) == (g is None), (rep, i)
+            if w is None:
+                continue
+            assert g["n_points"] == w["n_points"] and g["argmax"] == w["argmax"] and g["n_surv"] == w["n_surv"], (rep, i)
+            for k in ("T", "up", "right", "scale", "R"):
+                assert np.array_equal(g[k], w[k]), (rep, i, k)
+            assert g["peak"] == w["peak"]
+    # the device stage against the oracle's pre-processing (member 0 of lane 0 still holds instance 0's cloud)
+    cat, m = inst[0]
+    cfg = CATEGORIES[cat]
+    pipe = next(p for (c_, cap, lane, slot, bit), (p, _) in runner._members.items() if bit == 0)
+    n = int(pipe.shape[0])
+    pts, _ = oracle.backproject(depth, NOCS_INTRINSICS, m)
+    p = pts / 1000.0
+    p = np.stack([-p[:, 0], -p[:, 1], p[:, 2]], -1)
+    keep = oracle.voxel_dedupe(p.astype(np.float32), cfg.res)
+    pc_want = p[keep].astype(np.float32)
+    assert n == len(keep) and np.array_equal(pipe.pc[:n].cpu().numpy(), pc_want)
+    assert np.array_equal(pipe.nrm[:n].cpu().numpy(), oracle.estimate_normals(pc_want, oracle.knn(pc_want, cfg.knn)))
+    corners, dims = grid_shape(pc_want, cfg.res)
+    assert tuple(int(v) for v in pipe.shape[1:4].cpu()) == tuple(dims) and np.array_equal(pipe.corner.cpu().numpy(), corners[0])
+    # another frame (different seed = different pairs): the captured chains read the new draws
+    got2 = runner.run(depth, inst, seed=4)
+    want2 = frame_poses(depth, inst, encs, pencs, device=dev, seed=4)
+    for w, g in zip(want2, got2):
+        assert (w is None) == (g is None) and (w is None or (g["argmax"] == w["argmax"] and np.array_equal(g["up"], w["up"])))
+    assert any(a is not None and b is not None and a["n_surv"] != b["n_surv"] for a, b in zip(got, got2))
