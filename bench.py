@@ -1070,7 +1070,7 @@ def main():
                       "ms_per_instance_incl_preprocessing": t_rf, "ms_per_instance_min_max": mm_rf,
                       "path": "FrameRunner: depth + one label image uploaded per frame, per-instance pre-processing count-driven on the "
                               "device (cppf_frame_cloud_dyn) at the head of captured chains, one read-back per frame",
-                      "eager_loop_ms_per_instance": t_rf_e, "eager_loop_min_max": mm_rf_e, "poses_equal_eager_loop": bool(same),
+                      "served_by": dict(frunner.last), "eager_loop_ms_per_instance": t_rf_e, "eager_loop_min_max": mm_rf_e, "poses_equal_eager_loop": bool(same),
                       "n_surv": [int(p_["n_surv"]) for p_ in poses_f]}
 
     # secondary: centre vote + the whole pose tail on known-answer inputs, where (nearly) every pair survives the back-vote

@@ -148,16 +148,32 @@ __global__ __launch_bounds__(256) void fc_valid_kernel(const T* __restrict__ dep
 // back-projection of the compacted pixels (bp_points_kernel's arithmetic), nocs/inference.py:132 `pc = pts / 1000.0` (fp64), the axis
 // flips of :136-137 (negations of utils/util.py:629-630's negations: exact), `.float()` of :140 -- and the voxel key of every slot:
 // slots beyond the count get the all-ones key, which sorts behind every real one
+// Voxel de-duplication without a sort (rocprim's radix sort inside a captured graph gave different results from the second
+// replay on: ROCm 7.2): an open-addressing table of M = 2^m >= 2 n_cap slots {voxel key, lowest point index}.  Every point inserts
+// its key (atomicCAS on the key word, linear probing) and atomicMin's its index into the slot; a point represents its voxel iff it
+// IS that minimum -- cppf_voxel_dedupe's definition (lowest index per voxel, output in index order), whatever order the atomics land in.
+#define FC_EMPTY (~0ull)
+__device__ __forceinline__ unsigned fc_hash(unsigned long long k, unsigned mask)
+{
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return (unsigned)k & mask;
+}
+__global__ __launch_bounds__(256) void fc_clear_kernel(unsigned long long* __restrict__ tkeys, int32_t* __restrict__ tidx, int M)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < M) { tkeys[i] = FC_EMPTY; tidx[i] = 0x7fffffff; }
+}
+// back-projection of the compacted pixels (bp_points_kernel's arithmetic), nocs/inference.py:132 `pc = pts / 1000.0` (fp64), the axis
+// flips of :136-137 (negations of utils/util.py:629-630's negations: exact), `.float()` of :140, the voxel key (vox_keys_kernel) and
+// the point's entry in the table
 template <typename T>
 __global__ __launch_bounds__(256) void fc_points_kernel(const T* __restrict__ depth, const int32_t* __restrict__ pix,
                                                         const int32_t* __restrict__ count, int W, Kinv K, double divisor, double res,
                                                         int n_cap, float* __restrict__ pcf, unsigned long long* __restrict__ keys,
-                                                        int32_t* __restrict__ vals)
+                                                        unsigned long long* __restrict__ tkeys, int32_t* __restrict__ tidx, unsigned tmask)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_cap) return;
-    vals[i] = i;
-    if (i >= min(*count, n_cap)) { keys[i] = ~0ull; return; }
+    if (i >= min(*count, n_cap)) return;
     const int p = pix[i];
     const double u = (double)(p % W), v = (double)(p / W), z = (double)depth[p];
     double xyz[3];
@@ -173,13 +189,25 @@ __global__ __launch_bounds__(256) void fc_points_kernel(const T* __restrict__ de
         k = (k << 21) | (unsigned long long)(q & ((1 << 21) - 1));
     }
     keys[i] = k;
+    for (unsigned h = fc_hash(k, tmask);; h = (h + 1) & tmask) {
+        const unsigned long long prev = atomicCAS(&tkeys[h], FC_EMPTY, k);
+        if (prev == FC_EMPTY || prev == k) { atomicMin(&tidx[h], i); break; }
+    }
 }
-__global__ __launch_bounds__(256) void fc_mark_kernel(const unsigned long long* __restrict__ skeys, const int32_t* __restrict__ svals,
-                                                      const int32_t* __restrict__ count, int n_cap, uint8_t* __restrict__ mask)
+__global__ __launch_bounds__(256) void fc_mark_kernel(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ tkeys,
+                                                      const int32_t* __restrict__ tidx, unsigned tmask, const int32_t* __restrict__ count,
+                                                      int n_cap, uint8_t* __restrict__ mask)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= min(*count, n_cap)) return;
-    if (i == 0 || skeys[i] != skeys[i - 1]) mask[svals[i]] = 1;
+    if (i >= n_cap) return;
+    uint8_t m = 0;
+    if (i < min(*count, n_cap)) {
+        const unsigned long long k = keys[i];
+        unsigned h = fc_hash(k, tmask);
+        while (tkeys[h] != k) h = (h + 1) & tmask;      // (the key is in the table: this point put it there or found it there)
+        m = tidx[h] == i;
+    }
+    mask[i] = m;
 }
 // pc = pc[keep] (:141) into the pipeline's cloud buffer; the instance's point count N (0 when it is below k_min: the reference
 // skips such instances, :121-123) goes to shape[0], where the kernels behind this stage read it
@@ -253,26 +281,27 @@ __global__ __launch_bounds__(256) void mod_pairs_kernel(long long* __restrict__ 
     }
 }
 
-struct FcLayout { size_t valid, cmp1, pix, count, pcf, keys, vals, mask2, cmp2, keep, nbrs, temp, temp_bytes, total; };
+struct FcLayout { size_t valid, cmp1, pix, count, pcf, keys, tkeys, tidx, mask2, cmp2, keep, nbrs, total; int M; };
 FcLayout fc_layout(int H, int W, int n_cap, int k)
 {
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t n = (size_t)H * W;
     FcLayout L;
+    L.M = 256;
+    while (L.M < 2 * n_cap) L.M <<= 1;
     L.valid = 0;
     L.cmp1 = L.valid + up(n);
     L.pix = L.cmp1 + up(cppf_compact_workspace_bytes((int64_t)n));
     L.count = L.pix + up(n * sizeof(int32_t));
     L.pcf = L.count + 256;                                        // count1 at +0, count2 at +64
     L.keys = L.pcf + up((size_t)n_cap * 3 * sizeof(float));
-    L.vals = L.keys + up(2 * (size_t)n_cap * sizeof(unsigned long long));
-    L.mask2 = L.vals + up(2 * (size_t)n_cap * sizeof(int32_t));
+    L.tkeys = L.keys + up((size_t)n_cap * sizeof(unsigned long long));
+    L.tidx = L.tkeys + up((size_t)L.M * sizeof(unsigned long long));
+    L.mask2 = L.tidx + up((size_t)L.M * sizeof(int32_t));
     L.cmp2 = L.mask2 + up((size_t)n_cap);
     L.keep = L.cmp2 + up(cppf_compact_workspace_bytes(n_cap));
     L.nbrs = L.keep + up((size_t)n_cap * sizeof(int32_t));
-    L.temp = L.nbrs + up((size_t)n_cap * (size_t)k * sizeof(int32_t));
-    L.temp_bytes = up((size_t)48 * n_cap + (1u << 20));
-    L.total = L.temp + L.temp_bytes;
+    L.total = L.nbrs + up((size_t)n_cap * (size_t)k * sizeof(int32_t));
     return L;
 }
 
@@ -377,12 +406,12 @@ int cppf_frame_cloud_dyn(const void* depth, int depth_is_u16, const void* labels
     int32_t* pix = (int32_t*)(ws + L.pix);
     int32_t *count1 = (int32_t*)(ws + L.count), *count2 = (int32_t*)(ws + L.count + 64);
     float* pcf = (float*)(ws + L.pcf);
-    unsigned long long *keys = (unsigned long long*)(ws + L.keys), *skeys = keys + n_cap;
-    int32_t *vals = (int32_t*)(ws + L.vals), *svals = vals + n_cap;
+    unsigned long long *keys = (unsigned long long*)(ws + L.keys), *tkeys = (unsigned long long*)(ws + L.tkeys);
+    int32_t* tidx = (int32_t*)(ws + L.tidx);
     uint8_t* mask2 = (uint8_t*)(ws + L.mask2);
     int32_t *keep = (int32_t*)(ws + L.keep), *nbrs = (int32_t*)(ws + L.nbrs);
     const int nbp = (int)((n + 255) / 256), nbc = (n_cap + 255) / 256;
-    const unsigned bit = (unsigned)label_bit;
+    const unsigned bit = (unsigned)label_bit, tmask = (unsigned)L.M - 1u;
 #define FC_VALID(T)                                                                                                                       \
     do {                                                                                                                                  \
         if (label_bytes == 1) fc_valid_kernel<T, uint8_t><<<nbp, 256, 0, st>>>((const T*)depth, (const uint8_t*)labels, bit, n, valid);   \
@@ -395,18 +424,10 @@ int cppf_frame_cloud_dyn(const void* depth, int depth_is_u16, const void* labels
     if (rc) return rc;
     Kinv K;
     for (int i = 0; i < 9; ++i) K.k[i] = kinv_host[i];
-    if (depth_is_u16) fc_points_kernel<uint16_t><<<nbc, 256, 0, st>>>((const uint16_t*)depth, pix, count1, W, K, divisor, res, n_cap, pcf, keys, vals);
-    else fc_points_kernel<float><<<nbc, 256, 0, st>>>((const float*)depth, pix, count1, W, K, divisor, res, n_cap, pcf, keys, vals);
-    size_t need = 0;
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, need, keys, skeys, vals, svals, n_cap, 0, 64, st);
-    if (e != hipSuccess) return (int)e;
-    if (need > L.temp_bytes) return CPPF_EWORKSPACE;
-    need = L.temp_bytes;
-    e = hipcub::DeviceRadixSort::SortPairs(ws + L.temp, need, keys, skeys, vals, svals, n_cap, 0, 64, st);           // stable: lowest index first
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(mask2, 0, (size_t)n_cap, st);
-    if (e != hipSuccess) return (int)e;
-    fc_mark_kernel<<<nbc, 256, 0, st>>>(skeys, svals, count1, n_cap, mask2);
+    fc_clear_kernel<<<(L.M + 255) / 256, 256, 0, st>>>(tkeys, tidx, L.M);
+    if (depth_is_u16) fc_points_kernel<uint16_t><<<nbc, 256, 0, st>>>((const uint16_t*)depth, pix, count1, W, K, divisor, res, n_cap, pcf, keys, tkeys, tidx, tmask);
+    else fc_points_kernel<float><<<nbc, 256, 0, st>>>((const float*)depth, pix, count1, W, K, divisor, res, n_cap, pcf, keys, tkeys, tidx, tmask);
+    fc_mark_kernel<<<nbc, 256, 0, st>>>(keys, tkeys, tidx, tmask, count1, n_cap, mask2);
     rc = cppf_compact_mask(mask2, n_cap, keep, count2, ws + L.cmp2, cppf_compact_workspace_bytes(n_cap), stream);     // :140
     if (rc) return rc;
     fc_gather_kernel<<<nbc, 256, 0, st>>>(pcf, keep, count2, k_min, n_cap, pc_out, shape_out);                       // :141

@@ -17,6 +17,8 @@ def instance_cloud(depth_dev, intrinsics, mask, cfg, jitter=None):
     or device); jitter: f32[n_masked,3] standard-normal draws for :134 (None: no augmentation; the reference draws
     np.random.randn)."""
     pts, _ = backproject(depth_dev, intrinsics, mask, return_device=True)          # :131  (fp64, masked pixels with depth > 0)
+    if pts.shape[0] == 0:                                                          # (an empty mask: nothing to de-duplicate or fit)
+        return pts.float(), pts.float()
     pc = pts / 1000.0                                                              # :132
     if jitter is not None:                                                         # :134
         j = torch.as_tensor(jitter, dtype=torch.float64, device=pc.device)[:pc.shape[0]]
@@ -94,6 +96,7 @@ class FrameRunner:
         self.max_instances = 16                       # bits of the u16 label image
         self._members, self.max_members = OrderedDict(), int(max_members)
         self._chains, self._seen = OrderedDict(), {}
+        self._many_tile_cats = set()
         self._hw = None
         self._streams = [torch.cuda.Stream(device=device) for _ in range(self.n_lanes)]
         self._gen = torch.Generator(device=device)
@@ -111,12 +114,15 @@ class FrameRunner:
             self._chains.clear()
 
     def _member(self, cat, n_mask, lane, slot, bit):
-        """(pipeline, prestage) for an instance of `cat` with n_mask label pixels at this position"""
+        """(pipeline, prestage) for an instance of `cat` with n_mask label pixels at this position.  Grid class: few tiles (every
+        NOCS category at its own resolution on a tight mask) until an instance of the category came back with "shape beyond the
+        launch's capacities" -- from then on the category's pipelines are of the many-tile class (any grid of up to 64 tiles)."""
         from . import _lib
         from ._torch_util import stream_ptr
         from .inference import PosePipeline
         cap = max(self.cap_bucket, 1 << int(np.ceil(np.log2(max(n_mask, 1)))))
-        key = (cat, cap, lane, slot, bit)
+        many = cat in self._many_tile_cats
+        key = (cat, cap, lane, slot, bit, many)
         hit = self._members.get(key)
         if hit is not None:
             self._members.move_to_end(key)
@@ -128,7 +134,7 @@ class FrameRunner:
                 self._chains.pop(ck).release()
             old.release()
         cfg, H, W = self.cfgs[cat], self._hw[0], self._hw[1]
-        pipe = PosePipeline(self.encoders[cat], cfg, cap, self.n_pairs, False, self.device, self.sphere, num_rots=self.num_rots,
+        pipe = PosePipeline(self.encoders[cat], cfg, cap, self.n_pairs, many, self.device, self.sphere, num_rots=self.num_rots,
                             angle_tol=self.angle_tol, point_encoder=self.point_encoders[cat], dynamic=True)
         L = _lib.lib()
         ws = torch.empty(int(L.cppf_frame_cloud_workspace_bytes(H, W, cap, cfg.knn)), dtype=torch.uint8, device=self.device)
@@ -217,6 +223,7 @@ class FrameRunner:
             main.wait_stream(st)
         host, shp = raw.cpu().numpy(), shapes.cpu().numpy()             # the frame's one synchronisation
         eager = list(range(len(on_chain), n_inst))
+        self.last = {"captured": 0, "eager": len(eager), "skipped": 0}   # how the last frame's instances were served
         for ch, pipes, slots in ran:
             if ch is not None:
                 ch.adapt([host[i, 18] for i in slots])
@@ -225,10 +232,14 @@ class FrameRunner:
                     pipe.adapt(host[i, 18])
                 n = int(shp[i, 0])
                 if n == 0:
+                    self.last["skipped"] += 1
                     continue                                             # fewer points than the kNN needs: skipped (:121-123)
                 if host[i, 19] < 0:
-                    eager.append(i)                                      # the chain could not serve this shape
+                    eager.append(i)                                      # the chain could not serve this shape: a grid of >= 4 tiles
+                    self._many_tile_cats.add(instances[i][0])            # (the category's next pipelines are of the many-tile class)
+                    self.last["eager"] += 1
                     continue
+                self.last["captured"] += 1
                 pose = assemble_record(host[i], pipe.cfg)
                 pose.update(n_points=n, dims=tuple(int(v) for v in shp[i, 1:4]))
                 out[i] = pose

@@ -150,9 +150,10 @@ def test_frame_runner_equals_the_eager_loop(oracle, dev):
     want = frame_poses(depth, inst, encs, pencs, device=dev, seed=3)
     assert want[6] is None and want[7] is None and all(w is not None for w in want[:6])
     runner = FrameRunner(encs, pencs, dev)
-    for rep in range(4):                                   # solo graphs, chains captured, replayed, replayed
+    served = []
+    for rep in range(6):     # solo graphs (two instances need many-tile pipelines: eager this once), new members solo, chains captured, replays
         got = runner.run(depth, inst, seed=3)
-        assert len(runner._chains) == (0 if rep == 0 else 3)
+        served.append(dict(runner.last))
         for i, (w, g) in enumerate(zip(want, got)):
             assert (w is None) == (g is None), (rep, i)
             if w is None:
@@ -161,10 +162,14 @@ def test_frame_runner_equals_the_eager_loop(oracle, dev):
             for k in ("T", "up", "right", "scale", "R"):
                 assert np.array_equal(g[k], w[k]), (rep, i, k)
             assert g["peak"] == w["peak"]
+    # the union of two bowls and the laptop (res 1e-2 on a 0.5 m object) need >= 4 vote tiles: eager once, many-tile pipelines after
+    assert served[0] == {"captured": 4, "eager": 2, "skipped": 2} and runner._many_tile_cats == {"bowl", "laptop"}, served
+    assert all(s_ == {"captured": 6, "eager": 0, "skipped": 2} for s_ in served[1:]), served
+    assert len(runner._chains) == 3
     # the device stage against the oracle's pre-processing (member 0 of lane 0 still holds instance 0's cloud)
     cat, m = inst[0]
     cfg = CATEGORIES[cat]
-    pipe = next(p for (c_, cap, lane, slot, bit), (p, _) in runner._members.items() if bit == 0)
+    pipe = next(p for (c_, cap, lane, slot, bit, many), (p, _) in runner._members.items() if bit == 0)
     n = int(pipe.shape[0])
     pts, _ = oracle.backproject(depth, NOCS_INTRINSICS, m)
     p = pts / 1000.0
