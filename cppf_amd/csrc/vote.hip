@@ -1096,8 +1096,13 @@ __device__ __forceinline__ void v3_vote_body(const V3Args& A, const int bid)
             s0 = (int)(ra_in & 0xffu); l0 = (int)((ra_in >> 8) & 0xffu); s1 = (int)((ra_in >> 16) & 0xffu); l1 = (int)(ra_in >> 24);
             s2 = (int)(rb_in & 0xffu); l2 = (int)((rb_in >> 8) & 0xffu);
         }
-        const int cnt = n > 0 ? l0 + l1 + l2 : 0;
-        const int incl = wave_incl_scan(cnt);
+        // The walk's unit is a SLOT = two consecutive candidates of a lane's concatenated runs (round 5; one candidate before): a
+        // step pulls the source lane's frame ONCE for both -- thirteen ds_bpermute and the source / position bookkeeping were a
+        // third of a step's LDS time and a seventh of its VALU (profiles/r1_issue_microbench.txt: a ds_bpermute occupies the LDS
+        // pipe like three ds_read_b32) -- and deposits twice.  Only a lane's LAST slot can be half empty (odd candidate count).
+        const int cnt = n > 0 ? l0 + l1 + l2 : 0;          // candidates
+        const int slots = (cnt + 1) >> 1;
+        const int incl = wave_incl_scan(slots);
         const int total = __builtin_amdgcn_readlane(incl, 63);
         if (total > 0) {
             const unsigned long long nz = __ballot(cnt > 0);
@@ -1118,7 +1123,7 @@ __device__ __forceinline__ void v3_vote_body(const V3Args& A, const int bid)
 #pragma unroll
             for (int step = 32; step > 0; step >>= 1) src += (__shfl(incl, src + step - 1, 64) <= q0) ? step : 0;
             src = min(src, 63);
-            int k = q0 - (__shfl(incl, src, 64) - __shfl(cnt, src, 64));
+            int k = q0 - (__shfl(incl, src, 64) - __shfl(slots, src, 64));      // slot within the source lane
             struct Pulled { f3 cc, x, y; float prob; uint32_t a, b; int tab; };
             auto pull = [&](const int from) {
                 Pulled q;
@@ -1132,24 +1137,38 @@ __device__ __forceinline__ void v3_vote_body(const V3Args& A, const int bid)
                 return q;
             };
             // two steps per trip, the frames ping-ponging between `cur` and `nx` (a single-step loop copies the 13 pulled registers
-            // every step); each step requests the next step's frame (behind its own table read) before it deposits
+            // every step); each step requests the next step's frame (behind its own table reads) before it deposits
             auto step = [&](const int it, const Pulled& use, Pulled& next) {
                 const uint32_t a = use.a, b = use.b;
-                const int t1 = (int)((a >> 8) & 0xffu), t2 = (int)((a >> 16) & 0xffu);
-                const int toff = use.tab + (k << 3) + ((int)(b & 0xffffu) & -(int)(k >= t1)) + ((int)(b >> 16) & -(int)(k >= t2));
+                const int t1 = (int)((a >> 8) & 0xffu), t2 = (int)((a >> 16) & 0xffu), cn = (int)(a >> 24);
+                const int g1 = (int)(b & 0xffffu), g2 = (int)(b >> 16);
+                const int c0 = k << 1, c1 = c0 + 1;                     // the slot's candidates in the lane's concatenated runs
+                const int toff0 = use.tab + (c0 << 3) + (g1 & -(int)(c0 >= t1)) + (g2 & -(int)(c0 >= t2));
+                const int toff1 = use.tab + (c1 << 3) + (g1 & -(int)(c1 >= t1)) + (g2 & -(int)(c1 >= t2));
+                const bool live = it < mine, two = live && c1 < cn;
                 k += 1;
-                const bool adv = k >= (int)(a >> 24);
+                const bool adv = (k << 1) >= cn;
                 src = adv ? (int)(a & 0xffu) : src;
                 k = adv ? 0 : k;
-                float2 cs;
-                if (WIDE) cs = it < mine ? rot_cs((toff & 0xffff) >> 3, toff >> 16) : make_float2(1.f, 0.f);
-                else cs = *reinterpret_cast<const float2*>(ltab_b + (it < mine ? toff : 0));
+                float2 cs0, cs1;
+                if (WIDE) {
+                    cs0 = live ? rot_cs((toff0 & 0xffff) >> 3, toff0 >> 16) : make_float2(1.f, 0.f);
+                    cs1 = two ? rot_cs((toff1 & 0xffff) >> 3, toff1 >> 16) : make_float2(1.f, 0.f);
+                } else {
+                    cs0 = *reinterpret_cast<const float2*>(ltab_b + (live ? toff0 : 0));
+                    cs1 = *reinterpret_cast<const float2*>(ltab_b + (two ? toff1 : 0));
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 next = pull(src);
                 __builtin_amdgcn_sched_barrier(0);
-                if (it < mine) {
-                    const f3 offset = add3(scl3(use.x, cs.x), scl3(use.y, cs.y));      // :34
+                if (live) {
+                    const f3 offset = add3(scl3(use.x, cs0.x), scl3(use.y, cs0.y));    // :34
                     const f3 v = sub3(add3(use.cc, offset), cr);                       // numerator of :35
+                    v3_deposit(VT, v, use.prob);
+                }
+                if (two) {
+                    const f3 offset = add3(scl3(use.x, cs1.x), scl3(use.y, cs1.y));
+                    const f3 v = sub3(add3(use.cc, offset), cr);
                     v3_deposit(VT, v, use.prob);
                 }
             };
