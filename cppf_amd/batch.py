@@ -262,4 +262,4 @@ class BatchPoseRunner:
                 for pipe, slot in zip(pipes, slots):
                     pipe.adapt(host[slot, 18])
         local = torch.from_numpy(assemble_batch(host[:len(mine)], cfgs, mine, sharding.RECORD)).to(self.device)
-        return sharding.gather_records(local, len(objects), rank, world, self.device)
+        return sharding.gather_records(local, len(objects), rank, world, self.device, validate=False)   # (rows built in object order above)

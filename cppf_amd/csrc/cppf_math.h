@@ -94,6 +94,9 @@ __device__ __forceinline__ float inv_sqrt_rn(float x)
 __device__ __forceinline__ float det_exp2w(float l, float c)
 {
     const float y = fmaf(l, CPPF_LOG2E, c);
+#ifdef CPPF_PRICE_V_EXP   // pricing aid only (never in the shipped library): the hardware's 2^x (v_exp_f32, ~1 ulp,
+    return __builtin_amdgcn_exp2f(y);   // not reproducible on the host) instead of the exact polynomial: what bit-parity of the sampled bins costs
+#endif
     const float f = __builtin_amdgcn_fractf(y);          // min(y - floor(y), 0x1.fffffep-1f)
     const int e = (int)floorf(y);                        // v_cvt_flr_i32_f32 (selected under -fno-honor-nans: csrc/Makefile)
     float p = 1.353416778e-02f;

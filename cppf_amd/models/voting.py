@@ -31,7 +31,15 @@ def _as_device_tensor(a):
     outputs (grid_obj, output_ocs, candidates) land in the caller's memory.  Scalars and host objects pass through unchanged."""
     if isinstance(a, torch.Tensor) or not hasattr(a, "__cuda_array_interface__"):
         return a
-    return torch.as_tensor(a, device="cuda")
+    # (no device argument: torch reads the device of the pointer from the interface, so an array that lives on another GPU than
+    # the current one is wrapped where it is instead of being COPIED to the current device -- in-place outputs would land in a
+    # temporary and the caller's array stay zero)
+    t = torch.as_tensor(a)
+    ptr = a.__cuda_array_interface__["data"][0]
+    if not t.is_cuda or (t.numel() > 0 and t.data_ptr() != ptr):
+        raise ValueError("could not wrap the __cuda_array_interface__ array zero-copy (a strided or read-only view?): pass a "
+                         "C-contiguous device array")
+    return t
 
 
 class _Kernel:

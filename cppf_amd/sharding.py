@@ -11,6 +11,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import _lib
+
 RECORD = 20  # f64 per object: T[3] up[3] right[3] scale[3] argmax peak n_surv object_id + 4 spare
 
 
@@ -85,14 +87,15 @@ def _object_order(n_objects, world, device):
     return perm
 
 
-def gather_records(local_records, n_objects, rank, world, device=None, force_collective=None, validate=False):
+def gather_records(local_records, n_objects, rank, world, device=None, force_collective=None, validate=None):
     """The single end-of-batch collective.  local_records: f64[n_local, RECORD], row s = object `rank + s * world` (the order
     shard_objects() hands the objects out in; object id in column 15).  Returns f64[n_objects, RECORD] in object order on
     every rank (all_gather: the same cost as a gather at this size and every rank can continue with the poses).
 
     The layout is FIXED: every rank contributes ceil(n_objects / world) rows (unused ones zero), the result is the rank-major
     concatenation, and object j is row (j mod W) * n_max + j // W of it -- one index_select with a cached permutation, no
-    data-dependent filter, no sort, no host synchronisation.  `validate` re-checks the object ids on the host (tests).
+    data-dependent filter, no sort, no host synchronisation.  `validate` re-checks the object ids on the host (default: only on the
+    single-rank shortcut, which has no fixed layout to rely on).
     force_collective (default: CPPF_FORCE_DIST when a group exists): run the collective with a single rank too."""
     if force_collective is None:
         force_collective = forced() and dist.is_initialized()
@@ -101,6 +104,9 @@ def gather_records(local_records, n_objects, rank, world, device=None, force_col
         raise ValueError(f"rank {rank} holds {local_records.shape[0]} records, its share of {n_objects} objects is {n_local}")
     if world == 1 and not force_collective:
         out = local_records[:n_objects]
+        if validate is None:      # the shortcut re-orders nothing: records handed over in another order would come back as the poses of
+            validate = True       # other objects, so the ids are looked at here (one small read-back; callers that build the records in
+                                  # object order themselves -- BatchPoseRunner, bench.py -- pass validate=False)
     else:
         n_max = (n_objects + world - 1) // world
         out_dev = device if device is not None else local_records.device
@@ -155,6 +161,13 @@ def vote_sharded(pc, outputs, point_idxs, corner, dims, res, n_pairs_total, worl
     same call with world = 1 on the whole list.  quantum == 0 flags a launch that could not vote in integers."""
     from .models import voting
     dev = pc.device
+    # HARD LIMIT, checked before any collective runs (a rank that raised later would leave its peers waiting in the all-reduce):
+    # the integer image exists on the tiled vote only -- grids of up to 64 LDS tiles (1.9 M cells; every category of the reference
+    # at its resolution needs <= 16) and probs that are finite and non-negative.  Larger grids: vote unsharded (cppf_vote_argmax
+    # falls back to global fp32 atomics there) or coarsen `res`.
+    if int(_lib.lib().cppf_vote_tiles(int(dims[0]), int(dims[1]), int(dims[2]))) == 0:
+        raise _lib.CppfError(f"vote_sharded: a grid of {tuple(int(d) for d in dims)} cells needs more than 64 LDS tiles; the pair-sharded "
+                             "vote all-reduces the tiled vote's integer image and has no form for such grids")
     bits = voting.vote_fixed_point_bits(n_pairs_total, num_rots, dims)      # of the WHOLE list: safe for every slice
     raw = torch.empty(tuple(int(d) for d in dims), dtype=torch.int64, device=dev)
     quantum = torch.empty(1, dtype=torch.float32, device=dev)

@@ -25,7 +25,11 @@ def real2prob(val, max_val, num_bins):
 
 def targets(pc, normals, idx, center, R, half_extents, cfg):
     """utils/dataset.py:27-60 (generate_target) + :229-246 for an object whose centre / axes / half extents are known, as soft
-    bin distributions: (tr [P,2,tr_bins], rot [P,2,rot_bins], aux [P,2], scale [3]) on pc.device (pc in the WORLD frame)."""
+    bin distributions: (tr [P,2,tr_bins], rot [P,2,rot_bins], aux [P,2], scale [3]) on pc.device (pc in the WORLD frame).
+    generate_target's `right_sym` branch (utils/dataset.py:49-50) is not restated: every config of the reference leaves it False
+    (config/category/*.yaml), and a config that sets it is refused rather than silently trained without it."""
+    if getattr(cfg, "right_sym", False):
+        raise NotImplementedError("right_sym categories are not supported by cppf_amd.training.targets (no reference config uses them)")
     dev = pc.device
     c = torch.as_tensor(center, dtype=torch.float32, device=dev)
     Rm = torch.as_tensor(R, dtype=torch.float32, device=dev)

@@ -18,11 +18,23 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+ref = next((a for a in sys.argv[1:] if not a.startswith("--")), "/root/reference")
 out_dir = os.path.dirname(os.path.abspath(__file__))
 
 
+# Trust: the two FunctionDefs below are exec'd from the reference checkout with this user's privileges.  The checkout is untrusted
+# content, so the files are pinned by hash -- the versions that were read (functions are pure numpy / torch arithmetic) -- and a
+# modified checkout is refused (--trust-modified-reference overrides, for a reviewed upgrade of the reference).
+PINNED = {"utils/dataset.py": "5abbd20c0b137c9c5bf35997cda5eb210ab6e8017baba2537bb96d400c7035a6",
+          "utils/util.py": "d6b3854a81d35c3eb0139899f0e2a687095ba37e3294bcb084ec8f4e8d4dddf0"}
+
+
 def extract(path, name, env):
+    import hashlib
+    rel = os.path.relpath(path, ref)
+    digest = hashlib.sha256(open(path, "rb").read()).hexdigest()
+    if digest != PINNED.get(rel) and "--trust-modified-reference" not in sys.argv:
+        raise SystemExit(f"{rel}: sha256 {digest} is not the pinned version; refusing to exec code from it")
     tree = ast.parse(open(path).read())
     for node in tree.body:
         if isinstance(node, ast.FunctionDef) and node.name == name:
@@ -72,6 +84,7 @@ for tag, (up_sym, z_right, regress_right) in (("plain", (False, False, True)), (
                 f"{tag}.rot_soft": rot_soft.astype(np.float32), f"{tag}.scale": scale_t,
                 f"{tag}.loss": np.float64(loss.item()), f"{tag}.flags": np.array([up_sym, z_right, regress_right])})
 out["half_extents"] = half_extents
+out["reference_sha256"] = np.array([f"{k}:{v}" for k, v in sorted(PINNED.items())])      # which reference sources produced this file
 out["preds"] = preds.numpy()              # (the same seeded draw for every tag)
 np.savez_compressed(os.path.join(out_dir, "train_targets.npz"), **out)
 print("train_targets.npz written")

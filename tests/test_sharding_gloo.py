@@ -63,6 +63,8 @@ def test_shard_objects_round_robin():
     assert one[:, 15].tolist() == [0.0, 1.0, 2.0]
     with pytest.raises(AssertionError):
         sharding.gather_records(torch.stack([sharding.pack_record(j, _fake_pose(j)) for j in (2, 0, 1)]), 3, 0, 1, validate=True)
+    with pytest.raises(AssertionError):      # ... and by default on the single-rank shortcut: mis-ordered records are caught
+        sharding.gather_records(torch.stack([sharding.pack_record(j, _fake_pose(j)) for j in (2, 0, 1)]), 3, 0, 1)
     with pytest.raises(ValueError):
         sharding.gather_records(torch.zeros((1, sharding.RECORD), dtype=torch.float64), 3, 0, 1)
     perm = sharding._object_order(7, 3, torch.device("cpu")).tolist()      # rank-major rows -> object order
