@@ -862,7 +862,12 @@ def main():
 
     G_cells = int(np.prod(dims))
     tr_vote = [pmc_traffic("v3_vote_kernel<true>"), pmc_traffic("v3_reduce_kernel")]
-    tr_vote_w = [pmc_traffic("v3_vote_kernel<true>", "pmc_traffic_timed_width"), pmc_traffic("v3_reduce_kernel", "pmc_traffic_timed_width")]
+    # the timed regions' votes: with chains of B objects ONE vote + ONE reduce launch per chain (v3_*_batch_kernel): per-launch bytes / B
+    if m["mlp_batch"] > 1 and not args.no_vote_batch:
+        tr_vote_w = [pmc_traffic("v3_vote_batch_kernel", "pmc_traffic_timed_width"), pmc_traffic("v3_reduce_batch_kernel", "pmc_traffic_timed_width")]
+        tr_vote_w = [None if v is None else v / m["mlp_batch"] for v in tr_vote_w]
+    else:
+        tr_vote_w = [pmc_traffic("v3_vote_kernel<true>", "pmc_traffic_timed_width"), pmc_traffic("v3_reduce_kernel", "pmc_traffic_timed_width")]
     alg_bytes = 24 * P + 4 * G_cells          # (mu, nu) 8 B + int64 pair 16 B read per pair, the grid written once
     vote_roofline = {"bound": "lds_atomics", "kernel": "v3_vote_kernel<true> (+ v3_reduce_kernel in the time)", "unit": "T lane-atomics/s",
                      "peak": PEAK_LDS_ATOMICS,
@@ -870,7 +875,9 @@ def main():
                      "traffic": (tr_vote[0] + tr_vote[1]) if all(tr_vote) else None, "algorithmic_bytes": alg_bytes,
                      "traffic_ratio": ((tr_vote[0] + tr_vote[1]) / alg_bytes) if all(tr_vote) else None,
                      # the timed regions launch the vote `vote_workgroups` wide (half the partial tiles at 128): their own PMC passes
-                     "traffic_timed_regions": ({"vote_workgroups": objs[0]["pipe"].vote_workgroups, "bytes": tr_vote_w[0] + tr_vote_w[1],
+                     "traffic_timed_regions": ({"vote_workgroups_per_object": m.get("vote_batch_workgroups") or objs[0]["pipe"].vote_workgroups,
+                                                "launch": "v3_vote_batch_kernel + v3_reduce_batch_kernel, per object" if m["mlp_batch"] > 1 and not args.no_vote_batch
+                                                else "v3_vote_kernel<true> + v3_reduce_kernel", "bytes": tr_vote_w[0] + tr_vote_w[1],
                                                 "ratio": (tr_vote_w[0] + tr_vote_w[1]) / alg_bytes} if all(tr_vote_w) else None),
                      "note": "the vote is bound by LDS read-modify-writes, not by HBM or MFMA (SURVEY.md 8d): achieved = samples that land in "
                              "the grid x 8 trilinear corners (one returning ds_add_u32 each) / time of vote + reduce kernels (HIP events "

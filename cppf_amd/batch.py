@@ -238,9 +238,7 @@ class BatchPoseRunner:
                     if not on_device:
                         pipe.load(None, None, None, obj["point_idxs"], obj["u_tr"], obj["u_rot"], None)
                     else:
-                        gen = torch.Generator(device=self.device)
-                        gen.manual_seed(int(seed) * 1000003 + j)
-                        pipe.sample_inputs(gen, n_points=obj["pc"].shape[0])
+                        pipe.sample_inputs(int(seed) * 1000003 + j, n_points=obj["pc"].shape[0])      # a function of (seed, object index)
                     pipes.append(pipe)
                     cfgs.append(obj["cfg"])
                 chain = self._chain_for(pipes)

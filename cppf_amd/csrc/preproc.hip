@@ -305,6 +305,36 @@ FcLayout fc_layout(int H, int W, int n_cap, int k)
     return L;
 }
 
+// ---- pair list + bin uniforms drawn on the device (cppf_sample_pairs): Philox-4x32-10 (Salmon et al., SC'11), counter = pair index,
+// key = the caller's 64-bit seed; stateless, so a pair's draw depends on (seed, pair index) only -- whichever rank or stream draws it.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c.x, p1 = (unsigned long long)0xCD9E8D57u * c.z;
+        c = make_uint4((unsigned)(p1 >> 32) ^ c.y ^ k.x, (unsigned)p1, (unsigned)(p0 >> 32) ^ c.w ^ k.y, (unsigned)p0);
+        k.x += 0x9E3779B9u; k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+__global__ __launch_bounds__(256) void sample_pairs_kernel(long long* __restrict__ idx, float* __restrict__ u_tr, float* __restrict__ u_rot,
+                                                           int64_t P, int64_t n_points, const int32_t* __restrict__ n_dev,
+                                                           unsigned long long seed)
+{
+    const unsigned long long N = (unsigned long long)(n_dev ? (int64_t)*n_dev : n_points);
+    const uint2 key = make_uint2((unsigned)seed, (unsigned)(seed >> 32));
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (int64_t)gridDim.x * 256) {
+        const uint4 a = philox4x32_10(make_uint4((unsigned)p, (unsigned)(p >> 32), 0u, 0u), key);
+        const uint4 b = philox4x32_10(make_uint4((unsigned)p, (unsigned)(p >> 32), 1u, 0u), key);
+        // index = floor(r N / 2^32): uniform over [0, N) up to a bias of N / 2^32 (np.random.randint(0, N, (P, 2)), nocs/inference.py:177)
+        reinterpret_cast<longlong2*>(idx)[p] = make_longlong2((long long)(((unsigned long long)a.x * N) >> 32),
+                                                              (long long)(((unsigned long long)a.y * N) >> 32));
+        // uniforms in [0, 1): the top 24 bits (stand-ins for torch.multinomial's draws, :186,250,254)
+        if (u_tr) reinterpret_cast<float2*>(u_tr)[p] = make_float2((float)(a.z >> 8) * 0x1p-24f, (float)(a.w >> 8) * 0x1p-24f);
+        if (u_rot) reinterpret_cast<float2*>(u_rot)[p] = make_float2((float)(b.x >> 8) * 0x1p-24f, (float)(b.y >> 8) * 0x1p-24f);
+    }
+}
+
 struct VoxLayout { size_t keys, vals, mask, compact, temp, temp_bytes, total; };
 VoxLayout vox_layout(int64_t N)
 {
@@ -435,6 +465,17 @@ int cppf_frame_cloud_dyn(const void* depth, int depth_is_u16, const void* labels
     if (rc) return rc;
     fc_normals_kernel<<<nbc, 256, 0, st>>>(pc_out, nbrs, shape_out, knn_k, nrm_out);
     fc_grid_kernel<<<1, 1024, 0, st>>>(pc_out, (float)res, corner_out, shape_out);                                    // :194-195
+    return (int)hipGetLastError();
+}
+
+int cppf_sample_pairs(long long* idx, float* u_tr, float* u_rot, int64_t n_pairs, int64_t n_points, const int32_t* n_dev,
+                      unsigned long long seed, void* stream)
+{
+    if (n_pairs < 0 || (n_pairs > 0 && !idx) || (!n_dev && (n_points < 1 || n_points > 0x7fffffffll))) return CPPF_EINVAL;
+    if (n_pairs == 0) return 0;
+    int64_t nb = (n_pairs + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    sample_pairs_kernel<<<(int)nb, 256, 0, (hipStream_t)stream>>>(idx, u_tr, u_rot, n_pairs, n_points, n_dev, seed);
     return (int)hipGetLastError();
 }
 

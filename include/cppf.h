@@ -627,6 +627,13 @@ size_t cppf_frame_cloud_workspace_bytes(int H, int W, int n_cap, int knn_k);
 int cppf_frame_cloud_dyn(const void* depth, int depth_is_u16, const void* labels, int label_bytes, int label_bit, int H, int W,
                          const double* kinv_host, double divisor, double res, int knn_k, int k_min, int n_cap, float* pc_out,
                          float* nrm_out, float* corner_out, int32_t* shape_out, void* workspace, size_t workspace_bytes, void* stream);
+/* Pair list and bin uniforms drawn on the device -- the reference draws the pairs with np.random.randint(0, N, (P, 2)) on the host
+ * (nocs/inference.py:177: 8 MB per instance at C2 over PCIe) and the bins with torch.multinomial (:186,250,254).  idx device
+ * i64[n_pairs,2] uniform over [0, N); u_tr / u_rot device f32[n_pairs,2] uniform over [0, 1) (either may be NULL).  N = n_points, or
+ * *n_dev (device i32) when n_dev != NULL.  Philox-4x32-10 keyed by `seed`, counter = pair index: the draw of a pair is a function of
+ * (seed, pair index) alone.  Same distributions as the reference's generators, not the same numbers (parity tests pass arrays). */
+int cppf_sample_pairs(long long* idx, float* u_tr, float* u_rot, int64_t n_pairs, int64_t n_points, const int32_t* n_dev,
+                      unsigned long long seed, void* stream);
 int cppf_mod_pairs_dyn(long long* idx, int64_t n_pairs, const int32_t* n_dev, void* stream);
 size_t cppf_backproject_workspace_bytes(int H, int W);
 int cppf_backproject(const void* depth, int depth_is_u16, const uint8_t* mask, int H, int W, const double* kinv_host,

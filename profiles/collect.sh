@@ -17,6 +17,10 @@ python $R/profiles/kstats.py $(find /tmp/kt -name '*.db' | head -1) > $OUT/kerne
 # default command three objects are in flight and a launch that shares the chip with a neighbour's head or tail lasts longer)
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt1 -- $BENCH --streams 1 --no-secondary > $OUT/bench_under_trace_one_stream.log 2>&1
 python $R/profiles/kstats.py $(find /tmp/kt1 -name '*.db' | head -1) > $OUT/kernel_trace_stats_one_stream.txt 2>&1
+# ... and the launches the timed regions really make (4 objects per chain: ONE pair-kernel launch, ONE vote + ONE reduce launch), one chain
+# at a time: the averages of pair_mlp_batch_kernel / v3_vote_batch_kernel here are what bench.py's roofline.launch_ms is about
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt4 -- $BENCH --streams 1 --mlp-batch 4 --vote-batch-workgroups 64 --no-secondary > $OUT/bench_under_trace_batch_one_stream.log 2>&1
+python $R/profiles/kstats.py $(find /tmp/kt4 -name '*.db' | head -1) > $OUT/kernel_trace_stats_batch_one_stream.txt 2>&1
 : > $OUT/pmc_counters.txt
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" \
@@ -30,11 +34,11 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_s
   python $R/profiles/pmcstats.py $f >> $OUT/pmc_counters.txt
 done
 python $R/profiles/make_traffic_json.py $OUT/pmc_counters.txt > $OUT/pmc_traffic.json
-# the same two traffic counters for the default command: its timed regions launch the vote 128 workgroups wide (three instances in flight)
+# the same two traffic counters for the default command: its timed regions vote 4 objects per launch, 64 workgroups each (three chains in flight)
 : > $OUT/pmc_counters_timed_width.txt
 for set in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc$i -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --regions 5 > /tmp/pmc$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc$i -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --regions 5 --vote-batch-workgroups 64 > /tmp/pmc$i.log 2>&1
   f=$(find /tmp/pmc$i -name '*counter_collection.csv' | head -1)
   python $R/profiles/pmcstats.py $f >> $OUT/pmc_counters_timed_width.txt
 done

@@ -6,11 +6,12 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out/final
 cd $R
 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 > gpurun_out/final/gputest.txt
-python bench.py --steps 20 --warmup 5 > gpurun_out/final/bench_default.json 2> gpurun_out/final/bench_default.err
-python bench.py --steps 20 --warmup 5 --all-heads --no-cpu-baseline > gpurun_out/final/bench_all_heads.json 2>/dev/null
-for c in c3 c5; do python bench.py --steps 20 --warmup 5 --config $c --no-cpu-baseline > gpurun_out/final/bench_$c.json 2>/dev/null; done
-python bench.py --config c4 --no-cpu-baseline > gpurun_out/final/bench_c4.json 2>/dev/null
-python bench.py --config c1 > gpurun_out/final/bench_c1.json 2>/dev/null
+python bench.py --steps 20 --warmup 5 --full-record gpurun_out/final/bench_default_full.json > gpurun_out/final/bench_default.json 2> gpurun_out/final/bench_default.err
+python bench.py --steps 20 --warmup 5 --all-heads --no-cpu-baseline --no-secondary --full-line --full-record "" > gpurun_out/final/bench_all_heads.json 2>/dev/null
+for c in c3 c5; do python bench.py --steps 20 --warmup 5 --config $c --no-cpu-baseline --no-secondary --full-line --full-record "" > gpurun_out/final/bench_$c.json 2>/dev/null; done
+python bench.py --config c4 --no-cpu-baseline --full-line --full-record "" > gpurun_out/final/bench_c4.json 2>/dev/null
+python bench.py --gpus 2 --no-cpu-baseline --no-secondary --full-record "" > gpurun_out/final/bench_gpus2_shared.json 2>/dev/null
+python bench.py --config c1 --full-line --full-record "" > gpurun_out/final/bench_c1.json 2>/dev/null
 bash profiles/collect.sh > gpurun_out/final/collect.log 2>&1
 cat gpurun_out/final/gputest.txt
 python - <<'PY'

@@ -119,3 +119,50 @@ def test_backproject_on_device_equals_oracle(oracle, golden, dev):
     _, keep = sparse_quantize(pc, return_index=True, quantization_size=0.004)
     ko = oracle.voxel_dedupe(pc.cpu().numpy(), 0.004)
     assert np.array_equal(keep.cpu().numpy() if hasattr(keep, "cpu") else keep, ko)
+
+
+def _philox4x32_10(c, k):
+    """numpy restatement of Philox-4x32-10 (Salmon et al., SC'11; the Random123 reference constants) on arrays of counters"""
+    c = [np.asarray(x, np.uint64) for x in c]
+    k0, k1 = np.uint64(k[0]), np.uint64(k[1])
+    M0, M1, W0, W1, lo = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [(p1 >> np.uint64(32)) ^ c[1] ^ k0, p1 & lo, (p0 >> np.uint64(32)) ^ c[3] ^ k1, p0 & lo]
+        k0, k1 = (k0 + W0) & lo, (k1 + W1) & lo
+    return c
+
+
+def test_device_pair_sampler_is_philox_and_uniform(dev):
+    """cppf_sample_pairs (the pair list of nocs/inference.py:177 and the stand-ins for torch.multinomial's draws, drawn on the device):
+    equal to a numpy Philox-4x32-10 keyed by the seed with counter = pair index -- so a pair's draw is a function of (seed, index)
+    alone --, indices uniform over [0, N), uniforms in [0, 1); N by value and from a device record"""
+    import torch
+    from cppf_amd import _lib
+    from cppf_amd._torch_util import stream_ptr
+    L = _lib.lib()
+    P, N, seed = 200003, 3001, 0x1234_5678_9ABC_DEF1
+    idx = torch.empty((P, 2), dtype=torch.int64, device=dev)
+    u = torch.empty((2, P, 2), dtype=torch.float32, device=dev)
+    _lib.check(L.cppf_sample_pairs(idx.data_ptr(), u[0].data_ptr(), u[1].data_ptr(), P, N, None, seed, stream_ptr(dev)), "sample")
+    p = np.arange(P, dtype=np.uint64)
+    key = (seed & 0xFFFFFFFF, seed >> 32)
+    a = _philox4x32_10([p, np.zeros_like(p), np.zeros_like(p), np.zeros_like(p)], key)
+    b = _philox4x32_10([p, np.zeros_like(p), np.ones_like(p), np.zeros_like(p)], key)
+    want_idx = np.stack([(a[0] * np.uint64(N)) >> np.uint64(32), (a[1] * np.uint64(N)) >> np.uint64(32)], -1).astype(np.int64)
+    f = lambda r: ((r >> np.uint64(8)).astype(np.float32) * np.float32(2.0 ** -24))
+    assert np.array_equal(idx.cpu().numpy(), want_idx)
+    assert np.array_equal(u[0].cpu().numpy(), np.stack([f(a[2]), f(a[3])], -1)) and np.array_equal(u[1].cpu().numpy(), np.stack([f(b[0]), f(b[1])], -1))
+    i, uu = idx.cpu().numpy(), u.cpu().numpy()
+    assert i.min() == 0 and i.max() == N - 1 and uu.min() >= 0.0 and uu.max() < 1.0
+    counts = np.bincount(i.reshape(-1), minlength=N)
+    chi2 = float(((counts - 2 * P / N) ** 2 / (2 * P / N)).sum())
+    assert abs(chi2 - N) < 6 * np.sqrt(2 * N), chi2                      # chi-square of a uniform draw: N +- sqrt(2N)
+    assert abs(uu.mean() - 0.5) < 2e-3 and abs(np.corrcoef(i[:, 0], i[:, 1])[0, 1]) < 0.01
+    # a shorter list is a prefix; another seed is another list; N from a device record
+    idx2 = torch.empty((1000, 2), dtype=torch.int64, device=dev)
+    nd = torch.tensor([N, 1, 1, 1], dtype=torch.int32, device=dev)
+    _lib.check(L.cppf_sample_pairs(idx2.data_ptr(), None, None, 1000, 1, nd.data_ptr(), seed, stream_ptr(dev)), "sample")
+    assert torch.equal(idx2, idx[:1000])
+    _lib.check(L.cppf_sample_pairs(idx2.data_ptr(), None, None, 1000, N, None, seed + 1, stream_ptr(dev)), "sample")
+    assert not torch.equal(idx2, idx[:1000])
