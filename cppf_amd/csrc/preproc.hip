@@ -421,7 +421,8 @@ size_t cppf_frame_cloud_workspace_bytes(int H, int W, int n_cap, int knn_k)
 
 int cppf_frame_cloud_dyn(const void* depth, int depth_is_u16, const void* labels, int label_bytes, int label_bit, int H, int W,
                          const double* kinv_host, double divisor, double res, int knn_k, int k_min, int n_cap, float* pc_out,
-                         float* nrm_out, float* corner_out, int32_t* shape_out, void* workspace, size_t workspace_bytes, void* stream)
+                         float* nrm_out, float* corner_out, int32_t* shape_out, int32_t* nbrs_out, void* workspace, size_t workspace_bytes,
+                         void* stream)
 {
     if (H < 1 || W < 1 || (int64_t)H * W > 0x7fffffffll || !depth || !labels || !kinv_host || !pc_out || !nrm_out || !corner_out || !shape_out)
         return CPPF_EINVAL;
@@ -439,7 +440,7 @@ int cppf_frame_cloud_dyn(const void* depth, int depth_is_u16, const void* labels
     unsigned long long *keys = (unsigned long long*)(ws + L.keys), *tkeys = (unsigned long long*)(ws + L.tkeys);
     int32_t* tidx = (int32_t*)(ws + L.tidx);
     uint8_t* mask2 = (uint8_t*)(ws + L.mask2);
-    int32_t *keep = (int32_t*)(ws + L.keep), *nbrs = (int32_t*)(ws + L.nbrs);
+    int32_t *keep = (int32_t*)(ws + L.keep), *nbrs = nbrs_out ? nbrs_out : (int32_t*)(ws + L.nbrs);
     const int nbp = (int)((n + 255) / 256), nbc = (n_cap + 255) / 256;
     const unsigned bit = (unsigned)label_bit, tmask = (unsigned)L.M - 1u;
 #define FC_VALID(T)                                                                                                                       \

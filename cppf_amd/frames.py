@@ -139,12 +139,17 @@ class FrameRunner:
         L = _lib.lib()
         ws = torch.empty(int(L.cppf_frame_cloud_workspace_bytes(H, W, cap, cfg.knn)), dtype=torch.uint8, device=self.device)
         dev, depth, labels, kinv = self.device, self._depth, self._labels, self.kinv
+        # the normals are fitted on the k = cfg.knn neighbour sets; a point encoder with the same k (config/config.yaml: 60 for both)
+        # reuses them instead of searching again (the stage writes them straight into the pipeline's neighbour buffer)
+        share = pipe.point_encoder is not None and pipe.point_encoder.k == cfg.knn
+        pipe.nbrs_ready = share
+        nbrs_ptr = pipe._nbrs.data_ptr() if share else None
 
         def prestage():
             with torch.cuda.device(dev):
                 _lib.check(L.cppf_frame_cloud_dyn(depth.data_ptr(), 1, labels.data_ptr(), 2, bit, H, W, kinv.ctypes.data, 1000.0,
                                                   float(cfg.res), cfg.knn, cfg.knn + 1, cap, pipe.pc.data_ptr(), pipe.nrm.data_ptr(),
-                                                  pipe.corner.data_ptr(), pipe.shape.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                  pipe.corner.data_ptr(), pipe.shape.data_ptr(), nbrs_ptr, ws.data_ptr(), ws.numel(),
                                                   stream_ptr(dev)), "cppf_frame_cloud_dyn")
                 _lib.check(L.cppf_mod_pairs_dyn(pipe.idx.data_ptr(), pipe.idx.shape[0], pipe.shape.data_ptr(), stream_ptr(dev)),
                            "cppf_mod_pairs_dyn")
@@ -183,8 +188,10 @@ class FrameRunner:
         labels[...] = 0
         counts = []
         for i in on_chain:
-            m = np.asarray(instances[i][1]) != 0
-            labels[m] |= np.uint16(1 << i)
+            m = np.asarray(instances[i][1])
+            if m.dtype != np.bool_:
+                m = m != 0
+            np.bitwise_or(labels, np.uint16(1 << i), out=labels, where=m)      # (no fancy indexing: 0.1 ms per 480 x 640 mask)
             counts.append(int(np.count_nonzero(m)))
         self._depth_host.numpy()[...] = depth.view(np.int16)
         main = torch.cuda.current_stream(dev)

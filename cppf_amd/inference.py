@@ -252,7 +252,8 @@ class CenterPipeline:
         shape = self.shape if self.dynamic else None
         if self.point_encoder is not None:                                    # nocs/inference.py:180-181, no N x N matrix
             if self.dynamic:
-                self.feat = self.point_encoder.forward_dyn(self.pc, self.nrm, shape, out=self._feat_out, nbrs=self._nbrs)
+                self.feat = self.point_encoder.forward_dyn(self.pc, self.nrm, shape, out=self._feat_out, nbrs=self._nbrs,
+                                                           nbrs_ready=getattr(self, "nbrs_ready", False))
             else:
                 self.feat = self.point_encoder(self.pc[None], self.nrm[None])[0]
         self.outputs, self.heads = self.encoder.forward_decode(
@@ -771,7 +772,8 @@ class PoseChain:
             if p.point_encoder is None:
                 feats.append(p.feat)
             elif p.dynamic:
-                feats.append(p.point_encoder.forward_dyn(p.pc, p.nrm, p.shape, out=p._feat_out, nbrs=p._nbrs))
+                feats.append(p.point_encoder.forward_dyn(p.pc, p.nrm, p.shape, out=p._feat_out, nbrs=p._nbrs,
+                                                         nbrs_ready=getattr(p, "nbrs_ready", False)))
             else:
                 feats.append(p.point_encoder(p.pc[None], p.nrm[None])[0])
         items = []

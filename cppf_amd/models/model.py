@@ -420,10 +420,12 @@ class PointEncoder(_DeviceWeights, nn.Module):
             self._image_rebuilt(dev)
         return self._packed
 
-    def forward_dyn(self, pc, pc_normal, n_dev, out=None, nbrs=None):
+    def forward_dyn(self, pc, pc_normal, n_dev, out=None, nbrs=None, nbrs_ready=False):
         """Shape-polymorphic forward for captured chains (cppf_knn_dyn + cppf_point_encoder_forward_dyn): pc / pc_normal are
         capacity-sized f32[n_cap,3] device tensors, `n_dev` a device i32 tensor whose first element is the number of valid
-        points (>= k: the caller's duty).  Rows >= n of the result are left untouched.  Returns f32[n_cap, out_dim + out_dim//4]."""
+        points (>= k: the caller's duty).  Rows >= n of the result are left untouched.  Returns f32[n_cap, out_dim + out_dim//4].
+        nbrs_ready: `nbrs` already holds the k-neighbour sets of the cloud (cppf_knn's output for the same k, e.g. left by
+        cppf_frame_cloud_dyn, which fits the normals on them): the search is not repeated."""
         require_cuda()
         n_cap = pc.shape[0]
         packed, desc = self._packed_weights(pc.device)
@@ -437,8 +439,9 @@ class PointEncoder(_DeviceWeights, nn.Module):
         ws = workspace(L.cppf_point_encoder_workspace_bytes(n_cap, desc["n_out"], desc["n_glob"], self.num_layers), pc.device,
                        "point_encoder")
         with torch.cuda.device(pc.device):
-            _lib.check(L.cppf_knn_dyn(pc.data_ptr(), n_cap, n_dev.data_ptr(), self.k, nbrs.data_ptr(), stream_ptr(pc.device)),
-                       "cppf_knn_dyn")
+            if not nbrs_ready:
+                _lib.check(L.cppf_knn_dyn(pc.data_ptr(), n_cap, n_dev.data_ptr(), self.k, nbrs.data_ptr(), stream_ptr(pc.device)),
+                           "cppf_knn_dyn")
             rc = L.cppf_point_encoder_forward_dyn(pc.data_ptr(), pc_normal.data_ptr(), nbrs.data_ptr(), n_cap, n_dev.data_ptr(),
                                                   self.k, packed.data_ptr(), hid, len(desc["hidden"]), desc["rank"],
                                                   desc["n_nbr_feats"], desc["n_out"], desc["n_glob"], self.num_layers,

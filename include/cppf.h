@@ -621,12 +621,15 @@ int cppf_point_encoder_forward_train(const float* pc, const float* nrm, const in
  * grid corner to corner_out f32[3] and the instance's shape record to shape_out i32[4] = {N, gx, gy, gz} -- what the *_dyn entry
  * points read.  N = 0 (and a 1x1x1 grid) when fewer than k_min points are left: the reference skips such instances (:121-123);
  * the *_dyn vote then reports arg-max -1.  n_cap >= the number of set label pixels (the caller counts them on the host) bounds
- * every buffer; rows >= N of pc_out / nrm_out are left untouched.  Results equal the four single calls on the same inputs, bit for
+ * every buffer; rows >= N of pc_out / nrm_out are left untouched.  nbrs_out (may be NULL): device i32[n_cap, knn_k] that receives the
+ * neighbour sets the normals were fitted on -- cppf_knn's output, which a point encoder with the same k can reuse instead of
+ * searching again (nocs/inference.py:180 computes the same cdist + topk).  Results equal the four single calls on the same inputs, bit for
  * bit.  cppf_mod_pairs_dyn: idx[i] <- idx[i] mod N for pairs drawn as full-range non-negative integers before N was known (:177). */
 size_t cppf_frame_cloud_workspace_bytes(int H, int W, int n_cap, int knn_k);
 int cppf_frame_cloud_dyn(const void* depth, int depth_is_u16, const void* labels, int label_bytes, int label_bit, int H, int W,
                          const double* kinv_host, double divisor, double res, int knn_k, int k_min, int n_cap, float* pc_out,
-                         float* nrm_out, float* corner_out, int32_t* shape_out, void* workspace, size_t workspace_bytes, void* stream);
+                         float* nrm_out, float* corner_out, int32_t* shape_out, int32_t* nbrs_out, void* workspace, size_t workspace_bytes,
+                         void* stream);
 /* Pair list and bin uniforms drawn on the device -- the reference draws the pairs with np.random.randint(0, N, (P, 2)) on the host
  * (nocs/inference.py:177: 8 MB per instance at C2 over PCIe) and the bins with torch.multinomial (:186,250,254).  idx device
  * i64[n_pairs,2] uniform over [0, N); u_tr / u_rot device f32[n_pairs,2] uniform over [0, 1) (either may be NULL).  N = n_points, or

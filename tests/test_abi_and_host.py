@@ -439,3 +439,65 @@ def test_bench_vote_width_rule():
     assert bench.vote_width(a, 100000, (20, 20, 20)) == 64       # never below 64
     assert bench.vote_width(types.SimpleNamespace(vote_workgroups=-1, streams=1)) == 0
     assert bench.vote_width(types.SimpleNamespace(vote_workgroups=200, streams=3)) == 200
+
+
+def test_round5_entry_points_host_logic_without_a_device():
+    """the batched entry points' plans and argument checks (no launches): pair-list plan, vote widths, frame stage workspace,
+    pair sampler / batched vote / batched tail argument errors, the fused vote's width-independent fixed-point bits"""
+    from cppf_amd import _lib
+    from cppf_amd.models.model import batch_plan
+    L = _lib.lib()
+    P = 524288
+    for n in (1, 2, 4, 8):            # equal lists: XCD-pinned, list i on XCDs [i per_xcd, (i + 1) per_xcd)
+        pl = batch_plan([P] * n)
+        assert pl["per_xcd"] == 8 // n and pl["grid"] % 8 == 0 and pl["wg_begin"][0] == 0 and pl["wg_begin"][-1] >= pl["grid"]
+    assert batch_plan([P] * 3)["per_xcd"] == 0 and batch_plan([P, P // 2])["per_xcd"] == 0 and batch_plan([P, P - P // 11])["per_xcd"] == 4
+    ragged = batch_plan([81920, 64, 100000])
+    assert ragged["per_xcd"] == 0 and all(b > a for a, b in zip(ragged["wg_begin"], ragged["wg_begin"][1:]))      # at least one each
+    with pytest.raises(_lib.CppfError):
+        batch_plan([0])
+    # vote widths of a batch: 256 / n, never below 64 (the width the fixed-point scale is chosen for), a hint overrides
+    assert [L.cppf_vote_batch_workgroups(n, 0) for n in (1, 2, 3, 4, 8)] == [256, 128, 85, 64, 64]
+    assert L.cppf_vote_batch_workgroups(4, 128 << 8) == 128 and L.cppf_vote_batch_workgroups(4, 32 << 8) == 64
+    assert L.cppf_vote_batch_workgroups(0, 0) == -1 and L.cppf_vote_batch_workgroups(9, 0) == -1
+    # the fused vote's bits do not depend on the launch width any more: the plan query (full width) says what a 64-wide launch uses
+    plan = (C.c_int32 * 10)()
+    assert L.cppf_vote_plan_query(P, 72, 26, 76, 26, plan) == 0 and plan[0] == 2 and plan[8] == 256 and plan[9] == 22
+    assert L.cppf_vote_fixed_point_bits(P, 72, 26, 76, 26) == 22 and L.cppf_vote_fixed_point_bits(65536, 72, 26, 76, 26) == 24
+    # argument errors before any HIP call
+    assert L.cppf_vote_argmax_batch(0, None, 72, 1, 0, None) == -1 and L.cppf_vote_argmax_batch(1, None, 72, 1, 0, None) == -1
+    it = (_lib.VoteItem * 1)()
+    assert L.cppf_vote_argmax_batch(1, C.cast(it, C.c_void_p), 0, 1, 0, None) == -1               # n_rots out of range
+    assert L.cppf_vote_argmax_batch(1, C.cast(it, C.c_void_p), 72, 1, 2, None) == -1              # unknown flag bit
+    dims = (C.c_int * 4)(84, 32, 32, 16)
+    assert L.cppf_pose_tail_batch(0, None, 40, dims, 3, 141, 32, 36, 72, None, None, 480, 1, 0.9, 10000, None) == -1
+    assert L.cppf_pair_mlp_decode_sel_batch(0, None, 40, dims, 3, 141, 32, 36, None) == -1
+    assert L.cppf_sample_pairs(None, None, None, 10, 100, None, 1, None) == -1 and L.cppf_sample_pairs(None, None, None, 0, 100, None, 1, None) == 0
+    assert L.cppf_mod_pairs_dyn(None, 0, None, None) == 0 and L.cppf_mod_pairs_dyn(None, 5, None, None) == -1
+    # the frame stage's workspace grows with the image and with the capacity; bad arguments are refused
+    w1, w2 = L.cppf_frame_cloud_workspace_bytes(480, 640, 4096, 60), L.cppf_frame_cloud_workspace_bytes(480, 640, 65536, 60)
+    assert 0 < w1 < w2 < (1 << 27) and L.cppf_frame_cloud_workspace_bytes(0, 640, 4096, 60) == 0
+    assert L.cppf_frame_cloud_dyn(None, 1, None, 2, 0, 480, 640, None, 1000.0, 0.004, 60, 61, 4096, None, None, None, None, None, None, 0, None) == -1
+
+
+def test_bench_compact_line_fits_the_drivers_tail():
+    """bench.py prints a compact line (< 4 KB) with the contract's fields and both rooflines; the full record goes to
+    bench_full.json.  Checked on the committed full record of this round's default run."""
+    import glob
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    recs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_default_full.json")))
+    if not recs:
+        pytest.skip("no committed full record yet")
+    full = json.load(open(recs[-1]))
+    line = bench.compact(full)
+    text = json.dumps(line)
+    assert len(text) < 4096, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["value"] == full["value"] and line["metric"] == bench.METRIC and "workload" in line["config"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"])
