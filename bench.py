@@ -1382,8 +1382,8 @@ def compact(out):
     line = {k_: out[k_] for k_ in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                    "vs_baseline", "dtype", "data") if k_ in out}
     cfg = dict(out["config"])
-    if len(cfg.get("workload", "")) > 420:
-        cfg["workload"] = cfg["workload"][:330] + " ... (full text: bench_full.json)"
+    if len(cfg.get("workload", "")) > 300:
+        cfg["workload"] = cfg["workload"][:240] + " ... (full text: bench_full.json)"
     line["config"] = cfg
     for k_ in ("pairs_per_ms_per_gpu", "regions", "region_ms_min_max", "median_ms_one_instance", "vote_workgroups", "mlp_batch", "vote_batch",
                "vote_batch_workgroups", "vote_batch_calibration_ms_per_step", "dist", "argmax_matches_oracle", "argmax_objects_matching_oracle", "argmax_steps_matching_oracle", "objects_per_s"):

@@ -27,6 +27,7 @@ static int v3_fixed_bits_bound(int64_t n_ppfs, int n_rots, int gx, int gy, int g
 static bool v3_eligible(int64_t n_ppfs, int n_rots, int gx, int gy, int gz);
 static size_t v3_workspace_bytes(int64_t n_ppfs, int gx, int gy, int gz);
 static size_t v3_workspace_bytes_dyn(int many_tiles, int64_t n_ppfs);
+static int v3_fused_tiles();
 // fixed-point bits of the largest weight in the tiled vote of this launch: exact for < 4 tiles; a LOWER bound for the binned path,
 // whose scale follows the queues' lengths (a finer quantum than reported, never a coarser one); 0: global fp32 atomics, no quantisation
 extern "C" int cppf_vote_fixed_point_bits(int64_t n_ppfs, int n_rots, int gx, int gy, int gz)
@@ -1541,7 +1542,7 @@ static int v3_fixed_bits_bound(int64_t n_ppfs, int n_rots, int gx, int gy, int g
 {
     const V3Tiling t = v3_tiling(gx, gy, gz);
     const int wgs = v3_wgs(n_ppfs, t.T);
-    if (t.T < 4) return v3_bits((unsigned)v3_fused_bits_pairs(n_ppfs, wgs / t.T, t.T), n_rots);   // (what v3_prepare passes)
+    if (t.T < v3_fused_tiles()) return v3_bits((unsigned)v3_fused_bits_pairs(n_ppfs, wgs / t.T, t.T), n_rots);   // (what v3_prepare passes)
     // binned: chunk <= W / E <= P T / (wgs - T) records (C_t = 1 + floor(n_t E / W) >= n_t E / W), and never more than a tile's queue (<= P)
     const int64_t E = wgs - t.T > 0 ? wgs - t.T : 1;
     const int64_t worst = min(n_ppfs, (n_ppfs * t.T + E - 1) / E + 1);
@@ -1568,8 +1569,8 @@ extern "C" int cppf_vote_plan_query(int64_t n_ppfs, int n_rots, int gx, int gy, 
     if (v3_eligible(n_ppfs, n_rots, gx, gy, gz)) {
         const V3Tiling t = v3_tiling(gx, gy, gz);
         int wgs = v3_wgs(n_ppfs, t.T);
-        if (t.T < 4) wgs = (wgs / t.T) * t.T;
-        const int o[10] = {t.T < 4 ? 2 : 3, t.T, t.tx, t.ty, t.ntx, t.nty, t.hx, t.hy, wgs, v3_fixed_bits_bound(n_ppfs, n_rots, gx, gy, gz)};
+        if (t.T < v3_fused_tiles()) wgs = (wgs / t.T) * t.T;
+        const int o[10] = {t.T < v3_fused_tiles() ? 2 : 3, t.T, t.tx, t.ty, t.ntx, t.nty, t.hx, t.hy, wgs, v3_fixed_bits_bound(n_ppfs, n_rots, gx, gy, gz)};
         for (int k = 0; k < 10; ++k) out[k] = o[k];
         return 0;
     }
@@ -1578,6 +1579,21 @@ extern "C" int cppf_vote_plan_query(int64_t n_ppfs, int n_rots, int gx, int gy, 
 
 // what cppf_vote_grid_raw adds to a vote: the exact integer image of the grid, its quantum, and bits fixed by the caller
 struct VoteExtras { long long* grid_raw; float* quantum_out; int fixed_bits; };
+
+// Grids of fewer than this many tiles take the fused kernel (every tile's workgroups cull and screen the pair list themselves),
+// the others bin first.  CPPF_FUSED_MAX_TILES (development knob, read once) moves the boundary for by-value launches; the queues'
+// room in the workspace is always sized for the default boundary, so the knob can only be RAISED.
+#define V3_FUSED_TILES 4
+static int v3_fused_tiles()
+{
+    static int v = 0;
+    if (v == 0) {
+        const char* e = getenv("CPPF_FUSED_MAX_TILES");
+        const int w = e ? atoi(e) : V3_FUSED_TILES;
+        v = w < V3_FUSED_TILES ? V3_FUSED_TILES : (w > VOTE_MAX_TILES + 1 ? VOTE_MAX_TILES + 1 : w);
+    }
+    return v;
+}
 
 struct V3Launch { V3Args A; int red_blocks, bps; };
 
@@ -1623,7 +1639,7 @@ static int v3_prepare(V3Launch& Lc, const float* points, const float* outputs, c
         A.t = v3_tiling(gx, gy, gz);
         A.wgs = v3_wgs(n_ppfs, A.t.T);
         if (A.wgs > wgs_max) A.wgs = wgs_max > A.t.T ? wgs_max : A.t.T;
-        A.fused = A.t.T < 4 ? 1 : 0;
+        A.fused = A.t.T < v3_fused_tiles() ? 1 : 0;
         if (A.fused) {   // static chunks: the same number for every tile
             A.wgs = (A.wgs / A.t.T) * A.t.T;
             A.kk = v3_bits((unsigned)v3_fused_bits_pairs(n_ppfs, A.wgs / A.t.T, A.t.T), n_rots);
@@ -1880,7 +1896,7 @@ extern "C" int cppf_vote_argmax_batch(int n_items, const CppfVoteItem* items, in
         if (batched && dyn) batched = !it.many_tiles && it.n_ppfs <= 0xffffffffll && it.grid_capacity >= 1 &&
                                       it.grid_capacity <= 3ll * V3_TILE_FLOATS && it.workspace_bytes >= v3_workspace_bytes_dyn(0, it.n_ppfs);
         if (batched && !dyn) batched = it.gx >= 1 && it.gy >= 1 && it.gz >= 1 && v3_eligible(it.n_ppfs, n_rots, it.gx, it.gy, it.gz) &&
-                                       v3_tiling(it.gx, it.gy, it.gz).T < 4 && it.workspace_bytes >= v3_workspace_bytes(it.n_ppfs, it.gx, it.gy, it.gz);
+                                       v3_tiling(it.gx, it.gy, it.gz).T < v3_fused_tiles() && it.workspace_bytes >= v3_workspace_bytes(it.n_ppfs, it.gx, it.gy, it.gz);
         if (!batched) {   // its own launches (and its own argument checks)
             const int rc = dyn ? cppf_vote_argmax_dyn(it.points, it.outputs, it.probs, it.point_idxs, it.idx_is_i64, it.grid, it.grid_capacity,
                                                       it.corner, it.res, it.n_points, it.n_ppfs, n_rots, it.shape_dev, it.many_tiles, adaptive,

@@ -35,10 +35,11 @@ def main():
     regime = sys.argv[2] if len(sys.argv) > 2 else "all"       # known-answer | uniform-bin
     dev = torch.device("cuda:0")
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    for name, (N, K, res) in (("c2", (4096, 128, None)), ("c5", (8192, 256, 2e-3))):
+    # c2posed: the C2 object in an arbitrary pose (a real scene's instances are not upright): a bounding box of 9-12 tiles
+    for name, (N, K, res) in (("c2", (4096, 128, None)), ("c5", (8192, 256, 2e-3)), ("c2posed", (4096, 128, None))):
         if which not in ("all", name):
             continue
-        ob = syn.make_object("bottle", N, 0)
+        ob = syn.make_posed_object("bottle", N, 900101, rotate=True) if name == "c2posed" else syn.make_object("bottle", N, 0)
         cfg = ob["cfg"]
         r = res or cfg.res
         idx = syn.make_pairs(N, K, 0)
