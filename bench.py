@@ -286,8 +286,12 @@ def make_stepper(dev, pipes, streams, res_buf, steps, B, vote_batch=True, vote_b
                 bp = batches[c % len(batches)]
                 with torch.cuda.stream(streams[(c % len(batches)) % S]):     # a batch always on the same stream: it never runs beside itself
                     bp.run(check_weights=c < len(batches))
-                    for q, p in enumerate(bp.pipes):
-                        res_buf[(c * B + q) % steps].copy_(p.result, non_blocking=True)
+                    lo = (c * B) % steps
+                    if lo + B <= steps:          # the chain's B result records in one copy (they sit side by side: bp.results)
+                        res_buf[lo:lo + B].copy_(bp.results, non_blocking=True)
+                    else:
+                        for q, p in enumerate(bp.pipes):
+                            res_buf[(c * B + q) % steps].copy_(p.result, non_blocking=True)
             j = (n // B) * B
         for k in range(j, n):
             with torch.cuda.stream(streams[k % S]):

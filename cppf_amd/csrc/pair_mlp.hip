@@ -345,9 +345,8 @@ __device__ __forceinline__ float ppf_from(f3 pa, f3 pb, f3 na, f3 nb, int g)
 // one fmaf chain per output in k order.  One block per PROJ_PPB points, a thread per column and PROJ_PPB / 2 points: a
 // weight is loaded once for the thread's points (one block per 2 points re-read the 20 KB of weights 2 048 times at N = 4096).
 #define PROJ_PPB 8
-__global__ __launch_bounds__(256) void point_proj_kernel(const float* __restrict__ feat,
-                                                         const float* __restrict__ packed, float* __restrict__ T,
-                                                         int64_t N)
+__device__ __forceinline__ void point_proj_body(const float* __restrict__ feat, const float* __restrict__ packed, float* __restrict__ T,
+                                                int64_t N)
 {
     __shared__ float f[PROJ_PPB][STD_F];
     const int half = threadIdx.x >> 7, r = threadIdx.x & 127;
@@ -372,6 +371,19 @@ __global__ __launch_bounds__(256) void point_proj_kernel(const float* __restrict
         const int64_t n = n0 + half + 2 * q;
         if (n < N) T[n * PROJ_COLS + r] = acc[q];
     }
+}
+__global__ __launch_bounds__(256) void point_proj_kernel(const float* __restrict__ feat, const float* __restrict__ packed,
+                                                         float* __restrict__ T, int64_t N)
+{
+    point_proj_body(feat, packed, T, N);
+}
+// the projections of several clouds in one launch (cppf_pair_mlp_decode_batch): cloud blockIdx.y; as wide as the largest needs
+struct ProjBatch { const float* feat[8]; const float* packed[8]; float* table[8]; int64_t N[8]; };
+__global__ __launch_bounds__(256) void point_proj_batch_kernel(ProjBatch B)
+{
+    const int i = blockIdx.y;
+    if ((int64_t)blockIdx.x * PROJ_PPB >= B.N[i]) return;
+    point_proj_body(B.feat[i], B.packed[i], B.table[i], B.N[i]);
 }
 
 // The kernel's body for workgroup `wg` of the `n_wg` that share the pair list of `A` (one launch = one list: wg = blockIdx.x of
@@ -1020,17 +1032,22 @@ extern "C" int cppf_pair_mlp_decode_batch(int n_items, const CppfPairMlpItem* it
         if (!it.workspace || it.workspace_bytes < (size_t)it.n_points * PROJ_COLS * sizeof(float)) return CPPF_EWORKSPACE;
     }
     batch_plan(n_items, n_pairs, B.wg_begin, &B.per_xcd, &given);
+    ProjBatch PJ = {};
+    int64_t proj_blocks = 1;
     for (int i = 0; i < n_items; ++i) {
         const CppfPairMlpItem& it = items[i];
         float* table = static_cast<float*>(it.workspace);
-        hipLaunchKernelGGL(point_proj_kernel, dim3((unsigned)((it.n_points + PROJ_PPB - 1) / PROJ_PPB)), dim3(256), 0, st, it.feat, it.packed,
-                           table, it.n_points);
-        CPPF_CHECK_LAUNCH();
+        PJ.feat[i] = it.feat; PJ.packed[i] = it.packed; PJ.table[i] = table; PJ.N[i] = it.n_points;
+        const int64_t nb = (it.n_points + PROJ_PPB - 1) / PROJ_PPB;
+        proj_blocks = nb > proj_blocks ? nb : proj_blocks;
         MlpArgs& A = B.item[i];
         A.pc = it.pc; A.nrm = it.nrm; A.feat = it.feat; A.idxs = it.idxs; A.packed = it.packed; A.P = it.n_pairs; A.out_dim = out_dim;
         A.idx64 = it.idx_is_i64; A.u_tr = it.u_tr; A.u_rot = it.u_rot; A.outputs = it.outputs; A.heads = it.heads;
         A.vr0 = it.vr0; A.vr1 = it.vr1; A.table = table;
     }
+    // the per-point projections of all lists in ONE launch (round 5: n launches of ~5 us each in front of the pair kernel before)
+    hipLaunchKernelGGL(point_proj_batch_kernel, dim3((unsigned)proj_blocks, (unsigned)n_items), dim3(256), 0, st, PJ);
+    CPPF_CHECK_LAUNCH();
     static bool attr_done[2] = {false, false};
     const void* fn = heads ? reinterpret_cast<const void*>(&pair_mlp_batch_kernel<true>) : reinterpret_cast<const void*>(&pair_mlp_batch_kernel<false>);
     if (!attr_done[heads]) {

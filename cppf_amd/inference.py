@@ -555,6 +555,16 @@ class CenterBatchPipeline:
         self.pipes, self.device = pipes, pipes[0].device
         self.vote_batch, self.vote_workgroups = bool(vote_batch), int(vote_workgroups or 0)
         self._use_graph, self._graph, self._images = use_graph, None, None
+        # the members' 16-byte result records side by side in ONE block (`results` u8[n,16]): a caller that logs every step moves
+        # a chain's results with one small copy; the members' `result` / `out_idx` / `out_val` become views into it (their own
+        # captured graphs, which wrote the old records, are dropped)
+        self.results = torch.zeros((len(pipes), 16), dtype=torch.uint8, device=self.device)
+        for i, p in enumerate(pipes):
+            p.result = self.results[i]
+            p.out_idx, p.out_val = p.result[:8].view(torch.int64), p.result[8:12].view(F32)
+            p._graph = None
+            if hasattr(p, "ws"):
+                p.ws.out_idx, p.ws.out_val = p.out_idx, p.out_val
 
     def _capture_key(self):
         """what the captured launches bake in besides the weight images: the vote widths and the members' buffers"""
