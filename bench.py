@@ -249,12 +249,20 @@ def vote_width(args, n_pairs=524288, dims=(26, 76, 26)):
 
 
 def mlp_batch(args, n_pairs=524288):
-    """objects per launch of the pair kernel in the timed regions: 4 with several instances in flight (1, 2, 4 or 8 lists of equal
-    length keep each list on its own XCDs: cppf_pair_mlp_decode_batch), 1 beyond a million pairs per object -- a launch's fixed
-    cost is under 2 % of it there and the longer chains overlap worse (C5: 0.449 against 0.441 ms per step)"""
+    """objects per launch of the pair kernel in the timed regions: 8 with several instances in flight up to C2's size, 4 up to a
+    million pairs (1, 2, 4 or 8 lists of equal length keep each list on its own XCDs: cppf_pair_mlp_decode_batch), 1 beyond -- a
+    launch's fixed cost is under 2 % of it there and the longer chains overlap worse (C5: 0.449 against 0.441 ms per step)"""
     if args.mlp_batch >= 1:
         return min(args.mlp_batch, 8)
-    return 4 if args.streams > 1 and not args.no_graph and n_pairs <= (1 << 20) else 1
+    if args.streams <= 1 or args.no_graph or n_pairs > (1 << 20):
+        return 1
+    # ... and never so long that a timed region of --steps steps holds fewer chains than streams (measured at C2: 20 steps per region
+    # 6.04 G pairs/s in chains of 4 against 5.74 in chains of 8 -- two chains and a remainder of 4 --, 50 steps 6.19 in chains of 8)
+    cap = max(1, args.steps // max(args.streams, 1))
+    B = 8 if n_pairs <= (1 << 19) else 4
+    while B > cap:
+        B //= 2
+    return max(B, 1)
 
 
 VOTE_BATCH_WIDTHS = (64, 96, 128)
@@ -275,6 +283,15 @@ def make_stepper(dev, pipes, streams, res_buf, steps, B, vote_batch=True, vote_b
     B = max(1, min(B, n_obj // S))      # at least one chain per stream (a captured chain does not run beside itself)
     batches = [CenterBatchPipeline(pipes[i:i + B], vote_batch=vote_batch, vote_workgroups=max(vote_batch_wgs, 0))
                for i in range(0, n_obj - n_obj % B, B)] if B > 1 else []
+    rem_chains = {}     # a remainder of r = n mod B steps: ONE shorter chain of the objects whose turn it is (built on first use)
+
+    def rem_chain(first, r):
+        key = (first, r)
+        if key not in rem_chains:
+            rem_chains[key] = CenterBatchPipeline([pipes[(first + q) % n_obj] for q in range(r)], vote_batch=vote_batch,
+                                                  vote_workgroups=batches[0].vote_workgroups, own_results=False)
+        rem_chains[key].vote_workgroups = batches[0].vote_workgroups
+        return rem_chains[key]
 
     def run(n):
         main = torch.cuda.current_stream(dev)
@@ -293,6 +310,14 @@ def make_stepper(dev, pipes, streams, res_buf, steps, B, vote_batch=True, vote_b
                         for q, p in enumerate(bp.pipes):
                             res_buf[(c * B + q) % steps].copy_(p.result, non_blocking=True)
             j = (n // B) * B
+            if n - j >= 2:            # the remainder as one shorter chain on the next stream in turn
+                c = n // B
+                with torch.cuda.stream(streams[(c % len(batches)) % S]):
+                    rc_ = rem_chain(j % n_obj, n - j)
+                    rc_.run(check_weights=False)
+                    for q, p in enumerate(rc_.pipes):
+                        res_buf[(j + q) % steps].copy_(p.result, non_blocking=True)
+                j = n
         for k in range(j, n):
             with torch.cuda.stream(streams[k % S]):
                 pipes[k % n_obj].run(check_weights=k < n_obj + j)

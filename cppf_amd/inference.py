@@ -544,7 +544,9 @@ class CenterBatchPipeline:
     members on one device, no point encoder in front, all with the rotation heads or none, the same num_rots / adaptive; up to 8.
     vote_workgroups: workgroups per object of the batched vote (None / 0: 256 / n, at least 32)."""
 
-    def __init__(self, pipes, use_graph=True, vote_batch=True, vote_workgroups=None):
+    def __init__(self, pipes, use_graph=True, vote_batch=True, vote_workgroups=None, own_results=True):
+        """own_results=False: the members keep the result records they have (a pipeline that is a member of a second, shorter
+        chain -- bench.py's remainder chains -- keeps the views the first chain gave it; `results` is then None)"""
         pipes = list(pipes)
         if not 1 <= len(pipes) <= 8:
             raise ValueError("1 to 8 pipelines per batch")
@@ -558,8 +560,8 @@ class CenterBatchPipeline:
         # the members' 16-byte result records side by side in ONE block (`results` u8[n,16]): a caller that logs every step moves
         # a chain's results with one small copy; the members' `result` / `out_idx` / `out_val` become views into it (their own
         # captured graphs, which wrote the old records, are dropped)
-        self.results = torch.zeros((len(pipes), 16), dtype=torch.uint8, device=self.device)
-        for i, p in enumerate(pipes):
+        self.results = torch.zeros((len(pipes), 16), dtype=torch.uint8, device=self.device) if own_results else None
+        for i, p in enumerate(pipes if own_results else []):
             p.result = self.results[i]
             p.out_idx, p.out_val = p.result[:8].view(torch.int64), p.result[8:12].view(F32)
             p._graph = None
@@ -568,7 +570,8 @@ class CenterBatchPipeline:
 
     def _capture_key(self):
         """what the captured launches bake in besides the weight images: the vote widths and the members' buffers"""
-        return (self.vote_batch, self.vote_workgroups) + tuple((p.vote_workgroups, p.idx.data_ptr(), p.grid.data_ptr()) for p in self.pipes)
+        return (self.vote_batch, self.vote_workgroups) + tuple((p.vote_workgroups, p.idx.data_ptr(), p.grid.data_ptr(), p.result.data_ptr())
+                                                               for p in self.pipes)
 
     def _chain(self):
         from .models.model import forward_decode_batch
