@@ -265,7 +265,7 @@ def mlp_batch(args, n_pairs=524288):
     return max(B, 1)
 
 
-VOTE_BATCH_WIDTHS = (64, 96, 128)
+VOTE_BATCH_WIDTHS = (64, 96, 128, 192)
 
 
 def make_stepper(dev, pipes, streams, res_buf, steps, B, vote_batch=True, vote_batch_wgs=0):
@@ -771,7 +771,7 @@ def main():
     ap.add_argument("--no-vote-batch", action="store_true", help="with --mlp-batch > 1: a vote + reduce launch per object (round 4's chain) "
                     "instead of ONE vote launch and ONE reduce launch for the objects of a chain (cppf_vote_argmax_batch)")
     ap.add_argument("--vote-batch-workgroups", type=int, default=-1, help="workgroups per object of the batched vote: 0 = 256 / objects per "
-                    "chain (at least 32); 32..256; -1 = calibrated during the warm-up (64 / 96 / 128 timed on the workload, fastest kept)")
+                    "chain (at least 32); 32..256; -1 = calibrated during the warm-up (64 / 96 / 128 / 192 timed on the workload, fastest kept)")
     ap.add_argument("--streams", type=int, default=3, help="instances in flight per GPU: step k runs on HIP stream k mod S "
                     "(1 = strictly one instance at a time)")
     ap.add_argument("--objects", type=int, default=9, help="distinct objects the steps rotate over (rounded up to a multiple of "
