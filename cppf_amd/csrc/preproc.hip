@@ -319,9 +319,10 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k)
 }
 __global__ __launch_bounds__(256) void sample_pairs_kernel(long long* __restrict__ idx, float* __restrict__ u_tr, float* __restrict__ u_rot,
                                                            int64_t P, int64_t n_points, const int32_t* __restrict__ n_dev,
-                                                           unsigned long long seed)
+                                                           unsigned long long seed, const unsigned long long* __restrict__ seed_dev)
 {
     const unsigned long long N = (unsigned long long)(n_dev ? (int64_t)*n_dev : n_points);
+    if (seed_dev) seed = *seed_dev;      // (a captured launch: the seed of this replay is in memory)
     const uint2 key = make_uint2((unsigned)seed, (unsigned)(seed >> 32));
     for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (int64_t)gridDim.x * 256) {
         const uint4 a = philox4x32_10(make_uint4((unsigned)p, (unsigned)(p >> 32), 0u, 0u), key);
@@ -470,13 +471,13 @@ int cppf_frame_cloud_dyn(const void* depth, int depth_is_u16, const void* labels
 }
 
 int cppf_sample_pairs(long long* idx, float* u_tr, float* u_rot, int64_t n_pairs, int64_t n_points, const int32_t* n_dev,
-                      unsigned long long seed, void* stream)
+                      unsigned long long seed, const unsigned long long* seed_dev, void* stream)
 {
     if (n_pairs < 0 || (n_pairs > 0 && !idx) || (!n_dev && (n_points < 1 || n_points > 0x7fffffffll))) return CPPF_EINVAL;
     if (n_pairs == 0) return 0;
     int64_t nb = (n_pairs + 255) / 256;
     if (nb > 4096) nb = 4096;
-    sample_pairs_kernel<<<(int)nb, 256, 0, (hipStream_t)stream>>>(idx, u_tr, u_rot, n_pairs, n_points, n_dev, seed);
+    sample_pairs_kernel<<<(int)nb, 256, 0, (hipStream_t)stream>>>(idx, u_tr, u_rot, n_pairs, n_points, n_dev, seed, seed_dev);
     return (int)hipGetLastError();
 }
 

@@ -29,16 +29,23 @@ def instance_cloud(depth_dev, intrinsics, mask, cfg, jitter=None):
     return pc, estimate_normals(pc, cfg.knn)                                       # :142
 
 
-def draw_pairs(gen, seed, i, n_pairs, dev, idx=None, u=None):
-    """The pair list and the bin uniforms of instance i of a frame, drawn on the device BEFORE the instance's point count N is known
-    to the host: full-range non-negative integers (reduced mod N where N is known: `idx % n` here, cppf_mod_pairs_dyn inside a
-    captured chain) and uniforms f32[2, n_pairs, 2] (stand-ins for torch.multinomial's draws, nocs/inference.py:186,250).  Same
-    distribution as np.random.randint(0, N, (n_pairs, 2)) (:177) up to a bias of N / 2^63."""
-    gen.manual_seed(int(seed) * 1000003 + int(i))
+def pair_seed(seed, i):
+    """the Philox key of instance i of a frame drawn with `seed`"""
+    return (int(seed) * 1000003 + int(i)) & 0x7FFFFFFFFFFFFFFF
+
+
+def draw_pairs(seed, i, n_pairs, dev, n_points, idx=None, u=None):
+    """The pair list of nocs/inference.py:177 (uniform over [0, n_points)) and the bin uniforms f32[2, n_pairs, 2] (stand-ins for
+    torch.multinomial's draws, :186,250) of instance i of a frame, drawn on the device by cppf_sample_pairs: a function of
+    (seed, i, pair index) alone, so the eager loop (N known on the host) and a captured chain (N in a device record, the seed in
+    device memory) draw the same numbers."""
+    from . import _lib
+    from ._torch_util import stream_ptr
     idx = torch.empty((n_pairs, 2), dtype=torch.int64, device=dev) if idx is None else idx
     u = torch.empty((2, n_pairs, 2), dtype=torch.float32, device=dev) if u is None else u
-    idx.random_(generator=gen)
-    u.uniform_(0.0, 1.0, generator=gen)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().cppf_sample_pairs(idx.data_ptr(), u[0].data_ptr(), u[1].data_ptr(), n_pairs, int(n_points), None,
+                                                pair_seed(seed, i), None, stream_ptr(dev)), "cppf_sample_pairs")
     return idx, u
 
 
@@ -51,7 +58,6 @@ def frame_poses(depth, instances, encoders, point_encoders, intrinsics=NOCS_INTR
     dev = device or torch.device("cuda", 0)
     d_dev = torch.from_numpy(np.ascontiguousarray(depth).view(np.int16)).to(dev)   # one upload per frame
     sphere = np.array(fibonacci_sphere(num_sphere_bins(angle_tol)))                # :100-102
-    gen = torch.Generator(device=dev)
     out = []
     for i, (cat, mask) in enumerate(instances):
         enc, penc, cfg = encoders[cat], point_encoders[cat], (cfgs or CATEGORIES)[cat]
@@ -60,8 +66,7 @@ def frame_poses(depth, instances, encoders, point_encoders, intrinsics=NOCS_INTR
         if n < cfg.knn + 1:
             out.append(None)
             continue
-        idx, u = draw_pairs(gen, seed, i if index_of is None else index_of[i], n_pairs, dev)     # :177, and the draws of :186,250
-        idx = idx % n
+        idx, u = draw_pairs(seed, i if index_of is None else index_of[i], n_pairs, dev, n)       # :177, and the draws of :186,250
         with torch.no_grad():
             feat = penc(pc[None], nrm[None])[0]                                    # :180-181
             pose = estimate_pose(enc, pc, nrm, feat, idx, u[0], u[1], cfg, sphere, num_rots=num_rots, angle_tol=angle_tol)
@@ -99,7 +104,8 @@ class FrameRunner:
         self._many_tile_cats = set()
         self._hw = None
         self._streams = [torch.cuda.Stream(device=device) for _ in range(self.n_lanes)]
-        self._gen = torch.Generator(device=device)
+        self._seeds_host = torch.zeros(16, dtype=torch.int64).pin_memory()        # the instances' Philox keys, uploaded with the frame
+        self._seeds = torch.zeros(16, dtype=torch.int64, device=device)
 
     def _frame_buffers(self, H, W):
         if self._hw != (H, W):
@@ -138,7 +144,7 @@ class FrameRunner:
                             angle_tol=self.angle_tol, point_encoder=self.point_encoders[cat], dynamic=True)
         L = _lib.lib()
         ws = torch.empty(int(L.cppf_frame_cloud_workspace_bytes(H, W, cap, cfg.knn)), dtype=torch.uint8, device=self.device)
-        dev, depth, labels, kinv = self.device, self._depth, self._labels, self.kinv
+        dev, depth, labels, kinv, seeds = self.device, self._depth, self._labels, self.kinv, self._seeds
         # the normals are fitted on the k = cfg.knn neighbour sets; a point encoder with the same k (config/config.yaml: 60 for both)
         # reuses them instead of searching again (the stage writes them straight into the pipeline's neighbour buffer)
         share = pipe.point_encoder is not None and pipe.point_encoder.k == cfg.knn
@@ -151,8 +157,9 @@ class FrameRunner:
                                                   float(cfg.res), cfg.knn, cfg.knn + 1, cap, pipe.pc.data_ptr(), pipe.nrm.data_ptr(),
                                                   pipe.corner.data_ptr(), pipe.shape.data_ptr(), nbrs_ptr, ws.data_ptr(), ws.numel(),
                                                   stream_ptr(dev)), "cppf_frame_cloud_dyn")
-                _lib.check(L.cppf_mod_pairs_dyn(pipe.idx.data_ptr(), pipe.idx.shape[0], pipe.shape.data_ptr(), stream_ptr(dev)),
-                           "cppf_mod_pairs_dyn")
+                # pairs and bin uniforms: N from the shape record the stage just wrote, the key from the frame's seed block
+                _lib.check(L.cppf_sample_pairs(pipe.idx.data_ptr(), pipe.u_tr.data_ptr(), pipe.u_rot.data_ptr(), pipe.idx.shape[0], 1,
+                                               pipe.shape.data_ptr(), 0, seeds.data_ptr() + 8 * bit, stream_ptr(dev)), "cppf_sample_pairs")
         pipe._frame_ws = ws
         self._members[key] = (pipe, prestage)
         return pipe, prestage
@@ -194,9 +201,11 @@ class FrameRunner:
             np.bitwise_or(labels, np.uint16(1 << i), out=labels, where=m)      # (no fancy indexing: 0.1 ms per 480 x 640 mask)
             counts.append(int(np.count_nonzero(m)))
         self._depth_host.numpy()[...] = depth.view(np.int16)
+        self._seeds_host.numpy()[:len(on_chain)] = [pair_seed(seed, i) for i in on_chain]
         main = torch.cuda.current_stream(dev)
-        self._depth.copy_(self._depth_host, non_blocking=True)          # one upload per frame (two images)
+        self._depth.copy_(self._depth_host, non_blocking=True)          # one upload per frame (two images + the seeds)
         self._labels.copy_(self._labels_host, non_blocking=True)
+        self._seeds.copy_(self._seeds_host, non_blocking=True)
         for cat in {instances[i][0] for i in on_chain}:
             self.encoders[cat]._packed_weights(dev)
             self.point_encoders[cat]._packed_weights(dev)
@@ -213,7 +222,6 @@ class FrameRunner:
                 pipes, pres = [], []
                 for q, i in enumerate(slots):
                     pipe, pre = self._member(instances[i][0], counts[i], lane, q, i)
-                    draw_pairs(self._gen, seed, i, self.n_pairs, dev, idx=pipe.idx, u=pipe._u)
                     pipes.append(pipe)
                     pres.append(pre)
                 ch = self._chain_for(pipes, pres)

@@ -729,7 +729,7 @@ class PosePipeline(CenterPipeline):
             seed = seed.initial_seed()
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().cppf_sample_pairs(self.idx.data_ptr(), self.u_tr.data_ptr(), self.u_rot.data_ptr(), self.idx.shape[0], n,
-                                                    None, int(seed) & 0xFFFFFFFFFFFFFFFF, stream_ptr(self.device)), "cppf_sample_pairs")
+                                                    None, int(seed) & 0xFFFFFFFFFFFFFFFF, None, stream_ptr(self.device)), "cppf_sample_pairs")
 
 
 class PoseChain:

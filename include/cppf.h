@@ -634,9 +634,10 @@ int cppf_frame_cloud_dyn(const void* depth, int depth_is_u16, const void* labels
  * (nocs/inference.py:177: 8 MB per instance at C2 over PCIe) and the bins with torch.multinomial (:186,250,254).  idx device
  * i64[n_pairs,2] uniform over [0, N); u_tr / u_rot device f32[n_pairs,2] uniform over [0, 1) (either may be NULL).  N = n_points, or
  * *n_dev (device i32) when n_dev != NULL.  Philox-4x32-10 keyed by `seed`, counter = pair index: the draw of a pair is a function of
- * (seed, pair index) alone.  Same distributions as the reference's generators, not the same numbers (parity tests pass arrays). */
+ * (seed, pair index) alone; seed_dev != NULL: the seed is read from device memory instead (a captured launch replayed with a new seed
+ * per frame).  With N = 0 every index is 0.  Same distributions as the reference's generators, not the same numbers (parity tests pass arrays). */
 int cppf_sample_pairs(long long* idx, float* u_tr, float* u_rot, int64_t n_pairs, int64_t n_points, const int32_t* n_dev,
-                      unsigned long long seed, void* stream);
+                      unsigned long long seed, const unsigned long long* seed_dev, void* stream);
 int cppf_mod_pairs_dyn(long long* idx, int64_t n_pairs, const int32_t* n_dev, void* stream);
 size_t cppf_backproject_workspace_bytes(int H, int W);
 int cppf_backproject(const void* depth, int depth_is_u16, const uint8_t* mask, int H, int W, const double* kinv_host,

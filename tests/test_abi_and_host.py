@@ -472,7 +472,7 @@ def test_round5_entry_points_host_logic_without_a_device():
     dims = (C.c_int * 4)(84, 32, 32, 16)
     assert L.cppf_pose_tail_batch(0, None, 40, dims, 3, 141, 32, 36, 72, None, None, 480, 1, 0.9, 10000, None) == -1
     assert L.cppf_pair_mlp_decode_sel_batch(0, None, 40, dims, 3, 141, 32, 36, None) == -1
-    assert L.cppf_sample_pairs(None, None, None, 10, 100, None, 1, None) == -1 and L.cppf_sample_pairs(None, None, None, 0, 100, None, 1, None) == 0
+    assert L.cppf_sample_pairs(None, None, None, 10, 100, None, 1, None, None) == -1 and L.cppf_sample_pairs(None, None, None, 0, 100, None, 1, None, None) == 0
     assert L.cppf_mod_pairs_dyn(None, 0, None, None) == 0 and L.cppf_mod_pairs_dyn(None, 5, None, None) == -1
     # the frame stage's workspace grows with the image and with the capacity; bad arguments are refused
     w1, w2 = L.cppf_frame_cloud_workspace_bytes(480, 640, 4096, 60), L.cppf_frame_cloud_workspace_bytes(480, 640, 65536, 60)

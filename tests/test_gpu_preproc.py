@@ -144,7 +144,7 @@ def test_device_pair_sampler_is_philox_and_uniform(dev):
     P, N, seed = 200003, 3001, 0x1234_5678_9ABC_DEF1
     idx = torch.empty((P, 2), dtype=torch.int64, device=dev)
     u = torch.empty((2, P, 2), dtype=torch.float32, device=dev)
-    _lib.check(L.cppf_sample_pairs(idx.data_ptr(), u[0].data_ptr(), u[1].data_ptr(), P, N, None, seed, stream_ptr(dev)), "sample")
+    _lib.check(L.cppf_sample_pairs(idx.data_ptr(), u[0].data_ptr(), u[1].data_ptr(), P, N, None, seed, None, stream_ptr(dev)), "sample")
     p = np.arange(P, dtype=np.uint64)
     key = (seed & 0xFFFFFFFF, seed >> 32)
     a = _philox4x32_10([p, np.zeros_like(p), np.zeros_like(p), np.zeros_like(p)], key)
@@ -162,7 +162,7 @@ def test_device_pair_sampler_is_philox_and_uniform(dev):
     # a shorter list is a prefix; another seed is another list; N from a device record
     idx2 = torch.empty((1000, 2), dtype=torch.int64, device=dev)
     nd = torch.tensor([N, 1, 1, 1], dtype=torch.int32, device=dev)
-    _lib.check(L.cppf_sample_pairs(idx2.data_ptr(), None, None, 1000, 1, nd.data_ptr(), seed, stream_ptr(dev)), "sample")
+    _lib.check(L.cppf_sample_pairs(idx2.data_ptr(), None, None, 1000, 1, nd.data_ptr(), seed, None, stream_ptr(dev)), "sample")
     assert torch.equal(idx2, idx[:1000])
-    _lib.check(L.cppf_sample_pairs(idx2.data_ptr(), None, None, 1000, N, None, seed + 1, stream_ptr(dev)), "sample")
+    _lib.check(L.cppf_sample_pairs(idx2.data_ptr(), None, None, 1000, N, None, seed + 1, None, stream_ptr(dev)), "sample")
     assert not torch.equal(idx2, idx[:1000])
