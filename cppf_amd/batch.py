@@ -23,8 +23,8 @@ from .utils.util import fibonacci_sphere, num_sphere_bins
 
 class BatchPoseRunner:
     def __init__(self, encoders, device, num_rots=72, adaptive=True, angle_tol=1.5, max_rot_pairs=10000,
-                 use_graph=True, point_encoders=None, n_bucket=1024, max_pipelines=24, dynamic=True, n_lanes=3,
-                 max_scratch_bytes=16 << 30, vote_workgroups=None, chain_len=None, max_chains=24):
+                 use_graph=True, point_encoders=None, n_bucket=1024, max_pipelines=192, dynamic=True, n_lanes=3,
+                 max_scratch_bytes=64 << 30, vote_workgroups=None, chain_len=None, max_chains=24):
         """encoders: {category name: PPFEncoder on `device`} (the reference keeps one per category,
         nocs/inference.py:79-90).  point_encoders: optional {category name: PointEncoder}; objects of those
         categories need no `feat` -- kNN + SPRIN run at the head of the captured graph (:180-181).
@@ -41,8 +41,13 @@ class BatchPoseRunner:
         neighbours in flight half the chip per vote moves more instances per second (profiles/r4_vote_workgroups.txt) -- and one
         workgroup per CU otherwise (longer pair lists, many-tile grids, a single lane).
         chain_len: instances whose launches are SHARED (inference.PoseChain: one pair-kernel launch, one vote + one reduce launch and
-        six tail launches for the whole chain instead of ~15 launches per instance).  None = the rank's instances split evenly over
-        the lanes, at most 8 per chain; 1 = every instance its own captured pipeline (round 4).  A chain is captured the SECOND time
+        six tail launches for the whole chain instead of ~15 launches per instance).  None = chains only when the batch is large
+        enough to keep every lane two chains deep -- min(8, instances / (2 n_lanes)) -- because a small batch is bounded by the host
+        staging it, and a chain cannot start before its last member is staged (measured on 8 / 16 / 32 / 64 C2-size objects:
+        no chains 0.189 / 0.163 / 0.164 / 0.158 ms per object, chains 0.193 / 0.164 / 0.161 / 0.140); 1 = every instance its own
+        captured pipeline (round 4).  A pipeline serves one (category, point bucket, pair count, grid class, lane, chain position):
+        `max_pipelines` / `max_scratch_bytes` bound the cache (a mixed batch of six categories in chains of 8 on 3 lanes wants up to
+        144 pipelines of ~0.1 GB at C2 size; a cache that is too small re-captures on every batch).  A chain is captured the SECOND time
         its combination of pipelines (category, point bucket, pair count, grid class per position) comes up -- a one-off combination
         runs its members' own graphs -- and at most `max_chains` captured chains are kept (least recently used first out)."""
         self.encoders, self.device = encoders, device
@@ -218,7 +223,7 @@ class BatchPoseRunner:
             st.wait_stream(main)
         checked = set()          # pipelines whose weight images were looked at in this batch (once is enough: nothing
         #                          updates parameters while run() is on the stack)
-        L = self.chain_len or max(1, min(8, -(-len(mine) // self.n_lanes)))
+        L = self.chain_len or max(1, min(8, len(mine) // (2 * self.n_lanes)))
         groups = [list(range(g, min(g + L, len(mine)))) for g in range(0, len(mine), L)]     # consecutive instances share a chain
         ran = []                 # (chain or None, pipelines, slots) per group, for adapt()
         for gi, slots in enumerate(groups):

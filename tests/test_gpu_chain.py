@@ -121,7 +121,7 @@ def test_runner_chains_equal_per_instance_runs(oracle, golden, dev):
         objects.append(dict(pc=ob["pc"], normals=ob["normals"], feat=ob["feat"], point_idxs=idx, u_tr=u_tr, u_rot=u_rot, cfg=ob["cfg"]))
     solo = BatchPoseRunner(encs, dev, chain_len=1)
     want = solo.run(objects).cpu().numpy()
-    runner = BatchPoseRunner(encs, dev)
+    runner = BatchPoseRunner(encs, dev, chain_len=3)  # (the default shares launches only from 2 x n_lanes instances per lane on)
     got1 = runner.run(objects).cpu().numpy()          # first sighting: the members' own graphs
     assert not runner._chains
     got2 = runner.run(objects).cpu().numpy()          # second: chains captured
@@ -135,6 +135,10 @@ def test_runner_chains_equal_per_instance_runs(oracle, golden, dev):
     for rep in range(3):
         np.testing.assert_array_equal(runner.run(objs2).cpu().numpy(), w2)
     sph = golden("sphere.npz")["pts"]
+    auto = BatchPoseRunner(encs, dev)                 # 8 instances on 3 lanes: no chains by default, same records
+    np.testing.assert_array_equal(auto.run(objects).cpu().numpy(), want)
+    np.testing.assert_array_equal(auto.run(objects).cpu().numpy(), want)
+    assert not auto._chains
     for j in (0, 5):
         obj = objects[j]
         o = oracle.estimate_pose(obj["pc"], obj["normals"], obj["feat"], obj["point_idxs"], sd, ocfg_of(obj["cfg"]), obj["u_tr"], obj["u_rot"], sph)
