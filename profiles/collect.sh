@@ -29,7 +29,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_s
   i=$((i+1))
   # (--vote-workgroups 0: every kernel at its full width, one workgroup per CU -- the launches bench.py's stage timings and
   #  rooflines are about; the timed regions' narrower vote is counted separately below)
-  timeout 600 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc$i -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --regions 5 --vote-workgroups 0 > /tmp/pmc$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc$i -- python $R/bench.py --steps 12 --mlp-batch 4 --warmup 2 --no-cpu-baseline --no-secondary --regions 5 --vote-workgroups 0 > /tmp/pmc$i.log 2>&1
   f=$(find /tmp/pmc$i -name '*counter_collection.csv' | head -1)
   python $R/profiles/pmcstats.py $f >> $OUT/pmc_counters.txt
 done
@@ -38,7 +38,7 @@ python $R/profiles/make_traffic_json.py $OUT/pmc_counters.txt > $OUT/pmc_traffic
 : > $OUT/pmc_counters_timed_width.txt
 for set in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc$i -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --regions 5 --vote-batch-workgroups 64 > /tmp/pmc$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc$i -- python $R/bench.py --steps 12 --mlp-batch 4 --warmup 2 --no-cpu-baseline --no-secondary --regions 5 --vote-batch-workgroups 64 > /tmp/pmc$i.log 2>&1
   f=$(find /tmp/pmc$i -name '*counter_collection.csv' | head -1)
   python $R/profiles/pmcstats.py $f >> $OUT/pmc_counters_timed_width.txt
 done

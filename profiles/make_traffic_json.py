@@ -15,7 +15,8 @@ for line in open(sys.argv[1]):
         kernel = line.strip()
 names = {"point_proj_kernel": "point_proj_kernel", "pair_mlp_kernel<false, true, true, false>": "pair_mlp_kernel<false, true, true>",
          "pair_mlp_kernel<false, true, false, false>": "pair_mlp_kernel<false, true, false>",
-         "pair_mlp_batch_kernel<false>": "pair_mlp_batch_kernel<false>", "pair_mlp_batch_kernel<true>": "pair_mlp_batch_kernel<true>",
+         "pair_mlp_batch_kernel<false, false>": "pair_mlp_batch_kernel<false>", "pair_mlp_batch_kernel<true, false>": "pair_mlp_batch_kernel<true>",
+         "point_proj_batch_kernel": "point_proj_batch_kernel",
          "reduce_argmax_kernel": "reduce_argmax_kernel", "v3_vote_kernel<true, false>": "v3_vote_kernel<true>",
          "v3_vote_kernel<false, false>": "v3_vote_kernel<false>", "v3_bin_kernel<false>": "v3_bin_kernel", "v3_reduce_kernel": "v3_reduce_kernel",
          "v3_vote_batch_kernel": "v3_vote_batch_kernel", "v3_reduce_batch_kernel": "v3_reduce_batch_kernel",
