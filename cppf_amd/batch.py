@@ -197,14 +197,18 @@ class BatchPoseRunner:
 
     def run(self, objects, rank=0, world=1, seed=0):
         """objects: the WHOLE batch (list, same on every rank).  Returns f64[n_objects, RECORD] in object
-        order on every rank (sharding.pack_record layout).
+        order on every rank (sharding.pack_record layout): on the device when a process group gathered them, on the host for
+        a single rank without a group (the records were just assembled there: no upload only to be read back).
 
         The rank's instances are enqueued back to back -- inputs, graph replay, a 21-double device copy of the result --
         and all results are read back once at the end (one synchronisation per batch instead of one per instance).  An
         object without `point_idxs` gets its pairs (n_pairs = obj["n_pairs"]) and bin uniforms drawn on the device from
         `seed` and its index: then only the cloud itself crosses PCIe."""
         mine = sharding.shard_objects(len(objects), rank, world)
-        raw = torch.zeros((max(len(mine), 1), 21), dtype=torch.float64, device=self.device)
+        raw = self.__dict__.get("_raw")           # (every row in use is overwritten by its instance's record copy)
+        if raw is None or raw.shape[0] < max(len(mine), 1):
+            raw = self._raw = torch.zeros((max(len(mine), 1), 21), dtype=torch.float64, device=self.device)
+        raw = raw[:max(len(mine), 1)]
         cfgs, used = [], []
         # n_lanes instances in flight: consecutive instances rotate over the HIP streams, each with its own pipelines
         # (buffers + captured graph), so one instance's head overlaps the previous one's tail
@@ -221,8 +225,6 @@ class BatchPoseRunner:
                 self.point_encoders[cat]._packed_weights(self.device)
         for st in self._streams:
             st.wait_stream(main)
-        checked = set()          # pipelines whose weight images were looked at in this batch (once is enough: nothing
-        #                          updates parameters while run() is on the stack)
         L = self.chain_len or max(1, min(8, len(mine) // (2 * self.n_lanes)))
         groups = [list(range(g, min(g + L, len(mine)))) for g in range(0, len(mine), L)]     # consecutive instances share a chain
         ran = []                 # (chain or None, pipelines, slots) per group, for adapt()
@@ -247,13 +249,12 @@ class BatchPoseRunner:
                     pipes.append(pipe)
                     cfgs.append(obj["cfg"])
                 chain = self._chain_for(pipes)
-                fresh = any(id(p) not in checked for p in pipes)
+                # (check_weights=None: the images were refreshed above, once per batch; a pipeline only compares their addresses)
                 if chain is not None:
-                    chain.run_async([raw[slot] for slot in slots], check_weights=fresh)
+                    chain.run_async([raw[slot] for slot in slots], check_weights=None)
                 else:
                     for pipe, slot in zip(pipes, slots):
-                        pipe.run_async(raw[slot], check_weights=id(pipe) not in checked)
-                checked.update(id(p) for p in pipes)
+                        pipe.run_async(raw[slot], check_weights=None)
                 ran.append((chain, pipes, slots))
         for st in self._streams:
             main.wait_stream(st)
@@ -264,5 +265,7 @@ class BatchPoseRunner:
             else:
                 for pipe, slot in zip(pipes, slots):
                     pipe.adapt(host[slot, 18])
-        local = torch.from_numpy(assemble_batch(host[:len(mine)], cfgs, mine, sharding.RECORD)).to(self.device)
+        local = torch.from_numpy(assemble_batch(host[:len(mine)], cfgs, mine, sharding.RECORD))
+        if world > 1 or sharding.dist.is_initialized():       # the gather needs them on the device; a single rank returns them as they are
+            local = local.to(self.device)
         return sharding.gather_records(local, len(objects), rank, world, self.device, validate=False)   # (rows built in object order above)

@@ -31,7 +31,15 @@ F32, I32 = torch.float32, torch.int32
 
 
 def grid_shape(pc_host, res):
-    """nocs/inference.py:194-195 on the host copy of the cloud: corners, int32((max-min)/res)+1."""
+    """nocs/inference.py:194-195 on the host copy of the cloud: corners, int32((max-min)/res)+1 (cppf_host_grid_shape: one pass
+    over the cloud in C; the numpy form below -- same types, same results -- serves anything that is not a C-contiguous f32[N,3])."""
+    a = np.asarray(pc_host)
+    if a.dtype == np.float32 and a.ndim == 2 and a.shape[1] == 3 and a.shape[0] > 0 and a.flags.c_contiguous:
+        corners = np.empty((2, 3), np.float32)
+        dims = np.empty(3, np.int32)
+        if _lib.lib().cppf_host_grid_shape(a.ctypes.data, a.shape[0], float(np.float32(res)), corners.ctypes.data, dims.ctypes.data) == 0 \
+                and not np.isnan(corners).any():
+            return corners, (int(dims[0]), int(dims[1]), int(dims[2]))
     t = np.ascontiguousarray(np.asarray(pc_host, dtype=np.float32).T)    # [3,N]: numpy reduces the long axis 20x faster than axis 0 of [N,3]
     corners = np.stack([t.min(1), t.max(1)])
     grid_res = ((corners[1] - corners[0]) / np.float32(res)).astype(np.int32) + 1
@@ -276,8 +284,17 @@ class CenterPipeline:
             ids.append(self.point_encoder._packed_weights(self.device)[0].data_ptr())
         return tuple(ids)
 
+    def _image_ptrs(self):
+        """the addresses of the weight images as they are NOW, without looking at the parameters (a caller that has just refreshed
+        the images of its encoders -- BatchPoseRunner, once per batch -- only needs to know whether an image MOVED since capture)"""
+        enc, penc = self.encoder, self.point_encoder
+        if enc._packed is None or (penc is not None and getattr(penc, "_packed", None) is None):
+            return self._weight_images()
+        return (enc._packed.data_ptr(),) if penc is None else (enc._packed.data_ptr(), penc._packed[0].data_ptr())
+
     def run(self, check_weights=True):
-        """check_weights=False skips the per-run look at the encoders' parameters (a caller that runs many instances
+        """check_weights=None: the caller refreshed the weight images itself, only their addresses are compared (_image_ptrs).
+        check_weights=False skips the per-run look at the encoders' parameters (a caller that runs many instances
         between parameter updates checks once per batch: BatchPoseRunner)."""
         # scratch requested by the chain belongs to this pipeline (see workspace_scope): pipelines replay concurrently
         with torch.no_grad(), workspace_scope(id(self)):
@@ -286,7 +303,8 @@ class CenterPipeline:
                 return self.out_idx, self.out_val
             # a changed parameter is re-packed here, on this stream, into the buffer the captured launches read; if the
             # image itself moved (device change, other size) the captured addresses are stale: capture again
-            images = self._weight_images() if check_weights or self._graph is None else self._images
+            images = (self._weight_images() if check_weights or self._graph is None else
+                      (self._image_ptrs() if check_weights is None else self._images))
             if self._graph is not None and images != self._images:
                 self._graph = None
             if self._graph is None:
@@ -846,7 +864,8 @@ class PoseChain:
             else:
                 form = self.full_first
                 graph, images = self._graphs.get(form, (None, None))
-                now = ((tuple(tuple(p._weight_images()) for p in self.pipes) if check_weights or graph is None else images[0]), self._key())
+                now = ((tuple(tuple(p._weight_images()) for p in self.pipes) if check_weights or graph is None else
+                        (tuple(tuple(p._image_ptrs()) for p in self.pipes) if check_weights is None else images[0])), self._key())
                 if graph is not None and now != images:
                     graph = None
                 if graph is None:

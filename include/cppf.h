@@ -638,6 +638,9 @@ int cppf_frame_cloud_dyn(const void* depth, int depth_is_u16, const void* labels
  * per frame).  With N = 0 every index is 0.  Same distributions as the reference's generators, not the same numbers (parity tests pass arrays). */
 int cppf_sample_pairs(long long* idx, float* u_tr, float* u_rot, int64_t n_pairs, int64_t n_points, const int32_t* n_dev,
                       unsigned long long seed, const unsigned long long* seed_dev, void* stream);
+/* Host helper (no device): the grid of nocs/inference.py:194-195 for a HOST cloud f32[n_points,3]: corners_host f32[6] = {min xyz, max xyz},
+ * dims_host i32[3] = int32((max - min) / res) + 1 with the quotient in fp32.  NaN coordinates are ignored by the comparisons. */
+int cppf_host_grid_shape(const float* pc_host, int64_t n_points, float res, float* corners_host, int32_t* dims_host);
 int cppf_mod_pairs_dyn(long long* idx, int64_t n_pairs, const int32_t* n_dev, void* stream);
 size_t cppf_backproject_workspace_bytes(int H, int W);
 int cppf_backproject(const void* depth, int depth_is_u16, const uint8_t* mask, int H, int W, const double* kinv_host,
