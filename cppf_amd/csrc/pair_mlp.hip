@@ -709,6 +709,8 @@ struct MlpBatch {
     int n;
     int per_xcd;   // > 0: lists of (nearly) equal length, 8 % n == 0: list i on XCDs [i per_xcd, (i + 1) per_xcd) -- see below
 };
+static_assert(sizeof(ProjBatch) <= 4096, "ProjBatch travels by value: kernel arguments are limited to 4 KB");
+static_assert(sizeof(MlpBatch) <= 4096, "MlpBatch travels by value: kernel arguments are limited to 4 KB");
 template <bool HEADS, bool SEL = false>
 __global__ __launch_bounds__(MLP_THREADS, MLP_WAVES_PER_SIMD) void pair_mlp_batch_kernel(MlpBatch B)
 {

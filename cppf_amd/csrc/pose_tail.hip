@@ -1167,6 +1167,7 @@ struct TailBatch {
     const float* sphere32;
     float thr;
 };
+static_assert(sizeof(TailBatch) <= 4096, "TailBatch travels by value: kernel arguments are limited to 4 KB");
 __global__ void tail_begin_batch_kernel(TailBatch B)
 {
     const TailItem& I = B.item[blockIdx.x];

@@ -1323,6 +1323,7 @@ struct V3Batch {
     int bps[V3_BATCH_MAX];
     int n;
 };
+static_assert(sizeof(V3Batch) <= 4096, "V3Batch travels by value: kernel arguments are limited to 4 KB");
 __global__ __launch_bounds__(V3_THREADS) void v3_vote_batch_kernel(V3Batch B)
 {
     int i = 0;
