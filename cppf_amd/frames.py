@@ -98,22 +98,22 @@ class FrameRunner:
         self.cfgs = cfgs or CATEGORIES
         self.n_lanes, self.chain_len, self.cap_bucket = max(1, int(n_lanes)), chain_len, int(cap_bucket)
         self.sphere = np.array(fibonacci_sphere(num_sphere_bins(angle_tol)))
-        self.max_instances = 16                       # bits of the u16 label image
+        self.max_instances = 32                       # bits of the u32 label image
         self._members, self.max_members = OrderedDict(), int(max_members)
         self._chains, self._seen = OrderedDict(), {}
         self._many_tile_cats = set()
         self._hw = None
         self._streams = [torch.cuda.Stream(device=device) for _ in range(self.n_lanes)]
-        self._seeds_host = torch.zeros(16, dtype=torch.int64).pin_memory()        # the instances' Philox keys, uploaded with the frame
-        self._seeds = torch.zeros(16, dtype=torch.int64, device=device)
+        self._seeds_host = torch.zeros(32, dtype=torch.int64).pin_memory()        # the instances' Philox keys, uploaded with the frame
+        self._seeds = torch.zeros(32, dtype=torch.int64, device=device)
 
     def _frame_buffers(self, H, W):
         if self._hw != (H, W):
             self._hw = (H, W)
             self._depth_host = torch.empty((H, W), dtype=torch.int16).pin_memory()
-            self._labels_host = torch.empty((H, W), dtype=torch.int16).pin_memory()
+            self._labels_host = torch.empty((H, W), dtype=torch.int32).pin_memory()
             self._depth = torch.empty((H, W), dtype=torch.int16, device=self.device)
-            self._labels = torch.empty((H, W), dtype=torch.int16, device=self.device)
+            self._labels = torch.empty((H, W), dtype=torch.int32, device=self.device)
             for ch in self._chains.values():
                 ch.release()
             self._members.clear()
@@ -153,7 +153,7 @@ class FrameRunner:
 
         def prestage():
             with torch.cuda.device(dev):
-                _lib.check(L.cppf_frame_cloud_dyn(depth.data_ptr(), 1, labels.data_ptr(), 2, bit, H, W, kinv.ctypes.data, 1000.0,
+                _lib.check(L.cppf_frame_cloud_dyn(depth.data_ptr(), 1, labels.data_ptr(), 4, bit, H, W, kinv.ctypes.data, 1000.0,
                                                   float(cfg.res), cfg.knn, cfg.knn + 1, cap, pipe.pc.data_ptr(), pipe.nrm.data_ptr(),
                                                   pipe.corner.data_ptr(), pipe.shape.data_ptr(), nbrs_ptr, ws.data_ptr(), ws.numel(),
                                                   stream_ptr(dev)), "cppf_frame_cloud_dyn")
@@ -191,14 +191,14 @@ class FrameRunner:
         n_inst = len(instances)
         out = [None] * n_inst
         on_chain = list(range(min(n_inst, self.max_instances)))
-        labels = self._labels_host.numpy().view(np.uint16)
+        labels = self._labels_host.numpy().view(np.uint32)
         labels[...] = 0
         counts = []
         for i in on_chain:
             m = np.asarray(instances[i][1])
             if m.dtype != np.bool_:
                 m = m != 0
-            np.bitwise_or(labels, np.uint16(1 << i), out=labels, where=m)      # (no fancy indexing: 0.1 ms per 480 x 640 mask)
+            np.bitwise_or(labels, np.uint32(1 << i), out=labels, where=m)      # (no fancy indexing: 0.1 ms per 480 x 640 mask)
             counts.append(int(np.count_nonzero(m)))
         self._depth_host.numpy()[...] = depth.view(np.int16)
         self._seeds_host.numpy()[:len(on_chain)] = [pair_seed(seed, i) for i in on_chain]

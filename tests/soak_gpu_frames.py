@@ -36,7 +36,7 @@ def run(seconds, seed):
     while time.time() < t_end:
         if not layouts or rng.random() < 0.5:            # a new layout half of the time, a repeated one otherwise (chains get captured and replayed)
             inst = []
-            for _ in range(int(rng.integers(1, 10))):
+            for _ in range(int(rng.integers(1, 10)) if rng.random() < 0.85 else int(rng.integers(17, 36))):   # (sometimes more than a label image's 32 bits)
                 h, w = int(rng.integers(2, 200)), int(rng.integers(2, 200))
                 r0, c0 = int(rng.integers(0, 480 - h)), int(rng.integers(0, 640 - w))
                 m = np.zeros(depth.shape, bool)
