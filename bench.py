@@ -440,6 +440,24 @@ def repeated(fn, inner, n=5, per=1.0):
     return ts[len(ts) // 2], [ts[0], ts[-1]]
 
 
+def event_median(step, inner=10, n=5, warm=1):
+    """a secondary timed with HIP events: n brackets of `inner` calls of step() after `warm` untimed ones -> (median ms per call,
+    [min, max])"""
+    for _ in range(warm):
+        step()
+    ts = []
+    for _ in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(inner):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / inner)
+    ts.sort()
+    return ts[len(ts) // 2], [ts[0], ts[-1]]
+
+
 def bracket(fns, n):
     """the closures of `fns` (one per object, cycled) launched n times back to back between two HIP events on the launch stream,
     so that the device queue stays full and the quotient is the kernels' own duration (no host-side launch gaps inside the
@@ -1199,25 +1217,18 @@ def main():
 
     # secondary: the step before the path -- kNN(60) + SPRIN point encoder producing `feat`
     # (nocs/inference.py:180-181), random-init weights of the reference's configuration (train.py:34)
-    t_penc = None
+    t_penc = mm_penc = None
     if secondary:
         from cppf_amd.models.model import PointEncoder
         torch.manual_seed(1)
         penc = PointEncoder(k=60, spfcs=[32, 64, 32, 32], num_layers=1, out_dim=32).eval().to(dev)
         settle()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.no_grad():
-            for it in range(6):
-                if it == 1:
-                    e0.record()
-                penc(pipe.pc[None], pipe.nrm[None])
-            e1.record()
-        torch.cuda.synchronize()
-        t_penc = e0.elapsed_time(e1) / 5
+            t_penc, mm_penc = event_median(lambda: penc(pipe.pc[None], pipe.nrm[None]), inner=5)
 
     # secondary: one training-size forward + backward of the pair encoder (train.py:66,91:
     # 200 000 pairs, dL/dlogits given), HIP forward + HIP backward through the autograd.Function
-    t_train = t_step = t_full = None
+    t_train = t_step = t_full = mm_train = mm_step = mm_full = None
     if secondary:
         Pt = 200000
         n_pts = m["n_points"]
@@ -1227,32 +1238,24 @@ def main():
         feat_t = pipe.feat.clone().requires_grad_(True)
         enc.train()
         settle()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for it in range(11):
-            if it == 1:
-                e0.record()
+        def step_fwd_bwd():
             enc.zero_grad()
             feat_t.grad = None
             enc.forward_with_idx(pc, nrm, feat_t, idx_t).backward(Rt)
-        e1.record()
-        torch.cuda.synchronize()
-        t_train = e0.elapsed_time(e1) / 10
+        t_train, mm_train = event_median(step_fwd_bwd)
         # the same with the weights changing every step (train.py:89-92: zero_grad, backward, Adam step): the weight
         # image is re-packed on the device each step, nothing synchronises with the host
         import copy
         enc_t = copy.deepcopy(enc)
         opt = torch.optim.Adam(enc_t.parameters(), lr=1e-4)
         settle()
-        for it in range(11):
-            if it == 1:
-                e0.record()
+
+        def step_adam():
             opt.zero_grad()
             feat_t.grad = None
             enc_t.forward_with_idx(pc, nrm, feat_t, idx_t).backward(Rt)
             opt.step()
-        e1.record()
-        torch.cuda.synchronize()
-        t_step = e0.elapsed_time(e1) / 10
+        t_step, mm_step = event_median(step_adam)
         # the whole of train.py:58-92 for one sample: cdist, point encoder, pair encoder, backward through both, Adam
         from cppf_amd.models.model import PointEncoder
         torch.manual_seed(2)
@@ -1260,18 +1263,15 @@ def main():
         opt2 = torch.optim.Adam([*penc_t.parameters(), *enc_t.parameters()], lr=1e-4)
         pcs_b, nrm_b = pc[None], nrm[None]
         settle()
-        for it in range(11):
-            if it == 1:
-                e0.record()
+
+        def step_full():
             opt2.zero_grad()
             with torch.no_grad():
                 dist_b = torch.cdist(pcs_b, pcs_b)
             f_b = penc_t(pcs_b, nrm_b, dist_b)
             enc_t(pcs_b, nrm_b, f_b, idxs=idx_t)[0].backward(Rt)
             opt2.step()
-        e1.record()
-        torch.cuda.synchronize()
-        t_full = e0.elapsed_time(e1) / 10
+        t_full, mm_full = event_median(step_full)
         enc.eval()
 
     dinfo = dist_info(world, dev)
@@ -1328,7 +1328,9 @@ def main():
                          "point_encoder_knn60_sprin": t_penc,
                          "pair_encoder_fwd_bwd_200k_pairs": t_train,
                          "pair_encoder_fwd_bwd_adam_step_200k_pairs": t_step,
-                         "train_step_both_encoders_adam_200k_pairs": t_full},
+                         "train_step_both_encoders_adam_200k_pairs": t_full,
+                         "min_max": {"point_encoder_knn60_sprin": mm_penc, "pair_encoder_fwd_bwd_200k_pairs": mm_train,
+                                     "pair_encoder_fwd_bwd_adam_step_200k_pairs": mm_step, "train_step_both_encoders_adam_200k_pairs": mm_full}},
             "other_configs": other or None,
             # dominant kernel = the fused pair encoder (one launch between the two events): exact-fp32 MFMA.
             # frac is BOUNDED: the MFMA FLOP the kernel EXECUTES over the fp32-MFMA peak.  (Rounds 1-3 divided the reference's
