@@ -1,4 +1,6 @@
 """torch plumbing for the C ABI: pointer extraction, argument checks, stream, scratch cache."""
+import threading
+
 import numpy as np
 import torch
 
@@ -44,7 +46,7 @@ def scalar(v):
     return v
 
 
-_ws_scope = None
+_ws_tls = threading.local()          # the enclosing scope is per host thread: two threads may drive two pipelines
 
 
 class workspace_scope:
@@ -57,13 +59,11 @@ class workspace_scope:
         self.owner = owner
 
     def __enter__(self):
-        global _ws_scope
-        self.prev, _ws_scope = _ws_scope, self.owner
+        self.prev, _ws_tls.scope = getattr(_ws_tls, "scope", None), self.owner
         return self
 
     def __exit__(self, *exc):
-        global _ws_scope
-        _ws_scope = self.prev
+        _ws_tls.scope = self.prev
         return False
 
 
@@ -77,7 +77,8 @@ def workspace(nbytes, device, tag="ws", zero=False):
     """Grow-only scratch per (device, owner, tag); owner = the enclosing workspace_scope, else the current stream (reuse on
     one stream is stream-ordered).  zero=True: a fresh allocation starts zero-filled (the vote's workspace keeps a header
     between calls that must start at zero, include/cppf.h: cppf_vote_workspace_init_bytes)."""
-    owner = ("scope", _ws_scope) if _ws_scope is not None else torch.cuda.current_stream(device).cuda_stream
+    scope = getattr(_ws_tls, "scope", None)
+    owner = ("scope", scope) if scope is not None else torch.cuda.current_stream(device).cuda_stream
     key = (device, owner, tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:

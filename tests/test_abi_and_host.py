@@ -501,3 +501,29 @@ def test_bench_compact_line_fits_the_drivers_tail():
     assert line["value"] == full["value"] and line["metric"] == bench.METRIC and "workload" in line["config"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
     assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"])
+
+
+def test_workspace_scope_is_per_thread():
+    """scratch ownership follows the host thread that entered the scope (two threads may drive two pipelines): a scope entered
+    on one thread is invisible on another, and nesting restores the outer owner"""
+    import threading
+    from cppf_amd import _torch_util as tu
+    seen, gate, done = {}, threading.Barrier(2), threading.Barrier(2)
+
+    def worker(name):
+        with tu.workspace_scope(name):
+            gate.wait(timeout=10)                       # both threads are inside their scopes now
+            seen[name] = getattr(tu._ws_tls, "scope", None)
+            with tu.workspace_scope(name + "/inner"):
+                seen[name + "/inner"] = tu._ws_tls.scope
+            seen[name + "/after"] = tu._ws_tls.scope
+            done.wait(timeout=10)
+        seen[name + "/out"] = getattr(tu._ws_tls, "scope", None)
+
+    ts = [threading.Thread(target=worker, args=(n,)) for n in ("a", "b")]
+    for t_ in ts:
+        t_.start()
+    for t_ in ts:
+        t_.join(20)
+    assert seen == {"a": "a", "b": "b", "a/inner": "a/inner", "b/inner": "b/inner", "a/after": "a", "b/after": "b", "a/out": None, "b/out": None}
+    assert getattr(tu._ws_tls, "scope", None) is None
