@@ -209,10 +209,11 @@ class FrameRunner:
         for cat in {instances[i][0] for i in on_chain}:
             self.encoders[cat]._packed_weights(dev)
             self.point_encoders[cat]._packed_weights(dev)
-        for st in self._streams:
-            st.wait_stream(main)
+        # (zero-filled on the caller's stream BEFORE the lanes fork from it: a lane's record copy must not race the fill)
         raw = torch.zeros((max(len(on_chain), 1), 21), dtype=torch.float64, device=dev)
         shapes = torch.zeros((max(len(on_chain), 1), 4), dtype=torch.int32, device=dev)
+        for st in self._streams:
+            st.wait_stream(main)
         Lc = self.chain_len or max(1, min(8, -(-len(on_chain) // self.n_lanes)))
         groups = [on_chain[g:g + Lc] for g in range(0, len(on_chain), Lc)]
         ran = []
