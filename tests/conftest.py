@@ -40,3 +40,21 @@ def dev():
 
 def sd_from_npz(g):
     return {k[3:]: g[k] for k in g.files if k.startswith("sd.")}
+
+
+@pytest.fixture(scope="session")
+def c_host(oracle, tmp_path_factory):
+    """tests/c_host/vote_host.c -- a host in plain C over include/cppf.h -- compiled with gcc as C99 against the in-tree
+    libcppf_hip.so (the product) and liboracle.so (its checker); returns the binary's path"""
+    import subprocess
+    from cppf_amd import _lib
+    _lib.lib()                                                     # (fails loudly when the HIP library was not built)
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    csrc, orc = os.path.join(ROOT, "cppf_amd", "csrc"), os.path.join(ROOT, "oracle")
+    exe = str(tmp_path_factory.mktemp("c_host") / "vote_host")
+    cmd = ["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(rocm, "include"),
+           os.path.join(ROOT, "tests", "c_host", "vote_host.c"), "-o", exe, "-L" + csrc, "-lcppf_hip", "-L" + orc, "-l:liboracle.so",
+           "-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-lm"] + ["-Wl,-rpath," + d for d in (csrc, orc, os.path.join(rocm, "lib"))]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    return exe

@@ -527,3 +527,12 @@ def test_workspace_scope_is_per_thread():
         t_.join(20)
     assert seen == {"a": "a", "b": "b", "a/inner": "a/inner", "b/inner": "b/inner", "a/after": "a", "b/after": "b", "a/out": None, "b/out": None}
     assert getattr(tu._ws_tls, "scope", None) is None
+
+
+def test_plain_c_host_compiles_and_runs_the_host_only_entry_points(c_host):
+    """include/cppf.h is a C header (gcc -std=c99 -Wall -Werror) and libcppf_hip.so links into a C program: ABI version, error
+    strings, the host grid shape of nocs/inference.py:194-195, launch plans, EINVAL before any device call -- no Python in the loop"""
+    import subprocess
+    p = subprocess.run([c_host], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "host ok: ABI 3" in p.stdout

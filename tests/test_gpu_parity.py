@@ -1084,3 +1084,13 @@ def test_center_batch_pipeline_equals_member_pipelines(golden, dev):
     assert int(pipes[0].out_idx) == int(fresh.out_idx) and not torch.equal(fresh.outputs, want[0][0])
     with pytest.raises(ValueError):
         CenterBatchPipeline([])
+
+
+def test_plain_c_host_votes_on_the_device_and_matches_the_oracle(c_host, dev):
+    """the drop-in boundary from a host that is not Python: tests/c_host/vote_host.c allocates with hipMalloc, zeroes the vote's
+    workspace once, calls cppf_vote_argmax three times on one stream and compares grid, arg-max, peak and centre with
+    orc_ppf_voting / orc_grid_argmax / orc_center_from_argmax (models/voting.py:8-66, nocs/inference.py:207-210)"""
+    import subprocess
+    p = subprocess.run([c_host, "gpu"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "device ok" in p.stdout, p.stdout
