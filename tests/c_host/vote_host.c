@@ -4,6 +4,10 @@
  *   vote_host gpu        the centre vote + arg-max of one synthetic object on the device (cppf_vote_argmax, the drop-in for
  *                        models/voting.py:8-66 + nocs/inference.py:207-210), checked against the oracle's restatement of the same
  *                        lines (oracle/cppf_oracle.c: orc_ppf_voting / orc_grid_argmax / orc_center_from_argmax)
+ *   vote_host chain      the whole hot path from C: PPF + pair MLP + centre decode (cppf_pair_mlp_pack / cppf_pair_mlp_decode:
+ *                        models/model.py:117-137, nocs/inference.py:185-188) on the reference's architecture with seeded random
+ *                        weights, int64 pair list, then the vote of what it emitted; (mu, nu) of every pair compared BIT FOR BIT with
+ *                        orc_pair_mlp(order 1) + orc_decode_center, the arg-max with the oracle's vote of the same (mu, nu)
  *
  * TEST code: it links the oracle as the checker (tests/test_abi_and_host.py, tests/test_gpu_parity.py build and run it). */
 #define __HIP_PLATFORM_AMD__ 1
@@ -20,6 +24,9 @@ void orc_ppf_voting(const float* points, const float* outputs, const float* prob
                     const float* corner, float res, int64_t n_ppfs, int n_rots, int gx, int gy, int gz, int adaptive, int64_t* n_atomics);
 int64_t orc_grid_argmax(const float* grid, int64_t n, float* val);
 void orc_center_from_argmax(int64_t flat, int gy, int gz, const float* corner, double res, double* T);
+int orc_pair_mlp(const float* pc, const float* nrm, const float* feat, const int64_t* idxs, int64_t N, int F, int64_t P,
+                 const float* params, const int64_t* offs, const int* dims, int n_res, int out_dim, int order, float* out);
+void orc_decode_center(const float* logits, int64_t P, int ld, int nb, const float* u, float vr0, float vr1, float* outputs, int32_t* bins);
 
 #define REQUIRE(cond)                                                                  \
     do {                                                                               \
@@ -163,9 +170,124 @@ static int on_device(void)
     return 0;
 }
 
+
+/* train.py:35 / config: ppffcs [84, 32, 32, 16], 141 logits = 2 x 32 centre bins + 2 x 36 orientation bins + 2 + 3 */
+enum { F = 40, N_RES = 3, OUT_DIM = 141, TR_BINS = 32, ROT_BINS = 36 };
+static const int DIMS[N_RES + 1] = {2 * F + 4, 32, 32, 16};
+static const float VR0 = 0.25f, VR1 = 0.25f;                /* config/category/bottle.yaml: vote_range */
+
+static int chain_on_device(void)
+{
+    static float pc[3 * N], nrm[3 * N], feat[N * F], unused_outputs[2 * P], centre[3], u_tr[2 * P], outputs[2 * P], ref_out[2 * P];
+    static int32_t idx32[2 * P];
+    static int64_t idx64[2 * P];
+    make_object(pc, idx32, unused_outputs, centre);
+    for (int i = 0; i < N; ++i) {                           /* normals: radial (the surface of revolution's), unit length */
+        const float x = pc[3 * i] - centre[0], z = pc[3 * i + 2] - centre[2], r = sqrtf(x * x + z * z) + 1e-12f;
+        nrm[3 * i] = x / r; nrm[3 * i + 1] = 0.f; nrm[3 * i + 2] = z / r;
+    }
+    for (int i = 0; i < N * F; ++i) feat[i] = 2.f * unif() - 1.f;
+    for (int i = 0; i < 2 * P; ++i) { idx64[i] = idx32[i]; u_tr[i] = unif(); }
+    /* parameters in the oracle's / cppf_pair_mlp_pack's layout: flat torch tensors + offset table (include/cppf.h) */
+    static float params[65536];
+    int64_t offs[6 * N_RES + 2], at = 0;
+    for (int l = 0; l < N_RES; ++l) {
+        const int Kd = DIMS[l], Nn = DIMS[l + 1];
+        const int sizes[6] = {Nn * Kd, Nn, Nn * Nn, Nn, Kd != Nn ? Nn * Kd : 0, Kd != Nn ? Nn : 0};
+        for (int t = 0; t < 6; ++t) {
+            offs[6 * l + t] = sizes[t] ? at : -1;
+            const float bound = 1.f / sqrtf((float)(t == 2 || t == 3 ? Nn : Kd));       /* torch.nn.Linear's default init */
+            for (int i = 0; i < sizes[t]; ++i) params[at++] = bound * (2.f * unif() - 1.f);
+        }
+    }
+    offs[6 * N_RES] = at;
+    for (int i = 0; i < OUT_DIM * DIMS[N_RES]; ++i) params[at++] = 0.25f * (2.f * unif() - 1.f);
+    offs[6 * N_RES + 1] = at;
+    for (int i = 0; i < OUT_DIM; ++i) params[at++] = 0.25f * (2.f * unif() - 1.f);
+    REQUIRE(at <= (int64_t)(sizeof params / sizeof params[0]));
+
+    const size_t n_packed = cppf_pair_mlp_packed_floats(F, DIMS, N_RES, OUT_DIM);
+    const size_t mlp_ws = cppf_pair_mlp_workspace_bytes(N, F, DIMS, N_RES, OUT_DIM);
+    REQUIRE(n_packed > 0 && mlp_ws > 0);
+    float* packed = (float*)malloc(n_packed * 4);
+    REQUIRE(packed && cppf_pair_mlp_pack(params, offs, F, DIMS, N_RES, OUT_DIM, packed) == 0);
+
+    float corners[6]; int32_t dims[3];
+    REQUIRE(cppf_host_grid_shape(pc, N, RES, corners, dims) == 0);
+    const int gx = dims[0], gy = dims[1], gz = dims[2];
+    const size_t cells = (size_t)gx * gy * gz;
+    const size_t need = cppf_vote_workspace_bytes(P, ROTS, gx, gy, gz), init = cppf_vote_workspace_init_bytes();
+
+    float *d_pc, *d_nrm, *d_feat, *d_packed, *d_u, *d_out, *d_grid, *d_corner, *d_val;
+    int64_t* d_idx;
+    long long* d_arg;
+    void *d_ws, *d_mlp_ws;
+    HIP(hipSetDevice(0));
+    hipStream_t st;
+    HIP(hipStreamCreate(&st));
+    HIP(hipMalloc((void**)&d_pc, sizeof pc)); HIP(hipMalloc((void**)&d_nrm, sizeof nrm)); HIP(hipMalloc((void**)&d_feat, sizeof feat));
+    HIP(hipMalloc((void**)&d_packed, n_packed * 4)); HIP(hipMalloc((void**)&d_u, sizeof u_tr)); HIP(hipMalloc((void**)&d_out, sizeof outputs));
+    HIP(hipMalloc((void**)&d_idx, sizeof idx64)); HIP(hipMalloc((void**)&d_grid, cells * 4)); HIP(hipMalloc((void**)&d_corner, 12));
+    HIP(hipMalloc((void**)&d_val, 4)); HIP(hipMalloc((void**)&d_arg, 8)); HIP(hipMalloc(&d_ws, need)); HIP(hipMalloc(&d_mlp_ws, mlp_ws));
+    HIP(hipMemcpyAsync(d_pc, pc, sizeof pc, hipMemcpyHostToDevice, st));
+    HIP(hipMemcpyAsync(d_nrm, nrm, sizeof nrm, hipMemcpyHostToDevice, st));
+    HIP(hipMemcpyAsync(d_feat, feat, sizeof feat, hipMemcpyHostToDevice, st));
+    HIP(hipMemcpyAsync(d_packed, packed, n_packed * 4, hipMemcpyHostToDevice, st));
+    HIP(hipMemcpyAsync(d_u, u_tr, sizeof u_tr, hipMemcpyHostToDevice, st));
+    HIP(hipMemcpyAsync(d_idx, idx64, sizeof idx64, hipMemcpyHostToDevice, st));
+    HIP(hipMemcpyAsync(d_corner, corners, 12, hipMemcpyHostToDevice, st));
+    HIP(hipMemsetAsync(d_ws, 0, init < need ? init : need, st));
+    long long arg = -2; float val = 0.f;
+    for (int rep = 0; rep < 2; ++rep) {
+        int rc = cppf_pair_mlp_decode(d_pc, d_nrm, d_feat, d_idx, /*idx_is_i64*/ 1, d_packed, N, F, DIMS, N_RES, P, OUT_DIM, TR_BINS,
+                                      ROT_BINS, VR0, VR1, d_u, NULL, d_out, NULL, d_mlp_ws, mlp_ws, st);
+        if (rc) { fprintf(stderr, "cppf_pair_mlp_decode: %s\n", cppf_error_string(rc)); return 1; }
+        rc = cppf_vote_argmax(d_pc, d_out, NULL, d_idx, /*idx_is_i64*/ 1, d_grid, d_corner, RES, N, P, ROTS, gx, gy, gz, 1, 0, d_arg, d_val,
+                              d_ws, need, st);
+        if (rc) { fprintf(stderr, "cppf_vote_argmax: %s\n", cppf_error_string(rc)); return 1; }
+    }
+    float* grid = (float*)malloc(cells * 4);
+    float* ref = (float*)calloc(cells, 4);
+    float* logits = (float*)malloc((size_t)P * OUT_DIM * 4);
+    REQUIRE(grid && ref && logits);
+    HIP(hipMemcpyAsync(outputs, d_out, sizeof outputs, hipMemcpyDeviceToHost, st));
+    HIP(hipMemcpyAsync(grid, d_grid, cells * 4, hipMemcpyDeviceToHost, st));
+    HIP(hipMemcpyAsync(&arg, d_arg, 8, hipMemcpyDeviceToHost, st));
+    HIP(hipMemcpyAsync(&val, d_val, 4, hipMemcpyDeviceToHost, st));
+    HIP(hipStreamSynchronize(st));
+
+    REQUIRE(orc_pair_mlp(pc, nrm, feat, idx64, N, F, P, params, offs, DIMS, N_RES, OUT_DIM, /*order*/ 1, logits) == 0);
+    orc_decode_center(logits, P, OUT_DIM, TR_BINS, u_tr, VR0, VR1, ref_out, NULL);
+    int64_t differing = 0;
+    for (int i = 0; i < 2 * P; ++i) differing += memcmp(&outputs[i], &ref_out[i], 4) != 0;
+    static float ones[N];
+    for (int i = 0; i < N; ++i) ones[i] = 1.f;
+    int64_t n_atomics = 0;
+    orc_ppf_voting(pc, ref_out, ones, idx32, ref, corners, RES, P, ROTS, gx, gy, gz, 1, &n_atomics);
+    float ref_val = 0.f;
+    const int64_t ref_arg = orc_grid_argmax(ref, (int64_t)cells, &ref_val);
+    double worst = 0.;
+    for (size_t i = 0; i < cells; ++i) { const double d = fabs((double)grid[i] - (double)ref[i]); worst = d > worst ? d : worst; }
+    printf("chain: P=%d pairs, %lld of %d (mu, nu) values differ from the oracle's; grid %dx%dx%d, %lld samples landed; arg-max %lld "
+           "(oracle %lld) peak %.5f (oracle %.5f) max |cell diff| %.3g\n", (int)P, (long long)differing, 2 * (int)P, gx, gy, gz,
+           (long long)(n_atomics / 8), arg, (long long)ref_arg, val, ref_val, worst);
+    REQUIRE(differing == 0);                                              /* PPF + MLP + decode: bit for bit */
+    REQUIRE(arg >= 0 && (size_t)arg < cells && val == grid[arg]);
+    REQUIRE(worst <= 1e-4 * ref_val + 1e-5);
+    /* nocs/inference.py:208: the same cell -- or, when two cells tie within the fp32 sums' own rounding, one of the tied ones */
+    REQUIRE(arg == (long long)ref_arg || ref[arg] >= ref_val - 2e-5f * ref_val);
+    printf("chain ok\n");
+    free(grid); free(ref); free(logits); free(packed);
+    hipFree(d_pc); hipFree(d_nrm); hipFree(d_feat); hipFree(d_packed); hipFree(d_u); hipFree(d_out); hipFree(d_idx); hipFree(d_grid);
+    hipFree(d_corner); hipFree(d_val); hipFree(d_arg); hipFree(d_ws); hipFree(d_mlp_ws);
+    hipStreamDestroy(st);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     setvbuf(stdout, NULL, _IONBF, 0);
     if (argc > 1 && strcmp(argv[1], "gpu") == 0) return on_device();
+    if (argc > 1 && strcmp(argv[1], "chain") == 0) return chain_on_device();
     return host_only();
 }

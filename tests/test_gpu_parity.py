@@ -1094,3 +1094,14 @@ def test_plain_c_host_votes_on_the_device_and_matches_the_oracle(c_host, dev):
     p = subprocess.run([c_host, "gpu"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "device ok" in p.stdout, p.stdout
+
+
+def test_plain_c_host_runs_the_whole_hot_path_and_matches_the_oracle_bit_for_bit(c_host, dev):
+    """the same host, the whole path: cppf_pair_mlp_pack + cppf_pair_mlp_decode (PPF, MLP on the reference's architecture with
+    seeded random weights, centre decode; int64 pair list) -> cppf_vote_argmax; every (mu, nu) equal to orc_pair_mlp(order 1) +
+    orc_decode_center bit for bit, the arg-max the oracle's (models/model.py:117-137, nocs/inference.py:185-211)"""
+    import subprocess
+    p = subprocess.run([c_host, "chain"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "chain ok" in p.stdout and " 0 of " in p.stdout, p.stdout
+    print(p.stdout)
