@@ -82,6 +82,7 @@ _SIGS = {
     "cppf_sample_pairs": (C.c_int, [vp, vp, vp, i64, i64, vp, C.c_uint64, vp, vp]),
     "cppf_host_grid_shape": (C.c_int, [vp, i64, f32, vp, vp]),
     "cppf_mod_pairs_dyn": (C.c_int, [vp, i64, vp, vp]),
+    "cppf_stage_batch": (C.c_int, [i32, vp, vp]),
     "cppf_backproject_workspace_bytes": (sz, [i32, i32]),
     "cppf_backproject": (C.c_int, [vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
     "cppf_voxel_dedupe_workspace_bytes": (sz, [i64]),
@@ -119,7 +120,20 @@ class PoseTailItem(C.Structure):
                 ("count", C.c_void_p), ("counts", C.c_void_p), ("best_idx", C.c_void_p), ("ticket", C.c_void_p),
                 ("sums_workspace", C.c_void_p), ("sums_workspace_bytes", C.c_size_t), ("n_points", C.c_int64), ("n_pairs", C.c_int64),
                 ("res64", C.c_double), ("res", C.c_float), ("tol", C.c_float), ("gx", C.c_int), ("gy", C.c_int), ("gz", C.c_int),
-                ("n_dirs", C.c_int), ("second_pass", C.c_int)]
+                ("n_dirs", C.c_int), ("second_pass", C.c_int),
+                ("record_out", C.c_void_p), ("object_id_dev", C.c_void_p), ("object_id_host", C.c_longlong),
+                ("scale_mean", C.c_double * 3), ("regress_right", C.c_int)]
+
+
+class StageItem(C.Structure):
+    """include/cppf.h: CppfStageItem (one object of cppf_stage_batch); its device-side descriptor CppfStageDesc is six 64-bit words:
+    {pc_src, nrm_src, feat_src, n_points, seed, object_id}"""
+    _fields_ = [("desc", C.c_void_p), ("pc", C.c_void_p), ("nrm", C.c_void_p), ("feat", C.c_void_p), ("corner", C.c_void_p),
+                ("shape", C.c_void_p), ("idx", C.c_void_p), ("u_tr", C.c_void_p), ("u_rot", C.c_void_p), ("n_pairs", C.c_int64),
+                ("n_cap", C.c_int64), ("F", C.c_int), ("res", C.c_float)]
+
+
+STAGE_DESC_WORDS = 6
 
 
 class VoteItem(C.Structure):
@@ -131,7 +145,7 @@ class VoteItem(C.Structure):
                 ("many_tiles", C.c_int)]
 
 
-ABI_VERSION = 3     # include/cppf.h CPPF_ABI_VERSION: batched votes (CppfVoteItem), cppf_pair_mlp_batch_plan
+ABI_VERSION = 4     # include/cppf.h CPPF_ABI_VERSION: records assembled on the device (CppfPoseTailItem.record_out), cppf_stage_batch
 
 
 class CppfError(RuntimeError):

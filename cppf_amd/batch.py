@@ -21,6 +21,11 @@ from .inference import PoseChain, PosePipeline, assemble_batch, grid_class, grid
 from .utils.util import fibonacci_sphere, num_sphere_bins
 
 
+def _shape_error(obj, pipe):
+    return ValueError(f"object of shape N={obj['pc'].shape[0]}, grid {tuple(obj['dims'])} on an exact-shape pipeline built for "
+                      f"N={pipe.n_points}, grid {tuple(pipe.dims)}")
+
+
 class BatchPoseRunner:
     def __init__(self, encoders, device, num_rots=72, adaptive=True, angle_tol=1.5, max_rot_pairs=10000,
                  use_graph=True, point_encoders=None, n_bucket=1024, max_pipelines=192, dynamic=True, n_lanes=3,
@@ -104,28 +109,33 @@ class BatchPoseRunner:
             self._pipes.move_to_end(key)
         return pipe
 
-    def _chain_for(self, pipes):
+    def _chain_for(self, pipes, staged=False):
         """the captured chain of these pipelines, or None (a single instance; a member the chain cannot take; a combination seen for
-        the first time: its members run their own graphs)"""
-        if len(pipes) < 2 or any(not p._split_ok or p.rot_order is not None or p._sph[2] == 0 for p in pipes):
+        the first time: its members run their own graphs).  staged=True (objects resident on the device, _run_resident): always a
+        chain -- of one member too -- returned with `capture`: False on a combination's first sighting (it then runs eagerly)."""
+        if any(not p._split_ok or p.rot_order is not None or p._sph[2] == 0 for p in pipes):
+            if staged:
+                raise ValueError("device-resident objects need the standard pair encoder and sphere bins sorted by y (PoseChain)")
             return None
-        key = tuple(id(p) for p in pipes)
+        if len(pipes) < 2 and not staged:
+            return None
+        key = tuple(id(p) for p in pipes) + (("staged",) if staged else ())
         chain = self._chains.get(key)
         if chain is not None:
             self._chains.move_to_end(key)
-            return chain
+            return (chain, True) if staged else chain
         seen = self._chain_seen.get(key, 0) + 1
         if len(self._chain_seen) > 4096:
             self._chain_seen.clear()
         self._chain_seen[key] = seen
-        if seen < 2:
+        if seen < 2 and not staged:
             return None
         while len(self._chains) >= self.max_chains:
             torch.cuda.synchronize(self.device)
             self._chains.popitem(last=False)[1].release()
-        chain = self._chains[key] = PoseChain(pipes, use_graph=self.kw["use_graph"],
+        chain = self._chains[key] = PoseChain(pipes, use_graph=self.kw["use_graph"], staged=staged,
                                               vote_workgroups=0 if self.vote_workgroups is None else self.vote_workgroups)
-        return chain
+        return (chain, seen >= 2) if staged else chain
 
     @staticmethod
     def footprint_bytes(n_points, n_pairs, many_tiles, dims):
@@ -186,6 +196,99 @@ class BatchPoseRunner:
         if obj["normals"].shape != obj["pc"].shape:
             raise ValueError(f"object {j}: normals {obj['normals'].shape} vs points {obj['pc'].shape}")
 
+    def put(self, objects):
+        """Upload a batch ONCE: -> the same objects with `pc`, `normals` and `feat` as device tensors and the grid's `dims` (host ints)
+        beside them -- the form SURVEY.md 8(d) times ("inputs already resident on device").  run() takes such objects through chains
+        whose first launch reads them where they are (cppf_stage_batch): no staging copies, no host arithmetic, no read-back; the
+        records it returns stay on the device.  Host arrays, or device tensors (then `dims` is computed on the device, one read-back
+        here).  An object needs `n_pairs` (pairs and bin uniforms are drawn on the device, as for host objects without `point_idxs`)."""
+        out = []
+        for j, obj in enumerate(objects):
+            self._check(j, obj)
+            if obj.get("point_idxs") is not None or "n_pairs" not in obj:
+                raise ValueError(f"object {j}: a device-resident object draws its pairs on the device: give n_pairs, not point_idxs")
+            o = dict(obj)
+            if torch.is_tensor(obj["pc"]) and obj["pc"].is_cuda:
+                for k in ("pc", "normals", "feat"):
+                    if obj.get(k) is not None:
+                        o[k] = obj[k].to(device=self.device, dtype=torch.float32).contiguous()
+                if o.get("dims") is None:
+                    lo, hi = o["pc"].amin(0), o["pc"].amax(0)
+                    o["dims"] = tuple(int(v) for v in (((hi - lo) / np.float32(obj["cfg"].res)).to(torch.int32) + 1).tolist())
+            else:
+                _, o["dims"] = grid_shape(obj["pc"], obj["cfg"].res)
+                for k in ("pc", "normals", "feat"):
+                    if obj.get(k) is not None:
+                        o[k] = torch.from_numpy(np.ascontiguousarray(obj[k], dtype=np.float32)).to(self.device)
+            o["dims"] = tuple(int(v) for v in o["dims"])
+            out.append(o)
+        return out
+
+    def _run_resident(self, objects, mine, rank, world, seed):
+        """run() for objects put() on the device: per chain one 48-byte-per-member descriptor copy, one graph replay, one device copy
+        of the finished records; nothing is read back (the survivor counts that choose a chain's form for the NEXT batch are copied
+        to pinned memory asynchronously and looked at when the next batch starts)."""
+        dev, n = self.device, len(mine)
+        self._adapt_resident()
+        local = self.__dict__.get("_local")
+        if local is None or local.shape[0] < max(n, 1):
+            local = self._local = torch.zeros((max(n, 1), sharding.RECORD), dtype=torch.float64, device=dev)
+        local = local[:max(n, 1)]
+        if self._streams is None:
+            self._streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_lanes)]
+        main = torch.cuda.current_stream(dev)
+        for cat in {objects[j]["cfg"].category for j in mine}:
+            if cat in self.encoders:
+                self.encoders[cat]._packed_weights(dev)
+            if cat in self.point_encoders:
+                self.point_encoders[cat]._packed_weights(dev)
+        for st in self._streams:
+            st.wait_stream(main)
+        # every lane busy from the start: chains of ceil(n / lanes) members (8 objects on 3 lanes: 3 + 3 + 2)
+        L = self.chain_len or max(1, min(8, -(-n // self.n_lanes)))
+        groups = [list(range(g, min(g + L, n))) for g in range(0, n, L)]
+        ran = []
+        for gi, slots in enumerate(groups):
+            lane = gi % self.n_lanes
+            with torch.cuda.stream(self._streams[lane]):
+                pipes, objs = [], []
+                for q, slot in enumerate(slots):
+                    obj = objects[mine[slot]]
+                    pipe = self._pipe(obj["cfg"], obj["pc"].shape[0], int(obj["n_pairs"]), obj["dims"], lane, q)
+                    if pipe.dynamic:
+                        pipe.set_shape(obj["pc"].shape[0], obj["dims"], upload=False)      # (capacity check + host bookkeeping)
+                    elif obj["pc"].shape[0] != pipe.n_points or tuple(obj["dims"]) != tuple(pipe.dims):
+                        raise _shape_error(obj, pipe)
+                    pipes.append(pipe)
+                    objs.append(obj)
+                chain, capture = self._chain_for(pipes, staged=True)
+                chain.run_staged(objs, [int(seed) * 1000003 + mine[slot] for slot in slots], [mine[slot] for slot in slots],
+                                 local[slots[0]:slots[-1] + 1], check_weights=None, capture=capture)
+                ran.append((chain, slots))
+        for st in self._streams:
+            main.wait_stream(st)
+        snap = self.__dict__.get("_snap")
+        if snap is None or snap[0].shape[0] < n:
+            snap = self._snap = (torch.zeros((max(n, 1), sharding.RECORD), dtype=torch.float64).pin_memory(), torch.cuda.Event())
+        snap[0][:n].copy_(local[:n], non_blocking=True)
+        snap[1].record(main)
+        self._pending = ran
+        return sharding.gather_records(local, len(objects), rank, world, dev, validate=False)
+
+    def _adapt_resident(self):
+        """the split / full-first form of the chains of the last resident batch, from its survivor counts (PoseChain.adapt), once
+        their asynchronous copy has landed"""
+        ran = self.__dict__.get("_pending")
+        if not ran or not self._snap[1].query():
+            return
+        host = self._snap[0].numpy()
+        if np.any(host[[s for _, slots in ran for s in slots], 12] < 0):
+            self._pending = None
+            raise RuntimeError("an instance of the last batch did not fit the shape-polymorphic pipeline it ran on (arg-max index -1)")
+        for chain, slots in ran:
+            chain.adapt([host[s, 14] for s in slots])
+        self._pending = None
+
     def run_object(self, obj):
         """obj: dict(pc, normals, feat, point_idxs, u_tr, u_rot, cfg) of host arrays -> pose dict."""
         self._check(0, obj)
@@ -205,6 +308,11 @@ class BatchPoseRunner:
         object without `point_idxs` gets its pairs (n_pairs = obj["n_pairs"]) and bin uniforms drawn on the device from
         `seed` and its index: then only the cloud itself crosses PCIe."""
         mine = sharding.shard_objects(len(objects), rank, world)
+        resident = [torch.is_tensor(objects[j]["pc"]) and objects[j]["pc"].is_cuda for j in mine]
+        if any(resident):
+            if not all(resident) or any(objects[j].get("dims") is None for j in mine):
+                raise ValueError("a batch is either host arrays or objects returned by put(): device tensors need `dims` beside them")
+            return self._run_resident(objects, mine, rank, world, seed)
         raw = self.__dict__.get("_raw")           # (every row in use is overwritten by its instance's record copy)
         if raw is None or raw.shape[0] < max(len(mine), 1):
             raw = self._raw = torch.zeros((max(len(mine), 1), 21), dtype=torch.float64, device=self.device)

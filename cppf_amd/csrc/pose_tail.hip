@@ -992,7 +992,48 @@ struct PoseSumsArgs {
     long long* best_idx;
     double *best_dir, *sign, *scale_out, *partial;
     unsigned* ticket;
+    // the finished record (cppf.h: CppfPoseTailItem.record_out), assembled by the workgroup that draws the last ticket; NULL: not assembled
+    double* record_out; const double* rec; const long long* object_id_dev; long long object_id_host; double scale_mean[3]; int regress_right;
 };
+// The host end of nocs/inference.py:299-339 (cppf_amd.inference._assemble, the same operations in the same order) from the sums one
+// thread holds: fin = {up/down loss sums of direction 0, of direction 1, three scale sums}, bdir = the two best sphere bins.
+__device__ __forceinline__ void assemble_record(const PoseSumsArgs& A, const double* fin, const double (*bdir)[3], const double n_surv)
+{
+    double* out = A.record_out;
+    const double n = fmax(n_surv, 1.0);
+    double dirs[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+    for (int j = 0; j < 2; ++j) {
+        if (j >= A.n_dirs) break;
+        const bool flip = fin[2 * j + 1] / n < fin[2 * j] / n;              // down_loss < up_loss (:299-302)
+        for (int c = 0; c < 3; ++c) dirs[j][c] = flip ? -bdir[j][c] : bdir[j][c];
+    }
+    const double* up = dirs[0];
+    double r[3];
+    if (A.regress_right && A.n_dirs > 1) {                                  // :305-312
+        const double d = (up[0] * dirs[1][0] + up[1] * dirs[1][1]) + up[2] * dirs[1][2];
+        for (int c = 0; c < 3; ++c) r[c] = dirs[1][c] - d * up[c];
+    } else {
+        r[0] = 0.0; r[1] = -up[2]; r[2] = up[1];
+    }
+    double nr = sqrt((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]) + 1e-9;
+    for (int c = 0; c < 3; ++c) r[c] = r[c] / nr;
+    if (sqrt((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]) < 1e-7) {           // :325-328; numpy.random.default_rng(0).standard_normal(3)
+        r[0] = 0x1.017ed89db8441p-3; r[1] = -0x1.0e8cfe9bd45ccp-3; r[2] = 0x1.47e57a468b06dp-1;
+        const double d = (r[0] * up[0] + r[1] * up[1]) + r[2] * up[2];
+        for (int c = 0; c < 3; ++c) r[c] = r[c] - d * up[c];
+        nr = sqrt((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]);
+        for (int c = 0; c < 3; ++c) r[c] = r[c] / nr;
+    }
+    for (int c = 0; c < 3; ++c) {
+        out[c] = A.rec[c];
+        out[3 + c] = up[c];
+        out[6 + c] = r[c];
+        const float mean = (float)(fin[4 + c] / n);                         // torch's mean is fp32 (:335)
+        out[9 + c] = ((double)(float)exp((double)mean) * A.scale_mean[c]) * 2.0;
+    }
+    out[12] = A.rec[19]; out[13] = A.rec[20]; out[14] = n_surv;
+    out[15] = (double)(A.object_id_dev ? *A.object_id_dev : A.object_id_host);
+}
 __device__ __forceinline__ void pose_sums_body(const PoseSumsArgs& A)
 {
     __shared__ double shc[RED_THREADS / 64][PS_COMP];
@@ -1104,6 +1145,13 @@ __device__ __forceinline__ void pose_sums_body(const PoseSumsArgs& A)
         if (c < 4) { if (c < 2 * A.n_dirs) A.sign[3 * (c >> 1) + (c & 1)] = s; }
         else if (c < 7 && A.scale_logits) A.scale_out[c - 4] = s;
     }
+    if (A.record_out) {            // (workgroup-uniform)
+        double* fin = &shc[0][0];  // the block sums were consumed above: the LDS is free
+        __syncthreads();
+        if (l == 0) fin[c] = (c < 4 ? c < 2 * A.n_dirs : (c < 7 && A.scale_logits)) ? s : 0.0;
+        __syncthreads();
+        if (tid == 0) assemble_record(A, fin, bdir, (double)n_sel);
+    }
     if (tid < A.n_dirs) A.sign[3 * tid + 2] = (double)n_sel;
     if (tid == 0 && A.scale_logits) A.scale_out[3] = (double)n_sel;
     if (tid == 0) __hip_atomic_store(A.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
@@ -1136,6 +1184,8 @@ extern "C" int cppf_pose_sums(const float* pc, const float* nrm, const int32_t* 
     A.counts_dir_step = counts_dir_step;
     A.best_idx = best_idx; A.best_dir = best_dir; A.sign = sign; A.scale_out = scale_out;
     A.partial = static_cast<double*>(workspace); A.ticket = ticket;
+    A.record_out = nullptr; A.rec = nullptr; A.object_id_dev = nullptr; A.object_id_host = 0; A.regress_right = 0;
+    A.scale_mean[0] = A.scale_mean[1] = A.scale_mean[2] = 0.0;
     hipLaunchKernelGGL(pose_sums_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, (hipStream_t)stream, A);
     CPPF_CHECK_LAUNCH();
     return 0;
@@ -1233,6 +1283,9 @@ extern "C" int cppf_pose_tail_batch(int n_items, const CppfPoseTailItem* items, 
         S.aux_stride = 8; S.scale_stride = 8; S.n_dirs = it.n_dirs; S.n_sphere = n_sphere; S.counts_dir_step = n_sphere;
         S.best_idx = it.best_idx; S.best_dir = it.rec + 3; S.sign = it.rec + 9; S.scale_out = it.rec + 15;
         S.partial = static_cast<double*>(it.sums_workspace); S.ticket = it.ticket;
+        S.record_out = it.record_out; S.rec = it.rec; S.object_id_dev = it.object_id_dev; S.object_id_host = it.object_id_host;
+        S.scale_mean[0] = it.scale_mean[0]; S.scale_mean[1] = it.scale_mean[1]; S.scale_mean[2] = it.scale_mean[2];
+        S.regress_right = it.regress_right;
         int64_t nb = (it.n_pairs + 4 * 256 - 1) / (4 * 256);
         nb = nb > 1024 ? 1024 : nb;
         bv_blocks = nb > bv_blocks ? nb : bv_blocks;

@@ -336,6 +336,67 @@ __global__ __launch_bounds__(256) void sample_pairs_kernel(long long* __restrict
     }
 }
 
+// ---- cppf_stage_batch: the head of a captured chain for objects already on the device.  Workgroup roles by blockIdx.x, object =
+// blockIdx.y: 0 = grid set-up (nocs/inference.py:194-195, the arithmetic of grid_setup_kernel), 1 .. STAGE_COPY_BLOCKS = copies of cloud,
+// normals and features into the chain's buffers, the rest = the pair / uniform draws (sample_pairs_kernel's, bit for bit).
+#define STAGE_MAX 8
+#define STAGE_COPY_BLOCKS 16
+struct StageBatch { CppfStageItem item[STAGE_MAX]; int n_sample_blocks; };
+__global__ __launch_bounds__(256) void stage_batch_kernel(StageBatch B)
+{
+    const CppfStageItem& I = B.item[blockIdx.y];
+    const CppfStageDesc D = *I.desc;
+    const int64_t N = D.n_points < 0 ? 0 : (D.n_points > I.n_cap ? I.n_cap : D.n_points);
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0) {
+        __shared__ float slo[4][3], shi[4][3];
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int64_t i = tid; i < N; i += 256)
+            for (int j = 0; j < 3; ++j) {
+                const float v = D.pc_src[3 * i + j];
+                lo[j] = fminf(lo[j], v);
+                hi[j] = fmaxf(hi[j], v);
+            }
+        for (int j = 0; j < 3; ++j)
+            for (int off = 32; off > 0; off >>= 1) {
+                lo[j] = fminf(lo[j], __shfl_xor(lo[j], off, 64));
+                hi[j] = fmaxf(hi[j], __shfl_xor(hi[j], off, 64));
+            }
+        if ((tid & 63) == 0)
+            for (int j = 0; j < 3; ++j) { slo[tid >> 6][j] = lo[j]; shi[tid >> 6][j] = hi[j]; }
+        __syncthreads();
+        if (tid < 3) {
+            float l = slo[0][tid], h = shi[0][tid];
+            for (int w = 1; w < 4; ++w) { l = fminf(l, slo[w][tid]); h = fmaxf(h, shi[w][tid]); }
+            I.corner[tid] = N > 0 ? l : 0.f;
+            if (I.shape) I.shape[1 + tid] = N > 0 ? (int32_t)((h - l) / I.res) + 1 : 1;
+        }
+        if (tid == 3 && I.shape) I.shape[0] = (int32_t)N;
+        return;
+    }
+    if (blockIdx.x <= STAGE_COPY_BLOCKS) {
+        const int64_t n3 = 3 * N, nf = I.feat && D.feat_src ? (int64_t)I.F * N : 0, total = 2 * n3 + nf;
+        for (int64_t i = (int64_t)(blockIdx.x - 1) * 256 + tid; i < total; i += (int64_t)STAGE_COPY_BLOCKS * 256) {
+            if (i < n3) I.pc[i] = D.pc_src[i];
+            else if (i < 2 * n3) I.nrm[i - n3] = D.nrm_src[i - n3];
+            else I.feat[i - 2 * n3] = D.feat_src[i - 2 * n3];
+        }
+        return;
+    }
+    if (!I.idx) return;
+    const unsigned long long Nu = (unsigned long long)N;
+    const uint2 key = make_uint2((unsigned)D.seed, (unsigned)(D.seed >> 32));
+    const int64_t first = (int64_t)(blockIdx.x - 1 - STAGE_COPY_BLOCKS) * 256 + tid, step = (int64_t)B.n_sample_blocks * 256;
+    for (int64_t p = first; p < I.n_pairs; p += step) {
+        const uint4 a = philox4x32_10(make_uint4((unsigned)p, (unsigned)(p >> 32), 0u, 0u), key);
+        const uint4 b = philox4x32_10(make_uint4((unsigned)p, (unsigned)(p >> 32), 1u, 0u), key);
+        reinterpret_cast<longlong2*>(I.idx)[p] = make_longlong2((long long)(((unsigned long long)a.x * Nu) >> 32),
+                                                                (long long)(((unsigned long long)a.y * Nu) >> 32));
+        if (I.u_tr) reinterpret_cast<float2*>(I.u_tr)[p] = make_float2((float)(a.z >> 8) * 0x1p-24f, (float)(a.w >> 8) * 0x1p-24f);
+        if (I.u_rot) reinterpret_cast<float2*>(I.u_rot)[p] = make_float2((float)(b.x >> 8) * 0x1p-24f, (float)(b.y >> 8) * 0x1p-24f);
+    }
+}
+
 struct VoxLayout { size_t keys, vals, mask, compact, temp, temp_bytes, total; };
 VoxLayout vox_layout(int64_t N)
 {
@@ -478,6 +539,27 @@ int cppf_sample_pairs(long long* idx, float* u_tr, float* u_rot, int64_t n_pairs
     int64_t nb = (n_pairs + 255) / 256;
     if (nb > 4096) nb = 4096;
     sample_pairs_kernel<<<(int)nb, 256, 0, (hipStream_t)stream>>>(idx, u_tr, u_rot, n_pairs, n_points, n_dev, seed, seed_dev);
+    return (int)hipGetLastError();
+}
+
+int cppf_stage_batch(int n_items, const CppfStageItem* items, void* stream)
+{
+    if (n_items < 1 || n_items > STAGE_MAX || !items) return CPPF_EINVAL;
+    StageBatch B = {};
+    int64_t max_pairs = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const CppfStageItem& it = items[i];
+        if (!it.desc || !it.pc || !it.nrm || !it.corner || it.n_cap < 1 || it.n_cap > 0x7fffffffll || it.n_pairs < 0 || !(it.res > 0.f) ||
+            (it.feat && it.F < 1) || (it.n_pairs > 0 && it.idx && (reinterpret_cast<uintptr_t>(it.idx) & 15)))
+            return CPPF_EINVAL;
+        B.item[i] = it;
+        if (it.idx && it.n_pairs > max_pairs) max_pairs = it.n_pairs;
+    }
+    int64_t nb = (max_pairs + 511) / 512;          // two pairs per thread at the largest list
+    if (nb > 2048) nb = 2048;
+    B.n_sample_blocks = (int)(nb < 1 ? 1 : nb);
+    const unsigned gx = 1 + STAGE_COPY_BLOCKS + (max_pairs > 0 ? (unsigned)B.n_sample_blocks : 0u);
+    stage_batch_kernel<<<dim3(gx, (unsigned)n_items), 256, 0, (hipStream_t)stream>>>(B);
     return (int)hipGetLastError();
 }
 

@@ -766,10 +766,15 @@ class PoseChain:
 
     FULL_FIRST_ON, FULL_FIRST_OFF = PosePipeline.FULL_FIRST_ON, PosePipeline.FULL_FIRST_OFF
 
-    def __init__(self, pipes, use_graph=True, vote_workgroups=0, prestages=None):
+    def __init__(self, pipes, use_graph=True, vote_workgroups=0, prestages=None, staged=False):
         """prestages: optional list of callables, one per member (or None): launches enqueued at the head of the chain, in front of
         the member's point encoder -- e.g. the count-driven pre-processing that fills the member's cloud, normals, corner and shape
-        record from a depth frame (cppf_amd.frames.FrameRunner)."""
+        record from a depth frame (cppf_amd.frames.FrameRunner).
+        staged=True: the chain serves objects that are ALREADY on the device (run_staged): its first launch (cppf_stage_batch) copies
+        each member's cloud / normals / features from where the caller keeps them, sets up its grid and draws its pairs and bin
+        uniforms -- all read from a 48-byte device descriptor per member, rewritten with one small copy per replay -- and its last
+        launch assembles the members' FINISHED records (`records` f64[n, sharding.RECORD], the host end of nocs/inference.py:299-339
+        on the device): nothing comes back to the host."""
         pipes = list(pipes)
         if not 1 <= len(pipes) <= 8:
             raise ValueError("1 to 8 pipelines per chain")
@@ -789,12 +794,40 @@ class PoseChain:
         self.vote_workgroups = int(vote_workgroups or 0)
         self.full_first = False
         self._use_graph, self._graphs, self._owned, self.tensors = use_graph, {}, {}, None
+        self.staged = bool(staged)
+        if self.staged:
+            from .sharding import RECORD
+            n, W = len(pipes), _lib.STAGE_DESC_WORDS
+            self.desc = torch.zeros((n, W), dtype=torch.int64, device=self.device)       # CppfStageDesc per member
+            self.records = torch.zeros((n, RECORD), dtype=torch.float64, device=self.device)
+            # a ring of pinned descriptor blocks: a block is rewritten only after the copy that last read it has executed
+            self._desc_ring = []
+            for _ in range(4):
+                h = torch.zeros((n, W), dtype=torch.int64).pin_memory()
+                self._desc_ring.append((h, h.numpy().view(np.uint64), torch.cuda.Event()))
+            self._ring_pos = 0
+
+    def _stage(self):
+        """the chain's first launch (staged chains): clouds in, grids set up, pairs and uniforms drawn (cppf_stage_batch)"""
+        pipes = self.pipes
+        arr = (_lib.StageItem * len(pipes))()
+        for i, p in enumerate(pipes):
+            a = arr[i]
+            a.desc, a.pc, a.nrm, a.corner = self.desc[i].data_ptr(), p.pc.data_ptr(), p.nrm.data_ptr(), p.corner.data_ptr()
+            a.feat = p.feat.data_ptr() if p.point_encoder is None else None
+            a.shape = p.shape.data_ptr() if p.dynamic else None
+            a.idx, a.u_tr, a.u_rot = p.idx.data_ptr(), p.u_tr.data_ptr(), p.u_rot.data_ptr()
+            a.n_pairs, a.n_cap, a.F, a.res = p.idx.shape[0], p.pc.shape[0], p.feat.shape[1], float(np.float32(p.cfg.res))
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().cppf_stage_batch(len(pipes), arr, stream_ptr(self.device)), "cppf_stage_batch")
 
     def _chain(self):
         from .models.model import forward_decode_batch
         import ctypes as C
         pipes, p0 = self.pipes, self.pipes[0]
         L = _lib.lib()
+        if self.staged:                                                          # nocs/inference.py:177,194-196 for resident objects
+            self._stage()
         for pre in self.prestages:                                               # nocs/inference.py:131-142 (FrameRunner)
             if pre is not None:
                 pre()
@@ -844,6 +877,10 @@ class PoseChain:
             a.res64, a.res, a.tol = float(p.cfg.res), float(p.cfg.res), float(np.float32(3 * p.cfg.res))
             a.gx, a.gy, a.gz = (1, 1, 1) if p.dynamic else p.dims
             a.n_dirs, a.second_pass = (2 if p.cfg.regress_right else 1), (0 if self.full_first else 1)
+            if self.staged:                      # the finished record, assembled by the last launch (:299-339)
+                a.record_out, a.object_id_dev = self.records[i].data_ptr(), self.desc[i].data_ptr() + 40
+                a.scale_mean = (C.c_double * 3)(*[float(v) for v in p.cfg.scale_mean])
+                a.regress_right = 1 if p.cfg.regress_right else 0
             keep.append((pws, packed))
         dims = (C.c_int * len(p0.encoder.ppffcs))(*p0.encoder.ppffcs)
         thr = float(np.float32(np.cos(p0.angle_tol / 180 * np.pi)))
@@ -856,10 +893,29 @@ class PoseChain:
     def _key(self):
         return (self.vote_workgroups,) + tuple((p.idx.data_ptr(), p.pc.data_ptr()) for p in self.pipes)
 
-    def run_async(self, records_out, check_weights=True):
-        """Replay the chain and copy every member's 21-double record into records_out[i] (device f64[21]) on the current stream."""
+    def run_staged(self, objs, seeds, ids, rows_out, check_weights=None, capture=True):
+        """Staged chains: objs[i] = dict(pc, normals[, feat]) of DEVICE f32 tensors (contiguous; they must stay alive and unchanged
+        until the chain has run), seeds[i] the Philox key of member i's pair / uniform draws, ids[i] its object id; rows_out: device
+        f64[n, RECORD] that receives the members' finished records (one device copy).  No host synchronisation.
+        capture=False: a chain that has no captured graph yet runs its launches eagerly this time (a one-off combination)."""
+        n = len(self.pipes)
+        host, words, ev = self._desc_ring[self._ring_pos % len(self._desc_ring)]
+        self._ring_pos += 1
+        ev.synchronize()
+        for i, (o, p) in enumerate(zip(objs, self.pipes)):
+            feat = o.get("feat") if p.point_encoder is None else None
+            words[i] = (o["pc"].data_ptr(), o["normals"].data_ptr(), 0 if feat is None else feat.data_ptr(), o["pc"].shape[0],
+                        int(seeds[i]) & 0xFFFFFFFFFFFFFFFF, int(ids[i]))
+        self.desc.copy_(host, non_blocking=True)
+        ev.record(torch.cuda.current_stream(self.device))
+        self.run_async(None, check_weights, eager=not capture and self._graphs.get(self.full_first, (None, None))[0] is None)
+        rows_out.copy_(self.records[:n] if rows_out.shape[0] == n else self.records[:rows_out.shape[0]], non_blocking=True)
+
+    def run_async(self, records_out, check_weights=True, eager=False):
+        """Replay the chain and copy every member's 21-double record into records_out[i] (device f64[21]) on the current stream
+        (records_out None: no copies).  eager: launch instead of capturing / replaying."""
         with torch.no_grad(), workspace_scope(id(self)):
-            if not self._use_graph:
+            if not self._use_graph or eager:
                 self._chain()
             else:
                 form = self.full_first
@@ -887,7 +943,7 @@ class PoseChain:
                 graph.replay()
                 for p in self.pipes:
                     p._note_images_read()
-        for p, r in zip(self.pipes, records_out):
+        for p, r in zip(self.pipes, records_out or ()):
             r.copy_(p.ws.rec, non_blocking=True)
 
     def run(self, check_weights=True):

@@ -43,7 +43,8 @@
 extern "C" {
 #endif
 
-#define CPPF_ABI_VERSION 3   /* 2: vote workspace contract (state in its first cppf_vote_workspace_init_bytes() bytes), cppf_vote_grid_raw; 3: batched votes (CppfVoteItem), cppf_pair_mlp_batch_plan */
+#define CPPF_ABI_VERSION 4   /* 2: vote workspace contract (state in its first cppf_vote_workspace_init_bytes() bytes), cppf_vote_grid_raw; 3: batched votes (CppfVoteItem), cppf_pair_mlp_batch_plan;
+                              * 4: CppfPoseTailItem assembles the finished pose record on the device (record_out ...), cppf_stage_batch */
 
 #define CPPF_EINVAL (-1)     /* bad argument (null pointer, negative size, n_rots out of range) */
 #define CPPF_EWORKSPACE (-2) /* workspace too small / missing */
@@ -176,6 +177,18 @@ typedef struct CppfPoseTailItem {
     double res64;                                                   /* res as the caller holds it (fp64: T = corner + cand * res, :210) */
     float res, tol;                                                 /* fp32 res of the kernels; back-vote tolerance (3 * res) */
     int gx, gy, gz, n_dirs, second_pass;
+    /* Optional (record_out != NULL): the FINISHED pose record, assembled by launch 6's last workgroup -- the host end of
+     * nocs/inference.py:299-339 (axis flips from the sign sums, right axis orthogonalised or derived, scale = exp(mean) * scale_mean * 2) --
+     * so that a batch's records enter the end-of-batch gather without a host round trip.
+     *   record_out  device f64[16]: T[3] | up[3] | right[3] | scale[3] | arg-max index | peak | survivors | object id
+     *   object id = *object_id_dev (device i64, e.g. &CppfStageDesc.object_id) when that is not NULL, else object_id_host
+     * A degenerate right axis (|right| < 1e-7, :325-328: the reference draws a random vector) takes the fixed vector
+     * numpy.random.default_rng(0).standard_normal(3), as cppf_amd.inference._assemble does. */
+    double* record_out;
+    const long long* object_id_dev;
+    long long object_id_host;
+    double scale_mean[3];                                           /* config/category/<cat>.yaml: scale_mean */
+    int regress_right;                                              /* the category regresses the right axis (:305-312) */
 } CppfPoseTailItem;
 int cppf_pose_tail_batch(int n_items, const CppfPoseTailItem* items_host, int F, const int* dims, int n_res, int out_dim, int tr_bins,
                          int rot_bins, int n_rots, const float* sphere32, const double* sphere64, int n_sphere, int sphere_sorted_by_y,
@@ -642,6 +655,34 @@ int cppf_sample_pairs(long long* idx, float* u_tr, float* u_rot, int64_t n_pairs
  * dims_host i32[3] = int32((max - min) / res) + 1 with the quotient in fp32.  NaN coordinates are ignored by the comparisons. */
 int cppf_host_grid_shape(const float* pc_host, int64_t n_points, float res, float* corners_host, int32_t* dims_host);
 int cppf_mod_pairs_dyn(long long* idx, int64_t n_pairs, const int32_t* n_dev, void* stream);
+/* The head of a captured chain for objects that are ALREADY on the device ("inputs already resident on device"): for up
+ * to 8 objects, ONE launch copies each object's cloud, normals and (optional) per-point features from wherever the caller keeps them
+ * into the chain's own buffers, sets up its vote grid (nocs/inference.py:194-195: corner = min(pc), dims = int32((max - min) / res) + 1,
+ * as cppf_grid_setup) and draws its pair list and bin uniforms (:177,186,250: as cppf_sample_pairs, bit for bit, with seed = desc.seed).
+ * What changes from one replay to the next -- where the object lives, how many points it has, its seed, its id -- is read from a
+ * DESCRIPTOR in device memory (the caller rewrites the descriptors with one small copy before each replay); what does not -- the
+ * chain's buffers -- travels by value, so the launch is capturable in a hipGraph.  The reference's counterpart is the host side of the
+ * instance loop, nocs/inference.py:120-142,177,194-196 (numpy arrays uploaded per instance). */
+typedef struct CppfStageDesc {          /* DEVICE memory, 48 bytes, one per object of the chain */
+    const float* pc_src;                /* device f32[n_points,3] */
+    const float* nrm_src;               /* device f32[n_points,3] */
+    const float* feat_src;              /* device f32[n_points,F] or NULL (features come from a point encoder in the chain) */
+    long long n_points;                 /* <= the item's n_cap (the caller checks) */
+    unsigned long long seed;            /* Philox key of the pair / uniform draws */
+    long long object_id;                /* copied into the pose record (CppfPoseTailItem.object_id_dev may point here) */
+} CppfStageDesc;
+typedef struct CppfStageItem {          /* host memory, by value at launch: the chain's buffers */
+    const CppfStageDesc* desc;          /* device */
+    float* pc; float* nrm; float* feat; /* device f32[n_cap,3], f32[n_cap,3], f32[n_cap,F] (feat NULL: not copied) */
+    float* corner;                      /* device f32[3] */
+    int32_t* shape;                     /* device i32[4] <- {n_points, gx, gy, gz}, or NULL (a static-shape pipeline: only `corner` is written) */
+    long long* idx;                     /* device i64[n_pairs,2] or NULL (no draw) */
+    float* u_tr; float* u_rot;          /* device f32[n_pairs,2] each; either may be NULL */
+    int64_t n_pairs, n_cap;
+    int F;
+    float res;
+} CppfStageItem;
+int cppf_stage_batch(int n_items, const CppfStageItem* items_host, void* stream);
 size_t cppf_backproject_workspace_bytes(int H, int W);
 int cppf_backproject(const void* depth, int depth_is_u16, const uint8_t* mask, int H, int W, const double* kinv_host,
                      double* pts, int32_t* pix, int32_t* count, void* workspace, size_t workspace_bytes, void* stream);

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} declared in include/cppf.h but not exported"
     assert set(declared) == set(_lib.exported_symbols())
     assert not hasattr(L, "cppf_debug_mlp_chain_only")
-    assert L.cppf_abi_version() == 3 == _lib.ABI_VERSION and "#define CPPF_ABI_VERSION 3" in hdr
+    assert L.cppf_abi_version() == 4 == _lib.ABI_VERSION and "#define CPPF_ABI_VERSION 4" in hdr
     assert b"workspace" in L.cppf_error_string(-2)
 
 
@@ -52,6 +52,7 @@ def test_workspace_queries_and_argument_errors_without_a_device():
     assert L.cppf_backvote(None, None, None, None, None, 0.004, 10, 72, 4, 4, 4, None, 0.01, None, None) == -1
     assert L.cppf_grid_argmax(None, 10, None, None, None, 0, None) == -1
     assert L.cppf_rot_voting(None, None, None, None, 10, 72, None) == -1
+    assert L.cppf_stage_batch(0, None, None) == -1 and L.cppf_stage_batch(1, None, None) == -1
     # empty pair lists are legal no-ops (ragged inputs), with null pointers
     assert L.cppf_backvote(None, None, None, None, None, 0.004, 0, 72, 4, 4, 4, None, 0.01, None, None) == 0
     assert L.cppf_rot_voting(None, None, None, None, 0, 72, None) == 0
@@ -535,4 +536,4 @@ def test_plain_c_host_compiles_and_runs_the_host_only_entry_points(c_host):
     import subprocess
     p = subprocess.run([c_host], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stdout + p.stderr
-    assert "host ok: ABI 3" in p.stdout
+    assert "host ok: ABI 4" in p.stdout
