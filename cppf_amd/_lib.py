@@ -79,6 +79,7 @@ _SIGS = {
     "cppf_knn": (C.c_int, [vp, vp, i32, i32, vp, vp]),
     "cppf_frame_cloud_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "cppf_frame_cloud_dyn": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, vp, C.c_double, C.c_double, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "cppf_frame_cloud_dyn_bit": (C.c_int, [vp, i32, vp, i32, vp, i32, i32, vp, C.c_double, C.c_double, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
     "cppf_sample_pairs": (C.c_int, [vp, vp, vp, i64, i64, vp, C.c_uint64, vp, vp]),
     "cppf_host_grid_shape": (C.c_int, [vp, i64, f32, vp, vp]),
     "cppf_mod_pairs_dyn": (C.c_int, [vp, i64, vp, vp]),

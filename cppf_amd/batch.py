@@ -212,9 +212,15 @@ class BatchPoseRunner:
                 for k in ("pc", "normals", "feat"):
                     if obj.get(k) is not None:
                         o[k] = obj[k].to(device=self.device, dtype=torch.float32).contiguous()
-                if o.get("dims") is None:
-                    lo, hi = o["pc"].amin(0), o["pc"].amax(0)
-                    o["dims"] = tuple(int(v) for v in (((hi - lo) / np.float32(obj["cfg"].res)).to(torch.int32) + 1).tolist())
+                if o.get("dims") is None:            # cppf_grid_setup: the arithmetic the chain's own grid set-up uses (a torch
+                    from . import _lib               # division by a scalar multiplies by its reciprocal: other dims at the edges)
+                    from ._torch_util import stream_ptr
+                    cd = torch.empty(8, dtype=torch.int32, device=self.device)
+                    with torch.cuda.device(self.device):
+                        _lib.check(_lib.lib().cppf_grid_setup(o["pc"].data_ptr(), o["pc"].shape[0], float(np.float32(obj["cfg"].res)),
+                                                              cd[:3].view(torch.float32).data_ptr(), cd[4:7].data_ptr(),
+                                                              stream_ptr(self.device)), "cppf_grid_setup")
+                    o["dims"] = tuple(int(v) for v in cd[4:7].tolist())
             else:
                 _, o["dims"] = grid_shape(obj["pc"], obj["cfg"].res)
                 for k in ("pc", "normals", "feat"):
@@ -244,8 +250,11 @@ class BatchPoseRunner:
                 self.point_encoders[cat]._packed_weights(dev)
         for st in self._streams:
             st.wait_stream(main)
-        # every lane busy from the start: chains of ceil(n / lanes) members (8 objects on 3 lanes: 3 + 3 + 2)
-        L = self.chain_len or max(1, min(8, -(-n // self.n_lanes)))
+        # chains of 1, 2, 4 or 8 members -- lists of equal length in those numbers keep each list on its own XCDs in the pair kernel
+        # (cppf_pair_mlp_batch_plan) -- the smallest such length that gives every lane at most one chain, capped at 8: 8 objects on 3
+        # lanes run as 4 + 4 (0.145 ms per object; 3 + 3 + 2: 0.151, 2 + 2 + 2 + 2: 0.161), 16 as 8 + 8, 24 as 8 + 8 + 8
+        # (profiles/r6_resident_probe.txt)
+        L = self.chain_len or min(8, 1 << max(0, (-(-n // self.n_lanes) - 1).bit_length()))
         groups = [list(range(g, min(g + L, n))) for g in range(0, n, L)]
         ran = []
         for gi, slots in enumerate(groups):
@@ -267,12 +276,16 @@ class BatchPoseRunner:
                 ran.append((chain, slots))
         for st in self._streams:
             main.wait_stream(st)
+        if self.__dict__.get("own_done") is not None:      # a caller's timing event: this rank's chains, before the gather (bench.py)
+            self.own_done.record(main)
         snap = self.__dict__.get("_snap")
         if snap is None or snap[0].shape[0] < n:
             snap = self._snap = (torch.zeros((max(n, 1), sharding.RECORD), dtype=torch.float64).pin_memory(), torch.cuda.Event())
         snap[0][:n].copy_(local[:n], non_blocking=True)
         snap[1].record(main)
         self._pending = ran
+        if world == 1 and not (sharding.forced() and sharding.dist.is_initialized()):
+            return local[:len(objects)].clone()            # (the next batch overwrites `local`: hand the caller its own copy)
         return sharding.gather_records(local, len(objects), rank, world, dev, validate=False)
 
     def _adapt_resident(self):

@@ -140,9 +140,10 @@ __global__ __launch_bounds__(256) void normals_kernel(const float* __restrict__ 
 // valid pixel = bit `bit` of the frame's label image set and depth > 0 (utils/util.py:609-610 with instance_mask = that bit)
 template <typename T, typename LT>
 __global__ __launch_bounds__(256) void fc_valid_kernel(const T* __restrict__ depth, const LT* __restrict__ labels, unsigned bit, int64_t n,
-                                                       uint8_t* __restrict__ valid)
+                                                       uint8_t* __restrict__ valid, const int32_t* __restrict__ bit_dev)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (bit_dev) bit = (unsigned)*bit_dev & (8u * (unsigned)sizeof(LT) - 1u);      // (a captured launch: this replay's bit is in memory)
     if (i < n) valid[i] = ((labels[i] >> bit) & 1) && (depth[i] > (T)0);
 }
 // back-projection of the compacted pixels (bp_points_kernel's arithmetic), nocs/inference.py:132 `pc = pts / 1000.0` (fp64), the axis
@@ -481,10 +482,10 @@ size_t cppf_frame_cloud_workspace_bytes(int H, int W, int n_cap, int knn_k)
     return fc_layout(H, W, n_cap, knn_k).total;
 }
 
-int cppf_frame_cloud_dyn(const void* depth, int depth_is_u16, const void* labels, int label_bytes, int label_bit, int H, int W,
-                         const double* kinv_host, double divisor, double res, int knn_k, int k_min, int n_cap, float* pc_out,
-                         float* nrm_out, float* corner_out, int32_t* shape_out, int32_t* nbrs_out, void* workspace, size_t workspace_bytes,
-                         void* stream)
+static int frame_cloud_impl(const void* depth, int depth_is_u16, const void* labels, int label_bytes, int label_bit, const int32_t* bit_dev,
+                            int H, int W, const double* kinv_host, double divisor, double res, int knn_k, int k_min, int n_cap, float* pc_out,
+                            float* nrm_out, float* corner_out, int32_t* shape_out, int32_t* nbrs_out, void* workspace, size_t workspace_bytes,
+                            void* stream)
 {
     if (H < 1 || W < 1 || (int64_t)H * W > 0x7fffffffll || !depth || !labels || !kinv_host || !pc_out || !nrm_out || !corner_out || !shape_out)
         return CPPF_EINVAL;
@@ -507,9 +508,9 @@ int cppf_frame_cloud_dyn(const void* depth, int depth_is_u16, const void* labels
     const unsigned bit = (unsigned)label_bit, tmask = (unsigned)L.M - 1u;
 #define FC_VALID(T)                                                                                                                       \
     do {                                                                                                                                  \
-        if (label_bytes == 1) fc_valid_kernel<T, uint8_t><<<nbp, 256, 0, st>>>((const T*)depth, (const uint8_t*)labels, bit, n, valid);   \
-        else if (label_bytes == 2) fc_valid_kernel<T, uint16_t><<<nbp, 256, 0, st>>>((const T*)depth, (const uint16_t*)labels, bit, n, valid); \
-        else fc_valid_kernel<T, uint32_t><<<nbp, 256, 0, st>>>((const T*)depth, (const uint32_t*)labels, bit, n, valid);                  \
+        if (label_bytes == 1) fc_valid_kernel<T, uint8_t><<<nbp, 256, 0, st>>>((const T*)depth, (const uint8_t*)labels, bit, n, valid, bit_dev);   \
+        else if (label_bytes == 2) fc_valid_kernel<T, uint16_t><<<nbp, 256, 0, st>>>((const T*)depth, (const uint16_t*)labels, bit, n, valid, bit_dev); \
+        else fc_valid_kernel<T, uint32_t><<<nbp, 256, 0, st>>>((const T*)depth, (const uint32_t*)labels, bit, n, valid, bit_dev);                  \
     } while (0)
     if (depth_is_u16) FC_VALID(uint16_t); else FC_VALID(float);
 #undef FC_VALID
@@ -529,6 +530,25 @@ int cppf_frame_cloud_dyn(const void* depth, int depth_is_u16, const void* labels
     fc_normals_kernel<<<nbc, 256, 0, st>>>(pc_out, nbrs, shape_out, knn_k, nrm_out);
     fc_grid_kernel<<<1, 1024, 0, st>>>(pc_out, (float)res, corner_out, shape_out);                                    // :194-195
     return (int)hipGetLastError();
+}
+
+int cppf_frame_cloud_dyn(const void* depth, int depth_is_u16, const void* labels, int label_bytes, int label_bit, int H, int W,
+                         const double* kinv_host, double divisor, double res, int knn_k, int k_min, int n_cap, float* pc_out,
+                         float* nrm_out, float* corner_out, int32_t* shape_out, int32_t* nbrs_out, void* workspace, size_t workspace_bytes,
+                         void* stream)
+{
+    return frame_cloud_impl(depth, depth_is_u16, labels, label_bytes, label_bit, nullptr, H, W, kinv_host, divisor, res, knn_k, k_min, n_cap,
+                            pc_out, nrm_out, corner_out, shape_out, nbrs_out, workspace, workspace_bytes, stream);
+}
+
+int cppf_frame_cloud_dyn_bit(const void* depth, int depth_is_u16, const void* labels, int label_bytes, const int32_t* label_bit_dev, int H,
+                             int W, const double* kinv_host, double divisor, double res, int knn_k, int k_min, int n_cap, float* pc_out,
+                             float* nrm_out, float* corner_out, int32_t* shape_out, int32_t* nbrs_out, void* workspace,
+                             size_t workspace_bytes, void* stream)
+{
+    if (!label_bit_dev) return CPPF_EINVAL;
+    return frame_cloud_impl(depth, depth_is_u16, labels, label_bytes, 0, label_bit_dev, H, W, kinv_host, divisor, res, knn_k, k_min, n_cap,
+                            pc_out, nrm_out, corner_out, shape_out, nbrs_out, workspace, workspace_bytes, stream);
 }
 
 int cppf_sample_pairs(long long* idx, float* u_tr, float* u_rot, int64_t n_pairs, int64_t n_points, const int32_t* n_dev,
@@ -569,12 +589,15 @@ int cppf_host_grid_shape(const float* pc_host, int64_t n_points, float res, floa
 {
     if (!pc_host || n_points < 1 || !(res > 0.f) || !corners_host || !dims_host) return CPPF_EINVAL;
     float lo[3] = {pc_host[0], pc_host[1], pc_host[2]}, hi[3] = {pc_host[0], pc_host[1], pc_host[2]};
-    for (int64_t i = 1; i < n_points; ++i)
+    float bad = 0.f;                                   // v - v is 0 for a finite v, NaN for NaN and +-inf: one accumulator, no branch
+    for (int64_t i = 0; i < n_points; ++i)
         for (int c = 0; c < 3; ++c) {
             const float v = pc_host[3 * i + c];
+            bad += v - v;
             lo[c] = v < lo[c] ? v : lo[c];
             hi[c] = v > hi[c] ? v : hi[c];
         }
+    if (bad != 0.f) return CPPF_ENONFINITE;            // (numpy's min / max would propagate the NaN: the caller fails loudly, as the reference)
     for (int c = 0; c < 3; ++c) {
         corners_host[c] = lo[c]; corners_host[3 + c] = hi[c];
         const volatile float q = (hi[c] - lo[c]) / res;

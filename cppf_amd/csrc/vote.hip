@@ -2001,6 +2001,7 @@ extern "C" const char* cppf_error_string(int code)
     case CPPF_EINVAL: return "cppf: invalid argument";
     case CPPF_EWORKSPACE: return "cppf: workspace missing or too small";
     case CPPF_EUNSUPPORTED: return "cppf: unsupported layer shape";
+    case CPPF_ENONFINITE: return "cppf: the cloud holds non-finite coordinates";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "cppf: unknown error";
     }
 }

@@ -89,7 +89,9 @@ class FrameRunner:
     fewer points than the kNN needs is skipped like the reference's (:121-123)."""
 
     def __init__(self, encoders, point_encoders, device, intrinsics=NOCS_INTRINSICS, n_pairs=100000, angle_tol=1.5, num_rots=72,
-                 cfgs=None, n_lanes=3, chain_len=None, cap_bucket=4096, max_members=48):
+                 cfgs=None, n_lanes=3, chain_len=None, cap_bucket=4096, max_members=48, max_chains=32):
+        """max_members: pipelines kept (each with its captured graph and ~0.1 GB of buffers at 100 000 pairs); max_chains: captured
+        chains kept (at least the groups of one frame: a chain of the running frame is never evicted)."""
         from collections import OrderedDict
         self.encoders, self.point_encoders, self.device = encoders, point_encoders, device
         self.intrinsics = np.asarray(intrinsics, np.float64)
@@ -99,13 +101,17 @@ class FrameRunner:
         self.n_lanes, self.chain_len, self.cap_bucket = max(1, int(n_lanes)), chain_len, int(cap_bucket)
         self.sphere = np.array(fibonacci_sphere(num_sphere_bins(angle_tol)))
         self.max_instances = 32                       # bits of the u32 label image
-        self._members, self.max_members = OrderedDict(), int(max_members)
-        self._chains, self._seen = OrderedDict(), {}
+        # members: pipelines (+ pre-processing stage) keyed by what their buffers and launches are sized for -- (category, point
+        # capacity, grid class) -- and handed to the instances of a frame from a pool, first free first: WHICH instance a member
+        # serves (its label bit, its Philox key) is written to the member's device record per frame, not baked into its launches,
+        # so a video whose instance count, order or mask sizes change keeps replaying the graphs it has
+        self._members, self.max_members = OrderedDict(), int(max_members)          # id(pipe) -> member, least recently used first
+        self._pool = {}                                                            # class key -> [member, ...]
+        self._chains, self._seen, self.max_chains = OrderedDict(), {}, max(1, int(max_chains))
         self._many_tile_cats = set()
         self._hw = None
         self._streams = [torch.cuda.Stream(device=device) for _ in range(self.n_lanes)]
-        self._seeds_host = torch.zeros(32, dtype=torch.int64).pin_memory()        # the instances' Philox keys, uploaded with the frame
-        self._seeds = torch.zeros(32, dtype=torch.int64, device=device)
+        self._slots_host = torch.zeros((32, 2), dtype=torch.int64).pin_memory()    # {label bit, Philox key} per instance of the frame
 
     def _frame_buffers(self, H, W):
         if self._hw != (H, W):
@@ -116,35 +122,43 @@ class FrameRunner:
             self._labels = torch.empty((H, W), dtype=torch.int32, device=self.device)
             for ch in self._chains.values():
                 ch.release()
+            for mem in self._members.values():
+                mem["pipe"].release()
             self._members.clear()
+            self._pool.clear()
             self._chains.clear()
 
-    def _member(self, cat, n_mask, lane, slot, bit):
-        """(pipeline, prestage) for an instance of `cat` with n_mask label pixels at this position.  Grid class: few tiles (every
-        NOCS category at its own resolution on a tight mask) until an instance of the category came back with "shape beyond the
-        launch's capacities" -- from then on the category's pipelines are of the many-tile class (any grid of up to 64 tiles)."""
+    def _member(self, cat, n_mask, used):
+        """A member of class (category, capacity for n_mask label pixels, grid class) that no instance of this frame holds yet
+        (`used`: ids taken), created when the pool has none.  Grid class: few tiles (every NOCS category at its own resolution on a
+        tight mask) until an instance of the category came back with "shape beyond the launch's capacities" -- from then on the
+        category's members are of the many-tile class (any grid of up to 64 tiles)."""
         from . import _lib
         from ._torch_util import stream_ptr
         from .inference import PosePipeline
         cap = max(self.cap_bucket, 1 << int(np.ceil(np.log2(max(n_mask, 1)))))
-        many = cat in self._many_tile_cats
-        key = (cat, cap, lane, slot, bit, many)
-        hit = self._members.get(key)
-        if hit is not None:
-            self._members.move_to_end(key)
-            return hit
+        key = (cat, cap, cat in self._many_tile_cats)
+        for mem in self._pool.get(key, ()):
+            if id(mem["pipe"]) not in used:
+                self._members.move_to_end(id(mem["pipe"]))
+                return mem
         while len(self._members) >= self.max_members:
+            victim = next((k for k in self._members if k not in used), None)
+            if victim is None:
+                break                                   # every member is in use by this frame: the bound yields
             torch.cuda.synchronize(self.device)
-            _, (old, _) = self._members.popitem(last=False)
-            for ck in [ck for ck in self._chains if id(old) in ck]:
+            old = self._members.pop(victim)
+            self._pool[old["key"]].remove(old)
+            for ck in [ck for ck in self._chains if victim in ck]:
                 self._chains.pop(ck).release()
-            old.release()
+            old["pipe"].release()
         cfg, H, W = self.cfgs[cat], self._hw[0], self._hw[1]
-        pipe = PosePipeline(self.encoders[cat], cfg, cap, self.n_pairs, many, self.device, self.sphere, num_rots=self.num_rots,
+        pipe = PosePipeline(self.encoders[cat], cfg, cap, self.n_pairs, key[2], self.device, self.sphere, num_rots=self.num_rots,
                             angle_tol=self.angle_tol, point_encoder=self.point_encoders[cat], dynamic=True)
         L = _lib.lib()
         ws = torch.empty(int(L.cppf_frame_cloud_workspace_bytes(H, W, cap, cfg.knn)), dtype=torch.uint8, device=self.device)
-        dev, depth, labels, kinv, seeds = self.device, self._depth, self._labels, self.kinv, self._seeds
+        slot = torch.zeros(2, dtype=torch.int64, device=self.device)          # {label bit (low 32 bits), Philox key}: written per frame
+        dev, depth, labels, kinv = self.device, self._depth, self._labels, self.kinv
         # the normals are fitted on the k = cfg.knn neighbour sets; a point encoder with the same k (config/config.yaml: 60 for both)
         # reuses them instead of searching again (the stage writes them straight into the pipeline's neighbour buffer)
         share = pipe.point_encoder is not None and pipe.point_encoder.k == cfg.knn
@@ -153,33 +167,41 @@ class FrameRunner:
 
         def prestage():
             with torch.cuda.device(dev):
-                _lib.check(L.cppf_frame_cloud_dyn(depth.data_ptr(), 1, labels.data_ptr(), 4, bit, H, W, kinv.ctypes.data, 1000.0,
-                                                  float(cfg.res), cfg.knn, cfg.knn + 1, cap, pipe.pc.data_ptr(), pipe.nrm.data_ptr(),
-                                                  pipe.corner.data_ptr(), pipe.shape.data_ptr(), nbrs_ptr, ws.data_ptr(), ws.numel(),
-                                                  stream_ptr(dev)), "cppf_frame_cloud_dyn")
-                # pairs and bin uniforms: N from the shape record the stage just wrote, the key from the frame's seed block
+                _lib.check(L.cppf_frame_cloud_dyn_bit(depth.data_ptr(), 1, labels.data_ptr(), 4, slot.data_ptr(), H, W, kinv.ctypes.data,
+                                                      1000.0, float(cfg.res), cfg.knn, cfg.knn + 1, cap, pipe.pc.data_ptr(),
+                                                      pipe.nrm.data_ptr(), pipe.corner.data_ptr(), pipe.shape.data_ptr(), nbrs_ptr,
+                                                      ws.data_ptr(), ws.numel(), stream_ptr(dev)), "cppf_frame_cloud_dyn_bit")
+                # pairs and bin uniforms: N from the shape record the stage just wrote, the key from the member's record
                 _lib.check(L.cppf_sample_pairs(pipe.idx.data_ptr(), pipe.u_tr.data_ptr(), pipe.u_rot.data_ptr(), pipe.idx.shape[0], 1,
-                                               pipe.shape.data_ptr(), 0, seeds.data_ptr() + 8 * bit, stream_ptr(dev)), "cppf_sample_pairs")
-        pipe._frame_ws = ws
-        self._members[key] = (pipe, prestage)
-        return pipe, prestage
+                                               pipe.shape.data_ptr(), 0, slot.data_ptr() + 8, stream_ptr(dev)), "cppf_sample_pairs")
+        mem = dict(pipe=pipe, pre=prestage, slot=slot, ws=ws, key=key)
+        self._members[id(pipe)] = mem
+        self._pool.setdefault(key, []).append(mem)
+        return mem
 
-    def _chain_for(self, pipes, pres):
+    def _chain_for(self, pipes, pres, busy):
+        """the captured chain of this combination of members (second sighting on), or None: its members run their own graphs.
+        `busy`: chains of the running frame, which an eviction must not touch."""
         from .inference import PoseChain
         key = tuple(id(p) for p in pipes)
         ch = self._chains.get(key)
         if ch is not None:
             self._chains.move_to_end(key)
+            busy.add(key)
             return ch
         n = self._seen[key] = self._seen.get(key, 0) + 1
         if len(self._seen) > 4096:
             self._seen.clear()
         if n < 2:
             return None
-        while len(self._chains) >= 16:
+        while len(self._chains) >= self.max_chains:
+            victim = next((k for k in self._chains if k not in busy), None)
+            if victim is None:
+                return None                              # (more groups in this frame than max_chains)
             torch.cuda.synchronize(self.device)
-            self._chains.popitem(last=False)[1].release()
+            self._chains.pop(victim).release()
         ch = self._chains[key] = PoseChain(pipes, prestages=pres)
+        busy.add(key)
         return ch
 
     def run(self, depth, instances, seed=0):
@@ -201,11 +223,12 @@ class FrameRunner:
             np.bitwise_or(labels, np.uint32(1 << i), out=labels, where=m)      # (no fancy indexing: 0.1 ms per 480 x 640 mask)
             counts.append(int(np.count_nonzero(m)))
         self._depth_host.numpy()[...] = depth.view(np.int16)
-        self._seeds_host.numpy()[:len(on_chain)] = [pair_seed(seed, i) for i in on_chain]
+        slots = self._slots_host.numpy()
+        for i in on_chain:
+            slots[i] = (i, pair_seed(seed, i))
         main = torch.cuda.current_stream(dev)
-        self._depth.copy_(self._depth_host, non_blocking=True)          # one upload per frame (two images + the seeds)
+        self._depth.copy_(self._depth_host, non_blocking=True)          # one upload per frame (two images)
         self._labels.copy_(self._labels_host, non_blocking=True)
-        self._seeds.copy_(self._seeds_host, non_blocking=True)
         for cat in {instances[i][0] for i in on_chain}:
             self.encoders[cat]._packed_weights(dev)
             self.point_encoders[cat]._packed_weights(dev)
@@ -216,25 +239,29 @@ class FrameRunner:
             st.wait_stream(main)
         Lc = self.chain_len or max(1, min(8, -(-len(on_chain) // self.n_lanes)))
         groups = [on_chain[g:g + Lc] for g in range(0, len(on_chain), Lc)]
-        ran = []
-        for gi, slots in enumerate(groups):
+        ran, used, busy = [], set(), set()
+        for gi, slots_g in enumerate(groups):
             lane = gi % self.n_lanes
             with torch.cuda.stream(self._streams[lane]):
                 pipes, pres = [], []
-                for q, i in enumerate(slots):
-                    pipe, pre = self._member(instances[i][0], counts[i], lane, q, i)
-                    pipes.append(pipe)
-                    pres.append(pre)
-                ch = self._chain_for(pipes, pres)
+                for i in slots_g:
+                    mem = self._member(instances[i][0], counts[i], used)
+                    used.add(id(mem["pipe"]))
+                    mem["slot"].copy_(self._slots_host[i], non_blocking=True)     # which instance this member serves in this frame
+                    pipes.append(mem["pipe"])
+                    pres.append(mem["pre"])
+                ch = self._chain_for(pipes, pres, busy)
+                # (check_weights=None: the images were refreshed above, once per frame; a pipeline compares their addresses, so a
+                # weight image that moved -- an encoder re-created or resized -- re-captures instead of reading a stale address)
                 if ch is not None:
-                    ch.run_async([raw[i] for i in slots], check_weights=False)
+                    ch.run_async([raw[i] for i in slots_g], check_weights=None)
                 else:
-                    for pipe, pre, i in zip(pipes, pres, slots):
+                    for pipe, pre, i in zip(pipes, pres, slots_g):
                         pre()
-                        pipe.run_async(raw[i], check_weights=False)
-                for pipe, i in zip(pipes, slots):
+                        pipe.run_async(raw[i], check_weights=None)
+                for pipe, i in zip(pipes, slots_g):
                     shapes[i].copy_(pipe.shape, non_blocking=True)
-                ran.append((ch, pipes, slots))
+                ran.append((ch, pipes, slots_g))
         for st in self._streams:
             main.wait_stream(st)
         host, shp = raw.cpu().numpy(), shapes.cpu().numpy()             # the frame's one synchronisation

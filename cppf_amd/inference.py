@@ -37,11 +37,15 @@ def grid_shape(pc_host, res):
     if a.dtype == np.float32 and a.ndim == 2 and a.shape[1] == 3 and a.shape[0] > 0 and a.flags.c_contiguous:
         corners = np.empty((2, 3), np.float32)
         dims = np.empty(3, np.int32)
-        if _lib.lib().cppf_host_grid_shape(a.ctypes.data, a.shape[0], float(np.float32(res)), corners.ctypes.data, dims.ctypes.data) == 0 \
-                and not np.isnan(corners).any():
+        rc = _lib.lib().cppf_host_grid_shape(a.ctypes.data, a.shape[0], float(np.float32(res)), corners.ctypes.data, dims.ctypes.data)
+        if rc == 0:
             return corners, (int(dims[0]), int(dims[1]), int(dims[2]))
+        if rc == -4:      # CPPF_ENONFINITE; the reference fails at np.zeros(grid_res) with the dims such a cloud gives (:196)
+            raise ValueError("the cloud holds NaN / inf coordinates: no vote grid can be laid over it")
     t = np.ascontiguousarray(np.asarray(pc_host, dtype=np.float32).T)    # [3,N]: numpy reduces the long axis 20x faster than axis 0 of [N,3]
     corners = np.stack([t.min(1), t.max(1)])
+    if not np.isfinite(corners).all():
+        raise ValueError("the cloud holds NaN / inf coordinates: no vote grid can be laid over it")
     grid_res = ((corners[1] - corners[0]) / np.float32(res)).astype(np.int32) + 1
     return corners, tuple(int(v) for v in grid_res)
 
@@ -560,7 +564,7 @@ class CenterBatchPipeline:
     fours), `vote_batch=False`: a vote + reduce launch per member at the member's own width.  Members keep their buffers and results
     (`pipes[i].out_idx`, `.result`, `.outputs`, `.grid`): load them as usual, run the batch instead of the members.  Static-shape
     members on one device, no point encoder in front, all with the rotation heads or none, the same num_rots / adaptive; up to 8.
-    vote_workgroups: workgroups per object of the batched vote (None / 0: 256 / n, at least 32)."""
+    vote_workgroups: workgroups per object of the batched vote (None / 0: 256 / n, at least 64; 64..256)."""
 
     def __init__(self, pipes, use_graph=True, vote_batch=True, vote_workgroups=None, own_results=True):
         """own_results=False: the members keep the result records they have (a pipeline that is a member of a second, shorter

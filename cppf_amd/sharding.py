@@ -30,7 +30,9 @@ def init_distributed(backend=None, force=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "0") or 0) or (local + 1)
+    # ranks on this node: LOCAL_WORLD_SIZE (torchrun sets it); without it the job is taken to be ONE node (WORLD_SIZE) -- a value every
+    # rank agrees on, so that all of them pick the same backend (a per-rank guess made rank 0 choose nccl and rank 1 gloo)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "0") or 0) or world
     n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
     shared = 0 < n_dev < local_world
     if shared:
@@ -87,15 +89,15 @@ def _object_order(n_objects, world, device):
     return perm
 
 
-def gather_records(local_records, n_objects, rank, world, device=None, force_collective=None, validate=None):
+def gather_records(local_records, n_objects, rank, world, device=None, force_collective=None, validate=False):
     """The single end-of-batch collective.  local_records: f64[n_local, RECORD], row s = object `rank + s * world` (the order
     shard_objects() hands the objects out in; object id in column 15).  Returns f64[n_objects, RECORD] in object order on
     every rank (all_gather: the same cost as a gather at this size and every rank can continue with the poses).
 
     The layout is FIXED: every rank contributes ceil(n_objects / world) rows (unused ones zero), the result is the rank-major
     concatenation, and object j is row (j mod W) * n_max + j // W of it -- one index_select with a cached permutation, no
-    data-dependent filter, no sort, no host synchronisation.  `validate` re-checks the object ids on the host (default: only on the
-    single-rank shortcut, which has no fixed layout to rely on).
+    data-dependent filter, no sort, no host synchronisation.  validate=True (opt-in, the same for every world size) re-checks on the
+    host that row j carries object id j; all-zero rows -- objects a caller skipped -- pass.
     force_collective (default: CPPF_FORCE_DIST when a group exists): run the collective with a single rank too."""
     if force_collective is None:
         force_collective = forced() and dist.is_initialized()
@@ -103,10 +105,7 @@ def gather_records(local_records, n_objects, rank, world, device=None, force_col
     if local_records.shape[0] < n_local:
         raise ValueError(f"rank {rank} holds {local_records.shape[0]} records, its share of {n_objects} objects is {n_local}")
     if world == 1 and not force_collective:
-        out = local_records[:n_objects]
-        if validate is None:      # the shortcut re-orders nothing: records handed over in another order would come back as the poses of
-            validate = True       # other objects, so the ids are looked at here (one small read-back; callers that build the records in
-                                  # object order themselves -- BatchPoseRunner, bench.py -- pass validate=False)
+        out = local_records[:n_objects]    # (the shortcut re-orders nothing: a caller unsure of its row order passes validate=True)
     else:
         n_max = (n_objects + world - 1) // world
         out_dev = device if device is not None else local_records.device
@@ -117,8 +116,9 @@ def gather_records(local_records, n_objects, rank, world, device=None, force_col
         dist.all_gather_into_tensor(allb, buf)
         out = allb.index_select(0, _object_order(n_objects, world, dev)).to(out_dev)
     if validate:
-        ids = out[:, 15].cpu()
-        if not torch.equal(ids, torch.arange(n_objects, dtype=torch.float64)):
+        host = out.cpu()
+        ids, filled = host[:, 15], (host != 0).any(dim=1)
+        if not torch.equal(ids[filled], torch.arange(n_objects, dtype=torch.float64)[filled]):
             raise AssertionError(f"gathered records are not in object order: {ids.tolist()}")
     return out
 

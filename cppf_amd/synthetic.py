@@ -212,3 +212,28 @@ def make_posed_object(category="bottle", n_points=2048, seed=0, size_range=(0.8,
     pc = pc + np.clip(cfg.res / 4 * rng.standard_normal(pc.shape), -cfg.res / 2, cfg.res / 2)     # nocs/inference.py:134
     return dict(pc=pc.astype(np.float32), normals=(nrm @ R.T).astype(np.float32), center=center, R=R,
                 half_extents=np.array([sx, sy, sz]), cfg=cfg, category=category)
+
+
+def philox_pairs(seed, n_pairs, n_points):
+    """Host twin of the device sampler (cppf_sample_pairs / cppf_stage_batch, csrc/preproc.hip): Philox-4x32-10 keyed by the 64-bit
+    `seed`, counter = {pair index, 0 | 1} -> (idx i64[P,2] uniform over [0, n_points), u_tr f32[P,2], u_rot f32[P,2] in [0, 1)), the
+    same numbers bit for bit (tests/test_gpu_resident.py), so that a checker on the host can reproduce the pairs a captured chain
+    drew on the device (the reference draws them with np.random.randint / torch.multinomial, nocs/inference.py:177,186,250)."""
+    M0, M1, W0, W1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85)
+    mask, s32 = np.uint64(0xFFFFFFFF), np.uint64(32)
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    p = np.arange(int(n_pairs), dtype=np.uint64)
+
+    def block(c2):
+        c = [p & mask, p >> s32, np.full_like(p, c2), np.zeros_like(p)]
+        k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64(seed >> 32)
+        for _ in range(10):
+            p0, p1 = M0 * c[0], M1 * c[2]                       # 32 x 32 -> 64 bit products
+            c = [(p1 >> s32) ^ c[1] ^ k0, p1 & mask, (p0 >> s32) ^ c[3] ^ k1, p0 & mask]
+            k0, k1 = (k0 + W0) & mask, (k1 + W1) & mask
+        return c
+    a, b = block(0), block(1)
+    N = np.uint64(int(n_points))
+    idx = np.stack([(a[0] * N) >> s32, (a[1] * N) >> s32], -1).astype(np.int64)
+    u = lambda w: ((w >> np.uint64(8)).astype(np.float32) * np.float32(2.0 ** -24))
+    return idx, np.stack([u(a[2]), u(a[3])], -1), np.stack([u(b[0]), u(b[1])], -1)

@@ -49,6 +49,7 @@ extern "C" {
 #define CPPF_EINVAL (-1)     /* bad argument (null pointer, negative size, n_rots out of range) */
 #define CPPF_EWORKSPACE (-2) /* workspace too small / missing */
 #define CPPF_EUNSUPPORTED (-3) /* layer shape not supported by any device kernel */
+#define CPPF_ENONFINITE (-4) /* a host cloud holds NaN / inf coordinates (cppf_host_grid_shape) */
 
 int cppf_abi_version(void);
 const char* cppf_error_string(int code);
@@ -643,6 +644,13 @@ int cppf_frame_cloud_dyn(const void* depth, int depth_is_u16, const void* labels
                          const double* kinv_host, double divisor, double res, int knn_k, int k_min, int n_cap, float* pc_out,
                          float* nrm_out, float* corner_out, int32_t* shape_out, int32_t* nbrs_out, void* workspace, size_t workspace_bytes,
                          void* stream);
+/* The same with the label bit read from device memory at run time (*label_bit_dev, taken modulo the label width): ONE captured launch
+ * serves whichever instance of a frame is handed to it -- a video whose instances change order, number or mask size replays the
+ * graphs it has (cppf_amd.frames.FrameRunner keeps them per (category, capacity) and writes {bit, seed} per frame). */
+int cppf_frame_cloud_dyn_bit(const void* depth, int depth_is_u16, const void* labels, int label_bytes, const int32_t* label_bit_dev, int H,
+                             int W, const double* kinv_host, double divisor, double res, int knn_k, int k_min, int n_cap, float* pc_out,
+                             float* nrm_out, float* corner_out, int32_t* shape_out, int32_t* nbrs_out, void* workspace,
+                             size_t workspace_bytes, void* stream);
 /* Pair list and bin uniforms drawn on the device -- the reference draws the pairs with np.random.randint(0, N, (P, 2)) on the host
  * (nocs/inference.py:177: 8 MB per instance at C2 over PCIe) and the bins with torch.multinomial (:186,250,254).  idx device
  * i64[n_pairs,2] uniform over [0, N); u_tr / u_rot device f32[n_pairs,2] uniform over [0, 1) (either may be NULL).  N = n_points, or
@@ -652,7 +660,8 @@ int cppf_frame_cloud_dyn(const void* depth, int depth_is_u16, const void* labels
 int cppf_sample_pairs(long long* idx, float* u_tr, float* u_rot, int64_t n_pairs, int64_t n_points, const int32_t* n_dev,
                       unsigned long long seed, const unsigned long long* seed_dev, void* stream);
 /* Host helper (no device): the grid of nocs/inference.py:194-195 for a HOST cloud f32[n_points,3]: corners_host f32[6] = {min xyz, max xyz},
- * dims_host i32[3] = int32((max - min) / res) + 1 with the quotient in fp32.  NaN coordinates are ignored by the comparisons. */
+ * dims_host i32[3] = int32((max - min) / res) + 1 with the quotient in fp32.  A cloud with a NaN / inf coordinate anywhere returns
+ * CPPF_ENONFINITE (numpy's min / max would propagate it into the dims: the reference fails at np.zeros(grid_res), :196). */
 int cppf_host_grid_shape(const float* pc_host, int64_t n_points, float res, float* corners_host, int32_t* dims_host);
 int cppf_mod_pairs_dyn(long long* idx, int64_t n_pairs, const int32_t* n_dev, void* stream);
 /* The head of a captured chain for objects that are ALREADY on the device ("inputs already resident on device"): for up

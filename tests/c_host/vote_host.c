@@ -82,6 +82,14 @@ static int host_only(void)
     REQUIRE(dims[0] == (int32_t)(0.1f / RES) + 1 && dims[1] == (int32_t)(0.3f / RES) + 1 && dims[2] == dims[0]);
     REQUIRE(corners[0] == 0.f && corners[4] == 0.3f);
     REQUIRE(cppf_host_grid_shape(NULL, 4, RES, corners, dims) == CPPF_EINVAL);
+    {   /* a NaN in the middle of the cloud is reported, not skipped by the comparisons */
+        float holed[12];
+        for (int i = 0; i < 12; ++i) holed[i] = cloud[i];
+        holed[7] = 0.f / 0.f;
+        REQUIRE(cppf_host_grid_shape(holed, 4, RES, corners, dims) == CPPF_ENONFINITE);
+        holed[7] = 1.f / 0.f;
+        REQUIRE(cppf_host_grid_shape(holed, 4, RES, corners, dims) == CPPF_ENONFINITE);
+    }
     /* launch plans: BASELINE.json configs[1] (26 x 76 x 26: fused, < 4 tiles) and configs[4]-style (52 x 152 x 52: binned) */
     int32_t plan[10];
     REQUIRE(cppf_vote_plan_query(524288, ROTS, 26, 76, 26, plan) == 0 && plan[0] == 2 && plan[1] >= 1 && plan[1] < 4);

@@ -537,3 +537,22 @@ def test_plain_c_host_compiles_and_runs_the_host_only_entry_points(c_host):
     p = subprocess.run([c_host], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "host ok: ABI 4" in p.stdout
+
+
+def test_grid_shape_fails_loudly_on_non_finite_clouds():
+    """nocs/inference.py:194-196 on a cloud with a NaN: numpy's min / max propagate it into the dims and np.zeros refuses them; both
+    paths of cppf_amd.inference.grid_shape (the C pass and the numpy form) raise instead of laying a plausible grid over the rest"""
+    from cppf_amd.inference import grid_shape
+    rng = np.random.default_rng(0)
+    pc = rng.random((100, 3)).astype(np.float32)
+    c0, d0 = grid_shape(pc, 0.01)
+    c1, d1 = grid_shape(pc.astype(np.float64), 0.01)            # (the numpy form: not a C-contiguous f32 array)
+    assert d0 == d1 and np.array_equal(c0, c1)
+    for bad in (np.nan, np.inf, -np.inf):
+        for row in (0, 57, 99):
+            q = pc.copy()
+            q[row, 1] = bad
+            with pytest.raises(ValueError):
+                grid_shape(q, 0.01)
+            with pytest.raises(ValueError):
+                grid_shape(q.astype(np.float64), 0.01)

@@ -153,11 +153,44 @@ def test_bench_launches_its_own_ranks(extra):
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["unit"] == "pairs/s"
     n_dev = torch.cuda.device_count()
     assert d["dist"]["ranks_seen"] == 2 and len(d["dist"]["device_per_rank"]) == 2
+    assert len(d["dist"]["rank_region_ms"]) == 2 and all(v > 0 for v in d["dist"]["rank_region_ms"]) and d["dist"]["imbalance"] >= 1.0
     if n_dev < 2:
-        assert d["dist"] == {"backend": "gloo", "forced_single_rank": False, "ranks_seen": 2, "device_per_rank": [0, 0], "shared_gpu": True}
+        assert {k: d["dist"][k] for k in ("backend", "forced_single_rank", "ranks_seen", "device_per_rank", "shared_gpu")} == \
+            {"backend": "gloo", "forced_single_rank": False, "ranks_seen": 2, "device_per_rank": [0, 0], "shared_gpu": True}
     else:
         assert d["dist"]["backend"] == "nccl" and d["dist"]["device_per_rank"] == [0, 1] and d["dist"]["shared_gpu"] is False
     # a launcher's environment with the wrong size is an error message and exit code 2, not an assertion trace
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-secondary", "--no-cpu-baseline"],
                          env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
     assert bad.returncode == 2 and "WORLD_SIZE=1" in bad.stderr and "Traceback" not in bad.stderr
+
+
+@pytest.mark.parametrize("extra,n_checked", [(["--steps", "6", "--objects", "3", "--min-seconds", "0.2"], 48),
+                                             (["--config", "c4", "--steps", "8", "--regions", "5"], 8)])
+def test_eight_rank_line_checks_every_rank_against_the_oracle(extra, n_checked):
+    """`python bench.py --gpus 8` the way the driver's scaling run issues it, on however many GPUs this box has (one: the eight ranks
+    share it over gloo): the printed line must prove itself -- ranks_seen 8, every rank's objects against the oracle (the headline: the
+    arg-max of every object every rank stepped through; c4: >= 1 full pose record per rank, pairs re-drawn on the host by the
+    sampler's numpy twin), per-rank region times and their imbalance, the CPU binding, and cpu_baseline still on the line"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT") and not k.startswith("CPPF_")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--warmup", "1", "--no-secondary"] + extra,
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out_lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert out_lines[-1].startswith("{")
+    d = json.loads(out_lines[-1])
+    assert d["n_gpus"] == 8 and d["value"] > 0 and d["dist"]["ranks_seen"] == 8 and len(d["dist"]["device_per_rank"]) == 8
+    assert len(d["dist"]["rank_region_ms"]) == 8 and all(v > 0 for v in d["dist"]["rank_region_ms"]) and d["dist"]["imbalance"] >= 1.0
+    assert len(d["dist"]["cpu_binding"]) == 8
+    assert d["argmax_matches_oracle"] is True and d["argmax_objects_matching_oracle"] == f"{n_checked}/{n_checked}"
+    if "c4" in extra:
+        assert d["records_matching_oracle"] == "8/8" and sorted(o % 8 for o in d["objects_checked"]) == list(range(8))
+        assert d["scaling"] == "strong"
+    else:
+        assert d["argmax_objects_matching_oracle_per_rank"] == ["6/6"] * 8
+        assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["spread"][1] <= d["cpu_baseline"]["best"]

@@ -153,6 +153,9 @@ def test_device_pair_sampler_is_philox_and_uniform(dev):
     f = lambda r: ((r >> np.uint64(8)).astype(np.float32) * np.float32(2.0 ** -24))
     assert np.array_equal(idx.cpu().numpy(), want_idx)
     assert np.array_equal(u[0].cpu().numpy(), np.stack([f(a[2]), f(a[3])], -1)) and np.array_equal(u[1].cpu().numpy(), np.stack([f(b[0]), f(b[1])], -1))
+    import cppf_amd.synthetic as syn             # the host twin bench_cpu.py re-draws a device-resident batch's pairs with
+    ti, tu, tv = syn.philox_pairs(seed, P, N)
+    assert np.array_equal(ti, want_idx) and np.array_equal(tu, u[0].cpu().numpy()) and np.array_equal(tv, u[1].cpu().numpy())
     i, uu = idx.cpu().numpy(), u.cpu().numpy()
     assert i.min() == 0 and i.max() == N - 1 and uu.min() >= 0.0 and uu.max() < 1.0
     counts = np.bincount(i.reshape(-1), minlength=N)

@@ -169,7 +169,7 @@ def test_frame_runner_equals_the_eager_loop(oracle, dev):
     # the device stage against the oracle's pre-processing (member 0 of lane 0 still holds instance 0's cloud)
     cat, m = inst[0]
     cfg = CATEGORIES[cat]
-    pipe = next(p for (c_, cap, lane, slot, bit, many), (p, _) in runner._members.items() if bit == 0)
+    pipe = next(m_["pipe"] for m_ in runner._members.values() if int(m_["slot"][0].item()) == 0 and m_["key"][0] == cat)
     n = int(pipe.shape[0])
     pts, _ = oracle.backproject(depth, NOCS_INTRINSICS, m)
     p = pts / 1000.0
@@ -186,3 +186,48 @@ def test_frame_runner_equals_the_eager_loop(oracle, dev):
     for w, g in zip(want2, got2):
         assert (w is None) == (g is None) and (w is None or (g["argmax"] == w["argmax"] and np.array_equal(g["up"], w["up"])))
     assert any(a is not None and b is not None and a["n_surv"] != b["n_surv"] for a, b in zip(got, got2))
+
+
+@pytest.mark.gpu
+def test_frame_runner_keeps_its_graphs_when_the_instances_change(dev):
+    """A video: the instances of a frame change order, number and mask (members were keyed by lane, chain position and
+    label bit, so every such change minted new pipelines and captures).  Members are keyed by what their launches are sized for --
+    (category, capacity, grid class) -- and told per frame which instance they serve: permuted / dropped / re-added instances reuse
+    the members that exist, poses stay those of the eager loop, and a chain cache smaller than a frame's groups still serves it"""
+    from cppf_amd import training
+    from cppf_amd.config import CATEGORIES
+    from cppf_amd.frames import FrameRunner, frame_poses
+    from cppf_amd.utils.util import read_depth_png
+    depth = read_depth_png(DEPTH)
+    inst = instances(depth)
+    nets = {}
+    for cat, src in (("mug", "mug"), ("laptop", "laptop"), ("bowl", "bottle"), ("can", "bottle")):
+        penc, enc = training.load_weights(os.path.join(GOLDEN, f"trained_{src}.npz"), CATEGORIES[src], dev)
+        nets[cat] = (enc, penc)
+    encs = {c: v[0] for c, v in nets.items()}
+    pencs = {c: v[1] for c, v in nets.items()}
+
+    def check(runner, frame, seed):
+        want = frame_poses(depth, frame, encs, pencs, device=dev, seed=seed)
+        got = runner.run(depth, frame, seed=seed)
+        for w, g in zip(want, got):
+            assert (w is None) == (g is None)
+            if w is not None:
+                assert g["argmax"] == w["argmax"] and g["n_surv"] == w["n_surv"] and np.array_equal(g["T"], w["T"]) and np.array_equal(g["up"], w["up"])
+
+    runner = FrameRunner(encs, pencs, dev)
+    for rep in range(3):
+        check(runner, inst, rep)
+    n_members = len(runner._members)
+    rng = np.random.default_rng(0)
+    for rep in range(6):                       # permutations, subsets, the full frame again
+        order = rng.permutation(len(inst))[:rng.integers(2, len(inst) + 1)]
+        check(runner, [inst[i] for i in order], 10 + rep)
+        assert len(runner._members) == n_members, (rep, len(runner._members), n_members)
+    check(runner, inst, 99)
+    assert len(runner._members) == n_members
+    # a chain cache that cannot hold one frame's groups: chains of the running frame are never evicted, the frame is served all the same
+    small = FrameRunner(encs, pencs, dev, chain_len=1, n_lanes=2, max_chains=2)
+    for rep in range(4):
+        check(small, inst, rep)
+    assert len(small._chains) <= 2

@@ -63,8 +63,13 @@ def test_shard_objects_round_robin():
     assert one[:, 15].tolist() == [0.0, 1.0, 2.0]
     with pytest.raises(AssertionError):
         sharding.gather_records(torch.stack([sharding.pack_record(j, _fake_pose(j)) for j in (2, 0, 1)]), 3, 0, 1, validate=True)
-    with pytest.raises(AssertionError):      # ... and by default on the single-rank shortcut: mis-ordered records are caught
-        sharding.gather_records(torch.stack([sharding.pack_record(j, _fake_pose(j)) for j in (2, 0, 1)]), 3, 0, 1)
+    # validation is opt-in at every world size (the same call must not behave differently with one rank); all-zero rows --
+    # objects a caller skipped -- pass it
+    mis = sharding.gather_records(torch.stack([sharding.pack_record(j, _fake_pose(j)) for j in (2, 0, 1)]), 3, 0, 1)
+    assert mis[:, 15].tolist() == [2.0, 0.0, 1.0]
+    skipped = torch.stack([sharding.pack_record(j, _fake_pose(j)) for j in (0, 1, 2)])
+    skipped[1] = 0
+    assert sharding.gather_records(skipped, 3, 0, 1, validate=True)[:, 15].tolist() == [0.0, 0.0, 2.0]
     with pytest.raises(ValueError):
         sharding.gather_records(torch.zeros((1, sharding.RECORD), dtype=torch.float64), 3, 0, 1)
     perm = sharding._object_order(7, 3, torch.device("cpu")).tolist()      # rank-major rows -> object order
