@@ -556,3 +556,22 @@ def test_grid_shape_fails_loudly_on_non_finite_clouds():
                 grid_shape(q, 0.01)
             with pytest.raises(ValueError):
                 grid_shape(q.astype(np.float64), 0.01)
+
+
+def test_workspace_bounds_at_five_million_pairs():
+    """what the vote asks for at the notebook's size: a by-value launch sizes its pair -> tile queues for the
+    tiles the grid HAS (67 x 34 x 67: 8); the global-atomics path keeps no queues; a shape-polymorphic many-tile pipeline sizes them
+    for every tile of its class (64): 3.9 GB -- callers at this size launch by value, as the notebook does"""
+    from cppf_amd import _lib
+    L = _lib.lib()
+    P5M = 5_000_000
+    tiles = L.cppf_vote_tiles(67, 34, 67)
+    assert 4 <= tiles <= 8
+    by_value = L.cppf_vote_workspace_bytes(P5M, 72, 67, 34, 67)
+    assert by_value <= tiles * P5M * 12 + (64 << 20)            # 12 B per (pair, tile) record worst case + partial tiles
+    assert by_value <= 0.6 * (1 << 30)
+    assert L.cppf_vote_workspace_bytes(P5M, 72, 330, 166, 334) == L.cppf_vote_workspace_init_bytes()      # beyond 64 tiles: no queues
+    few = L.cppf_vote_workspace_bytes_dyn_pairs(0, P5M)
+    assert few <= (64 << 20)                                      # few-tile class: no queues at all, whatever P
+    many = L.cppf_vote_workspace_bytes_dyn_pairs(1, P5M)
+    assert 64 * P5M * 12 <= many <= 64 * P5M * 12 + (300 << 20)
