@@ -357,8 +357,10 @@ __host__ __device__ inline int64_t v3_fused_bits_pairs(int64_t n_ppfs, int C, in
     return v3_fused_chunk_pairs(n_ppfs, C < Cc ? C : Cc);
 }
 
-struct V3Plan { V3Tiling t; int wgs, slot; size_t pool_off, part_off, total; int64_t pool_cap; };
-// pool: T queues of `cap` records (12 B) each -- every pair can visit every tile, and the HBM is there (288 GB)
+struct V3Plan { V3Tiling t; int wgs, slot; size_t pool_off, frames_off, part_off, total; int64_t pool_cap; };
+// pool: T queues of `cap` records (12 B) each -- every pair can visit every tile, and the HBM is there (288 GB) -- and, behind them,
+// one 48-byte FRAME per pair (V3_FRAME_BYTES: the bin kernel computes a pair's exact frame once, every tile's consumer loads it)
+#define V3_FRAME_BYTES 48
 static V3Plan v3_plan(int64_t n_ppfs, const V3Tiling& t, int gz, int wgs, int64_t cap, int64_t cells)
 {
     V3Plan p;
@@ -367,9 +369,9 @@ static V3Plan v3_plan(int64_t n_ppfs, const V3Tiling& t, int gz, int wgs, int64_
     // calls with different grids, and the plane's "zero between launches" invariant must not depend on the previous layout)
     p.pool_off = VOTE_WS_PART + V3_HDR_BYTES + V3_PLANE_BYTES;
     (void)cells;
-    p.part_off = p.pool_off + align_up((size_t)t.T * (size_t)cap * 12, 256);
+    p.frames_off = p.pool_off + align_up((size_t)t.T * (size_t)cap * 12, 256);
+    p.part_off = p.frames_off + (cap > 0 ? align_up((size_t)n_ppfs * V3_FRAME_BYTES, 256) : 0);
     p.total = p.part_off + (size_t)wgs * p.slot * sizeof(uint32_t);   // one partial tile per workgroup
-    (void)n_ppfs;
     return p;
 }
 
@@ -392,6 +394,7 @@ struct V3Args {
     unsigned long long* plane;   // extra plane, one u64 per grid cell
     uint32_t* pool;        // [T][pool_cap][3]
     int64_t pool_cap;
+    float4* frames;        // binned: [n_ppfs][3] = {cc.xyz, x.x | x.yz, y.xy | y.z, n, prob, -}: a pair's exact frame, written by the bin kernel
     uint32_t* partials;    // [wgs][slot]: workgroup b's tile
     unsigned long long* packed;
     float* grid;
@@ -580,37 +583,34 @@ __global__ __launch_bounds__(V3_BIN_THREADS) void v3_bin_kernel(V3Args A)
                (off_plane <= reach + sall) & (dmin2 <= r_hi * r_hi * 1.0001f) & (dmax2 * 1.0001f >= r_lo * r_lo);
     };
     auto setup = [&]() {
-            // ---- per pair: the frame in APPROXIMATE arithmetic (reciprocal / rsqrt, ~45 instructions instead of the ~180 of the exact
-            // frame with its IEEE divisions and square roots).  It only feeds the arc screen, whose acceptance boxes are widened by
-            // more than its error (relative ~1e-6 on every component: below); the consumer recomputes the exact frame.  What must
-            // agree exactly between the two kernels is the rotation count n (:31: a division and a product of the stored (mu, nu),
-            // no frame involved); a pair the consumer finds degenerate (:21) deposits nothing whatever was queued for it, and the test
-            // here keeps every pair the exact test can keep (L >= 0.9e-7 for the exact L >= 1e-7).
+            // ---- per pair: the EXACT frame (pair_frame: :20-28 with their IEEE divisions and square roots, ~180 instructions), once:
+            // it feeds the arc screen here (whose acceptance boxes stay widened as for round 3-5's approximate frame) and is left in
+            // `frames` for the consumers -- a pair visits 3.4 tiles at C5 and 4-5 on a posed object, and every visit used to recompute
+            // it from the pair list, the points and (mu, nu): 48 bytes of dependent gathers replaced by 48 bytes of one load level.
             Fcc = {0.f, 0.f, 0.f}; Fx = Fcc; Fy = Fcc; Fu = Fcc;
             Rq = 0.f;
             n = 0;
             if (valid) {
                 const float2 o = reinterpret_cast<const float2*>(A.outputs)[p];
                 const int2 ij = v3_pair_idx(A, p);
-                const f3 a = ld3(A.points, ij.x), b = ld3(A.points, ij.y);
-                const f3 d = sub3(a, b);
-                const float L2 = fmaf(d.z, d.z, fmaf(d.y, d.y, d.x * d.x));
-                const float L = __builtin_amdgcn_sqrtf(L2);
-                if (L >= 0.9e-7f) {
-                    const f3 u = scl3(d, __builtin_amdgcn_rcpf(L + 1e-7f));
-                    Fu = u;
+                f3 a, ab, xd;
+                float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0, f2 = f0;       // (a degenerate pair, :21: n = 0, never queued)
+                if (pair_frame(A.points, ij.x, ij.y, a, ab, xd)) {                   // :20-28, the consumer's arithmetic
+                    Fu = ab;
                     Rq = fabsf(o.y) * rinv;
-                    Fcc = {fmaf(-u.x, o.x, a.x), fmaf(-u.y, o.x, a.y), fmaf(-u.z, o.x, a.z)};                 // :23
-                    f3 co = {0.f, -u.z, u.y};                                                                 // :26-27
-                    float lc = __builtin_amdgcn_sqrtf(fmaf(u.y, u.y, u.z * u.z));
-                    if (lc < 1e-6f) { co = {-u.y, u.x, 0.f}; lc = __builtin_amdgcn_sqrtf(fmaf(u.y, u.y, u.x * u.x)); }
-                    Fx = scl3(co, o.y * __builtin_amdgcn_rcpf(lc + 1e-7f));                                   // :28
-                    Fy = {fmaf(Fx.y, u.z, -Fx.z * u.y), fmaf(Fx.z, u.x, -Fx.x * u.z), fmaf(Fx.x, u.y, -Fx.y * u.x)};   // :29
+                    Fcc = sub3(a, scl3(ab, o.x));                                    // :23
+                    Fx = scl3(xd, o.y);                                              // :28
+                    Fy = cross3(Fx, ab);                                             // :29
                     n = A.n_rots;
                     if (A.adaptive) n = min((int)((double)(o.y / res) * (2 * CPPF_PI)), A.n_rots);   // :31
                     n = max(n, 0);
+                    const float prob = A.probs ? fmaxf(A.probs[ij.x], A.probs[ij.y]) : 1.f;
+                    f0 = make_float4(Fcc.x, Fcc.y, Fcc.z, Fx.x); f1 = make_float4(Fx.y, Fx.z, Fy.x, Fy.y);
+                    f2 = make_float4(Fy.z, __int_as_float(n), prob, 0.f);
                     if (WIDE && n <= wb) n = 0;   // no rotation of this pair in the window
                 }
+                float4* fr = A.frames + 3 * p;
+                fr[0] = f0; fr[1] = f1; fr[2] = f2;
             }
             const int Lw = WIDE ? max(min(n - wb, 72), 0) : n;   // bits of this pair's masks
             cq = scl3(sub3(Fcc, cr), rinv); xq = scl3(Fx, rinv); yq = scl3(Fy, rinv);
@@ -1063,7 +1063,15 @@ __device__ __forceinline__ void v3_vote_body(const V3Args& A, const int bid)
         f3 Fcc = {0.f, 0.f, 0.f}, Fx = Fcc, Fy = Fcc;
         float Fprob = 1.f;
         int n = 0;
-        if (valid) {
+        if (valid && !FUSED) {   // the frame the bin kernel left for this pair (the same arithmetic as below, once per pair, not per tile)
+            const float4* fr = A.frames + 3 * p;
+            const float4 f0 = fr[0], f1 = fr[1], f2 = fr[2];
+            Fcc = {f0.x, f0.y, f0.z}; Fx = {f0.w, f1.x, f1.y}; Fy = {f1.z, f1.w, f2.x};
+            n = __float_as_int(f2.y);
+            Fprob = f2.z;
+            if (WIDE && n <= wb) n = 0;
+        }
+        if (valid && FUSED) {
             const float2 o = reinterpret_cast<const float2*>(A.outputs)[p];
             const int2 ij = v3_pair_idx(A, p);
             f3 a, ab, xd;
@@ -1557,7 +1565,8 @@ static size_t v3_workspace_bytes(int64_t n_ppfs, int gx, int gy, int gz)
 static size_t v3_workspace_bytes_dyn(int many_tiles, int64_t n_ppfs)
 {
     const int t_cap = many_tiles ? VOTE_MAX_TILES : 3, wgs = V3_WGS;
-    return VOTE_WS_PART + V3_HDR_BYTES + V3_PLANE_BYTES + (many_tiles ? align_up((size_t)t_cap * (size_t)n_ppfs * 12, 256) : 0) +
+    return VOTE_WS_PART + V3_HDR_BYTES + V3_PLANE_BYTES +
+           (many_tiles ? align_up((size_t)t_cap * (size_t)n_ppfs * 12, 256) + align_up((size_t)n_ppfs * V3_FRAME_BYTES, 256) : 0) +
            (size_t)wgs * V3_TILE_FLOATS * sizeof(uint32_t);
 }
 // What a by-value launch will do for this problem (tests, tools): out = {path, T, tx, ty, ntx, nty, hx, hy, workgroups, bits};
@@ -1633,7 +1642,8 @@ static int v3_prepare(V3Launch& Lc, const float* points, const float* outputs, c
         if (ex && ex->grid_raw) return CPPF_EINVAL;
         if (grid_cap > (int64_t)A.t_cap * V3_TILE_FLOATS) return CPPF_EINVAL;   // (a grid of the class has at most that many cells)
         A.pool = reinterpret_cast<uint32_t*>(ws + VOTE_WS_PART + V3_HDR_BYTES + V3_PLANE_BYTES);
-        A.partials = A.pool + (many_tiles ? align_up((size_t)A.t_cap * (size_t)n_ppfs * 12, 256) / 4 : 0);
+        A.frames = reinterpret_cast<float4*>(A.pool + (many_tiles ? align_up((size_t)A.t_cap * (size_t)n_ppfs * 12, 256) / 4 : 0));
+        A.partials = reinterpret_cast<uint32_t*>(A.frames) + (many_tiles ? align_up((size_t)n_ppfs * V3_FRAME_BYTES, 256) / 4 : 0);
         const int bps = ((V3_TILE_FLOATS + RED_CELLS - 1) / RED_CELLS + RED_FANIN - 1) / RED_FANIN * RED_FANIN;
         Lc.red_blocks = A.t_cap * bps;
     } else {
@@ -1648,6 +1658,7 @@ static int v3_prepare(V3Launch& Lc, const float* points, const float* outputs, c
         A.t_cap = A.t.T;
         const V3Plan pl = v3_plan(n_ppfs, A.t, gz, v3_wgs(n_ppfs, A.t.T), A.fused ? 0 : n_ppfs, (int64_t)gx * gy * gz);
         A.pool = reinterpret_cast<uint32_t*>(ws + pl.pool_off);
+        A.frames = reinterpret_cast<float4*>(ws + pl.frames_off);
         A.partials = reinterpret_cast<uint32_t*>(ws + pl.part_off);
         const int bps = ((pl.slot + RED_CELLS - 1) / RED_CELLS + RED_FANIN - 1) / RED_FANIN * RED_FANIN;
         Lc.red_blocks = A.t.T * bps;
