@@ -151,7 +151,8 @@ def c4_encoders(dev=None):
 def run_c4(dev, rank, world, args, n_objects=64, n_regions=0, host_staged=False):
     """64 mixed-category objects sharded round-robin over the ranks, full pose per object, ONE gather inside the timed region.
     The objects are uploaded once (BatchPoseRunner.put: SURVEY.md 8d, "inputs already resident on device"); host_staged: every
-    batch stages its clouds and features from pinned host memory and assembles the records on the host (round 5's definition)."""
+    batch brings its clouds and features from the host (one pinned copy per object on its lane's stream, BatchPoseRunner._upload):
+    the PCIe-inclusive rate -- never `value` of the default command."""
     from cppf_amd.batch import BatchPoseRunner
     n_points, k = (args.n_points or 4096), (args.pairs_per_point or 128)
     runner = BatchPoseRunner(c4_encoders(dev), dev, n_lanes=max(1, args.streams),
@@ -239,7 +240,7 @@ def main_c4(args, dev, rank, world, binding):
     if rank != 0:
         return
     total_pairs = m["reps"] * m["n_objects"] * m["P"]
-    how = ("clouds and features staged from pinned host memory per batch, records assembled on the host" if m["host_staged"] else
+    how = ("clouds and features sent from pinned host memory per batch (the PCIe-inclusive rate), records assembled on the device" if m["host_staged"] else
            "objects uploaded once (inputs resident in HBM), staged into the chains' buffers by cppf_stage_batch, records assembled on "
            "the device")
     out = {"metric": METRIC, "value": total_pairs / m["elapsed"], "unit": "pairs/s", "n_gpus": world,
@@ -292,8 +293,8 @@ def main():
                     "--streams); 9 x ~70 MB of buffers exceed the 256 MB Infinity Cache")
     ap.add_argument("--no-graph", action="store_true", help="launch the chain eagerly instead of replaying a hipGraph")
     ap.add_argument("--all-heads", action="store_true", help="first pass decodes all 141 logits of every pair (round 1-2's headline)")
-    ap.add_argument("--host-staged", action="store_true", help="--config c4: stage every batch from pinned host memory (round 5's "
-                    "definition) instead of objects resident on the device")
+    ap.add_argument("--host-staged", action="store_true", help="--config c4: every batch brings its clouds and features from the host "
+                    "(the PCIe-inclusive rate) instead of objects resident on the device")
     ap.add_argument("--c4-check", type=int, default=8, help="--config c4: objects (spread over the ranks, at least one each) whose "
                     "records rank 0 checks against the oracle's full pose")
     ap.add_argument("--n-points", type=int, default=0, help="exploration only; overrides the config's N")

@@ -440,8 +440,8 @@ def collect(ctx, R):
         mixed = " mixed-category objects (N=4096 K=128), full pose each, BatchPoseRunner, pairs drawn on the device, "
         other["c4_one_gpu_share"] = c4_entry(8, False, "8" + mixed + "objects resident on the device (put()), records assembled on "
                                              "the device, no read-back in the batch")
-        other["c4_one_gpu_share_host_staged"] = c4_entry(8, True, "8" + mixed + "clouds and features staged from pinned host "
-                                                         "memory per batch, one read-back per batch (round 5's path)")
+        other["c4_one_gpu_share_host_staged"] = c4_entry(8, True, "8" + mixed + "clouds and features sent from pinned host memory "
+                                                         "per batch (the PCIe-inclusive rate; round 5: 0.193)")
         other["c4_whole_batch_one_gpu"] = c4_entry(64, False, "64" + mixed + "objects resident on the device", reps=1)
         c4_pred = ctx.c4_prediction(other["c4_whole_batch_one_gpu"]["ms_per_object"], other["c4_one_gpu_share"]["ms_per_object"])
         args.steps = keep[0]

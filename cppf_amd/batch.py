@@ -29,7 +29,7 @@ def _shape_error(obj, pipe):
 class BatchPoseRunner:
     def __init__(self, encoders, device, num_rots=72, adaptive=True, angle_tol=1.5, max_rot_pairs=10000,
                  use_graph=True, point_encoders=None, n_bucket=1024, max_pipelines=192, dynamic=True, n_lanes=3,
-                 max_scratch_bytes=64 << 30, vote_workgroups=None, chain_len=None, max_chains=24):
+                 max_scratch_bytes=64 << 30, vote_workgroups=None, chain_len=None, max_chains=24, staged_host=True):
         """encoders: {category name: PPFEncoder on `device`} (the reference keeps one per category,
         nocs/inference.py:79-90).  point_encoders: optional {category name: PointEncoder}; objects of those
         categories need no `feat` -- kNN + SPRIN run at the head of the captured graph (:180-181).
@@ -54,7 +54,10 @@ class BatchPoseRunner:
         `max_pipelines` / `max_scratch_bytes` bound the cache (a mixed batch of six categories in chains of 8 on 3 lanes wants up to
         144 pipelines of ~0.1 GB at C2 size; a cache that is too small re-captures on every batch).  A chain is captured the SECOND time
         its combination of pipelines (category, point bucket, pair count, grid class per position) comes up -- a one-off combination
-        runs its members' own graphs -- and at most `max_chains` captured chains are kept (least recently used first out)."""
+        runs its members' own graphs -- and at most `max_chains` captured chains are kept (least recently used first out).
+        staged_host: host objects WITHOUT their own pair lists (pairs drawn on the device: `n_pairs`) are uploaded with one copy each and
+        take the chains of device-resident objects (put(), _run_resident): records assembled on the device, nothing read back -- the
+        batch's records are then returned on the device whatever the world size.  False: round 5's per-instance path for them too."""
         self.encoders, self.device = encoders, device
         self.point_encoders = point_encoders or {}
         self.n_lanes = max(1, int(n_lanes))
@@ -68,6 +71,7 @@ class BatchPoseRunner:
         self._chains, self._chain_seen = OrderedDict(), {}     # LRU: tuple of member ids -> PoseChain; sightings of a combination
         self._pipes = OrderedDict()    # LRU: key -> PosePipeline
         self._staging = {}         # pinned host staging sets for the small per-instance arrays, see _stage()
+        self.staged_host = bool(staged_host)
         self._stage_pos = 0
         self._streams = None
 
@@ -230,11 +234,58 @@ class BatchPoseRunner:
             out.append(o)
         return out
 
-    def _run_resident(self, objects, mine, rank, world, seed):
-        """run() for objects put() on the device: per chain one 48-byte-per-member descriptor copy, one graph replay, one device copy
+    def _upload_batch(self, objects, mine, host_dims):
+        """Host objects on their way into staged chains: the clouds, normals and (when the caller supplies them) features of ALL of a
+        rank's objects packed into ONE pinned block and sent with ONE asynchronous copy on a copy stream of its own -- so the copy of
+        batch k + 1 runs under the chains of batch k (two device blocks alternate; a block is overwritten only after the chains that
+        read it two batches ago have been joined) -- and the chains' first launch reads each object there like any resident one.
+        One copy per BATCH, not per object: a 36 KB copy (a 1 500-point cloud) costs the host 35 us on this stack, eight of them made
+        the reference-default batch host-bound.  -> ([the objects as put() would return them], event the lanes wait for)"""
+        dev = self.device
+        metas, total = [], 0
+        for j in mine:
+            obj = objects[j]
+            self._check(j, obj)
+            feat = obj.get("feat") if obj["cfg"].category not in self.point_encoders else None
+            n, F = obj["pc"].shape[0], 0 if feat is None else feat.shape[1]
+            metas.append((obj, feat, n, F, total))
+            total += ((6 + F) * n + 63) & ~63                       # (256-byte aligned objects)
+        st = self.__dict__.get("_up")
+        if st is None or st["words"] < total:
+            if st is not None:
+                torch.cuda.synchronize(dev)
+            words = max(total, 1 << 16) * 5 // 4
+            st = self._up = dict(words=words, pos=0, stream=(st or {}).get("stream") or torch.cuda.Stream(device=dev), blocks=[])
+            for _ in range(2):
+                h = torch.empty(words, dtype=torch.float32).pin_memory()
+                st["blocks"].append(dict(host=h, arr=h.numpy(), dev=torch.empty(words, dtype=torch.float32, device=dev),
+                                         sent=torch.cuda.Event(), free=torch.cuda.Event()))
+        blk = st["blocks"][st["pos"] % 2]
+        st["pos"] += 1
+        blk["sent"].synchronize()                                    # the copy that last read this pinned block has executed
+        arr, dblk, out = blk["arr"], blk["dev"], []
+        for obj, feat, n, F, off in metas:
+            arr[off:off + 3 * n].reshape(n, 3)[...] = obj["pc"]
+            arr[off + 3 * n:off + 6 * n].reshape(n, 3)[...] = obj["normals"]
+            if F:
+                arr[off + 6 * n:off + (6 + F) * n].reshape(n, F)[...] = feat
+            o = dict(obj, pc=dblk[off:off + 3 * n].view(n, 3), normals=dblk[off + 3 * n:off + 6 * n].view(n, 3))
+            o["feat"] = dblk[off + 6 * n:off + (6 + F) * n].view(n, F) if F else None
+            out.append(o)
+        for o, j in zip(out, mine):
+            o["dims"] = tuple(int(v) for v in host_dims[j])
+        with torch.cuda.stream(st["stream"]):
+            st["stream"].wait_event(blk["free"])                     # the chains that read this device block two batches ago are done
+            dblk[:total].copy_(blk["host"][:total], non_blocking=True)
+            blk["sent"].record(st["stream"])
+        return out, blk
+
+    def _run_resident(self, objects, mine, rank, world, seed, host_dims=None):
+        """run() for objects put() on the device -- and for host objects whose pairs are drawn on the device, which are uploaded on
+        the way (_upload_batch): per chain one 48-byte-per-member descriptor copy, one graph replay, one device copy
         of the finished records; nothing is read back (the survivor counts that choose a chain's form for the NEXT batch are copied
         to pinned memory asynchronously and looked at when the next batch starts)."""
-        dev, n = self.device, len(mine)
+        dev, n, n_total = self.device, len(mine), len(objects)
         self._adapt_resident()
         local = self.__dict__.get("_local")
         if local is None or local.shape[0] < max(n, 1):
@@ -248,8 +299,14 @@ class BatchPoseRunner:
                 self.encoders[cat]._packed_weights(dev)
             if cat in self.point_encoders:
                 self.point_encoders[cat]._packed_weights(dev)
+        blk = None
+        if host_dims is not None:           # host objects: one packed copy for the whole batch, on the copy stream (_upload_batch)
+            uploaded, blk = self._upload_batch(objects, mine, host_dims)
+            objects = dict(zip(mine, uploaded))
         for st in self._streams:
             st.wait_stream(main)
+            if blk is not None:
+                st.wait_event(blk["sent"])
         # chains of 1, 2, 4 or 8 members -- lists of equal length in those numbers keep each list on its own XCDs in the pair kernel
         # (cppf_pair_mlp_batch_plan) -- the smallest such length that gives every lane at most one chain, capped at 8: 8 objects on 3
         # lanes run as 4 + 4 (0.145 ms per object; 3 + 3 + 2: 0.151, 2 + 2 + 2 + 2: 0.161), 16 as 8 + 8, 24 as 8 + 8 + 8
@@ -276,6 +333,8 @@ class BatchPoseRunner:
                 ran.append((chain, slots))
         for st in self._streams:
             main.wait_stream(st)
+        if blk is not None:
+            blk["free"].record(main)        # (joined: every chain that read the device block has finished before this point of `main`)
         if self.__dict__.get("own_done") is not None:      # a caller's timing event: this rank's chains, before the gather (bench.py)
             self.own_done.record(main)
         snap = self.__dict__.get("_snap")
@@ -285,8 +344,23 @@ class BatchPoseRunner:
         snap[1].record(main)
         self._pending = ran
         if world == 1 and not (sharding.forced() and sharding.dist.is_initialized()):
-            return local[:len(objects)].clone()            # (the next batch overwrites `local`: hand the caller its own copy)
-        return sharding.gather_records(local, len(objects), rank, world, dev, validate=False)
+            return local[:n_total].clone()                 # (the next batch overwrites `local`: hand the caller its own copy)
+        return sharding.gather_records(local, n_total, rank, world, dev, validate=False)
+
+    def _stageable(self, objects, mine):
+        """can these host objects take the staged chains (the standard fused pair encoder; grids of the tiled vote)?  -> {object index:
+        grid dims} (computed once here, used by _upload_batch), or None"""
+        out = {}
+        for j in mine:
+            obj = objects[j]
+            enc = self.encoders.get(obj["cfg"].category)
+            if enc is None or not enc.fused_decode_supported(obj["cfg"].tr_num_bins, obj["cfg"].rot_num_bins):
+                return None
+            _, dims = grid_shape(obj["pc"], obj["cfg"].res)
+            if grid_class(dims)[0] == 0:
+                return None
+            out[j] = dims
+        return out
 
     def _adapt_resident(self):
         """the split / full-first form of the chains of the last resident batch, from its survivor counts (PoseChain.adapt), once
@@ -326,6 +400,12 @@ class BatchPoseRunner:
             if not all(resident) or any(objects[j].get("dims") is None for j in mine):
                 raise ValueError("a batch is either host arrays or objects returned by put(): device tensors need `dims` beside them")
             return self._run_resident(objects, mine, rank, world, seed)
+        # host objects whose pairs are drawn on the device take the same staged chains (uploaded on the way): the host only packs and
+        # sends the clouds.  Explicit pair lists (parity tests, callers with their own draws) keep the per-instance path below.
+        if self.staged_host and mine and all(objects[j].get("point_idxs") is None and "n_pairs" in objects[j] for j in mine):
+            host_dims = self._stageable(objects, mine)
+            if host_dims is not None:
+                return self._run_resident(objects, mine, rank, world, seed, host_dims)
         raw = self.__dict__.get("_raw")           # (every row in use is overwritten by its instance's record copy)
         if raw is None or raw.shape[0] < max(len(mine), 1):
             raw = self._raw = torch.zeros((max(len(mine), 1), 21), dtype=torch.float64, device=self.device)

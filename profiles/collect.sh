@@ -43,7 +43,24 @@ for set in "FETCH_SIZE" "WRITE_SIZE"; do
   python $R/profiles/pmcstats.py $f >> $OUT/pmc_counters_timed_width.txt
 done
 python $R/profiles/make_traffic_json.py $OUT/pmc_counters_timed_width.txt > $OUT/pmc_traffic_timed_width.json
+# the batch drivers (round 6): per-kernel device microseconds PER INSTANCE (kstats.py <db> <rows> <instances>) of
+#   FrameRunner on the reference's demo depth frame (bench.py real_frame)             -> kernel_trace_stats_frame.txt
+#   the reference-default batch (100 000 pairs, kNN + SPRIN + pose; bench.py level3)  -> kernel_trace_stats_level3.txt (host-staged), _level3_resident.txt
+#   one GPU's share of the C4 batch, 8 mixed-category objects resident on the device  -> kernel_trace_stats_c4_share.txt
+batch_trace() {   # name, then env assignments + script
+  local name=$1; shift
+  timeout 600 env "$@" > /dev/null 2>&1   # (warm the file cache: the first import of a fresh box is slow)
+  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt_$name -- env "$@" > $OUT/$name.log 2>&1
+  local n=$(grep -o "instances_processed [0-9]*" $OUT/$name.log | tail -1 | cut -d" " -f2)
+  grep "ms per" $OUT/$name.log | tail -2 > $OUT/kernel_trace_stats_$name.txt
+  python $R/profiles/kstats.py $(find /tmp/kt_$name -name '*.db' | head -1) 30 ${n:-1} >> $OUT/kernel_trace_stats_$name.txt 2>&1
+}
+batch_trace frame python $R/scripts/profile_frame.py
+batch_trace level3 MODE=level3 python $R/scripts/profile_level3.py
+batch_trace level3_resident MODE=level3 RESIDENT=1 python $R/scripts/profile_level3.py
+batch_trace c4_share MODE=c4 RESIDENT=1 python $R/scripts/profile_level3.py
 # the vote stage alone per configuration and regime (known-answer = what a trained network emits)
 bash $R/profiles/vote_ktrace.sh c2 > $OUT/vote_regimes_ktrace.txt 2>&1
 bash $R/profiles/vote_ktrace.sh c5 >> $OUT/vote_regimes_ktrace.txt 2>&1
+bash $R/profiles/vote_ktrace.sh c2posed >> $OUT/vote_regimes_ktrace.txt 2>&1
 tail -3 $OUT/bench_under_trace.log | cut -c1-300

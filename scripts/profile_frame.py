@@ -34,6 +34,7 @@ t0 = time.perf_counter()
 for _ in range(n):
     runner.run(depth, inst)
 torch.cuda.synchronize()
+print("instances_processed %d" % ((5 + n) * len(inst)))
 print("FrameRunner ms per frame", (time.perf_counter() - t0) / n * 1e3, "chains", len(runner._chains),
       [(k[0], k[1], k[5]) for k in runner._members], runner.last)
 if os.environ.get("CPROFILE"):
@@ -45,8 +46,9 @@ if os.environ.get("CPROFILE"):
         runner.run(depth, inst)
     pr.disable()
     pstats.Stats(pr).sort_stats("cumulative").print_stats(25)
-t0 = time.perf_counter()
-for _ in range(5):
-    frame_poses(depth, inst, encs, pencs, device=dev)
-torch.cuda.synchronize()
-print("eager ms per frame", (time.perf_counter() - t0) / 5 * 1e3)
+if os.environ.get("EAGER"):          # (off under rocprofv3: its launches would be summed into the per-instance kernel times)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        frame_poses(depth, inst, encs, pencs, device=dev)
+    torch.cuda.synchronize()
+    print("eager ms per frame", (time.perf_counter() - t0) / 5 * 1e3)

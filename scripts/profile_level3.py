@@ -50,4 +50,5 @@ for _ in range(5):
         runner.run(batch)
     torch.cuda.synchronize()
     ts.append((time.perf_counter() - t0) / (n // 5) / len(batch) * 1e3)
+print("instances_processed %d" % ((8 + 5 * (n // 5)) * len(batch)))
 print(("resident " if os.environ.get("RESIDENT") else "") + "%s lanes %d chain_len %s: ms per instance median %.4f [%.4f, %.4f]" % (mode, lanes, cl, sorted(ts)[2], min(ts), max(ts)))
