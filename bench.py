@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 
 import bench_cpu                                       # noqa: E402
 import cppf_amd.synthetic as syn                       # noqa: E402
-from bench_dist import bind_rank_cpus, dist_info, self_launch      # noqa: E402
+from bench_dist import bind_rank_cpus, binding_dict, dist_info, self_launch      # noqa: E402
 from bench_util import (CONFIGS, METRIC, TRAINED_WEIGHTS, compact, emit, events_per_chain, make_center_set,      # noqa: E402,F401
                         make_stepper, mlp_batch, settle, vote_width, workload_text)
 from cppf_amd import sharding                          # noqa: E402
@@ -255,7 +255,7 @@ def main_c4(args, dev, rank, world, binding):
                       "objects": m["n_objects"], "objects_per_gpu": m["n_objects"] / world, "parallelism": f"objects x{world}"},
            "objects_per_s": m["reps"] * m["n_objects"] / m["elapsed"],
            "regions": len(m["regions"]), "region_ms_min_max": [m["regions"][0] * 1e3, m["regions"][-1] * 1e3],
-           "dist": dinfo}
+           "dist": dinfo, "cpu_binding": binding_dict(binding)}
     if not args.no_cpu_baseline:      # >= 1 object of every rank against the oracle's full pose (the worker reproduces the device's draws)
         sample = sorted({r + world * s for r in range(world) for s in range(max(1, args.c4_check // world))
                          if r + world * s < m["n_objects"]})
@@ -318,7 +318,7 @@ def main():
         sys.exit(2)
     dev = torch.device("cuda", local)          # (local = LOCAL_RANK, or LOCAL_RANK mod the GPUs present when ranks share devices)
     torch.cuda.set_device(dev)
-    binding = bind_rank_cpus(int(os.environ.get("LOCAL_RANK", "0")), world, dev)
+    binding = bind_rank_cpus(int(os.environ.get("LOCAL_RANK", "0")), world, dev)      # (one rank too: next to its GPU)
 
     if args.config == "c4":
         main_c4(args, dev, rank, world, binding)
@@ -356,7 +356,7 @@ def main():
             # the timed region (exactly `steps` steps + the gather, barrier + synchronize on both sides) was run `regions` times;
             # value / ms_per_step come from the MEDIAN region (max over ranks per region)
             "regions": len(m["regions"]), "region_ms_min_max": [m["regions"][0] * 1e3, m["regions"][-1] * 1e3],
-            "dist": dinfo,
+            "dist": dinfo, "cpu_binding": binding_dict(binding),      # (this process's CPUs: the ones next to its GPU, bench_dist.py)
             # hipEvents around the whole chain on one object, one at a time, objects rotating
             "median_ms_one_instance": lat[len(lat) // 2], "one_instance_ms_min_max": [lat[0], lat[-1]], "one_instance_runs": len(lat),
             "vote_workgroups": m["objs"][0]["pipe"].vote_workgroups,      # width of the single chains' vote launches (0 = one per CU)

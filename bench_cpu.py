@@ -47,12 +47,18 @@ def oracle_center(o, sd, threads=None, all_heads=False):
     return flat, {"mlp": t1 - t0, "decode": t2 - t1, "vote_argmax": t3 - t2}
 
 
-def physical_cores():
+def original_cpus():
+    """the CPUs this process could run on before bench_dist.bind_rank_cpus narrowed it to its GPU's share (None: never bound)"""
+    text = os.environ.get("CPPF_BENCH_ORIG_CPUS")
+    return {int(c_) for c_ in text.split(",")} if text else None
+
+
+def physical_cores(allowed=None):
     """distinct (package, core) pairs among the CPUs this process may run on (0 when /proc/cpuinfo does not say)"""
-    if os.environ.get("CPPF_BENCH_PHYSICAL_CORES"):
+    if allowed is None and os.environ.get("CPPF_BENCH_PHYSICAL_CORES"):
         return int(os.environ["CPPF_BENCH_PHYSICAL_CORES"])
     try:
-        allowed = os.sched_getaffinity(0)
+        allowed = allowed if allowed is not None else os.sched_getaffinity(0)
         cores, cpu, pkg = set(), None, 0
         with open("/proc/cpuinfo") as f:
             for ln in f:
@@ -171,16 +177,21 @@ def run_cpu_worker(jobs, timeout=900, bind=True):
     """The CPU legs (cpu_baseline sweeps, the oracle's arg-max of every object) in a process of their own: thread binding
     (OMP_PROC_BIND=close OMP_PLACES=cores must be in the environment before the OpenMP runtimes load, and would pin THIS process's
     main thread -- the one that feeds the GPU -- to one core), no distributed environment.  jobs: list of dicts, see cpu_worker."""
-    env = dict(os.environ, CPPF_BENCH_HOST_THREADS=str(host_threads()), CPPF_BENCH_PHYSICAL_CORES=str(physical_cores()))
+    # a rank of a multi-GPU run is bound to the CPUs next to its GPU (bench_dist.bind_rank_cpus); the CPU legs are the HOST's numbers:
+    # the worker gets the whole machine back
+    orig = original_cpus()
+    env = dict(os.environ, CPPF_BENCH_HOST_THREADS=str(len(orig) if orig else host_threads()),
+               CPPF_BENCH_PHYSICAL_CORES=str(physical_cores(orig) if orig else physical_cores()))
     if bind:
         env.update(OMP_PROC_BIND="close", OMP_PLACES="cores")
     else:
         env.pop("OMP_PROC_BIND", None)
         env.pop("OMP_PLACES", None)
-    for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "CPPF_FORCE_DIST", "OMP_NUM_THREADS", "TORCHELASTIC_RUN_ID"):
+    for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "CPPF_FORCE_DIST", "OMP_NUM_THREADS", "TORCHELASTIC_RUN_ID",
+               "CPPF_BENCH_ORIG_CPUS"):
         env.pop(k_, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-worker", json.dumps(jobs)], env=env, capture_output=True,
-                       text=True, timeout=timeout)
+                       text=True, timeout=timeout, preexec_fn=(lambda: os.sched_setaffinity(0, orig)) if orig else None)
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("[")]
     if p.returncode != 0 or not lines:
         raise RuntimeError(f"bench.py --cpu-worker failed ({p.returncode}): {p.stderr[-2000:]}")

@@ -29,12 +29,14 @@ def self_launch(args, argv):
 
 
 def bind_rank_cpus(local, world, dev):
-    """Give this rank the CPUs next to its GPU: /sys/bus/pci/devices/<GPU>/local_cpulist (the GPU's NUMA node), split evenly between
-    the ranks whose GPUs share that list; torch's intra-op threads are capped to the share (at most 8: the host side of a rank is one
-    enqueueing thread).  -> [numa node, CPUs in the share, first, last] (numa -1 / zeros: nothing bound -- no sysfs entry, one rank,
-    CPPF_BENCH_NO_BIND=1).  A launcher that pinned the ranks already (the mask is narrower than the machine) is left alone."""
+    """Give this rank the CPUs next to its GPU: /sys/bus/pci/devices/<GPU>/local_cpulist (the GPU's NUMA node), whole physical cores
+    in contiguous blocks split evenly between the ranks whose GPUs share that list (one rank: the whole list -- a process the
+    scheduler parked on the other socket enqueues measurably slower); with several ranks torch's intra-op threads are capped to the
+    share (at most 8: the host side of a rank is one enqueueing thread).  -> [numa node, CPUs in the share, first, last] (numa -1 /
+    zeros: nothing bound -- no sysfs entry, CPPF_BENCH_NO_BIND=1).  A launcher that pinned the ranks already (the mask is narrower
+    than the machine) is left alone."""
     none = [-1, 0, 0, 0]
-    if world <= 1 or os.environ.get("CPPF_BENCH_NO_BIND") or not hasattr(os, "sched_setaffinity"):
+    if os.environ.get("CPPF_BENCH_NO_BIND") or not hasattr(os, "sched_setaffinity"):
         return none
     try:
         def cpulist(i):
@@ -52,19 +54,39 @@ def bind_rank_cpus(local, world, dev):
         allowed = os.sched_getaffinity(0)
         if len(allowed) < (os.cpu_count() or 1):
             return none
+        os.environ["CPPF_BENCH_ORIG_CPUS"] = ",".join(str(c_) for c_ in sorted(allowed))    # (the CPU worker gets the whole machine back)
         numa, cpus = cpulist(dev.index)
         cpus = [c_ for c_ in cpus if c_ in allowed]
         n_local = int(os.environ.get("LOCAL_WORLD_SIZE", world))
         n_dev = torch.cuda.device_count()
-        sharers = [r for r in range(n_local) if cpulist(r % n_dev)[1] == cpulist(dev.index)[1]]
-        share = cpus[sharers.index(local)::len(sharers)] if local in sharers else cpus
+        sharers = [r for r in range(n_local) if cpulist(r % n_dev)[1] == cpulist(dev.index)[1]] if world > 1 else [local]
+        cores = {}                                    # physical core (its lowest hardware thread) -> its hardware threads in the list
+        for c_ in cpus:
+            try:
+                with open(f"/sys/devices/system/cpu/cpu{c_}/topology/thread_siblings_list") as f:
+                    key = int(f.read().replace("-", ",").split(",")[0])
+            except (OSError, ValueError):
+                key = c_
+            cores.setdefault(key, []).append(c_)
+        keys = sorted(cores)
+        if local in sharers and len(sharers) > 1:
+            per = max(1, len(keys) // len(sharers))
+            i = sharers.index(local)
+            keys = keys[i * per:(i + 1) * per] if i < len(sharers) - 1 else keys[i * per:]
+        share = sorted(c_ for k_ in keys for c_ in cores[k_])
         if not share:
             return none
         os.sched_setaffinity(0, share)
-        torch.set_num_threads(max(1, min(8, len(share))))
+        if world > 1:
+            torch.set_num_threads(max(1, min(8, len(share))))
         return [numa, len(share), min(share), max(share)]
     except (OSError, ValueError, AttributeError, RuntimeError):
         return none
+
+
+def binding_dict(b):
+    """bind_rank_cpus' result as it is printed"""
+    return None if not b or b[0] < 0 else {"numa": int(b[0]), "cpus": int(b[1]), "range": [int(b[2]), int(b[3])]}
 
 
 def dist_info(world, dev, own_ms=None, binding=None):
@@ -87,4 +109,4 @@ def dist_info(world, dev, own_ms=None, binding=None):
     return {"backend": torch.distributed.get_backend(), "forced_single_rank": world == 1, "ranks_seen": int(one.item()),
             "device_per_rank": devs, "shared_gpu": len(set(devs)) < len(devs),
             "rank_region_ms": [float(f"{v:.6g}") for v in ms], "imbalance": (max(ms) / min(ms)) if min(ms) > 0 else None,
-            "cpu_binding": [None if r[2] < 0 else {"numa": int(r[2]), "cpus": int(r[3]), "range": [int(r[4]), int(r[5])]} for r in every]}
+            "cpu_binding": [binding_dict(r[2:6]) for r in every]}

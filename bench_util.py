@@ -375,7 +375,7 @@ def compact(out):
         cfg["workload"] = cfg["workload"][:240] + " ... (full text: bench_full.json)"
     line["config"] = cfg
     for k_ in ("pairs_per_ms_per_gpu", "regions", "region_ms_min_max", "median_ms_one_instance", "vote_workgroups", "mlp_batch",
-               "vote_batch", "vote_batch_workgroups", "vote_batch_calibration_ms_per_step", "dist", "argmax_matches_oracle",
+               "vote_batch", "vote_batch_workgroups", "vote_batch_calibration_ms_per_step", "dist", "cpu_binding", "argmax_matches_oracle",
                "argmax_objects_matching_oracle", "argmax_steps_matching_oracle", "argmax_objects_matching_oracle_per_rank",
                "records_matching_oracle", "objects_checked", "objects_per_s", "c4_strong_scaling_predicted"):
         if k_ in out:
