@@ -148,6 +148,10 @@ def c4_encoders(dev=None):
     return encs
 
 
+def args_no_overlap(args):
+    return bool(getattr(args, "no_overlap_batches", False))
+
+
 def run_c4(dev, rank, world, args, n_objects=64, n_regions=0, host_staged=False):
     """64 mixed-category objects sharded round-robin over the ranks, full pose per object, ONE gather inside the timed region.
     The objects are uploaded once (BatchPoseRunner.put: SURVEY.md 8d, "inputs already resident on device"); host_staged: every
@@ -155,7 +159,7 @@ def run_c4(dev, rank, world, args, n_objects=64, n_regions=0, host_staged=False)
     the PCIe-inclusive rate -- never `value` of the default command."""
     from cppf_amd.batch import BatchPoseRunner
     n_points, k = (args.n_points or 4096), (args.pairs_per_point or 128)
-    runner = BatchPoseRunner(c4_encoders(dev), dev, n_lanes=max(1, args.streams),
+    runner = BatchPoseRunner(c4_encoders(dev), dev, n_lanes=max(1, args.streams), overlap_batches=not args_no_overlap(args),
                              vote_workgroups=None if args.vote_workgroups < 0 else args.vote_workgroups)
     objects = c4_objects(n_objects, n_points, k)
     if not host_staged:
@@ -242,7 +246,7 @@ def main_c4(args, dev, rank, world, binding):
     total_pairs = m["reps"] * m["n_objects"] * m["P"]
     how = ("clouds and features sent from pinned host memory per batch (the PCIe-inclusive rate), records assembled on the device" if m["host_staged"] else
            "objects uploaded once (inputs resident in HBM), staged into the chains' buffers by cppf_stage_batch, records assembled on "
-           "the device")
+           "the device" + ("" if args_no_overlap(args) else ", a batch's chains waiting for their own inputs only (overlap_batches)"))
     out = {"metric": METRIC, "value": total_pairs / m["elapsed"], "unit": "pairs/s", "n_gpus": world,
            "steps": m["reps"] * m["n_objects"], "warmup": args.warmup,
            "ms_per_step": m["elapsed"] / (m["reps"] * m["n_objects"]) * 1e3, "higher_is_better": True, "scaling": "strong",
@@ -295,6 +299,8 @@ def main():
     ap.add_argument("--all-heads", action="store_true", help="first pass decodes all 141 logits of every pair (round 1-2's headline)")
     ap.add_argument("--host-staged", action="store_true", help="--config c4: every batch brings its clouds and features from the host "
                     "(the PCIe-inclusive rate) instead of objects resident on the device")
+    ap.add_argument("--no-overlap-batches", action="store_true", help="--config c4: every batch's chains wait for the caller's stream "
+                    "(i.e. for the previous batch's join) instead of for their own inputs only (BatchPoseRunner(overlap_batches=...))")
     ap.add_argument("--c4-check", type=int, default=8, help="--config c4: objects (spread over the ranks, at least one each) whose "
                     "records rank 0 checks against the oracle's full pose")
     ap.add_argument("--n-points", type=int, default=0, help="exploration only; overrides the config's N")

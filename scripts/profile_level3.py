@@ -27,7 +27,8 @@ if mode == "level3":
     sizes = (717, 1203, 1890, 960, 1544, 2011, 1333, 1777)
     robjs = [syn.make_posed_object(cats[j % 3], n_j, 910000 + j) for j, n_j in enumerate(sizes)]
     batch = [dict(pc=o["pc"], normals=o["normals"], cfg=o["cfg"], n_pairs=100000) for o in robjs]
-    runner = BatchPoseRunner({c: nets[c][1] for c in cats}, dev, point_encoders={c: nets[c][0] for c in cats}, n_lanes=lanes, chain_len=cl)
+    runner = BatchPoseRunner({c: nets[c][1] for c in cats}, dev, point_encoders={c: nets[c][0] for c in cats}, n_lanes=lanes, chain_len=cl,
+                             overlap_batches=bool(os.environ.get("OVERLAP")))
 else:
     encs = {}
     for i, c in enumerate(NOCS_CATEGORIES):
@@ -35,7 +36,7 @@ else:
         cfg = syn.make_object(c, 8, 0)["cfg"]
         encs[c] = PPFEncoder(cfg.ppffcs, cfg.out_dim).eval().to(dev)
     batch = bench.c4_objects(int(os.environ.get("OBJECTS", "8")), 4096, 128)
-    runner = BatchPoseRunner(encs, dev, n_lanes=lanes, chain_len=cl)
+    runner = BatchPoseRunner(encs, dev, n_lanes=lanes, chain_len=cl, overlap_batches=bool(os.environ.get("OVERLAP")))
 if os.environ.get("RESIDENT"):
     batch = runner.put(batch)
 for _ in range(8):
@@ -51,4 +52,4 @@ for _ in range(5):
     torch.cuda.synchronize()
     ts.append((time.perf_counter() - t0) / (n // 5) / len(batch) * 1e3)
 print("instances_processed %d" % ((8 + 5 * (n // 5)) * len(batch)))
-print(("resident " if os.environ.get("RESIDENT") else "") + "%s lanes %d chain_len %s: ms per instance median %.4f [%.4f, %.4f]" % (mode, lanes, cl, sorted(ts)[2], min(ts), max(ts)))
+print(("overlap " if os.environ.get("OVERLAP") else "") + ("resident " if os.environ.get("RESIDENT") else "") + "%s lanes %d chain_len %s: ms per instance median %.4f [%.4f, %.4f]" % (mode, lanes, cl, sorted(ts)[2], min(ts), max(ts)))

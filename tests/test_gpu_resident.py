@@ -152,13 +152,15 @@ def test_resident_batch_equals_the_host_path_and_the_oracle(oracle, golden, dev,
         np.testing.assert_allclose(recs[0][j, 9:12], o["scale"], rtol=1e-6)
 
 
-def test_resident_objects_given_as_device_tensors_and_a_new_batch_per_run(dev):
-    """put() of device tensors (dims computed on the device); a runner fed a DIFFERENT batch every run (new addresses, new sizes in the
+@pytest.mark.parametrize("overlap", [False, True])
+def test_resident_objects_given_as_device_tensors_and_a_new_batch_per_run(dev, overlap):
+    """(overlap: BatchPoseRunner(overlap_batches=True) -- a batch's chains wait for their inputs' events only, so lanes run ahead into
+    the next batch while the caller's stream still reads this one's records)  put() of device tensors (dims computed on the device); a runner fed a DIFFERENT batch every run (new addresses, new sizes in the
     same buckets, new seeds) returns what a fresh runner returns for that batch -- nothing of a replay is baked into the graphs"""
     from cppf_amd.batch import BatchPoseRunner
     sd = seeded_sd(1, 4.0)
     encoders = {c: make_encoder(sd, dev) for c in NOCS_CATEGORIES}
-    runner = BatchPoseRunner(encoders, dev)
+    runner = BatchPoseRunner(encoders, dev, overlap_batches=overlap)
     outs = []
     batches = [mixed_batch(5, (900, 1000, 800), 30000, 400 + 10 * b) for b in range(3)]
     for b, objs in enumerate(batches):
@@ -174,3 +176,24 @@ def test_resident_objects_given_as_device_tensors_and_a_new_batch_per_run(dev):
         runner.run([batches[0][0], runner.put(batches[0])[1]])            # host and resident objects mixed
     with pytest.raises(ValueError):
         runner.put([dict(batches[0][0], point_idxs=np.zeros((4, 2), np.int64))])
+
+
+def test_overlapping_batches_return_each_batch_its_own_records(dev):
+    """overlap_batches=True with nothing between the runs: many batches of DIFFERENT objects enqueued back to back without a
+    synchronisation -- resident and host-array batches alternating, more batches in flight than the two record buffers -- every
+    returned tensor must hold its own batch's records (what a fresh, non-overlapping runner returns for it)"""
+    from cppf_amd.batch import BatchPoseRunner
+    sd = seeded_sd(2, 4.0)
+    encoders = {c: make_encoder(sd, dev) for c in NOCS_CATEGORIES}
+    runner = BatchPoseRunner(encoders, dev, overlap_batches=True, n_lanes=3)
+    batches = [mixed_batch(int(n), (600, 1000, 800, 1200), 20000, 700 + 20 * b) for b, n in enumerate((8, 3, 8, 13, 1, 8, 8, 5))]
+    for warm in range(2):                                   # chains captured on their second sighting
+        for b, objs in enumerate(batches):
+            runner.run(runner.put(objs) if b % 2 == 0 else objs, seed=b)
+    torch.cuda.synchronize()
+    outs = [runner.run(runner.put(objs) if b % 2 == 0 else objs, seed=b) for b, objs in enumerate(batches)]      # no sync in between
+    outs = [o.cpu().numpy() for o in outs]
+    fresh = BatchPoseRunner(encoders, dev)
+    for b, objs in enumerate(batches):
+        want = fresh.run(fresh.put(objs), seed=b).cpu().numpy()
+        np.testing.assert_array_equal(outs[b], want, err_msg=f"batch {b}")
