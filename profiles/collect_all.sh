@@ -10,7 +10,10 @@ python bench.py --steps 20 --warmup 5 --full-record gpurun_out/final/bench_defau
 python bench.py --steps 20 --warmup 5 --all-heads --no-cpu-baseline --no-secondary --full-line --full-record "" > gpurun_out/final/bench_all_heads.json 2>/dev/null
 for c in c3 c5; do python bench.py --steps 20 --warmup 5 --config $c --no-cpu-baseline --no-secondary --full-line --full-record "" > gpurun_out/final/bench_$c.json 2>/dev/null; done
 python bench.py --config c4 --no-cpu-baseline --full-line --full-record "" > gpurun_out/final/bench_c4.json 2>/dev/null
-python bench.py --gpus 2 --no-cpu-baseline --no-secondary --full-record "" > gpurun_out/final/bench_gpus2_shared.json 2>/dev/null
+# two ranks on this box's one GPU (gloo rendezvous, shared device: a code-path run, not a scaling measurement) -- the line must prove
+# itself: every rank's objects against the oracle, per-rank times, CPU binding, cpu_baseline (bench.py, bench_dist.py)
+python bench.py --gpus 2 --no-secondary --min-seconds 1 --full-record "" > gpurun_out/final/bench_gpus2_shared.json 2>/dev/null
+python bench.py --gpus 2 --config c4 --full-record "" > gpurun_out/final/bench_c4_gpus2_shared.json 2>/dev/null
 python bench.py --config c1 --full-line --full-record "" > gpurun_out/final/bench_c1.json 2>/dev/null
 bash profiles/collect.sh > gpurun_out/final/collect.log 2>&1
 cat gpurun_out/final/gputest.txt

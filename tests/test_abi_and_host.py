@@ -569,7 +569,7 @@ def test_workspace_bounds_at_five_million_pairs():
     assert 4 <= tiles <= 8
     by_value = L.cppf_vote_workspace_bytes(P5M, 72, 67, 34, 67)
     assert by_value <= tiles * P5M * 12 + P5M * 48 + (64 << 20)   # 12 B per (pair, tile) record worst case + a 48 B frame per pair + partial tiles
-    assert by_value <= 0.6 * (1 << 30)
+    assert by_value <= 0.65 * (1 << 30)                          # 6 tiles: 0.36 GB of queues + 0.24 GB of frames + partial tiles
     assert L.cppf_vote_workspace_bytes(P5M, 72, 330, 166, 334) == L.cppf_vote_workspace_init_bytes()      # beyond 64 tiles: no queues
     few = L.cppf_vote_workspace_bytes_dyn_pairs(0, P5M)
     assert few <= (64 << 20)                                      # few-tile class: no queues at all, whatever P
