@@ -153,6 +153,21 @@ class CppfError(RuntimeError):
     pass
 
 
+def tile_class(many):
+    """what the *_dyn entry points take as `many_tiles` (include/cppf.h): 0 = up to 3 LDS tiles (fused vote), 1 / True = up to 64,
+    4..64 = up to that many"""
+    m = 1 if many is True else int(many)
+    if m in (0, 1) or 4 <= m <= 64:
+        return m
+    raise ValueError(f"tile capacity class {many!r}: 0, 1 (= 64 tiles) or 4..64")
+
+
+def tiles_cap(many):
+    """tiles a launch of that class serves"""
+    m = tile_class(many)
+    return 3 if m == 0 else (64 if m == 1 else m)
+
+
 def library_path():
     return _SO
 

@@ -37,8 +37,9 @@ class BatchPoseRunner:
         n_bucket: point capacities are multiples of it; max_pipelines: bound of the pipeline cache;
         dynamic=False: one exact-shape pipeline per distinct instance shape (fixed-shape workloads only);
         max_scratch_bytes: second bound of the cache, on the pipelines' estimated device footprint (buffers + the vote's workspace,
-        whose pair -> tile queues are sized for the worst case, every pair in every tile of the grid class: 64 x 12 B per pair for
-        many-tile grids, i.e. ~0.45 GB per pipeline at 524 288 pairs, ~1.7 GB at 2 M; INTEGRATION.md "Memory");
+        whose pair -> tile queues are sized for the worst case, every pair in every tile of the grid class: 16 x 12 + 48 B per pair
+        for grids of 4-16 tiles (0.13 GB per pipeline at 524 288 pairs, 0.5 GB at 2 M), 64 x 12 + 48 B beyond (0.43 / 1.7 GB);
+        INTEGRATION.md "Memory");
         n_lanes: instances in flight (HIP streams, each with its own pipelines).  Three measured best on a ragged batch of
         small instances (N 400-2000, 100 k pairs: 0.216 / 0.136 / 0.115 / 0.144 ms per instance with 1 / 2 / 3 / 4 lanes): the
         neighbours fill the gaps between an instance's ~15 short dependent launches.
@@ -159,8 +160,8 @@ class BatchPoseRunner:
             ws = L.cppf_vote_workspace_bytes(int(n_pairs), 72, int(dims[0]), int(dims[1]), int(dims[2]))
             grid = 4 * int(dims[0]) * int(dims[1]) * int(dims[2])
         else:
-            ws = L.cppf_vote_workspace_bytes_dyn_pairs(1 if many_tiles else 0, int(n_pairs))
-            grid = 4 * (64 if many_tiles else 3) * int(L.cppf_vote_tile_cells())
+            ws = L.cppf_vote_workspace_bytes_dyn_pairs(_lib.tile_class(many_tiles), int(n_pairs))
+            grid = 4 * _lib.tiles_cap(many_tiles) * int(L.cppf_vote_tile_cells())
         return int(ws) + grid + 100 * int(n_pairs) + 1400 * int(n_points)
 
     _RING = 4

@@ -1562,9 +1562,15 @@ static size_t v3_workspace_bytes(int64_t n_ppfs, int gx, int gy, int gz)
     const V3Tiling t = v3_tiling(gx, gy, gz);
     return v3_plan(n_ppfs, t, gz, v3_wgs(n_ppfs, t.T), t.T < 4 ? 0 : n_ppfs, (int64_t)gx * gy * gz).total;   // (< 4 tiles: no queues)
 }
+// tiles a *_dyn launch of class `many_tiles` serves: 0 -> 3 (the fused kernel), 1 -> 64 (any tiled grid), 4..64 -> that many (queues and
+// the reduce launch sized for them: a posed NOCS object needs 9-12 tiles, the C5 grid 16 -- a quarter of the 64-tile footprint)
+static inline int v3_dyn_tcap(int many_tiles)
+{
+    return many_tiles == 0 ? 3 : (many_tiles < 4 || many_tiles > VOTE_MAX_TILES ? VOTE_MAX_TILES : many_tiles);
+}
 static size_t v3_workspace_bytes_dyn(int many_tiles, int64_t n_ppfs)
 {
-    const int t_cap = many_tiles ? VOTE_MAX_TILES : 3, wgs = V3_WGS;
+    const int t_cap = v3_dyn_tcap(many_tiles), wgs = V3_WGS;
     return VOTE_WS_PART + V3_HDR_BYTES + V3_PLANE_BYTES +
            (many_tiles ? align_up((size_t)t_cap * (size_t)n_ppfs * 12, 256) + align_up((size_t)n_ppfs * V3_FRAME_BYTES, 256) : 0) +
            (size_t)wgs * V3_TILE_FLOATS * sizeof(uint32_t);
@@ -1636,7 +1642,7 @@ static int v3_prepare(V3Launch& Lc, const float* points, const float* outputs, c
     A.pool_cap = n_ppfs;
     A.plane = reinterpret_cast<unsigned long long*>(ws + VOTE_WS_PART + V3_HDR_BYTES);
     if (shape_dev) {
-        A.t_cap = many_tiles ? VOTE_MAX_TILES : 3;
+        A.t_cap = v3_dyn_tcap(many_tiles);
         A.wgs = wgs_max;
         A.fused = many_tiles ? 0 : 1;
         if (ex && ex->grid_raw) return CPPF_EINVAL;

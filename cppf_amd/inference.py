@@ -124,16 +124,18 @@ _grid_class_cache = {}
 
 
 def grid_class(dims):
-    """(tiles, many_tiles, cell capacity) of the shape-polymorphic vote for a grid of `dims`: launches come in two
-    geometries, < 4 LDS tiles (256 workgroups, <= 3 tiles of cells) and <= 64 tiles (2 048 workgroups, <= 64 tiles of cells);
-    tiles == 0: the grid needs more than the tiled vote serves -- only the exact-shape pipeline runs it."""
+    """(tiles, tile capacity class, cell capacity) of the shape-polymorphic vote for a grid of `dims`: launches come in three
+    classes -- 0: < 4 LDS tiles (the fused vote, <= 3 tiles of cells), 16: up to 16 tiles (bin + vote with queues for 16 tiles: posed
+    NOCS objects need 9-12, the C5 grid 16), 1: up to 64 (queues for 64) -- the value is what the *_dyn entry points take as
+    `many_tiles` (truthy = a binned class); tiles == 0: the grid needs more than the tiled vote serves -- only the exact-shape
+    pipeline runs it."""
     key = (int(dims[0]), int(dims[1]), int(dims[2]))
     hit = _grid_class_cache.get(key)
     if hit is None:
         L = _lib.lib()
         T = int(L.cppf_vote_tiles(*key))
-        many = T >= 4
-        hit = (T, many, (64 if many else 3) * int(L.cppf_vote_tile_cells()))
+        many = 0 if T < 4 else (16 if T <= 16 else 1)
+        hit = (T, many, _lib.tiles_cap(many) * int(L.cppf_vote_tile_cells()))
         if len(_grid_class_cache) < 4096:
             _grid_class_cache[key] = hit
     return hit
@@ -188,13 +190,13 @@ class CenterPipeline:
         self.corner = self._in[6 * n:6 * n + 3]
         self.probs = None       # all ones (nocs/inference.py:201): the vote takes None for that and reads nothing
         if self.dynamic:
-            if isinstance(dims, (bool, np.bool_)):
-                self.many_tiles = bool(dims)
+            if isinstance(dims, (bool, np.bool_, int, np.integer)):       # a capacity class (_lib.tile_class)
+                self.many_tiles = _lib.tile_class(bool(dims) if isinstance(dims, (bool, np.bool_)) else int(dims))
             else:
                 T, self.many_tiles, _ = grid_class(dims)
                 if T == 0:
                     raise _lib.CppfError(f"grid {tuple(dims)} needs more LDS tiles than the shape-polymorphic vote serves")
-            self.grid_flat = z((64 if self.many_tiles else 3) * int(_lib.lib().cppf_vote_tile_cells()))
+            self.grid_flat = z(_lib.tiles_cap(self.many_tiles) * int(_lib.lib().cppf_vote_tile_cells()))
             self.shape = self._in[6 * n + 4:6 * n + 8].view(I32)               # {n_points, gx, gy, gz}, read by the *_dyn kernels
             self.shape_host = (0, 0, 0, 0)
             self.dims = None
@@ -222,7 +224,7 @@ class CenterPipeline:
             raise _lib.CppfError("set_shape() is for dynamic pipelines")
         T, many, cap = grid_class(dims)
         k_min = self.point_encoder.k if self.point_encoder is not None else 1
-        if not (k_min <= n_points <= self.n_points) or T == 0 or (many and not self.many_tiles) or \
+        if not (k_min <= n_points <= self.n_points) or T == 0 or T > _lib.tiles_cap(self.many_tiles) or \
                 int(dims[0]) * int(dims[1]) * int(dims[2]) > self.grid_flat.numel():
             raise _lib.CppfError(f"instance shape N={n_points}, grid {tuple(dims)} does not fit this pipeline "
                                  f"(N in {k_min}..{self.n_points}, many_tiles={self.many_tiles})")

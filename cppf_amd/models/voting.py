@@ -162,12 +162,13 @@ def vote_argmax_dyn(points, outputs, probs, point_idxs, grid_flat, shape, corner
     if shape.numel() < 4 or (probs is not None and probs.numel() != points.shape[0]):
         raise ValueError("shape must be i32[4]; probs must have one entry per (capacity) point")
     L = _lib.lib()
-    ws = workspace(L.cppf_vote_workspace_bytes_dyn_pairs(1 if many_tiles else 0, int(point_idxs.shape[0])), dev, "vote_dyn", zero=True)
+    many_tiles = _lib.tile_class(many_tiles)
+    ws = workspace(L.cppf_vote_workspace_bytes_dyn_pairs(many_tiles, int(point_idxs.shape[0])), dev, "vote_dyn", zero=True)
     with torch.cuda.device(dev):
         rc = L.cppf_vote_argmax_dyn(points.data_ptr(), outputs.data_ptr(), None if probs is None else probs.data_ptr(), point_idxs.data_ptr(),
                                     1 if i64 else 0, grid_flat.data_ptr(), grid_flat.numel(), corner.data_ptr(),
                                     float(scalar(res)), points.shape[0], point_idxs.shape[0], int(n_rots), shape.data_ptr(),
-                                    1 if many_tiles else 0, 1 if adaptive else 0, _vote_flags(accumulate, workgroups),
+                                    many_tiles, 1 if adaptive else 0, _vote_flags(accumulate, workgroups),
                                     out_idx.data_ptr(), out_val.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr(dev))
     _lib.check(rc, "cppf_vote_argmax_dyn")
     return out_idx, out_val
@@ -219,7 +220,7 @@ def vote_argmax_batch(items, n_rots, adaptive, accumulate=False, workgroups=0, w
         a = arr[i]
         if shape is not None:
             dev_tensor(shape, I32, "shape", None, dev)
-            many = 1 if it.get("many_tiles") else 0
+            many = _lib.tile_class(it.get("many_tiles") or 0)
             ws = workspace(L.cppf_vote_workspace_bytes_dyn_pairs(many, int(n_ppfs)), dev, f"{ws_tag}dyn{i}", zero=True)
             a.shape_dev, a.grid_capacity, a.many_tiles = shape.data_ptr(), grid.numel(), many
             a.gx = a.gy = a.gz = 1

@@ -233,7 +233,10 @@ int cppf_compact_mask(const uint8_t* mask, int64_t n, int32_t* surv, int32_t* co
  * capacities only size allocations and launch geometry.
  *   cppf_vote_tiles           LDS tiles the vote needs for a grid (0: more than the tiled path serves) -- lets the caller
  *                             pick `many_tiles` (needed when any instance can need >= 4 tiles; costs the binning launch and the
- *                             room for the pair -> tile queues, see cppf_vote_workspace_bytes_dyn_pairs)
+ *                             room for the pair -> tile queues, see cppf_vote_workspace_bytes_dyn_pairs).  `many_tiles` is a tile
+ *                             CAPACITY CLASS: 0 = up to 3 tiles (the fused kernel), 1 = up to 64 (any tiled grid), 4..64 = up to that
+ *                             many (ABI 4: queues and reduce launch sized for them -- a posed NOCS object needs 9-12 tiles, the C5
+ *                             grid 16: class 16 asks for a quarter of class 1's queues)
  *   cppf_vote_argmax_dyn      cppf_vote_argmax; grid_obj holds grid_capacity cells, the real grid f32[gx,gy,gz] occupies its
  *                             first gx*gy*gz cells; probs/points rows beyond n_points are never read.  A record that exceeds
  *                             a capacity (cells, n_points_cap, tiles) writes out_idx = -1, out_val = NaN and votes nothing.
@@ -242,7 +245,7 @@ int cppf_compact_mask(const uint8_t* mask, int64_t n, int32_t* surv, int32_t* co
  *                             for n_cap; rows >= n_points of nbrs / out are left untouched.  k <= n_points is the caller's duty.
  * ------------------------------------------------------------------------------------------- */
 int cppf_vote_tiles(int gx, int gy, int gz);
-int cppf_vote_tile_cells(void);   /* cells of one LDS tile: a launch serves grids of up to 3 (64 with many_tiles) times that */
+int cppf_vote_tile_cells(void);   /* cells of one LDS tile: a launch serves grids of up to 3 (many_tiles = 1: 64; = n: n) times that */
 /* Workspace of a *_dyn vote launch: the state block, the pair -> tile queues of the many-tile class (n_ppfs records of 12 B for
  * every tile of the class: sized for the worst case, every pair in every tile) and one partial tile per workgroup.
  * (ABI 1 had a second, smaller size that selected round 2's kernels; those are gone.) */

@@ -9,7 +9,7 @@ python -m pytest tests -m gpu -x -q 2>&1 | tail -5 > gpurun_out/final/gputest.tx
 python bench.py --steps 20 --warmup 5 --full-record gpurun_out/final/bench_default_full.json > gpurun_out/final/bench_default.json 2> gpurun_out/final/bench_default.err
 python bench.py --steps 20 --warmup 5 --all-heads --no-cpu-baseline --no-secondary --full-line --full-record "" > gpurun_out/final/bench_all_heads.json 2>/dev/null
 for c in c3 c5; do python bench.py --steps 20 --warmup 5 --config $c --no-cpu-baseline --no-secondary --full-line --full-record "" > gpurun_out/final/bench_$c.json 2>/dev/null; done
-python bench.py --config c4 --no-cpu-baseline --full-line --full-record "" > gpurun_out/final/bench_c4.json 2>/dev/null
+python bench.py --config c4 --full-line --full-record "" > gpurun_out/final/bench_c4.json 2>/dev/null     # (with the oracle check of 8 records)
 # two ranks on this box's one GPU (gloo rendezvous, shared device: a code-path run, not a scaling measurement) -- the line must prove
 # itself: every rank's objects against the oracle, per-rank times, CPU binding, cpu_baseline (bench.py, bench_dist.py)
 python bench.py --gpus 2 --no-secondary --min-seconds 1 --full-record "" > gpurun_out/final/bench_gpus2_shared.json 2>/dev/null

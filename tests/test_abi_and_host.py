@@ -323,7 +323,14 @@ def test_shape_polymorphic_plan_queries_without_a_device():
     assert L.cppf_vote_tiles(600, 600, 600) == 0                         # beyond the tiled vote: global atomics only
     for dims in ((26, 76, 26), (52, 152, 52), (100, 49, 76), (5, 5, 4000)):
         T, many, cap = grid_class(dims)
-        assert T * cells >= dims[0] * dims[1] * dims[2] and many == (T >= 4) and cap == (64 if many else 3) * cells
+        assert T * cells >= dims[0] * dims[1] * dims[2] and bool(many) == (T >= 4) and many == (0 if T < 4 else (16 if T <= 16 else 1))
+        assert cap == _lib.tiles_cap(many) * cells and _lib.tiles_cap(many) >= T
+    assert [_lib.tiles_cap(m_) for m_ in (0, False, 1, True, 4, 16, 64)] == [3, 3, 64, 64, 4, 16, 64]
+    with pytest.raises(ValueError):
+        _lib.tile_class(3)
+    # ... and the queues of a capacity class are sized for ITS tiles: class 16 asks for a quarter of class 1's
+    q16, q64 = (L.cppf_vote_workspace_bytes_dyn_pairs(m_, 2 ** 21) - L.cppf_vote_workspace_bytes_dyn_pairs(0, 2 ** 21) for m_ in (16, 1))
+    assert q16 == 16 * 2 ** 21 * 12 + 2 ** 21 * 48 and q64 == 64 * 2 ** 21 * 12 + 2 ** 21 * 48
     # the dyn workspace holds the partial tiles of ANY plan its launch geometry can meet
     few, many = L.cppf_vote_workspace_bytes_dyn_pairs(0, 524288), L.cppf_vote_workspace_bytes_dyn_pairs(1, 2 ** 21)
     assert few >= L.cppf_vote_workspace_bytes(524288, 72, 26, 76, 26) and many >= L.cppf_vote_workspace_bytes(2 ** 21, 72, 52, 152, 52)

@@ -247,3 +247,40 @@ def test_batch_runner_ragged_batch_bounded_cache(oracle, golden, dev):
     objects[3].pop("feat")
     with pytest.raises(ValueError):
         runner.run(objects)
+
+
+def test_tile_capacity_classes(dev):
+    """`many_tiles` is a tile capacity class (ABI 4: 0 = 3 tiles, 1 = 64, 4..64 = that many): a 16-tile grid through class 16 (a quarter
+    of class 1's queues) and through class 1 gives the by-value launch's grid and arg-max bit for bit; a grid that needs more tiles
+    than the class holds is refused (arg-max -1 / NaN, nothing voted); BatchPoseRunner's pipelines take the 16 class for such grids"""
+    ob = syn.make_object("bottle", 2048, 21)
+    cfg = ob["cfg"]
+    idx = syn.make_pairs(2048, 40, 21)
+    out = syn.closed_form_outputs(ob["pc"], ob["center"], idx, cfg, quantise=True)
+    pc, outputs, idx_d = t(ob["pc"], dev), t(out, dev), t(idx, dev)
+    cells = _lib.lib().cppf_vote_tile_cells()
+    oi, ov = torch.zeros(1, dtype=torch.int64, device=dev), torch.zeros(1, dtype=F32, device=dev)
+    seen = set()
+    for res in (2e-3, 1.6e-3):
+        corners, dims = grid_shape(ob["pc"], res)
+        T, many, cap = grid_class(dims)
+        seen.add(many)
+        corner = t(corners[0].copy(), dev)
+        grid = torch.empty(dims, dtype=F32, device=dev)
+        i0, v0 = voting.vote_argmax(pc, outputs, None, idx_d, grid, corner, res, 72, True, accumulate=False)
+        shape = torch.tensor([2048, *dims], dtype=I32, device=dev)
+        G = dims[0] * dims[1] * dims[2]
+        for cls in {many, 1, 64, max(T, 4)}:
+            flat = torch.full((_lib.tiles_cap(cls) * cells,), -7.0, dtype=F32, device=dev)
+            voting.vote_argmax_dyn(pc, outputs, None, idx_d, flat, shape, corner, res, 72, True, oi, ov, many_tiles=cls)
+            assert int(oi) == int(i0) and float(ov) == float(v0), (res, cls)
+            assert torch.equal(flat[:G].view(dims), grid) and bool((flat[G:] == -7.0).all()), (res, cls)
+        if T > 4:        # one tile short of what the grid needs: refused, nothing written
+            flat = torch.full((T * cells,), 3.0, dtype=F32, device=dev)
+            voting.vote_argmax_dyn(pc, outputs, None, idx_d, flat, shape, corner, res, 72, True, oi, ov, many_tiles=T - 1)
+            assert int(oi) == -1 and np.isnan(float(ov)) and bool((flat == 3.0).all()), (res, T)
+    assert seen == {16, 1}, seen          # 16 tiles at res 2e-3, more at 1.6e-3
+    # a shape-polymorphic pipeline of class 16 holds a quarter of the queues and grid of class 1
+    from cppf_amd.batch import BatchPoseRunner
+    small, big = BatchPoseRunner.footprint_bytes(2048, 2 ** 19, 16, None), BatchPoseRunner.footprint_bytes(2048, 2 ** 19, 1, None)
+    assert big - small == 48 * 2 ** 19 * 12 + 48 * cells * 4
