@@ -37,6 +37,7 @@ from bench_dist import bind_rank_cpus, binding_dict, dist_info, self_launch     
 from bench_util import (CONFIGS, METRIC, TRAINED_WEIGHTS, compact, emit, events_per_chain, make_center_set,      # noqa: E402,F401
                         make_stepper, mlp_batch, settle, vote_width, workload_text)
 from cppf_amd import sharding                          # noqa: E402
+from cppf_amd._torch_util import lane_streams          # noqa: E402
 from cppf_amd.config import NOCS_CATEGORIES            # noqa: E402
 from cppf_amd.models.model import PPFEncoder           # noqa: E402
 
@@ -69,7 +70,7 @@ def run_center_config(name, enc, sd, dev, rank, world, args):
                            use_graph=not args.no_graph, vote_workgroups=lambda P_, d_: vote_width(args, P_, d_))
     pipes = [o["pipe"] for o in objs]
     P = objs[0]["idx"].shape[0]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+    streams = lane_streams(dev, n_streams)      # (streams on distinct hardware queues, cppf_amd._torch_util.lane_streams)
     steps = args.steps
     res_all = torch.zeros((steps, 16), dtype=torch.uint8, device=dev)   # {i64 arg-max, f32 peak} of every step
     rec_tmpl = torch.zeros((steps, sharding.RECORD), dtype=torch.float64, device=dev)
@@ -185,8 +186,7 @@ def run_c4(dev, rank, world, args, n_objects=64, n_regions=0, host_staged=False)
             torch.distributed.barrier()
         torch.cuda.synchronize()
         t = time.perf_counter() - t0
-        if not host_staged:
-            own_ms.append(ev0.elapsed_time(runner.own_done))      # (of the last batch of the region)
+        own_ms.append(ev0.elapsed_time(runner.own_done))          # (region start -> the last batch's chains joined, on the device)
         return t, recs
 
     if n_regions == 1:

@@ -13,6 +13,7 @@ import cppf_amd.synthetic as syn
 from bench_util import (CONFIGS, FLOP_PER_PAIR, FLOP_PER_PAIR_CENTRE, FLOP_PER_PAIR_CENTRE_EXECUTED, FLOP_PER_PAIR_EXECUTED, NUM_ROTS,
                         PEAK_F32_MFMA, PEAK_LDS_ATOMICS, ROOT, TRAINED_WEIGHTS, bracket, event_median, events_per_chain, make_center_set,
                         make_stepper, make_trained_set, pmc_traffic, repeated, settle, vote_width)
+from cppf_amd._torch_util import lane_streams
 from cppf_amd.inference import PoseWorkspace
 from cppf_amd.models import voting
 
@@ -172,7 +173,7 @@ def collect(ctx, R):
     if secondary and not args.all_heads:
         ah = make_center_set(enc, dev, m["n_points"], m["k"], CONFIGS[args.config]["res"], m["n_obj"], seed0=100 * rank,
                              with_heads=True, use_graph=not args.no_graph, vote_workgroups=lambda P_, d_: vote_width(args, P_, d_))
-        sts = [torch.cuda.Stream(device=dev) for _ in range(m["n_streams"])]
+        sts = lane_streams(dev, m["n_streams"])
 
         ah_steps = make_stepper(dev, [o["pipe"] for o in ah], sts, res_sec, steps, m["mlp_batch"], not args.no_vote_batch,
                                 args.vote_batch_workgroups)
@@ -222,7 +223,7 @@ def collect(ctx, R):
             tobjs, penc_t, enc_t = make_trained_set(dev, m["n_points"], m["k"], m["n_obj"], 900100, rotate, use_graph=not args.no_graph,
                                                     vote_workgroups=lambda P_, d_: vote_width(args, P_, d_))
             tpipes = [o["pipe"] for o in tobjs]
-            streams = [torch.cuda.Stream(device=dev) for _ in range(m["n_streams"])]
+            streams = lane_streams(dev, m["n_streams"])
 
             tr_steps = make_stepper(dev, tpipes, streams, res_sec, steps, m["mlp_batch"], not args.no_vote_batch,
                                     args.vote_batch_workgroups)
@@ -429,7 +430,9 @@ def collect(ctx, R):
             args.steps = 8 * reps
             m4 = run_c4(dev, rank, world, args, n_objects=n_obj, host_staged=host_staged)
             per = m4["reps"] * n_obj
+            span = m4["own_ms"][len(m4["own_ms"]) // 2] / per if m4["own_ms"] else None     # region start -> the rank's chains joined, HIP events
             entry = {"workload": what + f"; median of 7 regions of {reps} batches", "ms_per_object": m4["elapsed"] / per * 1e3,
+                     "device_span_ms_per_object": span,
                      "ms_per_object_min_max": [m4["regions"][0] / per * 1e3, m4["regions"][-1] / per * 1e3],
                      "pairs_per_s": per * m4["P"] / m4["elapsed"]}
             if reps > 1 and n_obj <= 8:

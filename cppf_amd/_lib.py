@@ -84,6 +84,7 @@ _SIGS = {
     "cppf_host_grid_shape": (C.c_int, [vp, i64, f32, vp, vp]),
     "cppf_mod_pairs_dyn": (C.c_int, [vp, i64, vp, vp]),
     "cppf_stage_batch": (C.c_int, [i32, vp, vp]),
+    "cppf_copy_words": (C.c_int, [vp, vp, i64, vp]),
     "cppf_backproject_workspace_bytes": (sz, [i32, i32]),
     "cppf_backproject": (C.c_int, [vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
     "cppf_voxel_dedupe_workspace_bytes": (sz, [i64]),

@@ -13,6 +13,71 @@ def stream_ptr(device=None):
     return torch.cuda.current_stream(device).cuda_stream
 
 
+def copy_words(dst, src, device):
+    """dst <- src (tensors of 8-byte elements, contiguous, the same number of elements; either may be PINNED host memory) by a kernel
+    of the current stream of `device`, not by a copy engine (cppf_copy_words: small copies on the SDMA queues can wait behind another
+    stream's transfers)"""
+    n = dst.numel()
+    assert src.numel() == n and dst.element_size() == 8 and src.element_size() == 8 and dst.is_contiguous() and src.is_contiguous()
+    with torch.cuda.device(device):
+        _lib.check(_lib.lib().cppf_copy_words(dst.data_ptr(), src.data_ptr(), n, stream_ptr(device)), "cppf_copy_words")
+
+
+_lane_cache = {}
+
+
+def _runs_beside(ref, cand, device, spin_cycles):
+    """does work on `cand` execute WHILE `ref` is busy?  ref spins for a few hundred microseconds; an event recorded on cand right
+    after must complete well before the spin ends.  Streams that share a hardware queue are served in order, so it would not."""
+    e_ref, e_c = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(device)
+    with torch.cuda.stream(ref):
+        t0.record()
+        torch.cuda._sleep(spin_cycles)
+        t1.record()
+    with torch.cuda.stream(cand):
+        e_c.record()
+    torch.cuda.synchronize(device)
+    spin, lag = t0.elapsed_time(t1), t0.elapsed_time(e_c)
+    return spin > 0.05 and lag < 0.5 * spin
+
+
+def lane_streams(device, n):
+    """n HIP streams for work that must overlap.  The HIP runtime multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4
+    by default) chosen when a stream is created, and streams that share a queue are served IN ORDER: two lanes on one queue run one
+    after the other (measured: 8-object batches 0.13 against 0.16 ms per object, the headline 6.0 against 5.75 G pairs/s, decided
+    by how many streams the process happened to create before -- a pool stream's queue is its creation index modulo the queues).
+    Which queue a stream got cannot be asked, so it is measured: candidates are probed pairwise with a spinning kernel
+    (_runs_beside: profiles/r6_stream_queues.txt holds such a matrix) and a set whose members run beside each other is kept (per
+    device and caller stream; as many as the queues allow, the rest filled with whatever is left).  The caller's stream is tested one
+    way only -- its work must not queue behind a lane's; nothing runs beside a kernel of the legacy default stream in this probe."""
+    require_cuda()
+    main = torch.cuda.current_stream(device)
+    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), main.cuda_stream)
+    have = _lane_cache.setdefault(key, [])
+    if len(have) >= n:
+        return have[:n]
+    spin = 400_000                                    # ~0.2-0.4 ms of s_sleep at the shader clock
+    cands = [torch.cuda.Stream(device=device) for _ in range(12)]
+    good, rest = list(have), []
+    for c in cands:
+        if len(good) >= n:
+            break
+        try:
+            # (the caller's stream must not be stuck behind a lane either: its joins and the records' hand-over live there)
+            ok = _runs_beside(c, main, device, spin) and all(_runs_beside(g, c, device, spin) and _runs_beside(c, g, device, spin) for g in good)
+        except RuntimeError:
+            ok = False
+        (good if ok else rest).append(c)
+    while len(good) < n and rest:                     # fewer independent queues than lanes: the remaining lanes share
+        good.append(rest.pop(0))
+    while len(good) < n:
+        good.append(torch.cuda.Stream(device=device))
+    _lane_cache[key] = good
+    return good[:n]
+
+
 def require_cuda():
     if not torch.cuda.is_available():
         raise _lib.CppfError("cppf_amd needs a HIP device (torch.cuda.is_available() is False); "

@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from . import sharding
+from ._torch_util import copy_words, lane_streams
 from .inference import PoseChain, PosePipeline, assemble_batch, grid_class, grid_shape
 from .utils.util import fibonacci_sphere, num_sphere_bins
 
@@ -312,7 +313,7 @@ class BatchPoseRunner:
         lb["pos"] += 1
         local, read_done = lb["bufs"][which][:max(n, 1)], lb["read"][which]
         if self._streams is None:
-            self._streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_lanes)]
+            self._streams = lane_streams(dev, self.n_lanes)
         main = torch.cuda.current_stream(dev)
         for cat in {objects[j]["cfg"].category for j in mine}:
             if cat in self.encoders:
@@ -369,7 +370,7 @@ class BatchPoseRunner:
         snap = self.__dict__.get("_snap")
         if snap is None or snap[0].shape[0] < n:
             snap = self._snap = (torch.zeros((max(n, 1), sharding.RECORD), dtype=torch.float64).pin_memory(), torch.cuda.Event())
-        snap[0][:n].copy_(local[:n], non_blocking=True)
+        copy_words(snap[0][:n], local[:n], dev)             # (into pinned memory by a kernel: no copy engine in a batch's steady state)
         snap[1].record(main)
         self._pending = ran
         if world == 1 and not (sharding.forced() and sharding.dist.is_initialized()):
@@ -446,7 +447,7 @@ class BatchPoseRunner:
         # n_lanes instances in flight: consecutive instances rotate over the HIP streams, each with its own pipelines
         # (buffers + captured graph), so one instance's head overlaps the previous one's tail
         if self._streams is None:
-            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n_lanes)]
+            self._streams = lane_streams(self.device, self.n_lanes)
         main = torch.cuda.current_stream(self.device)
         # weight images: looked at ONCE per batch, here on the caller's stream, before the lanes fan out -- a parameter update
         # since the last batch is re-packed (in place) now, and every lane's replays are ordered after it by the wait below

@@ -398,6 +398,15 @@ __global__ __launch_bounds__(256) void stage_batch_kernel(StageBatch B)
     }
 }
 
+// cppf_copy_words: a few 64-bit words moved by a kernel of the stream instead of by a copy engine.  hipMemcpyAsync hands small copies to
+// the SDMA engines, whose queues are shared between streams and served in order: a 200-byte descriptor copy of lane 0 then waits
+// behind the caller's stream's read-back, which waits for the previous batch -- a false dependency that (depending on which engine
+// the runtime picked in this process) serialised consecutive batches.  Either pointer may be pinned host memory (device-accessible).
+__global__ __launch_bounds__(256) void copy_words_kernel(unsigned long long* __restrict__ dst, const unsigned long long* __restrict__ src, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 struct VoxLayout { size_t keys, vals, mask, compact, temp, temp_bytes, total; };
 VoxLayout vox_layout(int64_t N)
 {
@@ -559,6 +568,16 @@ int cppf_sample_pairs(long long* idx, float* u_tr, float* u_rot, int64_t n_pairs
     int64_t nb = (n_pairs + 255) / 256;
     if (nb > 4096) nb = 4096;
     sample_pairs_kernel<<<(int)nb, 256, 0, (hipStream_t)stream>>>(idx, u_tr, u_rot, n_pairs, n_points, n_dev, seed, seed_dev);
+    return (int)hipGetLastError();
+}
+
+int cppf_copy_words(void* dst, const void* src, int64_t n_words, void* stream)
+{
+    if (n_words < 0 || (n_words > 0 && (!dst || !src)) || ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 7)) return CPPF_EINVAL;
+    if (n_words == 0) return 0;
+    int64_t nb = (n_words + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    copy_words_kernel<<<(int)nb, 256, 0, (hipStream_t)stream>>>(static_cast<unsigned long long*>(dst), static_cast<const unsigned long long*>(src), n_words);
     return (int)hipGetLastError();
 }
 

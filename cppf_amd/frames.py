@@ -110,7 +110,8 @@ class FrameRunner:
         self._chains, self._seen, self.max_chains = OrderedDict(), {}, max(1, int(max_chains))
         self._many_tile_cats = set()
         self._hw = None
-        self._streams = [torch.cuda.Stream(device=device) for _ in range(self.n_lanes)]
+        from ._torch_util import lane_streams
+        self._streams = lane_streams(device, self.n_lanes)        # (streams that really run beside each other: distinct hardware queues)
         self._slots_host = torch.zeros((32, 2), dtype=torch.int64).pin_memory()    # {label bit, Philox key} per instance of the frame
 
     def _frame_buffers(self, H, W):

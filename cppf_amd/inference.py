@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._torch_util import release_scope, require_cuda, stream_ptr, workspace, workspace_scope
+from ._torch_util import copy_words, release_scope, require_cuda, stream_ptr, workspace, workspace_scope
 from .models import voting
 
 F32, I32 = torch.float32, torch.int32
@@ -912,10 +912,10 @@ class PoseChain:
             feat = o.get("feat") if p.point_encoder is None else None
             words[i] = (o["pc"].data_ptr(), o["normals"].data_ptr(), 0 if feat is None else feat.data_ptr(), o["pc"].shape[0],
                         int(seeds[i]) & 0xFFFFFFFFFFFFFFFF, int(ids[i]))
-        self.desc.copy_(host, non_blocking=True)
+        copy_words(self.desc, host, self.device)          # (kernels, not copy engines: see cppf_copy_words)
         ev.record(torch.cuda.current_stream(self.device))
         self.run_async(None, check_weights, eager=not capture and self._graphs.get(self.full_first, (None, None))[0] is None)
-        rows_out.copy_(self.records[:n] if rows_out.shape[0] == n else self.records[:rows_out.shape[0]], non_blocking=True)
+        copy_words(rows_out, self.records[:rows_out.shape[0]], self.device)
 
     def run_async(self, records_out, check_weights=True, eager=False):
         """Replay the chain and copy every member's 21-double record into records_out[i] (device f64[21]) on the current stream

@@ -695,6 +695,10 @@ typedef struct CppfStageItem {          /* host memory, by value at launch: the 
     float res;
 } CppfStageItem;
 int cppf_stage_batch(int n_items, const CppfStageItem* items_host, void* stream);
+/* n_words 64-bit words from src to dst by a KERNEL of `stream` (8-byte aligned; either side may be pinned host memory, which the device
+ * reads / writes in place).  For the few hundred bytes a batch driver moves per chain -- descriptors in, records out: a copy engine's
+ * queue is shared between streams and in order, so such copies can wait behind another stream's unrelated transfer. */
+int cppf_copy_words(void* dst, const void* src, int64_t n_words, void* stream);
 size_t cppf_backproject_workspace_bytes(int H, int W);
 int cppf_backproject(const void* depth, int depth_is_u16, const uint8_t* mask, int H, int W, const double* kinv_host,
                      double* pts, int32_t* pix, int32_t* count, void* workspace, size_t workspace_bytes, void* stream);

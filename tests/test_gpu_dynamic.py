@@ -276,7 +276,7 @@ def test_tile_capacity_classes(dev):
             assert int(oi) == int(i0) and float(ov) == float(v0), (res, cls)
             assert torch.equal(flat[:G].view(dims), grid) and bool((flat[G:] == -7.0).all()), (res, cls)
         if T > 4:        # one tile short of what the grid needs: refused, nothing written
-            flat = torch.full((T * cells,), 3.0, dtype=F32, device=dev)
+            flat = torch.full(((T - 1) * cells,), 3.0, dtype=F32, device=dev)
             voting.vote_argmax_dyn(pc, outputs, None, idx_d, flat, shape, corner, res, 72, True, oi, ov, many_tiles=T - 1)
             assert int(oi) == -1 and np.isnan(float(ov)) and bool((flat == 3.0).all()), (res, T)
     assert seen == {16, 1}, seen          # 16 tiles at res 2e-3, more at 1.6e-3
