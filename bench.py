@@ -153,11 +153,12 @@ def args_no_overlap(args):
     return bool(getattr(args, "no_overlap_batches", False))
 
 
-def run_c4(dev, rank, world, args, n_objects=64, n_regions=0, host_staged=False):
+def run_c4(dev, rank, world, args, n_objects=64, n_regions=0, host_staged=False, reps_list=None):
     """64 mixed-category objects sharded round-robin over the ranks, full pose per object, ONE gather inside the timed region.
     The objects are uploaded once (BatchPoseRunner.put: SURVEY.md 8d, "inputs already resident on device"); host_staged: every
     batch brings its clouds and features from the host (one pinned copy per object on its lane's stream, BatchPoseRunner._upload):
-    the PCIe-inclusive rate -- never `value` of the default command."""
+    the PCIe-inclusive rate -- never `value` of the default command.  reps_list: also time regions of that many batches each with the
+    same runner -> m["by_reps"] = {batches per region: sorted region seconds} (bench_secondary.py: the share at matched region lengths)."""
     from cppf_amd.batch import BatchPoseRunner
     n_points, k = (args.n_points or 4096), (args.pairs_per_point or 128)
     runner = BatchPoseRunner(c4_encoders(dev), dev, n_lanes=max(1, args.streams), overlap_batches=not args_no_overlap(args),
@@ -196,8 +197,12 @@ def run_c4(dev, rank, world, args, n_objects=64, n_regions=0, host_staged=False)
         regions, recs = timed_regions(region, args, group, dev)
     torch.cuda.synchronize()
     assert recs.shape[0] == n_objects and bool(torch.isfinite(recs[:, :12]).all())
-    return dict(elapsed=regions[len(regions) // 2], regions=regions, reps=reps, n_objects=n_objects, P=n_points * k,
-                n_points=n_points, k=k, recs=recs.cpu().numpy(), own_ms=sorted(own_ms), host_staged=host_staged)
+    by_reps = {}
+    for r_ in reps_list or ():
+        reps = int(r_)                                     # (region() reads `reps`)
+        by_reps[reps] = timed_regions(region, args, group, dev)[0]
+    return dict(elapsed=regions[len(regions) // 2], regions=regions, reps=max(1, args.steps // 8), n_objects=n_objects, P=n_points * k,
+                n_points=n_points, k=k, recs=recs.cpu().numpy(), own_ms=sorted(own_ms), host_staged=host_staged, by_reps=by_reps)
 
 
 def run_c1(args):
@@ -228,12 +233,15 @@ def run_c1(args):
     emit(out, args)
 
 
-def c4_prediction(t64_ms, t8_ms, gather_ms=0.042):
-    """BASELINE.json configs[3] on 8 GPUs from two one-GPU measurements: 64 objects on one GPU against one GPU's share of 8 objects
-    plus the gather (profiles/r4_rccl_w1.txt: 42 us for the all_gather of the records at world 1; latency-bound at any world)"""
-    return {"t64_ms_per_object": t64_ms, "t8_ms_per_object": t8_ms, "gather_ms": gather_ms,
+def c4_prediction(t64_ms, t8_ms, batches_per_region, gather_ms=0.042):
+    """BASELINE.json configs[3] on 8 GPUs from two one-GPU measurements at the SAME number of batches per timed region (the 8-GPU run
+    and the one-GPU run hold --steps / 8 batches between their barriers: 2 at the driver's --steps 20): 64 objects on one GPU against
+    one GPU's share of 8 objects plus the gather (profiles/r4_rccl_w1.txt: 42 us for the all_gather of the records at world 1;
+    latency-bound at any world)"""
+    return {"t64_ms_per_object": t64_ms, "t8_ms_per_object": t8_ms, "batches_per_region": batches_per_region, "gather_ms": gather_ms,
             "speedup_8_gpus": 64 * t64_ms / (8 * t8_ms + gather_ms),
-            "formula": "64 x T64 / (8 x T8 + gather): one GPU's 64-object batch over one GPU's 8-object share + the one collective"}
+            "formula": "64 x T64 / (8 x T8 + gather): one GPU's 64-object batch over one GPU's 8-object share + the one collective "
+                       "per batch, both timed with the same number of batches per region"}
 
 
 def main_c4(args, dev, rank, world, binding):

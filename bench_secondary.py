@@ -424,29 +424,28 @@ def collect(ctx, R):
         args.steps = 8
         args.regions, args.min_seconds = 7, 0.0
 
-        def c4_entry(n_obj, host_staged, what, reps=4):
-            """regions of `reps` batches back to back (the 8-GPU run's regions hold --steps / 8 batches: the chains of a batch start
-            while the previous one's drain) and, beside it, of ONE batch from an idle device to the last record"""
-            args.steps = 8 * reps
-            m4 = run_c4(dev, rank, world, args, n_objects=n_obj, host_staged=host_staged)
+        def c4_entry(n_obj, host_staged, what, reps_list=(2, 1, 8)):
+            """one runner, regions of 2 batches back to back (what --steps 20 gives the 8-GPU run: the chains of a batch start while
+            the previous one's drain), of ONE batch from an idle device to the last record, and of 8 (the pipelined rate)"""
+            args.steps = 8 * reps_list[0]
+            m4 = run_c4(dev, rank, world, args, n_objects=n_obj, host_staged=host_staged, reps_list=reps_list[1:])
             per = m4["reps"] * n_obj
             span = m4["own_ms"][len(m4["own_ms"]) // 2] / per if m4["own_ms"] else None     # region start -> the rank's chains joined, HIP events
-            entry = {"workload": what + f"; median of 7 regions of {reps} batches", "ms_per_object": m4["elapsed"] / per * 1e3,
-                     "device_span_ms_per_object": span,
+            entry = {"workload": what + f"; median of 7 regions of {reps_list[0]} batches", "batches_per_region": reps_list[0],
+                     "ms_per_object": m4["elapsed"] / per * 1e3, "device_span_ms_per_object": span,
                      "ms_per_object_min_max": [m4["regions"][0] / per * 1e3, m4["regions"][-1] / per * 1e3],
                      "pairs_per_s": per * m4["P"] / m4["elapsed"]}
-            if reps > 1 and n_obj <= 8:
-                args.steps = 8
-                m1 = run_c4(dev, rank, world, args, n_objects=n_obj, host_staged=host_staged)
-                entry["ms_per_object_one_batch_from_idle"] = m1["elapsed"] / n_obj * 1e3
+            for r_, regs in m4["by_reps"].items():
+                key = "ms_per_object_one_batch_from_idle" if r_ == 1 else f"ms_per_object_{r_}_batches_per_region"
+                entry[key] = regs[len(regs) // 2] / (r_ * n_obj) * 1e3
             return entry
         mixed = " mixed-category objects (N=4096 K=128), full pose each, BatchPoseRunner, pairs drawn on the device, "
         other["c4_one_gpu_share"] = c4_entry(8, False, "8" + mixed + "objects resident on the device (put()), records assembled on "
                                              "the device, no read-back in the batch")
         other["c4_one_gpu_share_host_staged"] = c4_entry(8, True, "8" + mixed + "clouds and features sent from pinned host memory "
                                                          "per batch (the PCIe-inclusive rate; round 5: 0.193)")
-        other["c4_whole_batch_one_gpu"] = c4_entry(64, False, "64" + mixed + "objects resident on the device", reps=1)
-        c4_pred = ctx.c4_prediction(other["c4_whole_batch_one_gpu"]["ms_per_object"], other["c4_one_gpu_share"]["ms_per_object"])
+        other["c4_whole_batch_one_gpu"] = c4_entry(64, False, "64" + mixed + "objects resident on the device", reps_list=(2, 1))
+        c4_pred = ctx.c4_prediction(other["c4_whole_batch_one_gpu"]["ms_per_object"], other["c4_one_gpu_share"]["ms_per_object"], 2)
         args.steps = keep[0]
         args.regions, args.min_seconds = keep_r
 
