@@ -372,14 +372,17 @@ def compact(out):
                                    "vs_baseline", "dtype", "data") if k_ in out}
     cfg = dict(out["config"])
     if len(cfg.get("workload", "")) > 300:
-        cfg["workload"] = cfg["workload"][:240] + " ... (full text: bench_full.json)"
+        cfg["workload"] = cfg["workload"][:150] + " ... (full text: bench_full.json)"
     line["config"] = cfg
     for k_ in ("pairs_per_ms_per_gpu", "regions", "region_ms_min_max", "median_ms_one_instance", "vote_workgroups", "mlp_batch",
                "vote_batch", "vote_batch_workgroups", "vote_batch_calibration_ms_per_step", "dist", "cpu_binding", "argmax_matches_oracle",
                "argmax_objects_matching_oracle", "argmax_steps_matching_oracle", "argmax_objects_matching_oracle_per_rank",
-               "records_matching_oracle", "objects_checked", "objects_per_s", "c4_strong_scaling_predicted"):
+               "records_matching_oracle", "objects_checked", "objects_per_s"):
         if k_ in out:
             line[k_] = out[k_]
+    if out.get("c4_strong_scaling_predicted"):
+        line["c4_strong_scaling_predicted"] = pick(out["c4_strong_scaling_predicted"],
+                                                   ("t64_ms_per_object", "t8_ms_per_object", "batches_per_region", "speedup_8_gpus"))
     line["roofline"] = pick(out.get("roofline"), ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_ms",
                                                   "lists_per_launch",
                                                   "executed_flop_per_pair"))
@@ -394,12 +397,13 @@ def compact(out):
             line["roofline_vote"]["traffic_timed_regions"] = pick(rv["traffic_timed_regions"], ("bytes", "ratio"))
     cb = out.get("cpu_baseline")
     if cb is not None:
-        line["cpu_baseline"] = pick(cb, ("value", "best", "unit", "cores", "kind", "spread", "passes", "omp_binding", "physical_cores",
+        line["cpu_baseline"] = pick(cb, ("value", "best", "unit", "cores", "kind", "spread", "passes", "physical_cores",
                                          "host_threads_available"))
-        line["cpu_baseline"]["sample"] = cb["sample"][:100] + " ..."
+        line["cpu_baseline"]["bound"] = bool((cb.get("omp_binding") or {}).get("OMP_PROC_BIND"))      # threads bound close to cores?
+        line["cpu_baseline"]["sample"] = cb["sample"][:60] + " ..."
         line["cpu_baseline"]["sweep_Mpairs_per_s"] = {str(e["threads"]): round(e["pairs_per_s"] / 1e6, 2) for e in cb.get("sweep", [])}
         if cb.get("other_binding"):
-            line["cpu_baseline"]["other_binding"] = pick(cb["other_binding"], ("value", "cores", "omp_binding"))
+            line["cpu_baseline"]["other_binding"] = pick(cb["other_binding"], ("value", "cores"))
         if cb.get("c1"):
             line["cpu_baseline"]["c1"] = pick(cb["c1"], ("value", "unit", "best_threads"))
     tr = out.get("trained_regime")
