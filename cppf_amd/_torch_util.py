@@ -67,7 +67,7 @@ def lane_streams(device, n):
         try:
             # (the caller's stream must not be stuck behind a lane either: its joins and the records' hand-over live there)
             ok = _runs_beside(c, main, device, spin) and all(_runs_beside(g, c, device, spin) and _runs_beside(c, g, device, spin) for g in good)
-        except RuntimeError:
+        except (RuntimeError, AttributeError):       # (no spin kernel in this torch build, a probe disturbed: take the stream as it is)
             ok = False
         (good if ok else rest).append(c)
     while len(good) < n and rest:                     # fewer independent queues than lanes: the remaining lanes share
