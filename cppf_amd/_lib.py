@@ -132,7 +132,7 @@ class StageItem(C.Structure):
     {pc_src, nrm_src, feat_src, n_points, seed, object_id}"""
     _fields_ = [("desc", C.c_void_p), ("pc", C.c_void_p), ("nrm", C.c_void_p), ("feat", C.c_void_p), ("corner", C.c_void_p),
                 ("shape", C.c_void_p), ("idx", C.c_void_p), ("u_tr", C.c_void_p), ("u_rot", C.c_void_p), ("n_pairs", C.c_int64),
-                ("n_cap", C.c_int64), ("F", C.c_int), ("res", C.c_float)]
+                ("n_cap", C.c_int64), ("F", C.c_int), ("res", C.c_float), ("idx_is_i64", C.c_int)]
 
 
 STAGE_DESC_WORDS = 6

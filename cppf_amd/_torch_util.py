@@ -53,6 +53,9 @@ def lane_streams(device, n):
     device and caller stream; as many as the queues allow, the rest filled with whatever is left).  The caller's stream is tested one
     way only -- its work must not queue behind a lane's; nothing runs beside a kernel of the legacy default stream in this probe."""
     require_cuda()
+    import os
+    if os.environ.get("CPPF_NO_LANE_PROBE"):          # (development knob: plain pool streams, whatever queues they got)
+        return [torch.cuda.Stream(device=device) for _ in range(n)]
     main = torch.cuda.current_stream(device)
     key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), main.cuda_stream)
     have = _lane_cache.setdefault(key, [])

@@ -31,7 +31,7 @@ class BatchPoseRunner:
     def __init__(self, encoders, device, num_rots=72, adaptive=True, angle_tol=1.5, max_rot_pairs=10000,
                  use_graph=True, point_encoders=None, n_bucket=1024, max_pipelines=192, dynamic=True, n_lanes=3,
                  max_scratch_bytes=64 << 30, vote_workgroups=None, chain_len=None, max_chains=24, staged_host=True,
-                 overlap_batches=False):
+                 overlap_batches=False, idx_i32=True):
         """encoders: {category name: PPFEncoder on `device`} (the reference keeps one per category,
         nocs/inference.py:79-90).  point_encoders: optional {category name: PointEncoder}; objects of those
         categories need no `feat` -- kNN + SPRIN run at the head of the captured graph (:180-181).
@@ -66,7 +66,8 @@ class BatchPoseRunner:
         includes the previous batch's join: lane 0 then starts batch k + 1 while lane 1 still finishes batch k (records are
         double-buffered).  The contract that buys it: objects returned by put() are snapshots -- work the caller enqueues on its
         stream AFTER put() that rewrites them in place is not waited for.  (Host arrays are copied at call time, so their batches
-        overlap regardless.)  The records run() returns are ordered on the caller's stream as always.  Measured: 8 resident C2-size
+        overlap regardless.)  The records run() returns are ordered on the caller's stream as always.  idx_i32: the pair lists a staged chain draws are int32 (half the index bytes through every kernel of the
+        chain; the draws are the same numbers).  Measured: 8 resident C2-size
         objects 0.140 -> 0.129 ms per object, 64: 0.121 -> 0.118; from host arrays 0.149 -> 0.135 (profiles/r6_resident_probe.txt)."""
         self.encoders, self.device = encoders, device
         self.point_encoders = point_encoders or {}
@@ -81,20 +82,21 @@ class BatchPoseRunner:
         self._chains, self._chain_seen = OrderedDict(), {}     # LRU: tuple of member ids -> PoseChain; sightings of a combination
         self._pipes = OrderedDict()    # LRU: key -> PosePipeline
         self._staging = {}         # pinned host staging sets for the small per-instance arrays, see _stage()
-        self.staged_host, self.overlap_batches = bool(staged_host), bool(overlap_batches)
+        self.staged_host, self.overlap_batches, self.idx_i32 = bool(staged_host), bool(overlap_batches), bool(idx_i32)
         self._stage_pos = 0
         self._streams = None
 
     # ------------------------------------------------------------------ pipeline cache
-    def _pipe(self, cfg, n_points, n_pairs, dims, lane=0, slot=0):
-        """The pipeline that serves this instance shape at position `slot` of a chain on this lane (created on first use, LRU-bounded)."""
+    def _pipe(self, cfg, n_points, n_pairs, dims, lane=0, slot=0, idx_i32=False):
+        """The pipeline that serves this instance shape at position `slot` of a chain on this lane (created on first use, LRU-bounded).
+        idx_i32: its pair list is int32 (staged chains, whose pairs are drawn on the device)."""
         T, many, _ = grid_class(dims)
         dyn = self.dynamic and T > 0
         if dyn:
             n_cap = -(-int(n_points) // self.n_bucket) * self.n_bucket
-            key = (cfg.category, n_cap, n_pairs, many, lane, slot)
+            key = (cfg.category, n_cap, n_pairs, many, lane, slot, idx_i32)
         else:
-            key = (cfg.category, n_points, n_pairs, tuple(dims), lane, slot)
+            key = (cfg.category, n_points, n_pairs, tuple(dims), lane, slot, idx_i32)
         pipe = self._pipes.get(key)
         if pipe is None:
             need = self.footprint_bytes(n_cap if dyn else n_points, n_pairs, many if dyn else None, dims)
@@ -113,15 +115,28 @@ class BatchPoseRunner:
                 width = 128 if (self.n_lanes > 1 and few and n_pairs <= (1 << 19)) else 0
             if dyn:
                 pipe = PosePipeline(self.encoders[cfg.category], cfg, n_cap, n_pairs, many, self.device, self.sphere,
-                                    point_encoder=self.point_encoders.get(cfg.category), dynamic=True, vote_workgroups=width, **self.kw)
+                                    point_encoder=self.point_encoders.get(cfg.category), dynamic=True, vote_workgroups=width,
+                                    idx_i32=idx_i32, **self.kw)
             else:
                 pipe = PosePipeline(self.encoders[cfg.category], cfg, n_points, n_pairs, dims, self.device,
-                                    self.sphere, point_encoder=self.point_encoders.get(cfg.category), vote_workgroups=width, **self.kw)
+                                    self.sphere, point_encoder=self.point_encoders.get(cfg.category), vote_workgroups=width,
+                                    idx_i32=idx_i32, **self.kw)
             self._pipes[key] = pipe
             self._bytes[key] = need
         else:
             self._pipes.move_to_end(key)
         return pipe
+
+    def _lanes(self):
+        """(the lanes' streams, the upload stream): streams that run beside each other (lane_streams: distinct hardware queues).  The
+        queues are few (4 besides the caller's), so the upload stream is picked right after the first two lanes -- small batches run on
+        two lanes, and an upload stream that shares a lane's queue parks its wait for an older batch in front of that lane's chains
+        (the reference-default batch from host arrays: 0.164 against 0.140 ms per instance)."""
+        if self.__dict__.get("_lane_set") is None:
+            s = lane_streams(self.device, self.n_lanes + 1)
+            k = min(2, self.n_lanes)
+            self._lane_set = (s[:k] + s[k + 1:], s[k])
+        return self._lane_set
 
     def _chain_for(self, pipes, staged=False):
         """the captured chain of these pipelines, or None (a single instance; a member the chain cannot take; a combination seen for
@@ -269,7 +284,7 @@ class BatchPoseRunner:
             if st is not None:
                 torch.cuda.synchronize(dev)
             words = max(total, 1 << 16) * 5 // 4
-            st = self._up = dict(words=words, pos=0, stream=(st or {}).get("stream") or torch.cuda.Stream(device=dev), blocks=[])
+            st = self._up = dict(words=words, pos=0, stream=(st or {}).get("stream") or self._lanes()[1], blocks=[])
             for _ in range(2):
                 h = torch.empty(words, dtype=torch.float32).pin_memory()
                 st["blocks"].append(dict(host=h, arr=h.numpy(), dev=torch.empty(words, dtype=torch.float32, device=dev),
@@ -313,7 +328,7 @@ class BatchPoseRunner:
         lb["pos"] += 1
         local, read_done = lb["bufs"][which][:max(n, 1)], lb["read"][which]
         if self._streams is None:
-            self._streams = lane_streams(dev, self.n_lanes)
+            self._streams = self._lanes()[0]
         main = torch.cuda.current_stream(dev)
         for cat in {objects[j]["cfg"].category for j in mine}:
             if cat in self.encoders:
@@ -350,7 +365,7 @@ class BatchPoseRunner:
                 pipes, objs = [], []
                 for q, slot in enumerate(slots):
                     obj = objects[mine[slot]]
-                    pipe = self._pipe(obj["cfg"], obj["pc"].shape[0], int(obj["n_pairs"]), obj["dims"], lane, q)
+                    pipe = self._pipe(obj["cfg"], obj["pc"].shape[0], int(obj["n_pairs"]), obj["dims"], lane, q, idx_i32=self.idx_i32)
                     if pipe.dynamic:
                         pipe.set_shape(obj["pc"].shape[0], obj["dims"], upload=False)      # (capacity check + host bookkeeping)
                     elif obj["pc"].shape[0] != pipe.n_points or tuple(obj["dims"]) != tuple(pipe.dims):
@@ -404,7 +419,8 @@ class BatchPoseRunner:
         host = self._snap[0].numpy()
         if np.any(host[[s for _, slots in ran for s in slots], 12] < 0):
             self._pending = None
-            raise RuntimeError("an instance of the last batch did not fit the shape-polymorphic pipeline it ran on (arg-max index -1)")
+            from ._lib import CppfError
+            raise CppfError("an instance of the last batch did not fit the shape-polymorphic pipeline it ran on (arg-max index -1)")
         for chain, slots in ran:
             chain.adapt([host[s, 14] for s in slots])
         self._pending = None
@@ -447,7 +463,7 @@ class BatchPoseRunner:
         # n_lanes instances in flight: consecutive instances rotate over the HIP streams, each with its own pipelines
         # (buffers + captured graph), so one instance's head overlaps the previous one's tail
         if self._streams is None:
-            self._streams = lane_streams(self.device, self.n_lanes)
+            self._streams = self._lanes()[0]
         main = torch.cuda.current_stream(self.device)
         # weight images: looked at ONCE per batch, here on the caller's stream, before the lanes fan out -- a parameter update
         # since the last batch is re-packed (in place) now, and every lane's replays are ordered after it by the wait below

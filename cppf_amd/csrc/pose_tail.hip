@@ -1226,8 +1226,9 @@ __global__ void tail_begin_batch_kernel(TailBatch B)
 __global__ __launch_bounds__(256) void backvote_batch_kernel(TailBatch B)
 {
     const TailItem& I = B.item[blockIdx.y];
-    backvote_body(I.points, I.outputs, nullptr, nullptr, I.corner, I.res, I.n_ppfs, B.n_rots, I.gx, I.gy, I.gz, I.T32, I.tol, I.mask, I.shape,
-                  I.vote_ws, I.chunk_counts, I.idx64, I.idx32);
+    // (idx64 null: the pair list was drawn as int32 -- idx32 is the input, nothing to convert)
+    backvote_body(I.points, I.outputs, nullptr, I.idx64 ? nullptr : I.idx32, I.corner, I.res, I.n_ppfs, B.n_rots, I.gx, I.gy, I.gz, I.T32, I.tol,
+                  I.mask, I.shape, I.vote_ws, I.chunk_counts, I.idx64, I.idx64 ? I.idx32 : nullptr);
 }
 __global__ __launch_bounds__(CMP_BLOCK) void compact_scatter_batch_kernel(TailBatch B)
 {
@@ -1261,7 +1262,7 @@ extern "C" int cppf_pose_tail_batch(int n_items, const CppfPoseTailItem* items, 
     int64_t bv_blocks = 1, cmp_blocks = 1, rot_blocks = 1;
     for (int i = 0; i < n_items; ++i) {
         const CppfPoseTailItem& it = items[i];
-        if (!it.pc || !it.nrm || !it.idx64 || !it.idx32 || !it.outputs || !it.heads || !it.corner || !it.argmax_idx || !it.rec || !it.T32 ||
+        if (!it.pc || !it.nrm || !it.idx32 || !it.outputs || !it.heads || !it.corner || !it.argmax_idx || !it.rec || !it.T32 ||
             !it.mask || !it.chunk_counts || !it.surv || !it.count || !it.counts || !it.ticket || !it.sums_workspace)
             return CPPF_EINVAL;
         if (it.n_pairs < 1 || it.n_pairs > 8192ll * CMP_BLOCK || it.n_points < 1 || it.n_dirs < 1 || it.n_dirs > PS_MAX_DIRS) return CPPF_EINVAL;
@@ -1300,9 +1301,10 @@ extern "C" int cppf_pose_tail_batch(int n_items, const CppfPoseTailItem* items, 
             if (!it.feat || !it.packed || !it.u_rot || !it.mlp_workspace) return CPPF_EINVAL;
             CppfPairMlpItem& M = sel_items[n_second++];
             M = CppfPairMlpItem{};
-            M.pc = it.pc; M.nrm = it.nrm; M.feat = it.feat; M.idxs = it.idx64; M.packed = it.packed; M.u_rot = it.u_rot; M.heads = it.heads;
+            M.pc = it.pc; M.nrm = it.nrm; M.feat = it.feat; M.idxs = it.idx64 ? (const void*)it.idx64 : (const void*)it.idx32;
+            M.packed = it.packed; M.u_rot = it.u_rot; M.heads = it.heads;
             M.workspace = it.mlp_workspace; M.workspace_bytes = it.mlp_workspace_bytes; M.n_points = it.n_points; M.n_pairs = it.n_pairs;
-            M.idx_is_i64 = 1; M.sel = it.surv; M.n_sel_dev = it.count; M.max_sel = it.n_pairs;
+            M.idx_is_i64 = it.idx64 ? 1 : 0; M.sel = it.surv; M.n_sel_dev = it.count; M.max_sel = it.n_pairs;
         }
     }
     // 1. T = corner + unravel(arg-max) * res (:209-210); zeroes the record, the bin counts, the chunk counts and the tickets

@@ -391,8 +391,9 @@ __global__ __launch_bounds__(256) void stage_batch_kernel(StageBatch B)
     for (int64_t p = first; p < I.n_pairs; p += step) {
         const uint4 a = philox4x32_10(make_uint4((unsigned)p, (unsigned)(p >> 32), 0u, 0u), key);
         const uint4 b = philox4x32_10(make_uint4((unsigned)p, (unsigned)(p >> 32), 1u, 0u), key);
-        reinterpret_cast<longlong2*>(I.idx)[p] = make_longlong2((long long)(((unsigned long long)a.x * Nu) >> 32),
-                                                                (long long)(((unsigned long long)a.y * Nu) >> 32));
+        const unsigned long long i0 = ((unsigned long long)a.x * Nu) >> 32, i1 = ((unsigned long long)a.y * Nu) >> 32;
+        if (I.idx_is_i64) reinterpret_cast<longlong2*>(I.idx)[p] = make_longlong2((long long)i0, (long long)i1);
+        else reinterpret_cast<int2*>(I.idx)[p] = make_int2((int)i0, (int)i1);
         if (I.u_tr) reinterpret_cast<float2*>(I.u_tr)[p] = make_float2((float)(a.z >> 8) * 0x1p-24f, (float)(a.w >> 8) * 0x1p-24f);
         if (I.u_rot) reinterpret_cast<float2*>(I.u_rot)[p] = make_float2((float)(b.x >> 8) * 0x1p-24f, (float)(b.y >> 8) * 0x1p-24f);
     }
@@ -589,7 +590,7 @@ int cppf_stage_batch(int n_items, const CppfStageItem* items, void* stream)
     for (int i = 0; i < n_items; ++i) {
         const CppfStageItem& it = items[i];
         if (!it.desc || !it.pc || !it.nrm || !it.corner || it.n_cap < 1 || it.n_cap > 0x7fffffffll || it.n_pairs < 0 || !(it.res > 0.f) ||
-            (it.feat && it.F < 1) || (it.n_pairs > 0 && it.idx && (reinterpret_cast<uintptr_t>(it.idx) & 15)))
+            (it.feat && it.F < 1) || (it.n_pairs > 0 && it.idx && (reinterpret_cast<uintptr_t>(it.idx) & (it.idx_is_i64 ? 15 : 7))))
             return CPPF_EINVAL;
         B.item[i] = it;
         if (it.idx && it.n_pairs > max_pairs) max_pairs = it.n_pairs;

@@ -134,7 +134,8 @@ def grid_class(dims):
     if hit is None:
         L = _lib.lib()
         T = int(L.cppf_vote_tiles(*key))
-        many = 0 if T < 4 else (16 if T <= 16 else 1)
+        import os
+        many = 0 if T < 4 else (16 if T <= 16 and not os.environ.get("CPPF_TILE_CLASS_64") else 1)
         hit = (T, many, _lib.tiles_cap(many) * int(L.cppf_vote_tile_cells()))
         if len(_grid_class_cache) < 4096:
             _grid_class_cache[key] = hit
@@ -165,10 +166,13 @@ class CenterPipeline:
     is re-packed into the same device buffer, which the captured launches read; a moved / resized image re-captures."""
 
     def __init__(self, encoder, cfg, n_points, n_pairs, dims, device, num_rots=72, adaptive=True, with_heads=True,
-                 use_graph=True, point_encoder=None, dynamic=False, vote_workgroups=0):
+                 use_graph=True, point_encoder=None, dynamic=False, vote_workgroups=0, idx_i32=False):
         """vote_workgroups: 0 = the vote launches one workgroup per CU (fastest for ONE instance on an idle chip); 64..256 = at
         most that many (cppf.h: CPPF_VOTE_WORKGROUPS) -- for callers that keep several pipelines in flight on different streams,
-        where fewer, longer-lived vote workgroups leave the rest of the chip to the other streams (bench.py, BatchPoseRunner)."""
+        where fewer, longer-lived vote workgroups leave the rest of the chip to the other streams (bench.py, BatchPoseRunner).
+        idx_i32: the pipeline's pair list is int32[P,2] instead of the reference's int64 (nocs/inference.py:177) -- for lists that are
+        drawn on the device (a staged chain: cppf_stage_batch) every kernel that streams the list moves half the index bytes, and
+        the tail needs no int32 copy; a host list loaded into it is narrowed (indices are < n_points)."""
         require_cuda()
         self.vote_workgroups = int(vote_workgroups or 0)
         self.encoder, self.cfg, self.device = encoder, cfg, device
@@ -183,8 +187,8 @@ class CenterPipeline:
         self._in = z(6 * n + 8)
         self.pc, self.nrm = self._in[:3 * n].view(n, 3), self._in[3 * n:6 * n].view(n, 3)
         self.feat = z(n_points, F)
-        self.idx = z(n_pairs, 2, dtype=torch.int64)
-        self.idx32 = z(n_pairs, 2, dtype=I32)
+        self.idx = z(n_pairs, 2, dtype=I32 if idx_i32 else torch.int64)
+        self.idx32 = self.idx if idx_i32 else z(n_pairs, 2, dtype=I32)
         self._u = z(2, n_pairs, 2)                     # one buffer: device-side sampling fills both with one launch
         self.u_tr, self.u_rot = self._u[0], self._u[1]
         self.corner = self._in[6 * n:6 * n + 3]
@@ -666,12 +670,12 @@ class PosePipeline(CenterPipeline):
 
     def __init__(self, encoder, cfg, n_points, n_pairs, dims, device, sphere_pts, num_rots=72, adaptive=True,
                  angle_tol=1.5, max_rot_pairs=10000, use_graph=True, point_encoder=None, dynamic=False, rot_order_len=0,
-                 vote_workgroups=0):
+                 vote_workgroups=0, idx_i32=False):
         """rot_order_len > 0: the pipeline owns a static i32[rot_order_len] buffer `rot_order` (positions in the survivor
         list, see estimate_pose) that the captured orientation vote reads -- fill it before run() to reproduce the reference's
         shuffled subsample (nocs/inference.py:277-280); it starts as 0, 1, 2, ... (= the first survivors)."""
         super().__init__(encoder, cfg, n_points, n_pairs, dims, device, num_rots, adaptive, False, use_graph, point_encoder,
-                         dynamic, vote_workgroups)
+                         dynamic, vote_workgroups, idx_i32)
         self.rot_order = (torch.arange(int(rot_order_len), dtype=I32, device=device) if rot_order_len else None)
         sph64 = np.asarray(sphere_pts, dtype=np.float64)
         self.ws = PoseWorkspace(device, n_pairs, self.dims, sph64.shape[0], grid=self.grid_flat if self.dynamic else self.grid)
@@ -724,7 +728,8 @@ class PosePipeline(CenterPipeline):
                       self.dims, self.num_rots, self.angle_tol, self.max_rot_pairs, *self._sph,
                       shape=self.shape if self.dynamic else None,
                       second_pass=None if self.full_first else (self.encoder, self.feat, self.idx, self.u_rot),
-                      idx64=self.idx,             # the tail's kernels take int32 indices: written by the back-vote launch
+                      idx64=self.idx if self.idx.dtype == torch.int64 else None,   # the tail's kernels take int32 indices: written
+                                                                                  # by the back-vote launch unless the list is int32 already
                       rot_order=self.rot_order)
 
     def run(self, rng=None, check_weights=True):
@@ -747,6 +752,8 @@ class PosePipeline(CenterPipeline):
         One launch (cppf_sample_pairs: Philox keyed by `seed`, counter = pair index; a torch.Generator is accepted for its
         initial_seed()): 6 us where torch's two generator kernels took 38.  Same distribution as the reference's draws, not the
         same stream of numbers -- parity tests pass explicit arrays."""
+        if self.idx.dtype != torch.int64:
+            raise _lib.CppfError("sample_inputs() draws int64 pair lists (cppf_sample_pairs); an int32 pipeline is filled by a staged chain")
         n = self.shape_host[0] if self.dynamic else self.pc.shape[0]
         n = int(n_points) if n_points is not None else n
         if isinstance(seed, torch.Generator):
@@ -824,6 +831,7 @@ class PoseChain:
             a.shape = p.shape.data_ptr() if p.dynamic else None
             a.idx, a.u_tr, a.u_rot = p.idx.data_ptr(), p.u_tr.data_ptr(), p.u_rot.data_ptr()
             a.n_pairs, a.n_cap, a.F, a.res = p.idx.shape[0], p.pc.shape[0], p.feat.shape[1], float(np.float32(p.cfg.res))
+            a.idx_is_i64 = 1 if p.idx.dtype == torch.int64 else 0
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().cppf_stage_batch(len(pipes), arr, stream_ptr(self.device)), "cppf_stage_batch")
 
@@ -869,7 +877,8 @@ class PoseChain:
             ws, a = p.ws, arr[i]
             pws = workspace(L.cppf_pose_sums_workspace_bytes(), self.device, f"pose_sums{i}")
             packed = p.encoder._packed_weights(self.device)
-            a.pc, a.nrm, a.feat, a.idx64, a.idx32 = p.pc.data_ptr(), p.nrm.data_ptr(), feats[i].data_ptr(), p.idx.data_ptr(), p.idx32.data_ptr()
+            a.pc, a.nrm, a.feat, a.idx32 = p.pc.data_ptr(), p.nrm.data_ptr(), feats[i].data_ptr(), p.idx32.data_ptr()
+            a.idx64 = p.idx.data_ptr() if p.idx.dtype == torch.int64 else None          # (None: the list is int32, idx32 is the input)
             a.outputs, a.u_rot, a.heads, a.corner = outputs[i].data_ptr(), p.u_rot.data_ptr(), heads[i].data_ptr(), p.corner.data_ptr()
             a.shape_dev = p.shape.data_ptr() if p.dynamic else None
             a.argmax_idx, a.peak = p.out_idx.data_ptr(), p.out_val.data_ptr()
@@ -910,6 +919,11 @@ class PoseChain:
         ev.synchronize()
         for i, (o, p) in enumerate(zip(objs, self.pipes)):
             feat = o.get("feat") if p.point_encoder is None else None
+            if feat is None and p.point_encoder is None:
+                raise ValueError(f"member {i}: no `feat` and no point encoder in its pipeline (the chain would reuse the last object's features)")
+            if o["pc"].shape[0] > p.pc.shape[0] or (feat is not None and feat.shape != (o["pc"].shape[0], p.feat.shape[1])):
+                raise ValueError(f"member {i}: cloud of {o['pc'].shape[0]} points / features {None if feat is None else tuple(feat.shape)} "
+                                 f"do not fit a pipeline of {p.pc.shape[0]} x {p.feat.shape[1]}")
             words[i] = (o["pc"].data_ptr(), o["normals"].data_ptr(), 0 if feat is None else feat.data_ptr(), o["pc"].shape[0],
                         int(seeds[i]) & 0xFFFFFFFFFFFFFFFF, int(ids[i]))
         copy_words(self.desc, host, self.device)          # (kernels, not copy engines: see cppf_copy_words)

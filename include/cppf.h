@@ -164,7 +164,8 @@ int cppf_counts_argmax_select(const int32_t* counts, int n, const double* sphere
  * column: fibonacci_sphere; sphere_sorted_by_y = +1 descending / -1 ascending), thr = cos(angle_tol), max_rot_pairs (:277-280). */
 typedef struct CppfPoseTailItem {
     const float* pc; const float* nrm; const float* feat;          /* device f32[n_points,3], f32[n_points,3], f32[n_points,F] */
-    const long long* idx64; int32_t* idx32;                         /* pair list i64[n_pairs,2]; its i32 copy (OUTPUT of launch 2) */
+    const long long* idx64; int32_t* idx32;                         /* pair list i64[n_pairs,2]; its i32 copy (OUTPUT of launch 2).  idx64 NULL:
+                                                                     * the list IS idx32 (an INPUT: drawn as int32, cppf_stage_batch) */
     const float* outputs; const float* u_rot; float* heads;         /* (mu, nu) f32[n_pairs,2]; uniforms f32[n_pairs,2]; see above */
     const float* corner; const int32_t* shape_dev;                  /* f32[3]; NULL (dims by value) or device i32[4] {n_points, gx, gy, gz} */
     const long long* argmax_idx; const float* peak;                 /* the vote's outputs */
@@ -688,11 +689,13 @@ typedef struct CppfStageItem {          /* host memory, by value at launch: the 
     float* pc; float* nrm; float* feat; /* device f32[n_cap,3], f32[n_cap,3], f32[n_cap,F] (feat NULL: not copied) */
     float* corner;                      /* device f32[3] */
     int32_t* shape;                     /* device i32[4] <- {n_points, gx, gy, gz}, or NULL (a static-shape pipeline: only `corner` is written) */
-    long long* idx;                     /* device i64[n_pairs,2] or NULL (no draw) */
+    void* idx;                          /* device i64[n_pairs,2] (idx_is_i64) or i32[n_pairs,2], or NULL (no draw) */
     float* u_tr; float* u_rot;          /* device f32[n_pairs,2] each; either may be NULL */
     int64_t n_pairs, n_cap;
     int F;
     float res;
+    int idx_is_i64;                     /* 1: the reference's int64 pair list (nocs/inference.py:177); 0: int32 -- half the index bytes for
+                                         * every kernel of the chain that streams the list (the values are < n_points < 2^31 either way) */
 } CppfStageItem;
 int cppf_stage_batch(int n_items, const CppfStageItem* items_host, void* stream);
 /* n_words 64-bit words from src to dst by a KERNEL of `stream` (8-byte aligned; either side may be pinned host memory, which the device

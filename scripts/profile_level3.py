@@ -28,7 +28,7 @@ if mode == "level3":
     robjs = [syn.make_posed_object(cats[j % 3], n_j, 910000 + j) for j, n_j in enumerate(sizes)]
     batch = [dict(pc=o["pc"], normals=o["normals"], cfg=o["cfg"], n_pairs=100000) for o in robjs]
     runner = BatchPoseRunner({c: nets[c][1] for c in cats}, dev, point_encoders={c: nets[c][0] for c in cats}, n_lanes=lanes, chain_len=cl,
-                             overlap_batches=bool(os.environ.get("OVERLAP")))
+                             overlap_batches=bool(os.environ.get("OVERLAP")), idx_i32=not os.environ.get("IDX64"))
 else:
     encs = {}
     for i, c in enumerate(NOCS_CATEGORIES):
@@ -36,7 +36,7 @@ else:
         cfg = syn.make_object(c, 8, 0)["cfg"]
         encs[c] = PPFEncoder(cfg.ppffcs, cfg.out_dim).eval().to(dev)
     batch = bench.c4_objects(int(os.environ.get("OBJECTS", "8")), 4096, 128)
-    runner = BatchPoseRunner(encs, dev, n_lanes=lanes, chain_len=cl, overlap_batches=bool(os.environ.get("OVERLAP")))
+    runner = BatchPoseRunner(encs, dev, n_lanes=lanes, chain_len=cl, overlap_batches=bool(os.environ.get("OVERLAP")), idx_i32=not os.environ.get("IDX64"))
 if os.environ.get("RESIDENT"):
     batch = runner.put(batch)
 for _ in range(8):

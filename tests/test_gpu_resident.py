@@ -32,7 +32,7 @@ def draw(dev, seed, n_pairs, n_points):
 
 def test_stage_batch_equals_the_single_calls(dev):
     """ragged clouds (one of a single point, one filling its buffer), with and without features, a static-shape member (no shape
-    record), a member that draws nothing"""
+    record), a member that draws nothing, int64 and int32 pair lists (the same numbers)"""
     L = _lib.lib()
     rng = np.random.default_rng(5)
     specs = [(1000, 1024, 4099, 40, True), (1, 64, 77, 40, True), (2048, 2048, 100000, 8, True), (333, 1024, 0, 40, True),
@@ -49,7 +49,8 @@ def test_stage_batch_equals_the_single_calls(dev):
         src = [torch.from_numpy(a).to(dev) if a is not None else None for a in (pc, nrm, feat)]
         dst = dict(pc=torch.full((cap, 3), 7.0, device=dev), nrm=torch.full((cap, 3), 7.0, device=dev),
                    feat=torch.full((cap, F), 7.0, device=dev), corner=torch.zeros(3, device=dev),
-                   shape=torch.full((4,), -5, dtype=torch.int32, device=dev), idx=torch.full((max(P, 1), 2), -1, dtype=torch.int64, device=dev),
+                   shape=torch.full((4,), -5, dtype=torch.int32, device=dev),
+                   idx=torch.full((max(P, 1), 2), -1, dtype=torch.int32 if i == 4 else torch.int64, device=dev),
                    u=torch.full((2, max(P, 1), 2), -1.0, device=dev))
         seed = 0xFEDCBA9876543210 + i
         desc_host[i] = (src[0].data_ptr(), src[1].data_ptr(), 0 if feat is None else src[2].data_ptr(), n, seed, 40 + i)
@@ -58,7 +59,7 @@ def test_stage_batch_equals_the_single_calls(dev):
         a.shape = dst["shape"].data_ptr() if dyn else None
         a.idx = dst["idx"].data_ptr() if P else None
         a.u_tr, a.u_rot = dst["u"][0].data_ptr(), (dst["u"][1].data_ptr() if i != 1 else None)
-        a.n_pairs, a.n_cap, a.F, a.res = P, cap, F, float(res)
+        a.n_pairs, a.n_cap, a.F, a.res, a.idx_is_i64 = P, cap, F, float(res), 0 if i == 4 else 1
         keep.append((src, dst))
         want.append((pc, nrm, feat, res, seed))
     desc = torch.from_numpy(desc_host.view(np.int64)).to(dev)
@@ -79,7 +80,8 @@ def test_stage_batch_equals_the_single_calls(dev):
         assert dst["shape"].cpu().tolist() == ([n, *dims] if dyn else [-5] * 4)
         if P:
             idx, u_tr, u_rot = draw(dev, seed, P, n)
-            np.testing.assert_array_equal(dst["idx"].cpu().numpy(), idx)
+            assert dst["idx"].dtype == (torch.int32 if i == 4 else torch.int64)
+            np.testing.assert_array_equal(dst["idx"].cpu().numpy().astype(np.int64), idx)
             np.testing.assert_array_equal(dst["u"][0].cpu().numpy(), u_tr)
             if i != 1:
                 np.testing.assert_array_equal(dst["u"][1].cpu().numpy(), u_rot)
