@@ -66,9 +66,10 @@ class BatchPoseRunner:
         includes the previous batch's join: lane 0 then starts batch k + 1 while lane 1 still finishes batch k (records are
         double-buffered).  The contract that buys it: objects returned by put() are snapshots -- work the caller enqueues on its
         stream AFTER put() that rewrites them in place is not waited for.  (Host arrays are copied at call time, so their batches
-        overlap regardless.)  The records run() returns are ordered on the caller's stream as always.  idx_i32: the pair lists a staged chain draws are int32 (half the index bytes through every kernel of the
-        chain; the draws are the same numbers).  Measured: 8 resident C2-size
-        objects 0.140 -> 0.129 ms per object, 64: 0.121 -> 0.118; from host arrays 0.149 -> 0.135 (profiles/r6_resident_probe.txt)."""
+        overlap regardless.)  The records run() returns are ordered on the caller's stream as always.
+        idx_i32: the pair lists a staged chain draws are int32 (half the index bytes through every kernel of the chain; the draws are the
+        same numbers).  Measured on 8 resident C2-size objects: 0.1338 -> 0.1301 ms per object at 4 batches per timed region, 0.1294 ->
+        0.1256 at 8 (profiles/r6_resident_probe.txt)."""
         self.encoders, self.device = encoders, device
         self.point_encoders = point_encoders or {}
         self.n_lanes = max(1, int(n_lanes))
