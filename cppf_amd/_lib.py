@@ -37,6 +37,7 @@ _SIGS = {
     "cppf_knn_dyn": (C.c_int, [vp, i32, vp, i32, vp, vp]),
     "cppf_point_encoder_forward_dyn": (C.c_int, [vp, vp, vp, i32, vp, i32, vp, C.POINTER(C.c_int), i32, i32, i32, i32, i32, i32,
                                                  vp, vp, sz, vp]),
+    "cppf_point_encoder_forward_batch": (C.c_int, [i32, vp, i32, C.POINTER(C.c_int), i32, i32, i32, i32, i32, i32, vp]),
     "cppf_grid_argmax": (C.c_int, [vp, i64, vp, vp, vp, sz, vp]),
     "cppf_center_from_argmax": (C.c_int, [vp, vp, C.c_double, i32, i32, vp, vp, vp, vp, vp]),
     "cppf_counts_argmax_select": (C.c_int, [vp, i32, vp, vp, vp, vp]),
@@ -136,6 +137,13 @@ class StageItem(C.Structure):
 
 
 STAGE_DESC_WORDS = 6
+
+
+class PointEncItem(C.Structure):
+    """include/cppf.h: CppfPointEncItem (one cloud of cppf_point_encoder_forward_batch)"""
+    _fields_ = [("pc", C.c_void_p), ("nrm", C.c_void_p), ("nbrs", C.c_void_p), ("n_dev", C.c_void_p), ("packed", C.c_void_p),
+                ("out", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("n_cap", C.c_int32),
+                ("nbrs_ready", C.c_int32)]
 
 
 class VoteItem(C.Structure):

@@ -62,9 +62,8 @@ __device__ __forceinline__ int wave_sum(int v)
 //   4. candidates below it, and the first ties, are written out in slot (= index) order.
 // More than KNN_CAP candidates (duplicate-heavy inputs) run the bisection over re-streamed keys instead.
 template <bool FROM_DIST>
-__global__ __launch_bounds__(KNN_WAVES * 64) void knn_kernel(const float* __restrict__ pc, const float* __restrict__ dist,
-                                                             int N, int k, int32_t* __restrict__ out,
-                                                             const int32_t* __restrict__ n_dev)
+__device__ __forceinline__ void knn_body(const float* __restrict__ pc, const float* __restrict__ dist, int N, int k,
+                                         int32_t* __restrict__ out, const int32_t* __restrict__ n_dev)
 {
     if (n_dev) N = min(*n_dev, N);   // *_dyn: the launch is sized for a capacity, the point count is in memory
     __shared__ uint32_t cand_key[KNN_WAVES][KNN_CAP];
@@ -190,6 +189,26 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_kernel(const float* __rest
     }
 }
 
+template <bool FROM_DIST>
+__global__ __launch_bounds__(KNN_WAVES * 64) void knn_kernel(const float* __restrict__ pc, const float* __restrict__ dist,
+                                                             int N, int k, int32_t* __restrict__ out,
+                                                             const int32_t* __restrict__ n_dev)
+{
+    knn_body<FROM_DIST>(pc, dist, N, k, out, n_dev);
+}
+
+// The searches of a chain's members in ONE launch (cppf_point_encoder_forward_batch): blockIdx.y = member, blockIdx.x its query
+// blocks (the grid is sized for the largest member; the others' surplus blocks leave at once).  A cloud of 700-2000 points is 700-2000
+// wavefronts: one member fills a quarter of the chip's wave slots, four or eight of them fill it.
+constexpr int SP_BATCH_MAX = 8;
+struct KnnBatch { const float* pc[SP_BATCH_MAX]; int32_t* out[SP_BATCH_MAX]; const int32_t* n_dev[SP_BATCH_MAX]; int N[SP_BATCH_MAX]; int k; };
+__global__ __launch_bounds__(KNN_WAVES * 64) void knn_batch_kernel(KnnBatch B)
+{
+    const int i = blockIdx.y;
+    if (!B.out[i]) return;               // (a member whose neighbour sets are already there)
+    knn_body<false>(B.pc[i], nullptr, B.N[i], B.k, B.out[i], B.n_dev[i]);
+}
+
 // --------------------------------------------------------------------------------------------- conv
 __host__ __device__ constexpr int sp_per_wave(int n_in) { return 16 * SP_KSTRIDE + 64 * n_in + SP_RANK * n_in + 64 * 3 + SP_NOUT + 64 * 8; }
 __host__ __device__ constexpr int sp_waves(int n_in) { return n_in <= 4 ? SP_WAVES_MAX : 4; }
@@ -214,12 +233,14 @@ struct ConvArgs {
 
 // hidden = {32, 64, 32, 32}, rank 32, n_out 32 (train.py:34).  Dynamic LDS: the workgroup's weight image
 // (SPW_FLOATS), then per wave  kern[16][33] | nf[64][n_in] | contracted[32*n_in] | r[64][3] | y[32] | x6[64][8]
-__global__ __launch_bounds__(SP_WAVES_MAX * 64) void sprin_conv_kernel(ConvArgs A)
+__device__ __forceinline__ void sprin_conv_body(const ConvArgs& A)
 {
     extern __shared__ __attribute__((aligned(16))) float sp_lds[];
     const int w = threadIdx.x >> 6, lane = lane_id();
     __shared__ uint32_t gmax[32];
     __shared__ float gw[32 * SP_NOUT + 32];   // GlobalInfoProp's weights and bias, read in the epilogue
+    const int N = A.n_dev ? min(*A.n_dev, A.N) : A.N;
+    if (blockIdx.x * (blockDim.x >> 6) >= N) return;   // whole workgroup past the cloud (capacity launch; a shorter member of a batch)
     if (threadIdx.x < 32) gmax[threadIdx.x] = 0u;
     for (int i = threadIdx.x; i < A.n_glob * (SP_NOUT + 1); i += blockDim.x) gw[i] = A.glob_w[i];
     const int n_in = A.n_in, k = A.k;
@@ -234,8 +255,6 @@ __global__ __launch_bounds__(SP_WAVES_MAX * 64) void sprin_conv_kernel(ConvArgs 
     for (int i = threadIdx.x; i < SPW_FLOATS / 4; i += blockDim.x)
         reinterpret_cast<f32x4*>(Wl)[i] = reinterpret_cast<const f32x4*>(A.wimg)[i];
     const int n = blockIdx.x * (blockDim.x >> 6) + w;
-    const int N = A.n_dev ? min(*A.n_dev, A.N) : A.N;
-    if (blockIdx.x * (blockDim.x >> 6) >= N) return;   // whole workgroup past the cloud (capacity launch)
     const bool live = n < N;
     const int nc = live ? n : N - 1;
     const int jc = lane < k ? lane : k - 1;
@@ -352,11 +371,17 @@ __global__ __launch_bounds__(SP_WAVES_MAX * 64) void sprin_conv_kernel(ConvArgs 
     if (threadIdx.x < 32) A.wgmax[(size_t)blockIdx.x * 32 + threadIdx.x] = gmax[threadIdx.x];
 }
 
+__global__ __launch_bounds__(SP_WAVES_MAX * 64) void sprin_conv_kernel(ConvArgs A) { sprin_conv_body(A); }
+
+// ... and the members' convolutions in one launch (blockIdx.y = member: its own cloud, neighbour sets, weight image -- members of
+// different categories carry different encoders -- and output)
+struct ConvBatch { ConvArgs item[SP_BATCH_MAX]; };
+__global__ __launch_bounds__(SP_WAVES_MAX * 64) void sprin_conv_batch_kernel(ConvBatch B) { sprin_conv_body(B.item[blockIdx.y]); }
+
 // GlobalInfoProp (models/sprin.py:75-84), second half: the maximum over the workgroups' maxima (every block recomputes it from
 // L2: <= N/4 x 32 words) and the broadcast into columns n_out.. of every point's row.
-__global__ __launch_bounds__(256) void sprin_fill_kernel(float* __restrict__ out, int N, int stride, int n_glob,
-                                                         const uint32_t* __restrict__ wgmax, int waves,
-                                                         const int32_t* __restrict__ n_dev)
+__device__ __forceinline__ void sprin_fill_body(float* __restrict__ out, int N, int stride, int n_glob,
+                                                const uint32_t* __restrict__ wgmax, int waves, const int32_t* __restrict__ n_dev)
 {
     if (n_dev) N = min(*n_dev, N);
     if ((int64_t)blockIdx.x * 256 >= (int64_t)N * n_glob) return;
@@ -389,6 +414,20 @@ __global__ __launch_bounds__(256) void sprin_fill_kernel(float* __restrict__ out
     if (t >= N * n_glob) return;
     const int n = t / n_glob, c = t - n * n_glob;
     out[(size_t)n * stride + SP_NOUT + c] = ord2f(gl[c]);
+}
+
+__global__ __launch_bounds__(256) void sprin_fill_kernel(float* __restrict__ out, int N, int stride, int n_glob,
+                                                         const uint32_t* __restrict__ wgmax, int waves,
+                                                         const int32_t* __restrict__ n_dev)
+{
+    sprin_fill_body(out, N, stride, n_glob, wgmax, waves, n_dev);
+}
+
+struct FillBatch { float* out[SP_BATCH_MAX]; const uint32_t* wgmax[SP_BATCH_MAX]; const int32_t* n_dev[SP_BATCH_MAX]; int N[SP_BATCH_MAX]; int stride, n_glob, waves; };
+__global__ __launch_bounds__(256) void sprin_fill_batch_kernel(FillBatch B)
+{
+    const int i = blockIdx.y;
+    sprin_fill_body(B.out[i], B.N[i], B.stride, B.n_glob, B.wgmax[i], B.waves, B.n_dev[i]);
 }
 
 int64_t conv_params(const int32_t* hidden, int n_hidden, int rank, int n_in, int n_out)
@@ -509,6 +548,47 @@ int cppf_point_encoder_forward_train(const float* pc, const float* nrm, const in
     if (num_layers != 1 || !contraction_out) return num_layers != 1 ? CPPF_EUNSUPPORTED : CPPF_EINVAL;
     return sp_forward(pc, nrm, nbrs, n_points, k, packed, hidden, n_hidden, rank, n_nbr_feats, n_out, n_glob, num_layers, out,
                       contraction_out, workspace, workspace_bytes, stream);
+}
+
+// kNN + convolution + GlobalInfoProp of up to 8 clouds in three launches (the one-layer standard encoder, train.py:34): what
+// cppf_knn_dyn + cppf_point_encoder_forward_dyn do per cloud, bit for bit (the same device functions; a member only picks its
+// arguments by blockIdx.y).
+int cppf_point_encoder_forward_batch(int n_items, const CppfPointEncItem* items, int k, const int32_t* hidden, int n_hidden, int rank,
+                                     int n_nbr_feats, int n_out, int n_glob, int num_layers, void* stream)
+{
+    if (n_items < 1 || n_items > SP_BATCH_MAX || !items || k <= 0 || !hidden) return CPPF_EINVAL;
+    if (num_layers != 1 || !sp_std_shape(hidden, n_hidden, rank, n_nbr_feats, n_out, n_glob) || k > 64) return CPPF_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int W = n_out + n_glob, waves = sp_waves(n_nbr_feats);
+    const size_t nat = sp_natural_floats(hidden, n_hidden, rank, n_nbr_feats, n_out, n_glob, 1);
+    const int64_t cp = conv_params(hidden, n_hidden, rank, n_nbr_feats, n_out);
+    KnnBatch KB;
+    ConvBatch CB;
+    FillBatch FB;
+    memset(&KB, 0, sizeof(KB)); memset(&CB, 0, sizeof(CB)); memset(&FB, 0, sizeof(FB));
+    KB.k = k; FB.stride = W; FB.n_glob = n_glob; FB.waves = waves;
+    int n_max = 0, any_search = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const CppfPointEncItem& it = items[i];
+        if (it.n_cap < 1 || k > it.n_cap) return CPPF_EINVAL;
+        if (!it.pc || !it.nrm || !it.nbrs || !it.packed || !it.out) return CPPF_EINVAL;
+        if (!it.workspace || it.workspace_bytes < cppf_point_encoder_workspace_bytes(it.n_cap, n_out, n_glob, 1)) return CPPF_EWORKSPACE;
+        uint32_t* wgmax = (uint32_t*)((char*)it.workspace + 256);
+        KB.pc[i] = it.pc; KB.out[i] = it.nbrs_ready ? nullptr : it.nbrs; KB.n_dev[i] = it.n_dev; KB.N[i] = it.n_cap;
+        any_search |= !it.nbrs_ready;
+        CB.item[i] = ConvArgs{it.pc, it.nrm, nullptr, it.nbrs, it.packed, it.packed + nat, it.out, it.n_cap, k, n_nbr_feats, W, nullptr,
+                              it.n_dev, it.packed + cp, wgmax, n_glob};
+        FB.out[i] = it.out; FB.wgmax[i] = wgmax; FB.n_dev[i] = it.n_dev; FB.N[i] = it.n_cap;
+        n_max = it.n_cap > n_max ? it.n_cap : n_max;
+    }
+    if (any_search)
+        knn_batch_kernel<<<dim3((n_max + KNN_WAVES - 1) / KNN_WAVES, n_items), KNN_WAVES * 64, 0, st>>>(KB);
+    const size_t lds = ((size_t)SPW_FLOATS + (size_t)waves * sp_per_wave(n_nbr_feats)) * sizeof(float);
+    hipError_t e = hipFuncSetAttribute((const void*)sprin_conv_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    sprin_conv_batch_kernel<<<dim3((n_max + waves - 1) / waves, n_items), waves * 64, lds, st>>>(CB);
+    sprin_fill_batch_kernel<<<dim3((n_max * n_glob + 255) / 256, n_items), 256, 0, st>>>(FB);
+    return (int)hipGetLastError();
 }
 
 static int sp_forward(const float* pc, const float* nrm, const int32_t* nbrs, int n_points, int k, const float* packed,

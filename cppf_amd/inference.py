@@ -20,6 +20,8 @@ surviving pairs only, like the reference's, through cppf_pair_mlp_decode_sel), a
 10 000-pair subset of :277-280 is the first `max_rot_pairs` survivors in pair order (pairs are
 i.i.d. uniform, so a prefix is distributed exactly like a shuffled subset).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -134,7 +136,6 @@ def grid_class(dims):
     if hit is None:
         L = _lib.lib()
         T = int(L.cppf_vote_tiles(*key))
-        import os
         many = 0 if T < 4 else (16 if T <= 16 and not os.environ.get("CPPF_TILE_CLASS_64") else 1)
         hit = (T, many, _lib.tiles_cap(many) * int(L.cppf_vote_tile_cells()))
         if len(_grid_class_cache) < 4096:
@@ -846,11 +847,20 @@ class PoseChain:
             if pre is not None:
                 pre()
         feats = []            # (the members' own attributes are left alone: a member may also run on its own captured graph)
-        for p in pipes:                                                          # nocs/inference.py:180-181
+        # nocs/inference.py:180-181.  The shape-polymorphic members' encoders share three launches (search, convolution,
+        # GlobalInfoProp for all of them: a cloud of 700-2000 points fills a quarter of the chip); others run one after the other.
+        enc_members = [p for p in pipes if p.point_encoder is not None and p.dynamic]
+        batched = None
+        if len(enc_members) > 1 and not os.environ.get("CPPF_NO_POINT_BATCH"):      # (the knob: A/B measurements)
+            from .models.model import point_encoder_forward_batch
+            batched = point_encoder_forward_batch([dict(encoder=p.point_encoder, pc=p.pc, nrm=p.nrm, n_dev=p.shape, out=p._feat_out,
+                                                        nbrs=p._nbrs, nbrs_ready=getattr(p, "nbrs_ready", False)) for p in enc_members])
+        for p in pipes:
             if p.point_encoder is None:
                 feats.append(p.feat)
             elif p.dynamic:
-                feats.append(p.point_encoder.forward_dyn(p.pc, p.nrm, p.shape, out=p._feat_out, nbrs=p._nbrs,
+                feats.append(p._feat_out if batched is not None else
+                             p.point_encoder.forward_dyn(p.pc, p.nrm, p.shape, out=p._feat_out, nbrs=p._nbrs,
                                                          nbrs_ready=getattr(p, "nbrs_ready", False)))
             else:
                 feats.append(p.point_encoder(p.pc[None], p.nrm[None])[0])

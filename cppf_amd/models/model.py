@@ -452,6 +452,42 @@ class PointEncoder(_DeviceWeights, nn.Module):
         return out
 
 
+def point_encoder_forward_batch(members):
+    """The point encoders of a chain's members in three launches (cppf_point_encoder_forward_batch) instead of three each.
+    members: dicts(encoder, pc, nrm, n_dev, out, nbrs[, nbrs_ready]) as PointEncoder.forward_dyn takes them, 1..8 of them, encoders
+    of the one-layer standard form with the same k (instances of different categories carry different weights).  -> [out per
+    member], bit-equal to forward_dyn member by member; None when the members do not qualify (the caller then loops forward_dyn)."""
+    require_cuda()
+    e0 = members[0]["encoder"]
+    if not 1 <= len(members) <= 8 or any(m["encoder"].num_layers != 1 or m["encoder"].k != e0.k or m["encoder"].spfcs != e0.spfcs
+                                         or m["encoder"].out_dim != e0.out_dim or m["encoder"].num_nbr_feats != e0.num_nbr_feats
+                                         for m in members):
+        return None
+    dev = members[0]["pc"].device
+    L = _lib.lib()
+    arr = (_lib.PointEncItem * len(members))()
+    keep = []
+    desc = None
+    for i, m in enumerate(members):
+        packed, desc = m["encoder"]._packed_weights(dev)
+        n_cap = m["pc"].shape[0]
+        ws = workspace(L.cppf_point_encoder_workspace_bytes(n_cap, desc["n_out"], desc["n_glob"], 1), dev, f"point_encoder{i}")
+        a = arr[i]
+        a.pc, a.nrm, a.nbrs, a.out = m["pc"].data_ptr(), m["nrm"].data_ptr(), m["nbrs"].data_ptr(), m["out"].data_ptr()
+        a.n_dev = None if m.get("n_dev") is None else m["n_dev"].data_ptr()
+        a.packed, a.workspace, a.workspace_bytes = packed.data_ptr(), ws.data_ptr(), ws.numel()
+        a.n_cap, a.nbrs_ready = n_cap, 1 if m.get("nbrs_ready") else 0
+        keep.append((packed, ws))
+    hid = (C.c_int * len(desc["hidden"]))(*desc["hidden"])
+    with torch.cuda.device(dev):
+        rc = L.cppf_point_encoder_forward_batch(len(members), C.cast(arr, C.c_void_p), e0.k, hid, len(desc["hidden"]), desc["rank"],
+                                                desc["n_nbr_feats"], desc["n_out"], desc["n_glob"], 1, stream_ptr(dev))
+    if rc == -3:
+        return None
+    _lib.check(rc, "cppf_point_encoder_forward_batch")
+    return [m["out"] for m in members]
+
+
 class PPFEncoder(_DeviceWeights, nn.Module):
     def __init__(self, ppffcs, out_dim):
         super().__init__()

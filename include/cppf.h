@@ -308,6 +308,26 @@ int cppf_point_encoder_forward_dyn(const float* pc, const float* nrm, const int3
                                    int k, const float* packed, const int32_t* hidden, int n_hidden, int rank, int n_nbr_feats,
                                    int n_out, int n_glob, int num_layers, float* out, void* workspace,
                                    size_t workspace_bytes, void* stream);
+/* The point encoders of up to 8 instances -- models/model.py:47-57 per instance of the loop nocs/inference.py:120,180-181 -- in THREE
+ * launches (search, convolution, GlobalInfoProp) instead of three per instance: what cppf_knn_dyn + cppf_point_encoder_forward_dyn
+ * compute per cloud, bit for bit (ABI 4).  A cloud of 700-2000 points is that many wavefronts, a fraction of the chip; the members of
+ * a chain fill it.  One-layer standard encoder only (train.py:34; anything else: CPPF_EUNSUPPORTED, call the per-cloud entry points).
+ * Members may carry different weights (instances of different categories).  n_dev NULL: n_cap is the point count.
+ * nbrs_ready != 0: `nbrs` already holds the member's neighbour sets (cppf_frame_cloud_dyn leaves them), no search for it. */
+typedef struct CppfPointEncItem {
+    const float* pc;          /* device f32[n_cap,3] */
+    const float* nrm;         /* device f32[n_cap,3] */
+    int32_t* nbrs;            /* device i32[n_cap,k] */
+    const int32_t* n_dev;     /* device i32[1]: points in use, or NULL */
+    const float* packed;      /* this member's encoder image (cppf_point_encoder_pack / _pack_device) */
+    float* out;               /* device f32[n_cap, n_out + n_glob]; rows >= the point count are left untouched */
+    void* workspace;          /* cppf_point_encoder_workspace_bytes(n_cap, n_out, n_glob, 1), the member's own */
+    size_t workspace_bytes;
+    int32_t n_cap;
+    int32_t nbrs_ready;
+} CppfPointEncItem;
+int cppf_point_encoder_forward_batch(int n_items, const CppfPointEncItem* items_host, int k, const int32_t* hidden, int n_hidden,
+                                     int rank, int n_nbr_feats, int n_out, int n_glob, int num_layers, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Orientation candidates.  Replaces `rot_voting_kernel` = CUDA `rot_voting`

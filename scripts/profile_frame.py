@@ -36,7 +36,7 @@ for _ in range(n):
 torch.cuda.synchronize()
 print("instances_processed %d" % ((5 + n) * len(inst)))
 print("FrameRunner ms per frame", (time.perf_counter() - t0) / n * 1e3, "chains", len(runner._chains),
-      [(k[0], k[1], k[5]) for k in runner._members], runner.last)
+      [m["key"] for m in runner._members.values()], runner.last)
 if os.environ.get("CPROFILE"):
     import cProfile
     import pstats

@@ -170,3 +170,53 @@ def test_batch_runner_with_point_encoders(dev, oracle):
     a = BatchPoseRunner(encs, dev, point_encoders=pencs).run(objs).cpu().numpy()
     b = BatchPoseRunner(encs, dev).run(objs_feat).cpu().numpy()
     assert a.shape == (5, 20) and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("sizes,caps,ready", [
+    ([717, 1203, 1890, 960], [1024, 2048, 2048, 1024], [0, 0, 0, 0]),      # the reference-default batch's clouds in their buckets
+    ([64, 2011, 300, 1544, 1333, 1777, 90, 1024], [64, 3072, 512, 2048, 2048, 2048, 128, 1024], [0, 1, 0, 0, 1, 0, 0, 1]),
+    ([515], [1024], [0]),
+])
+def test_point_encoder_batch_equals_the_per_cloud_entry_points_and_the_oracle(dev, oracle, sizes, caps, ready):
+    """cppf_point_encoder_forward_batch (three launches for up to 8 clouds; members of different categories carry different weights;
+    capacity-sized buffers with the point count in device memory; members whose neighbour sets are already there): every member's
+    neighbour sets and features equal cppf_knn_dyn + cppf_point_encoder_forward_dyn's and the oracle's, bit for bit; rows beyond a
+    member's point count are left untouched."""
+    from cppf_amd.models.model import point_encoder_forward_batch
+    k = 60
+    encs = [_encoder(dev, 1, seed=40 + (i % 3), k=k) for i in range(len(sizes))]
+    members, singles, clouds = [], [], []
+    for i, (n, cap, rdy) in enumerate(zip(sizes, caps, ready)):
+        pc, nrm = _cloud(n, 900 + i)
+        clouds.append((pc, nrm))
+        pcd, nrmd = torch.full((cap, 3), 7.0, device=dev), torch.full((cap, 3), 7.0, device=dev)
+        pcd[:n], nrmd[:n] = torch.from_numpy(pc).to(dev), torch.from_numpy(nrm).to(dev)
+        n_dev = torch.tensor([n, 0, 0, 0], dtype=torch.int32, device=dev)
+        nbrs = torch.full((cap, k), -5, dtype=torch.int32, device=dev)
+        if rdy:
+            nbrs[:n] = torch.from_numpy(oracle.knn(pc, k).astype(np.int32)).to(dev)
+        out = torch.full((cap, 40), -3.0, device=dev)
+        members.append(dict(encoder=encs[i], pc=pcd, nrm=nrmd, n_dev=n_dev, out=out, nbrs=nbrs, nbrs_ready=bool(rdy)))
+        singles.append(encs[i].forward_dyn(pcd, nrmd, n_dev, out=torch.full((cap, 40), -3.0, device=dev),
+                                           nbrs=torch.full((cap, k), -5, dtype=torch.int32, device=dev)).cpu().numpy())
+    outs = point_encoder_forward_batch(members)
+    assert outs is not None and len(outs) == len(sizes)
+    for i, (n, cap) in enumerate(zip(sizes, caps)):
+        pc, nrm = clouds[i]
+        got, nb = outs[i].cpu().numpy(), members[i]["nbrs"].cpu().numpy()
+        want_nb = oracle.knn(pc, k)
+        assert np.array_equal(nb[:n], want_nb) and np.all(nb[n:] == -5)
+        assert np.array_equal(got, singles[i])
+        assert np.array_equal(got[:n], _oracle_out(oracle, encs[i], pc, nrm, want_nb)) and np.all(got[n:] == -3.0)
+    # members that do not qualify: the caller loops over forward_dyn
+    assert point_encoder_forward_batch([dict(members[0], encoder=_encoder(dev, 2, seed=1, k=k))]) is None
+    assert point_encoder_forward_batch([members[0], dict(members[0], encoder=_encoder(dev, 1, seed=1, k=17))]) is None
+    # the C ABI's argument checks
+    L = _lib.lib()
+    arr = (_lib.PointEncItem * 1)()
+    import ctypes as C
+    hid = (C.c_int * 4)(32, 64, 32, 32)
+    assert L.cppf_point_encoder_forward_batch(0, C.cast(arr, C.c_void_p), k, hid, 4, 32, 2, 32, 8, 1, None) == -1
+    assert L.cppf_point_encoder_forward_batch(9, C.cast(arr, C.c_void_p), k, hid, 4, 32, 2, 32, 8, 1, None) == -1
+    assert L.cppf_point_encoder_forward_batch(1, C.cast(arr, C.c_void_p), k, hid, 4, 32, 2, 32, 8, 2, None) == -3
+    assert L.cppf_point_encoder_forward_batch(1, C.cast(arr, C.c_void_p), k, hid, 4, 32, 2, 32, 8, 1, None) == -1      # (null pointers)
