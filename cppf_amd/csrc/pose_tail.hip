@@ -777,6 +777,75 @@ __device__ __forceinline__ void rot_sphere_band_body(const float* __restrict__ p
         if (cnt[j]) atomicAdd(&counts[j], cnt[j]);
 }
 
+// The same count for launches that serve several instances at once (cppf_pose_tail_batch).  rot_sphere_band_body's blocks take groups
+// of 2 or 8 pairs -- tuned for ONE instance on an idle chip, where a group is a latency chain and only more groups in flight hide
+// it -- and every block pays the set-up (the 480 bins, the rotation row in fp64, the flush) for 144 or 576 candidates: as much
+// work as the candidates themselves.  In a chain of 4-8 instances beside other lanes the chip is full anyway and total work is what
+// counts: here a block owns a CONTIGUOUS share of the survivors (<= 256 blocks per instance and direction), computes the frames of up
+// to 64 pairs in one step and sweeps their candidates with full lanes; bins as float4 (one LDS read per band step instead of three).
+// Same candidates, same dot products, same threshold test, integer counts: identical results.
+#define SPHE_PAIRS 64
+#define SPHE_BLOCKS 256
+__device__ __forceinline__ void rot_sphere_band_even_body(const float* __restrict__ points, const float* __restrict__ preds_rot,
+                                                          int rot_stride, const int32_t* __restrict__ point_idxs,
+                                                          const int32_t* __restrict__ sel, const int32_t* __restrict__ n_sel_dev,
+                                                          int64_t n_sel_host, int64_t max_pairs, int n_rots,
+                                                          const float* __restrict__ sphere, int n_sphere, float thr,
+                                                          int32_t* __restrict__ counts, int descending, int rot_dir_step,
+                                                          int counts_dir_step)
+{
+    preds_rot += (int64_t)blockIdx.y * rot_dir_step;
+    counts += (int64_t)blockIdx.y * counts_dir_step;
+    __shared__ RotFrame frames[SPHE_PAIRS];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float4* sph4 = reinterpret_cast<float4*>(lds);                // [n_sphere] {x, y, z, -}
+    int* cnt = reinterpret_cast<int*>(lds + 4 * n_sphere);        // [n_sphere]
+    float2* row = reinterpret_cast<float2*>(cnt + n_sphere);      // [n_rots]
+    const int64_t n_avail = n_sel_dev ? (int64_t)*n_sel_dev : n_sel_host;
+    const int64_t n_sel = n_avail < max_pairs ? n_avail : max_pairs;
+    const int64_t per = (n_sel + gridDim.x - 1) / gridDim.x;
+    const int64_t k_begin = (int64_t)blockIdx.x * per, k_end = k_begin + per < n_sel ? k_begin + per : n_sel;
+    if (k_begin >= k_end) return;
+    for (int i = threadIdx.x; i < n_sphere; i += 256) { sph4[i] = make_float4(sphere[3 * i], sphere[3 * i + 1], sphere[3 * i + 2], 0.f); cnt[i] = 0; }
+    for (int i = threadIdx.x; i < n_rots; i += 256) row[i] = rot_cs(i, n_rots);
+    float band = 2.f - 2.f * thr;
+    band = sqrtf(fminf(fmaxf(band, 0.f), 4.f) + 1e-5f) + 1e-4f;
+    for (int64_t k0 = k_begin; k0 < k_end; k0 += SPHE_PAIRS) {
+        const int np = (int)min((int64_t)SPHE_PAIRS, k_end - k0);
+        __syncthreads();   // (previous round's frames are no longer read; first trip: the tables above are complete)
+        if ((int)threadIdx.x < np) {
+            const int64_t sl = k0 + threadIdx.x;
+            const int p = sel ? sel[sl] : (int)sl;
+            const int2 ij = reinterpret_cast<const int2*>(point_idxs)[p];
+            frames[threadIdx.x] = rot_frame(points, ij.x, ij.y, preds_rot[(int64_t)p * rot_stride]);
+        }
+        __syncthreads();
+        const int items = np * n_rots;
+        for (int k = threadIdx.x; k < items; k += 256) {
+            const int pl = k / n_rots, i = k - pl * n_rots;
+            f3 up = {0.f, 0.f, 0.f};
+            if (frames[pl].ok) up = rot_candidate(frames[pl], row[i]);
+            const float ylo = up.y - band, yhi = up.y + band;
+            int lo = 0, hi = n_sphere;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const float y = sph4[mid].y;
+                const bool before = descending ? (y > yhi) : (y < ylo);
+                if (before) lo = mid + 1; else hi = mid;
+            }
+            for (int j = lo; j < n_sphere; ++j) {
+                const float4 sb = sph4[j];
+                if (descending ? (sb.y < ylo) : (sb.y > yhi)) break;
+                const float d = fmaf(up.z, sb.z, fmaf(up.y, sb.y, up.x * sb.x));
+                if (d > thr) atomicAdd(&cnt[j], 1);
+            }
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < n_sphere; j += 256)
+        if (cnt[j]) atomicAdd(&counts[j], cnt[j]);
+}
+
 __global__ __launch_bounds__(256) void rot_sphere_band_kernel(const float* __restrict__ points, const float* __restrict__ preds_rot,
                                                               int rot_stride, const int32_t* __restrict__ point_idxs,
                                                               const int32_t* __restrict__ sel, const int32_t* __restrict__ n_sel_dev,
@@ -1212,7 +1281,7 @@ struct TailItem {
 };
 struct TailBatch {
     TailItem item[TAIL_BATCH_MAX];
-    int n, n_rots, n_sphere, descending;
+    int n, n_rots, n_sphere, descending, sphere_legacy;
     int64_t max_rot_pairs;
     const float* sphere32;
     float thr;
@@ -1239,8 +1308,12 @@ __global__ __launch_bounds__(256) void rot_sphere_band_batch_kernel(TailBatch B)
 {
     const TailItem& I = B.item[blockIdx.z];
     if ((int)blockIdx.y >= I.n_dirs) return;
-    rot_sphere_band_body(I.points, I.heads, 8, I.idx32, I.surv, I.count, I.n_ppfs, B.max_rot_pairs, B.n_rots, B.sphere32, B.n_sphere, B.thr,
-                         I.counts, B.descending, 1, B.n_sphere, nullptr, 0);
+    if (B.sphere_legacy)
+        rot_sphere_band_body(I.points, I.heads, 8, I.idx32, I.surv, I.count, I.n_ppfs, B.max_rot_pairs, B.n_rots, B.sphere32, B.n_sphere, B.thr,
+                             I.counts, B.descending, 1, B.n_sphere, nullptr, 0);
+    else
+        rot_sphere_band_even_body(I.points, I.heads, 8, I.idx32, I.surv, I.count, I.n_ppfs, B.max_rot_pairs, B.n_rots, B.sphere32, B.n_sphere,
+                                  B.thr, I.counts, B.descending, 1, B.n_sphere);
 }
 __global__ __launch_bounds__(RED_THREADS) void pose_sums_batch_kernel(TailBatch B)
 {
@@ -1256,6 +1329,11 @@ extern "C" int cppf_pose_tail_batch(int n_items, const CppfPoseTailItem* items, 
     hipStream_t st = (hipStream_t)stream;
     TailBatch B = {};
     B.n = n_items; B.n_rots = n_rots; B.n_sphere = n_sphere; B.descending = sphere_sorted_by_y > 0 ? 1 : 0;
+    {   // development knob (A/B measurements): the single-instance grouping of the sphere count in the batched launch
+        static int legacy = -1;
+        if (legacy < 0) legacy = getenv("CPPF_SPHERE_LEGACY") ? 1 : 0;
+        B.sphere_legacy = legacy;
+    }
     B.max_rot_pairs = max_rot_pairs; B.sphere32 = sphere32; B.thr = thr;
     CppfPairMlpItem sel_items[TAIL_BATCH_MAX];
     int n_second = 0, max_dirs = 1;
@@ -1288,13 +1366,14 @@ extern "C" int cppf_pose_tail_batch(int n_items, const CppfPoseTailItem* items, 
         S.scale_mean[0] = it.scale_mean[0]; S.scale_mean[1] = it.scale_mean[1]; S.scale_mean[2] = it.scale_mean[2];
         S.regress_right = it.regress_right;
         int64_t nb = (it.n_pairs + 4 * 256 - 1) / (4 * 256);
-        nb = nb > 1024 ? 1024 : nb;
+        nb = nb > 256 ? 256 : nb;      // (every block loads the 21 KB rotation table: at least two trips per wave for it; 1024: 1 % slower)
         bv_blocks = nb > bv_blocks ? nb : bv_blocks;
         nb = (it.n_pairs + CMP_BLOCK - 1) / CMP_BLOCK;
         cmp_blocks = nb > cmp_blocks ? nb : cmp_blocks;
         const int64_t bound = it.n_pairs < max_rot_pairs ? it.n_pairs : max_rot_pairs;
-        nb = (bound + 1) / 2;
-        nb = nb > 2048 ? 2048 : nb;
+        nb = (bound + 7) / 8;                          // (rot_sphere_band_even_body: a block owns a contiguous share of the survivors)
+        nb = nb > SPHE_BLOCKS ? SPHE_BLOCKS : nb;
+        if (B.sphere_legacy) { nb = (bound + 1) / 2; nb = nb > 2048 ? 2048 : nb; }
         rot_blocks = nb > rot_blocks ? nb : rot_blocks;
         max_dirs = it.n_dirs > max_dirs ? it.n_dirs : max_dirs;
         if (it.second_pass) {
@@ -1325,7 +1404,12 @@ extern "C" int cppf_pose_tail_batch(int n_items, const CppfPoseTailItem* items, 
     }
     // 5. orientation vote + sphere-bin count (:259-284), both directions
     if (max_rot_pairs > 0) {
-        const size_t lds_rot = (size_t)(4 * n_sphere + 2 * n_rots) * sizeof(float);
+        const size_t lds_rot = (size_t)(5 * n_sphere + 2 * n_rots) * sizeof(float);
+        static bool lds_attr = false;      // (4 096 bins x 20 B + the rotation row: above the 64 KB a launch gets unasked)
+        if (!lds_attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rot_sphere_band_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            lds_attr = true;
+        }
         hipLaunchKernelGGL(rot_sphere_band_batch_kernel, dim3((unsigned)rot_blocks, (unsigned)max_dirs, (unsigned)n_items), dim3(256), lds_rot, st, B);
         CPPF_CHECK_LAUNCH();
     }

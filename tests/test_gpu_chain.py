@@ -14,7 +14,7 @@ from test_gpu_configs import check_argmax, check_pose, make_encoder, ocfg_of, se
 pytestmark = pytest.mark.gpu
 
 
-def make_members(dev, sph, enc, specs, dynamic, point_encoder=None):
+def make_members(dev, sph, enc, specs, dynamic, point_encoder=None, **kw):
     pipes, data = [], []
     for j, (cat, n, k, seed) in enumerate(specs):
         ob = syn.make_object(cat, n, seed)
@@ -22,9 +22,9 @@ def make_members(dev, sph, enc, specs, dynamic, point_encoder=None):
         u_tr, u_rot = syn.make_uniforms(idx.shape[0], seed)
         corners, dims = grid_shape(ob["pc"], ob["cfg"].res)
         if dynamic:
-            p = PosePipeline(enc, ob["cfg"], 2048, idx.shape[0], False, dev, sph, dynamic=True, point_encoder=point_encoder)
+            p = PosePipeline(enc, ob["cfg"], 2048, idx.shape[0], False, dev, sph, dynamic=True, point_encoder=point_encoder, **kw)
         else:
-            p = PosePipeline(enc, ob["cfg"], n, idx.shape[0], dims, dev, sph, point_encoder=point_encoder)
+            p = PosePipeline(enc, ob["cfg"], n, idx.shape[0], dims, dev, sph, point_encoder=point_encoder, **kw)
         p.load(ob["pc"], ob["normals"], None if point_encoder is not None else ob["feat"], idx, u_tr, u_rot, corners[0].copy(), dims=dims if dynamic else None)
         pipes.append(p)
         data.append(dict(ob=ob, idx=idx, u_tr=u_tr, u_rot=u_rot, corners=corners, dims=dims))
@@ -71,6 +71,37 @@ def test_chain_records_equal_member_pipelines_and_oracle(oracle, golden, dev, dy
     assert poses2[0]["argmax"] == poses[0]["argmax"] and poses2[1]["n_surv"] != poses[1]["n_surv"]
     with pytest.raises(ValueError):
         PoseChain([pipes[0], pipes[0]])
+
+
+@pytest.mark.parametrize("n_bins,gain", [(3600, 12.0), (37, 1.0), (480, 12.0)])
+def test_chain_sphere_count_equals_member_pipelines_on_other_spheres(dev, n_bins, gain):
+    """the chain's orientation count (rot_sphere_band_even_body: a block owns a contiguous share of the survivors) against the
+    members' own launches (groups of 2 or 8 pairs) on a fine sphere (0.2 degrees: 3 600 bins, above the default 64 KB of LDS), a
+    coarse one and the default, with few survivors and with the cap on the voting pairs reached (nocs/inference.py:277; set to 1 000
+    here): records bit for bit, both forms"""
+    from cppf_amd.utils.util import fibonacci_sphere
+    sph = np.array(fibonacci_sphere(n_bins))
+    enc = make_encoder(seeded_sd(3, gain), dev)
+    specs = [("bottle", 1500, 40, 11), ("mug", 1200, 10, 12), ("laptop", 1800, 64, 13), ("bowl", 700, 3, 14)]
+    pipes, _ = make_members(dev, sph, enc, specs, True, max_rot_pairs=1000)
+    chain = PoseChain(pipes)
+    survivors = []
+    for form in (False, True):
+        want = []
+        for p in pipes:
+            p.adapt(p.idx.shape[0] if form else 0)
+            p.run()
+            want.append(p.ws.rec.cpu().numpy().copy())
+        chain.full_first = form
+        for rep in range(2):
+            recs = torch.zeros((len(pipes), 21), dtype=torch.float64, device=dev)
+            chain.run_async(list(recs))
+            torch.cuda.synchronize()
+            got = recs.cpu().numpy()
+            for j, w in enumerate(want):
+                assert np.array_equal(got[j], w), (form, rep, j, got[j], w)
+        survivors = [int(w[18]) for w in want]
+    assert min(survivors) < 1000 and (gain < 2 or max(survivors) > 1000)      # (both sides of the cap are exercised)
 
 
 def test_chain_with_point_encoders_and_many_tile_member(oracle, golden, dev):
