@@ -445,7 +445,12 @@ __device__ __forceinline__ void v3_split(const V3Args& A, int T, int* sp)
         const unsigned long long E = (unsigned long long)max(A.wgs - nonempty, 0);
         const int C = n > 0u ? 1 + (int)((unsigned long long)n * E / (W > 0ull ? W : 1ull)) : 0;
         const int incl = wave_incl_scan(C);
-        int big = C > 0 ? (int)((n + (unsigned)C - 1u) / (unsigned)C) : 0;
+        // the scale follows the largest chunk of the NARROWEST launch an object can get (V3_BITS_WGS workgroups, as for the fused
+        // vote: see v3_fused_bits_pairs), or of this one if it is narrower still: whatever width a caller or a batch chooses, every
+        // deposit is quantised alike and the grid -- the exact integer sum -- is the same bits
+        const unsigned long long Eref = (unsigned long long)max(min(A.wgs, V3_BITS_WGS) - nonempty, 0);
+        const int Cref = n > 0u ? 1 + (int)((unsigned long long)n * Eref / (W > 0ull ? W : 1ull)) : 0;
+        int big = Cref > 0 ? (int)((n + (unsigned)Cref - 1u) / (unsigned)Cref) : 0;
         for (int off = 32; off > 0; off >>= 1) big = max(big, __shfl_xor(big, off, 64));
         sp[lane] = C; sp[64 + lane] = incl - C; sp[128 + lane] = (int)n;
         if (lane == 0) sp[192] = big;
@@ -1336,7 +1341,9 @@ __global__ __launch_bounds__(V3_THREADS) void v3_vote_batch_kernel(V3Batch B)
 {
     int i = 0;
     while (i + 1 < B.n && (int)blockIdx.x >= B.wg_begin[i + 1]) ++i;
-    v3_vote_body<true, false>(B.item[i], (int)blockIdx.x - B.wg_begin[i]);
+    // (workgroup-uniform: a member whose grid needs >= 4 tiles was binned by its own v3_bin_kernel launch and takes the consumer form)
+    if (B.item[i].fused) v3_vote_body<true, false>(B.item[i], (int)blockIdx.x - B.wg_begin[i]);
+    else v3_vote_body<false, false>(B.item[i], (int)blockIdx.x - B.wg_begin[i]);
 }
 
 // ---------------------------------------------------------------------------- v3_reduce_kernel
@@ -1552,9 +1559,11 @@ static int v3_fixed_bits_bound(int64_t n_ppfs, int n_rots, int gx, int gy, int g
     const V3Tiling t = v3_tiling(gx, gy, gz);
     const int wgs = v3_wgs(n_ppfs, t.T);
     if (t.T < v3_fused_tiles()) return v3_bits((unsigned)v3_fused_bits_pairs(n_ppfs, wgs / t.T, t.T), n_rots);   // (what v3_prepare passes)
-    // binned: chunk <= W / E <= P T / (wgs - T) records (C_t = 1 + floor(n_t E / W) >= n_t E / W), and never more than a tile's queue (<= P)
-    const int64_t E = wgs - t.T > 0 ? wgs - t.T : 1;
-    const int64_t worst = min(n_ppfs, (n_ppfs * t.T + E - 1) / E + 1);
+    // binned: the scale follows the chunks of a launch of min(wgs, V3_BITS_WGS) workgroups (v3_split): chunk <= W / E <= P T / (that - T)
+    // records (C_t = 1 + floor(n_t E / W) >= n_t E / W), and never more than a tile's queue (<= P: what E = 0 leaves, one chunk per tile)
+    const int wref = wgs < V3_BITS_WGS ? wgs : V3_BITS_WGS;
+    const int64_t E = wref - t.T;
+    const int64_t worst = E > 0 ? min(n_ppfs, (n_ppfs * t.T + E - 1) / E + 1) : n_ppfs;
     return v3_bits((unsigned)(worst > 0x7fffffff ? 0x7fffffff : worst), n_rots);
 }
 static size_t v3_workspace_bytes(int64_t n_ppfs, int gx, int gy, int gz)
@@ -1687,6 +1696,17 @@ static void v3_set_attrs()
     }
 }
 
+// the bin launch of a many-tile object: super-rounds of bin_sr x 512 pairs, as long as possible, but two workgroups for every CU first
+static size_t v3_bin_geometry(V3Args& A, dim3& bin_grid)
+{
+    int64_t srb = A.n_ppfs / ((int64_t)V3_BIN_THREADS * 512);
+    srb = srb < 1 ? 1 : (srb > V3_BIN_SR ? V3_BIN_SR : srb);
+    A.bin_sr = (int)srb;
+    const int64_t rounds = (A.n_ppfs + V3_BIN_THREADS * srb - 1) / (V3_BIN_THREADS * srb);
+    bin_grid = dim3((unsigned)(rounds < 512 ? rounds : 512));
+    return (size_t)V3_STAGE * 16 + VOTE_BELOW_N * 16 + 2 * VOTE_MAX_TILES * 4 + 64 + (V3_BIN_THREADS / 64) * (V3_IRING * 2 + (64 * V3_BIN_SR + 64) * 4);
+}
+
 static int v3_launch(const float* points, const float* outputs, const float* probs, const void* point_idxs, int idx_is_i64,
                      float* grid_obj, const float* corner, float res, int64_t n_points, int64_t n_ppfs, int n_rots, int gx, int gy,
                      int gz, int adaptive, int accumulate, bool want_argmax, long long* out_idx, float* out_val, void* workspace,
@@ -1702,13 +1722,8 @@ static int v3_launch(const float* points, const float* outputs, const float* pro
     const bool wide = n_rots > VOTE_WIN;
     v3_set_attrs();
     const size_t lds_vote = v3_vote_lds(A);
-    // super-rounds of bin_sr x 512 pairs: as long as possible, but two workgroups for every CU first
-    int64_t srb = n_ppfs / ((int64_t)V3_BIN_THREADS * 512);
-    srb = srb < 1 ? 1 : (srb > V3_BIN_SR ? V3_BIN_SR : srb);
-    A.bin_sr = (int)srb;
-    const int64_t rounds = (n_ppfs + V3_BIN_THREADS * srb - 1) / (V3_BIN_THREADS * srb);
-    const size_t lds_bin = (size_t)V3_STAGE * 16 + VOTE_BELOW_N * 16 + 2 * VOTE_MAX_TILES * 4 + 64 + (V3_BIN_THREADS / 64) * (V3_IRING * 2 + (64 * V3_BIN_SR + 64) * 4);
-    const dim3 bin_grid((unsigned)(rounds < 512 ? rounds : 512));
+    dim3 bin_grid;
+    const size_t lds_bin = v3_bin_geometry(A, bin_grid);
     const int bps = Lc.bps;
     // (two workgroups of 16 waves fill a CU: at most one round of blocks, each looping over its items)
     const dim3 red_grid((unsigned)(red_blocks < 2 * V3_WGS ? red_blocks : 2 * V3_WGS));
@@ -1902,19 +1917,29 @@ extern "C" int cppf_vote_argmax_batch(int n_items, const CppfVoteItem* items, in
     if (n_rots < 1 || n_rots > CPPF_MAX_ROTS) return CPPF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int accumulate = flags & 1;
-    const int width = cppf_vote_batch_workgroups(n_items, flags);
+    auto shares_the_launch = [&](const CppfVoteItem& it) -> bool {
+        const bool dyn = it.shape_dev != nullptr;
+        bool batched = n_rots <= VOTE_WIN && it.n_ppfs >= 1 && it.points && it.grid && it.corner && it.outputs && it.point_idxs &&
+                       it.out_idx && it.out_val && it.workspace && it.n_points >= 1;
+        if (batched && dyn) batched = it.n_ppfs <= 0xffffffffll && it.grid_capacity >= 1 &&
+                                      it.grid_capacity <= (int64_t)v3_dyn_tcap(it.many_tiles) * V3_TILE_FLOATS &&
+                                      it.workspace_bytes >= v3_workspace_bytes_dyn(it.many_tiles, it.n_ppfs);
+        if (batched && !dyn) batched = it.gx >= 1 && it.gy >= 1 && it.gz >= 1 && v3_eligible(it.n_ppfs, n_rots, it.gx, it.gy, it.gz) &&
+                                       it.workspace_bytes >= v3_workspace_bytes(it.n_ppfs, it.gx, it.gy, it.gz);
+        return batched;
+    };
+    // the default width divides the chip between the objects that SHARE the launch (a chain of four with one many-tile member, which
+    // takes its own launches, used to leave a quarter of the CUs idle during the other three's vote)
+    int n_shared = 0;
+    for (int i = 0; i < n_items; ++i) n_shared += shares_the_launch(items[i]) ? 1 : 0;
+    const int width = cppf_vote_batch_workgroups(n_shared > 0 ? n_shared : n_items, flags);
     V3Batch B = {};
     int vote_wgs = 0, red_blocks = 0;
     size_t lds_vote = 0;
     for (int i = 0; i < n_items; ++i) {
         const CppfVoteItem& it = items[i];
         const bool dyn = it.shape_dev != nullptr;
-        bool batched = n_rots <= VOTE_WIN && it.n_ppfs >= 1 && it.points && it.grid && it.corner && it.outputs && it.point_idxs &&
-                       it.out_idx && it.out_val && it.workspace && it.n_points >= 1;
-        if (batched && dyn) batched = !it.many_tiles && it.n_ppfs <= 0xffffffffll && it.grid_capacity >= 1 &&
-                                      it.grid_capacity <= 3ll * V3_TILE_FLOATS && it.workspace_bytes >= v3_workspace_bytes_dyn(0, it.n_ppfs);
-        if (batched && !dyn) batched = it.gx >= 1 && it.gy >= 1 && it.gz >= 1 && v3_eligible(it.n_ppfs, n_rots, it.gx, it.gy, it.gz) &&
-                                       v3_tiling(it.gx, it.gy, it.gz).T < v3_fused_tiles() && it.workspace_bytes >= v3_workspace_bytes(it.n_ppfs, it.gx, it.gy, it.gz);
+        const bool batched = shares_the_launch(it);
         if (!batched) {   // its own launches (and its own argument checks)
             const int rc = dyn ? cppf_vote_argmax_dyn(it.points, it.outputs, it.probs, it.point_idxs, it.idx_is_i64, it.grid, it.grid_capacity,
                                                       it.corner, it.res, it.n_points, it.n_ppfs, n_rots, it.shape_dev, it.many_tiles, adaptive,
@@ -1928,8 +1953,15 @@ extern "C" int cppf_vote_argmax_batch(int n_items, const CppfVoteItem* items, in
         V3Launch Lc;
         const int rc = v3_prepare(Lc, it.points, it.outputs, it.probs, it.point_idxs, it.idx_is_i64, it.grid, it.corner, it.res, it.n_points,
                                   it.n_ppfs, n_rots, dyn ? 1 : it.gx, dyn ? 1 : it.gy, dyn ? 1 : it.gz, adaptive, accumulate, true, it.out_idx,
-                                  it.out_val, it.workspace, it.shape_dev, dyn ? it.grid_capacity : 0, 0, nullptr, width);
+                                  it.out_val, it.workspace, it.shape_dev, dyn ? it.grid_capacity : 0, dyn ? it.many_tiles : 0, nullptr, width);
         if (rc != 0) return rc;
+        if (!Lc.A.fused) {   // a grid of >= 4 tiles: its own bin launch first; its consumer and its reduce share the launches below
+            v3_set_attrs();
+            dim3 bin_grid;
+            const size_t lds_bin = v3_bin_geometry(Lc.A, bin_grid);
+            hipLaunchKernelGGL(v3_bin_kernel<false>, bin_grid, dim3(V3_BIN_THREADS), lds_bin, st, Lc.A);
+            CPPF_CHECK_LAUNCH();
+        }
         const int k = B.n++;
         B.item[k] = Lc.A;
         B.bps[k] = Lc.bps;
@@ -1937,8 +1969,9 @@ extern "C" int cppf_vote_argmax_batch(int n_items, const CppfVoteItem* items, in
         B.red_begin[k] = red_blocks;
         vote_wgs += Lc.A.wgs;
         // reduce blocks: the batch as about one round of the chip (two 16-wave blocks per CU), never fewer than 64 per object
-        int rb = 2 * V3_WGS / n_items;
+        int rb = 2 * V3_WGS / (n_shared > 0 ? n_shared : n_items);
         rb = rb < 64 ? 64 : rb;
+        if (!Lc.A.fused && rb < V3_WGS) rb = V3_WGS;   // (many tiles: ~120 runs of cells per tile, each a chain of dependent round trips)
         red_blocks += Lc.red_blocks < rb ? Lc.red_blocks : rb;
         lds_vote = v3_vote_lds(Lc.A);
     }

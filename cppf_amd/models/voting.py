@@ -183,13 +183,13 @@ def vote_batch_workgroups(n_items, workgroups=0):
 
 
 def vote_argmax_batch(items, n_rots, adaptive, accumulate=False, workgroups=0, ws_tag="vote_b", workspaces_out=None):
-    """vote_argmax / vote_argmax_dyn for up to 8 objects enqueued together (cppf_vote_argmax_batch): the objects whose grids take
-    the fused vote (< 4 LDS tiles: every NOCS category) share ONE vote launch and ONE reduce launch, each on
-    vote_batch_workgroups(len(items), workgroups) workgroups; the others get their own launches.  `items`: dicts
+    """vote_argmax / vote_argmax_dyn for up to 8 objects enqueued together (cppf_vote_argmax_batch): the objects share ONE vote
+    launch and ONE reduce launch, each on 256 / len(items) workgroups (at least 64; `workgroups` overrides); an object whose grid
+    needs >= 4 LDS tiles (a posed object) gets its own binning launch first.  `items`: dicts
     {points, outputs, point_idxs, grid, corner, res, out_idx, out_val[, probs][, shape, many_tiles]} -- `grid` f32[gx,gy,gz], or with
     `shape` (device i32[4] {n_points, gx, gy, gz}) a flat capacity buffer as for vote_argmax_dyn.  Every object keeps its own vote
     workspace (scratch tag ws_tag + index in the current workspace scope).  Same grids, arg-max and peaks as the single calls, at
-    any width (the fixed-point scale of the fused vote does not follow the width)."""
+    any width (the fixed-point scale does not follow the width)."""
     if not 1 <= len(items) <= 8:
         raise ValueError("1 to 8 objects per call")
     L = _lib.lib()

@@ -267,15 +267,16 @@ int cppf_vote_argmax_dyn(const float* points, const float* outputs, const float*
                          size_t workspace_bytes, void* stream);
 
 /* The votes of up to 8 objects -- the instances of a frame (nocs/inference.py:120 loops over them), each with its own cloud, pair
- * list, grid, results and vote workspace -- enqueued together.  Items whose vote takes the fused kernel (a grid of < 4 LDS tiles:
- * every NOCS category; dims by value, or from a device record when shape_dev != NULL and many_tiles == 0) and n_rots <= 72 share
- * ONE vote launch and ONE reduce launch: workgroups [w_i, w_{i+1}) are item i's launch.  Each object then runs on fewer,
- * longer-lived workgroups -- cppf_vote_batch_workgroups(n_items, flags) each: 256 / n_items (at least 64) unless
- * CPPF_VOTE_WORKGROUPS(n) in `flags` says otherwise -- which divides the partial-tile traffic per object (a workgroup zeroes, dumps
- * and has read back its 113 KB tile whatever it deposits) without idling the rest of the chip, and the launch prologue is paid once.
- * Every other item gets the launches cppf_vote_argmax / cppf_vote_argmax_dyn would issue for it.  Per item the grid, arg-max and
- * peak are those of its own cppf_vote_argmax* call, bit for bit, whatever either call's width: the grid is the exact integer sum of the
- * quantised deposits and the fixed-point scale of the fused vote is that of a 64-wide launch at every width.  flags: as `accumulate` of
+ * list, grid, results and vote workspace -- enqueued together.  Items on the tiled path (a grid of <= 64 LDS tiles; dims by value,
+ * or from a device record when shape_dev != NULL) with n_rots <= 72 share ONE vote launch and ONE reduce launch: workgroups
+ * [w_i, w_{i+1}) are item i's launch; an item whose grid needs >= 4 tiles (a posed object, a fine grid) first gets its own binning
+ * launch.  Each object then runs on fewer, longer-lived workgroups -- cppf_vote_batch_workgroups(n, flags) each, n = the items that
+ * share the launch: 256 / n (at least 64) unless CPPF_VOTE_WORKGROUPS(n) in `flags` says otherwise -- which divides the partial-tile
+ * traffic per object (a workgroup zeroes, dumps and has read back its 113 KB tile whatever it deposits) without idling the rest of
+ * the chip, and the launch prologue is paid once.  Every other item (n_rots > 72, an empty pair list, a grid beyond the tiled path)
+ * gets the launches cppf_vote_argmax / cppf_vote_argmax_dyn would issue for it.  Per item the grid, arg-max and peak are those of
+ * its own cppf_vote_argmax* call, bit for bit, whatever either call's width: the grid is the exact integer sum of the quantised
+ * deposits and the fixed-point scale is that of a 64-wide launch at every width (both forms).  flags: as `accumulate` of
  * cppf_vote_argmax.  Replaces n launches of `ppf_kernel` (models/voting.py:8-66, nocs/inference.py:192-205) + np.argmax (:207-208). */
 typedef struct CppfVoteItem {
     const float* points;      /* device f32[n_points,3] */

@@ -3,9 +3,9 @@ Reference: n launches of ppf_kernel (models/voting.py:8-66, nocs/inference.py:19
 loop at nocs/inference.py:120.
 
 Per object the batched call must give the grid, arg-max and peak of its own cppf_vote_argmax call BIT FOR BIT -- at ANY width: the
-grid is the exact integer sum of the quantised deposits, whichever workgroup took whichever pair, and the fixed-point scale of the
-fused vote does not follow the launch width (csrc/vote.hip v3_fused_bits_pairs) -- and the oracle's vote within the fixed-point
-tolerance (tests/test_gpu_parity.py check_grid)."""
+grid is the exact integer sum of the quantised deposits, whichever workgroup took whichever pair, and the fixed-point scale does
+not follow the launch width (csrc/vote.hip v3_fused_bits_pairs; v3_split for grids of >= 4 tiles) -- and the oracle's vote within
+the fixed-point tolerance (tests/test_gpu_parity.py check_grid)."""
 import numpy as np
 import pytest
 import torch
@@ -85,8 +85,8 @@ def test_eight_objects_in_one_launch(oracle, dev):
 
 
 def test_mixed_batch_many_tile_and_accumulate(oracle, dev):
-    """an object whose grid needs >= 4 tiles (fine resolution) rides along with its own bin + vote + reduce launches; accumulate
-    adds to pre-filled grids (the reference's += semantics, models/voting.py:56-63)"""
+    """an object whose grid needs >= 4 tiles (fine resolution) gets its own bin launch and shares the vote + reduce launches;
+    accumulate adds to pre-filled grids (the reference's += semantics, models/voting.py:56-63)"""
     cases = [make_case("bottle", 1500, 32, 21), make_case("bottle", 2048, 32, 22, res_scale=0.5), make_case("mug", 1200, 40, 23)]
     assert _lib.lib().cppf_vote_tiles(*cases[1]["dims"]) >= 4 and _lib.lib().cppf_vote_tiles(*cases[0]["dims"]) < 4
     items = [item_of(c, dev, poison=False) for c in cases]
@@ -103,6 +103,42 @@ def test_mixed_batch_many_tile_and_accumulate(oracle, dev):
         assert torch.equal(it["grid"], one["grid"]) and int(it["out_idx"]) == int(one["out_idx"])
         check_grid(oracle, it["grid"].cpu().numpy(), c["ob"]["pc"], c["outputs"], c["idx"].astype(np.int32), c["corner"], c["dims"], c["res"],
                    72, True, grid0=np.full(c["dims"], 0.25, np.float32), bits_slack=3)
+
+
+@pytest.mark.parametrize("width", [0, 64, 128])
+def test_many_tile_members_share_the_launches_at_any_width(oracle, dev, width):
+    """grids of >= 4 tiles (a posed object's bounding box; a fine grid) beside few-tile ones, by value and shape-polymorphic (tile
+    class 16): one bin launch each, ONE vote launch and ONE reduce launch for all -- every grid, arg-max and peak equal to the
+    object's own call at full width, at 64 and at the runner's 128 (the binned vote's scale does not follow the width either)"""
+    posed = syn.make_posed_object("bottle", 1800, 41)
+    c_posed = dict(ob=posed, res=float(np.float32(posed["cfg"].res)), idx=syn.make_pairs(1800, 48, 41))
+    c_posed["outputs"] = syn.closed_form_outputs(posed["pc"], posed["pc"].mean(0).astype(np.float64), c_posed["idx"], posed["cfg"], quantise=True)
+    corners, c_posed["dims"] = grid_shape(posed["pc"], c_posed["res"])
+    c_posed["corner"] = corners[0].copy()
+    cases = [make_case("mug", 1500, 40, 42), c_posed, make_case("bottle", 2048, 32, 43, res_scale=0.5), make_case("can", 1024, 64, 44)]
+    tiles = [_lib.lib().cppf_vote_tiles(*c["dims"]) for c in cases]
+    assert tiles[0] < 4 and 4 <= tiles[1] <= 16 and 4 <= tiles[2] <= 16 and tiles[3] < 4
+    items = [item_of(c, dev) for c in cases]
+    # member 1 shape-polymorphic: a flat capacity buffer of the 16-tile class, dims in a device record
+    cap_cells = 16 * int(_lib.lib().cppf_vote_tile_cells())
+    n1 = cases[1]["ob"]["pc"].shape[0]
+    pts = torch.zeros((2048, 3), dtype=torch.float32, device=dev)
+    pts[:n1] = t(cases[1]["ob"]["pc"], dev)
+    items[1].update(points=pts, grid=torch.full((cap_cells,), float("nan"), dtype=torch.float32, device=dev),
+                    shape=torch.tensor([n1, *cases[1]["dims"]], dtype=torch.int32, device=dev), many_tiles=16)
+    for rep in range(2):
+        voting.vote_argmax_batch(items, 72, True, accumulate=False, workgroups=width)
+    torch.cuda.synchronize()
+    for j, (c, it) in enumerate(zip(cases, items)):
+        G = int(np.prod(c["dims"]))
+        got = it["grid"][:G].view(*c["dims"]) if j == 1 else it["grid"]
+        for w1 in (0, 64, 128):
+            one = single(c, dev, w1)
+            assert torch.equal(got, one["grid"]), (j, w1)
+            assert int(it["out_idx"]) == int(one["out_idx"]) and float(it["out_val"]) == float(one["out_val"]), (j, w1)
+        g64, _ = check_grid(oracle, got.cpu().numpy(), c["ob"]["pc"], c["outputs"], c["idx"].astype(np.int32), c["corner"], c["dims"],
+                            c["res"], 72, True)
+        assert int(it["out_idx"]) == int(np.argmax(g64))
 
 
 def test_batched_dyn_items_equal_by_value(oracle, dev):
