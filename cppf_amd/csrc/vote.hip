@@ -1363,7 +1363,7 @@ __device__ __forceinline__ void v3_rezero(V3Hdr* h)
 __device__ __forceinline__ void v3_reduce_body(const V3Args& A, const int bps, const int bid, const int nblocks)
 {
     __shared__ unsigned long long part[RED_GROUPS][RED_CELLS];
-    __shared__ unsigned long long wkey[RED_CELLS / 64];
+    __shared__ unsigned long long wkey[RED_GROUPS];
     __shared__ int sp[200];
     const int tid = threadIdx.x, lane = tid & 63, cg = tid >> 6;
     if (bid == 0 && tid == 0) {   // rotation table left by the vote kernel of this call: valid from the next launch on
@@ -1415,6 +1415,67 @@ __device__ __forceinline__ void v3_reduce_body(const V3Args& A, const int bps, c
     const bool raw = hfmt == 0u;
     const bool any_extra = hextra != 0u;
     unsigned long long best = 0ull;   // this thread's arg-max key over the block's items
+    // Narrow launches over many tiles (a posed object as one of a batch's members: 64-128 workgroups over ~10 tiles, i.e. 6-12 partial
+    // tiles per tile where the block-wide form below is laid out for 128: ten of its sixteen waves had nothing to add, and a block's
+    // ~5 items were five chains of dependent round trips one after the other): every WAVE takes an item of its own -- the few
+    // chunks in flight together, then the lane's four cells finished in registers -- sixteen items per block and trip, no barrier.
+    const bool wave_items = !A.fused && A.wgs <= 128;   // (workgroup-uniform: a block serves one object)
+    if (wave_items) {
+        for (int item = bid * RED_GROUPS + cg; item < T * bps; item += nblocks * RED_GROUPS) {
+            const int t = item / bps, j = item - t * bps;
+            const int tix = t / pt.nty, tiy = t - tix * pt.nty;
+            const int x0 = tix * pt.tx, y0 = tiy * pt.ty;
+            const int tx = min(pt.tx, gx - x0), ty = min(pt.ty, gy - y0);
+            const int tyh = pt.ty + pt.hy, ltyz = tyh * gz;
+            const int nwords = (tx + pt.hx) * ltyz;
+            const int k0 = j * RED_CELLS + lane * 4;
+            if (k0 >= nwords) continue;   // (k0 + 3 < slot: both are multiples of 4)
+            const int C = sp[t], base_b = sp[64 + t];
+            const unsigned n_own = (unsigned)sp[128 + t];
+            unsigned long long acc[4] = {0ull, 0ull, 0ull, 0ull};
+            float facc[4] = {0.f, 0.f, 0.f, 0.f};
+            const uint32_t* base = A.partials + (int64_t)base_b * slot + k0;
+            auto add = [&](const uint4 v) {
+                if (raw) { acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w; }
+                else { facc[0] += __uint_as_float(v.x); facc[1] += __uint_as_float(v.y); facc[2] += __uint_as_float(v.z); facc[3] += __uint_as_float(v.w); }
+            };
+            const bool full = n_own >= 64u * (unsigned)C;
+            int c = 0;
+            if (full) {
+                for (; c + 3 < C; c += 4) {
+                    uint4 v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const uint4*>(base + (int64_t)(c + q) * slot);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) add(v[q]);
+                }
+            }
+            for (; c < C; ++c)
+                if (full || v3_chunk_live(n_own, c, C, base_b + c)) add(*reinterpret_cast<const uint4*>(base + (int64_t)c * slot));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u;
+                if (k >= nwords) continue;
+                const int lx = k / ltyz, rem = k - lx * ltyz, ly = rem / gz, z = rem - ly * gz;
+                if (!(lx < tx && ly < ty)) continue;   // a halo word: the owner's cell got it through the extra plane
+                const int64_t cell = ((int64_t)(x0 + lx) * gy + (y0 + ly)) * gz + z;
+                const unsigned long long ext = any_extra ? A.plane[cell] : 0ull;
+                if (ext) A.plane[cell] = 0ull;
+                float v;
+                if (raw) {
+                    const unsigned long long s_ = ext + acc[u];
+                    if (A.grid_raw) A.grid_raw[cell] = (long long)s_ + (A.accumulate ? A.grid_raw[cell] : 0ll);
+                    v = (float)((double)s_ * (double)hquantum);
+                } else {
+                    v = __uint_as_float((uint32_t)ext) + facc[u];
+                }
+                if (A.accumulate && A.grid) v = A.grid[cell] + v;
+                if (A.grid) A.grid[cell] = v;
+                const unsigned long long key = ((unsigned long long)f2ord(v) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)cell);
+                best = key > best ? key : best;
+            }
+        }
+    } else
     // a block takes the items (tile t, run j of RED_CELLS words) blockIdx, blockIdx + gridDim, ...: header, split and the two reports
     // once per block, not once per item (a grid of 16 tiles has 1 760 items)
     for (int item = bid; item < T * bps; item += nblocks) {
@@ -1496,11 +1557,8 @@ __device__ __forceinline__ void v3_reduce_body(const V3Args& A, const int bps, c
     }
     __syncthreads();   // (part: the next item's sums)
     }
-    unsigned long long key = best;
-    if (tid < RED_CELLS) {
-        key = wave_max_u64(key);
-        if (lane == 0) wkey[cg] = key;
-    }
+    unsigned long long key = wave_max_u64(best);   // (block-wide form: only the first RED_CELLS threads own cells, the others hold 0)
+    if (lane == 0) wkey[cg] = key;
     // two-level arg-max (see reduce_tiles_kernel): block b reports to group b mod V3_RED_FANIN, a group's last reporter reports for it.
     // A group's {key, count} sits in the spare words 2..5 of queue-counter line g of the header -- one 128-byte line, i.e. one L2 channel,
     // per group: in the caller's `packed` array the eight groups of round 2 shared one line and their atomics queued behind each other
@@ -1510,7 +1568,7 @@ __device__ __forceinline__ void v3_reduce_body(const V3Args& A, const int bps, c
     const unsigned n_groups_used = (unsigned)nblocks < V3_RED_FANIN ? (unsigned)nblocks : V3_RED_FANIN;
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < RED_CELLS / 64; ++w) key = wkey[w] > key ? wkey[w] : key;
+        for (int w = 1; w < RED_GROUPS; ++w) key = wkey[w] > key ? wkey[w] : key;
         auto report = [](unsigned long long* slot_, unsigned long long k_) -> unsigned {
             const unsigned long long old = atomicMax(slot_, k_);
             unsigned d1 = (unsigned)old, d2;
