@@ -1557,8 +1557,12 @@ __device__ __forceinline__ void v3_reduce_body(const V3Args& A, const int bps, c
     }
     __syncthreads();   // (part: the next item's sums)
     }
-    unsigned long long key = wave_max_u64(best);   // (block-wide form: only the first RED_CELLS threads own cells, the others hold 0)
-    if (lane == 0) wkey[cg] = key;
+    unsigned long long key = best;
+    const int n_wkeys = wave_items ? RED_GROUPS : RED_CELLS / 64;   // (block-wide form: only the first RED_CELLS threads own cells)
+    if (cg < n_wkeys) {
+        key = wave_max_u64(key);
+        if (lane == 0) wkey[cg] = key;
+    }
     // two-level arg-max (see reduce_tiles_kernel): block b reports to group b mod V3_RED_FANIN, a group's last reporter reports for it.
     // A group's {key, count} sits in the spare words 2..5 of queue-counter line g of the header -- one 128-byte line, i.e. one L2 channel,
     // per group: in the caller's `packed` array the eight groups of round 2 shared one line and their atomics queued behind each other
@@ -1568,7 +1572,7 @@ __device__ __forceinline__ void v3_reduce_body(const V3Args& A, const int bps, c
     const unsigned n_groups_used = (unsigned)nblocks < V3_RED_FANIN ? (unsigned)nblocks : V3_RED_FANIN;
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < RED_GROUPS; ++w) key = wkey[w] > key ? wkey[w] : key;
+        for (int w = 1; w < n_wkeys; ++w) key = wkey[w] > key ? wkey[w] : key;
         auto report = [](unsigned long long* slot_, unsigned long long k_) -> unsigned {
             const unsigned long long old = atomicMax(slot_, k_);
             unsigned d1 = (unsigned)old, d2;
