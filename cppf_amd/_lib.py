@@ -37,6 +37,8 @@ _SIGS = {
     "cppf_knn_dyn": (C.c_int, [vp, i32, vp, i32, vp, vp]),
     "cppf_point_encoder_forward_dyn": (C.c_int, [vp, vp, vp, i32, vp, i32, vp, C.POINTER(C.c_int), i32, i32, i32, i32, i32, i32,
                                                  vp, vp, sz, vp]),
+    "cppf_gather_words": (C.c_int, [i32, vp, i64, vp, vp]),
+    "cppf_frame_cloud_dyn_batch": (C.c_int, [i32, vp, vp, i32, vp, i32, i32, i32, vp, C.c_double, vp]),
     "cppf_point_encoder_forward_batch": (C.c_int, [i32, vp, i32, C.POINTER(C.c_int), i32, i32, i32, i32, i32, i32, vp]),
     "cppf_grid_argmax": (C.c_int, [vp, i64, vp, vp, vp, sz, vp]),
     "cppf_center_from_argmax": (C.c_int, [vp, vp, C.c_double, i32, i32, vp, vp, vp, vp, vp]),
@@ -137,6 +139,14 @@ class StageItem(C.Structure):
 
 
 STAGE_DESC_WORDS = 6
+
+
+class FrameCloudItem(C.Structure):
+    """include/cppf.h: CppfFrameCloudItem (one instance of cppf_frame_cloud_dyn_batch)"""
+    _fields_ = [("label_bit_dev", C.c_void_p), ("seed_dev", C.c_void_p), ("pc_out", C.c_void_p), ("nrm_out", C.c_void_p),
+                ("corner_out", C.c_void_p), ("shape_out", C.c_void_p), ("nbrs_out", C.c_void_p), ("idx", C.c_void_p), ("u_tr", C.c_void_p),
+                ("u_rot", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("res", C.c_double),
+                ("n_pairs", C.c_int64), ("knn_k", C.c_int32), ("k_min", C.c_int32), ("n_cap", C.c_int32), ("idx_is_i64", C.c_int32)]
 
 
 class PointEncItem(C.Structure):

@@ -23,6 +23,22 @@ def copy_words(dst, src, device):
         _lib.check(_lib.lib().cppf_copy_words(dst.data_ptr(), src.data_ptr(), n, stream_ptr(device)), "cppf_copy_words")
 
 
+def gather_words(dst, srcs, device):
+    """dst[r] <- srcs[r] (dst: [len(srcs), W] of 8-byte elements or an equivalent view; srcs: device tensors of at least W such words
+    each, in different allocations) with ONE launch on the current stream (cppf_gather_words) instead of a small copy per row"""
+    import ctypes as C
+    n = len(srcs)
+    if n == 0:
+        return
+    words = dst.numel() * dst.element_size() // 8 // n
+    assert dst.is_contiguous() and dst.numel() * dst.element_size() == n * words * 8
+    for i in range(0, n, 32):
+        part = srcs[i:i + 32]
+        ptrs = (C.c_void_p * len(part))(*[t_.data_ptr() for t_ in part])
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().cppf_gather_words(len(part), ptrs, words, dst.data_ptr() + i * words * 8, stream_ptr(device)), "cppf_gather_words")
+
+
 _lane_cache = {}
 
 

@@ -2,6 +2,7 @@
 // compaction, orientation vote + sphere-bin count, axis sign / scale reductions, grid set-up (nocs/inference.py:194-195,209-339).
 // C ABI in include/cppf.h; reference semantics cited per kernel.  (Split from vote.hip in round 5; the centre vote stays there.)
 #include "vote_common.h"
+#include "compact.h"
 
 // nocs/inference.py:209-210: cand = unravel_index(argmax); T = corners[0] + cand * res in fp64;
 // T32 is the float32 copy handed to backvote (:225).
@@ -427,7 +428,6 @@ extern "C" int cppf_backvote_dyn(const float* points, const float* outputs, floa
 // ----------------------------------------------------------------------------- compaction
 // surv = nonzero(mask) in increasing order (point_idxs[mask], nocs/inference.py:231).
 // Three small kernels: per-block counts, one-block scan of the counts, scatter.
-#define CMP_BLOCK 1024
 __global__ __launch_bounds__(CMP_BLOCK) void compact_count_kernel(const uint8_t* __restrict__ mask, int64_t n,
                                                                    int32_t* __restrict__ block_counts)
 {
@@ -492,36 +492,8 @@ __global__ __launch_bounds__(CMP_BLOCK) void compact_scatter_kernel(const uint8_
     }
 }
 
-// cppf_compact_scatter: the scatter step alone, for chunk counts that already exist (cppf_backvote_count): every block sums
-// the counts of the chunks before its own (<= CMP_SELF_MAX of them, from L2) instead of waiting for a scan kernel.
-#define CMP_SELF_MAX 8192
+// cppf_compact_scatter: the scatter step alone, for chunk counts that already exist (cppf_backvote_count): compact.h
 static_assert(CMP_BLOCK == 1024, "backvote_kernel counts survivors per chunk of 1 << 10 pairs");
-__device__ __forceinline__ void compact_scatter_self_body(const uint8_t* __restrict__ mask, int64_t n,
-                                                          const int32_t* __restrict__ chunk_counts,
-                                                          int32_t* __restrict__ surv, int32_t* __restrict__ total)
-{
-    const unsigned nblocks = (unsigned)((n + CMP_BLOCK - 1) / CMP_BLOCK);   // (a batched launch is as wide as its longest list)
-    if (blockIdx.x >= nblocks) return;
-    __shared__ int wsum[CMP_BLOCK / 64];
-    __shared__ int wpre[CMP_BLOCK / 64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int before = 0;
-    for (int k = threadIdx.x; k < (int)blockIdx.x; k += CMP_BLOCK) before += chunk_counts[k];
-    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
-    const int64_t i = (int64_t)blockIdx.x * CMP_BLOCK + threadIdx.x;
-    const bool f = i < n && mask[i] != 0;
-    const unsigned long long b = __ballot(f);
-    if (lane == 0) { wsum[w] = __popcll(b); wpre[w] = before; }
-    __syncthreads();
-    int woff = 0, base = 0;
-    for (int k = 0; k < CMP_BLOCK / 64; ++k) { base += wpre[k]; woff += k < w ? wsum[k] : 0; }
-    if (f) surv[base + woff + __popcll(b & ((1ull << lane) - 1ull))] = (int32_t)i;
-    if (blockIdx.x == nblocks - 1 && threadIdx.x == 0) {
-        int own = 0;
-        for (int k = 0; k < CMP_BLOCK / 64; ++k) own += wsum[k];
-        *total = base + own;
-    }
-}
 __global__ __launch_bounds__(CMP_BLOCK) void compact_scatter_self_kernel(const uint8_t* __restrict__ mask, int64_t n,
                                                                           const int32_t* __restrict__ chunk_counts,
                                                                           int32_t* __restrict__ surv, int32_t* __restrict__ total)

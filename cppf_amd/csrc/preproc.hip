@@ -9,7 +9,9 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
+#include <string.h>
 #include "../../include/cppf.h"
+#include "compact.h"
 
 namespace {
 
@@ -168,10 +170,10 @@ __global__ __launch_bounds__(256) void fc_clear_kernel(unsigned long long* __res
 // flips of :136-137 (negations of utils/util.py:629-630's negations: exact), `.float()` of :140, the voxel key (vox_keys_kernel) and
 // the point's entry in the table
 template <typename T>
-__global__ __launch_bounds__(256) void fc_points_kernel(const T* __restrict__ depth, const int32_t* __restrict__ pix,
-                                                        const int32_t* __restrict__ count, int W, Kinv K, double divisor, double res,
-                                                        int n_cap, float* __restrict__ pcf, unsigned long long* __restrict__ keys,
-                                                        unsigned long long* __restrict__ tkeys, int32_t* __restrict__ tidx, unsigned tmask)
+__device__ __forceinline__ void fc_points_body(const T* __restrict__ depth, const int32_t* __restrict__ pix,
+                                               const int32_t* __restrict__ count, int W, const Kinv& K, double divisor, double res,
+                                               int n_cap, float* __restrict__ pcf, unsigned long long* __restrict__ keys,
+                                               unsigned long long* __restrict__ tkeys, int32_t* __restrict__ tidx, unsigned tmask)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= min(*count, n_cap)) return;
@@ -195,6 +197,23 @@ __global__ __launch_bounds__(256) void fc_points_kernel(const T* __restrict__ de
         if (prev == FC_EMPTY || prev == k) { atomicMin(&tidx[h], i); break; }
     }
 }
+template <typename T>
+__global__ __launch_bounds__(256) void fc_points_kernel(const T* __restrict__ depth, const int32_t* __restrict__ pix,
+                                                        const int32_t* __restrict__ count, int W, Kinv K, double divisor, double res,
+                                                        int n_cap, float* __restrict__ pcf, unsigned long long* __restrict__ keys,
+                                                        unsigned long long* __restrict__ tkeys, int32_t* __restrict__ tidx, unsigned tmask)
+{
+    fc_points_body<T>(depth, pix, count, W, K, divisor, res, n_cap, pcf, keys, tkeys, tidx, tmask);
+}
+// does point i represent its voxel (the lowest index among the points of its key)?
+__device__ __forceinline__ bool fc_is_representative(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ tkeys,
+                                                     const int32_t* __restrict__ tidx, unsigned tmask, int i)
+{
+    const unsigned long long k = keys[i];
+    unsigned h = fc_hash(k, tmask);
+    while (tkeys[h] != k) h = (h + 1) & tmask;      // (the key is in the table: this point put it there or found it there)
+    return tidx[h] == i;
+}
 __global__ __launch_bounds__(256) void fc_mark_kernel(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ tkeys,
                                                       const int32_t* __restrict__ tidx, unsigned tmask, const int32_t* __restrict__ count,
                                                       int n_cap, uint8_t* __restrict__ mask)
@@ -202,12 +221,7 @@ __global__ __launch_bounds__(256) void fc_mark_kernel(const unsigned long long* 
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_cap) return;
     uint8_t m = 0;
-    if (i < min(*count, n_cap)) {
-        const unsigned long long k = keys[i];
-        unsigned h = fc_hash(k, tmask);
-        while (tkeys[h] != k) h = (h + 1) & tmask;      // (the key is in the table: this point put it there or found it there)
-        m = tidx[h] == i;
-    }
+    if (i < min(*count, n_cap)) m = fc_is_representative(keys, tkeys, tidx, tmask, i);
     mask[i] = m;
 }
 // pc = pc[keep] (:141) into the pipeline's cloud buffer; the instance's point count N (0 when it is below k_min: the reference
@@ -223,8 +237,8 @@ __global__ __launch_bounds__(256) void fc_gather_kernel(const float* __restrict_
     const int s = keep[i];
     pc_out[3 * i] = pcf[3 * s]; pc_out[3 * i + 1] = pcf[3 * s + 1]; pc_out[3 * i + 2] = pcf[3 * s + 2];
 }
-__global__ __launch_bounds__(256) void fc_normals_kernel(const float* __restrict__ pc, const int32_t* __restrict__ nbrs,
-                                                         const int32_t* __restrict__ n_dev, int k, float* __restrict__ normals)
+__device__ __forceinline__ void fc_normals_body(const float* __restrict__ pc, const int32_t* __restrict__ nbrs,
+                                                const int32_t* __restrict__ n_dev, int k, float* __restrict__ normals)
 {
     const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (n >= *n_dev) return;
@@ -243,14 +257,19 @@ __global__ __launch_bounds__(256) void fc_normals_kernel(const float* __restrict
 #pragma unroll
     for (int i = 0; i < 3; ++i) normals[3 * n + i] = (float)v[i];
 }
+__global__ __launch_bounds__(256) void fc_normals_kernel(const float* __restrict__ pc, const int32_t* __restrict__ nbrs,
+                                                         const int32_t* __restrict__ n_dev, int k, float* __restrict__ normals)
+{
+    fc_normals_body(pc, nbrs, n_dev, k, normals);
+}
 // nocs/inference.py:194-195 from the device count: corner = min(pc), dims = int32((max - min) / res) + 1 -> shape[1..3]
-__global__ __launch_bounds__(1024) void fc_grid_kernel(const float* __restrict__ pc, float res, float* __restrict__ corner,
-                                                       int32_t* __restrict__ shape)
+// (minima and maxima: exact in any order, whatever the block size)
+__device__ __forceinline__ void fc_grid_body(const float* __restrict__ pc, float res, float* __restrict__ corner, int32_t* __restrict__ shape)
 {
     __shared__ float slo[16][3], shi[16][3];
     const int N = shape[0];
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = threadIdx.x; i < N; i += 1024)
+    for (int i = threadIdx.x; i < N; i += (int)blockDim.x)
         for (int j = 0; j < 3; ++j) {
             const float v = pc[3 * i + j];
             lo[j] = fminf(lo[j], v);
@@ -267,10 +286,15 @@ __global__ __launch_bounds__(1024) void fc_grid_kernel(const float* __restrict__
     if (threadIdx.x < 3) {
         const int j = threadIdx.x;
         float l = slo[0][j], h = shi[0][j];
-        for (int w = 1; w < 16; ++w) { l = fminf(l, slo[w][j]); h = fmaxf(h, shi[w][j]); }
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { l = fminf(l, slo[w][j]); h = fmaxf(h, shi[w][j]); }
         corner[j] = N > 0 ? l : 0.f;
         shape[1 + j] = N > 0 ? (int32_t)((h - l) / res) + 1 : 1;
     }
+}
+__global__ __launch_bounds__(1024) void fc_grid_kernel(const float* __restrict__ pc, float res, float* __restrict__ corner,
+                                                       int32_t* __restrict__ shape)
+{
+    fc_grid_body(pc, res, corner, shape);
 }
 // idx = idx mod N (both columns): pairs drawn as full-range integers on the device before the instance's N is known anywhere but here
 __global__ __launch_bounds__(256) void mod_pairs_kernel(long long* __restrict__ idx, int64_t n2, const int32_t* __restrict__ n_dev)
@@ -399,6 +423,109 @@ __global__ __launch_bounds__(256) void stage_batch_kernel(StageBatch B)
     }
 }
 
+// ---- cppf_frame_cloud_dyn_batch: the frame stage of up to 8 instances of ONE frame in eight launches instead of sixteen each.
+// A frame's chain is launch-bound on the host (a hipGraph launch costs the host per kernel node: three chains of two instances, 52
+// nodes each, took 1.2 of a frame's 1.6 ms to enqueue) and its ~15 pre-processing kernels per instance run for ~5 us each.  Here a
+// launch serves every member (blockIdx.y) and neighbouring steps share launches: the mask kernels count their own 1 024-byte chunks
+// (no count + scan launches: compact.h), the first one clears the voxel table on the way, the normals launch also sets up the grid
+// and draws the pairs.  Per member the arithmetic is that of cppf_frame_cloud_dyn + cppf_sample_pairs (the same device functions).
+#define FCB_MAX 8
+struct FcbItem {
+    const int32_t* bit_dev; const unsigned long long* seed_dev;
+    uint8_t *valid, *mask2;
+    int32_t *cc1, *cc2, *pix, *count1, *count2, *tidx, *keep, *nbrs, *shape_out;
+    float *pcf, *pc_out, *nrm_out, *corner_out, *u_tr, *u_rot;
+    unsigned long long *keys, *tkeys;
+    void* idx;
+    double res;
+    long long n_pairs;
+    int knn_k, k_min, n_cap, M, idx_is_i64;
+};
+struct FcbBatch { FcbItem item[FCB_MAX]; const void* depth; const void* labels; long long n_pix; Kinv K; double divisor; int W, label_bytes, n_sample_blocks; };
+static_assert(sizeof(FcbBatch) <= 4096, "FcbBatch travels by value: kernel arguments are limited to 4 KB");
+
+// 1. valid pixels of every member's label bit + their chunk counts; the member's voxel table cleared on the way
+template <typename T>
+__global__ __launch_bounds__(CMP_BLOCK) void fcb_valid_kernel(FcbBatch B)
+{
+    const FcbItem& I = B.item[blockIdx.y];
+    const long long i = (long long)blockIdx.x * CMP_BLOCK + threadIdx.x;
+    for (long long k = i; k < I.M; k += (long long)gridDim.x * CMP_BLOCK) { I.tkeys[k] = FC_EMPTY; I.tidx[k] = 0x7fffffff; }
+    bool f = false;
+    if (i < B.n_pix) {
+        const T d = static_cast<const T*>(B.depth)[i];
+        unsigned lab;
+        if (B.label_bytes == 1) lab = static_cast<const uint8_t*>(B.labels)[i];
+        else if (B.label_bytes == 2) lab = static_cast<const uint16_t*>(B.labels)[i];
+        else lab = static_cast<const uint32_t*>(B.labels)[i];
+        const unsigned bit = (unsigned)*I.bit_dev & (8u * (unsigned)B.label_bytes - 1u);
+        f = ((lab >> bit) & 1u) && (d > (T)0);
+        I.valid[i] = f;
+    }
+    const int s = compact_chunk_count(f);
+    if (threadIdx.x == 0) I.cc1[blockIdx.x] = s;
+}
+// 2. / 5. the compactions (np.where order, :612; pc[keep], :140-141)
+__global__ __launch_bounds__(CMP_BLOCK) void fcb_scatter_kernel(FcbBatch B, int second)
+{
+    const FcbItem& I = B.item[blockIdx.y];
+    if (second) compact_scatter_self_body(I.mask2, I.n_cap, I.cc2, I.keep, I.count2);
+    else compact_scatter_self_body(I.valid, B.n_pix, I.cc1, I.pix, I.count1);
+}
+// 3. back-projection, voxel keys, table inserts
+template <typename T>
+__global__ __launch_bounds__(256) void fcb_points_kernel(FcbBatch B)
+{
+    const FcbItem& I = B.item[blockIdx.y];
+    fc_points_body<T>(static_cast<const T*>(B.depth), I.pix, I.count1, B.W, B.K, B.divisor, I.res, I.n_cap, I.pcf, I.keys, I.tkeys, I.tidx,
+                      (unsigned)I.M - 1u);
+}
+// 4. the representatives of the voxels + their chunk counts
+__global__ __launch_bounds__(CMP_BLOCK) void fcb_mark_kernel(FcbBatch B)
+{
+    const FcbItem& I = B.item[blockIdx.y];
+    const int i = blockIdx.x * CMP_BLOCK + threadIdx.x;
+    if ((long long)blockIdx.x * CMP_BLOCK >= I.n_cap) return;      // (a shorter member: workgroup-uniform)
+    bool f = false;
+    if (i < I.n_cap) {
+        if (i < min(*I.count1, I.n_cap)) f = fc_is_representative(I.keys, I.tkeys, I.tidx, (unsigned)I.M - 1u, i);
+        I.mask2[i] = f;
+    }
+    const int s = compact_chunk_count(f);
+    if (threadIdx.x == 0) I.cc2[blockIdx.x] = s;
+}
+// 6. pc = pc[keep], the point count
+__global__ __launch_bounds__(256) void fcb_gather_kernel(FcbBatch B)
+{
+    const FcbItem& I = B.item[blockIdx.y];
+    const int n = min(*I.count2, I.n_cap);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) I.shape_out[0] = n >= I.k_min ? n : 0;
+    if (i >= n) return;
+    const int sidx = I.keep[i];
+    I.pc_out[3 * i] = I.pcf[3 * sidx]; I.pc_out[3 * i + 1] = I.pcf[3 * sidx + 1]; I.pc_out[3 * i + 2] = I.pcf[3 * sidx + 2];
+}
+// 8. (7 = the neighbour search, sprin.hip) normals on blocks [0, nbc), the grid set-up on block nbc, the pair / uniform draws behind it
+__global__ __launch_bounds__(256) void fcb_finish_kernel(FcbBatch B, int nbc)
+{
+    const FcbItem& I = B.item[blockIdx.y];
+    if ((int)blockIdx.x < nbc) { fc_normals_body(I.pc_out, I.nbrs, I.shape_out, I.knn_k, I.nrm_out); return; }
+    if ((int)blockIdx.x == nbc) { fc_grid_body(I.pc_out, (float)I.res, I.corner_out, I.shape_out); return; }
+    if (!I.idx) return;
+    const unsigned long long N = (unsigned long long)(long long)I.shape_out[0], seed = *I.seed_dev;
+    const uint2 key = make_uint2((unsigned)seed, (unsigned)(seed >> 32));
+    const long long first = (long long)((int)blockIdx.x - nbc - 1) * 256 + threadIdx.x, step = (long long)B.n_sample_blocks * 256;
+    for (long long p = first; p < I.n_pairs; p += step) {
+        const uint4 a = philox4x32_10(make_uint4((unsigned)p, (unsigned)(p >> 32), 0u, 0u), key);
+        const uint4 b = philox4x32_10(make_uint4((unsigned)p, (unsigned)(p >> 32), 1u, 0u), key);
+        const unsigned long long i0 = ((unsigned long long)a.x * N) >> 32, i1 = ((unsigned long long)a.y * N) >> 32;
+        if (I.idx_is_i64) reinterpret_cast<longlong2*>(I.idx)[p] = make_longlong2((long long)i0, (long long)i1);
+        else reinterpret_cast<int2*>(I.idx)[p] = make_int2((int)i0, (int)i1);
+        if (I.u_tr) reinterpret_cast<float2*>(I.u_tr)[p] = make_float2((float)(a.z >> 8) * 0x1p-24f, (float)(a.w >> 8) * 0x1p-24f);
+        if (I.u_rot) reinterpret_cast<float2*>(I.u_rot)[p] = make_float2((float)(b.x >> 8) * 0x1p-24f, (float)(b.y >> 8) * 0x1p-24f);
+    }
+}
+
 // cppf_copy_words: a few 64-bit words moved by a kernel of the stream instead of by a copy engine.  hipMemcpyAsync hands small copies to
 // the SDMA engines, whose queues are shared between streams and served in order: a 200-byte descriptor copy of lane 0 then waits
 // behind the caller's stream's read-back, which waits for the previous batch -- a false dependency that (depending on which engine
@@ -406,6 +533,16 @@ __global__ __launch_bounds__(256) void stage_batch_kernel(StageBatch B)
 __global__ __launch_bounds__(256) void copy_words_kernel(unsigned long long* __restrict__ dst, const unsigned long long* __restrict__ src, int64_t n)
 {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+// cppf_gather_words: row r of dst <- the first n_words 64-bit words at src[r] (up to 32 rows, one launch): the records / shape words of
+// a chain's members, each in its own pipeline's buffers, into one array -- instead of one small copy per member
+#define GATHER_MAX 32
+struct GatherRows { const unsigned long long* src[GATHER_MAX]; };
+__global__ __launch_bounds__(64) void gather_words_kernel(GatherRows G, unsigned long long* __restrict__ dst, int n_words)
+{
+    const unsigned long long* s_ = G.src[blockIdx.x];
+    for (int t = threadIdx.x; t < n_words; t += 64) dst[(size_t)blockIdx.x * n_words + t] = s_[t];
 }
 
 struct VoxLayout { size_t keys, vals, mask, compact, temp, temp_bytes, total; };
@@ -561,6 +698,67 @@ int cppf_frame_cloud_dyn_bit(const void* depth, int depth_is_u16, const void* la
                             pc_out, nrm_out, corner_out, shape_out, nbrs_out, workspace, workspace_bytes, stream);
 }
 
+int cppf_frame_cloud_dyn_batch(int n_items, const CppfFrameCloudItem* items, const void* depth, int depth_is_u16, const void* labels,
+                               int label_bytes, int H, int W, const double* kinv_host, double divisor, void* stream)
+{
+    if (n_items < 1 || n_items > FCB_MAX || !items) return CPPF_EINVAL;
+    if (H < 1 || W < 1 || (int64_t)H * W > 0x7fffffffll || !depth || !labels || !kinv_host || !(divisor > 0.0)) return CPPF_EINVAL;
+    if (label_bytes != 1 && label_bytes != 2 && label_bytes != 4) return CPPF_EINVAL;
+    const int64_t n = (int64_t)H * W;
+    if ((n + CMP_BLOCK - 1) / CMP_BLOCK > CMP_SELF_MAX) return CPPF_EUNSUPPORTED;
+    FcbBatch B;
+    memset(&B, 0, sizeof(B));
+    B.depth = depth; B.labels = labels; B.n_pix = n; B.divisor = divisor; B.W = W; B.label_bytes = label_bytes;
+    for (int i = 0; i < 9; ++i) B.K.k[i] = kinv_host[i];
+    CppfKnnBatchItem knn[FCB_MAX];
+    int cap_max = 0;
+    int64_t max_pairs = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const CppfFrameCloudItem& it = items[i];
+        if (!it.label_bit_dev || !it.pc_out || !it.nrm_out || !it.corner_out || !it.shape_out) return CPPF_EINVAL;
+        if (it.n_cap < 1 || it.knn_k < 1 || it.knn_k > 64 || it.knn_k > it.n_cap || it.k_min < it.knn_k || !(it.res > 0.0)) return CPPF_EINVAL;
+        if (it.n_pairs < 0 || (it.n_pairs > 0 && (!it.idx || !it.seed_dev || (reinterpret_cast<uintptr_t>(it.idx) & (it.idx_is_i64 ? 15 : 7)))))
+            return CPPF_EINVAL;
+        const FcLayout L = fc_layout(H, W, it.n_cap, it.knn_k);
+        if (!it.workspace || it.workspace_bytes < L.total) return CPPF_EWORKSPACE;
+        char* ws = static_cast<char*>(it.workspace);
+        FcbItem& I = B.item[i];
+        I.bit_dev = it.label_bit_dev; I.seed_dev = it.seed_dev;
+        I.valid = (uint8_t*)(ws + L.valid); I.mask2 = (uint8_t*)(ws + L.mask2);
+        I.cc1 = (int32_t*)(ws + L.cmp1); I.cc2 = (int32_t*)(ws + L.cmp2); I.pix = (int32_t*)(ws + L.pix);
+        I.count1 = (int32_t*)(ws + L.count); I.count2 = (int32_t*)(ws + L.count + 64);
+        I.tidx = (int32_t*)(ws + L.tidx); I.keep = (int32_t*)(ws + L.keep); I.nbrs = it.nbrs_out ? it.nbrs_out : (int32_t*)(ws + L.nbrs);
+        I.shape_out = it.shape_out; I.pcf = (float*)(ws + L.pcf); I.pc_out = it.pc_out; I.nrm_out = it.nrm_out; I.corner_out = it.corner_out;
+        I.u_tr = it.u_tr; I.u_rot = it.u_rot; I.keys = (unsigned long long*)(ws + L.keys); I.tkeys = (unsigned long long*)(ws + L.tkeys);
+        I.idx = it.n_pairs > 0 ? it.idx : nullptr; I.res = it.res; I.n_pairs = it.n_pairs;
+        I.knn_k = it.knn_k; I.k_min = it.k_min; I.n_cap = it.n_cap; I.M = L.M; I.idx_is_i64 = it.idx_is_i64;
+        knn[i] = CppfKnnBatchItem{it.pc_out, I.nbrs, it.shape_out, it.n_cap, it.knn_k};
+        cap_max = it.n_cap > cap_max ? it.n_cap : cap_max;
+        max_pairs = it.n_pairs > max_pairs ? it.n_pairs : max_pairs;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned ni = (unsigned)n_items;
+    const unsigned nbp = (unsigned)((n + CMP_BLOCK - 1) / CMP_BLOCK), nbc = (unsigned)((cap_max + 255) / 256),
+                   nbc4 = (unsigned)((cap_max + CMP_BLOCK - 1) / CMP_BLOCK);
+    if (depth_is_u16) fcb_valid_kernel<uint16_t><<<dim3(nbp, ni), CMP_BLOCK, 0, st>>>(B);
+    else fcb_valid_kernel<float><<<dim3(nbp, ni), CMP_BLOCK, 0, st>>>(B);
+    fcb_scatter_kernel<<<dim3(nbp, ni), CMP_BLOCK, 0, st>>>(B, 0);
+    if (depth_is_u16) fcb_points_kernel<uint16_t><<<dim3(nbc, ni), 256, 0, st>>>(B);
+    else fcb_points_kernel<float><<<dim3(nbc, ni), 256, 0, st>>>(B);
+    fcb_mark_kernel<<<dim3(nbc4, ni), CMP_BLOCK, 0, st>>>(B);
+    fcb_scatter_kernel<<<dim3(nbc4, ni), CMP_BLOCK, 0, st>>>(B, 1);
+    fcb_gather_kernel<<<dim3(nbc, ni), 256, 0, st>>>(B);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    const int rc = cppf_internal_knn_batch(n_items, knn, stream);
+    if (rc) return rc;
+    int64_t nsb = (max_pairs + 511) / 512;          // two pairs per thread at the longest list
+    nsb = nsb > 2048 ? 2048 : nsb;
+    B.n_sample_blocks = (int)(nsb < 1 ? 1 : nsb);
+    fcb_finish_kernel<<<dim3(nbc + 1 + (max_pairs > 0 ? (unsigned)B.n_sample_blocks : 0u), ni), 256, 0, st>>>(B, (int)nbc);
+    return (int)hipGetLastError();
+}
+
 int cppf_sample_pairs(long long* idx, float* u_tr, float* u_rot, int64_t n_pairs, int64_t n_points, const int32_t* n_dev,
                       unsigned long long seed, const unsigned long long* seed_dev, void* stream)
 {
@@ -579,6 +777,20 @@ int cppf_copy_words(void* dst, const void* src, int64_t n_words, void* stream)
     int64_t nb = (n_words + 255) / 256;
     if (nb > 1024) nb = 1024;
     copy_words_kernel<<<(int)nb, 256, 0, (hipStream_t)stream>>>(static_cast<unsigned long long*>(dst), static_cast<const unsigned long long*>(src), n_words);
+    return (int)hipGetLastError();
+}
+
+int cppf_gather_words(int n_rows, const void* const* src_host, int64_t n_words, void* dst, void* stream)
+{
+    if (n_rows < 0 || n_rows > GATHER_MAX || n_words < 0 || n_words > 0x7fffffffll) return CPPF_EINVAL;
+    if (n_rows == 0 || n_words == 0) return 0;
+    if (!src_host || !dst || (reinterpret_cast<uintptr_t>(dst) & 7)) return CPPF_EINVAL;
+    GatherRows G = {};
+    for (int r = 0; r < n_rows; ++r) {
+        if (!src_host[r] || (reinterpret_cast<uintptr_t>(src_host[r]) & 7)) return CPPF_EINVAL;
+        G.src[r] = static_cast<const unsigned long long*>(src_host[r]);
+    }
+    gather_words_kernel<<<n_rows, 64, 0, (hipStream_t)stream>>>(G, static_cast<unsigned long long*>(dst), (int)n_words);
     return (int)hipGetLastError();
 }
 

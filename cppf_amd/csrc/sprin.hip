@@ -19,6 +19,7 @@
 #include "../../include/cppf.h"
 #include "cppf_math.h"
 #include "sprin_layout.h"
+#include "compact.h"
 
 using namespace cppf;
 using namespace sprin;
@@ -201,12 +202,12 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_kernel(const float* __rest
 // blocks (the grid is sized for the largest member; the others' surplus blocks leave at once).  A cloud of 700-2000 points is 700-2000
 // wavefronts: one member fills a quarter of the chip's wave slots, four or eight of them fill it.
 constexpr int SP_BATCH_MAX = 8;
-struct KnnBatch { const float* pc[SP_BATCH_MAX]; int32_t* out[SP_BATCH_MAX]; const int32_t* n_dev[SP_BATCH_MAX]; int N[SP_BATCH_MAX]; int k; };
+struct KnnBatch { const float* pc[SP_BATCH_MAX]; int32_t* out[SP_BATCH_MAX]; const int32_t* n_dev[SP_BATCH_MAX]; int N[SP_BATCH_MAX]; int k[SP_BATCH_MAX]; };
 __global__ __launch_bounds__(KNN_WAVES * 64) void knn_batch_kernel(KnnBatch B)
 {
     const int i = blockIdx.y;
     if (!B.out[i]) return;               // (a member whose neighbour sets are already there)
-    knn_body<false>(B.pc[i], nullptr, B.N[i], B.k, B.out[i], B.n_dev[i]);
+    knn_body<false>(B.pc[i], nullptr, B.N[i], B.k[i], B.out[i], B.n_dev[i]);
 }
 
 // --------------------------------------------------------------------------------------------- conv
@@ -442,6 +443,23 @@ int64_t conv_params(const int32_t* hidden, int n_hidden, int rank, int n_in, int
 
 }  // namespace
 
+// (compact.h) the k-neighbour searches of up to 8 clouds in one launch, each with its own k, capacity and device point count
+int cppf_internal_knn_batch(int n_items, const CppfKnnBatchItem* items, void* stream)
+{
+    if (n_items < 1 || n_items > SP_BATCH_MAX || !items) return CPPF_EINVAL;
+    KnnBatch KB;
+    memset(&KB, 0, sizeof(KB));
+    int n_max = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const CppfKnnBatchItem& it = items[i];
+        if (!it.pc || !it.nbrs || !it.n_dev || it.n_cap < 1 || it.k < 1 || it.k > it.n_cap) return CPPF_EINVAL;
+        KB.pc[i] = it.pc; KB.out[i] = it.nbrs; KB.n_dev[i] = it.n_dev; KB.N[i] = it.n_cap; KB.k[i] = it.k;
+        n_max = it.n_cap > n_max ? it.n_cap : n_max;
+    }
+    knn_batch_kernel<<<dim3((n_max + KNN_WAVES - 1) / KNN_WAVES, n_items), KNN_WAVES * 64, 0, (hipStream_t)stream>>>(KB);
+    return (int)hipGetLastError();
+}
+
 extern "C" {
 
 int cppf_knn(const float* pc, const float* dist, int n_points, int k, int32_t* nbrs, void* stream)
@@ -566,7 +584,7 @@ int cppf_point_encoder_forward_batch(int n_items, const CppfPointEncItem* items,
     ConvBatch CB;
     FillBatch FB;
     memset(&KB, 0, sizeof(KB)); memset(&CB, 0, sizeof(CB)); memset(&FB, 0, sizeof(FB));
-    KB.k = k; FB.stride = W; FB.n_glob = n_glob; FB.waves = waves;
+    FB.stride = W; FB.n_glob = n_glob; FB.waves = waves;
     int n_max = 0, any_search = 0;
     for (int i = 0; i < n_items; ++i) {
         const CppfPointEncItem& it = items[i];
@@ -574,7 +592,7 @@ int cppf_point_encoder_forward_batch(int n_items, const CppfPointEncItem* items,
         if (!it.pc || !it.nrm || !it.nbrs || !it.packed || !it.out) return CPPF_EINVAL;
         if (!it.workspace || it.workspace_bytes < cppf_point_encoder_workspace_bytes(it.n_cap, n_out, n_glob, 1)) return CPPF_EWORKSPACE;
         uint32_t* wgmax = (uint32_t*)((char*)it.workspace + 256);
-        KB.pc[i] = it.pc; KB.out[i] = it.nbrs_ready ? nullptr : it.nbrs; KB.n_dev[i] = it.n_dev; KB.N[i] = it.n_cap;
+        KB.pc[i] = it.pc; KB.out[i] = it.nbrs_ready ? nullptr : it.nbrs; KB.n_dev[i] = it.n_dev; KB.N[i] = it.n_cap; KB.k[i] = k;
         any_search |= !it.nbrs_ready;
         CB.item[i] = ConvArgs{it.pc, it.nrm, nullptr, it.nbrs, it.packed, it.packed + nat, it.out, it.n_cap, k, n_nbr_feats, W, nullptr,
                               it.n_dev, it.packed + cp, wgmax, n_glob};

@@ -89,9 +89,12 @@ class FrameRunner:
     fewer points than the kNN needs is skipped like the reference's (:121-123)."""
 
     def __init__(self, encoders, point_encoders, device, intrinsics=NOCS_INTRINSICS, n_pairs=100000, angle_tol=1.5, num_rots=72,
-                 cfgs=None, n_lanes=3, chain_len=None, cap_bucket=4096, max_members=48, max_chains=32):
+                 cfgs=None, n_lanes=3, chain_len=None, cap_bucket=4096, max_members=48, max_chains=32, batch_prestage=True):
         """max_members: pipelines kept (each with its captured graph and ~0.1 GB of buffers at 100 000 pairs); max_chains: captured
-        chains kept (at least the groups of one frame: a chain of the running frame is never evicted)."""
+        chains kept (at least the groups of one frame: a chain of the running frame is never evicted).
+        chain_len: instances per captured chain (None: two chains of equal length from four instances on, at most 8 members each);
+        batch_prestage=False: round 5's form, every member's own sixteen pre-processing launches at the head of its chain and
+        chains of ceil(n / n_lanes)."""
         from collections import OrderedDict
         self.encoders, self.point_encoders, self.device = encoders, point_encoders, device
         self.intrinsics = np.asarray(intrinsics, np.float64)
@@ -100,6 +103,7 @@ class FrameRunner:
         self.cfgs = cfgs or CATEGORIES
         self.n_lanes, self.chain_len, self.cap_bucket = max(1, int(n_lanes)), chain_len, int(cap_bucket)
         self.sphere = np.array(fibonacci_sphere(num_sphere_bins(angle_tol)))
+        self.batch_prestage = bool(batch_prestage)
         self.max_instances = 32                       # bits of the u32 label image
         # members: pipelines (+ pre-processing stage) keyed by what their buffers and launches are sized for -- (category, point
         # capacity, grid class) -- and handed to the instances of a frame from a pool, first free first: WHICH instance a member
@@ -112,7 +116,12 @@ class FrameRunner:
         self._hw = None
         from ._torch_util import lane_streams
         self._streams = lane_streams(device, self.n_lanes)        # (streams that really run beside each other: distinct hardware queues)
-        self._slots_host = torch.zeros((32, 2), dtype=torch.int64).pin_memory()    # {label bit, Philox key} per instance of the frame
+        # {label bit, Philox key} of the instance a member serves in the running frame: one row per member in ONE device table, sent
+        # with one copy per frame (a copy per member was 6-8 small transfers at the head of every frame)
+        self._slot_rows = max(64, 2 * self.max_members)
+        self._slots_host = torch.zeros((self._slot_rows, 2), dtype=torch.int64).pin_memory()
+        self._slots_dev = torch.zeros((self._slot_rows, 2), dtype=torch.int64, device=device)
+        self._free_rows = list(range(self._slot_rows - 1, -1, -1))
 
     def _frame_buffers(self, H, W):
         if self._hw != (H, W):
@@ -128,6 +137,7 @@ class FrameRunner:
             self._members.clear()
             self._pool.clear()
             self._chains.clear()
+            self._free_rows = list(range(self._slot_rows - 1, -1, -1))
 
     def _member(self, cat, n_mask, used):
         """A member of class (category, capacity for n_mask label pixels, grid class) that no instance of this frame holds yet
@@ -149,6 +159,7 @@ class FrameRunner:
                 break                                   # every member is in use by this frame: the bound yields
             torch.cuda.synchronize(self.device)
             old = self._members.pop(victim)
+            self._free_rows.append(old["row"])
             self._pool[old["key"]].remove(old)
             for ck in [ck for ck in self._chains if victim in ck]:
                 self._chains.pop(ck).release()
@@ -158,7 +169,10 @@ class FrameRunner:
                             angle_tol=self.angle_tol, point_encoder=self.point_encoders[cat], dynamic=True)
         L = _lib.lib()
         ws = torch.empty(int(L.cppf_frame_cloud_workspace_bytes(H, W, cap, cfg.knn)), dtype=torch.uint8, device=self.device)
-        slot = torch.zeros(2, dtype=torch.int64, device=self.device)          # {label bit (low 32 bits), Philox key}: written per frame
+        if not self._free_rows:                       # (more live members than rows: only when the bound yielded to a huge frame)
+            raise RuntimeError("FrameRunner: no free member record; raise max_members")
+        row = self._free_rows.pop()
+        slot = self._slots_dev[row]                   # {label bit (low 32 bits), Philox key}: written per frame
         dev, depth, labels, kinv = self.device, self._depth, self._labels, self.kinv
         # the normals are fitted on the k = cfg.knn neighbour sets; a point encoder with the same k (config/config.yaml: 60 for both)
         # reuses them instead of searching again (the stage writes them straight into the pipeline's neighbour buffer)
@@ -175,10 +189,33 @@ class FrameRunner:
                 # pairs and bin uniforms: N from the shape record the stage just wrote, the key from the member's record
                 _lib.check(L.cppf_sample_pairs(pipe.idx.data_ptr(), pipe.u_tr.data_ptr(), pipe.u_rot.data_ptr(), pipe.idx.shape[0], 1,
                                                pipe.shape.data_ptr(), 0, slot.data_ptr() + 8, stream_ptr(dev)), "cppf_sample_pairs")
-        mem = dict(pipe=pipe, pre=prestage, slot=slot, ws=ws, key=key)
+        mem = dict(pipe=pipe, pre=prestage, slot=slot, row=row, ws=ws, key=key, cfg=cfg, cap=cap, nbrs_ptr=nbrs_ptr)
         self._members[id(pipe)] = mem
         self._pool.setdefault(key, []).append(mem)
         return mem
+
+    def _batch_prestage(self, mems):
+        """the frame stage of a chain's members in eight launches (cppf_frame_cloud_dyn_batch) instead of sixteen each: a callable
+        for the head of their captured chain"""
+        import ctypes as C
+        from . import _lib
+        from ._torch_util import stream_ptr
+        L, dev, H, W = _lib.lib(), self.device, self._hw[0], self._hw[1]
+        depth, labels, kinv = self._depth, self._labels, self.kinv
+        arr = (_lib.FrameCloudItem * len(mems))()
+        for a, m in zip(arr, mems):
+            pipe, cfg = m["pipe"], m["cfg"]
+            a.label_bit_dev, a.seed_dev = m["slot"].data_ptr(), m["slot"].data_ptr() + 8
+            a.pc_out, a.nrm_out, a.corner_out, a.shape_out = pipe.pc.data_ptr(), pipe.nrm.data_ptr(), pipe.corner.data_ptr(), pipe.shape.data_ptr()
+            a.nbrs_out, a.idx, a.u_tr, a.u_rot = m["nbrs_ptr"], pipe.idx.data_ptr(), pipe.u_tr.data_ptr(), pipe.u_rot.data_ptr()
+            a.workspace, a.workspace_bytes, a.res, a.n_pairs = m["ws"].data_ptr(), m["ws"].numel(), float(cfg.res), pipe.idx.shape[0]
+            a.knn_k, a.k_min, a.n_cap, a.idx_is_i64 = cfg.knn, cfg.knn + 1, m["cap"], 1 if pipe.idx.dtype == torch.int64 else 0
+
+        def prestage():
+            with torch.cuda.device(dev):
+                _lib.check(L.cppf_frame_cloud_dyn_batch(len(mems), C.cast(arr, C.c_void_p), depth.data_ptr(), 1, labels.data_ptr(), 4, H, W,
+                                                        kinv.ctypes.data, 1000.0, stream_ptr(dev)), "cppf_frame_cloud_dyn_batch")
+        return prestage
 
     def _chain_for(self, pipes, pres, busy):
         """the captured chain of this combination of members (second sighting on), or None: its members run their own graphs.
@@ -201,11 +238,12 @@ class FrameRunner:
                 return None                              # (more groups in this frame than max_chains)
             torch.cuda.synchronize(self.device)
             self._chains.pop(victim).release()
-        ch = self._chains[key] = PoseChain(pipes, prestages=pres)
+        ch = self._chains[key] = PoseChain(pipes, prestages=pres() if callable(pres) else pres)
         busy.add(key)
         return ch
 
     def run(self, depth, instances, seed=0):
+        from ._torch_util import gather_words
         from .inference import assemble_record
         dev = self.device
         depth = np.ascontiguousarray(depth)
@@ -224,9 +262,6 @@ class FrameRunner:
             np.bitwise_or(labels, np.uint32(1 << i), out=labels, where=m)      # (no fancy indexing: 0.1 ms per 480 x 640 mask)
             counts.append(int(np.count_nonzero(m)))
         self._depth_host.numpy()[...] = depth.view(np.int16)
-        slots = self._slots_host.numpy()
-        for i in on_chain:
-            slots[i] = (i, pair_seed(seed, i))
         main = torch.cuda.current_stream(dev)
         self._depth.copy_(self._depth_host, non_blocking=True)          # one upload per frame (two images)
         self._labels.copy_(self._labels_host, non_blocking=True)
@@ -236,32 +271,47 @@ class FrameRunner:
         # (zero-filled on the caller's stream BEFORE the lanes fork from it: a lane's record copy must not race the fill)
         raw = torch.zeros((max(len(on_chain), 1), 21), dtype=torch.float64, device=dev)
         shapes = torch.zeros((max(len(on_chain), 1), 4), dtype=torch.int32, device=dev)
-        for st in self._streams:
-            st.wait_stream(main)
-        Lc = self.chain_len or max(1, min(8, -(-len(on_chain) // self.n_lanes)))
+        if self.chain_len:
+            Lc = self.chain_len
+        elif self.batch_prestage:          # two chains of equal length on two lanes (measured on 6 instances: 3 + 3 1.48 ms per
+            n_ch = max(2 if len(on_chain) >= 4 and self.n_lanes > 1 else 1, -(-len(on_chain) // 8))     # frame, one chain 1.58, 2 + 2 + 2 1.50)
+            Lc = max(1, -(-len(on_chain) // n_ch))
+        else:
+            Lc = max(1, min(8, -(-len(on_chain) // self.n_lanes)))
         groups = [on_chain[g:g + Lc] for g in range(0, len(on_chain), Lc)]
         ran, used, busy = [], set(), set()
-        for gi, slots_g in enumerate(groups):
+        # which member serves which instance of this frame: decided for the whole frame first, written to the members' rows of the
+        # record table and sent with one copy on the caller's stream, before the lanes fork from it
+        slots_tbl, members_of = self._slots_host.numpy(), []
+        for slots_g in groups:
+            mems = []
+            for i in slots_g:
+                mem = self._member(instances[i][0], counts[i], used)
+                used.add(id(mem["pipe"]))
+                slots_tbl[mem["row"]] = (i, pair_seed(seed, i))
+                mems.append(mem)
+            members_of.append(mems)
+        if on_chain:
+            self._slots_dev.copy_(self._slots_host, non_blocking=True)
+        for st in self._streams:
+            st.wait_stream(main)
+        for gi, (slots_g, mems) in enumerate(zip(groups, members_of)):
             lane = gi % self.n_lanes
             with torch.cuda.stream(self._streams[lane]):
-                pipes, pres = [], []
-                for i in slots_g:
-                    mem = self._member(instances[i][0], counts[i], used)
-                    used.add(id(mem["pipe"]))
-                    mem["slot"].copy_(self._slots_host[i], non_blocking=True)     # which instance this member serves in this frame
-                    pipes.append(mem["pipe"])
-                    pres.append(mem["pre"])
-                ch = self._chain_for(pipes, pres, busy)
+                pipes, pres = [m["pipe"] for m in mems], [m["pre"] for m in mems]
+                # (a chain's members share the launches of their frame stage; without a chain every member runs its own)
+                ch = self._chain_for(pipes, (lambda: [self._batch_prestage(mems)] + [None] * (len(mems) - 1)) if self.batch_prestage else pres, busy)
                 # (check_weights=None: the images were refreshed above, once per frame; a pipeline compares their addresses, so a
                 # weight image that moved -- an encoder re-created or resized -- re-captures instead of reading a stale address)
                 if ch is not None:
-                    ch.run_async([raw[i] for i in slots_g], check_weights=None)
+                    ch.run_async(None, check_weights=None)
                 else:
-                    for pipe, pre, i in zip(pipes, pres, slots_g):
+                    for pipe, pre in zip(pipes, pres):
                         pre()
-                        pipe.run_async(raw[i], check_weights=None)
-                for pipe, i in zip(pipes, slots_g):
-                    shapes[i].copy_(pipe.shape, non_blocking=True)
+                        pipe.run_async(None, check_weights=None)
+                # the members' records and shape words, each in its own pipeline's buffers: one launch each into the frame's arrays
+                gather_words(raw[slots_g[0]:slots_g[-1] + 1], [p.ws.rec for p in pipes], dev)
+                gather_words(shapes[slots_g[0]:slots_g[-1] + 1], [p.shape for p in pipes], dev)
                 ran.append((ch, pipes, slots_g))
         for st in self._streams:
             main.wait_stream(st)

@@ -745,7 +745,8 @@ class PosePipeline(CenterPipeline):
         no host synchronisation, so a batch of instances runs back to back (BatchPoseRunner reads all records back at
         once and assembles the poses with `assemble_record`)."""
         super().run(check_weights)
-        record_out.copy_(self.ws.rec, non_blocking=True)
+        if record_out is not None:          # (None: the caller collects the records itself, e.g. several pipelines' with one launch)
+            record_out.copy_(self.ws.rec, non_blocking=True)
 
     def sample_inputs(self, seed, n_points=None):
         """Draw the pair list and the bin-sampling uniforms on the device (the reference draws the pairs with np.random.randint on

@@ -676,6 +676,31 @@ int cppf_frame_cloud_dyn_bit(const void* depth, int depth_is_u16, const void* la
                              int W, const double* kinv_host, double divisor, double res, int knn_k, int k_min, int n_cap, float* pc_out,
                              float* nrm_out, float* corner_out, int32_t* shape_out, int32_t* nbrs_out, void* workspace,
                              size_t workspace_bytes, void* stream);
+/* The frame stage of up to 8 instances of ONE frame (nocs/inference.py:120 loops over them) in EIGHT launches instead of sixteen
+ * per instance, their pair lists and bin uniforms included (cppf_sample_pairs, the key read from *seed_dev): per instance the results
+ * of cppf_frame_cloud_dyn_bit + cppf_sample_pairs, bit for bit (ABI 4).  A frame's chain is launch-bound -- ~15 kernels of ~5 us per
+ * instance, and a hipGraph launch costs the host per kernel node -- so a launch serves every member (blockIdx.y), the mask kernels
+ * count their own chunks (no count + scan launches), the first one clears the voxel table, the normals launch also sets up the grid
+ * and draws the pairs.  Every member has its own capacity, resolution, k, workspace (cppf_frame_cloud_workspace_bytes) and outputs. */
+typedef struct CppfFrameCloudItem {
+    const int32_t* label_bit_dev;          /* device i32: the member's bit of the label image (taken modulo the label width) */
+    const unsigned long long* seed_dev;    /* device u64: Philox key of its pair / uniform draws (n_pairs > 0) */
+    float* pc_out;                         /* device f32[n_cap,3] */
+    float* nrm_out;                        /* device f32[n_cap,3] */
+    float* corner_out;                     /* device f32[3] */
+    int32_t* shape_out;                    /* device i32[4] {N (0: fewer than k_min points), gx, gy, gz} */
+    int32_t* nbrs_out;                     /* device i32[n_cap,knn_k] or NULL (kept in the workspace) */
+    void* idx;                             /* device i64[n_pairs,2] (idx_is_i64) or i32[n_pairs,2] */
+    float* u_tr;                           /* device f32[n_pairs,2] or NULL */
+    float* u_rot;                          /* device f32[n_pairs,2] or NULL */
+    void* workspace;
+    size_t workspace_bytes;
+    double res;
+    int64_t n_pairs;                       /* 0: no draws */
+    int32_t knn_k, k_min, n_cap, idx_is_i64;
+} CppfFrameCloudItem;
+int cppf_frame_cloud_dyn_batch(int n_items, const CppfFrameCloudItem* items_host, const void* depth, int depth_is_u16, const void* labels,
+                               int label_bytes, int H, int W, const double* kinv_host, double divisor, void* stream);
 /* Pair list and bin uniforms drawn on the device -- the reference draws the pairs with np.random.randint(0, N, (P, 2)) on the host
  * (nocs/inference.py:177: 8 MB per instance at C2 over PCIe) and the bins with torch.multinomial (:186,250,254).  idx device
  * i64[n_pairs,2] uniform over [0, N); u_tr / u_rot device f32[n_pairs,2] uniform over [0, 1) (either may be NULL).  N = n_points, or
@@ -723,6 +748,9 @@ int cppf_stage_batch(int n_items, const CppfStageItem* items_host, void* stream)
  * reads / writes in place).  For the few hundred bytes a batch driver moves per chain -- descriptors in, records out: a copy engine's
  * queue is shared between streams and in order, so such copies can wait behind another stream's unrelated transfer. */
 int cppf_copy_words(void* dst, const void* src, int64_t n_words, void* stream);
+/* row r of dst (n_words 64-bit words each) <- the words at src_host[r] (a HOST array of up to 32 device pointers, 8-byte aligned), one
+ * launch: the result records of a chain's members into one array instead of one small copy per member (ABI 4) */
+int cppf_gather_words(int n_rows, const void* const* src_host, int64_t n_words, void* dst, void* stream);
 size_t cppf_backproject_workspace_bytes(int H, int W);
 int cppf_backproject(const void* depth, int depth_is_u16, const uint8_t* mask, int H, int W, const double* kinv_host,
                      double* pts, int32_t* pix, int32_t* count, void* workspace, size_t workspace_bytes, void* stream);

@@ -25,7 +25,9 @@ for cat, src in (("mug", "mug"), ("laptop", "laptop"), ("bowl", "bottle"), ("can
     nets[cat] = (enc, penc)
 encs = {c: v[0] for c, v in nets.items()}
 pencs = {c: v[1] for c, v in nets.items()}
-runner = FrameRunner(encs, pencs, dev, n_lanes=int(os.environ.get("LANES", "3")))
+cl = os.environ.get("CHAIN_LEN")
+runner = FrameRunner(encs, pencs, dev, n_lanes=int(os.environ.get("LANES", "3")), chain_len=int(cl) if cl else None,
+                     batch_prestage=not os.environ.get("NO_BATCH_PRE"))
 for _ in range(5):
     runner.run(depth, inst)
 torch.cuda.synchronize()

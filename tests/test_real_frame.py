@@ -123,8 +123,11 @@ def test_real_frame_preprocessing_equals_oracle_and_poses_are_sane(oracle, dev):
 
 
 @pytest.mark.gpu
-def test_frame_runner_equals_the_eager_loop(oracle, dev):
-    """FrameRunner (depth + one label image uploaded per frame, every instance's pre-processing count-driven on the device at the
+@pytest.mark.parametrize("batch_prestage", [True, False])
+def test_frame_runner_equals_the_eager_loop(oracle, dev, batch_prestage):
+    """(batch_prestage: the members' frame stages in eight shared launches -- cppf_frame_cloud_dyn_batch, two chains of four for the
+    frame's eight instances -- or every member's own sixteen, three chains on three lanes.)
+    FrameRunner (depth + one label image uploaded per frame, every instance's pre-processing count-driven on the device at the
     head of a captured, shape-polymorphic chain, the instances of a lane sharing their launches, ONE read-back per frame) gives
     frame_poses' poses -- the eager per-instance loop, nocs/inference.py:108-142,177-339 -- bit for bit: first sighting (members'
     own graphs), captured chains, replays; overlapping masks, an instance too small for the kNN (skipped like :121-123), an empty
@@ -149,7 +152,7 @@ def test_frame_runner_equals_the_eager_loop(oracle, dev):
     pencs = {c: v[1] for c, v in nets.items()}
     want = frame_poses(depth, inst, encs, pencs, device=dev, seed=3)
     assert want[6] is None and want[7] is None and all(w is not None for w in want[:6])
-    runner = FrameRunner(encs, pencs, dev)
+    runner = FrameRunner(encs, pencs, dev, batch_prestage=batch_prestage)
     served = []
     for rep in range(6):     # solo graphs (two instances need many-tile pipelines: eager this once), new members solo, chains captured, replays
         got = runner.run(depth, inst, seed=3)
@@ -165,7 +168,7 @@ def test_frame_runner_equals_the_eager_loop(oracle, dev):
     # the union of two bowls and the laptop (res 1e-2 on a 0.5 m object) need >= 4 vote tiles: eager once, many-tile pipelines after
     assert served[0] == {"captured": 4, "eager": 2, "skipped": 2} and runner._many_tile_cats == {"bowl", "laptop"}, served
     assert all(s_ == {"captured": 6, "eager": 0, "skipped": 2} for s_ in served[1:]), served
-    assert len(runner._chains) == 3
+    assert len(runner._chains) == (2 if batch_prestage else 3)
     # the device stage against the oracle's pre-processing (member 0 of lane 0 still holds instance 0's cloud)
     cat, m = inst[0]
     cfg = CATEGORIES[cat]
