@@ -252,7 +252,9 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void reduce_argmax_kernel(float* _
 // `v3_vote_kernel`, workgroup (tile t, chunk c), consumes records [c n_t / C, (c+1) n_t / C) of tile t's queue: exact frame
 // again (12 B/record of HBM traffic instead of 52), then the run walk of vote_kernel.
 #define V3_TILE_FLOATS 30720      // 120 KiB of LDS for the tile incl. its halo
+#ifndef V3_STAGE
 #define V3_STAGE 3072             // staged records per flush (16 B each in LDS: 48 KiB; 72 KiB with the rings and pair queues: two workgroups per CU)
+#endif
 #define V3_MAGIC 0x43503356u
 #define V3_THREADS 1024
 #define V3_BIN_THREADS 512
