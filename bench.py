@@ -252,7 +252,8 @@ def main_c4(args, dev, rank, world, binding):
     if rank != 0:
         return
     total_pairs = m["reps"] * m["n_objects"] * m["P"]
-    how = ("clouds and features sent from pinned host memory per batch (the PCIe-inclusive rate), records assembled on the device" if m["host_staged"] else
+    how = ("clouds and features sent from pinned host memory per batch (the PCIe-inclusive rate), records assembled on the device"
+           if m["host_staged"] else
            "objects uploaded once (inputs resident in HBM), staged into the chains' buffers by cppf_stage_batch, records assembled on "
            "the device" + ("" if args_no_overlap(args) else ", a batch's chains waiting for their own inputs only (overlap_batches)"))
     out = {"metric": METRIC, "value": total_pairs / m["elapsed"], "unit": "pairs/s", "n_gpus": world,

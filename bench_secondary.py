@@ -430,7 +430,8 @@ def collect(ctx, R):
             args.steps = 8 * reps_list[0]
             m4 = run_c4(dev, rank, world, args, n_objects=n_obj, host_staged=host_staged, reps_list=reps_list[1:])
             per = m4["reps"] * n_obj
-            span = m4["own_ms"][len(m4["own_ms"]) // 2] / per if m4["own_ms"] else None     # region start -> the rank's chains joined, HIP events
+            # (region start -> the rank's chains joined, HIP events)
+            span = m4["own_ms"][len(m4["own_ms"]) // 2] / per if m4["own_ms"] else None
             entry = {"workload": what + f"; median of 7 regions of {reps_list[0]} batches", "batches_per_region": reps_list[0],
                      "ms_per_object": m4["elapsed"] / per * 1e3, "device_span_ms_per_object": span,
                      "ms_per_object_min_max": [m4["regions"][0] / per * 1e3, m4["regions"][-1] / per * 1e3],
