@@ -350,12 +350,23 @@ def collect(ctx, R):
             poses_f = frunner.run(depth, inst)
         settle()
         t_rf, mm_rf = repeated(lambda: frunner.run(depth, inst), 4, 7, per=len(inst))
+        def video(n_frames=6):                      # a video loop: frame k + 1 submitted before frame k is collected
+            prev = None
+            for _ in range(n_frames):
+                cur = frunner.submit(depth, inst)
+                if prev is not None:
+                    prev.result()
+                prev = cur
+            prev.result()
+        video()
+        t_rf_p, mm_rf_p = repeated(lambda: video(6), 2, 7, per=6 * len(inst))
         poses_f = frunner.run(depth, inst)
         same = all((a is None) == (b is None) and (a is None or (a["argmax"] == b["argmax"] and np.array_equal(a["T"], b["T"])
                                                                    and np.array_equal(a["up"], b["up"]) and a["n_surv"] == b["n_surv"]))
                    for a, b in zip(poses_e, poses_f))
         real_frame = {"instances": len(inst), "points_per_instance": [int(p_["n_points"]) for p_ in poses_f], "pairs_per_instance": 100000,
                       "ms_per_instance_incl_preprocessing": t_rf, "ms_per_instance_min_max": mm_rf,
+                      "ms_per_instance_pipelined": t_rf_p, "ms_per_instance_pipelined_min_max": mm_rf_p,     # (FrameRunner.submit)
                       "path": "FrameRunner: depth + one label image uploaded per frame, per-instance pre-processing count-driven on the "
                               "device (cppf_frame_cloud_dyn) at the head of captured chains, one read-back per frame",
                       "served_by": dict(frunner.last), "eager_loop_ms_per_instance": t_rf_e, "eager_loop_min_max": mm_rf_e,

@@ -119,15 +119,22 @@ class FrameRunner:
         # {label bit, Philox key} of the instance a member serves in the running frame: one row per member in ONE device table, sent
         # with one copy per frame (a copy per member was 6-8 small transfers at the head of every frame)
         self._slot_rows = max(64, 2 * self.max_members)
-        self._slots_host = torch.zeros((self._slot_rows, 2), dtype=torch.int64).pin_memory()
         self._slots_dev = torch.zeros((self._slot_rows, 2), dtype=torch.int64, device=device)
         self._free_rows = list(range(self._slot_rows - 1, -1, -1))
 
     def _frame_buffers(self, H, W):
         if self._hw != (H, W):
             self._hw = (H, W)
-            self._depth_host = torch.empty((H, W), dtype=torch.int16).pin_memory()
-            self._labels_host = torch.empty((H, W), dtype=torch.int32).pin_memory()
+            torch.cuda.synchronize(self.device)            # (frames still in flight read the buffers that go away here)
+            # two pinned sets alternate (submit() of frame k + 1 fills one while the copies of frame k still read the other); a set is
+            # rewritten only after the copies that last read it have executed (`sent`)
+            self._host_sets = [dict(depth=torch.empty((H, W), dtype=torch.int16).pin_memory(),
+                                    labels=torch.empty((H, W), dtype=torch.int32).pin_memory(),
+                                    slots=torch.zeros((self._slot_rows, 2), dtype=torch.int64).pin_memory(),
+                                    raw=torch.zeros((self.max_instances, 21), dtype=torch.float64).pin_memory(),
+                                    shapes=torch.zeros((self.max_instances, 4), dtype=torch.int32).pin_memory(),
+                                    sent=torch.cuda.Event(), done=torch.cuda.Event(), owner=None) for _ in range(2)]
+            self._set_pos = 0
             self._depth = torch.empty((H, W), dtype=torch.int16, device=self.device)
             self._labels = torch.empty((H, W), dtype=torch.int32, device=self.device)
             for ch in self._chains.values():
@@ -243,16 +250,27 @@ class FrameRunner:
         return ch
 
     def run(self, depth, instances, seed=0):
+        """-> the frame's poses (list of pose dicts / None, as frame_poses): submit() + result()"""
+        return self.submit(depth, instances, seed).result()
+
+    def submit(self, depth, instances, seed=0):
+        """Enqueue a frame and return at once: -> PendingFrame, whose result() waits for the frame's one read-back and returns the
+        poses.  A video loop that submits frame k + 1 before it asks for frame k's result overlaps the host's share of a frame (the
+        label image, the members' bookkeeping, the enqueue: ~0.6 of the demo frame's 1.45 ms) with the device's.  Frames execute in
+        submission order; at most two may be pending (a third submit() first collects the oldest's result)."""
         from ._torch_util import gather_words
-        from .inference import assemble_record
         dev = self.device
         depth = np.ascontiguousarray(depth)
         H, W = depth.shape
         self._frame_buffers(H, W)
+        hs = self._host_sets[self._set_pos % 2]
+        self._set_pos += 1
+        if hs["owner"] is not None:
+            hs["owner"].result()                     # (its result arrays live in this set)
+        hs["sent"].synchronize()                     # the uploads that last read this set have executed
         n_inst = len(instances)
-        out = [None] * n_inst
         on_chain = list(range(min(n_inst, self.max_instances)))
-        labels = self._labels_host.numpy().view(np.uint32)
+        labels = hs["labels"].numpy().view(np.uint32)
         labels[...] = 0
         counts = []
         for i in on_chain:
@@ -261,10 +279,11 @@ class FrameRunner:
                 m = m != 0
             np.bitwise_or(labels, np.uint32(1 << i), out=labels, where=m)      # (no fancy indexing: 0.1 ms per 480 x 640 mask)
             counts.append(int(np.count_nonzero(m)))
-        self._depth_host.numpy()[...] = depth.view(np.int16)
+        hs["depth"].numpy()[...] = depth.view(np.int16)
         main = torch.cuda.current_stream(dev)
-        self._depth.copy_(self._depth_host, non_blocking=True)          # one upload per frame (two images)
-        self._labels.copy_(self._labels_host, non_blocking=True)
+        # (on the caller's stream, i.e. behind the previous frame's join: the chains' launches have these two buffers' addresses baked in)
+        self._depth.copy_(hs["depth"], non_blocking=True)               # one upload per frame (two images)
+        self._labels.copy_(hs["labels"], non_blocking=True)
         for cat in {instances[i][0] for i in on_chain}:
             self.encoders[cat]._packed_weights(dev)
             self.point_encoders[cat]._packed_weights(dev)
@@ -282,7 +301,7 @@ class FrameRunner:
         ran, used, busy = [], set(), set()
         # which member serves which instance of this frame: decided for the whole frame first, written to the members' rows of the
         # record table and sent with one copy on the caller's stream, before the lanes fork from it
-        slots_tbl, members_of = self._slots_host.numpy(), []
+        slots_tbl, members_of = hs["slots"].numpy(), []
         for slots_g in groups:
             mems = []
             for i in slots_g:
@@ -292,7 +311,8 @@ class FrameRunner:
                 mems.append(mem)
             members_of.append(mems)
         if on_chain:
-            self._slots_dev.copy_(self._slots_host, non_blocking=True)
+            self._slots_dev.copy_(hs["slots"], non_blocking=True)
+        hs["sent"].record(main)
         for st in self._streams:
             st.wait_stream(main)
         for gi, (slots_g, mems) in enumerate(zip(groups, members_of)):
@@ -315,7 +335,23 @@ class FrameRunner:
                 ran.append((ch, pipes, slots_g))
         for st in self._streams:
             main.wait_stream(st)
-        host, shp = raw.cpu().numpy(), shapes.cpu().numpy()             # the frame's one synchronisation
+        n = max(len(on_chain), 1)
+        hs["raw"][:n].copy_(raw, non_blocking=True)                     # the frame's one read-back (two small arrays), asynchronous
+        hs["shapes"][:n].copy_(shapes, non_blocking=True)
+        hs["done"].record(main)
+        pend = PendingFrame(self, hs, depth, instances, seed, on_chain, ran, (raw, shapes))
+        hs["owner"] = pend
+        return pend
+
+    def _finish(self, pend):
+        """result() of a pending frame: wait for its read-back, adapt the chains, assemble the poses, run what the chains could not serve"""
+        from .inference import assemble_record
+        hs, instances, on_chain, ran = pend._hs, pend._instances, pend._on_chain, pend._ran
+        hs["done"].synchronize()
+        n_inst = len(instances)
+        out = [None] * n_inst
+        host, shp = hs["raw"].numpy().copy(), hs["shapes"].numpy().copy()
+        hs["owner"] = None
         eager = list(range(len(on_chain), n_inst))
         self.last = {"captured": 0, "eager": len(eager), "skipped": 0}   # how the last frame's instances were served
         for ch, pipes, slots in ran:
@@ -338,8 +374,22 @@ class FrameRunner:
                 pose.update(n_points=n, dims=tuple(int(v) for v in shp[i, 1:4]))
                 out[i] = pose
         if eager:
-            sub = frame_poses(depth, [instances[i] for i in eager], self.encoders, self.point_encoders, self.intrinsics, self.n_pairs,
-                              seed, dev, self.angle_tol, self.num_rots, self.cfgs, index_of=eager)
+            sub = frame_poses(pend._depth, [instances[i] for i in eager], self.encoders, self.point_encoders, self.intrinsics, self.n_pairs,
+                              pend._seed, self.device, self.angle_tol, self.num_rots, self.cfgs, index_of=eager)
             for i, p in zip(eager, sub):
                 out[i] = p
         return out
+
+
+class PendingFrame:
+    """a frame FrameRunner.submit() enqueued; result() -> its poses (waits for the frame's read-back; idempotent)"""
+
+    def __init__(self, runner, hs, depth, instances, seed, on_chain, ran, keep):
+        self._runner, self._hs, self._depth, self._instances, self._seed = runner, hs, depth, instances, seed
+        self._on_chain, self._ran, self._keep, self._out = on_chain, ran, keep, None
+
+    def result(self):
+        if self._out is None:
+            self._out = self._runner._finish(self)
+            self._ran = self._keep = None
+        return self._out

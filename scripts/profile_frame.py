@@ -39,6 +39,17 @@ torch.cuda.synchronize()
 print("instances_processed %d" % ((5 + n) * len(inst)))
 print("FrameRunner ms per frame", (time.perf_counter() - t0) / n * 1e3, "chains", len(runner._chains),
       [m["key"] for m in runner._members.values()], runner.last)
+if os.environ.get("PIPELINED"):
+    t0 = time.perf_counter()
+    prev = None
+    for _ in range(n):
+        cur = runner.submit(depth, inst)
+        if prev is not None:
+            prev.result()
+        prev = cur
+    prev.result()
+    torch.cuda.synchronize()
+    print("FrameRunner pipelined ms per frame", (time.perf_counter() - t0) / n * 1e3)
 if os.environ.get("CPROFILE"):
     import cProfile
     import pstats

@@ -234,3 +234,51 @@ def test_frame_runner_keeps_its_graphs_when_the_instances_change(dev):
     for rep in range(4):
         check(small, inst, rep)
     assert len(small._chains) <= 2
+
+
+@pytest.mark.gpu
+def test_pipelined_frames_equal_the_synchronous_ones(dev):
+    """FrameRunner.submit(): a video loop that enqueues frame k + 1 before it collects frame k (the host's share of a frame under the
+    device's).  Different frames (subsets, permutations, seeds) back to back, three submitted before the first result is asked for
+    (the third collects the oldest: two pinned sets), results out of order: every frame's poses equal run()'s on a fresh look, the
+    first sightings (members' own graphs), the captures and the replays alike."""
+    from cppf_amd import training
+    from cppf_amd.config import CATEGORIES
+    from cppf_amd.frames import FrameRunner
+    from cppf_amd.utils.util import read_depth_png
+    depth = read_depth_png(DEPTH)
+    inst = instances(depth)
+    nets = {}
+    for cat, src in (("mug", "mug"), ("laptop", "laptop"), ("bowl", "bottle"), ("can", "bottle")):
+        penc, enc = training.load_weights(os.path.join(GOLDEN, f"trained_{src}.npz"), CATEGORIES[src], dev)
+        nets[cat] = (enc, penc)
+    encs = {c: v[0] for c, v in nets.items()}
+    pencs = {c: v[1] for c, v in nets.items()}
+    rng = np.random.default_rng(5)
+    frames = []
+    for k in range(9):
+        order = rng.permutation(len(inst))[:rng.integers(2, len(inst) + 1)] if k % 3 else np.arange(len(inst))
+        d = depth if k % 2 == 0 else np.ascontiguousarray(np.where(depth > 0, depth + np.uint16(1 + k), depth).astype(depth.dtype))
+        frames.append((d, [inst[i] for i in order], 40 + k))
+    sync = FrameRunner(encs, pencs, dev)
+    want = []
+    for rep in range(2):                        # (twice: the second pass replays captured chains)
+        want = [sync.run(d, f, seed=sd) for d, f, sd in frames]
+    piped = FrameRunner(encs, pencs, dev)
+    for rep in range(2):
+        pend = []
+        for k, (d, f, sd) in enumerate(frames):
+            pend.append(piped.submit(d, f, seed=sd))
+            if k % 4 == 3:                       # collect some in the middle, newest first
+                for p in reversed(pend[-2:]):
+                    p.result()
+        got = [p.result() for p in pend]
+        for k, (w_f, g_f) in enumerate(zip(want, got)):
+            assert len(w_f) == len(g_f)
+            for w, g in zip(w_f, g_f):
+                assert (w is None) == (g is None), (rep, k)
+                if w is not None:
+                    assert g["argmax"] == w["argmax"] and g["n_surv"] == w["n_surv"] and g["n_points"] == w["n_points"], (rep, k)
+                    for key in ("T", "up", "right", "scale"):
+                        assert np.array_equal(g[key], w[key]), (rep, k, key)
+    assert pend[0].result() is got[0]           # idempotent
