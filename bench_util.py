@@ -428,7 +428,7 @@ def compact(out):
                                                        "level3_batch_runner_captured_ms"))
     if out.get("real_frame"):
         line["real_frame"] = pick(out["real_frame"], ("instances", "ms_per_instance_incl_preprocessing", "ms_per_instance_min_max",
-                                                      "eager_loop_ms_per_instance", "poses_equal_eager_loop"))
+                                                      "ms_per_instance_pipelined", "eager_loop_ms_per_instance", "poses_equal_eager_loop"))
     def rounded(x):          # 6 significant digits are plenty beside a spread; the contract's own numbers stay as measured
         if isinstance(x, float):
             return float(f"{x:.6g}")
