@@ -427,8 +427,8 @@ def compact(out):
                                                       ("level1_reference_call_sequence_ms", "level2_estimate_pose_eager_ms",
                                                        "level3_batch_runner_captured_ms"))
     if out.get("real_frame"):
-        line["real_frame"] = pick(out["real_frame"], ("instances", "ms_per_instance_incl_preprocessing", "ms_per_instance_min_max",
-                                                      "ms_per_instance_pipelined", "eager_loop_ms_per_instance", "poses_equal_eager_loop"))
+        line["real_frame"] = pick(out["real_frame"], ("instances", "ms_per_instance_incl_preprocessing", "ms_per_instance_pipelined",
+                                                      "eager_loop_ms_per_instance", "poses_equal_eager_loop"))
     def rounded(x):          # 6 significant digits are plenty beside a spread; the contract's own numbers stay as measured
         if isinstance(x, float):
             return float(f"{x:.6g}")
