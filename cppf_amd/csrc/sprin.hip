@@ -292,45 +292,59 @@ __device__ __forceinline__ void sprin_conv_body(const ConvArgs& A)
     for (int c = 0; c < 6; ++c) x6l[lane * 8 + c] = x6[c];
     x6l[lane * 8 + 6] = 0.f; x6l[lane * 8 + 7] = 0.f;
     __syncthreads();
-    // conv_kernel(6, 32, 32, 64, 32, 32) (models/sprin.py:64-72) on MFMA, 16 neighbour rows at a time
+    // conv_kernel(6, 32, 32, 64, 32, 32) (models/sprin.py:64-72) on MFMA, 16 neighbour rows at a time -- TWO row blocks in flight
+    // (sp_mfma_layer2: shared weight reads, two independent MFMA chains per output block; one block's LayerNorm under the other's
+    // MFMAs), their results contracted one after the other, in neighbour order
     {
         const int j = lane & 15, g = lane >> 4;
 #pragma unroll 1
-        for (int rb = 0; rb < 4; ++rb) {
+        for (int rb = 0; rb < 4; rb += 2) {
             f32x4 a1[2], a2[4], a3[2], a4[2], kr[2];
+            f32x4 b1[2], b2[4], b3[2], b4[2], ks[2];
 #pragma unroll
-            for (int ob = 0; ob < 2; ++ob) a1[ob] = *reinterpret_cast<const f32x4*>(Wl + SPW_B1 + 16 * ob + 4 * g);
+            for (int ob = 0; ob < 2; ++ob) { a1[ob] = *reinterpret_cast<const f32x4*>(Wl + SPW_B1 + 16 * ob + 4 * g); b1[ob] = a1[ob]; }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const float bx = x6l[(16 * rb + j) * 8 + 4 * s + g];
+                const float bx = x6l[(16 * rb + j) * 8 + 4 * s + g], by = x6l[(16 * (rb + 1) + j) * 8 + 4 * s + g];
 #pragma unroll
-                for (int ob = 0; ob < 2; ++ob)
-                    a1[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wl[SPW_L1 + (ob * 2 + s) * 64 + lane], bx, a1[ob], 0, 0, 0);
+                for (int ob = 0; ob < 2; ++ob) {
+                    const float w = Wl[SPW_L1 + (ob * 2 + s) * 64 + lane];
+                    a1[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, bx, a1[ob], 0, 0, 0);
+                    b1[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, by, b1[ob], 0, 0, 0);
+                }
             }
             sp_ln_relu4<2>(a1, Wl + SPW_B1 + 32, Wl + SPW_B1 + 64, lane, g);
-            sp_mfma_layer<2, 4>(Wl + SPW_L2, Wl + SPW_B2, a1, a2, lane, g);
+            sp_ln_relu4<2>(b1, Wl + SPW_B1 + 32, Wl + SPW_B1 + 64, lane, g);
+            sp_mfma_layer2<2, 4>(Wl + SPW_L2, Wl + SPW_B2, a1, b1, a2, b2, lane, g);
             sp_ln_relu4<4>(a2, Wl + SPW_B2 + 64, Wl + SPW_B2 + 128, lane, g);
-            sp_mfma_layer<4, 2>(Wl + SPW_L3, Wl + SPW_B3, a2, a3, lane, g);
+            sp_ln_relu4<4>(b2, Wl + SPW_B2 + 64, Wl + SPW_B2 + 128, lane, g);
+            sp_mfma_layer2<4, 2>(Wl + SPW_L3, Wl + SPW_B3, a2, b2, a3, b3, lane, g);
             sp_ln_relu4<2>(a3, Wl + SPW_B3 + 32, Wl + SPW_B3 + 64, lane, g);
-            sp_mfma_layer<2, 2>(Wl + SPW_L4, Wl + SPW_B4, a3, a4, lane, g);
+            sp_ln_relu4<2>(b3, Wl + SPW_B3 + 32, Wl + SPW_B3 + 64, lane, g);
+            sp_mfma_layer2<2, 2>(Wl + SPW_L4, Wl + SPW_B4, a3, b3, a4, b4, lane, g);
             sp_ln_relu4<2>(a4, Wl + SPW_B4 + 32, Wl + SPW_B4 + 64, lane, g);
-            sp_mfma_layer<2, 2>(Wl + SPW_L5, Wl + SPW_B5, a4, kr, lane, g);
+            sp_ln_relu4<2>(b4, Wl + SPW_B4 + 32, Wl + SPW_B4 + 64, lane, g);
+            sp_mfma_layer2<2, 2>(Wl + SPW_L5, Wl + SPW_B5, a4, b4, kr, ks, lane, g);
 #pragma unroll
-            for (int ob = 0; ob < 2; ++ob)
+            for (int half = 0; half < 2; ++half) {
+                const int rbh = rb + half;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) kern[j * SP_KSTRIDE + 16 * ob + 4 * g + r] = kr[ob][r];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes, before other lanes read them
-            // einsum("bnkr,bnki->bnri") (models/sprin.py:99): contracted[r*n_in + i] accumulates these 16 neighbours,
-            // sequentially and in neighbour order across the row blocks
-            const int jn = min(16, k - 16 * rb);
-            for (int t = lane; t < SP_RANK * n_in; t += 64) {
-                const int r = t / n_in, i = t - r * n_in;
-                float acc = rb == 0 ? 0.f : contracted[t];
+                for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) kern[j * SP_KSTRIDE + 16 * ob + 4 * g + r] = half ? ks[ob][r] : kr[ob][r];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes, before other lanes read them
+                // einsum("bnkr,bnki->bnri") (models/sprin.py:99): contracted[r*n_in + i] accumulates these 16 neighbours,
+                // sequentially and in neighbour order across the row blocks
+                const int jn = min(16, k - 16 * rbh);
+                for (int t = lane; t < SP_RANK * n_in; t += 64) {
+                    const int r = t / n_in, i = t - r * n_in;
+                    float acc = rbh == 0 ? 0.f : contracted[t];
 #pragma unroll 8
-                for (int jj = 0; jj < jn; ++jj) acc = fmaf(kern[jj * SP_KSTRIDE + r], nf[(16 * rb + jj) * n_in + i], acc);
-                contracted[t] = acc;
+                    for (int jj = 0; jj < jn; ++jj) acc = fmaf(kern[jj * SP_KSTRIDE + r], nf[(16 * rbh + jj) * n_in + i], acc);
+                    contracted[t] = acc;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (kern is rewritten by the other half / the next trip)
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
     const float* p = A.params + SP_NAT_KERNEL;   // outnet parameters follow the kernel-MLP in the natural layout

@@ -43,6 +43,25 @@ __device__ __forceinline__ void sp_mfma_layer(const float* __restrict__ Wl, cons
             y[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wl[(ob * 4 * NIB + s) * 64 + lane], x[s / 4][s % 4], y[ob], 0, 0, 0);
     }
 }
+// the same layer for TWO row blocks at once: every weight element is read from LDS once and feeds both blocks' MFMAs -- two
+// independent accumulator chains per output block (a chain of 4 NIB dependent fp32 MFMAs otherwise waits for itself) and half the
+// LDS reads.  Per block the operations and their order are those of sp_mfma_layer: the same bits.
+template <int NIB, int NOB>
+__device__ __forceinline__ void sp_mfma_layer2(const float* __restrict__ Wl, const float* __restrict__ bias, const f32x4 (&xa)[NIB],
+                                               const f32x4 (&xb)[NIB], f32x4 (&ya)[NOB], f32x4 (&yb)[NOB], int lane, int g)
+{
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) { ya[ob] = *reinterpret_cast<const f32x4*>(bias + 16 * ob + 4 * g); yb[ob] = ya[ob]; }
+#pragma unroll
+    for (int s = 0; s < 4 * NIB; ++s) {
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) {
+            const float w = Wl[(ob * 4 * NIB + s) * 64 + lane];
+            ya[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, xa[s / 4][s % 4], ya[ob], 0, 0, 0);
+            yb[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, xb[s / 4][s % 4], yb[ob], 0, 0, 0);
+        }
+    }
+}
 // LayerNorm (eps 1e-5, affine) + ReLU on a row spread over the 4 lanes g: per-lane partial sums in (ob, r) order,
 // combined as (p0 + p1) + (p2 + p3) through the LDS crossbar (oracle/sprin_oracle.c:layer_norm_ord)
 template <int NOB>
