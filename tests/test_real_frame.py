@@ -282,3 +282,85 @@ def test_pipelined_frames_equal_the_synchronous_ones(dev):
                     for key in ("T", "up", "right", "scale"):
                         assert np.array_equal(g[key], w[key]), (rep, k, key)
     assert pend[0].result() is got[0]           # idempotent
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth_float,label_bytes,idx64", [(False, 4, True), (True, 1, False), (False, 2, False)])
+def test_frame_cloud_batch_equals_the_single_entry_points(dev, depth_float, label_bytes, idx64):
+    """cppf_frame_cloud_dyn_batch (eight launches for all members) against cppf_frame_cloud_dyn_bit + cppf_sample_pairs per member
+    through the C ABI: members of different capacity, resolution and k, u16 and f32 depth, 8 / 16 / 32-bit label images, int32 and
+    int64 pair lists, a member whose mask is empty, one with fewer points than k_min: clouds, normals, neighbour sets, corners,
+    shape records, pairs and uniforms bit for bit"""
+    import ctypes as C
+    import torch
+    from cppf_amd import _lib
+    from cppf_amd._torch_util import stream_ptr
+    from cppf_amd.frames import NOCS_INTRINSICS
+    from cppf_amd.utils.util import read_depth_png
+    L = _lib.lib()
+    depth = read_depth_png(DEPTH)
+    H, W = depth.shape
+    inst = instances(depth)
+    masks = [inst[0][1], inst[5][1], inst[1][1] | inst[2][1], np.zeros_like(inst[0][1]), inst[4][1] & (np.arange(W)[None, :] < 377)]
+    spec = [(4096, 0.004, 30), (65536, 0.01, 60), (8192, 0.003, 16), (4096, 0.004, 30), (4096, 0.004, 60)]      # (capacity, res, k)
+    ldt = {1: np.uint8, 2: np.uint16, 4: np.uint32}[label_bytes]
+    labels = np.zeros((H, W), ldt)
+    for i, m in enumerate(masks):
+        labels |= (m.astype(ldt) << ldt(i))
+    dd = torch.from_numpy(depth.astype(np.float32) if depth_float else depth.view(np.int16)).to(dev)
+    ld = torch.from_numpy(labels.view({1: np.uint8, 2: np.int16, 4: np.int32}[label_bytes])).to(dev)
+    kinv = np.ascontiguousarray(np.linalg.inv(NOCS_INTRINSICS))
+    n_pairs = 5000
+    idt = torch.int64 if idx64 else torch.int32
+
+    def buffers(cap, k):
+        z = lambda *s_, dt=torch.float32: torch.full(s_, -7, dtype=dt, device=dev)
+        return dict(pc=z(cap, 3), nrm=z(cap, 3), corner=z(3), shape=z(4, dt=torch.int32), nbrs=z(cap, k, dt=torch.int32),
+                    idx=z(n_pairs, 2, dt=idt), u_tr=z(n_pairs, 2), u_rot=z(n_pairs, 2),
+                    ws=torch.zeros(int(L.cppf_frame_cloud_workspace_bytes(H, W, cap, k)), dtype=torch.uint8, device=dev),
+                    slot=torch.zeros(2, dtype=torch.int64, device=dev))
+
+    one, many = [buffers(c, k) for c, _, k in spec], [buffers(c, k) for c, _, k in spec]
+    for i, b in enumerate(one + many):
+        j = i % len(spec)
+        b["slot"].copy_(torch.tensor([j, 1000003 * 7 + j], dtype=torch.int64))
+    with torch.cuda.device(dev):
+        for b, (cap, res, k) in zip(one, spec):
+            _lib.check(L.cppf_frame_cloud_dyn_bit(dd.data_ptr(), 0 if depth_float else 1, ld.data_ptr(), label_bytes, b["slot"].data_ptr(), H, W,
+                                                  kinv.ctypes.data, 1000.0, res, k, k + 1, cap, b["pc"].data_ptr(), b["nrm"].data_ptr(),
+                                                  b["corner"].data_ptr(), b["shape"].data_ptr(), b["nbrs"].data_ptr(), b["ws"].data_ptr(),
+                                                  b["ws"].numel(), stream_ptr(dev)), "cppf_frame_cloud_dyn_bit")
+            if idx64:
+                _lib.check(L.cppf_sample_pairs(b["idx"].data_ptr(), b["u_tr"].data_ptr(), b["u_rot"].data_ptr(), n_pairs, 1,
+                                               b["shape"].data_ptr(), 0, b["slot"].data_ptr() + 8, stream_ptr(dev)), "cppf_sample_pairs")
+        arr = (_lib.FrameCloudItem * len(spec))()
+        for a, b, (cap, res, k) in zip(arr, many, spec):
+            a.label_bit_dev, a.seed_dev = b["slot"].data_ptr(), b["slot"].data_ptr() + 8
+            a.pc_out, a.nrm_out, a.corner_out, a.shape_out, a.nbrs_out = (b[n].data_ptr() for n in ("pc", "nrm", "corner", "shape", "nbrs"))
+            a.idx, a.u_tr, a.u_rot, a.workspace, a.workspace_bytes = b["idx"].data_ptr(), b["u_tr"].data_ptr(), b["u_rot"].data_ptr(), b["ws"].data_ptr(), b["ws"].numel()
+            a.res, a.n_pairs, a.knn_k, a.k_min, a.n_cap, a.idx_is_i64 = res, n_pairs, k, k + 1, cap, 1 if idx64 else 0
+        _lib.check(L.cppf_frame_cloud_dyn_batch(len(spec), C.cast(arr, C.c_void_p), dd.data_ptr(), 0 if depth_float else 1, ld.data_ptr(),
+                                                label_bytes, H, W, kinv.ctypes.data, 1000.0, stream_ptr(dev)), "cppf_frame_cloud_dyn_batch")
+    torch.cuda.synchronize()
+    counts = []
+    for j, (a, b) in enumerate(zip(one, many)):
+        n = int(a["shape"][0])
+        counts.append(n)
+        assert torch.equal(a["shape"], b["shape"]) and torch.equal(a["corner"], b["corner"]), j
+        # (whole buffers, pre-filled alike: what either form leaves untouched beyond the cloud is part of the comparison)
+        assert torch.equal(a["pc"], b["pc"]) and torch.equal(a["nrm"], b["nrm"]) and torch.equal(a["nbrs"], b["nbrs"]), j
+        assert torch.all(b["nrm"][n:] == -7) and torch.all(b["nbrs"][n:] == -7)
+        if idx64:
+            assert torch.equal(a["idx"], b["idx"]) and torch.equal(a["u_tr"], b["u_tr"]) and torch.equal(a["u_rot"], b["u_rot"]), j
+        else:        # the single sampler draws int64 lists: the same numbers, from the Philox twin on the host
+            import cppf_amd.synthetic as syn
+            idx_w, utr_w, urot_w = syn.philox_pairs(1000003 * 7 + j, n_pairs, n)
+            assert np.array_equal(b["idx"].cpu().numpy(), idx_w.astype(np.int32)), j
+            assert np.array_equal(b["u_tr"].cpu().numpy(), utr_w) and np.array_equal(b["u_rot"].cpu().numpy(), urot_w), j
+    assert counts[3] == 0 and counts[4] == 0 and counts[1] > 2000 and counts[0] > 100, counts      # (member 4: fewer points than k_min)
+    # argument checks
+    assert L.cppf_frame_cloud_dyn_batch(0, C.cast(arr, C.c_void_p), dd.data_ptr(), 1, ld.data_ptr(), 4, H, W, kinv.ctypes.data, 1000.0, None) == -1
+    assert L.cppf_frame_cloud_dyn_batch(9, C.cast(arr, C.c_void_p), dd.data_ptr(), 1, ld.data_ptr(), 4, H, W, kinv.ctypes.data, 1000.0, None) == -1
+    assert L.cppf_frame_cloud_dyn_batch(1, C.cast(arr, C.c_void_p), dd.data_ptr(), 1, ld.data_ptr(), 3, H, W, kinv.ctypes.data, 1000.0, None) == -1
+    arr[0].workspace_bytes = 16
+    assert L.cppf_frame_cloud_dyn_batch(1, C.cast(arr, C.c_void_p), dd.data_ptr(), 1, ld.data_ptr(), 4, H, W, kinv.ctypes.data, 1000.0, None) == -2
