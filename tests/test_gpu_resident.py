@@ -199,3 +199,28 @@ def test_overlapping_batches_return_each_batch_its_own_records(dev):
     for b, objs in enumerate(batches):
         want = fresh.run(fresh.put(objs), seed=b).cpu().numpy()
         np.testing.assert_array_equal(outs[b], want, err_msg=f"batch {b}")
+
+
+def test_gather_words_rows_from_separate_buffers(dev):
+    """cppf_gather_words: the 8-byte words of up to 32 separately allocated buffers into the rows of one array with one launch
+    (FrameRunner's records and shape words); the Python helper cuts longer lists into launches of 32"""
+    import ctypes as C
+    from cppf_amd import _lib
+    from cppf_amd._torch_util import gather_words
+    rng = np.random.default_rng(0)
+    for n_rows, words in ((1, 21), (8, 21), (32, 2), (45, 5)):
+        srcs = [torch.from_numpy(rng.standard_normal(words + 3)).to(dev) for _ in range(n_rows)]       # (longer than a row: only `words` are taken)
+        dst = torch.full((n_rows, words), -1.0, dtype=torch.float64, device=dev)
+        gather_words(dst, srcs, dev)
+        torch.cuda.synchronize()
+        assert torch.equal(dst, torch.stack([s_[:words] for s_ in srcs]))
+    shapes = [torch.tensor([5 + i, 7, 8, 9], dtype=torch.int32, device=dev) for i in range(6)]        # i32[4] = two words
+    out = torch.zeros((6, 4), dtype=torch.int32, device=dev)
+    gather_words(out, shapes, dev)
+    assert out.cpu().tolist() == [[5 + i, 7, 8, 9] for i in range(6)]
+    L = _lib.lib()
+    ptrs = (C.c_void_p * 1)(srcs[0].data_ptr())
+    assert L.cppf_gather_words(33, ptrs, 4, dst.data_ptr(), None) == -1
+    assert L.cppf_gather_words(1, ptrs, 4, dst.data_ptr() + 4, None) == -1            # (destination not 8-byte aligned)
+    assert L.cppf_gather_words(1, None, 4, dst.data_ptr(), None) == -1
+    assert L.cppf_gather_words(0, None, 4, None, None) == 0
