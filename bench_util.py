@@ -154,20 +154,23 @@ def make_stepper(dev, pipes, streams, res_buf, steps, B, vote_batch=True, vote_b
         """-> {width: ms per step}; leaves the fastest width set (no-op unless vote_batch_wgs == -1 and the votes are batched)"""
         if not (batches and vote_batch and vote_batch_wgs < 0):
             return None
-        n_steps = n_steps or max(2 * len(batches) * B, 24)
+        # Timings long enough to tell 2 % apart (64 against 96 at C2: 0.0877 against 0.0894 ms per step): 7 x 72 steps (~6 ms each) per
+        # width.  Round 6 found the 5 x 24 steps of before mis-measuring the FIRST width by 2-3 % in one process of five on some boxes
+        # (a 2 ms timing right behind the captures); the run then kept 96 workgroups and the headline read 5.8 instead of 6.0 G pairs/s.
+        n_steps = n_steps or max(6 * len(batches) * B, 72)
         seen = {}
         for w in VOTE_BATCH_WIDTHS:
             for bp in batches:
                 bp.vote_workgroups = w
-            run(2 * len(batches) * B)                # capture + the slow first replays
+            run(4 * len(batches) * B)                # capture + the slow first replays
             ts = []
-            for _ in range(5):
+            for _ in range(7):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 run(n_steps)
                 torch.cuda.synchronize()
                 ts.append((time.perf_counter() - t0) / n_steps * 1e3)
-            seen[w] = sorted(ts)[2]
+            seen[w] = sorted(ts)[3]
         best = min(seen, key=seen.get)
         for bp in batches:
             bp.vote_workgroups = best
